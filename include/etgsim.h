@@ -1,0 +1,178 @@
+/*
+ * etgsim.h -- C-ABI of the MI355X-native batched A1 quadruped simulator.
+ *
+ * This is the drop-in boundary of the hot path: the Gym surface
+ *     env.reset(ETG_w=, ETG_b=, ...) -> (obs, info)
+ *     env.step(action, donef=)       -> (obs, reward, done, info)
+ * that PaddleRobotics' QuadrupedalRobots/ETGRL drives
+ * (reference: ETGRL/train.py:131,147,186,195,215,228; pretrain.py:131,138;
+ *  model/Dynamic_parallel_model.py:55,61; env_test.py:47,53).
+ * In the reference that surface is served by `rlschool.make_env('Quadrupedal')`
+ * (train.py:305-309) on top of one pybullet client per robot; here it is served
+ * by hand-written gfx950 kernels for N robots at once.  The Python host
+ * (paddlerobotics_amd/env.py) binds these entry points with ctypes and passes
+ * raw device pointers (torch tensor .data_ptr()).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative ETG_ERR_* code otherwise,
+ *     and never throws across the ABI; etg_last_error() returns a message.
+ *   - the caller owns obs/action/reward/done/info device buffers; the library
+ *     owns its internal SoA state.  All work is enqueued on the passed HIP
+ *     stream (a hipStream_t passed as void*); no hidden synchronisation.
+ *   - a handle is bound to one device; calls on one handle are serialised by
+ *     the caller.
+ *   - there is NO CPU fallback in this library: with no HIP device every entry
+ *     point that would launch work fails with ETG_ERR_NO_DEVICE.
+ */
+#ifndef ETGSIM_H_
+#define ETGSIM_H_
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ETG_NUM_LEGS 4
+#define ETG_NUM_MOTORS 12
+#define ETG_ACT_DIM 12
+#define ETG_OBS_DIM 49   /* train.py:311 with the default sensor set */
+#define ETG_STATE_DIM 37 /* pos3 quat4(xyzw) linvel3 angvel3 (world) q12 qd12      */
+#define ETG_DYN_DIM 48   /* flattened dynamic_param dict, train.py:112-126          */
+#define ETG_RBF_H 20     /* ETG_H, train.py:479                                     */
+#define ETG_INFO_DIM 64  /* per-env info row, layout below                          */
+
+/* info row layout (floats) -- the keys callers read */
+#define ETG_INFO_TORSO 0
+#define ETG_INFO_FEET 1
+#define ETG_INFO_UP 2
+#define ETG_INFO_TAU 3
+#define ETG_INFO_STAND 4
+#define ETG_INFO_BADFOOT 5
+#define ETG_INFO_FOOTCONTACT 6
+#define ETG_INFO_DONE 7
+#define ETG_INFO_VELX 8
+#define ETG_INFO_ETG_ACT 9       /* 12: info["ETG_act"], env_test.py:54          */
+#define ETG_INFO_JOINT_ANGLE 21  /* 12: info["joint_angle"], Dynamic_parallel_model.py:63 */
+#define ETG_INFO_OBS_IMU 33      /* 6 : info["obs-IMU"] = rpy,drpy (un-normalised) */
+#define ETG_INFO_FOOT_CONTACT 39 /* 4 : info["FootContactSensor"], EnvWrapper.py:108 */
+#define ETG_INFO_REAL_ACTION 43  /* 12: info["real_action"] = q_des, EnvWrapper.py:108 */
+#define ETG_INFO_BASE 55         /* 3 : base position (world)                      */
+#define ETG_INFO_RPY 58          /* 3 : true roll pitch yaw                        */
+#define ETG_INFO_ENERGY 61       /* 1 : sum_ticks sum_j |tau_j qd_j| dt            */
+#define ETG_INFO_STEPS 62        /* 1 : control steps since reset                  */
+
+enum {
+  ETG_OK = 0,
+  ETG_ERR_BAD_ARG = -1,
+  ETG_ERR_NO_DEVICE = -2,
+  ETG_ERR_HIP = -3,
+  ETG_ERR_ALLOC = -4,
+  ETG_ERR_STATE = -5
+};
+
+/* Rigid-body inertial parameters of one link, in the link frame. */
+typedef struct EtgLink {
+  double mass;
+  double com[3];
+  double inertia[6]; /* about the COM: xx yy zz xy xz yz */
+} EtgLink;
+
+/* The A1 model.  Values come from paddlerobotics_amd/a1_model.py; the kinematic
+ * ones are the reference's (deployment/robots/a1.py:52,70-73,83,98-100), the
+ * inertial ones are recalled from pybullet_data/a1/a1.urdf (absent from the
+ * reference tree -- SURVEY App. B). Base frame = trunk COM frame.            */
+typedef struct EtgRobotModel {
+  EtgLink trunk;             /* com must be 0 (base frame is the trunk COM frame) */
+  EtgLink hip[4], thigh[4], calf[4], foot[4]; /* per leg FR,FL,RR,RL (already mirrored) */
+  double hip_origin[4][3];   /* hip joint origin in the base frame = a1.py HIP_OFFSETS */
+  double thigh_y[4];         /* +-0.08505, sign (-1)^(leg+1), a1.py:100          */
+  double upper_len;          /* 0.2, a1.py:98 */
+  double lower_len;          /* 0.2, a1.py:99 */
+  double foot_radius;        /* 0.02 collision sphere                           */
+  double init_pos[3];        /* 0,0,0.32  a1.py:52 */
+  double pose_ori[12];       /* [0,.9,-1.8]*4  a1.py:83 */
+  double base_foot[12];      /* ETG nominal foot positions in the base frame    */
+  double etg_mean[12];       /* EnvWrapper.py:50-53 */
+  double etg_std[12];        /* EnvWrapper.py:54-55 */
+} EtgRobotModel;
+
+typedef struct EtgConfig {
+  int32_t num_envs;
+  int32_t action_repeat;   /* physics ticks per control step (13)              */
+  int32_t settle_ticks;    /* ticks holding pose_ori on reset (500, a1.py:294) */
+  int32_t solver_iters;    /* PGS sweeps per tick                              */
+  int32_t enable_action_interp; /* minitaur.py:1384-1401                        */
+  int32_t enable_action_filter; /* action_filter.py (Butterworth), default off */
+  int32_t obs_normal;      /* `normal` kwarg, EnvWrapper.py:66-87              */
+  int32_t terrain;         /* 0 = flat plane z=0, 1 = heightfield              */
+  double sim_dt;           /* 0.002                                            */
+  double erp;              /* Baumgarte factor for penetrating contacts (0.2)  */
+  double contact_margin;   /* speculative contact distance (0.02)             */
+  double warmstart;        /* impulse warm-start factor (0.85)                */
+  double torque_limit;     /* <=0: none (A1 passes none, a1.py:256-274)        */
+  double etg_T, etg_T2, etg_amp, etg_sigma_sq, etg_phase[2]; /* train.py:296-297 */
+  double etg_dt;           /* control period 0.026                             */
+  double reward_w[8];      /* torso feet up tau stand badfoot footcontact done */
+  double reward_p;         /* train.py:472 */
+  double vel_d;            /* train.py:470 */
+  double filter_b[3], filter_a[3]; /* Butterworth coefficients (host computes) */
+  /* heightfield (terrain==1): row-major [hf_ny][hf_nx] heights, cell size, origin */
+  int32_t hf_nx, hf_ny;
+  double hf_cell, hf_x0, hf_y0;
+} EtgConfig;
+
+typedef struct EtgHandle EtgHandle;
+
+/* ---- lifecycle ---------------------------------------------------------- */
+int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int device, EtgHandle** out);
+void etg_destroy(EtgHandle* h);
+const char* etg_last_error(void);
+int etg_version(void);
+
+/* ---- parameters (device pointers, float32) ------------------------------
+ * dyn   : [N,48] physical-unit dynamic_param rows (layout of train.py:112-126:
+ *         latency_ms, footfriction, basemass, baseinertia3, legmass3,
+ *         leginertia12, kp12, kd12, gravity3) or NULL to keep.
+ * etg_w : [N,3,20] if per_env else [3,20]; etg_b : [N,3] / [3]; NULL keeps.
+ * mask  : [N] uint8 or NULL (= all): only masked envs are updated.           */
+int etg_set_params(EtgHandle* h, const float* dyn, const float* etg_w, const float* etg_b,
+                   int per_env, const uint8_t* mask, void* stream);
+/* heightfield heights [hf_ny*hf_nx] float32 device pointer (terrain==1)      */
+int etg_set_heightfield(EtgHandle* h, const float* heights, void* stream);
+
+/* ---- the hot path ------------------------------------------------------- */
+/* reset masked envs (NULL = all): place at init pose, settle, write obs[N,49]
+ * rows of the reset envs (other rows untouched).                             */
+int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* stream);
+/* one control step for all envs. action [N,12] (already scaled by act_bound,
+ * train.py:147); donef [N] uint8 or NULL; outputs obs [N,49], reward [N],
+ * done [N] uint8, info [N,64] or NULL.                                       */
+int etg_step(EtgHandle* h, const float* action, const uint8_t* donef, float* obs,
+             float* reward, uint8_t* done, float* info, void* stream);
+/* fused open-loop rollout: n_steps control steps with action == 0
+ * (pretrain.py:129-154), accumulating per-env return/length with alive
+ * masking; ret [N] f32, len [N] i32. obs [N,49] receives the final obs.      */
+int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float* ret, int32_t* len,
+                         void* stream);
+
+/* ---- state access for parity tests (device pointers, [N,37] f32) --------- */
+int etg_get_state(EtgHandle* h, float* state, void* stream);
+int etg_set_state(EtgHandle* h, const float* state, void* stream);
+
+/* ---- policy (the one dense contraction, model/mujoco_model.py:44-60) -----
+ * act = tanh(W3 relu(W2 relu(W1 obs + b1) + b2) + b3) * act_scale
+ * weights are torch [out,in] row-major fp32 device pointers; obs [N,in_dim],
+ * act [N,12].  precision: 0 = fp32 MFMA (exact f32), 1 = bf16 MFMA.           */
+typedef struct EtgPolicy EtgPolicy;
+int etg_policy_create(int in_dim, int hidden, int out_dim, int device, EtgPolicy** out);
+int etg_policy_load(EtgPolicy* p, const float* w1, const float* b1, const float* w2,
+                    const float* b2, const float* w3, const float* b3, void* stream);
+int etg_policy_forward(EtgPolicy* p, const float* obs, int n, float act_scale, int precision,
+                       float* act, void* stream);
+void etg_policy_destroy(EtgPolicy* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ETGSIM_H_ */

@@ -1,0 +1,1095 @@
+/*
+ * etgsim_oracle.cpp -- CPU restatement of the ETGRL env.step()/reset() hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This file is the parity oracle (and the timed
+ * "port" CPU baseline of bench.py).  Nothing under paddlerobotics_amd/ may
+ * import, link or call it; only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg do.
+ *
+ * What it restates, and from where (paths relative to
+ * /root/reference/QuadrupedalRobots/ETGRL):
+ *   - ETG RBF basis / trot fan-out        rlschool ETG_layer (ABSENT from the tree);
+ *                                         form pinned by gait_action_list_ETG_exp.npy
+ *                                         and train.py:81-110,296-297 (SURVEY 8a a1,a2)
+ *   - leg IK / FK / Jacobian              deployment/robots/a1.py:97-173,464-497
+ *   - PD motor model                      deployment/robots/laikago_motor.py:103-175
+ *   - sub-step loop, action interpolation deployment/robots/minitaur.py:242-260,1384-1401
+ *   - latency-delayed observation         deployment/robots/minitaur.py:1142-1204
+ *   - reset / settle                      deployment/robots/minitaur.py:403-445, a1.py:289-349
+ *   - observation layout                  deployment/envs/EnvWrapper.py:28-121
+ *   - Butterworth action filter           deployment/robots/action_filter.py:46-216
+ *   - policy forward                      model/mujoco_model.py:44-60, alg/sac.py:60-63
+ *   - stepSimulation()                    Bullet (pybullet), ABSENT and unpinned: this
+ *                                         file DEFINES the rigid-body model (floating-base
+ *                                         articulated dynamics by CRBA + RNEA + dense
+ *                                         Cholesky, foot-sphere/ground contact with
+ *                                         Coulomb friction by projected Gauss-Seidel,
+ *                                         semi-implicit Euler).  PARITY UNPINNED for
+ *                                         dynamics/contact/reward/termination: neither
+ *                                         pybullet nor rlschool exists in the reference
+ *                                         tree or in this image.
+ *
+ * The implementation is deliberately GENERIC (13-body kinematic tree, 6x6
+ * spatial algebra, dense 18x18 factorisation) so that it is an independent
+ * check of the hand-specialised 4-lanes-per-robot HIP kernels.
+ *
+ * Build: see oracle/Makefile (g++ -O2 -shared).  Exports a C ABI (etgo_*),
+ * each entry point in a double ("64") and a float ("32") instantiation.
+ */
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <thread>
+#include <vector>
+
+#include "../include/etgsim.h"
+
+namespace {
+
+constexpr int NB = 13;       // trunk + 4 x (hip, thigh, calf[+foot])
+constexpr int NV = 18;       // 6 base + 12 joints
+constexpr int RING = 64;     // latency ring depth (ticks)
+constexpr int HIST = 31;     // q12 qd12 quat4 wlocal3  (minitaur.py:1142-1149 minus torques)
+
+// ---------------------------------------------------------------- small math
+template <class T> inline void cross(const T* a, const T* b, T* c) {
+  T x = a[1] * b[2] - a[2] * b[1], y = a[2] * b[0] - a[0] * b[2], z = a[0] * b[1] - a[1] * b[0];
+  c[0] = x; c[1] = y; c[2] = z;
+}
+template <class T> inline T dot3(const T* a, const T* b) { return a[0] * b[0] + a[1] * b[1] + a[2] * b[2]; }
+template <class T> inline void mat3_mul_vec(const T R[3][3], const T* v, T* o) {
+  T x = R[0][0] * v[0] + R[0][1] * v[1] + R[0][2] * v[2];
+  T y = R[1][0] * v[0] + R[1][1] * v[1] + R[1][2] * v[2];
+  T z = R[2][0] * v[0] + R[2][1] * v[1] + R[2][2] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+template <class T> inline void mat3T_mul_vec(const T R[3][3], const T* v, T* o) {
+  T x = R[0][0] * v[0] + R[1][0] * v[1] + R[2][0] * v[2];
+  T y = R[0][1] * v[0] + R[1][1] * v[1] + R[2][1] * v[2];
+  T z = R[0][2] * v[0] + R[1][2] * v[1] + R[2][2] * v[2];
+  o[0] = x; o[1] = y; o[2] = z;
+}
+template <class T> inline void mat3_mul(const T A[3][3], const T B[3][3], T C[3][3]) {
+  T t[3][3];
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) t[i][j] = A[i][0] * B[0][j] + A[i][1] * B[1][j] + A[i][2] * B[2][j];
+  std::memcpy(C, t, sizeof(t));
+}
+// quaternion xyzw (pybullet order) -> rotation matrix (body -> world)
+template <class T> inline void quat_to_mat(const T* q, T R[3][3]) {
+  T n = q[0] * q[0] + q[1] * q[1] + q[2] * q[2] + q[3] * q[3];
+  T s = T(2) / n;
+  T x = q[0], y = q[1], z = q[2], w = q[3];
+  R[0][0] = 1 - s * (y * y + z * z); R[0][1] = s * (x * y - z * w); R[0][2] = s * (x * z + y * w);
+  R[1][0] = s * (x * y + z * w); R[1][1] = 1 - s * (x * x + z * z); R[1][2] = s * (y * z - x * w);
+  R[2][0] = s * (x * z - y * w); R[2][1] = s * (y * z + x * w); R[2][2] = 1 - s * (x * x + y * y);
+}
+template <class T> inline void quat_mul(const T* a, const T* b, T* o) {  // xyzw
+  T x = a[3] * b[0] + a[0] * b[3] + a[1] * b[2] - a[2] * b[1];
+  T y = a[3] * b[1] - a[0] * b[2] + a[1] * b[3] + a[2] * b[0];
+  T z = a[3] * b[2] + a[0] * b[1] - a[1] * b[0] + a[2] * b[3];
+  T w = a[3] * b[3] - a[0] * b[0] - a[1] * b[1] - a[2] * b[2];
+  o[0] = x; o[1] = y; o[2] = z; o[3] = w;
+}
+// roll-pitch-yaw (ZYX) of a quaternion, the getEulerFromQuaternion convention
+// (minitaur.py:620,633)
+template <class T> inline void quat_to_rpy(const T* q, T* rpy) {
+  T R[3][3];
+  quat_to_mat(q, R);
+  T sp = -R[2][0];
+  if (sp > T(1)) sp = T(1);
+  if (sp < T(-1)) sp = T(-1);
+  rpy[0] = std::atan2(R[2][1], R[2][2]);
+  rpy[1] = std::asin(sp);
+  rpy[2] = std::atan2(R[1][0], R[0][0]);
+}
+
+// ---------------------------------------------------------------- spatial algebra
+// motion vector [w; v], force vector [n; f]; 6x6 inertia as dense matrix.
+template <class T> struct Xform {  // Plucker transform parent(A) -> child(B): E = rot A->B coords, r = B origin in A coords
+  T E[3][3];
+  T r[3];
+};
+template <class T> inline void x_apply_motion(const Xform<T>& X, const T* v, T* o) {
+  T t[3], rw[3];
+  cross(X.r, v, rw);  // r x w
+  for (int i = 0; i < 3; i++) t[i] = v[3 + i] - rw[i];
+  T a[3], b[3];
+  mat3_mul_vec(X.E, v, a);
+  mat3_mul_vec(X.E, t, b);
+  for (int i = 0; i < 3; i++) { o[i] = a[i]; o[3 + i] = b[i]; }
+}
+// X^T f : child coords force -> parent coords
+template <class T> inline void x_applyT_force(const Xform<T>& X, const T* f, T* o) {
+  T n[3], l[3], rl[3];
+  mat3T_mul_vec(X.E, f, n);
+  mat3T_mul_vec(X.E, f + 3, l);
+  cross(X.r, l, rl);
+  for (int i = 0; i < 3; i++) { o[i] = n[i] + rl[i]; o[3 + i] = l[i]; }
+}
+template <class T> inline void x_to_mat(const Xform<T>& X, T M[6][6]) {
+  T rx[3][3] = {{0, -X.r[2], X.r[1]}, {X.r[2], 0, -X.r[0]}, {-X.r[1], X.r[0], 0}};
+  T Erx[3][3];
+  mat3_mul(X.E, rx, Erx);
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      M[i][j] = X.E[i][j]; M[i][3 + j] = 0;
+      M[3 + i][j] = -Erx[i][j]; M[3 + i][3 + j] = X.E[i][j];
+    }
+}
+// I_parent += X^T I_child X
+template <class T> inline void inertia_accumulate(const Xform<T>& X, const T Ic[6][6], T Ip[6][6]) {
+  T M[6][6], t[6][6];
+  x_to_mat(X, M);
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      T s = 0;
+      for (int k = 0; k < 6; k++) s += Ic[i][k] * M[k][j];
+      t[i][j] = s;
+    }
+  for (int i = 0; i < 6; i++)
+    for (int j = 0; j < 6; j++) {
+      T s = 0;
+      for (int k = 0; k < 6; k++) s += M[k][i] * t[k][j];
+      Ip[i][j] += s;
+    }
+}
+template <class T> inline void mat6_mul_vec(const T M[6][6], const T* v, T* o) {
+  T t[6];
+  for (int i = 0; i < 6; i++) {
+    T s = 0;
+    for (int k = 0; k < 6; k++) s += M[i][k] * v[k];
+    t[i] = s;
+  }
+  std::memcpy(o, t, sizeof(t));
+}
+// spatial cross products
+template <class T> inline void crm(const T* v, const T* m, T* o) {  // v x m (motion)
+  T a[3], b[3], c[3];
+  cross(v, m, a);
+  cross(v, m + 3, b);
+  cross(v + 3, m, c);
+  for (int i = 0; i < 3; i++) { o[i] = a[i]; o[3 + i] = b[i] + c[i]; }
+}
+template <class T> inline void crf(const T* v, const T* f, T* o) {  // v x* f (force)
+  T a[3], b[3], c[3];
+  cross(v, f, a);
+  cross(v + 3, f + 3, b);
+  cross(v, f + 3, c);
+  for (int i = 0; i < 3; i++) { o[i] = a[i] + b[i]; o[3 + i] = c[i]; }
+}
+// spatial inertia (about the link-frame origin) from mass, com, inertia about com
+template <class T> inline void make_spatial_inertia(T m, const T* c, const T Ic[3][3], T I[6][6]) {
+  T cx[3][3] = {{0, -c[2], c[1]}, {c[2], 0, -c[0]}, {-c[1], c[0], 0}};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) {
+      T cc = 0;
+      for (int k = 0; k < 3; k++) cc += cx[i][k] * cx[j][k];  // cx cx^T
+      I[i][j] = Ic[i][j] + m * cc;
+      I[i][3 + j] = m * cx[i][j];
+      I[3 + i][j] = -m * cx[i][j];  // m cx^T
+      I[3 + i][3 + j] = (i == j) ? m : T(0);
+    }
+}
+
+// ---------------------------------------------------------------- kinematics from the reference
+// a1.py:97-110
+template <class T> inline void leg_ik(const T* foot, T l_hip_sign, T* ang) {
+  const T l_up = T(0.2), l_low = T(0.2);
+  T l_hip = T(0.08505) * l_hip_sign;
+  T x = foot[0], y = foot[1], z = foot[2];
+  T theta_knee = -std::acos((x * x + y * y + z * z - l_hip * l_hip - l_low * l_low - l_up * l_up) /
+                            (2 * l_low * l_up));
+  T l = std::sqrt(l_up * l_up + l_low * l_low + 2 * l_up * l_low * std::cos(theta_knee));
+  T theta_hip = std::asin(-x / l) - theta_knee / 2;
+  T c1 = l_hip * y - l * std::cos(theta_hip + theta_knee / 2) * z;
+  T s1 = l * std::cos(theta_hip + theta_knee / 2) * y + l_hip * z;
+  ang[0] = std::atan2(s1, c1);
+  ang[1] = theta_hip;
+  ang[2] = theta_knee;
+}
+// a1.py:113-129
+template <class T> inline void leg_fk(const T* ang, T l_hip_sign, T* p) {
+  const T l_up = T(0.2), l_low = T(0.2);
+  T l_hip = T(0.08505) * l_hip_sign;
+  T leg_distance = std::sqrt(l_up * l_up + l_low * l_low + 2 * l_up * l_low * std::cos(ang[2]));
+  T eff_swing = ang[1] + ang[2] / 2;
+  T off_x_hip = -leg_distance * std::sin(eff_swing);
+  T off_z_hip = -leg_distance * std::cos(eff_swing);
+  T off_y_hip = l_hip;
+  p[0] = off_x_hip;
+  p[1] = std::cos(ang[0]) * off_y_hip - std::sin(ang[0]) * off_z_hip;
+  p[2] = std::sin(ang[0]) * off_y_hip + std::cos(ang[0]) * off_z_hip;
+}
+// a1.py:132-160
+template <class T> inline void leg_jacobian(const T* a, int leg_id, T J[3][3]) {
+  const T l_up = T(0.2), l_low = T(0.2);
+  T l_hip = T(0.08505) * ((leg_id + 1) % 2 == 0 ? T(1) : T(-1));
+  T t1 = a[0], t2 = a[1], t3 = a[2];
+  T l_eff = std::sqrt(l_up * l_up + l_low * l_low + 2 * l_up * l_low * std::cos(t3));
+  T t_eff = t2 + t3 / 2;
+  J[0][0] = 0;
+  J[0][1] = -l_eff * std::cos(t_eff);
+  J[0][2] = l_low * l_up * std::sin(t3) * std::sin(t_eff) / l_eff - l_eff * std::cos(t_eff) / 2;
+  J[1][0] = -l_hip * std::sin(t1) + l_eff * std::cos(t1) * std::cos(t_eff);
+  J[1][1] = -l_eff * std::sin(t1) * std::sin(t_eff);
+  J[1][2] = -l_low * l_up * std::sin(t1) * std::sin(t3) * std::cos(t_eff) / l_eff -
+            l_eff * std::sin(t1) * std::sin(t_eff) / 2;
+  J[2][0] = l_hip * std::cos(t1) + l_eff * std::sin(t1) * std::cos(t_eff);
+  J[2][1] = l_eff * std::sin(t_eff) * std::cos(t1);
+  J[2][2] = l_low * l_up * std::sin(t3) * std::cos(t1) * std::cos(t_eff) / l_eff +
+            l_eff * std::sin(t_eff) * std::cos(t1) / 2;
+}
+inline double hip_sign(int leg) { return ((leg + 1) % 2 == 0) ? 1.0 : -1.0; }  // (-1)**(leg+1), a1.py:485
+
+// ---------------------------------------------------------------- ETG
+// RBF basis of the (absent) rlschool ETG_layer; validated against the two
+// gait_action_list_*.npy fixtures to 4e-15 (tests/test_golden_etg.py).
+template <class T> struct EtgBasis {
+  T u[ETG_RBF_H][2];
+  T omega, amp, sigma_sq, phase[2], Tperiod, T2;
+  void init(const EtgConfig& c) {
+    Tperiod = T(c.etg_T); T2 = T(c.etg_T2); amp = T(c.etg_amp); sigma_sq = T(c.etg_sigma_sq);
+    phase[0] = T(c.etg_phase[0]); phase[1] = T(c.etg_phase[1]);
+    omega = T(2.0 * M_PI / c.etg_T);
+    for (int h = 0; h < ETG_RBF_H; h++) {
+      T t = T(h) * Tperiod / T(ETG_RBF_H - 0.9);
+      u[h][0] = amp * std::sin(phase[0] + t * omega);
+      u[h][1] = amp * std::sin(phase[1] + t * omega);
+    }
+  }
+  void rbf(T t, T* r) const {
+    T x0 = amp * std::sin(phase[0] + t * omega), x1 = amp * std::sin(phase[1] + t * omega);
+    for (int h = 0; h < ETG_RBF_H; h++) {
+      T d0 = x0 - u[h][0], d1 = x1 - u[h][1];
+      r[h] = std::exp(-(d0 * d0 + d1 * d1) / sigma_sq);
+    }
+  }
+};
+
+// ---------------------------------------------------------------- per-env data
+template <class T> struct Env {
+  // rigid-body state
+  T pos[3], quat[4], wb[3], vb[3];  // base twist in base coordinates
+  T q[12], qd[12];
+  T lam[12];  // warm-start impulses, per foot (n, t1, t2)
+  // latency ring
+  T hist[RING][HIST];
+  int64_t tick;  // ticks since reset (hist[(tick) % RING] is the newest)
+  // control
+  int step_count;
+  T last_qdes[12];
+  int has_last;
+  T first_rpy[3];
+  int first_rpy_set;
+  T last_base[3];
+  T last_foot_w[12];
+  T fx[2][12], fy[2][12];  // action filter history
+  // parameters
+  T etg_w[3][ETG_RBF_H], etg_b[3];
+  T dyn[ETG_DYN_DIM];
+  // derived model
+  T I[NB][6][6];  // link spatial inertias (link frame)
+  T kp[12], kd[12], mu, latency, grav[3];
+  // outputs of the last tick
+  T tau[12];
+  int contact[4];
+  T energy;
+};
+
+template <class T> struct Sim {
+  EtgConfig cfg;
+  EtgRobotModel model;
+  EtgBasis<T> basis;
+  int N;
+  std::vector<Env<T>> env;
+  std::vector<float> heights;
+  mutable T* dbgM = nullptr;  // optional taps (tests): 18x18 mass matrix, 18 bias
+  mutable T* dbgC = nullptr;
+  // tree description
+  int parent[NB];
+  int axis[NB];     // 0 = x, 1 = y
+  T jorigin[NB][3]; // joint origin in the parent frame
+};
+
+template <class T> void build_tree(Sim<T>& s) {
+  const EtgRobotModel& m = s.model;
+  s.parent[0] = -1; s.axis[0] = -1;
+  for (int l = 0; l < 4; l++) {
+    int h = 1 + 3 * l, t = h + 1, c = h + 2;
+    s.parent[h] = 0; s.axis[h] = 0;
+    for (int k = 0; k < 3; k++) s.jorigin[h][k] = T(m.hip_origin[l][k]);
+    s.parent[t] = h; s.axis[t] = 1;
+    s.jorigin[t][0] = 0; s.jorigin[t][1] = T(m.thigh_y[l]); s.jorigin[t][2] = 0;
+    s.parent[c] = t; s.axis[c] = 1;
+    s.jorigin[c][0] = 0; s.jorigin[c][1] = 0; s.jorigin[c][2] = T(-m.upper_len);
+  }
+}
+
+// scaled link inertia: mass ratio rm, per-axis inertia ratios ri: I' = S I S, S = diag(sqrt(ri))
+template <class T> void link_spatial(const EtgLink& L, double rm, const double* ri, const double* shift, T I[6][6]) {
+  T Ic[3][3];
+  double s[3] = {std::sqrt(ri[0]), std::sqrt(ri[1]), std::sqrt(ri[2])};
+  double M[3][3] = {{L.inertia[0], L.inertia[3], L.inertia[4]},
+                    {L.inertia[3], L.inertia[1], L.inertia[5]},
+                    {L.inertia[4], L.inertia[5], L.inertia[2]}};
+  for (int i = 0; i < 3; i++)
+    for (int j = 0; j < 3; j++) Ic[i][j] = T(s[i] * M[i][j] * s[j]);
+  T c[3] = {T(L.com[0] + shift[0]), T(L.com[1] + shift[1]), T(L.com[2] + shift[2])};
+  make_spatial_inertia(T(L.mass * rm), c, Ic, I);
+}
+
+template <class T> void derive_params(Sim<T>& s, Env<T>& e) {
+  const EtgRobotModel& m = s.model;
+  const T* d = e.dyn;
+  e.latency = d[0] * T(0.001);  // ms -> s (train.py:116)
+  e.mu = d[1];
+  double zero[3] = {0, 0, 0};
+  double bi[3] = {(double)d[3], (double)d[4], (double)d[5]};
+  link_spatial<T>(m.trunk, (double)d[2], bi, zero, e.I[0]);
+  for (int l = 0; l < 4; l++) {
+    int h = 1 + 3 * l;
+    double r0[3] = {(double)d[9], (double)d[10], (double)d[11]};
+    double r1[3] = {(double)d[12], (double)d[13], (double)d[14]};
+    double r2[3] = {(double)d[15], (double)d[16], (double)d[17]};
+    double r3[3] = {(double)d[18], (double)d[19], (double)d[20]};
+    link_spatial<T>(m.hip[l], (double)d[6], r0, zero, e.I[h]);
+    link_spatial<T>(m.thigh[l], (double)d[7], r1, zero, e.I[h + 1]);
+    // calf + rigidly attached foot (fixed joint at (0,0,-lower_len), a1.py:99)
+    T Ic[6][6], If[6][6];
+    link_spatial<T>(m.calf[l], (double)d[8], r2, zero, Ic);
+    double fs[3] = {0, 0, -m.lower_len};
+    link_spatial<T>(m.foot[l], 1.0, r3, fs, If);
+    for (int i = 0; i < 6; i++)
+      for (int j = 0; j < 6; j++) e.I[h + 2][i][j] = Ic[i][j] + If[i][j];
+  }
+  for (int j = 0; j < 12; j++) { e.kp[j] = d[21 + j]; e.kd[j] = d[33 + j]; }
+  for (int k = 0; k < 3; k++) e.grav[k] = d[45 + k];
+}
+
+// ---------------------------------------------------------------- terrain
+template <class T> inline void terrain_query(const Sim<T>& s, T x, T y, T* h, T* n) {
+  if (s.cfg.terrain == 0 || s.heights.empty()) {
+    *h = 0; n[0] = 0; n[1] = 0; n[2] = 1;
+    return;
+  }
+  // bilinear heightfield, clamped at the border
+  const int nx = s.cfg.hf_nx, ny = s.cfg.hf_ny;
+  T fx = (x - T(s.cfg.hf_x0)) / T(s.cfg.hf_cell), fy = (y - T(s.cfg.hf_y0)) / T(s.cfg.hf_cell);
+  if (fx < 0) fx = 0;
+  if (fy < 0) fy = 0;
+  if (fx > T(nx - 1)) fx = T(nx - 1);
+  if (fy > T(ny - 1)) fy = T(ny - 1);
+  int ix = (int)fx, iy = (int)fy;
+  if (ix > nx - 2) ix = nx - 2;
+  if (iy > ny - 2) iy = ny - 2;
+  T tx = fx - T(ix), ty = fy - T(iy);
+  T h00 = T(s.heights[iy * nx + ix]), h10 = T(s.heights[iy * nx + ix + 1]);
+  T h01 = T(s.heights[(iy + 1) * nx + ix]), h11 = T(s.heights[(iy + 1) * nx + ix + 1]);
+  *h = (1 - tx) * (1 - ty) * h00 + tx * (1 - ty) * h10 + (1 - tx) * ty * h01 + tx * ty * h11;
+  T dhdx = ((1 - ty) * (h10 - h00) + ty * (h11 - h01)) / T(s.cfg.hf_cell);
+  T dhdy = ((1 - tx) * (h01 - h00) + tx * (h11 - h10)) / T(s.cfg.hf_cell);
+  T inv = T(1) / std::sqrt(dhdx * dhdx + dhdy * dhdy + 1);
+  n[0] = -dhdx * inv; n[1] = -dhdy * inv; n[2] = inv;
+}
+
+// ---------------------------------------------------------------- one physics tick
+// stepSimulation() of minitaur.py:244, as defined by this repo (DESIGN.md "physics model"):
+//   M(q) [a_b; qdd] + C(q, v) = [0; tau] + J^T f
+// 1. CRBA -> M (18x18), RNEA(qdd = 0, a_b = -g) -> C
+// 2. v* = v + dt M^-1 ([0;tau] - C)
+// 3. contacts: foot spheres vs ground; rows (n, t1, t2) per active foot; Delassus
+//    A = J M^-1 J^T; projected Gauss-Seidel in fixed order with cone projection
+// 4. v+ = v* + M^-1 J^T lambda ; semi-implicit Euler on positions
+template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
+  const T dt = T(s.cfg.sim_dt);
+  T R[3][3];
+  quat_to_mat(e.quat, R);
+
+  // ---- kinematics
+  Xform<T> Xup[NB];
+  T S[NB][6];
+  T v[NB][6], avp[NB][6], fvp[NB][6];
+  T IC[NB][6][6];
+  for (int k = 0; k < 3; k++) { v[0][k] = e.wb[k]; v[0][3 + k] = e.vb[k]; }
+  T gb[3];
+  mat3T_mul_vec(R, e.grav, gb);
+  for (int k = 0; k < 3; k++) { avp[0][k] = 0; avp[0][3 + k] = -gb[k]; }
+  {
+    T Iv[6], Ia[6], c[6];
+    mat6_mul_vec(e.I[0], v[0], Iv);
+    mat6_mul_vec(e.I[0], avp[0], Ia);
+    crf(v[0], Iv, c);
+    for (int k = 0; k < 6; k++) fvp[0][k] = Ia[k] + c[k];
+  }
+  std::memcpy(IC, e.I, sizeof(IC));
+  for (int i = 1; i < NB; i++) {
+    T ang = e.q[i - 1];
+    T cs = std::cos(ang), sn = std::sin(ang);
+    // E = rot(axis, ang)^T (parent -> child coordinates)
+    T E[3][3];
+    if (s.axis[i] == 0) {
+      T t[3][3] = {{1, 0, 0}, {0, cs, sn}, {0, -sn, cs}};
+      std::memcpy(E, t, sizeof(t));
+    } else {
+      T t[3][3] = {{cs, 0, -sn}, {0, 1, 0}, {sn, 0, cs}};
+      std::memcpy(E, t, sizeof(t));
+    }
+    std::memcpy(Xup[i].E, E, sizeof(E));
+    for (int k = 0; k < 3; k++) Xup[i].r[k] = s.jorigin[i][k];
+    for (int k = 0; k < 6; k++) S[i][k] = 0;
+    S[i][s.axis[i]] = 1;
+    int p = s.parent[i];
+    T vj[6];
+    for (int k = 0; k < 6; k++) vj[k] = S[i][k] * e.qd[i - 1];
+    x_apply_motion(Xup[i], v[p], v[i]);
+    for (int k = 0; k < 6; k++) v[i][k] += vj[k];
+    T t6[6];
+    x_apply_motion(Xup[i], avp[p], avp[i]);
+    crm(v[i], vj, t6);
+    for (int k = 0; k < 6; k++) avp[i][k] += t6[k];
+    T Iv[6], Ia[6], c[6];
+    mat6_mul_vec(e.I[i], v[i], Iv);
+    mat6_mul_vec(e.I[i], avp[i], Ia);
+    crf(v[i], Iv, c);
+    for (int k = 0; k < 6; k++) fvp[i][k] = Ia[k] + c[k];
+  }
+  // ---- backward pass: composite inertias and bias forces
+  for (int i = NB - 1; i >= 1; i--) {
+    int p = s.parent[i];
+    inertia_accumulate(Xup[i], IC[i], IC[p]);
+    T f[6];
+    x_applyT_force(Xup[i], fvp[i], f);
+    for (int k = 0; k < 6; k++) fvp[p][k] += f[k];
+  }
+  T M[NV][NV];
+  T C[NV];
+  std::memset(M, 0, sizeof(M));
+  for (int a = 0; a < 6; a++) {
+    C[a] = fvp[0][a];
+    for (int b = 0; b < 6; b++) M[a][b] = IC[0][a][b];
+  }
+  for (int i = 1; i < NB; i++) {
+    C[5 + i] = dot3(S[i], fvp[i]) + dot3(S[i] + 3, fvp[i] + 3);
+    T fh[6];
+    mat6_mul_vec(IC[i], S[i], fh);
+    M[5 + i][5 + i] = dot3(S[i], fh) + dot3(S[i] + 3, fh + 3);
+    int j = i;
+    while (s.parent[j] > 0) {
+      T t[6];
+      x_applyT_force(Xup[j], fh, t);
+      std::memcpy(fh, t, sizeof(t));
+      j = s.parent[j];
+      T h = dot3(S[j], fh) + dot3(S[j] + 3, fh + 3);
+      M[5 + i][5 + j] = h; M[5 + j][5 + i] = h;
+    }
+    T t[6];
+    x_applyT_force(Xup[j], fh, t);
+    for (int a = 0; a < 6; a++) { M[a][5 + i] = t[a]; M[5 + i][a] = t[a]; }
+  }
+  if (s.dbgM) std::memcpy(s.dbgM, M, sizeof(M));
+  if (s.dbgC) std::memcpy(s.dbgC, C, sizeof(C));
+  // ---- Cholesky M = L L^T
+  T L[NV][NV];
+  std::memset(L, 0, sizeof(L));
+  for (int i = 0; i < NV; i++)
+    for (int j = 0; j <= i; j++) {
+      T sum = M[i][j];
+      for (int k = 0; k < j; k++) sum -= L[i][k] * L[j][k];
+      if (i == j) L[i][i] = std::sqrt(sum);
+      else L[i][j] = sum / L[j][j];
+    }
+  auto chol_solve = [&](const T* b, T* x) {
+    T y[NV];
+    for (int i = 0; i < NV; i++) {
+      T sum = b[i];
+      for (int k = 0; k < i; k++) sum -= L[i][k] * y[k];
+      y[i] = sum / L[i][i];
+    }
+    for (int i = NV - 1; i >= 0; i--) {
+      T sum = y[i];
+      for (int k = i + 1; k < NV; k++) sum -= L[k][i] * x[k];
+      x[i] = sum / L[i][i];
+    }
+  };
+  T rhs[NV], acc[NV], vel[NV];
+  for (int a = 0; a < 6; a++) rhs[a] = -C[a];
+  for (int j = 0; j < 12; j++) rhs[6 + j] = tau[j] - C[6 + j];
+  chol_solve(rhs, acc);
+  for (int k = 0; k < 3; k++) { vel[k] = e.wb[k]; vel[3 + k] = e.vb[k]; }
+  for (int j = 0; j < 12; j++) vel[6 + j] = e.qd[j];
+  for (int i = 0; i < NV; i++) vel[i] += dt * acc[i];
+
+  // ---- contacts
+  // world poses of the leg links: R_w[i], p_w[i] (link origin in world)
+  T Rw[NB][3][3], pw[NB][3];
+  std::memcpy(Rw[0], R, sizeof(R));
+  for (int k = 0; k < 3; k++) pw[0][k] = e.pos[k];
+  for (int i = 1; i < NB; i++) {
+    int p = s.parent[i];
+    T Et[3][3];
+    for (int a = 0; a < 3; a++)
+      for (int b = 0; b < 3; b++) Et[a][b] = Xup[i].E[b][a];
+    mat3_mul(Rw[p], Et, Rw[i]);
+    T o[3];
+    mat3_mul_vec(Rw[p], Xup[i].r, o);
+    for (int k = 0; k < 3; k++) pw[i][k] = pw[p][k] + o[k];
+  }
+  T J[12][NV];
+  T target[12];
+  int active[4];
+  std::memset(J, 0, sizeof(J));
+  const T rad = T(s.model.foot_radius);
+  for (int l = 0; l < 4; l++) {
+    int c = 3 + 3 * l;  // calf body
+    T fl[3] = {0, 0, T(-s.model.lower_len)}, fw[3];
+    mat3_mul_vec(Rw[c], fl, fw);
+    for (int k = 0; k < 3; k++) fw[k] += pw[c][k];  // foot centre, world
+    T h, n[3];
+    terrain_query(s, fw[0], fw[1], &h, n);
+    T phi = (fw[2] - h) * n[2] - rad;  // distance along the normal to the tangent plane
+    active[l] = phi < T(s.cfg.contact_margin);
+    e.contact[l] = 0;
+    if (!active[l]) {
+      for (int k = 0; k < 3; k++) { e.lam[3 * l + k] = 0; target[3 * l + k] = 0; }
+      continue;
+    }
+    // contact frame: n, t1 = normalised projection of world x, t2 = n x t1
+    T t1[3] = {1 - n[0] * n[0], -n[0] * n[1], -n[0] * n[2]};
+    T inv = T(1) / std::sqrt(dot3(t1, t1));
+    for (int k = 0; k < 3; k++) t1[k] *= inv;
+    T t2[3];
+    cross(n, t1, t2);
+    T cp[3];  // contact point (sphere bottom along the normal), world
+    for (int k = 0; k < 3; k++) cp[k] = fw[k] - rad * n[k];
+    const T* dirs[3] = {n, t1, t2};
+    for (int r = 0; r < 3; r++) {
+      const T* d = dirs[r];
+      T* row = J[3 * l + r];
+      T rel[3], rxd[3], tmp[3];
+      for (int k = 0; k < 3; k++) rel[k] = cp[k] - e.pos[k];
+      cross(rel, d, rxd);
+      mat3T_mul_vec(R, rxd, tmp);  // base angular part in base coords
+      for (int k = 0; k < 3; k++) row[k] = tmp[k];
+      mat3T_mul_vec(R, d, tmp);
+      for (int k = 0; k < 3; k++) row[3 + k] = tmp[k];
+      for (int b = c; b > 0; b = s.parent[b]) {  // joints of this leg
+        T axw[3] = {Rw[b][0][s.axis[b]], Rw[b][1][s.axis[b]], Rw[b][2][s.axis[b]]};
+        T rj[3], cr[3];
+        for (int k = 0; k < 3; k++) rj[k] = cp[k] - pw[b][k];
+        cross(axw, rj, cr);
+        row[5 + b] = dot3(d, cr);
+      }
+    }
+    // normal target velocity: speculative for a gap, Baumgarte for penetration
+    target[3 * l] = (phi > 0) ? -phi / dt : -T(s.cfg.erp) * phi / dt;
+    target[3 * l + 1] = 0; target[3 * l + 2] = 0;
+    for (int k = 0; k < 3; k++) e.lam[3 * l + k] *= T(s.cfg.warmstart);
+  }
+  // Delassus operator
+  T MiJt[12][NV];
+  T A[12][12];
+  for (int r = 0; r < 12; r++) {
+    if (!active[r / 3]) { std::memset(MiJt[r], 0, sizeof(MiJt[r])); continue; }
+    chol_solve(J[r], MiJt[r]);
+  }
+  for (int r = 0; r < 12; r++)
+    for (int c = 0; c < 12; c++) {
+      T sum = 0;
+      for (int k = 0; k < NV; k++) sum += J[r][k] * MiJt[c][k];
+      A[r][c] = sum;
+    }
+  T u[12];
+  for (int r = 0; r < 12; r++) {
+    T sum = 0;
+    for (int k = 0; k < NV; k++) sum += J[r][k] * vel[k];
+    for (int c = 0; c < 12; c++) sum += A[r][c] * e.lam[c];
+    u[r] = sum;
+  }
+  auto apply = [&](int row, T d) {
+    for (int r = 0; r < 12; r++) u[r] += A[r][row] * d;
+  };
+  for (int it = 0; it < s.cfg.solver_iters; it++) {
+    for (int l = 0; l < 4; l++) {
+      if (!active[l]) continue;
+      int r0 = 3 * l;
+      // normal
+      T ln = e.lam[r0] - (u[r0] - target[r0]) / A[r0][r0];
+      if (ln < 0) ln = 0;
+      apply(r0, ln - e.lam[r0]);
+      e.lam[r0] = ln;
+      // tangents (sequential), then projection on the friction disc
+      for (int k = 1; k < 3; k++) {
+        T lt = e.lam[r0 + k] - u[r0 + k] / A[r0 + k][r0 + k];
+        apply(r0 + k, lt - e.lam[r0 + k]);
+        e.lam[r0 + k] = lt;
+      }
+      T lim = e.mu * ln;
+      T nt = std::sqrt(e.lam[r0 + 1] * e.lam[r0 + 1] + e.lam[r0 + 2] * e.lam[r0 + 2]);
+      if (nt > lim) {
+        T sc = (nt > 0) ? lim / nt : T(0);
+        for (int k = 1; k < 3; k++) {
+          T lt = e.lam[r0 + k] * sc;
+          apply(r0 + k, lt - e.lam[r0 + k]);
+          e.lam[r0 + k] = lt;
+        }
+      }
+    }
+  }
+  for (int r = 0; r < 12; r++) {
+    if (!active[r / 3]) continue;
+    for (int k = 0; k < NV; k++) vel[k] += MiJt[r][k] * e.lam[r];
+  }
+  for (int l = 0; l < 4; l++) e.contact[l] = active[l] && e.lam[3 * l] > 0;
+
+  // ---- integrate (semi-implicit Euler)
+  for (int k = 0; k < 3; k++) { e.wb[k] = vel[k]; e.vb[k] = vel[3 + k]; }
+  for (int j = 0; j < 12; j++) { e.qd[j] = vel[6 + j]; e.q[j] += dt * e.qd[j]; }
+  T vw[3];
+  mat3_mul_vec(R, e.vb, vw);
+  for (int k = 0; k < 3; k++) e.pos[k] += dt * vw[k];
+  T th[3] = {e.wb[0] * dt, e.wb[1] * dt, e.wb[2] * dt};
+  T ang = std::sqrt(dot3(th, th));
+  T dq[4];
+  if (ang > T(1e-12)) {
+    T sh = std::sin(ang / 2) / ang;
+    dq[0] = th[0] * sh; dq[1] = th[1] * sh; dq[2] = th[2] * sh; dq[3] = std::cos(ang / 2);
+  } else {
+    dq[0] = th[0] / 2; dq[1] = th[1] / 2; dq[2] = th[2] / 2; dq[3] = 1;
+  }
+  T qn[4];
+  quat_mul(e.quat, dq, qn);
+  T nn = T(1) / std::sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
+  for (int k = 0; k < 4; k++) e.quat[k] = qn[k] * nn;
+}
+
+// ---------------------------------------------------------------- robot layer
+// GetTrueObservation (minitaur.py:1142-1149) without the torques
+template <class T> void push_history(Env<T>& e) {
+  e.tick++;
+  T* h = e.hist[e.tick % RING];
+  for (int j = 0; j < 12; j++) { h[j] = e.q[j]; h[12 + j] = e.qd[j]; }
+  for (int k = 0; k < 4; k++) h[24 + k] = e.quat[k];
+  // body-frame angular velocity (TransformAngularVelocityToLocalFrame, minitaur.py:849-870)
+  for (int k = 0; k < 3; k++) h[28 + k] = e.wb[k];
+}
+// _GetDelayedObservation (minitaur.py:1172-1193); the ring is always full after the settle
+template <class T> void delayed_obs(const Sim<T>& s, const Env<T>& e, T* o) {
+  const T dt = T(s.cfg.sim_dt);
+  if (e.latency <= 0) {
+    std::memcpy(o, e.hist[e.tick % RING], sizeof(T) * HIST);
+    return;
+  }
+  int n = (int)(e.latency / dt);
+  if (n > RING - 2) n = RING - 2;
+  T rem = e.latency - T(n) * dt;
+  T alpha = rem / dt;
+  const T* a = e.hist[(e.tick - n + 4 * RING) % RING];
+  const T* b = e.hist[(e.tick - n - 1 + 4 * RING) % RING];
+  for (int k = 0; k < HIST; k++) o[k] = (T(1) - alpha) * a[k] + alpha * b[k];
+}
+
+// one sub-step: ApplyAction (PD, laikago_motor.py:165-173; pd_latency = 0) -> tick -> history
+template <class T> void sub_step(const Sim<T>& s, Env<T>& e, const T* qdes) {
+  T tau[12];
+  for (int j = 0; j < 12; j++) {
+    T t = -(e.kp[j] * (e.q[j] - qdes[j])) - e.kd[j] * e.qd[j];
+    if (s.cfg.torque_limit > 0) {
+      T lim = T(s.cfg.torque_limit);
+      if (t > lim) t = lim;
+      if (t < -lim) t = -lim;
+    }
+    tau[j] = t;
+    e.tau[j] = t;
+  }
+  physics_tick(s, e, tau);
+  for (int j = 0; j < 12; j++) e.energy += std::fabs(tau[j] * e.qd[j]) * T(s.cfg.sim_dt);
+  push_history(e);
+}
+
+template <class T> void foot_world(const Sim<T>& s, const Env<T>& e, T* fw /*12*/, T* fb /*12 base frame*/) {
+  T R[3][3];
+  quat_to_mat(e.quat, R);
+  for (int l = 0; l < 4; l++) {
+    T p[3];
+    leg_fk(e.q + 3 * l, T(hip_sign(l)), p);
+    for (int k = 0; k < 3; k++) p[k] += T(s.model.hip_origin[l][k]);
+    T w[3];
+    mat3_mul_vec(R, p, w);
+    for (int k = 0; k < 3; k++) { fb[3 * l + k] = p[k]; fw[3 * l + k] = w[k] + e.pos[k]; }
+  }
+}
+
+// ETG joint-space action at time t (SURVEY 8a a1-a3,a5): two phases, trot fan-out,
+// IK with the 0.95 shrink guard, minus pose_ori
+template <class T> void etg_action(const Sim<T>& s, const Env<T>& e, T t, T* act) {
+  T r1[ETG_RBF_H], r2[ETG_RBF_H];
+  s.basis.rbf(t, r1);
+  s.basis.rbf(t + s.basis.T2 * s.basis.Tperiod, r2);
+  T a1[3], a2[3];
+  for (int k = 0; k < 3; k++) {
+    T s1 = 0, s2 = 0;
+    for (int h = 0; h < ETG_RBF_H; h++) { s1 += e.etg_w[k][h] * r1[h]; s2 += e.etg_w[k][h] * r2[h]; }
+    a1[k] = s1 + e.etg_b[k]; a2[k] = s2 + e.etg_b[k];
+  }
+  for (int l = 0; l < 4; l++) {
+    const T* d = (l == 0 || l == 3) ? a1 : a2;
+    T scale = 1;
+    T ang[3];
+    for (int it = 0; it < 200; it++) {
+      T foot[3];
+      for (int k = 0; k < 3; k++)
+        foot[k] = T(s.model.base_foot[3 * l + k]) + d[k] * scale - T(s.model.hip_origin[l][k]);
+      leg_ik(foot, T(hip_sign(l)), ang);
+      if (std::isfinite(ang[0]) && std::isfinite(ang[1]) && std::isfinite(ang[2])) break;
+      scale *= T(0.95);
+      if (it == 199) { ang[0] = T(s.model.pose_ori[0]); ang[1] = T(s.model.pose_ori[1]); ang[2] = T(s.model.pose_ori[2]); }
+    }
+    for (int k = 0; k < 3; k++) act[3 * l + k] = ang[k] - T(s.model.pose_ori[3 * l + k]);
+  }
+}
+
+// observation assembly (EnvWrapper.py:60-109): sorted keys
+// BaseDisplacement(3) FootContactSensor(4) IMU(6) MotorAngleAcc(24) + ETG(12) = 49
+template <class T> void build_obs(const Sim<T>& s, Env<T>& e, const T* etg_act, T* obs, T* imu_raw) {
+  T d[HIST];
+  delayed_obs(s, e, d);
+  T rpy[3];
+  quat_to_rpy(d + 24, rpy);
+  if (!e.first_rpy_set) {
+    for (int k = 0; k < 3; k++) e.first_rpy[k] = rpy[k];
+    e.first_rpy_set = 1;
+  }
+  const bool nrm = s.cfg.obs_normal != 0;
+  const T ctrl_dt = T(s.cfg.sim_dt) * T(s.cfg.action_repeat);
+  int o = 0;
+  for (int k = 0; k < 3; k++) {
+    T disp = e.pos[k] - e.last_base[k];
+    obs[o++] = nrm ? disp / ctrl_dt : disp;
+  }
+  for (int l = 0; l < 4; l++) obs[o++] = e.contact[l] ? T(1) : T(0);
+  for (int k = 0; k < 3; k++) {
+    T r = rpy[k] - e.first_rpy[k];
+    imu_raw[k] = r;
+    obs[o++] = nrm ? r / T(0.1) : r;
+  }
+  for (int k = 0; k < 3; k++) {
+    imu_raw[3 + k] = d[28 + k];
+    obs[o++] = nrm ? d[28 + k] / T(0.5) : d[28 + k];
+  }
+  for (int j = 0; j < 12; j++) {
+    T a = d[j];
+    // MapToMinusPiToPi (minitaur.py:67-83)
+    a = std::fmod(a, T(2 * M_PI));
+    if (a >= T(M_PI)) a -= T(2 * M_PI);
+    else if (a < T(-M_PI)) a += T(2 * M_PI);
+    obs[o++] = nrm ? (a - T(s.model.pose_ori[j])) / T(0.1) : a;
+  }
+  for (int j = 0; j < 12; j++) obs[o++] = d[12 + j];
+  for (int j = 0; j < 12; j++)
+    obs[o++] = nrm ? (etg_act[j] - T(s.model.etg_mean[j])) / T(s.model.etg_std[j]) : etg_act[j];
+}
+
+template <class T> void reset_env(Sim<T>& s, Env<T>& e, T* obs) {
+  const EtgRobotModel& m = s.model;
+  for (int k = 0; k < 3; k++) { e.pos[k] = T(m.init_pos[k]); e.wb[k] = 0; e.vb[k] = 0; }
+  e.quat[0] = e.quat[1] = e.quat[2] = 0; e.quat[3] = 1;
+  for (int j = 0; j < 12; j++) { e.q[j] = T(m.pose_ori[j]); e.qd[j] = 0; e.lam[j] = 0; e.tau[j] = 0; }
+  for (int l = 0; l < 4; l++) e.contact[l] = 0;
+  e.tick = 0; e.energy = 0;
+  std::memset(e.hist, 0, sizeof(e.hist));
+  // ReceiveObservation before settling (a1.py:290): fill the whole ring with the
+  // initial reading so that the delayed observation is defined from tick 0
+  e.tick = -1;
+  push_history(e);
+  for (int r = 1; r < RING; r++) std::memcpy(e.hist[r], e.hist[0], sizeof(T) * HIST);
+  T qdes[12];
+  for (int j = 0; j < 12; j++) qdes[j] = T(m.pose_ori[j]);
+  for (int i = 0; i < s.cfg.settle_ticks; i++) sub_step(s, e, qdes);  // a1.py:294-297
+  e.step_count = 0; e.has_last = 0; e.first_rpy_set = 0; e.energy = 0;
+  for (int j = 0; j < 12; j++) {
+    e.last_qdes[j] = qdes[j];
+    for (int k = 0; k < 2; k++) { e.fx[k][j] = qdes[j]; e.fy[k][j] = qdes[j]; }  // init_history, action_filter.py:122-126
+  }
+  for (int k = 0; k < 3; k++) e.last_base[k] = e.pos[k];
+  T fb[12];
+  foot_world(s, e, e.last_foot_w, fb);
+  T act[12], imu[6];
+  etg_action(s, e, T(0), act);
+  build_obs(s, e, act, obs, imu);
+}
+
+// reward pieces (own definitions, DESIGN.md "reward"): c_prec saturating kernel
+template <class T> inline T c_prec(T v, T t, T m) {
+  T w = std::atanh(std::sqrt(T(0.95))) / m;
+  T x = (v - t) * w;
+  return std::tanh(x * x);
+}
+
+template <class T>
+void step_env(Sim<T>& s, Env<T>& e, const T* action, int donef, T* obs, T* reward, uint8_t* done, T* info) {
+  const EtgRobotModel& m = s.model;
+  const int R_ = s.cfg.action_repeat;
+  const T ctrl_dt = T(s.cfg.sim_dt) * T(R_);
+  // ETG at t = (k+1) dt  (fixture convention of gait_action_list_ETG_exp.npy)
+  T t = T(e.step_count + 1) * T(s.cfg.etg_dt);
+  T etg[12], qdes[12];
+  etg_action(s, e, t, etg);
+  for (int j = 0; j < 12; j++) qdes[j] = T(m.pose_ori[j]) + etg[j] + action[j];
+  if (s.cfg.enable_action_filter) {  // action_filter.py:111-120 (order 2)
+    for (int j = 0; j < 12; j++) {
+      T y = T(s.cfg.filter_b[0]) * qdes[j] + T(s.cfg.filter_b[1]) * e.fx[0][j] + T(s.cfg.filter_b[2]) * e.fx[1][j] -
+            T(s.cfg.filter_a[1]) * e.fy[0][j] - T(s.cfg.filter_a[2]) * e.fy[1][j];
+      e.fx[1][j] = e.fx[0][j]; e.fx[0][j] = qdes[j];
+      e.fy[1][j] = e.fy[0][j]; e.fy[0][j] = y;
+      qdes[j] = y;
+    }
+  }
+  e.energy = 0;
+  for (int i = 0; i < R_; i++) {  // minitaur.py:254-258
+    T proc[12];
+    if (s.cfg.enable_action_interp && e.has_last) {
+      T lerp = T(i + 1) / T(R_);
+      for (int j = 0; j < 12; j++) proc[j] = e.last_qdes[j] + lerp * (qdes[j] - e.last_qdes[j]);
+    } else {
+      for (int j = 0; j < 12; j++) proc[j] = qdes[j];
+    }
+    sub_step(s, e, proc);
+  }
+  for (int j = 0; j < 12; j++) e.last_qdes[j] = qdes[j];
+  e.has_last = 1;
+  e.step_count++;
+
+  T imu[6];
+  build_obs(s, e, etg, obs, imu);
+
+  // ---- reward / termination (this repo's definitions; rlschool's are absent)
+  T Rm[3][3];
+  quat_to_mat(e.quat, Rm);
+  T rpy[3];
+  quat_to_rpy(e.quat, rpy);
+  T fw[12], fb[12];
+  foot_world(s, e, fw, fb);
+  T dx = e.pos[0] - e.last_base[0];
+  T vx = dx / ctrl_dt;
+  T torso = vx < T(s.cfg.vel_d) ? vx : T(s.cfg.vel_d);
+  T up = (T(1) - c_prec(rpy[0], T(0), T(0.5))) * (T(1) - c_prec(rpy[1], T(0), T(0.5)));
+  T feet = 0;
+  for (int l = 0; l < 4; l++) feet += (fw[3 * l] - e.last_foot_w[3 * l]) * T(0.25);
+  feet = feet / ctrl_dt;
+  feet = feet < T(s.cfg.vel_d) ? feet : T(s.cfg.vel_d);
+  T tau_r = -e.energy;
+  int lost = 0, bad = 0;
+  for (int l = 0; l < 4; l++) {
+    lost += e.contact[l] ? 0 : 1;
+    // knee height: thigh-calf joint in world
+    T ang[3] = {e.q[3 * l], e.q[3 * l + 1], 0};
+    T cs = std::cos(ang[0]), sn = std::sin(ang[0]);
+    T ly = T(m.thigh_y[l]);
+    T kx = -T(m.upper_len) * std::sin(ang[1]);
+    T kzh = -T(m.upper_len) * std::cos(ang[1]);
+    T kb[3] = {T(m.hip_origin[l][0]) + kx, T(m.hip_origin[l][1]) + cs * ly - sn * kzh,
+               T(m.hip_origin[l][2]) + sn * ly + cs * kzh};
+    T kw[3];
+    mat3_mul_vec(Rm, kb, kw);
+    T hgt, nrm[3];
+    terrain_query(s, kw[0] + e.pos[0], kw[1] + e.pos[1], &hgt, nrm);
+    if (kw[2] + e.pos[2] - hgt < T(0.03)) bad++;
+  }
+  T badfoot = -T(bad);
+  T footcontact = -T(lost - 2 > 0 ? lost - 2 : 0);
+  T footz_mean = (fb[2] + fb[5] + fb[8] + fb[11]) * T(0.25);
+  T footz_max = fb[2];
+  for (int l = 1; l < 4; l++) footz_max = fb[3 * l + 2] > footz_max ? fb[3 * l + 2] : footz_max;
+  bool finite = std::isfinite(e.pos[0]) && std::isfinite(e.pos[2]) && std::isfinite(e.q[0]);
+  bool term = Rm[2][2] < T(0.5) || footz_mean > T(-0.1) || footz_max > 0 || std::fabs(rpy[2]) > T(0.6) || !finite;
+  const double* w = s.cfg.reward_w;
+  T terms[8] = {T(w[0]) * torso, T(w[1]) * feet, T(w[2]) * up, T(w[3]) * tau_r, T(0),
+                T(w[5]) * badfoot, T(w[6]) * footcontact, T(w[7]) * (term ? T(-1) : T(0))};
+  T sum = 0;
+  for (int k = 0; k < 8; k++) sum += terms[k];
+  *reward = T(s.cfg.reward_p) * sum;
+  *done = (term || donef) ? 1 : 0;
+  if (info) {
+    for (int k = 0; k < ETG_INFO_DIM; k++) info[k] = 0;
+    for (int k = 0; k < 8; k++) info[k] = terms[k];
+    info[ETG_INFO_VELX] = vx;
+    for (int j = 0; j < 12; j++) {
+      info[ETG_INFO_ETG_ACT + j] = etg[j];
+      info[ETG_INFO_JOINT_ANGLE + j] = e.q[j];
+      info[ETG_INFO_REAL_ACTION + j] = qdes[j];
+    }
+    for (int k = 0; k < 6; k++) info[ETG_INFO_OBS_IMU + k] = imu[k];
+    for (int l = 0; l < 4; l++) info[ETG_INFO_FOOT_CONTACT + l] = e.contact[l] ? T(1) : T(0);
+    for (int k = 0; k < 3; k++) { info[ETG_INFO_BASE + k] = e.pos[k]; info[ETG_INFO_RPY + k] = rpy[k]; }
+    info[ETG_INFO_ENERGY] = e.energy;
+    info[ETG_INFO_STEPS] = T(e.step_count);
+  }
+  for (int k = 0; k < 3; k++) e.last_base[k] = e.pos[k];
+  for (int k = 0; k < 12; k++) e.last_foot_w[k] = fw[k];
+}
+
+template <class T> void get_state(const Env<T>& e, T* st) {
+  T R[3][3];
+  quat_to_mat(e.quat, R);
+  T vw[3], ww[3];
+  mat3_mul_vec(R, e.vb, vw);
+  mat3_mul_vec(R, e.wb, ww);
+  for (int k = 0; k < 3; k++) { st[k] = e.pos[k]; st[7 + k] = vw[k]; st[10 + k] = ww[k]; }
+  for (int k = 0; k < 4; k++) st[3 + k] = e.quat[k];
+  for (int j = 0; j < 12; j++) { st[13 + j] = e.q[j]; st[25 + j] = e.qd[j]; }
+}
+template <class T> void set_state(Env<T>& e, const T* st) {
+  for (int k = 0; k < 3; k++) e.pos[k] = st[k];
+  T n = 0;
+  for (int k = 0; k < 4; k++) n += st[3 + k] * st[3 + k];
+  n = T(1) / std::sqrt(n);
+  for (int k = 0; k < 4; k++) e.quat[k] = st[3 + k] * n;
+  T R[3][3];
+  quat_to_mat(e.quat, R);
+  mat3T_mul_vec(R, st + 7, e.vb);
+  mat3T_mul_vec(R, st + 10, e.wb);
+  for (int j = 0; j < 12; j++) { e.q[j] = st[13 + j]; e.qd[j] = st[25 + j]; e.lam[j] = 0; }
+  // re-seed the latency ring with the new reading
+  e.tick = -1;
+  push_history(e);
+  for (int r = 1; r < RING; r++) std::memcpy(e.hist[r], e.hist[0], sizeof(T) * HIST);
+  for (int k = 0; k < 3; k++) e.last_base[k] = e.pos[k];
+}
+
+template <class F> void par_for(int n, int threads, F f) {
+  if (threads <= 1 || n < 2) {
+    for (int i = 0; i < n; i++) f(i);
+    return;
+  }
+  std::vector<std::thread> th;
+  int per = (n + threads - 1) / threads;
+  for (int t = 0; t < threads; t++) {
+    int a = t * per, b = a + per < n ? a + per : n;
+    if (a >= b) break;
+    th.emplace_back([=]() { for (int i = a; i < b; i++) f(i); });
+  }
+  for (auto& x : th) x.join();
+}
+}  // namespace
+
+// ---------------------------------------------------------------- C ABI
+#define DEFINE_API(SFX, T)                                                                         \
+  extern "C" void* etgo_create##SFX(const EtgConfig* cfg, const EtgRobotModel* model) {            \
+    auto* s = new Sim<T>();                                                                         \
+    s->cfg = *cfg; s->model = *model; s->N = cfg->num_envs;                                         \
+    s->basis.init(*cfg);                                                                            \
+    build_tree(*s);                                                                                 \
+    s->env.resize(s->N);                                                                            \
+    for (auto& e : s->env) {                                                                        \
+      std::memset((void*)&e, 0, sizeof(e));                                                         \
+      e.quat[3] = 1;                                                                                \
+    }                                                                                               \
+    return s;                                                                                       \
+  }                                                                                                 \
+  extern "C" void etgo_destroy##SFX(void* h) { delete (Sim<T>*)h; }                                 \
+  extern "C" void etgo_set_params##SFX(void* h, const T* dyn, const T* w, const T* b, int per_env,  \
+                                        const uint8_t* mask) {                                      \
+    auto* s = (Sim<T>*)h;                                                                           \
+    for (int i = 0; i < s->N; i++) {                                                                \
+      if (mask && !mask[i]) continue;                                                               \
+      Env<T>& e = s->env[i];                                                                        \
+      if (dyn) { std::memcpy(e.dyn, dyn + (size_t)i * ETG_DYN_DIM, sizeof(T) * ETG_DYN_DIM); derive_params(*s, e); } \
+      if (w) std::memcpy(e.etg_w, w + (per_env ? (size_t)i * 3 * ETG_RBF_H : 0), sizeof(T) * 3 * ETG_RBF_H); \
+      if (b) std::memcpy(e.etg_b, b + (per_env ? (size_t)i * 3 : 0), sizeof(T) * 3);               \
+    }                                                                                               \
+  }                                                                                                 \
+  extern "C" void etgo_set_heightfield##SFX(void* h, const float* hts) {                            \
+    auto* s = (Sim<T>*)h;                                                                           \
+    s->heights.assign(hts, hts + (size_t)s->cfg.hf_nx * s->cfg.hf_ny);                              \
+  }                                                                                                 \
+  extern "C" void etgo_reset##SFX(void* h, const uint8_t* mask, T* obs, int threads) {              \
+    auto* s = (Sim<T>*)h;                                                                           \
+    par_for(s->N, threads, [=](int i) {                                                             \
+      if (mask && !mask[i]) return;                                                                 \
+      reset_env(*s, s->env[i], obs + (size_t)i * ETG_OBS_DIM);                                      \
+    });                                                                                             \
+  }                                                                                                 \
+  extern "C" void etgo_step##SFX(void* h, const T* action, const uint8_t* donef, T* obs, T* reward, \
+                                  uint8_t* done, T* info, int threads) {                            \
+    auto* s = (Sim<T>*)h;                                                                           \
+    par_for(s->N, threads, [=](int i) {                                                             \
+      step_env(*s, s->env[i], action + (size_t)i * 12, donef ? donef[i] : 0,                        \
+               obs + (size_t)i * ETG_OBS_DIM, reward + i, done + i,                                 \
+               info ? info + (size_t)i * ETG_INFO_DIM : (T*)nullptr);                               \
+    });                                                                                             \
+  }                                                                                                 \
+  extern "C" void etgo_get_state##SFX(void* h, T* st) {                                             \
+    auto* s = (Sim<T>*)h;                                                                           \
+    for (int i = 0; i < s->N; i++) get_state(s->env[i], st + (size_t)i * ETG_STATE_DIM);            \
+  }                                                                                                 \
+  extern "C" void etgo_set_state##SFX(void* h, const T* st) {                                       \
+    auto* s = (Sim<T>*)h;                                                                           \
+    for (int i = 0; i < s->N; i++) set_state(s->env[i], st + (size_t)i * ETG_STATE_DIM);            \
+  }                                                                                                 \
+  /* raw physics ticks with given torques (for invariants tests) */                                 \
+  extern "C" void etgo_tick##SFX(void* h, const T* tau, int nticks) {                               \
+    auto* s = (Sim<T>*)h;                                                                           \
+    for (int i = 0; i < s->N; i++)                                                                  \
+      for (int k = 0; k < nticks; k++) physics_tick(*s, s->env[i], tau + (size_t)i * 12);           \
+  }                                                                                                 \
+  /* mass matrix / bias taps of env 0 at its current state (one throw-away tick on a copy) */       \
+  extern "C" void etgo_dynamics_terms##SFX(void* h, int env, T* M, T* C) {                           \
+    auto* s = (Sim<T>*)h;                                                                           \
+    Env<T> copy = s->env[env];                                                                      \
+    T tau[12] = {0};                                                                                \
+    s->dbgM = M; s->dbgC = C;                                                                       \
+    physics_tick(*s, copy, tau);                                                                    \
+    s->dbgM = nullptr; s->dbgC = nullptr;                                                           \
+  }                                                                                                 \
+  extern "C" void etgo_get_lambda##SFX(void* h, T* lam) {                                           \
+    auto* s = (Sim<T>*)h;                                                                           \
+    for (int i = 0; i < s->N; i++) std::memcpy(lam + (size_t)i * 12, s->env[i].lam, sizeof(T) * 12); \
+  }                                                                                                 \
+  extern "C" void etgo_etg_rbf##SFX(void* h, T t, T* r) { ((Sim<T>*)h)->basis.rbf(t, r); }         \
+  extern "C" void etgo_etg_action##SFX(void* h, int env, T t, T* act) {                             \
+    auto* s = (Sim<T>*)h;                                                                           \
+    etg_action(*s, s->env[env], t, act);                                                            \
+  }                                                                                                 \
+  extern "C" void etgo_leg_ik##SFX(const T* foot, T sign, T* ang) { leg_ik(foot, sign, ang); }      \
+  extern "C" void etgo_leg_fk##SFX(const T* ang, T sign, T* p) { leg_fk(ang, sign, p); }            \
+  extern "C" void etgo_leg_jacobian##SFX(const T* ang, int leg, T* J) {                             \
+    T Jm[3][3];                                                                                     \
+    leg_jacobian(ang, leg, Jm);                                                                     \
+    std::memcpy(J, Jm, sizeof(Jm));                                                                 \
+  }                                                                                                 \
+  extern "C" void etgo_pd_torque##SFX(const T* qdes, const T* q, const T* qd, const T* kp,          \
+                                       const T* kd, int n, T* tau) {                                \
+    for (int j = 0; j < n; j++) tau[j] = -(kp[j] * (q[j] - qdes[j])) - kd[j] * qd[j];               \
+  }                                                                                                 \
+  /* policy forward: model/mujoco_model.py:53-57 + alg/sac.py:60-63 */                              \
+  extern "C" void etgo_mlp_forward##SFX(const T* obs, int n, int in_dim, int hid, int out_dim,      \
+                                         const T* w1, const T* b1, const T* w2, const T* b2,        \
+                                         const T* w3, const T* b3, T scale, T* act) {               \
+    std::vector<T> h1(hid), h2(hid);                                                                \
+    for (int i = 0; i < n; i++) {                                                                   \
+      const T* o = obs + (size_t)i * in_dim;                                                        \
+      for (int a = 0; a < hid; a++) {                                                               \
+        T sum = b1[a];                                                                              \
+        for (int k = 0; k < in_dim; k++) sum += w1[(size_t)a * in_dim + k] * o[k];                  \
+        h1[a] = sum > 0 ? sum : 0;                                                                  \
+      }                                                                                             \
+      for (int a = 0; a < hid; a++) {                                                               \
+        T sum = b2[a];                                                                              \
+        for (int k = 0; k < hid; k++) sum += w2[(size_t)a * hid + k] * h1[k];                       \
+        h2[a] = sum > 0 ? sum : 0;                                                                  \
+      }                                                                                             \
+      for (int a = 0; a < out_dim; a++) {                                                           \
+        T sum = b3[a];                                                                              \
+        for (int k = 0; k < hid; k++) sum += w3[(size_t)a * hid + k] * h2[k];                       \
+        act[(size_t)i * out_dim + a] = std::tanh(sum) * scale;                                      \
+      }                                                                                             \
+    }                                                                                               \
+  }
+
+DEFINE_API(64, double)
+DEFINE_API(32, float)
+
+extern "C" int etgo_version(void) { return 1; }
