@@ -1,0 +1,824 @@
+// etg_core.h -- per-robot math of the fused env.step()/reset() kernels.
+//
+// Mapping (DESIGN.md "kernel mapping"): ONE ROBOT = ONE QUAD = 4 ADJACENT LANES, lane l
+// owns leg l (FR, FL, RR, RL); a wave64 carries 16 robots.  Everything a leg owns (its
+// 3 joints, 3 links, foot contact, ETG/IK/PD) lives in that lane's registers; the
+// floating base (pose, twist, 6x6 articulated inertia) is REPLICATED in the 4 lanes and
+// kept bit-identical by combining per-leg contributions with order-symmetric quad
+// reductions (DPP quad_perm on gfx950).
+//
+// The code is written against an abstract lane scalar F:
+//   - HIP build (etg_kernels.hip): F = float, quad ops = DPP, this is the product.
+//   - tests/emu build: F = a 4-wide struct executed on the host, used ONLY by tests to
+//     debug this exact source against the oracle without a GPU.
+//
+// Model (same as oracle/etgsim_oracle.cpp, derived independently there with generic
+// spatial algebra): floating base + 4 x (hip-x, thigh-y, calf-y) revolute chains, all
+// quantities expressed in the base frame about the base origin (trunk COM);
+//   M(q)[a_b; qdd] + C = [0; tau] + J^T f
+// solved by block elimination on the arrow structure of M (leg blocks 3x3, base Schur
+// complement 6x6), contacts by projected Gauss-Seidel over the 4 feet in lane order.
+#pragma once
+
+#include "etg_layout.h"
+
+namespace etg {
+
+// ------------------------------------------------------------------ tiny vector algebra
+template <class F> struct V3 { F x, y, z; };
+template <class F> ETG_HD V3<F> operator+(V3<F> a, V3<F> b) { return {a.x + b.x, a.y + b.y, a.z + b.z}; }
+template <class F> ETG_HD V3<F> operator-(V3<F> a, V3<F> b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+template <class F> ETG_HD V3<F> operator*(F s, V3<F> a) { return {s * a.x, s * a.y, s * a.z}; }
+template <class F> ETG_HD F dot(V3<F> a, V3<F> b) { return a.x * b.x + a.y * b.y + a.z * b.z; }
+template <class F> ETG_HD V3<F> cross(V3<F> a, V3<F> b) {
+  return {a.y * b.z - a.z * b.y, a.z * b.x - a.x * b.z, a.x * b.y - a.y * b.x};
+}
+template <class F> struct S3 { F xx, yy, zz, xy, xz, yz; };  // symmetric 3x3
+template <class F> ETG_HD V3<F> mul(S3<F> s, V3<F> v) {
+  return {s.xx * v.x + s.xy * v.y + s.xz * v.z, s.xy * v.x + s.yy * v.y + s.yz * v.z,
+          s.xz * v.x + s.yz * v.y + s.zz * v.z};
+}
+template <class F> struct SV { V3<F> a, l; };  // spatial vector: (angular, linear) / (moment, force)
+template <class F> ETG_HD SV<F> operator+(SV<F> p, SV<F> q) { return {p.a + q.a, p.l + q.l}; }
+template <class F> ETG_HD SV<F> operator-(SV<F> p, SV<F> q) { return {p.a - q.a, p.l - q.l}; }
+template <class F> ETG_HD SV<F> operator*(F s, SV<F> p) { return {s * p.a, s * p.l}; }
+template <class F> ETG_HD F dot(SV<F> p, SV<F> q) { return dot(p.a, q.a) + dot(p.l, q.l); }
+template <class F> ETG_HD F comp(const SV<F>& p, int i) {  // compile-time i after unrolling
+  return i == 0 ? p.a.x : i == 1 ? p.a.y : i == 2 ? p.a.z : i == 3 ? p.l.x : i == 4 ? p.l.y : p.l.z;
+}
+// motion x motion, motion x* force
+template <class F> ETG_HD SV<F> crm(SV<F> v, SV<F> m) { return {cross(v.a, m.a), cross(v.a, m.l) + cross(v.l, m.a)}; }
+template <class F> ETG_HD SV<F> crf(SV<F> v, SV<F> f) { return {cross(v.a, f.a) + cross(v.l, f.l), cross(v.a, f.l)}; }
+
+// rigid-body inertia about the base origin, in base axes
+template <class F> struct RBI { F m; V3<F> h; S3<F> I; };
+template <class F> ETG_HD RBI<F> operator+(RBI<F> a, RBI<F> b) {
+  return {a.m + b.m, a.h + b.h,
+          {a.I.xx + b.I.xx, a.I.yy + b.I.yy, a.I.zz + b.I.zz, a.I.xy + b.I.xy, a.I.xz + b.I.xz, a.I.yz + b.I.yz}};
+}
+template <class F> ETG_HD SV<F> apply(const RBI<F>& I, SV<F> v) {
+  return {mul(I.I, v.a) + cross(I.h, v.l), I.m * v.l - cross(I.h, v.a)};
+}
+// link frame given by its axes (ex, ey, ez) in base coordinates
+template <class F> struct Fr { V3<F> ex, ey, ez; };
+template <class F> ETG_HD V3<F> rot(const Fr<F>& R, V3<F> v) { return v.x * R.ex + v.y * R.ey + v.z * R.ez; }
+template <class F> ETG_HD RBI<F> link_inertia(F m, V3<F> com, S3<F> Ic, const Fr<F>& R, V3<F> o) {
+  V3<F> c = o + rot(R, com);
+  // R Ic R^T
+  V3<F> tx = Ic.xx * R.ex + Ic.xy * R.ey + Ic.xz * R.ez;
+  V3<F> ty = Ic.xy * R.ex + Ic.yy * R.ey + Ic.yz * R.ez;
+  V3<F> tz = Ic.xz * R.ex + Ic.yz * R.ey + Ic.zz * R.ez;
+  S3<F> I;
+  I.xx = R.ex.x * tx.x + R.ey.x * ty.x + R.ez.x * tz.x;
+  I.yy = R.ex.y * tx.y + R.ey.y * ty.y + R.ez.y * tz.y;
+  I.zz = R.ex.z * tx.z + R.ey.z * ty.z + R.ez.z * tz.z;
+  I.xy = R.ex.x * tx.y + R.ey.x * ty.y + R.ez.x * tz.y;
+  I.xz = R.ex.x * tx.z + R.ey.x * ty.z + R.ez.x * tz.z;
+  I.yz = R.ex.y * tx.z + R.ey.y * ty.z + R.ez.y * tz.z;
+  // parallel axis to the base origin
+  I.xx = I.xx + m * (c.y * c.y + c.z * c.z);
+  I.yy = I.yy + m * (c.x * c.x + c.z * c.z);
+  I.zz = I.zz + m * (c.x * c.x + c.y * c.y);
+  I.xy = I.xy - m * c.x * c.y;
+  I.xz = I.xz - m * c.x * c.z;
+  I.yz = I.yz - m * c.y * c.z;
+  return {m, m * c, I};
+}
+
+// ------------------------------------------------------------------ per-lane parameters / state
+template <class F> struct LaneParams {
+  F m[3];
+  V3<F> com[3];
+  S3<F> Ic[3];
+  V3<F> o1;       // hip joint origin in the base frame (a1.py:71-73 HIP_OFFSETS)
+  F sy;           // signed thigh offset (+-0.08505, a1.py:100)
+  F kp[3], kd[3]; // laikago_motor.py:165-173
+  F mu;
+  F m0;
+  S3<F> I0;
+  V3<F> g;        // gravity, world
+  F lat_n, lat_alpha;  // minitaur.py:1185-1188: n_steps_ago, blend_alpha
+  V3<F> base_foot, pose, emean, estd;
+  F hipsign;
+};
+
+template <class F> struct LaneState {
+  V3<F> p;            // base origin, world
+  F qx, qy, qz, qw;   // base orientation (xyzw, body -> world)
+  V3<F> wb, vb;       // base twist in base coordinates
+  F q[3], qd[3], lam[3];
+  F contact;          // 1 if this lane's foot carried load in the last tick
+  F energy;           // sum |tau qd| dt of this lane's joints since the step began
+};
+
+template <class F, class Ctx> ETG_HD LaneParams<F> load_params(const Ctx& c, const float* par) {
+  LaneParams<F> P;
+  int k = 0;
+  for (int i = 0; i < 3; i++) {
+    P.m[i] = c.ld_lane(par, k++);
+    P.com[i].x = c.ld_lane(par, k++); P.com[i].y = c.ld_lane(par, k++); P.com[i].z = c.ld_lane(par, k++);
+    P.Ic[i].xx = c.ld_lane(par, k++); P.Ic[i].yy = c.ld_lane(par, k++); P.Ic[i].zz = c.ld_lane(par, k++);
+    P.Ic[i].xy = c.ld_lane(par, k++); P.Ic[i].xz = c.ld_lane(par, k++); P.Ic[i].yz = c.ld_lane(par, k++);
+  }
+  P.o1.x = c.ld_lane(par, k++); P.o1.y = c.ld_lane(par, k++); P.o1.z = c.ld_lane(par, k++);
+  P.sy = c.ld_lane(par, k++);
+  for (int i = 0; i < 3; i++) P.kp[i] = c.ld_lane(par, k++);
+  for (int i = 0; i < 3; i++) P.kd[i] = c.ld_lane(par, k++);
+  P.mu = c.ld_lane(par, k++);
+  P.m0 = c.ld_lane(par, k++);
+  P.I0.xx = c.ld_lane(par, k++); P.I0.yy = c.ld_lane(par, k++); P.I0.zz = c.ld_lane(par, k++);
+  P.I0.xy = c.ld_lane(par, k++); P.I0.xz = c.ld_lane(par, k++); P.I0.yz = c.ld_lane(par, k++);
+  P.g.x = c.ld_lane(par, k++); P.g.y = c.ld_lane(par, k++); P.g.z = c.ld_lane(par, k++);
+  P.lat_n = c.ld_lane(par, k++); P.lat_alpha = c.ld_lane(par, k++);
+  P.base_foot.x = c.ld_lane(par, k++); P.base_foot.y = c.ld_lane(par, k++); P.base_foot.z = c.ld_lane(par, k++);
+  P.pose.x = c.ld_lane(par, k++); P.pose.y = c.ld_lane(par, k++); P.pose.z = c.ld_lane(par, k++);
+  P.emean.x = c.ld_lane(par, k++); P.emean.y = c.ld_lane(par, k++); P.emean.z = c.ld_lane(par, k++);
+  P.estd.x = c.ld_lane(par, k++); P.estd.y = c.ld_lane(par, k++); P.estd.z = c.ld_lane(par, k++);
+  P.hipsign = c.ld_lane(par, k++);
+  return P;
+}
+
+template <class F, class Ctx> ETG_HD LaneState<F> load_state(const Ctx& c, const float* base, const float* leg) {
+  LaneState<F> L;
+  L.p.x = c.ld_env(base, BS_PX); L.p.y = c.ld_env(base, BS_PY); L.p.z = c.ld_env(base, BS_PZ);
+  L.qx = c.ld_env(base, BS_QX); L.qy = c.ld_env(base, BS_QY); L.qz = c.ld_env(base, BS_QZ); L.qw = c.ld_env(base, BS_QW);
+  L.wb.x = c.ld_env(base, BS_WX); L.wb.y = c.ld_env(base, BS_WY); L.wb.z = c.ld_env(base, BS_WZ);
+  L.vb.x = c.ld_env(base, BS_VX); L.vb.y = c.ld_env(base, BS_VY); L.vb.z = c.ld_env(base, BS_VZ);
+  for (int j = 0; j < 3; j++) {
+    L.q[j] = c.ld_lane(leg, LG_Q + j); L.qd[j] = c.ld_lane(leg, LG_QD + j); L.lam[j] = c.ld_lane(leg, LG_LAM + j);
+  }
+  L.contact = c.ld_lane(leg, LG_CONTACT);
+  L.energy = F(0.0f);
+  return L;
+}
+template <class F, class Ctx> ETG_HD void store_state(const Ctx& c, float* base, float* leg, const LaneState<F>& L) {
+  c.st_env(base, BS_PX, L.p.x); c.st_env(base, BS_PY, L.p.y); c.st_env(base, BS_PZ, L.p.z);
+  c.st_env(base, BS_QX, L.qx); c.st_env(base, BS_QY, L.qy); c.st_env(base, BS_QZ, L.qz); c.st_env(base, BS_QW, L.qw);
+  c.st_env(base, BS_WX, L.wb.x); c.st_env(base, BS_WY, L.wb.y); c.st_env(base, BS_WZ, L.wb.z);
+  c.st_env(base, BS_VX, L.vb.x); c.st_env(base, BS_VY, L.vb.y); c.st_env(base, BS_VZ, L.vb.z);
+  for (int j = 0; j < 3; j++) {
+    c.st_lane(leg, LG_Q + j, L.q[j]); c.st_lane(leg, LG_QD + j, L.qd[j]); c.st_lane(leg, LG_LAM + j, L.lam[j]);
+  }
+  c.st_lane(leg, LG_CONTACT, L.contact);
+}
+
+// rows of the base rotation matrix R (body -> world): r0 = R^T x_w etc.
+template <class F> struct Rows { V3<F> r0, r1, r2; };
+template <class F> ETG_HD Rows<F> quat_rows(F x, F y, F z, F w) {
+  F two(2.0f), one(1.0f);
+  Rows<F> R;
+  R.r0 = {one - two * (y * y + z * z), two * (x * y - z * w), two * (x * z + y * w)};
+  R.r1 = {two * (x * y + z * w), one - two * (x * x + z * z), two * (y * z - x * w)};
+  R.r2 = {two * (x * z - y * w), two * (y * z + x * w), one - two * (x * x + y * y)};
+  return R;
+}
+
+// in-place LDL^T of a symmetric 6x6 stored as lower triangle s[i*(i+1)/2+j]:
+// on return s holds unit-lower L (strictly lower part), dinv[j] = 1/d_j
+template <class F> ETG_HD void ldl6(F* s, F* dinv) {
+  F d[6];
+#pragma unroll
+  for (int j = 0; j < 6; j++) {
+    F dj = s[j * (j + 1) / 2 + j];
+#pragma unroll
+    for (int k = 0; k < j; k++) {
+      F ljk = s[j * (j + 1) / 2 + k];
+      dj = dj - ljk * ljk * d[k];
+    }
+    d[j] = dj;
+    dinv[j] = F(1.0f) / dj;
+#pragma unroll
+    for (int i = j + 1; i < 6; i++) {
+      F v = s[i * (i + 1) / 2 + j];
+#pragma unroll
+      for (int k = 0; k < j; k++) v = v - s[i * (i + 1) / 2 + k] * s[j * (j + 1) / 2 + k] * d[k];
+      s[i * (i + 1) / 2 + j] = v * dinv[j];
+    }
+  }
+}
+template <class F> ETG_HD void fwd6(const F* L, F* b) {  // b <- L^-1 b
+#pragma unroll
+  for (int i = 1; i < 6; i++)
+#pragma unroll
+    for (int k = 0; k < i; k++) b[i] = b[i] - L[i * (i + 1) / 2 + k] * b[k];
+}
+template <class F> ETG_HD void bwd6(const F* L, F* b) {  // b <- L^-T b
+#pragma unroll
+  for (int i = 4; i >= 0; i--)
+#pragma unroll
+    for (int k = i + 1; k < 6; k++) b[i] = b[i] - L[k * (k + 1) / 2 + i] * b[k];
+}
+
+// ------------------------------------------------------------------ one physics tick
+// stepSimulation() + ApplyAction + ReceiveObservation of minitaur.py:242-246 for one quad.
+template <class F, class Ctx>
+ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const LaneParams<F>& P, LaneState<F>& L, const F* qdes) {
+  typedef V3<F> V;
+  typedef SV<F> W;
+  const F dt(K.dt), zero(0.0f), one(1.0f);
+
+  // ---- PD motor model (laikago_motor.py:165-173, pd_latency = 0)
+  F tau[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    F t = -(P.kp[j] * (L.q[j] - qdes[j])) - P.kd[j] * L.qd[j];
+    if (K.torque_limit > 0.0f) t = fminf_(fmaxf_(t, F(-K.torque_limit)), F(K.torque_limit));
+    tau[j] = t;
+  }
+
+  // ---- leg kinematics in the base frame
+  F sa, ca, sh, ch, shk, chk;
+  sincos_(L.q[0], sa, ca);
+  sincos_(L.q[1], sh, ch);
+  sincos_(L.q[1] + L.q[2], shk, chk);
+  Fr<F> R1 = {{one, zero, zero}, {zero, ca, sa}, {zero, -sa, ca}};
+  Fr<F> R2 = {{ch, sa * sh, -(ca * sh)}, {zero, ca, sa}, {sh, -(sa * ch), ca * ch}};
+  Fr<F> R3 = {{chk, sa * shk, -(ca * shk)}, {zero, ca, sa}, {shk, -(sa * chk), ca * chk}};
+  V yax = {zero, ca, sa};
+  V xax = {one, zero, zero};
+  V o1 = P.o1;
+  V o2 = o1 + P.sy * yax;
+  V o3 = o2 - F(K.upper_len) * R2.ez;
+  V pf = o3 - F(K.lower_len) * R3.ez;
+
+  RBI<F> I1 = link_inertia(P.m[0], P.com[0], P.Ic[0], R1, o1);
+  RBI<F> I2 = link_inertia(P.m[1], P.com[1], P.Ic[1], R2, o2);
+  RBI<F> I3 = link_inertia(P.m[2], P.com[2], P.Ic[2], R3, o3);
+  W S1 = {xax, cross(o1, xax)}, S2 = {yax, cross(o2, yax)}, S3_ = {yax, cross(o3, yax)};
+
+  // ---- velocities, bias accelerations (qdd = 0, a_base = -g), bias forces (RNEA)
+  Rows<F> Rw = quat_rows(L.qx, L.qy, L.qz, L.qw);
+  V gb;  // R^T g: columns of R are (r0.x, r1.x, r2.x) ...
+  gb.x = Rw.r0.x * P.g.x + Rw.r1.x * P.g.y + Rw.r2.x * P.g.z;
+  gb.y = Rw.r0.y * P.g.x + Rw.r1.y * P.g.y + Rw.r2.y * P.g.z;
+  gb.z = Rw.r0.z * P.g.x + Rw.r1.z * P.g.y + Rw.r2.z * P.g.z;
+  W V0 = {L.wb, L.vb};
+  W V1 = V0 + L.qd[0] * S1;
+  W V2 = V1 + L.qd[1] * S2;
+  W V3_ = V2 + L.qd[2] * S3_;
+  W a0 = {{zero, zero, zero}, {-gb.x, -gb.y, -gb.z}};
+  W a1 = a0 + L.qd[0] * crm(V0, S1);
+  W a2 = a1 + L.qd[1] * crm(V1, S2);
+  W a3 = a2 + L.qd[2] * crm(V2, S3_);
+  W f3 = apply(I3, a3) + crf(V3_, apply(I3, V3_));
+  W f2 = apply(I2, a2) + crf(V2, apply(I2, V2)) + f3;
+  W f1 = apply(I1, a1) + crf(V1, apply(I1, V1)) + f2;
+  F C1 = dot(S1, f1), C2 = dot(S2, f2), C3 = dot(S3_, f3);
+  RBI<F> I0 = {P.m0, {zero, zero, zero}, P.I0};
+  W f0 = apply(I0, a0) + crf(V0, apply(I0, V0));
+
+  // ---- composite inertias, leg block H (3x3), base coupling Fm (6x3) (CRBA)
+  RBI<F> Ic2 = I2 + I3;
+  RBI<F> Ic1 = I1 + Ic2;
+  W F1 = apply(Ic1, S1), F2 = apply(Ic2, S2), F3 = apply(I3, S3_);
+  F H11 = dot(S1, F1), H12 = dot(S1, F2), H13 = dot(S1, F3);
+  F H22 = dot(S2, F2), H23 = dot(S2, F3), H33 = dot(S3_, F3);
+  // H^-1 by cofactors
+  F cA = H22 * H33 - H23 * H23, cB = H13 * H23 - H12 * H33, cC = H12 * H23 - H13 * H22;
+  F cD = H11 * H33 - H13 * H13, cE = H12 * H13 - H11 * H23, cF = H11 * H22 - H12 * H12;
+  F idet = one / (H11 * cA + H12 * cB + H13 * cC);
+  F Hi11 = cA * idet, Hi12 = cB * idet, Hi13 = cC * idet, Hi22 = cD * idet, Hi23 = cE * idet, Hi33 = cF * idet;
+  // P = Fm H^-1 (columns)
+  W P1 = Hi11 * F1 + Hi12 * F2 + Hi13 * F3;
+  W P2 = Hi12 * F1 + Hi22 * F2 + Hi23 * F3;
+  W P3 = Hi13 * F1 + Hi23 * F2 + Hi33 * F3;
+  F rl1 = tau[0] - C1, rl2 = tau[1] - C2, rl3 = tau[2] - C3;
+  W pb = rl1 * P1 + rl2 * P2 + rl3 * P3;
+
+  // ---- base Schur complement: S = Mbb - sum_legs P Fm^T, rhs = -(f0 + sum f1) - sum pb
+  F s[21];
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++)
+      s[i * (i + 1) / 2 + j] =
+          c.qsum(comp(P1, i) * comp(F1, j) + comp(P2, i) * comp(F2, j) + comp(P3, i) * comp(F3, j));
+  RBI<F> Ib;
+  Ib.m = P.m0 + c.qsum(Ic1.m);
+  Ib.h = {c.qsum(Ic1.h.x), c.qsum(Ic1.h.y), c.qsum(Ic1.h.z)};
+  Ib.I = {P.I0.xx + c.qsum(Ic1.I.xx), P.I0.yy + c.qsum(Ic1.I.yy), P.I0.zz + c.qsum(Ic1.I.zz),
+          P.I0.xy + c.qsum(Ic1.I.xy), P.I0.xz + c.qsum(Ic1.I.xz), P.I0.yz + c.qsum(Ic1.I.yz)};
+  // Mbb lower triangle: rows/cols (wx wy wz vx vy vz); [w,w] = I, [v,w] = -[h]x, [v,v] = m
+  F mbb[21];
+  mbb[0] = Ib.I.xx;
+  mbb[1] = Ib.I.xy; mbb[2] = Ib.I.yy;
+  mbb[3] = Ib.I.xz; mbb[4] = Ib.I.yz; mbb[5] = Ib.I.zz;
+  mbb[6] = zero;     mbb[7] = Ib.h.z;   mbb[8] = -Ib.h.y;  mbb[9] = Ib.m;
+  mbb[10] = -Ib.h.z; mbb[11] = zero;    mbb[12] = Ib.h.x;  mbb[13] = zero; mbb[14] = Ib.m;
+  mbb[15] = Ib.h.y;  mbb[16] = -Ib.h.x; mbb[17] = zero;    mbb[18] = zero; mbb[19] = zero; mbb[20] = Ib.m;
+#pragma unroll
+  for (int i = 0; i < 21; i++) s[i] = mbb[i] - s[i];
+  F rb[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) rb[i] = -(comp(f0, i) + c.qsum(comp(f1, i))) - c.qsum(comp(pb, i));
+  F dinv[6];
+  ldl6(s, dinv);
+  fwd6(s, rb);
+#pragma unroll
+  for (int i = 0; i < 6; i++) rb[i] = rb[i] * dinv[i];
+  bwd6(s, rb);
+  W ab = {{rb[0], rb[1], rb[2]}, {rb[3], rb[4], rb[5]}};
+  F qdd1 = Hi11 * rl1 + Hi12 * rl2 + Hi13 * rl3 - dot(P1, ab);
+  F qdd2 = Hi12 * rl1 + Hi22 * rl2 + Hi23 * rl3 - dot(P2, ab);
+  F qdd3 = Hi13 * rl1 + Hi23 * rl2 + Hi33 * rl3 - dot(P3, ab);
+
+  // ---- unconstrained velocity
+  V wbs = L.wb + dt * ab.a, vbs = L.vb + dt * ab.l;
+  F qds1 = L.qd[0] + dt * qdd1, qds2 = L.qd[1] + dt * qdd2, qds3 = L.qd[2] + dt * qdd3;
+
+  // ---- foot contact (sphere vs ground)
+  V fw = {L.p.x + dot(Rw.r0, pf), L.p.y + dot(Rw.r1, pf), L.p.z + dot(Rw.r2, pf)};
+  F hgt, nwx, nwy, nwz;
+  c.terrain(K, fw.x, fw.y, hgt, nwx, nwy, nwz);
+  F phi = (fw.z - hgt) * nwz - F(K.foot_radius);
+  auto act = phi < F(K.margin);
+  F actf = sel_(act, one, zero);
+  // contact frame in world: n, t1 = normalised (x_w - (x_w.n) n), t2 = n x t1; then to base coords
+  V nw = {nwx, nwy, nwz};
+  V t1w = {one - nwx * nwx, -(nwx * nwy), -(nwx * nwz)};
+  F it1 = rsqrt_(dot(t1w, t1w));
+  t1w = it1 * t1w;
+  V t2w = cross(nw, t1w);
+  V dn = {Rw.r0.x * nw.x + Rw.r1.x * nw.y + Rw.r2.x * nw.z, Rw.r0.y * nw.x + Rw.r1.y * nw.y + Rw.r2.y * nw.z,
+          Rw.r0.z * nw.x + Rw.r1.z * nw.y + Rw.r2.z * nw.z};
+  V d1 = {Rw.r0.x * t1w.x + Rw.r1.x * t1w.y + Rw.r2.x * t1w.z, Rw.r0.y * t1w.x + Rw.r1.y * t1w.y + Rw.r2.y * t1w.z,
+          Rw.r0.z * t1w.x + Rw.r1.z * t1w.y + Rw.r2.z * t1w.z};
+  V d2 = {Rw.r0.x * t2w.x + Rw.r1.x * t2w.y + Rw.r2.x * t2w.z, Rw.r0.y * t2w.x + Rw.r1.y * t2w.y + Rw.r2.y * t2w.z,
+          Rw.r0.z * t2w.x + Rw.r1.z * t2w.y + Rw.r2.z * t2w.z};
+  V rc = pf - F(K.foot_radius) * dn;
+  V k1 = cross(xax, rc - o1), k2 = cross(yax, rc - o2), k3 = cross(yax, rc - o3);
+  V dir[3] = {dn, d1, d2};
+  F Jl[3][3];     // [row d][joint]
+  F HJ[3][3];     // H^-1 Jl^T, [row d][joint]
+  W Z[3];         // D^-1/2 L^-1 G_d
+  F sq[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) sq[i] = sqrt_(dinv[i]);
+#pragma unroll
+  for (int d = 0; d < 3; d++) {
+    Jl[d][0] = actf * dot(dir[d], k1);
+    Jl[d][1] = actf * dot(dir[d], k2);
+    Jl[d][2] = actf * dot(dir[d], k3);
+    HJ[d][0] = Hi11 * Jl[d][0] + Hi12 * Jl[d][1] + Hi13 * Jl[d][2];
+    HJ[d][1] = Hi12 * Jl[d][0] + Hi22 * Jl[d][1] + Hi23 * Jl[d][2];
+    HJ[d][2] = Hi13 * Jl[d][0] + Hi23 * Jl[d][1] + Hi33 * Jl[d][2];
+    W Jb = {actf * cross(rc, dir[d]), actf * dir[d]};
+    W G = Jb - (Jl[d][0] * P1 + Jl[d][1] * P2 + Jl[d][2] * P3);
+    F g6[6] = {G.a.x, G.a.y, G.a.z, G.l.x, G.l.y, G.l.z};
+    fwd6(s, g6);
+    Z[d] = {{g6[0] * sq[0], g6[1] * sq[1], g6[2] * sq[2]}, {g6[3] * sq[3], g6[4] * sq[4], g6[5] * sq[5]}};
+  }
+  // Delassus blocks A[j] = Z_mine^T Z_j (+ local leg compliance on the own block)
+  F A[4][3][3];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    W Zj[3];
+#pragma unroll
+    for (int e = 0; e < 3; e++)
+      Zj[e] = {{c.qbcast(Z[e].a.x, j), c.qbcast(Z[e].a.y, j), c.qbcast(Z[e].a.z, j)},
+               {c.qbcast(Z[e].l.x, j), c.qbcast(Z[e].l.y, j), c.qbcast(Z[e].l.z, j)}};
+    auto own = c.lane_is(j);
+#pragma unroll
+    for (int d = 0; d < 3; d++)
+#pragma unroll
+      for (int e = 0; e < 3; e++) {
+        F loc = Jl[d][0] * HJ[e][0] + Jl[d][1] * HJ[e][1] + Jl[d][2] * HJ[e][2];
+        A[j][d][e] = dot(Z[d], Zj[e]) + sel_(own, loc, zero);
+      }
+  }
+  // own diagonal inverses
+  F Aown[3][3];
+#pragma unroll
+  for (int d = 0; d < 3; d++)
+#pragma unroll
+    for (int e = 0; e < 3; e++)
+      Aown[d][e] = sel_(c.lane_is(0), A[0][d][e], sel_(c.lane_is(1), A[1][d][e], sel_(c.lane_is(2), A[2][d][e], A[3][d][e])));
+  F iA0 = sel_(act, one / Aown[0][0], zero), iA1 = sel_(act, one / Aown[1][1], zero), iA2 = sel_(act, one / Aown[2][2], zero);
+  // contact-point velocity under the unconstrained motion
+  V vc = vbs + cross(wbs, rc) + qds1 * k1 + qds2 * k2 + qds3 * k3;
+  F u0 = actf * dot(dn, vc), u1 = actf * dot(d1, vc), u2 = actf * dot(d2, vc);
+  F tgt = sel_(phi > zero, -(phi / dt), -(F(K.erp) * phi / dt));
+  // warm start (Bullet-style 0.85 factor); inactive feet forget their impulse
+  F l0 = actf * F(K.warmstart) * L.lam[0], l1 = actf * F(K.warmstart) * L.lam[1], l2 = actf * F(K.warmstart) * L.lam[2];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    F b0 = c.qbcast(l0, j), b1 = c.qbcast(l1, j), b2 = c.qbcast(l2, j);
+    u0 = u0 + A[j][0][0] * b0 + A[j][0][1] * b1 + A[j][0][2] * b2;
+    u1 = u1 + A[j][1][0] * b0 + A[j][1][1] * b1 + A[j][1][2] * b2;
+    u2 = u2 + A[j][2][0] * b0 + A[j][2][1] * b1 + A[j][2][2] * b2;
+  }
+  // ---- projected Gauss-Seidel: feet in lane order, rows (n, t1, t2), disc projection
+  for (int it = 0; it < K.iters; it++) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      F ln = fmaxf_(zero, l0 - (u0 - tgt) * iA0);
+      F dln = ln - l0;
+      F u1p = u1 + Aown[1][0] * dln;
+      F lt1 = l1 - u1p * iA1;
+      F d1l = lt1 - l1;
+      F u2p = u2 + Aown[2][0] * dln + Aown[2][1] * d1l;
+      F lt2 = l2 - u2p * iA2;
+      F lim = P.mu * ln;
+      F nt2 = lt1 * lt1 + lt2 * lt2;
+      auto over = nt2 > lim * lim;
+      F sc = sel_(over, lim * rsqrt_(fmaxf_(nt2, F(1e-30f))), one);
+      lt1 = lt1 * sc;
+      lt2 = lt2 * sc;
+      auto mine = c.lane_is(j) && act;
+      F e0 = sel_(mine, ln - l0, zero), e1 = sel_(mine, lt1 - l1, zero), e2 = sel_(mine, lt2 - l2, zero);
+      l0 = l0 + e0; l1 = l1 + e1; l2 = l2 + e2;
+      F b0 = c.qbcast(e0, j), b1 = c.qbcast(e1, j), b2 = c.qbcast(e2, j);
+      u0 = u0 + A[j][0][0] * b0 + A[j][0][1] * b1 + A[j][0][2] * b2;
+      u1 = u1 + A[j][1][0] * b0 + A[j][1][1] * b1 + A[j][1][2] * b2;
+      u2 = u2 + A[j][2][0] * b0 + A[j][2][1] * b1 + A[j][2][2] * b2;
+    }
+  }
+  // ---- apply impulses: base via the Schur factor, leg via H^-1
+  W zs = l0 * Z[0] + l1 * Z[1] + l2 * Z[2];
+  F db[6] = {c.qsum(zs.a.x) * sq[0], c.qsum(zs.a.y) * sq[1], c.qsum(zs.a.z) * sq[2],
+             c.qsum(zs.l.x) * sq[3], c.qsum(zs.l.y) * sq[4], c.qsum(zs.l.z) * sq[5]};
+  bwd6(s, db);
+  W dB = {{db[0], db[1], db[2]}, {db[3], db[4], db[5]}};
+  L.wb = wbs + dB.a;
+  L.vb = vbs + dB.l;
+  L.qd[0] = qds1 + HJ[0][0] * l0 + HJ[1][0] * l1 + HJ[2][0] * l2 - dot(P1, dB);
+  L.qd[1] = qds2 + HJ[0][1] * l0 + HJ[1][1] * l1 + HJ[2][1] * l2 - dot(P2, dB);
+  L.qd[2] = qds3 + HJ[0][2] * l0 + HJ[1][2] * l1 + HJ[2][2] * l2 - dot(P3, dB);
+  L.lam[0] = l0; L.lam[1] = l1; L.lam[2] = l2;
+  L.contact = sel_(act && (l0 > zero), one, zero);
+
+  // ---- semi-implicit Euler on positions
+#pragma unroll
+  for (int j = 0; j < 3; j++) L.q[j] = L.q[j] + dt * L.qd[j];
+  L.p.x = L.p.x + dt * dot(Rw.r0, L.vb);
+  L.p.y = L.p.y + dt * dot(Rw.r1, L.vb);
+  L.p.z = L.p.z + dt * dot(Rw.r2, L.vb);
+  V th = dt * L.wb;
+  F a2_ = dot(th, th);
+  // sin(a/2)/a and cos(a/2) by series (|a| <= ~0.1 per tick)
+  F sh2 = F(0.5f) - a2_ * (F(1.0f / 48.0f) - a2_ * F(1.0f / 3840.0f));
+  F ch2 = one - a2_ * (F(0.125f) - a2_ * (F(1.0f / 384.0f) - a2_ * F(1.0f / 46080.0f)));
+  F dx = th.x * sh2, dy = th.y * sh2, dz = th.z * sh2, dw = ch2;
+  F nx = L.qw * dx + L.qx * dw + L.qy * dz - L.qz * dy;
+  F ny = L.qw * dy - L.qx * dz + L.qy * dw + L.qz * dx;
+  F nz = L.qw * dz + L.qx * dy - L.qy * dx + L.qz * dw;
+  F nw_ = L.qw * dw - L.qx * dx - L.qy * dy - L.qz * dz;
+  F inv = rsqrt_(nx * nx + ny * ny + nz * nz + nw_ * nw_);
+  L.qx = nx * inv; L.qy = ny * inv; L.qz = nz * inv; L.qw = nw_ * inv;
+
+  L.energy = L.energy + (fabsf_(tau[0] * L.qd[0]) + fabsf_(tau[1] * L.qd[1]) + fabsf_(tau[2] * L.qd[2])) * dt;
+}
+
+// ------------------------------------------------------------------ latency ring (minitaur.py:1142-1193)
+// per lane 8 floats per tick: q3 qd3 + two base words (lane0: qx qy, lane1: qz qw,
+// lane2: wx wy, lane3: wz 0)
+template <class F, class Ctx> ETG_HD void ring_push(const Ctx& c, float* ring, int slot, const LaneState<F>& L) {
+  F b0 = sel_(c.lane_is(0), L.qx, sel_(c.lane_is(1), L.qz, sel_(c.lane_is(2), L.wb.x, L.wb.z)));
+  F b1 = sel_(c.lane_is(0), L.qy, sel_(c.lane_is(1), L.qw, sel_(c.lane_is(2), L.wb.y, F(0.0f))));
+  c.st_ring(ring, slot, 0, L.q[0]); c.st_ring(ring, slot, 1, L.q[1]); c.st_ring(ring, slot, 2, L.q[2]);
+  c.st_ring(ring, slot, 3, L.qd[0]); c.st_ring(ring, slot, 4, L.qd[1]); c.st_ring(ring, slot, 5, L.qd[2]);
+  c.st_ring(ring, slot, 6, b0); c.st_ring(ring, slot, 7, b1);
+}
+template <class F> struct Delayed { F q[3], qd[3]; F qx, qy, qz, qw; V3<F> w; };
+template <class F, class Ctx>
+ETG_HD Delayed<F> ring_read(const Ctx& c, const float* ring, int tick, const LaneParams<F>& P, const LaneState<F>& L) {
+  // n_steps_ago / blend_alpha are env-uniform; lat_n < 0 encodes latency <= 0
+  F v[8];
+  int n = c.uniform_int(P.lat_n);
+  if (n < 0) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) v[k] = c.ld_ring(ring, tick & (RING - 1), k);
+  } else {
+    int sa = (tick - n) & (RING - 1), sb = (tick - n - 1) & (RING - 1);
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      F a = c.ld_ring(ring, sa, k), b = c.ld_ring(ring, sb, k);
+      v[k] = (F(1.0f) - P.lat_alpha) * a + P.lat_alpha * b;
+    }
+  }
+  Delayed<F> D;
+  for (int k = 0; k < 3; k++) { D.q[k] = v[k]; D.qd[k] = v[3 + k]; }
+  D.qx = c.qbcast(v[6], 0); D.qy = c.qbcast(v[7], 0);
+  D.qz = c.qbcast(v[6], 1); D.qw = c.qbcast(v[7], 1);
+  D.w = {c.qbcast(v[6], 2), c.qbcast(v[7], 2), c.qbcast(v[6], 3)};
+  (void)L;
+  return D;
+}
+
+// ------------------------------------------------------------------ ETG + IK
+// a1.py:97-110
+template <class F> ETG_HD void leg_ik(V3<F> foot, F sign, F* ang) {
+  const F l_up(0.2f), l_low(0.2f);
+  F l_hip = F(0.08505f) * sign;
+  F x = foot.x, y = foot.y, z = foot.z;
+  F theta_knee = -acos_((x * x + y * y + z * z - l_hip * l_hip - l_low * l_low - l_up * l_up) / (F(2.0f) * l_low * l_up));
+  F l = sqrt_(l_up * l_up + l_low * l_low + F(2.0f) * l_up * l_low * cos_(theta_knee));
+  F theta_hip = asin_(-x / l) - theta_knee * F(0.5f);
+  F cc = cos_(theta_hip + theta_knee * F(0.5f));
+  F c1 = l_hip * y - l * cc * z;
+  F s1 = l * cc * y + l_hip * z;
+  ang[0] = atan2_(s1, c1);
+  ang[1] = theta_hip;
+  ang[2] = theta_knee;
+}
+// joint-space ETG action of this lane's leg at time t (minus pose_ori)
+template <class F, class Ctx>
+ETG_HD void etg_action(const Ctx& c, const KCfg& K, const LaneParams<F>& P, const float* etgp, float t, F* act) {
+  // legs 0,3 use r(t), legs 1,2 use r(t + T2*T) (trot)
+  F tl = sel_(c.lane_is(0) || c.lane_is(3), F(t), F(t + K.etg_T2 * K.etg_T));
+  F x0 = F(K.etg_amp) * sin_(F(K.etg_phase0) + tl * F(K.etg_omega));
+  F x1 = F(K.etg_amp) * sin_(F(K.etg_phase1) + tl * F(K.etg_omega));
+  F ax = c.ld_env(etgp, EP_B + 0), az = c.ld_env(etgp, EP_B + 2);
+  F ay = c.ld_env(etgp, EP_B + 1);
+  const F isig(1.0f / K.etg_sigma_sq);
+#pragma unroll 4
+  for (int h = 0; h < ETG_RBF_H; h++) {
+    F d0 = x0 - F(K.etg_u[h][0]), d1 = x1 - F(K.etg_u[h][1]);
+    F r = exp_(-((d0 * d0 + d1 * d1) * isig));
+    ax = ax + c.ld_env(etgp, EP_W + h) * r;
+    ay = ay + c.ld_env(etgp, EP_W + ETG_RBF_H + h) * r;
+    az = az + c.ld_env(etgp, EP_W + 2 * ETG_RBF_H + h) * r;
+  }
+  // IK with the 0.95 shrink guard against unreachable targets
+  F scale(1.0f);
+  F ang[3] = {P.pose.x, P.pose.y, P.pose.z};
+  auto pending = c.lane_is(0) || !c.lane_is(0);  // all-true mask
+  for (int it = 0; it < 200; it++) {
+    V3<F> foot = {P.base_foot.x + ax * scale - P.o1.x, P.base_foot.y + ay * scale - P.o1.y,
+                  P.base_foot.z + az * scale - P.o1.z};
+    F a[3];
+    leg_ik(foot, P.hipsign, a);
+    auto ok = isfinite_(a[0]) && isfinite_(a[1]) && isfinite_(a[2]);
+    auto take = pending && ok;
+    ang[0] = sel_(take, a[0], ang[0]); ang[1] = sel_(take, a[1], ang[1]); ang[2] = sel_(take, a[2], ang[2]);
+    pending = pending && !ok;
+    scale = scale * F(0.95f);
+    if (!c.any(pending)) break;
+  }
+  act[0] = ang[0] - P.pose.x; act[1] = ang[1] - P.pose.y; act[2] = ang[2] - P.pose.z;
+}
+
+// roll-pitch-yaw (ZYX) of a quaternion (getEulerFromQuaternion, minitaur.py:620,633)
+template <class F> ETG_HD V3<F> quat_rpy(F x, F y, F z, F w) {
+  F n = x * x + y * y + z * z + w * w;
+  F s = F(2.0f) / n;
+  F r20 = s * (x * z - y * w), r21 = s * (y * z + x * w), r22 = F(1.0f) - s * (x * x + y * y);
+  F r10 = s * (x * y + z * w), r00 = F(1.0f) - s * (y * y + z * z);
+  F sp = fminf_(fmaxf_(-r20, F(-1.0f)), F(1.0f));
+  return {atan2_(r21, r22), asin_(sp), atan2_(r10, r00)};
+}
+
+template <class F> ETG_HD F c_prec(F v, F t, F m) {
+  // atanh(sqrt(0.95)) = 2.1783...
+  F w = F(2.178343806f) / m;
+  F x = (v - t) * w;
+  return tanh_(x * x);
+}
+
+// ------------------------------------------------------------------ observation (EnvWrapper.py:60-109)
+// sorted keys: BaseDisplacement(3) FootContactSensor(4) IMU(6) MotorAngleAcc(24) + ETG(12) = 49
+template <class F, class Ctx>
+ETG_HD void write_obs(const Ctx& c, const KCfg& K, const LaneParams<F>& P, const LaneState<F>& L, const float* ring,
+                      int tick, float* ctl, const F* etg, F lbx, F lby, F lbz, bool set_first, float* obs, F* imu) {
+  Delayed<F> D = ring_read(c, ring, tick, P, L);
+  V3<F> rpy = quat_rpy(D.qx, D.qy, D.qz, D.qw);
+  F f0, f1, f2;
+  if (set_first) {
+    f0 = rpy.x; f1 = rpy.y; f2 = rpy.z;
+    c.st_env(ctl, CT_FIRST_RPY + 0, f0); c.st_env(ctl, CT_FIRST_RPY + 1, f1); c.st_env(ctl, CT_FIRST_RPY + 2, f2);
+  } else {
+    f0 = c.ld_env(ctl, CT_FIRST_RPY + 0); f1 = c.ld_env(ctl, CT_FIRST_RPY + 1); f2 = c.ld_env(ctl, CT_FIRST_RPY + 2);
+  }
+  const bool nrm = K.obs_normal != 0;
+  const float cdt = K.dt * (float)K.action_repeat;
+  F sdis(nrm ? 1.0f / cdt : 1.0f), srpy(nrm ? 10.0f : 1.0f), sdr(nrm ? 2.0f : 1.0f), sq(nrm ? 10.0f : 1.0f);
+  imu[0] = rpy.x - f0; imu[1] = rpy.y - f1; imu[2] = rpy.z - f2;
+  imu[3] = D.w.x; imu[4] = D.w.y; imu[5] = D.w.z;
+  if (obs) {
+    c.st_row_env(obs, ETG_OBS_DIM, 0, (L.p.x - lbx) * sdis);
+    c.st_row_env(obs, ETG_OBS_DIM, 1, (L.p.y - lby) * sdis);
+    c.st_row_env(obs, ETG_OBS_DIM, 2, (L.p.z - lbz) * sdis);
+    c.st_row_lane(obs, ETG_OBS_DIM, 3, 1, L.contact);
+    for (int k = 0; k < 3; k++) c.st_row_env(obs, ETG_OBS_DIM, 7 + k, imu[k] * srpy);
+    for (int k = 0; k < 3; k++) c.st_row_env(obs, ETG_OBS_DIM, 10 + k, imu[3 + k] * sdr);
+    F pose[3] = {P.pose.x, P.pose.y, P.pose.z};
+    F em[3] = {P.emean.x, P.emean.y, P.emean.z}, es[3] = {P.estd.x, P.estd.y, P.estd.z};
+    for (int j = 0; j < 3; j++) {
+      // MapToMinusPiToPi (minitaur.py:67-83)
+      F a = wrap_pi_(D.q[j]);
+      c.st_row_lane(obs, ETG_OBS_DIM, 13 + j, 3, nrm ? (a - pose[j]) * sq : a);
+      c.st_row_lane(obs, ETG_OBS_DIM, 25 + j, 3, D.qd[j]);
+      c.st_row_lane(obs, ETG_OBS_DIM, 37 + j, 3, nrm ? (etg[j] - em[j]) / es[j] : etg[j]);
+    }
+  }
+}
+
+// world x of this lane's foot centre and base-frame foot z / knee height over ground
+template <class F> struct FootKin { F fwx, fbz, knee_h; };
+template <class F, class Ctx>
+ETG_HD FootKin<F> foot_kin(const Ctx& c, const KCfg& K, const LaneParams<F>& P, const LaneState<F>& L) {
+  F sa, ca, sh, ch, shk, chk;
+  sincos_(L.q[0], sa, ca);
+  sincos_(L.q[1], sh, ch);
+  sincos_(L.q[1] + L.q[2], shk, chk);
+  F Lu(K.upper_len), Ll(K.lower_len);
+  V3<F> yax = {F(0.0f), ca, sa};
+  V3<F> o2 = P.o1 + P.sy * yax;
+  V3<F> e2 = {sh, -(sa * ch), ca * ch}, e3 = {shk, -(sa * chk), ca * chk};
+  V3<F> o3 = o2 - Lu * e2;
+  V3<F> pf = o3 - Ll * e3;
+  Rows<F> Rw = quat_rows(L.qx, L.qy, L.qz, L.qw);
+  FootKin<F> k;
+  k.fwx = L.p.x + dot(Rw.r0, pf);
+  k.fbz = pf.z;
+  F kx = L.p.x + dot(Rw.r0, o3), ky = L.p.y + dot(Rw.r1, o3), kz = L.p.z + dot(Rw.r2, o3);
+  F hgt, nx, ny, nz;
+  c.terrain(K, kx, ky, hgt, nx, ny, nz);
+  k.knee_h = kz - hgt;
+  return k;
+}
+
+// ------------------------------------------------------------------ one control step (env.step)
+// returns reward / done for the quad; obs/info optional.
+template <class F, class Ctx>
+ETG_HD void control_step(const Ctx& c, const KCfg& K, const LaneParams<F>& P, LaneState<F>& L, float* ring, float* ctl,
+                         int* ictl, float* legctl, const float* etgp, const F* action, F donef, float* obs, F& reward, F& done,
+                         float* info) {
+  int step_count = c.ld_env_i(ictl, IC_STEP);
+  int tick = c.ld_env_i(ictl, IC_TICK);
+  int has_last = c.ld_env_i(ictl, IC_HAS_LAST);
+  // ETG at t = (k+1) dt (fixture convention of gait_action_list_ETG_exp.npy)
+  F etg[3], qdes[3];
+  etg_action(c, K, P, etgp, (float)(step_count + 1) * K.etg_dt, etg);
+  F pose[3] = {P.pose.x, P.pose.y, P.pose.z};
+#pragma unroll
+  for (int j = 0; j < 3; j++) qdes[j] = pose[j] + etg[j] + action[j];
+  if (K.enable_filter) {  // action_filter.py:111-120, order 2
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      F x0 = c.ld_lane(legctl, LC_FX0 + j), x1 = c.ld_lane(legctl, LC_FX1 + j);
+      F y0 = c.ld_lane(legctl, LC_FY0 + j), y1 = c.ld_lane(legctl, LC_FY1 + j);
+      F y = F(K.fb[0]) * qdes[j] + F(K.fb[1]) * x0 + F(K.fb[2]) * x1 - F(K.fa[1]) * y0 - F(K.fa[2]) * y1;
+      c.st_lane(legctl, LC_FX1 + j, x0); c.st_lane(legctl, LC_FX0 + j, qdes[j]);
+      c.st_lane(legctl, LC_FY1 + j, y0); c.st_lane(legctl, LC_FY0 + j, y);
+      qdes[j] = y;
+    }
+  }
+  F last[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) last[j] = c.ld_lane(legctl, LC_LAST_QDES + j);
+  F lbx = c.ld_env(ctl, CT_LAST_BASE + 0), lby = c.ld_env(ctl, CT_LAST_BASE + 1), lbz = c.ld_env(ctl, CT_LAST_BASE + 2);
+  F last_fwx = c.ld_lane(legctl, LC_LAST_FOOT_X);
+  L.energy = F(0.0f);
+  const bool interp = K.enable_interp && has_last;
+  for (int i = 0; i < K.action_repeat; i++) {  // minitaur.py:254-258
+    F proc[3];
+    float lerp = (float)(i + 1) / (float)K.action_repeat;
+#pragma unroll
+    for (int j = 0; j < 3; j++) proc[j] = interp ? last[j] + F(lerp) * (qdes[j] - last[j]) : qdes[j];
+    physics_tick(c, K, P, L, proc);
+    tick++;
+    ring_push(c, ring, tick & (RING - 1), L);
+  }
+#pragma unroll
+  for (int j = 0; j < 3; j++) c.st_lane(legctl, LC_LAST_QDES + j, qdes[j]);
+  step_count++;
+  c.st_env_i(ictl, IC_STEP, step_count);
+  c.st_env_i(ictl, IC_TICK, tick);
+  c.st_env_i(ictl, IC_HAS_LAST, 1);
+  c.ring_fence();
+
+  F imu[6];
+  write_obs(c, K, P, L, ring, tick, ctl, etg, lbx, lby, lbz, false, obs, imu);
+
+  // ---- reward / termination (this repo's definitions)
+  const float cdt = K.dt * (float)K.action_repeat;
+  Rows<F> Rw = quat_rows(L.qx, L.qy, L.qz, L.qw);
+  V3<F> rpy = quat_rpy(L.qx, L.qy, L.qz, L.qw);
+  FootKin<F> fk = foot_kin(c, K, P, L);
+  F vx = (L.p.x - lbx) * F(1.0f / cdt);
+  F torso = fminf_(vx, F(K.vel_d));
+  F up = (F(1.0f) - c_prec(rpy.x, F(0.0f), F(0.5f))) * (F(1.0f) - c_prec(rpy.y, F(0.0f), F(0.5f)));
+  F feet = c.qsum((fk.fwx - last_fwx) * F(0.25f)) * F(1.0f / cdt);
+  feet = fminf_(feet, F(K.vel_d));
+  F energy = c.qsum(L.energy);
+  F lost = c.qsum(F(1.0f) - L.contact);
+  F bad = c.qsum(sel_(fk.knee_h < F(0.03f), F(1.0f), F(0.0f)));
+  F footcontact = -fmaxf_(lost - F(2.0f), F(0.0f));
+  F fz_mean = c.qsum(fk.fbz) * F(0.25f);
+  F fz_max = c.qmax(fk.fbz);
+  auto fin = isfinite_(L.p.x) && isfinite_(L.p.z) && isfinite_(c.qbcast(L.q[0], 0));
+  auto term = (Rw.r2.z < F(0.5f)) || (fz_mean > F(-0.1f)) || (fz_max > F(0.0f)) || (fabsf_(rpy.z) > F(0.6f)) || !fin;
+  F termf = sel_(term, F(1.0f), F(0.0f));
+  F terms[8] = {F(K.rw[0]) * torso, F(K.rw[1]) * feet, F(K.rw[2]) * up, F(K.rw[3]) * (-energy), F(0.0f),
+                F(K.rw[5]) * (-bad), F(K.rw[6]) * footcontact, F(K.rw[7]) * (-termf)};
+  F sum = terms[0];
+#pragma unroll
+  for (int k = 1; k < 8; k++) sum = sum + terms[k];
+  reward = F(K.reward_p) * sum;
+  done = sel_(term || (donef > F(0.5f)), F(1.0f), F(0.0f));
+  if (info) {
+    for (int k = 0; k < 8; k++) c.st_row_env(info, ETG_INFO_DIM, k, terms[k]);
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_VELX, vx);
+    for (int j = 0; j < 3; j++) {
+      c.st_row_lane(info, ETG_INFO_DIM, ETG_INFO_ETG_ACT + j, 3, etg[j]);
+      c.st_row_lane(info, ETG_INFO_DIM, ETG_INFO_JOINT_ANGLE + j, 3, L.q[j]);
+      c.st_row_lane(info, ETG_INFO_DIM, ETG_INFO_REAL_ACTION + j, 3, qdes[j]);
+    }
+    for (int k = 0; k < 6; k++) c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_OBS_IMU + k, imu[k]);
+    c.st_row_lane(info, ETG_INFO_DIM, ETG_INFO_FOOT_CONTACT, 1, L.contact);
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_BASE + 0, L.p.x);
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_BASE + 1, L.p.y);
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_BASE + 2, L.p.z);
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_RPY + 0, rpy.x);
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_RPY + 1, rpy.y);
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_RPY + 2, rpy.z);
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_ENERGY, energy);
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_STEPS, F((float)step_count));
+    for (int k = ETG_INFO_STEPS + 1; k < ETG_INFO_DIM; k++) c.st_row_env(info, ETG_INFO_DIM, k, F(0.0f));
+  }
+  c.st_env(ctl, CT_LAST_BASE + 0, L.p.x); c.st_env(ctl, CT_LAST_BASE + 1, L.p.y); c.st_env(ctl, CT_LAST_BASE + 2, L.p.z);
+  c.st_lane(legctl, LC_LAST_FOOT_X, fk.fwx);
+}
+
+// ------------------------------------------------------------------ reset (minitaur.py:403-445, a1.py:289-349)
+template <class F, class Ctx>
+ETG_HD void reset_quad(const Ctx& c, const KCfg& K, const LaneParams<F>& P, LaneState<F>& L, float* ring, float* ctl,
+                       int* ictl, float* legctl, const float* etgp, float* obs) {
+  L.p = {F(K.init_pos[0]), F(K.init_pos[1]), F(K.init_pos[2])};
+  L.qx = F(0.0f); L.qy = F(0.0f); L.qz = F(0.0f); L.qw = F(1.0f);
+  L.wb = {F(0.0f), F(0.0f), F(0.0f)};
+  L.vb = {F(0.0f), F(0.0f), F(0.0f)};
+  F pose[3] = {P.pose.x, P.pose.y, P.pose.z};
+  for (int j = 0; j < 3; j++) { L.q[j] = pose[j]; L.qd[j] = F(0.0f); L.lam[j] = F(0.0f); }
+  L.contact = F(0.0f);
+  L.energy = F(0.0f);
+  // ReceiveObservation before settling (a1.py:290): seed every ring slot with the initial reading
+  for (int sl = 0; sl < RING; sl++) ring_push(c, ring, sl, L);
+  int tick = 0;
+  for (int i = 0; i < K.settle_ticks; i++) {  // a1.py:294-297
+    physics_tick(c, K, P, L, pose);
+    tick++;
+    ring_push(c, ring, tick & (RING - 1), L);
+  }
+  c.ring_fence();
+  L.energy = F(0.0f);
+  c.st_env_i(ictl, IC_STEP, 0);
+  c.st_env_i(ictl, IC_TICK, tick);
+  c.st_env_i(ictl, IC_HAS_LAST, 0);
+  c.st_env(ctl, CT_LAST_BASE + 0, L.p.x); c.st_env(ctl, CT_LAST_BASE + 1, L.p.y); c.st_env(ctl, CT_LAST_BASE + 2, L.p.z);
+  for (int j = 0; j < 3; j++) {
+    c.st_lane(legctl, LC_LAST_QDES + j, pose[j]);
+    c.st_lane(legctl, LC_FX0 + j, pose[j]); c.st_lane(legctl, LC_FX1 + j, pose[j]);  // init_history, action_filter.py:122-126
+    c.st_lane(legctl, LC_FY0 + j, pose[j]); c.st_lane(legctl, LC_FY1 + j, pose[j]);
+  }
+  FootKin<F> fk = foot_kin(c, K, P, L);
+  c.st_lane(legctl, LC_LAST_FOOT_X, fk.fwx);
+  F etg[3], imu[6];
+  etg_action(c, K, P, etgp, 0.0f, etg);
+  write_obs(c, K, P, L, ring, tick, ctl, etg, L.p.x, L.p.y, L.p.z, true, obs, imu);
+}
+
+// ------------------------------------------------------------------ state access (parity tests)
+// external state row [37]: pos3 quat4(xyzw) linvel3 angvel3 (world frame, pybullet convention) q12 qd12
+template <class F, class Ctx> ETG_HD void get_state_quad(const Ctx& c, const LaneState<F>& L, float* st) {
+  Rows<F> R = quat_rows(L.qx, L.qy, L.qz, L.qw);
+  c.st_row_env(st, ETG_STATE_DIM, 0, L.p.x); c.st_row_env(st, ETG_STATE_DIM, 1, L.p.y); c.st_row_env(st, ETG_STATE_DIM, 2, L.p.z);
+  c.st_row_env(st, ETG_STATE_DIM, 3, L.qx); c.st_row_env(st, ETG_STATE_DIM, 4, L.qy);
+  c.st_row_env(st, ETG_STATE_DIM, 5, L.qz); c.st_row_env(st, ETG_STATE_DIM, 6, L.qw);
+  c.st_row_env(st, ETG_STATE_DIM, 7, dot(R.r0, L.vb)); c.st_row_env(st, ETG_STATE_DIM, 8, dot(R.r1, L.vb));
+  c.st_row_env(st, ETG_STATE_DIM, 9, dot(R.r2, L.vb));
+  c.st_row_env(st, ETG_STATE_DIM, 10, dot(R.r0, L.wb)); c.st_row_env(st, ETG_STATE_DIM, 11, dot(R.r1, L.wb));
+  c.st_row_env(st, ETG_STATE_DIM, 12, dot(R.r2, L.wb));
+  for (int j = 0; j < 3; j++) {
+    c.st_row_lane(st, ETG_STATE_DIM, 13 + j, 3, L.q[j]);
+    c.st_row_lane(st, ETG_STATE_DIM, 25 + j, 3, L.qd[j]);
+  }
+}
+template <class F, class Ctx>
+ETG_HD void set_state_quad(const Ctx& c, const float* st, LaneState<F>& L, float* ring, float* ctl, int* ictl) {
+  L.p = {c.ld_row_env(st, ETG_STATE_DIM, 0), c.ld_row_env(st, ETG_STATE_DIM, 1), c.ld_row_env(st, ETG_STATE_DIM, 2)};
+  F x = c.ld_row_env(st, ETG_STATE_DIM, 3), y = c.ld_row_env(st, ETG_STATE_DIM, 4);
+  F z = c.ld_row_env(st, ETG_STATE_DIM, 5), w = c.ld_row_env(st, ETG_STATE_DIM, 6);
+  F inv = rsqrt_(x * x + y * y + z * z + w * w);
+  L.qx = x * inv; L.qy = y * inv; L.qz = z * inv; L.qw = w * inv;
+  Rows<F> R = quat_rows(L.qx, L.qy, L.qz, L.qw);
+  V3<F> vw = {c.ld_row_env(st, ETG_STATE_DIM, 7), c.ld_row_env(st, ETG_STATE_DIM, 8), c.ld_row_env(st, ETG_STATE_DIM, 9)};
+  V3<F> ww = {c.ld_row_env(st, ETG_STATE_DIM, 10), c.ld_row_env(st, ETG_STATE_DIM, 11), c.ld_row_env(st, ETG_STATE_DIM, 12)};
+  // R^T v
+  L.vb = {R.r0.x * vw.x + R.r1.x * vw.y + R.r2.x * vw.z, R.r0.y * vw.x + R.r1.y * vw.y + R.r2.y * vw.z,
+          R.r0.z * vw.x + R.r1.z * vw.y + R.r2.z * vw.z};
+  L.wb = {R.r0.x * ww.x + R.r1.x * ww.y + R.r2.x * ww.z, R.r0.y * ww.x + R.r1.y * ww.y + R.r2.y * ww.z,
+          R.r0.z * ww.x + R.r1.z * ww.y + R.r2.z * ww.z};
+  for (int j = 0; j < 3; j++) {
+    L.q[j] = c.ld_row_lane(st, ETG_STATE_DIM, 13 + j, 3);
+    L.qd[j] = c.ld_row_lane(st, ETG_STATE_DIM, 25 + j, 3);
+    L.lam[j] = F(0.0f);
+  }
+  L.contact = F(0.0f);
+  for (int sl = 0; sl < RING; sl++) ring_push(c, ring, sl, L);  // re-seed the latency ring
+  c.st_env_i(ictl, IC_TICK, 0);
+  c.st_env(ctl, CT_LAST_BASE + 0, L.p.x); c.st_env(ctl, CT_LAST_BASE + 1, L.p.y); c.st_env(ctl, CT_LAST_BASE + 2, L.p.z);
+}
+
+}  // namespace etg

@@ -1,0 +1,240 @@
+// etg_layout.h -- HBM data layout of the simulator state, the kernel-uniform config
+// block, and the float lane-math primitives etg_core.h is written against.
+//
+// Layout (DESIGN.md "data layout in HBM"): everything is structure-of-arrays so that a
+// wave's 64 lanes touch 64 consecutive floats:
+//   base  [BS_N ][N]      floating-base state, one column per robot (read by its 4 lanes)
+//   leg   [LG_N ][4N]     per-leg state, one column per lane  (lane id = 4*env + leg)
+//   ctl   [CT_N ][N]      per-robot control-loop floats ; ictl [IC_N][N] ints
+//   legctl[LC_N ][4N]     per-leg control-loop floats
+//   etgp  [EP_N ][N]      ETG weights w[3][20] + b[3] per robot
+//   par   [PR_N ][4N]     derived physical parameters per lane
+//   ring  [RING][8][4N]   latency ring (minitaur.py:1142-1193), 8 floats per lane per tick
+#pragma once
+
+#include <math.h>
+#include <stdint.h>
+
+#include "../../include/etgsim.h"
+
+#if defined(__HIPCC__)
+#define ETG_HD __device__ __forceinline__
+#else
+#define ETG_HD inline
+#endif
+
+namespace etg {
+
+constexpr int RING = 64;  // ticks of history; latency <= 80 ms at dt = 2 ms needs 42
+
+enum { BS_PX, BS_PY, BS_PZ, BS_QX, BS_QY, BS_QZ, BS_QW, BS_WX, BS_WY, BS_WZ, BS_VX, BS_VY, BS_VZ, BS_N };
+enum { LG_Q = 0, LG_QD = 3, LG_LAM = 6, LG_CONTACT = 9, LG_N = 10 };
+enum { CT_FIRST_RPY = 0, CT_LAST_BASE = 3, CT_N = 6 };
+enum { IC_STEP = 0, IC_TICK = 1, IC_HAS_LAST = 2, IC_N = 3 };
+enum { LC_LAST_QDES = 0, LC_FX0 = 3, LC_FX1 = 6, LC_FY0 = 9, LC_FY1 = 12, LC_LAST_FOOT_X = 15, LC_N = 16 };
+enum { EP_W = 0, EP_B = 60, EP_N = 63 };
+constexpr int PR_N = 66;  // fields read by load_params(), in that order
+
+struct KCfg {
+  int n_env;
+  int action_repeat, settle_ticks, iters, enable_interp, enable_filter, obs_normal, terrain;
+  float dt, erp, margin, warmstart, torque_limit;
+  float upper_len, lower_len, foot_radius;
+  float init_pos[3];
+  float etg_T, etg_T2, etg_amp, etg_sigma_sq, etg_phase0, etg_phase1, etg_omega, etg_dt;
+  float etg_u[ETG_RBF_H][2];
+  float rw[8], reward_p, vel_d;
+  float fb[3], fa[3];
+  int hf_nx, hf_ny;
+  float hf_cell, hf_x0, hf_y0;
+  const float* hf;
+};
+
+struct DevState {
+  float *base, *leg, *ctl, *legctl, *etgp, *par, *ring;
+  int* ictl;
+};
+
+// ---- float lane math ------------------------------------------------------------
+ETG_HD float sel_(bool c, float a, float b) { return c ? a : b; }
+ETG_HD float fminf_(float a, float b) { return fminf(a, b); }
+ETG_HD float fmaxf_(float a, float b) { return fmaxf(a, b); }
+ETG_HD float fabsf_(float a) { return fabsf(a); }
+ETG_HD float sqrt_(float a) { return sqrtf(a); }
+ETG_HD float sin_(float a) { return sinf(a); }
+ETG_HD float cos_(float a) { return cosf(a); }
+ETG_HD float exp_(float a) { return expf(a); }
+ETG_HD float tanh_(float a) { return tanhf(a); }
+ETG_HD float acos_(float a) { return acosf(a); }
+ETG_HD float asin_(float a) { return asinf(a); }
+ETG_HD float atan2_(float a, float b) { return atan2f(a, b); }
+ETG_HD bool isfinite_(float a) { return isfinite(a); }
+#if defined(__HIPCC__)
+ETG_HD float rsqrt_(float a) { return 1.0f / sqrtf(a); }
+ETG_HD void sincos_(float a, float& s, float& c) { sincosf(a, &s, &c); }
+#else
+ETG_HD float rsqrt_(float a) { return 1.0f / sqrtf(a); }
+ETG_HD void sincos_(float a, float& s, float& c) { s = sinf(a); c = cosf(a); }
+#endif
+// MapToMinusPiToPi (minitaur.py:67-83)
+ETG_HD float wrap_pi_(float a) {
+  const float two_pi = 6.283185307179586f, pi = 3.141592653589793f;
+  a = fmodf(a, two_pi);
+  if (a >= pi) a -= two_pi;
+  else if (a < -pi) a += two_pi;
+  return a;
+}
+
+// ---- derived per-lane parameters (shared by the set_params kernel and the test emulator)
+// dyn: one 48-float dynamic_param row (train.py:112-126 layout), leg in 0..3.
+// I' = S I S with S = diag(sqrt(ratio)) for the per-axis inertia ratios.
+struct ModelF {  // float copy of EtgRobotModel
+  float trunk_m, trunk_I[6];
+  float link_m[4][4], link_com[4][4][3], link_I[4][4][6];  // [leg][hip,thigh,calf,foot]
+  float hip_origin[4][3], thigh_y[4];
+  float lower_len;
+  float pose[12], base_foot[12], emean[12], estd[12];
+};
+
+ETG_HD void scale_inertia(const float* I, const float* r, float* o) {
+  float s0 = sqrtf(r[0]), s1 = sqrtf(r[1]), s2 = sqrtf(r[2]);
+  o[0] = I[0] * s0 * s0; o[1] = I[1] * s1 * s1; o[2] = I[2] * s2 * s2;
+  o[3] = I[3] * s0 * s1; o[4] = I[4] * s0 * s2; o[5] = I[5] * s1 * s2;
+}
+
+ETG_HD void derive_lane_params(const ModelF& M, const float* dyn, int leg, float sim_dt, float* out /*PR_N*/) {
+  int k = 0;
+  // hip, thigh
+  for (int i = 0; i < 2; i++) {
+    float I[6];
+    scale_inertia(M.link_I[leg][i], dyn + 9 + 3 * i, I);
+    out[k++] = M.link_m[leg][i] * dyn[6 + i];
+    for (int a = 0; a < 3; a++) out[k++] = M.link_com[leg][i][a];
+    for (int a = 0; a < 6; a++) out[k++] = I[a];
+  }
+  {  // calf + rigidly attached foot at (0,0,-lower_len)  (fixed toe joint, a1.py:99)
+    float Ic[6], If[6];
+    scale_inertia(M.link_I[leg][2], dyn + 15, Ic);
+    scale_inertia(M.link_I[leg][3], dyn + 18, If);
+    float mc = M.link_m[leg][2] * dyn[8], mf = M.link_m[leg][3];
+    const float* cc = M.link_com[leg][2];
+    float cf[3] = {M.link_com[leg][3][0], M.link_com[leg][3][1], M.link_com[leg][3][2] - M.lower_len};
+    float m = mc + mf;
+    float c[3] = {(mc * cc[0] + mf * cf[0]) / m, (mc * cc[1] + mf * cf[1]) / m, (mc * cc[2] + mf * cf[2]) / m};
+    float I[6] = {0, 0, 0, 0, 0, 0};
+    const float* srcI[2] = {Ic, If};
+    const float* srcc[2] = {cc, cf};
+    float srcm[2] = {mc, mf};
+    for (int b = 0; b < 2; b++) {
+      float d[3] = {srcc[b][0] - c[0], srcc[b][1] - c[1], srcc[b][2] - c[2]};
+      I[0] += srcI[b][0] + srcm[b] * (d[1] * d[1] + d[2] * d[2]);
+      I[1] += srcI[b][1] + srcm[b] * (d[0] * d[0] + d[2] * d[2]);
+      I[2] += srcI[b][2] + srcm[b] * (d[0] * d[0] + d[1] * d[1]);
+      I[3] += srcI[b][3] - srcm[b] * d[0] * d[1];
+      I[4] += srcI[b][4] - srcm[b] * d[0] * d[2];
+      I[5] += srcI[b][5] - srcm[b] * d[1] * d[2];
+    }
+    out[k++] = m;
+    for (int a = 0; a < 3; a++) out[k++] = c[a];
+    for (int a = 0; a < 6; a++) out[k++] = I[a];
+  }
+  for (int a = 0; a < 3; a++) out[k++] = M.hip_origin[leg][a];
+  out[k++] = M.thigh_y[leg];
+  for (int j = 0; j < 3; j++) out[k++] = dyn[21 + 3 * leg + j];  // kp
+  for (int j = 0; j < 3; j++) out[k++] = dyn[33 + 3 * leg + j];  // kd
+  out[k++] = dyn[1];                                            // foot friction
+  out[k++] = M.trunk_m * dyn[2];
+  {
+    float I[6];
+    scale_inertia(M.trunk_I, dyn + 3, I);
+    for (int a = 0; a < 6; a++) out[k++] = I[a];
+  }
+  for (int a = 0; a < 3; a++) out[k++] = dyn[45 + a];  // gravity
+  {  // control latency (ms) -> n_steps_ago, blend_alpha (minitaur.py:1185-1188)
+    float lat = dyn[0] * 0.001f;
+    if (lat <= 0.0f) {
+      out[k++] = -1.0f; out[k++] = 0.0f;
+    } else {
+      int n = (int)(lat / sim_dt);
+      if (n > RING - 2) n = RING - 2;
+      out[k++] = (float)n;
+      out[k++] = (lat - (float)n * sim_dt) / sim_dt;
+    }
+  }
+  for (int a = 0; a < 3; a++) out[k++] = M.base_foot[3 * leg + a];
+  for (int a = 0; a < 3; a++) out[k++] = M.pose[3 * leg + a];
+  for (int a = 0; a < 3; a++) out[k++] = M.emean[3 * leg + a];
+  for (int a = 0; a < 3; a++) out[k++] = M.estd[3 * leg + a];
+  out[k++] = (leg & 1) ? 1.0f : -1.0f;  // (-1)**(leg+1), a1.py:485
+}
+
+// host helpers: EtgConfig/EtgRobotModel (double) -> kernel blocks (float)
+inline KCfg make_kcfg(const EtgConfig& c, const EtgRobotModel& m) {
+  KCfg K;
+  K.n_env = c.num_envs;
+  K.action_repeat = c.action_repeat; K.settle_ticks = c.settle_ticks; K.iters = c.solver_iters;
+  K.enable_interp = c.enable_action_interp; K.enable_filter = c.enable_action_filter;
+  K.obs_normal = c.obs_normal; K.terrain = c.terrain;
+  K.dt = (float)c.sim_dt; K.erp = (float)c.erp; K.margin = (float)c.contact_margin;
+  K.warmstart = (float)c.warmstart; K.torque_limit = (float)c.torque_limit;
+  K.upper_len = (float)m.upper_len; K.lower_len = (float)m.lower_len; K.foot_radius = (float)m.foot_radius;
+  for (int k = 0; k < 3; k++) K.init_pos[k] = (float)m.init_pos[k];
+  K.etg_T = (float)c.etg_T; K.etg_T2 = (float)c.etg_T2; K.etg_amp = (float)c.etg_amp;
+  K.etg_sigma_sq = (float)c.etg_sigma_sq; K.etg_phase0 = (float)c.etg_phase[0]; K.etg_phase1 = (float)c.etg_phase[1];
+  const double omega = 2.0 * M_PI / c.etg_T;
+  K.etg_omega = (float)omega; K.etg_dt = (float)c.etg_dt;
+  for (int h = 0; h < ETG_RBF_H; h++) {
+    double t = h * c.etg_T / (ETG_RBF_H - 0.9);
+    K.etg_u[h][0] = (float)(c.etg_amp * sin(c.etg_phase[0] + t * omega));
+    K.etg_u[h][1] = (float)(c.etg_amp * sin(c.etg_phase[1] + t * omega));
+  }
+  for (int k = 0; k < 8; k++) K.rw[k] = (float)c.reward_w[k];
+  K.reward_p = (float)c.reward_p; K.vel_d = (float)c.vel_d;
+  for (int k = 0; k < 3; k++) { K.fb[k] = (float)c.filter_b[k]; K.fa[k] = (float)c.filter_a[k]; }
+  K.hf_nx = c.hf_nx; K.hf_ny = c.hf_ny;
+  K.hf_cell = (float)c.hf_cell; K.hf_x0 = (float)c.hf_x0; K.hf_y0 = (float)c.hf_y0;
+  K.hf = nullptr;
+  return K;
+}
+
+inline ModelF make_modelf(const EtgRobotModel& m) {
+  ModelF M;
+  M.trunk_m = (float)m.trunk.mass;
+  for (int a = 0; a < 6; a++) M.trunk_I[a] = (float)m.trunk.inertia[a];
+  for (int l = 0; l < 4; l++) {
+    const EtgLink* links[4] = {&m.hip[l], &m.thigh[l], &m.calf[l], &m.foot[l]};
+    for (int i = 0; i < 4; i++) {
+      M.link_m[l][i] = (float)links[i]->mass;
+      for (int a = 0; a < 3; a++) M.link_com[l][i][a] = (float)links[i]->com[a];
+      for (int a = 0; a < 6; a++) M.link_I[l][i][a] = (float)links[i]->inertia[a];
+    }
+    for (int a = 0; a < 3; a++) M.hip_origin[l][a] = (float)m.hip_origin[l][a];
+    M.thigh_y[l] = (float)m.thigh_y[l];
+  }
+  M.lower_len = (float)m.lower_len;
+  for (int j = 0; j < 12; j++) {
+    M.pose[j] = (float)m.pose_ori[j]; M.base_foot[j] = (float)m.base_foot[j];
+    M.emean[j] = (float)m.etg_mean[j]; M.estd[j] = (float)m.etg_std[j];
+  }
+  return M;
+}
+
+// bilinear heightfield query shared by both builds (clamped at the border)
+ETG_HD void heightfield_query(const KCfg& K, float x, float y, float& h, float& nx, float& ny, float& nz) {
+  float fx = (x - K.hf_x0) / K.hf_cell, fy = (y - K.hf_y0) / K.hf_cell;
+  fx = fminf(fmaxf(fx, 0.0f), (float)(K.hf_nx - 1));
+  fy = fminf(fmaxf(fy, 0.0f), (float)(K.hf_ny - 1));
+  int ix = (int)fx, iy = (int)fy;
+  if (ix > K.hf_nx - 2) ix = K.hf_nx - 2;
+  if (iy > K.hf_ny - 2) iy = K.hf_ny - 2;
+  float tx = fx - (float)ix, ty = fy - (float)iy;
+  float h00 = K.hf[iy * K.hf_nx + ix], h10 = K.hf[iy * K.hf_nx + ix + 1];
+  float h01 = K.hf[(iy + 1) * K.hf_nx + ix], h11 = K.hf[(iy + 1) * K.hf_nx + ix + 1];
+  h = (1 - tx) * (1 - ty) * h00 + tx * (1 - ty) * h10 + (1 - tx) * ty * h01 + tx * ty * h11;
+  float dhdx = ((1 - ty) * (h10 - h00) + ty * (h11 - h01)) / K.hf_cell;
+  float dhdy = ((1 - tx) * (h01 - h00) + tx * (h11 - h10)) / K.hf_cell;
+  float inv = 1.0f / sqrtf(dhdx * dhdx + dhdy * dhdy + 1.0f);
+  nx = -dhdx * inv; ny = -dhdy * inv; nz = inv;
+}
+
+}  // namespace etg

@@ -1,0 +1,88 @@
+"""ctypes wrapper of the TEST-ONLY host emulation of the HIP kernels (etg_emu.cpp)."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from paddlerobotics_amd import a1_model as A
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        so = os.path.join(_HERE, "libetg_emu.so")
+        srcs = [os.path.join(_HERE, "etg_emu.cpp")] + [
+            os.path.join(_HERE, "..", "..", "paddlerobotics_amd", "csrc", f) for f in ("etg_core.h", "etg_layout.h")]
+        if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
+                                   "-o", so, srcs[0]])
+        _LIB = C.CDLL(so)
+        _LIB.emu_create.restype = C.c_void_p
+    return _LIB
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+class EmuSim:
+    def __init__(self, cfg, model=None):
+        self.cfg, self.model = cfg, model if model is not None else A.default_model()
+        self.N = cfg.num_envs
+        self._l = lib()
+        self._h = C.c_void_p(self._l.emu_create(C.byref(cfg), C.byref(self.model)))
+        self.set_params(dyn=np.tile(A.default_dynamic_row(), (self.N, 1)), etg_w=np.zeros((3, 20)), etg_b=np.zeros(3))
+
+    def __del__(self):
+        try:
+            self._l.emu_destroy(self._h)
+        except Exception:
+            pass
+
+    def set_params(self, dyn=None, etg_w=None, etg_b=None, mask=None):
+        per_env = 0
+        f = lambda a: None if a is None else np.ascontiguousarray(a, dtype=np.float32)
+        dyn, etg_w, etg_b = f(dyn), f(etg_w), f(etg_b)
+        if etg_w is not None:
+            per_env = int(etg_w.ndim == 3)
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        self._l.emu_set_params(self._h, _p(dyn), _p(etg_w), _p(etg_b), per_env, _p(mask))
+
+    def set_heightfield(self, h):
+        self._hf = np.ascontiguousarray(h, dtype=np.float32)
+        self._l.emu_set_heightfield(self._h, _p(self._hf))
+
+    def reset(self, mask=None):
+        obs = np.zeros((self.N, A.OBS_DIM), dtype=np.float32)
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        self._l.emu_reset(self._h, _p(mask), _p(obs))
+        return obs
+
+    def step(self, action, donef=None):
+        action = np.ascontiguousarray(action, dtype=np.float32)
+        obs = np.zeros((self.N, A.OBS_DIM), dtype=np.float32)
+        rew = np.zeros(self.N, dtype=np.float32)
+        done = np.zeros(self.N, dtype=np.uint8)
+        info = np.zeros((self.N, A.INFO_DIM), dtype=np.float32)
+        if donef is not None:
+            donef = np.ascontiguousarray(donef, dtype=np.uint8)
+        self._l.emu_step(self._h, _p(action), _p(donef), _p(obs), _p(rew), _p(done), _p(info))
+        return obs, rew, done, info
+
+    def get_state(self):
+        st = np.zeros((self.N, A.STATE_DIM), dtype=np.float32)
+        self._l.emu_get_state(self._h, _p(st))
+        return st
+
+    def set_state(self, st):
+        st = np.ascontiguousarray(st, dtype=np.float32)
+        self._l.emu_set_state(self._h, _p(st))
+
+    def replication_check(self, env=0, nticks=50):
+        return self._l.emu_tick_replication_check(self._h, int(env), int(nticks))
