@@ -1,0 +1,185 @@
+#!/usr/bin/env python
+"""bench.py -- env-steps/sec of the batched A1 simulator (BASELINE.json metric).
+
+A "step" is one env.step() of the whole batch: one 0.026 s control step = 13 physics ticks
+for every robot on the rank's GPU.  Workload at N=1 GPU: BASELINE.json configs[1]
+("4096 parallel A1, flat terrain, ETG open-loop (no policy net), 1 MI355X"); --config 3 adds
+the residual MLP policy (configs[2]).  With --gpus N the driver launches one rank per GPU;
+robots shard embarrassingly (4096 per rank, weak scaling) and the only collective is one
+all_gather of the episode returns after the timed rollout (configs[3]).
+
+Rank 0 prints ONE JSON line (see the contract in the task description); `roofline` is the
+dynamics kernel against the HBM roofline, `cpu_baseline` the oracle timed on host cores.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from paddlerobotics_amd import a1_model as A  # noqa: E402
+from paddlerobotics_amd.etg import ETG_layer, Opt_with_points  # noqa: E402
+from paddlerobotics_amd.etg_fit import opt_with_points_batched  # noqa: E402
+
+HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
+BYTES_PER_STEP_CFG2 = 816  # 564 B + 252 B per-env ETG w,b
+BYTES_PER_STEP_CFG3 = 808 + 252
+
+
+def etg_population(n, seed, device):
+    """BASELINE config 2: per-env ETG control points = prior + N(0, 0.02^2) (SimpleGA first ask)."""
+    layer = ETG_layer(0.5, 0.026, 20, 0.04, np.array([-np.pi / 2, 0]), 0.2, 0.5)
+    w0, b0, prior = Opt_with_points(layer, ETG_T=0.5, Footheight=0.1, Steplength=0.05)
+    rng = np.random.default_rng(seed)
+    pts = prior[None] + 0.02 * rng.normal(size=(n, 6, 2))
+    w, b = opt_with_points_batched(layer, 0.5, pts, b0, w0, device=device)
+    return w.float(), b.float()
+
+
+def cpu_baseline(n_envs, steps, threads):
+    """The CPU oracle (port of the path, fp64 like stock pybullet) on a bounded sample."""
+    from oracle.oracle import OracleSim
+    cfg = A.default_config(n_envs, solver_iters=4)
+    sim = OracleSim(cfg, threads=threads)
+    w, b = etg_population(n_envs, 0, "cpu")
+    sim.set_params(etg_w=w.double().numpy(), etg_b=b.double().numpy())
+    sim.reset()
+    act = np.zeros((n_envs, 12))
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        sim.step(act, want_info=False)
+    dt = time.perf_counter() - t0
+    return n_envs * steps / dt
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--num-envs", type=int, default=4096, help="robots per GPU")
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3))
+    ap.add_argument("--precision", type=int, default=0, help="policy MFMA: 0 fp32, 1 bf16")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the simulator has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from paddlerobotics_amd.env import make_env
+    from paddlerobotics_amd.policy import MfmaPolicy
+    N = args.num_envs
+    env = make_env("Quadrupedal", num_envs=N, device=str(dev), solver_iters=4)
+    w, b = etg_population(N, seed=rank, device=dev)
+    env.reset(ETG_w=w, ETG_b=b)
+    policy = None
+    act = None
+    if args.config == 3:
+        policy = MfmaPolicy(A.OBS_DIM, 12, device=str(dev))
+        policy.load_state_dict(MfmaPolicy.init_like_reference(A.OBS_DIM, 12, seed=0))
+        act = torch.zeros(N, 12, device=dev)
+
+    ret = torch.zeros(N, device=dev)
+    alive = torch.ones(N, device=dev)
+
+    def one_step():
+        if policy is not None:
+            policy.predict(env.obs, 0.3, args.precision, out=act)   # act_bound 0.3, train.py:488
+            _, r, d, _ = env.step(act, want_info=False)
+        else:
+            _, r, d, _ = env.step(None, want_info=False)
+        ret.add_(alive * r)
+        alive.mul_((~d).float())
+
+    for _ in range(args.warmup):
+        one_step()
+    # per-launch duration of the dynamics kernel, HIP events on the launch stream
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def barrier():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        if policy is not None:
+            policy.predict(env.obs, 0.3, args.precision, out=act)
+            ev[k][0].record()
+            _, r, d, _ = env.step(act, want_info=False)
+            ev[k][1].record()
+        else:
+            ev[k][0].record()
+            _, r, d, _ = env.step(None, want_info=False)
+            ev[k][1].record()
+        ret.add_(alive * r)
+        alive.mul_((~d).float())
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        # the one exchange of the path: gather episode returns (configs[3]; cf. the scatter/gather of
+        # model/Dynamic_parallel_model.py:157-160)
+        allret = torch.empty(world * N, device=dev)
+        dist.all_gather_into_tensor(allret, ret)
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    kern_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in ev]))
+
+    if rank == 0:
+        total_steps = world * N * args.steps
+        value = total_steps / elapsed
+        bytes_per = BYTES_PER_STEP_CFG2 if args.config == 2 else BYTES_PER_STEP_CFG3
+        achieved = bytes_per * N / (kern_ms * 1e-3)
+        out = {
+            "metric": "env-steps/sec, 4096 A1 quadrupeds; 1/2/4/8-GPU scaling",
+            "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("configs[1]: %d parallel A1 per GPU, flat terrain, ETG open-loop, per-env ETG "
+                                    "params = prior + N(0,0.02^2)" % N) if args.config == 2 else
+                       ("configs[2]: %d parallel A1 per GPU, flat, ETG + residual MLP policy (random init, "
+                        "precision %d)" % (N, args.precision)),
+                       "robots_per_gpu": N, "action_repeat": 13, "sim_dt": 0.002, "solver_iters": 4,
+                       "parallelism": "env-shard x%d" % world},
+            "roofline": {"bound": "hbm", "kernel": "etg::k_step", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": bytes_per,
+                         "note": "VALU-bound by construction (~1e3 FLOP/B, SURVEY 8d); see DESIGN.md"},
+            "survivors": float(alive.mean().item()),
+        }
+        if not args.no_cpu_baseline:
+            cores = os.cpu_count() or 1
+            one = cpu_baseline(64, 60, 1)
+            allc = cpu_baseline(max(64, 16 * cores), 40, cores)
+            out["cpu_baseline"] = {"value": allc, "unit": "env-steps/s", "cores": cores, "kind": "port",
+                                   "sample": "oracle/etgsim_oracle.cpp fp64, %d envs x 40 steps on %d threads; "
+                                             "single-thread: %.0f env-steps/s (64 envs x 60 steps)" %
+                                             (max(64, 16 * cores), cores, one),
+                                   "single_thread": one}
+        print(json.dumps(out))
+    env.close()
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

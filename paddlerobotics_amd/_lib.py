@@ -1,0 +1,62 @@
+"""ctypes binding of the C-ABI in include/etgsim.h (paddlerobotics_amd/csrc/libetgsim.so).
+
+There is no CPU fallback: if the library is missing this module raises, and if no HIP
+device is visible etg_create() fails with ETG_ERR_NO_DEVICE.
+"""
+import ctypes as C
+import os
+
+from . import build as _build
+
+_LIB = None
+
+SYMBOLS = [
+    "etg_create", "etg_destroy", "etg_last_error", "etg_version", "etg_set_params",
+    "etg_set_heightfield", "etg_reset", "etg_step", "etg_rollout_openloop", "etg_get_state",
+    "etg_set_state", "etg_policy_create", "etg_policy_load", "etg_policy_forward",
+    "etg_policy_destroy",
+]
+
+
+class EtgError(RuntimeError):
+    pass
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load():
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = lib_path()
+    if not os.path.exists(path):
+        raise EtgError(
+            "paddlerobotics_amd: %s is missing -- build it with `python -m paddlerobotics_amd.build` "
+            "(hipcc --offload-arch=gfx950). There is no CPU fallback." % path)
+    lib = C.CDLL(path)
+    lib.etg_last_error.restype = C.c_char_p
+    vp, i32 = C.c_void_p, C.c_int
+    lib.etg_create.argtypes = [vp, vp, i32, C.POINTER(vp)]
+    lib.etg_destroy.argtypes = [vp]
+    lib.etg_destroy.restype = None
+    lib.etg_set_params.argtypes = [vp, vp, vp, vp, i32, vp, vp]
+    lib.etg_set_heightfield.argtypes = [vp, vp, vp]
+    lib.etg_reset.argtypes = [vp, vp, vp, vp]
+    lib.etg_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.etg_rollout_openloop.argtypes = [vp, i32, vp, vp, vp, vp]
+    lib.etg_get_state.argtypes = [vp, vp, vp]
+    lib.etg_set_state.argtypes = [vp, vp, vp]
+    lib.etg_policy_create.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
+    lib.etg_policy_load.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.etg_policy_forward.argtypes = [vp, vp, i32, C.c_float, i32, vp, vp]
+    lib.etg_policy_destroy.argtypes = [vp]
+    lib.etg_policy_destroy.restype = None
+    _LIB = lib
+    return lib
+
+
+def check(code):
+    if code != 0:
+        raise EtgError("etgsim error %d: %s" % (code, load().etg_last_error().decode()))

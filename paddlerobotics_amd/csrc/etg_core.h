@@ -86,21 +86,13 @@ template <class F> ETG_HD RBI<F> link_inertia(F m, V3<F> com, S3<F> Ic, const Fr
 }
 
 // ------------------------------------------------------------------ per-lane parameters / state
-template <class F> struct LaneParams {
-  F m[3];
-  V3<F> com[3];
-  S3<F> Ic[3];
-  V3<F> o1;       // hip joint origin in the base frame (a1.py:71-73 HIP_OFFSETS)
-  F sy;           // signed thigh offset (+-0.08505, a1.py:100)
-  F kp[3], kd[3]; // laikago_motor.py:165-173
-  F mu;
-  F m0;
-  S3<F> I0;
-  V3<F> g;        // gravity, world
-  F lat_n, lat_alpha;  // minitaur.py:1185-1188: n_steps_ago, blend_alpha
-  V3<F> base_foot, pose, emean, estd;
-  F hipsign;
-};
+// Per-lane parameters are NOT held in registers: the context serves them from a
+// lane-private LDS column (GPU) / the par array (emulator) at the point of use:
+//   c.par(k) with k one of the PR_* field indices of etg_layout.h.
+template <class F, class Ctx> ETG_HD V3<F> par3(const Ctx& c, int k) { return {c.par(k), c.par(k + 1), c.par(k + 2)}; }
+template <class F, class Ctx> ETG_HD S3<F> par_s3(const Ctx& c, int k) {
+  return {c.par(k), c.par(k + 1), c.par(k + 2), c.par(k + 3), c.par(k + 4), c.par(k + 5)};
+}
 
 template <class F> struct LaneState {
   V3<F> p;            // base origin, world
@@ -110,33 +102,6 @@ template <class F> struct LaneState {
   F contact;          // 1 if this lane's foot carried load in the last tick
   F energy;           // sum |tau qd| dt of this lane's joints since the step began
 };
-
-template <class F, class Ctx> ETG_HD LaneParams<F> load_params(const Ctx& c, const float* par) {
-  LaneParams<F> P;
-  int k = 0;
-  for (int i = 0; i < 3; i++) {
-    P.m[i] = c.ld_lane(par, k++);
-    P.com[i].x = c.ld_lane(par, k++); P.com[i].y = c.ld_lane(par, k++); P.com[i].z = c.ld_lane(par, k++);
-    P.Ic[i].xx = c.ld_lane(par, k++); P.Ic[i].yy = c.ld_lane(par, k++); P.Ic[i].zz = c.ld_lane(par, k++);
-    P.Ic[i].xy = c.ld_lane(par, k++); P.Ic[i].xz = c.ld_lane(par, k++); P.Ic[i].yz = c.ld_lane(par, k++);
-  }
-  P.o1.x = c.ld_lane(par, k++); P.o1.y = c.ld_lane(par, k++); P.o1.z = c.ld_lane(par, k++);
-  P.sy = c.ld_lane(par, k++);
-  for (int i = 0; i < 3; i++) P.kp[i] = c.ld_lane(par, k++);
-  for (int i = 0; i < 3; i++) P.kd[i] = c.ld_lane(par, k++);
-  P.mu = c.ld_lane(par, k++);
-  P.m0 = c.ld_lane(par, k++);
-  P.I0.xx = c.ld_lane(par, k++); P.I0.yy = c.ld_lane(par, k++); P.I0.zz = c.ld_lane(par, k++);
-  P.I0.xy = c.ld_lane(par, k++); P.I0.xz = c.ld_lane(par, k++); P.I0.yz = c.ld_lane(par, k++);
-  P.g.x = c.ld_lane(par, k++); P.g.y = c.ld_lane(par, k++); P.g.z = c.ld_lane(par, k++);
-  P.lat_n = c.ld_lane(par, k++); P.lat_alpha = c.ld_lane(par, k++);
-  P.base_foot.x = c.ld_lane(par, k++); P.base_foot.y = c.ld_lane(par, k++); P.base_foot.z = c.ld_lane(par, k++);
-  P.pose.x = c.ld_lane(par, k++); P.pose.y = c.ld_lane(par, k++); P.pose.z = c.ld_lane(par, k++);
-  P.emean.x = c.ld_lane(par, k++); P.emean.y = c.ld_lane(par, k++); P.emean.z = c.ld_lane(par, k++);
-  P.estd.x = c.ld_lane(par, k++); P.estd.y = c.ld_lane(par, k++); P.estd.z = c.ld_lane(par, k++);
-  P.hipsign = c.ld_lane(par, k++);
-  return P;
-}
 
 template <class F, class Ctx> ETG_HD LaneState<F> load_state(const Ctx& c, const float* base, const float* leg) {
   LaneState<F> L;
@@ -212,7 +177,7 @@ template <class F> ETG_HD void bwd6(const F* L, F* b) {  // b <- L^-T b
 // ------------------------------------------------------------------ one physics tick
 // stepSimulation() + ApplyAction + ReceiveObservation of minitaur.py:242-246 for one quad.
 template <class F, class Ctx>
-ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const LaneParams<F>& P, LaneState<F>& L, const F* qdes) {
+ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* qdes) {
   typedef V3<F> V;
   typedef SV<F> W;
   const F dt(K.dt), zero(0.0f), one(1.0f);
@@ -221,7 +186,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const LaneParams<F>& P, La
   F tau[3];
 #pragma unroll
   for (int j = 0; j < 3; j++) {
-    F t = -(P.kp[j] * (L.q[j] - qdes[j])) - P.kd[j] * L.qd[j];
+    F t = -(c.par(PR_KP + j) * (L.q[j] - qdes[j])) - c.par(PR_KD + j) * L.qd[j];
     if (K.torque_limit > 0.0f) t = fminf_(fmaxf_(t, F(-K.torque_limit)), F(K.torque_limit));
     tau[j] = t;
   }
@@ -236,22 +201,24 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const LaneParams<F>& P, La
   Fr<F> R3 = {{chk, sa * shk, -(ca * shk)}, {zero, ca, sa}, {shk, -(sa * chk), ca * chk}};
   V yax = {zero, ca, sa};
   V xax = {one, zero, zero};
-  V o1 = P.o1;
-  V o2 = o1 + P.sy * yax;
+  V o1 = par3<F>(c, PR_O1);
+  V o2 = o1 + c.par(PR_SY) * yax;
   V o3 = o2 - F(K.upper_len) * R2.ez;
   V pf = o3 - F(K.lower_len) * R3.ez;
 
-  RBI<F> I1 = link_inertia(P.m[0], P.com[0], P.Ic[0], R1, o1);
-  RBI<F> I2 = link_inertia(P.m[1], P.com[1], P.Ic[1], R2, o2);
-  RBI<F> I3 = link_inertia(P.m[2], P.com[2], P.Ic[2], R3, o3);
+  RBI<F> I1 = link_inertia(c.par(PR_LINK), par3<F>(c, PR_LINK + 1), par_s3<F>(c, PR_LINK + 4), R1, o1);
+  RBI<F> I2 = link_inertia(c.par(PR_LINK + 10), par3<F>(c, PR_LINK + 11), par_s3<F>(c, PR_LINK + 14), R2, o2);
+  RBI<F> I3 = link_inertia(c.par(PR_LINK + 20), par3<F>(c, PR_LINK + 21), par_s3<F>(c, PR_LINK + 24), R3, o3);
   W S1 = {xax, cross(o1, xax)}, S2 = {yax, cross(o2, yax)}, S3_ = {yax, cross(o3, yax)};
 
+  c.phase();
   // ---- velocities, bias accelerations (qdd = 0, a_base = -g), bias forces (RNEA)
   Rows<F> Rw = quat_rows(L.qx, L.qy, L.qz, L.qw);
   V gb;  // R^T g: columns of R are (r0.x, r1.x, r2.x) ...
-  gb.x = Rw.r0.x * P.g.x + Rw.r1.x * P.g.y + Rw.r2.x * P.g.z;
-  gb.y = Rw.r0.y * P.g.x + Rw.r1.y * P.g.y + Rw.r2.y * P.g.z;
-  gb.z = Rw.r0.z * P.g.x + Rw.r1.z * P.g.y + Rw.r2.z * P.g.z;
+  V gw = par3<F>(c, PR_G);
+  gb.x = Rw.r0.x * gw.x + Rw.r1.x * gw.y + Rw.r2.x * gw.z;
+  gb.y = Rw.r0.y * gw.x + Rw.r1.y * gw.y + Rw.r2.y * gw.z;
+  gb.z = Rw.r0.z * gw.x + Rw.r1.z * gw.y + Rw.r2.z * gw.z;
   W V0 = {L.wb, L.vb};
   W V1 = V0 + L.qd[0] * S1;
   W V2 = V1 + L.qd[1] * S2;
@@ -264,9 +231,12 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const LaneParams<F>& P, La
   W f2 = apply(I2, a2) + crf(V2, apply(I2, V2)) + f3;
   W f1 = apply(I1, a1) + crf(V1, apply(I1, V1)) + f2;
   F C1 = dot(S1, f1), C2 = dot(S2, f2), C3 = dot(S3_, f3);
-  RBI<F> I0 = {P.m0, {zero, zero, zero}, P.I0};
+  const F m0 = c.par(PR_M0);
+  const S3<F> I0s = par_s3<F>(c, PR_I0);
+  RBI<F> I0 = {m0, {zero, zero, zero}, I0s};
   W f0 = apply(I0, a0) + crf(V0, apply(I0, V0));
 
+  c.phase();
   // ---- composite inertias, leg block H (3x3), base coupling Fm (6x3) (CRBA)
   RBI<F> Ic2 = I2 + I3;
   RBI<F> Ic1 = I1 + Ic2;
@@ -285,6 +255,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const LaneParams<F>& P, La
   F rl1 = tau[0] - C1, rl2 = tau[1] - C2, rl3 = tau[2] - C3;
   W pb = rl1 * P1 + rl2 * P2 + rl3 * P3;
 
+  c.phase();
   // ---- base Schur complement: S = Mbb - sum_legs P Fm^T, rhs = -(f0 + sum f1) - sum pb
   F s[21];
 #pragma unroll
@@ -294,10 +265,10 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const LaneParams<F>& P, La
       s[i * (i + 1) / 2 + j] =
           c.qsum(comp(P1, i) * comp(F1, j) + comp(P2, i) * comp(F2, j) + comp(P3, i) * comp(F3, j));
   RBI<F> Ib;
-  Ib.m = P.m0 + c.qsum(Ic1.m);
+  Ib.m = m0 + c.qsum(Ic1.m);
   Ib.h = {c.qsum(Ic1.h.x), c.qsum(Ic1.h.y), c.qsum(Ic1.h.z)};
-  Ib.I = {P.I0.xx + c.qsum(Ic1.I.xx), P.I0.yy + c.qsum(Ic1.I.yy), P.I0.zz + c.qsum(Ic1.I.zz),
-          P.I0.xy + c.qsum(Ic1.I.xy), P.I0.xz + c.qsum(Ic1.I.xz), P.I0.yz + c.qsum(Ic1.I.yz)};
+  Ib.I = {I0s.xx + c.qsum(Ic1.I.xx), I0s.yy + c.qsum(Ic1.I.yy), I0s.zz + c.qsum(Ic1.I.zz),
+          I0s.xy + c.qsum(Ic1.I.xy), I0s.xz + c.qsum(Ic1.I.xz), I0s.yz + c.qsum(Ic1.I.yz)};
   // Mbb lower triangle: rows/cols (wx wy wz vx vy vz); [w,w] = I, [v,w] = -[h]x, [v,v] = m
   F mbb[21];
   mbb[0] = Ib.I.xx;
@@ -322,10 +293,12 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const LaneParams<F>& P, La
   F qdd2 = Hi12 * rl1 + Hi22 * rl2 + Hi23 * rl3 - dot(P2, ab);
   F qdd3 = Hi13 * rl1 + Hi23 * rl2 + Hi33 * rl3 - dot(P3, ab);
 
+  c.phase();
   // ---- unconstrained velocity
   V wbs = L.wb + dt * ab.a, vbs = L.vb + dt * ab.l;
   F qds1 = L.qd[0] + dt * qdd1, qds2 = L.qd[1] + dt * qdd2, qds3 = L.qd[2] + dt * qdd3;
 
+  c.phase();
   // ---- foot contact (sphere vs ground)
   V fw = {L.p.x + dot(Rw.r0, pf), L.p.y + dot(Rw.r1, pf), L.p.z + dot(Rw.r2, pf)};
   F hgt, nwx, nwy, nwz;
@@ -368,6 +341,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const LaneParams<F>& P, La
     fwd6(s, g6);
     Z[d] = {{g6[0] * sq[0], g6[1] * sq[1], g6[2] * sq[2]}, {g6[3] * sq[3], g6[4] * sq[4], g6[5] * sq[5]}};
   }
+  c.phase();
   // Delassus blocks A[j] = Z_mine^T Z_j (+ local leg compliance on the own block)
   F A[4][3][3];
 #pragma unroll
@@ -394,6 +368,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const LaneParams<F>& P, La
     for (int e = 0; e < 3; e++)
       Aown[d][e] = sel_(c.lane_is(0), A[0][d][e], sel_(c.lane_is(1), A[1][d][e], sel_(c.lane_is(2), A[2][d][e], A[3][d][e])));
   F iA0 = sel_(act, one / Aown[0][0], zero), iA1 = sel_(act, one / Aown[1][1], zero), iA2 = sel_(act, one / Aown[2][2], zero);
+  c.phase();
   // contact-point velocity under the unconstrained motion
   V vc = vbs + cross(wbs, rc) + qds1 * k1 + qds2 * k2 + qds3 * k3;
   F u0 = actf * dot(dn, vc), u1 = actf * dot(d1, vc), u2 = actf * dot(d2, vc);
@@ -407,7 +382,9 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const LaneParams<F>& P, La
     u1 = u1 + A[j][1][0] * b0 + A[j][1][1] * b1 + A[j][1][2] * b2;
     u2 = u2 + A[j][2][0] * b0 + A[j][2][1] * b1 + A[j][2][2] * b2;
   }
+  c.phase();
   // ---- projected Gauss-Seidel: feet in lane order, rows (n, t1, t2), disc projection
+  const F mu = c.par(PR_MU);
   for (int it = 0; it < K.iters; it++) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -418,7 +395,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const LaneParams<F>& P, La
       F d1l = lt1 - l1;
       F u2p = u2 + Aown[2][0] * dln + Aown[2][1] * d1l;
       F lt2 = l2 - u2p * iA2;
-      F lim = P.mu * ln;
+      F lim = mu * ln;
       F nt2 = lt1 * lt1 + lt2 * lt2;
       auto over = nt2 > lim * lim;
       F sc = sel_(over, lim * rsqrt_(fmaxf_(nt2, F(1e-30f))), one);
@@ -433,6 +410,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const LaneParams<F>& P, La
       u2 = u2 + A[j][2][0] * b0 + A[j][2][1] * b1 + A[j][2][2] * b2;
     }
   }
+  c.phase();
   // ---- apply impulses: base via the Schur factor, leg via H^-1
   W zs = l0 * Z[0] + l1 * Z[1] + l2 * Z[2];
   F db[6] = {c.qsum(zs.a.x) * sq[0], c.qsum(zs.a.y) * sq[1], c.qsum(zs.a.z) * sq[2],
@@ -447,6 +425,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const LaneParams<F>& P, La
   L.lam[0] = l0; L.lam[1] = l1; L.lam[2] = l2;
   L.contact = sel_(act && (l0 > zero), one, zero);
 
+  c.phase();
   // ---- semi-implicit Euler on positions
 #pragma unroll
   for (int j = 0; j < 3; j++) L.q[j] = L.q[j] + dt * L.qd[j];
@@ -481,10 +460,11 @@ template <class F, class Ctx> ETG_HD void ring_push(const Ctx& c, float* ring, i
 }
 template <class F> struct Delayed { F q[3], qd[3]; F qx, qy, qz, qw; V3<F> w; };
 template <class F, class Ctx>
-ETG_HD Delayed<F> ring_read(const Ctx& c, const float* ring, int tick, const LaneParams<F>& P, const LaneState<F>& L) {
+ETG_HD Delayed<F> ring_read(const Ctx& c, const float* ring, int tick) {
   // n_steps_ago / blend_alpha are env-uniform; lat_n < 0 encodes latency <= 0
   F v[8];
-  int n = c.uniform_int(P.lat_n);
+  int n = c.uniform_int(c.par(PR_LAT_N));
+  const F alpha = c.par(PR_LAT_A);
   if (n < 0) {
 #pragma unroll
     for (int k = 0; k < 8; k++) v[k] = c.ld_ring(ring, tick & (RING - 1), k);
@@ -493,7 +473,7 @@ ETG_HD Delayed<F> ring_read(const Ctx& c, const float* ring, int tick, const Lan
 #pragma unroll
     for (int k = 0; k < 8; k++) {
       F a = c.ld_ring(ring, sa, k), b = c.ld_ring(ring, sb, k);
-      v[k] = (F(1.0f) - P.lat_alpha) * a + P.lat_alpha * b;
+      v[k] = (F(1.0f) - alpha) * a + alpha * b;
     }
   }
   Delayed<F> D;
@@ -501,7 +481,6 @@ ETG_HD Delayed<F> ring_read(const Ctx& c, const float* ring, int tick, const Lan
   D.qx = c.qbcast(v[6], 0); D.qy = c.qbcast(v[7], 0);
   D.qz = c.qbcast(v[6], 1); D.qw = c.qbcast(v[7], 1);
   D.w = {c.qbcast(v[6], 2), c.qbcast(v[7], 2), c.qbcast(v[6], 3)};
-  (void)L;
   return D;
 }
 
@@ -523,7 +502,7 @@ template <class F> ETG_HD void leg_ik(V3<F> foot, F sign, F* ang) {
 }
 // joint-space ETG action of this lane's leg at time t (minus pose_ori)
 template <class F, class Ctx>
-ETG_HD void etg_action(const Ctx& c, const KCfg& K, const LaneParams<F>& P, const float* etgp, float t, F* act) {
+ETG_HD void etg_action(const Ctx& c, const KCfg& K, const float* etgp, float t, F* act) {
   // legs 0,3 use r(t), legs 1,2 use r(t + T2*T) (trot)
   F tl = sel_(c.lane_is(0) || c.lane_is(3), F(t), F(t + K.etg_T2 * K.etg_T));
   F x0 = F(K.etg_amp) * sin_(F(K.etg_phase0) + tl * F(K.etg_omega));
@@ -541,13 +520,14 @@ ETG_HD void etg_action(const Ctx& c, const KCfg& K, const LaneParams<F>& P, cons
   }
   // IK with the 0.95 shrink guard against unreachable targets
   F scale(1.0f);
-  F ang[3] = {P.pose.x, P.pose.y, P.pose.z};
+  const V3<F> posev = par3<F>(c, PR_POSE), bfoot = par3<F>(c, PR_BASE_FOOT), o1 = par3<F>(c, PR_O1);
+  const F hipsign = c.par(PR_HIPSIGN);
+  F ang[3] = {posev.x, posev.y, posev.z};
   auto pending = c.lane_is(0) || !c.lane_is(0);  // all-true mask
   for (int it = 0; it < 200; it++) {
-    V3<F> foot = {P.base_foot.x + ax * scale - P.o1.x, P.base_foot.y + ay * scale - P.o1.y,
-                  P.base_foot.z + az * scale - P.o1.z};
+    V3<F> foot = {bfoot.x + ax * scale - o1.x, bfoot.y + ay * scale - o1.y, bfoot.z + az * scale - o1.z};
     F a[3];
-    leg_ik(foot, P.hipsign, a);
+    leg_ik(foot, hipsign, a);
     auto ok = isfinite_(a[0]) && isfinite_(a[1]) && isfinite_(a[2]);
     auto take = pending && ok;
     ang[0] = sel_(take, a[0], ang[0]); ang[1] = sel_(take, a[1], ang[1]); ang[2] = sel_(take, a[2], ang[2]);
@@ -555,7 +535,7 @@ ETG_HD void etg_action(const Ctx& c, const KCfg& K, const LaneParams<F>& P, cons
     scale = scale * F(0.95f);
     if (!c.any(pending)) break;
   }
-  act[0] = ang[0] - P.pose.x; act[1] = ang[1] - P.pose.y; act[2] = ang[2] - P.pose.z;
+  act[0] = ang[0] - posev.x; act[1] = ang[1] - posev.y; act[2] = ang[2] - posev.z;
 }
 
 // roll-pitch-yaw (ZYX) of a quaternion (getEulerFromQuaternion, minitaur.py:620,633)
@@ -578,9 +558,9 @@ template <class F> ETG_HD F c_prec(F v, F t, F m) {
 // ------------------------------------------------------------------ observation (EnvWrapper.py:60-109)
 // sorted keys: BaseDisplacement(3) FootContactSensor(4) IMU(6) MotorAngleAcc(24) + ETG(12) = 49
 template <class F, class Ctx>
-ETG_HD void write_obs(const Ctx& c, const KCfg& K, const LaneParams<F>& P, const LaneState<F>& L, const float* ring,
+ETG_HD void write_obs(const Ctx& c, const KCfg& K, const LaneState<F>& L, const float* ring,
                       int tick, float* ctl, const F* etg, F lbx, F lby, F lbz, bool set_first, float* obs, F* imu) {
-  Delayed<F> D = ring_read(c, ring, tick, P, L);
+  Delayed<F> D = ring_read<F>(c, ring, tick);
   V3<F> rpy = quat_rpy(D.qx, D.qy, D.qz, D.qw);
   F f0, f1, f2;
   if (set_first) {
@@ -601,14 +581,13 @@ ETG_HD void write_obs(const Ctx& c, const KCfg& K, const LaneParams<F>& P, const
     c.st_row_lane(obs, ETG_OBS_DIM, 3, 1, L.contact);
     for (int k = 0; k < 3; k++) c.st_row_env(obs, ETG_OBS_DIM, 7 + k, imu[k] * srpy);
     for (int k = 0; k < 3; k++) c.st_row_env(obs, ETG_OBS_DIM, 10 + k, imu[3 + k] * sdr);
-    F pose[3] = {P.pose.x, P.pose.y, P.pose.z};
-    F em[3] = {P.emean.x, P.emean.y, P.emean.z}, es[3] = {P.estd.x, P.estd.y, P.estd.z};
     for (int j = 0; j < 3; j++) {
+      const F posej = c.par(PR_POSE + j), emj = c.par(PR_EMEAN + j), esj = c.par(PR_ESTD + j);
       // MapToMinusPiToPi (minitaur.py:67-83)
       F a = wrap_pi_(D.q[j]);
-      c.st_row_lane(obs, ETG_OBS_DIM, 13 + j, 3, nrm ? (a - pose[j]) * sq : a);
+      c.st_row_lane(obs, ETG_OBS_DIM, 13 + j, 3, nrm ? (a - posej) * sq : a);
       c.st_row_lane(obs, ETG_OBS_DIM, 25 + j, 3, D.qd[j]);
-      c.st_row_lane(obs, ETG_OBS_DIM, 37 + j, 3, nrm ? (etg[j] - em[j]) / es[j] : etg[j]);
+      c.st_row_lane(obs, ETG_OBS_DIM, 37 + j, 3, nrm ? (etg[j] - emj) / esj : etg[j]);
     }
   }
 }
@@ -616,14 +595,14 @@ ETG_HD void write_obs(const Ctx& c, const KCfg& K, const LaneParams<F>& P, const
 // world x of this lane's foot centre and base-frame foot z / knee height over ground
 template <class F> struct FootKin { F fwx, fbz, knee_h; };
 template <class F, class Ctx>
-ETG_HD FootKin<F> foot_kin(const Ctx& c, const KCfg& K, const LaneParams<F>& P, const LaneState<F>& L) {
+ETG_HD FootKin<F> foot_kin(const Ctx& c, const KCfg& K, const LaneState<F>& L) {
   F sa, ca, sh, ch, shk, chk;
   sincos_(L.q[0], sa, ca);
   sincos_(L.q[1], sh, ch);
   sincos_(L.q[1] + L.q[2], shk, chk);
   F Lu(K.upper_len), Ll(K.lower_len);
   V3<F> yax = {F(0.0f), ca, sa};
-  V3<F> o2 = P.o1 + P.sy * yax;
+  V3<F> o2 = par3<F>(c, PR_O1) + c.par(PR_SY) * yax;
   V3<F> e2 = {sh, -(sa * ch), ca * ch}, e3 = {shk, -(sa * chk), ca * chk};
   V3<F> o3 = o2 - Lu * e2;
   V3<F> pf = o3 - Ll * e3;
@@ -641,7 +620,7 @@ ETG_HD FootKin<F> foot_kin(const Ctx& c, const KCfg& K, const LaneParams<F>& P, 
 // ------------------------------------------------------------------ one control step (env.step)
 // returns reward / done for the quad; obs/info optional.
 template <class F, class Ctx>
-ETG_HD void control_step(const Ctx& c, const KCfg& K, const LaneParams<F>& P, LaneState<F>& L, float* ring, float* ctl,
+ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ring, float* ctl,
                          int* ictl, float* legctl, const float* etgp, const F* action, F donef, float* obs, F& reward, F& done,
                          float* info) {
   int step_count = c.ld_env_i(ictl, IC_STEP);
@@ -649,10 +628,9 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, const LaneParams<F>& P, La
   int has_last = c.ld_env_i(ictl, IC_HAS_LAST);
   // ETG at t = (k+1) dt (fixture convention of gait_action_list_ETG_exp.npy)
   F etg[3], qdes[3];
-  etg_action(c, K, P, etgp, (float)(step_count + 1) * K.etg_dt, etg);
-  F pose[3] = {P.pose.x, P.pose.y, P.pose.z};
+  etg_action(c, K, etgp, (float)(step_count + 1) * K.etg_dt, etg);
 #pragma unroll
-  for (int j = 0; j < 3; j++) qdes[j] = pose[j] + etg[j] + action[j];
+  for (int j = 0; j < 3; j++) qdes[j] = c.par(PR_POSE + j) + etg[j] + action[j];
   if (K.enable_filter) {  // action_filter.py:111-120, order 2
 #pragma unroll
     for (int j = 0; j < 3; j++) {
@@ -676,7 +654,7 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, const LaneParams<F>& P, La
     float lerp = (float)(i + 1) / (float)K.action_repeat;
 #pragma unroll
     for (int j = 0; j < 3; j++) proc[j] = interp ? last[j] + F(lerp) * (qdes[j] - last[j]) : qdes[j];
-    physics_tick(c, K, P, L, proc);
+    physics_tick(c, K, L, proc);
     tick++;
     ring_push(c, ring, tick & (RING - 1), L);
   }
@@ -689,13 +667,13 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, const LaneParams<F>& P, La
   c.ring_fence();
 
   F imu[6];
-  write_obs(c, K, P, L, ring, tick, ctl, etg, lbx, lby, lbz, false, obs, imu);
+  write_obs(c, K, L, ring, tick, ctl, etg, lbx, lby, lbz, false, obs, imu);
 
   // ---- reward / termination (this repo's definitions)
   const float cdt = K.dt * (float)K.action_repeat;
   Rows<F> Rw = quat_rows(L.qx, L.qy, L.qz, L.qw);
   V3<F> rpy = quat_rpy(L.qx, L.qy, L.qz, L.qw);
-  FootKin<F> fk = foot_kin(c, K, P, L);
+  FootKin<F> fk = foot_kin(c, K, L);
   F vx = (L.p.x - lbx) * F(1.0f / cdt);
   F torso = fminf_(vx, F(K.vel_d));
   F up = (F(1.0f) - c_prec(rpy.x, F(0.0f), F(0.5f))) * (F(1.0f) - c_prec(rpy.y, F(0.0f), F(0.5f)));
@@ -743,13 +721,13 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, const LaneParams<F>& P, La
 
 // ------------------------------------------------------------------ reset (minitaur.py:403-445, a1.py:289-349)
 template <class F, class Ctx>
-ETG_HD void reset_quad(const Ctx& c, const KCfg& K, const LaneParams<F>& P, LaneState<F>& L, float* ring, float* ctl,
+ETG_HD void reset_quad(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ring, float* ctl,
                        int* ictl, float* legctl, const float* etgp, float* obs) {
   L.p = {F(K.init_pos[0]), F(K.init_pos[1]), F(K.init_pos[2])};
   L.qx = F(0.0f); L.qy = F(0.0f); L.qz = F(0.0f); L.qw = F(1.0f);
   L.wb = {F(0.0f), F(0.0f), F(0.0f)};
   L.vb = {F(0.0f), F(0.0f), F(0.0f)};
-  F pose[3] = {P.pose.x, P.pose.y, P.pose.z};
+  F pose[3] = {c.par(PR_POSE), c.par(PR_POSE + 1), c.par(PR_POSE + 2)};
   for (int j = 0; j < 3; j++) { L.q[j] = pose[j]; L.qd[j] = F(0.0f); L.lam[j] = F(0.0f); }
   L.contact = F(0.0f);
   L.energy = F(0.0f);
@@ -757,7 +735,7 @@ ETG_HD void reset_quad(const Ctx& c, const KCfg& K, const LaneParams<F>& P, Lane
   for (int sl = 0; sl < RING; sl++) ring_push(c, ring, sl, L);
   int tick = 0;
   for (int i = 0; i < K.settle_ticks; i++) {  // a1.py:294-297
-    physics_tick(c, K, P, L, pose);
+    physics_tick(c, K, L, pose);
     tick++;
     ring_push(c, ring, tick & (RING - 1), L);
   }
@@ -772,11 +750,11 @@ ETG_HD void reset_quad(const Ctx& c, const KCfg& K, const LaneParams<F>& P, Lane
     c.st_lane(legctl, LC_FX0 + j, pose[j]); c.st_lane(legctl, LC_FX1 + j, pose[j]);  // init_history, action_filter.py:122-126
     c.st_lane(legctl, LC_FY0 + j, pose[j]); c.st_lane(legctl, LC_FY1 + j, pose[j]);
   }
-  FootKin<F> fk = foot_kin(c, K, P, L);
+  FootKin<F> fk = foot_kin(c, K, L);
   c.st_lane(legctl, LC_LAST_FOOT_X, fk.fwx);
   F etg[3], imu[6];
-  etg_action(c, K, P, etgp, 0.0f, etg);
-  write_obs(c, K, P, L, ring, tick, ctl, etg, L.p.x, L.p.y, L.p.z, true, obs, imu);
+  etg_action(c, K, etgp, 0.0f, etg);
+  write_obs(c, K, L, ring, tick, ctl, etg, L.p.x, L.p.y, L.p.z, true, obs, imu);
 }
 
 // ------------------------------------------------------------------ state access (parity tests)

@@ -1,0 +1,326 @@
+// etg_kernels.hip -- gfx950 kernels + C-ABI of the batched A1 simulator (include/etgsim.h).
+//
+// One robot = one quad of lanes (etg_core.h).  A workgroup is ONE wave64 = 16 robots:
+// at the headline size (4096 robots) that is 256 workgroups, one per CU, so the launch
+// spreads over all 8 XCDs; nothing is shared between workgroups, so no XCD-aware remap
+// is needed.  All quad reductions/broadcasts are DPP quad_perm moves (no LDS, no
+// ds_bpermute).  State is SoA in HBM (etg_layout.h), so every global access of a wave
+// is one contiguous 256-B segment per field.
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "etg_core.h"
+
+namespace etg {
+
+// ---- DPP quad helpers -------------------------------------------------------------
+template <int CTRL> __device__ __forceinline__ float dpp_(float x) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), CTRL, 0xF, 0xF, false));
+}
+
+struct GpuCtx {
+  int gid, env, lane, N, NL;
+  const float* lds;  // this lane's parameter column in LDS: lds[k * BLOCK]
+  __device__ __forceinline__ float par(int k) const { return lds[k * 64]; }
+  __device__ __forceinline__ float ld_lane(const float* p, int f) const { return p[(size_t)f * NL + gid]; }
+  __device__ __forceinline__ void st_lane(float* p, int f, float v) const { p[(size_t)f * NL + gid] = v; }
+  __device__ __forceinline__ float ld_env(const float* p, int f) const { return p[(size_t)f * N + env]; }
+  __device__ __forceinline__ void st_env(float* p, int f, float v) const { if (lane == 0) p[(size_t)f * N + env] = v; }
+  __device__ __forceinline__ int ld_env_i(const int* p, int f) const { return p[(size_t)f * N + env]; }
+  __device__ __forceinline__ void st_env_i(int* p, int f, int v) const { if (lane == 0) p[(size_t)f * N + env] = v; }
+  __device__ __forceinline__ void st_ring(float* r, int slot, int k, float v) const { r[((size_t)slot * 8 + k) * NL + gid] = v; }
+  __device__ __forceinline__ float ld_ring(const float* r, int slot, int k) const { return r[((size_t)slot * 8 + k) * NL + gid]; }
+  // the ring is written and read back by the SAME lane (program order): no fence needed
+  __device__ __forceinline__ void ring_fence() const {}
+  // phase boundary: keep the machine scheduler from interleaving whole phases of the tick
+  // (it otherwise stretches live ranges to >500 registers and spills)
+  __device__ __forceinline__ void phase() const { __builtin_amdgcn_sched_barrier(0); }
+  __device__ __forceinline__ void st_row_env(float* p, int rowlen, int col, float v) const { if (lane == 0) p[(size_t)env * rowlen + col] = v; }
+  __device__ __forceinline__ void st_row_lane(float* p, int rowlen, int col0, int stride, float v) const { p[(size_t)env * rowlen + col0 + stride * lane] = v; }
+  __device__ __forceinline__ float ld_row_env(const float* p, int rowlen, int col) const { return p[(size_t)env * rowlen + col]; }
+  __device__ __forceinline__ float ld_row_lane(const float* p, int rowlen, int col0, int stride) const { return p[(size_t)env * rowlen + col0 + stride * lane]; }
+  // order-symmetric quad sum: (x0+x1)+(x2+x3) on every lane, bit-identical across the quad
+  __device__ __forceinline__ float qsum(float a) const {
+    float t = a + dpp_<0xB1>(a);  // quad_perm [1,0,3,2]
+    return t + dpp_<0x4E>(t);     // quad_perm [2,3,0,1]
+  }
+  __device__ __forceinline__ float qmax(float a) const {
+    float t = fmaxf(a, dpp_<0xB1>(a));
+    return fmaxf(t, dpp_<0x4E>(t));
+  }
+  __device__ __forceinline__ float qbcast(float a, int j) const {  // j is a constant after unrolling
+    switch (j) {
+      case 0: return dpp_<0x00>(a);
+      case 1: return dpp_<0x55>(a);
+      case 2: return dpp_<0xAA>(a);
+      default: return dpp_<0xFF>(a);
+    }
+  }
+  __device__ __forceinline__ bool lane_is(int j) const { return lane == j; }
+  __device__ __forceinline__ bool any(bool b) const { return __any(b); }
+  __device__ __forceinline__ int uniform_int(float a) const { return (int)a; }
+  __device__ __forceinline__ void terrain(const KCfg& K, float x, float y, float& h, float& nx, float& ny, float& nz) const {
+    if (K.terrain == 0) { h = 0.0f; nx = 0.0f; ny = 0.0f; nz = 1.0f; }
+    else heightfield_query(K, x, y, h, nx, ny, nz);
+  }
+};
+
+__device__ __forceinline__ bool make_ctx(const KCfg& K, GpuCtx& c) {
+  c.gid = blockIdx.x * blockDim.x + threadIdx.x;
+  c.N = K.n_env;
+  c.NL = 4 * K.n_env;
+  c.env = c.gid >> 2;
+  c.lane = c.gid & 3;
+  c.lds = nullptr;
+  return c.gid < c.NL;
+}
+
+constexpr int BLOCK = 64;
+
+// Stage the lane's 66 derived parameters in LDS, [field][lane] (conflict-free: lane i hits
+// bank i).  Each lane reads back only its own column, so no barrier is needed -- the LDS
+// is a software-managed register file extension here, not a sharing medium.
+__device__ __forceinline__ void stage_params(GpuCtx& c, const DevState& D, float* lds_par) {
+#pragma unroll 6
+  for (int k = 0; k < PR_N; k++) lds_par[k * BLOCK + threadIdx.x] = D.par[(size_t)k * c.NL + c.gid];
+  c.lds = lds_par + threadIdx.x;
+}
+
+__global__ void __launch_bounds__(BLOCK) k_set_params(KCfg K, ModelF M, DevState D, const float* dyn, const float* w,
+                                                       const float* b, int per_env, const uint8_t* mask) {
+  GpuCtx c;
+  if (!make_ctx(K, c)) return;
+  if (mask && !mask[c.env]) return;
+  if (dyn) {
+    float row[ETG_DYN_DIM], out[PR_N];
+    for (int k = 0; k < ETG_DYN_DIM; k++) row[k] = dyn[(size_t)c.env * ETG_DYN_DIM + k];
+    derive_lane_params(M, row, c.lane, K.dt, out);
+    for (int k = 0; k < PR_N; k++) D.par[(size_t)k * c.NL + c.gid] = out[k];
+  }
+  // the 63 ETG floats of a robot are copied by its 4 lanes (16 each)
+  for (int k = c.lane; k < 60; k += 4)
+    if (w) D.etgp[(size_t)(EP_W + k) * c.N + c.env] = w[(per_env ? (size_t)c.env * 60 : 0) + k];
+  if (b && c.lane < 3) D.etgp[(size_t)(EP_B + c.lane) * c.N + c.env] = b[(per_env ? (size_t)c.env * 3 : 0) + c.lane];
+}
+
+__global__ void __launch_bounds__(BLOCK) k_reset(KCfg K, DevState D, const uint8_t* mask, float* obs) {
+  GpuCtx c;
+  if (!make_ctx(K, c)) return;
+  if (mask && !mask[c.env]) return;
+  __shared__ float lds_par[PR_N * BLOCK];
+  stage_params(c, D, lds_par);
+  LaneState<float> L;
+  reset_quad(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, obs);
+  store_state(c, D.base, D.leg, L);
+}
+
+__global__ void __launch_bounds__(BLOCK) k_step(KCfg K, DevState D, const float* action, const uint8_t* donef, float* obs,
+                                                 float* reward, uint8_t* done, float* info) {
+  GpuCtx c;
+  if (!make_ctx(K, c)) return;
+  __shared__ float lds_par[PR_N * BLOCK];
+  stage_params(c, D, lds_par);
+  LaneState<float> L = load_state<float>(c, D.base, D.leg);
+  float act[3];
+#pragma unroll
+  for (int j = 0; j < 3; j++) act[j] = action ? c.ld_row_lane(action, ETG_ACT_DIM, j, 3) : 0.0f;
+  float r, d;
+  control_step(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, act, donef ? (float)donef[c.env] : 0.0f, obs, r, d,
+               info);
+  store_state(c, D.base, D.leg, L);
+  if (c.lane == 0) {
+    reward[c.env] = r;
+    done[c.env] = d > 0.5f ? 1 : 0;
+  }
+}
+
+// fused open-loop rollout (pretrain.py:129-154 with action == 0): n_steps control steps in
+// one launch, state resident in registers, return/length accumulated with alive masking.
+__global__ void __launch_bounds__(BLOCK) k_rollout(KCfg K, DevState D, int n_steps, float* obs, float* ret, int* len) {
+  GpuCtx c;
+  if (!make_ctx(K, c)) return;
+  __shared__ float lds_par[PR_N * BLOCK];
+  stage_params(c, D, lds_par);
+  LaneState<float> L = load_state<float>(c, D.base, D.leg);
+  float act[3] = {0.0f, 0.0f, 0.0f};
+  float total = 0.0f, alive = 1.0f;
+  int steps = 0;
+  for (int k = 0; k < n_steps; k++) {
+    float r, d;
+    control_step(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, act, 0.0f, (k == n_steps - 1) ? obs : nullptr, r, d,
+                 nullptr);
+    total += alive * r;
+    steps += alive > 0.5f ? 1 : 0;
+    alive = d > 0.5f ? 0.0f : alive;
+  }
+  store_state(c, D.base, D.leg, L);
+  if (c.lane == 0) {
+    ret[c.env] = total;
+    len[c.env] = steps;
+  }
+}
+
+__global__ void __launch_bounds__(BLOCK) k_get_state(KCfg K, DevState D, float* st) {
+  GpuCtx c;
+  if (!make_ctx(K, c)) return;
+  LaneState<float> L = load_state<float>(c, D.base, D.leg);
+  get_state_quad(c, L, st);
+}
+__global__ void __launch_bounds__(BLOCK) k_set_state(KCfg K, DevState D, const float* st) {
+  GpuCtx c;
+  if (!make_ctx(K, c)) return;
+  LaneState<float> L;
+  set_state_quad(c, st, L, D.ring, D.ctl, D.ictl);
+  store_state(c, D.base, D.leg, L);
+}
+
+}  // namespace etg
+
+// ====================================================================== C ABI
+using namespace etg;
+
+struct EtgHandle {
+  int device;
+  int N;
+  KCfg K;
+  ModelF M;
+  DevState D;
+  float* hf;
+};
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+  g_err = msg;
+  return code;
+}
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess) return fail(ETG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+  } while (0)
+
+extern "C" const char* etg_last_error(void) { return g_err.c_str(); }
+// shared with policy_mlp.hip so that one etg_last_error() serves the whole ABI
+extern "C" void etg_set_last_error_(const char* msg) { g_err = msg ? msg : ""; }
+extern "C" int etg_version(void) { return 1; }
+
+static int grid_for(const EtgHandle* h) { return (4 * h->N + BLOCK - 1) / BLOCK; }
+
+extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int device, EtgHandle** out) {
+  if (!cfg || !model || !out) return fail(ETG_ERR_BAD_ARG, "etg_create: null argument");
+  if (cfg->num_envs <= 0) return fail(ETG_ERR_BAD_ARG, "etg_create: num_envs must be > 0");
+  if (cfg->action_repeat <= 0 || cfg->sim_dt <= 0) return fail(ETG_ERR_BAD_ARG, "etg_create: bad action_repeat/sim_dt");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+    return fail(ETG_ERR_NO_DEVICE, "etg_create: no HIP device (this library has no CPU path)");
+  if (device < 0 || device >= ndev) return fail(ETG_ERR_BAD_ARG, "etg_create: bad device index");
+  HIP_TRY(hipSetDevice(device));
+  EtgHandle* h = new EtgHandle();
+  h->device = device;
+  h->N = cfg->num_envs;
+  h->K = make_kcfg(*cfg, *model);
+  h->M = make_modelf(*model);
+  h->hf = nullptr;
+  size_t N = h->N, NL = 4 * N;
+  struct { void** p; size_t bytes; } allocs[] = {
+      {(void**)&h->D.base, BS_N * N * 4},   {(void**)&h->D.leg, LG_N * NL * 4},   {(void**)&h->D.ctl, CT_N * N * 4},
+      {(void**)&h->D.ictl, IC_N * N * 4},   {(void**)&h->D.legctl, LC_N * NL * 4}, {(void**)&h->D.etgp, EP_N * N * 4},
+      {(void**)&h->D.par, PR_N * NL * 4},   {(void**)&h->D.ring, (size_t)RING * 8 * NL * 4}};
+  for (auto& a : allocs) {
+    if (hipMalloc(a.p, a.bytes) != hipSuccess) return fail(ETG_ERR_ALLOC, "etg_create: hipMalloc failed");
+    HIP_TRY(hipMemset(*a.p, 0, a.bytes));
+  }
+  // default physical parameters = param2dynamic_dict(zeros(48)) (train.py:112-126)
+  std::vector<float> row(ETG_DYN_DIM, 1.0f);
+  row[0] = 40.0f; row[1] = 0.2f; row[2] = 1.5f;
+  for (int j = 0; j < 12; j++) { row[21 + j] = 80.0f; row[33 + j] = (j % 3 == 0) ? 1.0f : 2.0f; }
+  row[45] = 0.0f; row[46] = 0.0f; row[47] = -10.0f;
+  std::vector<float> dyn(N * ETG_DYN_DIM);
+  for (size_t i = 0; i < N; i++) std::copy(row.begin(), row.end(), dyn.begin() + i * ETG_DYN_DIM);
+  float* ddyn = nullptr;
+  if (hipMalloc((void**)&ddyn, dyn.size() * 4) != hipSuccess) return fail(ETG_ERR_ALLOC, "etg_create: hipMalloc failed");
+  HIP_TRY(hipMemcpy(ddyn, dyn.data(), dyn.size() * 4, hipMemcpyHostToDevice));
+  hipLaunchKernelGGL(k_set_params, dim3(grid_for(h)), dim3(BLOCK), 0, 0, h->K, h->M, h->D, ddyn, nullptr, nullptr, 0, nullptr);
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipFree(ddyn));
+  *out = h;
+  return ETG_OK;
+}
+
+extern "C" void etg_destroy(EtgHandle* h) {
+  if (!h) return;
+  (void)hipSetDevice(h->device);
+  void* ptrs[] = {h->D.base, h->D.leg, h->D.ctl, h->D.ictl, h->D.legctl, h->D.etgp, h->D.par, h->D.ring, h->hf};
+  for (void* p : ptrs)
+    if (p) (void)hipFree(p);
+  delete h;
+}
+
+#define CHECK_HANDLE(h)                                         \
+  if (!(h)) return fail(ETG_ERR_BAD_ARG, "null handle");       \
+  HIP_TRY(hipSetDevice((h)->device));
+
+extern "C" int etg_set_params(EtgHandle* h, const float* dyn, const float* etg_w, const float* etg_b, int per_env,
+                              const uint8_t* mask, void* stream) {
+  CHECK_HANDLE(h);
+  if ((etg_w == nullptr) != (etg_b == nullptr)) return fail(ETG_ERR_BAD_ARG, "etg_set_params: pass both etg_w and etg_b or neither");
+  hipLaunchKernelGGL(k_set_params, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->M, h->D, dyn, etg_w,
+                     etg_b, per_env, mask);
+  HIP_TRY(hipGetLastError());
+  return ETG_OK;
+}
+
+extern "C" int etg_set_heightfield(EtgHandle* h, const float* heights, void* stream) {
+  CHECK_HANDLE(h);
+  if (h->K.terrain != 1 || h->K.hf_nx < 2 || h->K.hf_ny < 2) return fail(ETG_ERR_STATE, "etg_set_heightfield: config has no heightfield");
+  size_t bytes = (size_t)h->K.hf_nx * h->K.hf_ny * 4;
+  if (!h->hf && hipMalloc((void**)&h->hf, bytes) != hipSuccess) return fail(ETG_ERR_ALLOC, "etg_set_heightfield: hipMalloc failed");
+  HIP_TRY(hipMemcpyAsync(h->hf, heights, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  h->K.hf = h->hf;
+  return ETG_OK;
+}
+
+extern "C" int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* stream) {
+  CHECK_HANDLE(h);
+  if (!obs) return fail(ETG_ERR_BAD_ARG, "etg_reset: obs is null");
+  if (h->K.terrain == 1 && !h->K.hf) return fail(ETG_ERR_STATE, "etg_reset: heightfield not set");
+  hipLaunchKernelGGL(k_reset, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, mask, obs);
+  HIP_TRY(hipGetLastError());
+  return ETG_OK;
+}
+
+extern "C" int etg_step(EtgHandle* h, const float* action, const uint8_t* donef, float* obs, float* reward,
+                        uint8_t* done, float* info, void* stream) {
+  CHECK_HANDLE(h);
+  if (!obs || !reward || !done) return fail(ETG_ERR_BAD_ARG, "etg_step: obs/reward/done must be non-null");
+  hipLaunchKernelGGL(k_step, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, action, donef, obs,
+                     reward, done, info);
+  HIP_TRY(hipGetLastError());
+  return ETG_OK;
+}
+
+extern "C" int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float* ret, int32_t* len, void* stream) {
+  CHECK_HANDLE(h);
+  if (n_steps <= 0 || !ret || !len) return fail(ETG_ERR_BAD_ARG, "etg_rollout_openloop: bad arguments");
+  hipLaunchKernelGGL(k_rollout, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, n_steps, obs, ret, len);
+  HIP_TRY(hipGetLastError());
+  return ETG_OK;
+}
+
+extern "C" int etg_get_state(EtgHandle* h, float* state, void* stream) {
+  CHECK_HANDLE(h);
+  if (!state) return fail(ETG_ERR_BAD_ARG, "etg_get_state: null");
+  hipLaunchKernelGGL(k_get_state, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, state);
+  HIP_TRY(hipGetLastError());
+  return ETG_OK;
+}
+
+extern "C" int etg_set_state(EtgHandle* h, const float* state, void* stream) {
+  CHECK_HANDLE(h);
+  if (!state) return fail(ETG_ERR_BAD_ARG, "etg_set_state: null");
+  hipLaunchKernelGGL(k_set_state, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, state);
+  HIP_TRY(hipGetLastError());
+  return ETG_OK;
+}

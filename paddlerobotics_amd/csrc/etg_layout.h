@@ -33,7 +33,10 @@ enum { CT_FIRST_RPY = 0, CT_LAST_BASE = 3, CT_N = 6 };
 enum { IC_STEP = 0, IC_TICK = 1, IC_HAS_LAST = 2, IC_N = 3 };
 enum { LC_LAST_QDES = 0, LC_FX0 = 3, LC_FX1 = 6, LC_FY0 = 9, LC_FY1 = 12, LC_LAST_FOOT_X = 15, LC_N = 16 };
 enum { EP_W = 0, EP_B = 60, EP_N = 63 };
-constexpr int PR_N = 66;  // fields read by load_params(), in that order
+// per-lane derived parameters, in the order derive_lane_params() writes them
+enum { PR_LINK = 0 /* 3 x (m, com3, Ic6) */, PR_O1 = 30, PR_SY = 33, PR_KP = 34, PR_KD = 37, PR_MU = 40, PR_M0 = 41,
+       PR_I0 = 42, PR_G = 48, PR_LAT_N = 51, PR_LAT_A = 52, PR_BASE_FOOT = 53, PR_POSE = 56, PR_EMEAN = 59,
+       PR_ESTD = 62, PR_HIPSIGN = 65, PR_N = 66 };
 
 struct KCfg {
   int n_env;

@@ -1,0 +1,239 @@
+// policy_mlp.hip -- the residual-policy forward (the one dense contraction of the path):
+//   act = tanh(W3 relu(W2 relu(W1 obs + b1) + b2) + b3) * act_scale
+// reference: model/mujoco_model.py:44-60 (Actor.forward, mean head), alg/sac.py:60-63
+// (predict = tanh(mean)), train.py:320 (act_bound scaling).  Weights keep torch's
+// [out, in] row-major fp32 layout (mujoco_agent.py:61-65 state_dict keys l1/l2/mean_linear).
+//
+// One launch fuses the three layers.  A workgroup (4 waves) owns 16 consecutive robots;
+// its activations (16 x 256 fp32) never leave LDS; the 327 KB of weights are streamed
+// from L2 (they are shared by all workgroups and stay L2/MALL-resident).  At 4096 robots
+// that is 256 workgroups = one per CU.
+//   precision 0: v_mfma_f32_16x16x4_f32  -- exact fp32 (bitwise an fmaf chain)
+//   precision 1: v_mfma_f32_16x16x32_bf16 -- operands rounded to bf16 (RNE) in registers
+// MFMA operand mapping (16x16 tiles, wave64): lane l holds A[i = l&15][k-slot l>>4] and
+// B[k-slot l>>4][j = l&15]; D[row = 4*(l>>4)+r][col = l&15].  The k index a slot covers is
+// free as long as A and B agree, so each lane loads a CONTIGUOUS float4 (fp32 path) or
+// 8 floats (bf16 path) of its row and feeds one component per MFMA.
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/etgsim.h"
+
+namespace {
+
+constexpr int TM = 16;         // robots per workgroup
+constexpr int HID = 256;       // hidden width (Actor: 256)
+constexpr int HS = HID + 4;    // LDS row stride in floats: rotates 16-B slots by one per row
+constexpr int THREADS = 256;
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ float4 load_w4(const float* w, int n, int nmax, int k, int kdim) {
+  // W[n][k..k+3], zero outside [0,nmax) x [0,kdim); rows are only 4-byte aligned (kdim = 49)
+  float4 v = {0.f, 0.f, 0.f, 0.f};
+  if (n < nmax) {
+    const float* p = w + (size_t)n * kdim + k;
+    if (k + 3 < kdim && ((kdim & 3) == 0)) {
+      v = *reinterpret_cast<const float4*>(p);
+    } else {
+      if (k + 0 < kdim) v.x = p[0];
+      if (k + 1 < kdim) v.y = p[1];
+      if (k + 2 < kdim) v.z = p[2];
+      if (k + 3 < kdim) v.w = p[3];
+    }
+  }
+  return v;
+}
+
+__device__ __forceinline__ __bf16 to_bf16(float x) {  // round to nearest even
+  unsigned u = __float_as_uint(x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  unsigned short h = (unsigned short)(u >> 16);
+  return __builtin_bit_cast(__bf16, h);
+}
+
+// out[16][ncols of this wave] = act(in[16][kpad] * W^T + b); W is [nout][kdim]
+template <bool BF16>
+__device__ __forceinline__ void hidden_layer(const float* in, int kpad, const float* w, int kdim, const float* b,
+                                             float* out, int wave, int lane) {
+  const int i = lane & 15, g = lane >> 4;
+  f32x4 acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; t++) acc[t] = {0.f, 0.f, 0.f, 0.f};
+  if (!BF16) {
+    for (int kb = 0; kb < kpad; kb += 16) {
+      const float4 a = *reinterpret_cast<const float4*>(&in[i * HS + kb + 4 * g]);
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const float4 bw = load_w4(w, 64 * wave + 16 * t + i, HID, kb + 4 * g, kdim);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bw.x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bw.y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bw.z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bw.w, acc[t], 0, 0, 0);
+      }
+    }
+  } else {
+    for (int kb = 0; kb < kpad; kb += 32) {  // kpad is a multiple of 32 on this path
+      const float4 a0 = *reinterpret_cast<const float4*>(&in[i * HS + kb + 8 * g]);
+      const float4 a1 = *reinterpret_cast<const float4*>(&in[i * HS + kb + 8 * g + 4]);
+      bf16x8 av = {to_bf16(a0.x), to_bf16(a0.y), to_bf16(a0.z), to_bf16(a0.w),
+                   to_bf16(a1.x), to_bf16(a1.y), to_bf16(a1.z), to_bf16(a1.w)};
+#pragma unroll
+      for (int t = 0; t < 4; t++) {
+        const int n = 64 * wave + 16 * t + i;
+        const float4 b0 = load_w4(w, n, HID, kb + 8 * g, kdim);
+        const float4 b1 = load_w4(w, n, HID, kb + 8 * g + 4, kdim);
+        bf16x8 bv = {to_bf16(b0.x), to_bf16(b0.y), to_bf16(b0.z), to_bf16(b0.w),
+                     to_bf16(b1.x), to_bf16(b1.y), to_bf16(b1.z), to_bf16(b1.w)};
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; t++) {
+    const int col = 64 * wave + 16 * t + i;
+    const float bias = b[col];
+#pragma unroll
+    for (int r = 0; r < 4; r++) out[(4 * g + r) * HS + col] = fmaxf(acc[t][r] + bias, 0.0f);
+  }
+}
+
+template <bool BF16>
+__global__ void __launch_bounds__(THREADS) k_policy(const float* __restrict__ obs, int n, int in_dim,
+                                                    const float* __restrict__ w1, const float* __restrict__ b1,
+                                                    const float* __restrict__ w2, const float* __restrict__ b2,
+                                                    const float* __restrict__ w3, const float* __restrict__ b3,
+                                                    int out_dim, float scale, float* __restrict__ act) {
+  __shared__ __attribute__((aligned(16))) float bufA[TM * HS];
+  __shared__ __attribute__((aligned(16))) float bufB[TM * HS];
+  __shared__ float part[4][TM][16];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int row0 = blockIdx.x * TM;
+  const int kpad1 = BF16 ? ((in_dim + 31) / 32) * 32 : ((in_dim + 15) / 16) * 16;
+  // obs tile -> LDS, zero padded (rows past n, columns past in_dim)
+  for (int idx = tid; idx < TM * 64; idx += THREADS) {
+    const int r = idx >> 6, c = idx & 63;
+    float v = 0.0f;
+    if (c < in_dim && row0 + r < n) v = obs[(size_t)(row0 + r) * in_dim + c];
+    bufA[r * HS + c] = v;
+  }
+  __syncthreads();
+  hidden_layer<BF16>(bufA, kpad1, w1, in_dim, b1, bufB, wave, lane);
+  __syncthreads();
+  hidden_layer<BF16>(bufB, HID, w2, HID, b2, bufA, wave, lane);
+  __syncthreads();
+  // output layer: one 16x16 tile (out_dim <= 16), K split over the 4 waves
+  {
+    const int i = lane & 15, g = lane >> 4;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    const int k0 = 64 * wave;
+    if (!BF16) {
+#pragma unroll
+      for (int kb = 0; kb < 64; kb += 16) {
+        const float4 a = *reinterpret_cast<const float4*>(&bufA[i * HS + k0 + kb + 4 * g]);
+        const float4 bw = load_w4(w3, i, out_dim, k0 + kb + 4 * g, HID);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bw.x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bw.y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bw.z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bw.w, acc, 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int kb = 0; kb < 64; kb += 32) {
+        const float4 a0 = *reinterpret_cast<const float4*>(&bufA[i * HS + k0 + kb + 8 * g]);
+        const float4 a1 = *reinterpret_cast<const float4*>(&bufA[i * HS + k0 + kb + 8 * g + 4]);
+        const float4 b0 = load_w4(w3, i, out_dim, k0 + kb + 8 * g, HID);
+        const float4 b1v = load_w4(w3, i, out_dim, k0 + kb + 8 * g + 4, HID);
+        bf16x8 av = {to_bf16(a0.x), to_bf16(a0.y), to_bf16(a0.z), to_bf16(a0.w),
+                     to_bf16(a1.x), to_bf16(a1.y), to_bf16(a1.z), to_bf16(a1.w)};
+        bf16x8 bv = {to_bf16(b0.x), to_bf16(b0.y), to_bf16(b0.z), to_bf16(b0.w),
+                     to_bf16(b1v.x), to_bf16(b1v.y), to_bf16(b1v.z), to_bf16(b1v.w)};
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc, 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) part[wave][4 * g + r][i] = acc[r];
+  }
+  __syncthreads();
+  {
+    const int r = tid >> 4, cidx = tid & 15;  // 256 threads = 16 rows x 16 cols
+    if (cidx < out_dim && row0 + r < n) {
+      // fixed summation order over the 4 K-slices
+      float v = ((part[0][r][cidx] + part[1][r][cidx]) + (part[2][r][cidx] + part[3][r][cidx])) + b3[cidx];
+      act[(size_t)(row0 + r) * out_dim + cidx] = tanhf(v) * scale;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" void etg_set_last_error_(const char* msg);
+
+struct EtgPolicy {
+  int device, in_dim, hidden, out_dim;
+  float *w1, *b1, *w2, *b2, *w3, *b3;
+};
+
+static int pfail(int code, const char* msg) {
+  etg_set_last_error_(msg);
+  return code;
+}
+
+extern "C" int etg_policy_create(int in_dim, int hidden, int out_dim, int device, EtgPolicy** out) {
+  if (!out || in_dim <= 0 || in_dim > 64 || hidden != HID || out_dim <= 0 || out_dim > 16)
+    return pfail(ETG_ERR_BAD_ARG, "etg_policy_create: need in_dim<=64, hidden==256, out_dim<=16");
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0) return pfail(ETG_ERR_NO_DEVICE, "etg_policy_create: no HIP device");
+  if (device < 0 || device >= ndev) return pfail(ETG_ERR_BAD_ARG, "etg_policy_create: bad device");
+  if (hipSetDevice(device) != hipSuccess) return pfail(ETG_ERR_HIP, "hipSetDevice");
+  EtgPolicy* p = new EtgPolicy();
+  p->device = device; p->in_dim = in_dim; p->hidden = hidden; p->out_dim = out_dim;
+  struct { float** q; size_t n; } a[] = {{&p->w1, (size_t)hidden * in_dim}, {&p->b1, (size_t)hidden},
+                                         {&p->w2, (size_t)hidden * hidden}, {&p->b2, (size_t)hidden},
+                                         {&p->w3, (size_t)out_dim * hidden}, {&p->b3, (size_t)out_dim}};
+  for (auto& x : a)
+    if (hipMalloc((void**)x.q, x.n * 4) != hipSuccess) return pfail(ETG_ERR_ALLOC, "etg_policy_create: hipMalloc failed");
+  *out = p;
+  return ETG_OK;
+}
+
+extern "C" int etg_policy_load(EtgPolicy* p, const float* w1, const float* b1, const float* w2, const float* b2,
+                               const float* w3, const float* b3, void* stream) {
+  if (!p || !w1 || !b1 || !w2 || !b2 || !w3 || !b3) return pfail(ETG_ERR_BAD_ARG, "etg_policy_load: null");
+  if (hipSetDevice(p->device) != hipSuccess) return pfail(ETG_ERR_HIP, "hipSetDevice");
+  hipStream_t s = (hipStream_t)stream;
+  struct { float* d; const float* src; size_t n; } c[] = {
+      {p->w1, w1, (size_t)p->hidden * p->in_dim}, {p->b1, b1, (size_t)p->hidden},
+      {p->w2, w2, (size_t)p->hidden * p->hidden}, {p->b2, b2, (size_t)p->hidden},
+      {p->w3, w3, (size_t)p->out_dim * p->hidden}, {p->b3, b3, (size_t)p->out_dim}};
+  for (auto& x : c)
+    if (hipMemcpyAsync(x.d, x.src, x.n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+      return pfail(ETG_ERR_HIP, "etg_policy_load: hipMemcpyAsync failed");
+  return ETG_OK;
+}
+
+extern "C" int etg_policy_forward(EtgPolicy* p, const float* obs, int n, float act_scale, int precision, float* act,
+                                  void* stream) {
+  if (!p || !obs || !act || n <= 0) return pfail(ETG_ERR_BAD_ARG, "etg_policy_forward: bad arguments");
+  if (hipSetDevice(p->device) != hipSuccess) return pfail(ETG_ERR_HIP, "hipSetDevice");
+  dim3 grid((n + TM - 1) / TM), block(THREADS);
+  if (precision == 0)
+    hipLaunchKernelGGL(k_policy<false>, grid, block, 0, (hipStream_t)stream, obs, n, p->in_dim, p->w1, p->b1, p->w2, p->b2,
+                       p->w3, p->b3, p->out_dim, act_scale, act);
+  else
+    hipLaunchKernelGGL(k_policy<true>, grid, block, 0, (hipStream_t)stream, obs, n, p->in_dim, p->w1, p->b1, p->w2, p->b2,
+                       p->w3, p->b3, p->out_dim, act_scale, act);
+  if (hipGetLastError() != hipSuccess) return pfail(ETG_ERR_HIP, "etg_policy_forward: launch failed");
+  return ETG_OK;
+}
+
+extern "C" void etg_policy_destroy(EtgPolicy* p) {
+  if (!p) return;
+  (void)hipSetDevice(p->device);
+  float* ptrs[] = {p->w1, p->b1, p->w2, p->b2, p->w3, p->b3};
+  for (float* q : ptrs)
+    if (q) (void)hipFree(q);
+  delete p;
+}

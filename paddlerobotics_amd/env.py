@@ -1,0 +1,215 @@
+"""Batched drop-in for the Gym surface ETGRL drives.
+
+Reference surface (QuadrupedalRobots/ETGRL):
+    env = rlschool.make_env('Quadrupedal', task=, motor_control_mode=, render=, sensor_mode=,
+                            normal=, dynamic_param=, reward_param=, ETG=, ETG_T=, reward_p=,
+                            ETG_path=, random_param=, ETG_H=, vel_d=, step_y=,
+                            enable_action_filter=)                     train.py:305-309
+    obs, info = env.reset(ETG_w=w, ETG_b=b, x_noise=0)                 train.py:131,186,215
+    obs, info = env.reset(hardset=False, dynamic_param=dict)           Dynamic_parallel_model.py:55
+    obs, reward, done, info = env.step(action * act_bound, donef=bool) train.py:147,195,228
+    env.observation_space.shape[0], env.action_space.shape[0]          train.py:311-312
+Here every array gains a leading [num_envs] dimension and lives on the GPU as a torch
+tensor; the work is done by hand-written gfx950 kernels behind the C-ABI of
+include/etgsim.h.  There is no CPU path.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import a1_model as A
+from . import _lib
+from .etg import ETG_layer, Opt_with_points
+
+TASKS = ("ground", "heightfield")
+
+
+class Box:
+    """Minimal stand-in for gym.spaces.Box (gym is not a dependency)."""
+
+    def __init__(self, low, high, shape, dtype=np.float32):
+        self.low = np.full(shape, low, dtype=dtype)
+        self.high = np.full(shape, high, dtype=dtype)
+        self.shape = tuple(shape)
+        self.dtype = np.dtype(dtype)
+
+    def sample(self):
+        return np.random.uniform(self.low, self.high).astype(self.dtype)
+
+
+def _ptr(t):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+class BatchedQuadrupedEnv:
+    def __init__(self, num_envs=1, device="cuda:0", task="ground", motor_control_mode=None, render=False,
+                 sensor_mode=None, normal=1, dynamic_param=None, reward_param=None, ETG=1, ETG_T=0.5,
+                 reward_p=5.0, ETG_path="", random_param=None, ETG_H=20, vel_d=0.5, step_y=0.05,
+                 enable_action_filter=False, ETG_T2=0.5, action_repeat=13, sim_time_step=0.002,
+                 settle_ticks=500, solver_iters=4, enable_action_interpolation=False,
+                 heightfield=None, **unused):
+        if render:
+            raise ValueError("render is not supported by the batched GPU simulator")
+        if int(ETG_H) != A.RBF_H:
+            raise ValueError("ETG_H must be %d" % A.RBF_H)
+        if task == "heightfield" and heightfield is None:
+            raise ValueError("task='heightfield' needs heightfield=dict(heights=[ny,nx], cell=, origin=(x0,y0))")
+        self.num_envs = int(num_envs)
+        self.device = torch.device(device)
+        if self.device.type != "cuda":
+            raise ValueError("BatchedQuadrupedEnv runs on a HIP device only (device='cuda:N')")
+        self.ETG = int(ETG)
+        self.cfg = A.default_config(
+            self.num_envs, action_repeat=action_repeat, sim_dt=sim_time_step, settle_ticks=settle_ticks,
+            solver_iters=solver_iters, enable_action_interp=enable_action_interpolation,
+            enable_action_filter=enable_action_filter, normal=normal,
+            terrain=1 if heightfield is not None else 0, ETG_T=ETG_T, ETG_T2=ETG_T2,
+            reward_param=reward_param, reward_p=reward_p, vel_d=vel_d, heightfield=heightfield)
+        self.model = A.default_model()
+        self.observation_space = Box(-np.inf, np.inf, (A.OBS_DIM,))
+        self.action_space = Box(-1.0, 1.0, (A.NUM_MOTORS,))
+        self._lib = _lib.load()
+        self._h = C.c_void_p()
+        idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
+        _lib.check(self._lib.etg_create(C.byref(self.cfg), C.byref(self.model), idx, C.byref(self._h)))
+        N, dev = self.num_envs, self.device
+        self.obs = torch.zeros(N, A.OBS_DIM, device=dev)
+        self.reward = torch.zeros(N, device=dev)
+        self.done = torch.zeros(N, dtype=torch.uint8, device=dev)
+        self.info_buf = torch.zeros(N, A.INFO_DIM, device=dev)
+        self._zero_action = torch.zeros(N, A.NUM_MOTORS, device=dev)
+        self._hf = None
+        if heightfield is not None:
+            self._hf = torch.as_tensor(np.ascontiguousarray(heightfield["heights"], dtype=np.float32), device=dev)
+            _lib.check(self._lib.etg_set_heightfield(self._h, _ptr(self._hf), self._stream()))
+        # ETG prior (train.py:296-299) unless ETG_path provides w, b
+        self._etg_layer = ETG_layer(ETG_T, self.cfg.etg_dt, A.RBF_H, 0.04, np.array([-np.pi / 2, 0]), 0.2, ETG_T2)
+        if ETG_path:
+            data = np.load(ETG_path)
+            w0, b0 = data["w"], data["b"]
+        elif self.ETG:
+            w0, b0, _ = Opt_with_points(self._etg_layer, ETG_T=ETG_T, Footheight=0.1, Steplength=0.05)
+        else:
+            w0, b0 = np.zeros((3, A.RBF_H)), np.zeros(3)
+        self.set_etg(w0, b0)
+        if dynamic_param is not None:
+            self.set_dynamic_param(dynamic_param)
+
+    # ---- plumbing --------------------------------------------------------------
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _f32(self, x, shape, what):
+        t = torch.as_tensor(x, dtype=torch.float32, device=self.device).contiguous()
+        if tuple(t.shape) != tuple(shape):
+            raise ValueError("%s must have shape %s, got %s" % (what, tuple(shape), tuple(t.shape)))
+        return t
+
+    def _mask(self, env_ids):
+        if env_ids is None:
+            return None
+        m = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
+        m[torch.as_tensor(env_ids, device=self.device, dtype=torch.long)] = 1
+        return m
+
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h:
+            torch.cuda.synchronize(self.device)
+            self._lib.etg_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters ------------------------------------------------------------
+    def set_etg(self, ETG_w, ETG_b, env_ids=None):
+        w = torch.as_tensor(np.asarray(ETG_w) if not torch.is_tensor(ETG_w) else ETG_w, dtype=torch.float32,
+                            device=self.device).contiguous()
+        b = torch.as_tensor(np.asarray(ETG_b) if not torch.is_tensor(ETG_b) else ETG_b, dtype=torch.float32,
+                            device=self.device).contiguous()
+        per_env = int(w.dim() == 3)
+        if per_env:
+            if tuple(w.shape) != (self.num_envs, 3, A.RBF_H) or tuple(b.shape) != (self.num_envs, 3):
+                raise ValueError("per-env ETG_w/ETG_b must be [N,3,20] / [N,3]")
+        elif tuple(w.shape) != (3, A.RBF_H) or tuple(b.shape) != (3,):
+            raise ValueError("ETG_w/ETG_b must be [3,20] / [3]")
+        m = self._mask(env_ids)
+        _lib.check(self._lib.etg_set_params(self._h, None, _ptr(w), _ptr(b), per_env, _ptr(m), self._stream()))
+        self._keep = (w, b, m)
+
+    def set_dynamic_param(self, dynamic_param, env_ids=None):
+        """dynamic_param: dict as produced by param2dynamic_dict (train.py:112-126), a [48] row,
+        or an [N,48] tensor/array of rows (one per robot)."""
+        if isinstance(dynamic_param, dict):
+            dynamic_param = A.dynamic_dict_to_row(dynamic_param)
+        t = torch.as_tensor(np.asarray(dynamic_param) if not torch.is_tensor(dynamic_param) else dynamic_param,
+                            dtype=torch.float32, device=self.device)
+        if t.dim() == 1:
+            t = t.unsqueeze(0).expand(self.num_envs, -1)
+        t = t.contiguous()
+        if tuple(t.shape) != (self.num_envs, A.DYN_DIM):
+            raise ValueError("dynamic_param rows must be [N,48]")
+        m = self._mask(env_ids)
+        _lib.check(self._lib.etg_set_params(self._h, _ptr(t), None, None, 0, _ptr(m), self._stream()))
+        self._keep_dyn = (t, m)
+
+    # ---- Gym surface -----------------------------------------------------------
+    def _info(self):
+        d = {k: (self.info_buf[:, a] if b - a == 1 else self.info_buf[:, a:b]) for k, (a, b) in A.INFO_SLICES.items()}
+        return d
+
+    def reset(self, env_ids=None, ETG_w=None, ETG_b=None, dynamic_param=None, x_noise=0, hardset=False, **kwargs):
+        if ETG_w is not None:
+            self.set_etg(ETG_w, ETG_b, env_ids)
+        if dynamic_param is not None:
+            self.set_dynamic_param(dynamic_param, env_ids)
+        m = self._mask(env_ids)
+        _lib.check(self._lib.etg_reset(self._h, _ptr(m), _ptr(self.obs), self._stream()))
+        info = {"ETG_act": None}
+        return self.obs, info
+
+    def step(self, action, donef=None, want_info=True):
+        a = self._zero_action if action is None else self._f32(action, (self.num_envs, A.NUM_MOTORS), "action")
+        df = None
+        if donef is not None:
+            if isinstance(donef, (bool, int, np.bool_)):
+                df = torch.full((self.num_envs,), int(bool(donef)), dtype=torch.uint8, device=self.device)
+            else:
+                df = torch.as_tensor(donef, device=self.device).to(torch.uint8).contiguous()
+                if tuple(df.shape) != (self.num_envs,):
+                    raise ValueError("donef must be a bool or have shape [N]")
+        _lib.check(self._lib.etg_step(self._h, _ptr(a), _ptr(df), _ptr(self.obs), _ptr(self.reward), _ptr(self.done),
+                                      _ptr(self.info_buf) if want_info else None, self._stream()))
+        self._keep_step = (a, df)
+        return self.obs, self.reward, self.done.bool(), (self._info() if want_info else {})
+
+    def rollout_openloop(self, n_steps):
+        """n_steps control steps with zero residual action (pretrain.py:129-154), fused in one
+        launch; returns (episode_return[N], episode_len[N]) with alive masking."""
+        ret = torch.zeros(self.num_envs, device=self.device)
+        ln = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        _lib.check(self._lib.etg_rollout_openloop(self._h, int(n_steps), _ptr(self.obs), _ptr(ret), _ptr(ln),
+                                                  self._stream()))
+        return ret, ln
+
+    # ---- state access (parity tests) -------------------------------------------
+    def get_state(self):
+        st = torch.zeros(self.num_envs, A.STATE_DIM, device=self.device)
+        _lib.check(self._lib.etg_get_state(self._h, _ptr(st), self._stream()))
+        return st
+
+    def set_state(self, state):
+        st = self._f32(state, (self.num_envs, A.STATE_DIM), "state")
+        _lib.check(self._lib.etg_set_state(self._h, _ptr(st), self._stream()))
+        self._keep_state = st
+
+
+def make_env(name="Quadrupedal", **kwargs):
+    """rlschool.make_env('Quadrupedal', ...) stand-in (train.py:305-309) plus num_envs/device."""
+    if name != "Quadrupedal":
+        raise ValueError("only the 'Quadrupedal' environment exists here")
+    return BatchedQuadrupedEnv(**kwargs)

@@ -1,0 +1,54 @@
+"""Batched Opt_with_points / LS_sol (train.py:59-110) in torch, for thousands of ES candidates.
+
+The reference fits every candidate's ETG weights on the host with two <=1000-step gradient
+descents (train.py:100-104); at 4096+ candidates per generation that dwarfs the rollout, so
+the same iteration is run for all candidates at once (float64, per-candidate stopping rule
+identical to LS_sol's `while err > precision and i < 1000`).  Works on any torch device.
+"""
+import numpy as np
+import torch
+
+from .etg import control_times
+
+
+def ls_sol_batched(A, b, precision=1e-4, alpha=0.05, lamb=1.0, w0=None, max_iter=1000):
+    """A [m,n] shared, b [B,m]; returns x [B,n] -- per-row identical to LS_sol(A, b_i, ...)."""
+    A = A.to(torch.float64)
+    b = b.to(torch.float64)
+    Bsz, n = b.shape[0], A.shape[1]
+    x = torch.zeros(Bsz, n, dtype=torch.float64, device=b.device) if w0 is None else \
+        w0.to(torch.float64).expand(Bsz, n).clone()
+    anchor = None if w0 is None else x.clone()
+    AtA = A.T @ A
+    Atb = b @ A                      # [B,n]
+    active = torch.ones(Bsz, dtype=torch.bool, device=b.device)
+    for _ in range(max_iter):
+        r = x @ A.T - b
+        active = active & ((r * r).sum(1) > precision)
+        if not bool(active.any()):
+            break
+        g = x @ AtA - Atb
+        if anchor is not None:
+            g = g + lamb * (x - anchor)
+        x = torch.where(active[:, None], x - alpha * g, x)
+    return x
+
+
+def opt_with_points_batched(ETG, ETG_T, points, b0, w0, precision=1e-4, lamb=0.5, device="cpu"):
+    """points [B,6,2] (prior + candidate offsets), b0 [3], w0 [3,20] -> (w [B,3,20], b [B,3]).
+    Same as calling Opt_with_points(ETG, ETG_T, points=points[i], b0=b0, w0=w0) for every i."""
+    feats = torch.as_tensor(np.array([ETG.update(t) for t in control_times(ETG_T)]), dtype=torch.float64,
+                            device=device)
+    pts = torch.as_tensor(points, dtype=torch.float64, device=device)
+    b0 = np.asarray(b0, dtype=np.float64)
+    b = torch.tensor([b0[0], b0[-1]], dtype=torch.float64, device=device)
+    centred = pts - b
+    w0t = torch.as_tensor(np.asarray(w0), dtype=torch.float64, device=device)
+    x1 = ls_sol_batched(feats, centred[:, :, 0], precision, 0.05, lamb, w0t[0][None])
+    x2 = ls_sol_batched(feats, centred[:, :, 1], precision, 0.05, lamb, w0t[-1][None])
+    Bsz = pts.shape[0]
+    w = torch.zeros(Bsz, 3, feats.shape[1], dtype=torch.float64, device=device)
+    w[:, 0], w[:, 2] = x1, x2
+    bb = torch.zeros(Bsz, 3, dtype=torch.float64, device=device)
+    bb[:, 0], bb[:, 2] = b[0], b[1]
+    return w, bb

@@ -44,6 +44,8 @@ inline void sincos_(F4 a, F4& s, F4& c) { for (int i = 0; i < 4; i++) { s.v[i] =
 namespace etg {
 struct EmuCtx {
   int env, N;
+  const float* parp;
+  F4 par(int k) const { return ld_lane(parp, k); }
   int NL() const { return 4 * N; }
   F4 ld_lane(const float* p, int f) const { F4 r; for (int l = 0; l < 4; l++) r.v[l] = p[(size_t)f * NL() + 4 * env + l]; return r; }
   void st_lane(float* p, int f, F4 v) const { for (int l = 0; l < 4; l++) p[(size_t)f * NL() + 4 * env + l] = v.v[l]; }
@@ -54,6 +56,7 @@ struct EmuCtx {
   void st_ring(float* r, int slot, int k, F4 v) const { for (int l = 0; l < 4; l++) r[((size_t)slot * 8 + k) * NL() + 4 * env + l] = v.v[l]; }
   F4 ld_ring(const float* r, int slot, int k) const { F4 o; for (int l = 0; l < 4; l++) o.v[l] = r[((size_t)slot * 8 + k) * NL() + 4 * env + l]; return o; }
   void ring_fence() const {}
+  void phase() const {}
   void st_row_env(float* p, int rowlen, int col, F4 v) const { p[(size_t)env * rowlen + col] = v.v[0]; }
   void st_row_lane(float* p, int rowlen, int col0, int stride, F4 v) const { for (int l = 0; l < 4; l++) p[(size_t)env * rowlen + col0 + stride * l] = v.v[l]; }
   F4 ld_row_env(const float* p, int rowlen, int col) const { return F4(p[(size_t)env * rowlen + col]); }
@@ -121,23 +124,21 @@ extern "C" void emu_reset(void* h, const uint8_t* mask, float* obs) {
   Emu* e = (Emu*)h;
   for (int i = 0; i < e->N; i++) {
     if (mask && !mask[i]) continue;
-    EmuCtx c{i, e->N};
-    LaneParams<F4> P = load_params<F4>(c, e->par.data());
+    EmuCtx c{i, e->N, e->par.data()};
     LaneState<F4> L;
-    reset_quad(c, e->K, P, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs);
+    reset_quad(c, e->K, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs);
     store_state(c, e->base.data(), e->leg.data(), L);
   }
 }
 extern "C" void emu_step(void* h, const float* action, const uint8_t* donef, float* obs, float* reward, uint8_t* done, float* info) {
   Emu* e = (Emu*)h;
   for (int i = 0; i < e->N; i++) {
-    EmuCtx c{i, e->N};
-    LaneParams<F4> P = load_params<F4>(c, e->par.data());
+    EmuCtx c{i, e->N, e->par.data()};
     LaneState<F4> L = load_state<F4>(c, e->base.data(), e->leg.data());
     F4 act[3];
     for (int j = 0; j < 3; j++) act[j] = c.ld_row_lane(action, 12, j, 3);
     F4 r, d;
-    control_step(c, e->K, P, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), act,
+    control_step(c, e->K, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), act,
                  F4(donef ? (float)donef[i] : 0.f), obs, r, d, info);
     store_state(c, e->base.data(), e->leg.data(), L);
     reward[i] = r.v[0];
@@ -147,7 +148,7 @@ extern "C" void emu_step(void* h, const float* action, const uint8_t* donef, flo
 extern "C" void emu_get_state(void* h, float* st) {
   Emu* e = (Emu*)h;
   for (int i = 0; i < e->N; i++) {
-    EmuCtx c{i, e->N};
+    EmuCtx c{i, e->N, e->par.data()};
     LaneState<F4> L = load_state<F4>(c, e->base.data(), e->leg.data());
     get_state_quad(c, L, st);
   }
@@ -155,7 +156,7 @@ extern "C" void emu_get_state(void* h, float* st) {
 extern "C" void emu_set_state(void* h, const float* st) {
   Emu* e = (Emu*)h;
   for (int i = 0; i < e->N; i++) {
-    EmuCtx c{i, e->N};
+    EmuCtx c{i, e->N, e->par.data()};
     LaneState<F4> L;
     set_state_quad(c, st, L, e->ring.data(), e->ctl.data(), e->ictl.data());
     store_state(c, e->base.data(), e->leg.data(), L);
@@ -164,13 +165,12 @@ extern "C" void emu_set_state(void* h, const float* st) {
 // checks that the replicated base state is bit-identical across a quad's lanes after a tick
 extern "C" int emu_tick_replication_check(void* h, int env, int nticks) {
   Emu* e = (Emu*)h;
-  EmuCtx c{env, e->N};
-  LaneParams<F4> P = load_params<F4>(c, e->par.data());
+  EmuCtx c{env, e->N, e->par.data()};
   LaneState<F4> L = load_state<F4>(c, e->base.data(), e->leg.data());
-  F4 qdes[3] = {P.pose.x, P.pose.y, P.pose.z};
+  F4 qdes[3] = {c.par(PR_POSE), c.par(PR_POSE + 1), c.par(PR_POSE + 2)};
   int bad = 0;
   for (int t = 0; t < nticks; t++) {
-    physics_tick(c, e->K, P, L, qdes);
+    physics_tick(c, e->K, L, qdes);
     const F4* f[] = {&L.p.x, &L.p.y, &L.p.z, &L.qx, &L.qy, &L.qz, &L.qw, &L.wb.x, &L.wb.y, &L.wb.z, &L.vb.x, &L.vb.y, &L.vb.z};
     for (auto* x : f)
       for (int l = 1; l < 4; l++) bad += std::memcmp(&x->v[0], &x->v[l], 4) != 0;

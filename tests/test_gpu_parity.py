@@ -1,0 +1,236 @@
+"""-m gpu: the HIP path (through the C-ABI, paddlerobotics_amd.env) against the CPU oracle and
+the golden fixtures.  Tolerances: ETG+IK+PD <= 1e-6..2e-5 abs in fp32; dynamics vs
+the fp64 oracle over short horizons: joint angles <= 1e-3 rad, base pose <= 1e-3 m,
+reward <= 1e-3 relative (+ abs floor); MLP fp32 <= 1e-5, bf16 <= 5e-2."""
+import numpy as np
+import pytest
+
+from paddlerobotics_amd import a1_model as A
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+
+def _need_gpu():
+    if not torch.cuda.is_available():
+        pytest.fail("no HIP device visible: -m gpu tests must run on the MI355X box")
+
+
+def _etg_params(n, seed=0):
+    from paddlerobotics_amd.etg import ETG_layer, Opt_with_points
+    layer = ETG_layer(0.5, 0.026, 20, 0.04, np.array([-np.pi / 2, 0]), 0.2, 0.5)
+    w0, b0, prior = Opt_with_points(layer, ETG_T=0.5, Footheight=0.1, Steplength=0.05)
+    rng = np.random.default_rng(seed)
+    W, B = np.zeros((n, 3, 20)), np.zeros((n, 3))
+    for i in range(n):
+        W[i], B[i], _ = Opt_with_points(layer, ETG_T=0.5, w0=w0, b0=b0, points=prior + 0.02 * rng.normal(size=(6, 2)))
+    return W, B
+
+
+def _make(n, **kw):
+    from paddlerobotics_amd.env import make_env
+    return make_env("Quadrupedal", num_envs=n, device="cuda:0", **kw)
+
+
+def _oracle(n, **kw):
+    from oracle.oracle import OracleSim
+    return OracleSim(A.default_config(n, **kw))
+
+
+def test_native_library_is_loaded():
+    _need_gpu()
+    from paddlerobotics_amd import _lib
+    lib = _lib.load()
+    assert lib.etg_version() == 1
+    with open("/proc/self/maps") as f:
+        assert "libetgsim.so" in f.read()
+
+
+def test_reset_and_step_match_oracle():
+    _need_gpu()
+    n = 32
+    W, B = _etg_params(n)
+    env = _make(n, solver_iters=4)
+    orc = _oracle(n, solver_iters=4)
+    env.reset(ETG_w=W, ETG_b=B)
+    orc.set_params(etg_w=W, etg_b=B)
+    obs_o = orc.reset()
+    obs_g = env.obs.cpu().numpy()
+    st_g, st_o = env.get_state().cpu().numpy(), orc.get_state()
+    assert np.abs(st_g[:, :7] - st_o[:, :7]).max() < 1e-3          # base pose after the 500-tick settle
+    assert np.abs(st_g[:, 13:25] - st_o[:, 13:25]).max() < 1e-3    # joint angles
+    assert np.abs(obs_g - obs_o).max() < 2e-2                      # normalised obs (x10 scales)
+    rng = np.random.default_rng(1)
+    for k in range(20):
+        act = rng.uniform(-0.1, 0.1, size=(n, 12))
+        og, rg, dg, ig = env.step(torch.as_tensor(act, dtype=torch.float32))
+        oo, ro, do, io = orc.step(act)
+        st_g, st_o = env.get_state().cpu().numpy(), orc.get_state()
+        assert np.abs(st_g[:, 13:25] - st_o[:, 13:25]).max() < 1e-3, k
+        assert np.abs(st_g[:, :3] - st_o[:, :3]).max() < 1e-3, k
+        assert np.abs(st_g[:, 3:7] - st_o[:, 3:7]).max() < 1e-3, k
+        rg = rg.cpu().numpy()
+        assert np.all(np.abs(rg - ro) < 1e-3 * (1 + np.abs(ro)) + 2e-3), k
+        assert np.array_equal(dg.cpu().numpy().astype(np.uint8), do), k
+        ig = env.info_buf.cpu().numpy()
+        assert np.abs(ig[:, 9:21] - io[:, 9:21]).max() < 2e-5      # ETG_act (pure function)
+        assert np.abs(ig[:, 43:55] - io[:, 43:55]).max() < 2e-5    # real_action
+    env.close()
+
+
+def test_etg_act_matches_reference_fixture(golden):
+    """info['ETG_act'] over an episode reproduces gait_action_list_ETG_exp.npy rows (env_test.py:51-54)."""
+    _need_gpu()
+    g = golden("etg")
+    env = _make(4, settle_ticks=50)
+    env.reset(ETG_w=g["exp_w"], ETG_b=g["exp_b"])
+    rows = {int(r): a for r, a in zip(g["exp_rows"], g["exp_act"])}
+    for k in range(60):
+        env.step(None)
+        if k in rows:
+            got = env.info_buf[:, 9:21].cpu().numpy()
+            assert np.abs(got - rows[k][None]).max() < 2e-5, k
+    env.close()
+
+
+def test_state_roundtrip_and_tick_from_given_state():
+    _need_gpu()
+    n = 16
+    env, orc = _make(n, settle_ticks=20), _oracle(n, settle_ticks=20)
+    env.reset()
+    orc.reset()
+    rng = np.random.default_rng(3)
+    st = orc.get_state()
+    st[:, 2] += rng.uniform(0, 0.05, n)
+    st[:, 7:13] += rng.normal(size=(n, 6)) * 0.2
+    st[:, 13:25] += rng.normal(size=(n, 12)) * 0.05
+    st[:, 25:37] += rng.normal(size=(n, 12)) * 0.5
+    env.set_state(torch.as_tensor(st, dtype=torch.float32))
+    orc.set_state(st)
+    assert np.abs(env.get_state().cpu().numpy() - orc.get_state()).max() < 1e-5
+    for _ in range(3):
+        env.step(None)
+        orc.step(np.zeros((n, 12)))
+    assert np.abs(env.get_state().cpu().numpy()[:, 13:25] - orc.get_state()[:, 13:25]).max() < 1e-3
+    env.close()
+
+
+def test_dynamic_params_and_masked_reset():
+    _need_gpu()
+    n = 8
+    rng = np.random.default_rng(5)
+    rows = np.stack([A.dynamic_dict_to_row(A.param2dynamic_dict(rng.uniform(-0.5, 0.5, 48))) for _ in range(n)])
+    env, orc = _make(n, settle_ticks=100), _oracle(n, settle_ticks=100)
+    env.reset(dynamic_param=rows)
+    orc.set_params(dyn=rows)
+    orc.reset()
+    for _ in range(5):
+        env.step(None)
+        orc.step(np.zeros((n, 12)))
+    assert np.abs(env.get_state().cpu().numpy()[:, 13:25] - orc.get_state()[:, 13:25]).max() < 1e-3
+    # partial reset: only envs 1 and 6 restart, the others keep their state bit-for-bit
+    before = env.get_state().cpu().numpy()
+    env.reset(env_ids=[1, 6])
+    mask = np.zeros(n, dtype=np.uint8)
+    mask[[1, 6]] = 1
+    orc.reset(mask=mask)
+    after = env.get_state().cpu().numpy()
+    keep = [i for i in range(n) if i not in (1, 6)]
+    assert np.array_equal(before[keep], after[keep])
+    assert np.abs(after[[1, 6]] - orc.get_state()[[1, 6]]).max() < 1e-3
+    env.close()
+
+
+def test_policy_mfma_matches_torch_fixture(golden):
+    _need_gpu()
+    from paddlerobotics_amd.policy import MfmaPolicy
+    g = golden("mlp")
+    sd = {"actor_model." + k.replace("_weight", ".weight").replace("_bias", ".bias"): torch.as_tensor(g[k])
+          for k in ("l1_weight", "l1_bias", "l2_weight", "l2_bias", "mean_linear_weight", "mean_linear_bias")}
+    pol = MfmaPolicy(46, 12)
+    pol.load_state_dict(sd)
+    obs = torch.as_tensor(g["obs"], device="cuda:0")
+    act = pol.predict(obs, 1.0, precision=0).cpu().numpy()
+    assert np.abs(act - g["act"]).max() < 1e-5
+    act_bf16 = pol.predict(obs, 1.0, precision=1).cpu().numpy()
+    assert np.abs(act_bf16 - g["act"]).max() < 5e-2
+    # ragged batch (not a multiple of the 16-row tile) and scaling (train.py:320)
+    act7 = pol.predict(obs[:7].contiguous(), 0.3, precision=0).cpu().numpy()
+    assert np.abs(act7 - 0.3 * g["act"][:7]).max() < 1e-5
+
+
+def test_policy_random_init_config3_vs_oracle():
+    _need_gpu()
+    from oracle import oracle as O
+    from paddlerobotics_amd.policy import MfmaPolicy
+    sd = MfmaPolicy.init_like_reference(49, 12, seed=0)
+    pol = MfmaPolicy(49, 12)
+    pol.load_state_dict(sd)
+    torch.manual_seed(1)
+    obs = torch.randn(4096, 49) * 2
+    act = pol.predict(obs.cuda(), 0.3, precision=0).cpu().numpy()
+    ws = [sd["actor_model." + k].numpy() for k in ("l1.weight", "l1.bias", "l2.weight", "l2.bias", "mean_linear.weight", "mean_linear.bias")]
+    ref = O.mlp_forward(obs.numpy(), *ws, scale=0.3)
+    assert np.abs(act - ref).max() < 1e-5
+
+
+def test_full_size_determinism_and_batch_invariance():
+    """BASELINE config 2 size (4096 robots): reruns are bit-identical, and a robot's trajectory does
+    not depend on the batch it is simulated in (robot i of 4096 == the same robot alone)."""
+    _need_gpu()
+    n = 4096
+    W, B = _etg_params(64, seed=7)
+    W, B = np.tile(W, (n // 64, 1, 1)), np.tile(B, (n // 64, 1))
+    out = []
+    for _ in range(2):
+        env = _make(n)
+        env.reset(ETG_w=W, ETG_b=B)
+        ret, ln = env.rollout_openloop(40)
+        out.append((ret.cpu().numpy(), ln.cpu().numpy(), env.get_state().cpu().numpy(), env.obs.cpu().numpy()))
+        env.close()
+    for a, b in zip(out[0], out[1]):
+        assert np.array_equal(a, b)
+    # tiling: robots i and i+64 share parameters -> identical results
+    assert np.array_equal(out[0][2][:64], out[0][2][64:128])
+    small = _make(64)
+    small.reset(ETG_w=W[:64], ETG_b=B[:64])
+    ret_s, ln_s = small.rollout_openloop(40)
+    assert np.array_equal(ret_s.cpu().numpy(), out[0][0][:64])
+    assert np.array_equal(small.get_state().cpu().numpy(), out[0][2][:64])
+    assert np.all(np.isfinite(out[0][2]))
+    small.close()
+
+
+def test_fused_rollout_equals_stepping():
+    _need_gpu()
+    n = 64
+    W, B = _etg_params(n, seed=11)
+    a, b = _make(n), _make(n)
+    a.reset(ETG_w=W, ETG_b=B)
+    b.reset(ETG_w=W, ETG_b=B)
+    ret, ln = a.rollout_openloop(30)
+    tot = torch.zeros(n, device="cuda:0")
+    alive = torch.ones(n, device="cuda:0")
+    steps = torch.zeros(n, device="cuda:0")
+    for _ in range(30):
+        _, r, d, _ = b.step(None)
+        tot += alive * r
+        steps += alive
+        alive = alive * (~d).float()
+    assert torch.allclose(ret, tot, rtol=1e-4, atol=1e-3)
+    assert torch.equal(ln.float(), steps)
+    assert np.abs(a.get_state().cpu().numpy() - b.get_state().cpu().numpy()).max() < 1e-4
+    a.close()
+    b.close()
+
+
+def test_bad_arguments_raise():
+    _need_gpu()
+    env = _make(4, settle_ticks=5)
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(3, 12))
+    with pytest.raises(ValueError):
+        env.set_etg(np.zeros((2, 20)), np.zeros(3))
+    with pytest.raises(ValueError):
+        env.set_dynamic_param(np.zeros((4, 47)))
+    env.close()
