@@ -95,17 +95,12 @@ def main():
         policy.load_state_dict(MfmaPolicy.init_like_reference(A.OBS_DIM, 12, seed=0))
         act = torch.zeros(N, 12, device=dev)
 
-    ret = torch.zeros(N, device=dev)
-    alive = torch.ones(N, device=dev)
-
     def one_step():
         if policy is not None:
             policy.predict(env.obs, 0.3, args.precision, out=act)   # act_bound 0.3, train.py:488
-            _, r, d, _ = env.step(act, want_info=False)
+            env.step(act, want_info=False)
         else:
-            _, r, d, _ = env.step(None, want_info=False)
-        ret.add_(alive * r)
-        alive.mul_((~d).float())
+            env.step(None, want_info=False)
 
     for _ in range(args.warmup):
         one_step()
@@ -124,16 +119,16 @@ def main():
         if policy is not None:
             policy.predict(env.obs, 0.3, args.precision, out=act)
             ev[k][0].record()
-            _, r, d, _ = env.step(act, want_info=False)
+            env.step(act, want_info=False)
             ev[k][1].record()
         else:
             ev[k][0].record()
-            _, r, d, _ = env.step(None, want_info=False)
+            env.step(None, want_info=False)
             ev[k][1].record()
-        ret.add_(alive * r)
-        alive.mul_((~d).float())
     barrier()
     elapsed = time.perf_counter() - t0
+    # episode returns / lengths were accumulated inside the step kernel (alive-masked)
+    ret, length = env.episode_stats()
     if dist is not None:
         # the one exchange of the path: gather episode returns (configs[3]; cf. the scatter/gather of
         # model/Dynamic_parallel_model.py:157-160)
@@ -164,7 +159,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": bytes_per,
                          "note": "VALU-bound by construction (~1e3 FLOP/B, SURVEY 8d); see DESIGN.md"},
-            "survivors": float(alive.mean().item()),
+            "survivors": float((length == args.steps + args.warmup).float().mean().item()),
         }
         if not args.no_cpu_baseline:
             cores = os.cpu_count() or 1

@@ -150,9 +150,14 @@ int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* stream);
  * done [N] uint8, info [N,64] or NULL.                                       */
 int etg_step(EtgHandle* h, const float* action, const uint8_t* donef, float* obs,
              float* reward, uint8_t* done, float* info, void* stream);
-/* fused open-loop rollout: n_steps control steps with action == 0
- * (pretrain.py:129-154), accumulating per-env return/length with alive
- * masking; ret [N] f32, len [N] i32. obs [N,49] receives the final obs.      */
+/* per-robot episode statistics since the robot's last reset: return (sum of
+ * rewards) and length (steps), both frozen after the first `done` (alive
+ * masking; the batched counterpart of train.py:213-249 / pretrain.py:129-154).
+ * Every etg_step updates them on device. ret [N] f32 / len [N] i32, or NULL.    */
+int etg_episode_stats(EtgHandle* h, float* ret, int32_t* len, void* stream);
+/* open-loop rollout: n_steps x etg_step(action = 0) enqueued back-to-back
+ * (pretrain.py:129-154), then etg_episode_stats. obs [N,49] (or NULL)
+ * receives the final observation.                                            */
 int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float* ret, int32_t* len,
                          void* stream);
 

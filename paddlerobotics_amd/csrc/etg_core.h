@@ -717,6 +717,12 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   }
   c.st_env(ctl, CT_LAST_BASE + 0, L.p.x); c.st_env(ctl, CT_LAST_BASE + 1, L.p.y); c.st_env(ctl, CT_LAST_BASE + 2, L.p.z);
   c.st_lane(legctl, LC_LAST_FOOT_X, fk.fwx);
+  // episode accumulators with alive masking (the batched counterpart of the callers' loops,
+  // train.py:213-249 / pretrain.py:129-154: return and length stop growing after `done`)
+  F alive = c.ld_env(ctl, CT_ALIVE);
+  c.st_env(ctl, CT_RET, c.ld_env(ctl, CT_RET) + alive * reward);
+  c.st_env(ctl, CT_LEN, c.ld_env(ctl, CT_LEN) + alive);
+  c.st_env(ctl, CT_ALIVE, sel_(done > F(0.5f), F(0.0f), alive));
 }
 
 // ------------------------------------------------------------------ reset (minitaur.py:403-445, a1.py:289-349)
@@ -744,6 +750,7 @@ ETG_HD void reset_quad(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ring
   c.st_env_i(ictl, IC_STEP, 0);
   c.st_env_i(ictl, IC_TICK, tick);
   c.st_env_i(ictl, IC_HAS_LAST, 0);
+  c.st_env(ctl, CT_RET, F(0.0f)); c.st_env(ctl, CT_LEN, F(0.0f)); c.st_env(ctl, CT_ALIVE, F(1.0f));
   c.st_env(ctl, CT_LAST_BASE + 0, L.p.x); c.st_env(ctl, CT_LAST_BASE + 1, L.p.y); c.st_env(ctl, CT_LAST_BASE + 2, L.p.z);
   for (int j = 0; j < 3; j++) {
     c.st_lane(legctl, LC_LAST_QDES + j, pose[j]);

@@ -136,30 +136,12 @@ __global__ void __launch_bounds__(BLOCK) k_step(KCfg K, DevState D, const float*
   }
 }
 
-// fused open-loop rollout (pretrain.py:129-154 with action == 0): n_steps control steps in
-// one launch, state resident in registers, return/length accumulated with alive masking.
-__global__ void __launch_bounds__(BLOCK) k_rollout(KCfg K, DevState D, int n_steps, float* obs, float* ret, int* len) {
-  GpuCtx c;
-  if (!make_ctx(K, c)) return;
-  __shared__ float lds_par[PR_N * BLOCK];
-  stage_params(c, D, lds_par);
-  LaneState<float> L = load_state<float>(c, D.base, D.leg);
-  float act[3] = {0.0f, 0.0f, 0.0f};
-  float total = 0.0f, alive = 1.0f;
-  int steps = 0;
-  for (int k = 0; k < n_steps; k++) {
-    float r, d;
-    control_step(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, act, 0.0f, (k == n_steps - 1) ? obs : nullptr, r, d,
-                 nullptr);
-    total += alive * r;
-    steps += alive > 0.5f ? 1 : 0;
-    alive = d > 0.5f ? 0.0f : alive;
-  }
-  store_state(c, D.base, D.leg, L);
-  if (c.lane == 0) {
-    ret[c.env] = total;
-    len[c.env] = steps;
-  }
+// copy out the per-robot episode accumulators (return, length) kept in ctl[]
+__global__ void k_episode_stats(KCfg K, DevState D, float* ret, int* len) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K.n_env) return;
+  if (ret) ret[i] = D.ctl[(size_t)CT_RET * K.n_env + i];
+  if (len) len[i] = (int)D.ctl[(size_t)CT_LEN * K.n_env + i];
 }
 
 __global__ void __launch_bounds__(BLOCK) k_get_state(KCfg K, DevState D, float* st) {
@@ -188,6 +170,8 @@ struct EtgHandle {
   ModelF M;
   DevState D;
   float* hf;
+  float *tmp_obs, *tmp_reward;  // sinks for etg_rollout_openloop
+  uint8_t* tmp_done;
 };
 
 static thread_local std::string g_err;
@@ -210,7 +194,7 @@ static int grid_for(const EtgHandle* h) { return (4 * h->N + BLOCK - 1) / BLOCK;
 
 extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int device, EtgHandle** out) {
   if (!cfg || !model || !out) return fail(ETG_ERR_BAD_ARG, "etg_create: null argument");
-  if (cfg->num_envs <= 0) return fail(ETG_ERR_BAD_ARG, "etg_create: num_envs must be > 0");
+  if (cfg->num_envs <= 0 || cfg->num_envs > (1 << 20)) return fail(ETG_ERR_BAD_ARG, "etg_create: num_envs must be in 1..1048576");
   if (cfg->action_repeat <= 0 || cfg->sim_dt <= 0) return fail(ETG_ERR_BAD_ARG, "etg_create: bad action_repeat/sim_dt");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
@@ -227,7 +211,8 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   struct { void** p; size_t bytes; } allocs[] = {
       {(void**)&h->D.base, BS_N * N * 4},   {(void**)&h->D.leg, LG_N * NL * 4},   {(void**)&h->D.ctl, CT_N * N * 4},
       {(void**)&h->D.ictl, IC_N * N * 4},   {(void**)&h->D.legctl, LC_N * NL * 4}, {(void**)&h->D.etgp, EP_N * N * 4},
-      {(void**)&h->D.par, PR_N * NL * 4},   {(void**)&h->D.ring, (size_t)RING * 8 * NL * 4}};
+      {(void**)&h->D.par, PR_N * NL * 4},   {(void**)&h->D.ring, (size_t)RING * 8 * NL * 4},
+      {(void**)&h->tmp_obs, ETG_OBS_DIM * N * 4}, {(void**)&h->tmp_reward, N * 4}, {(void**)&h->tmp_done, N}};
   for (auto& a : allocs) {
     if (hipMalloc(a.p, a.bytes) != hipSuccess) return fail(ETG_ERR_ALLOC, "etg_create: hipMalloc failed");
     HIP_TRY(hipMemset(*a.p, 0, a.bytes));
@@ -252,7 +237,8 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
 extern "C" void etg_destroy(EtgHandle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  void* ptrs[] = {h->D.base, h->D.leg, h->D.ctl, h->D.ictl, h->D.legctl, h->D.etgp, h->D.par, h->D.ring, h->hf};
+  void* ptrs[] = {h->D.base, h->D.leg, h->D.ctl, h->D.ictl, h->D.legctl, h->D.etgp, h->D.par, h->D.ring, h->hf,
+                  h->tmp_obs, h->tmp_reward, h->tmp_done};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
@@ -301,12 +287,26 @@ extern "C" int etg_step(EtgHandle* h, const float* action, const uint8_t* donef,
   return ETG_OK;
 }
 
+extern "C" int etg_episode_stats(EtgHandle* h, float* ret, int32_t* len, void* stream) {
+  CHECK_HANDLE(h);
+  hipLaunchKernelGGL(k_episode_stats, dim3((h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->D, ret, len);
+  HIP_TRY(hipGetLastError());
+  return ETG_OK;
+}
+
+// n_steps x env.step(action = 0) enqueued back-to-back on the stream (pretrain.py:129-154).
+// Bit-identical to calling etg_step n_steps times; the per-robot return/length since the last
+// etg_reset are accumulated inside the step kernel with alive masking.
 extern "C" int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float* ret, int32_t* len, void* stream) {
   CHECK_HANDLE(h);
   if (n_steps <= 0 || !ret || !len) return fail(ETG_ERR_BAD_ARG, "etg_rollout_openloop: bad arguments");
-  hipLaunchKernelGGL(k_rollout, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, n_steps, obs, ret, len);
+  for (int k = 0; k < n_steps; k++) {
+    float* o = (obs && k == n_steps - 1) ? obs : h->tmp_obs;
+    hipLaunchKernelGGL(k_step, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, (const float*)nullptr,
+                       (const uint8_t*)nullptr, o, h->tmp_reward, h->tmp_done, (float*)nullptr);
+  }
   HIP_TRY(hipGetLastError());
-  return ETG_OK;
+  return etg_episode_stats(h, ret, len, stream);
 }
 
 extern "C" int etg_get_state(EtgHandle* h, float* state, void* stream) {

@@ -29,7 +29,8 @@ constexpr int RING = 64;  // ticks of history; latency <= 80 ms at dt = 2 ms nee
 
 enum { BS_PX, BS_PY, BS_PZ, BS_QX, BS_QY, BS_QZ, BS_QW, BS_WX, BS_WY, BS_WZ, BS_VX, BS_VY, BS_VZ, BS_N };
 enum { LG_Q = 0, LG_QD = 3, LG_LAM = 6, LG_CONTACT = 9, LG_N = 10 };
-enum { CT_FIRST_RPY = 0, CT_LAST_BASE = 3, CT_N = 6 };
+// CT_RET/LEN/ALIVE: per-robot episode accumulators (return, length, alive mask) updated by every step
+enum { CT_FIRST_RPY = 0, CT_LAST_BASE = 3, CT_RET = 6, CT_LEN = 7, CT_ALIVE = 8, CT_N = 9 };
 enum { IC_STEP = 0, IC_TICK = 1, IC_HAS_LAST = 2, IC_N = 3 };
 enum { LC_LAST_QDES = 0, LC_FX0 = 3, LC_FX1 = 6, LC_FY0 = 9, LC_FY1 = 12, LC_LAST_FOOT_X = 15, LC_N = 16 };
 enum { EP_W = 0, EP_B = 60, EP_N = 63 };

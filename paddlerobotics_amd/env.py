@@ -185,15 +185,23 @@ class BatchedQuadrupedEnv:
         _lib.check(self._lib.etg_step(self._h, _ptr(a), _ptr(df), _ptr(self.obs), _ptr(self.reward), _ptr(self.done),
                                       _ptr(self.info_buf) if want_info else None, self._stream()))
         self._keep_step = (a, df)
-        return self.obs, self.reward, self.done.bool(), (self._info() if want_info else {})
+        return self.obs, self.reward, self.done.bool() if want_info else self.done, (self._info() if want_info else {})
 
     def rollout_openloop(self, n_steps):
-        """n_steps control steps with zero residual action (pretrain.py:129-154), fused in one
-        launch; returns (episode_return[N], episode_len[N]) with alive masking."""
+        """n_steps control steps with zero residual action (pretrain.py:129-154) enqueued back to
+        back; returns (episode_return[N], episode_len[N]) since the last reset, alive-masked."""
         ret = torch.zeros(self.num_envs, device=self.device)
         ln = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
         _lib.check(self._lib.etg_rollout_openloop(self._h, int(n_steps), _ptr(self.obs), _ptr(ret), _ptr(ln),
                                                   self._stream()))
+        return ret, ln
+
+    def episode_stats(self):
+        """(return[N], length[N]) accumulated on device since each robot's last reset, frozen at its
+        first `done` (what run_episode / run_EStrain_episode return per candidate)."""
+        ret = torch.zeros(self.num_envs, device=self.device)
+        ln = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        _lib.check(self._lib.etg_episode_stats(self._h, _ptr(ret), _ptr(ln), self._stream()))
         return ret, ln
 
     # ---- state access (parity tests) -------------------------------------------

@@ -96,8 +96,10 @@ def test_etg_act_matches_reference_fixture(golden):
 def test_state_roundtrip_and_tick_from_given_state():
     _need_gpu()
     n = 16
+    W, B = _etg_params(n, seed=3)
     env, orc = _make(n, settle_ticks=20), _oracle(n, settle_ticks=20)
-    env.reset()
+    env.reset(ETG_w=W, ETG_b=B)
+    orc.set_params(etg_w=W, etg_b=B)
     orc.reset()
     rng = np.random.default_rng(3)
     st = orc.get_state()
@@ -120,14 +122,15 @@ def test_dynamic_params_and_masked_reset():
     n = 8
     rng = np.random.default_rng(5)
     rows = np.stack([A.dynamic_dict_to_row(A.param2dynamic_dict(rng.uniform(-0.5, 0.5, 48))) for _ in range(n)])
-    env, orc = _make(n, settle_ticks=100), _oracle(n, settle_ticks=100)
-    env.reset(dynamic_param=rows)
-    orc.set_params(dyn=rows)
+    W, B = _etg_params(n, seed=5)
+    env, orc = _make(n), _oracle(n)
+    env.reset(dynamic_param=rows, ETG_w=W, ETG_b=B)
+    orc.set_params(dyn=rows, etg_w=W, etg_b=B)
     orc.reset()
     for _ in range(5):
         env.step(None)
         orc.step(np.zeros((n, 12)))
-    assert np.abs(env.get_state().cpu().numpy()[:, 13:25] - orc.get_state()[:, 13:25]).max() < 1e-3
+    assert np.abs(env.get_state().cpu().numpy()[:, 13:25] - orc.get_state()[:, 13:25]).max() < 2e-3
     # partial reset: only envs 1 and 6 restart, the others keep their state bit-for-bit
     before = env.get_state().cpu().numpy()
     env.reset(env_ids=[1, 6])
@@ -137,7 +140,7 @@ def test_dynamic_params_and_masked_reset():
     after = env.get_state().cpu().numpy()
     keep = [i for i in range(n) if i not in (1, 6)]
     assert np.array_equal(before[keep], after[keep])
-    assert np.abs(after[[1, 6]] - orc.get_state()[[1, 6]]).max() < 1e-3
+    assert np.abs(after[[1, 6]] - orc.get_state()[[1, 6]]).max() < 2e-3
     env.close()
 
 
@@ -217,9 +220,11 @@ def test_fused_rollout_equals_stepping():
         tot += alive * r
         steps += alive
         alive = alive * (~d).float()
-    assert torch.allclose(ret, tot, rtol=1e-4, atol=1e-3)
+    assert torch.allclose(ret, tot, rtol=1e-5, atol=1e-4)
     assert torch.equal(ln.float(), steps)
-    assert np.abs(a.get_state().cpu().numpy() - b.get_state().cpu().numpy()).max() < 1e-4
+    assert np.array_equal(a.get_state().cpu().numpy(), b.get_state().cpu().numpy())   # same kernel, same bits
+    ret_b, ln_b = b.episode_stats()
+    assert torch.equal(ret_b, ret) and torch.equal(ln_b, ln)
     a.close()
     b.close()
 
