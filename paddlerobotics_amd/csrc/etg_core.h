@@ -139,8 +139,8 @@ template <class F> ETG_HD Rows<F> quat_rows(F x, F y, F z, F w) {
 }
 
 // in-place LDL^T of a symmetric 6x6 stored as lower triangle s[i*(i+1)/2+j]:
-// on return s holds unit-lower L (strictly lower part), dinv[j] = 1/d_j
-template <class F> ETG_HD void ldl6(F* s, F* dinv) {
+// on return s holds unit-lower L (strictly lower part), dinv[j] = 1/d_j, dsq[j] = 1/sqrt(d_j)
+template <class F> ETG_HD void ldl6(F* s, F* dinv, F* dsq) {
   F d[6];
 #pragma unroll
   for (int j = 0; j < 6; j++) {
@@ -151,7 +151,8 @@ template <class F> ETG_HD void ldl6(F* s, F* dinv) {
       dj = dj - ljk * ljk * d[k];
     }
     d[j] = dj;
-    dinv[j] = F(1.0f) / dj;
+    dinv[j] = rcp_(dj);
+    dsq[j] = rsqrt_(dj);
 #pragma unroll
     for (int i = j + 1; i < 6; i++) {
       F v = s[i * (i + 1) / 2 + j];
@@ -246,7 +247,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* 
   // H^-1 by cofactors
   F cA = H22 * H33 - H23 * H23, cB = H13 * H23 - H12 * H33, cC = H12 * H23 - H13 * H22;
   F cD = H11 * H33 - H13 * H13, cE = H12 * H13 - H11 * H23, cF = H11 * H22 - H12 * H12;
-  F idet = one / (H11 * cA + H12 * cB + H13 * cC);
+  F idet = rcp_(H11 * cA + H12 * cB + H13 * cC);
   F Hi11 = cA * idet, Hi12 = cB * idet, Hi13 = cC * idet, Hi22 = cD * idet, Hi23 = cE * idet, Hi33 = cF * idet;
   // P = Fm H^-1 (columns)
   W P1 = Hi11 * F1 + Hi12 * F2 + Hi13 * F3;
@@ -282,8 +283,8 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* 
   F rb[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) rb[i] = -(comp(f0, i) + c.qsum(comp(f1, i))) - c.qsum(comp(pb, i));
-  F dinv[6];
-  ldl6(s, dinv);
+  F dinv[6], sq[6];
+  ldl6(s, dinv, sq);
   fwd6(s, rb);
 #pragma unroll
   for (int i = 0; i < 6; i++) rb[i] = rb[i] * dinv[i];
@@ -324,9 +325,6 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* 
   F Jl[3][3];     // [row d][joint]
   F HJ[3][3];     // H^-1 Jl^T, [row d][joint]
   W Z[3];         // D^-1/2 L^-1 G_d
-  F sq[6];
-#pragma unroll
-  for (int i = 0; i < 6; i++) sq[i] = sqrt_(dinv[i]);
 #pragma unroll
   for (int d = 0; d < 3; d++) {
     Jl[d][0] = actf * dot(dir[d], k1);
@@ -367,12 +365,13 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* 
 #pragma unroll
     for (int e = 0; e < 3; e++)
       Aown[d][e] = sel_(c.lane_is(0), A[0][d][e], sel_(c.lane_is(1), A[1][d][e], sel_(c.lane_is(2), A[2][d][e], A[3][d][e])));
-  F iA0 = sel_(act, one / Aown[0][0], zero), iA1 = sel_(act, one / Aown[1][1], zero), iA2 = sel_(act, one / Aown[2][2], zero);
+  F iA0 = sel_(act, rcp_(Aown[0][0]), zero), iA1 = sel_(act, rcp_(Aown[1][1]), zero), iA2 = sel_(act, rcp_(Aown[2][2]), zero);
   c.phase();
   // contact-point velocity under the unconstrained motion
   V vc = vbs + cross(wbs, rc) + qds1 * k1 + qds2 * k2 + qds3 * k3;
   F u0 = actf * dot(dn, vc), u1 = actf * dot(d1, vc), u2 = actf * dot(d2, vc);
-  F tgt = sel_(phi > zero, -(phi / dt), -(F(K.erp) * phi / dt));
+  const F idt(1.0f / K.dt);
+  F tgt = sel_(phi > zero, -(phi * idt), -(F(K.erp) * phi * idt));
   // warm start (Bullet-style 0.85 factor); inactive feet forget their impulse
   F l0 = actf * F(K.warmstart) * L.lam[0], l1 = actf * F(K.warmstart) * L.lam[1], l2 = actf * F(K.warmstart) * L.lam[2];
 #pragma unroll

@@ -64,7 +64,6 @@ ETG_HD float sel_(bool c, float a, float b) { return c ? a : b; }
 ETG_HD float fminf_(float a, float b) { return fminf(a, b); }
 ETG_HD float fmaxf_(float a, float b) { return fmaxf(a, b); }
 ETG_HD float fabsf_(float a) { return fabsf(a); }
-ETG_HD float sqrt_(float a) { return sqrtf(a); }
 ETG_HD float sin_(float a) { return sinf(a); }
 ETG_HD float cos_(float a) { return cosf(a); }
 ETG_HD float exp_(float a) { return expf(a); }
@@ -74,10 +73,31 @@ ETG_HD float asin_(float a) { return asinf(a); }
 ETG_HD float atan2_(float a, float b) { return atan2f(a, b); }
 ETG_HD bool isfinite_(float a) { return isfinite(a); }
 #if defined(__HIPCC__)
-ETG_HD float rsqrt_(float a) { return 1.0f / sqrtf(a); }
-ETG_HD void sincos_(float a, float& s, float& c) { sincosf(a, &s, &c); }
+// Hardware 1-ulp reciprocal / rsqrt / sqrt: the IEEE-exact expansions cost 10-15 dependent
+// instructions each and sit on the serial critical path of the LDL^T and of every PGS turn.
+ETG_HD float rcp_(float a) { return __builtin_amdgcn_rcpf(a); }
+ETG_HD float rsqrt_(float a) { return __builtin_amdgcn_rsqf(a); }
+ETG_HD float sqrt_(float a) { return __builtin_amdgcn_sqrtf(a); }
+// sin/cos for joint angles: Cody-Waite reduction by pi/2 + cephes minimax polynomials
+// (|error| < 2e-7 for |x| < 1e3; joint angles are within +-4.2 rad).  libm's sincosf carries a
+// Payne-Hanek slow path whose branches alone cost more than this whole routine.
+ETG_HD void sincos_(float x, float& s, float& c) {
+  const float k = rintf(x * 0.636619772f);
+  float r = fmaf(k, -1.57079637f, x);
+  r = fmaf(k, 4.37113900e-08f, r);
+  const float z = r * r;
+  const float ps = fmaf(fmaf(fmaf(-1.9515295891e-4f, z, 8.3321608736e-3f), z, -1.6666654611e-1f) * z, r, r);
+  const float pc = fmaf(fmaf(fmaf(2.443315711809948e-5f, z, -1.388731625493765e-3f), z, 4.166664568298827e-2f), z * z,
+                        fmaf(-0.5f, z, 1.0f));
+  const int q = (int)k;
+  const float sv = (q & 1) ? pc : ps, cv = (q & 1) ? ps : pc;
+  s = (q & 2) ? -sv : sv;
+  c = ((q + 1) & 2) ? -cv : cv;
+}
 #else
+ETG_HD float rcp_(float a) { return 1.0f / a; }
 ETG_HD float rsqrt_(float a) { return 1.0f / sqrtf(a); }
+ETG_HD float sqrt_(float a) { return sqrtf(a); }
 ETG_HD void sincos_(float a, float& s, float& c) { s = sinf(a); c = cosf(a); }
 #endif
 // MapToMinusPiToPi (minitaur.py:67-83)

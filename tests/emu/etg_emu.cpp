@@ -30,7 +30,7 @@ inline B4 operator||(B4 a, B4 b) { B4 r; for (int i = 0; i < 4; i++) r.v[i] = a.
 inline B4 operator!(B4 a) { B4 r; for (int i = 0; i < 4; i++) r.v[i] = !a.v[i]; return r; }
 inline F4 sel_(B4 c, F4 a, F4 b) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
 #define FN1(name) inline F4 name(F4 a) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = name(a.v[i]); return r; }
-FN1(fabsf_) FN1(sqrt_) FN1(rsqrt_) FN1(sin_) FN1(cos_) FN1(exp_) FN1(tanh_) FN1(acos_) FN1(asin_) FN1(wrap_pi_)
+FN1(fabsf_) FN1(sqrt_) FN1(rsqrt_) FN1(rcp_) FN1(sin_) FN1(cos_) FN1(exp_) FN1(tanh_) FN1(acos_) FN1(asin_) FN1(wrap_pi_)
 #undef FN1
 inline F4 fminf_(F4 a, F4 b) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = fminf(a.v[i], b.v[i]); return r; }
 inline F4 fmaxf_(F4 a, F4 b) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = fmaxf(a.v[i], b.v[i]); return r; }
