@@ -1,0 +1,69 @@
+"""Batched counterpart of the reference's episode loops and of one ES generation.
+
+  run_episode / run_EStrain_episode   pretrain.py:129-154, train.py:213-249
+  one ES generation                   pretrain.py:220-243, train.py:398-418
+  scatter / gather of candidates      model/Dynamic_parallel_model.py:157-160 (xparl) -> here one
+                                      all_gather of the episode returns over RCCL (or gloo in tests)
+
+Candidate i of the population is robot i of the global batch; with world_size ranks, rank r owns
+candidates [r*N, (r+1)*N).  Every rank draws the same population (same seed) and runs the same
+tell(), so the next population needs no broadcast.
+"""
+import numpy as np
+import torch
+
+from .etg_fit import opt_with_points_batched
+
+
+def run_episodes(env, max_step, ETG_w=None, ETG_b=None, policy=None, action_bound=0.3, precision=0,
+                 dynamic_param=None):
+    """reset(ETG_w, ETG_b) then `max_step`+1 steps (the reference loops while steps <= max_step and passes
+    donef=(steps > max_step)); returns per-robot (episode_return, episode_length) with alive masking."""
+    env.reset(ETG_w=ETG_w, ETG_b=ETG_b, dynamic_param=dynamic_param)
+    act = None
+    for steps in range(1, max_step + 2):
+        if policy is not None:
+            act = policy.predict(env.obs, action_bound, precision, out=act)
+        env.step(act, donef=(steps > max_step), want_info=False)
+    return env.episode_stats()
+
+
+def shard_bounds(total, rank, world):
+    per = total // world
+    if per * world != total:
+        raise ValueError("population %d is not divisible by world size %d" % (total, world))
+    return rank * per, (rank + 1) * per
+
+
+def gather_returns(local_returns, dist=None):
+    """The one exchange of the path: all ranks end up with the full [world*N] return vector."""
+    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+        return local_returns
+    out = torch.empty(local_returns.numel() * dist.get_world_size(), dtype=local_returns.dtype,
+                      device=local_returns.device)
+    dist.all_gather_into_tensor(out, local_returns.contiguous())
+    return out
+
+
+def es_generation(solver, evaluate, dist=None, rank=0, world=1):
+    """ask -> evaluate this rank's slice -> gather -> tell (replicated). `evaluate(solutions_slice)`
+    returns the slice's fitness tensor. Returns the full fitness vector."""
+    solutions = solver.ask()
+    lo, hi = shard_bounds(solutions.shape[0], rank, world)
+    local = evaluate(solutions[lo:hi])
+    fitness = gather_returns(torch.as_tensor(local), dist)
+    solver.tell(fitness)
+    return fitness
+
+
+def make_etg_evaluator(env, etg_layer, ETG_T, prior_points, w0, b0, max_step=400, policy=None, action_bound=0.3):
+    """Fitness of ETG control-point offsets (12 numbers per candidate), as in pretrain.py:226-233."""
+    prior = torch.as_tensor(np.asarray(prior_points), dtype=torch.float64, device=env.device)
+
+    def evaluate(solutions):
+        pts = prior[None] + solutions.to(env.device).reshape(-1, 6, 2)
+        w, b = opt_with_points_batched(etg_layer, ETG_T, pts, b0, w0, device=env.device)
+        ret, _ = run_episodes(env, max_step, ETG_w=w.float(), ETG_b=b.float(), policy=policy,
+                              action_bound=action_bound)
+        return ret
+    return evaluate

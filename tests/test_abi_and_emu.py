@@ -112,3 +112,27 @@ def test_kernel_math_emulation_state_roundtrip_and_filter():
     st = orc.get_state()
     emu.set_state(st)
     assert np.abs(emu.get_state() - st).max() < 1e-6
+
+
+def test_kernel_math_emulation_heightfield_matches_oracle():
+    """BASELINE config 5 terrain: 256x256 grid, 0.05 m cells, heights U(0, 0.05) from default_rng(0)."""
+    from oracle.oracle import OracleSim
+    from tests.emu.emu import EmuSim
+    n = 2
+    rng = np.random.default_rng(0)
+    hf = dict(heights=rng.uniform(0, 0.05, size=(256, 256)).astype(np.float32), cell=0.05, origin=(-6.4, -6.4))
+    cfg = A.default_config(n, solver_iters=4, terrain=1, heightfield=hf)
+    W, B = _params(n, seed=9)
+    orc, emu = OracleSim(cfg), EmuSim(cfg)
+    for s in (orc, emu):
+        s.set_heightfield(hf["heights"])
+        s.set_params(etg_w=W, etg_b=B)
+    orc.reset()
+    emu.reset()
+    assert np.abs(emu.get_state()[:, :7] - orc.get_state()[:, :7]).max() < 2e-3
+    assert orc.get_state()[:, 2].min() > 0.2          # standing on the terrain, not sunk into it
+    for k in range(6):
+        orc.step(np.zeros((n, 12)))
+        emu.step(np.zeros((n, 12)))
+        # the bilinear terrain is only C0: contact normals jump at cell edges, so fp32/fp64 part faster
+        assert np.abs(emu.get_state()[:, 13:25] - orc.get_state()[:, 13:25]).max() < 1e-2

@@ -1,0 +1,79 @@
+"""Host logic of the ES loop: SimpleGA vs the reference trace, and the multi-rank sharding /
+gather / replicated tell on CPU with gloo (world_size 2)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from paddlerobotics_amd.es import SimpleGA
+from paddlerobotics_amd import rollout as R
+
+
+def test_simple_ga_matches_reference_trace(golden):
+    g = golden("ga")
+    ga = SimpleGA(12, sigma_init=0.02, sigma_decay=0.99, sigma_limit=0.005, elite_ratio=0.1, weight_decay=0.005,
+                  popsize=40, param=np.zeros(12))
+    np.random.seed(123)          # replay the numpy stream in alg/es.py's consumption order
+    for it in range(3):
+        normal = np.random.randn(40, 12)
+        parents = np.zeros((40, 2), dtype=np.int64)
+        mate_u = np.zeros((40, 12))
+        for i in range(40):
+            parents[i, 0] = np.random.choice(range(4))
+            parents[i, 1] = np.random.choice(range(4))
+            if it > 0:
+                mate_u[i] = np.random.rand(12)
+        sol = ga.ask(draws=(normal, parents, mate_u)).numpy()
+        assert np.allclose(sol, g["sol%d" % it], atol=1e-14), it
+        ga.tell(g["fit%d" % it])
+        assert np.allclose(ga.elite_params.numpy(), g["elite%d" % it], atol=1e-14)
+        assert np.allclose(ga.elite_rewards.numpy(), g["elite_rewards%d" % it], atol=1e-12)
+        assert np.allclose(ga.best_param.numpy(), g["best%d" % it], atol=1e-14)
+        assert abs(ga.sigma - float(g["sigma%d" % it])) < 1e-15
+
+
+def test_shard_bounds_and_single_rank_generation():
+    assert R.shard_bounds(8192, 1, 2) == (4096, 8192)
+    with pytest.raises(ValueError):
+        R.shard_bounds(10, 0, 3)
+    ga = SimpleGA(12, popsize=16, sigma_init=0.1, seed=3)
+    fit = R.es_generation(ga, lambda s: -(s * s).sum(1))
+    assert fit.shape == (16,) and not ga.first_iteration
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ga = SimpleGA(12, popsize=32, sigma_init=0.05, seed=7, dtype=torch.float32)
+
+    def evaluate(sol):   # stands in for the GPU rollout of this rank's robots
+        return -((sol - 0.03) ** 2).sum(1).float()
+    fits = [R.es_generation(ga, evaluate, dist=dist, rank=rank, world=world) for _ in range(3)]
+    out[rank] = (torch.stack(fits).numpy(), ga.best_param.numpy(), ga.sigma)
+    dist.destroy_process_group()
+
+
+def test_two_rank_generation_equals_single_rank():
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    ga = SimpleGA(12, popsize=32, sigma_init=0.05, seed=7, dtype=torch.float32)
+    ref = [R.es_generation(ga, lambda s: -((s - 0.03) ** 2).sum(1).float()) for _ in range(3)]
+    for r in range(world):
+        fits, best, sigma = out[r]
+        assert np.array_equal(fits, torch.stack(ref).numpy())       # gather order = candidate order
+        assert np.array_equal(best, ga.best_param.numpy()) and sigma == ga.sigma   # replicated tell
