@@ -24,7 +24,8 @@ class EtgError(RuntimeError):
 
 
 def lib_path():
-    return _build.LIB
+    # ETG_LIB selects an alternative build of the same HIP sources (A/B experiments in tools/)
+    return os.environ.get("ETG_LIB", _build.LIB)
 
 
 def load():

@@ -212,7 +212,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* 
   RBI<F> I3 = link_inertia(c.par(PR_LINK + 20), par3<F>(c, PR_LINK + 21), par_s3<F>(c, PR_LINK + 24), R3, o3);
   W S1 = {xax, cross(o1, xax)}, S2 = {yax, cross(o2, yax)}, S3_ = {yax, cross(o3, yax)};
 
-  c.phase();
+  c.phase(0);
   // ---- velocities, bias accelerations (qdd = 0, a_base = -g), bias forces (RNEA)
   Rows<F> Rw = quat_rows(L.qx, L.qy, L.qz, L.qw);
   V gb;  // R^T g: columns of R are (r0.x, r1.x, r2.x) ...
@@ -237,7 +237,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* 
   RBI<F> I0 = {m0, {zero, zero, zero}, I0s};
   W f0 = apply(I0, a0) + crf(V0, apply(I0, V0));
 
-  c.phase();
+  c.phase(1);
   // ---- composite inertias, leg block H (3x3), base coupling Fm (6x3) (CRBA)
   RBI<F> Ic2 = I2 + I3;
   RBI<F> Ic1 = I1 + Ic2;
@@ -256,7 +256,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* 
   F rl1 = tau[0] - C1, rl2 = tau[1] - C2, rl3 = tau[2] - C3;
   W pb = rl1 * P1 + rl2 * P2 + rl3 * P3;
 
-  c.phase();
+  c.phase(2);
   // ---- base Schur complement: S = Mbb - sum_legs P Fm^T, rhs = -(f0 + sum f1) - sum pb
   F s[21];
 #pragma unroll
@@ -294,31 +294,39 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* 
   F qdd2 = Hi12 * rl1 + Hi22 * rl2 + Hi23 * rl3 - dot(P2, ab);
   F qdd3 = Hi13 * rl1 + Hi23 * rl2 + Hi33 * rl3 - dot(P3, ab);
 
-  c.phase();
+  c.phase(3);
   // ---- unconstrained velocity
   V wbs = L.wb + dt * ab.a, vbs = L.vb + dt * ab.l;
   F qds1 = L.qd[0] + dt * qdd1, qds2 = L.qd[1] + dt * qdd2, qds3 = L.qd[2] + dt * qdd3;
 
-  c.phase();
+  c.phase(4);
   // ---- foot contact (sphere vs ground)
   V fw = {L.p.x + dot(Rw.r0, pf), L.p.y + dot(Rw.r1, pf), L.p.z + dot(Rw.r2, pf)};
-  F hgt, nwx, nwy, nwz;
-  c.terrain(K, fw.x, fw.y, hgt, nwx, nwy, nwz);
-  F phi = (fw.z - hgt) * nwz - F(K.foot_radius);
+  F phi;
+  V dn, d1, d2;
+  if (Ctx::kFlat) {
+    // plane z = 0: n = z_w, t1 = x_w, t2 = y_w -> in base coordinates the rows of R
+    phi = fw.z - F(K.foot_radius);
+    dn = Rw.r2; d1 = Rw.r0; d2 = Rw.r1;
+  } else {
+    F hgt, nwx, nwy, nwz;
+    c.terrain(K, fw.x, fw.y, hgt, nwx, nwy, nwz);
+    phi = (fw.z - hgt) * nwz - F(K.foot_radius);
+    // contact frame in world: n, t1 = normalised (x_w - (x_w.n) n), t2 = n x t1; then to base coords
+    V nw = {nwx, nwy, nwz};
+    V t1w = {one - nwx * nwx, -(nwx * nwy), -(nwx * nwz)};
+    F it1 = rsqrt_(dot(t1w, t1w));
+    t1w = it1 * t1w;
+    V t2w = cross(nw, t1w);
+    dn = {Rw.r0.x * nw.x + Rw.r1.x * nw.y + Rw.r2.x * nw.z, Rw.r0.y * nw.x + Rw.r1.y * nw.y + Rw.r2.y * nw.z,
+          Rw.r0.z * nw.x + Rw.r1.z * nw.y + Rw.r2.z * nw.z};
+    d1 = {Rw.r0.x * t1w.x + Rw.r1.x * t1w.y + Rw.r2.x * t1w.z, Rw.r0.y * t1w.x + Rw.r1.y * t1w.y + Rw.r2.y * t1w.z,
+          Rw.r0.z * t1w.x + Rw.r1.z * t1w.y + Rw.r2.z * t1w.z};
+    d2 = {Rw.r0.x * t2w.x + Rw.r1.x * t2w.y + Rw.r2.x * t2w.z, Rw.r0.y * t2w.x + Rw.r1.y * t2w.y + Rw.r2.y * t2w.z,
+          Rw.r0.z * t2w.x + Rw.r1.z * t2w.y + Rw.r2.z * t2w.z};
+  }
   auto act = phi < F(K.margin);
   F actf = sel_(act, one, zero);
-  // contact frame in world: n, t1 = normalised (x_w - (x_w.n) n), t2 = n x t1; then to base coords
-  V nw = {nwx, nwy, nwz};
-  V t1w = {one - nwx * nwx, -(nwx * nwy), -(nwx * nwz)};
-  F it1 = rsqrt_(dot(t1w, t1w));
-  t1w = it1 * t1w;
-  V t2w = cross(nw, t1w);
-  V dn = {Rw.r0.x * nw.x + Rw.r1.x * nw.y + Rw.r2.x * nw.z, Rw.r0.y * nw.x + Rw.r1.y * nw.y + Rw.r2.y * nw.z,
-          Rw.r0.z * nw.x + Rw.r1.z * nw.y + Rw.r2.z * nw.z};
-  V d1 = {Rw.r0.x * t1w.x + Rw.r1.x * t1w.y + Rw.r2.x * t1w.z, Rw.r0.y * t1w.x + Rw.r1.y * t1w.y + Rw.r2.y * t1w.z,
-          Rw.r0.z * t1w.x + Rw.r1.z * t1w.y + Rw.r2.z * t1w.z};
-  V d2 = {Rw.r0.x * t2w.x + Rw.r1.x * t2w.y + Rw.r2.x * t2w.z, Rw.r0.y * t2w.x + Rw.r1.y * t2w.y + Rw.r2.y * t2w.z,
-          Rw.r0.z * t2w.x + Rw.r1.z * t2w.y + Rw.r2.z * t2w.z};
   V rc = pf - F(K.foot_radius) * dn;
   V k1 = cross(xax, rc - o1), k2 = cross(yax, rc - o2), k3 = cross(yax, rc - o3);
   V dir[3] = {dn, d1, d2};
@@ -339,7 +347,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* 
     fwd6(s, g6);
     Z[d] = {{g6[0] * sq[0], g6[1] * sq[1], g6[2] * sq[2]}, {g6[3] * sq[3], g6[4] * sq[4], g6[5] * sq[5]}};
   }
-  c.phase();
+  c.phase(5);
   // Delassus blocks A[j] = Z_mine^T Z_j (+ local leg compliance on the own block)
   F A[4][3][3];
 #pragma unroll
@@ -366,7 +374,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* 
     for (int e = 0; e < 3; e++)
       Aown[d][e] = sel_(c.lane_is(0), A[0][d][e], sel_(c.lane_is(1), A[1][d][e], sel_(c.lane_is(2), A[2][d][e], A[3][d][e])));
   F iA0 = sel_(act, rcp_(Aown[0][0]), zero), iA1 = sel_(act, rcp_(Aown[1][1]), zero), iA2 = sel_(act, rcp_(Aown[2][2]), zero);
-  c.phase();
+  c.phase(6);
   // contact-point velocity under the unconstrained motion
   V vc = vbs + cross(wbs, rc) + qds1 * k1 + qds2 * k2 + qds3 * k3;
   F u0 = actf * dot(dn, vc), u1 = actf * dot(d1, vc), u2 = actf * dot(d2, vc);
@@ -381,35 +389,39 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* 
     u1 = u1 + A[j][1][0] * b0 + A[j][1][1] * b1 + A[j][1][2] * b2;
     u2 = u2 + A[j][2][0] * b0 + A[j][2][1] * b1 + A[j][2][2] * b2;
   }
-  c.phase();
-  // ---- projected Gauss-Seidel: feet in lane order, rows (n, t1, t2), disc projection
+  c.phase(7);
+  // ---- projected Gauss-Seidel: feet in lane order, rows (n, t1, t2), disc projection.
+  // The serial chain of a turn is what bounds this loop, so the row updates are written with the
+  // impulse history folded into per-lane constants (k10 = A10/A11, ...):
+  //   ln  = max(0, l0 - (u0 - tgt)/A00)
+  //   lt1 = l1 - (u1 + A10 (ln - l0))/A11                    (sequential within the foot)
+  //   lt2 = l2 - (u2 + A20 (ln - l0) + A21 (lt1 - l1))/A22
+  //   (lt1, lt2) *= min(1, mu ln / |lt|)
+  // and lane j's raw deltas are broadcast unmasked: an inactive foot has iA = 0 and l = 0, which
+  // makes its deltas exact zeros.
   const F mu = c.par(PR_MU);
+  const F k10 = Aown[1][0] * iA1, k20 = Aown[2][0] * iA2, k21 = Aown[2][1] * iA2, c0 = tgt * iA0;
+  F own[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) own[j] = sel_(c.lane_is(j), one, zero);
   for (int it = 0; it < K.iters; it++) {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-      F ln = fmaxf_(zero, l0 - (u0 - tgt) * iA0);
-      F dln = ln - l0;
-      F u1p = u1 + Aown[1][0] * dln;
-      F lt1 = l1 - u1p * iA1;
-      F d1l = lt1 - l1;
-      F u2p = u2 + Aown[2][0] * dln + Aown[2][1] * d1l;
-      F lt2 = l2 - u2p * iA2;
-      F lim = mu * ln;
-      F nt2 = lt1 * lt1 + lt2 * lt2;
-      auto over = nt2 > lim * lim;
-      F sc = sel_(over, lim * rsqrt_(fmaxf_(nt2, F(1e-30f))), one);
-      lt1 = lt1 * sc;
-      lt2 = lt2 * sc;
-      auto mine = c.lane_is(j) && act;
-      F e0 = sel_(mine, ln - l0, zero), e1 = sel_(mine, lt1 - l1, zero), e2 = sel_(mine, lt2 - l2, zero);
-      l0 = l0 + e0; l1 = l1 + e1; l2 = l2 + e2;
+      F ln = fmaxf_(zero, (l0 + c0) - u0 * iA0);
+      F q1 = (l1 - u1 * iA1) + k10 * l0;
+      F lt1 = q1 - k10 * ln;
+      F q2 = ((l2 - u2 * iA2) + k20 * l0) + k21 * l1;
+      F lt2 = (q2 - k20 * ln) - k21 * lt1;
+      F sc = fminf_(one, (mu * ln) * rsqrt_(fmaxf_(lt1 * lt1 + lt2 * lt2, F(1e-30f))));
+      F e0 = ln - l0, e1 = lt1 * sc - l1, e2 = lt2 * sc - l2;
       F b0 = c.qbcast(e0, j), b1 = c.qbcast(e1, j), b2 = c.qbcast(e2, j);
       u0 = u0 + A[j][0][0] * b0 + A[j][0][1] * b1 + A[j][0][2] * b2;
       u1 = u1 + A[j][1][0] * b0 + A[j][1][1] * b1 + A[j][1][2] * b2;
       u2 = u2 + A[j][2][0] * b0 + A[j][2][1] * b1 + A[j][2][2] * b2;
+      l0 = l0 + own[j] * e0; l1 = l1 + own[j] * e1; l2 = l2 + own[j] * e2;  // the owner commits
     }
   }
-  c.phase();
+  c.phase(8);
   // ---- apply impulses: base via the Schur factor, leg via H^-1
   W zs = l0 * Z[0] + l1 * Z[1] + l2 * Z[2];
   F db[6] = {c.qsum(zs.a.x) * sq[0], c.qsum(zs.a.y) * sq[1], c.qsum(zs.a.z) * sq[2],
@@ -424,7 +436,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* 
   L.lam[0] = l0; L.lam[1] = l1; L.lam[2] = l2;
   L.contact = sel_(act && (l0 > zero), one, zero);
 
-  c.phase();
+  c.phase(9);
   // ---- semi-implicit Euler on positions
 #pragma unroll
   for (int j = 0; j < 3; j++) L.q[j] = L.q[j] + dt * L.qd[j];
@@ -610,9 +622,13 @@ ETG_HD FootKin<F> foot_kin(const Ctx& c, const KCfg& K, const LaneState<F>& L) {
   k.fwx = L.p.x + dot(Rw.r0, pf);
   k.fbz = pf.z;
   F kx = L.p.x + dot(Rw.r0, o3), ky = L.p.y + dot(Rw.r1, o3), kz = L.p.z + dot(Rw.r2, o3);
-  F hgt, nx, ny, nz;
-  c.terrain(K, kx, ky, hgt, nx, ny, nz);
-  k.knee_h = kz - hgt;
+  if (Ctx::kFlat) {
+    k.knee_h = kz;
+  } else {
+    F hgt, nx, ny, nz;
+    c.terrain(K, kx, ky, hgt, nx, ny, nz);
+    k.knee_h = kz - hgt;
+  }
   return k;
 }
 

@@ -36,7 +36,19 @@ struct GpuCtx {
   __device__ __forceinline__ void ring_fence() const {}
   // phase boundary: keep the machine scheduler from interleaving whole phases of the tick
   // (it otherwise stretches live ranges to >500 registers and spills)
-  __device__ __forceinline__ void phase() const { __builtin_amdgcn_sched_barrier(0); }
+  __device__ __forceinline__ void phase(int id) const {
+    __builtin_amdgcn_sched_barrier(0);
+#ifdef ETG_PROFILE_PHASES  // tools/phase_profile.py: per-phase s_memtime deltas of one wave
+    long long t = clock64();
+    prof[id] += t - prof_last;
+    prof_last = t;
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+#ifdef ETG_PROFILE_PHASES
+  mutable long long prof[16];
+  mutable long long prof_last;
+#endif
   __device__ __forceinline__ void st_row_env(float* p, int rowlen, int col, float v) const { if (lane == 0) p[(size_t)env * rowlen + col] = v; }
   __device__ __forceinline__ void st_row_lane(float* p, int rowlen, int col0, int stride, float v) const { p[(size_t)env * rowlen + col0 + stride * lane] = v; }
   __device__ __forceinline__ float ld_row_env(const float* p, int rowlen, int col) const { return p[(size_t)env * rowlen + col]; }
@@ -66,6 +78,9 @@ struct GpuCtx {
     else heightfield_query(K, x, y, h, nx, ny, nz);
   }
 };
+
+// FLAT selects the plane-z=0 fast path at compile time (contact frame = rows of R, no terrain lookup)
+template <bool FLAT> struct GpuCtxT : GpuCtx { static constexpr bool kFlat = FLAT; };
 
 __device__ __forceinline__ bool make_ctx(const KCfg& K, GpuCtx& c) {
   c.gid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -105,8 +120,9 @@ __global__ void __launch_bounds__(BLOCK) k_set_params(KCfg K, ModelF M, DevState
   if (b && c.lane < 3) D.etgp[(size_t)(EP_B + c.lane) * c.N + c.env] = b[(per_env ? (size_t)c.env * 3 : 0) + c.lane];
 }
 
+template <bool FLAT>
 __global__ void __launch_bounds__(BLOCK) k_reset(KCfg K, DevState D, const uint8_t* mask, float* obs) {
-  GpuCtx c;
+  GpuCtxT<FLAT> c;
   if (!make_ctx(K, c)) return;
   if (mask && !mask[c.env]) return;
   __shared__ float lds_par[PR_N * BLOCK];
@@ -116,9 +132,10 @@ __global__ void __launch_bounds__(BLOCK) k_reset(KCfg K, DevState D, const uint8
   store_state(c, D.base, D.leg, L);
 }
 
+template <bool FLAT>
 __global__ void __launch_bounds__(BLOCK) k_step(KCfg K, DevState D, const float* action, const uint8_t* donef, float* obs,
                                                  float* reward, uint8_t* done, float* info) {
-  GpuCtx c;
+  GpuCtxT<FLAT> c;
   if (!make_ctx(K, c)) return;
   __shared__ float lds_par[PR_N * BLOCK];
   stage_params(c, D, lds_par);
@@ -127,9 +144,20 @@ __global__ void __launch_bounds__(BLOCK) k_step(KCfg K, DevState D, const float*
 #pragma unroll
   for (int j = 0; j < 3; j++) act[j] = action ? c.ld_row_lane(action, ETG_ACT_DIM, j, 3) : 0.0f;
   float r, d;
+#ifdef ETG_PROFILE_PHASES
+  for (int k = 0; k < 16; k++) c.prof[k] = 0;
+  c.prof_last = clock64();
+  long long t_begin = c.prof_last;
+#endif
   control_step(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, act, donef ? (float)donef[c.env] : 0.0f, obs, r, d,
                info);
   store_state(c, D.base, D.leg, L);
+#ifdef ETG_PROFILE_PHASES
+  if (c.gid == 0 && info) {  // overwrite the first info row with the cycle breakdown (debug build only)
+    for (int k = 0; k < 16; k++) info[k] = (float)c.prof[k];
+    info[16] = (float)(clock64() - t_begin);
+  }
+#endif
   if (c.lane == 0) {
     reward[c.env] = r;
     done[c.env] = d > 0.5f ? 1 : 0;
@@ -145,13 +173,13 @@ __global__ void k_episode_stats(KCfg K, DevState D, float* ret, int* len) {
 }
 
 __global__ void __launch_bounds__(BLOCK) k_get_state(KCfg K, DevState D, float* st) {
-  GpuCtx c;
+  GpuCtxT<true> c;
   if (!make_ctx(K, c)) return;
   LaneState<float> L = load_state<float>(c, D.base, D.leg);
   get_state_quad(c, L, st);
 }
 __global__ void __launch_bounds__(BLOCK) k_set_state(KCfg K, DevState D, const float* st) {
-  GpuCtx c;
+  GpuCtxT<true> c;
   if (!make_ctx(K, c)) return;
   LaneState<float> L;
   set_state_quad(c, st, L, D.ring, D.ctl, D.ictl);
@@ -272,7 +300,10 @@ extern "C" int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* st
   CHECK_HANDLE(h);
   if (!obs) return fail(ETG_ERR_BAD_ARG, "etg_reset: obs is null");
   if (h->K.terrain == 1 && !h->K.hf) return fail(ETG_ERR_STATE, "etg_reset: heightfield not set");
-  hipLaunchKernelGGL(k_reset, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, mask, obs);
+  if (h->K.terrain == 0)
+    hipLaunchKernelGGL(k_reset<true>, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, mask, obs);
+  else
+    hipLaunchKernelGGL(k_reset<false>, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, mask, obs);
   HIP_TRY(hipGetLastError());
   return ETG_OK;
 }
@@ -281,8 +312,12 @@ extern "C" int etg_step(EtgHandle* h, const float* action, const uint8_t* donef,
                         uint8_t* done, float* info, void* stream) {
   CHECK_HANDLE(h);
   if (!obs || !reward || !done) return fail(ETG_ERR_BAD_ARG, "etg_step: obs/reward/done must be non-null");
-  hipLaunchKernelGGL(k_step, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, action, donef, obs,
-                     reward, done, info);
+  if (h->K.terrain == 0)
+    hipLaunchKernelGGL(k_step<true>, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, action, donef,
+                       obs, reward, done, info);
+  else
+    hipLaunchKernelGGL(k_step<false>, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, action, donef,
+                       obs, reward, done, info);
   HIP_TRY(hipGetLastError());
   return ETG_OK;
 }
@@ -302,8 +337,8 @@ extern "C" int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float
   if (n_steps <= 0 || !ret || !len) return fail(ETG_ERR_BAD_ARG, "etg_rollout_openloop: bad arguments");
   for (int k = 0; k < n_steps; k++) {
     float* o = (obs && k == n_steps - 1) ? obs : h->tmp_obs;
-    hipLaunchKernelGGL(k_step, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, (const float*)nullptr,
-                       (const uint8_t*)nullptr, o, h->tmp_reward, h->tmp_done, (float*)nullptr);
+    int rc = etg_step(h, nullptr, nullptr, o, h->tmp_reward, h->tmp_done, nullptr, stream);
+    if (rc != ETG_OK) return rc;
   }
   HIP_TRY(hipGetLastError());
   return etg_episode_stats(h, ret, len, stream);

@@ -42,7 +42,7 @@ inline void sincos_(F4 a, F4& s, F4& c) { for (int i = 0; i < 4; i++) { s.v[i] =
 #include "../../paddlerobotics_amd/csrc/etg_core.h"
 
 namespace etg {
-struct EmuCtx {
+struct EmuCtxBase {
   int env, N;
   const float* parp;
   F4 par(int k) const { return ld_lane(parp, k); }
@@ -56,7 +56,7 @@ struct EmuCtx {
   void st_ring(float* r, int slot, int k, F4 v) const { for (int l = 0; l < 4; l++) r[((size_t)slot * 8 + k) * NL() + 4 * env + l] = v.v[l]; }
   F4 ld_ring(const float* r, int slot, int k) const { F4 o; for (int l = 0; l < 4; l++) o.v[l] = r[((size_t)slot * 8 + k) * NL() + 4 * env + l]; return o; }
   void ring_fence() const {}
-  void phase() const {}
+  void phase(int) const {}
   void st_row_env(float* p, int rowlen, int col, F4 v) const { p[(size_t)env * rowlen + col] = v.v[0]; }
   void st_row_lane(float* p, int rowlen, int col0, int stride, F4 v) const { for (int l = 0; l < 4; l++) p[(size_t)env * rowlen + col0 + stride * l] = v.v[l]; }
   F4 ld_row_env(const float* p, int rowlen, int col) const { return F4(p[(size_t)env * rowlen + col]); }
@@ -74,6 +74,12 @@ struct EmuCtx {
     }
   }
 };
+
+template <bool FLAT> struct EmuCtxT : EmuCtxBase {
+  static constexpr bool kFlat = FLAT;
+  EmuCtxT(int e, int n, const float* p) { env = e; N = n; parp = p; }
+};
+typedef EmuCtxT<false> EmuCtx;   // generic-terrain instantiation; the flat fast path is EmuCtxT<true>
 
 struct Emu {
   KCfg K;
@@ -124,23 +130,35 @@ extern "C" void emu_reset(void* h, const uint8_t* mask, float* obs) {
   Emu* e = (Emu*)h;
   for (int i = 0; i < e->N; i++) {
     if (mask && !mask[i]) continue;
-    EmuCtx c{i, e->N, e->par.data()};
     LaneState<F4> L;
-    reset_quad(c, e->K, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs);
-    store_state(c, e->base.data(), e->leg.data(), L);
+    if (e->K.terrain == 0) {
+      EmuCtxT<true> c(i, e->N, e->par.data());
+      reset_quad(c, e->K, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs);
+      store_state(c, e->base.data(), e->leg.data(), L);
+    } else {
+      EmuCtxT<false> c(i, e->N, e->par.data());
+      reset_quad(c, e->K, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs);
+      store_state(c, e->base.data(), e->leg.data(), L);
+    }
   }
 }
 extern "C" void emu_step(void* h, const float* action, const uint8_t* donef, float* obs, float* reward, uint8_t* done, float* info) {
   Emu* e = (Emu*)h;
   for (int i = 0; i < e->N; i++) {
-    EmuCtx c{i, e->N, e->par.data()};
-    LaneState<F4> L = load_state<F4>(c, e->base.data(), e->leg.data());
+    EmuCtx c0(i, e->N, e->par.data());
+    LaneState<F4> L = load_state<F4>(c0, e->base.data(), e->leg.data());
     F4 act[3];
-    for (int j = 0; j < 3; j++) act[j] = c.ld_row_lane(action, 12, j, 3);
+    for (int j = 0; j < 3; j++) act[j] = c0.ld_row_lane(action, 12, j, 3);
     F4 r, d;
-    control_step(c, e->K, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), act,
-                 F4(donef ? (float)donef[i] : 0.f), obs, r, d, info);
-    store_state(c, e->base.data(), e->leg.data(), L);
+    if (e->K.terrain == 0) {
+      EmuCtxT<true> c(i, e->N, e->par.data());
+      control_step(c, e->K, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), act,
+                   F4(donef ? (float)donef[i] : 0.f), obs, r, d, info);
+    } else {
+      control_step(c0, e->K, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), act,
+                   F4(donef ? (float)donef[i] : 0.f), obs, r, d, info);
+    }
+    store_state(c0, e->base.data(), e->leg.data(), L);
     reward[i] = r.v[0];
     done[i] = d.v[0] > 0.5f;
   }
@@ -148,7 +166,7 @@ extern "C" void emu_step(void* h, const float* action, const uint8_t* donef, flo
 extern "C" void emu_get_state(void* h, float* st) {
   Emu* e = (Emu*)h;
   for (int i = 0; i < e->N; i++) {
-    EmuCtx c{i, e->N, e->par.data()};
+    EmuCtx c(i, e->N, e->par.data());
     LaneState<F4> L = load_state<F4>(c, e->base.data(), e->leg.data());
     get_state_quad(c, L, st);
   }
@@ -156,7 +174,7 @@ extern "C" void emu_get_state(void* h, float* st) {
 extern "C" void emu_set_state(void* h, const float* st) {
   Emu* e = (Emu*)h;
   for (int i = 0; i < e->N; i++) {
-    EmuCtx c{i, e->N, e->par.data()};
+    EmuCtx c(i, e->N, e->par.data());
     LaneState<F4> L;
     set_state_quad(c, st, L, e->ring.data(), e->ctl.data(), e->ictl.data());
     store_state(c, e->base.data(), e->leg.data(), L);
@@ -165,7 +183,7 @@ extern "C" void emu_set_state(void* h, const float* st) {
 // checks that the replicated base state is bit-identical across a quad's lanes after a tick
 extern "C" int emu_tick_replication_check(void* h, int env, int nticks) {
   Emu* e = (Emu*)h;
-  EmuCtx c{env, e->N, e->par.data()};
+  EmuCtxT<true> c(env, e->N, e->par.data());
   LaneState<F4> L = load_state<F4>(c, e->base.data(), e->leg.data());
   F4 qdes[3] = {c.par(PR_POSE), c.par(PR_POSE + 1), c.par(PR_POSE + 2)};
   int bad = 0;

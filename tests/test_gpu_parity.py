@@ -257,3 +257,45 @@ def test_bad_arguments_raise():
     with pytest.raises(ValueError):
         env.set_dynamic_param(np.zeros((4, 47)))
     env.close()
+
+
+def test_heightfield_terrain_matches_oracle():
+    """BASELINE config 5 terrain (256x256, 0.05 m cells, heights U(0,0.05), default_rng(0))."""
+    _need_gpu()
+    n = 16
+    rng = np.random.default_rng(0)
+    hf = dict(heights=rng.uniform(0, 0.05, size=(256, 256)).astype(np.float32), cell=0.05, origin=(-6.4, -6.4))
+    W, B = _etg_params(n, seed=13)
+    env = _make(n, task="heightfield", heightfield=hf)
+    orc = _oracle(n, terrain=1, heightfield=hf)
+    orc.set_heightfield(hf["heights"])
+    orc.set_params(etg_w=W, etg_b=B)
+    env.reset(ETG_w=W, ETG_b=B)
+    orc.reset()
+    assert np.abs(env.get_state().cpu().numpy()[:, :7] - orc.get_state()[:, :7]).max() < 2e-3
+    assert orc.get_state()[:, 2].min() > 0.2
+    for _ in range(5):
+        env.step(None)
+        orc.step(np.zeros((n, 12)))
+    err = np.abs(env.get_state().cpu().numpy()[:, 13:25] - orc.get_state()[:, 13:25]).max(1)
+    assert np.median(err) < 2e-3 and err.max() < 2e-2      # C0 terrain: normals jump at cell edges
+    env.close()
+
+
+def test_es_generation_on_gpu_improves_fitness():
+    _need_gpu()
+    from paddlerobotics_amd.es import SimpleGA
+    from paddlerobotics_amd.etg import ETG_layer, Opt_with_points
+    from paddlerobotics_amd import rollout as R
+    n = 256
+    env = _make(n)
+    layer = ETG_layer(0.5, 0.026, 20, 0.04, np.array([-np.pi / 2, 0]), 0.2, 0.5)
+    w0, b0, prior = Opt_with_points(layer, ETG_T=0.5, Footheight=0.1, Steplength=0.05)
+    ga = SimpleGA(12, sigma_init=0.02, sigma_decay=0.99, sigma_limit=0.005, elite_ratio=0.1, weight_decay=0.005,
+                  popsize=n, param=np.zeros(12), device="cuda:0", seed=0)
+    ev = R.make_etg_evaluator(env, layer, 0.5, prior, w0, b0, max_step=150)
+    f0 = R.es_generation(ga, ev).mean().item()
+    for _ in range(3):
+        f = R.es_generation(ga, ev).mean().item()
+    assert f > f0
+    env.close()

@@ -1,0 +1,17 @@
+"""Per-phase cycle breakdown of one wave of k_step (debug build with -DETG_PROFILE_PHASES)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ["ETG_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_variants", "lib_prof.so")
+import numpy as np, torch
+from paddlerobotics_amd.env import make_env
+env = make_env("Quadrupedal", num_envs=4096, device="cuda:0")
+env.reset()
+for _ in range(20): env.step(None)
+env.step(None, want_info=True); torch.cuda.synchronize()
+row = env.info_buf[0].cpu().numpy()
+names = ["0 integ+ring+PD+trig+links", "1 RNEA", "2 CRBA/Hinv/P", "3 Schur+LDL+solve", "4 v*+contact setup+Z", "5 Delassus A", "6 u init/warm", "7 PGS", "8 apply impulses", "9 -", "10 -"]
+tot = row[16]
+print("total cycles per control step (wave 0): %.0f  (%.1f us at 2.4 GHz)" % (tot, tot / 2400))
+for k in range(10):
+    print("  after-phase %-24s %9.0f cycles  %5.1f %%  (%.0f per tick)" % (names[k], row[k], 100 * row[k] / tot, row[k] / 13))
+print("  outside ticks          %9.0f cycles  %5.1f %%" % (tot - row[:10].sum(), 100 * (tot - row[:10].sum()) / tot))
