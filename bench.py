@@ -27,6 +27,7 @@ from paddlerobotics_amd import a1_model as A  # noqa: E402
 from paddlerobotics_amd.etg import ETG_layer, Opt_with_points  # noqa: E402
 from paddlerobotics_amd.etg_fit import opt_with_points_batched  # noqa: E402
 
+SOLVER_ITERS = 2           # library default (K=2 vs K=50 differ by <0.4 mm after 5 m)
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
 BYTES_PER_STEP_CFG2 = 816  # 564 B + 252 B per-env ETG w,b
 BYTES_PER_STEP_CFG3 = 808 + 252
@@ -45,7 +46,7 @@ def etg_population(n, seed, device):
 def cpu_baseline(n_envs, steps, threads):
     """The CPU oracle (port of the path, fp64 like stock pybullet) on a bounded sample."""
     from oracle.oracle import OracleSim
-    cfg = A.default_config(n_envs, solver_iters=4)
+    cfg = A.default_config(n_envs, solver_iters=SOLVER_ITERS)
     sim = OracleSim(cfg, threads=threads)
     w, b = etg_population(n_envs, 0, "cpu")
     sim.set_params(etg_w=w.double().numpy(), etg_b=b.double().numpy())
@@ -66,8 +67,11 @@ def main():
     ap.add_argument("--num-envs", type=int, default=4096, help="robots per GPU")
     ap.add_argument("--config", type=int, default=2, choices=(2, 3))
     ap.add_argument("--precision", type=int, default=0, help="policy MFMA: 0 fp32, 1 bf16")
+    ap.add_argument("--solver-iters", type=int, default=SOLVER_ITERS, help="PGS sweeps per tick")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
+    global SOLVER_ITERS
+    SOLVER_ITERS = args.solver_iters
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -85,7 +89,7 @@ def main():
     from paddlerobotics_amd.env import make_env
     from paddlerobotics_amd.policy import MfmaPolicy
     N = args.num_envs
-    env = make_env("Quadrupedal", num_envs=N, device=str(dev), solver_iters=4)
+    env = make_env("Quadrupedal", num_envs=N, device=str(dev), solver_iters=args.solver_iters)
     w, b = etg_population(N, seed=rank, device=dev)
     env.reset(ETG_w=w, ETG_b=b)
     policy = None
@@ -153,7 +157,7 @@ def main():
                                     "params = prior + N(0,0.02^2)" % N) if args.config == 2 else
                        ("configs[2]: %d parallel A1 per GPU, flat, ETG + residual MLP policy (random init, "
                         "precision %d)" % (N, args.precision)),
-                       "robots_per_gpu": N, "action_repeat": 13, "sim_dt": 0.002, "solver_iters": 4,
+                       "robots_per_gpu": N, "action_repeat": 13, "sim_dt": 0.002, "solver_iters": args.solver_iters,
                        "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "etg::k_step", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,

@@ -163,7 +163,7 @@ def butter2_lowpass(fc, fs):
     return (b0, 2 * b0, b0), (1.0, 2 * (k * k - 1) * norm, (1 - k / q + k * k) * norm)
 
 
-def default_config(num_envs, *, action_repeat=13, sim_dt=0.002, settle_ticks=500, solver_iters=8,
+def default_config(num_envs, *, action_repeat=13, sim_dt=0.002, settle_ticks=500, solver_iters=2,
                    enable_action_interp=False, enable_action_filter=False, normal=1, terrain=0,
                    erp=0.2, contact_margin=0.02, warmstart=0.85, torque_limit=0.0,
                    ETG_T=0.5, ETG_T2=0.5, etg_amp=0.2, etg_sigma_sq=0.04,

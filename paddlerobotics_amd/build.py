@@ -35,8 +35,11 @@ def build(force=False, verbose=False):
     # -fno-slp-vectorize: the SLP vectoriser otherwise packs the scalar 3-vector algebra into
     # v_pk_*_f32 pairs, which costs ~900 v_mov + ~450 accvgpr moves per tick and 500+ registers
     # (measured: 373 -> 282 registers, 45% fewer instructions; DESIGN.md "register pressure")
+    # -fno-signed-zeros -ffinite-math-only: lets the compiler fold the x*0 / x*1 terms that the
+    # structured link frames (axes (1,0,0), (0,c,s)) put into the generic vector algebra (-6 %
+    # instructions); NaN guards use an exponent bit test, IK validity an explicit domain test.
     cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-slp-vectorize", "-Wno-unused-value", "-o", LIB] + srcs
+           "-fno-slp-vectorize", "-fno-signed-zeros", "-ffinite-math-only", "-Wno-unused-value", "-o", LIB] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

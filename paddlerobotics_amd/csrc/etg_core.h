@@ -193,10 +193,11 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* 
   }
 
   // ---- leg kinematics in the base frame
-  F sa, ca, sh, ch, shk, chk;
+  F sa, ca, sh, ch, sk, ck;
   sincos_(L.q[0], sa, ca);
   sincos_(L.q[1], sh, ch);
-  sincos_(L.q[1] + L.q[2], shk, chk);
+  sincos_(L.q[2], sk, ck);
+  const F shk = sh * ck + ch * sk, chk = ch * ck - sh * sk;  // angle addition instead of a third sincos
   Fr<F> R1 = {{one, zero, zero}, {zero, ca, sa}, {zero, -sa, ca}};
   Fr<F> R2 = {{ch, sa * sh, -(ca * sh)}, {zero, ca, sa}, {sh, -(sa * ch), ca * ch}};
   Fr<F> R3 = {{chk, sa * shk, -(ca * shk)}, {zero, ca, sa}, {shk, -(sa * chk), ca * chk}};
@@ -496,20 +497,27 @@ ETG_HD Delayed<F> ring_read(const Ctx& c, const float* ring, int tick) {
 }
 
 // ------------------------------------------------------------------ ETG + IK
-// a1.py:97-110
-template <class F> ETG_HD void leg_ik(V3<F> foot, F sign, F* ang) {
-  const F l_up(0.2f), l_low(0.2f);
+// a1.py:97-110.  The reference detects an unreachable target through the NaN that arccos/arcsin
+// return outside [-1,1]; here the domain test is explicit (same predicate, no reliance on NaN
+// propagation) and the arguments are clamped so the functions stay in-domain.
+template <class F, class B> ETG_HD void leg_ik(V3<F> foot, F sign, F* ang, B& valid) {
+  const F l_up(0.2f), l_low(0.2f), one(1.0f);
   F l_hip = F(0.08505f) * sign;
   F x = foot.x, y = foot.y, z = foot.z;
-  F theta_knee = -acos_((x * x + y * y + z * z - l_hip * l_hip - l_low * l_low - l_up * l_up) / (F(2.0f) * l_low * l_up));
-  F l = sqrt_(l_up * l_up + l_low * l_low + F(2.0f) * l_up * l_low * cos_(theta_knee));
-  F theta_hip = asin_(-x / l) - theta_knee * F(0.5f);
+  F ck = (x * x + y * y + z * z - l_hip * l_hip - l_low * l_low - l_up * l_up) / (F(2.0f) * l_low * l_up);
+  F ckc = fminf_(fmaxf_(ck, -one), one);
+  F theta_knee = -acos_(ckc);
+  F l = sqrt_(fmaxf_(l_up * l_up + l_low * l_low + F(2.0f) * l_up * l_low * cos_(theta_knee), F(1e-12f)));
+  F sarg = -x / l;
+  F sargc = fminf_(fmaxf_(sarg, -one), one);
+  F theta_hip = asin_(sargc) - theta_knee * F(0.5f);
   F cc = cos_(theta_hip + theta_knee * F(0.5f));
   F c1 = l_hip * y - l * cc * z;
   F s1 = l * cc * y + l_hip * z;
   ang[0] = atan2_(s1, c1);
   ang[1] = theta_hip;
   ang[2] = theta_knee;
+  valid = (fabsf_(ck) <= one) && (fabsf_(sarg) <= one) && isfinite_(ck) && isfinite_(sarg);
 }
 // joint-space ETG action of this lane's leg at time t (minus pose_ori)
 template <class F, class Ctx>
@@ -538,8 +546,8 @@ ETG_HD void etg_action(const Ctx& c, const KCfg& K, const float* etgp, float t, 
   for (int it = 0; it < 200; it++) {
     V3<F> foot = {bfoot.x + ax * scale - o1.x, bfoot.y + ay * scale - o1.y, bfoot.z + az * scale - o1.z};
     F a[3];
-    leg_ik(foot, hipsign, a);
-    auto ok = isfinite_(a[0]) && isfinite_(a[1]) && isfinite_(a[2]);
+    auto ok = pending;
+    leg_ik(foot, hipsign, a, ok);
     auto take = pending && ok;
     ang[0] = sel_(take, a[0], ang[0]); ang[1] = sel_(take, a[1], ang[1]); ang[2] = sel_(take, a[2], ang[2]);
     pending = pending && !ok;

@@ -71,7 +71,13 @@ ETG_HD float tanh_(float a) { return tanhf(a); }
 ETG_HD float acos_(float a) { return acosf(a); }
 ETG_HD float asin_(float a) { return asinf(a); }
 ETG_HD float atan2_(float a, float b) { return atan2f(a, b); }
-ETG_HD bool isfinite_(float a) { return isfinite(a); }
+// bit test, so that -ffinite-math-only (used to fold the x*0 / x*1 terms of the structured frames)
+// cannot optimise the NaN guards away
+ETG_HD bool isfinite_(float a) {
+  unsigned u;
+  __builtin_memcpy(&u, &a, 4);
+  return (u & 0x7f800000u) != 0x7f800000u;
+}
 #if defined(__HIPCC__)
 // Hardware 1-ulp reciprocal / rsqrt / sqrt: the IEEE-exact expansions cost 10-15 dependent
 // instructions each and sit on the serial critical path of the LDL^T and of every PGS turn.

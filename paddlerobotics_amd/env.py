@@ -47,7 +47,7 @@ class BatchedQuadrupedEnv:
                  sensor_mode=None, normal=1, dynamic_param=None, reward_param=None, ETG=1, ETG_T=0.5,
                  reward_p=5.0, ETG_path="", random_param=None, ETG_H=20, vel_d=0.5, step_y=0.05,
                  enable_action_filter=False, ETG_T2=0.5, action_repeat=13, sim_time_step=0.002,
-                 settle_ticks=500, solver_iters=4, enable_action_interpolation=False,
+                 settle_ticks=500, solver_iters=2, enable_action_interpolation=False,
                  heightfield=None, **unused):
         if render:
             raise ValueError("render is not supported by the batched GPU simulator")

@@ -136,3 +136,22 @@ def test_kernel_math_emulation_heightfield_matches_oracle():
         emu.step(np.zeros((n, 12)))
         # the bilinear terrain is only C0: contact normals jump at cell edges, so fp32/fp64 part faster
         assert np.abs(emu.get_state()[:, 13:25] - orc.get_state()[:, 13:25]).max() < 1e-2
+
+
+def test_kernel_math_emulation_ik_guard_unreachable_targets():
+    """ETG offsets that put the foot out of reach exercise the 0.95 shrink loop (SURVEY App. A act_clip)."""
+    from oracle.oracle import OracleSim
+    from tests.emu.emu import EmuSim
+    n = 3
+    cfg = A.default_config(n, settle_ticks=5)
+    W = np.zeros((n, 3, 20))
+    B = np.array([[0.0, 0.0, -0.25], [0.35, 0.0, -0.1], [0.0, 0.0, 0.02]])   # too low / too far / reachable
+    orc, emu = OracleSim(cfg), EmuSim(cfg)
+    for s in (orc, emu):
+        s.set_params(etg_w=W, etg_b=B)
+        s.reset()
+    _, _, _, i1 = orc.step(np.zeros((n, 12)))
+    _, _, _, i2 = emu.step(np.zeros((n, 12)))
+    assert np.all(np.isfinite(i1[:, 9:21])) and np.all(np.isfinite(i2[:, 9:21]))
+    assert np.abs(i2[:, 9:21] - i1[:, 9:21]).max() < 1e-3      # shrink factor changes 5 % per iteration
+    assert np.abs(i1[0, 9:21]).max() > 0.05                      # the guard produced a real (shrunk) action
