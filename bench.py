@@ -60,6 +60,7 @@ def cpu_baseline(n_envs, steps, threads):
 
 
 def main():
+    global SOLVER_ITERS
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
@@ -70,7 +71,6 @@ def main():
     ap.add_argument("--solver-iters", type=int, default=SOLVER_ITERS, help="PGS sweeps per tick")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
-    global SOLVER_ITERS
     SOLVER_ITERS = args.solver_iters
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

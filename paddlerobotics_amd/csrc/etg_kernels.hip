@@ -70,6 +70,15 @@ struct GpuCtx {
       default: return dpp_<0xFF>(a);
     }
   }
+  // acc[i] += a@lane_i * b@this_lane for the 4 lanes of the quad: v_mfma_f32_4x4x1_16b_f32 computes
+  // 16 independent 4x4 outer products per wave64, block b = lanes 4b..4b+3, D[i][j] = A[lane i] *
+  // B[lane j] held at lane j / register i (layout verified on hardware: tools/ubench/mfma4x4.hip)
+  __device__ __forceinline__ void quad_outer(float a, float b, float* acc) const {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 v = {acc[0], acc[1], acc[2], acc[3]};
+    v = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, v, 0, 0, 0);
+    acc[0] = v[0]; acc[1] = v[1]; acc[2] = v[2]; acc[3] = v[3];
+  }
   __device__ __forceinline__ bool lane_is(int j) const { return lane == j; }
   __device__ __forceinline__ bool any(bool b) const { return __any(b); }
   __device__ __forceinline__ int uniform_int(float a) const { return (int)a; }

@@ -64,6 +64,11 @@ struct EmuCtxBase {
   F4 qsum(F4 a) const { return F4((a.v[0] + a.v[1]) + (a.v[2] + a.v[3])); }
   F4 qmax(F4 a) const { return F4(fmaxf(fmaxf(a.v[0], a.v[1]), fmaxf(a.v[2], a.v[3]))); }
   F4 qbcast(F4 a, int j) const { return F4(a.v[j]); }
+  // acc[i] (at lane l) += a@lane_i * b@lane_l   (v_mfma_f32_4x4x1_16b_f32 semantics, one block per quad)
+  void quad_outer(F4 a, F4 b, F4* acc) const {
+    for (int i = 0; i < 4; i++)
+      for (int l = 0; l < 4; l++) acc[i].v[l] = fmaf(a.v[i], b.v[l], acc[i].v[l]);
+  }
   B4 lane_is(int j) const { B4 r; for (int l = 0; l < 4; l++) r.v[l] = (l == j); return r; }
   bool any(B4 b) const { return b.v[0] || b.v[1] || b.v[2] || b.v[3]; }
   int uniform_int(F4 a) const { return (int)a.v[0]; }
