@@ -29,6 +29,10 @@ from paddlerobotics_amd.etg_fit import opt_with_points_batched  # noqa: E402
 
 SOLVER_ITERS = 2           # library default (K=2 vs K=50 differ by <0.4 mm after 5 m)
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
+# HBM bytes per k_step launch at N = 4096 from the PMC counters (profiles/r01_pmc_k_step.txt:
+# FETCH_SIZE + WRITE_SIZE, separate passes, KB units; dword accesses, uncalibrated width -- see
+# DESIGN.md section 7).  Scaled linearly with N for other batch sizes.
+PMC_TRAFFIC_BYTES_AT_4096 = (4800.5 + 3080.0) * 1024.0
 BYTES_PER_STEP_CFG2 = 816  # 564 B + 252 B per-env ETG w,b
 BYTES_PER_STEP_CFG3 = 808 + 252
 
@@ -129,15 +133,16 @@ def main():
             ev[k][0].record()
             env.step(None, want_info=False)
             ev[k][1].record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    # episode returns / lengths were accumulated inside the step kernel (alive-masked)
+    # episode returns / lengths were accumulated inside the step kernel (alive-masked); for N > 1 the
+    # one exchange of the path -- all_gather of the returns (configs[3]; cf. the xparl scatter/gather
+    # of model/Dynamic_parallel_model.py:157-160) -- is part of the timed region
     ret, length = env.episode_stats()
     if dist is not None:
-        # the one exchange of the path: gather episode returns (configs[3]; cf. the scatter/gather of
-        # model/Dynamic_parallel_model.py:157-160)
         allret = torch.empty(world * N, device=dev)
         dist.all_gather_into_tensor(allret, ret)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -160,9 +165,11 @@ def main():
                        "robots_per_gpu": N, "action_repeat": 13, "sim_dt": 0.002, "solver_iters": args.solver_iters,
                        "parallelism": "env-shard x%d" % world},
             "roofline": {"bound": "hbm", "kernel": "etg::k_step", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK, "traffic": None,
+                         "unit": "GB/s", "frac": achieved / HBM_PEAK,
+                         "traffic": (PMC_TRAFFIC_BYTES_AT_4096 * N / 4096.0) if PMC_TRAFFIC_BYTES_AT_4096 else None,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": bytes_per,
-                         "note": "VALU-bound by construction (~1e3 FLOP/B, SURVEY 8d); see DESIGN.md"},
+                         "note": "VALU-issue-bound by construction (~1e3 FLOP/B, SURVEY 8d): 256 waves, one per busy "
+                                 "SIMD, 1 VALU issue / 4 cycles; see DESIGN.md section 7"},
             "survivors": float((length == args.steps + args.warmup).float().mean().item()),
         }
         if not args.no_cpu_baseline:

@@ -2,8 +2,8 @@
 # PMC counters of the bench command, one counter group per pass (no trace domains mixed in)
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$R/gpurun_out/pmc_$1
-mkdir -p $OUT
+OUT=/tmp/pmc_$1
+mkdir -p $OUT $R/gpurun_out
 run() { # name counters...
   name=$1; shift
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o pmc -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/$name.log 2>&1 || echo "pass $name failed"
@@ -12,7 +12,7 @@ run fetch FETCH_SIZE
 run write WRITE_SIZE
 run valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES
 run lds SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
-python - <<PY
+python - > $R/gpurun_out/pmc_$1.txt <<PY
 import csv, glob, collections
 for name in ("fetch","write","valu","lds"):
     fs = glob.glob("$OUT/%s/**/*counter_collection.csv" % name, recursive=True)
@@ -24,3 +24,5 @@ for name in ("fetch","write","valu","lds"):
     for k, v in acc.items():
         print("%-24s mean per k_step launch %14.1f  (n=%d)" % (k, sum(v)/len(v), len(v)))
 PY
+mkdir -p $R/gpurun_out
+cat $R/gpurun_out/pmc_$1.txt
