@@ -30,64 +30,75 @@ constexpr int THREADS = 256;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-__device__ __forceinline__ float4 load_w4(const float* w, int n, int nmax, int k, int kdim) {
-  // W[n][k..k+3], zero outside [0,nmax) x [0,kdim); rows are only 4-byte aligned (kdim = 49)
-  float4 v = {0.f, 0.f, 0.f, 0.f};
-  if (n < nmax) {
-    const float* p = w + (size_t)n * kdim + k;
-    if (k + 3 < kdim && ((kdim & 3) == 0)) {
-      v = *reinterpret_cast<const float4*>(p);
-    } else {
-      if (k + 0 < kdim) v.x = p[0];
-      if (k + 1 < kdim) v.y = p[1];
-      if (k + 2 < kdim) v.z = p[2];
-      if (k + 3 < kdim) v.w = p[3];
-    }
-  }
-  return v;
-}
-
 __device__ __forceinline__ __bf16 to_bf16(float x) {  // round to nearest even
   unsigned u = __float_as_uint(x);
   u += 0x7FFFu + ((u >> 16) & 1u);
   unsigned short h = (unsigned short)(u >> 16);
   return __builtin_bit_cast(__bf16, h);
 }
+__device__ __forceinline__ bf16x8 pack_bf16(float4 a, float4 b) {
+  bf16x8 v = {to_bf16(a.x), to_bf16(a.y), to_bf16(a.z), to_bf16(a.w), to_bf16(b.x), to_bf16(b.y), to_bf16(b.z), to_bf16(b.w)};
+  return v;
+}
 
-// out[16][ncols of this wave] = act(in[16][kpad] * W^T + b); W is [nout][kdim]
+// Weights are re-laid out once (etg_policy_load) into MFMA-fragment order so that every wave-level
+// weight fetch is ONE fully coalesced 1-KiB global_load_dwordx4:
+//   packed[((tile * nkb + kb) * 64 + lane) * 4 + c] = W[tile*16 + (lane & 15)][kb*16 + 4*(lane >> 4) + c]
+// (zero outside the matrix).  torch's [out, in] layout stays the API format.
+__global__ void k_pack_weights(const float* __restrict__ w, int nout, int kdim, int ntiles, int nkb, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int total = ntiles * nkb * 64 * 4;
+  if (idx >= total) return;
+  const int c = idx & 3, lane = (idx >> 2) & 63, blk = idx >> 8;
+  const int kb = blk % nkb, tile = blk / nkb;
+  const int n = tile * 16 + (lane & 15), k = kb * 16 + 4 * (lane >> 4) + c;
+  out[idx] = (n < nout && k < kdim) ? w[(size_t)n * kdim + k] : 0.0f;
+}
+
+// out[16][this wave's 64 columns] = relu(in[16][16*nkb] * W^T + b); wp = packed weights of the layer
 template <bool BF16>
-__device__ __forceinline__ void hidden_layer(const float* in, int kpad, const float* w, int kdim, const float* b,
+__device__ __forceinline__ void hidden_layer(const float* in, int nkb, const float4* __restrict__ wp, const float* b,
                                              float* out, int wave, int lane) {
   const int i = lane & 15, g = lane >> 4;
   f32x4 acc[4];
 #pragma unroll
   for (int t = 0; t < 4; t++) acc[t] = {0.f, 0.f, 0.f, 0.f};
+  // tile t of this wave: packed block ((4*wave + t) * nkb + kb); software-pipelined: the next k-block's
+  // fragments are in flight while the MFMAs of the current one issue
+  const float4* base = wp + (size_t)(4 * wave) * nkb * 64 + lane;
+  const int tstride = nkb * 64;
   if (!BF16) {
-    for (int kb = 0; kb < kpad; kb += 16) {
-      const float4 a = *reinterpret_cast<const float4*>(&in[i * HS + kb + 4 * g]);
+    float4 w0[4], w1[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) w0[t] = base[t * tstride];
+    for (int kb = 0; kb < nkb; kb++) {
+      const float4 a = *reinterpret_cast<const float4*>(&in[i * HS + kb * 16 + 4 * g]);
+      if (kb + 1 < nkb) {
+#pragma unroll
+        for (int t = 0; t < 4; t++) w1[t] = base[t * tstride + (kb + 1) * 64];
+      }
 #pragma unroll
       for (int t = 0; t < 4; t++) {
-        const float4 bw = load_w4(w, 64 * wave + 16 * t + i, HID, kb + 4 * g, kdim);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bw.x, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bw.y, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bw.z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bw.w, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w0[t].x, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w0[t].y, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w0[t].z, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w0[t].w, acc[t], 0, 0, 0);
       }
+#pragma unroll
+      for (int t = 0; t < 4; t++) w0[t] = w1[t];
     }
   } else {
-    for (int kb = 0; kb < kpad; kb += 32) {  // kpad is a multiple of 32 on this path
-      const float4 a0 = *reinterpret_cast<const float4*>(&in[i * HS + kb + 8 * g]);
-      const float4 a1 = *reinterpret_cast<const float4*>(&in[i * HS + kb + 8 * g + 4]);
-      bf16x8 av = {to_bf16(a0.x), to_bf16(a0.y), to_bf16(a0.z), to_bf16(a0.w),
-                   to_bf16(a1.x), to_bf16(a1.y), to_bf16(a1.z), to_bf16(a1.w)};
+    // one bf16 MFMA (K = 32) consumes two consecutive 16-wide k-blocks; the k-slot order is free as
+    // long as A and B agree, so lane group g takes k = kb*16 + 4g..4g+3 from each block
+    for (int kb = 0; kb < nkb; kb += 2) {
+      const float4 a0 = *reinterpret_cast<const float4*>(&in[i * HS + kb * 16 + 4 * g]);
+      const float4 a1 = *reinterpret_cast<const float4*>(&in[i * HS + (kb + 1) * 16 + 4 * g]);
+      const bf16x8 av = pack_bf16(a0, a1);
 #pragma unroll
       for (int t = 0; t < 4; t++) {
-        const int n = 64 * wave + 16 * t + i;
-        const float4 b0 = load_w4(w, n, HID, kb + 8 * g, kdim);
-        const float4 b1 = load_w4(w, n, HID, kb + 8 * g + 4, kdim);
-        bf16x8 bv = {to_bf16(b0.x), to_bf16(b0.y), to_bf16(b0.z), to_bf16(b0.w),
-                     to_bf16(b1.x), to_bf16(b1.y), to_bf16(b1.z), to_bf16(b1.w)};
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[t], 0, 0, 0);
+        const float4 b0 = base[t * tstride + kb * 64];
+        const float4 b1 = base[t * tstride + (kb + 1) * 64];
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pack_bf16(b0, b1), acc[t], 0, 0, 0);
       }
     }
   }
@@ -102,17 +113,16 @@ __device__ __forceinline__ void hidden_layer(const float* in, int kpad, const fl
 
 template <bool BF16>
 __global__ void __launch_bounds__(THREADS) k_policy(const float* __restrict__ obs, int n, int in_dim,
-                                                    const float* __restrict__ w1, const float* __restrict__ b1,
-                                                    const float* __restrict__ w2, const float* __restrict__ b2,
-                                                    const float* __restrict__ w3, const float* __restrict__ b3,
+                                                    const float4* __restrict__ w1p, const float* __restrict__ b1,
+                                                    const float4* __restrict__ w2p, const float* __restrict__ b2,
+                                                    const float4* __restrict__ w3p, const float* __restrict__ b3,
                                                     int out_dim, float scale, float* __restrict__ act) {
   __shared__ __attribute__((aligned(16))) float bufA[TM * HS];
   __shared__ __attribute__((aligned(16))) float bufB[TM * HS];
   __shared__ float part[4][TM][16];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int row0 = blockIdx.x * TM;
-  const int kpad1 = BF16 ? ((in_dim + 31) / 32) * 32 : ((in_dim + 15) / 16) * 16;
-  // obs tile -> LDS, zero padded (rows past n, columns past in_dim)
+  // obs tile -> LDS, zero padded (rows past n, columns past in_dim up to the 64-wide padded K)
   for (int idx = tid; idx < TM * 64; idx += THREADS) {
     const int r = idx >> 6, c = idx & 63;
     float v = 0.0f;
@@ -120,20 +130,21 @@ __global__ void __launch_bounds__(THREADS) k_policy(const float* __restrict__ ob
     bufA[r * HS + c] = v;
   }
   __syncthreads();
-  hidden_layer<BF16>(bufA, kpad1, w1, in_dim, b1, bufB, wave, lane);
+  hidden_layer<BF16>(bufA, 4, w1p, b1, bufB, wave, lane);       // K padded to 64 = 4 k-blocks
   __syncthreads();
-  hidden_layer<BF16>(bufB, HID, w2, HID, b2, bufA, wave, lane);
+  hidden_layer<BF16>(bufB, HID / 16, w2p, b2, bufA, wave, lane);
   __syncthreads();
-  // output layer: one 16x16 tile (out_dim <= 16), K split over the 4 waves
+  // output layer: one 16x16 tile (out_dim <= 16), K split over the 4 waves (4 k-blocks each)
   {
     const int i = lane & 15, g = lane >> 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const int k0 = 64 * wave;
+    const float4* base = w3p + lane;
     if (!BF16) {
 #pragma unroll
-      for (int kb = 0; kb < 64; kb += 16) {
-        const float4 a = *reinterpret_cast<const float4*>(&bufA[i * HS + k0 + kb + 4 * g]);
-        const float4 bw = load_w4(w3, i, out_dim, k0 + kb + 4 * g, HID);
+      for (int kk = 0; kk < 4; kk++) {
+        const int kb = 4 * wave + kk;
+        const float4 a = *reinterpret_cast<const float4*>(&bufA[i * HS + kb * 16 + 4 * g]);
+        const float4 bw = base[kb * 64];
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bw.x, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bw.y, acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bw.z, acc, 0, 0, 0);
@@ -141,16 +152,12 @@ __global__ void __launch_bounds__(THREADS) k_policy(const float* __restrict__ ob
       }
     } else {
 #pragma unroll
-      for (int kb = 0; kb < 64; kb += 32) {
-        const float4 a0 = *reinterpret_cast<const float4*>(&bufA[i * HS + k0 + kb + 8 * g]);
-        const float4 a1 = *reinterpret_cast<const float4*>(&bufA[i * HS + k0 + kb + 8 * g + 4]);
-        const float4 b0 = load_w4(w3, i, out_dim, k0 + kb + 8 * g, HID);
-        const float4 b1v = load_w4(w3, i, out_dim, k0 + kb + 8 * g + 4, HID);
-        bf16x8 av = {to_bf16(a0.x), to_bf16(a0.y), to_bf16(a0.z), to_bf16(a0.w),
-                     to_bf16(a1.x), to_bf16(a1.y), to_bf16(a1.z), to_bf16(a1.w)};
-        bf16x8 bv = {to_bf16(b0.x), to_bf16(b0.y), to_bf16(b0.z), to_bf16(b0.w),
-                     to_bf16(b1v.x), to_bf16(b1v.y), to_bf16(b1v.z), to_bf16(b1v.w)};
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc, 0, 0, 0);
+      for (int kk = 0; kk < 4; kk += 2) {
+        const int kb = 4 * wave + kk;
+        const float4 a0 = *reinterpret_cast<const float4*>(&bufA[i * HS + kb * 16 + 4 * g]);
+        const float4 a1 = *reinterpret_cast<const float4*>(&bufA[i * HS + (kb + 1) * 16 + 4 * g]);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pack_bf16(a0, a1), pack_bf16(base[kb * 64], base[(kb + 1) * 64]), acc,
+                                                      0, 0, 0);
       }
     }
 #pragma unroll
@@ -173,8 +180,9 @@ extern "C" void etg_set_last_error_(const char* msg);
 
 struct EtgPolicy {
   int device, in_dim, hidden, out_dim;
-  float *w1, *b1, *w2, *b2, *w3, *b3;
+  float *w1, *b1, *w2, *b2, *w3, *b3;  // w1/w2/w3 hold the PACKED (MFMA-fragment order) copies
 };
+static size_t packed_floats(int ntiles, int nkb) { return (size_t)ntiles * nkb * 64 * 4; }
 
 static int pfail(int code, const char* msg) {
   etg_set_last_error_(msg);
@@ -190,9 +198,9 @@ extern "C" int etg_policy_create(int in_dim, int hidden, int out_dim, int device
   if (hipSetDevice(device) != hipSuccess) return pfail(ETG_ERR_HIP, "hipSetDevice");
   EtgPolicy* p = new EtgPolicy();
   p->device = device; p->in_dim = in_dim; p->hidden = hidden; p->out_dim = out_dim;
-  struct { float** q; size_t n; } a[] = {{&p->w1, (size_t)hidden * in_dim}, {&p->b1, (size_t)hidden},
-                                         {&p->w2, (size_t)hidden * hidden}, {&p->b2, (size_t)hidden},
-                                         {&p->w3, (size_t)out_dim * hidden}, {&p->b3, (size_t)out_dim}};
+  struct { float** q; size_t n; } a[] = {{&p->w1, packed_floats(HID / 16, 4)}, {&p->b1, (size_t)hidden},
+                                         {&p->w2, packed_floats(HID / 16, HID / 16)}, {&p->b2, (size_t)hidden},
+                                         {&p->w3, packed_floats(1, HID / 16)}, {&p->b3, (size_t)out_dim}};
   for (auto& x : a)
     if (hipMalloc((void**)x.q, x.n * 4) != hipSuccess) return pfail(ETG_ERR_ALLOC, "etg_policy_create: hipMalloc failed");
   *out = p;
@@ -204,13 +212,20 @@ extern "C" int etg_policy_load(EtgPolicy* p, const float* w1, const float* b1, c
   if (!p || !w1 || !b1 || !w2 || !b2 || !w3 || !b3) return pfail(ETG_ERR_BAD_ARG, "etg_policy_load: null");
   if (hipSetDevice(p->device) != hipSuccess) return pfail(ETG_ERR_HIP, "hipSetDevice");
   hipStream_t s = (hipStream_t)stream;
-  struct { float* d; const float* src; size_t n; } c[] = {
-      {p->w1, w1, (size_t)p->hidden * p->in_dim}, {p->b1, b1, (size_t)p->hidden},
-      {p->w2, w2, (size_t)p->hidden * p->hidden}, {p->b2, b2, (size_t)p->hidden},
-      {p->w3, w3, (size_t)p->out_dim * p->hidden}, {p->b3, b3, (size_t)p->out_dim}};
+  struct { float* d; const float* src; int nout, kdim, ntiles, nkb; } pk[] = {
+      {p->w1, w1, p->hidden, p->in_dim, HID / 16, 4},
+      {p->w2, w2, p->hidden, p->hidden, HID / 16, HID / 16},
+      {p->w3, w3, p->out_dim, p->hidden, 1, HID / 16}};
+  for (auto& x : pk) {
+    const int total = x.ntiles * x.nkb * 256;
+    hipLaunchKernelGGL(k_pack_weights, dim3((total + 255) / 256), dim3(256), 0, s, x.src, x.nout, x.kdim, x.ntiles, x.nkb, x.d);
+  }
+  struct { float* d; const float* src; size_t n; } c[] = {{p->b1, b1, (size_t)p->hidden}, {p->b2, b2, (size_t)p->hidden},
+                                                         {p->b3, b3, (size_t)p->out_dim}};
   for (auto& x : c)
     if (hipMemcpyAsync(x.d, x.src, x.n * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
       return pfail(ETG_ERR_HIP, "etg_policy_load: hipMemcpyAsync failed");
+  if (hipGetLastError() != hipSuccess) return pfail(ETG_ERR_HIP, "etg_policy_load: pack launch failed");
   return ETG_OK;
 }
 
@@ -220,11 +235,11 @@ extern "C" int etg_policy_forward(EtgPolicy* p, const float* obs, int n, float a
   if (hipSetDevice(p->device) != hipSuccess) return pfail(ETG_ERR_HIP, "hipSetDevice");
   dim3 grid((n + TM - 1) / TM), block(THREADS);
   if (precision == 0)
-    hipLaunchKernelGGL(k_policy<false>, grid, block, 0, (hipStream_t)stream, obs, n, p->in_dim, p->w1, p->b1, p->w2, p->b2,
-                       p->w3, p->b3, p->out_dim, act_scale, act);
+    hipLaunchKernelGGL(k_policy<false>, grid, block, 0, (hipStream_t)stream, obs, n, p->in_dim, (const float4*)p->w1, p->b1,
+                       (const float4*)p->w2, p->b2, (const float4*)p->w3, p->b3, p->out_dim, act_scale, act);
   else
-    hipLaunchKernelGGL(k_policy<true>, grid, block, 0, (hipStream_t)stream, obs, n, p->in_dim, p->w1, p->b1, p->w2, p->b2,
-                       p->w3, p->b3, p->out_dim, act_scale, act);
+    hipLaunchKernelGGL(k_policy<true>, grid, block, 0, (hipStream_t)stream, obs, n, p->in_dim, (const float4*)p->w1, p->b1,
+                       (const float4*)p->w2, p->b2, (const float4*)p->w3, p->b3, p->out_dim, act_scale, act);
   if (hipGetLastError() != hipSuccess) return pfail(ETG_ERR_HIP, "etg_policy_forward: launch failed");
   return ETG_OK;
 }
