@@ -177,6 +177,16 @@ int etg_policy_forward(EtgPolicy* p, const float* obs, int n, float act_scale, i
                        float* act, void* stream);
 void etg_policy_destroy(EtgPolicy* p);
 
+/* ---- ETG parameterisation (the step right before reset) ----
+ * Batched Opt_with_points / LS_sol (train.py:59-110): for every candidate fit the
+ * x- and z-row of the ETG weights through its 6 control points by LS_sol's
+ * gradient descent (same stopping rule), anchored at w0 with weight lamb.
+ * points [nb,6,2], feats [6,20] (ETG basis at the 6 control times), w0 [2,20]
+ * (x row, z row); float64 device pointers. out_w [nb,3,20], out_b [nb,3] float64.  */
+int etg_fit_etg(const double* points, int nb, const double* feats, const double* w0, double b0x,
+                double b0z, double precision, double alpha, double lamb, int max_iter,
+                double* out_w, double* out_b, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -15,7 +15,7 @@ SYMBOLS = [
     "etg_set_heightfield", "etg_reset", "etg_step", "etg_episode_stats", "etg_rollout_openloop",
     "etg_get_state",
     "etg_set_state", "etg_policy_create", "etg_policy_load", "etg_policy_forward",
-    "etg_policy_destroy",
+    "etg_policy_destroy", "etg_fit_etg",
 ]
 
 
@@ -56,6 +56,8 @@ def load():
     lib.etg_policy_forward.argtypes = [vp, vp, i32, C.c_float, i32, vp, vp]
     lib.etg_policy_destroy.argtypes = [vp]
     lib.etg_policy_destroy.restype = None
+    dbl = C.c_double
+    lib.etg_fit_etg.argtypes = [vp, i32, vp, vp, dbl, dbl, dbl, dbl, dbl, i32, vp, vp, vp]
     _LIB = lib
     return lib
 

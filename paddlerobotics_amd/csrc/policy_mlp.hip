@@ -77,13 +77,16 @@ __device__ __forceinline__ void hidden_layer(const float* in, int nkb, const flo
 #pragma unroll
         for (int t = 0; t < 4; t++) w1[t] = base[t * tstride + (kb + 1) * 64];
       }
+      // k-component outer, tile inner: 4 independent accumulators back to back, so the 40-cycle
+      // dependent-accumulator latency of v_mfma_f32_16x16x4_f32 never stalls the 32-cycle issue
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w0[t].x, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w0[t].y, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w0[t].z, acc[t], 0, 0, 0);
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w0[t].w, acc[t], 0, 0, 0);
-      }
+      for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w0[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w0[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w0[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w0[t].w, acc[t], 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < 4; t++) w0[t] = w1[t];
     }

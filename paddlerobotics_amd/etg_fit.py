@@ -40,6 +40,8 @@ def opt_with_points_batched(ETG, ETG_T, points, b0, w0, precision=1e-4, lamb=0.5
     feats = torch.as_tensor(np.array([ETG.update(t) for t in control_times(ETG_T)]), dtype=torch.float64,
                             device=device)
     pts = torch.as_tensor(points, dtype=torch.float64, device=device)
+    if pts.is_cuda:
+        return _fit_hip(pts.contiguous(), feats.contiguous(), b0, w0, precision, lamb)
     b0 = np.asarray(b0, dtype=np.float64)
     b = torch.tensor([b0[0], b0[-1]], dtype=torch.float64, device=device)
     centred = pts - b
@@ -52,3 +54,22 @@ def opt_with_points_batched(ETG, ETG_T, points, b0, w0, precision=1e-4, lamb=0.5
     bb = torch.zeros(Bsz, 3, dtype=torch.float64, device=device)
     bb[:, 0], bb[:, 2] = b[0], b[1]
     return w, bb
+
+
+def _fit_hip(pts, feats, b0, w0, precision, lamb, alpha=0.05, max_iter=1000):
+    """The HIP kernel behind the C-ABI (csrc/etg_fit.hip: one lane per candidate-dimension)."""
+    import ctypes as C
+    from . import _lib
+    lib = _lib.load()
+    dev = pts.device
+    b0 = np.asarray(b0, dtype=np.float64)
+    w0x = torch.as_tensor(np.asarray(w0), dtype=torch.float64, device=dev)
+    w0t = torch.stack([w0x[0], w0x[-1]]).contiguous()
+    nb = pts.shape[0]
+    w = torch.empty(nb, 3, feats.shape[1], dtype=torch.float64, device=dev)
+    b = torch.empty(nb, 3, dtype=torch.float64, device=dev)
+    stream = C.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    _lib.check(lib.etg_fit_etg(C.c_void_p(pts.data_ptr()), nb, C.c_void_p(feats.data_ptr()), C.c_void_p(w0t.data_ptr()),
+                               float(b0[0]), float(b0[-1]), float(precision), float(alpha), float(lamb), int(max_iter),
+                               C.c_void_p(w.data_ptr()), C.c_void_p(b.data_ptr()), stream))
+    return w, b

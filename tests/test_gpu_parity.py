@@ -316,3 +316,21 @@ def test_ik_guard_unreachable_targets_on_gpu():
     assert np.all(np.isfinite(ig[:, 9:21]))
     assert np.abs(ig[:, 9:21] - io[:, 9:21]).max() < 1e-3
     env.close()
+
+
+def test_batched_opt_with_points_hip_kernel_matches_reference(golden):
+    """csrc/etg_fit.hip vs the reference's Opt_with_points outputs (tests/golden/opt.npz)."""
+    _need_gpu()
+    from paddlerobotics_amd.etg import ETG_layer
+    from paddlerobotics_amd.etg_fit import opt_with_points_batched
+    g = golden("opt")
+    layer = ETG_layer(0.5, 0.026, 20, 0.04, np.array([-np.pi / 2, 0]), 0.2, 0.5)
+    pts = g["prior"][None] + g["dpts"]
+    w, b = opt_with_points_batched(layer, 0.5, pts, g["b0"], g["w0"], device="cuda:0")
+    assert np.allclose(w.cpu().numpy(), g["w"], atol=1e-9) and np.allclose(b.cpu().numpy(), g["b"], atol=1e-12)
+    # a large ragged batch agrees with the torch implementation of the same iteration
+    rng = np.random.default_rng(0)
+    big = g["prior"][None] + 0.02 * rng.normal(size=(1001, 6, 2))
+    w_h, b_h = opt_with_points_batched(layer, 0.5, big, g["b0"], g["w0"], device="cuda:0")
+    w_t, b_t = opt_with_points_batched(layer, 0.5, big, g["b0"], g["w0"], device="cpu")
+    assert np.allclose(w_h.cpu().numpy(), w_t.numpy(), atol=1e-9) and np.allclose(b_h.cpu().numpy(), b_t.numpy(), atol=1e-12)
