@@ -3,9 +3,10 @@
 // One robot = one quad of lanes (etg_core.h).  A workgroup is ONE wave64 = 16 robots:
 // at the headline size (4096 robots) that is 256 workgroups, one per CU, so the launch
 // spreads over all 8 XCDs; nothing is shared between workgroups, so no XCD-aware remap
-// is needed.  All quad reductions/broadcasts are DPP quad_perm moves (no LDS, no
-// ds_bpermute).  State is SoA in HBM (etg_layout.h), so every global access of a wave
-// is one contiguous 256-B segment per field.
+// is needed.  Quad reductions/broadcasts are DPP quad_perm moves, the contact operator's
+// 4x4 blocks are v_mfma_f32_4x4x1, and LDS holds each lane's private parameter column
+// (no barriers anywhere).  State is SoA in HBM (etg_layout.h), so every global access of
+// a wave is one contiguous 256-B segment per field.
 #include <hip/hip_runtime.h>
 
 #include <string>

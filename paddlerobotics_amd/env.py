@@ -53,8 +53,11 @@ class BatchedQuadrupedEnv:
             raise ValueError("render is not supported by the batched GPU simulator")
         if int(ETG_H) != A.RBF_H:
             raise ValueError("ETG_H must be %d" % A.RBF_H)
-        if task == "heightfield" and heightfield is None:
-            raise ValueError("task='heightfield' needs heightfield=dict(heights=[ny,nx], cell=, origin=(x0,y0))")
+        if task not in TASKS:
+            raise ValueError("task %r is not available: this simulator has 'ground' (flat plane) and 'heightfield' "
+                             "(pass heightfield=dict(heights=[ny,nx], cell=, origin=(x0,y0)))" % (task,))
+        if (task == "heightfield") != (heightfield is not None):
+            raise ValueError("task='heightfield' and the heightfield= argument go together")
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
         if self.device.type != "cuda":
