@@ -73,6 +73,7 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=(2, 3))
     ap.add_argument("--precision", type=int, default=0, help="policy MFMA: 0 fp32, 1 bf16")
     ap.add_argument("--solver-iters", type=int, default=SOLVER_ITERS, help="PGS sweeps per tick")
+    ap.add_argument("--lanes", type=int, default=16, choices=(4, 16), help="kernel mapping: lanes per robot")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     SOLVER_ITERS = args.solver_iters
@@ -93,7 +94,8 @@ def main():
     from paddlerobotics_amd.env import make_env
     from paddlerobotics_amd.policy import MfmaPolicy
     N = args.num_envs
-    env = make_env("Quadrupedal", num_envs=N, device=str(dev), solver_iters=args.solver_iters)
+    env = make_env("Quadrupedal", num_envs=N, device=str(dev), solver_iters=args.solver_iters,
+                   lanes_per_robot=args.lanes)
     w, b = etg_population(N, seed=rank, device=dev)
     env.reset(ETG_w=w, ETG_b=b)
     policy = None
@@ -162,9 +164,9 @@ def main():
                                     "params = prior + N(0,0.02^2)" % N) if args.config == 2 else
                        ("configs[2]: %d parallel A1 per GPU, flat, ETG + residual MLP policy (random init, "
                         "precision %d)" % (N, args.precision)),
-                       "robots_per_gpu": N, "action_repeat": 13, "sim_dt": 0.002, "solver_iters": args.solver_iters,
+                       "robots_per_gpu": N, "action_repeat": 13, "sim_dt": 0.002, "solver_iters": args.solver_iters, "lanes_per_robot": args.lanes,
                        "parallelism": "env-shard x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "etg::k_step", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "etg::k_step16" if args.lanes == 16 else "etg::k_step", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK,
                          "traffic": (PMC_TRAFFIC_BYTES_AT_4096 * N / 4096.0) if PMC_TRAFFIC_BYTES_AT_4096 else None,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": bytes_per,

@@ -120,6 +120,9 @@ typedef struct EtgConfig {
   /* heightfield (terrain==1): row-major [hf_ny][hf_nx] heights, cell size, origin */
   int32_t hf_nx, hf_ny;
   double hf_cell, hf_x0, hf_y0;
+  /* kernel mapping: 16 = one robot per 16-lane DPP row (default, fills the chip at 4096 robots),
+   * 4 = one robot per quad (one leg per lane). Same results to fp32 roundoff, same state layout. */
+  int32_t lanes_per_robot;
 } EtgConfig;
 
 typedef struct EtgHandle EtgHandle;

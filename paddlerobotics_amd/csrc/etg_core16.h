@@ -1,0 +1,605 @@
+// etg_core16.h -- the same env.step()/reset() math as etg_core.h, mapped ONE ROBOT = ONE DPP ROW.
+//
+// Why a second mapping: with one wave per busy SIMD a wave issues one VALU instruction per
+// 4 cycles, so a control step costs (instructions per lane) x 4 cycles, and at the headline size
+// (4096 robots) the 4-lanes-per-robot kernel only occupies 256 of the chip's 1024 SIMDs
+// (DESIGN.md "what bounds the kernel").  Here a robot is the 16 lanes of one DPP row:
+//     lane r = 4*leg + sub,   leg = the quad inside the row,   sub = 0,1,2,3
+//     sub 0..2 : joint/link `sub` of the leg (hip, thigh, calf)  AND contact row `sub` (n, t1, t2)
+//     sub 3    : auxiliary lane (all its link/row contributions are zero; carries base ring words)
+// 4096 robots -> 1024 waves = one per SIMD, and each lane executes ~1/2 of the instructions.
+// Chain recursions (velocity/acceleration prefix, composite force/inertia suffix) are 2-step
+// quad_perm scans, leg-level gathers are quad_perm broadcasts, robot-level reductions are 4-step
+// row butterflies (quad xor1, xor2, row_half_mirror, row_mirror), the sequential contact solve
+// broadcasts one row's impulse change with row_newbcast, and the Delassus blocks are
+// v_mfma_f32_4x4x1 outer products between a quad and a leg-rotated copy of the row (row_ror).
+// State lives in the same HBM arrays as the 4-lane kernel (etg_layout.h), so both kernels are
+// interchangeable on one handle.
+#pragma once
+
+#include "etg_core.h"
+
+namespace etg {
+
+template <class F> struct State16 {
+  V3<F> p;
+  F qx, qy, qz, qw;
+  V3<F> wb, vb;
+  F q, qd;       // this lane's joint (0 on the aux lane)
+  F lam;         // this lane's contact row impulse (row = sub: n, t1, t2)
+  F contact;     // leg-level flag, replicated in the quad
+  F energy;
+};
+
+template <class F, class Ctx> ETG_HD State16<F> load_state16(const Ctx& c, const float* base, const float* leg) {
+  State16<F> L;
+  L.p = {c.ld_env(base, BS_PX), c.ld_env(base, BS_PY), c.ld_env(base, BS_PZ)};
+  L.qx = c.ld_env(base, BS_QX); L.qy = c.ld_env(base, BS_QY); L.qz = c.ld_env(base, BS_QZ); L.qw = c.ld_env(base, BS_QW);
+  L.wb = {c.ld_env(base, BS_WX), c.ld_env(base, BS_WY), c.ld_env(base, BS_WZ)};
+  L.vb = {c.ld_env(base, BS_VX), c.ld_env(base, BS_VY), c.ld_env(base, BS_VZ)};
+  const F mj = c.jointf();
+  L.q = mj * c.ld_joint(leg, LG_Q);
+  L.qd = mj * c.ld_joint(leg, LG_QD);
+  L.lam = mj * c.ld_joint(leg, LG_LAM);
+  L.contact = c.ld_legf(leg, LG_CONTACT);
+  L.energy = F(0.0f);
+  return L;
+}
+template <class F, class Ctx> ETG_HD void store_state16(const Ctx& c, float* base, float* leg, const State16<F>& L) {
+  c.st_env(base, BS_PX, L.p.x); c.st_env(base, BS_PY, L.p.y); c.st_env(base, BS_PZ, L.p.z);
+  c.st_env(base, BS_QX, L.qx); c.st_env(base, BS_QY, L.qy); c.st_env(base, BS_QZ, L.qz); c.st_env(base, BS_QW, L.qw);
+  c.st_env(base, BS_WX, L.wb.x); c.st_env(base, BS_WY, L.wb.y); c.st_env(base, BS_WZ, L.wb.z);
+  c.st_env(base, BS_VX, L.vb.x); c.st_env(base, BS_VY, L.vb.y); c.st_env(base, BS_VZ, L.vb.z);
+  c.st_joint(leg, LG_Q, L.q); c.st_joint(leg, LG_QD, L.qd); c.st_joint(leg, LG_LAM, L.lam);
+  c.st_legf(leg, LG_CONTACT, L.contact);
+}
+
+// scans along the 3-link chain held by sub-lanes 0..2 of a quad (the aux lane holds zeros)
+template <class F, class Ctx> ETG_HD F chain_prefix(const Ctx& c, F x, F m1, F m2) { return x + m1 * c.qdn1(x) + m2 * c.qdn2(x); }
+template <class F, class Ctx> ETG_HD F chain_suffix(const Ctx& c, F x) { return x + c.qup1(x) + c.qup2(x); }
+template <class F, class Ctx> ETG_HD SV<F> chain_prefix(const Ctx& c, SV<F> v, F m1, F m2) {
+  return {{chain_prefix(c, v.a.x, m1, m2), chain_prefix(c, v.a.y, m1, m2), chain_prefix(c, v.a.z, m1, m2)},
+          {chain_prefix(c, v.l.x, m1, m2), chain_prefix(c, v.l.y, m1, m2), chain_prefix(c, v.l.z, m1, m2)}};
+}
+template <class F, class Ctx> ETG_HD SV<F> chain_suffix(const Ctx& c, SV<F> v) {
+  return {{chain_suffix(c, v.a.x), chain_suffix(c, v.a.y), chain_suffix(c, v.a.z)},
+          {chain_suffix(c, v.l.x), chain_suffix(c, v.l.y), chain_suffix(c, v.l.z)}};
+}
+template <class F, class Ctx> ETG_HD SV<F> quad_bcast(const Ctx& c, SV<F> v, int j) {
+  return {{c.qb(v.a.x, j), c.qb(v.a.y, j), c.qb(v.a.z, j)}, {c.qb(v.l.x, j), c.qb(v.l.y, j), c.qb(v.l.z, j)}};
+}
+
+// leg geometry shared by every lane of the quad
+template <class F> struct LegGeo { F sa, ca, sh, ch, shk, chk; V3<F> yax, o1, o2, o3, pf, ez2, ez3; };
+template <class F, class Ctx> ETG_HD LegGeo<F> leg_geometry(const Ctx& c, const KCfg& K, F q_own) {
+  LegGeo<F> g;
+  F sq, cq;
+  sincos_(q_own, sq, cq);  // one sincos per lane (its own joint), shared through the quad
+  g.sa = c.qb(sq, 0); g.ca = c.qb(cq, 0);
+  g.sh = c.qb(sq, 1); g.ch = c.qb(cq, 1);
+  const F sk = c.qb(sq, 2), ck = c.qb(cq, 2);
+  g.shk = g.sh * ck + g.ch * sk;
+  g.chk = g.ch * ck - g.sh * sk;
+  const F zero(0.0f);
+  g.yax = {zero, g.ca, g.sa};
+  g.ez2 = {g.sh, -(g.sa * g.ch), g.ca * g.ch};
+  g.ez3 = {g.shk, -(g.sa * g.chk), g.ca * g.chk};
+  g.o1 = par3<F>(c, PR_O1);
+  g.o2 = g.o1 + c.par(PR_SY) * g.yax;
+  g.o3 = g.o2 - F(K.upper_len) * g.ez2;
+  g.pf = g.o3 - F(K.lower_len) * g.ez3;
+  return g;
+}
+
+// ------------------------------------------------------------------ one physics tick, 16 lanes per robot
+template <class F, class Ctx>
+ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, State16<F>& L, F qdes) {
+  typedef V3<F> V;
+  typedef SV<F> W;
+  const F dt(K.dt), zero(0.0f), one(1.0f);
+  const F mj = c.jointf();                    // 1 on joint lanes (sub 0..2), 0 on the aux lane
+  const auto s0 = c.sub_is(0), s1 = c.sub_is(1);
+  const F f0 = sel_(s0, one, zero), f1 = sel_(s1, one, zero), f2 = sel_(c.sub_is(2), one, zero);
+  const F m1 = one - f0;                      // sub >= 1 (aux lane results are discarded)
+  const F m2 = m1 - f1;                       // sub >= 2
+
+  // ---- PD motor model (laikago_motor.py:165-173), this lane's joint
+  F tau = mj * (-(c.par_joint(PR_KP) * (L.q - qdes)) - c.par_joint(PR_KD) * L.qd);
+  if (K.torque_limit > 0.0f) tau = fminf_(fmaxf_(tau, F(-K.torque_limit)), F(K.torque_limit));
+
+  // ---- leg geometry, this lane's link frame R_s = Rx(a) Ry(theta_s), theta = (0, h, h+k)
+  const LegGeo<F> g = leg_geometry(c, K, L.q);
+  const F ct = sel_(s0, one, sel_(s1, g.ch, g.chk)), st = sel_(s0, zero, sel_(s1, g.sh, g.shk));
+  Fr<F> R = {{ct, g.sa * st, -(g.ca * st)}, g.yax, {st, -(g.sa * ct), g.ca * ct}};
+  V os = {sel_(s0, g.o1.x, sel_(s1, g.o2.x, g.o3.x)), sel_(s0, g.o1.y, sel_(s1, g.o2.y, g.o3.y)),
+          sel_(s0, g.o1.z, sel_(s1, g.o2.z, g.o3.z))};
+  V zs = {f0, m1 * g.ca, m1 * g.sa};          // joint axis: x for the hip, y' for thigh and calf
+  W S = {zs, cross(os, zs)};
+  RBI<F> I = link_inertia(c.par_link(0), V{c.par_link(1), c.par_link(2), c.par_link(3)},
+                          S3<F>{c.par_link(4), c.par_link(5), c.par_link(6), c.par_link(7), c.par_link(8), c.par_link(9)},
+                          R, os);
+  c.phase(0);
+  // ---- RNEA along the chain (prefix scans), bias forces (suffix scan)
+  Rows<F> Rw = quat_rows(L.qx, L.qy, L.qz, L.qw);
+  V gw = par3<F>(c, PR_G);
+  V gb = {Rw.r0.x * gw.x + Rw.r1.x * gw.y + Rw.r2.x * gw.z, Rw.r0.y * gw.x + Rw.r1.y * gw.y + Rw.r2.y * gw.z,
+          Rw.r0.z * gw.x + Rw.r1.z * gw.y + Rw.r2.z * gw.z};
+  W V0 = {L.wb, L.vb};
+  W vJ = L.qd * S;
+  W Vs = V0 + chain_prefix(c, vJ, m1, m2);
+  W Vpar = Vs - vJ;
+  W a0 = {{zero, zero, zero}, {-gb.x, -gb.y, -gb.z}};
+  W as = a0 + chain_prefix(c, L.qd * crm(Vpar, S), m1, m2);
+  W f = apply(I, as) + crf(Vs, apply(I, Vs));
+  W fc = chain_suffix(c, f);
+  F C = dot(S, fc);
+  const F m0 = c.par(PR_M0);
+  const S3<F> I0s = par_s3<F>(c, PR_I0);
+  RBI<F> I0 = {m0, {zero, zero, zero}, I0s};
+  W fb0 = apply(I0, a0) + crf(V0, apply(I0, V0));
+  c.phase(1);
+  // ---- CRBA: composite inertia (suffix scan), this joint's column F = Ic S, leg block H (replicated)
+  RBI<F> Ic;
+  Ic.m = chain_suffix(c, I.m);
+  Ic.h = {chain_suffix(c, I.h.x), chain_suffix(c, I.h.y), chain_suffix(c, I.h.z)};
+  Ic.I = {chain_suffix(c, I.I.xx), chain_suffix(c, I.I.yy), chain_suffix(c, I.I.zz),
+          chain_suffix(c, I.I.xy), chain_suffix(c, I.I.xz), chain_suffix(c, I.I.yz)};
+  W Fs = mj * apply(Ic, S);
+  W Fj[3] = {quad_bcast(c, Fs, 0), quad_bcast(c, Fs, 1), quad_bcast(c, Fs, 2)};
+  V xax = {one, zero, zero};
+  W S0 = {xax, cross(g.o1, xax)}, S1 = {g.yax, cross(g.o2, g.yax)}, S2 = {g.yax, cross(g.o3, g.yax)};
+  F H11 = dot(S0, Fj[0]), H12 = dot(S0, Fj[1]), H13 = dot(S0, Fj[2]);
+  F H22 = dot(S1, Fj[1]), H23 = dot(S1, Fj[2]), H33 = dot(S2, Fj[2]);
+  F cA = H22 * H33 - H23 * H23, cB = H13 * H23 - H12 * H33, cC = H12 * H23 - H13 * H22;
+  F cD = H11 * H33 - H13 * H13, cE = H12 * H13 - H11 * H23, cF = H11 * H22 - H12 * H12;
+  F idet = rcp_(H11 * cA + H12 * cB + H13 * cC);
+  F Hi11 = cA * idet, Hi12 = cB * idet, Hi13 = cC * idet, Hi22 = cD * idet, Hi23 = cE * idet, Hi33 = cF * idet;
+  // row `sub` of H^-1 (zero on the aux lane)
+  F h0 = f0 * Hi11 + f1 * Hi12 + f2 * Hi13, h1 = f0 * Hi12 + f1 * Hi22 + f2 * Hi23, h2 = f0 * Hi13 + f1 * Hi23 + f2 * Hi33;
+  W P = h0 * Fj[0] + h1 * Fj[1] + h2 * Fj[2];          // column `sub` of P = Fm H^-1
+  F rl = tau - C;                                      // (aux lane: tau = 0, C = 0 since S = 0 there)
+  c.phase(2);
+  // ---- base Schur complement: every term is a sum over the robot's 16 lanes
+  F s[21];
+#pragma unroll
+  for (int i = 0; i < 6; i++)
+#pragma unroll
+    for (int j = 0; j <= i; j++) s[i * (i + 1) / 2 + j] = c.sum16(comp(P, i) * comp(Fs, j));
+  RBI<F> Ib;  // composite of the whole robot = trunk + sum of every link
+  Ib.m = m0 + c.sum16(I.m);
+  Ib.h = {c.sum16(I.h.x), c.sum16(I.h.y), c.sum16(I.h.z)};
+  Ib.I = {I0s.xx + c.sum16(I.I.xx), I0s.yy + c.sum16(I.I.yy), I0s.zz + c.sum16(I.I.zz),
+          I0s.xy + c.sum16(I.I.xy), I0s.xz + c.sum16(I.I.xz), I0s.yz + c.sum16(I.I.yz)};
+  F mbb[21];
+  mbb[0] = Ib.I.xx;
+  mbb[1] = Ib.I.xy; mbb[2] = Ib.I.yy;
+  mbb[3] = Ib.I.xz; mbb[4] = Ib.I.yz; mbb[5] = Ib.I.zz;
+  mbb[6] = zero;     mbb[7] = Ib.h.z;   mbb[8] = -Ib.h.y;  mbb[9] = Ib.m;
+  mbb[10] = -Ib.h.z; mbb[11] = zero;    mbb[12] = Ib.h.x;  mbb[13] = zero; mbb[14] = Ib.m;
+  mbb[15] = Ib.h.y;  mbb[16] = -Ib.h.x; mbb[17] = zero;    mbb[18] = zero; mbb[19] = zero; mbb[20] = Ib.m;
+#pragma unroll
+  for (int i = 0; i < 21; i++) s[i] = mbb[i] - s[i];
+  F rb[6];
+#pragma unroll
+  for (int i = 0; i < 6; i++) rb[i] = -comp(fb0, i) - c.sum16(comp(f, i) + rl * comp(P, i));
+  F dinv[6], sq[6];
+  ldl6(s, dinv, sq);
+  fwd6(s, rb);
+#pragma unroll
+  for (int i = 0; i < 6; i++) rb[i] = rb[i] * dinv[i];
+  bwd6(s, rb);
+  W ab = {{rb[0], rb[1], rb[2]}, {rb[3], rb[4], rb[5]}};
+  const F rl0 = c.qb(rl, 0), rl1 = c.qb(rl, 1), rl2 = c.qb(rl, 2);
+  F qdd = h0 * rl0 + h1 * rl1 + h2 * rl2 - dot(P, ab);
+  c.phase(3);
+  // ---- unconstrained velocity
+  V wbs = L.wb + dt * ab.a, vbs = L.vb + dt * ab.l;
+  F qds = L.qd + dt * qdd;
+  c.phase(4);
+  // ---- foot contact: this lane owns contact row `sub` (n, t1, t2) of its leg
+  V fw = {L.p.x + dot(Rw.r0, g.pf), L.p.y + dot(Rw.r1, g.pf), L.p.z + dot(Rw.r2, g.pf)};
+  F phi;
+  V dn, d1, d2;
+  if (Ctx::kFlat) {
+    phi = fw.z - F(K.foot_radius);
+    dn = Rw.r2; d1 = Rw.r0; d2 = Rw.r1;
+  } else {
+    F hgt, nwx, nwy, nwz;
+    c.terrain(K, fw.x, fw.y, hgt, nwx, nwy, nwz);
+    phi = (fw.z - hgt) * nwz - F(K.foot_radius);
+    V nw = {nwx, nwy, nwz};
+    V t1w = {one - nwx * nwx, -(nwx * nwy), -(nwx * nwz)};
+    F it1 = rsqrt_(dot(t1w, t1w));
+    t1w = it1 * t1w;
+    V t2w = cross(nw, t1w);
+    dn = {Rw.r0.x * nw.x + Rw.r1.x * nw.y + Rw.r2.x * nw.z, Rw.r0.y * nw.x + Rw.r1.y * nw.y + Rw.r2.y * nw.z,
+          Rw.r0.z * nw.x + Rw.r1.z * nw.y + Rw.r2.z * nw.z};
+    d1 = {Rw.r0.x * t1w.x + Rw.r1.x * t1w.y + Rw.r2.x * t1w.z, Rw.r0.y * t1w.x + Rw.r1.y * t1w.y + Rw.r2.y * t1w.z,
+          Rw.r0.z * t1w.x + Rw.r1.z * t1w.y + Rw.r2.z * t1w.z};
+    d2 = {Rw.r0.x * t2w.x + Rw.r1.x * t2w.y + Rw.r2.x * t2w.z, Rw.r0.y * t2w.x + Rw.r1.y * t2w.y + Rw.r2.y * t2w.z,
+          Rw.r0.z * t2w.x + Rw.r1.z * t2w.y + Rw.r2.z * t2w.z};
+  }
+  auto act = phi < F(K.margin);
+  const F rowf = mj * sel_(act, one, zero);                     // 1 on the rows of an active foot
+  V rc = g.pf - F(K.foot_radius) * dn;
+  V k1 = cross(xax, rc - g.o1), k2 = cross(g.yax, rc - g.o2), k3 = cross(g.yax, rc - g.o3);
+  V dir = {sel_(s0, dn.x, sel_(s1, d1.x, d2.x)), sel_(s0, dn.y, sel_(s1, d1.y, d2.y)), sel_(s0, dn.z, sel_(s1, d1.z, d2.z))};
+  F Jl0 = rowf * dot(dir, k1), Jl1 = rowf * dot(dir, k2), Jl2 = rowf * dot(dir, k3);
+  F HJ0 = Hi11 * Jl0 + Hi12 * Jl1 + Hi13 * Jl2;
+  F HJ1 = Hi12 * Jl0 + Hi22 * Jl1 + Hi23 * Jl2;
+  F HJ2 = Hi13 * Jl0 + Hi23 * Jl1 + Hi33 * Jl2;
+  W Jb = {rowf * cross(rc, dir), rowf * dir};
+  W G = Jb - (HJ0 * Fj[0] + HJ1 * Fj[1] + HJ2 * Fj[2]);        // J_b^T - Fm H^-1 J_l^T
+  F g6[6] = {G.a.x, G.a.y, G.a.z, G.l.x, G.l.y, G.l.z};
+  fwd6(s, g6);
+  F Z[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) Z[k] = g6[k] * sq[k];
+  c.phase(5);
+  // ---- Delassus row of this lane.  Block against leg (l + kk) mod 4 = 4x4 outer product between
+  // this quad's Z and the row rotated by kk legs, contracted over the 6 base coordinates on the
+  // matrix pipe; the own block adds the leg compliance J_l H^-1 J_l^T.
+  F Arel[4][4];
+#pragma unroll
+  for (int kk = 0; kk < 4; kk++) {
+    F acc[4] = {zero, zero, zero, zero};
+#pragma unroll
+    for (int k = 0; k < 6; k++) c.quad_outer(c.legrot(Z[k], kk), Z[k], acc);   // acc[e] = Z_(l+kk, e) . Z_(l, sub)
+    if (kk == 0) {
+      c.quad_outer(HJ0, Jl0, acc);                                            // + sum_k HJ_e[k] Jl_sub[k]
+      c.quad_outer(HJ1, Jl1, acc);
+      c.quad_outer(HJ2, Jl2, acc);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; e++) Arel[kk][e] = acc[e];
+  }
+  // absolute indexing A[l'][e] = Arel[(l' - l) mod 4][e], once per tick
+  const auto l0b = c.leg_is(0), l1b = c.leg_is(1), l2b = c.leg_is(2);
+  F A[4][3];
+#pragma unroll
+  for (int lp = 0; lp < 4; lp++)
+#pragma unroll
+    for (int e = 0; e < 3; e++)
+      A[lp][e] = sel_(l0b, Arel[lp][e], sel_(l1b, Arel[(lp + 3) & 3][e], sel_(l2b, Arel[(lp + 2) & 3][e], Arel[(lp + 1) & 3][e])));
+  const F Add = sel_(s0, Arel[0][0], sel_(s1, Arel[0][1], Arel[0][2]));         // own diagonal
+  const F iA = sel_(rowf > F(0.5f), rcp_(Add), zero);
+  c.phase(6);
+  // ---- row velocity under the unconstrained motion, warm start
+  const F qs0 = c.qb(qds, 0), qs1 = c.qb(qds, 1), qs2 = c.qb(qds, 2);
+  V vc = vbs + cross(wbs, rc) + qs0 * k1 + qs1 * k2 + qs2 * k3;
+  F u = rowf * dot(dir, vc);
+  const F idt(1.0f / K.dt);
+  const F tgt = f0 * sel_(phi > zero, -(phi * idt), -(F(K.erp) * phi * idt));   // only normal rows have a target
+  F lam = rowf * F(K.warmstart) * L.lam;
+#pragma unroll
+  for (int lp = 0; lp < 4; lp++)
+#pragma unroll
+    for (int e = 0; e < 3; e++) u = u + A[lp][e] * c.rbcast(lam, 4 * lp + e);
+  c.phase(7);
+  // ---- projected Gauss-Seidel, rows in the order (FR n,t1,t2), (FL ...), (RR ...), (RL ...): the owner
+  // lane's candidate is broadcast over the row with row_newbcast and applied by every lane.
+  const F mu = c.par(PR_MU);
+  const F c0 = tgt * iA;
+  F ownl[4];
+#pragma unroll
+  for (int lp = 0; lp < 4; lp++) ownl[lp] = sel_(c.leg_is(lp), one, zero);
+  const F tangf = f1 + f2;
+  for (int it = 0; it < K.iters; it++) {
+#pragma unroll
+    for (int lp = 0; lp < 4; lp++) {
+      // normal row: ln = max(0, lam - (u - tgt)/A)
+      F dln = fmaxf_(zero, (lam + c0) - u * iA) - lam;
+      F b = c.rbcast(dln, 4 * lp);
+      u = u + A[lp][0] * b;
+      lam = lam + (ownl[lp] * f0) * dln;
+      // tangent rows, sequentially
+      F dt1 = -(u * iA);
+      b = c.rbcast(dt1, 4 * lp + 1);
+      u = u + A[lp][1] * b;
+      lam = lam + (ownl[lp] * f1) * dt1;
+      F dt2 = -(u * iA);
+      b = c.rbcast(dt2, 4 * lp + 2);
+      u = u + A[lp][2] * b;
+      lam = lam + (ownl[lp] * f2) * dt2;
+      // projection of (lt1, lt2) on the friction disc mu * ln
+      F lim = mu * c.qb(lam, 0);
+      F oth = c.qswap12(lam);
+      F sc = fminf_(one, lim * rsqrt_(fmaxf_(lam * lam + oth * oth, F(1e-30f))));
+      F dp = (ownl[lp] * tangf) * (lam * sc - lam);
+      F b1 = c.rbcast(dp, 4 * lp + 1), b2 = c.rbcast(dp, 4 * lp + 2);
+      u = u + A[lp][1] * b1 + A[lp][2] * b2;
+      lam = lam + dp;
+    }
+  }
+  c.phase(8);
+  // ---- apply impulses: base via the Schur factor, joints via H^-1
+  F db[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) db[k] = c.sum16(lam * Z[k]) * sq[k];
+  bwd6(s, db);
+  W dB = {{db[0], db[1], db[2]}, {db[3], db[4], db[5]}};
+  L.wb = wbs + dB.a;
+  L.vb = vbs + dB.l;
+  // joint j of this leg receives sum_d HJ_d[j] lam_d
+  const F dj0 = c.qsum(HJ0 * lam), dj1 = c.qsum(HJ1 * lam), dj2 = c.qsum(HJ2 * lam);
+  L.qd = mj * (qds + (f0 * dj0 + f1 * dj1 + f2 * dj2) - dot(P, dB));
+  L.lam = lam;
+  const F ln_leg = c.qb(lam, 0);
+  L.contact = sel_(act && (ln_leg > zero), one, zero);
+  c.phase(9);
+  // ---- semi-implicit Euler
+  L.q = L.q + dt * L.qd;
+  L.p.x = L.p.x + dt * dot(Rw.r0, L.vb);
+  L.p.y = L.p.y + dt * dot(Rw.r1, L.vb);
+  L.p.z = L.p.z + dt * dot(Rw.r2, L.vb);
+  V th = dt * L.wb;
+  F a2_ = dot(th, th);
+  F sh2 = F(0.5f) - a2_ * (F(1.0f / 48.0f) - a2_ * F(1.0f / 3840.0f));
+  F ch2 = one - a2_ * (F(0.125f) - a2_ * (F(1.0f / 384.0f) - a2_ * F(1.0f / 46080.0f)));
+  F dx = th.x * sh2, dy = th.y * sh2, dz = th.z * sh2, dw = ch2;
+  F nx = L.qw * dx + L.qx * dw + L.qy * dz - L.qz * dy;
+  F ny = L.qw * dy - L.qx * dz + L.qy * dw + L.qz * dx;
+  F nz = L.qw * dz + L.qx * dy - L.qy * dx + L.qz * dw;
+  F nw_ = L.qw * dw - L.qx * dx - L.qy * dy - L.qz * dz;
+  F inv = rsqrt_(nx * nx + ny * ny + nz * nz + nw_ * nw_);
+  L.qx = nx * inv; L.qy = ny * inv; L.qz = nz * inv; L.qw = nw_ * inv;
+  L.energy = L.energy + fabsf_(tau * L.qd) * dt;
+}
+
+// ------------------------------------------------------------------ latency ring, same HBM layout as the 4-lane kernel
+// slot k of leg-lane column: k = 0..2 q, 3..5 qd (joint lanes), 6,7 base words written by the aux lane
+template <class F, class Ctx> ETG_HD void ring_push16(const Ctx& c, float* ring, int slot, const State16<F>& L) {
+  const auto l0 = c.leg_is(0), l1 = c.leg_is(1), l2 = c.leg_is(2);
+  F b0 = sel_(l0, L.qx, sel_(l1, L.qz, sel_(l2, L.wb.x, L.wb.z)));
+  F b1 = sel_(l0, L.qy, sel_(l1, L.qw, sel_(l2, L.wb.y, F(0.0f))));
+  c.st_ring_joint(ring, slot, 0, L.q);
+  c.st_ring_joint(ring, slot, 3, L.qd);
+  c.st_ring_aux(ring, slot, 6, b0);
+  c.st_ring_aux(ring, slot, 7, b1);
+}
+template <class F> struct Delayed16 { F q, qd; F qx, qy, qz, qw; V3<F> w; };
+template <class F, class Ctx> ETG_HD Delayed16<F> ring_read16(const Ctx& c, const float* ring, int tick) {
+  F vq, vqd, v6, v7;
+  int n = c.uniform_int(c.par(PR_LAT_N));
+  const F alpha = c.par(PR_LAT_A);
+  if (n < 0) {
+    int sl = tick & (RING - 1);
+    vq = c.ld_ring_joint(ring, sl, 0); vqd = c.ld_ring_joint(ring, sl, 3);
+    v6 = c.ld_ring_k(ring, sl, 6); v7 = c.ld_ring_k(ring, sl, 7);
+  } else {
+    int sa = (tick - n) & (RING - 1), sb = (tick - n - 1) & (RING - 1);
+    const F oma = F(1.0f) - alpha;
+    vq = oma * c.ld_ring_joint(ring, sa, 0) + alpha * c.ld_ring_joint(ring, sb, 0);
+    vqd = oma * c.ld_ring_joint(ring, sa, 3) + alpha * c.ld_ring_joint(ring, sb, 3);
+    v6 = oma * c.ld_ring_k(ring, sa, 6) + alpha * c.ld_ring_k(ring, sb, 6);
+    v7 = oma * c.ld_ring_k(ring, sa, 7) + alpha * c.ld_ring_k(ring, sb, 7);
+  }
+  Delayed16<F> D;
+  D.q = vq; D.qd = vqd;
+  // the base words of leg-lane l are the same on its 4 sub-lanes: broadcast from sub-lane 0 of each leg
+  D.qx = c.rbcast(v6, 0); D.qy = c.rbcast(v7, 0);
+  D.qz = c.rbcast(v6, 4); D.qw = c.rbcast(v7, 4);
+  D.w = {c.rbcast(v6, 8), c.rbcast(v7, 8), c.rbcast(v6, 12)};
+  return D;
+}
+
+// ------------------------------------------------------------------ ETG + IK: computed by every lane of the leg, each keeps its joint
+template <class F, class Ctx>
+ETG_HD F etg_action16(const Ctx& c, const KCfg& K, const float* etgp, float t) {
+  F tl = sel_(c.leg_is(0) || c.leg_is(3), F(t), F(t + K.etg_T2 * K.etg_T));
+  F x0 = F(K.etg_amp) * sin_(F(K.etg_phase0) + tl * F(K.etg_omega));
+  F x1 = F(K.etg_amp) * sin_(F(K.etg_phase1) + tl * F(K.etg_omega));
+  F ax = c.ld_env(etgp, EP_B + 0), ay = c.ld_env(etgp, EP_B + 1), az = c.ld_env(etgp, EP_B + 2);
+  const F isig(1.0f / K.etg_sigma_sq);
+#pragma unroll 4
+  for (int h = 0; h < ETG_RBF_H; h++) {
+    F d0 = x0 - F(K.etg_u[h][0]), d1 = x1 - F(K.etg_u[h][1]);
+    F r = exp_(-((d0 * d0 + d1 * d1) * isig));
+    ax = ax + c.ld_env(etgp, EP_W + h) * r;
+    ay = ay + c.ld_env(etgp, EP_W + ETG_RBF_H + h) * r;
+    az = az + c.ld_env(etgp, EP_W + 2 * ETG_RBF_H + h) * r;
+  }
+  F scale(1.0f);
+  const V3<F> posev = par3<F>(c, PR_POSE), bfoot = par3<F>(c, PR_BASE_FOOT), o1 = par3<F>(c, PR_O1);
+  const F hipsign = c.par(PR_HIPSIGN);
+  F ang[3] = {posev.x, posev.y, posev.z};
+  auto pending = c.leg_is(0) || !c.leg_is(0);
+  for (int it = 0; it < 200; it++) {
+    V3<F> foot = {bfoot.x + ax * scale - o1.x, bfoot.y + ay * scale - o1.y, bfoot.z + az * scale - o1.z};
+    F a[3];
+    auto ok = pending;
+    leg_ik(foot, hipsign, a, ok);
+    auto take = pending && ok;
+    ang[0] = sel_(take, a[0], ang[0]); ang[1] = sel_(take, a[1], ang[1]); ang[2] = sel_(take, a[2], ang[2]);
+    pending = pending && !ok;
+    scale = scale * F(0.95f);
+    if (!c.any(pending)) break;
+  }
+  const auto s0 = c.sub_is(0), s1 = c.sub_is(1);
+  F own = sel_(s0, ang[0] - posev.x, sel_(s1, ang[1] - posev.y, ang[2] - posev.z));
+  return c.jointf() * own;
+}
+
+// foot kinematics of the leg (replicated in the quad)
+template <class F> struct FootKin16 { F fwx, fbz, knee_h; };
+template <class F, class Ctx> ETG_HD FootKin16<F> foot_kin16(const Ctx& c, const KCfg& K, const State16<F>& L) {
+  const LegGeo<F> g = leg_geometry(c, K, L.q);
+  Rows<F> Rw = quat_rows(L.qx, L.qy, L.qz, L.qw);
+  FootKin16<F> k;
+  k.fwx = L.p.x + dot(Rw.r0, g.pf);
+  k.fbz = g.pf.z;
+  F kx = L.p.x + dot(Rw.r0, g.o3), ky = L.p.y + dot(Rw.r1, g.o3), kz = L.p.z + dot(Rw.r2, g.o3);
+  if (Ctx::kFlat) {
+    k.knee_h = kz;
+  } else {
+    F hgt, nx, ny, nz;
+    c.terrain(K, kx, ky, hgt, nx, ny, nz);
+    k.knee_h = kz - hgt;
+  }
+  return k;
+}
+
+// observation (EnvWrapper.py:60-109), same 49-float row as write_obs()
+template <class F, class Ctx>
+ETG_HD void write_obs16(const Ctx& c, const KCfg& K, const State16<F>& L, const float* ring, int tick, float* ctl, F etg,
+                        F lbx, F lby, F lbz, bool set_first, float* obs, F* imu) {
+  Delayed16<F> D = ring_read16<F>(c, ring, tick);
+  V3<F> rpy = quat_rpy(D.qx, D.qy, D.qz, D.qw);
+  F r0, r1, r2;
+  if (set_first) {
+    r0 = rpy.x; r1 = rpy.y; r2 = rpy.z;
+    c.st_env(ctl, CT_FIRST_RPY + 0, r0); c.st_env(ctl, CT_FIRST_RPY + 1, r1); c.st_env(ctl, CT_FIRST_RPY + 2, r2);
+  } else {
+    r0 = c.ld_env(ctl, CT_FIRST_RPY + 0); r1 = c.ld_env(ctl, CT_FIRST_RPY + 1); r2 = c.ld_env(ctl, CT_FIRST_RPY + 2);
+  }
+  const bool nrm = K.obs_normal != 0;
+  const float cdt = K.dt * (float)K.action_repeat;
+  F sdis(nrm ? 1.0f / cdt : 1.0f), srpy(nrm ? 10.0f : 1.0f), sdr(nrm ? 2.0f : 1.0f), sqn(nrm ? 10.0f : 1.0f);
+  imu[0] = rpy.x - r0; imu[1] = rpy.y - r1; imu[2] = rpy.z - r2;
+  imu[3] = D.w.x; imu[4] = D.w.y; imu[5] = D.w.z;
+  if (obs) {
+    c.st_row_env(obs, ETG_OBS_DIM, 0, (L.p.x - lbx) * sdis);
+    c.st_row_env(obs, ETG_OBS_DIM, 1, (L.p.y - lby) * sdis);
+    c.st_row_env(obs, ETG_OBS_DIM, 2, (L.p.z - lbz) * sdis);
+    c.st_row_leg(obs, ETG_OBS_DIM, 3, L.contact);
+    for (int k = 0; k < 3; k++) c.st_row_env(obs, ETG_OBS_DIM, 7 + k, imu[k] * srpy);
+    for (int k = 0; k < 3; k++) c.st_row_env(obs, ETG_OBS_DIM, 10 + k, imu[3 + k] * sdr);
+    const F posej = c.par_joint(PR_POSE), emj = c.par_joint(PR_EMEAN), esj = c.par_joint(PR_ESTD);
+    F a = wrap_pi_(D.q);
+    c.st_row_joint(obs, ETG_OBS_DIM, 13, nrm ? (a - posej) * sqn : a);
+    c.st_row_joint(obs, ETG_OBS_DIM, 25, D.qd);
+    c.st_row_joint(obs, ETG_OBS_DIM, 37, nrm ? (etg - emj) / esj : etg);
+  }
+}
+
+// ------------------------------------------------------------------ one control step (env.step), 16 lanes per robot
+template <class F, class Ctx>
+ETG_HD void control_step16(const Ctx& c, const KCfg& K, State16<F>& L, float* ring, float* ctl, int* ictl, float* legctl,
+                           const float* etgp, F action, F donef, float* obs, F& reward, F& done, float* info) {
+  int step_count = c.ld_env_i(ictl, IC_STEP);
+  int tick = c.ld_env_i(ictl, IC_TICK);
+  int has_last = c.ld_env_i(ictl, IC_HAS_LAST);
+  const F mj = c.jointf();
+  F etg = etg_action16<F>(c, K, etgp, (float)(step_count + 1) * K.etg_dt);
+  F qdes = mj * (c.par_joint(PR_POSE) + etg + action);
+  if (K.enable_filter) {
+    F x0 = c.ld_joint(legctl, LC_FX0), x1 = c.ld_joint(legctl, LC_FX1);
+    F y0 = c.ld_joint(legctl, LC_FY0), y1 = c.ld_joint(legctl, LC_FY1);
+    F y = F(K.fb[0]) * qdes + F(K.fb[1]) * x0 + F(K.fb[2]) * x1 - F(K.fa[1]) * y0 - F(K.fa[2]) * y1;
+    c.st_joint(legctl, LC_FX1, x0); c.st_joint(legctl, LC_FX0, qdes);
+    c.st_joint(legctl, LC_FY1, y0); c.st_joint(legctl, LC_FY0, y);
+    qdes = mj * y;
+  }
+  F last = c.ld_joint(legctl, LC_LAST_QDES);
+  F lbx = c.ld_env(ctl, CT_LAST_BASE + 0), lby = c.ld_env(ctl, CT_LAST_BASE + 1), lbz = c.ld_env(ctl, CT_LAST_BASE + 2);
+  F last_fwx = c.ld_legf(legctl, LC_LAST_FOOT_X);
+  L.energy = F(0.0f);
+  const bool interp = K.enable_interp && has_last;
+  const int n_lat = c.uniform_int(c.par(PR_LAT_N));
+  for (int i = 0; i < K.action_repeat; i++) {
+    float lerp = (float)(i + 1) / (float)K.action_repeat;
+    F proc = interp ? last + F(lerp) * (qdes - last) : qdes;
+    physics_tick16(c, K, L, proc);
+    tick++;
+    const bool need = n_lat < 0 ? (i == K.action_repeat - 1)
+                                : (((i + 1 + n_lat) % K.action_repeat == 0) || ((i + 2 + n_lat) % K.action_repeat == 0));
+    if (need) ring_push16(c, ring, tick & (RING - 1), L);
+  }
+  c.st_joint(legctl, LC_LAST_QDES, qdes);
+  step_count++;
+  c.st_env_i(ictl, IC_STEP, step_count);
+  c.st_env_i(ictl, IC_TICK, tick);
+  c.st_env_i(ictl, IC_HAS_LAST, 1);
+
+  F imu[6];
+  write_obs16(c, K, L, ring, tick, ctl, etg, lbx, lby, lbz, false, obs, imu);
+
+  const float cdt = K.dt * (float)K.action_repeat;
+  Rows<F> Rw = quat_rows(L.qx, L.qy, L.qz, L.qw);
+  V3<F> rpy = quat_rpy(L.qx, L.qy, L.qz, L.qw);
+  FootKin16<F> fk = foot_kin16(c, K, L);
+  const F legw = sel_(c.sub_is(0), F(1.0f), F(0.0f));   // count each leg once in robot-level sums
+  F vx = (L.p.x - lbx) * F(1.0f / cdt);
+  F torso = fminf_(vx, F(K.vel_d));
+  F up = (F(1.0f) - c_prec(rpy.x, F(0.0f), F(0.5f))) * (F(1.0f) - c_prec(rpy.y, F(0.0f), F(0.5f)));
+  F feet = c.sum16(legw * (fk.fwx - last_fwx) * F(0.25f)) * F(1.0f / cdt);
+  feet = fminf_(feet, F(K.vel_d));
+  F energy = c.sum16(L.energy);
+  F lost = c.sum16(legw * (F(1.0f) - L.contact));
+  F bad = c.sum16(legw * sel_(fk.knee_h < F(0.03f), F(1.0f), F(0.0f)));
+  F footcontact = -fmaxf_(lost - F(2.0f), F(0.0f));
+  F fz_mean = c.sum16(legw * fk.fbz) * F(0.25f);
+  F fz_max = c.max16(fk.fbz);
+  auto fin = isfinite_(L.p.x) && isfinite_(L.p.z) && isfinite_(c.rbcast(L.q, 0));
+  auto term = (Rw.r2.z < F(0.5f)) || (fz_mean > F(-0.1f)) || (fz_max > F(0.0f)) || (fabsf_(rpy.z) > F(0.6f)) || !fin;
+  F termf = sel_(term, F(1.0f), F(0.0f));
+  F terms[8] = {F(K.rw[0]) * torso, F(K.rw[1]) * feet, F(K.rw[2]) * up, F(K.rw[3]) * (-energy), F(0.0f),
+                F(K.rw[5]) * (-bad), F(K.rw[6]) * footcontact, F(K.rw[7]) * (-termf)};
+  F sum = terms[0];
+#pragma unroll
+  for (int k = 1; k < 8; k++) sum = sum + terms[k];
+  reward = F(K.reward_p) * sum;
+  done = sel_(term || (donef > F(0.5f)), F(1.0f), F(0.0f));
+  if (info) {
+    for (int k = 0; k < 8; k++) c.st_row_env(info, ETG_INFO_DIM, k, terms[k]);
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_VELX, vx);
+    c.st_row_joint(info, ETG_INFO_DIM, ETG_INFO_ETG_ACT, etg);
+    c.st_row_joint(info, ETG_INFO_DIM, ETG_INFO_JOINT_ANGLE, L.q);
+    c.st_row_joint(info, ETG_INFO_DIM, ETG_INFO_REAL_ACTION, qdes);
+    for (int k = 0; k < 6; k++) c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_OBS_IMU + k, imu[k]);
+    c.st_row_leg(info, ETG_INFO_DIM, ETG_INFO_FOOT_CONTACT, L.contact);
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_BASE + 0, L.p.x);
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_BASE + 1, L.p.y);
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_BASE + 2, L.p.z);
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_RPY + 0, rpy.x);
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_RPY + 1, rpy.y);
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_RPY + 2, rpy.z);
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_ENERGY, energy);
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_STEPS, F((float)step_count));
+    for (int k = ETG_INFO_STEPS + 1; k < ETG_INFO_DIM; k++) c.st_row_env(info, ETG_INFO_DIM, k, F(0.0f));
+  }
+  c.st_env(ctl, CT_LAST_BASE + 0, L.p.x); c.st_env(ctl, CT_LAST_BASE + 1, L.p.y); c.st_env(ctl, CT_LAST_BASE + 2, L.p.z);
+  c.st_legf(legctl, LC_LAST_FOOT_X, fk.fwx);
+  F alive = c.ld_env(ctl, CT_ALIVE);
+  c.st_env(ctl, CT_RET, c.ld_env(ctl, CT_RET) + alive * reward);
+  c.st_env(ctl, CT_LEN, c.ld_env(ctl, CT_LEN) + alive);
+  c.st_env(ctl, CT_ALIVE, sel_(done > F(0.5f), F(0.0f), alive));
+}
+
+// ------------------------------------------------------------------ reset
+template <class F, class Ctx>
+ETG_HD void reset_row16(const Ctx& c, const KCfg& K, State16<F>& L, float* ring, float* ctl, int* ictl, float* legctl,
+                        const float* etgp, float* obs) {
+  const F mj = c.jointf();
+  L.p = {F(K.init_pos[0]), F(K.init_pos[1]), F(K.init_pos[2])};
+  L.qx = F(0.0f); L.qy = F(0.0f); L.qz = F(0.0f); L.qw = F(1.0f);
+  L.wb = {F(0.0f), F(0.0f), F(0.0f)};
+  L.vb = {F(0.0f), F(0.0f), F(0.0f)};
+  const F pose = mj * c.par_joint(PR_POSE);
+  L.q = pose; L.qd = F(0.0f); L.lam = F(0.0f);
+  L.contact = F(0.0f);
+  L.energy = F(0.0f);
+  for (int sl = 0; sl < RING; sl++) ring_push16(c, ring, sl, L);
+  int tick = 0;
+  for (int i = 0; i < K.settle_ticks; i++) {
+    physics_tick16(c, K, L, pose);
+    tick++;
+    ring_push16(c, ring, tick & (RING - 1), L);
+  }
+  L.energy = F(0.0f);
+  c.st_env_i(ictl, IC_STEP, 0);
+  c.st_env_i(ictl, IC_TICK, tick);
+  c.st_env_i(ictl, IC_HAS_LAST, 0);
+  c.st_env(ctl, CT_RET, F(0.0f)); c.st_env(ctl, CT_LEN, F(0.0f)); c.st_env(ctl, CT_ALIVE, F(1.0f));
+  c.st_env(ctl, CT_LAST_BASE + 0, L.p.x); c.st_env(ctl, CT_LAST_BASE + 1, L.p.y); c.st_env(ctl, CT_LAST_BASE + 2, L.p.z);
+  c.st_joint(legctl, LC_LAST_QDES, pose);
+  c.st_joint(legctl, LC_FX0, pose); c.st_joint(legctl, LC_FX1, pose);
+  c.st_joint(legctl, LC_FY0, pose); c.st_joint(legctl, LC_FY1, pose);
+  FootKin16<F> fk = foot_kin16(c, K, L);
+  c.st_legf(legctl, LC_LAST_FOOT_X, fk.fwx);
+  F imu[6];
+  F etg = etg_action16<F>(c, K, etgp, 0.0f);
+  write_obs16(c, K, L, ring, tick, ctl, etg, L.p.x, L.p.y, L.p.z, true, obs, imu);
+}
+
+}  // namespace etg

@@ -12,7 +12,7 @@
 #include <string>
 #include <vector>
 
-#include "etg_core.h"
+#include "etg_core16.h"
 
 namespace etg {
 
@@ -174,6 +174,134 @@ __global__ void __launch_bounds__(BLOCK) k_step(KCfg K, DevState D, const float*
   }
 }
 
+// ====================================================================== 16 lanes per robot
+// One robot = one 16-lane DPP row (etg_core16.h): lane r = 4*leg + sub.  A workgroup is still one
+// wave64 = 4 robots; 4096 robots -> 1024 workgroups = one wave on every SIMD of the chip.
+constexpr int LDS16_FIELDS = PR_N + 10;  // the 66 leg-level parameters + this lane's own link block
+
+struct GpuCtx16 {
+  int env, r, leg, sub, sc, tid, N, NL;
+  size_t col;        // 4*env + leg : column of the leg-level SoA arrays
+  const float* lds;  // this lane's LDS column
+  __device__ __forceinline__ float jointf() const { return sub < 3 ? 1.0f : 0.0f; }
+  __device__ __forceinline__ bool sub_is(int j) const { return sub == j; }
+  __device__ __forceinline__ bool leg_is(int j) const { return leg == j; }
+  __device__ __forceinline__ bool any(bool b) const { return __any(b); }
+  __device__ __forceinline__ int uniform_int(float a) const { return (int)a; }
+  __device__ __forceinline__ float par(int k) const { return lds[k * 64]; }
+  __device__ __forceinline__ float par_link(int k) const { return lds[(PR_N + k) * 64]; }
+  __device__ __forceinline__ float par_joint(int base) const { return lds[(base + sc) * 64]; }
+  // ---- quad (= leg) exchanges
+  __device__ __forceinline__ float qb(float a, int j) const {
+    switch (j) { case 0: return dpp_<0x00>(a); case 1: return dpp_<0x55>(a); case 2: return dpp_<0xAA>(a); default: return dpp_<0xFF>(a); }
+  }
+  __device__ __forceinline__ float qup1(float a) const { return dpp_<0xF9>(a); }     // quad_perm [1,2,3,3]
+  __device__ __forceinline__ float qup2(float a) const { return dpp_<0xFE>(a); }     // quad_perm [2,3,3,3]
+  __device__ __forceinline__ float qdn1(float a) const { return dpp_<0x90>(a); }     // quad_perm [0,0,1,2]
+  __device__ __forceinline__ float qdn2(float a) const { return dpp_<0x40>(a); }     // quad_perm [0,0,0,1]
+  __device__ __forceinline__ float qswap12(float a) const { return dpp_<0xD8>(a); }  // quad_perm [0,2,1,3]
+  __device__ __forceinline__ float qsum(float a) const { float t = a + dpp_<0xB1>(a); return t + dpp_<0x4E>(t); }
+  // ---- row (= robot) exchanges: xor1, xor2, row_half_mirror, row_mirror -- order-symmetric, so the
+  // result is bit-identical on the 16 lanes
+  __device__ __forceinline__ float sum16(float a) const {
+    float t = a + dpp_<0xB1>(a); t = t + dpp_<0x4E>(t); t = t + dpp_<0x141>(t); return t + dpp_<0x140>(t);
+  }
+  __device__ __forceinline__ float max16(float a) const {
+    float t = fmaxf(a, dpp_<0xB1>(a)); t = fmaxf(t, dpp_<0x4E>(t)); t = fmaxf(t, dpp_<0x141>(t)); return fmaxf(t, dpp_<0x140>(t));
+  }
+  __device__ __forceinline__ float rbcast(float a, int r0) const {  // row_newbcast:r0 (constant after unrolling)
+    switch (r0) {
+      case 0: return dpp_<0x150>(a); case 1: return dpp_<0x151>(a); case 2: return dpp_<0x152>(a); case 3: return dpp_<0x153>(a);
+      case 4: return dpp_<0x154>(a); case 5: return dpp_<0x155>(a); case 6: return dpp_<0x156>(a); case 7: return dpp_<0x157>(a);
+      case 8: return dpp_<0x158>(a); case 9: return dpp_<0x159>(a); case 10: return dpp_<0x15A>(a); case 11: return dpp_<0x15B>(a);
+      case 12: return dpp_<0x15C>(a); case 13: return dpp_<0x15D>(a); case 14: return dpp_<0x15E>(a); default: return dpp_<0x15F>(a);
+    }
+  }
+  // value of the same sub-lane in leg (leg + kk) mod 4: row_ror:n delivers lane (i - n) mod 16
+  __device__ __forceinline__ float legrot(float a, int kk) const {
+    switch (kk) { case 0: return a; case 1: return dpp_<0x12C>(a); case 2: return dpp_<0x128>(a); default: return dpp_<0x124>(a); }
+  }
+  __device__ __forceinline__ void quad_outer(float a, float b, float* acc) const {
+    typedef float f32x4 __attribute__((ext_vector_type(4)));
+    f32x4 v = {acc[0], acc[1], acc[2], acc[3]};
+    v = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, v, 0, 0, 0);
+    acc[0] = v[0]; acc[1] = v[1]; acc[2] = v[2]; acc[3] = v[3];
+  }
+  // ---- memory (same SoA arrays as the 4-lane kernels)
+  __device__ __forceinline__ float ld_joint(const float* p, int f0) const { return p[(size_t)(f0 + sc) * NL + col]; }
+  __device__ __forceinline__ void st_joint(float* p, int f0, float v) const { if (sub < 3) p[(size_t)(f0 + sub) * NL + col] = v; }
+  __device__ __forceinline__ float ld_legf(const float* p, int f) const { return p[(size_t)f * NL + col]; }
+  __device__ __forceinline__ void st_legf(float* p, int f, float v) const { if (sub == 0) p[(size_t)f * NL + col] = v; }
+  __device__ __forceinline__ float ld_env(const float* p, int f) const { return p[(size_t)f * N + env]; }
+  __device__ __forceinline__ void st_env(float* p, int f, float v) const { if (r == 0) p[(size_t)f * N + env] = v; }
+  __device__ __forceinline__ int ld_env_i(const int* p, int f) const { return p[(size_t)f * N + env]; }
+  __device__ __forceinline__ void st_env_i(int* p, int f, int v) const { if (r == 0) p[(size_t)f * N + env] = v; }
+  __device__ __forceinline__ void st_ring_joint(float* rg, int slot, int k0, float v) const { if (sub < 3) rg[((size_t)slot * 8 + k0 + sub) * NL + col] = v; }
+  __device__ __forceinline__ void st_ring_aux(float* rg, int slot, int k, float v) const { if (sub == 3) rg[((size_t)slot * 8 + k) * NL + col] = v; }
+  __device__ __forceinline__ float ld_ring_joint(const float* rg, int slot, int k0) const { return rg[((size_t)slot * 8 + k0 + sc) * NL + col]; }
+  __device__ __forceinline__ float ld_ring_k(const float* rg, int slot, int k) const { return rg[((size_t)slot * 8 + k) * NL + col]; }
+  __device__ __forceinline__ float ld_row_joint(const float* p, int rowlen, int col0) const { return sub < 3 ? p[(size_t)env * rowlen + col0 + 3 * leg + sub] : 0.0f; }
+  __device__ __forceinline__ void st_row_joint(float* p, int rowlen, int col0, float v) const { if (sub < 3) p[(size_t)env * rowlen + col0 + 3 * leg + sub] = v; }
+  __device__ __forceinline__ void st_row_leg(float* p, int rowlen, int col0, float v) const { if (sub == 0) p[(size_t)env * rowlen + col0 + leg] = v; }
+  __device__ __forceinline__ void st_row_env(float* p, int rowlen, int c_, float v) const { if (r == 0) p[(size_t)env * rowlen + c_] = v; }
+  __device__ __forceinline__ float ld_row_env(const float* p, int rowlen, int c_) const { return p[(size_t)env * rowlen + c_]; }
+  __device__ __forceinline__ void phase(int) const { __builtin_amdgcn_sched_barrier(0); }
+  __device__ __forceinline__ void terrain(const KCfg& K, float x, float y, float& h, float& nx, float& ny, float& nz) const {
+    if (K.terrain == 0) { h = 0.0f; nx = 0.0f; ny = 0.0f; nz = 1.0f; }
+    else heightfield_query(K, x, y, h, nx, ny, nz);
+  }
+};
+template <bool FLAT> struct GpuCtx16T : GpuCtx16 { static constexpr bool kFlat = FLAT; };
+
+__device__ __forceinline__ bool make_ctx16(const KCfg& K, const DevState& D, GpuCtx16& c, float* lds_all) {
+  c.tid = threadIdx.x;
+  c.env = blockIdx.x * 4 + (threadIdx.x >> 4);
+  c.r = threadIdx.x & 15;
+  c.leg = c.r >> 2;
+  c.sub = c.r & 3;
+  c.sc = c.sub < 2 ? c.sub : 2;
+  c.N = K.n_env;
+  c.NL = 4 * K.n_env;
+  if (c.env >= c.N) return false;   // whole rows drop out together, so every DPP/MFMA group stays complete
+  c.col = (size_t)4 * c.env + c.leg;
+  // stage the leg's 66 parameters and this lane's own link block (zeros on the aux lane) in LDS
+  float* mine = lds_all + threadIdx.x;
+#pragma unroll 6
+  for (int k = 0; k < PR_N; k++) mine[k * 64] = D.par[(size_t)k * c.NL + c.col];
+#pragma unroll
+  for (int k = 0; k < 10; k++) mine[(PR_N + k) * 64] = c.sub < 3 ? D.par[(size_t)(PR_LINK + 10 * c.sub + k) * c.NL + c.col] : 0.0f;
+  c.lds = mine;
+  return true;
+}
+
+template <bool FLAT>
+__global__ void __launch_bounds__(BLOCK) k_reset16(KCfg K, DevState D, const uint8_t* mask, float* obs) {
+  __shared__ float lds_par[LDS16_FIELDS * BLOCK];
+  GpuCtx16T<FLAT> c;
+  if (!make_ctx16(K, D, c, lds_par)) return;
+  if (mask && !mask[c.env]) return;
+  State16<float> L;
+  reset_row16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, obs);
+  store_state16(c, D.base, D.leg, L);
+}
+
+template <bool FLAT>
+__global__ void __launch_bounds__(BLOCK) k_step16(KCfg K, DevState D, const float* action, const uint8_t* donef, float* obs,
+                                                   float* reward, uint8_t* done, float* info) {
+  __shared__ float lds_par[LDS16_FIELDS * BLOCK];
+  GpuCtx16T<FLAT> c;
+  if (!make_ctx16(K, D, c, lds_par)) return;
+  State16<float> L = load_state16<float>(c, D.base, D.leg);
+  float act = action ? c.ld_row_joint(action, ETG_ACT_DIM, 0) : 0.0f;
+  float r, d;
+  control_step16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, act, donef ? (float)donef[c.env] : 0.0f, obs, r, d, info);
+  store_state16(c, D.base, D.leg, L);
+  if (c.r == 0) {
+    reward[c.env] = r;
+    done[c.env] = d > 0.5f ? 1 : 0;
+  }
+}
+
 // copy out the per-robot episode accumulators (return, length) kept in ctl[]
 __global__ void k_episode_stats(KCfg K, DevState D, float* ret, int* len) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -208,6 +336,7 @@ struct EtgHandle {
   ModelF M;
   DevState D;
   float* hf;
+  int lanes;                    // 4 or 16 lanes per robot (EtgConfig.lanes_per_robot)
   float *tmp_obs, *tmp_reward;  // sinks for etg_rollout_openloop
   uint8_t* tmp_done;
 };
@@ -245,6 +374,11 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   h->K = make_kcfg(*cfg, *model);
   h->M = make_modelf(*model);
   h->hf = nullptr;
+  if (cfg->lanes_per_robot != 0 && cfg->lanes_per_robot != 4 && cfg->lanes_per_robot != 16) {
+    delete h;
+    return fail(ETG_ERR_BAD_ARG, "etg_create: lanes_per_robot must be 4 or 16");
+  }
+  h->lanes = cfg->lanes_per_robot == 4 ? 4 : 16;
   size_t N = h->N, NL = 4 * N;
   struct { void** p; size_t bytes; } allocs[] = {
       {(void**)&h->D.base, BS_N * N * 4},   {(void**)&h->D.leg, LG_N * NL * 4},   {(void**)&h->D.ctl, CT_N * N * 4},
@@ -310,7 +444,13 @@ extern "C" int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* st
   CHECK_HANDLE(h);
   if (!obs) return fail(ETG_ERR_BAD_ARG, "etg_reset: obs is null");
   if (h->K.terrain == 1 && !h->K.hf) return fail(ETG_ERR_STATE, "etg_reset: heightfield not set");
-  if (h->K.terrain == 0)
+  const dim3 g16((h->N + 3) / 4);
+  if (h->lanes == 16) {
+    if (h->K.terrain == 0)
+      hipLaunchKernelGGL(k_reset16<true>, g16, dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, mask, obs);
+    else
+      hipLaunchKernelGGL(k_reset16<false>, g16, dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, mask, obs);
+  } else if (h->K.terrain == 0)
     hipLaunchKernelGGL(k_reset<true>, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, mask, obs);
   else
     hipLaunchKernelGGL(k_reset<false>, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, mask, obs);
@@ -322,7 +462,13 @@ extern "C" int etg_step(EtgHandle* h, const float* action, const uint8_t* donef,
                         uint8_t* done, float* info, void* stream) {
   CHECK_HANDLE(h);
   if (!obs || !reward || !done) return fail(ETG_ERR_BAD_ARG, "etg_step: obs/reward/done must be non-null");
-  if (h->K.terrain == 0)
+  const dim3 g16((h->N + 3) / 4);
+  if (h->lanes == 16) {
+    if (h->K.terrain == 0)
+      hipLaunchKernelGGL(k_step16<true>, g16, dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, action, donef, obs, reward, done, info);
+    else
+      hipLaunchKernelGGL(k_step16<false>, g16, dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, action, donef, obs, reward, done, info);
+  } else if (h->K.terrain == 0)
     hipLaunchKernelGGL(k_step<true>, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, action, donef,
                        obs, reward, done, info);
   else

@@ -48,7 +48,7 @@ class BatchedQuadrupedEnv:
                  reward_p=5.0, ETG_path="", random_param=None, ETG_H=20, vel_d=0.5, step_y=0.05,
                  enable_action_filter=False, ETG_T2=0.5, action_repeat=13, sim_time_step=0.002,
                  settle_ticks=500, solver_iters=2, enable_action_interpolation=False,
-                 heightfield=None, **unused):
+                 heightfield=None, lanes_per_robot=16, **unused):
         if render:
             raise ValueError("render is not supported by the batched GPU simulator")
         if int(ETG_H) != A.RBF_H:
@@ -68,7 +68,8 @@ class BatchedQuadrupedEnv:
             solver_iters=solver_iters, enable_action_interp=enable_action_interpolation,
             enable_action_filter=enable_action_filter, normal=normal,
             terrain=1 if heightfield is not None else 0, ETG_T=ETG_T, ETG_T2=ETG_T2,
-            reward_param=reward_param, reward_p=reward_p, vel_d=vel_d, heightfield=heightfield)
+            reward_param=reward_param, reward_p=reward_p, vel_d=vel_d, heightfield=heightfield,
+            lanes_per_robot=lanes_per_robot)
         self.model = A.default_model()
         self.observation_space = Box(-np.inf, np.inf, (A.OBS_DIM,))
         self.action_space = Box(-1.0, 1.0, (A.NUM_MOTORS,))

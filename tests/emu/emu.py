@@ -15,8 +15,10 @@ def lib():
     global _LIB
     if _LIB is None:
         so = os.path.join(_HERE, "libetg_emu.so")
-        srcs = [os.path.join(_HERE, "etg_emu.cpp")] + [
-            os.path.join(_HERE, "..", "..", "paddlerobotics_amd", "csrc", f) for f in ("etg_core.h", "etg_layout.h")]
+        srcs = [os.path.join(_HERE, "etg_emu.cpp"), os.path.join(_HERE, "emu_lanes.h")] + [
+            os.path.join(_HERE, "..", "..", "paddlerobotics_amd", "csrc", f)
+            for f in ("etg_core.h", "etg_core16.h", "etg_layout.h") if os.path.exists(
+                os.path.join(_HERE, "..", "..", "paddlerobotics_amd", "csrc", f))]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
             subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
                                    "-o", so, srcs[0]])
@@ -30,11 +32,14 @@ def _p(a):
 
 
 class EmuSim:
-    def __init__(self, cfg, model=None):
+    def __init__(self, cfg, model=None, lanes=4):
+        """lanes: 4 = etg_core.h (one leg per lane), 16 = etg_core16.h (one robot per DPP row)."""
         self.cfg, self.model = cfg, model if model is not None else A.default_model()
         self.N = cfg.num_envs
+        self.lanes = lanes
         self._l = lib()
         self._h = C.c_void_p(self._l.emu_create(C.byref(cfg), C.byref(self.model)))
+        self._l.emu_set_lanes(self._h, int(lanes))
         self.set_params(dyn=np.tile(A.default_dynamic_row(), (self.N, 1)), etg_w=np.zeros((3, 20)), etg_b=np.zeros(3))
 
     def __del__(self):
@@ -85,4 +90,5 @@ class EmuSim:
         self._l.emu_set_state(self._h, _p(st))
 
     def replication_check(self, env=0, nticks=50):
-        return self._l.emu_tick_replication_check(self._h, int(env), int(nticks))
+        f = self._l.emu16_tick_replication_check if self.lanes == 16 else self._l.emu_tick_replication_check
+        return f(self._h, int(env), int(nticks))

@@ -9,37 +9,10 @@
 #include <cstring>
 #include <vector>
 
-#include "../../paddlerobotics_amd/csrc/etg_layout.h"
-
-namespace etg {
-struct B4 { bool v[4]; };
-struct F4 {
-  float v[4];
-  F4() {}
-  explicit F4(float s) { v[0] = v[1] = v[2] = v[3] = s; }
-};
-#define OP2(op) inline F4 operator op(F4 a, F4 b) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] op b.v[i]; return r; }
-OP2(+) OP2(-) OP2(*) OP2(/)
-#undef OP2
-inline F4 operator-(F4 a) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = -a.v[i]; return r; }
-#define CMP(op) inline B4 operator op(F4 a, F4 b) { B4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] op b.v[i]; return r; }
-CMP(<) CMP(>) CMP(<=) CMP(>=)
-#undef CMP
-inline B4 operator&&(B4 a, B4 b) { B4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] && b.v[i]; return r; }
-inline B4 operator||(B4 a, B4 b) { B4 r; for (int i = 0; i < 4; i++) r.v[i] = a.v[i] || b.v[i]; return r; }
-inline B4 operator!(B4 a) { B4 r; for (int i = 0; i < 4; i++) r.v[i] = !a.v[i]; return r; }
-inline F4 sel_(B4 c, F4 a, F4 b) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
-#define FN1(name) inline F4 name(F4 a) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = name(a.v[i]); return r; }
-FN1(fabsf_) FN1(sqrt_) FN1(rsqrt_) FN1(rcp_) FN1(sin_) FN1(cos_) FN1(exp_) FN1(tanh_) FN1(acos_) FN1(asin_) FN1(wrap_pi_)
-#undef FN1
-inline F4 fminf_(F4 a, F4 b) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = fminf(a.v[i], b.v[i]); return r; }
-inline F4 fmaxf_(F4 a, F4 b) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = fmaxf(a.v[i], b.v[i]); return r; }
-inline F4 atan2_(F4 a, F4 b) { F4 r; for (int i = 0; i < 4; i++) r.v[i] = atan2f(a.v[i], b.v[i]); return r; }
-inline B4 isfinite_(F4 a) { B4 r; for (int i = 0; i < 4; i++) r.v[i] = std::isfinite(a.v[i]); return r; }
-inline void sincos_(F4 a, F4& s, F4& c) { for (int i = 0; i < 4; i++) { s.v[i] = sinf(a.v[i]); c.v[i] = cosf(a.v[i]); } }
-}  // namespace etg
+#include "emu_lanes.h"
 
 #include "../../paddlerobotics_amd/csrc/etg_core.h"
+#include "../../paddlerobotics_amd/csrc/etg_core16.h"
 
 namespace etg {
 struct EmuCtxBase {
@@ -86,7 +59,78 @@ template <bool FLAT> struct EmuCtxT : EmuCtxBase {
 };
 typedef EmuCtxT<false> EmuCtx;   // generic-terrain instantiation; the flat fast path is EmuCtxT<true>
 
+// ---- 16 lanes per robot (etg_core16.h): lane r = 4*leg + sub
+struct EmuCtx16Base {
+  int env, N;
+  const float* parp;
+  int NL() const { return 4 * N; }
+  static int leg(int r) { return r >> 2; }
+  static int sub(int r) { return r & 3; }
+  static int sc(int r) { return (r & 3) < 2 ? (r & 3) : 2; }
+  size_t col(int r) const { return (size_t)4 * env + leg(r); }
+  F16 jointf() const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = sub(r) < 3 ? 1.f : 0.f; return o; }
+  B16 sub_is(int j) const { B16 o; for (int r = 0; r < 16; r++) o.v[r] = sub(r) == j; return o; }
+  B16 leg_is(int j) const { B16 o; for (int r = 0; r < 16; r++) o.v[r] = leg(r) == j; return o; }
+  bool any(B16 b) const { for (int r = 0; r < 16; r++) if (b.v[r]) return true; return false; }
+  int uniform_int(F16 a) const { return (int)a.v[0]; }
+  F16 par(int k) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = parp[(size_t)k * NL() + col(r)]; return o; }
+  F16 par_link(int k) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = sub(r) < 3 ? parp[(size_t)(PR_LINK + 10 * sub(r) + k) * NL() + col(r)] : 0.f; return o; }
+  F16 par_joint(int base) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = parp[(size_t)(base + sc(r)) * NL() + col(r)]; return o; }
+  // quad (leg) exchanges
+  F16 qb(F16 x, int j) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = x.v[(r & ~3) + j]; return o; }
+  F16 qperm(F16 x, int a, int b, int c_, int d) const { int p[4] = {a, b, c_, d}; F16 o; for (int r = 0; r < 16; r++) o.v[r] = x.v[(r & ~3) + p[r & 3]]; return o; }
+  F16 qup1(F16 x) const { return qperm(x, 1, 2, 3, 3); }
+  F16 qup2(F16 x) const { return qperm(x, 2, 3, 3, 3); }
+  F16 qdn1(F16 x) const { return qperm(x, 0, 0, 1, 2); }
+  F16 qdn2(F16 x) const { return qperm(x, 0, 0, 0, 1); }
+  F16 qswap12(F16 x) const { return qperm(x, 0, 2, 1, 3); }
+  F16 qsum(F16 x) const { F16 t = x + qperm(x, 1, 0, 3, 2); return t + qperm(t, 2, 3, 0, 1); }
+  // robot (row) exchanges: same butterfly order as the DPP sequence of the GPU context
+  F16 half_mirror(F16 x) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = x.v[(r & 8) + 7 - (r & 7)]; return o; }
+  F16 mirror(F16 x) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = x.v[15 - r]; return o; }
+  F16 sum16(F16 x) const { F16 t = qsum(x); t = t + half_mirror(t); return t + mirror(t); }
+  F16 max16(F16 x) const {
+    F16 t = fmaxf_(x, qperm(x, 1, 0, 3, 2)); t = fmaxf_(t, qperm(t, 2, 3, 0, 1)); t = fmaxf_(t, half_mirror(t)); return fmaxf_(t, mirror(t));
+  }
+  F16 rbcast(F16 x, int r0) const { return F16(x.v[r0]); }
+  F16 legrot(F16 x, int kk) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = x.v[(r + 4 * kk) & 15]; return o; }
+  void quad_outer(F16 a, F16 b, F16* acc) const {
+    for (int i = 0; i < 4; i++)
+      for (int r = 0; r < 16; r++) acc[i].v[r] = fmaf(a.v[(r & ~3) + i], b.v[r], acc[i].v[r]);
+  }
+  // memory
+  F16 ld_joint(const float* p, int f0) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = p[(size_t)(f0 + sc(r)) * NL() + col(r)]; return o; }
+  void st_joint(float* p, int f0, F16 v) const { for (int r = 0; r < 16; r++) if (sub(r) < 3) p[(size_t)(f0 + sub(r)) * NL() + col(r)] = v.v[r]; }
+  F16 ld_legf(const float* p, int f) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = p[(size_t)f * NL() + col(r)]; return o; }
+  void st_legf(float* p, int f, F16 v) const { for (int r = 0; r < 16; r += 4) p[(size_t)f * NL() + col(r)] = v.v[r]; }
+  F16 ld_env(const float* p, int f) const { return F16(p[(size_t)f * N + env]); }
+  void st_env(float* p, int f, F16 v) const { p[(size_t)f * N + env] = v.v[0]; }
+  int ld_env_i(const int* p, int f) const { return p[(size_t)f * N + env]; }
+  void st_env_i(int* p, int f, int v) const { p[(size_t)f * N + env] = v; }
+  void st_ring_joint(float* rg, int slot, int k0, F16 v) const { for (int r = 0; r < 16; r++) if (sub(r) < 3) rg[((size_t)slot * 8 + k0 + sub(r)) * NL() + col(r)] = v.v[r]; }
+  void st_ring_aux(float* rg, int slot, int k, F16 v) const { for (int r = 3; r < 16; r += 4) rg[((size_t)slot * 8 + k) * NL() + col(r)] = v.v[r]; }
+  F16 ld_ring_joint(const float* rg, int slot, int k0) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = rg[((size_t)slot * 8 + k0 + sc(r)) * NL() + col(r)]; return o; }
+  F16 ld_ring_k(const float* rg, int slot, int k) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = rg[((size_t)slot * 8 + k) * NL() + col(r)]; return o; }
+  F16 ld_row_joint(const float* p, int rowlen, int col0) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = sub(r) < 3 ? p[(size_t)env * rowlen + col0 + 3 * leg(r) + sub(r)] : 0.f; return o; }
+  void st_row_joint(float* p, int rowlen, int col0, F16 v) const { for (int r = 0; r < 16; r++) if (sub(r) < 3) p[(size_t)env * rowlen + col0 + 3 * leg(r) + sub(r)] = v.v[r]; }
+  void st_row_leg(float* p, int rowlen, int col0, F16 v) const { for (int r = 0; r < 16; r += 4) p[(size_t)env * rowlen + col0 + leg(r)] = v.v[r]; }
+  void st_row_env(float* p, int rowlen, int col_, F16 v) const { p[(size_t)env * rowlen + col_] = v.v[0]; }
+  F16 ld_row_env(const float* p, int rowlen, int col_) const { return F16(p[(size_t)env * rowlen + col_]); }
+  void phase(int) const {}
+  void terrain(const KCfg& K, F16 x, F16 y, F16& h, F16& nx, F16& ny, F16& nz) const {
+    for (int r = 0; r < 16; r++) {
+      if (K.terrain == 0 || K.hf == nullptr) { h.v[r] = 0; nx.v[r] = 0; ny.v[r] = 0; nz.v[r] = 1; }
+      else heightfield_query(K, x.v[r], y.v[r], h.v[r], nx.v[r], ny.v[r], nz.v[r]);
+    }
+  }
+};
+template <bool FLAT> struct EmuCtx16T : EmuCtx16Base {
+  static constexpr bool kFlat = FLAT;
+  EmuCtx16T(int e, int n, const float* p) { env = e; N = n; parp = p; }
+};
+
 struct Emu {
+  int lanes = 4;
   KCfg K;
   ModelF M;
   int N;
@@ -109,6 +153,7 @@ extern "C" void* emu_create(const EtgConfig* cfg, const EtgRobotModel* model) {
   return e;
 }
 extern "C" void emu_destroy(void* h) { delete (Emu*)h; }
+extern "C" void emu_set_lanes(void* h, int lanes) { ((Emu*)h)->lanes = lanes; }
 extern "C" void emu_set_params(void* h, const float* dyn, const float* w, const float* b, int per_env, const uint8_t* mask) {
   Emu* e = (Emu*)h;
   int N = e->N;
@@ -135,6 +180,19 @@ extern "C" void emu_reset(void* h, const uint8_t* mask, float* obs) {
   Emu* e = (Emu*)h;
   for (int i = 0; i < e->N; i++) {
     if (mask && !mask[i]) continue;
+    if (e->lanes == 16) {
+      State16<F16> S;
+      if (e->K.terrain == 0) {
+        EmuCtx16T<true> c(i, e->N, e->par.data());
+        reset_row16(c, e->K, S, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs);
+        store_state16(c, e->base.data(), e->leg.data(), S);
+      } else {
+        EmuCtx16T<false> c(i, e->N, e->par.data());
+        reset_row16(c, e->K, S, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs);
+        store_state16(c, e->base.data(), e->leg.data(), S);
+      }
+      continue;
+    }
     LaneState<F4> L;
     if (e->K.terrain == 0) {
       EmuCtxT<true> c(i, e->N, e->par.data());
@@ -150,6 +208,26 @@ extern "C" void emu_reset(void* h, const uint8_t* mask, float* obs) {
 extern "C" void emu_step(void* h, const float* action, const uint8_t* donef, float* obs, float* reward, uint8_t* done, float* info) {
   Emu* e = (Emu*)h;
   for (int i = 0; i < e->N; i++) {
+    if (e->lanes == 16) {
+      F16 r16, d16;
+      F16 dn(donef ? (float)donef[i] : 0.f);
+      if (e->K.terrain == 0) {
+        EmuCtx16T<true> c(i, e->N, e->par.data());
+        State16<F16> S = load_state16<F16>(c, e->base.data(), e->leg.data());
+        control_step16(c, e->K, S, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(),
+                       c.ld_row_joint(action, 12, 0), dn, obs, r16, d16, info);
+        store_state16(c, e->base.data(), e->leg.data(), S);
+      } else {
+        EmuCtx16T<false> c(i, e->N, e->par.data());
+        State16<F16> S = load_state16<F16>(c, e->base.data(), e->leg.data());
+        control_step16(c, e->K, S, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(),
+                       c.ld_row_joint(action, 12, 0), dn, obs, r16, d16, info);
+        store_state16(c, e->base.data(), e->leg.data(), S);
+      }
+      reward[i] = r16.v[0];
+      done[i] = d16.v[0] > 0.5f;
+      continue;
+    }
     EmuCtx c0(i, e->N, e->par.data());
     LaneState<F4> L = load_state<F4>(c0, e->base.data(), e->leg.data());
     F4 act[3];
@@ -197,6 +275,22 @@ extern "C" int emu_tick_replication_check(void* h, int env, int nticks) {
     const F4* f[] = {&L.p.x, &L.p.y, &L.p.z, &L.qx, &L.qy, &L.qz, &L.qw, &L.wb.x, &L.wb.y, &L.wb.z, &L.vb.x, &L.vb.y, &L.vb.z};
     for (auto* x : f)
       for (int l = 1; l < 4; l++) bad += std::memcmp(&x->v[0], &x->v[l], 4) != 0;
+  }
+  return bad;
+}
+
+// 16-lane variant: replicated base state must be bit-identical across the 16 lanes of the row
+extern "C" int emu16_tick_replication_check(void* h, int env, int nticks) {
+  Emu* e = (Emu*)h;
+  EmuCtx16T<true> c(env, e->N, e->par.data());
+  State16<F16> L = load_state16<F16>(c, e->base.data(), e->leg.data());
+  F16 qdes = c.jointf() * c.par_joint(PR_POSE);
+  int bad = 0;
+  for (int t = 0; t < nticks; t++) {
+    physics_tick16(c, e->K, L, qdes);
+    const F16* f[] = {&L.p.x, &L.p.y, &L.p.z, &L.qx, &L.qy, &L.qz, &L.qw, &L.wb.x, &L.wb.y, &L.wb.z, &L.vb.x, &L.vb.y, &L.vb.z};
+    for (auto* x : f)
+      for (int l = 1; l < 16; l++) bad += std::memcmp(&x->v[0], &x->v[l], 4) != 0;
   }
   return bad;
 }

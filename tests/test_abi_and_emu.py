@@ -68,7 +68,8 @@ def _params(n, seed=0):
     return W, B
 
 
-def test_kernel_math_emulation_tracks_oracle():
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_kernel_math_emulation_tracks_oracle(lanes):
     from oracle.oracle import OracleSim
     from tests.emu.emu import EmuSim
     n = 4
@@ -76,7 +77,7 @@ def test_kernel_math_emulation_tracks_oracle():
     W, B = _params(n)
     rng = np.random.default_rng(2)
     rows = np.stack([A.dynamic_dict_to_row(A.param2dynamic_dict(rng.uniform(-0.4, 0.4, 48))) for _ in range(n)])
-    orc, emu = OracleSim(cfg), EmuSim(cfg)
+    orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=lanes)
     for s in (orc, emu):
         s.set_params(dyn=rows, etg_w=W, etg_b=B)
     oo, oe = orc.reset(), emu.reset()
@@ -94,12 +95,13 @@ def test_kernel_math_emulation_tracks_oracle():
         assert np.abs(i2[:, 9:21] - i1[:, 9:21]).max() < 2e-5
 
 
-def test_kernel_math_emulation_state_roundtrip_and_filter():
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_kernel_math_emulation_state_roundtrip_and_filter(lanes):
     from oracle.oracle import OracleSim
     from tests.emu.emu import EmuSim
     n = 2
     cfg = A.default_config(n, settle_ticks=30, enable_action_filter=True, enable_action_interp=True)
-    orc, emu = OracleSim(cfg), EmuSim(cfg)
+    orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=lanes)
     orc.reset()
     emu.reset()
     rng = np.random.default_rng(4)
@@ -114,7 +116,8 @@ def test_kernel_math_emulation_state_roundtrip_and_filter():
     assert np.abs(emu.get_state() - st).max() < 1e-6
 
 
-def test_kernel_math_emulation_heightfield_matches_oracle():
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_kernel_math_emulation_heightfield_matches_oracle(lanes):
     """BASELINE config 5 terrain: 256x256 grid, 0.05 m cells, heights U(0, 0.05) from default_rng(0)."""
     from oracle.oracle import OracleSim
     from tests.emu.emu import EmuSim
@@ -123,7 +126,7 @@ def test_kernel_math_emulation_heightfield_matches_oracle():
     hf = dict(heights=rng.uniform(0, 0.05, size=(256, 256)).astype(np.float32), cell=0.05, origin=(-6.4, -6.4))
     cfg = A.default_config(n, solver_iters=4, terrain=1, heightfield=hf)
     W, B = _params(n, seed=9)
-    orc, emu = OracleSim(cfg), EmuSim(cfg)
+    orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=lanes)
     for s in (orc, emu):
         s.set_heightfield(hf["heights"])
         s.set_params(etg_w=W, etg_b=B)
@@ -138,7 +141,8 @@ def test_kernel_math_emulation_heightfield_matches_oracle():
         assert np.abs(emu.get_state()[:, 13:25] - orc.get_state()[:, 13:25]).max() < 1e-2
 
 
-def test_kernel_math_emulation_ik_guard_unreachable_targets():
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_kernel_math_emulation_ik_guard_unreachable_targets(lanes):
     """ETG offsets that put the foot out of reach exercise the 0.95 shrink loop (SURVEY App. A act_clip)."""
     from oracle.oracle import OracleSim
     from tests.emu.emu import EmuSim
@@ -146,7 +150,7 @@ def test_kernel_math_emulation_ik_guard_unreachable_targets():
     cfg = A.default_config(n, settle_ticks=5)
     W = np.zeros((n, 3, 20))
     B = np.array([[0.0, 0.0, -0.25], [0.35, 0.0, -0.1], [0.0, 0.0, 0.02]])   # too low / too far / reachable
-    orc, emu = OracleSim(cfg), EmuSim(cfg)
+    orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=lanes)
     for s in (orc, emu):
         s.set_params(etg_w=W, etg_b=B)
         s.reset()
@@ -155,3 +159,26 @@ def test_kernel_math_emulation_ik_guard_unreachable_targets():
     assert np.all(np.isfinite(i1[:, 9:21])) and np.all(np.isfinite(i2[:, 9:21]))
     assert np.abs(i2[:, 9:21] - i1[:, 9:21]).max() < 1e-3      # shrink factor changes 5 % per iteration
     assert np.abs(i1[0, 9:21]).max() > 0.05                      # the guard produced a real (shrunk) action
+
+
+def test_both_lane_mappings_share_one_state_layout():
+    """A robot stepped by the 16-lane mapping can be handed to the 4-lane mapping mid-episode (same HBM
+    arrays) and both stay within roundoff of each other."""
+    from tests.emu.emu import EmuSim
+    n = 2
+    cfg = A.default_config(n, settle_ticks=60)
+    W, B = _params(n, seed=21)
+    a, b = EmuSim(cfg, lanes=16), EmuSim(cfg, lanes=4)
+    for s in (a, b):
+        s.set_params(etg_w=W, etg_b=B)
+        s.reset()
+    assert np.abs(a.get_state() - b.get_state()).max() < 1e-3
+    for k in range(4):
+        a.step(np.zeros((n, 12)))
+        b.step(np.zeros((n, 12)))
+    a._l.emu_set_lanes(a._h, 4)          # continue the 16-lane run with the 4-lane code
+    b._l.emu_set_lanes(b._h, 16)
+    for k in range(4):
+        a.step(np.zeros((n, 12)))
+        b.step(np.zeros((n, 12)))
+    assert np.abs(a.get_state()[:, 13:25] - b.get_state()[:, 13:25]).max() < 1e-3

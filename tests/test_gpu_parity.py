@@ -334,3 +334,26 @@ def test_batched_opt_with_points_hip_kernel_matches_reference(golden):
     w_h, b_h = opt_with_points_batched(layer, 0.5, big, g["b0"], g["w0"], device="cuda:0")
     w_t, b_t = opt_with_points_batched(layer, 0.5, big, g["b0"], g["w0"], device="cpu")
     assert np.allclose(w_h.cpu().numpy(), w_t.numpy(), atol=1e-9) and np.allclose(b_h.cpu().numpy(), b_t.numpy(), atol=1e-12)
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_both_kernel_mappings_match_oracle(lanes):
+    """lanes_per_robot = 4 (one leg per lane) and 16 (one robot per DPP row) against the oracle."""
+    _need_gpu()
+    n = 24                     # not a multiple of 16: exercises partial waves of both mappings
+    W, B = _etg_params(n, seed=17)
+    env, orc = _make(n, lanes_per_robot=lanes), _oracle(n)
+    env.reset(ETG_w=W, ETG_b=B)
+    orc.set_params(etg_w=W, etg_b=B)
+    obs_o = orc.reset()
+    assert np.abs(env.obs.cpu().numpy() - obs_o).max() < 2e-2
+    assert np.abs(env.get_state().cpu().numpy()[:, :7] - orc.get_state()[:, :7]).max() < 1e-3
+    rng = np.random.default_rng(2)
+    for k in range(10):
+        act = rng.uniform(-0.1, 0.1, size=(n, 12))
+        env.step(torch.as_tensor(act, dtype=torch.float32))
+        orc.step(act)
+        st_g, st_o = env.get_state().cpu().numpy(), orc.get_state()
+        assert np.abs(st_g[:, 13:25] - st_o[:, 13:25]).max() < 1e-3, k
+        assert np.abs(st_g[:, :7] - st_o[:, :7]).max() < 1e-3, k
+    env.close()
