@@ -241,18 +241,17 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, State16<F>& L, F qdes) {
   // matrix pipe; the own block adds the leg compliance J_l H^-1 J_l^T.
   F Arel[4][4];
 #pragma unroll
-  for (int kk = 0; kk < 4; kk++) {
-    F acc[4] = {zero, zero, zero, zero};
+  for (int kk = 0; kk < 4; kk++)
 #pragma unroll
-    for (int k = 0; k < 6; k++) c.quad_outer(c.legrot(Z[k], kk), Z[k], acc);   // acc[e] = Z_(l+kk, e) . Z_(l, sub)
-    if (kk == 0) {
-      c.quad_outer(HJ0, Jl0, acc);                                            // + sum_k HJ_e[k] Jl_sub[k]
-      c.quad_outer(HJ1, Jl1, acc);
-      c.quad_outer(HJ2, Jl2, acc);
-    }
+    for (int e = 0; e < 4; e++) Arel[kk][e] = zero;
+  // k outer / kk inner: consecutive MFMAs hit different accumulators, so the 2-pass MFMA latency is hidden
 #pragma unroll
-    for (int e = 0; e < 4; e++) Arel[kk][e] = acc[e];
-  }
+  for (int k = 0; k < 6; k++)
+#pragma unroll
+    for (int kk = 0; kk < 4; kk++) c.quad_outer(c.legrot(Z[k], kk), Z[k], Arel[kk]);   // += Z_(l+kk, e)[k] * Z_(l, sub)[k]
+  c.quad_outer(HJ0, Jl0, Arel[0]);                                                   // own block: + sum_k HJ_e[k] Jl_sub[k]
+  c.quad_outer(HJ1, Jl1, Arel[0]);
+  c.quad_outer(HJ2, Jl2, Arel[0]);
   // absolute indexing A[l'][e] = Arel[(l' - l) mod 4][e], once per tick
   const auto l0b = c.leg_is(0), l1b = c.leg_is(1), l2b = c.leg_is(2);
   F A[4][3];
