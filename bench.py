@@ -29,10 +29,10 @@ from paddlerobotics_amd.etg_fit import opt_with_points_batched  # noqa: E402
 
 SOLVER_ITERS = 2           # library default (K=2 vs K=50 differ by <0.4 mm after 5 m)
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
-# HBM bytes per k_step launch at N = 4096 from the PMC counters (profiles/r01_pmc_k_step.txt:
-# FETCH_SIZE + WRITE_SIZE, separate passes, KB units; dword accesses, uncalibrated width -- see
-# DESIGN.md section 7).  Scaled linearly with N for other batch sizes.
-PMC_TRAFFIC_BYTES_AT_4096 = (4800.5 + 3080.0) * 1024.0
+# HBM bytes per step-kernel launch at N = 4096 from the PMC counters (profiles/r01_pmc_k_step16.txt
+# and r01_pmc_k_step_lanes4.txt: FETCH_SIZE + WRITE_SIZE, separate passes, KB units; dword accesses,
+# uncalibrated width -- see DESIGN.md section 7).  Scaled linearly with N for other batch sizes.
+PMC_TRAFFIC_BYTES_AT_4096 = {16: (4063.5 + 3076.0) * 1024.0, 4: (4094.0 + 3076.0) * 1024.0}
 BYTES_PER_STEP_CFG2 = 816  # 564 B + 252 B per-env ETG w,b
 BYTES_PER_STEP_CFG3 = 808 + 252
 
@@ -73,7 +73,8 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=(2, 3))
     ap.add_argument("--precision", type=int, default=0, help="policy MFMA: 0 fp32, 1 bf16")
     ap.add_argument("--solver-iters", type=int, default=SOLVER_ITERS, help="PGS sweeps per tick")
-    ap.add_argument("--lanes", type=int, default=16, choices=(4, 16), help="kernel mapping: lanes per robot")
+    ap.add_argument("--lanes", type=int, default=0, choices=(0, 4, 16),
+                    help="kernel mapping, lanes per robot (0 = library default: 16 up to 4096 robots, else 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     args = ap.parse_args()
     SOLVER_ITERS = args.solver_iters
@@ -96,6 +97,7 @@ def main():
     N = args.num_envs
     env = make_env("Quadrupedal", num_envs=N, device=str(dev), solver_iters=args.solver_iters,
                    lanes_per_robot=args.lanes)
+    lanes = env.lanes_per_robot
     w, b = etg_population(N, seed=rank, device=dev)
     env.reset(ETG_w=w, ETG_b=b)
     policy = None
@@ -164,14 +166,14 @@ def main():
                                     "params = prior + N(0,0.02^2)" % N) if args.config == 2 else
                        ("configs[2]: %d parallel A1 per GPU, flat, ETG + residual MLP policy (random init, "
                         "precision %d)" % (N, args.precision)),
-                       "robots_per_gpu": N, "action_repeat": 13, "sim_dt": 0.002, "solver_iters": args.solver_iters, "lanes_per_robot": args.lanes,
+                       "robots_per_gpu": N, "action_repeat": 13, "sim_dt": 0.002, "solver_iters": args.solver_iters, "lanes_per_robot": lanes,
                        "parallelism": "env-shard x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "etg::k_step16" if args.lanes == 16 else "etg::k_step", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+            "roofline": {"bound": "hbm", "kernel": "etg::k_step16" if lanes == 16 else "etg::k_step", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                         "traffic": (PMC_TRAFFIC_BYTES_AT_4096 * N / 4096.0) if PMC_TRAFFIC_BYTES_AT_4096 else None,
+                         "traffic": PMC_TRAFFIC_BYTES_AT_4096[lanes] * N / 4096.0,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": bytes_per,
-                         "note": "VALU-issue-bound by construction (~1e3 FLOP/B, SURVEY 8d): 256 waves, one per busy "
-                                 "SIMD, 1 VALU issue / 4 cycles; see DESIGN.md section 7"},
+                         "note": "VALU-issue-bound by construction (~1e3 FLOP/B, SURVEY 8d): one wave per SIMD, "
+                                 "1 VALU issue / 4 cycles; see DESIGN.md section 7"},
             "survivors": float((length == args.steps + args.warmup).float().mean().item()),
         }
         if not args.no_cpu_baseline:

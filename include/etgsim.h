@@ -120,8 +120,9 @@ typedef struct EtgConfig {
   /* heightfield (terrain==1): row-major [hf_ny][hf_nx] heights, cell size, origin */
   int32_t hf_nx, hf_ny;
   double hf_cell, hf_x0, hf_y0;
-  /* kernel mapping: 16 = one robot per 16-lane DPP row (default, fills the chip at 4096 robots),
-   * 4 = one robot per quad (one leg per lane). Same results to fp32 roundoff, same state layout. */
+  /* kernel mapping: 16 = one robot per 16-lane DPP row (fills the chip at 4096 robots), 4 = one
+   * robot per quad (one leg per lane; 4x the robots per wave, for batches > 4096), 0 = auto
+   * (16 if num_envs <= 4096 else 4). Same results to fp32 roundoff, same state layout.         */
   int32_t lanes_per_robot;
 } EtgConfig;
 
@@ -132,6 +133,7 @@ int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int device, Etg
 void etg_destroy(EtgHandle* h);
 const char* etg_last_error(void);
 int etg_version(void);
+int etg_lanes_per_robot(const EtgHandle* h); /* the mapping etg_create resolved (4 or 16) */
 
 /* ---- parameters (device pointers, float32) ------------------------------
  * dyn   : [N,48] physical-unit dynamic_param rows (layout of train.py:112-126:

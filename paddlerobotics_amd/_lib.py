@@ -11,7 +11,7 @@ from . import build as _build
 _LIB = None
 
 SYMBOLS = [
-    "etg_create", "etg_destroy", "etg_last_error", "etg_version", "etg_set_params",
+    "etg_create", "etg_destroy", "etg_last_error", "etg_version", "etg_lanes_per_robot", "etg_set_params",
     "etg_set_heightfield", "etg_reset", "etg_step", "etg_episode_stats", "etg_rollout_openloop",
     "etg_get_state",
     "etg_set_state", "etg_policy_create", "etg_policy_load", "etg_policy_forward",
@@ -43,6 +43,7 @@ def load():
     lib.etg_create.argtypes = [vp, vp, i32, C.POINTER(vp)]
     lib.etg_destroy.argtypes = [vp]
     lib.etg_destroy.restype = None
+    lib.etg_lanes_per_robot.argtypes = [vp]
     lib.etg_set_params.argtypes = [vp, vp, vp, vp, i32, vp, vp]
     lib.etg_set_heightfield.argtypes = [vp, vp, vp]
     lib.etg_reset.argtypes = [vp, vp, vp, vp]

@@ -95,8 +95,17 @@ struct GpuCtx {
 // FLAT selects the plane-z=0 fast path at compile time (contact frame = rows of R, no terrain lookup)
 template <bool FLAT> struct GpuCtxT : GpuCtx { static constexpr bool kFlat = FLAT; };
 
+// Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its own L2.  Robots
+// of neighbouring blocks share 128 B lines of the SoA state (a block covers only 16-64 B of a field), so
+// give every XCD a CONTIGUOUS range of robots: the blocks that share a line then share an L2 and the
+// line is fetched from HBM once instead of once per XCD.  Bijective for any grid size.
+__device__ __forceinline__ int xcd_contiguous_block() {
+  const int nb = gridDim.x, b = blockIdx.x, x = b & 7, q = nb >> 3, r = nb & 7;
+  return x * q + (x < r ? x : r) + (b >> 3);
+}
+
 __device__ __forceinline__ bool make_ctx(const KCfg& K, GpuCtx& c) {
-  c.gid = blockIdx.x * blockDim.x + threadIdx.x;
+  c.gid = xcd_contiguous_block() * blockDim.x + threadIdx.x;
   c.N = K.n_env;
   c.NL = 4 * K.n_env;
   c.env = c.gid >> 2;
@@ -258,7 +267,7 @@ template <bool FLAT> struct GpuCtx16T : GpuCtx16 { static constexpr bool kFlat =
 
 __device__ __forceinline__ bool make_ctx16(const KCfg& K, const DevState& D, GpuCtx16& c, float* lds_all) {
   c.tid = threadIdx.x;
-  c.env = blockIdx.x * 4 + (threadIdx.x >> 4);
+  c.env = xcd_contiguous_block() * 4 + (threadIdx.x >> 4);
   c.r = threadIdx.x & 15;
   c.leg = c.r >> 2;
   c.sub = c.r & 3;
@@ -358,7 +367,8 @@ static int fail(int code, const std::string& msg) {
 extern "C" const char* etg_last_error(void) { return g_err.c_str(); }
 // shared with policy_mlp.hip so that one etg_last_error() serves the whole ABI
 extern "C" void etg_set_last_error_(const char* msg) { g_err = msg ? msg : ""; }
-extern "C" int etg_version(void) { return 1; }
+extern "C" int etg_lanes_per_robot(const EtgHandle* h) { return h ? h->lanes : ETG_ERR_BAD_ARG; }
+int etg_version(void) { return 1; }
 
 static int grid_for(const EtgHandle* h) { return (4 * h->N + BLOCK - 1) / BLOCK; }
 
@@ -381,7 +391,10 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
     delete h;
     return fail(ETG_ERR_BAD_ARG, "etg_create: lanes_per_robot must be 4 or 16");
   }
-  h->lanes = cfg->lanes_per_robot == 4 ? 4 : 16;
+  // 0 = auto.  Both kernels hold one wave per SIMD (register footprint), so the chip runs 1024 waves
+  // at a time: 16 lanes/robot fills it with 4096 robots and is faster per robot up to there; beyond
+  // that the 4-lanes/robot kernel packs 4x the robots per wave (measured crossover).
+  h->lanes = cfg->lanes_per_robot != 0 ? cfg->lanes_per_robot : (cfg->num_envs <= 4096 ? 16 : 4);
   size_t N = h->N, NL = 4 * N;
   struct { void** p; size_t bytes; } allocs[] = {
       {(void**)&h->D.base, BS_N * N * 4},   {(void**)&h->D.leg, LG_N * NL * 4},   {(void**)&h->D.ctl, CT_N * N * 4},

@@ -48,7 +48,7 @@ class BatchedQuadrupedEnv:
                  reward_p=5.0, ETG_path="", random_param=None, ETG_H=20, vel_d=0.5, step_y=0.05,
                  enable_action_filter=False, ETG_T2=0.5, action_repeat=13, sim_time_step=0.002,
                  settle_ticks=500, solver_iters=2, enable_action_interpolation=False,
-                 heightfield=None, lanes_per_robot=16, **unused):
+                 heightfield=None, lanes_per_robot=0, **unused):
         if render:
             raise ValueError("render is not supported by the batched GPU simulator")
         if int(ETG_H) != A.RBF_H:
@@ -77,6 +77,7 @@ class BatchedQuadrupedEnv:
         self._h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
         _lib.check(self._lib.etg_create(C.byref(self.cfg), C.byref(self.model), idx, C.byref(self._h)))
+        self.lanes_per_robot = int(self._lib.etg_lanes_per_robot(self._h))   # 0 (auto) resolved by the library
         N, dev = self.num_envs, self.device
         self.obs = torch.zeros(N, A.OBS_DIM, device=dev)
         self.reward = torch.zeros(N, device=dev)

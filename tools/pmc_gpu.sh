@@ -6,7 +6,7 @@ OUT=/tmp/pmc_$1
 mkdir -p $OUT $R/gpurun_out
 run() { # name counters...
   name=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o pmc -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline > $OUT/$name.log 2>&1 || echo "pass $name failed"
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o pmc -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline $PMC_BENCH_ARGS > $OUT/$name.log 2>&1 || echo "pass $name failed"
 }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
@@ -19,10 +19,10 @@ for name in ("fetch","write","valu","lds"):
     if not fs: print(name, "no output"); continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
-        if "k_step" in r["Kernel_Name"]:
+        if "k_step" in r["Kernel_Name"]:  # k_step<..> (4 lanes/robot) or k_step16<..> (16 lanes/robot)
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
-        print("%-24s mean per k_step launch %14.1f  (n=%d)" % (k, sum(v)/len(v), len(v)))
+        print("%-24s mean per step-kernel launch %14.1f  (n=%d)" % (k, sum(v)/len(v), len(v)))
 PY
 mkdir -p $R/gpurun_out
 cat $R/gpurun_out/pmc_$1.txt
