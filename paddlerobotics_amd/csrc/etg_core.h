@@ -670,19 +670,22 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   F last_fwx = c.ld_lane(legctl, LC_LAST_FOOT_X);
   L.energy = F(0.0f);
   const bool interp = K.enable_interp && has_last;
+  // Only the two readings a later observation will blend (minitaur.py:1185-1193: ticks T-n and
+  // T-n-1 of some step end T) have to reach the ring: (i+1+n) mod R in {0, R-1}, i.e. i == ia or i == ib.
   const int n_lat = c.uniform_int(c.par(PR_LAT_N));
+  const int R_ = K.action_repeat;
+  const float inv_repeat = 1.0f / (float)K.action_repeat;
+  const int mlat = n_lat < 0 ? 0 : n_lat % R_;
+  const int ia = R_ - 1 - mlat;
+  const int ib = n_lat < 0 ? ia : (ia == 0 ? R_ - 1 : ia - 1);
   for (int i = 0; i < K.action_repeat; i++) {  // minitaur.py:254-258
     F proc[3];
-    float lerp = (float)(i + 1) / (float)K.action_repeat;
+    float lerp = (float)(i + 1) * inv_repeat;
 #pragma unroll
     for (int j = 0; j < 3; j++) proc[j] = interp ? last[j] + F(lerp) * (qdes[j] - last[j]) : qdes[j];
     physics_tick(c, K, L, proc);
     tick++;
-    // Only the two readings a later observation will blend (minitaur.py:1185-1193: ticks T-n and
-    // T-n-1 of some step end T) have to reach the ring: (i+1+n) mod R in {0, R-1}.
-    const bool need = n_lat < 0 ? (i == K.action_repeat - 1)
-                                : (((i + 1 + n_lat) % K.action_repeat == 0) || ((i + 2 + n_lat) % K.action_repeat == 0));
-    if (need) ring_push(c, ring, tick & (RING - 1), L);
+    if (i == ia || i == ib) ring_push(c, ring, tick & (RING - 1), L);
   }
 #pragma unroll
   for (int j = 0; j < 3; j++) c.st_lane(legctl, LC_LAST_QDES + j, qdes[j]);

@@ -55,7 +55,9 @@ template <class F, class Ctx> ETG_HD void store_state16(const Ctx& c, float* bas
 }
 
 // scans along the 3-link chain held by sub-lanes 0..2 of a quad (the aux lane holds zeros)
-template <class F, class Ctx> ETG_HD F chain_prefix(const Ctx& c, F x, F m1, F m2) { return x + m1 * c.qdn1(x) + m2 * c.qdn2(x); }
+// prefix: the inputs are ZERO on the aux lane (they carry a factor qd, masked there), so the quad_perms
+// [3,0,1,2] and [3,3,0,1] shift zeros in from the aux lane and no lane mask is needed (two v_add_f32_dpp)
+template <class F, class Ctx> ETG_HD F chain_prefix(const Ctx& c, F x, F, F) { return x + c.qdn1(x) + c.qdn2(x); }
 template <class F, class Ctx> ETG_HD F chain_suffix(const Ctx& c, F x) { return x + c.qup1(x) + c.qup2(x); }
 template <class F, class Ctx> ETG_HD SV<F> chain_prefix(const Ctx& c, SV<F> v, F m1, F m2) {
   return {{chain_prefix(c, v.a.x, m1, m2), chain_prefix(c, v.a.y, m1, m2), chain_prefix(c, v.a.z, m1, m2)},
@@ -69,9 +71,21 @@ template <class F, class Ctx> ETG_HD SV<F> quad_bcast(const Ctx& c, SV<F> v, int
   return {{c.qb(v.a.x, j), c.qb(v.a.y, j), c.qb(v.a.z, j)}, {c.qb(v.l.x, j), c.qb(v.l.y, j), c.qb(v.l.z, j)}};
 }
 
+// per-lane constants of a physics tick, read from the LDS parameter column ONCE per kernel and kept in
+// registers over the 13 (step) / 500 (settle) ticks: a lone wave per SIMD cannot hide the LDS latency of
+// re-reading them at the top of every tick (phase profile: +~1000 cycles per tick)
+template <class F> struct TickPar { F kp, kd, sy, m0, mu, link[10]; V3<F> o1, gw; S3<F> I0s; };
+template <class F, class Ctx> ETG_HD TickPar<F> load_tick_par(const Ctx& c) {
+  TickPar<F> t;
+  t.kp = c.par_joint(PR_KP); t.kd = c.par_joint(PR_KD); t.sy = c.par(PR_SY); t.m0 = c.par(PR_M0); t.mu = c.par(PR_MU);
+  for (int k = 0; k < 10; k++) t.link[k] = c.par_link(k);
+  t.o1 = par3<F>(c, PR_O1); t.gw = par3<F>(c, PR_G); t.I0s = par_s3<F>(c, PR_I0);
+  return t;
+}
+
 // leg geometry shared by every lane of the quad
 template <class F> struct LegGeo { F sa, ca, sh, ch, shk, chk; V3<F> yax, o1, o2, o3, pf, ez2, ez3; };
-template <class F, class Ctx> ETG_HD LegGeo<F> leg_geometry(const Ctx& c, const KCfg& K, F q_own) {
+template <class F, class Ctx> ETG_HD LegGeo<F> leg_geometry(const Ctx& c, const KCfg& K, const V3<F>& o1, F sy, F q_own) {
   LegGeo<F> g;
   F sq, cq;
   sincos_(q_own, sq, cq);  // one sincos per lane (its own joint), shared through the quad
@@ -84,8 +98,8 @@ template <class F, class Ctx> ETG_HD LegGeo<F> leg_geometry(const Ctx& c, const 
   g.yax = {zero, g.ca, g.sa};
   g.ez2 = {g.sh, -(g.sa * g.ch), g.ca * g.ch};
   g.ez3 = {g.shk, -(g.sa * g.chk), g.ca * g.chk};
-  g.o1 = par3<F>(c, PR_O1);
-  g.o2 = g.o1 + c.par(PR_SY) * g.yax;
+  g.o1 = o1;
+  g.o2 = g.o1 + sy * g.yax;
   g.o3 = g.o2 - F(K.upper_len) * g.ez2;
   g.pf = g.o3 - F(K.lower_len) * g.ez3;
   return g;
@@ -93,7 +107,7 @@ template <class F, class Ctx> ETG_HD LegGeo<F> leg_geometry(const Ctx& c, const 
 
 // ------------------------------------------------------------------ one physics tick, 16 lanes per robot
 template <class F, class Ctx>
-ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, State16<F>& L, F qdes) {
+ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, State16<F>& L, F qdes) {
   typedef V3<F> V;
   typedef SV<F> W;
   const F dt(K.dt), zero(0.0f), one(1.0f);
@@ -104,24 +118,23 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, State16<F>& L, F qdes) {
   const F m2 = m1 - f1;                       // sub >= 2
 
   // ---- PD motor model (laikago_motor.py:165-173), this lane's joint
-  F tau = mj * (-(c.par_joint(PR_KP) * (L.q - qdes)) - c.par_joint(PR_KD) * L.qd);
+  F tau = mj * (-(tp.kp * (L.q - qdes)) - tp.kd * L.qd);
   if (K.torque_limit > 0.0f) tau = fminf_(fmaxf_(tau, F(-K.torque_limit)), F(K.torque_limit));
 
   // ---- leg geometry, this lane's link frame R_s = Rx(a) Ry(theta_s), theta = (0, h, h+k)
-  const LegGeo<F> g = leg_geometry(c, K, L.q);
+  const LegGeo<F> g = leg_geometry(c, K, tp.o1, tp.sy, L.q);
   const F ct = sel_(s0, one, sel_(s1, g.ch, g.chk)), st = sel_(s0, zero, sel_(s1, g.sh, g.shk));
   Fr<F> R = {{ct, g.sa * st, -(g.ca * st)}, g.yax, {st, -(g.sa * ct), g.ca * ct}};
   V os = {sel_(s0, g.o1.x, sel_(s1, g.o2.x, g.o3.x)), sel_(s0, g.o1.y, sel_(s1, g.o2.y, g.o3.y)),
           sel_(s0, g.o1.z, sel_(s1, g.o2.z, g.o3.z))};
   V zs = {f0, m1 * g.ca, m1 * g.sa};          // joint axis: x for the hip, y' for thigh and calf
   W S = {zs, cross(os, zs)};
-  RBI<F> I = link_inertia(c.par_link(0), V{c.par_link(1), c.par_link(2), c.par_link(3)},
-                          S3<F>{c.par_link(4), c.par_link(5), c.par_link(6), c.par_link(7), c.par_link(8), c.par_link(9)},
-                          R, os);
+  RBI<F> I = link_inertia(tp.link[0], V{tp.link[1], tp.link[2], tp.link[3]},
+                          S3<F>{tp.link[4], tp.link[5], tp.link[6], tp.link[7], tp.link[8], tp.link[9]}, R, os);
   c.phase(0);
   // ---- RNEA along the chain (prefix scans), bias forces (suffix scan)
   Rows<F> Rw = quat_rows(L.qx, L.qy, L.qz, L.qw);
-  V gw = par3<F>(c, PR_G);
+  const V gw = tp.gw;
   V gb = {Rw.r0.x * gw.x + Rw.r1.x * gw.y + Rw.r2.x * gw.z, Rw.r0.y * gw.x + Rw.r1.y * gw.y + Rw.r2.y * gw.z,
           Rw.r0.z * gw.x + Rw.r1.z * gw.y + Rw.r2.z * gw.z};
   W V0 = {L.wb, L.vb};
@@ -133,8 +146,8 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, State16<F>& L, F qdes) {
   W f = apply(I, as) + crf(Vs, apply(I, Vs));
   W fc = chain_suffix(c, f);
   F C = dot(S, fc);
-  const F m0 = c.par(PR_M0);
-  const S3<F> I0s = par_s3<F>(c, PR_I0);
+  const F m0 = tp.m0;
+  const S3<F> I0s = tp.I0s;
   RBI<F> I0 = {m0, {zero, zero, zero}, I0s};
   W fb0 = apply(I0, a0) + crf(V0, apply(I0, V0));
   c.phase(1);
@@ -160,25 +173,23 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, State16<F>& L, F qdes) {
   F rl = tau - C;                                      // (aux lane: tau = 0, C = 0 since S = 0 there)
   c.phase(2);
   // ---- base Schur complement: every term is a sum over the robot's 16 lanes
+  // S = M_bb - Fm H^-1 Fm^T with M_bb = trunk + sum of the links' inertias about the base origin: each lane
+  // subtracts its P F^T term from ITS link's 6x6 inertia before the one 16-lane reduction (21 sums)
+  const F lm[21] = {I.I.xx,
+                    I.I.xy, I.I.yy,
+                    I.I.xz, I.I.yz, I.I.zz,
+                    zero, I.h.z, -I.h.y, I.m,
+                    -I.h.z, zero, I.h.x, zero, I.m,
+                    I.h.y, -I.h.x, zero, zero, zero, I.m};
   F s[21];
 #pragma unroll
   for (int i = 0; i < 6; i++)
 #pragma unroll
-    for (int j = 0; j <= i; j++) s[i * (i + 1) / 2 + j] = c.sum16(comp(P, i) * comp(Fs, j));
-  RBI<F> Ib;  // composite of the whole robot = trunk + sum of every link
-  Ib.m = m0 + c.sum16(I.m);
-  Ib.h = {c.sum16(I.h.x), c.sum16(I.h.y), c.sum16(I.h.z)};
-  Ib.I = {I0s.xx + c.sum16(I.I.xx), I0s.yy + c.sum16(I.I.yy), I0s.zz + c.sum16(I.I.zz),
-          I0s.xy + c.sum16(I.I.xy), I0s.xz + c.sum16(I.I.xz), I0s.yz + c.sum16(I.I.yz)};
-  F mbb[21];
-  mbb[0] = Ib.I.xx;
-  mbb[1] = Ib.I.xy; mbb[2] = Ib.I.yy;
-  mbb[3] = Ib.I.xz; mbb[4] = Ib.I.yz; mbb[5] = Ib.I.zz;
-  mbb[6] = zero;     mbb[7] = Ib.h.z;   mbb[8] = -Ib.h.y;  mbb[9] = Ib.m;
-  mbb[10] = -Ib.h.z; mbb[11] = zero;    mbb[12] = Ib.h.x;  mbb[13] = zero; mbb[14] = Ib.m;
-  mbb[15] = Ib.h.y;  mbb[16] = -Ib.h.x; mbb[17] = zero;    mbb[18] = zero; mbb[19] = zero; mbb[20] = Ib.m;
-#pragma unroll
-  for (int i = 0; i < 21; i++) s[i] = mbb[i] - s[i];
+    for (int j = 0; j <= i; j++) s[i * (i + 1) / 2 + j] = c.sum16(lm[i * (i + 1) / 2 + j] - comp(P, i) * comp(Fs, j));
+  s[0] = s[0] + I0s.xx;
+  s[1] = s[1] + I0s.xy; s[2] = s[2] + I0s.yy;
+  s[3] = s[3] + I0s.xz; s[4] = s[4] + I0s.yz; s[5] = s[5] + I0s.zz;
+  s[9] = s[9] + m0; s[14] = s[14] + m0; s[20] = s[20] + m0;
   F rb[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) rb[i] = -comp(fb0, i) - c.sum16(comp(f, i) + rl * comp(P, i));
@@ -189,8 +200,8 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, State16<F>& L, F qdes) {
   for (int i = 0; i < 6; i++) rb[i] = rb[i] * dinv[i];
   bwd6(s, rb);
   W ab = {{rb[0], rb[1], rb[2]}, {rb[3], rb[4], rb[5]}};
-  const F rl0 = c.qb(rl, 0), rl1 = c.qb(rl, 1), rl2 = c.qb(rl, 2);
-  F qdd = h0 * rl0 + h1 * rl1 + h2 * rl2 - dot(P, ab);
+  F qdd = -dot(P, ab);                                 // + row `sub` of H^-1 times (tau - C) of the leg
+  c.fmac_qb(qdd, rl, h0, 0); c.fmac_qb(qdd, rl, h1, 1); c.fmac_qb(qdd, rl, h2, 2);   // rl is a phase old: no DPP hazard
   c.phase(3);
   // ---- unconstrained velocity
   V wbs = L.wb + dt * ab.a, vbs = L.vb + dt * ab.l;
@@ -236,31 +247,40 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, State16<F>& L, F qdes) {
 #pragma unroll
   for (int k = 0; k < 6; k++) Z[k] = g6[k] * sq[k];
   c.phase(5);
-  // ---- Delassus row of this lane.  Block against leg (l + kk) mod 4 = 4x4 outer product between
-  // this quad's Z and the row rotated by kk legs, contracted over the 6 base coordinates on the
-  // matrix pipe; the own block adds the leg compliance J_l H^-1 J_l^T.
-  F Arel[4][4];
-#pragma unroll
-  for (int kk = 0; kk < 4; kk++)
-#pragma unroll
-    for (int e = 0; e < 4; e++) Arel[kk][e] = zero;
-  // k outer / kk inner: consecutive MFMAs hit different accumulators, so the 2-pass MFMA latency is hidden
-#pragma unroll
-  for (int k = 0; k < 6; k++)
-#pragma unroll
-    for (int kk = 0; kk < 4; kk++) c.quad_outer(c.legrot(Z[k], kk), Z[k], Arel[kk]);   // += Z_(l+kk, e)[k] * Z_(l, sub)[k]
-  c.quad_outer(HJ0, Jl0, Arel[0]);                                                   // own block: + sum_k HJ_e[k] Jl_sub[k]
-  c.quad_outer(HJ1, Jl1, Arel[0]);
-  c.quad_outer(HJ2, Jl2, Arel[0]);
-  // absolute indexing A[l'][e] = Arel[(l' - l) mod 4][e], once per tick
-  const auto l0b = c.leg_is(0), l1b = c.leg_is(1), l2b = c.leg_is(2);
+  // ---- Delassus row of this lane: A[l'][e] = Z_own . Z_(l',e) over the 6 base coordinates, every term one
+  // fused broadcast-FMA (v_fmac_f32_dpp row_newbcast); rows of the own leg add the leg compliance
+  // J_l H^-1 J_l^T.  (The 4-lane kernel contracts the same products on the matrix pipe; with one row per
+  // lane the DPP form needs no accumulator shuffles and no MFMA latency padding.)
+  F lam = rowf * F(K.warmstart) * L.lam;                        // warm start (defined here: DPP source below)
+  F hj[3] = {HJ0, HJ1, HJ2};
+  c.dpp_ready(Z, 6);
+  c.dpp_ready(hj, 3);
+  c.dpp_ready(&lam, 1);
   F A[4][3];
 #pragma unroll
   for (int lp = 0; lp < 4; lp++)
 #pragma unroll
-    for (int e = 0; e < 3; e++)
-      A[lp][e] = sel_(l0b, Arel[lp][e], sel_(l1b, Arel[(lp + 3) & 3][e], sel_(l2b, Arel[(lp + 2) & 3][e], Arel[(lp + 1) & 3][e])));
-  const F Add = sel_(s0, Arel[0][0], sel_(s1, Arel[0][1], Arel[0][2]));         // own diagonal
+    for (int e = 0; e < 3; e++) A[lp][e] = c.rbcast(Z[0], 4 * lp + e) * Z[0];
+#pragma unroll
+  for (int k = 1; k < 6; k++)
+#pragma unroll
+    for (int lp = 0; lp < 4; lp++)
+#pragma unroll
+      for (int e = 0; e < 3; e++) c.fmac_rbcast(A[lp][e], Z[k], Z[k], 4 * lp + e);
+  F ownl[4];
+#pragma unroll
+  for (int lp = 0; lp < 4; lp++) ownl[lp] = sel_(c.leg_is(lp), one, zero);
+#pragma unroll
+  for (int e = 0; e < 3; e++) {
+    F own = c.qb(hj[0], e) * Jl0;                               // sum_j HJ_e[j] Jl_sub[j]
+    c.fmac_qb(own, hj[1], Jl1, e);
+    c.fmac_qb(own, hj[2], Jl2, e);
+#pragma unroll
+    for (int lp = 0; lp < 4; lp++) A[lp][e] = A[lp][e] + ownl[lp] * own;
+  }
+  F Add = hj[0] * Jl0 + hj[1] * Jl1 + hj[2] * Jl2;              // own diagonal
+#pragma unroll
+  for (int k = 0; k < 6; k++) Add = Add + Z[k] * Z[k];
   const F iA = sel_(rowf > F(0.5f), rcp_(Add), zero);
   c.phase(6);
   // ---- row velocity under the unconstrained motion, warm start
@@ -269,19 +289,15 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, State16<F>& L, F qdes) {
   F u = rowf * dot(dir, vc);
   const F idt(1.0f / K.dt);
   const F tgt = f0 * sel_(phi > zero, -(phi * idt), -(F(K.erp) * phi * idt));   // only normal rows have a target
-  F lam = rowf * F(K.warmstart) * L.lam;
 #pragma unroll
   for (int lp = 0; lp < 4; lp++)
 #pragma unroll
-    for (int e = 0; e < 3; e++) u = u + A[lp][e] * c.rbcast(lam, 4 * lp + e);
+    for (int e = 0; e < 3; e++) c.fmac_rbcast(u, lam, A[lp][e], 4 * lp + e);
   c.phase(7);
   // ---- projected Gauss-Seidel, rows in the order (FR n,t1,t2), (FL ...), (RR ...), (RL ...): the owner
   // lane's candidate is broadcast over the row with row_newbcast and applied by every lane.
-  const F mu = c.par(PR_MU);
+  const F mu = tp.mu;
   const F c0 = tgt * iA;
-  F ownl[4];
-#pragma unroll
-  for (int lp = 0; lp < 4; lp++) ownl[lp] = sel_(c.leg_is(lp), one, zero);
   const F tangf = f1 + f2;
   for (int it = 0; it < K.iters; it++) {
 #pragma unroll
@@ -320,7 +336,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, State16<F>& L, F qdes) {
   L.wb = wbs + dB.a;
   L.vb = vbs + dB.l;
   // joint j of this leg receives sum_d HJ_d[j] lam_d
-  const F dj0 = c.qsum(HJ0 * lam), dj1 = c.qsum(HJ1 * lam), dj2 = c.qsum(HJ2 * lam);
+  const F dj0 = c.qsum(hj[0] * lam), dj1 = c.qsum(hj[1] * lam), dj2 = c.qsum(hj[2] * lam);
   L.qd = mj * (qds + (f0 * dj0 + f1 * dj1 + f2 * dj2) - dot(P, dB));
   L.lam = lam;
   const F ln_leg = c.qb(lam, 0);
@@ -422,7 +438,7 @@ ETG_HD F etg_action16(const Ctx& c, const KCfg& K, const float* etgp, float t) {
 // foot kinematics of the leg (replicated in the quad)
 template <class F> struct FootKin16 { F fwx, fbz, knee_h; };
 template <class F, class Ctx> ETG_HD FootKin16<F> foot_kin16(const Ctx& c, const KCfg& K, const State16<F>& L) {
-  const LegGeo<F> g = leg_geometry(c, K, L.q);
+  const LegGeo<F> g = leg_geometry(c, K, par3<F>(c, PR_O1), c.par(PR_SY), L.q);
   Rows<F> Rw = quat_rows(L.qx, L.qy, L.qz, L.qw);
   FootKin16<F> k;
   k.fwx = L.p.x + dot(Rw.r0, g.pf);
@@ -494,15 +510,21 @@ ETG_HD void control_step16(const Ctx& c, const KCfg& K, State16<F>& L, float* ri
   F last_fwx = c.ld_legf(legctl, LC_LAST_FOOT_X);
   L.energy = F(0.0f);
   const bool interp = K.enable_interp && has_last;
+  // The observation at the end of the step reads ring slots tick_end - n and tick_end - n - 1 only, so
+  // only the ticks that land there are pushed: i == ia or i == ib (one modulo per step, not two per tick).
   const int n_lat = c.uniform_int(c.par(PR_LAT_N));
+  const int R_ = K.action_repeat;
+  const float inv_repeat = 1.0f / (float)K.action_repeat;
+  const int mlat = n_lat < 0 ? 0 : n_lat % R_;
+  const int ia = R_ - 1 - mlat;
+  const int ib = n_lat < 0 ? ia : (ia == 0 ? R_ - 1 : ia - 1);
+  const TickPar<F> tp = load_tick_par<F>(c);
   for (int i = 0; i < K.action_repeat; i++) {
-    float lerp = (float)(i + 1) / (float)K.action_repeat;
+    float lerp = (float)(i + 1) * inv_repeat;
     F proc = interp ? last + F(lerp) * (qdes - last) : qdes;
-    physics_tick16(c, K, L, proc);
+    physics_tick16(c, K, tp, L, proc);
     tick++;
-    const bool need = n_lat < 0 ? (i == K.action_repeat - 1)
-                                : (((i + 1 + n_lat) % K.action_repeat == 0) || ((i + 2 + n_lat) % K.action_repeat == 0));
-    if (need) ring_push16(c, ring, tick & (RING - 1), L);
+    if (i == ia || i == ib) ring_push16(c, ring, tick & (RING - 1), L);
   }
   c.st_joint(legctl, LC_LAST_QDES, qdes);
   step_count++;
@@ -580,8 +602,9 @@ ETG_HD void reset_row16(const Ctx& c, const KCfg& K, State16<F>& L, float* ring,
   L.energy = F(0.0f);
   for (int sl = 0; sl < RING; sl++) ring_push16(c, ring, sl, L);
   int tick = 0;
+  const TickPar<F> tp = load_tick_par<F>(c);
   for (int i = 0; i < K.settle_ticks; i++) {
-    physics_tick16(c, K, L, pose);
+    physics_tick16(c, K, tp, L, pose);
     tick++;
     ring_push16(c, ring, tick & (RING - 1), L);
   }

@@ -209,8 +209,8 @@ struct GpuCtx16 {
   }
   __device__ __forceinline__ float qup1(float a) const { return dpp_<0xF9>(a); }     // quad_perm [1,2,3,3]
   __device__ __forceinline__ float qup2(float a) const { return dpp_<0xFE>(a); }     // quad_perm [2,3,3,3]
-  __device__ __forceinline__ float qdn1(float a) const { return dpp_<0x90>(a); }     // quad_perm [0,0,1,2]
-  __device__ __forceinline__ float qdn2(float a) const { return dpp_<0x40>(a); }     // quad_perm [0,0,0,1]
+  __device__ __forceinline__ float qdn1(float a) const { return dpp_<0x93>(a); }     // quad_perm [3,0,1,2]
+  __device__ __forceinline__ float qdn2(float a) const { return dpp_<0x4F>(a); }     // quad_perm [3,3,0,1]
   __device__ __forceinline__ float qswap12(float a) const { return dpp_<0xD8>(a); }  // quad_perm [0,2,1,3]
   __device__ __forceinline__ float qsum(float a) const { float t = a + dpp_<0xB1>(a); return t + dpp_<0x4E>(t); }
   // ---- row (= robot) exchanges: xor1, xor2, row_half_mirror, row_mirror -- order-symmetric, so the
@@ -239,6 +239,38 @@ struct GpuCtx16 {
     v = __builtin_amdgcn_mfma_f32_4x4x1f32(a, b, v, 0, 0, 0);
     acc[0] = v[0]; acc[1] = v[1]; acc[2] = v[2]; acc[3] = v[3];
   }
+  // ---- fused broadcast-multiply-accumulate: acc += x@lane(r0 of the row / j of the quad) * y in ONE VOP2-DPP
+  // instruction.  The compiler's DPP combiner only folds v_mov_dpp into mul/add (FMAs are still VOP3 when it
+  // runs), so the FMA form is spelled out.  HAZARD: the hardware wants 2 wait states between the VALU write
+  // of x and a DPP read of it, and the compiler does not see into the asm -- callers pass an x that went
+  // through dpp_ready() (one s_nop 1 for a whole group of sources).
+#define ETG_FMAC_DPP(CTRL) asm("v_fmac_f32_dpp %0, %1, %2 " CTRL " row_mask:0xf bank_mask:0xf bound_ctrl:1" : "+v"(acc) : "v"(x), "v"(y))
+  __device__ __forceinline__ void fmac_rbcast(float& acc, float x, float y, int r0) const {
+    switch (r0) {
+      case 0: ETG_FMAC_DPP("row_newbcast:0"); break;   case 1: ETG_FMAC_DPP("row_newbcast:1"); break;
+      case 2: ETG_FMAC_DPP("row_newbcast:2"); break;   case 3: ETG_FMAC_DPP("row_newbcast:3"); break;
+      case 4: ETG_FMAC_DPP("row_newbcast:4"); break;   case 5: ETG_FMAC_DPP("row_newbcast:5"); break;
+      case 6: ETG_FMAC_DPP("row_newbcast:6"); break;   case 7: ETG_FMAC_DPP("row_newbcast:7"); break;
+      case 8: ETG_FMAC_DPP("row_newbcast:8"); break;   case 9: ETG_FMAC_DPP("row_newbcast:9"); break;
+      case 10: ETG_FMAC_DPP("row_newbcast:10"); break; case 11: ETG_FMAC_DPP("row_newbcast:11"); break;
+      case 12: ETG_FMAC_DPP("row_newbcast:12"); break; case 13: ETG_FMAC_DPP("row_newbcast:13"); break;
+      case 14: ETG_FMAC_DPP("row_newbcast:14"); break; default: ETG_FMAC_DPP("row_newbcast:15"); break;
+    }
+  }
+  __device__ __forceinline__ void fmac_qb(float& acc, float x, float y, int j) const {
+    switch (j) {
+      case 0: ETG_FMAC_DPP("quad_perm:[0,0,0,0]"); break; case 1: ETG_FMAC_DPP("quad_perm:[1,1,1,1]"); break;
+      case 2: ETG_FMAC_DPP("quad_perm:[2,2,2,2]"); break; default: ETG_FMAC_DPP("quad_perm:[3,3,3,3]"); break;
+    }
+  }
+#undef ETG_FMAC_DPP
+  // every value that later feeds fmac_rbcast / fmac_qb as the broadcast source passes through here: the
+  // asm "modifies" them, so their producers are ordered before it and the DPP reads after it
+  __device__ __forceinline__ void dpp_ready(float* v, int n) const {
+    if (n == 6) asm volatile("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
+    else if (n == 3) asm volatile("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
+    else asm volatile("s_nop 1" : "+v"(v[0]));
+  }
   // ---- memory (same SoA arrays as the 4-lane kernels)
   __device__ __forceinline__ float ld_joint(const float* p, int f0) const { return p[(size_t)(f0 + sc) * NL + col]; }
   __device__ __forceinline__ void st_joint(float* p, int f0, float v) const { if (sub < 3) p[(size_t)(f0 + sub) * NL + col] = v; }
@@ -257,7 +289,21 @@ struct GpuCtx16 {
   __device__ __forceinline__ void st_row_leg(float* p, int rowlen, int col0, float v) const { if (sub == 0) p[(size_t)env * rowlen + col0 + leg] = v; }
   __device__ __forceinline__ void st_row_env(float* p, int rowlen, int c_, float v) const { if (r == 0) p[(size_t)env * rowlen + c_] = v; }
   __device__ __forceinline__ float ld_row_env(const float* p, int rowlen, int c_) const { return p[(size_t)env * rowlen + c_]; }
-  __device__ __forceinline__ void phase(int) const { __builtin_amdgcn_sched_barrier(0); }
+  __device__ __forceinline__ void phase(int id) const {
+#ifndef ETG_NO_PHASE_BARRIER16
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+#ifdef ETG_PROFILE_PHASES
+    long long t = clock64();
+    prof[id] += t - prof_last;
+    prof_last = t;
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+#ifdef ETG_PROFILE_PHASES
+  mutable long long prof[16];
+  mutable long long prof_last;
+#endif
   __device__ __forceinline__ void terrain(const KCfg& K, float x, float y, float& h, float& nx, float& ny, float& nz) const {
     if (K.terrain == 0) { h = 0.0f; nx = 0.0f; ny = 0.0f; nz = 1.0f; }
     else heightfield_query(K, x, y, h, nx, ny, nz);
@@ -306,8 +352,19 @@ __global__ void __launch_bounds__(BLOCK) k_step16(KCfg K, DevState D, const floa
   State16<float> L = load_state16<float>(c, D.base, D.leg);
   float act = action ? c.ld_row_joint(action, ETG_ACT_DIM, 0) : 0.0f;
   float r, d;
+#ifdef ETG_PROFILE_PHASES
+  for (int k = 0; k < 16; k++) c.prof[k] = 0;
+  c.prof_last = clock64();
+  long long t_begin = c.prof_last;
+#endif
   control_step16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, act, donef ? (float)donef[c.env] : 0.0f, obs, r, d, info);
   store_state16(c, D.base, D.leg, L);
+#ifdef ETG_PROFILE_PHASES
+  if (c.env == 0 && c.r == 0 && info) {
+    for (int k = 0; k < 16; k++) info[k] = (float)c.prof[k];
+    info[16] = (float)(clock64() - t_begin);
+  }
+#endif
   if (c.r == 0) {
     reward[c.env] = r;
     done[c.env] = d > 0.5f ? 1 : 0;

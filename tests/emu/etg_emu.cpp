@@ -81,8 +81,8 @@ struct EmuCtx16Base {
   F16 qperm(F16 x, int a, int b, int c_, int d) const { int p[4] = {a, b, c_, d}; F16 o; for (int r = 0; r < 16; r++) o.v[r] = x.v[(r & ~3) + p[r & 3]]; return o; }
   F16 qup1(F16 x) const { return qperm(x, 1, 2, 3, 3); }
   F16 qup2(F16 x) const { return qperm(x, 2, 3, 3, 3); }
-  F16 qdn1(F16 x) const { return qperm(x, 0, 0, 1, 2); }
-  F16 qdn2(F16 x) const { return qperm(x, 0, 0, 0, 1); }
+  F16 qdn1(F16 x) const { return qperm(x, 3, 0, 1, 2); }
+  F16 qdn2(F16 x) const { return qperm(x, 3, 3, 0, 1); }
   F16 qswap12(F16 x) const { return qperm(x, 0, 2, 1, 3); }
   F16 qsum(F16 x) const { F16 t = x + qperm(x, 1, 0, 3, 2); return t + qperm(t, 2, 3, 0, 1); }
   // robot (row) exchanges: same butterfly order as the DPP sequence of the GPU context
@@ -93,6 +93,9 @@ struct EmuCtx16Base {
     F16 t = fmaxf_(x, qperm(x, 1, 0, 3, 2)); t = fmaxf_(t, qperm(t, 2, 3, 0, 1)); t = fmaxf_(t, half_mirror(t)); return fmaxf_(t, mirror(t));
   }
   F16 rbcast(F16 x, int r0) const { return F16(x.v[r0]); }
+  void fmac_rbcast(F16& acc, F16 x, F16 y, int r0) const { for (int r = 0; r < 16; r++) acc.v[r] = std::fmaf(x.v[r0], y.v[r], acc.v[r]); }
+  void fmac_qb(F16& acc, F16 x, F16 y, int j) const { for (int r = 0; r < 16; r++) acc.v[r] = std::fmaf(x.v[(r & ~3) + j], y.v[r], acc.v[r]); }
+  void dpp_ready(F16*, int) const {}
   F16 legrot(F16 x, int kk) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = x.v[(r + 4 * kk) & 15]; return o; }
   void quad_outer(F16 a, F16 b, F16* acc) const {
     for (int i = 0; i < 4; i++)
@@ -286,8 +289,9 @@ extern "C" int emu16_tick_replication_check(void* h, int env, int nticks) {
   State16<F16> L = load_state16<F16>(c, e->base.data(), e->leg.data());
   F16 qdes = c.jointf() * c.par_joint(PR_POSE);
   int bad = 0;
+  const TickPar<F16> tp = load_tick_par<F16>(c);
   for (int t = 0; t < nticks; t++) {
-    physics_tick16(c, e->K, L, qdes);
+    physics_tick16(c, e->K, tp, L, qdes);
     const F16* f[] = {&L.p.x, &L.p.y, &L.p.z, &L.qx, &L.qy, &L.qz, &L.qw, &L.wb.x, &L.wb.y, &L.wb.z, &L.vb.x, &L.vb.y, &L.vb.z};
     for (auto* x : f)
       for (int l = 1; l < 16; l++) bad += std::memcmp(&x->v[0], &x->v[l], 4) != 0;

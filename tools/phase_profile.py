@@ -4,13 +4,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 os.environ["ETG_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_variants", "lib_prof.so")
 import numpy as np, torch
 from paddlerobotics_amd.env import make_env
-env = make_env("Quadrupedal", num_envs=4096, device="cuda:0")
+lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 16
+env = make_env("Quadrupedal", num_envs=4096, device="cuda:0", lanes_per_robot=lanes)
 env.reset()
 for _ in range(20): env.step(None)
 env.step(None, want_info=True); torch.cuda.synchronize()
 row = env.info_buf[0].cpu().numpy()
 names = ["0 integ+ring+PD+trig+links", "1 RNEA", "2 CRBA/Hinv/P", "3 Schur+LDL+solve", "4 v*+contact setup+Z", "5 Delassus A", "6 u init/warm", "7 PGS", "8 apply impulses", "9 -", "10 -"]
 tot = row[16]
+print("lanes_per_robot", lanes)
 print("total cycles per control step (wave 0): %.0f  (%.1f us at 2.4 GHz)" % (tot, tot / 2400))
 for k in range(10):
     print("  after-phase %-24s %9.0f cycles  %5.1f %%  (%.0f per tick)" % (names[k], row[k], 100 * row[k] / tot, row[k] / 13))
