@@ -124,6 +124,10 @@ typedef struct EtgConfig {
    * robot per quad (one leg per lane; 4x the robots per wave, for batches > 4096), 0 = auto
    * (16 if num_envs <= 4096 else 4). Same results to fp32 roundoff, same state layout.         */
   int32_t lanes_per_robot;
+  /* terrain variants: the heightfield's hf_ny rows are hf_bands equal bands stacked along y; robot e
+   * walks on band e % hf_bands (its own y axis, clamped inside the band). 0 or 1 = one shared terrain.
+   * This is how per-episode stair/slope parameters (train.py:48-50) coexist in one batch.          */
+  int32_t hf_bands;
 } EtgConfig;
 
 typedef struct EtgHandle EtgHandle;
@@ -145,6 +149,11 @@ int etg_set_params(EtgHandle* h, const float* dyn, const float* etg_w, const flo
                    int per_env, const uint8_t* mask, void* stream);
 /* heightfield heights [hf_ny*hf_nx] float32 device pointer (terrain==1)      */
 int etg_set_heightfield(EtgHandle* h, const float* heights, void* stream);
+
+/* external force on the trunk COM, world frame, newtons: force [N,3] float32 device pointer, applied on
+ * every tick of the following steps until replaced; NULL clears it (random_force of train.py:254,
+ * README "Add external random force").                                                              */
+int etg_set_external_force(EtgHandle* h, const float* force, void* stream);
 
 /* ---- the hot path ------------------------------------------------------- */
 /* reset masked envs (NULL = all): place at init pose, settle, write obs[N,49]

@@ -293,6 +293,8 @@ template <class T> struct Env {
   // derived model
   T I[NB][6][6];  // link spatial inertias (link frame)
   T kp[12], kd[12], mu, latency, grav[3];
+  T fext[3];  // external force on the trunk COM, world frame (etg_set_external_force)
+  int band;   // terrain band of this robot (env index % hf_bands)
   // outputs of the last tick
   T tau[12];
   int contact[4];
@@ -370,13 +372,16 @@ template <class T> void derive_params(Sim<T>& s, Env<T>& e) {
 }
 
 // ---------------------------------------------------------------- terrain
-template <class T> inline void terrain_query(const Sim<T>& s, T x, T y, T* h, T* n) {
+template <class T> inline void terrain_query(const Sim<T>& s, int band, T x, T y, T* h, T* n) {
   if (s.cfg.terrain == 0 || s.heights.empty()) {
     *h = 0; n[0] = 0; n[1] = 0; n[2] = 1;
     return;
   }
   // bilinear heightfield, clamped at the border
-  const int nx = s.cfg.hf_nx, ny = s.cfg.hf_ny;
+  // hf_bands terrain variants stacked along y in the heights array (etgsim.h), clamped inside the band
+  const int bands = s.cfg.hf_bands > 1 ? s.cfg.hf_bands : 1;
+  const int nx = s.cfg.hf_nx, ny = s.cfg.hf_ny / bands;
+  const float* hts = s.heights.data() + (size_t)band * ny * nx;
   T fx = (x - T(s.cfg.hf_x0)) / T(s.cfg.hf_cell), fy = (y - T(s.cfg.hf_y0)) / T(s.cfg.hf_cell);
   if (fx < 0) fx = 0;
   if (fy < 0) fy = 0;
@@ -386,8 +391,8 @@ template <class T> inline void terrain_query(const Sim<T>& s, T x, T y, T* h, T*
   if (ix > nx - 2) ix = nx - 2;
   if (iy > ny - 2) iy = ny - 2;
   T tx = fx - T(ix), ty = fy - T(iy);
-  T h00 = T(s.heights[iy * nx + ix]), h10 = T(s.heights[iy * nx + ix + 1]);
-  T h01 = T(s.heights[(iy + 1) * nx + ix]), h11 = T(s.heights[(iy + 1) * nx + ix + 1]);
+  T h00 = T(hts[iy * nx + ix]), h10 = T(hts[iy * nx + ix + 1]);
+  T h01 = T(hts[(iy + 1) * nx + ix]), h11 = T(hts[(iy + 1) * nx + ix + 1]);
   *h = (1 - tx) * (1 - ty) * h00 + tx * (1 - ty) * h10 + (1 - tx) * ty * h01 + tx * ty * h11;
   T dhdx = ((1 - ty) * (h10 - h00) + ty * (h11 - h01)) / T(s.cfg.hf_cell);
   T dhdy = ((1 - tx) * (h01 - h00) + tx * (h11 - h10)) / T(s.cfg.hf_cell);
@@ -516,6 +521,11 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
   };
   T rhs[NV], acc[NV], vel[NV];
   for (int a = 0; a < 6; a++) rhs[a] = -C[a];
+  {  // external force on the trunk COM: world -> base coordinates
+    T fb[3];
+    mat3T_mul_vec(R, e.fext, fb);
+    for (int k = 0; k < 3; k++) rhs[3 + k] += fb[k];
+  }
   for (int j = 0; j < 12; j++) rhs[6 + j] = tau[j] - C[6 + j];
   chol_solve(rhs, acc);
   for (int k = 0; k < 3; k++) { vel[k] = e.wb[k]; vel[3 + k] = e.vb[k]; }
@@ -548,7 +558,7 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
     mat3_mul_vec(Rw[c], fl, fw);
     for (int k = 0; k < 3; k++) fw[k] += pw[c][k];  // foot centre, world
     T h, n[3];
-    terrain_query(s, fw[0], fw[1], &h, n);
+    terrain_query(s, e.band, fw[0], fw[1], &h, n);
     T phi = (fw[2] - h) * n[2] - rad;  // distance along the normal to the tangent plane
     active[l] = phi < T(s.cfg.contact_margin);
     e.contact[l] = 0;
@@ -807,7 +817,10 @@ template <class T> void reset_env(Sim<T>& s, Env<T>& e, T* obs) {
   for (int r = 1; r < RING; r++) std::memcpy(e.hist[r], e.hist[0], sizeof(T) * HIST);
   T qdes[12];
   for (int j = 0; j < 12; j++) qdes[j] = T(m.pose_ori[j]);
+  T fsave[3];   // the settle runs without the external force
+  for (int k = 0; k < 3; k++) { fsave[k] = e.fext[k]; e.fext[k] = 0; }
   for (int i = 0; i < s.cfg.settle_ticks; i++) sub_step(s, e, qdes);  // a1.py:294-297
+  for (int k = 0; k < 3; k++) e.fext[k] = fsave[k];
   e.step_count = 0; e.has_last = 0; e.first_rpy_set = 0; e.energy = 0;
   for (int j = 0; j < 12; j++) {
     e.last_qdes[j] = qdes[j];
@@ -895,7 +908,7 @@ void step_env(Sim<T>& s, Env<T>& e, const T* action, int donef, T* obs, T* rewar
     T kw[3];
     mat3_mul_vec(Rm, kb, kw);
     T hgt, nrm[3];
-    terrain_query(s, kw[0] + e.pos[0], kw[1] + e.pos[1], &hgt, nrm);
+    terrain_query(s, e.band, kw[0] + e.pos[0], kw[1] + e.pos[1], &hgt, nrm);
     if (kw[2] + e.pos[2] - hgt < T(0.03)) bad++;
   }
   T badfoot = -T(bad);
@@ -983,9 +996,11 @@ template <class F> void par_for(int n, int threads, F f) {
     s->basis.init(*cfg);                                                                            \
     build_tree(*s);                                                                                 \
     s->env.resize(s->N);                                                                            \
-    for (auto& e : s->env) {                                                                        \
+    for (int i = 0; i < s->N; i++) {                                                                \
+      auto& e = s->env[i];                                                                          \
       std::memset((void*)&e, 0, sizeof(e));                                                         \
       e.quat[3] = 1;                                                                                \
+      e.band = i % (cfg->hf_bands > 1 ? cfg->hf_bands : 1);                                         \
     }                                                                                               \
     return s;                                                                                       \
   }                                                                                                 \
@@ -1000,6 +1015,11 @@ template <class F> void par_for(int n, int threads, F f) {
       if (w) std::memcpy(e.etg_w, w + (per_env ? (size_t)i * 3 * ETG_RBF_H : 0), sizeof(T) * 3 * ETG_RBF_H); \
       if (b) std::memcpy(e.etg_b, b + (per_env ? (size_t)i * 3 : 0), sizeof(T) * 3);               \
     }                                                                                               \
+  }                                                                                                 \
+  extern "C" void etgo_set_external_force##SFX(void* h, const T* force) {                           \
+    auto* s = (Sim<T>*)h;                                                                           \
+    for (int i = 0; i < s->N; i++)                                                                  \
+      for (int k = 0; k < 3; k++) s->env[i].fext[k] = force ? force[(size_t)i * 3 + k] : T(0);      \
   }                                                                                                 \
   extern "C" void etgo_set_heightfield##SFX(void* h, const float* hts) {                            \
     auto* s = (Sim<T>*)h;                                                                           \

@@ -89,6 +89,11 @@ class OracleSim:
         h = np.ascontiguousarray(heights, dtype=np.float32)
         self._f("set_heightfield")(self._h, _p(h))
 
+    def set_external_force(self, force):
+        """force [N,3] world-frame newtons on the trunk COM, or None to clear."""
+        f = None if force is None else self._arr(force, (self.N, 3))
+        self._f("set_external_force")(self._h, _p(f))
+
     def reset(self, mask=None, obs=None):
         if obs is None:
             obs = np.zeros((self.N, A.OBS_DIM), dtype=self.dtype)

@@ -72,6 +72,7 @@ class EtgConfig(C.Structure):
         ("hf_nx", C.c_int32), ("hf_ny", C.c_int32),
         ("hf_cell", C.c_double), ("hf_x0", C.c_double), ("hf_y0", C.c_double),
         ("lanes_per_robot", C.c_int32),
+        ("hf_bands", C.c_int32),
     ]
 
 
@@ -200,6 +201,9 @@ def default_config(num_envs, *, action_repeat=13, sim_dt=0.002, settle_ticks=500
         c.hf_ny, c.hf_nx = heightfield["heights"].shape
         c.hf_cell = heightfield["cell"]
         c.hf_x0, c.hf_y0 = heightfield["origin"]
+        c.hf_bands = int(heightfield.get("bands", 1))
+        if c.hf_ny % max(c.hf_bands, 1):
+            raise ValueError("heightfield rows (%d) must be a multiple of bands (%d)" % (c.hf_ny, c.hf_bands))
     return c
 
 
@@ -230,6 +234,12 @@ def dynamic_dict_to_row(d):
         np.asarray(d['legmass']).reshape(3), np.asarray(d['leginertia']).reshape(12),
         np.asarray(d['motor_kp']).reshape(12), np.asarray(d['motor_kd']).reshape(12),
         np.asarray(g).reshape(3)]).astype(np.float64)
+
+
+def param2dynamic_rows(params):
+    """[n,48] parameter vectors in [-1,1] -> [n,48] physical rows (one param2dynamic_dict each)."""
+    P = np.atleast_2d(np.asarray(params, dtype=np.float64))
+    return np.stack([dynamic_dict_to_row(param2dynamic_dict(p)) for p in P])
 
 
 def default_dynamic_row():

@@ -178,7 +178,7 @@ template <class F> ETG_HD void bwd6(const F* L, F* b) {  // b <- L^-T b
 // ------------------------------------------------------------------ one physics tick
 // stepSimulation() + ApplyAction + ReceiveObservation of minitaur.py:242-246 for one quad.
 template <class F, class Ctx>
-ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* qdes) {
+ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* qdes, const V3<F>& fext_w) {
   typedef V3<F> V;
   typedef SV<F> W;
   const F dt(K.dt), zero(0.0f), one(1.0f);
@@ -284,6 +284,11 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* 
   F rb[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) rb[i] = -(comp(f0, i) + c.qsum(comp(f1, i))) - c.qsum(comp(pb, i));
+  if (K.ext_force) {  // external force on the trunk COM (world frame) -> base frame: R^T f
+    rb[3] = rb[3] + Rw.r0.x * fext_w.x + Rw.r1.x * fext_w.y + Rw.r2.x * fext_w.z;
+    rb[4] = rb[4] + Rw.r0.y * fext_w.x + Rw.r1.y * fext_w.y + Rw.r2.y * fext_w.z;
+    rb[5] = rb[5] + Rw.r0.z * fext_w.x + Rw.r1.z * fext_w.y + Rw.r2.z * fext_w.z;
+  }
   F dinv[6], sq[6];
   ldl6(s, dinv, sq);
   fwd6(s, rb);
@@ -675,6 +680,8 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   const int n_lat = c.uniform_int(c.par(PR_LAT_N));
   const int R_ = K.action_repeat;
   const float inv_repeat = 1.0f / (float)K.action_repeat;
+  V3<F> fext = {F(0.0f), F(0.0f), F(0.0f)};
+  if (K.ext_force) fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
   const int mlat = n_lat < 0 ? 0 : n_lat % R_;
   const int ia = R_ - 1 - mlat;
   const int ib = n_lat < 0 ? ia : (ia == 0 ? R_ - 1 : ia - 1);
@@ -683,7 +690,7 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
     float lerp = (float)(i + 1) * inv_repeat;
 #pragma unroll
     for (int j = 0; j < 3; j++) proc[j] = interp ? last[j] + F(lerp) * (qdes[j] - last[j]) : qdes[j];
-    physics_tick(c, K, L, proc);
+    physics_tick(c, K, L, proc, fext);
     tick++;
     if (i == ia || i == ib) ring_push(c, ring, tick & (RING - 1), L);
   }
@@ -770,7 +777,7 @@ ETG_HD void reset_quad(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ring
   for (int sl = 0; sl < RING; sl++) ring_push(c, ring, sl, L);
   int tick = 0;
   for (int i = 0; i < K.settle_ticks; i++) {  // a1.py:294-297
-    physics_tick(c, K, L, pose);
+    physics_tick(c, K, L, pose, V3<F>{F(0.0f), F(0.0f), F(0.0f)});
     tick++;
     ring_push(c, ring, tick & (RING - 1), L);
   }

@@ -74,12 +74,13 @@ template <class F, class Ctx> ETG_HD SV<F> quad_bcast(const Ctx& c, SV<F> v, int
 // per-lane constants of a physics tick, read from the LDS parameter column ONCE per kernel and kept in
 // registers over the 13 (step) / 500 (settle) ticks: a lone wave per SIMD cannot hide the LDS latency of
 // re-reading them at the top of every tick (phase profile: +~1000 cycles per tick)
-template <class F> struct TickPar { F kp, kd, sy, m0, mu, link[10]; V3<F> o1, gw; S3<F> I0s; };
+template <class F> struct TickPar { F kp, kd, sy, m0, mu, link[10]; V3<F> o1, gw, fext; S3<F> I0s; };
 template <class F, class Ctx> ETG_HD TickPar<F> load_tick_par(const Ctx& c) {
   TickPar<F> t;
   t.kp = c.par_joint(PR_KP); t.kd = c.par_joint(PR_KD); t.sy = c.par(PR_SY); t.m0 = c.par(PR_M0); t.mu = c.par(PR_MU);
   for (int k = 0; k < 10; k++) t.link[k] = c.par_link(k);
   t.o1 = par3<F>(c, PR_O1); t.gw = par3<F>(c, PR_G); t.I0s = par_s3<F>(c, PR_I0);
+  t.fext = {F(0.0f), F(0.0f), F(0.0f)};   // external trunk force (world frame); control_step16 fills it in
   return t;
 }
 
@@ -193,6 +194,11 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   F rb[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) rb[i] = -comp(fb0, i) - c.sum16(comp(f, i) + rl * comp(P, i));
+  if (K.ext_force) {  // external force on the trunk COM (world frame) -> base frame: R^T f
+    rb[3] = rb[3] + Rw.r0.x * tp.fext.x + Rw.r1.x * tp.fext.y + Rw.r2.x * tp.fext.z;
+    rb[4] = rb[4] + Rw.r0.y * tp.fext.x + Rw.r1.y * tp.fext.y + Rw.r2.y * tp.fext.z;
+    rb[5] = rb[5] + Rw.r0.z * tp.fext.x + Rw.r1.z * tp.fext.y + Rw.r2.z * tp.fext.z;
+  }
   F dinv[6], sq[6];
   ldl6(s, dinv, sq);
   fwd6(s, rb);
@@ -518,7 +524,8 @@ ETG_HD void control_step16(const Ctx& c, const KCfg& K, State16<F>& L, float* ri
   const int mlat = n_lat < 0 ? 0 : n_lat % R_;
   const int ia = R_ - 1 - mlat;
   const int ib = n_lat < 0 ? ia : (ia == 0 ? R_ - 1 : ia - 1);
-  const TickPar<F> tp = load_tick_par<F>(c);
+  TickPar<F> tp = load_tick_par<F>(c);
+  if (K.ext_force) tp.fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
   for (int i = 0; i < K.action_repeat; i++) {
     float lerp = (float)(i + 1) * inv_repeat;
     F proc = interp ? last + F(lerp) * (qdes - last) : qdes;

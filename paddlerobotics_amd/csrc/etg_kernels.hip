@@ -88,7 +88,7 @@ struct GpuCtx {
   __device__ __forceinline__ int uniform_int(float a) const { return (int)a; }
   __device__ __forceinline__ void terrain(const KCfg& K, float x, float y, float& h, float& nx, float& ny, float& nz) const {
     if (K.terrain == 0) { h = 0.0f; nx = 0.0f; ny = 0.0f; nz = 1.0f; }
-    else heightfield_query(K, x, y, h, nx, ny, nz);
+    else heightfield_query(K, env, x, y, h, nx, ny, nz);
   }
 };
 
@@ -306,7 +306,7 @@ struct GpuCtx16 {
 #endif
   __device__ __forceinline__ void terrain(const KCfg& K, float x, float y, float& h, float& nx, float& ny, float& nz) const {
     if (K.terrain == 0) { h = 0.0f; nx = 0.0f; ny = 0.0f; nz = 1.0f; }
-    else heightfield_query(K, x, y, h, nx, ny, nz);
+    else heightfield_query(K, env, x, y, h, nx, ny, nz);
   }
 };
 template <bool FLAT> struct GpuCtx16T : GpuCtx16 { static constexpr bool kFlat = FLAT; };
@@ -369,6 +369,13 @@ __global__ void __launch_bounds__(BLOCK) k_step16(KCfg K, DevState D, const floa
     reward[c.env] = r;
     done[c.env] = d > 0.5f ? 1 : 0;
   }
+}
+
+// external force rows [N,3] -> the three SoA columns ctl[CT_FEXT + k][N]
+__global__ void k_set_fext(KCfg K, DevState D, const float* force) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K.n_env) return;
+  for (int k = 0; k < 3; k++) D.ctl[(size_t)(CT_FEXT + k) * K.n_env + i] = force[(size_t)i * 3 + k];
 }
 
 // copy out the per-robot episode accumulators (return, length) kept in ctl[]
@@ -506,10 +513,24 @@ extern "C" int etg_set_params(EtgHandle* h, const float* dyn, const float* etg_w
 extern "C" int etg_set_heightfield(EtgHandle* h, const float* heights, void* stream) {
   CHECK_HANDLE(h);
   if (h->K.terrain != 1 || h->K.hf_nx < 2 || h->K.hf_ny < 2) return fail(ETG_ERR_STATE, "etg_set_heightfield: config has no heightfield");
-  size_t bytes = (size_t)h->K.hf_nx * h->K.hf_ny * 4;
+  size_t bytes = (size_t)h->K.hf_nx * h->K.hf_ny * h->K.hf_bands * 4;
   if (!h->hf && hipMalloc((void**)&h->hf, bytes) != hipSuccess) return fail(ETG_ERR_ALLOC, "etg_set_heightfield: hipMalloc failed");
   HIP_TRY(hipMemcpyAsync(h->hf, heights, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   h->K.hf = h->hf;
+  return ETG_OK;
+}
+
+extern "C" int etg_set_external_force(EtgHandle* h, const float* force, void* stream) {
+  CHECK_HANDLE(h);
+  float* dst = h->D.ctl + (size_t)CT_FEXT * h->N;      // ctl[CT_FEXT + k][N]
+  if (!force) {
+    HIP_TRY(hipMemsetAsync(dst, 0, (size_t)3 * h->N * 4, (hipStream_t)stream));
+    h->K.ext_force = 0;
+    return ETG_OK;
+  }
+  hipLaunchKernelGGL(k_set_fext, dim3((h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->D, force);
+  HIP_TRY(hipGetLastError());
+  h->K.ext_force = 1;
   return ETG_OK;
 }
 

@@ -30,7 +30,8 @@ constexpr int RING = 64;  // ticks of history; latency <= 80 ms at dt = 2 ms nee
 enum { BS_PX, BS_PY, BS_PZ, BS_QX, BS_QY, BS_QZ, BS_QW, BS_WX, BS_WY, BS_WZ, BS_VX, BS_VY, BS_VZ, BS_N };
 enum { LG_Q = 0, LG_QD = 3, LG_LAM = 6, LG_CONTACT = 9, LG_N = 10 };
 // CT_RET/LEN/ALIVE: per-robot episode accumulators (return, length, alive mask) updated by every step
-enum { CT_FIRST_RPY = 0, CT_LAST_BASE = 3, CT_RET = 6, CT_LEN = 7, CT_ALIVE = 8, CT_N = 9 };
+// CT_FEXT: external force on the trunk COM (world frame, N), etg_set_external_force()
+enum { CT_FIRST_RPY = 0, CT_LAST_BASE = 3, CT_RET = 6, CT_LEN = 7, CT_ALIVE = 8, CT_FEXT = 9, CT_N = 12 };
 enum { IC_STEP = 0, IC_TICK = 1, IC_HAS_LAST = 2, IC_N = 3 };
 enum { LC_LAST_QDES = 0, LC_FX0 = 3, LC_FX1 = 6, LC_FY0 = 9, LC_FY1 = 12, LC_LAST_FOOT_X = 15, LC_N = 16 };
 enum { EP_W = 0, EP_B = 60, EP_N = 63 };
@@ -49,9 +50,11 @@ struct KCfg {
   float etg_u[ETG_RBF_H][2];
   float rw[8], reward_p, vel_d;
   float fb[3], fa[3];
-  int hf_nx, hf_ny;
+  int hf_nx, hf_ny;      // hf_ny = rows of ONE band
+  int hf_bands;          // bands stacked along y in the heights array; robot e uses band e % hf_bands
   float hf_cell, hf_x0, hf_y0;
   const float* hf;
+  int ext_force;         // 1 once etg_set_external_force() installed a force (ctl[CT_FEXT..])
 };
 
 struct DevState {
@@ -221,7 +224,9 @@ inline KCfg make_kcfg(const EtgConfig& c, const EtgRobotModel& m) {
   for (int k = 0; k < 8; k++) K.rw[k] = (float)c.reward_w[k];
   K.reward_p = (float)c.reward_p; K.vel_d = (float)c.vel_d;
   for (int k = 0; k < 3; k++) { K.fb[k] = (float)c.filter_b[k]; K.fa[k] = (float)c.filter_a[k]; }
-  K.hf_nx = c.hf_nx; K.hf_ny = c.hf_ny;
+  K.hf_bands = c.hf_bands > 1 ? c.hf_bands : 1;
+  K.hf_nx = c.hf_nx; K.hf_ny = c.hf_ny / K.hf_bands;
+  K.ext_force = 0;
   K.hf_cell = (float)c.hf_cell; K.hf_x0 = (float)c.hf_x0; K.hf_y0 = (float)c.hf_y0;
   K.hf = nullptr;
   return K;
@@ -250,7 +255,8 @@ inline ModelF make_modelf(const EtgRobotModel& m) {
 }
 
 // bilinear heightfield query shared by both builds (clamped at the border)
-ETG_HD void heightfield_query(const KCfg& K, float x, float y, float& h, float& nx, float& ny, float& nz) {
+ETG_HD void heightfield_query(const KCfg& K, int env, float x, float y, float& h, float& nx, float& ny, float& nz) {
+  const float* hf = K.hf + (size_t)(env % K.hf_bands) * K.hf_ny * K.hf_nx;
   float fx = (x - K.hf_x0) / K.hf_cell, fy = (y - K.hf_y0) / K.hf_cell;
   fx = fminf(fmaxf(fx, 0.0f), (float)(K.hf_nx - 1));
   fy = fminf(fmaxf(fy, 0.0f), (float)(K.hf_ny - 1));
@@ -258,8 +264,8 @@ ETG_HD void heightfield_query(const KCfg& K, float x, float y, float& h, float& 
   if (ix > K.hf_nx - 2) ix = K.hf_nx - 2;
   if (iy > K.hf_ny - 2) iy = K.hf_ny - 2;
   float tx = fx - (float)ix, ty = fy - (float)iy;
-  float h00 = K.hf[iy * K.hf_nx + ix], h10 = K.hf[iy * K.hf_nx + ix + 1];
-  float h01 = K.hf[(iy + 1) * K.hf_nx + ix], h11 = K.hf[(iy + 1) * K.hf_nx + ix + 1];
+  float h00 = hf[iy * K.hf_nx + ix], h10 = hf[iy * K.hf_nx + ix + 1];
+  float h01 = hf[(iy + 1) * K.hf_nx + ix], h11 = hf[(iy + 1) * K.hf_nx + ix + 1];
   h = (1 - tx) * (1 - ty) * h00 + tx * (1 - ty) * h10 + (1 - tx) * ty * h01 + tx * ty * h11;
   float dhdx = ((1 - ty) * (h10 - h00) + ty * (h11 - h01)) / K.hf_cell;
   float dhdy = ((1 - tx) * (h01 - h00) + tx * (h11 - h10)) / K.hf_cell;

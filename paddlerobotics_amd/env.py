@@ -21,8 +21,47 @@ import torch
 from . import a1_model as A
 from . import _lib
 from .etg import ETG_layer, Opt_with_points
+from .terrain import TERRAIN_TASKS, make_task_heightfield
 
-TASKS = ("ground", "heightfield")
+TASKS = ("ground", "heightfield") + TERRAIN_TASKS
+
+# observation columns of the 49-float row by sensor (sorted-by-key order of EnvWrapper.py:60-109)
+_OBS_COLS = {"dis": (0, 3), "contact": (3, 7), "imu_rpy": (7, 10), "imu_drpy": (10, 13), "motor_q": (13, 25),
+             "motor_qd": (25, 37), "ETG": (37, 49)}
+DEFAULT_SENSOR_MODE = {"dis": 1, "motor": 1, "imu": 1, "contact": 1, "ETG": 1}
+
+
+def sensor_columns(sensor_mode):
+    """Columns of the full 49-float observation selected by a reference sensor_mode dict, following the
+    obs-dim rule of deployment/test.py:26-46 (motor 1 -> angles+velocities, 2 -> angles; imu 1 -> rpy+drpy,
+    2 -> rpy; dis / contact / ETG on-off).  Sensors this simulator does not provide raise."""
+    sm = dict(DEFAULT_SENSOR_MODE)
+    sm.update(sensor_mode or {})
+    for k in ("ETG_obs", "footpose", "dynamic_vec", "force_vec", "noise"):
+        if sm.get(k):
+            raise NotImplementedError("sensor_mode[%r] is not provided by the batched simulator" % k)
+    rnn = sm.get("RNN")
+    if rnn and rnn.get("time_steps", 0) > 0:
+        raise NotImplementedError("sensor_mode['RNN'] observation stacking is not provided")
+    cols = []
+    def add(name):
+        a, b = _OBS_COLS[name]
+        cols.extend(range(a, b))
+    if sm.get("dis"):
+        add("dis")
+    if sm.get("contact"):
+        add("contact")
+    if sm.get("imu") in (1, 2):
+        add("imu_rpy")
+        if sm["imu"] == 1:
+            add("imu_drpy")
+    if sm.get("motor") in (1, 2):
+        add("motor_q")
+        if sm["motor"] == 1:
+            add("motor_qd")
+    if sm.get("ETG"):
+        add("ETG")
+    return cols
 
 
 class Box:
@@ -48,16 +87,33 @@ class BatchedQuadrupedEnv:
                  reward_p=5.0, ETG_path="", random_param=None, ETG_H=20, vel_d=0.5, step_y=0.05,
                  enable_action_filter=False, ETG_T2=0.5, action_repeat=13, sim_time_step=0.002,
                  settle_ticks=500, solver_iters=2, enable_action_interpolation=False,
-                 heightfield=None, lanes_per_robot=0, **unused):
+                 heightfield=None, lanes_per_robot=0, terrain_variants=16, terrain_seed=0,
+                 random_dynamics_scale=0.3, random_force_prob=0.02, random_force_steps=8,
+                 random_force_range=(5.0, 25.0), seed=0, **unused):
         if render:
             raise ValueError("render is not supported by the batched GPU simulator")
         if int(ETG_H) != A.RBF_H:
             raise ValueError("ETG_H must be %d" % A.RBF_H)
         if task not in TASKS:
-            raise ValueError("task %r is not available: this simulator has 'ground' (flat plane) and 'heightfield' "
-                             "(pass heightfield=dict(heights=[ny,nx], cell=, origin=(x0,y0)))" % (task,))
-        if (task == "heightfield") != (heightfield is not None):
+            raise ValueError("task %r is not available: this simulator has %s (for 'heightfield' pass "
+                             "heightfield=dict(heights=[ny,nx], cell=, origin=(x0,y0)))" % (task, ", ".join(TASKS)))
+        if task in TERRAIN_TASKS:
+            if heightfield is not None:
+                raise ValueError("task=%r builds its own heightfield" % task)
+            heightfield = make_task_heightfield(task, variants=int(terrain_variants), seed=int(terrain_seed))
+        elif (task == "heightfield") != (heightfield is not None):
             raise ValueError("task='heightfield' and the heightfield= argument go together")
+        self.task = task
+        self.terrain = heightfield
+        if motor_control_mode not in (None, "pose", "traj", 1) and getattr(motor_control_mode, "name", "") != "POSITION":
+            raise NotImplementedError("only the POSITION motor mode (train.py mode_map 'pose'/'traj') is simulated")
+        self._cols = sensor_columns(sensor_mode)
+        rp = dict(random_param or {})
+        self._rand_dyn = bool(rp.get("random_dynamics", 0))
+        self._rand_force = bool(rp.get("random_force", 0))
+        self._rand_dyn_scale = float(random_dynamics_scale)
+        self._rf_prob, self._rf_steps, self._rf_range = float(random_force_prob), int(random_force_steps), random_force_range
+        self._np_rng = np.random.default_rng(seed)
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -71,7 +127,7 @@ class BatchedQuadrupedEnv:
             reward_param=reward_param, reward_p=reward_p, vel_d=vel_d, heightfield=heightfield,
             lanes_per_robot=lanes_per_robot)
         self.model = A.default_model()
-        self.observation_space = Box(-np.inf, np.inf, (A.OBS_DIM,))
+        self.observation_space = Box(-np.inf, np.inf, (len(self._cols),))
         self.action_space = Box(-1.0, 1.0, (A.NUM_MOTORS,))
         self._lib = _lib.load()
         self._h = C.c_void_p()
@@ -84,6 +140,11 @@ class BatchedQuadrupedEnv:
         self.done = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.info_buf = torch.zeros(N, A.INFO_DIM, device=dev)
         self._zero_action = torch.zeros(N, A.NUM_MOTORS, device=dev)
+        self._col_idx = None if len(self._cols) == A.OBS_DIM else torch.tensor(self._cols, device=dev)
+        self._gen = torch.Generator(device=dev)
+        self._gen.manual_seed(int(seed))
+        self._force = torch.zeros(N, 3, device=dev)
+        self._force_left = torch.zeros(N, dtype=torch.int32, device=dev)
         self._hf = None
         if heightfield is not None:
             self._hf = torch.as_tensor(np.ascontiguousarray(heightfield["heights"], dtype=np.float32), device=dev)
@@ -172,10 +233,45 @@ class BatchedQuadrupedEnv:
             self.set_etg(ETG_w, ETG_b, env_ids)
         if dynamic_param is not None:
             self.set_dynamic_param(dynamic_param, env_ids)
+        elif self._rand_dyn:
+            # random_param['random_dynamics'] (train.py:253): a fresh draw of the 48 dynamic parameters for
+            # every robot being reset, param2dynamic_dict(U(-1,1) * scale) (train.py:112-126)
+            rows = A.param2dynamic_rows(self._np_rng.uniform(-1, 1, size=(self.num_envs, A.DYN_DIM)) * self._rand_dyn_scale)
+            self.set_dynamic_param(rows, env_ids)
         m = self._mask(env_ids)
+        if self._rand_force:
+            keep = torch.ones(self.num_envs, dtype=torch.bool, device=self.device) if m is None else ~m.bool()
+            self._force_left *= keep.to(torch.int32)
+            self._force *= keep.unsqueeze(1).float()
+            _lib.check(self._lib.etg_set_external_force(self._h, _ptr(self._force), self._stream()))
         _lib.check(self._lib.etg_reset(self._h, _ptr(m), _ptr(self.obs), self._stream()))
         info = {"ETG_act": None}
-        return self.obs, info
+        return self._obs_view(), info
+
+    def _obs_view(self):
+        return self.obs if self._col_idx is None else self.obs.index_select(1, self._col_idx)
+
+    def set_external_force(self, force):
+        """force [N,3] (world frame, N) pushed on every trunk until replaced; None clears it."""
+        if force is None:
+            _lib.check(self._lib.etg_set_external_force(self._h, None, self._stream()))
+            return
+        self._force = self._f32(force, (self.num_envs, 3), "force").clone()
+        _lib.check(self._lib.etg_set_external_force(self._h, _ptr(self._force), self._stream()))
+
+    def _random_pushes(self):
+        """random_param['random_force'] (train.py:254; rlschool's schedule is absent, this one is ours): each
+        step an idle robot starts, with probability p, a push of `steps` control steps with a horizontal
+        force of U(range) newtons in a uniform direction.  All on device, no host sync."""
+        N, dev, g = self.num_envs, self.device, self._gen
+        start = (torch.rand(N, device=dev, generator=g) < self._rf_prob) & (self._force_left == 0)
+        ang = torch.rand(N, device=dev, generator=g) * (2 * np.pi)
+        mag = self._rf_range[0] + (self._rf_range[1] - self._rf_range[0]) * torch.rand(N, device=dev, generator=g)
+        new = torch.stack([mag * torch.cos(ang), mag * torch.sin(ang), torch.zeros_like(mag)], dim=1)
+        self._force_left = torch.where(start, torch.full_like(self._force_left, self._rf_steps),
+                                       torch.clamp(self._force_left - 1, min=0))
+        self._force = torch.where(start.unsqueeze(1), new, self._force) * (self._force_left > 0).unsqueeze(1).float()
+        _lib.check(self._lib.etg_set_external_force(self._h, _ptr(self._force), self._stream()))
 
     def step(self, action, donef=None, want_info=True):
         a = self._zero_action if action is None else self._f32(action, (self.num_envs, A.NUM_MOTORS), "action")
@@ -187,10 +283,13 @@ class BatchedQuadrupedEnv:
                 df = torch.as_tensor(donef, device=self.device).to(torch.uint8).contiguous()
                 if tuple(df.shape) != (self.num_envs,):
                     raise ValueError("donef must be a bool or have shape [N]")
+        if self._rand_force:
+            self._random_pushes()
         _lib.check(self._lib.etg_step(self._h, _ptr(a), _ptr(df), _ptr(self.obs), _ptr(self.reward), _ptr(self.done),
                                       _ptr(self.info_buf) if want_info else None, self._stream()))
         self._keep_step = (a, df)
-        return self.obs, self.reward, self.done.bool() if want_info else self.done, (self._info() if want_info else {})
+        return (self._obs_view(), self.reward, self.done.bool() if want_info else self.done,
+                (self._info() if want_info else {}))
 
     def rollout_openloop(self, n_steps):
         """n_steps control steps with zero residual action (pretrain.py:129-154) enqueued back to

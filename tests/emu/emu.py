@@ -62,6 +62,10 @@ class EmuSim:
         self._hf = np.ascontiguousarray(h, dtype=np.float32)
         self._l.emu_set_heightfield(self._h, _p(self._hf))
 
+    def set_external_force(self, force):
+        f = None if force is None else np.ascontiguousarray(force, dtype=np.float32)
+        self._l.emu_set_external_force(self._h, _p(f))
+
     def reset(self, mask=None):
         obs = np.zeros((self.N, A.OBS_DIM), dtype=np.float32)
         if mask is not None:

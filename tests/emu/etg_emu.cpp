@@ -48,7 +48,7 @@ struct EmuCtxBase {
   void terrain(const KCfg& K, F4 x, F4 y, F4& h, F4& nx, F4& ny, F4& nz) const {
     for (int l = 0; l < 4; l++) {
       if (K.terrain == 0 || K.hf == nullptr) { h.v[l] = 0; nx.v[l] = 0; ny.v[l] = 0; nz.v[l] = 1; }
-      else heightfield_query(K, x.v[l], y.v[l], h.v[l], nx.v[l], ny.v[l], nz.v[l]);
+      else heightfield_query(K, env, x.v[l], y.v[l], h.v[l], nx.v[l], ny.v[l], nz.v[l]);
     }
   }
 };
@@ -123,7 +123,7 @@ struct EmuCtx16Base {
   void terrain(const KCfg& K, F16 x, F16 y, F16& h, F16& nx, F16& ny, F16& nz) const {
     for (int r = 0; r < 16; r++) {
       if (K.terrain == 0 || K.hf == nullptr) { h.v[r] = 0; nx.v[r] = 0; ny.v[r] = 0; nz.v[r] = 1; }
-      else heightfield_query(K, x.v[r], y.v[r], h.v[r], nx.v[r], ny.v[r], nz.v[r]);
+      else heightfield_query(K, env, x.v[r], y.v[r], h.v[r], nx.v[r], ny.v[r], nz.v[r]);
     }
   }
 };
@@ -176,8 +176,14 @@ extern "C" void emu_set_params(void* h, const float* dyn, const float* w, const 
 }
 extern "C" void emu_set_heightfield(void* h, const float* hts) {
   Emu* e = (Emu*)h;
-  e->hf.assign(hts, hts + (size_t)e->K.hf_nx * e->K.hf_ny);
+  e->hf.assign(hts, hts + (size_t)e->K.hf_nx * e->K.hf_ny * e->K.hf_bands);
   e->K.hf = e->hf.data();
+}
+extern "C" void emu_set_external_force(void* h, const float* force) {
+  Emu* e = (Emu*)h;
+  for (int i = 0; i < e->N; i++)
+    for (int k = 0; k < 3; k++) e->ctl[(size_t)(CT_FEXT + k) * e->N + i] = force ? force[(size_t)i * 3 + k] : 0.0f;
+  e->K.ext_force = force ? 1 : 0;
 }
 extern "C" void emu_reset(void* h, const uint8_t* mask, float* obs) {
   Emu* e = (Emu*)h;
@@ -274,7 +280,7 @@ extern "C" int emu_tick_replication_check(void* h, int env, int nticks) {
   F4 qdes[3] = {c.par(PR_POSE), c.par(PR_POSE + 1), c.par(PR_POSE + 2)};
   int bad = 0;
   for (int t = 0; t < nticks; t++) {
-    physics_tick(c, e->K, L, qdes);
+    physics_tick(c, e->K, L, qdes, V3<F4>{F4(0.0f), F4(0.0f), F4(0.0f)});
     const F4* f[] = {&L.p.x, &L.p.y, &L.p.z, &L.qx, &L.qy, &L.qz, &L.qw, &L.wb.x, &L.wb.y, &L.wb.z, &L.vb.x, &L.vb.y, &L.vb.z};
     for (auto* x : f)
       for (int l = 1; l < 4; l++) bad += std::memcmp(&x->v[0], &x->v[l], 4) != 0;

@@ -1,0 +1,125 @@
+"""Terrain tasks, terrain bands, external force, sensor_mode and randomisation helpers,
+on the CPU: the kernel source runs through the host emulation (tests/emu) against the oracle."""
+import numpy as np
+import pytest
+
+from paddlerobotics_amd import a1_model as A
+from paddlerobotics_amd import terrain as T
+
+
+def _params(n, seed=0):
+    from paddlerobotics_amd.etg import ETG_layer, Opt_with_points
+    from paddlerobotics_amd.etg_fit import opt_with_points_batched
+    layer = ETG_layer(0.5, 0.026, 20, 0.04, np.array([-np.pi / 2, 0]), 0.2, 0.5)
+    w0, b0, prior = Opt_with_points(layer, ETG_T=0.5, Footheight=0.1, Steplength=0.05)
+    pts = prior[None] + 0.02 * np.random.default_rng(seed).normal(size=(n, 6, 2))
+    w, b = opt_with_points_batched(layer, 0.5, pts, b0, w0, device="cpu")
+    return w.numpy(), b.numpy()
+
+
+def test_stair_and_slope_profiles():
+    """stairs: n treads of the given width/height up, plateau, down to zero; ramps reach the same top."""
+    x = np.linspace(-1, 12, 2601)
+    for task in ("stairstair", "stairslope", "slopestair", "slopeslope"):
+        z, end = T.profile(task, x, step_height=0.09, step_width=0.3, slope=0.3, n_steps=5)
+        assert z[x < 0.99].max() == 0.0 and abs(z.max() - 0.45) < 1e-12
+        assert np.all(z[x > end + 1e-9] == 0.0)
+        assert z.min() >= 0.0
+    z, _ = T.profile("stairstair", x, 0.09, 0.3, 0.3, 5)
+    levels = np.unique(np.round(z, 9))
+    assert np.allclose(levels, 0.09 * np.arange(6))                 # only tread heights occur
+    zs, _ = T.profile("slopeslope", x, 0.09, 0.3, 0.3, 5)
+    assert np.abs(np.diff(zs) / np.diff(x)).max() <= 0.3 + 1e-9     # ramp gradient = SLOPE
+
+
+def test_task_heightfield_bands_use_reference_ranges():
+    hf = T.make_task_heightfield("stairstair", variants=8, seed=3)
+    rows = hf["heights"].shape[0] // 8
+    assert hf["bands"] == 8 and hf["heights"].shape[0] == 8 * rows
+    p = hf["params"]
+    assert np.all((p[:, 0] >= 0.08 - 1e-9) & (p[:, 0] <= 0.1 + 1e-9))      # STEP_HEIGHT, train.py:48
+    assert np.all((p[:, 1] >= 0.26 - 1e-9) & (p[:, 1] <= 0.4 + 1e-9))      # STEP_WIDTH, train.py:50
+    for v in range(8):
+        band = hf["heights"][v * rows:(v + 1) * rows]
+        assert np.all(band == band[:1])                                     # a pure x-profile
+        assert abs(band.max() - 5 * p[v, 0]) < 1e-6
+    beam = T.make_task_heightfield("balancebeam", variants=1)
+    mid = beam["heights"].shape[0] // 2
+    assert beam["heights"][mid].max() == 0.0 and beam["heights"][0, -1] < -0.4
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_emulation_terrain_bands_match_oracle(lanes):
+    """two robots on two different stair variants of one banded heightfield"""
+    from oracle.oracle import OracleSim
+    from tests.emu.emu import EmuSim
+    n = 2
+    hf = T.make_task_heightfield("stairstair", variants=2, seed=1, cell=0.05)
+    # give band 1 a pedestal under the start position so that the two robots see different ground
+    rows = hf["heights"].shape[0] // 2
+    hf["heights"][rows:, :] += 0.03
+    cfg = A.default_config(n, solver_iters=4, terrain=1, heightfield=hf)
+    assert cfg.hf_bands == 2
+    W, B = _params(n, seed=4)
+    orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=lanes)
+    for s in (orc, emu):
+        s.set_heightfield(hf["heights"])
+        s.set_params(etg_w=W, etg_b=B)
+    orc.reset(); emu.reset()
+    so, se = orc.get_state(), emu.get_state()
+    assert abs((so[1, 2] - so[0, 2]) - 0.03) < 2e-3         # robot 1 stands on its own (raised) band
+    assert np.abs(se[:, :7] - so[:, :7]).max() < 2e-3
+    for k in range(5):
+        orc.step(np.zeros((n, 12))); emu.step(np.zeros((n, 12)))
+        assert np.abs(emu.get_state()[:, 13:25] - orc.get_state()[:, 13:25]).max() < 1e-2
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_emulation_external_force_matches_oracle(lanes):
+    """a sideways / forward push on the trunk: same response as the oracle, and it really pushes"""
+    from oracle.oracle import OracleSim
+    from tests.emu.emu import EmuSim
+    n = 3
+    cfg = A.default_config(n, solver_iters=4)
+    W, B = _params(n, seed=2)
+    force = np.array([[0, 0, 0], [0, 30.0, 0], [25.0, 0, 5.0]])
+    orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=lanes)
+    for s in (orc, emu):
+        s.set_params(etg_w=W[:1].repeat(n, 0), etg_b=B[:1].repeat(n, 0))
+        s.reset()
+        s.set_external_force(force)
+    for k in range(8):
+        orc.step(np.zeros((n, 12))); emu.step(np.zeros((n, 12)))
+    so, se = orc.get_state(), emu.get_state()
+    assert np.abs(se[:, :3] - so[:, :3]).max() < 3e-3 and np.abs(se[:, 13:25] - so[:, 13:25]).max() < 1e-2
+    assert so[1, 1] - so[0, 1] > 0.01          # pushed to +y relative to the unforced twin
+    assert so[2, 0] - so[0, 0] > 0.005         # pushed forward
+    # clearing the force: robots 1 and 2 stop being accelerated (forces are part of the step, not the state)
+    for s in (orc, emu):
+        s.set_external_force(None)
+    orc.step(np.zeros((n, 12))); emu.step(np.zeros((n, 12)))
+    assert np.abs(emu.get_state()[:, :3] - orc.get_state()[:, :3]).max() < 3e-3
+
+
+def test_sensor_mode_columns_follow_the_reference_obs_dim_rule():
+    """deployment/test.py:26-46: motor 1/2 -> 24/12, dis -> 3, imu 1/2 -> 6/3, contact -> 4, ETG -> 12"""
+    from paddlerobotics_amd.env import sensor_columns
+    def dim(**kw):
+        return len(sensor_columns(kw))
+    assert dim() == 49
+    assert dim(dis=0) == 46                      # the student observation (BCtrain.py:53-59)
+    assert dim(motor=2) == 37 and dim(imu=2) == 46 and dim(contact=0) == 45 and dim(ETG=0) == 37
+    assert dim(dis=0, motor=2, imu=2, contact=0, ETG=0) == 15
+    cols = sensor_columns({"dis": 0})
+    assert cols == list(range(3, 49))
+    with pytest.raises(NotImplementedError):
+        sensor_columns({"footpose": 1})
+
+
+def test_param2dynamic_rows_equal_the_dict_mapping():
+    rng = np.random.default_rng(0)
+    P = rng.uniform(-1.5, 1.5, size=(5, 48))
+    rows = A.param2dynamic_rows(P)
+    for i in range(5):
+        assert np.array_equal(rows[i], A.dynamic_dict_to_row(A.param2dynamic_dict(P[i])))
+    assert np.array_equal(A.param2dynamic_rows(np.zeros(48))[0], A.default_dynamic_row())
