@@ -191,6 +191,14 @@ def main():
                                              "single-thread: %.0f env-steps/s (64 envs x 60 steps)" %
                                              (max(64, 16 * cores), cores, one),
                                    "single_thread": one}
+            # the reference's real engine, if this box happens to have it; never expected here
+            try:
+                sys.path.insert(0, os.path.join(ROOT, "tools"))
+                import pybullet_baseline
+                pb = pybullet_baseline.run(100)
+            except Exception:                                   # noqa: BLE001 - a broken pybullet must not kill the bench
+                pb = None
+            out["cpu_baseline"]["pybullet_env_steps_per_s"] = pb   # None: pybullet unavailable, baseline is the port
         print(json.dumps(out))
     env.close()
     if dist is not None:

@@ -172,6 +172,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   F h0 = f0 * Hi11 + f1 * Hi12 + f2 * Hi13, h1 = f0 * Hi12 + f1 * Hi22 + f2 * Hi23, h2 = f0 * Hi13 + f1 * Hi23 + f2 * Hi33;
   W P = h0 * Fj[0] + h1 * Fj[1] + h2 * Fj[2];          // column `sub` of P = Fm H^-1
   F rl = tau - C;                                      // (aux lane: tau = 0, C = 0 since S = 0 there)
+  c.dpp_ready(&rl, 1);                                 // broadcast source of the fused DPP-FMAs below
   c.phase(2);
   // ---- base Schur complement: every term is a sum over the robot's 16 lanes
   // S = M_bb - Fm H^-1 Fm^T with M_bb = trunk + sum of the links' inertias about the base origin: each lane

@@ -99,3 +99,26 @@ def Opt_with_points(ETG, ETG_T=0.4, points=None, b0=None, w0=None, precision=1e-
     w_[0], w_[2] = sols[0].reshape(-1), sols[1].reshape(-1)
     b_ = np.array([b[0], 0.0, b[1]])
     return w_, b_, points
+
+
+def etg_joint_action(layer, w, b, t):
+    """Joint-space ETG action (12, minus pose_ori) at control time t -- the host-side restatement of what the
+    step kernel does per robot (csrc/etg_core.h: etg_action): RBF features at t for legs FR/RL and at
+    t + T2*T for FL/RR (trot), foot offset w r + b in the base frame, closed-form leg IK
+    (deployment/robots/a1.py:97-110).  Used for exporting `gait_action_list_*.npy` and by tools/."""
+    from . import a1_model as A
+    r1, r2 = layer._rbf(t), layer._rbf(t + layer.T2_ratio * layer.T)
+    w, b = np.asarray(w, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    act = np.zeros(12)
+    for leg in range(4):
+        d = w @ (r1 if leg in (0, 3) else r2) + b
+        x, y, z = A.BASE_FOOT[3 * leg:3 * leg + 3] + d - A.HIP_OFFSETS[leg]
+        l_hip = A.L_HIP * (-1.0) ** (leg + 1)
+        ck = (x * x + y * y + z * z - l_hip ** 2 - A.L_LOW ** 2 - A.L_UP ** 2) / (2 * A.L_LOW * A.L_UP)
+        knee = -np.arccos(np.clip(ck, -1, 1))
+        l = np.sqrt(max(A.L_UP ** 2 + A.L_LOW ** 2 + 2 * A.L_UP * A.L_LOW * np.cos(knee), 1e-12))
+        hip = np.arcsin(np.clip(-x / l, -1, 1)) - knee / 2
+        c1 = l_hip * y - l * np.cos(hip + knee / 2) * z
+        s1 = l * np.cos(hip + knee / 2) * y + l_hip * z
+        act[3 * leg:3 * leg + 3] = np.array([np.arctan2(s1, c1), hip, knee]) - A.INIT_MOTOR_ANGLES[3 * leg:3 * leg + 3]
+    return act
