@@ -189,6 +189,13 @@ int etg_policy_load(EtgPolicy* p, const float* w1, const float* b1, const float*
                     const float* b2, const float* w3, const float* b3, void* stream);
 int etg_policy_forward(EtgPolicy* p, const float* obs, int n, float act_scale, int precision,
                        float* act, void* stream);
+/* stochastic head (SAC.sample, alg/sac.py:65-76; used by the training rollouts of train.py:141):
+ *   x = mean + exp(clamp(W_std h + b_std, -20, 2)) * noise,  act = tanh(x) * act_scale,
+ *   logp (optional, [N]) = sum_j [log N(x_j; mean_j, std_j) - log(1 - tanh(x_j)^2 + 1e-6)]
+ * noise [N,out_dim] is the caller's N(0,1) draw (device pointer), so the result is reproducible.    */
+int etg_policy_load_std(EtgPolicy* p, const float* w_std, const float* b_std, void* stream);
+int etg_policy_sample(EtgPolicy* p, const float* obs, int n, const float* noise, float act_scale,
+                      int precision, float* act, float* logp, void* stream);
 void etg_policy_destroy(EtgPolicy* p);
 
 /* ---- ETG parameterisation (the step right before reset) ----

@@ -197,3 +197,18 @@ def mlp_forward(obs, w1, b1, w2, b2, w3, b3, scale=1.0, dtype=np.float64):
     getattr(lib(), "etgo_mlp_forward" + sfx)(_p(obs), n, in_dim, hid, out_dim,
                                               *[_p(a) for a in ws], _ct(dtype)(scale), _p(act))
     return act
+
+
+def mlp_sample(obs, w1, b1, w2, b2, w3, b3, ws, bs, noise, scale=1.0):
+    """SAC.sample restated in numpy fp64 (alg/sac.py:65-76 over Actor.forward, model/mujoco_model.py:53-60):
+    -> (tanh(mean + exp(clamp(log_std, -20, 2)) * noise) * scale, log-probability [n,1])."""
+    f = np.float64
+    obs, noise = np.asarray(obs, f), np.asarray(noise, f)
+    h = np.maximum(obs @ np.asarray(w1, f).T + np.asarray(b1, f), 0)
+    h = np.maximum(h @ np.asarray(w2, f).T + np.asarray(b2, f), 0)
+    mean = h @ np.asarray(w3, f).T + np.asarray(b3, f)
+    log_std = np.clip(h @ np.asarray(ws, f).T + np.asarray(bs, f), -20.0, 2.0)
+    x = mean + np.exp(log_std) * noise
+    a = np.tanh(x)
+    logp = (-0.5 * noise ** 2 - log_std - 0.5 * np.log(2 * np.pi)) - np.log((1 - a ** 2) + 1e-6)
+    return a * scale, logp.sum(1, keepdims=True)

@@ -14,7 +14,7 @@ SYMBOLS = [
     "etg_create", "etg_destroy", "etg_last_error", "etg_version", "etg_lanes_per_robot", "etg_set_params",
     "etg_set_heightfield", "etg_set_external_force", "etg_reset", "etg_step", "etg_episode_stats", "etg_rollout_openloop",
     "etg_get_state",
-    "etg_set_state", "etg_policy_create", "etg_policy_load", "etg_policy_forward",
+    "etg_set_state", "etg_policy_create", "etg_policy_load", "etg_policy_forward", "etg_policy_load_std", "etg_policy_sample",
     "etg_policy_destroy", "etg_fit_etg",
 ]
 
@@ -56,6 +56,8 @@ def load():
     lib.etg_policy_create.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
     lib.etg_policy_load.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     lib.etg_policy_forward.argtypes = [vp, vp, i32, C.c_float, i32, vp, vp]
+    lib.etg_policy_load_std.argtypes = [vp, vp, vp, vp]
+    lib.etg_policy_sample.argtypes = [vp, vp, i32, vp, C.c_float, i32, vp, vp, vp]
     lib.etg_policy_destroy.argtypes = [vp]
     lib.etg_policy_destroy.restype = None
     dbl = C.c_double

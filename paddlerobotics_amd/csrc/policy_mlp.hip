@@ -114,15 +114,21 @@ __device__ __forceinline__ void hidden_layer(const float* in, int nkb, const flo
   }
 }
 
-template <bool BF16>
+// SAMPLE = false: act = tanh(mean) * scale                                  (SAC.predict, alg/sac.py:60-63)
+// SAMPLE = true : x = mean + exp(clamp(log_std, -20, 2)) * eps, act = tanh(x) * scale, and optionally
+//                 logp = sum_j [N(x_j; mean_j, std_j) log-density - log(1 - tanh(x_j)^2 + 1e-6)]
+//                 (SAC.sample, alg/sac.py:65-76; clamp of model/mujoco_model.py:58-59); eps is the caller's N(0,1)
+template <bool BF16, bool SAMPLE>
 __global__ void __launch_bounds__(THREADS) k_policy(const float* __restrict__ obs, int n, int in_dim,
                                                     const float4* __restrict__ w1p, const float* __restrict__ b1,
                                                     const float4* __restrict__ w2p, const float* __restrict__ b2,
                                                     const float4* __restrict__ w3p, const float* __restrict__ b3,
-                                                    int out_dim, float scale, float* __restrict__ act) {
+                                                    const float4* __restrict__ w3sp, const float* __restrict__ b3s,
+                                                    const float* __restrict__ eps, int out_dim, float scale,
+                                                    float* __restrict__ act, float* __restrict__ logp) {
   __shared__ __attribute__((aligned(16))) float bufA[TM * HS];
   __shared__ __attribute__((aligned(16))) float bufB[TM * HS];
-  __shared__ float part[4][TM][16];
+  __shared__ float part[SAMPLE ? 2 : 1][4][TM][16];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int row0 = blockIdx.x * TM;
   // obs tile -> LDS, zero padded (rows past n, columns past in_dim up to the 64-wide padded K)
@@ -137,11 +143,12 @@ __global__ void __launch_bounds__(THREADS) k_policy(const float* __restrict__ ob
   __syncthreads();
   hidden_layer<BF16>(bufB, HID / 16, w2p, b2, bufA, wave, lane);
   __syncthreads();
-  // output layer: one 16x16 tile (out_dim <= 16), K split over the 4 waves (4 k-blocks each)
-  {
+  // output layer: one 16x16 tile per head (out_dim <= 16), K split over the 4 waves (4 k-blocks each)
+#pragma unroll
+  for (int head = 0; head < (SAMPLE ? 2 : 1); head++) {
     const int i = lane & 15, g = lane >> 4;
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    const float4* base = w3p + lane;
+    const float4* base = (head == 0 ? w3p : w3sp) + lane;
     if (!BF16) {
 #pragma unroll
       for (int kk = 0; kk < 4; kk++) {
@@ -164,15 +171,29 @@ __global__ void __launch_bounds__(THREADS) k_policy(const float* __restrict__ ob
       }
     }
 #pragma unroll
-    for (int r = 0; r < 4; r++) part[wave][4 * g + r][i] = acc[r];
+    for (int r = 0; r < 4; r++) part[head][wave][4 * g + r][i] = acc[r];
   }
   __syncthreads();
   {
-    const int r = tid >> 4, cidx = tid & 15;  // 256 threads = 16 rows x 16 cols
-    if (cidx < out_dim && row0 + r < n) {
-      // fixed summation order over the 4 K-slices
-      float v = ((part[0][r][cidx] + part[1][r][cidx]) + (part[2][r][cidx] + part[3][r][cidx])) + b3[cidx];
-      act[(size_t)(row0 + r) * out_dim + cidx] = tanhf(v) * scale;
+    const int r = tid >> 4, cidx = tid & 15;  // 256 threads = 16 rows x 16 cols; a row = one 16-lane DPP row
+    const bool live = cidx < out_dim && row0 + r < n;
+    // fixed summation order over the 4 K-slices
+    float v = ((part[0][0][r][cidx] + part[0][1][r][cidx]) + (part[0][2][r][cidx] + part[0][3][r][cidx])) + (live ? b3[cidx] : 0.0f);
+    float lp = 0.0f;
+    if constexpr (SAMPLE) {
+      float ls = ((part[1][0][r][cidx] + part[1][1][r][cidx]) + (part[1][2][r][cidx] + part[1][3][r][cidx])) + (live ? b3s[cidx] : 0.0f);
+      ls = fminf(fmaxf(ls, -20.0f), 2.0f);
+      const float e = live ? eps[(size_t)(row0 + r) * out_dim + cidx] : 0.0f;
+      v = v + expf(ls) * e;
+      const float a = tanhf(v);
+      lp = live ? (-0.5f * e * e - ls - 0.9189385332046727f) - logf((1.0f - a * a) + 1e-6f) : 0.0f;
+      if (live) act[(size_t)(row0 + r) * out_dim + cidx] = a * scale;
+      if (logp) {   // sum over the row's 16 lanes (butterfly inside the DPP row)
+        lp += __shfl_xor(lp, 1); lp += __shfl_xor(lp, 2); lp += __shfl_xor(lp, 4); lp += __shfl_xor(lp, 8);
+        if (cidx == 0 && row0 + r < n) logp[row0 + r] = lp;
+      }
+    } else {
+      if (live) act[(size_t)(row0 + r) * out_dim + cidx] = tanhf(v) * scale;
     }
   }
 }
@@ -184,6 +205,8 @@ extern "C" void etg_set_last_error_(const char* msg);
 struct EtgPolicy {
   int device, in_dim, hidden, out_dim;
   float *w1, *b1, *w2, *b2, *w3, *b3;  // w1/w2/w3 hold the PACKED (MFMA-fragment order) copies
+  float *w3s, *b3s;                    // log-std head (etg_policy_load_std), packed like w3
+  int has_std;
 };
 static size_t packed_floats(int ntiles, int nkb) { return (size_t)ntiles * nkb * 64 * 4; }
 
@@ -203,7 +226,9 @@ extern "C" int etg_policy_create(int in_dim, int hidden, int out_dim, int device
   p->device = device; p->in_dim = in_dim; p->hidden = hidden; p->out_dim = out_dim;
   struct { float** q; size_t n; } a[] = {{&p->w1, packed_floats(HID / 16, 4)}, {&p->b1, (size_t)hidden},
                                          {&p->w2, packed_floats(HID / 16, HID / 16)}, {&p->b2, (size_t)hidden},
-                                         {&p->w3, packed_floats(1, HID / 16)}, {&p->b3, (size_t)out_dim}};
+                                         {&p->w3, packed_floats(1, HID / 16)}, {&p->b3, (size_t)out_dim},
+                                         {&p->w3s, packed_floats(1, HID / 16)}, {&p->b3s, (size_t)out_dim}};
+  p->has_std = 0;
   for (auto& x : a)
     if (hipMalloc((void**)x.q, x.n * 4) != hipSuccess) return pfail(ETG_ERR_ALLOC, "etg_policy_create: hipMalloc failed");
   *out = p;
@@ -232,25 +257,57 @@ extern "C" int etg_policy_load(EtgPolicy* p, const float* w1, const float* b1, c
   return ETG_OK;
 }
 
+extern "C" int etg_policy_load_std(EtgPolicy* p, const float* w_std, const float* b_std, void* stream) {
+  if (!p || !w_std || !b_std) return pfail(ETG_ERR_BAD_ARG, "etg_policy_load_std: null");
+  if (hipSetDevice(p->device) != hipSuccess) return pfail(ETG_ERR_HIP, "hipSetDevice");
+  hipStream_t s = (hipStream_t)stream;
+  const int total = (HID / 16) * 256;
+  hipLaunchKernelGGL(k_pack_weights, dim3((total + 255) / 256), dim3(256), 0, s, w_std, p->out_dim, p->hidden, 1, HID / 16, p->w3s);
+  if (hipMemcpyAsync(p->b3s, b_std, (size_t)p->out_dim * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
+    return pfail(ETG_ERR_HIP, "etg_policy_load_std: hipMemcpyAsync failed");
+  if (hipGetLastError() != hipSuccess) return pfail(ETG_ERR_HIP, "etg_policy_load_std: pack launch failed");
+  p->has_std = 1;
+  return ETG_OK;
+}
+
+#define ETG_POLICY_ARGS obs, n, p->in_dim, (const float4*)p->w1, p->b1, (const float4*)p->w2, p->b2, (const float4*)p->w3, p->b3, \
+                        (const float4*)p->w3s, p->b3s
 extern "C" int etg_policy_forward(EtgPolicy* p, const float* obs, int n, float act_scale, int precision, float* act,
                                   void* stream) {
   if (!p || !obs || !act || n <= 0) return pfail(ETG_ERR_BAD_ARG, "etg_policy_forward: bad arguments");
   if (hipSetDevice(p->device) != hipSuccess) return pfail(ETG_ERR_HIP, "hipSetDevice");
   dim3 grid((n + TM - 1) / TM), block(THREADS);
   if (precision == 0)
-    hipLaunchKernelGGL(k_policy<false>, grid, block, 0, (hipStream_t)stream, obs, n, p->in_dim, (const float4*)p->w1, p->b1,
-                       (const float4*)p->w2, p->b2, (const float4*)p->w3, p->b3, p->out_dim, act_scale, act);
+    hipLaunchKernelGGL((k_policy<false, false>), grid, block, 0, (hipStream_t)stream, ETG_POLICY_ARGS, nullptr, p->out_dim,
+                       act_scale, act, nullptr);
   else
-    hipLaunchKernelGGL(k_policy<true>, grid, block, 0, (hipStream_t)stream, obs, n, p->in_dim, (const float4*)p->w1, p->b1,
-                       (const float4*)p->w2, p->b2, (const float4*)p->w3, p->b3, p->out_dim, act_scale, act);
+    hipLaunchKernelGGL((k_policy<true, false>), grid, block, 0, (hipStream_t)stream, ETG_POLICY_ARGS, nullptr, p->out_dim,
+                       act_scale, act, nullptr);
   if (hipGetLastError() != hipSuccess) return pfail(ETG_ERR_HIP, "etg_policy_forward: launch failed");
   return ETG_OK;
 }
 
+extern "C" int etg_policy_sample(EtgPolicy* p, const float* obs, int n, const float* noise, float act_scale, int precision,
+                                 float* act, float* logp, void* stream) {
+  if (!p || !obs || !act || !noise || n <= 0) return pfail(ETG_ERR_BAD_ARG, "etg_policy_sample: bad arguments");
+  if (!p->has_std) return pfail(ETG_ERR_STATE, "etg_policy_sample: etg_policy_load_std() first");
+  if (hipSetDevice(p->device) != hipSuccess) return pfail(ETG_ERR_HIP, "hipSetDevice");
+  dim3 grid((n + TM - 1) / TM), block(THREADS);
+  if (precision == 0)
+    hipLaunchKernelGGL((k_policy<false, true>), grid, block, 0, (hipStream_t)stream, ETG_POLICY_ARGS, noise, p->out_dim,
+                       act_scale, act, logp);
+  else
+    hipLaunchKernelGGL((k_policy<true, true>), grid, block, 0, (hipStream_t)stream, ETG_POLICY_ARGS, noise, p->out_dim,
+                       act_scale, act, logp);
+  if (hipGetLastError() != hipSuccess) return pfail(ETG_ERR_HIP, "etg_policy_sample: launch failed");
+  return ETG_OK;
+}
+#undef ETG_POLICY_ARGS
+
 extern "C" void etg_policy_destroy(EtgPolicy* p) {
   if (!p) return;
   (void)hipSetDevice(p->device);
-  float* ptrs[] = {p->w1, p->b1, p->w2, p->b2, p->w3, p->b3};
+  float* ptrs[] = {p->w1, p->b1, p->w2, p->b2, p->w3, p->b3, p->w3s, p->b3s};
   for (float* q : ptrs)
     if (q) (void)hipFree(q);
   delete p;

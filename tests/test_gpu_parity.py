@@ -180,6 +180,36 @@ def test_policy_mfma_matches_torch_fixture(golden):
     assert np.abs(act7 - 0.3 * g["act"][:7]).max() < 1e-5
 
 
+def test_policy_sample_head_matches_torch_fixture(golden):
+    """SAC.sample on the MFMA kernel (etg_policy_sample) vs the reference actor evaluated with torch."""
+    _need_gpu()
+    from paddlerobotics_amd.policy import MfmaPolicy
+    g, gs = golden("mlp"), golden("mlp_sample")
+    sd = {"actor_model." + k.replace("_weight", ".weight").replace("_bias", ".bias"): torch.as_tensor(g[k])
+          for k in ("l1_weight", "l1_bias", "l2_weight", "l2_bias", "mean_linear_weight", "mean_linear_bias")}
+    sd["actor_model.std_linear.weight"] = torch.as_tensor(gs["std_linear_weight"])
+    sd["actor_model.std_linear.bias"] = torch.as_tensor(gs["std_linear_bias"])
+    pol = MfmaPolicy(46, 12)
+    pol.load_state_dict(sd)
+    obs, noise = torch.as_tensor(gs["obs"], device="cuda:0"), torch.as_tensor(gs["noise"], device="cuda:0")
+    act, logp = pol.sample(obs, 1.0, precision=0, noise=noise)
+    act, logp = act.cpu().numpy(), logp.cpu().numpy()
+    assert np.abs(act - gs["action"]).max() < 2e-5
+    sat = (1 - gs["action"] ** 2).min(1) < 1e-4
+    assert np.abs(logp - gs["log_prob"])[~sat].max() < 5e-3
+    a3 = pol.sample(obs[:5].contiguous(), 0.3, noise=noise[:5].contiguous(), return_logp=False).cpu().numpy()
+    assert np.abs(a3 - 0.3 * gs["action"][:5]).max() < 2e-5          # ragged batch + act_bound scaling
+    # predict() is unchanged by the presence of the std head
+    assert np.abs(pol.predict(torch.as_tensor(g["obs"], device="cuda:0")).cpu().numpy() - g["act"]).max() < 1e-5
+    # own noise: reproducible with a generator, different across draws
+    gen = torch.Generator(device="cuda:0"); gen.manual_seed(5)
+    s1, _ = pol.sample(obs, generator=gen)
+    gen.manual_seed(5)
+    s2, _ = pol.sample(obs, generator=gen)
+    s3, _ = pol.sample(obs, generator=gen)
+    assert torch.equal(s1, s2) and not torch.equal(s1, s3)
+
+
 def test_policy_random_init_config3_vs_oracle():
     _need_gpu()
     from oracle import oracle as O
