@@ -128,6 +128,11 @@ typedef struct EtgConfig {
    * walks on band e % hf_bands (its own y axis, clamped inside the band). 0 or 1 = one shared terrain.
    * This is how per-episode stair/slope parameters (train.py:48-50) coexist in one batch.          */
   int32_t hf_bands;
+  /* motor control mode (robot_config.MotorControlMode, train.py mode_map): 0 = POSITION -- the action is a
+   * joint-angle residual on pose_ori + ETG and the PD law of laikago_motor.py:165-173 makes the torque;
+   * 1 = TORQUE -- the action IS the 12 motor torques (laikago_motor.py:140-143), no ETG/pose added; the
+   * reset settle always runs under POSITION control like a1.py:289-304.                              */
+  int32_t motor_mode;
 } EtgConfig;
 
 typedef struct EtgHandle EtgHandle;

@@ -702,10 +702,11 @@ template <class T> void delayed_obs(const Sim<T>& s, const Env<T>& e, T* o) {
 }
 
 // one sub-step: ApplyAction (PD, laikago_motor.py:165-173; pd_latency = 0) -> tick -> history
-template <class T> void sub_step(const Sim<T>& s, Env<T>& e, const T* qdes) {
+template <class T> void sub_step(const Sim<T>& s, Env<T>& e, const T* qdes, bool torque_cmd = false) {
   T tau[12];
   for (int j = 0; j < 12; j++) {
-    T t = -(e.kp[j] * (e.q[j] - qdes[j])) - e.kd[j] * e.qd[j];
+    // POSITION: laikago_motor.py:165-173; TORQUE: the command is the torque (laikago_motor.py:140-143)
+    T t = torque_cmd ? qdes[j] : -(e.kp[j] * (e.q[j] - qdes[j])) - e.kd[j] * e.qd[j];
     if (s.cfg.torque_limit > 0) {
       T lim = T(s.cfg.torque_limit);
       if (t > lim) t = lim;
@@ -850,7 +851,8 @@ void step_env(Sim<T>& s, Env<T>& e, const T* action, int donef, T* obs, T* rewar
   T t = T(e.step_count + 1) * T(s.cfg.etg_dt);
   T etg[12], qdes[12];
   etg_action(s, e, t, etg);
-  for (int j = 0; j < 12; j++) qdes[j] = T(m.pose_ori[j]) + etg[j] + action[j];
+  const bool torque_cmd = s.cfg.motor_mode == 1;
+  for (int j = 0; j < 12; j++) qdes[j] = torque_cmd ? action[j] : T(m.pose_ori[j]) + etg[j] + action[j];
   if (s.cfg.enable_action_filter) {  // action_filter.py:111-120 (order 2)
     for (int j = 0; j < 12; j++) {
       T y = T(s.cfg.filter_b[0]) * qdes[j] + T(s.cfg.filter_b[1]) * e.fx[0][j] + T(s.cfg.filter_b[2]) * e.fx[1][j] -
@@ -869,7 +871,7 @@ void step_env(Sim<T>& s, Env<T>& e, const T* action, int donef, T* obs, T* rewar
     } else {
       for (int j = 0; j < 12; j++) proc[j] = qdes[j];
     }
-    sub_step(s, e, proc);
+    sub_step(s, e, proc, torque_cmd);
   }
   for (int j = 0; j < 12; j++) e.last_qdes[j] = qdes[j];
   e.has_last = 1;

@@ -178,7 +178,8 @@ template <class F> ETG_HD void bwd6(const F* L, F* b) {  // b <- L^-T b
 // ------------------------------------------------------------------ one physics tick
 // stepSimulation() + ApplyAction + ReceiveObservation of minitaur.py:242-246 for one quad.
 template <class F, class Ctx>
-ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* qdes, const V3<F>& fext_w) {
+ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* qdes, const V3<F>& fext_w,
+                         bool torque_cmd = false) {
   typedef V3<F> V;
   typedef SV<F> W;
   const F dt(K.dt), zero(0.0f), one(1.0f);
@@ -187,7 +188,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* 
   F tau[3];
 #pragma unroll
   for (int j = 0; j < 3; j++) {
-    F t = -(c.par(PR_KP + j) * (L.q[j] - qdes[j])) - c.par(PR_KD + j) * L.qd[j];
+    F t = torque_cmd ? qdes[j] : -(c.par(PR_KP + j) * (L.q[j] - qdes[j])) - c.par(PR_KD + j) * L.qd[j];   // TORQUE mode: pass-through
     if (K.torque_limit > 0.0f) t = fminf_(fmaxf_(t, F(-K.torque_limit)), F(K.torque_limit));
     tau[j] = t;
   }
@@ -655,8 +656,9 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   // ETG at t = (k+1) dt (fixture convention of gait_action_list_ETG_exp.npy)
   F etg[3], qdes[3];
   etg_action(c, K, etgp, (float)(step_count + 1) * K.etg_dt, etg);
+  const bool torque_cmd = K.motor_mode == 1;
 #pragma unroll
-  for (int j = 0; j < 3; j++) qdes[j] = c.par(PR_POSE + j) + etg[j] + action[j];
+  for (int j = 0; j < 3; j++) qdes[j] = torque_cmd ? action[j] : c.par(PR_POSE + j) + etg[j] + action[j];
   if (K.enable_filter) {  // action_filter.py:111-120, order 2
 #pragma unroll
     for (int j = 0; j < 3; j++) {
@@ -690,7 +692,7 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
     float lerp = (float)(i + 1) * inv_repeat;
 #pragma unroll
     for (int j = 0; j < 3; j++) proc[j] = interp ? last[j] + F(lerp) * (qdes[j] - last[j]) : qdes[j];
-    physics_tick(c, K, L, proc, fext);
+    physics_tick(c, K, L, proc, fext, torque_cmd);
     tick++;
     if (i == ia || i == ib) ring_push(c, ring, tick & (RING - 1), L);
   }

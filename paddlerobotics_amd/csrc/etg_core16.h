@@ -108,7 +108,7 @@ template <class F, class Ctx> ETG_HD LegGeo<F> leg_geometry(const Ctx& c, const 
 
 // ------------------------------------------------------------------ one physics tick, 16 lanes per robot
 template <class F, class Ctx>
-ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, State16<F>& L, F qdes) {
+ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, State16<F>& L, F qdes, bool torque_cmd = false) {
   typedef V3<F> V;
   typedef SV<F> W;
   const F dt(K.dt), zero(0.0f), one(1.0f);
@@ -119,7 +119,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   const F m2 = m1 - f1;                       // sub >= 2
 
   // ---- PD motor model (laikago_motor.py:165-173), this lane's joint
-  F tau = mj * (-(tp.kp * (L.q - qdes)) - tp.kd * L.qd);
+  F tau = torque_cmd ? mj * qdes : mj * (-(tp.kp * (L.q - qdes)) - tp.kd * L.qd);   // TORQUE mode: pass-through
   if (K.torque_limit > 0.0f) tau = fminf_(fmaxf_(tau, F(-K.torque_limit)), F(K.torque_limit));
 
   // ---- leg geometry, this lane's link frame R_s = Rx(a) Ry(theta_s), theta = (0, h, h+k)
@@ -503,7 +503,8 @@ ETG_HD void control_step16(const Ctx& c, const KCfg& K, State16<F>& L, float* ri
   int has_last = c.ld_env_i(ictl, IC_HAS_LAST);
   const F mj = c.jointf();
   F etg = etg_action16<F>(c, K, etgp, (float)(step_count + 1) * K.etg_dt);
-  F qdes = mj * (c.par_joint(PR_POSE) + etg + action);
+  const bool torque_cmd = K.motor_mode == 1;
+  F qdes = torque_cmd ? mj * action : mj * (c.par_joint(PR_POSE) + etg + action);
   if (K.enable_filter) {
     F x0 = c.ld_joint(legctl, LC_FX0), x1 = c.ld_joint(legctl, LC_FX1);
     F y0 = c.ld_joint(legctl, LC_FY0), y1 = c.ld_joint(legctl, LC_FY1);
@@ -530,7 +531,7 @@ ETG_HD void control_step16(const Ctx& c, const KCfg& K, State16<F>& L, float* ri
   for (int i = 0; i < K.action_repeat; i++) {
     float lerp = (float)(i + 1) * inv_repeat;
     F proc = interp ? last + F(lerp) * (qdes - last) : qdes;
-    physics_tick16(c, K, tp, L, proc);
+    physics_tick16(c, K, tp, L, proc, torque_cmd);
     tick++;
     if (i == ia || i == ib) ring_push16(c, ring, tick & (RING - 1), L);
   }

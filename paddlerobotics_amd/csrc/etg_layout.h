@@ -55,6 +55,7 @@ struct KCfg {
   float hf_cell, hf_x0, hf_y0;
   const float* hf;
   int ext_force;         // 1 once etg_set_external_force() installed a force (ctl[CT_FEXT..])
+  int motor_mode;        // 0 POSITION (PD on a joint-angle command), 1 TORQUE (the command is the torque)
 };
 
 struct DevState {
@@ -227,6 +228,7 @@ inline KCfg make_kcfg(const EtgConfig& c, const EtgRobotModel& m) {
   K.hf_bands = c.hf_bands > 1 ? c.hf_bands : 1;
   K.hf_nx = c.hf_nx; K.hf_ny = c.hf_ny / K.hf_bands;
   K.ext_force = 0;
+  K.motor_mode = c.motor_mode;
   K.hf_cell = (float)c.hf_cell; K.hf_x0 = (float)c.hf_x0; K.hf_y0 = (float)c.hf_y0;
   K.hf = nullptr;
   return K;

@@ -105,8 +105,15 @@ class BatchedQuadrupedEnv:
             raise ValueError("task='heightfield' and the heightfield= argument go together")
         self.task = task
         self.terrain = heightfield
-        if motor_control_mode not in (None, "pose", "traj", 1) and getattr(motor_control_mode, "name", "") != "POSITION":
-            raise NotImplementedError("only the POSITION motor mode (train.py mode_map 'pose'/'traj') is simulated")
+        # train.py:56-58 mode_map: "pose"/"traj" -> POSITION, "torque" -> TORQUE; enum values also accepted
+        mname = getattr(motor_control_mode, "name", motor_control_mode)
+        if mname in (None, "pose", "traj", "POSITION", 1):
+            motor_mode = 0
+        elif mname in ("torque", "TORQUE", 2):
+            motor_mode = 1
+        else:
+            raise NotImplementedError("motor_control_mode %r: POSITION and TORQUE are simulated (HYBRID is not)" % (motor_control_mode,))
+        self.motor_mode = motor_mode
         self._cols = sensor_columns(sensor_mode)
         rp = dict(random_param or {})
         self._rand_dyn = bool(rp.get("random_dynamics", 0))
@@ -125,7 +132,7 @@ class BatchedQuadrupedEnv:
             enable_action_filter=enable_action_filter, normal=normal,
             terrain=1 if heightfield is not None else 0, ETG_T=ETG_T, ETG_T2=ETG_T2,
             reward_param=reward_param, reward_p=reward_p, vel_d=vel_d, heightfield=heightfield,
-            lanes_per_robot=lanes_per_robot)
+            lanes_per_robot=lanes_per_robot, motor_mode=motor_mode)
         self.model = A.default_model()
         self.observation_space = Box(-np.inf, np.inf, (len(self._cols),))
         self.action_space = Box(-1.0, 1.0, (A.NUM_MOTORS,))

@@ -489,3 +489,24 @@ def test_sensor_mode_selects_observation_columns():
     with pytest.raises(NotImplementedError):
         _make(n, sensor_mode={"footpose": 1})
     full.close(); stud.close()
+
+
+def test_torque_mode_matches_oracle():
+    """motor_control_mode='torque' (train.py mode_map): the action is the 12 motor torques."""
+    _need_gpu()
+    n = 16
+    env = _make(n, motor_control_mode="torque", solver_iters=4)
+    orc = _oracle(n, solver_iters=4, motor_mode=1)
+    env.reset(); orc.reset()
+    assert np.abs(env.get_state().cpu().numpy()[:, :7] - orc.get_state()[:, :7]).max() < 2e-3
+    rng = np.random.default_rng(3)
+    for _ in range(4):
+        tau = rng.uniform(-3, 3, size=(n, 12))
+        env.step(torch.as_tensor(tau, dtype=torch.float32))
+        orc.step(tau)
+    sg, so = env.get_state().cpu().numpy(), orc.get_state()
+    err = np.abs(sg[:, 13:25] - so[:, 13:25]).max(1)
+    assert np.median(err) < 2e-3 and err.max() < 2e-2
+    with pytest.raises(NotImplementedError):
+        _make(n, motor_control_mode="hybrid")
+    env.close()

@@ -123,3 +123,26 @@ def test_param2dynamic_rows_equal_the_dict_mapping():
     for i in range(5):
         assert np.array_equal(rows[i], A.dynamic_dict_to_row(A.param2dynamic_dict(P[i])))
     assert np.array_equal(A.param2dynamic_rows(np.zeros(48))[0], A.default_dynamic_row())
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_emulation_torque_mode_matches_oracle(lanes):
+    """motor_control_mode TORQUE (train.py mode_map; laikago_motor.py:140-143): the action is the torque."""
+    from oracle.oracle import OracleSim
+    from tests.emu.emu import EmuSim
+    n = 3
+    cfg = A.default_config(n, solver_iters=4, motor_mode=1)
+    orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=lanes)
+    orc.reset(); emu.reset()
+    assert np.abs(emu.get_state()[:, :7] - orc.get_state()[:, :7]).max() < 2e-3      # the settle runs under PD
+    assert orc.get_state()[:, 2].min() > 0.2
+    rng = np.random.default_rng(0)
+    z0 = orc.get_state()[:, 2].copy()
+    for k in range(4):
+        tau = rng.uniform(-3.0, 3.0, size=(n, 12))
+        tau[0] = 0.0                                         # robot 0: limp
+        orc.step(tau); emu.step(tau)
+        so, se = orc.get_state(), emu.get_state()
+        assert np.abs(se[:, 13:25] - so[:, 13:25]).max() < 1e-2 and np.abs(se[:, :3] - so[:, :3]).max() < 3e-3
+    # with zero torque the legs give way (in the position mode action 0 would hold the stance)
+    assert orc.get_state()[0, 2] < z0[0] - 0.03
