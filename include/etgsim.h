@@ -133,6 +133,11 @@ typedef struct EtgConfig {
    * 1 = TORQUE -- the action IS the 12 motor torques (laikago_motor.py:140-143), no ETG/pose added; the
    * reset settle always runs under POSITION control like a1.py:289-304.                              */
   int32_t motor_mode;
+  /* A1._ClipMotorCommands (deployment/robots/a1.py:439-457, MAX_MOTOR_ANGLE_CHANGE_PER_STEP = 0.2): when
+   * > 0, every sub-step's position command is clipped to the current motor angle +- this many radians
+   * (the true angle is used; the reference reads its latency-delayed observation). 0 = off (the default
+   * of the reference's constructor).                                                                  */
+  double clip_motor_commands;
 } EtgConfig;
 
 typedef struct EtgHandle EtgHandle;

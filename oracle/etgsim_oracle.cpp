@@ -706,7 +706,13 @@ template <class T> void sub_step(const Sim<T>& s, Env<T>& e, const T* qdes, bool
   T tau[12];
   for (int j = 0; j < 12; j++) {
     // POSITION: laikago_motor.py:165-173; TORQUE: the command is the torque (laikago_motor.py:140-143)
-    T t = torque_cmd ? qdes[j] : -(e.kp[j] * (e.q[j] - qdes[j])) - e.kd[j] * e.qd[j];
+    T cmd = qdes[j];
+    if (s.cfg.clip_motor_commands > 0 && !torque_cmd) {   // A1._ClipMotorCommands, a1.py:439-457
+      const T lim = T(s.cfg.clip_motor_commands);
+      if (cmd > e.q[j] + lim) cmd = e.q[j] + lim;
+      if (cmd < e.q[j] - lim) cmd = e.q[j] - lim;
+    }
+    T t = torque_cmd ? cmd : -(e.kp[j] * (e.q[j] - cmd)) - e.kd[j] * e.qd[j];
     if (s.cfg.torque_limit > 0) {
       T lim = T(s.cfg.torque_limit);
       if (t > lim) t = lim;

@@ -188,7 +188,9 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* 
   F tau[3];
 #pragma unroll
   for (int j = 0; j < 3; j++) {
-    F t = torque_cmd ? qdes[j] : -(c.par(PR_KP + j) * (L.q[j] - qdes[j])) - c.par(PR_KD + j) * L.qd[j];   // TORQUE mode: pass-through
+    F cmd = qdes[j];
+    if (K.clip_cmd > 0.0f && !torque_cmd) cmd = fminf_(fmaxf_(cmd, L.q[j] - F(K.clip_cmd)), L.q[j] + F(K.clip_cmd));   // a1.py:439-457
+    F t = torque_cmd ? cmd : -(c.par(PR_KP + j) * (L.q[j] - cmd)) - c.par(PR_KD + j) * L.qd[j];   // TORQUE mode: pass-through
     if (K.torque_limit > 0.0f) t = fminf_(fmaxf_(t, F(-K.torque_limit)), F(K.torque_limit));
     tau[j] = t;
   }

@@ -119,6 +119,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   const F m2 = m1 - f1;                       // sub >= 2
 
   // ---- PD motor model (laikago_motor.py:165-173), this lane's joint
+  if (K.clip_cmd > 0.0f && !torque_cmd) qdes = fminf_(fmaxf_(qdes, L.q - F(K.clip_cmd)), L.q + F(K.clip_cmd));   // a1.py:439-457
   F tau = torque_cmd ? mj * qdes : mj * (-(tp.kp * (L.q - qdes)) - tp.kd * L.qd);   // TORQUE mode: pass-through
   if (K.torque_limit > 0.0f) tau = fminf_(fmaxf_(tau, F(-K.torque_limit)), F(K.torque_limit));
 

@@ -56,6 +56,7 @@ struct KCfg {
   const float* hf;
   int ext_force;         // 1 once etg_set_external_force() installed a force (ctl[CT_FEXT..])
   int motor_mode;        // 0 POSITION (PD on a joint-angle command), 1 TORQUE (the command is the torque)
+  float clip_cmd;        // > 0: clip the position command to q +- clip_cmd every tick (a1.py:439-457)
 };
 
 struct DevState {
@@ -229,6 +230,7 @@ inline KCfg make_kcfg(const EtgConfig& c, const EtgRobotModel& m) {
   K.hf_nx = c.hf_nx; K.hf_ny = c.hf_ny / K.hf_bands;
   K.ext_force = 0;
   K.motor_mode = c.motor_mode;
+  K.clip_cmd = (float)c.clip_motor_commands;
   K.hf_cell = (float)c.hf_cell; K.hf_x0 = (float)c.hf_x0; K.hf_y0 = (float)c.hf_y0;
   K.hf = nullptr;
   return K;

@@ -89,7 +89,7 @@ class BatchedQuadrupedEnv:
                  settle_ticks=500, solver_iters=2, enable_action_interpolation=False,
                  heightfield=None, lanes_per_robot=0, terrain_variants=16, terrain_seed=0,
                  random_dynamics_scale=0.3, random_force_prob=0.02, random_force_steps=8,
-                 random_force_range=(5.0, 25.0), seed=0, **unused):
+                 random_force_range=(5.0, 25.0), seed=0, enable_clip_motor_commands=False, **unused):
         if render:
             raise ValueError("render is not supported by the batched GPU simulator")
         if int(ETG_H) != A.RBF_H:
@@ -132,7 +132,8 @@ class BatchedQuadrupedEnv:
             enable_action_filter=enable_action_filter, normal=normal,
             terrain=1 if heightfield is not None else 0, ETG_T=ETG_T, ETG_T2=ETG_T2,
             reward_param=reward_param, reward_p=reward_p, vel_d=vel_d, heightfield=heightfield,
-            lanes_per_robot=lanes_per_robot, motor_mode=motor_mode)
+            lanes_per_robot=lanes_per_robot, motor_mode=motor_mode,
+            clip_motor_commands=0.2 if enable_clip_motor_commands else 0.0)   # MAX_MOTOR_ANGLE_CHANGE_PER_STEP, a1.py
         self.model = A.default_model()
         self.observation_space = Box(-np.inf, np.inf, (len(self._cols),))
         self.action_space = Box(-1.0, 1.0, (A.NUM_MOTORS,))

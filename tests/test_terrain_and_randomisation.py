@@ -146,3 +146,24 @@ def test_emulation_torque_mode_matches_oracle(lanes):
         assert np.abs(se[:, 13:25] - so[:, 13:25]).max() < 1e-2 and np.abs(se[:, :3] - so[:, :3]).max() < 3e-3
     # with zero torque the legs give way (in the position mode action 0 would hold the stance)
     assert orc.get_state()[0, 2] < z0[0] - 0.03
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_emulation_clip_motor_commands_matches_oracle(lanes):
+    """A1._ClipMotorCommands (a1.py:439-457): the position command never leads the motor angle by more than
+    0.2 rad, so a 0.6 rad command step moves the joints more gently than unclipped."""
+    from oracle.oracle import OracleSim
+    from tests.emu.emu import EmuSim
+    n = 2
+    act = np.zeros((n, 12)); act[:, 1::3] = 0.6
+    res = {}
+    for clip in (0.0, 0.2):
+        cfg = A.default_config(n, solver_iters=4, clip_motor_commands=clip)
+        orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=lanes)
+        orc.reset(); emu.reset()
+        q0 = orc.get_state()[:, 13:25].copy()
+        orc.step(act); emu.step(act)
+        so, se = orc.get_state(), emu.get_state()
+        assert np.abs(se[:, 13:25] - so[:, 13:25]).max() < 2e-3
+        res[clip] = np.abs(so[:, 13:25] - q0).max()
+    assert res[0.2] < 0.8 * res[0.0]
