@@ -510,3 +510,21 @@ def test_torque_mode_matches_oracle():
     with pytest.raises(NotImplementedError):
         _make(n, motor_control_mode="hybrid")
     env.close()
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+@pytest.mark.parametrize("n", [1, 5, 37])
+def test_ragged_batch_sizes_match_oracle(n, lanes):
+    """batches that do not fill a wave / a multiple of 8 workgroups (partial DPP rows, XCD block remap)"""
+    _need_gpu()
+    W, B = _etg_params(n, seed=n)
+    env, orc = _make(n, lanes_per_robot=lanes, solver_iters=4), _oracle(n, solver_iters=4)
+    env.reset(ETG_w=W, ETG_b=B)
+    orc.set_params(etg_w=W, etg_b=B)
+    orc.reset()
+    for _ in range(3):
+        env.step(None)
+        orc.step(np.zeros((n, 12)))
+    sg, so = env.get_state().cpu().numpy(), orc.get_state()
+    assert np.abs(sg[:, 13:25] - so[:, 13:25]).max() < 2e-3 and np.abs(sg[:, :7] - so[:, :7]).max() < 2e-3
+    env.close()
