@@ -33,6 +33,12 @@ HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
 # and r01_pmc_k_step_lanes4.txt: FETCH_SIZE + WRITE_SIZE, separate passes, KB units; dword accesses,
 # uncalibrated width -- see DESIGN.md section 7).  Scaled linearly with N for other batch sizes.
 PMC_TRAFFIC_BYTES_AT_4096 = {16: (4063.5 + 3076.0) * 1024.0, 4: (4094.0 + 3076.0) * 1024.0}
+# VALU instructions one wave issues per step-kernel launch (SQ_INSTS_VALU / SQ_WAVES, same PMC files) and the
+# VALU issue capacity of a SIMD measured with tools/ubench/occupancy_rate.hip (8 resident waves of v_fma_f32:
+# 0.384 wave-instructions per SIMD-cycle at the nominal 2.4 GHz; one resident wave reaches 0.172).
+PMC_VALU_PER_WAVE = {16: 22356162.1 / 1024.0, 4: 7960133.8 / 256.0}
+VALU_PEAK_PER_SIMD_CYCLE = 0.384
+NOMINAL_HZ = 2.4e9
 BYTES_PER_STEP_CFG2 = 816  # 564 B + 252 B per-env ETG w,b
 BYTES_PER_STEP_CFG3 = 808 + 252
 
@@ -178,6 +184,11 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK,
                          "traffic": PMC_TRAFFIC_BYTES_AT_4096[lanes] * N / 4096.0,
                          "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": bytes_per,
+                         # the ceiling that actually binds: VALU issue of one wave per SIMD
+                         "valu_issue": {"achieved": PMC_VALU_PER_WAVE[lanes] / (kern_ms * 1e-3 * NOMINAL_HZ),
+                                        "peak": VALU_PEAK_PER_SIMD_CYCLE, "unit": "wave-instr/SIMD-cycle @2.4GHz",
+                                        "frac": PMC_VALU_PER_WAVE[lanes] / (kern_ms * 1e-3 * NOMINAL_HZ) / VALU_PEAK_PER_SIMD_CYCLE,
+                                        "single_wave_limit": 0.172} if N * lanes <= 1024 * 64 else None,
                          "note": "VALU-issue-bound by construction (~1e3 FLOP/B, SURVEY 8d): one wave per SIMD, "
                                  "1 VALU issue / 4 cycles; see DESIGN.md section 7"},
             "survivors": float((length == args.steps + args.warmup).float().mean().item()),
