@@ -135,6 +135,11 @@ class BatchedQuadrupedEnv:
             lanes_per_robot=lanes_per_robot, motor_mode=motor_mode,
             clip_motor_commands=0.2 if enable_clip_motor_commands else 0.0)   # MAX_MOTOR_ANGLE_CHANGE_PER_STEP, a1.py
         self.model = A.default_model()
+        if task == "balancebeam":
+            # README "step_y: the foot position at y axis for balance beam task" (train.py:463): the ETG's nominal
+            # foot positions are pulled in to y = -+step_y so the feet land on the beam (right legs negative y)
+            for leg in range(4):
+                self.model.base_foot[3 * leg + 1] = (-1.0 if leg % 2 == 0 else 1.0) * float(step_y)
         self.observation_space = Box(-np.inf, np.inf, (len(self._cols),))
         self.action_space = Box(-1.0, 1.0, (A.NUM_MOTORS,))
         self._lib = _lib.load()

@@ -528,3 +528,20 @@ def test_ragged_batch_sizes_match_oracle(n, lanes):
     sg, so = env.get_state().cpu().numpy(), orc.get_state()
     assert np.abs(sg[:, 13:25] - so[:, 13:25]).max() < 2e-3 and np.abs(sg[:, :7] - so[:, :7]).max() < 2e-3
     env.close()
+
+
+def test_balance_beam_uses_step_y_stance():
+    """task='balancebeam': feet are commanded to y = -+step_y (train.py:463) and stay on the 0.3 m beam"""
+    _need_gpu()
+    n = 8
+    env = _make(n, task="balancebeam", step_y=0.05, terrain_variants=1)
+    env.reset()
+    for _ in range(20):
+        env.step(None)
+    st = env.get_state().cpu().numpy()
+    assert np.isfinite(st).all() and st[:, 2].min() > 0.15            # standing on the beam, not in the pit
+    wide = _make(n)                                                    # default stance for comparison
+    wide.reset()
+    q_narrow, q_wide = env.get_state()[:, 13:25:3].abs().mean().item(), wide.get_state()[:, 13:25:3].abs().mean().item()
+    assert q_narrow > q_wide + 0.05                                    # hips abducted inwards to reach y = 0.05
+    env.close(); wide.close()
