@@ -165,6 +165,15 @@ int etg_set_heightfield(EtgHandle* h, const float* heights, void* stream);
  * README "Add external random force").                                                              */
 int etg_set_external_force(EtgHandle* h, const float* force, void* stream);
 
+/* random pushes, sampled on the device (random_param['random_force'], train.py:254; rlschool's own schedule is
+ * absent, this one is the repo's): call once per control step before etg_step. A robot without an active push
+ * starts one with probability `prob`: a horizontal force of magnitude U(fmin, fmax) N in a uniform direction,
+ * held for `duration_steps` control steps, then removed. Counter-based RNG keyed by (seed, robot, call index),
+ * so a run is reproducible. Robots being reset should have their push cleared with etg_clear_pushes.  */
+int etg_random_pushes(EtgHandle* h, uint64_t seed, float prob, int duration_steps, float fmin, float fmax,
+                      void* stream);
+int etg_clear_pushes(EtgHandle* h, const uint8_t* mask, void* stream);
+
 /* ---- the hot path ------------------------------------------------------- */
 /* reset masked envs (NULL = all): place at init pose, settle, write obs[N,49]
  * rows of the reset envs (other rows untouched).                             */

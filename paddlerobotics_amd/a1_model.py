@@ -241,9 +241,25 @@ def dynamic_dict_to_row(d):
 
 
 def param2dynamic_rows(params):
-    """[n,48] parameter vectors in [-1,1] -> [n,48] physical rows (one param2dynamic_dict each)."""
-    P = np.atleast_2d(np.asarray(params, dtype=np.float64))
-    return np.stack([dynamic_dict_to_row(param2dynamic_dict(p)) for p in P])
+    """[n,48] parameter vectors in [-1,1] -> [n,48] physical rows: param2dynamic_dict + dynamic_dict_to_row,
+    vectorised over n (tests check it against the per-row functions)."""
+    P = np.clip(np.atleast_2d(np.asarray(params, dtype=np.float64)), -1, 1)
+    n = P.shape[0]
+    if P.shape[1] < 48:
+        P = np.concatenate([P, np.zeros((n, 48 - P.shape[1]))], axis=1)
+    kd0 = np.array([1., 2., 2.] * 4)
+    out = np.empty((n, 48))
+    out[:, 0] = np.clip(40 + 10 * P[:, 0], 0, 80)
+    out[:, 1] = np.clip(0.2 + 10 * P[:, 1], 0, 20)
+    out[:, 2] = np.clip(1.5 + 1 * P[:, 2], 0.5, 3)
+    out[:, 3:6] = np.clip(1 + P[:, 3:6], 0.1, 3)
+    out[:, 6:9] = np.clip(1 + P[:, 6:9], 0.1, 3)
+    out[:, 9:21] = np.clip(1 + P[:, 9:21], 0.1, 3)
+    out[:, 21:33] = np.clip(80 + 40 * P[:, 21:33], 20, 200)
+    out[:, 33:45] = np.clip(kd0 + P[:, 33:45] * kd0, 0, 5)
+    out[:, 45:48] = np.clip(np.array([0, 0, -10]) + P[:, 45:48] * np.array([2, 2, 10]),
+                            np.array([-5, -5, -20]), np.array([5, 5, -4]))
+    return out
 
 
 def default_dynamic_row():

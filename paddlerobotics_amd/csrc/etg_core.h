@@ -767,8 +767,7 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
 
 // ------------------------------------------------------------------ reset (minitaur.py:403-445, a1.py:289-349)
 template <class F, class Ctx>
-ETG_HD void reset_quad(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ring, float* ctl,
-                       int* ictl, float* legctl, const float* etgp, float* obs) {
+ETG_HD void reset_settle(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ring) {
   L.p = {F(K.init_pos[0]), F(K.init_pos[1]), F(K.init_pos[2])};
   L.qx = F(0.0f); L.qy = F(0.0f); L.qz = F(0.0f); L.qw = F(1.0f);
   L.wb = {F(0.0f), F(0.0f), F(0.0f)};
@@ -787,6 +786,14 @@ ETG_HD void reset_quad(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ring
   }
   c.ring_fence();
   L.energy = F(0.0f);
+}
+// the part of a reset after the settle (L and the ring freshly settled or restored from the settle cache)
+template <class F, class Ctx>
+ETG_HD void reset_finish(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ring, float* ctl, int* ictl, float* legctl,
+                         const float* etgp, float* obs) {
+  F pose[3] = {c.par(PR_POSE), c.par(PR_POSE + 1), c.par(PR_POSE + 2)};
+  const int tick = K.settle_ticks;
+  L.energy = F(0.0f);
   c.st_env_i(ictl, IC_STEP, 0);
   c.st_env_i(ictl, IC_TICK, tick);
   c.st_env_i(ictl, IC_HAS_LAST, 0);
@@ -802,6 +809,12 @@ ETG_HD void reset_quad(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ring
   F etg[3], imu[6];
   etg_action(c, K, etgp, 0.0f, etg);
   write_obs(c, K, L, ring, tick, ctl, etg, L.p.x, L.p.y, L.p.z, true, obs, imu);
+}
+template <class F, class Ctx>
+ETG_HD void reset_quad(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ring, float* ctl,
+                       int* ictl, float* legctl, const float* etgp, float* obs) {
+  reset_settle(c, K, L, ring);
+  reset_finish(c, K, L, ring, ctl, ictl, legctl, etgp, obs);
 }
 
 // ------------------------------------------------------------------ state access (parity tests)

@@ -599,8 +599,7 @@ ETG_HD void control_step16(const Ctx& c, const KCfg& K, State16<F>& L, float* ri
 
 // ------------------------------------------------------------------ reset
 template <class F, class Ctx>
-ETG_HD void reset_row16(const Ctx& c, const KCfg& K, State16<F>& L, float* ring, float* ctl, int* ictl, float* legctl,
-                        const float* etgp, float* obs) {
+ETG_HD void reset_settle16(const Ctx& c, const KCfg& K, State16<F>& L, float* ring) {
   const F mj = c.jointf();
   L.p = {F(K.init_pos[0]), F(K.init_pos[1]), F(K.init_pos[2])};
   L.qx = F(0.0f); L.qy = F(0.0f); L.qz = F(0.0f); L.qw = F(1.0f);
@@ -619,6 +618,15 @@ ETG_HD void reset_row16(const Ctx& c, const KCfg& K, State16<F>& L, float* ring,
     ring_push16(c, ring, tick & (RING - 1), L);
   }
   L.energy = F(0.0f);
+}
+// everything of a reset that comes after the settle: control-loop state, episode accumulators, first observation.
+// L and the ring are the settled ones -- freshly computed, or restored from the per-robot settle cache.
+template <class F, class Ctx>
+ETG_HD void reset_finish16(const Ctx& c, const KCfg& K, State16<F>& L, float* ring, float* ctl, int* ictl, float* legctl,
+                           const float* etgp, float* obs) {
+  const F pose = c.jointf() * c.par_joint(PR_POSE);
+  const int tick = K.settle_ticks;
+  L.energy = F(0.0f);
   c.st_env_i(ictl, IC_STEP, 0);
   c.st_env_i(ictl, IC_TICK, tick);
   c.st_env_i(ictl, IC_HAS_LAST, 0);
@@ -632,6 +640,12 @@ ETG_HD void reset_row16(const Ctx& c, const KCfg& K, State16<F>& L, float* ring,
   F imu[6];
   F etg = etg_action16<F>(c, K, etgp, 0.0f);
   write_obs16(c, K, L, ring, tick, ctl, etg, L.p.x, L.p.y, L.p.z, true, obs, imu);
+}
+template <class F, class Ctx>
+ETG_HD void reset_row16(const Ctx& c, const KCfg& K, State16<F>& L, float* ring, float* ctl, int* ictl, float* legctl,
+                        const float* etgp, float* obs) {
+  reset_settle16(c, K, L, ring);
+  reset_finish16(c, K, L, ring, ctl, ictl, legctl, etgp, obs);
 }
 
 }  // namespace etg

@@ -131,6 +131,7 @@ __global__ void __launch_bounds__(BLOCK) k_set_params(KCfg K, ModelF M, DevState
   if (!make_ctx(K, c)) return;
   if (mask && !mask[c.env]) return;
   if (dyn) {
+    if (c.lane == 0) D.cache_ok[c.env] = 0;   // the settle depends on the dynamic parameters
     float row[ETG_DYN_DIM], out[PR_N];
     for (int k = 0; k < ETG_DYN_DIM; k++) row[k] = dyn[(size_t)c.env * ETG_DYN_DIM + k];
     derive_lane_params(M, row, c.lane, K.dt, out);
@@ -142,15 +143,66 @@ __global__ void __launch_bounds__(BLOCK) k_set_params(KCfg K, ModelF M, DevState
   if (b && c.lane < 3) D.etgp[(size_t)(EP_B + c.lane) * c.N + c.env] = b[(per_env ? (size_t)c.env * 3 : 0) + c.lane];
 }
 
+// ---- reset = settle (only for robots without a valid settle cache) -> restore from the cache -> finish
+// copy this lane's 8 ring words of all slots and its leg column between the live arrays and the cache
+__device__ __forceinline__ void copy_leg_column(const DevState& D, size_t col, size_t NL, bool to_cache) {
+  const float* src_leg = to_cache ? D.leg : D.cache_leg;
+  float* dst_leg = to_cache ? D.cache_leg : D.leg;
+  for (int f = 0; f < LG_N; f++) dst_leg[(size_t)f * NL + col] = src_leg[(size_t)f * NL + col];
+  const float* src = to_cache ? D.ring : D.cache_ring;
+  float* dst = to_cache ? D.cache_ring : D.ring;
+  for (int w = 0; w < RING * 8; w++) dst[(size_t)w * NL + col] = src[(size_t)w * NL + col];
+}
+__device__ __forceinline__ void copy_base_column(const DevState& D, int env, int N, bool to_cache) {
+  const float* src = to_cache ? D.base : D.cache_base;
+  float* dst = to_cache ? D.cache_base : D.base;
+  for (int f = 0; f < BS_N; f++) dst[(size_t)f * N + env] = src[(size_t)f * N + env];
+}
+
 template <bool FLAT>
-__global__ void __launch_bounds__(BLOCK) k_reset(KCfg K, DevState D, const uint8_t* mask, float* obs) {
+__global__ void __launch_bounds__(BLOCK) k_settle(KCfg K, DevState D, const uint8_t* mask) {
+  GpuCtxT<FLAT> c;
+  if (!make_ctx(K, c)) return;
+  if ((mask && !mask[c.env]) || D.cache_ok[c.env]) return;   // whole quads drop out together
+  __shared__ float lds_par[PR_N * BLOCK];
+  stage_params(c, D, lds_par);
+  LaneState<float> L;
+  reset_settle(c, K, L, D.ring);
+  store_state(c, D.cache_base, D.cache_leg, L);              // the ring is copied by k_cache_ring (needs the stores done)
+  store_state(c, D.base, D.leg, L);
+}
+
+// one thread per leg column: after a settle, snapshot the ring into the cache and mark the robot cached;
+// for every masked robot, bring state + ring back from the cache
+__global__ void __launch_bounds__(256) k_cache_sync(KCfg K, DevState D, const uint8_t* mask) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = K.n_env, NL = 4 * N;
+  if (col >= NL) return;
+  const int env = col >> 2;
+  if (mask && !mask[env]) return;
+  if (!D.cache_ok[env]) {   // just settled by k_settle: live arrays -> cache (ring only; state was stored to both)
+    for (int w = 0; w < RING * 8; w++) D.cache_ring[(size_t)w * NL + col] = D.ring[(size_t)w * NL + col];
+  } else {                  // cached: cache -> live arrays
+    copy_leg_column(D, col, NL, false);
+    if ((col & 3) == 0) copy_base_column(D, env, N, false);
+  }
+}
+__global__ void __launch_bounds__(256) k_cache_mark(KCfg K, DevState D, const uint8_t* mask) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= K.n_env) return;
+  if (mask && !mask[env]) return;
+  D.cache_ok[env] = 1;
+}
+
+template <bool FLAT>
+__global__ void __launch_bounds__(BLOCK) k_finish(KCfg K, DevState D, const uint8_t* mask, float* obs) {
   GpuCtxT<FLAT> c;
   if (!make_ctx(K, c)) return;
   if (mask && !mask[c.env]) return;
   __shared__ float lds_par[PR_N * BLOCK];
   stage_params(c, D, lds_par);
-  LaneState<float> L;
-  reset_quad(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, obs);
+  LaneState<float> L = load_state<float>(c, D.base, D.leg);
+  reset_finish(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, obs);
   store_state(c, D.base, D.leg, L);
 }
 
@@ -333,13 +385,25 @@ __device__ __forceinline__ bool make_ctx16(const KCfg& K, const DevState& D, Gpu
 }
 
 template <bool FLAT>
-__global__ void __launch_bounds__(BLOCK) k_reset16(KCfg K, DevState D, const uint8_t* mask, float* obs) {
+__global__ void __launch_bounds__(BLOCK) k_settle16(KCfg K, DevState D, const uint8_t* mask) {
+  __shared__ float lds_par[LDS16_FIELDS * BLOCK];
+  GpuCtx16T<FLAT> c;
+  if (!make_ctx16(K, D, c, lds_par)) return;
+  if ((mask && !mask[c.env]) || D.cache_ok[c.env]) return;   // whole rows drop out together
+  State16<float> L;
+  reset_settle16(c, K, L, D.ring);
+  store_state16(c, D.cache_base, D.cache_leg, L);
+  store_state16(c, D.base, D.leg, L);
+}
+
+template <bool FLAT>
+__global__ void __launch_bounds__(BLOCK) k_finish16(KCfg K, DevState D, const uint8_t* mask, float* obs) {
   __shared__ float lds_par[LDS16_FIELDS * BLOCK];
   GpuCtx16T<FLAT> c;
   if (!make_ctx16(K, D, c, lds_par)) return;
   if (mask && !mask[c.env]) return;
-  State16<float> L;
-  reset_row16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, obs);
+  State16<float> L = load_state16<float>(c, D.base, D.leg);
+  reset_finish16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, obs);
   store_state16(c, D.base, D.leg, L);
 }
 
@@ -378,6 +442,43 @@ __global__ void k_set_fext(KCfg K, DevState D, const float* force) {
   for (int k = 0; k < 3; k++) D.ctl[(size_t)(CT_FEXT + k) * K.n_env + i] = force[(size_t)i * 3 + k];
 }
 
+// counter-based uniform in [0,1): a 64-bit mix (splitmix64 finaliser) of (seed, robot, call, stream)
+__device__ __forceinline__ float push_uniform(unsigned long long seed, unsigned env, unsigned long long call, unsigned k) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (((unsigned long long)env << 32 | k) + 0xD1B54A32D192ED03ull * (call + 1));
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (float)(z >> 40) * (1.0f / 16777216.0f);
+}
+__global__ void k_random_pushes(KCfg K, DevState D, unsigned long long seed, unsigned long long call, float prob, int duration,
+                                float fmin, float fmax) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = K.n_env;
+  if (i >= N) return;
+  int left = D.ictl[(size_t)IC_PUSH_LEFT * N + i];
+  float fx = D.ctl[(size_t)(CT_FEXT + 0) * N + i], fy = D.ctl[(size_t)(CT_FEXT + 1) * N + i];
+  if (left > 0) {
+    left--;
+    if (left == 0) { fx = 0.0f; fy = 0.0f; }
+  } else if (push_uniform(seed, i, call, 0) < prob) {
+    const float ang = 6.283185307179586f * push_uniform(seed, i, call, 1);
+    const float mag = fmin + (fmax - fmin) * push_uniform(seed, i, call, 2);
+    fx = mag * cosf(ang); fy = mag * sinf(ang);
+    left = duration;
+  }
+  D.ictl[(size_t)IC_PUSH_LEFT * N + i] = left;
+  D.ctl[(size_t)(CT_FEXT + 0) * N + i] = fx;
+  D.ctl[(size_t)(CT_FEXT + 1) * N + i] = fy;
+  D.ctl[(size_t)(CT_FEXT + 2) * N + i] = 0.0f;
+}
+__global__ void k_clear_pushes(KCfg K, DevState D, const uint8_t* mask) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = K.n_env;
+  if (i >= N || (mask && !mask[i])) return;
+  D.ictl[(size_t)IC_PUSH_LEFT * N + i] = 0;
+  for (int k = 0; k < 3; k++) D.ctl[(size_t)(CT_FEXT + k) * N + i] = 0.0f;
+}
+
 // copy out the per-robot episode accumulators (return, length) kept in ctl[]
 __global__ void k_episode_stats(KCfg K, DevState D, float* ret, int* len) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -413,6 +514,7 @@ struct EtgHandle {
   DevState D;
   float* hf;
   int lanes;                    // 4 or 16 lanes per robot (EtgConfig.lanes_per_robot)
+  unsigned long long push_calls;  // stream position of etg_random_pushes
   float *tmp_obs, *tmp_reward;  // sinks for etg_rollout_openloop
   uint8_t* tmp_done;
 };
@@ -451,6 +553,7 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   h->K = make_kcfg(*cfg, *model);
   h->M = make_modelf(*model);
   h->hf = nullptr;
+  h->push_calls = 0;
   if (cfg->lanes_per_robot != 0 && cfg->lanes_per_robot != 4 && cfg->lanes_per_robot != 16) {
     delete h;
     return fail(ETG_ERR_BAD_ARG, "etg_create: lanes_per_robot must be 4 or 16");
@@ -464,6 +567,8 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
       {(void**)&h->D.base, BS_N * N * 4},   {(void**)&h->D.leg, LG_N * NL * 4},   {(void**)&h->D.ctl, CT_N * N * 4},
       {(void**)&h->D.ictl, IC_N * N * 4},   {(void**)&h->D.legctl, LC_N * NL * 4}, {(void**)&h->D.etgp, EP_N * N * 4},
       {(void**)&h->D.par, PR_N * NL * 4},   {(void**)&h->D.ring, (size_t)RING * 8 * NL * 4},
+      {(void**)&h->D.cache_base, BS_N * N * 4}, {(void**)&h->D.cache_leg, LG_N * NL * 4},
+      {(void**)&h->D.cache_ring, (size_t)RING * 8 * NL * 4}, {(void**)&h->D.cache_ok, N},
       {(void**)&h->tmp_obs, ETG_OBS_DIM * N * 4}, {(void**)&h->tmp_reward, N * 4}, {(void**)&h->tmp_done, N}};
   for (auto& a : allocs) {
     if (hipMalloc(a.p, a.bytes) != hipSuccess) return fail(ETG_ERR_ALLOC, "etg_create: hipMalloc failed");
@@ -490,6 +595,7 @@ extern "C" void etg_destroy(EtgHandle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   void* ptrs[] = {h->D.base, h->D.leg, h->D.ctl, h->D.ictl, h->D.legctl, h->D.etgp, h->D.par, h->D.ring, h->hf,
+                  h->D.cache_base, h->D.cache_leg, h->D.cache_ring, h->D.cache_ok,
                   h->tmp_obs, h->tmp_reward, h->tmp_done};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -516,6 +622,7 @@ extern "C" int etg_set_heightfield(EtgHandle* h, const float* heights, void* str
   size_t bytes = (size_t)h->K.hf_nx * h->K.hf_ny * h->K.hf_bands * 4;
   if (!h->hf && hipMalloc((void**)&h->hf, bytes) != hipSuccess) return fail(ETG_ERR_ALLOC, "etg_set_heightfield: hipMalloc failed");
   HIP_TRY(hipMemcpyAsync(h->hf, heights, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  HIP_TRY(hipMemsetAsync(h->D.cache_ok, 0, h->N, (hipStream_t)stream));   // the settle depends on the terrain
   h->K.hf = h->hf;
   return ETG_OK;
 }
@@ -534,20 +641,50 @@ extern "C" int etg_set_external_force(EtgHandle* h, const float* force, void* st
   return ETG_OK;
 }
 
+extern "C" int etg_random_pushes(EtgHandle* h, uint64_t seed, float prob, int duration_steps, float fmin, float fmax,
+                                 void* stream) {
+  CHECK_HANDLE(h);
+  if (prob < 0.0f || duration_steps < 1 || fmax < fmin) return fail(ETG_ERR_BAD_ARG, "etg_random_pushes: bad arguments");
+  hipLaunchKernelGGL(k_random_pushes, dim3((h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->D,
+                     (unsigned long long)seed, h->push_calls++, prob, duration_steps, fmin, fmax);
+  HIP_TRY(hipGetLastError());
+  h->K.ext_force = 1;
+  return ETG_OK;
+}
+
+extern "C" int etg_clear_pushes(EtgHandle* h, const uint8_t* mask, void* stream) {
+  CHECK_HANDLE(h);
+  hipLaunchKernelGGL(k_clear_pushes, dim3((h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->D, mask);
+  HIP_TRY(hipGetLastError());
+  return ETG_OK;
+}
+
 extern "C" int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* stream) {
   CHECK_HANDLE(h);
   if (!obs) return fail(ETG_ERR_BAD_ARG, "etg_reset: obs is null");
   if (h->K.terrain == 1 && !h->K.hf) return fail(ETG_ERR_STATE, "etg_reset: heightfield not set");
-  const dim3 g16((h->N + 3) / 4);
+  // 1. settle the masked robots that have no valid settle cache (kernel exits at once for the others)
+  // 2. snapshot their ring / restore state + ring of the cached ones, mark everything masked as cached
+  // 3. the part after the settle: control state, episode accumulators, first observation
+  const dim3 g16((h->N + 3) / 4), g4(grid_for(h)), gc((4 * h->N + 255) / 256), ge((h->N + 255) / 256);
+  hipStream_t s = (hipStream_t)stream;
+  const bool flat = h->K.terrain == 0;
   if (h->lanes == 16) {
-    if (h->K.terrain == 0)
-      hipLaunchKernelGGL(k_reset16<true>, g16, dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, mask, obs);
-    else
-      hipLaunchKernelGGL(k_reset16<false>, g16, dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, mask, obs);
-  } else if (h->K.terrain == 0)
-    hipLaunchKernelGGL(k_reset<true>, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, mask, obs);
-  else
-    hipLaunchKernelGGL(k_reset<false>, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, mask, obs);
+    if (flat) hipLaunchKernelGGL(k_settle16<true>, g16, dim3(BLOCK), 0, s, h->K, h->D, mask);
+    else hipLaunchKernelGGL(k_settle16<false>, g16, dim3(BLOCK), 0, s, h->K, h->D, mask);
+  } else {
+    if (flat) hipLaunchKernelGGL(k_settle<true>, g4, dim3(BLOCK), 0, s, h->K, h->D, mask);
+    else hipLaunchKernelGGL(k_settle<false>, g4, dim3(BLOCK), 0, s, h->K, h->D, mask);
+  }
+  hipLaunchKernelGGL(k_cache_sync, gc, dim3(256), 0, s, h->K, h->D, mask);
+  hipLaunchKernelGGL(k_cache_mark, ge, dim3(256), 0, s, h->K, h->D, mask);
+  if (h->lanes == 16) {
+    if (flat) hipLaunchKernelGGL(k_finish16<true>, g16, dim3(BLOCK), 0, s, h->K, h->D, mask, obs);
+    else hipLaunchKernelGGL(k_finish16<false>, g16, dim3(BLOCK), 0, s, h->K, h->D, mask, obs);
+  } else {
+    if (flat) hipLaunchKernelGGL(k_finish<true>, g4, dim3(BLOCK), 0, s, h->K, h->D, mask, obs);
+    else hipLaunchKernelGGL(k_finish<false>, g4, dim3(BLOCK), 0, s, h->K, h->D, mask, obs);
+  }
   HIP_TRY(hipGetLastError());
   return ETG_OK;
 }

@@ -32,7 +32,8 @@ enum { LG_Q = 0, LG_QD = 3, LG_LAM = 6, LG_CONTACT = 9, LG_N = 10 };
 // CT_RET/LEN/ALIVE: per-robot episode accumulators (return, length, alive mask) updated by every step
 // CT_FEXT: external force on the trunk COM (world frame, N), etg_set_external_force()
 enum { CT_FIRST_RPY = 0, CT_LAST_BASE = 3, CT_RET = 6, CT_LEN = 7, CT_ALIVE = 8, CT_FEXT = 9, CT_N = 12 };
-enum { IC_STEP = 0, IC_TICK = 1, IC_HAS_LAST = 2, IC_N = 3 };
+// IC_PUSH_LEFT: control steps the current random push still lasts (etg_random_pushes)
+enum { IC_STEP = 0, IC_TICK = 1, IC_HAS_LAST = 2, IC_PUSH_LEFT = 3, IC_N = 4 };
 enum { LC_LAST_QDES = 0, LC_FX0 = 3, LC_FX1 = 6, LC_FY0 = 9, LC_FY1 = 12, LC_LAST_FOOT_X = 15, LC_N = 16 };
 enum { EP_W = 0, EP_B = 60, EP_N = 63 };
 // per-lane derived parameters, in the order derive_lane_params() writes them
@@ -62,6 +63,11 @@ struct KCfg {
 struct DevState {
   float *base, *leg, *ctl, *legctl, *etgp, *par, *ring;
   int* ictl;
+  // settle cache: the state (base, leg) and latency ring right after the 500-tick reset settle of each robot.
+  // The settle only depends on the robot's dynamic parameters and terrain, so a later reset of the same robot
+  // copies it back instead of re-simulating (cache_ok[env]; cleared when its dyn row or the heightfield changes).
+  float *cache_base, *cache_leg, *cache_ring;
+  unsigned char* cache_ok;
 };
 
 // ---- float lane math ------------------------------------------------------------

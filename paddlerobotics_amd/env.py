@@ -81,6 +81,40 @@ def _ptr(t):
     return None if t is None else C.c_void_p(t.data_ptr())
 
 
+class _InfoView(dict):
+    """info dict of a step: the keys callers read (train.py:150-156, env_test.py:54, Dynamic_parallel_model.py:63-64)
+    as [N] / [N,k] views of the one device buffer the kernel filled.  The views are made on first access -- building
+    all 14 of them eagerly costs more host time per step than the step kernel takes."""
+
+    def __init__(self, buf):
+        super().__init__()
+        self._buf = buf
+
+    def __missing__(self, key):
+        a, b = A.INFO_SLICES[key]
+        v = self._buf[:, a] if b - a == 1 else self._buf[:, a:b]
+        self[key] = v
+        return v
+
+    def __contains__(self, key):
+        return key in A.INFO_SLICES
+
+    def get(self, key, default=None):
+        return self[key] if key in A.INFO_SLICES else default
+
+    def keys(self):
+        return A.INFO_SLICES.keys()
+
+    def items(self):
+        return [(k, self[k]) for k in A.INFO_SLICES]
+
+    def __iter__(self):
+        return iter(A.INFO_SLICES)
+
+    def __len__(self):
+        return len(A.INFO_SLICES)
+
+
 class BatchedQuadrupedEnv:
     def __init__(self, num_envs=1, device="cuda:0", task="ground", motor_control_mode=None, render=False,
                  sensor_mode=None, normal=1, dynamic_param=None, reward_param=None, ETG=1, ETG_T=0.5,
@@ -154,10 +188,8 @@ class BatchedQuadrupedEnv:
         self.info_buf = torch.zeros(N, A.INFO_DIM, device=dev)
         self._zero_action = torch.zeros(N, A.NUM_MOTORS, device=dev)
         self._col_idx = None if len(self._cols) == A.OBS_DIM else torch.tensor(self._cols, device=dev)
-        self._gen = torch.Generator(device=dev)
-        self._gen.manual_seed(int(seed))
-        self._force = torch.zeros(N, 3, device=dev)
-        self._force_left = torch.zeros(N, dtype=torch.int32, device=dev)
+        self._push_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._dyn_stage = self._dyn_dev = self._dyn_evt = None
         self._hf = None
         if heightfield is not None:
             self._hf = torch.as_tensor(np.ascontiguousarray(heightfield["heights"], dtype=np.float32), device=dev)
@@ -225,11 +257,29 @@ class BatchedQuadrupedEnv:
         or an [N,48] tensor/array of rows (one per robot)."""
         if isinstance(dynamic_param, dict):
             dynamic_param = A.dynamic_dict_to_row(dynamic_param)
-        t = torch.as_tensor(np.asarray(dynamic_param) if not torch.is_tensor(dynamic_param) else dynamic_param,
-                            dtype=torch.float32, device=self.device)
-        if t.dim() == 1:
-            t = t.unsqueeze(0).expand(self.num_envs, -1)
-        t = t.contiguous()
+        if torch.is_tensor(dynamic_param) and dynamic_param.device.type == "cuda":
+            t = dynamic_param.to(device=self.device, dtype=torch.float32)
+            if t.dim() == 1:
+                t = t.unsqueeze(0).expand(self.num_envs, -1)
+            t = t.contiguous()
+        else:
+            # host rows go through ONE persistent pinned staging buffer: a fresh pageable->device copy makes the
+            # runtime allocate pinned staging memory now and then (50-90 ms a time, measured)
+            rows = np.asarray(dynamic_param.cpu() if torch.is_tensor(dynamic_param) else dynamic_param, dtype=np.float32)
+            if rows.ndim == 1:
+                rows = np.broadcast_to(rows, (self.num_envs, rows.shape[0]))
+            if rows.shape != (self.num_envs, A.DYN_DIM):
+                raise ValueError("dynamic_param rows must be [N,48]")
+            if self._dyn_stage is None:
+                self._dyn_stage = torch.empty(self.num_envs, A.DYN_DIM, dtype=torch.float32, pin_memory=True)
+                self._dyn_dev = torch.empty(self.num_envs, A.DYN_DIM, dtype=torch.float32, device=self.device)
+                self._dyn_evt = torch.cuda.Event()
+            else:
+                self._dyn_evt.synchronize()                   # the previous upload has left the staging buffer
+            self._dyn_stage.numpy()[...] = rows
+            self._dyn_dev.copy_(self._dyn_stage, non_blocking=True)
+            self._dyn_evt.record(torch.cuda.current_stream(self.device))
+            t = self._dyn_dev
         if tuple(t.shape) != (self.num_envs, A.DYN_DIM):
             raise ValueError("dynamic_param rows must be [N,48]")
         m = self._mask(env_ids)
@@ -238,8 +288,7 @@ class BatchedQuadrupedEnv:
 
     # ---- Gym surface -----------------------------------------------------------
     def _info(self):
-        d = {k: (self.info_buf[:, a] if b - a == 1 else self.info_buf[:, a:b]) for k, (a, b) in A.INFO_SLICES.items()}
-        return d
+        return _InfoView(self.info_buf)
 
     def reset(self, env_ids=None, ETG_w=None, ETG_b=None, dynamic_param=None, x_noise=0, hardset=False, **kwargs):
         if ETG_w is not None:
@@ -250,13 +299,10 @@ class BatchedQuadrupedEnv:
             # random_param['random_dynamics'] (train.py:253): a fresh draw of the 48 dynamic parameters for
             # every robot being reset, param2dynamic_dict(U(-1,1) * scale) (train.py:112-126)
             rows = A.param2dynamic_rows(self._np_rng.uniform(-1, 1, size=(self.num_envs, A.DYN_DIM)) * self._rand_dyn_scale)
-            self.set_dynamic_param(rows, env_ids)
+            self.set_dynamic_param(rows, env_ids)          # masked: only the robots being reset take their row
         m = self._mask(env_ids)
         if self._rand_force:
-            keep = torch.ones(self.num_envs, dtype=torch.bool, device=self.device) if m is None else ~m.bool()
-            self._force_left *= keep.to(torch.int32)
-            self._force *= keep.unsqueeze(1).float()
-            _lib.check(self._lib.etg_set_external_force(self._h, _ptr(self._force), self._stream()))
+            _lib.check(self._lib.etg_clear_pushes(self._h, _ptr(m), self._stream()))
         _lib.check(self._lib.etg_reset(self._h, _ptr(m), _ptr(self.obs), self._stream()))
         info = {"ETG_act": None}
         return self._obs_view(), info
@@ -269,22 +315,15 @@ class BatchedQuadrupedEnv:
         if force is None:
             _lib.check(self._lib.etg_set_external_force(self._h, None, self._stream()))
             return
-        self._force = self._f32(force, (self.num_envs, 3), "force").clone()
+        self._force = self._f32(force, (self.num_envs, 3), "force").clone()   # kept alive until the copy ran
         _lib.check(self._lib.etg_set_external_force(self._h, _ptr(self._force), self._stream()))
 
     def _random_pushes(self):
-        """random_param['random_force'] (train.py:254; rlschool's schedule is absent, this one is ours): each
-        step an idle robot starts, with probability p, a push of `steps` control steps with a horizontal
-        force of U(range) newtons in a uniform direction.  All on device, no host sync."""
-        N, dev, g = self.num_envs, self.device, self._gen
-        start = (torch.rand(N, device=dev, generator=g) < self._rf_prob) & (self._force_left == 0)
-        ang = torch.rand(N, device=dev, generator=g) * (2 * np.pi)
-        mag = self._rf_range[0] + (self._rf_range[1] - self._rf_range[0]) * torch.rand(N, device=dev, generator=g)
-        new = torch.stack([mag * torch.cos(ang), mag * torch.sin(ang), torch.zeros_like(mag)], dim=1)
-        self._force_left = torch.where(start, torch.full_like(self._force_left, self._rf_steps),
-                                       torch.clamp(self._force_left - 1, min=0))
-        self._force = torch.where(start.unsqueeze(1), new, self._force) * (self._force_left > 0).unsqueeze(1).float()
-        _lib.check(self._lib.etg_set_external_force(self._h, _ptr(self._force), self._stream()))
+        """random_param['random_force'] (train.py:254): one tiny kernel per control step samples / expires the
+        pushes on the device (include/etgsim.h: etg_random_pushes)."""
+        _lib.check(self._lib.etg_random_pushes(self._h, C.c_uint64(self._push_seed), C.c_float(self._rf_prob),
+                                               int(self._rf_steps), C.c_float(self._rf_range[0]),
+                                               C.c_float(self._rf_range[1]), self._stream()))
 
     def step(self, action, donef=None, want_info=True):
         a = self._zero_action if action is None else self._f32(action, (self.num_envs, A.NUM_MOTORS), "action")
@@ -301,7 +340,7 @@ class BatchedQuadrupedEnv:
         _lib.check(self._lib.etg_step(self._h, _ptr(a), _ptr(df), _ptr(self.obs), _ptr(self.reward), _ptr(self.done),
                                       _ptr(self.info_buf) if want_info else None, self._stream()))
         self._keep_step = (a, df)
-        return (self._obs_view(), self.reward, self.done.bool() if want_info else self.done,
+        return (self._obs_view(), self.reward, self.done.view(torch.bool) if want_info else self.done,
                 (self._info() if want_info else {}))
 
     def rollout_openloop(self, n_steps):
