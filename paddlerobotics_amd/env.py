@@ -186,10 +186,10 @@ class BatchedQuadrupedEnv:
         self.reward = torch.zeros(N, device=dev)
         self.done = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.info_buf = torch.zeros(N, A.INFO_DIM, device=dev)
-        self._zero_action = torch.zeros(N, A.NUM_MOTORS, device=dev)
         self._col_idx = None if len(self._cols) == A.OBS_DIM else torch.tensor(self._cols, device=dev)
         self._push_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self._dyn_stage = self._dyn_dev = self._dyn_evt = None
+        self._all_done = None
         self._hf = None
         if heightfield is not None:
             self._hf = torch.as_tensor(np.ascontiguousarray(heightfield["heights"], dtype=np.float32), device=dev)
@@ -326,11 +326,14 @@ class BatchedQuadrupedEnv:
                                                C.c_float(self._rf_range[1]), self._stream()))
 
     def step(self, action, donef=None, want_info=True):
-        a = self._zero_action if action is None else self._f32(action, (self.num_envs, A.NUM_MOTORS), "action")
+        a = None if action is None else self._f32(action, (self.num_envs, A.NUM_MOTORS), "action")   # NULL = zero residual
         df = None
         if donef is not None:
             if isinstance(donef, (bool, int, np.bool_)):
-                df = torch.full((self.num_envs,), int(bool(donef)), dtype=torch.uint8, device=self.device)
+                if bool(donef):                               # False is the same as no donef at all
+                    if self._all_done is None:
+                        self._all_done = torch.ones(self.num_envs, dtype=torch.uint8, device=self.device)
+                    df = self._all_done
             else:
                 df = torch.as_tensor(donef, device=self.device).to(torch.uint8).contiguous()
                 if tuple(df.shape) != (self.num_envs,):
