@@ -56,9 +56,10 @@ __global__ void k_pack_weights(const float* __restrict__ w, int nout, int kdim, 
 }
 
 // out[16][this wave's 64 columns] = relu(in[16][16*nkb] * W^T + b); wp = packed weights of the layer
-template <bool BF16>
-__device__ __forceinline__ void hidden_layer(const float* in, int nkb, const float4* __restrict__ wp, const float* b,
+template <bool BF16, int NKB>
+__device__ __forceinline__ void hidden_layer(const float* in, const float4* __restrict__ wp, const float* b,
                                              float* out, int wave, int lane) {
+  constexpr int nkb = NKB;
   const int i = lane & 15, g = lane >> 4;
   f32x4 acc[4];
 #pragma unroll
@@ -68,15 +69,25 @@ __device__ __forceinline__ void hidden_layer(const float* in, int nkb, const flo
   const float4* base = wp + (size_t)(4 * wave) * nkb * 64 + lane;
   const int tstride = nkb * 64;
   if (!BF16) {
-    float4 w0[4], w1[4];
+    // weight fragments come from L2 (hundreds of ns) while one k-block is only 16 MFMAs (~0.2 us): keep PF
+    // k-blocks in flight in a register ring; the loop is fully unrolled so the ring indices are static
+    constexpr int PF = NKB < 3 ? NKB : 3;
+    float4 w[PF + 1][4];
 #pragma unroll
-    for (int t = 0; t < 4; t++) w0[t] = base[t * tstride];
+    for (int p = 0; p < PF; p++)
+#pragma unroll
+      for (int t = 0; t < 4; t++) w[p][t] = base[t * tstride + p * 64];
+    float4 av[2];   // the A fragment of the next k-block is read from LDS while this one's MFMAs issue
+    av[0] = *reinterpret_cast<const float4*>(&in[i * HS + 4 * g]);
+#pragma unroll
     for (int kb = 0; kb < nkb; kb++) {
-      const float4 a = *reinterpret_cast<const float4*>(&in[i * HS + kb * 16 + 4 * g]);
-      if (kb + 1 < nkb) {
+      const float4 a = av[kb & 1];
+      if (kb + 1 < nkb) av[(kb + 1) & 1] = *reinterpret_cast<const float4*>(&in[i * HS + (kb + 1) * 16 + 4 * g]);
+      if (kb + PF < nkb) {
 #pragma unroll
-        for (int t = 0; t < 4; t++) w1[t] = base[t * tstride + (kb + 1) * 64];
+        for (int t = 0; t < 4; t++) w[(kb + PF) % (PF + 1)][t] = base[t * tstride + (kb + PF) * 64];
       }
+      const float4* w0 = w[kb % (PF + 1)];
       // k-component outer, tile inner: 4 independent accumulators back to back, so the 40-cycle
       // dependent-accumulator latency of v_mfma_f32_16x16x4_f32 never stalls the 32-cycle issue
 #pragma unroll
@@ -87,8 +98,6 @@ __device__ __forceinline__ void hidden_layer(const float* in, int nkb, const flo
       for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w0[t].z, acc[t], 0, 0, 0);
 #pragma unroll
       for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w0[t].w, acc[t], 0, 0, 0);
-#pragma unroll
-      for (int t = 0; t < 4; t++) w0[t] = w1[t];
     }
   } else {
     // one bf16 MFMA (K = 32) consumes two consecutive 16-wide k-blocks; the k-slot order is free as
@@ -139,9 +148,9 @@ __global__ void __launch_bounds__(THREADS) k_policy(const float* __restrict__ ob
     bufA[r * HS + c] = v;
   }
   __syncthreads();
-  hidden_layer<BF16>(bufA, 4, w1p, b1, bufB, wave, lane);       // K padded to 64 = 4 k-blocks
+  hidden_layer<BF16, 4>(bufA, w1p, b1, bufB, wave, lane);        // K padded to 64 = 4 k-blocks
   __syncthreads();
-  hidden_layer<BF16>(bufB, HID / 16, w2p, b2, bufA, wave, lane);
+  hidden_layer<BF16, HID / 16>(bufB, w2p, b2, bufA, wave, lane);
   __syncthreads();
   // output layer: one 16x16 tile per head (out_dim <= 16), K split over the 4 waves (4 k-blocks each)
 #pragma unroll
