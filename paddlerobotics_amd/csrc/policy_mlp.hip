@@ -4,7 +4,7 @@
 // (predict = tanh(mean)), train.py:320 (act_bound scaling).  Weights keep torch's
 // [out, in] row-major fp32 layout (mujoco_agent.py:61-65 state_dict keys l1/l2/mean_linear).
 //
-// One launch fuses the three layers.  A workgroup (4 waves) owns 16 consecutive robots;
+// One launch fuses the three layers.  A workgroup (NW waves, 16 by default) owns 16 consecutive robots;
 // its activations (16 x 256 fp32) never leave LDS; the 327 KB of weights are streamed
 // from L2 (they are shared by all workgroups and stay L2/MALL-resident).  At 4096 robots
 // that is 256 workgroups = one per CU.
@@ -25,7 +25,13 @@ namespace {
 constexpr int TM = 16;         // robots per workgroup
 constexpr int HID = 256;       // hidden width (Actor: 256)
 constexpr int HS = HID + 4;    // LDS row stride in floats: rotates 16-B slots by one per row
-constexpr int THREADS = 256;
+#ifndef ETG_POLICY_WAVES
+#define ETG_POLICY_WAVES 16   // measured at 4096 rows: 4 waves 10.6 us, 8 waves 10.1 us, 16 waves 9.5 us (fp32)
+#endif
+constexpr int NW = ETG_POLICY_WAVES;          // waves per workgroup
+constexpr int TPW = (HID / 16) / NW;  // 16-column output tiles per wave in the hidden layers
+constexpr int KPW = (HID / 16) / NW;  // k-blocks per wave in the K-split output layer
+constexpr int THREADS = 64 * NW;
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -61,22 +67,22 @@ __device__ __forceinline__ void hidden_layer(const float* in, const float4* __re
                                              float* out, int wave, int lane) {
   constexpr int nkb = NKB;
   const int i = lane & 15, g = lane >> 4;
-  f32x4 acc[4];
+  f32x4 acc[TPW];
 #pragma unroll
-  for (int t = 0; t < 4; t++) acc[t] = {0.f, 0.f, 0.f, 0.f};
-  // tile t of this wave: packed block ((4*wave + t) * nkb + kb); software-pipelined: the next k-block's
+  for (int t = 0; t < TPW; t++) acc[t] = {0.f, 0.f, 0.f, 0.f};
+  // tile t of this wave: packed block ((TPW*wave + t) * nkb + kb); software-pipelined: the next k-block's
   // fragments are in flight while the MFMAs of the current one issue
-  const float4* base = wp + (size_t)(4 * wave) * nkb * 64 + lane;
+  const float4* base = wp + (size_t)(TPW * wave) * nkb * 64 + lane;
   const int tstride = nkb * 64;
   if (!BF16) {
     // weight fragments come from L2 (hundreds of ns) while one k-block is only 16 MFMAs (~0.2 us): keep PF
     // k-blocks in flight in a register ring; the loop is fully unrolled so the ring indices are static
     constexpr int PF = NKB < 3 ? NKB : 3;
-    float4 w[PF + 1][4];
+    float4 w[PF + 1][TPW];
 #pragma unroll
     for (int p = 0; p < PF; p++)
 #pragma unroll
-      for (int t = 0; t < 4; t++) w[p][t] = base[t * tstride + p * 64];
+      for (int t = 0; t < TPW; t++) w[p][t] = base[t * tstride + p * 64];
     float4 av[2];   // the A fragment of the next k-block is read from LDS while this one's MFMAs issue
     av[0] = *reinterpret_cast<const float4*>(&in[i * HS + 4 * g]);
 #pragma unroll
@@ -85,19 +91,19 @@ __device__ __forceinline__ void hidden_layer(const float* in, const float4* __re
       if (kb + 1 < nkb) av[(kb + 1) & 1] = *reinterpret_cast<const float4*>(&in[i * HS + (kb + 1) * 16 + 4 * g]);
       if (kb + PF < nkb) {
 #pragma unroll
-        for (int t = 0; t < 4; t++) w[(kb + PF) % (PF + 1)][t] = base[t * tstride + (kb + PF) * 64];
+        for (int t = 0; t < TPW; t++) w[(kb + PF) % (PF + 1)][t] = base[t * tstride + (kb + PF) * 64];
       }
       const float4* w0 = w[kb % (PF + 1)];
       // k-component outer, tile inner: 4 independent accumulators back to back, so the 40-cycle
       // dependent-accumulator latency of v_mfma_f32_16x16x4_f32 never stalls the 32-cycle issue
 #pragma unroll
-      for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w0[t].x, acc[t], 0, 0, 0);
+      for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w0[t].x, acc[t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w0[t].y, acc[t], 0, 0, 0);
+      for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w0[t].y, acc[t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w0[t].z, acc[t], 0, 0, 0);
+      for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w0[t].z, acc[t], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < 4; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w0[t].w, acc[t], 0, 0, 0);
+      for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w0[t].w, acc[t], 0, 0, 0);
     }
   } else {
     // one bf16 MFMA (K = 32) consumes two consecutive 16-wide k-blocks; the k-slot order is free as
@@ -107,7 +113,7 @@ __device__ __forceinline__ void hidden_layer(const float* in, const float4* __re
       const float4 a1 = *reinterpret_cast<const float4*>(&in[i * HS + (kb + 1) * 16 + 4 * g]);
       const bf16x8 av = pack_bf16(a0, a1);
 #pragma unroll
-      for (int t = 0; t < 4; t++) {
+      for (int t = 0; t < TPW; t++) {
         const float4 b0 = base[t * tstride + kb * 64];
         const float4 b1 = base[t * tstride + (kb + 1) * 64];
         acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pack_bf16(b0, b1), acc[t], 0, 0, 0);
@@ -115,8 +121,8 @@ __device__ __forceinline__ void hidden_layer(const float* in, const float4* __re
     }
   }
 #pragma unroll
-  for (int t = 0; t < 4; t++) {
-    const int col = 64 * wave + 16 * t + i;
+  for (int t = 0; t < TPW; t++) {
+    const int col = 16 * TPW * wave + 16 * t + i;
     const float bias = b[col];
 #pragma unroll
     for (int r = 0; r < 4; r++) out[(4 * g + r) * HS + col] = fmaxf(acc[t][r] + bias, 0.0f);
@@ -137,7 +143,7 @@ __global__ void __launch_bounds__(THREADS) k_policy(const float* __restrict__ ob
                                                     float* __restrict__ act, float* __restrict__ logp) {
   __shared__ __attribute__((aligned(16))) float bufA[TM * HS];
   __shared__ __attribute__((aligned(16))) float bufB[TM * HS];
-  __shared__ float part[SAMPLE ? 2 : 1][4][TM][16];
+  __shared__ float part[SAMPLE ? 2 : 1][NW][TM][16];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int row0 = blockIdx.x * TM;
   // obs tile -> LDS, zero padded (rows past n, columns past in_dim up to the 64-wide padded K)
@@ -160,8 +166,8 @@ __global__ void __launch_bounds__(THREADS) k_policy(const float* __restrict__ ob
     const float4* base = (head == 0 ? w3p : w3sp) + lane;
     if (!BF16) {
 #pragma unroll
-      for (int kk = 0; kk < 4; kk++) {
-        const int kb = 4 * wave + kk;
+      for (int kk = 0; kk < KPW; kk++) {
+        const int kb = KPW * wave + kk;
         const float4 a = *reinterpret_cast<const float4*>(&bufA[i * HS + kb * 16 + 4 * g]);
         const float4 bw = base[kb * 64];
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bw.x, acc, 0, 0, 0);
@@ -170,9 +176,12 @@ __global__ void __launch_bounds__(THREADS) k_policy(const float* __restrict__ ob
         acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bw.w, acc, 0, 0, 0);
       }
     } else {
+      // one bf16 MFMA spans two 16-wide k-blocks: with KPW = 1 only the even waves work here (odd ones add zeros)
+      constexpr int KP = KPW < 2 ? 2 : KPW;
+      const bool active = (wave % (KP / KPW)) == 0;
 #pragma unroll
-      for (int kk = 0; kk < 4; kk += 2) {
-        const int kb = 4 * wave + kk;
+      for (int kk = 0; kk < (active ? KP : 0); kk += 2) {
+        const int kb = KPW * wave + kk;
         const float4 a0 = *reinterpret_cast<const float4*>(&bufA[i * HS + kb * 16 + 4 * g]);
         const float4 a1 = *reinterpret_cast<const float4*>(&bufA[i * HS + (kb + 1) * 16 + 4 * g]);
         acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pack_bf16(a0, a1), pack_bf16(base[kb * 64], base[(kb + 1) * 64]), acc,
@@ -184,13 +193,20 @@ __global__ void __launch_bounds__(THREADS) k_policy(const float* __restrict__ ob
   }
   __syncthreads();
   {
-    const int r = tid >> 4, cidx = tid & 15;  // 256 threads = 16 rows x 16 cols; a row = one 16-lane DPP row
+    const int r = tid >> 4, cidx = tid & 15;  // first 256 threads = 16 rows x 16 cols; a row = one 16-lane DPP row
+    if (r >= TM) return;
     const bool live = cidx < out_dim && row0 + r < n;
-    // fixed summation order over the 4 K-slices
-    float v = ((part[0][0][r][cidx] + part[0][1][r][cidx]) + (part[0][2][r][cidx] + part[0][3][r][cidx])) + (live ? b3[cidx] : 0.0f);
+    // fixed summation order over the NW K-slices
+    float v = 0.0f;
+#pragma unroll
+    for (int q = 0; q < NW; q += 2) v += part[0][q][r][cidx] + part[0][q + 1][r][cidx];
+    v += live ? b3[cidx] : 0.0f;
     float lp = 0.0f;
     if constexpr (SAMPLE) {
-      float ls = ((part[1][0][r][cidx] + part[1][1][r][cidx]) + (part[1][2][r][cidx] + part[1][3][r][cidx])) + (live ? b3s[cidx] : 0.0f);
+      float ls = 0.0f;
+#pragma unroll
+      for (int q = 0; q < NW; q += 2) ls += part[1][q][r][cidx] + part[1][q + 1][r][cidx];
+      ls += live ? b3s[cidx] : 0.0f;
       ls = fminf(fmaxf(ls, -20.0f), 2.0f);
       const float e = live ? eps[(size_t)(row0 + r) * out_dim + cidx] : 0.0f;
       v = v + expf(ls) * e;
