@@ -307,28 +307,36 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   const F mu = tp.mu;
   const F c0 = tgt * iA;
   const F tangf = f1 + f2;
+  // owner masks of the three rows of every leg, hoisted out of the sweeps (1 on the lane that owns row e of leg lp)
+  F mk[4][3], mt[4];
+#pragma unroll
+  for (int lp = 0; lp < 4; lp++) {
+    mk[lp][0] = ownl[lp] * f0; mk[lp][1] = ownl[lp] * f1; mk[lp][2] = ownl[lp] * f2;
+    mt[lp] = ownl[lp] * tangf;
+  }
   for (int it = 0; it < K.iters; it++) {
 #pragma unroll
     for (int lp = 0; lp < 4; lp++) {
-      // normal row: ln = max(0, lam - (u - tgt)/A)
+      // normal row: ln = max(0, lam - (u - tgt)/A); the owner's lam update sits between the candidate and its
+      // broadcast, where the DPP read needs two wait states anyway
       F dln = fmaxf_(zero, (lam + c0) - u * iA) - lam;
+      lam = lam + mk[lp][0] * dln;
       F b = c.rbcast(dln, 4 * lp);
       u = u + A[lp][0] * b;
-      lam = lam + (ownl[lp] * f0) * dln;
       // tangent rows, sequentially
       F dt1 = -(u * iA);
+      lam = lam + mk[lp][1] * dt1;
       b = c.rbcast(dt1, 4 * lp + 1);
       u = u + A[lp][1] * b;
-      lam = lam + (ownl[lp] * f1) * dt1;
       F dt2 = -(u * iA);
+      lam = lam + mk[lp][2] * dt2;
       b = c.rbcast(dt2, 4 * lp + 2);
       u = u + A[lp][2] * b;
-      lam = lam + (ownl[lp] * f2) * dt2;
       // projection of (lt1, lt2) on the friction disc mu * ln
       F lim = mu * c.qb(lam, 0);
       F oth = c.qswap12(lam);
       F sc = fminf_(one, lim * rsqrt_(fmaxf_(lam * lam + oth * oth, F(1e-30f))));
-      F dp = (ownl[lp] * tangf) * (lam * sc - lam);
+      F dp = mt[lp] * (lam * sc - lam);
       F b1 = c.rbcast(dp, 4 * lp + 1), b2 = c.rbcast(dp, 4 * lp + 2);
       u = u + A[lp][1] * b1 + A[lp][2] * b2;
       lam = lam + dp;
