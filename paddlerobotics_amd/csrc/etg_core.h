@@ -144,11 +144,13 @@ template <class F> ETG_HD void ldl6(F* s, F* dinv, F* dsq) {
   F d[6];
 #pragma unroll
   for (int j = 0; j < 6; j++) {
+    // t[k] = L_jk d_k once per (j, k): every term of row j and of the column below it is then a single FMA
+    F t[6];
     F dj = s[j * (j + 1) / 2 + j];
 #pragma unroll
     for (int k = 0; k < j; k++) {
-      F ljk = s[j * (j + 1) / 2 + k];
-      dj = dj - ljk * ljk * d[k];
+      t[k] = s[j * (j + 1) / 2 + k] * d[k];
+      dj = dj - s[j * (j + 1) / 2 + k] * t[k];
     }
     d[j] = dj;
     dinv[j] = rcp_(dj);
@@ -157,7 +159,7 @@ template <class F> ETG_HD void ldl6(F* s, F* dinv, F* dsq) {
     for (int i = j + 1; i < 6; i++) {
       F v = s[i * (i + 1) / 2 + j];
 #pragma unroll
-      for (int k = 0; k < j; k++) v = v - s[i * (i + 1) / 2 + k] * s[j * (j + 1) / 2 + k] * d[k];
+      for (int k = 0; k < j; k++) v = v - s[i * (i + 1) / 2 + k] * t[k];
       s[i * (i + 1) / 2 + j] = v * dinv[j];
     }
   }
