@@ -53,6 +53,20 @@ def etg_population(n, seed, device):
     return w.float(), b.float()
 
 
+def device_copy_bandwidth(dev, nbytes=1 << 30, reps=5):
+    """attainable HBM bandwidth on this box: device-to-device copy, read + write bytes per second"""
+    a = torch.empty(nbytes // 4, dtype=torch.float32, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize(dev)
+    return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3)
+
+
 def cpu_baseline(n_envs, steps, threads):
     """The CPU oracle (port of the path, fp64 like stock pybullet) on a bounded sample."""
     from oracle.oracle import OracleSim
@@ -193,6 +207,7 @@ def main():
                                  "1 VALU issue / 4 cycles; see DESIGN.md section 7"},
             "survivors": float((length == args.steps + args.warmup).float().mean().item()),
         }
+        out["roofline"]["hbm_copy_measured_GBps"] = device_copy_bandwidth(dev) / 1e9
         if not args.no_cpu_baseline:
             cores = os.cpu_count() or 1
             one = cpu_baseline(64, 60, 1)
