@@ -177,11 +177,23 @@ template <class F> ETG_HD void bwd6(const F* L, F* b) {  // b <- L^-T b
     for (int k = i + 1; k < 6; k++) b[i] = b[i] - L[k * (k + 1) / 2 + i] * b[k];
 }
 
+// per-lane constants of a physics tick, fetched from the LDS parameter column ONCE per kernel (the compiler
+// parks them in AGPRs): a lone wave per SIMD cannot hide the LDS latency of re-reading them every tick
+template <class F> struct TickPar4 { F kp[3], kd[3], sy, m0, mu, link[30]; V3<F> o1, gw; S3<F> I0s; };
+template <class F, class Ctx> ETG_HD TickPar4<F> load_tick_par4(const Ctx& c) {
+  TickPar4<F> t;
+  for (int j = 0; j < 3; j++) { t.kp[j] = c.par(PR_KP + j); t.kd[j] = c.par(PR_KD + j); }
+  t.sy = c.par(PR_SY); t.m0 = c.par(PR_M0); t.mu = c.par(PR_MU);
+  for (int k = 0; k < 30; k++) t.link[k] = c.par(PR_LINK + k);
+  t.o1 = par3<F>(c, PR_O1); t.gw = par3<F>(c, PR_G); t.I0s = par_s3<F>(c, PR_I0);
+  return t;
+}
+
 // ------------------------------------------------------------------ one physics tick
 // stepSimulation() + ApplyAction + ReceiveObservation of minitaur.py:242-246 for one quad.
 template <class F, class Ctx>
-ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* qdes, const V3<F>& fext_w,
-                         bool torque_cmd = false) {
+ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, LaneState<F>& L, const F* qdes,
+                         const V3<F>& fext_w, bool torque_cmd = false) {
   typedef V3<F> V;
   typedef SV<F> W;
   const F dt(K.dt), zero(0.0f), one(1.0f);
@@ -192,7 +204,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* 
   for (int j = 0; j < 3; j++) {
     F cmd = qdes[j];
     if (K.clip_cmd > 0.0f && !torque_cmd) cmd = fminf_(fmaxf_(cmd, L.q[j] - F(K.clip_cmd)), L.q[j] + F(K.clip_cmd));   // a1.py:439-457
-    F t = torque_cmd ? cmd : -(c.par(PR_KP + j) * (L.q[j] - cmd)) - c.par(PR_KD + j) * L.qd[j];   // TORQUE mode: pass-through
+    F t = torque_cmd ? cmd : -(tp.kp[j] * (L.q[j] - cmd)) - tp.kd[j] * L.qd[j];   // TORQUE mode: pass-through
     if (K.torque_limit > 0.0f) t = fminf_(fmaxf_(t, F(-K.torque_limit)), F(K.torque_limit));
     tau[j] = t;
   }
@@ -208,21 +220,24 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* 
   Fr<F> R3 = {{chk, sa * shk, -(ca * shk)}, {zero, ca, sa}, {shk, -(sa * chk), ca * chk}};
   V yax = {zero, ca, sa};
   V xax = {one, zero, zero};
-  V o1 = par3<F>(c, PR_O1);
-  V o2 = o1 + c.par(PR_SY) * yax;
+  V o1 = tp.o1;
+  V o2 = o1 + tp.sy * yax;
   V o3 = o2 - F(K.upper_len) * R2.ez;
   V pf = o3 - F(K.lower_len) * R3.ez;
 
-  RBI<F> I1 = link_inertia(c.par(PR_LINK), par3<F>(c, PR_LINK + 1), par_s3<F>(c, PR_LINK + 4), R1, o1);
-  RBI<F> I2 = link_inertia(c.par(PR_LINK + 10), par3<F>(c, PR_LINK + 11), par_s3<F>(c, PR_LINK + 14), R2, o2);
-  RBI<F> I3 = link_inertia(c.par(PR_LINK + 20), par3<F>(c, PR_LINK + 21), par_s3<F>(c, PR_LINK + 24), R3, o3);
+  RBI<F> I1 = link_inertia(tp.link[0], V{tp.link[1], tp.link[2], tp.link[3]},
+                           S3<F>{tp.link[4], tp.link[5], tp.link[6], tp.link[7], tp.link[8], tp.link[9]}, R1, o1);
+  RBI<F> I2 = link_inertia(tp.link[10], V{tp.link[11], tp.link[12], tp.link[13]},
+                           S3<F>{tp.link[14], tp.link[15], tp.link[16], tp.link[17], tp.link[18], tp.link[19]}, R2, o2);
+  RBI<F> I3 = link_inertia(tp.link[20], V{tp.link[21], tp.link[22], tp.link[23]},
+                           S3<F>{tp.link[24], tp.link[25], tp.link[26], tp.link[27], tp.link[28], tp.link[29]}, R3, o3);
   W S1 = {xax, cross(o1, xax)}, S2 = {yax, cross(o2, yax)}, S3_ = {yax, cross(o3, yax)};
 
   c.phase(0);
   // ---- velocities, bias accelerations (qdd = 0, a_base = -g), bias forces (RNEA)
   Rows<F> Rw = quat_rows(L.qx, L.qy, L.qz, L.qw);
   V gb;  // R^T g: columns of R are (r0.x, r1.x, r2.x) ...
-  V gw = par3<F>(c, PR_G);
+  V gw = tp.gw;
   gb.x = Rw.r0.x * gw.x + Rw.r1.x * gw.y + Rw.r2.x * gw.z;
   gb.y = Rw.r0.y * gw.x + Rw.r1.y * gw.y + Rw.r2.y * gw.z;
   gb.z = Rw.r0.z * gw.x + Rw.r1.z * gw.y + Rw.r2.z * gw.z;
@@ -238,8 +253,8 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* 
   W f2 = apply(I2, a2) + crf(V2, apply(I2, V2)) + f3;
   W f1 = apply(I1, a1) + crf(V1, apply(I1, V1)) + f2;
   F C1 = dot(S1, f1), C2 = dot(S2, f2), C3 = dot(S3_, f3);
-  const F m0 = c.par(PR_M0);
-  const S3<F> I0s = par_s3<F>(c, PR_I0);
+  const F m0 = tp.m0;
+  const S3<F> I0s = tp.I0s;
   RBI<F> I0 = {m0, {zero, zero, zero}, I0s};
   W f0 = apply(I0, a0) + crf(V0, apply(I0, V0));
 
@@ -408,7 +423,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, LaneState<F>& L, const F* 
   //   (lt1, lt2) *= min(1, mu ln / |lt|)
   // and lane j's raw deltas are broadcast unmasked: an inactive foot has iA = 0 and l = 0, which
   // makes its deltas exact zeros.
-  const F mu = c.par(PR_MU);
+  const F mu = tp.mu;
   const F k10 = Aown[1][0] * iA1, k20 = Aown[2][0] * iA2, k21 = Aown[2][1] * iA2, c0 = tgt * iA0;
   F own[4];
 #pragma unroll
@@ -686,6 +701,7 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   const int n_lat = c.uniform_int(c.par(PR_LAT_N));
   const int R_ = K.action_repeat;
   const float inv_repeat = 1.0f / (float)K.action_repeat;
+  const TickPar4<F> tp = load_tick_par4<F>(c);
   V3<F> fext = {F(0.0f), F(0.0f), F(0.0f)};
   if (K.ext_force) fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
   const int mlat = n_lat < 0 ? 0 : n_lat % R_;
@@ -696,7 +712,7 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
     float lerp = (float)(i + 1) * inv_repeat;
 #pragma unroll
     for (int j = 0; j < 3; j++) proc[j] = interp ? last[j] + F(lerp) * (qdes[j] - last[j]) : qdes[j];
-    physics_tick(c, K, L, proc, fext, torque_cmd);
+    physics_tick(c, K, tp, L, proc, fext, torque_cmd);
     tick++;
     if (i == ia || i == ib) ring_push(c, ring, tick & (RING - 1), L);
   }
@@ -781,8 +797,9 @@ ETG_HD void reset_settle(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   // ReceiveObservation before settling (a1.py:290): seed every ring slot with the initial reading
   for (int sl = 0; sl < RING; sl++) ring_push(c, ring, sl, L);
   int tick = 0;
+  const TickPar4<F> tp = load_tick_par4<F>(c);
   for (int i = 0; i < K.settle_ticks; i++) {  // a1.py:294-297
-    physics_tick(c, K, L, pose, V3<F>{F(0.0f), F(0.0f), F(0.0f)});
+    physics_tick(c, K, tp, L, pose, V3<F>{F(0.0f), F(0.0f), F(0.0f)});
     tick++;
     ring_push(c, ring, tick & (RING - 1), L);
   }

@@ -280,7 +280,7 @@ extern "C" int emu_tick_replication_check(void* h, int env, int nticks) {
   F4 qdes[3] = {c.par(PR_POSE), c.par(PR_POSE + 1), c.par(PR_POSE + 2)};
   int bad = 0;
   for (int t = 0; t < nticks; t++) {
-    physics_tick(c, e->K, L, qdes, V3<F4>{F4(0.0f), F4(0.0f), F4(0.0f)});
+    physics_tick(c, e->K, load_tick_par4<F4>(c), L, qdes, V3<F4>{F4(0.0f), F4(0.0f), F4(0.0f)});
     const F4* f[] = {&L.p.x, &L.p.y, &L.p.z, &L.qx, &L.qy, &L.qz, &L.qw, &L.wb.x, &L.wb.y, &L.wb.z, &L.vb.x, &L.vb.y, &L.vb.z};
     for (auto* x : f)
       for (int l = 1; l < 4; l++) bad += std::memcmp(&x->v[0], &x->v[l], 4) != 0;
