@@ -515,6 +515,7 @@ struct EtgHandle {
   float* hf;
   int lanes;                    // 4 or 16 lanes per robot (EtgConfig.lanes_per_robot)
   unsigned long long push_calls;  // stream position of etg_random_pushes
+  bool was_reset;                 // etg_step before the first etg_reset is a caller error (state undefined)
   float *tmp_obs, *tmp_reward;  // sinks for etg_rollout_openloop
   uint8_t* tmp_done;
 };
@@ -554,6 +555,7 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   h->M = make_modelf(*model);
   h->hf = nullptr;
   h->push_calls = 0;
+  h->was_reset = false;
   if (cfg->lanes_per_robot != 0 && cfg->lanes_per_robot != 4 && cfg->lanes_per_robot != 16) {
     delete h;
     return fail(ETG_ERR_BAD_ARG, "etg_create: lanes_per_robot must be 4 or 16");
@@ -663,6 +665,7 @@ extern "C" int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* st
   CHECK_HANDLE(h);
   if (!obs) return fail(ETG_ERR_BAD_ARG, "etg_reset: obs is null");
   if (h->K.terrain == 1 && !h->K.hf) return fail(ETG_ERR_STATE, "etg_reset: heightfield not set");
+  h->was_reset = true;
   // 1. settle the masked robots that have no valid settle cache (kernel exits at once for the others)
   // 2. snapshot their ring / restore state + ring of the cached ones, mark everything masked as cached
   // 3. the part after the settle: control state, episode accumulators, first observation
@@ -693,6 +696,7 @@ extern "C" int etg_step(EtgHandle* h, const float* action, const uint8_t* donef,
                         uint8_t* done, float* info, void* stream) {
   CHECK_HANDLE(h);
   if (!obs || !reward || !done) return fail(ETG_ERR_BAD_ARG, "etg_step: obs/reward/done must be non-null");
+  if (!h->was_reset) return fail(ETG_ERR_STATE, "etg_step: call etg_reset first");
   const dim3 g16((h->N + 3) / 4);
   if (h->lanes == 16) {
     if (h->K.terrain == 0)

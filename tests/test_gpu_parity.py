@@ -586,3 +586,16 @@ def test_settle_cache_resets_are_bit_identical(lanes):
     orc.reset()
     assert np.abs(st2.cpu().numpy()[:, :7] - orc.get_state()[:, :7]).max() < 1e-3
     env.close()
+
+
+def test_step_before_reset_is_an_error():
+    _need_gpu()
+    from paddlerobotics_amd._lib import EtgError
+    env = _make(4)
+    with pytest.raises(EtgError):
+        env.step(None)
+    env.reset()
+    env.step(None)
+    with pytest.raises(ValueError):
+        env.step(torch.zeros(4, 11, device="cuda:0"))          # wrong action width, like minitaur.py:1002-1005
+    env.close()
