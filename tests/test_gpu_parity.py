@@ -599,3 +599,52 @@ def test_step_before_reset_is_an_error():
     with pytest.raises(ValueError):
         env.step(torch.zeros(4, 11, device="cuda:0"))          # wrong action width, like minitaur.py:1002-1005
     env.close()
+
+
+def test_full_batch_free_flight_momentum_matches_oracle_drift():
+    """Size-independent property at the full batch (4096 robots): with gravity off and the robots far above the
+    ground only internal PD torques act, so linear and angular momentum are conserved up to the first-order
+    integrator drift -- and that drift must be the oracle's, robot by robot (momenta from the oracle's M(q))."""
+    _need_gpu()
+    from oracle.oracle import OracleSim
+    from tests.test_oracle_physics import quat2mat
+    n = 4096
+    rng = np.random.default_rng(5)
+    row = A.default_dynamic_row(); row[45:48] = 0.0                      # gravity off
+    st = np.zeros((n, 37)); st[:, 2] = 5.0
+    qt = rng.normal(size=(n, 4)); st[:, 3:7] = qt / np.linalg.norm(qt, axis=1, keepdims=True)
+    st[:, 7:10] = rng.normal(size=(n, 3)); st[:, 10:13] = rng.normal(size=(n, 3)) * 2
+    st[:, 13:25] = A.INIT_MOTOR_ANGLES + rng.normal(size=(n, 12)) * 0.2
+    st[:, 25:37] = rng.normal(size=(n, 12)) * 3
+    env = _make(n, settle_ticks=0, ETG=0)                                # zero ETG, like the oracle below
+    env.set_dynamic_param(row)
+    env.reset()
+    env.set_state(torch.as_tensor(st, dtype=torch.float32))
+    sample = rng.choice(n, 48, replace=False)
+    one = OracleSim(A.default_config(1, settle_ticks=0))
+    one.set_params(dyn=row[None])
+
+    def momentum(s):
+        one.set_state(s[None])
+        M, _ = one.dynamics_terms()
+        R = quat2mat(s[3:7])
+        v = np.concatenate([R.T @ s[10:13], R.T @ s[7:10], s[25:37]])
+        h = M[:6] @ v
+        lin = R @ h[3:6]
+        return lin, R @ h[:3] + np.cross(s[:3], lin)
+    s0 = env.get_state().cpu().numpy().astype(np.float64)
+    env.step(None)
+    s1 = env.get_state().cpu().numpy().astype(np.float64)
+    assert np.isfinite(s1).all()
+    orc = OracleSim(A.default_config(len(sample), settle_ticks=0))
+    orc.set_params(dyn=np.tile(row, (len(sample), 1)))
+    orc.reset()
+    orc.set_state(s0[sample])
+    orc.step(np.zeros((len(sample), 12)))
+    so = orc.get_state()
+    for k, i in enumerate(sample):
+        l0, a0 = momentum(s0[i]); l1, a1 = momentum(s1[i]); lo, ao = momentum(so[k])
+        scale_l, scale_a = np.abs(l0).max() + 1.0, np.abs(a0).max() + 1.0
+        assert np.abs(l1 - l0).max() < 4e-2 * scale_l and np.abs(a1 - a0).max() < 6e-2 * scale_a    # conserved to O(dt)
+        assert np.abs(l1 - lo).max() < 5e-3 * scale_l and np.abs(a1 - ao).max() < 2e-2 * scale_a    # same drift as the oracle
+    env.close()
