@@ -208,7 +208,7 @@ def main():
             "survivors": float((length == args.steps + args.warmup).float().mean().item()),
         }
         out["roofline"]["hbm_copy_measured_GBps"] = device_copy_bandwidth(dev) / 1e9
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:          # the CPU baseline is an N = 1 exercise
             cores = os.cpu_count() or 1
             one = cpu_baseline(64, 60, 1)
             allc = cpu_baseline(max(64, 16 * cores), 40, cores)
