@@ -31,7 +31,7 @@
  *
  * The implementation is deliberately GENERIC (13-body kinematic tree, 6x6
  * spatial algebra, dense 18x18 factorisation) so that it is an independent
- * check of the hand-specialised 4-lanes-per-robot HIP kernels.
+ * check of the hand-specialised HIP kernels (16 and 4 lanes per robot).
  *
  * Build: see oracle/Makefile (g++ -O2 -shared).  Exports a C ABI (etgo_*),
  * each entry point in a double ("64") and a float ("32") instantiation.
