@@ -145,6 +145,7 @@ def main():
     EVENT_SPAN = min(8 if args.config == 2 else 1, max(args.steps, 1))
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(max(1, args.steps // EVENT_EVERY))]
+    evp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in ev] if args.config == 3 else []
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -157,7 +158,11 @@ def main():
     for k in range(args.steps):
         slot, phase = divmod(k, EVENT_EVERY)
         if policy is not None:
+            if phase == 8 and slot < len(evp):               # the policy kernel is timed on other steps than the dynamics
+                evp[slot][0].record()
             policy.predict(env.obs, 0.3, args.precision, out=act)
+            if phase == 8 and slot < len(evp):
+                evp[slot][1].record()
         if phase == 0 and slot < len(ev):
             ev[slot][0].record()
         env.step(act if policy is not None else None, want_info=False)
@@ -208,6 +213,13 @@ def main():
             "survivors": float((length == args.steps + args.warmup).float().mean().item()),
         }
         out["roofline"]["hbm_copy_measured_GBps"] = device_copy_bandwidth(dev) / 1e9
+        if evp and args.steps > 8:
+            pol_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in evp if True]))
+            flops = 2.0 * N * (A.OBS_DIM * 256 + 256 * 256 + 256 * 12)          # 162 304 FLOP per env-step
+            peak = 157.3 if args.precision == 0 else 2500.0                     # dense fp32 / bf16 MFMA peaks, TFLOP/s
+            out["policy_roofline"] = {"bound": "mfma", "kernel": "k_policy", "achieved": flops / (pol_ms * 1e-3) / 1e12,
+                                      "peak": peak, "unit": "TFLOP/s", "frac": flops / (pol_ms * 1e-3) / 1e12 / peak,
+                                      "kernel_ms": pol_ms, "dtype": "f32" if args.precision == 0 else "bf16"}
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is an N = 1 exercise
             cores = os.cpu_count() or 1
             one = cpu_baseline(64, 60, 1)
