@@ -90,7 +90,8 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--num-envs", type=int, default=4096, help="robots per GPU")
-    ap.add_argument("--config", type=int, default=2, choices=(2, 3))
+    ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5),
+                    help="BASELINE.json configs (1-based): 2 open loop, 3 + MLP policy, 5 open loop on the random heightfield")
     ap.add_argument("--precision", type=int, default=0, help="policy MFMA: 0 fp32, 1 bf16")
     ap.add_argument("--solver-iters", type=int, default=SOLVER_ITERS, help="PGS sweeps per tick")
     ap.add_argument("--lanes", type=int, default=0, choices=(0, 4, 16),
@@ -115,8 +116,12 @@ def main():
     from paddlerobotics_amd.env import make_env
     from paddlerobotics_amd.policy import MfmaPolicy
     N = args.num_envs
+    terrain_kw = {}
+    if args.config == 5:   # BASELINE config 5: 256x256 grid, 0.05 m cells, heights U(0, 0.05) m from default_rng(0)
+        hf = np.random.default_rng(0).uniform(0.0, 0.05, size=(256, 256)).astype(np.float32)
+        terrain_kw = dict(task="heightfield", heightfield=dict(heights=hf, cell=0.05, origin=(-6.4, -6.4)))
     env = make_env("Quadrupedal", num_envs=N, device=str(dev), solver_iters=args.solver_iters,
-                   lanes_per_robot=args.lanes)
+                   lanes_per_robot=args.lanes, **terrain_kw)
     lanes = env.lanes_per_robot
     w, b = etg_population(N, seed=rank, device=dev)
     env.reset(ETG_w=w, ETG_b=b)
@@ -142,7 +147,7 @@ def main():
     # a 50 us step (tools/gap_test.py) -- while un-instrumented launches run gap-free, so per-launch pairs
     # would mostly measure the events.
     EVENT_EVERY = 16
-    EVENT_SPAN = min(8 if args.config == 2 else 1, max(args.steps, 1))
+    EVENT_SPAN = min(1 if args.config == 3 else 8, max(args.steps, 1))
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(max(1, args.steps // EVENT_EVERY))]
     evp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in ev] if args.config == 3 else []
@@ -186,7 +191,7 @@ def main():
     if rank == 0:
         total_steps = world * N * args.steps
         value = total_steps / elapsed
-        bytes_per = BYTES_PER_STEP_CFG2 if args.config == 2 else BYTES_PER_STEP_CFG3
+        bytes_per = BYTES_PER_STEP_CFG3 if args.config == 3 else BYTES_PER_STEP_CFG2
         achieved = bytes_per * N / (kern_ms * 1e-3)
         out = {
             "metric": "env-steps/sec, 4096 A1 quadrupeds; 1/2/4/8-GPU scaling",
@@ -195,6 +200,8 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("configs[1]: %d parallel A1 per GPU, flat terrain, ETG open-loop, per-env ETG "
                                     "params = prior + N(0,0.02^2)" % N) if args.config == 2 else
+                       ("configs[4] (per GPU): %d parallel A1 per GPU, random heightfield 256x256 x 0.05 m, ETG open-loop, "
+                        "per-env ETG params" % N) if args.config == 5 else
                        ("configs[2]: %d parallel A1 per GPU, flat, ETG + residual MLP policy (random init, "
                         "precision %d)" % (N, args.precision)),
                        "robots_per_gpu": N, "action_repeat": 13, "sim_dt": 0.002, "solver_iters": args.solver_iters, "lanes_per_robot": lanes,
