@@ -420,16 +420,24 @@ ETG_HD F etg_action16(const Ctx& c, const KCfg& K, const float* etgp, float t) {
   F tl = sel_(c.leg_is(0) || c.leg_is(3), F(t), F(t + K.etg_T2 * K.etg_T));
   F x0 = F(K.etg_amp) * sin_(F(K.etg_phase0) + tl * F(K.etg_omega));
   F x1 = F(K.etg_amp) * sin_(F(K.etg_phase1) + tl * F(K.etg_omega));
-  F ax = c.ld_env(etgp, EP_B + 0), ay = c.ld_env(etgp, EP_B + 1), az = c.ld_env(etgp, EP_B + 2);
+  // the 20 RBF terms of the leg are split over its 4 lanes (sub-lane s takes h = 5 s .. 5 s + 4), then quad-summed
   const F isig(1.0f / K.etg_sigma_sq);
-#pragma unroll 4
-  for (int h = 0; h < ETG_RBF_H; h++) {
-    F d0 = x0 - F(K.etg_u[h][0]), d1 = x1 - F(K.etg_u[h][1]);
+  const auto s0 = c.sub_is(0), s1 = c.sub_is(1), s2 = c.sub_is(2);
+  F ax(0.0f), ay(0.0f), az(0.0f);
+#pragma unroll
+  for (int i = 0; i < ETG_RBF_H / 4; i++) {
+    const int q = ETG_RBF_H / 4;
+    const F u0 = sel_(s0, F(K.etg_u[i][0]), sel_(s1, F(K.etg_u[i + q][0]), sel_(s2, F(K.etg_u[i + 2 * q][0]), F(K.etg_u[i + 3 * q][0]))));
+    const F u1 = sel_(s0, F(K.etg_u[i][1]), sel_(s1, F(K.etg_u[i + q][1]), sel_(s2, F(K.etg_u[i + 2 * q][1]), F(K.etg_u[i + 3 * q][1]))));
+    F d0 = x0 - u0, d1 = x1 - u1;
     F r = exp_(-((d0 * d0 + d1 * d1) * isig));
-    ax = ax + c.ld_env(etgp, EP_W + h) * r;
-    ay = ay + c.ld_env(etgp, EP_W + ETG_RBF_H + h) * r;
-    az = az + c.ld_env(etgp, EP_W + 2 * ETG_RBF_H + h) * r;
+    ax = ax + c.ld_env_sub(etgp, EP_W + i, q) * r;
+    ay = ay + c.ld_env_sub(etgp, EP_W + ETG_RBF_H + i, q) * r;
+    az = az + c.ld_env_sub(etgp, EP_W + 2 * ETG_RBF_H + i, q) * r;
   }
+  ax = c.qsum(ax) + c.ld_env(etgp, EP_B + 0);
+  ay = c.qsum(ay) + c.ld_env(etgp, EP_B + 1);
+  az = c.qsum(az) + c.ld_env(etgp, EP_B + 2);
   F scale(1.0f);
   const V3<F> posev = par3<F>(c, PR_POSE), bfoot = par3<F>(c, PR_BASE_FOOT), o1 = par3<F>(c, PR_O1);
   const F hipsign = c.par(PR_HIPSIGN);
@@ -446,7 +454,6 @@ ETG_HD F etg_action16(const Ctx& c, const KCfg& K, const float* etgp, float t) {
     scale = scale * F(0.95f);
     if (!c.any(pending)) break;
   }
-  const auto s0 = c.sub_is(0), s1 = c.sub_is(1);
   F own = sel_(s0, ang[0] - posev.x, sel_(s1, ang[1] - posev.y, ang[2] - posev.z));
   return c.jointf() * own;
 }

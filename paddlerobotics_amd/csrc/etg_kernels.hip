@@ -329,6 +329,8 @@ struct GpuCtx16 {
   __device__ __forceinline__ float ld_legf(const float* p, int f) const { return p[(size_t)f * NL + col]; }
   __device__ __forceinline__ void st_legf(float* p, int f, float v) const { if (sub == 0) p[(size_t)f * NL + col] = v; }
   __device__ __forceinline__ float ld_env(const float* p, int f) const { return p[(size_t)f * N + env]; }
+  // field f0 + stride * sub of the per-robot array: the 4 sub-lanes of a leg split a table between them
+  __device__ __forceinline__ float ld_env_sub(const float* p, int f0, int stride) const { return p[(size_t)(f0 + stride * sub) * N + env]; }
   __device__ __forceinline__ void st_env(float* p, int f, float v) const { if (r == 0) p[(size_t)f * N + env] = v; }
   __device__ __forceinline__ int ld_env_i(const int* p, int f) const { return p[(size_t)f * N + env]; }
   __device__ __forceinline__ void st_env_i(int* p, int f, int v) const { if (r == 0) p[(size_t)f * N + env] = v; }

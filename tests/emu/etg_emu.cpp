@@ -107,6 +107,7 @@ struct EmuCtx16Base {
   F16 ld_legf(const float* p, int f) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = p[(size_t)f * NL() + col(r)]; return o; }
   void st_legf(float* p, int f, F16 v) const { for (int r = 0; r < 16; r += 4) p[(size_t)f * NL() + col(r)] = v.v[r]; }
   F16 ld_env(const float* p, int f) const { return F16(p[(size_t)f * N + env]); }
+  F16 ld_env_sub(const float* p, int f0, int stride) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = p[(size_t)(f0 + stride * (r & 3)) * N + env]; return o; }
   void st_env(float* p, int f, F16 v) const { p[(size_t)f * N + env] = v.v[0]; }
   int ld_env_i(const int* p, int f) const { return p[(size_t)f * N + env]; }
   void st_env_i(int* p, int f, int v) const { p[(size_t)f * N + env] = v; }
