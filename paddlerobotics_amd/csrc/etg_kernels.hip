@@ -376,10 +376,11 @@ __device__ __forceinline__ bool make_ctx16(const KCfg& K, const DevState& D, Gpu
   c.NL = 4 * K.n_env;
   if (c.env >= c.N) return false;   // whole rows drop out together, so every DPP/MFMA group stays complete
   c.col = (size_t)4 * c.env + c.leg;
-  // stage the leg's 66 parameters and this lane's own link block (zeros on the aux lane) in LDS
+  // stage the leg-level parameters and this lane's own link block (zeros on the aux lane) in LDS; the leg's
+  // three link blocks PR_LINK..PR_LINK+29 are only read through the own-link copy here, so they are skipped
   float* mine = lds_all + threadIdx.x;
 #pragma unroll 6
-  for (int k = 0; k < PR_N; k++) mine[k * 64] = D.par[(size_t)k * c.NL + c.col];
+  for (int k = PR_O1; k < PR_N; k++) mine[k * 64] = D.par[(size_t)k * c.NL + c.col];
 #pragma unroll
   for (int k = 0; k < 10; k++) mine[(PR_N + k) * 64] = c.sub < 3 ? D.par[(size_t)(PR_LINK + 10 * c.sub + k) * c.NL + c.col] : 0.0f;
   c.lds = mine;
