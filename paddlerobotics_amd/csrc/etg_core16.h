@@ -77,9 +77,13 @@ template <class F, class Ctx> ETG_HD SV<F> quad_bcast(const Ctx& c, SV<F> v, int
 template <class F> struct TickPar { F kp, kd, sy, m0, mu, link[10]; V3<F> o1, gw, fext; S3<F> I0s; };
 template <class F, class Ctx> ETG_HD TickPar<F> load_tick_par(const Ctx& c) {
   TickPar<F> t;
-  t.kp = c.par_joint(PR_KP); t.kd = c.par_joint(PR_KD); t.sy = c.par(PR_SY); t.m0 = c.par(PR_M0); t.mu = c.par(PR_MU);
-  for (int k = 0; k < 10; k++) t.link[k] = c.par_link(k);
-  t.o1 = par3<F>(c, PR_O1); t.gw = par3<F>(c, PR_G); t.I0s = par_s3<F>(c, PR_I0);
+  // tpar*: straight from the HBM parameter array into registers (no LDS hop) -- issued at kernel start, consumed in
+  // the tick loop
+  t.kp = c.tpar_joint(PR_KP); t.kd = c.tpar_joint(PR_KD); t.sy = c.tpar(PR_SY); t.m0 = c.tpar(PR_M0); t.mu = c.tpar(PR_MU);
+  for (int k = 0; k < 10; k++) t.link[k] = c.tpar_link(k);
+  t.o1 = {c.tpar(PR_O1), c.tpar(PR_O1 + 1), c.tpar(PR_O1 + 2)};
+  t.gw = {c.tpar(PR_G), c.tpar(PR_G + 1), c.tpar(PR_G + 2)};
+  t.I0s = {c.tpar(PR_I0), c.tpar(PR_I0 + 1), c.tpar(PR_I0 + 2), c.tpar(PR_I0 + 3), c.tpar(PR_I0 + 4), c.tpar(PR_I0 + 5)};
   t.fext = {F(0.0f), F(0.0f), F(0.0f)};   // external trunk force (world frame); control_step16 fills it in
   return t;
 }

@@ -241,20 +241,23 @@ __global__ void __launch_bounds__(BLOCK) k_step(KCfg K, DevState D, const float*
 // ====================================================================== 16 lanes per robot
 // One robot = one 16-lane DPP row (etg_core16.h): lane r = 4*leg + sub.  A workgroup is still one
 // wave64 = 4 robots; 4096 robots -> 1024 workgroups = one wave on every SIMD of the chip.
-constexpr int LDS16_FIELDS = PR_N + 10;  // the 66 leg-level parameters + this lane's own link block
+constexpr int LDS16_FIELDS = PR_N;  // one LDS column per lane, indexed by PR_* (only the staged fields are filled)
 
 struct GpuCtx16 {
   int env, r, leg, sub, sc, tid, N, NL;
   size_t col;        // 4*env + leg : column of the leg-level SoA arrays
   const float* lds;  // this lane's LDS column
+  const float* gpar; // D.par: the tick constants are read from it directly (tpar*)
   __device__ __forceinline__ float jointf() const { return sub < 3 ? 1.0f : 0.0f; }
   __device__ __forceinline__ bool sub_is(int j) const { return sub == j; }
   __device__ __forceinline__ bool leg_is(int j) const { return leg == j; }
   __device__ __forceinline__ bool any(bool b) const { return __any(b); }
   __device__ __forceinline__ int uniform_int(float a) const { return (int)a; }
   __device__ __forceinline__ float par(int k) const { return lds[k * 64]; }
-  __device__ __forceinline__ float par_link(int k) const { return lds[(PR_N + k) * 64]; }
   __device__ __forceinline__ float par_joint(int base) const { return lds[(base + sc) * 64]; }
+  __device__ __forceinline__ float tpar(int k) const { return gpar[(size_t)k * NL + col]; }
+  __device__ __forceinline__ float tpar_joint(int base) const { return gpar[(size_t)(base + sc) * NL + col]; }
+  __device__ __forceinline__ float tpar_link(int k) const { return sub < 3 ? gpar[(size_t)(PR_LINK + 10 * sub + k) * NL + col] : 0.0f; }
   // ---- quad (= leg) exchanges
   __device__ __forceinline__ float qb(float a, int j) const {
     switch (j) { case 0: return dpp_<0x00>(a); case 1: return dpp_<0x55>(a); case 2: return dpp_<0xAA>(a); default: return dpp_<0xFF>(a); }
@@ -376,13 +379,15 @@ __device__ __forceinline__ bool make_ctx16(const KCfg& K, const DevState& D, Gpu
   c.NL = 4 * K.n_env;
   if (c.env >= c.N) return false;   // whole rows drop out together, so every DPP/MFMA group stays complete
   c.col = (size_t)4 * c.env + c.leg;
-  // stage the leg-level parameters and this lane's own link block (zeros on the aux lane) in LDS; the leg's
-  // three link blocks PR_LINK..PR_LINK+29 are only read through the own-link copy here, so they are skipped
+  // stage in LDS only the leg-level parameters that the once-per-step code reads (c.par / c.par_joint); the tick
+  // constants (gains, link block, gravity, trunk inertia, mu) go straight to registers through tpar*
   float* mine = lds_all + threadIdx.x;
-#pragma unroll 6
-  for (int k = PR_O1; k < PR_N; k++) mine[k * 64] = D.par[(size_t)k * c.NL + c.col];
+  c.gpar = D.par;
+  constexpr int kStaged[] = {PR_O1, PR_O1 + 1, PR_O1 + 2, PR_SY, PR_LAT_N, PR_LAT_A, PR_BASE_FOOT, PR_BASE_FOOT + 1,
+                             PR_BASE_FOOT + 2, PR_POSE, PR_POSE + 1, PR_POSE + 2, PR_EMEAN, PR_EMEAN + 1, PR_EMEAN + 2,
+                             PR_ESTD, PR_ESTD + 1, PR_ESTD + 2, PR_HIPSIGN};
 #pragma unroll
-  for (int k = 0; k < 10; k++) mine[(PR_N + k) * 64] = c.sub < 3 ? D.par[(size_t)(PR_LINK + 10 * c.sub + k) * c.NL + c.col] : 0.0f;
+  for (int k : kStaged) mine[k * 64] = D.par[(size_t)k * c.NL + c.col];
   c.lds = mine;
   return true;
 }

@@ -75,6 +75,9 @@ struct EmuCtx16Base {
   int uniform_int(F16 a) const { return (int)a.v[0]; }
   F16 par(int k) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = parp[(size_t)k * NL() + col(r)]; return o; }
   F16 par_link(int k) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = sub(r) < 3 ? parp[(size_t)(PR_LINK + 10 * sub(r) + k) * NL() + col(r)] : 0.f; return o; }
+  F16 tpar(int k) const { return par(k); }
+  F16 tpar_joint(int base) const { return par_joint(base); }
+  F16 tpar_link(int k) const { return par_link(k); }
   F16 par_joint(int base) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = parp[(size_t)(base + sc(r)) * NL() + col(r)]; return o; }
   // quad (leg) exchanges
   F16 qb(F16 x, int j) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = x.v[(r & ~3) + j]; return o; }
