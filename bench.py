@@ -32,11 +32,11 @@ HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
 # HBM bytes per step-kernel launch at N = 4096 from the PMC counters (profiles/r01_pmc_k_step16.txt
 # and r01_pmc_k_step_lanes4.txt: FETCH_SIZE + WRITE_SIZE, separate passes, KB units; dword accesses,
 # uncalibrated width -- see DESIGN.md section 7).  Scaled linearly with N for other batch sizes.
-PMC_TRAFFIC_BYTES_AT_4096 = {16: (3967.5 + 3076.0) * 1024.0, 4: (4010.5 + 3076.0) * 1024.0}
+PMC_TRAFFIC_BYTES_AT_4096 = {16: (3978.5 + 3076.0) * 1024.0, 4: (4010.5 + 3076.0) * 1024.0}
 # VALU instructions one wave issues per step-kernel launch (SQ_INSTS_VALU / SQ_WAVES, same PMC files) and the
 # VALU issue capacity of a SIMD measured with tools/ubench/occupancy_rate.hip (8 resident waves of v_fma_f32:
 # 0.384 wave-instructions per SIMD-cycle at the nominal 2.4 GHz; one resident wave reaches 0.172).
-PMC_VALU_PER_WAVE = {16: 22112450.1 / 1024.0, 4: 8008005.8 / 256.0}
+PMC_VALU_PER_WAVE = {16: 21886146.1 / 1024.0, 4: 8008005.8 / 256.0}
 VALU_PEAK_PER_SIMD_CYCLE = 0.384
 NOMINAL_HZ = 2.4e9
 BYTES_PER_STEP_CFG2 = 816  # 564 B + 252 B per-env ETG w,b
