@@ -181,11 +181,14 @@ template <class F> ETG_HD void bwd6(const F* L, F* b) {  // b <- L^-T b
 // parks them in AGPRs): a lone wave per SIMD cannot hide the LDS latency of re-reading them every tick
 template <class F> struct TickPar4 { F kp[3], kd[3], sy, m0, mu, link[30]; V3<F> o1, gw; S3<F> I0s; };
 template <class F, class Ctx> ETG_HD TickPar4<F> load_tick_par4(const Ctx& c) {
+  // tpar: straight from the HBM parameter array into registers (no LDS hop)
   TickPar4<F> t;
-  for (int j = 0; j < 3; j++) { t.kp[j] = c.par(PR_KP + j); t.kd[j] = c.par(PR_KD + j); }
-  t.sy = c.par(PR_SY); t.m0 = c.par(PR_M0); t.mu = c.par(PR_MU);
-  for (int k = 0; k < 30; k++) t.link[k] = c.par(PR_LINK + k);
-  t.o1 = par3<F>(c, PR_O1); t.gw = par3<F>(c, PR_G); t.I0s = par_s3<F>(c, PR_I0);
+  for (int j = 0; j < 3; j++) { t.kp[j] = c.tpar(PR_KP + j); t.kd[j] = c.tpar(PR_KD + j); }
+  t.sy = c.tpar(PR_SY); t.m0 = c.tpar(PR_M0); t.mu = c.tpar(PR_MU);
+  for (int k = 0; k < 30; k++) t.link[k] = c.tpar(PR_LINK + k);
+  t.o1 = {c.tpar(PR_O1), c.tpar(PR_O1 + 1), c.tpar(PR_O1 + 2)};
+  t.gw = {c.tpar(PR_G), c.tpar(PR_G + 1), c.tpar(PR_G + 2)};
+  t.I0s = {c.tpar(PR_I0), c.tpar(PR_I0 + 1), c.tpar(PR_I0 + 2), c.tpar(PR_I0 + 3), c.tpar(PR_I0 + 4), c.tpar(PR_I0 + 5)};
   return t;
 }
 

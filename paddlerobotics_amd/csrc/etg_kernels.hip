@@ -27,7 +27,9 @@ template <int CTRL> __device__ __forceinline__ float dpp_(float x) {
 struct GpuCtx {
   int gid, env, lane, N, NL;
   const float* lds;  // this lane's parameter column in LDS: lds[k * BLOCK]
+  const float* gpar; // D.par, for the tick constants read straight into registers
   __device__ __forceinline__ float par(int k) const { return lds[k * 64]; }
+  __device__ __forceinline__ float tpar(int k) const { return gpar[(size_t)k * NL + gid]; }
   __device__ __forceinline__ float ld_lane(const float* p, int f) const { return p[(size_t)f * NL + gid]; }
   __device__ __forceinline__ void st_lane(float* p, int f, float v) const { p[(size_t)f * NL + gid] = v; }
   __device__ __forceinline__ float ld_env(const float* p, int f) const { return p[(size_t)f * N + env]; }
@@ -120,9 +122,14 @@ constexpr int BLOCK = 64;
 // bank i).  Each lane reads back only its own column, so no barrier is needed -- the LDS
 // is a software-managed register file extension here, not a sharing medium.
 __device__ __forceinline__ void stage_params(GpuCtx& c, const DevState& D, float* lds_par) {
-#pragma unroll 6
-  for (int k = 0; k < PR_N; k++) lds_par[k * BLOCK + threadIdx.x] = D.par[(size_t)k * c.NL + c.gid];
+  // only what the once-per-step code reads through c.par(); the tick constants go straight to registers (tpar)
+  constexpr int kStaged[] = {PR_O1, PR_O1 + 1, PR_O1 + 2, PR_SY, PR_LAT_N, PR_LAT_A, PR_BASE_FOOT, PR_BASE_FOOT + 1,
+                             PR_BASE_FOOT + 2, PR_POSE, PR_POSE + 1, PR_POSE + 2, PR_EMEAN, PR_EMEAN + 1, PR_EMEAN + 2,
+                             PR_ESTD, PR_ESTD + 1, PR_ESTD + 2, PR_HIPSIGN};
+#pragma unroll
+  for (int k : kStaged) lds_par[k * BLOCK + threadIdx.x] = D.par[(size_t)k * c.NL + c.gid];
   c.lds = lds_par + threadIdx.x;
+  c.gpar = D.par;
 }
 
 __global__ void __launch_bounds__(BLOCK) k_set_params(KCfg K, ModelF M, DevState D, const float* dyn, const float* w,

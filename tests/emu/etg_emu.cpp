@@ -19,6 +19,7 @@ struct EmuCtxBase {
   int env, N;
   const float* parp;
   F4 par(int k) const { return ld_lane(parp, k); }
+  F4 tpar(int k) const { return par(k); }
   int NL() const { return 4 * N; }
   F4 ld_lane(const float* p, int f) const { F4 r; for (int l = 0; l < 4; l++) r.v[l] = p[(size_t)f * NL() + 4 * env + l]; return r; }
   void st_lane(float* p, int f, F4 v) const { for (int l = 0; l < 4; l++) p[(size_t)f * NL() + 4 * env + l] = v.v[l]; }
