@@ -41,8 +41,8 @@ def sensor_columns(sensor_mode):
         if sm.get(k):
             raise NotImplementedError("sensor_mode[%r] is not provided by the batched simulator" % k)
     rnn = sm.get("RNN")
-    if rnn and rnn.get("time_steps", 0) > 0:
-        raise NotImplementedError("sensor_mode['RNN'] observation stacking is not provided")
+    if rnn and rnn.get("time_steps", 0) > 0 and rnn.get("mode", "stack") not in ("stack", "GRU"):
+        raise NotImplementedError("sensor_mode['RNN']['mode'] must be 'stack' or 'GRU'")
     cols = []
     def add(name):
         a, b = _OBS_COLS[name]
@@ -149,6 +149,15 @@ class BatchedQuadrupedEnv:
             raise NotImplementedError("motor_control_mode %r: POSITION and TORQUE are simulated (HYBRID is not)" % (motor_control_mode,))
         self.motor_mode = motor_mode
         self._cols = sensor_columns(sensor_mode)
+        # observation history (ObservationWrapper, deployment/envs/EnvWrapper.py:195-238): the current reading
+        # preceded by `time_steps` older ones taken `time_interval` control steps apart, flattened ("stack", obs
+        # dim x (time_steps + 1), deployment/test.py:44-45) or kept as a sequence ("GRU")
+        rnn = (sensor_mode or {}).get("RNN") or {}
+        self._hist_T = int(rnn.get("time_steps", 0))
+        self._hist_dt = int(rnn.get("time_interval", 1)) if self._hist_T > 0 else 1
+        self._hist_mode = rnn.get("mode", "stack")
+        self._hist = None
+        self._hist_head = 0
         rp = dict(random_param or {})
         self._rand_dyn = bool(rp.get("random_dynamics", 0))
         self._rand_force = bool(rp.get("random_force", 0))
@@ -174,7 +183,12 @@ class BatchedQuadrupedEnv:
             # foot positions are pulled in to y = -+step_y so the feet land on the beam (right legs negative y)
             for leg in range(4):
                 self.model.base_foot[3 * leg + 1] = (-1.0 if leg % 2 == 0 else 1.0) * float(step_y)
-        self.observation_space = Box(-np.inf, np.inf, (len(self._cols),))
+        d = len(self._cols)
+        if self._hist_T > 0:
+            shape = (d * (self._hist_T + 1),) if self._hist_mode == "stack" else (self._hist_T + 1, d)
+        else:
+            shape = (d,)
+        self.observation_space = Box(-np.inf, np.inf, shape)
         self.action_space = Box(-1.0, 1.0, (A.NUM_MOTORS,))
         self._lib = _lib.load()
         self._h = C.c_void_p()
@@ -305,10 +319,34 @@ class BatchedQuadrupedEnv:
             _lib.check(self._lib.etg_clear_pushes(self._h, _ptr(m), self._stream()))
         _lib.check(self._lib.etg_reset(self._h, _ptr(m), _ptr(self.obs), self._stream()))
         info = {"ETG_act": None}
-        return self._obs_view(), info
+        return self._obs_view(reset_mask=m, first=True), info
 
-    def _obs_view(self):
-        return self.obs if self._col_idx is None else self.obs.index_select(1, self._col_idx)
+    def _obs_view(self, reset_mask=None, first=False):
+        """the observation the caller sees: sensor_mode column selection, then (optionally) the history stack.
+        reset_mask: uint8 [N] of the robots that were just reset (None = all, with first=True)."""
+        o = self.obs if self._col_idx is None else self.obs.index_select(1, self._col_idx)
+        if self._hist_T == 0:
+            return o
+        H = self._hist_T * self._hist_dt
+        if self._hist is None:
+            self._hist = torch.zeros(H, self.num_envs, o.shape[1], device=self.device)
+        if first:   # reset: zero history for the reset robots; the list is read BEFORE the new reading is stored
+            if reset_mask is None:
+                self._hist.zero_()
+            else:
+                self._hist.mul_((1 - reset_mask.float()).view(1, -1, 1))
+        older = [self._hist[(self._hist_head + t * self._hist_dt) % H] for t in range(self._hist_T)]
+        seq = torch.stack(older + [o], dim=1)                      # [N, T+1, D]; copies, taken BEFORE the ring is updated
+        if first:
+            last = (self._hist_head + H - 1) % H
+            if reset_mask is None:
+                self._hist[last] = o
+            else:   # robots that were not reset keep their own history
+                self._hist[last] = torch.where(reset_mask.bool().unsqueeze(1), o, self._hist[last])
+        else:
+            self._hist_head = (self._hist_head + 1) % H          # logical shift by one ...
+            self._hist[(self._hist_head + H - 1) % H] = o          # ... and the newest reading goes last
+        return seq.reshape(self.num_envs, -1) if self._hist_mode == "stack" else seq
 
     def set_external_force(self, force):
         """force [N,3] (world frame, N) pushed on every trunk until replaced; None clears it."""

@@ -648,3 +648,41 @@ def test_full_batch_free_flight_momentum_matches_oracle_drift():
         assert np.abs(l1 - l0).max() < 4e-2 * scale_l and np.abs(a1 - a0).max() < 6e-2 * scale_a    # conserved to O(dt)
         assert np.abs(l1 - lo).max() < 5e-3 * scale_l and np.abs(a1 - ao).max() < 2e-2 * scale_a    # same drift as the oracle
     env.close()
+
+
+def test_observation_history_stack_follows_the_reference_wrapper():
+    """sensor_mode['RNN'] (ObservationWrapper, deployment/envs/EnvWrapper.py:195-238): zeros history at reset, the
+    list is read before the new reading is appended, readings `time_interval` steps apart, flattened for 'stack'."""
+    _need_gpu()
+    n, T, dt = 6, 2, 2
+    plain = _make(n)
+    hist = _make(n, sensor_mode={"RNN": {"time_steps": T, "time_interval": dt, "mode": "stack"}})
+    gru = _make(n, sensor_mode={"RNN": {"time_steps": T, "time_interval": dt, "mode": "GRU"}})
+    assert hist.observation_space.shape == (49 * (T + 1),) and gru.observation_space.shape == (T + 1, 49)
+    ref_hist = np.zeros((T * dt, n, 49), dtype=np.float32)           # the reference's obs_history, oldest first
+
+    def ref_stack(o):
+        lst = [ref_hist[t * dt].copy() for t in range(T)] + [o.copy()]
+        return np.stack(lst, axis=1)
+
+    o0 = plain.reset()[0].cpu().numpy()
+    want = ref_stack(o0)
+    ref_hist[-1] = o0
+    got = hist.reset()[0].cpu().numpy()
+    got_g = gru.reset()[0].cpu().numpy()
+    assert np.array_equal(got, want.reshape(n, -1)) and np.array_equal(got_g, want)
+    for k in range(7):
+        o = plain.step(None)[0].cpu().numpy()
+        want = ref_stack(o)
+        ref_hist[:-1] = ref_hist[1:].copy()
+        ref_hist[-1] = o
+        got = hist.step(None)[0].cpu().numpy()
+        assert np.array_equal(got, want.reshape(n, -1)), k
+        assert np.array_equal(gru.step(None)[0].cpu().numpy(), want)
+    # partial reset: only robot 2 starts a fresh (zero) history
+    ids = torch.tensor([2], device="cuda:0")
+    o = plain.reset(env_ids=ids)[0].cpu().numpy()
+    got = hist.reset(env_ids=ids)[0].cpu().numpy().reshape(n, T + 1, 49)
+    assert np.all(got[2, :T] == 0) and np.array_equal(got[2, T], o[2])
+    assert np.array_equal(got[0, T], o[0]) and np.any(got[0, :T] != 0)
+    plain.close(); hist.close(); gru.close()
