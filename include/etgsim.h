@@ -36,6 +36,7 @@ extern "C" {
 #define ETG_NUM_LEGS 4
 #define ETG_NUM_MOTORS 12
 #define ETG_ACT_DIM 12
+#define ETG_HYBRID_DIM 60 /* HYBRID motor commands: 12 x (q_des, kp, qd_des, kd, tau_ff), laikago_motor.py:30-37 */
 #define ETG_OBS_DIM 49   /* train.py:311 with the default sensor set */
 #define ETG_STATE_DIM 37 /* pos3 quat4(xyzw) linvel3 angvel3 (world) q12 qd12      */
 #define ETG_DYN_DIM 48   /* flattened dynamic_param dict, train.py:112-126          */
@@ -130,8 +131,10 @@ typedef struct EtgConfig {
   int32_t hf_bands;
   /* motor control mode (robot_config.MotorControlMode, train.py mode_map): 0 = POSITION -- the action is a
    * joint-angle residual on pose_ori + ETG and the PD law of laikago_motor.py:165-173 makes the torque;
-   * 1 = TORQUE -- the action IS the 12 motor torques (laikago_motor.py:140-143), no ETG/pose added; the
-   * reset settle always runs under POSITION control like a1.py:289-304.                              */
+   * 1 = TORQUE -- the action IS the 12 motor torques (laikago_motor.py:140-143), no ETG/pose added;
+   * 2 = HYBRID -- the action row has ETG_HYBRID_DIM = 60 floats, per motor (q_des, kp, qd_des, kd, tau_ff), and
+   * tau = -kp (q - q_des) - kd (qd - qd_des) + tau_ff (laikago_motor.py:152-167), no ETG/pose added.
+   * The reset settle always runs under POSITION control like a1.py:289-304.                          */
   int32_t motor_mode;
   /* A1._ClipMotorCommands (deployment/robots/a1.py:439-457, MAX_MOTOR_ANGLE_CHANGE_PER_STEP = 0.2): when
    * > 0, every sub-step's position command is clipped to the current motor angle +- this many radians
@@ -179,7 +182,7 @@ int etg_clear_pushes(EtgHandle* h, const uint8_t* mask, void* stream);
  * rows of the reset envs (other rows untouched).                             */
 int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* stream);
 /* one control step for all envs. action [N,12] (already scaled by act_bound,
- * train.py:147); donef [N] uint8 or NULL; outputs obs [N,49], reward [N],
+ * train.py:147; [N,60] in the HYBRID motor mode); donef [N] uint8 or NULL; outputs obs [N,49], reward [N],
  * done [N] uint8, info [N,64] or NULL.                                       */
 int etg_step(EtgHandle* h, const float* action, const uint8_t* donef, float* obs,
              float* reward, uint8_t* done, float* info, void* stream);

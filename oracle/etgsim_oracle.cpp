@@ -702,7 +702,8 @@ template <class T> void delayed_obs(const Sim<T>& s, const Env<T>& e, T* o) {
 }
 
 // one sub-step: ApplyAction (PD, laikago_motor.py:165-173; pd_latency = 0) -> tick -> history
-template <class T> void sub_step(const Sim<T>& s, Env<T>& e, const T* qdes, bool torque_cmd = false) {
+// hyb (HYBRID mode, laikago_motor.py:152-167): 12 x (kp, qd_des, kd, tau_ff) replacing the model's gains
+template <class T> void sub_step(const Sim<T>& s, Env<T>& e, const T* qdes, bool torque_cmd = false, const T* hyb = nullptr) {
   T tau[12];
   for (int j = 0; j < 12; j++) {
     // POSITION: laikago_motor.py:165-173; TORQUE: the command is the torque (laikago_motor.py:140-143)
@@ -712,7 +713,9 @@ template <class T> void sub_step(const Sim<T>& s, Env<T>& e, const T* qdes, bool
       if (cmd > e.q[j] + lim) cmd = e.q[j] + lim;
       if (cmd < e.q[j] - lim) cmd = e.q[j] - lim;
     }
-    T t = torque_cmd ? cmd : -(e.kp[j] * (e.q[j] - cmd)) - e.kd[j] * e.qd[j];
+    T t = torque_cmd ? cmd
+          : hyb ? (-(hyb[4 * j] * (e.q[j] - cmd)) - hyb[4 * j + 2] * (e.qd[j] - hyb[4 * j + 1])) + hyb[4 * j + 3]
+                : -(e.kp[j] * (e.q[j] - cmd)) - e.kd[j] * e.qd[j];
     if (s.cfg.torque_limit > 0) {
       T lim = T(s.cfg.torque_limit);
       if (t > lim) t = lim;
@@ -858,7 +861,13 @@ void step_env(Sim<T>& s, Env<T>& e, const T* action, int donef, T* obs, T* rewar
   T etg[12], qdes[12];
   etg_action(s, e, t, etg);
   const bool torque_cmd = s.cfg.motor_mode == 1;
-  for (int j = 0; j < 12; j++) qdes[j] = torque_cmd ? action[j] : T(m.pose_ori[j]) + etg[j] + action[j];
+  const bool hybrid_cmd = s.cfg.motor_mode == 2;   // action row = 12 x (q_des, kp, qd_des, kd, tau_ff)
+  T hyb[48];
+  if (hybrid_cmd)
+    for (int j = 0; j < 12; j++)
+      for (int k = 0; k < 4; k++) hyb[4 * j + k] = action[5 * j + 1 + k];
+  for (int j = 0; j < 12; j++)
+    qdes[j] = hybrid_cmd ? action[5 * j] : torque_cmd ? action[j] : T(m.pose_ori[j]) + etg[j] + action[j];
   if (s.cfg.enable_action_filter) {  // action_filter.py:111-120 (order 2)
     for (int j = 0; j < 12; j++) {
       T y = T(s.cfg.filter_b[0]) * qdes[j] + T(s.cfg.filter_b[1]) * e.fx[0][j] + T(s.cfg.filter_b[2]) * e.fx[1][j] -
@@ -877,7 +886,7 @@ void step_env(Sim<T>& s, Env<T>& e, const T* action, int donef, T* obs, T* rewar
     } else {
       for (int j = 0; j < 12; j++) proc[j] = qdes[j];
     }
-    sub_step(s, e, proc, torque_cmd);
+    sub_step(s, e, proc, torque_cmd, hybrid_cmd ? hyb : (const T*)nullptr);
   }
   for (int j = 0; j < 12; j++) e.last_qdes[j] = qdes[j];
   e.has_last = 1;
@@ -1044,7 +1053,7 @@ template <class F> void par_for(int n, int threads, F f) {
                                   uint8_t* done, T* info, int threads) {                            \
     auto* s = (Sim<T>*)h;                                                                           \
     par_for(s->N, threads, [=](int i) {                                                             \
-      step_env(*s, s->env[i], action + (size_t)i * 12, donef ? donef[i] : 0,                        \
+      step_env(*s, s->env[i], action + (size_t)i * (s->cfg.motor_mode == 2 ? ETG_HYBRID_DIM : 12), donef ? donef[i] : 0,                        \
                obs + (size_t)i * ETG_OBS_DIM, reward + i, done + i,                                 \
                info ? info + (size_t)i * ETG_INFO_DIM : (T*)nullptr);                               \
     });                                                                                             \
@@ -1091,6 +1100,11 @@ template <class F> void par_for(int n, int threads, F f) {
   extern "C" void etgo_pd_torque##SFX(const T* qdes, const T* q, const T* qd, const T* kp,          \
                                        const T* kd, int n, T* tau) {                                \
     for (int j = 0; j < n; j++) tau[j] = -(kp[j] * (q[j] - qdes[j])) - kd[j] * qd[j];               \
+  }                                                                                                 \
+  /* HYBRID command (laikago_motor.py:152-167): cmd = 12 x (q_des, kp, qd_des, kd, tau_ff) */      \
+  extern "C" void etgo_pd_torque_hybrid##SFX(const T* cmd, const T* q, const T* qd, int n, T* tau) { \
+    for (int j = 0; j < n; j++)                                                                     \
+      tau[j] = (-(cmd[5 * j + 1] * (q[j] - cmd[5 * j])) - cmd[5 * j + 3] * (qd[j] - cmd[5 * j + 2])) + cmd[5 * j + 4]; \
   }                                                                                                 \
   /* policy forward: model/mujoco_model.py:53-57 + alg/sac.py:60-63 */                              \
   extern "C" void etgo_mlp_forward##SFX(const T* obs, int n, int in_dim, int hid, int out_dim,      \

@@ -103,7 +103,7 @@ class OracleSim:
         return obs
 
     def step(self, action, donef=None, want_info=True):
-        action = self._arr(action, (self.N, 12))
+        action = self._arr(action, (self.N, 60 if self.cfg.motor_mode == 2 else 12))
         obs = np.zeros((self.N, A.OBS_DIM), dtype=self.dtype)
         rew = np.zeros(self.N, dtype=self.dtype)
         done = np.zeros(self.N, dtype=np.uint8)
@@ -184,6 +184,15 @@ def pd_torque(qdes, q, qd, kp, kd, dtype=np.float64):
     arrs = [np.ascontiguousarray(a, dtype=dtype) for a in (qdes, q, qd, kp, kd)]
     out = np.zeros(len(arrs[0]), dtype=dtype)
     getattr(lib(), "etgo_pd_torque" + sfx)(*[_p(a) for a in arrs], len(out), _p(out))
+    return out
+
+
+def pd_torque_hybrid(cmd, q, qd, dtype=np.float64):
+    """HYBRID motor command (laikago_motor.py:152-167): cmd[60] = 12 x (q_des, kp, qd_des, kd, tau_ff)."""
+    sfx = "64" if np.dtype(dtype) == np.float64 else "32"
+    arrs = [np.ascontiguousarray(a, dtype=dtype) for a in (cmd, q, qd)]
+    out = np.zeros(12, dtype=dtype)
+    getattr(lib(), "etgo_pd_torque_hybrid" + sfx)(*[_p(a) for a in arrs], 12, _p(out))
     return out
 
 

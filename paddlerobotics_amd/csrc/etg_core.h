@@ -179,11 +179,11 @@ template <class F> ETG_HD void bwd6(const F* L, F* b) {  // b <- L^-T b
 
 // per-lane constants of a physics tick, fetched from the LDS parameter column ONCE per kernel (the compiler
 // parks them in AGPRs): a lone wave per SIMD cannot hide the LDS latency of re-reading them every tick
-template <class F> struct TickPar4 { F kp[3], kd[3], sy, m0, mu, link[30]; V3<F> o1, gw; S3<F> I0s; };
+template <class F> struct TickPar4 { F kp[3], kd[3], qd_des[3], tau_ff[3], sy, m0, mu, link[30]; V3<F> o1, gw; S3<F> I0s; };
 template <class F, class Ctx> ETG_HD TickPar4<F> load_tick_par4(const Ctx& c) {
   // tpar: straight from the HBM parameter array into registers (no LDS hop)
   TickPar4<F> t;
-  for (int j = 0; j < 3; j++) { t.kp[j] = c.tpar(PR_KP + j); t.kd[j] = c.tpar(PR_KD + j); }
+  for (int j = 0; j < 3; j++) { t.kp[j] = c.tpar(PR_KP + j); t.kd[j] = c.tpar(PR_KD + j); t.qd_des[j] = F(0.0f); t.tau_ff[j] = F(0.0f); }
   t.sy = c.tpar(PR_SY); t.m0 = c.tpar(PR_M0); t.mu = c.tpar(PR_MU);
   for (int k = 0; k < 30; k++) t.link[k] = c.tpar(PR_LINK + k);
   t.o1 = {c.tpar(PR_O1), c.tpar(PR_O1 + 1), c.tpar(PR_O1 + 2)};
@@ -207,7 +207,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   for (int j = 0; j < 3; j++) {
     F cmd = qdes[j];
     if (K.clip_cmd > 0.0f && !torque_cmd) cmd = fminf_(fmaxf_(cmd, L.q[j] - F(K.clip_cmd)), L.q[j] + F(K.clip_cmd));   // a1.py:439-457
-    F t = torque_cmd ? cmd : -(tp.kp[j] * (L.q[j] - cmd)) - tp.kd[j] * L.qd[j];   // TORQUE mode: pass-through
+    F t = torque_cmd ? cmd : (-(tp.kp[j] * (L.q[j] - cmd)) - tp.kd[j] * (L.qd[j] - tp.qd_des[j])) + tp.tau_ff[j];   // TORQUE mode: pass-through
     if (K.torque_limit > 0.0f) t = fminf_(fmaxf_(t, F(-K.torque_limit)), F(K.torque_limit));
     tau[j] = t;
   }
@@ -671,7 +671,7 @@ ETG_HD FootKin<F> foot_kin(const Ctx& c, const KCfg& K, const LaneState<F>& L) {
 template <class F, class Ctx>
 ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ring, float* ctl,
                          int* ictl, float* legctl, const float* etgp, const F* action, F donef, float* obs, F& reward, F& done,
-                         float* info) {
+                         float* info, const F* hyb = nullptr) {   // hyb[4*j + (kp, qd_des, kd, tau_ff)], HYBRID mode
   int step_count = c.ld_env_i(ictl, IC_STEP);
   int tick = c.ld_env_i(ictl, IC_TICK);
   int has_last = c.ld_env_i(ictl, IC_HAS_LAST);
@@ -679,8 +679,9 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   F etg[3], qdes[3];
   etg_action(c, K, etgp, (float)(step_count + 1) * K.etg_dt, etg);
   const bool torque_cmd = K.motor_mode == 1;
+  const bool hybrid_cmd = K.motor_mode == 2 && hyb != nullptr;
 #pragma unroll
-  for (int j = 0; j < 3; j++) qdes[j] = torque_cmd ? action[j] : c.par(PR_POSE + j) + etg[j] + action[j];
+  for (int j = 0; j < 3; j++) qdes[j] = (torque_cmd || hybrid_cmd) ? action[j] : c.par(PR_POSE + j) + etg[j] + action[j];
   if (K.enable_filter) {  // action_filter.py:111-120, order 2
 #pragma unroll
     for (int j = 0; j < 3; j++) {
@@ -704,7 +705,9 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   const int n_lat = c.uniform_int(c.par(PR_LAT_N));
   const int R_ = K.action_repeat;
   const float inv_repeat = 1.0f / (float)K.action_repeat;
-  const TickPar4<F> tp = load_tick_par4<F>(c);
+  TickPar4<F> tp = load_tick_par4<F>(c);
+  if (hybrid_cmd)
+    for (int j = 0; j < 3; j++) { tp.kp[j] = hyb[4 * j]; tp.qd_des[j] = hyb[4 * j + 1]; tp.kd[j] = hyb[4 * j + 2]; tp.tau_ff[j] = hyb[4 * j + 3]; }
   V3<F> fext = {F(0.0f), F(0.0f), F(0.0f)};
   if (K.ext_force) fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
   const int mlat = n_lat < 0 ? 0 : n_lat % R_;

@@ -74,7 +74,7 @@ template <class F, class Ctx> ETG_HD SV<F> quad_bcast(const Ctx& c, SV<F> v, int
 // per-lane constants of a physics tick, read from the LDS parameter column ONCE per kernel and kept in
 // registers over the 13 (step) / 500 (settle) ticks: a lone wave per SIMD cannot hide the LDS latency of
 // re-reading them at the top of every tick (phase profile: +~1000 cycles per tick)
-template <class F> struct TickPar { F kp, kd, sy, m0, mu, link[10]; V3<F> o1, gw, fext; S3<F> I0s; };
+template <class F> struct TickPar { F kp, kd, qd_des, tau_ff, sy, m0, mu, link[10]; V3<F> o1, gw, fext; S3<F> I0s; };
 template <class F, class Ctx> ETG_HD TickPar<F> load_tick_par(const Ctx& c) {
   TickPar<F> t;
   // tpar*: straight from the HBM parameter array into registers (no LDS hop) -- issued at kernel start, consumed in
@@ -85,6 +85,7 @@ template <class F, class Ctx> ETG_HD TickPar<F> load_tick_par(const Ctx& c) {
   t.gw = {c.tpar(PR_G), c.tpar(PR_G + 1), c.tpar(PR_G + 2)};
   t.I0s = {c.tpar(PR_I0), c.tpar(PR_I0 + 1), c.tpar(PR_I0 + 2), c.tpar(PR_I0 + 3), c.tpar(PR_I0 + 4), c.tpar(PR_I0 + 5)};
   t.fext = {F(0.0f), F(0.0f), F(0.0f)};   // external trunk force (world frame); control_step16 fills it in
+  t.qd_des = F(0.0f); t.tau_ff = F(0.0f); // HYBRID motor commands only (laikago_motor.py:152-167)
   return t;
 }
 
@@ -124,7 +125,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
 
   // ---- PD motor model (laikago_motor.py:165-173), this lane's joint
   if (K.clip_cmd > 0.0f && !torque_cmd) qdes = fminf_(fmaxf_(qdes, L.q - F(K.clip_cmd)), L.q + F(K.clip_cmd));   // a1.py:439-457
-  F tau = torque_cmd ? mj * qdes : mj * (-(tp.kp * (L.q - qdes)) - tp.kd * L.qd);   // TORQUE mode: pass-through
+  F tau = torque_cmd ? mj * qdes : mj * ((-(tp.kp * (L.q - qdes)) - tp.kd * (L.qd - tp.qd_des)) + tp.tau_ff);   // TORQUE mode: pass-through
   if (K.torque_limit > 0.0f) tau = fminf_(fmaxf_(tau, F(-K.torque_limit)), F(K.torque_limit));
 
   // ---- leg geometry, this lane's link frame R_s = Rx(a) Ry(theta_s), theta = (0, h, h+k)
@@ -517,14 +518,16 @@ ETG_HD void write_obs16(const Ctx& c, const KCfg& K, const State16<F>& L, const 
 // ------------------------------------------------------------------ one control step (env.step), 16 lanes per robot
 template <class F, class Ctx>
 ETG_HD void control_step16(const Ctx& c, const KCfg& K, State16<F>& L, float* ring, float* ctl, int* ictl, float* legctl,
-                           const float* etgp, F action, F donef, float* obs, F& reward, F& done, float* info) {
+                           const float* etgp, F action, F donef, float* obs, F& reward, F& done, float* info,
+                           const F* hyb = nullptr) {   // hyb: (kp, qd_des, kd, tau_ff) of this lane's motor, HYBRID mode
   int step_count = c.ld_env_i(ictl, IC_STEP);
   int tick = c.ld_env_i(ictl, IC_TICK);
   int has_last = c.ld_env_i(ictl, IC_HAS_LAST);
   const F mj = c.jointf();
   F etg = etg_action16<F>(c, K, etgp, (float)(step_count + 1) * K.etg_dt);
   const bool torque_cmd = K.motor_mode == 1;
-  F qdes = torque_cmd ? mj * action : mj * (c.par_joint(PR_POSE) + etg + action);
+  const bool hybrid_cmd = K.motor_mode == 2 && hyb != nullptr;
+  F qdes = (torque_cmd || hybrid_cmd) ? mj * action : mj * (c.par_joint(PR_POSE) + etg + action);
   if (K.enable_filter) {
     F x0 = c.ld_joint(legctl, LC_FX0), x1 = c.ld_joint(legctl, LC_FX1);
     F y0 = c.ld_joint(legctl, LC_FY0), y1 = c.ld_joint(legctl, LC_FY1);
@@ -548,6 +551,7 @@ ETG_HD void control_step16(const Ctx& c, const KCfg& K, State16<F>& L, float* ri
   const int ib = n_lat < 0 ? ia : (ia == 0 ? R_ - 1 : ia - 1);
   TickPar<F> tp = load_tick_par<F>(c);
   if (K.ext_force) tp.fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
+  if (hybrid_cmd) { tp.kp = hyb[0]; tp.qd_des = mj * hyb[1]; tp.kd = hyb[2]; tp.tau_ff = mj * hyb[3]; }
   for (int i = 0; i < K.action_repeat; i++) {
     float lerp = (float)(i + 1) * inv_repeat;
     F proc = interp ? last + F(lerp) * (qdes - last) : qdes;

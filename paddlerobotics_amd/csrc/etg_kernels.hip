@@ -221,9 +221,14 @@ __global__ void __launch_bounds__(BLOCK) k_step(KCfg K, DevState D, const float*
   __shared__ float lds_par[PR_N * BLOCK];
   stage_params(c, D, lds_par);
   LaneState<float> L = load_state<float>(c, D.base, D.leg);
-  float act[3];
+  float act[3], hyb[12];
+  const bool hybrid = K.motor_mode == 2 && action;   // rows of 60: per motor (q_des, kp, qd_des, kd, tau_ff)
 #pragma unroll
-  for (int j = 0; j < 3; j++) act[j] = action ? c.ld_row_lane(action, ETG_ACT_DIM, j, 3) : 0.0f;
+  for (int j = 0; j < 3; j++) {
+    act[j] = !action ? 0.0f : hybrid ? c.ld_row_lane(action, ETG_HYBRID_DIM, 5 * j, 15) : c.ld_row_lane(action, ETG_ACT_DIM, j, 3);
+#pragma unroll
+    for (int k = 0; k < 4; k++) hyb[4 * j + k] = hybrid ? c.ld_row_lane(action, ETG_HYBRID_DIM, 5 * j + 1 + k, 15) : 0.0f;
+  }
   float r, d;
 #ifdef ETG_PROFILE_PHASES
   for (int k = 0; k < 16; k++) c.prof[k] = 0;
@@ -231,7 +236,7 @@ __global__ void __launch_bounds__(BLOCK) k_step(KCfg K, DevState D, const float*
   long long t_begin = c.prof_last;
 #endif
   control_step(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, act, donef ? (float)donef[c.env] : 0.0f, obs, r, d,
-               info);
+               info, hybrid ? hyb : nullptr);
   store_state(c, D.base, D.leg, L);
 #ifdef ETG_PROFILE_PHASES
   if (c.gid == 0 && info) {  // overwrite the first info row with the cycle breakdown (debug build only)
@@ -349,6 +354,8 @@ struct GpuCtx16 {
   __device__ __forceinline__ float ld_ring_joint(const float* rg, int slot, int k0) const { return rg[((size_t)slot * 8 + k0 + sc) * NL + col]; }
   __device__ __forceinline__ float ld_ring_k(const float* rg, int slot, int k) const { return rg[((size_t)slot * 8 + k) * NL + col]; }
   __device__ __forceinline__ float ld_row_joint(const float* p, int rowlen, int col0) const { return sub < 3 ? p[(size_t)env * rowlen + col0 + 3 * leg + sub] : 0.0f; }
+  // element k of this lane's motor in rows of `stride` values per motor (HYBRID commands: stride 5)
+  __device__ __forceinline__ float ld_row_motor(const float* p, int rowlen, int stride, int k) const { return sub < 3 ? p[(size_t)env * rowlen + stride * (3 * leg + sub) + k] : 0.0f; }
   __device__ __forceinline__ void st_row_joint(float* p, int rowlen, int col0, float v) const { if (sub < 3) p[(size_t)env * rowlen + col0 + 3 * leg + sub] = v; }
   __device__ __forceinline__ void st_row_leg(float* p, int rowlen, int col0, float v) const { if (sub == 0) p[(size_t)env * rowlen + col0 + leg] = v; }
   __device__ __forceinline__ void st_row_env(float* p, int rowlen, int c_, float v) const { if (r == 0) p[(size_t)env * rowlen + c_] = v; }
@@ -429,14 +436,19 @@ __global__ void __launch_bounds__(BLOCK) k_step16(KCfg K, DevState D, const floa
   GpuCtx16T<FLAT> c;
   if (!make_ctx16(K, D, c, lds_par)) return;
   State16<float> L = load_state16<float>(c, D.base, D.leg);
-  float act = action ? c.ld_row_joint(action, ETG_ACT_DIM, 0) : 0.0f;
+  const bool hybrid = K.motor_mode == 2 && action;   // rows of 60: per motor (q_des, kp, qd_des, kd, tau_ff)
+  float act = !action ? 0.0f : hybrid ? c.ld_row_motor(action, ETG_HYBRID_DIM, 5, 0) : c.ld_row_joint(action, ETG_ACT_DIM, 0);
+  float hyb[4];
+#pragma unroll
+  for (int k = 0; k < 4; k++) hyb[k] = hybrid ? c.ld_row_motor(action, ETG_HYBRID_DIM, 5, 1 + k) : 0.0f;
   float r, d;
 #ifdef ETG_PROFILE_PHASES
   for (int k = 0; k < 16; k++) c.prof[k] = 0;
   c.prof_last = clock64();
   long long t_begin = c.prof_last;
 #endif
-  control_step16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, act, donef ? (float)donef[c.env] : 0.0f, obs, r, d, info);
+  control_step16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, act, donef ? (float)donef[c.env] : 0.0f, obs, r, d, info,
+                 hybrid ? hyb : nullptr);
   store_state16(c, D.base, D.leg, L);
 #ifdef ETG_PROFILE_PHASES
   if (c.env == 0 && c.r == 0 && info) {
@@ -712,6 +724,7 @@ extern "C" int etg_step(EtgHandle* h, const float* action, const uint8_t* donef,
   CHECK_HANDLE(h);
   if (!obs || !reward || !done) return fail(ETG_ERR_BAD_ARG, "etg_step: obs/reward/done must be non-null");
   if (!h->was_reset) return fail(ETG_ERR_STATE, "etg_step: call etg_reset first");
+  if (h->K.motor_mode == 2 && !action) return fail(ETG_ERR_BAD_ARG, "etg_step: the HYBRID motor mode needs a [N,60] command");
   const dim3 g16((h->N + 3) / 4);
   if (h->lanes == 16) {
     if (h->K.terrain == 0)

@@ -145,8 +145,10 @@ class BatchedQuadrupedEnv:
             motor_mode = 0
         elif mname in ("torque", "TORQUE", 2):
             motor_mode = 1
+        elif mname in ("hybrid", "HYBRID", 3):
+            motor_mode = 2          # the action is the 60-vector of laikago_motor.py:152-161
         else:
-            raise NotImplementedError("motor_control_mode %r: POSITION and TORQUE are simulated (HYBRID is not)" % (motor_control_mode,))
+            raise NotImplementedError("motor_control_mode %r: POSITION, TORQUE and HYBRID exist" % (motor_control_mode,))
         self.motor_mode = motor_mode
         self._cols = sensor_columns(sensor_mode)
         # observation history (ObservationWrapper, deployment/envs/EnvWrapper.py:195-238): the current reading
@@ -189,7 +191,7 @@ class BatchedQuadrupedEnv:
         else:
             shape = (d,)
         self.observation_space = Box(-np.inf, np.inf, shape)
-        self.action_space = Box(-1.0, 1.0, (A.NUM_MOTORS,))
+        self.action_space = Box(-1.0, 1.0, (60 if motor_mode == 2 else A.NUM_MOTORS,))
         self._lib = _lib.load()
         self._h = C.c_void_p()
         idx = self.device.index if self.device.index is not None else torch.cuda.current_device()
@@ -364,7 +366,7 @@ class BatchedQuadrupedEnv:
                                                C.c_float(self._rf_range[1]), self._stream()))
 
     def step(self, action, donef=None, want_info=True):
-        a = None if action is None else self._f32(action, (self.num_envs, A.NUM_MOTORS), "action")   # NULL = zero residual
+        a = None if action is None else self._f32(action, (self.num_envs, self.action_space.shape[0]), "action")   # NULL = zero residual
         df = None
         if donef is not None:
             if isinstance(donef, (bool, int, np.bool_)):

@@ -119,6 +119,7 @@ struct EmuCtx16Base {
   void st_ring_aux(float* rg, int slot, int k, F16 v) const { for (int r = 3; r < 16; r += 4) rg[((size_t)slot * 8 + k) * NL() + col(r)] = v.v[r]; }
   F16 ld_ring_joint(const float* rg, int slot, int k0) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = rg[((size_t)slot * 8 + k0 + sc(r)) * NL() + col(r)]; return o; }
   F16 ld_ring_k(const float* rg, int slot, int k) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = rg[((size_t)slot * 8 + k) * NL() + col(r)]; return o; }
+  F16 ld_row_motor(const float* p, int rowlen, int stride, int k) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = sub(r) < 3 ? p[(size_t)env * rowlen + stride * (3 * leg(r) + sub(r)) + k] : 0.f; return o; }
   F16 ld_row_joint(const float* p, int rowlen, int col0) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = sub(r) < 3 ? p[(size_t)env * rowlen + col0 + 3 * leg(r) + sub(r)] : 0.f; return o; }
   void st_row_joint(float* p, int rowlen, int col0, F16 v) const { for (int r = 0; r < 16; r++) if (sub(r) < 3) p[(size_t)env * rowlen + col0 + 3 * leg(r) + sub(r)] = v.v[r]; }
   void st_row_leg(float* p, int rowlen, int col0, F16 v) const { for (int r = 0; r < 16; r += 4) p[(size_t)env * rowlen + col0 + leg(r)] = v.v[r]; }
@@ -228,14 +229,22 @@ extern "C" void emu_step(void* h, const float* action, const uint8_t* donef, flo
       if (e->K.terrain == 0) {
         EmuCtx16T<true> c(i, e->N, e->par.data());
         State16<F16> S = load_state16<F16>(c, e->base.data(), e->leg.data());
+        const bool hybrid = e->K.motor_mode == 2;
+        F16 hyb[4];
+        for (int k = 0; k < 4; k++) hyb[k] = hybrid ? c.ld_row_motor(action, ETG_HYBRID_DIM, 5, 1 + k) : F16(0.0f);
         control_step16(c, e->K, S, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(),
-                       c.ld_row_joint(action, 12, 0), dn, obs, r16, d16, info);
+                       hybrid ? c.ld_row_motor(action, ETG_HYBRID_DIM, 5, 0) : c.ld_row_joint(action, 12, 0), dn, obs, r16, d16,
+                       info, hybrid ? hyb : nullptr);
         store_state16(c, e->base.data(), e->leg.data(), S);
       } else {
         EmuCtx16T<false> c(i, e->N, e->par.data());
         State16<F16> S = load_state16<F16>(c, e->base.data(), e->leg.data());
+        const bool hybrid = e->K.motor_mode == 2;
+        F16 hyb[4];
+        for (int k = 0; k < 4; k++) hyb[k] = hybrid ? c.ld_row_motor(action, ETG_HYBRID_DIM, 5, 1 + k) : F16(0.0f);
         control_step16(c, e->K, S, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(),
-                       c.ld_row_joint(action, 12, 0), dn, obs, r16, d16, info);
+                       hybrid ? c.ld_row_motor(action, ETG_HYBRID_DIM, 5, 0) : c.ld_row_joint(action, 12, 0), dn, obs, r16, d16,
+                       info, hybrid ? hyb : nullptr);
         store_state16(c, e->base.data(), e->leg.data(), S);
       }
       reward[i] = r16.v[0];
@@ -244,16 +253,20 @@ extern "C" void emu_step(void* h, const float* action, const uint8_t* donef, flo
     }
     EmuCtx c0(i, e->N, e->par.data());
     LaneState<F4> L = load_state<F4>(c0, e->base.data(), e->leg.data());
-    F4 act[3];
-    for (int j = 0; j < 3; j++) act[j] = c0.ld_row_lane(action, 12, j, 3);
+    F4 act[3], hyb[12];
+    const bool hybrid = e->K.motor_mode == 2;
+    for (int j = 0; j < 3; j++) {
+      act[j] = hybrid ? c0.ld_row_lane(action, ETG_HYBRID_DIM, 5 * j, 15) : c0.ld_row_lane(action, 12, j, 3);
+      for (int k = 0; k < 4; k++) hyb[4 * j + k] = hybrid ? c0.ld_row_lane(action, ETG_HYBRID_DIM, 5 * j + 1 + k, 15) : F4(0.0f);
+    }
     F4 r, d;
     if (e->K.terrain == 0) {
       EmuCtxT<true> c(i, e->N, e->par.data());
       control_step(c, e->K, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), act,
-                   F4(donef ? (float)donef[i] : 0.f), obs, r, d, info);
+                   F4(donef ? (float)donef[i] : 0.f), obs, r, d, info, hybrid ? hyb : nullptr);
     } else {
       control_step(c0, e->K, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), act,
-                   F4(donef ? (float)donef[i] : 0.f), obs, r, d, info);
+                   F4(donef ? (float)donef[i] : 0.f), obs, r, d, info, hybrid ? hyb : nullptr);
     }
     store_state(c0, e->base.data(), e->leg.data(), L);
     reward[i] = r.v[0];

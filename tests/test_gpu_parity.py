@@ -507,7 +507,35 @@ def test_torque_mode_matches_oracle():
     err = np.abs(sg[:, 13:25] - so[:, 13:25]).max(1)
     assert np.median(err) < 2e-3 and err.max() < 2e-2
     with pytest.raises(NotImplementedError):
-        _make(n, motor_control_mode="hybrid")
+        _make(n, motor_control_mode="pwm")
+    env.close()
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_hybrid_mode_matches_oracle(lanes):
+    """motor_control_mode='hybrid': 60-float commands 12 x (q_des, kp, qd_des, kd, tau_ff), laikago_motor.py:152-167"""
+    _need_gpu()
+    n = 16
+    env = _make(n, motor_control_mode="hybrid", solver_iters=4, lanes_per_robot=lanes)
+    orc = _oracle(n, solver_iters=4, motor_mode=2)
+    assert env.action_space.shape == (60,)
+    env.reset(); orc.reset()
+    rng = np.random.default_rng(4)
+    for _ in range(4):
+        cmd = np.zeros((n, 60))
+        cmd[:, 0::5] = A.INIT_MOTOR_ANGLES + rng.normal(size=(n, 12)) * 0.05
+        cmd[:, 1::5] = rng.uniform(60, 120, size=(n, 12))
+        cmd[:, 2::5] = rng.normal(size=(n, 12)) * 0.2
+        cmd[:, 3::5] = rng.uniform(0.5, 2.5, size=(n, 12))
+        cmd[:, 4::5] = rng.normal(size=(n, 12)) * 0.5
+        env.step(torch.as_tensor(cmd, dtype=torch.float32))
+        orc.step(cmd)
+    sg, so = env.get_state().cpu().numpy(), orc.get_state()
+    err = np.abs(sg[:, 13:25] - so[:, 13:25]).max(1)
+    assert np.median(err) < 1e-3 and err.max() < 1e-2 and np.abs(sg[:, :3] - so[:, :3]).max() < 2e-3
+    from paddlerobotics_amd._lib import EtgError
+    with pytest.raises(EtgError):
+        env.step(None)                      # the hybrid mode has no "zero residual" default
     env.close()
 
 

@@ -167,3 +167,36 @@ def test_emulation_clip_motor_commands_matches_oracle(lanes):
         assert np.abs(se[:, 13:25] - so[:, 13:25]).max() < 2e-3
         res[clip] = np.abs(so[:, 13:25] - q0).max()
     assert res[0.2] < 0.8 * res[0.0]
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_emulation_hybrid_mode_matches_oracle(lanes):
+    """motor mode HYBRID: per-motor (q_des, kp, qd_des, kd, tau_ff) commands, laikago_motor.py:152-167"""
+    from oracle.oracle import OracleSim
+    from tests.emu.emu import EmuSim
+    n = 3
+    cfg = A.default_config(n, solver_iters=4, motor_mode=2)
+    orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=lanes)
+    orc.reset(); emu.reset()
+    assert np.abs(emu.get_state()[:, :7] - orc.get_state()[:, :7]).max() < 2e-3
+    rng = np.random.default_rng(2)
+    for k in range(4):
+        cmd = np.zeros((n, 60))
+        cmd[:, 0::5] = A.INIT_MOTOR_ANGLES + rng.normal(size=(n, 12)) * 0.05
+        cmd[:, 1::5] = rng.uniform(60, 120, size=(n, 12))
+        cmd[:, 2::5] = rng.normal(size=(n, 12)) * 0.2
+        cmd[:, 3::5] = rng.uniform(0.5, 2.5, size=(n, 12))
+        cmd[:, 4::5] = rng.normal(size=(n, 12)) * 0.5
+        orc.step(cmd); emu.step(cmd)
+        so, se = orc.get_state(), emu.get_state()
+        assert np.abs(se[:, 13:25] - so[:, 13:25]).max() < 5e-3 and np.abs(se[:, :3] - so[:, :3]).max() < 3e-3
+    assert orc.get_state()[:, 2].min() > 0.2          # the hybrid PD holds the stance
+    # with the model's own gains and zero feed-forward the HYBRID command reproduces the POSITION mode
+    pos = OracleSim(A.default_config(1, solver_iters=4)); hyb = OracleSim(A.default_config(1, solver_iters=4, motor_mode=2))
+    pos.reset(); hyb.reset()
+    for k in range(3):
+        _, _, _, info = pos.step(np.zeros((1, 12)))
+        qdes = info[0, A.INFO_SLICES["real_action"][0]:A.INFO_SLICES["real_action"][1]]
+        cmd = np.zeros((1, 60)); cmd[0, 0::5] = qdes; cmd[0, 1::5] = 80.0; cmd[0, 3::5] = [1., 2., 2.] * 4
+        hyb.step(cmd)
+        assert np.abs(hyb.get_state() - pos.get_state()).max() < 1e-9
