@@ -1,7 +1,7 @@
 // etg_core16.h -- the same env.step()/reset() math as etg_core.h, mapped ONE ROBOT = ONE DPP ROW.
 //
 // Why a second mapping: with one wave per busy SIMD a wave issues one VALU instruction per
-// 4 cycles, so a control step costs (instructions per lane) x 4 cycles, and at the headline size
+// ~4-5 cycles, so a control step costs (instructions per lane) x ~4.5 cycles, and at the headline size
 // (4096 robots) the 4-lanes-per-robot kernel only occupies 256 of the chip's 1024 SIMDs
 // (DESIGN.md "what bounds the kernel").  Here a robot is the 16 lanes of one DPP row:
 //     lane r = 4*leg + sub,   leg = the quad inside the row,   sub = 0,1,2,3
@@ -11,8 +11,8 @@
 // Chain recursions (velocity/acceleration prefix, composite force/inertia suffix) are 2-step
 // quad_perm scans, leg-level gathers are quad_perm broadcasts, robot-level reductions are 4-step
 // row butterflies (quad xor1, xor2, row_half_mirror, row_mirror), the sequential contact solve
-// broadcasts one row's impulse change with row_newbcast, and the Delassus blocks are
-// v_mfma_f32_4x4x1 outer products between a quad and a leg-rotated copy of the row (row_ror).
+// broadcasts one row's impulse change with row_newbcast, and the Delassus row of a lane is 72
+// fused broadcast-FMAs (v_fmac_f32_dpp row_newbcast) against the row's Z vectors.
 // State lives in the same HBM arrays as the 4-lane kernel (etg_layout.h), so both kernels are
 // interchangeable on one handle.
 #pragma once

@@ -1,12 +1,15 @@
 // etg_kernels.hip -- gfx950 kernels + C-ABI of the batched A1 simulator (include/etgsim.h).
 //
-// One robot = one quad of lanes (etg_core.h).  A workgroup is ONE wave64 = 16 robots:
-// at the headline size (4096 robots) that is 256 workgroups, one per CU, so the launch
-// spreads over all 8 XCDs; nothing is shared between workgroups, so no XCD-aware remap
-// is needed.  Quad reductions/broadcasts are DPP quad_perm moves, the contact operator's
-// 4x4 blocks are v_mfma_f32_4x4x1, and LDS holds each lane's private parameter column
-// (no barriers anywhere).  State is SoA in HBM (etg_layout.h), so every global access of
-// a wave is one contiguous 256-B segment per field.
+// Two lane mappings of the same algorithm over one HBM state layout (etg_layout.h):
+//   k_step16 / k_settle16 / k_finish16 (etg_core16.h): one robot = one 16-lane DPP row, a wave64 = 4 robots;
+//       4096 robots = 1024 single-wave workgroups = one wave on every SIMD (the default up to 4096 robots);
+//   k_step / k_settle / k_finish (etg_core.h): one robot = one quad (one leg per lane), a wave64 = 16 robots
+//       (bigger batches).
+// Workgroups are remapped so that each XCD owns a contiguous range of robots (xcd_contiguous_block).  Reductions
+// and broadcasts are DPP moves (quad_perm, row butterflies, row_newbcast), fused into the consuming ALU op where
+// possible (v_add_f32_dpp by the compiler, v_fmac_f32_dpp by inline asm); the 4-lane contact operator's 4x4
+// blocks are v_mfma_f32_4x4x1.  LDS holds each lane's private per-step parameter column (no barriers anywhere);
+// the per-tick constants go straight from HBM to registers.  A reset restores the cached 500-tick settle.
 #include <hip/hip_runtime.h>
 
 #include <string>
