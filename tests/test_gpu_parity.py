@@ -714,3 +714,25 @@ def test_observation_history_stack_follows_the_reference_wrapper():
     assert np.all(got[2, :T] == 0) and np.array_equal(got[2, T], o[2])
     assert np.array_equal(got[0, T], o[0]) and np.any(got[0, :T] != 0)
     plain.close(); hist.close(); gru.close()
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_short_control_latency_reads_this_steps_ring_slots(lanes):
+    """control_latency shorter than one control step (and zero): the delayed observation blends ring slots that
+    were written by other lanes earlier in the SAME kernel launch."""
+    _need_gpu()
+    n = 12
+    W, B = _etg_params(n, seed=8)
+    dyn = np.tile(A.default_dynamic_row(), (n, 1))
+    dyn[:, 0] = [0.0, 1.0, 2.0, 3.0, 4.5, 7.0, 11.0, 19.0, 25.0, 26.0, 27.5, 40.0]      # ms; 2 ms ticks, 26 ms steps
+    env, orc = _make(n, lanes_per_robot=lanes, solver_iters=4), _oracle(n, solver_iters=4)
+    env.set_dynamic_param(dyn)
+    orc.set_params(dyn=dyn, etg_w=W, etg_b=B)
+    obs_g = env.reset(ETG_w=W, ETG_b=B)[0].cpu().numpy()
+    obs_o = orc.reset()
+    assert np.abs(obs_g - obs_o).max() < 2e-2
+    for _ in range(4):
+        og = env.step(None)[0].cpu().numpy()
+        oo = orc.step(np.zeros((n, 12)))[0]
+        assert np.abs(og - oo).max() < 5e-2, np.abs(og - oo).max(1)
+    env.close()
