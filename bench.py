@@ -29,14 +29,16 @@ from paddlerobotics_amd.etg_fit import opt_with_points_batched  # noqa: E402
 
 SOLVER_ITERS = 2           # library default (K=2 vs K=50 differ by <0.4 mm after 5 m)
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
-# HBM bytes per step-kernel launch at N = 4096 from the PMC counters (profiles/r01_pmc_k_step16.txt
-# and r01_pmc_k_step_lanes4.txt: FETCH_SIZE + WRITE_SIZE, separate passes, KB units; dword accesses,
-# uncalibrated width -- see DESIGN.md section 7).  Scaled linearly with N for other batch sizes.
-PMC_TRAFFIC_BYTES_AT_4096 = {16: (3978.5 + 3076.0) * 1024.0, 4: (4010.5 + 3076.0) * 1024.0}
-# VALU instructions one wave issues per step-kernel launch (SQ_INSTS_VALU / SQ_WAVES, same PMC files) and the
-# VALU issue capacity of a SIMD measured with tools/ubench/occupancy_rate.hip (8 resident waves of v_fma_f32:
-# 0.384 wave-instructions per SIMD-cycle at the nominal 2.4 GHz; one resident wave reaches 0.172).
-PMC_VALU_PER_WAVE = {16: 21886146.1 / 1024.0, 4: 8008005.8 / 256.0}
+# PMC figures per CONTROL STEP at N = 4096 (profiles/r01_pmc_16lane_kernels.txt, r01_pmc_k_step_lanes4.txt; separate
+# passes, FETCH_SIZE / WRITE_SIZE in KB; dword accesses are a width the guide calls uncalibrated -- DESIGN.md
+# section 7).  k_rollout16 runs 50 control steps per launch, so its launch totals are divided by 50.  Scaled
+# linearly with N for other batch sizes.
+PMC_TRAFFIC_BYTES_AT_4096 = {"k_rollout16": (17553.0 + 30192.0) * 1024.0 / 50.0, "k_step16": (3982.5 + 4100.0) * 1024.0,
+                             "k_step": (4010.5 + 3076.0) * 1024.0}
+# VALU instructions one wave issues per control step (SQ_INSTS_VALU / SQ_WAVES, same files) and the VALU issue
+# capacity of a SIMD measured with tools/ubench/occupancy_rate.hip (8 resident waves of v_fma_f32: 0.384
+# wave-instructions per SIMD-cycle at the nominal 2.4 GHz; one resident wave reaches 0.172).
+PMC_VALU_PER_WAVE = {"k_rollout16": 1072505267.0 / 1024.0 / 50.0, "k_step16": 22040485.5 / 1024.0, "k_step": 8008005.8 / 256.0}
 VALU_PEAK_PER_SIMD_CYCLE = 0.384
 NOMINAL_HZ = 2.4e9
 BYTES_PER_STEP_CFG2 = 816  # 564 B + 252 B per-env ETG w,b
@@ -97,6 +99,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, choices=(0, 4, 16),
                     help="kernel mapping, lanes per robot (0 = library default: 16 up to 4096 robots, else 4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--stepwise", action="store_true",
+                    help="open-loop configs: time env.step() per control step instead of the fused open-loop rollout")
     args = ap.parse_args()
     SOLVER_ITERS = args.solver_iters
 
@@ -158,9 +162,20 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    # Open-loop configs (2, 5): the hot path is the episode loop with zero residual action (run_episode,
+    # pretrain.py:129-154), whose batched counterpart is etg_rollout_openloop -- up to 50 control steps per launch with
+    # state, control variables and tick constants in registers.  Config 3 needs the policy between steps, so it
+    # (and --stepwise) goes through env.step() once per control step.
+    fused = policy is None and not args.stepwise
     barrier()
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    if fused:
+        ev = ev[:1]
+        EVENT_SPAN = args.steps                               # one event pair around the K fused steps
+        ev[0][0].record()
+        env.rollout_openloop(args.steps)
+        ev[0][1].record()
+    for k in range(0 if fused else args.steps):
         slot, phase = divmod(k, EVENT_EVERY)
         if policy is not None:
             if phase == 8 and slot < len(evp):               # the policy kernel is timed on other steps than the dynamics
@@ -187,11 +202,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kern_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in ev])) / EVENT_SPAN if ev else float("nan")
+    survivors = float((length == args.steps + args.warmup).float().mean().item())
+    stepwise = None
+    if fused:   # for reference, not part of `value`: the same K steps through env.step(), one launch per control step
+        barrier()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            env.step(None, want_info=False)
+        barrier()
+        dt1 = time.perf_counter() - t1
+        stepwise = {"value": world * N * args.steps / dt1, "ms_per_step": dt1 / args.steps * 1e3,
+                    "note": "env.step() per control step (k_step16), the closed-loop-capable API"}
 
     if rank == 0:
         total_steps = world * N * args.steps
         value = total_steps / elapsed
         bytes_per = BYTES_PER_STEP_CFG3 if args.config == 3 else BYTES_PER_STEP_CFG2
+        kname = ("k_rollout16" if fused else "k_step16") if lanes == 16 else "k_step"
         achieved = bytes_per * N / (kern_ms * 1e-3)
         out = {
             "metric": "env-steps/sec, 4096 A1 quadrupeds; 1/2/4/8-GPU scaling",
@@ -206,19 +233,24 @@ def main():
                         "precision %d)" % (N, args.precision)),
                        "robots_per_gpu": N, "action_repeat": 13, "sim_dt": 0.002, "solver_iters": args.solver_iters, "lanes_per_robot": lanes,
                        "parallelism": "env-shard x%d" % world},
-            "roofline": {"bound": "hbm", "kernel": "etg::k_step16" if lanes == 16 else "etg::k_step", "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
+            "path": ("etg_rollout_openloop: fused kernel, up to 50 control steps per launch" if fused and lanes == 16 else
+                     "etg_rollout_openloop: one step kernel per control step" if fused else "env.step per control step"),
+            "roofline": {"bound": "hbm", "kernel": "etg::" + kname, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                         "traffic": PMC_TRAFFIC_BYTES_AT_4096[lanes] * N / 4096.0,
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_env_step": bytes_per,
+                         "traffic": PMC_TRAFFIC_BYTES_AT_4096[kname] * N / 4096.0,
+                         "kernel_ms": kern_ms, "kernel_ms_is": "per control step" if fused else "per launch",
+                         "algorithmic_bytes_per_env_step": bytes_per,
                          # the ceiling that actually binds: VALU issue of one wave per SIMD
-                         "valu_issue": {"achieved": PMC_VALU_PER_WAVE[lanes] / (kern_ms * 1e-3 * NOMINAL_HZ),
+                         "valu_issue": {"achieved": PMC_VALU_PER_WAVE[kname] / (kern_ms * 1e-3 * NOMINAL_HZ),
                                         "peak": VALU_PEAK_PER_SIMD_CYCLE, "unit": "wave-instr/SIMD-cycle @2.4GHz",
-                                        "frac": PMC_VALU_PER_WAVE[lanes] / (kern_ms * 1e-3 * NOMINAL_HZ) / VALU_PEAK_PER_SIMD_CYCLE,
+                                        "frac": PMC_VALU_PER_WAVE[kname] / (kern_ms * 1e-3 * NOMINAL_HZ) / VALU_PEAK_PER_SIMD_CYCLE,
                                         "single_wave_limit": 0.172} if N * lanes <= 1024 * 64 else None,
                          "note": "VALU-issue-bound by construction (~1e3 FLOP/B, SURVEY 8d): one wave per SIMD, "
                                  "1 VALU issue / 4 cycles; see DESIGN.md section 7"},
-            "survivors": float((length == args.steps + args.warmup).float().mean().item()),
+            "survivors": survivors,
         }
+        if stepwise is not None:
+            out["stepwise"] = stepwise
         out["roofline"]["hbm_copy_measured_GBps"] = device_copy_bandwidth(dev) / 1e9
         if evp and args.steps > 8:
             pol_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in evp if True]))

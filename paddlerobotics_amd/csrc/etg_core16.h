@@ -484,17 +484,9 @@ template <class F, class Ctx> ETG_HD FootKin16<F> foot_kin16(const Ctx& c, const
 
 // observation (EnvWrapper.py:60-109), same 49-float row as write_obs()
 template <class F, class Ctx>
-ETG_HD void write_obs16(const Ctx& c, const KCfg& K, const State16<F>& L, const float* ring, int tick, float* ctl, F etg,
-                        F lbx, F lby, F lbz, bool set_first, float* obs, F* imu) {
-  Delayed16<F> D = ring_read16<F>(c, ring, tick);
+ETG_HD void write_obs16(const Ctx& c, const KCfg& K, const State16<F>& L, const Delayed16<F>& D, F r0, F r1, F r2, F etg,
+                        F lbx, F lby, F lbz, float* obs, F* imu) {
   V3<F> rpy = quat_rpy(D.qx, D.qy, D.qz, D.qw);
-  F r0, r1, r2;
-  if (set_first) {
-    r0 = rpy.x; r1 = rpy.y; r2 = rpy.z;
-    c.st_env(ctl, CT_FIRST_RPY + 0, r0); c.st_env(ctl, CT_FIRST_RPY + 1, r1); c.st_env(ctl, CT_FIRST_RPY + 2, r2);
-  } else {
-    r0 = c.ld_env(ctl, CT_FIRST_RPY + 0); r1 = c.ld_env(ctl, CT_FIRST_RPY + 1); r2 = c.ld_env(ctl, CT_FIRST_RPY + 2);
-  }
   const bool nrm = K.obs_normal != 0;
   const float cdt = K.dt * (float)K.action_repeat;
   F sdis(nrm ? 1.0f / cdt : 1.0f), srpy(nrm ? 10.0f : 1.0f), sdr(nrm ? 2.0f : 1.0f), sqn(nrm ? 10.0f : 1.0f);
@@ -516,31 +508,67 @@ ETG_HD void write_obs16(const Ctx& c, const KCfg& K, const State16<F>& L, const 
 }
 
 // ------------------------------------------------------------------ one control step (env.step), 16 lanes per robot
+// The control-loop variables of a robot that live across steps.  A step kernel loads them once, runs one step
+// (env.step) or several (open-loop rollout) on them in registers, and stores them once.
+template <class F> struct StepCtl16 {
+  int step_count, tick, has_last;
+  F last, lbx, lby, lbz, last_fwx;   // last position command, last base position, last foot x (world)
+  F ret, len, alive;                 // episode accumulators
+  F r0, r1, r2;                      // first rpy reading after reset (EnvWrapper.py:79-84)
+  F fx0, fx1, fy0, fy1;              // action filter history (only with K.enable_filter)
+};
 template <class F, class Ctx>
-ETG_HD void control_step16(const Ctx& c, const KCfg& K, State16<F>& L, float* ring, float* ctl, int* ictl, float* legctl,
-                           const float* etgp, F action, F donef, float* obs, F& reward, F& done, float* info,
-                           const F* hyb = nullptr) {   // hyb: (kp, qd_des, kd, tau_ff) of this lane's motor, HYBRID mode
-  int step_count = c.ld_env_i(ictl, IC_STEP);
-  int tick = c.ld_env_i(ictl, IC_TICK);
-  int has_last = c.ld_env_i(ictl, IC_HAS_LAST);
+ETG_HD StepCtl16<F> load_ctl16(const Ctx& c, const KCfg& K, const float* ctl, const int* ictl, const float* legctl) {
+  StepCtl16<F> S;
+  S.step_count = c.ld_env_i(ictl, IC_STEP);
+  S.tick = c.ld_env_i(ictl, IC_TICK);
+  S.has_last = c.ld_env_i(ictl, IC_HAS_LAST);
+  S.last = c.ld_joint(legctl, LC_LAST_QDES);
+  S.lbx = c.ld_env(ctl, CT_LAST_BASE + 0); S.lby = c.ld_env(ctl, CT_LAST_BASE + 1); S.lbz = c.ld_env(ctl, CT_LAST_BASE + 2);
+  S.last_fwx = c.ld_legf(legctl, LC_LAST_FOOT_X);
+  S.ret = c.ld_env(ctl, CT_RET); S.len = c.ld_env(ctl, CT_LEN); S.alive = c.ld_env(ctl, CT_ALIVE);
+  S.r0 = c.ld_env(ctl, CT_FIRST_RPY + 0); S.r1 = c.ld_env(ctl, CT_FIRST_RPY + 1); S.r2 = c.ld_env(ctl, CT_FIRST_RPY + 2);
+  S.fx0 = S.fx1 = S.fy0 = S.fy1 = F(0.0f);
+  if (K.enable_filter) {
+    S.fx0 = c.ld_joint(legctl, LC_FX0); S.fx1 = c.ld_joint(legctl, LC_FX1);
+    S.fy0 = c.ld_joint(legctl, LC_FY0); S.fy1 = c.ld_joint(legctl, LC_FY1);
+  }
+  return S;
+}
+template <class F, class Ctx>
+ETG_HD void store_ctl16(const Ctx& c, const KCfg& K, const StepCtl16<F>& S, float* ctl, int* ictl, float* legctl) {
+  c.st_env_i(ictl, IC_STEP, S.step_count);
+  c.st_env_i(ictl, IC_TICK, S.tick);
+  c.st_env_i(ictl, IC_HAS_LAST, S.has_last);
+  c.st_joint(legctl, LC_LAST_QDES, S.last);
+  c.st_env(ctl, CT_LAST_BASE + 0, S.lbx); c.st_env(ctl, CT_LAST_BASE + 1, S.lby); c.st_env(ctl, CT_LAST_BASE + 2, S.lbz);
+  c.st_legf(legctl, LC_LAST_FOOT_X, S.last_fwx);
+  c.st_env(ctl, CT_RET, S.ret); c.st_env(ctl, CT_LEN, S.len); c.st_env(ctl, CT_ALIVE, S.alive);
+  if (K.enable_filter) {
+    c.st_joint(legctl, LC_FX0, S.fx0); c.st_joint(legctl, LC_FX1, S.fx1);
+    c.st_joint(legctl, LC_FY0, S.fy0); c.st_joint(legctl, LC_FY1, S.fy1);
+  }
+}
+
+// one env.step on the register-resident control state S and tick constants tp
+template <class F, class Ctx>
+ETG_HD void control_step16_core(const Ctx& c, const KCfg& K, TickPar<F>& tp, State16<F>& L, StepCtl16<F>& S, float* ring,
+                                const float* etgp, F action, F donef, float* obs, F& reward, F& done, float* info,
+                                const F* hyb = nullptr) {   // hyb: (kp, qd_des, kd, tau_ff) of this lane's motor, HYBRID mode
   const F mj = c.jointf();
-  F etg = etg_action16<F>(c, K, etgp, (float)(step_count + 1) * K.etg_dt);
+  F etg = etg_action16<F>(c, K, etgp, (float)(S.step_count + 1) * K.etg_dt);
   const bool torque_cmd = K.motor_mode == 1;
   const bool hybrid_cmd = K.motor_mode == 2 && hyb != nullptr;
   F qdes = (torque_cmd || hybrid_cmd) ? mj * action : mj * (c.par_joint(PR_POSE) + etg + action);
   if (K.enable_filter) {
-    F x0 = c.ld_joint(legctl, LC_FX0), x1 = c.ld_joint(legctl, LC_FX1);
-    F y0 = c.ld_joint(legctl, LC_FY0), y1 = c.ld_joint(legctl, LC_FY1);
-    F y = F(K.fb[0]) * qdes + F(K.fb[1]) * x0 + F(K.fb[2]) * x1 - F(K.fa[1]) * y0 - F(K.fa[2]) * y1;
-    c.st_joint(legctl, LC_FX1, x0); c.st_joint(legctl, LC_FX0, qdes);
-    c.st_joint(legctl, LC_FY1, y0); c.st_joint(legctl, LC_FY0, y);
+    F y = F(K.fb[0]) * qdes + F(K.fb[1]) * S.fx0 + F(K.fb[2]) * S.fx1 - F(K.fa[1]) * S.fy0 - F(K.fa[2]) * S.fy1;
+    S.fx1 = S.fx0; S.fx0 = qdes;
+    S.fy1 = S.fy0; S.fy0 = y;
     qdes = mj * y;
   }
-  F last = c.ld_joint(legctl, LC_LAST_QDES);
-  F lbx = c.ld_env(ctl, CT_LAST_BASE + 0), lby = c.ld_env(ctl, CT_LAST_BASE + 1), lbz = c.ld_env(ctl, CT_LAST_BASE + 2);
-  F last_fwx = c.ld_legf(legctl, LC_LAST_FOOT_X);
+  const F last = S.last, lbx = S.lbx, lby = S.lby, lbz = S.lbz, last_fwx = S.last_fwx;
   L.energy = F(0.0f);
-  const bool interp = K.enable_interp && has_last;
+  const bool interp = K.enable_interp && S.has_last;
   // The observation at the end of the step reads ring slots tick_end - n and tick_end - n - 1 only, so
   // only the ticks that land there are pushed: i == ia or i == ib (one modulo per step, not two per tick).
   const int n_lat = c.uniform_int(c.par(PR_LAT_N));
@@ -549,9 +577,8 @@ ETG_HD void control_step16(const Ctx& c, const KCfg& K, State16<F>& L, float* ri
   const int mlat = n_lat < 0 ? 0 : n_lat % R_;
   const int ia = R_ - 1 - mlat;
   const int ib = n_lat < 0 ? ia : (ia == 0 ? R_ - 1 : ia - 1);
-  TickPar<F> tp = load_tick_par<F>(c);
-  if (K.ext_force) tp.fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
   if (hybrid_cmd) { tp.kp = hyb[0]; tp.qd_des = mj * hyb[1]; tp.kd = hyb[2]; tp.tau_ff = mj * hyb[3]; }
+  int tick = S.tick;
   for (int i = 0; i < K.action_repeat; i++) {
     float lerp = (float)(i + 1) * inv_repeat;
     F proc = interp ? last + F(lerp) * (qdes - last) : qdes;
@@ -559,14 +586,13 @@ ETG_HD void control_step16(const Ctx& c, const KCfg& K, State16<F>& L, float* ri
     tick++;
     if (i == ia || i == ib) ring_push16(c, ring, tick & (RING - 1), L);
   }
-  c.st_joint(legctl, LC_LAST_QDES, qdes);
-  step_count++;
-  c.st_env_i(ictl, IC_STEP, step_count);
-  c.st_env_i(ictl, IC_TICK, tick);
-  c.st_env_i(ictl, IC_HAS_LAST, 1);
+  S.tick = tick;
+  S.last = qdes;
+  S.step_count++;
+  S.has_last = 1;
 
   F imu[6];
-  write_obs16(c, K, L, ring, tick, ctl, etg, lbx, lby, lbz, false, obs, imu);
+  write_obs16(c, K, L, ring_read16<F>(c, ring, tick), S.r0, S.r1, S.r2, etg, lbx, lby, lbz, obs, imu);
 
   const float cdt = K.dt * (float)K.action_repeat;
   Rows<F> Rw = quat_rows(L.qx, L.qy, L.qz, L.qw);
@@ -609,15 +635,41 @@ ETG_HD void control_step16(const Ctx& c, const KCfg& K, State16<F>& L, float* ri
     c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_RPY + 1, rpy.y);
     c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_RPY + 2, rpy.z);
     c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_ENERGY, energy);
-    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_STEPS, F((float)step_count));
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_STEPS, F((float)S.step_count));
     for (int k = ETG_INFO_STEPS + 1; k < ETG_INFO_DIM; k++) c.st_row_env(info, ETG_INFO_DIM, k, F(0.0f));
   }
-  c.st_env(ctl, CT_LAST_BASE + 0, L.p.x); c.st_env(ctl, CT_LAST_BASE + 1, L.p.y); c.st_env(ctl, CT_LAST_BASE + 2, L.p.z);
-  c.st_legf(legctl, LC_LAST_FOOT_X, fk.fwx);
-  F alive = c.ld_env(ctl, CT_ALIVE);
-  c.st_env(ctl, CT_RET, c.ld_env(ctl, CT_RET) + alive * reward);
-  c.st_env(ctl, CT_LEN, c.ld_env(ctl, CT_LEN) + alive);
-  c.st_env(ctl, CT_ALIVE, sel_(done > F(0.5f), F(0.0f), alive));
+  S.lbx = L.p.x; S.lby = L.p.y; S.lbz = L.p.z;
+  S.last_fwx = fk.fwx;
+  S.ret = S.ret + S.alive * reward;
+  S.len = S.len + S.alive;
+  S.alive = sel_(done > F(0.5f), F(0.0f), S.alive);
+}
+
+// env.step for one robot row: load the control state, one step, store it
+template <class F, class Ctx>
+ETG_HD void control_step16(const Ctx& c, const KCfg& K, State16<F>& L, float* ring, float* ctl, int* ictl, float* legctl,
+                           const float* etgp, F action, F donef, float* obs, F& reward, F& done, float* info,
+                           const F* hyb = nullptr) {
+  StepCtl16<F> S = load_ctl16<F>(c, K, ctl, ictl, legctl);
+  TickPar<F> tp = load_tick_par<F>(c);
+  if (K.ext_force) tp.fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
+  control_step16_core(c, K, tp, L, S, ring, etgp, action, donef, obs, reward, done, info, hyb);
+  store_ctl16(c, K, S, ctl, ictl, legctl);
+}
+
+// open-loop rollout (pretrain.py:129-154): n_steps env.steps with zero residual action in ONE kernel -- the robot's
+// state, control variables and tick constants stay in registers between the steps, and the per-launch cost
+// (parameter staging, state load/store, launch ramp) is paid once
+template <class F, class Ctx>
+ETG_HD void rollout_steps16(const Ctx& c, const KCfg& K, State16<F>& L, float* ring, float* ctl, int* ictl, float* legctl,
+                            const float* etgp, int n_steps, float* obs) {
+  StepCtl16<F> S = load_ctl16<F>(c, K, ctl, ictl, legctl);
+  TickPar<F> tp = load_tick_par<F>(c);
+  if (K.ext_force) tp.fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
+  F reward, done;
+  for (int s = 0; s < n_steps; s++)
+    control_step16_core(c, K, tp, L, S, ring, etgp, F(0.0f), F(0.0f), obs, reward, done, (float*)nullptr);
+  store_ctl16(c, K, S, ctl, ictl, legctl);
 }
 
 // ------------------------------------------------------------------ reset
@@ -662,7 +714,11 @@ ETG_HD void reset_finish16(const Ctx& c, const KCfg& K, State16<F>& L, float* ri
   c.st_legf(legctl, LC_LAST_FOOT_X, fk.fwx);
   F imu[6];
   F etg = etg_action16<F>(c, K, etgp, 0.0f);
-  write_obs16(c, K, L, ring, tick, ctl, etg, L.p.x, L.p.y, L.p.z, true, obs, imu);
+  // the first reading after reset defines the rpy reference (EnvWrapper.py:79-84)
+  const Delayed16<F> D0 = ring_read16<F>(c, ring, tick);
+  const V3<F> rpy0 = quat_rpy(D0.qx, D0.qy, D0.qz, D0.qw);
+  c.st_env(ctl, CT_FIRST_RPY + 0, rpy0.x); c.st_env(ctl, CT_FIRST_RPY + 1, rpy0.y); c.st_env(ctl, CT_FIRST_RPY + 2, rpy0.z);
+  write_obs16(c, K, L, D0, rpy0.x, rpy0.y, rpy0.z, etg, L.p.x, L.p.y, L.p.z, obs, imu);
 }
 template <class F, class Ctx>
 ETG_HD void reset_row16(const Ctx& c, const KCfg& K, State16<F>& L, float* ring, float* ctl, int* ictl, float* legctl,

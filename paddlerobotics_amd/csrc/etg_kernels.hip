@@ -465,6 +465,18 @@ __global__ void __launch_bounds__(BLOCK) k_step16(KCfg K, DevState D, const floa
   }
 }
 
+// n_steps open-loop control steps of every robot in one launch (rollout_steps16): state, control variables and
+// tick constants stay in registers between the steps
+template <bool FLAT>
+__global__ void __launch_bounds__(BLOCK) k_rollout16(KCfg K, DevState D, int n_steps, float* obs) {
+  __shared__ float lds_par[LDS16_FIELDS * BLOCK];
+  GpuCtx16T<FLAT> c;
+  if (!make_ctx16(K, D, c, lds_par)) return;
+  State16<float> L = load_state16<float>(c, D.base, D.leg);
+  rollout_steps16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, n_steps, obs);
+  store_state16(c, D.base, D.leg, L);
+}
+
 // external force rows [N,3] -> the three SoA columns ctl[CT_FEXT + k][N]
 __global__ void k_set_fext(KCfg K, DevState D, const float* force) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -757,10 +769,25 @@ extern "C" int etg_episode_stats(EtgHandle* h, float* ret, int32_t* len, void* s
 extern "C" int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float* ret, int32_t* len, void* stream) {
   CHECK_HANDLE(h);
   if (n_steps <= 0 || !ret || !len) return fail(ETG_ERR_BAD_ARG, "etg_rollout_openloop: bad arguments");
-  for (int k = 0; k < n_steps; k++) {
-    float* o = (obs && k == n_steps - 1) ? obs : h->tmp_obs;
-    int rc = etg_step(h, nullptr, nullptr, o, h->tmp_reward, h->tmp_done, nullptr, stream);
-    if (rc != ETG_OK) return rc;
+  if (!h->was_reset) return fail(ETG_ERR_STATE, "etg_rollout_openloop: call etg_reset first");
+  if (h->lanes == 16 && h->K.motor_mode != 2) {
+    // fused: up to ROLLOUT_CHUNK control steps per launch, everything in registers in between
+    constexpr int ROLLOUT_CHUNK = 50;
+    const dim3 g16((h->N + 3) / 4);
+    for (int done_steps = 0; done_steps < n_steps; done_steps += ROLLOUT_CHUNK) {
+      const int m = n_steps - done_steps < ROLLOUT_CHUNK ? n_steps - done_steps : ROLLOUT_CHUNK;
+      float* o = (obs && done_steps + m == n_steps) ? obs : h->tmp_obs;
+      if (h->K.terrain == 0)
+        hipLaunchKernelGGL(k_rollout16<true>, g16, dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, m, o);
+      else
+        hipLaunchKernelGGL(k_rollout16<false>, g16, dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, m, o);
+    }
+  } else {
+    for (int k = 0; k < n_steps; k++) {
+      float* o = (obs && k == n_steps - 1) ? obs : h->tmp_obs;
+      int rc = etg_step(h, nullptr, nullptr, o, h->tmp_reward, h->tmp_done, nullptr, stream);
+      if (rc != ETG_OK) return rc;
+    }
   }
   HIP_TRY(hipGetLastError());
   return etg_episode_stats(h, ret, len, stream);
