@@ -37,7 +37,8 @@ PMC_TRAFFIC_BYTES_AT_4096 = {"k_rollout16": (17553.0 + 30192.0) * 1024.0 / 50.0,
                              "k_step": (4010.5 + 3076.0) * 1024.0}
 # VALU instructions one wave issues per control step (SQ_INSTS_VALU / SQ_WAVES, same files) and the VALU issue
 # capacity of a SIMD measured with tools/ubench/occupancy_rate.hip (8 resident waves of v_fma_f32: 0.384
-# wave-instructions per SIMD-cycle at the nominal 2.4 GHz; one resident wave reaches 0.172).
+# wave-instructions per SIMD-cycle at the nominal 2.4 GHz; a lone wave issues one VALU instruction per 4.9-5.4
+# cycles, i.e. about 0.2 -- issue_rate2.hip).
 PMC_VALU_PER_WAVE = {"k_rollout16": 1072505267.0 / 1024.0 / 50.0, "k_step16": 22040485.5 / 1024.0, "k_step": 8008005.8 / 256.0}
 VALU_PEAK_PER_SIMD_CYCLE = 0.384
 NOMINAL_HZ = 2.4e9
@@ -244,7 +245,7 @@ def main():
                          "valu_issue": {"achieved": PMC_VALU_PER_WAVE[kname] / (kern_ms * 1e-3 * NOMINAL_HZ),
                                         "peak": VALU_PEAK_PER_SIMD_CYCLE, "unit": "wave-instr/SIMD-cycle @2.4GHz",
                                         "frac": PMC_VALU_PER_WAVE[kname] / (kern_ms * 1e-3 * NOMINAL_HZ) / VALU_PEAK_PER_SIMD_CYCLE,
-                                        "single_wave_limit": 0.172} if N * lanes <= 1024 * 64 else None,
+                                        "single_wave_limit": 0.2} if N * lanes <= 1024 * 64 else None,
                          "note": "VALU-issue-bound by construction (~1e3 FLOP/B, SURVEY 8d): one wave per SIMD, "
                                  "1 VALU issue / 4 cycles; see DESIGN.md section 7"},
             "survivors": survivors,
