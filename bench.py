@@ -34,12 +34,13 @@ HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
 # section 7).  k_rollout16 runs 50 control steps per launch, so its launch totals are divided by 50.  Scaled
 # linearly with N for other batch sizes.
 PMC_TRAFFIC_BYTES_AT_4096 = {"k_rollout16": (17553.0 + 30192.0) * 1024.0 / 50.0, "k_step16": (3982.5 + 4100.0) * 1024.0,
-                             "k_step": (4010.5 + 3076.0) * 1024.0}
+                             "k_step": (4010.5 + 3076.0) * 1024.0, "k_rollout": None}
 # VALU instructions one wave issues per control step (SQ_INSTS_VALU / SQ_WAVES, same files) and the VALU issue
 # capacity of a SIMD measured with tools/ubench/occupancy_rate.hip (8 resident waves of v_fma_f32: 0.384
 # wave-instructions per SIMD-cycle at the nominal 2.4 GHz; a lone wave issues one VALU instruction per 4.9-5.4
 # cycles, i.e. about 0.2 -- issue_rate2.hip).
-PMC_VALU_PER_WAVE = {"k_rollout16": 1072505267.0 / 1024.0 / 50.0, "k_step16": 22040485.5 / 1024.0, "k_step": 8008005.8 / 256.0}
+PMC_VALU_PER_WAVE = {"k_rollout16": 1072505267.0 / 1024.0 / 50.0, "k_step16": 22040485.5 / 1024.0, "k_step": 8008005.8 / 256.0,
+                     "k_rollout": 8008005.8 / 256.0}
 VALU_PEAK_PER_SIMD_CYCLE = 0.384
 NOMINAL_HZ = 2.4e9
 BYTES_PER_STEP_CFG2 = 816  # 564 B + 252 B per-env ETG w,b
@@ -219,7 +220,7 @@ def main():
         total_steps = world * N * args.steps
         value = total_steps / elapsed
         bytes_per = BYTES_PER_STEP_CFG3 if args.config == 3 else BYTES_PER_STEP_CFG2
-        kname = ("k_rollout16" if fused else "k_step16") if lanes == 16 else "k_step"
+        kname = ("k_rollout16" if fused else "k_step16") if lanes == 16 else ("k_rollout" if fused else "k_step")
         achieved = bytes_per * N / (kern_ms * 1e-3)
         out = {
             "metric": "env-steps/sec, 4096 A1 quadrupeds; 1/2/4/8-GPU scaling",
@@ -234,11 +235,11 @@ def main():
                         "precision %d)" % (N, args.precision)),
                        "robots_per_gpu": N, "action_repeat": 13, "sim_dt": 0.002, "solver_iters": args.solver_iters, "lanes_per_robot": lanes,
                        "parallelism": "env-shard x%d" % world},
-            "path": ("etg_rollout_openloop: fused kernel, up to 50 control steps per launch" if fused and lanes == 16 else
-                     "etg_rollout_openloop: one step kernel per control step" if fused else "env.step per control step"),
+            "path": ("etg_rollout_openloop: fused kernel, up to 50 control steps per launch" if fused else
+                     "env.step per control step"),
             "roofline": {"bound": "hbm", "kernel": "etg::" + kname, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK,
-                         "traffic": PMC_TRAFFIC_BYTES_AT_4096[kname] * N / 4096.0,
+                         "traffic": (PMC_TRAFFIC_BYTES_AT_4096[kname] * N / 4096.0) if PMC_TRAFFIC_BYTES_AT_4096[kname] else None,
                          "kernel_ms": kern_ms, "kernel_ms_is": "per control step" if fused else "per launch",
                          "algorithmic_bytes_per_env_step": bytes_per,
                          # the ceiling that actually binds: VALU issue of one wave per SIMD

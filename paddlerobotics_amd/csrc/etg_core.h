@@ -603,17 +603,9 @@ template <class F> ETG_HD F c_prec(F v, F t, F m) {
 // ------------------------------------------------------------------ observation (EnvWrapper.py:60-109)
 // sorted keys: BaseDisplacement(3) FootContactSensor(4) IMU(6) MotorAngleAcc(24) + ETG(12) = 49
 template <class F, class Ctx>
-ETG_HD void write_obs(const Ctx& c, const KCfg& K, const LaneState<F>& L, const float* ring,
-                      int tick, float* ctl, const F* etg, F lbx, F lby, F lbz, bool set_first, float* obs, F* imu) {
-  Delayed<F> D = ring_read<F>(c, ring, tick);
+ETG_HD void write_obs(const Ctx& c, const KCfg& K, const LaneState<F>& L, const Delayed<F>& D, F f0, F f1, F f2,
+                      const F* etg, F lbx, F lby, F lbz, float* obs, F* imu) {
   V3<F> rpy = quat_rpy(D.qx, D.qy, D.qz, D.qw);
-  F f0, f1, f2;
-  if (set_first) {
-    f0 = rpy.x; f1 = rpy.y; f2 = rpy.z;
-    c.st_env(ctl, CT_FIRST_RPY + 0, f0); c.st_env(ctl, CT_FIRST_RPY + 1, f1); c.st_env(ctl, CT_FIRST_RPY + 2, f2);
-  } else {
-    f0 = c.ld_env(ctl, CT_FIRST_RPY + 0); f1 = c.ld_env(ctl, CT_FIRST_RPY + 1); f2 = c.ld_env(ctl, CT_FIRST_RPY + 2);
-  }
   const bool nrm = K.obs_normal != 0;
   const float cdt = K.dt * (float)K.action_repeat;
   F sdis(nrm ? 1.0f / cdt : 1.0f), srpy(nrm ? 10.0f : 1.0f), sdr(nrm ? 2.0f : 1.0f), sq(nrm ? 10.0f : 1.0f);
@@ -668,13 +660,59 @@ ETG_HD FootKin<F> foot_kin(const Ctx& c, const KCfg& K, const LaneState<F>& L) {
 
 // ------------------------------------------------------------------ one control step (env.step)
 // returns reward / done for the quad; obs/info optional.
+// The control-loop variables of a robot that live across steps: loaded once per kernel, kept in registers over
+// one step (env.step) or many (open-loop rollout), stored once.
+template <class F> struct StepCtl4 {
+  int step_count, tick, has_last;
+  F last[3], lbx, lby, lbz, last_fwx;   // last position command, last base position, last foot x (world)
+  F ret, len, alive;                    // episode accumulators
+  F r0, r1, r2;                         // first rpy reading after reset (EnvWrapper.py:79-84)
+  F fx0[3], fx1[3], fy0[3], fy1[3];     // action filter history (only with K.enable_filter)
+};
 template <class F, class Ctx>
-ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ring, float* ctl,
-                         int* ictl, float* legctl, const float* etgp, const F* action, F donef, float* obs, F& reward, F& done,
-                         float* info, const F* hyb = nullptr) {   // hyb[4*j + (kp, qd_des, kd, tau_ff)], HYBRID mode
-  int step_count = c.ld_env_i(ictl, IC_STEP);
-  int tick = c.ld_env_i(ictl, IC_TICK);
-  int has_last = c.ld_env_i(ictl, IC_HAS_LAST);
+ETG_HD StepCtl4<F> load_ctl4(const Ctx& c, const KCfg& K, const float* ctl, const int* ictl, const float* legctl) {
+  StepCtl4<F> S;
+  S.step_count = c.ld_env_i(ictl, IC_STEP);
+  S.tick = c.ld_env_i(ictl, IC_TICK);
+  S.has_last = c.ld_env_i(ictl, IC_HAS_LAST);
+  for (int j = 0; j < 3; j++) S.last[j] = c.ld_lane(legctl, LC_LAST_QDES + j);
+  S.lbx = c.ld_env(ctl, CT_LAST_BASE + 0); S.lby = c.ld_env(ctl, CT_LAST_BASE + 1); S.lbz = c.ld_env(ctl, CT_LAST_BASE + 2);
+  S.last_fwx = c.ld_lane(legctl, LC_LAST_FOOT_X);
+  S.ret = c.ld_env(ctl, CT_RET); S.len = c.ld_env(ctl, CT_LEN); S.alive = c.ld_env(ctl, CT_ALIVE);
+  S.r0 = c.ld_env(ctl, CT_FIRST_RPY + 0); S.r1 = c.ld_env(ctl, CT_FIRST_RPY + 1); S.r2 = c.ld_env(ctl, CT_FIRST_RPY + 2);
+  for (int j = 0; j < 3; j++) {
+    S.fx0[j] = S.fx1[j] = S.fy0[j] = S.fy1[j] = F(0.0f);
+    if (K.enable_filter) {
+      S.fx0[j] = c.ld_lane(legctl, LC_FX0 + j); S.fx1[j] = c.ld_lane(legctl, LC_FX1 + j);
+      S.fy0[j] = c.ld_lane(legctl, LC_FY0 + j); S.fy1[j] = c.ld_lane(legctl, LC_FY1 + j);
+    }
+  }
+  return S;
+}
+template <class F, class Ctx>
+ETG_HD void store_ctl4(const Ctx& c, const KCfg& K, const StepCtl4<F>& S, float* ctl, int* ictl, float* legctl) {
+  c.st_env_i(ictl, IC_STEP, S.step_count);
+  c.st_env_i(ictl, IC_TICK, S.tick);
+  c.st_env_i(ictl, IC_HAS_LAST, S.has_last);
+  for (int j = 0; j < 3; j++) c.st_lane(legctl, LC_LAST_QDES + j, S.last[j]);
+  c.st_env(ctl, CT_LAST_BASE + 0, S.lbx); c.st_env(ctl, CT_LAST_BASE + 1, S.lby); c.st_env(ctl, CT_LAST_BASE + 2, S.lbz);
+  c.st_lane(legctl, LC_LAST_FOOT_X, S.last_fwx);
+  c.st_env(ctl, CT_RET, S.ret); c.st_env(ctl, CT_LEN, S.len); c.st_env(ctl, CT_ALIVE, S.alive);
+  if (K.enable_filter)
+    for (int j = 0; j < 3; j++) {
+      c.st_lane(legctl, LC_FX0 + j, S.fx0[j]); c.st_lane(legctl, LC_FX1 + j, S.fx1[j]);
+      c.st_lane(legctl, LC_FY0 + j, S.fy0[j]); c.st_lane(legctl, LC_FY1 + j, S.fy1[j]);
+    }
+}
+
+// one env.step on the register-resident control state S and tick constants tp
+template <class F, class Ctx>
+ETG_HD void control_step_core(const Ctx& c, const KCfg& K, TickPar4<F>& tp, const V3<F>& fext, LaneState<F>& L, StepCtl4<F>& S,
+                              float* ring, const float* etgp, const F* action, F donef, float* obs, F& reward, F& done,
+                              float* info, const F* hyb = nullptr) {   // hyb[4*j + (kp, qd_des, kd, tau_ff)], HYBRID mode
+  int step_count = S.step_count;
+  int tick = S.tick;
+  const int has_last = S.has_last;
   // ETG at t = (k+1) dt (fixture convention of gait_action_list_ETG_exp.npy)
   F etg[3], qdes[3];
   etg_action(c, K, etgp, (float)(step_count + 1) * K.etg_dt, etg);
@@ -685,19 +723,14 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   if (K.enable_filter) {  // action_filter.py:111-120, order 2
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      F x0 = c.ld_lane(legctl, LC_FX0 + j), x1 = c.ld_lane(legctl, LC_FX1 + j);
-      F y0 = c.ld_lane(legctl, LC_FY0 + j), y1 = c.ld_lane(legctl, LC_FY1 + j);
-      F y = F(K.fb[0]) * qdes[j] + F(K.fb[1]) * x0 + F(K.fb[2]) * x1 - F(K.fa[1]) * y0 - F(K.fa[2]) * y1;
-      c.st_lane(legctl, LC_FX1 + j, x0); c.st_lane(legctl, LC_FX0 + j, qdes[j]);
-      c.st_lane(legctl, LC_FY1 + j, y0); c.st_lane(legctl, LC_FY0 + j, y);
+      F y = F(K.fb[0]) * qdes[j] + F(K.fb[1]) * S.fx0[j] + F(K.fb[2]) * S.fx1[j] - F(K.fa[1]) * S.fy0[j] - F(K.fa[2]) * S.fy1[j];
+      S.fx1[j] = S.fx0[j]; S.fx0[j] = qdes[j];
+      S.fy1[j] = S.fy0[j]; S.fy0[j] = y;
       qdes[j] = y;
     }
   }
-  F last[3];
-#pragma unroll
-  for (int j = 0; j < 3; j++) last[j] = c.ld_lane(legctl, LC_LAST_QDES + j);
-  F lbx = c.ld_env(ctl, CT_LAST_BASE + 0), lby = c.ld_env(ctl, CT_LAST_BASE + 1), lbz = c.ld_env(ctl, CT_LAST_BASE + 2);
-  F last_fwx = c.ld_lane(legctl, LC_LAST_FOOT_X);
+  const F last[3] = {S.last[0], S.last[1], S.last[2]};
+  const F lbx = S.lbx, lby = S.lby, lbz = S.lbz, last_fwx = S.last_fwx;
   L.energy = F(0.0f);
   const bool interp = K.enable_interp && has_last;
   // Only the two readings a later observation will blend (minitaur.py:1185-1193: ticks T-n and
@@ -705,11 +738,8 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   const int n_lat = c.uniform_int(c.par(PR_LAT_N));
   const int R_ = K.action_repeat;
   const float inv_repeat = 1.0f / (float)K.action_repeat;
-  TickPar4<F> tp = load_tick_par4<F>(c);
   if (hybrid_cmd)
     for (int j = 0; j < 3; j++) { tp.kp[j] = hyb[4 * j]; tp.qd_des[j] = hyb[4 * j + 1]; tp.kd[j] = hyb[4 * j + 2]; tp.tau_ff[j] = hyb[4 * j + 3]; }
-  V3<F> fext = {F(0.0f), F(0.0f), F(0.0f)};
-  if (K.ext_force) fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
   const int mlat = n_lat < 0 ? 0 : n_lat % R_;
   const int ia = R_ - 1 - mlat;
   const int ib = n_lat < 0 ? ia : (ia == 0 ? R_ - 1 : ia - 1);
@@ -723,15 +753,13 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
     if (i == ia || i == ib) ring_push(c, ring, tick & (RING - 1), L);
   }
 #pragma unroll
-  for (int j = 0; j < 3; j++) c.st_lane(legctl, LC_LAST_QDES + j, qdes[j]);
+  for (int j = 0; j < 3; j++) S.last[j] = qdes[j];
   step_count++;
-  c.st_env_i(ictl, IC_STEP, step_count);
-  c.st_env_i(ictl, IC_TICK, tick);
-  c.st_env_i(ictl, IC_HAS_LAST, 1);
+  S.step_count = step_count; S.tick = tick; S.has_last = 1;
   c.ring_fence();
 
   F imu[6];
-  write_obs(c, K, L, ring, tick, ctl, etg, lbx, lby, lbz, false, obs, imu);
+  write_obs(c, K, L, ring_read<F>(c, ring, tick), S.r0, S.r1, S.r2, etg, lbx, lby, lbz, obs, imu);
 
   // ---- reward / termination (this repo's definitions)
   const float cdt = K.dt * (float)K.action_repeat;
@@ -779,15 +807,43 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
     c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_STEPS, F((float)step_count));
     for (int k = ETG_INFO_STEPS + 1; k < ETG_INFO_DIM; k++) c.st_row_env(info, ETG_INFO_DIM, k, F(0.0f));
   }
-  c.st_env(ctl, CT_LAST_BASE + 0, L.p.x); c.st_env(ctl, CT_LAST_BASE + 1, L.p.y); c.st_env(ctl, CT_LAST_BASE + 2, L.p.z);
-  c.st_lane(legctl, LC_LAST_FOOT_X, fk.fwx);
+  S.lbx = L.p.x; S.lby = L.p.y; S.lbz = L.p.z;
+  S.last_fwx = fk.fwx;
   // episode accumulators with alive masking (the batched counterpart of the callers' loops,
   // train.py:213-249 / pretrain.py:129-154: return and length stop growing after `done`)
-  F alive = c.ld_env(ctl, CT_ALIVE);
-  c.st_env(ctl, CT_RET, c.ld_env(ctl, CT_RET) + alive * reward);
-  c.st_env(ctl, CT_LEN, c.ld_env(ctl, CT_LEN) + alive);
-  c.st_env(ctl, CT_ALIVE, sel_(done > F(0.5f), F(0.0f), alive));
+  S.ret = S.ret + S.alive * reward;
+  S.len = S.len + S.alive;
+  S.alive = sel_(done > F(0.5f), F(0.0f), S.alive);
 }
+
+// env.step for one robot quad: load the control state, one step, store it
+template <class F, class Ctx>
+ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ring, float* ctl,
+                         int* ictl, float* legctl, const float* etgp, const F* action, F donef, float* obs, F& reward, F& done,
+                         float* info, const F* hyb = nullptr) {
+  StepCtl4<F> S = load_ctl4<F>(c, K, ctl, ictl, legctl);
+  TickPar4<F> tp = load_tick_par4<F>(c);
+  V3<F> fext = {F(0.0f), F(0.0f), F(0.0f)};
+  if (K.ext_force) fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
+  control_step_core(c, K, tp, fext, L, S, ring, etgp, action, donef, obs, reward, done, info, hyb);
+  store_ctl4(c, K, S, ctl, ictl, legctl);
+}
+
+// open-loop rollout (pretrain.py:129-154): n_steps env.steps with zero residual action in one kernel
+template <class F, class Ctx>
+ETG_HD void rollout_steps(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ring, float* ctl, int* ictl, float* legctl,
+                          const float* etgp, int n_steps, float* obs) {
+  StepCtl4<F> S = load_ctl4<F>(c, K, ctl, ictl, legctl);
+  TickPar4<F> tp = load_tick_par4<F>(c);
+  V3<F> fext = {F(0.0f), F(0.0f), F(0.0f)};
+  if (K.ext_force) fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
+  const F zero3[3] = {F(0.0f), F(0.0f), F(0.0f)};
+  F reward, done;
+  for (int s = 0; s < n_steps; s++)
+    control_step_core(c, K, tp, fext, L, S, ring, etgp, zero3, F(0.0f), obs, reward, done, (float*)nullptr);
+  store_ctl4(c, K, S, ctl, ictl, legctl);
+}
+
 
 // ------------------------------------------------------------------ reset (minitaur.py:403-445, a1.py:289-349)
 template <class F, class Ctx>
@@ -833,7 +889,11 @@ ETG_HD void reset_finish(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   c.st_lane(legctl, LC_LAST_FOOT_X, fk.fwx);
   F etg[3], imu[6];
   etg_action(c, K, etgp, 0.0f, etg);
-  write_obs(c, K, L, ring, tick, ctl, etg, L.p.x, L.p.y, L.p.z, true, obs, imu);
+  // the first reading after reset defines the rpy reference (EnvWrapper.py:79-84)
+  const Delayed<F> D0 = ring_read<F>(c, ring, tick);
+  const V3<F> rpy0 = quat_rpy(D0.qx, D0.qy, D0.qz, D0.qw);
+  c.st_env(ctl, CT_FIRST_RPY + 0, rpy0.x); c.st_env(ctl, CT_FIRST_RPY + 1, rpy0.y); c.st_env(ctl, CT_FIRST_RPY + 2, rpy0.z);
+  write_obs(c, K, L, D0, rpy0.x, rpy0.y, rpy0.z, etg, L.p.x, L.p.y, L.p.z, obs, imu);
 }
 template <class F, class Ctx>
 ETG_HD void reset_quad(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ring, float* ctl,

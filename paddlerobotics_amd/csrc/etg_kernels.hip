@@ -253,6 +253,18 @@ __global__ void __launch_bounds__(BLOCK) k_step(KCfg K, DevState D, const float*
   }
 }
 
+// n_steps open-loop control steps per launch (rollout_steps), the 4-lanes-per-robot counterpart of k_rollout16
+template <bool FLAT>
+__global__ void __launch_bounds__(BLOCK) k_rollout(KCfg K, DevState D, int n_steps, float* obs) {
+  GpuCtxT<FLAT> c;
+  if (!make_ctx(K, c)) return;
+  __shared__ float lds_par[PR_N * BLOCK];
+  stage_params(c, D, lds_par);
+  LaneState<float> L = load_state<float>(c, D.base, D.leg);
+  rollout_steps(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, n_steps, obs);
+  store_state(c, D.base, D.leg, L);
+}
+
 // ====================================================================== 16 lanes per robot
 // One robot = one 16-lane DPP row (etg_core16.h): lane r = 4*leg + sub.  A workgroup is still one
 // wave64 = 4 robots; 4096 robots -> 1024 workgroups = one wave on every SIMD of the chip.
@@ -770,17 +782,22 @@ extern "C" int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float
   CHECK_HANDLE(h);
   if (n_steps <= 0 || !ret || !len) return fail(ETG_ERR_BAD_ARG, "etg_rollout_openloop: bad arguments");
   if (!h->was_reset) return fail(ETG_ERR_STATE, "etg_rollout_openloop: call etg_reset first");
-  if (h->lanes == 16 && h->K.motor_mode != 2) {
+  if (h->K.motor_mode != 2) {
     // fused: up to ROLLOUT_CHUNK control steps per launch, everything in registers in between
     constexpr int ROLLOUT_CHUNK = 50;
-    const dim3 g16((h->N + 3) / 4);
+    const dim3 g16((h->N + 3) / 4), g4(grid_for(h));
+    const bool flat = h->K.terrain == 0;
+    hipStream_t s = (hipStream_t)stream;
     for (int done_steps = 0; done_steps < n_steps; done_steps += ROLLOUT_CHUNK) {
       const int m = n_steps - done_steps < ROLLOUT_CHUNK ? n_steps - done_steps : ROLLOUT_CHUNK;
       float* o = (obs && done_steps + m == n_steps) ? obs : h->tmp_obs;
-      if (h->K.terrain == 0)
-        hipLaunchKernelGGL(k_rollout16<true>, g16, dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, m, o);
-      else
-        hipLaunchKernelGGL(k_rollout16<false>, g16, dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, m, o);
+      if (h->lanes == 16) {
+        if (flat) hipLaunchKernelGGL(k_rollout16<true>, g16, dim3(BLOCK), 0, s, h->K, h->D, m, o);
+        else hipLaunchKernelGGL(k_rollout16<false>, g16, dim3(BLOCK), 0, s, h->K, h->D, m, o);
+      } else {
+        if (flat) hipLaunchKernelGGL(k_rollout<true>, g4, dim3(BLOCK), 0, s, h->K, h->D, m, o);
+        else hipLaunchKernelGGL(k_rollout<false>, g4, dim3(BLOCK), 0, s, h->K, h->D, m, o);
+      }
     }
   } else {
     for (int k = 0; k < n_steps; k++) {

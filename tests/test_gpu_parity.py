@@ -252,7 +252,8 @@ def test_full_size_determinism_and_batch_invariance():
     small.close()
 
 
-def test_fused_rollout_equals_stepping():
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_fused_rollout_equals_stepping(lanes):
     """etg_rollout_openloop runs up to 50 control steps per launch with everything in registers; env.step runs one.
     Same source, two kernels: the compiler fuses multiply-adds differently in the two contexts (-ffp-contract=fast;
     with =on the two are bit-identical, at 3 % of the step time), so the comparison is to rounding noise amplified by
@@ -260,7 +261,7 @@ def test_fused_rollout_equals_stepping():
     _need_gpu()
     n = 64
     W, B = _etg_params(n, seed=11)
-    a, b = _make(n), _make(n)
+    a, b = _make(n, lanes_per_robot=lanes), _make(n, lanes_per_robot=lanes)
     a.reset(ETG_w=W, ETG_b=B)
     b.reset(ETG_w=W, ETG_b=B)
     ret1, ln1 = a.rollout_openloop(1)            # a single step through the fused kernel is the step kernel's step
