@@ -30,11 +30,12 @@ from paddlerobotics_amd.etg_fit import opt_with_points_batched  # noqa: E402
 SOLVER_ITERS = 2           # library default (K=2 vs K=50 differ by <0.4 mm after 5 m)
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
 # PMC figures per CONTROL STEP at N = 4096 (profiles/r01_pmc_16lane_kernels.txt, r01_pmc_k_step_lanes4.txt; separate
-# passes, FETCH_SIZE / WRITE_SIZE in KB; dword accesses are a width the guide calls uncalibrated -- DESIGN.md
-# section 7).  k_rollout16 runs 50 control steps per launch, so its launch totals are divided by 50.  Scaled
-# linearly with N for other batch sizes.
-PMC_TRAFFIC_BYTES_AT_4096 = {"k_rollout16": (17553.0 + 30192.0) * 1024.0 / 50.0, "k_step16": (3982.5 + 4100.0) * 1024.0,
-                             "k_step": (4010.5 + 3076.0) * 1024.0, "k_rollout": None}
+# passes, FETCH_SIZE / WRITE_SIZE in KB).  Calibrated for this code's access width -- one dword per lane, coalesced
+# SoA -- with tools/ubench/pmc_calib.hip (a 512 MiB copy): FETCH_SIZE reports exactly 1/2 of the bytes read (as the
+# micro-arch guide found for wide reads), WRITE_SIZE is exact; hence the factor 2 on the fetch term.  k_rollout16
+# runs 50 control steps per launch, so its launch totals are divided by 50.  Scaled linearly with N.
+PMC_TRAFFIC_BYTES_AT_4096 = {"k_rollout16": (2 * 17553.0 + 30192.0) * 1024.0 / 50.0, "k_step16": (2 * 3982.5 + 4100.0) * 1024.0,
+                             "k_step": (2 * 4010.5 + 3076.0) * 1024.0, "k_rollout": None}
 # VALU instructions one wave issues per control step (SQ_INSTS_VALU / SQ_WAVES, same files) and the VALU issue
 # capacity of a SIMD measured with tools/ubench/occupancy_rate.hip (8 resident waves of v_fma_f32: 0.384
 # wave-instructions per SIMD-cycle at the nominal 2.4 GHz; a lone wave issues one VALU instruction per 4.9-5.4
