@@ -35,13 +35,13 @@ HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
 # micro-arch guide found for wide reads), WRITE_SIZE is exact; hence the factor 2 on the fetch term.  k_rollout16
 # runs 50 control steps per launch, so its launch totals are divided by 50.  Scaled linearly with N.
 PMC_TRAFFIC_BYTES_AT_4096 = {"k_rollout16": (2 * 17553.0 + 30192.0) * 1024.0 / 50.0, "k_step16": (2 * 3982.5 + 4100.0) * 1024.0,
-                             "k_step": (2 * 4010.5 + 3076.0) * 1024.0, "k_rollout": None}
+                             "k_step": (2 * 4010.5 + 3076.0) * 1024.0, "k_rollout": None, "k_rollout_policy16": None}
 # VALU instructions one wave issues per control step (SQ_INSTS_VALU / SQ_WAVES, same files) and the VALU issue
 # capacity of a SIMD measured with tools/ubench/occupancy_rate.hip (8 resident waves of v_fma_f32: 0.384
 # wave-instructions per SIMD-cycle at the nominal 2.4 GHz; a lone wave issues one VALU instruction per 4.9-5.4
 # cycles, i.e. about 0.2 -- issue_rate2.hip).
 PMC_VALU_PER_WAVE = {"k_rollout16": 1072505267.0 / 1024.0 / 50.0, "k_step16": 22040485.5 / 1024.0, "k_step": 8008005.8 / 256.0,
-                     "k_rollout": 8008005.8 / 256.0}
+                     "k_rollout": 8008005.8 / 256.0, "k_rollout_policy16": 1072505267.0 / 1024.0 / 50.0}
 VALU_PEAK_PER_SIMD_CYCLE = 0.384
 NOMINAL_HZ = 2.4e9
 BYTES_PER_STEP_CFG2 = 816  # 564 B + 252 B per-env ETG w,b
@@ -157,7 +157,6 @@ def main():
     EVENT_SPAN = min(1 if args.config == 3 else 8, max(args.steps, 1))
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for _ in range(max(1, args.steps // EVENT_EVERY))]
-    evp = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in ev] if args.config == 3 else []
 
     def barrier():
         torch.cuda.synchronize(dev)
@@ -169,23 +168,22 @@ def main():
     # pretrain.py:129-154), whose batched counterpart is etg_rollout_openloop -- up to 50 control steps per launch with
     # state, control variables and tick constants in registers.  Config 3 needs the policy between steps, so it
     # (and --stepwise) goes through env.step() once per control step.
-    fused = policy is None and not args.stepwise
+    fused = not args.stepwise                                 # config 3: etg_rollout_policy, the policy tile inside the kernel
     barrier()
     t0 = time.perf_counter()
     if fused:
         ev = ev[:1]
         EVENT_SPAN = args.steps                               # one event pair around the K fused steps
         ev[0][0].record()
-        env.rollout_openloop(args.steps)
+        if policy is None:
+            env.rollout_openloop(args.steps)
+        else:
+            env.rollout_policy(policy, args.steps, 0.3, args.precision)
         ev[0][1].record()
     for k in range(0 if fused else args.steps):
         slot, phase = divmod(k, EVENT_EVERY)
         if policy is not None:
-            if phase == 8 and slot < len(evp):               # the policy kernel is timed on other steps than the dynamics
-                evp[slot][0].record()
             policy.predict(env.obs, 0.3, args.precision, out=act)
-            if phase == 8 and slot < len(evp):
-                evp[slot][1].record()
         if phase == 0 and slot < len(ev):
             ev[slot][0].record()
         env.step(act if policy is not None else None, want_info=False)
@@ -211,17 +209,19 @@ def main():
         barrier()
         t1 = time.perf_counter()
         for _ in range(args.steps):
-            env.step(None, want_info=False)
+            one_step()
         barrier()
         dt1 = time.perf_counter() - t1
         stepwise = {"value": world * N * args.steps / dt1, "ms_per_step": dt1 / args.steps * 1e3,
-                    "note": "env.step() per control step (k_step16), the closed-loop-capable API"}
+                    "note": "env.step() per control step (k_step16)" + (", policy.predict() before each" if policy is not None else "")}
 
     if rank == 0:
         total_steps = world * N * args.steps
         value = total_steps / elapsed
         bytes_per = BYTES_PER_STEP_CFG3 if args.config == 3 else BYTES_PER_STEP_CFG2
         kname = ("k_rollout16" if fused else "k_step16") if lanes == 16 else ("k_rollout" if fused else "k_step")
+        if fused and policy is not None:
+            kname = "k_rollout_policy16"
         achieved = bytes_per * N / (kern_ms * 1e-3)
         out = {
             "metric": "env-steps/sec, 4096 A1 quadrupeds; 1/2/4/8-GPU scaling",
@@ -236,8 +236,9 @@ def main():
                         "precision %d)" % (N, args.precision)),
                        "robots_per_gpu": N, "action_repeat": 13, "sim_dt": 0.002, "solver_iters": args.solver_iters, "lanes_per_robot": lanes,
                        "parallelism": "env-shard x%d" % world},
-            "path": ("etg_rollout_openloop: fused kernel, up to 50 control steps per launch" if fused else
-                     "env.step per control step"),
+            "path": ("env.step per control step" if not fused else
+                     "etg_rollout_openloop: fused kernel, up to 50 control steps per launch" if policy is None else
+                     "etg_rollout_policy: policy MFMA tile + control step fused, up to 50 control steps per launch"),
             "roofline": {"bound": "hbm", "kernel": "etg::" + kname, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK,
                          "traffic": (PMC_TRAFFIC_BYTES_AT_4096[kname] * N / 4096.0) if PMC_TRAFFIC_BYTES_AT_4096[kname] else None,
@@ -255,8 +256,15 @@ def main():
         if stepwise is not None:
             out["stepwise"] = stepwise
         out["roofline"]["hbm_copy_measured_GBps"] = device_copy_bandwidth(dev) / 1e9
-        if evp and args.steps > 8:
-            pol_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in evp if True]))
+        if policy is not None:
+            # the stand-alone policy kernel (what env.step-wise callers launch), 50 back-to-back launches in one event pair
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(50):
+                policy.predict(env.obs, 0.3, args.precision, out=act)
+            e1.record()
+            torch.cuda.synchronize(dev)
+            pol_ms = e0.elapsed_time(e1) / 50.0
             flops = 2.0 * N * (A.OBS_DIM * 256 + 256 * 256 + 256 * 12)          # 162 304 FLOP per env-step
             peak = 157.3 if args.precision == 0 else 2500.0                     # dense fp32 / bf16 MFMA peaks, TFLOP/s
             out["policy_roofline"] = {"bound": "mfma", "kernel": "k_policy", "achieved": flops / (pol_ms * 1e-3) / 1e12,

@@ -220,6 +220,14 @@ int etg_policy_sample(EtgPolicy* p, const float* obs, int n, const float* noise,
                       int precision, float* act, float* logp, void* stream);
 void etg_policy_destroy(EtgPolicy* p);
 
+/* closed-loop rollout with a fixed actor in ONE kernel per 50 control steps (run_EStrain_episode / run_evaluate_episodes,
+ * train.py:182-249): per step action = tanh(mean(obs)) * act_scale as etg_policy_forward computes it, then one
+ * control step; a workgroup keeps its 16 robots' observations, actions and states on chip between the steps.
+ * obs [N,49]: in = the current observation (as left by etg_reset / etg_step), out = the final one.  ret / len as
+ * etg_episode_stats (may be NULL).  Needs the 16-lanes-per-robot mapping, num_envs % 16 == 0, a 49 -> 12 policy. */
+int etg_rollout_policy(EtgHandle* h, EtgPolicy* policy, int n_steps, float act_scale, int precision, float* obs,
+                       float* ret, int32_t* len, void* stream);
+
 /* ---- ETG parameterisation (the step right before reset) ----
  * Batched Opt_with_points / LS_sol (train.py:59-110): for every candidate fit the
  * x- and z-row of the ETG weights through its 6 control points by LS_sol's

@@ -15,7 +15,7 @@ SYMBOLS = [
     "etg_set_heightfield", "etg_set_external_force", "etg_random_pushes", "etg_clear_pushes", "etg_reset", "etg_step", "etg_episode_stats", "etg_rollout_openloop",
     "etg_get_state",
     "etg_set_state", "etg_policy_create", "etg_policy_load", "etg_policy_forward", "etg_policy_load_std", "etg_policy_sample",
-    "etg_policy_destroy", "etg_fit_etg",
+    "etg_policy_destroy", "etg_rollout_policy", "etg_fit_etg",
 ]
 
 
@@ -61,6 +61,7 @@ def load():
     lib.etg_policy_load_std.argtypes = [vp, vp, vp, vp]
     lib.etg_policy_sample.argtypes = [vp, vp, i32, vp, C.c_float, i32, vp, vp, vp]
     lib.etg_policy_destroy.argtypes = [vp]
+    lib.etg_rollout_policy.argtypes = [vp, vp, i32, C.c_float, i32, vp, vp, vp, vp]
     lib.etg_policy_destroy.restype = None
     dbl = C.c_double
     lib.etg_fit_etg.argtypes = [vp, i32, vp, vp, dbl, dbl, dbl, dbl, dbl, i32, vp, vp, vp]

@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "etg_core16.h"
+#include "policy_core.h"
 
 namespace etg {
 
@@ -275,6 +276,7 @@ struct GpuCtx16 {
   size_t col;        // 4*env + leg : column of the leg-level SoA arrays
   const float* lds;  // this lane's LDS column
   const float* gpar; // D.par: the tick constants are read from it directly (tpar*)
+  int row_base = 0;  // first robot of the [*, rowlen] row buffers (obs tile in LDS: the workgroup's first robot)
   __device__ __forceinline__ float jointf() const { return sub < 3 ? 1.0f : 0.0f; }
   __device__ __forceinline__ bool sub_is(int j) const { return sub == j; }
   __device__ __forceinline__ bool leg_is(int j) const { return leg == j; }
@@ -368,13 +370,13 @@ struct GpuCtx16 {
   __device__ __forceinline__ void st_ring_aux(float* rg, int slot, int k, float v) const { if (sub == 3) rg[((size_t)slot * 8 + k) * NL + col] = v; }
   __device__ __forceinline__ float ld_ring_joint(const float* rg, int slot, int k0) const { return rg[((size_t)slot * 8 + k0 + sc) * NL + col]; }
   __device__ __forceinline__ float ld_ring_k(const float* rg, int slot, int k) const { return rg[((size_t)slot * 8 + k) * NL + col]; }
-  __device__ __forceinline__ float ld_row_joint(const float* p, int rowlen, int col0) const { return sub < 3 ? p[(size_t)env * rowlen + col0 + 3 * leg + sub] : 0.0f; }
+  __device__ __forceinline__ float ld_row_joint(const float* p, int rowlen, int col0) const { return sub < 3 ? p[(size_t)(env - row_base) * rowlen + col0 + 3 * leg + sub] : 0.0f; }
   // element k of this lane's motor in rows of `stride` values per motor (HYBRID commands: stride 5)
-  __device__ __forceinline__ float ld_row_motor(const float* p, int rowlen, int stride, int k) const { return sub < 3 ? p[(size_t)env * rowlen + stride * (3 * leg + sub) + k] : 0.0f; }
-  __device__ __forceinline__ void st_row_joint(float* p, int rowlen, int col0, float v) const { if (sub < 3) p[(size_t)env * rowlen + col0 + 3 * leg + sub] = v; }
-  __device__ __forceinline__ void st_row_leg(float* p, int rowlen, int col0, float v) const { if (sub == 0) p[(size_t)env * rowlen + col0 + leg] = v; }
-  __device__ __forceinline__ void st_row_env(float* p, int rowlen, int c_, float v) const { if (r == 0) p[(size_t)env * rowlen + c_] = v; }
-  __device__ __forceinline__ float ld_row_env(const float* p, int rowlen, int c_) const { return p[(size_t)env * rowlen + c_]; }
+  __device__ __forceinline__ float ld_row_motor(const float* p, int rowlen, int stride, int k) const { return sub < 3 ? p[(size_t)(env - row_base) * rowlen + stride * (3 * leg + sub) + k] : 0.0f; }
+  __device__ __forceinline__ void st_row_joint(float* p, int rowlen, int col0, float v) const { if (sub < 3) p[(size_t)(env - row_base) * rowlen + col0 + 3 * leg + sub] = v; }
+  __device__ __forceinline__ void st_row_leg(float* p, int rowlen, int col0, float v) const { if (sub == 0) p[(size_t)(env - row_base) * rowlen + col0 + leg] = v; }
+  __device__ __forceinline__ void st_row_env(float* p, int rowlen, int c_, float v) const { if (r == 0) p[(size_t)(env - row_base) * rowlen + c_] = v; }
+  __device__ __forceinline__ float ld_row_env(const float* p, int rowlen, int c_) const { return p[(size_t)(env - row_base) * rowlen + c_]; }
   __device__ __forceinline__ void phase(int id) const {
 #ifndef ETG_NO_PHASE_BARRIER16
     __builtin_amdgcn_sched_barrier(0);
@@ -397,10 +399,12 @@ struct GpuCtx16 {
 };
 template <bool FLAT> struct GpuCtx16T : GpuCtx16 { static constexpr bool kFlat = FLAT; };
 
-__device__ __forceinline__ bool make_ctx16(const KCfg& K, const DevState& D, GpuCtx16& c, float* lds_all) {
-  c.tid = threadIdx.x;
-  c.env = xcd_contiguous_block() * 4 + (threadIdx.x >> 4);
-  c.r = threadIdx.x & 15;
+// robot_block = index of the group of 4 robots this wave carries, lane = lane in the wave, lds_wave = the wave's
+// own [LDS16_FIELDS][64] parameter staging area
+__device__ __forceinline__ bool make_ctx16_at(const KCfg& K, const DevState& D, GpuCtx16& c, float* lds_wave, int robot_block, int lane) {
+  c.tid = lane;
+  c.env = robot_block * 4 + (lane >> 4);
+  c.r = lane & 15;
   c.leg = c.r >> 2;
   c.sub = c.r & 3;
   c.sc = c.sub < 2 ? c.sub : 2;
@@ -410,7 +414,7 @@ __device__ __forceinline__ bool make_ctx16(const KCfg& K, const DevState& D, Gpu
   c.col = (size_t)4 * c.env + c.leg;
   // stage in LDS only the leg-level parameters that the once-per-step code reads (c.par / c.par_joint); the tick
   // constants (gains, link block, gravity, trunk inertia, mu) go straight to registers through tpar*
-  float* mine = lds_all + threadIdx.x;
+  float* mine = lds_wave + lane;
   c.gpar = D.par;
   constexpr int kStaged[] = {PR_O1, PR_O1 + 1, PR_O1 + 2, PR_SY, PR_LAT_N, PR_LAT_A, PR_BASE_FOOT, PR_BASE_FOOT + 1,
                              PR_BASE_FOOT + 2, PR_POSE, PR_POSE + 1, PR_POSE + 2, PR_EMEAN, PR_EMEAN + 1, PR_EMEAN + 2,
@@ -419,6 +423,9 @@ __device__ __forceinline__ bool make_ctx16(const KCfg& K, const DevState& D, Gpu
   for (int k : kStaged) mine[k * 64] = D.par[(size_t)k * c.NL + c.col];
   c.lds = mine;
   return true;
+}
+__device__ __forceinline__ bool make_ctx16(const KCfg& K, const DevState& D, GpuCtx16& c, float* lds_all) {
+  return make_ctx16_at(K, D, c, lds_all, xcd_contiguous_block(), threadIdx.x);
 }
 
 template <bool FLAT>
@@ -486,6 +493,62 @@ __global__ void __launch_bounds__(BLOCK) k_rollout16(KCfg K, DevState D, int n_s
   if (!make_ctx16(K, D, c, lds_par)) return;
   State16<float> L = load_state16<float>(c, D.base, D.leg);
   rollout_steps16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, n_steps, obs);
+  store_state16(c, D.base, D.leg, L);
+}
+
+// Closed-loop rollout in one launch: a workgroup of 4 waves owns 16 robots = one 16-row tile of the policy MLP
+// (policy_core.h).  Per control step: observations of the 16 robots (LDS) -> policy on MFMA (the 4 waves share
+// the tile like k_policy) -> tanh(mean) * act_scale in LDS -> every wave runs its 4 robots' control step, writing
+// the next observation back to LDS.  Nothing but the final observation, the ring and the episode accumulators
+// touches HBM between steps.  (run_EStrain_episode / run_evaluate_episodes, train.py:182-249, with a fixed actor.)
+struct PolicyW { const float4 *w1, *w2, *w3; const float *b1, *b2, *b3; int in_dim, out_dim; };
+template <bool FLAT, bool BF16>
+__global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, PolicyW P, int n_steps, float act_scale, float* obs) {
+  using namespace pol;
+  constexpr int NWP = 4;
+  __shared__ __attribute__((aligned(16))) float bufA[TM * HS];
+  __shared__ __attribute__((aligned(16))) float bufB[TM * HS];
+  __shared__ float part[NWP][TM][16];
+  __shared__ float act_lds[TM][16];
+  __shared__ float obs_lds[TM * ETG_OBS_DIM];
+  __shared__ float lds_par[NWP][LDS16_FIELDS * 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tile = xcd_contiguous_block();            // 16 robots; the host guarantees N % 16 == 0
+  GpuCtx16T<FLAT> c;
+  make_ctx16_at(K, D, c, lds_par[wave], 4 * tile + wave, lane);
+  State16<float> L = load_state16<float>(c, D.base, D.leg);
+  StepCtl16<float> S = load_ctl16<float>(c, K, D.ctl, D.ictl, D.legctl);
+  TickPar<float> tp = load_tick_par<float>(c);
+  if (K.ext_force) tp.fext = {c.ld_env(D.ctl, CT_FEXT + 0), c.ld_env(D.ctl, CT_FEXT + 1), c.ld_env(D.ctl, CT_FEXT + 2)};
+  // current observation of the tile -> LDS
+  for (int idx = tid; idx < TM * ETG_OBS_DIM; idx += 256) obs_lds[idx] = obs[(size_t)tile * TM * ETG_OBS_DIM + idx];
+  float reward, done;
+  for (int s = 0; s < n_steps; s++) {
+    __syncthreads();
+    for (int idx = tid; idx < TM * 64; idx += 256) {   // obs tile, zero padded to the 64-wide K of layer 1
+      const int r = idx >> 6, col = idx & 63;
+      bufA[r * HS + col] = col < P.in_dim ? obs_lds[r * ETG_OBS_DIM + col] : 0.0f;
+    }
+    __syncthreads();
+    hidden_layer<BF16, 4, NWP>(bufA, P.w1, P.b1, bufB, wave, lane);
+    __syncthreads();
+    hidden_layer<BF16, HID / 16, NWP>(bufB, P.w2, P.b2, bufA, wave, lane);
+    __syncthreads();
+    output_partial<BF16, NWP>(bufA, P.w3, wave, lane, part);
+    __syncthreads();
+    {
+      const int r = tid >> 4, cidx = tid & 15;          // 256 threads = 16 rows x 16 columns
+      const float v = ((part[0][r][cidx] + part[1][r][cidx]) + (part[2][r][cidx] + part[3][r][cidx])) + (cidx < P.out_dim ? P.b3[cidx] : 0.0f);
+      act_lds[r][cidx] = tanhf(v) * act_scale;
+    }
+    __syncthreads();
+    const float action = c.sub < 3 ? act_lds[4 * wave + (lane >> 4)][3 * c.leg + c.sub] : 0.0f;
+    // the step code addresses observation rows by robot index: rows of the LDS tile start at the tile's first robot
+    const bool last = s == n_steps - 1;
+    c.row_base = last ? 0 : tile * TM;
+    control_step16_core(c, K, tp, L, S, D.ring, D.etgp, action, 0.0f, last ? obs : obs_lds, reward, done, (float*)nullptr);
+  }
+  store_ctl16(c, K, S, D.ctl, D.ictl, D.legctl);
   store_state16(c, D.base, D.leg, L);
 }
 
@@ -808,6 +871,33 @@ extern "C" int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float
   }
   HIP_TRY(hipGetLastError());
   return etg_episode_stats(h, ret, len, stream);
+}
+
+extern "C" int etg_rollout_policy(EtgHandle* h, EtgPolicy* pol, int n_steps, float act_scale, int precision, float* obs,
+                                  float* ret, int32_t* len, void* stream) {
+  CHECK_HANDLE(h);
+  if (!pol || n_steps <= 0 || !obs) return fail(ETG_ERR_BAD_ARG, "etg_rollout_policy: bad arguments");
+  if (!h->was_reset) return fail(ETG_ERR_STATE, "etg_rollout_policy: call etg_reset first");
+  if (pol->device != h->device) return fail(ETG_ERR_BAD_ARG, "etg_rollout_policy: policy and simulator live on different devices");
+  if (pol->in_dim != ETG_OBS_DIM || pol->out_dim != ETG_ACT_DIM)
+    return fail(ETG_ERR_BAD_ARG, "etg_rollout_policy: the policy must map the 49-float observation to 12 actions");
+  if (h->lanes != 16 || h->N % 16 != 0 || h->K.motor_mode == 2)
+    return fail(ETG_ERR_STATE, "etg_rollout_policy: needs the 16-lanes-per-robot mapping, num_envs % 16 == 0, POSITION/TORQUE mode");
+  PolicyW P = {(const float4*)pol->w1, (const float4*)pol->w2, (const float4*)pol->w3, pol->b1, pol->b2, pol->b3, pol->in_dim, pol->out_dim};
+  constexpr int ROLLOUT_CHUNK = 50;
+  const dim3 g(h->N / 16), b(256);
+  hipStream_t s = (hipStream_t)stream;
+  const bool flat = h->K.terrain == 0;
+  for (int done_steps = 0; done_steps < n_steps; done_steps += ROLLOUT_CHUNK) {
+    const int m = n_steps - done_steps < ROLLOUT_CHUNK ? n_steps - done_steps : ROLLOUT_CHUNK;
+    if (flat && precision == 0) hipLaunchKernelGGL((k_rollout_policy16<true, false>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
+    else if (flat) hipLaunchKernelGGL((k_rollout_policy16<true, true>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
+    else if (precision == 0) hipLaunchKernelGGL((k_rollout_policy16<false, false>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
+    else hipLaunchKernelGGL((k_rollout_policy16<false, true>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
+  }
+  HIP_TRY(hipGetLastError());
+  if (ret || len) return etg_episode_stats(h, ret, len, stream);
+  return ETG_OK;
 }
 
 extern "C" int etg_get_state(EtgHandle* h, float* state, void* stream) {

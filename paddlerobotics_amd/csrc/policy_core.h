@@ -1,0 +1,140 @@
+// policy_core.h -- device code of the fused policy MLP shared by policy_mlp.hip (stand-alone k_policy, 16 waves per
+// 16-row tile) and etg_kernels.hip (the closed-loop rollout kernel, where the 4 waves that own a tile's 16 robots
+// also run their physics).  See policy_mlp.hip for the MFMA operand mapping and the packed weight layout.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace pol {
+
+constexpr int TM = 16;         // robots per tile / workgroup
+constexpr int HID = 256;       // hidden width (Actor: 256)
+constexpr int HS = HID + 4;    // LDS row stride in floats: rotates 16-B slots by one per row
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ __bf16 to_bf16(float x) {  // round to nearest even
+  unsigned u = __float_as_uint(x);
+  u += 0x7FFFu + ((u >> 16) & 1u);
+  unsigned short h = (unsigned short)(u >> 16);
+  return __builtin_bit_cast(__bf16, h);
+}
+__device__ __forceinline__ bf16x8 pack_bf16(float4 a, float4 b) {
+  bf16x8 v = {to_bf16(a.x), to_bf16(a.y), to_bf16(a.z), to_bf16(a.w), to_bf16(b.x), to_bf16(b.y), to_bf16(b.z), to_bf16(b.w)};
+  return v;
+}
+
+// out[16][this wave's 16*TPW columns] = relu(in[16][16*nkb] * W^T + b); wp = packed weights of the layer
+template <bool BF16, int NKB, int NW_>
+__device__ __forceinline__ void hidden_layer(const float* in, const float4* __restrict__ wp, const float* b,
+                                             float* out, int wave, int lane) {
+  constexpr int nkb = NKB;
+  constexpr int TPW = (HID / 16) / NW_;   // 16-column output tiles per wave
+  const int i = lane & 15, g = lane >> 4;
+  f32x4 acc[TPW];
+#pragma unroll
+  for (int t = 0; t < TPW; t++) acc[t] = {0.f, 0.f, 0.f, 0.f};
+  // tile t of this wave: packed block ((TPW*wave + t) * nkb + kb); software-pipelined: the next k-block's
+  // fragments are in flight while the MFMAs of the current one issue
+  const float4* base = wp + (size_t)(TPW * wave) * nkb * 64 + lane;
+  const int tstride = nkb * 64;
+  if (!BF16) {
+    // weight fragments come from L2 (hundreds of ns) while one k-block is only 16 MFMAs (~0.2 us): keep PF
+    // k-blocks in flight in a register ring; the loop is fully unrolled so the ring indices are static
+    constexpr int PF = NKB < 3 ? NKB : 3;
+    float4 w[PF + 1][TPW];
+#pragma unroll
+    for (int p = 0; p < PF; p++)
+#pragma unroll
+      for (int t = 0; t < TPW; t++) w[p][t] = base[t * tstride + p * 64];
+    float4 av[2];   // the A fragment of the next k-block is read from LDS while this one's MFMAs issue
+    av[0] = *reinterpret_cast<const float4*>(&in[i * HS + 4 * g]);
+#pragma unroll
+    for (int kb = 0; kb < nkb; kb++) {
+      const float4 a = av[kb & 1];
+      if (kb + 1 < nkb) av[(kb + 1) & 1] = *reinterpret_cast<const float4*>(&in[i * HS + (kb + 1) * 16 + 4 * g]);
+      if (kb + PF < nkb) {
+#pragma unroll
+        for (int t = 0; t < TPW; t++) w[(kb + PF) % (PF + 1)][t] = base[t * tstride + (kb + PF) * 64];
+      }
+      const float4* w0 = w[kb % (PF + 1)];
+      // k-component outer, tile inner: 4 independent accumulators back to back, so the 40-cycle
+      // dependent-accumulator latency of v_mfma_f32_16x16x4_f32 never stalls the 32-cycle issue
+#pragma unroll
+      for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, w0[t].x, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, w0[t].y, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, w0[t].z, acc[t], 0, 0, 0);
+#pragma unroll
+      for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, w0[t].w, acc[t], 0, 0, 0);
+    }
+  } else {
+    // one bf16 MFMA (K = 32) consumes two consecutive 16-wide k-blocks; the k-slot order is free as
+    // long as A and B agree, so lane group g takes k = kb*16 + 4g..4g+3 from each block
+    for (int kb = 0; kb < nkb; kb += 2) {
+      const float4 a0 = *reinterpret_cast<const float4*>(&in[i * HS + kb * 16 + 4 * g]);
+      const float4 a1 = *reinterpret_cast<const float4*>(&in[i * HS + (kb + 1) * 16 + 4 * g]);
+      const bf16x8 av = pack_bf16(a0, a1);
+#pragma unroll
+      for (int t = 0; t < TPW; t++) {
+        const float4 b0 = base[t * tstride + kb * 64];
+        const float4 b1 = base[t * tstride + (kb + 1) * 64];
+        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pack_bf16(b0, b1), acc[t], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < TPW; t++) {
+    const int col = 16 * TPW * wave + 16 * t + i;
+    const float bias = b[col];
+#pragma unroll
+    for (int r = 0; r < 4; r++) out[(4 * g + r) * HS + col] = fmaxf(acc[t][r] + bias, 0.0f);
+  }
+}
+
+// output layer: one 16x16 tile of head weights `whp`, K split over the NW_ waves; every wave leaves its partial
+// 16x16 product in part[wave]
+template <bool BF16, int NW_>
+__device__ __forceinline__ void output_partial(const float* bufA, const float4* __restrict__ whp, int wave, int lane,
+                                               float (*part)[TM][16]) {
+  constexpr int KPW = (HID / 16) / NW_;   // k-blocks per wave
+  const int i = lane & 15, g = lane >> 4;
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  const float4* base = whp + lane;
+  if (!BF16) {
+#pragma unroll
+    for (int kk = 0; kk < KPW; kk++) {
+      const int kb = KPW * wave + kk;
+      const float4 a = *reinterpret_cast<const float4*>(&bufA[i * HS + kb * 16 + 4 * g]);
+      const float4 bw = base[kb * 64];
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bw.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bw.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bw.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bw.w, acc, 0, 0, 0);
+    }
+  } else {
+    // one bf16 MFMA spans two 16-wide k-blocks: with KPW = 1 only the even waves work here (odd ones add zeros)
+    constexpr int KP = KPW < 2 ? 2 : KPW;
+    const bool active = (wave % (KP / KPW)) == 0;
+#pragma unroll
+    for (int kk = 0; kk < (active ? KP : 0); kk += 2) {
+      const int kb = KPW * wave + kk;
+      const float4 a0 = *reinterpret_cast<const float4*>(&bufA[i * HS + kb * 16 + 4 * g]);
+      const float4 a1 = *reinterpret_cast<const float4*>(&bufA[i * HS + (kb + 1) * 16 + 4 * g]);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pack_bf16(a0, a1), pack_bf16(base[kb * 64], base[(kb + 1) * 64]), acc, 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) part[wave][4 * g + r][i] = acc[r];
+}
+
+}  // namespace pol
+
+// the policy handle (C-ABI EtgPolicy of include/etgsim.h)
+struct EtgPolicy {
+  int device, in_dim, hidden, out_dim;
+  float *w1, *b1, *w2, *b2, *w3, *b3;  // w1/w2/w3 hold the PACKED (MFMA-fragment order) copies
+  float *w3s, *b3s;                    // log-std head (etg_policy_load_std), packed like w3
+  int has_std;
+};

@@ -395,6 +395,24 @@ class BatchedQuadrupedEnv:
                                                   self._stream()))
         return ret, ln
 
+    def rollout_policy(self, policy, n_steps, act_scale=0.3, precision=0):
+        """n_steps closed-loop control steps with a fixed actor (policy.predict semantics) fused into one kernel per 50
+        steps; returns (episode_return[N], episode_len[N]).  The batched run_EStrain_episode / run_evaluate_episodes
+        (train.py:182-249).  Falls back to stepping when the fused kernel does not apply."""
+        ok = (self.lanes_per_robot == 16 and self.num_envs % 16 == 0 and self.motor_mode != 2 and self._col_idx is None
+              and self._hist_T == 0 and not self._rand_force and policy.obs_dim == A.OBS_DIM and policy.action_dim == A.NUM_MOTORS)
+        if not ok:
+            act = None
+            for _ in range(int(n_steps)):
+                act = policy.predict(self._obs_view() if self._hist_T == 0 else self.obs, act_scale, precision, out=act)
+                self.step(act, want_info=False)
+            return self.episode_stats()
+        ret = torch.zeros(self.num_envs, device=self.device)
+        ln = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        _lib.check(self._lib.etg_rollout_policy(self._h, policy._h, int(n_steps), C.c_float(act_scale), int(precision),
+                                                _ptr(self.obs), _ptr(ret), _ptr(ln), self._stream()))
+        return ret, ln
+
     def episode_stats(self):
         """(return[N], length[N]) accumulated on device since each robot's last reset, frozen at its
         first `done` (what run_episode / run_EStrain_episode return per candidate)."""

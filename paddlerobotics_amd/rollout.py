@@ -24,6 +24,10 @@ def run_episodes(env, max_step, ETG_w=None, ETG_b=None, policy=None, action_boun
         # open loop: the fused rollout (etg_rollout_openloop, up to 50 control steps per launch).  The forced `done`
         # of the last step only ends the episode; return and length are the same as with the stepping loop.
         return env.rollout_openloop(max_step + 1)
+    if policy is not None and hasattr(env, "rollout_policy") and not getattr(env, "_rand_force", False):
+        # closed loop with a fixed actor: policy tile + control step fused per workgroup (etg_rollout_policy); falls back
+        # to predict() + step() inside when the fused kernel does not apply
+        return env.rollout_policy(policy, max_step + 1, action_bound, precision)
     act = None
     for steps in range(1, max_step + 2):
         if policy is not None:

@@ -746,3 +746,38 @@ def test_short_control_latency_reads_this_steps_ring_slots(lanes):
         oo = orc.step(np.zeros((n, 12)))[0]
         assert np.abs(og - oo).max() < 5e-2, np.abs(og - oo).max(1)
     env.close()
+
+
+def test_fused_policy_rollout_equals_predict_and_step():
+    """etg_rollout_policy (policy MFMA tile + 13 ticks per control step inside one kernel, 16 robots per workgroup)
+    against the loop it replaces: policy.predict(obs) then env.step(action)."""
+    _need_gpu()
+    from paddlerobotics_amd.policy import MfmaPolicy
+    n = 64
+    W, B = _etg_params(n, seed=17)
+    pol = MfmaPolicy(49, 12)
+    pol.load_state_dict(MfmaPolicy.init_like_reference(49, 12, seed=3))
+    a, b = _make(n), _make(n)
+    a.reset(ETG_w=W, ETG_b=B); b.reset(ETG_w=W, ETG_b=B)
+    ret1, ln1 = a.rollout_policy(pol, 1, 0.3)
+    b.step(pol.predict(b.obs, 0.3), want_info=False)
+    sa, sb = a.get_state().cpu().numpy(), b.get_state().cpu().numpy()
+    pos = list(range(7)) + list(range(13, 25))                # the tile's K-split sums in a different order: ~1 ulp actions
+    assert np.abs(sa - sb)[:, pos].max() < 1e-4 and np.abs(sa - sb).max() < 5e-2
+    assert np.abs(a.obs.cpu().numpy() - b.obs.cpu().numpy()).max() < 1e-3
+    ret, ln = a.rollout_policy(pol, 24, 0.3)
+    for _ in range(24):
+        b.step(pol.predict(b.obs, 0.3), want_info=False)
+    ret_b, ln_b = b.episode_stats()
+    same = (ln == ln_b)
+    assert same.float().mean().item() > 0.9
+    assert torch.allclose(ret[same], ret_b[same], rtol=2e-2, atol=0.5)
+    err = np.abs(a.get_state().cpu().numpy() - b.get_state().cpu().numpy())[:, 13:25].max(1)
+    assert np.median(err) < 5e-3
+    assert torch.isfinite(a.obs).all()
+    # configurations the fused kernel does not cover fall back to stepping
+    c = _make(24, lanes_per_robot=4)
+    c.reset()
+    r, l = c.rollout_policy(pol, 3, 0.3)
+    assert tuple(r.shape) == (24,) and int(l.max()) <= 3
+    a.close(); b.close(); c.close()
