@@ -206,6 +206,7 @@ class BatchedQuadrupedEnv:
         self._push_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self._dyn_stage = self._dyn_dev = self._dyn_evt = None
         self._all_done = None
+        self._last_view = None
         self._hf = None
         if heightfield is not None:
             self._hf = torch.as_tensor(np.ascontiguousarray(heightfield["heights"], dtype=np.float32), device=dev)
@@ -321,7 +322,8 @@ class BatchedQuadrupedEnv:
             _lib.check(self._lib.etg_clear_pushes(self._h, _ptr(m), self._stream()))
         _lib.check(self._lib.etg_reset(self._h, _ptr(m), _ptr(self.obs), self._stream()))
         info = {"ETG_act": None}
-        return self._obs_view(reset_mask=m, first=True), info
+        self._last_view = self._obs_view(reset_mask=m, first=True)
+        return self._last_view, info
 
     def _obs_view(self, reset_mask=None, first=False):
         """the observation the caller sees: sensor_mode column selection, then (optionally) the history stack.
@@ -383,7 +385,8 @@ class BatchedQuadrupedEnv:
         _lib.check(self._lib.etg_step(self._h, _ptr(a), _ptr(df), _ptr(self.obs), _ptr(self.reward), _ptr(self.done),
                                       _ptr(self.info_buf) if want_info else None, self._stream()))
         self._keep_step = (a, df)
-        return (self._obs_view(), self.reward, self.done.view(torch.bool) if want_info else self.done,
+        self._last_view = self._obs_view()
+        return (self._last_view, self.reward, self.done.view(torch.bool) if want_info else self.done,
                 (self._info() if want_info else {}))
 
     def rollout_openloop(self, n_steps):
@@ -404,7 +407,7 @@ class BatchedQuadrupedEnv:
         if not ok:
             act = None
             for _ in range(int(n_steps)):
-                act = policy.predict(self._obs_view() if self._hist_T == 0 else self.obs, act_scale, precision, out=act)
+                act = policy.predict(self._last_view.contiguous().view(self.num_envs, -1), act_scale, precision, out=act)
                 self.step(act, want_info=False)
             return self.episode_stats()
         ret = torch.zeros(self.num_envs, device=self.device)
