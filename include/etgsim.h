@@ -223,10 +223,11 @@ void etg_policy_destroy(EtgPolicy* p);
 /* closed-loop rollout with a fixed actor in ONE kernel per 50 control steps (run_EStrain_episode / run_evaluate_episodes,
  * train.py:182-249): per step action = tanh(mean(obs)) * act_scale as etg_policy_forward computes it, then one
  * control step; a workgroup keeps its 16 robots' observations, actions and states on chip between the steps.
- * obs [N,49]: in = the current observation (as left by etg_reset / etg_step), out = the final one.  ret / len as
- * etg_episode_stats (may be NULL).  Needs the 16-lanes-per-robot mapping, num_envs % 16 == 0, a 49 -> 12 policy. */
-int etg_rollout_policy(EtgHandle* h, EtgPolicy* policy, int n_steps, float act_scale, int precision, float* obs,
-                       float* ret, int32_t* len, void* stream);
+ * obs [N,49]: in = the current observation (as left by etg_reset / etg_step), out = the final one.  The actor sees the
+ * columns [obs_col0, obs_col0 + in_dim) of it (0 and 49 for the teacher, 3 and 46 for the student of BCtrain.py:53-59).
+ * ret / len as etg_episode_stats (may be NULL).  Needs the 16-lanes-per-robot mapping and num_envs % 16 == 0.        */
+int etg_rollout_policy(EtgHandle* h, EtgPolicy* policy, int n_steps, float act_scale, int precision, int obs_col0,
+                       float* obs, float* ret, int32_t* len, void* stream);
 
 /* ---- ETG parameterisation (the step right before reset) ----
  * Batched Opt_with_points / LS_sol (train.py:59-110): for every candidate fit the

@@ -501,7 +501,7 @@ __global__ void __launch_bounds__(BLOCK) k_rollout16(KCfg K, DevState D, int n_s
 // the tile like k_policy) -> tanh(mean) * act_scale in LDS -> every wave runs its 4 robots' control step, writing
 // the next observation back to LDS.  Nothing but the final observation, the ring and the episode accumulators
 // touches HBM between steps.  (run_EStrain_episode / run_evaluate_episodes, train.py:182-249, with a fixed actor.)
-struct PolicyW { const float4 *w1, *w2, *w3; const float *b1, *b2, *b3; int in_dim, out_dim; };
+struct PolicyW { const float4 *w1, *w2, *w3; const float *b1, *b2, *b3; int in_dim, out_dim, col0; };   // col0: first observation column the actor sees
 template <bool FLAT, bool BF16>
 __global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, PolicyW P, int n_steps, float act_scale, float* obs) {
   using namespace pol;
@@ -527,7 +527,7 @@ __global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, Po
     __syncthreads();
     for (int idx = tid; idx < TM * 64; idx += 256) {   // obs tile, zero padded to the 64-wide K of layer 1
       const int r = idx >> 6, col = idx & 63;
-      bufA[r * HS + col] = col < P.in_dim ? obs_lds[r * ETG_OBS_DIM + col] : 0.0f;
+      bufA[r * HS + col] = col < P.in_dim ? obs_lds[r * ETG_OBS_DIM + P.col0 + col] : 0.0f;
     }
     __syncthreads();
     hidden_layer<BF16, 4, NWP>(bufA, P.w1, P.b1, bufB, wave, lane);
@@ -873,17 +873,17 @@ extern "C" int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float
   return etg_episode_stats(h, ret, len, stream);
 }
 
-extern "C" int etg_rollout_policy(EtgHandle* h, EtgPolicy* pol, int n_steps, float act_scale, int precision, float* obs,
-                                  float* ret, int32_t* len, void* stream) {
+extern "C" int etg_rollout_policy(EtgHandle* h, EtgPolicy* pol, int n_steps, float act_scale, int precision, int obs_col0,
+                                  float* obs, float* ret, int32_t* len, void* stream) {
   CHECK_HANDLE(h);
   if (!pol || n_steps <= 0 || !obs) return fail(ETG_ERR_BAD_ARG, "etg_rollout_policy: bad arguments");
   if (!h->was_reset) return fail(ETG_ERR_STATE, "etg_rollout_policy: call etg_reset first");
   if (pol->device != h->device) return fail(ETG_ERR_BAD_ARG, "etg_rollout_policy: policy and simulator live on different devices");
-  if (pol->in_dim != ETG_OBS_DIM || pol->out_dim != ETG_ACT_DIM)
-    return fail(ETG_ERR_BAD_ARG, "etg_rollout_policy: the policy must map the 49-float observation to 12 actions");
+  if (obs_col0 < 0 || obs_col0 + pol->in_dim > ETG_OBS_DIM || pol->out_dim != ETG_ACT_DIM)
+    return fail(ETG_ERR_BAD_ARG, "etg_rollout_policy: the policy must map observation columns [col0, col0 + in_dim) to 12 actions");
   if (h->lanes != 16 || h->N % 16 != 0 || h->K.motor_mode == 2)
     return fail(ETG_ERR_STATE, "etg_rollout_policy: needs the 16-lanes-per-robot mapping, num_envs % 16 == 0, POSITION/TORQUE mode");
-  PolicyW P = {(const float4*)pol->w1, (const float4*)pol->w2, (const float4*)pol->w3, pol->b1, pol->b2, pol->b3, pol->in_dim, pol->out_dim};
+  PolicyW P = {(const float4*)pol->w1, (const float4*)pol->w2, (const float4*)pol->w3, pol->b1, pol->b2, pol->b3, pol->in_dim, pol->out_dim, obs_col0};
   constexpr int ROLLOUT_CHUNK = 50;
   const dim3 g(h->N / 16), b(256);
   hipStream_t s = (hipStream_t)stream;

@@ -402,8 +402,10 @@ class BatchedQuadrupedEnv:
         """n_steps closed-loop control steps with a fixed actor (policy.predict semantics) fused into one kernel per 50
         steps; returns (episode_return[N], episode_len[N]).  The batched run_EStrain_episode / run_evaluate_episodes
         (train.py:182-249).  Falls back to stepping when the fused kernel does not apply."""
-        ok = (self.lanes_per_robot == 16 and self.num_envs % 16 == 0 and self.motor_mode != 2 and self._col_idx is None
-              and self._hist_T == 0 and not self._rand_force and policy.obs_dim == A.OBS_DIM and policy.action_dim == A.NUM_MOTORS)
+        contiguous = self._cols == list(range(self._cols[0], self._cols[0] + len(self._cols)))   # e.g. the student's 3..48
+        ok = (self.lanes_per_robot == 16 and self.num_envs % 16 == 0 and self.motor_mode != 2 and contiguous
+              and self._hist_T == 0 and not self._rand_force and policy.obs_dim == len(self._cols)
+              and policy.action_dim == A.NUM_MOTORS)
         if not ok:
             act = None
             for _ in range(int(n_steps)):
@@ -413,7 +415,8 @@ class BatchedQuadrupedEnv:
         ret = torch.zeros(self.num_envs, device=self.device)
         ln = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
         _lib.check(self._lib.etg_rollout_policy(self._h, policy._h, int(n_steps), C.c_float(act_scale), int(precision),
-                                                _ptr(self.obs), _ptr(ret), _ptr(ln), self._stream()))
+                                                int(self._cols[0]), _ptr(self.obs), _ptr(ret), _ptr(ln), self._stream()))
+        self._last_view = self._obs_view()
         return ret, ln
 
     def episode_stats(self):

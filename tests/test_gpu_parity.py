@@ -775,6 +775,16 @@ def test_fused_policy_rollout_equals_predict_and_step():
     err = np.abs(a.get_state().cpu().numpy() - b.get_state().cpu().numpy())[:, 13:25].max(1)
     assert np.median(err) < 5e-3
     assert torch.isfinite(a.obs).all()
+    # the student's 46-float observation (columns 3..48, BCtrain.py:53-59) through the same fused kernel
+    spol = MfmaPolicy(46, 12)
+    spol.load_state_dict(MfmaPolicy.init_like_reference(46, 12, seed=5))
+    sa_env, sb_env = _make(n, sensor_mode={"dis": 0}), _make(n, sensor_mode={"dis": 0})
+    oa, _ = sa_env.reset(ETG_w=W, ETG_b=B); ob, _ = sb_env.reset(ETG_w=W, ETG_b=B)
+    sa_env.rollout_policy(spol, 3, 0.3)
+    for _ in range(3):
+        ob, _, _, _ = sb_env.step(spol.predict(ob.contiguous(), 0.3), want_info=False)
+    assert np.abs(sa_env.get_state().cpu().numpy() - sb_env.get_state().cpu().numpy())[:, pos].max() < 1e-3
+    sa_env.close(); sb_env.close()
     # configurations the fused kernel does not cover fall back to stepping
     c = _make(24, lanes_per_robot=4)
     c.reset()
