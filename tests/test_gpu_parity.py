@@ -791,3 +791,25 @@ def test_fused_policy_rollout_equals_predict_and_step():
     r, l = c.rollout_policy(pol, 3, 0.3)
     assert tuple(r.shape) == (24,) and int(l.max()) <= 3
     a.close(); b.close(); c.close()
+
+
+def test_fused_rollouts_on_terrain_match_stepping():
+    """the heightfield instantiations of the fused kernels (k_rollout16<false>, k_rollout_policy16<false, *>)"""
+    _need_gpu()
+    from paddlerobotics_amd.policy import MfmaPolicy
+    n = 32
+    pol = MfmaPolicy(49, 12)
+    pol.load_state_dict(MfmaPolicy.init_like_reference(49, 12, seed=1))
+    pos = list(range(7)) + list(range(13, 25))
+    for fused_call, step_call in (
+            (lambda e: e.rollout_openloop(6), lambda e: [e.step(None, want_info=False) for _ in range(6)]),
+            (lambda e: e.rollout_policy(pol, 6, 0.3), lambda e: [e.step(pol.predict(e.obs, 0.3), want_info=False) for _ in range(6)]),
+            (lambda e: e.rollout_policy(pol, 6, 0.3, 1), lambda e: [e.step(pol.predict(e.obs, 0.3, 1), want_info=False) for _ in range(6)])):
+        a, b = _make(n, task="stairstair", terrain_variants=4), _make(n, task="stairstair", terrain_variants=4)
+        a.reset(); b.reset()
+        fused_call(a); step_call(b)
+        sa, sb = a.get_state().cpu().numpy(), b.get_state().cpu().numpy()
+        assert np.isfinite(sa).all()
+        err = np.abs(sa - sb)[:, pos].max(1)
+        assert np.median(err) < 2e-3 and np.abs(a.obs.cpu().numpy() - b.obs.cpu().numpy()).mean() < 5e-2
+        a.close(); b.close()
