@@ -213,7 +213,7 @@ def main():
         barrier()
         dt1 = time.perf_counter() - t1
         stepwise = {"value": world * N * args.steps / dt1, "ms_per_step": dt1 / args.steps * 1e3,
-                    "note": "env.step() per control step (k_step16)" + (", policy.predict() before each" if policy is not None else "")}
+                    "note": "env.step() per control step (%s)" % ("k_step16" if lanes == 16 else "k_step") + (", policy.predict() before each" if policy is not None else "")}
 
     if rank == 0:
         total_steps = world * N * args.steps
