@@ -177,6 +177,13 @@ int etg_random_pushes(EtgHandle* h, uint64_t seed, float prob, int duration_step
                       void* stream);
 int etg_clear_pushes(EtgHandle* h, const uint8_t* mask, void* stream);
 
+/* start offsets xy [N,2] (m, added to init_pos x / y) used by the following resets of the masked robots
+ * (mask NULL = all; xy NULL = zero) -- the `x_noise` of env.reset (train.py:131,186,215; BCtrain.py:89: a start
+ * position jitter so the stairs are not always met in the same gait phase; rlschool's distribution is absent, the
+ * caller draws it). The robot settles AT the offset position; on flat ground, where the settle is translation
+ * invariant, a cached settle is shifted instead of re-simulated.                                            */
+int etg_set_reset_offsets(EtgHandle* h, const float* xy, const uint8_t* mask, void* stream);
+
 /* ---- the hot path ------------------------------------------------------- */
 /* reset masked envs (NULL = all): place at init pose, settle, write obs[N,49]
  * rows of the reset envs (other rows untouched).                             */

@@ -294,6 +294,7 @@ template <class T> struct Env {
   T I[NB][6][6];  // link spatial inertias (link frame)
   T kp[12], kd[12], mu, latency, grav[3];
   T fext[3];  // external force on the trunk COM, world frame (etg_set_external_force)
+  T reset_off[2];  // start offset (x, y) of the next reset (etg_set_reset_offsets)
   int band;   // terrain band of this robot (env index % hf_bands)
   // outputs of the last tick
   T tau[12];
@@ -815,6 +816,7 @@ template <class T> void build_obs(const Sim<T>& s, Env<T>& e, const T* etg_act, 
 template <class T> void reset_env(Sim<T>& s, Env<T>& e, T* obs) {
   const EtgRobotModel& m = s.model;
   for (int k = 0; k < 3; k++) { e.pos[k] = T(m.init_pos[k]); e.wb[k] = 0; e.vb[k] = 0; }
+  e.pos[0] += e.reset_off[0]; e.pos[1] += e.reset_off[1];
   e.quat[0] = e.quat[1] = e.quat[2] = 0; e.quat[3] = 1;
   for (int j = 0; j < 12; j++) { e.q[j] = T(m.pose_ori[j]); e.qd[j] = 0; e.lam[j] = 0; e.tau[j] = 0; }
   for (int l = 0; l < 4; l++) e.contact[l] = 0;
@@ -1037,6 +1039,13 @@ template <class F> void par_for(int n, int threads, F f) {
     auto* s = (Sim<T>*)h;                                                                           \
     for (int i = 0; i < s->N; i++)                                                                  \
       for (int k = 0; k < 3; k++) s->env[i].fext[k] = force ? force[(size_t)i * 3 + k] : T(0);      \
+  }                                                                                                 \
+  extern "C" void etgo_set_reset_offsets##SFX(void* h, const T* xy, const uint8_t* mask) {           \
+    auto* s = (Sim<T>*)h;                                                                           \
+    for (int i = 0; i < s->N; i++) {                                                                \
+      if (mask && !mask[i]) continue;                                                               \
+      for (int k = 0; k < 2; k++) s->env[i].reset_off[k] = xy ? xy[(size_t)i * 2 + k] : T(0);       \
+    }                                                                                               \
   }                                                                                                 \
   extern "C" void etgo_set_heightfield##SFX(void* h, const float* hts) {                            \
     auto* s = (Sim<T>*)h;                                                                           \

@@ -94,6 +94,13 @@ class OracleSim:
         f = None if force is None else self._arr(force, (self.N, 3))
         self._f("set_external_force")(self._h, _p(f))
 
+    def set_reset_offsets(self, xy, mask=None):
+        """start offsets [N,2] (m) of the following resets of the masked robots; None = zero."""
+        a = None if xy is None else self._arr(xy, (self.N, 2))
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        self._f("set_reset_offsets")(self._h, _p(a), _p(mask))
+
     def reset(self, mask=None, obs=None):
         if obs is None:
             obs = np.zeros((self.N, A.OBS_DIM), dtype=self.dtype)

@@ -847,8 +847,8 @@ ETG_HD void rollout_steps(const Ctx& c, const KCfg& K, LaneState<F>& L, float* r
 
 // ------------------------------------------------------------------ reset (minitaur.py:403-445, a1.py:289-349)
 template <class F, class Ctx>
-ETG_HD void reset_settle(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ring) {
-  L.p = {F(K.init_pos[0]), F(K.init_pos[1]), F(K.init_pos[2])};
+ETG_HD void reset_settle(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ring, F offx = F(0.0f), F offy = F(0.0f)) {
+  L.p = {F(K.init_pos[0]) + offx, F(K.init_pos[1]) + offy, F(K.init_pos[2])};   // (offx, offy): etg_set_reset_offsets
   L.qx = F(0.0f); L.qy = F(0.0f); L.qz = F(0.0f); L.qw = F(1.0f);
   L.wb = {F(0.0f), F(0.0f), F(0.0f)};
   L.vb = {F(0.0f), F(0.0f), F(0.0f)};
@@ -897,8 +897,8 @@ ETG_HD void reset_finish(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
 }
 template <class F, class Ctx>
 ETG_HD void reset_quad(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ring, float* ctl,
-                       int* ictl, float* legctl, const float* etgp, float* obs) {
-  reset_settle(c, K, L, ring);
+                       int* ictl, float* legctl, const float* etgp, float* obs, F offx = F(0.0f), F offy = F(0.0f)) {
+  reset_settle(c, K, L, ring, offx, offy);
   reset_finish(c, K, L, ring, ctl, ictl, legctl, etgp, obs);
 }
 

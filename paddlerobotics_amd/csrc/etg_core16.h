@@ -674,9 +674,9 @@ ETG_HD void rollout_steps16(const Ctx& c, const KCfg& K, State16<F>& L, float* r
 
 // ------------------------------------------------------------------ reset
 template <class F, class Ctx>
-ETG_HD void reset_settle16(const Ctx& c, const KCfg& K, State16<F>& L, float* ring) {
+ETG_HD void reset_settle16(const Ctx& c, const KCfg& K, State16<F>& L, float* ring, F offx = F(0.0f), F offy = F(0.0f)) {
   const F mj = c.jointf();
-  L.p = {F(K.init_pos[0]), F(K.init_pos[1]), F(K.init_pos[2])};
+  L.p = {F(K.init_pos[0]) + offx, F(K.init_pos[1]) + offy, F(K.init_pos[2])};   // (offx, offy): etg_set_reset_offsets
   L.qx = F(0.0f); L.qy = F(0.0f); L.qz = F(0.0f); L.qw = F(1.0f);
   L.wb = {F(0.0f), F(0.0f), F(0.0f)};
   L.vb = {F(0.0f), F(0.0f), F(0.0f)};
@@ -722,8 +722,8 @@ ETG_HD void reset_finish16(const Ctx& c, const KCfg& K, State16<F>& L, float* ri
 }
 template <class F, class Ctx>
 ETG_HD void reset_row16(const Ctx& c, const KCfg& K, State16<F>& L, float* ring, float* ctl, int* ictl, float* legctl,
-                        const float* etgp, float* obs) {
-  reset_settle16(c, K, L, ring);
+                        const float* etgp, float* obs, F offx = F(0.0f), F offy = F(0.0f)) {
+  reset_settle16(c, K, L, ring, offx, offy);
   reset_finish16(c, K, L, ring, ctl, ictl, legctl, etgp, obs);
 }
 

@@ -170,17 +170,33 @@ __device__ __forceinline__ void copy_base_column(const DevState& D, int env, int
   for (int f = 0; f < BS_N; f++) dst[(size_t)f * N + env] = src[(size_t)f * N + env];
 }
 
+// A cached settle is reusable when it ran at the start offset the robot resets to now; on flat ground the settle is
+// translation-invariant, so there any cached settle is reusable and k_cache_sync shifts it to the new offset.
+template <bool FLAT> __device__ __forceinline__ bool settle_cached(const KCfg& K, const DevState& D, int env) {
+  if (!D.cache_ok[env]) return false;
+  if (FLAT) return true;
+  return D.cache_off[env] == D.reset_off[env] && D.cache_off[K.n_env + env] == D.reset_off[K.n_env + env];
+}
+// every lane of the robot writes the same values (the robot's lanes share a wave: the reads above came first)
+__device__ __forceinline__ void settle_mark_fresh(const KCfg& K, const DevState& D, int env, float ox, float oy) {
+  D.cache_ok[env] = 0;   // "just settled": k_cache_sync snapshots the ring, k_cache_mark sets it again
+  D.cache_off[env] = ox;
+  D.cache_off[K.n_env + env] = oy;
+}
+
 template <bool FLAT>
 __global__ void __launch_bounds__(BLOCK) k_settle(KCfg K, DevState D, const uint8_t* mask) {
   GpuCtxT<FLAT> c;
   if (!make_ctx(K, c)) return;
-  if ((mask && !mask[c.env]) || D.cache_ok[c.env]) return;   // whole quads drop out together
+  if ((mask && !mask[c.env]) || settle_cached<FLAT>(K, D, c.env)) return;   // whole quads drop out together
   __shared__ float lds_par[PR_N * BLOCK];
   stage_params(c, D, lds_par);
   LaneState<float> L;
-  reset_settle(c, K, L, D.ring);
-  store_state(c, D.cache_base, D.cache_leg, L);              // the ring is copied by k_cache_ring (needs the stores done)
+  const float ox = D.reset_off[c.env], oy = D.reset_off[K.n_env + c.env];
+  reset_settle(c, K, L, D.ring, ox, oy);
+  store_state(c, D.cache_base, D.cache_leg, L);              // the ring is copied by k_cache_sync (needs the stores done)
   store_state(c, D.base, D.leg, L);
+  settle_mark_fresh(K, D, c.env, ox, oy);
 }
 
 // one thread per leg column: after a settle, snapshot the ring into the cache and mark the robot cached;
@@ -195,7 +211,12 @@ __global__ void __launch_bounds__(256) k_cache_sync(KCfg K, DevState D, const ui
     for (int w = 0; w < RING * 8; w++) D.cache_ring[(size_t)w * NL + col] = D.ring[(size_t)w * NL + col];
   } else {                  // cached: cache -> live arrays
     copy_leg_column(D, col, NL, false);
-    if ((col & 3) == 0) copy_base_column(D, env, N, false);
+    if ((col & 3) == 0) {
+      copy_base_column(D, env, N, false);
+      // shift to the offset of THIS reset (non-zero only on flat ground, see settle_cached)
+      D.base[(size_t)BS_PX * N + env] += D.reset_off[env] - D.cache_off[env];
+      D.base[(size_t)BS_PY * N + env] += D.reset_off[N + env] - D.cache_off[N + env];
+    }
   }
 }
 __global__ void __launch_bounds__(256) k_cache_mark(KCfg K, DevState D, const uint8_t* mask) {
@@ -433,11 +454,13 @@ __global__ void __launch_bounds__(BLOCK) k_settle16(KCfg K, DevState D, const ui
   __shared__ float lds_par[LDS16_FIELDS * BLOCK];
   GpuCtx16T<FLAT> c;
   if (!make_ctx16(K, D, c, lds_par)) return;
-  if ((mask && !mask[c.env]) || D.cache_ok[c.env]) return;   // whole rows drop out together
+  if ((mask && !mask[c.env]) || settle_cached<FLAT>(K, D, c.env)) return;   // whole rows drop out together
   State16<float> L;
-  reset_settle16(c, K, L, D.ring);
+  const float ox = D.reset_off[c.env], oy = D.reset_off[K.n_env + c.env];
+  reset_settle16(c, K, L, D.ring, ox, oy);
   store_state16(c, D.cache_base, D.cache_leg, L);
   store_state16(c, D.base, D.leg, L);
+  settle_mark_fresh(K, D, c.env, ox, oy);
 }
 
 template <bool FLAT>
@@ -688,6 +711,7 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
       {(void**)&h->D.par, PR_N * NL * 4},   {(void**)&h->D.ring, (size_t)RING * 8 * NL * 4},
       {(void**)&h->D.cache_base, BS_N * N * 4}, {(void**)&h->D.cache_leg, LG_N * NL * 4},
       {(void**)&h->D.cache_ring, (size_t)RING * 8 * NL * 4}, {(void**)&h->D.cache_ok, N},
+      {(void**)&h->D.reset_off, 2 * N * 4}, {(void**)&h->D.cache_off, 2 * N * 4},
       {(void**)&h->tmp_obs, ETG_OBS_DIM * N * 4}, {(void**)&h->tmp_reward, N * 4}, {(void**)&h->tmp_done, N}};
   for (auto& a : allocs) {
     if (hipMalloc(a.p, a.bytes) != hipSuccess) return fail(ETG_ERR_ALLOC, "etg_create: hipMalloc failed");
@@ -714,7 +738,7 @@ extern "C" void etg_destroy(EtgHandle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
   void* ptrs[] = {h->D.base, h->D.leg, h->D.ctl, h->D.ictl, h->D.legctl, h->D.etgp, h->D.par, h->D.ring, h->hf,
-                  h->D.cache_base, h->D.cache_leg, h->D.cache_ring, h->D.cache_ok,
+                  h->D.cache_base, h->D.cache_leg, h->D.cache_ring, h->D.cache_ok, h->D.reset_off, h->D.cache_off,
                   h->tmp_obs, h->tmp_reward, h->tmp_done};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
@@ -805,6 +829,19 @@ extern "C" int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* st
     if (flat) hipLaunchKernelGGL(k_finish<true>, g4, dim3(BLOCK), 0, s, h->K, h->D, mask, obs);
     else hipLaunchKernelGGL(k_finish<false>, g4, dim3(BLOCK), 0, s, h->K, h->D, mask, obs);
   }
+  HIP_TRY(hipGetLastError());
+  return ETG_OK;
+}
+
+__global__ void k_set_reset_offsets(KCfg K, DevState D, const float* xy, const uint8_t* mask) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= K.n_env || (mask && !mask[env])) return;
+  D.reset_off[env] = xy ? xy[2 * env] : 0.0f;
+  D.reset_off[K.n_env + env] = xy ? xy[2 * env + 1] : 0.0f;
+}
+extern "C" int etg_set_reset_offsets(EtgHandle* h, const float* xy, const uint8_t* mask, void* stream) {
+  CHECK_HANDLE(h);
+  hipLaunchKernelGGL(k_set_reset_offsets, dim3((h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->D, xy, mask);
   HIP_TRY(hipGetLastError());
   return ETG_OK;
 }

@@ -68,6 +68,8 @@ struct DevState {
   // copies it back instead of re-simulating (cache_ok[env]; cleared when its dyn row or the heightfield changes).
   float *cache_base, *cache_leg, *cache_ring;
   unsigned char* cache_ok;
+  // start offsets [2][N] (x, y; etg_set_reset_offsets) of the next reset, and the ones each cached settle ran at
+  float *reset_off, *cache_off;
 };
 
 // ---- float lane math ------------------------------------------------------------

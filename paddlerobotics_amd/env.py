@@ -206,6 +206,7 @@ class BatchedQuadrupedEnv:
         self._push_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self._dyn_stage = self._dyn_dev = self._dyn_evt = None
         self._all_done = None
+        self._noise_offsets = False
         self._last_view = None
         self._hf = None
         if heightfield is not None:
@@ -318,6 +319,16 @@ class BatchedQuadrupedEnv:
             rows = A.param2dynamic_rows(self._np_rng.uniform(-1, 1, size=(self.num_envs, A.DYN_DIM)) * self._rand_dyn_scale)
             self.set_dynamic_param(rows, env_ids)          # masked: only the robots being reset take their row
         m = self._mask(env_ids)
+        if x_noise:
+            # start-position jitter (train.py:131 `x_noise=args.x_noise`, an int flag there; rlschool's own
+            # distribution is absent): x0 ~ U(-0.1, 0.1) * x_noise metres for every robot being reset
+            xy = torch.zeros(self.num_envs, 2, dtype=torch.float32, device=self.device)
+            xy[:, 0] = torch.as_tensor(self._np_rng.uniform(-0.1, 0.1, size=self.num_envs) * float(x_noise), dtype=torch.float32)
+            self.set_reset_offsets(xy, env_ids)
+            self._noise_offsets = True
+        elif self._noise_offsets:       # an earlier reset jittered these robots: back to the nominal start
+            self.set_reset_offsets(None, env_ids)
+            self._noise_offsets = env_ids is not None
         if self._rand_force:
             _lib.check(self._lib.etg_clear_pushes(self._h, _ptr(m), self._stream()))
         _lib.check(self._lib.etg_reset(self._h, _ptr(m), _ptr(self.obs), self._stream()))
@@ -351,6 +362,16 @@ class BatchedQuadrupedEnv:
             self._hist_head = (self._hist_head + 1) % H          # logical shift by one ...
             self._hist[(self._hist_head + H - 1) % H] = o          # ... and the newest reading goes last
         return seq.reshape(self.num_envs, -1) if self._hist_mode == "stack" else seq
+
+    def set_reset_offsets(self, xy, env_ids=None):
+        """start offsets xy [N,2] (m, added to the initial x / y) of the following resets of `env_ids`
+        (None = all robots); xy None = zero. `reset(x_noise=...)` draws them itself."""
+        m = self._mask(env_ids)
+        if xy is None:
+            _lib.check(self._lib.etg_set_reset_offsets(self._h, None, _ptr(m), self._stream()))
+            return
+        self._offsets = self._f32(xy, (self.num_envs, 2), "reset offsets").clone()   # kept alive until the copy ran
+        _lib.check(self._lib.etg_set_reset_offsets(self._h, _ptr(self._offsets), _ptr(m), self._stream()))
 
     def set_external_force(self, force):
         """force [N,3] (world frame, N) pushed on every trunk until replaced; None clears it."""

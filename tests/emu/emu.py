@@ -66,6 +66,10 @@ class EmuSim:
         f = None if force is None else np.ascontiguousarray(force, dtype=np.float32)
         self._l.emu_set_external_force(self._h, _p(f))
 
+    def set_reset_offsets(self, xy):
+        a = None if xy is None else np.ascontiguousarray(xy, dtype=np.float32)
+        self._l.emu_set_reset_offsets(self._h, _p(a))
+
     def reset(self, mask=None):
         obs = np.zeros((self.N, A.OBS_DIM), dtype=np.float32)
         if mask is not None:

@@ -143,7 +143,7 @@ struct Emu {
   KCfg K;
   ModelF M;
   int N;
-  std::vector<float> base, leg, ctl, legctl, etgp, par, ring, hf;
+  std::vector<float> base, leg, ctl, legctl, etgp, par, ring, hf, reset_off;
   std::vector<int> ictl;
 };
 }  // namespace etg
@@ -191,19 +191,25 @@ extern "C" void emu_set_external_force(void* h, const float* force) {
     for (int k = 0; k < 3; k++) e->ctl[(size_t)(CT_FEXT + k) * e->N + i] = force ? force[(size_t)i * 3 + k] : 0.0f;
   e->K.ext_force = force ? 1 : 0;
 }
+extern "C" void emu_set_reset_offsets(void* h, const float* xy) {
+  Emu* e = (Emu*)h;
+  e->reset_off.assign((size_t)2 * e->N, 0.0f);
+  if (xy) std::copy(xy, xy + (size_t)2 * e->N, e->reset_off.begin());
+}
 extern "C" void emu_reset(void* h, const uint8_t* mask, float* obs) {
   Emu* e = (Emu*)h;
   for (int i = 0; i < e->N; i++) {
     if (mask && !mask[i]) continue;
+    const float ox = e->reset_off.empty() ? 0.0f : e->reset_off[2 * i], oy = e->reset_off.empty() ? 0.0f : e->reset_off[2 * i + 1];
     if (e->lanes == 16) {
       State16<F16> S;
       if (e->K.terrain == 0) {
         EmuCtx16T<true> c(i, e->N, e->par.data());
-        reset_row16(c, e->K, S, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs);
+        reset_row16(c, e->K, S, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs, F16(ox), F16(oy));
         store_state16(c, e->base.data(), e->leg.data(), S);
       } else {
         EmuCtx16T<false> c(i, e->N, e->par.data());
-        reset_row16(c, e->K, S, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs);
+        reset_row16(c, e->K, S, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs, F16(ox), F16(oy));
         store_state16(c, e->base.data(), e->leg.data(), S);
       }
       continue;
@@ -211,11 +217,11 @@ extern "C" void emu_reset(void* h, const uint8_t* mask, float* obs) {
     LaneState<F4> L;
     if (e->K.terrain == 0) {
       EmuCtxT<true> c(i, e->N, e->par.data());
-      reset_quad(c, e->K, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs);
+      reset_quad(c, e->K, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs, F4(ox), F4(oy));
       store_state(c, e->base.data(), e->leg.data(), L);
     } else {
       EmuCtxT<false> c(i, e->N, e->par.data());
-      reset_quad(c, e->K, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs);
+      reset_quad(c, e->K, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs, F4(ox), F4(oy));
       store_state(c, e->base.data(), e->leg.data(), L);
     }
   }

@@ -813,3 +813,61 @@ def test_fused_rollouts_on_terrain_match_stepping():
         err = np.abs(sa - sb)[:, pos].max(1)
         assert np.median(err) < 2e-3 and np.abs(a.obs.cpu().numpy() - b.obs.cpu().numpy()).mean() < 5e-2
         a.close(); b.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_reset_offsets_and_x_noise(lanes):
+    """etg_set_reset_offsets / reset(x_noise=...): flat ground shifts the cached settle, a heightfield re-settles at the
+    new start position; both agree with the oracle settling at the offset."""
+    _need_gpu()
+    n = 32
+    W, B = _etg_params(1, seed=2)
+    rng = np.random.default_rng(5)
+    xy1 = rng.uniform(-0.1, 0.1, size=(n, 2)); xy2 = rng.uniform(-0.1, 0.1, size=(n, 2))
+    # ---- flat
+    env = _make(n, lanes_per_robot=lanes)
+    env.reset(ETG_w=W[0], ETG_b=B[0])
+    st0 = env.get_state().clone()                               # nominal start, fills the settle cache
+    orc = _oracle(n)
+    orc.set_params(etg_w=W[0], etg_b=B[0])
+    for xy in (xy1, xy2):
+        env.set_reset_offsets(xy)
+        obs = env.reset()[0]
+        st = env.get_state()
+        shift = torch.as_tensor(xy, dtype=torch.float32, device="cuda:0")
+        assert (st[:, :2] - st0[:, :2] - shift).abs().max() < 1e-6 and torch.equal(st[:, 2:], st0[:, 2:])
+        orc.set_reset_offsets(xy)
+        oo = orc.reset()
+        assert np.abs(st.cpu().numpy()[:, :7] - orc.get_state()[:, :7]).max() < 1e-3
+        assert np.abs(obs.cpu().numpy() - oo).max() < 5e-2
+    ids = torch.tensor([3, 9], device="cuda:0")
+    env.set_reset_offsets(None, env_ids=ids)                    # only these two go back to the nominal start
+    env.reset()
+    st = env.get_state()
+    assert torch.equal(st[ids], st0[ids]) and (st[0, 0] - st0[0, 0] - float(xy2[0, 0])).abs() < 1e-6
+    # x_noise draws the jitter itself; a later plain reset returns to the nominal start
+    env.reset(x_noise=1)
+    x = env.get_state()[:, 0] - st0[:, 0]
+    assert x.abs().max() <= 0.1 + 1e-6 and x.std() > 0.02
+    env.reset()
+    assert torch.equal(env.get_state(), st0)
+    env.close()
+    # ---- heightfield: the settle depends on where the robot stands, so a new offset re-simulates it
+    hf_rng = np.random.default_rng(0)
+    hf = {"heights": hf_rng.uniform(0, 0.05, size=(128, 128)).astype(np.float32), "cell": 0.05, "origin": (-3.2, -3.2)}
+    env = _make(n, lanes_per_robot=lanes, task="heightfield", heightfield=hf)
+    orc = _oracle(n, terrain=1, heightfield=hf)
+    orc.set_heightfield(hf["heights"])
+    orc.set_params(etg_w=W[0], etg_b=B[0])
+    env.reset(ETG_w=W[0], ETG_b=B[0])
+    z0 = env.get_state()[:, 2].clone()
+    for xy in (xy1, xy2, xy2):                                   # the repeat exercises the cached path at an offset
+        env.set_reset_offsets(xy)
+        env.reset()
+        st = env.get_state().cpu().numpy()
+        orc.set_reset_offsets(xy)
+        orc.reset()
+        assert np.abs(st[:, :7] - orc.get_state()[:, :7]).max() < 2e-3
+    assert (env.get_state()[:, 2] - z0).abs().max() > 1e-3      # different ground under the feet
+    env.close()

@@ -200,3 +200,38 @@ def test_emulation_hybrid_mode_matches_oracle(lanes):
         cmd = np.zeros((1, 60)); cmd[0, 0::5] = qdes; cmd[0, 1::5] = 80.0; cmd[0, 3::5] = [1., 2., 2.] * 4
         hyb.step(cmd)
         assert np.abs(hyb.get_state() - pos.get_state()).max() < 1e-9
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_emulation_reset_offsets_match_oracle(lanes):
+    """start offsets (the x_noise of env.reset): on flat ground the settle is translation invariant; on stairs the
+    robot that starts closer to the first riser reaches it earlier -- same in the kernels' code and the oracle"""
+    from oracle.oracle import OracleSim
+    from tests.emu.emu import EmuSim
+    n = 3
+    xy = np.array([[0.0, 0.0], [0.08, 0.0], [-0.1, 0.05]])
+    W, B = _params(n, seed=5)
+    cfg = A.default_config(n, solver_iters=4)
+    orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=lanes)
+    for s in (orc, emu):
+        s.set_params(etg_w=W[:1].repeat(n, 0), etg_b=B[:1].repeat(n, 0))
+        s.set_reset_offsets(xy)
+    oo, oe = orc.reset(), emu.reset()
+    so, se = orc.get_state(), emu.get_state()
+    assert np.abs(so[:, :2] - so[0, :2] - xy).max() < 1e-9          # flat: a pure translation of robot 0's settle
+    assert np.abs(so[:, 2:] - so[0, 2:]).max() < 1e-9 and np.abs(oo - oo[0]).max() < 1e-9
+    assert np.abs(se[:, :7] - so[:, :7]).max() < 2e-3 and np.abs(oe - oo).max() < 5e-2
+    # stairs: a banded task heightfield, the flat approach ends at x = 1
+    hf = T.make_task_heightfield("stairstair", variants=1, seed=1, cell=0.05)
+    cfg = A.default_config(n, solver_iters=4, terrain=1, heightfield=hf)
+    orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=lanes)
+    for s in (orc, emu):
+        s.set_heightfield(hf["heights"])
+        s.set_params(etg_w=W[:1].repeat(n, 0), etg_b=B[:1].repeat(n, 0))
+        s.set_reset_offsets(xy)
+        s.reset()
+    assert np.abs(emu.get_state()[:, :7] - orc.get_state()[:, :7]).max() < 2e-3
+    assert np.abs(orc.get_state()[:, :2] - orc.get_state()[0, :2] - xy).max() < 1e-4
+    # None clears the offsets again
+    orc.set_reset_offsets(None); orc.reset()
+    assert np.abs(orc.get_state()[:, 0] - orc.get_state()[0, 0]).max() < 1e-9
