@@ -177,6 +177,14 @@ int etg_random_pushes(EtgHandle* h, uint64_t seed, float prob, int duration_step
                       void* stream);
 int etg_clear_pushes(EtgHandle* h, const uint8_t* mask, void* stream);
 
+/* Gaussian sensor noise (minitaur.py:1206-1211 _AddSensorNoise; stdev[5] in the order of SENSOR_NOISE_STDDEV,
+ * minitaur.py:102: motor angle, motor velocity, motor torque, base rpy, base rpy rate). Added to the delayed
+ * readings that make up the observation (joint angles before MapToMinusPiToPi, joint velocities, rpy, rpy rate;
+ * torques are not part of the 49-float row); rewards, termination and the motor model read the true state, as in
+ * the reference. Counter-based RNG keyed by (seed, robot, observation index, channel): reproducible, identical
+ * through etg_step and the fused rollouts. NULL or all-zero stdev switches it off (the default).            */
+int etg_set_sensor_noise(EtgHandle* h, const float* stdev, uint64_t seed);
+
 /* start offsets xy [N,2] (m, added to init_pos x / y) used by the following resets of the masked robots
  * (mask NULL = all; xy NULL = zero) -- the `x_noise` of env.reset (train.py:131,186,215; BCtrain.py:89: a start
  * position jitter so the stairs are not always met in the same gait phase; rlschool's distribution is absent, the

@@ -309,6 +309,11 @@ template <class T> struct Sim {
   int N;
   std::vector<Env<T>> env;
   std::vector<float> heights;
+  // Gaussian sensor noise (minitaur.py:1206-1211), etgo_set_sensor_noise; stream position of this call's observation
+  int noise_on = 0;
+  float noise_std[5] = {0, 0, 0, 0, 0};
+  uint64_t noise_seed = 0;
+  unsigned obs_calls = 0, noise_call = 0;
   mutable T* dbgM = nullptr;  // optional taps (tests): 18x18 mass matrix, 18 bias
   mutable T* dbgC = nullptr;
   // tree description
@@ -772,6 +777,23 @@ template <class T> void etg_action(const Sim<T>& s, const Env<T>& e, T t, T* act
   }
 }
 
+// counter-based standard normal pair (seed, robot, observation index, channel): splitmix64 finaliser twice, Box-Muller.
+// Restates the generator of the product (csrc/etg_layout.h: gauss_pair) so that both draw the same noise.
+static inline uint64_t mix64(uint64_t z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+template <class T> void gauss_pair(uint64_t seed, unsigned env, unsigned call, unsigned ch, T& a, T& b) {
+  uint64_t z = mix64(seed + 0x9E3779B97F4A7C15ull * ((uint64_t)env * 32ull + ch + 1ull));
+  z = mix64(z + call);
+  const T u1 = T((z >> 40) + 1ull) / T(16777216.0);
+  const T u2 = T((z >> 8) & 0xFFFFFFull) / T(16777216.0);
+  const T r = std::sqrt(T(-2) * std::log(u1)), th = T(2 * M_PI) * u2;
+  a = r * std::cos(th);
+  b = r * std::sin(th);
+}
+
 // observation assembly (EnvWrapper.py:60-109): sorted keys
 // BaseDisplacement(3) FootContactSensor(4) IMU(6) MotorAngleAcc(24) + ETG(12) = 49
 template <class T> void build_obs(const Sim<T>& s, Env<T>& e, const T* etg_act, T* obs, T* imu_raw) {
@@ -782,6 +804,18 @@ template <class T> void build_obs(const Sim<T>& s, Env<T>& e, const T* etg_act, 
   if (!e.first_rpy_set) {
     for (int k = 0; k < 3; k++) e.first_rpy[k] = rpy[k];
     e.first_rpy_set = 1;
+  }
+  if (s.noise_on) {   // _AddSensorNoise: motor angles [0], velocities [1], rpy [3], rpy rate [4] (torques [2] are not observed)
+    const unsigned ei = (unsigned)(&e - s.env.data());
+    T n0, n1;
+    for (int j = 0; j < 12; j++) {
+      gauss_pair<T>(s.noise_seed, ei, s.noise_call, j, n0, n1);
+      d[j] += T(s.noise_std[0]) * n0; d[12 + j] += T(s.noise_std[1]) * n1;
+    }
+    for (int k = 0; k < 3; k++) {
+      gauss_pair<T>(s.noise_seed, ei, s.noise_call, 16 + k, n0, n1);
+      rpy[k] += T(s.noise_std[3]) * n0; d[28 + k] += T(s.noise_std[4]) * n1;
+    }
   }
   const bool nrm = s.cfg.obs_normal != 0;
   const T ctrl_dt = T(s.cfg.sim_dt) * T(s.cfg.action_repeat);
@@ -1053,14 +1087,25 @@ template <class F> void par_for(int n, int threads, F f) {
   }                                                                                                 \
   extern "C" void etgo_reset##SFX(void* h, const uint8_t* mask, T* obs, int threads) {              \
     auto* s = (Sim<T>*)h;                                                                           \
+    s->noise_call = s->obs_calls++;                                                                 \
     par_for(s->N, threads, [=](int i) {                                                             \
       if (mask && !mask[i]) return;                                                                 \
       reset_env(*s, s->env[i], obs + (size_t)i * ETG_OBS_DIM);                                      \
     });                                                                                             \
   }                                                                                                 \
+  extern "C" void etgo_set_sensor_noise##SFX(void* h, const float* stdev, uint64_t seed) {         \
+    auto* s = (Sim<T>*)h;                                                                           \
+    s->noise_on = 0;                                                                                \
+    for (int k = 0; k < 5; k++) {                                                                   \
+      s->noise_std[k] = stdev ? stdev[k] : 0.0f;                                                    \
+      if (s->noise_std[k] > 0.0f) s->noise_on = 1;                                                  \
+    }                                                                                               \
+    s->noise_seed = seed;                                                                           \
+  }                                                                                                 \
   extern "C" void etgo_step##SFX(void* h, const T* action, const uint8_t* donef, T* obs, T* reward, \
                                   uint8_t* done, T* info, int threads) {                            \
     auto* s = (Sim<T>*)h;                                                                           \
+    s->noise_call = s->obs_calls++;                                                                 \
     par_for(s->N, threads, [=](int i) {                                                             \
       step_env(*s, s->env[i], action + (size_t)i * (s->cfg.motor_mode == 2 ? ETG_HYBRID_DIM : 12), donef ? donef[i] : 0,                        \
                obs + (size_t)i * ETG_OBS_DIM, reward + i, done + i,                                 \

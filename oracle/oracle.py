@@ -94,6 +94,11 @@ class OracleSim:
         f = None if force is None else self._arr(force, (self.N, 3))
         self._f("set_external_force")(self._h, _p(f))
 
+    def set_sensor_noise(self, stdev, seed=0):
+        """stdev[5]: motor angle, velocity, torque, rpy, rpy rate (minitaur.py:102 order); None switches it off."""
+        a = None if stdev is None else np.ascontiguousarray(stdev, dtype=np.float32)
+        self._f("set_sensor_noise")(self._h, _p(a), C.c_uint64(int(seed)))
+
     def set_reset_offsets(self, xy, mask=None):
         """start offsets [N,2] (m) of the following resets of the masked robots; None = zero."""
         a = None if xy is None else self._arr(xy, (self.N, 2))

@@ -12,7 +12,7 @@ _LIB = None
 
 SYMBOLS = [
     "etg_create", "etg_destroy", "etg_last_error", "etg_version", "etg_lanes_per_robot", "etg_set_params",
-    "etg_set_heightfield", "etg_set_external_force", "etg_random_pushes", "etg_clear_pushes", "etg_set_reset_offsets", "etg_reset", "etg_step", "etg_episode_stats", "etg_rollout_openloop",
+    "etg_set_heightfield", "etg_set_external_force", "etg_random_pushes", "etg_clear_pushes", "etg_set_reset_offsets", "etg_set_sensor_noise", "etg_reset", "etg_step", "etg_episode_stats", "etg_rollout_openloop",
     "etg_get_state",
     "etg_set_state", "etg_policy_create", "etg_policy_load", "etg_policy_forward", "etg_policy_load_std", "etg_policy_sample",
     "etg_policy_destroy", "etg_rollout_policy", "etg_fit_etg",
@@ -50,6 +50,7 @@ def load():
     lib.etg_random_pushes.argtypes = [vp, C.c_uint64, C.c_float, i32, C.c_float, C.c_float, vp]
     lib.etg_clear_pushes.argtypes = [vp, vp, vp]
     lib.etg_set_reset_offsets.argtypes = [vp, vp, vp, vp]
+    lib.etg_set_sensor_noise.argtypes = [vp, vp, C.c_uint64]
     lib.etg_reset.argtypes = [vp, vp, vp, vp]
     lib.etg_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     lib.etg_episode_stats.argtypes = [vp, vp, vp, vp]

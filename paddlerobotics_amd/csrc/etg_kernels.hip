@@ -548,6 +548,10 @@ __global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, Po
   float reward, done;
   for (int s = 0; s < n_steps; s++) {
     __syncthreads();
+    if (K.noise_on && s > 0) {   // sensor noise on the row the previous step left in LDS (the last one: k_add_noise)
+      add_sensor_noise(K, tile * TM + (tid >> 4), K.noise_call + s - 1, tid & 15, &obs_lds[(tid >> 4) * ETG_OBS_DIM]);
+      __syncthreads();
+    }
     for (int idx = tid; idx < TM * 64; idx += 256) {   // obs tile, zero padded to the 64-wide K of layer 1
       const int r = idx >> 6, col = idx & 63;
       bufA[r * HS + col] = col < P.in_dim ? obs_lds[r * ETG_OBS_DIM + P.col0 + col] : 0.0f;
@@ -573,6 +577,15 @@ __global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, Po
   }
   store_ctl16(c, K, S, D.ctl, D.ictl, D.legctl);
   store_state16(c, D.base, D.leg, L);
+}
+
+// Gaussian sensor noise on freshly written observation rows: one thread per (robot, channel).  A separate tiny
+// kernel so that the step kernels' code (and register allocation) is the same with and without noise.
+__global__ void k_add_noise(KCfg K, unsigned call, const uint8_t* mask, float* obs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int env = i >> 4;
+  if (env >= K.n_env || (mask && !mask[env])) return;
+  add_sensor_noise(K, env, call, i & 15, obs + (size_t)env * ETG_OBS_DIM);
 }
 
 // external force rows [N,3] -> the three SoA columns ctl[CT_FEXT + k][N]
@@ -655,6 +668,7 @@ struct EtgHandle {
   float* hf;
   int lanes;                    // 4 or 16 lanes per robot (EtgConfig.lanes_per_robot)
   unsigned long long push_calls;  // stream position of etg_random_pushes
+  unsigned obs_calls;             // stream position of the sensor noise: observations written so far
   bool was_reset;                 // etg_step before the first etg_reset is a caller error (state undefined)
   float *tmp_obs, *tmp_reward;  // sinks for etg_rollout_openloop
   uint8_t* tmp_done;
@@ -695,6 +709,7 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   h->M = make_modelf(*model);
   h->hf = nullptr;
   h->push_calls = 0;
+  h->obs_calls = 0;
   h->was_reset = false;
   if (cfg->lanes_per_robot != 0 && cfg->lanes_per_robot != 4 && cfg->lanes_per_robot != 16) {
     delete h;
@@ -743,6 +758,18 @@ extern "C" void etg_destroy(EtgHandle* h) {
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
+}
+
+// the next launch writes `n` observations per robot: give them the next n positions of the sensor-noise stream
+static inline void advance_obs_stream(EtgHandle* h, int n) {
+  h->K.noise_call = h->obs_calls;
+  h->obs_calls += (unsigned)n;
+}
+
+// noise for the observation rows the launch before wrote last (stream position K.noise_call + n - 1)
+static inline void launch_obs_noise(EtgHandle* h, int n, const uint8_t* mask, float* obs, hipStream_t s) {
+  if (!h->K.noise_on || !obs) return;
+  hipLaunchKernelGGL(k_add_noise, dim3((16 * h->N + 255) / 256), dim3(256), 0, s, h->K, h->K.noise_call + (unsigned)(n - 1), mask, obs);
 }
 
 #define CHECK_HANDLE(h)                                         \
@@ -807,6 +834,7 @@ extern "C" int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* st
   if (!obs) return fail(ETG_ERR_BAD_ARG, "etg_reset: obs is null");
   if (h->K.terrain == 1 && !h->K.hf) return fail(ETG_ERR_STATE, "etg_reset: heightfield not set");
   h->was_reset = true;
+  advance_obs_stream(h, 1);
   // 1. settle the masked robots that have no valid settle cache (kernel exits at once for the others)
   // 2. snapshot their ring / restore state + ring of the cached ones, mark everything masked as cached
   // 3. the part after the settle: control state, episode accumulators, first observation
@@ -829,6 +857,7 @@ extern "C" int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* st
     if (flat) hipLaunchKernelGGL(k_finish<true>, g4, dim3(BLOCK), 0, s, h->K, h->D, mask, obs);
     else hipLaunchKernelGGL(k_finish<false>, g4, dim3(BLOCK), 0, s, h->K, h->D, mask, obs);
   }
+  launch_obs_noise(h, 1, mask, obs, s);
   HIP_TRY(hipGetLastError());
   return ETG_OK;
 }
@@ -838,6 +867,18 @@ __global__ void k_set_reset_offsets(KCfg K, DevState D, const float* xy, const u
   if (env >= K.n_env || (mask && !mask[env])) return;
   D.reset_off[env] = xy ? xy[2 * env] : 0.0f;
   D.reset_off[K.n_env + env] = xy ? xy[2 * env + 1] : 0.0f;
+}
+extern "C" int etg_set_sensor_noise(EtgHandle* h, const float* stdev, uint64_t seed) {
+  CHECK_HANDLE(h);
+  h->K.noise_on = 0;
+  for (int k = 0; k < 5; k++) {
+    const float v = stdev ? stdev[k] : 0.0f;
+    if (!(v >= 0.0f)) return fail(ETG_ERR_BAD_ARG, "etg_set_sensor_noise: standard deviations must be >= 0");
+    h->K.noise_std[k] = v;
+    if (v > 0.0f) h->K.noise_on = 1;
+  }
+  h->K.noise_seed = seed;
+  return ETG_OK;
 }
 extern "C" int etg_set_reset_offsets(EtgHandle* h, const float* xy, const uint8_t* mask, void* stream) {
   CHECK_HANDLE(h);
@@ -852,6 +893,7 @@ extern "C" int etg_step(EtgHandle* h, const float* action, const uint8_t* donef,
   if (!obs || !reward || !done) return fail(ETG_ERR_BAD_ARG, "etg_step: obs/reward/done must be non-null");
   if (!h->was_reset) return fail(ETG_ERR_STATE, "etg_step: call etg_reset first");
   if (h->K.motor_mode == 2 && !action) return fail(ETG_ERR_BAD_ARG, "etg_step: the HYBRID motor mode needs a [N,60] command");
+  advance_obs_stream(h, 1);
   const dim3 g16((h->N + 3) / 4);
   if (h->lanes == 16) {
     if (h->K.terrain == 0)
@@ -864,6 +906,7 @@ extern "C" int etg_step(EtgHandle* h, const float* action, const uint8_t* donef,
   else
     hipLaunchKernelGGL(k_step<false>, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, action, donef,
                        obs, reward, done, info);
+  launch_obs_noise(h, 1, nullptr, obs, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return ETG_OK;
 }
@@ -891,6 +934,7 @@ extern "C" int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float
     for (int done_steps = 0; done_steps < n_steps; done_steps += ROLLOUT_CHUNK) {
       const int m = n_steps - done_steps < ROLLOUT_CHUNK ? n_steps - done_steps : ROLLOUT_CHUNK;
       float* o = (obs && done_steps + m == n_steps) ? obs : h->tmp_obs;
+      advance_obs_stream(h, m);
       if (h->lanes == 16) {
         if (flat) hipLaunchKernelGGL(k_rollout16<true>, g16, dim3(BLOCK), 0, s, h->K, h->D, m, o);
         else hipLaunchKernelGGL(k_rollout16<false>, g16, dim3(BLOCK), 0, s, h->K, h->D, m, o);
@@ -898,6 +942,7 @@ extern "C" int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float
         if (flat) hipLaunchKernelGGL(k_rollout<true>, g4, dim3(BLOCK), 0, s, h->K, h->D, m, o);
         else hipLaunchKernelGGL(k_rollout<false>, g4, dim3(BLOCK), 0, s, h->K, h->D, m, o);
       }
+      if (o == obs) launch_obs_noise(h, m, nullptr, obs, s);
     }
   } else {
     for (int k = 0; k < n_steps; k++) {
@@ -927,10 +972,12 @@ extern "C" int etg_rollout_policy(EtgHandle* h, EtgPolicy* pol, int n_steps, flo
   const bool flat = h->K.terrain == 0;
   for (int done_steps = 0; done_steps < n_steps; done_steps += ROLLOUT_CHUNK) {
     const int m = n_steps - done_steps < ROLLOUT_CHUNK ? n_steps - done_steps : ROLLOUT_CHUNK;
+    advance_obs_stream(h, m);
     if (flat && precision == 0) hipLaunchKernelGGL((k_rollout_policy16<true, false>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
     else if (flat) hipLaunchKernelGGL((k_rollout_policy16<true, true>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
     else if (precision == 0) hipLaunchKernelGGL((k_rollout_policy16<false, false>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
     else hipLaunchKernelGGL((k_rollout_policy16<false, true>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
+    launch_obs_noise(h, m, nullptr, obs, s);   // every chunk ends in the caller's rows: the next chunk reads them
   }
   HIP_TRY(hipGetLastError());
   if (ret || len) return etg_episode_stats(h, ret, len, stream);

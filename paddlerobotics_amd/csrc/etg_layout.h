@@ -58,7 +58,48 @@ struct KCfg {
   int ext_force;         // 1 once etg_set_external_force() installed a force (ctl[CT_FEXT..])
   int motor_mode;        // 0 POSITION (PD on a joint-angle command), 1 TORQUE (the command is the torque)
   float clip_cmd;        // > 0: clip the position command to q +- clip_cmd every tick (a1.py:439-457)
+  // Gaussian sensor noise (minitaur.py:1206-1211): stdev of motor angle, motor velocity, motor torque (not part of
+  // the 49-float observation), base rpy, base rpy rate -- the order of SENSOR_NOISE_STDDEV (minitaur.py:102)
+  int noise_on;
+  float noise_std[5];
+  unsigned long long noise_seed;
+  unsigned noise_call;   // stream position of the first observation this launch writes
 };
+
+// counter-based standard normal pair for (seed, robot, observation index, channel): splitmix64 finaliser twice, then
+// Box-Muller.  The same few lines are restated in the oracle (oracle/etgsim_oracle.cpp: gauss_pair).
+ETG_HD unsigned long long mix64_(unsigned long long z) {
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+ETG_HD void gauss_pair(unsigned long long seed, unsigned env, unsigned call, unsigned ch, float& a, float& b) {
+  unsigned long long z = mix64_(seed + 0x9E3779B97F4A7C15ull * ((unsigned long long)env * 32ull + ch + 1ull));
+  z = mix64_(z + call);
+  const float u1 = (float)((z >> 40) + 1ull) * (1.0f / 16777216.0f);           // (0, 1]
+  const float u2 = (float)((z >> 8) & 0xFFFFFFull) * (1.0f / 16777216.0f);    // [0, 1)
+  const float r = sqrtf(-2.0f * logf(u1)), th = 6.283185307179586f * u2;
+  a = r * cosf(th);
+  b = r * sinf(th);
+}
+// _AddSensorNoise (minitaur.py:1206-1211) on one written observation row, one call per channel slot 0..15:
+// slots 0..11 = joint j (angle column 13+j, velocity column 25+j), slots 12..14 = rpy k / rpy rate k (columns 7+k,
+// 10+k; RNG channels 16..18), slot 15 unused.  Scales follow the row's normalisation (write_obs).
+ETG_HD void add_sensor_noise(const KCfg& K, unsigned env, unsigned call, unsigned slot, float* row) {
+  if (slot >= 15) return;
+  const bool nrm = K.obs_normal != 0;
+  float n0, n1;
+  if (slot < 12) {
+    gauss_pair(K.noise_seed, env, call, slot, n0, n1);
+    row[13 + slot] += K.noise_std[0] * n0 * (nrm ? 10.0f : 1.0f);
+    row[25 + slot] += K.noise_std[1] * n1;
+  } else {
+    const unsigned k = slot - 12;
+    gauss_pair(K.noise_seed, env, call, 16 + k, n0, n1);
+    row[7 + k] += K.noise_std[3] * n0 * (nrm ? 10.0f : 1.0f);
+    row[10 + k] += K.noise_std[4] * n1 * (nrm ? 2.0f : 1.0f);
+  }
+}
 
 struct DevState {
   float *base, *leg, *ctl, *legctl, *etgp, *par, *ring;
@@ -237,6 +278,8 @@ inline KCfg make_kcfg(const EtgConfig& c, const EtgRobotModel& m) {
   K.hf_bands = c.hf_bands > 1 ? c.hf_bands : 1;
   K.hf_nx = c.hf_nx; K.hf_ny = c.hf_ny / K.hf_bands;
   K.ext_force = 0;
+  K.noise_on = 0; K.noise_seed = 0; K.noise_call = 0;
+  for (int k = 0; k < 5; k++) K.noise_std[k] = 0.0f;
   K.motor_mode = c.motor_mode;
   K.clip_cmd = (float)c.clip_motor_commands;
   K.hf_cell = (float)c.hf_cell; K.hf_x0 = (float)c.hf_x0; K.hf_y0 = (float)c.hf_y0;

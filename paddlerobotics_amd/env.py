@@ -123,7 +123,8 @@ class BatchedQuadrupedEnv:
                  settle_ticks=500, solver_iters=2, enable_action_interpolation=False,
                  heightfield=None, lanes_per_robot=0, terrain_variants=16, terrain_seed=0,
                  random_dynamics_scale=0.3, random_force_prob=0.02, random_force_steps=8,
-                 random_force_range=(5.0, 25.0), seed=0, enable_clip_motor_commands=False, **unused):
+                 random_force_range=(5.0, 25.0), seed=0, enable_clip_motor_commands=False,
+                 observation_noise_stdev=None, **unused):
         if render:
             raise ValueError("render is not supported by the batched GPU simulator")
         if int(ETG_H) != A.RBF_H:
@@ -204,6 +205,8 @@ class BatchedQuadrupedEnv:
         self.info_buf = torch.zeros(N, A.INFO_DIM, device=dev)
         self._col_idx = None if len(self._cols) == A.OBS_DIM else torch.tensor(self._cols, device=dev)
         self._push_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        if observation_noise_stdev is not None:
+            self.set_sensor_noise(observation_noise_stdev, seed=seed)
         self._dyn_stage = self._dyn_dev = self._dyn_evt = None
         self._all_done = None
         self._noise_offsets = False
@@ -362,6 +365,18 @@ class BatchedQuadrupedEnv:
             self._hist_head = (self._hist_head + 1) % H          # logical shift by one ...
             self._hist[(self._hist_head + H - 1) % H] = o          # ... and the newest reading goes last
         return seq.reshape(self.num_envs, -1) if self._hist_mode == "stack" else seq
+
+    def set_sensor_noise(self, stdev, seed=0):
+        """Gaussian sensor noise (minitaur.py:102,136 `observation_noise_stdev`): 5 standard deviations -- motor
+        angle, motor velocity, motor torque, base rpy, base rpy rate -- or None to switch it off.  Applies to the
+        observation rows (through step() and the fused rollouts alike); the dynamics never see it."""
+        if stdev is None:
+            _lib.check(self._lib.etg_set_sensor_noise(self._h, None, C.c_uint64(0)))
+            return
+        a = np.ascontiguousarray(stdev, dtype=np.float32)
+        if a.shape != (5,):
+            raise ValueError("observation_noise_stdev needs 5 values (angle, velocity, torque, rpy, rpy rate)")
+        _lib.check(self._lib.etg_set_sensor_noise(self._h, a.ctypes.data_as(C.c_void_p), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF)))
 
     def set_reset_offsets(self, xy, env_ids=None):
         """start offsets xy [N,2] (m, added to the initial x / y) of the following resets of `env_ids`

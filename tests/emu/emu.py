@@ -66,6 +66,11 @@ class EmuSim:
         f = None if force is None else np.ascontiguousarray(force, dtype=np.float32)
         self._l.emu_set_external_force(self._h, _p(f))
 
+    def set_sensor_noise(self, stdev, seed=0):
+        import ctypes
+        a = None if stdev is None else np.ascontiguousarray(stdev, dtype=np.float32)
+        self._l.emu_set_sensor_noise(self._h, _p(a), ctypes.c_uint64(seed))
+
     def set_reset_offsets(self, xy):
         a = None if xy is None else np.ascontiguousarray(xy, dtype=np.float32)
         self._l.emu_set_reset_offsets(self._h, _p(a))

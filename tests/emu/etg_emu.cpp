@@ -145,6 +145,7 @@ struct Emu {
   int N;
   std::vector<float> base, leg, ctl, legctl, etgp, par, ring, hf, reset_off;
   std::vector<int> ictl;
+  unsigned obs_calls = 0;
 };
 }  // namespace etg
 
@@ -196,8 +197,23 @@ extern "C" void emu_set_reset_offsets(void* h, const float* xy) {
   e->reset_off.assign((size_t)2 * e->N, 0.0f);
   if (xy) std::copy(xy, xy + (size_t)2 * e->N, e->reset_off.begin());
 }
+// what k_add_noise does after the step / reset kernels
+static void emu_obs_noise(Emu* e, const uint8_t* mask, float* obs) {
+  if (!e->K.noise_on) return;
+  for (int i = 0; i < e->N; i++) {
+    if (mask && !mask[i]) continue;
+    for (unsigned slot = 0; slot < 16; slot++) add_sensor_noise(e->K, i, e->K.noise_call, slot, obs + (size_t)i * ETG_OBS_DIM);
+  }
+}
+extern "C" void emu_set_sensor_noise(void* h, const float* stdev, uint64_t seed) {
+  Emu* e = (Emu*)h;
+  e->K.noise_on = 0;
+  for (int k = 0; k < 5; k++) { e->K.noise_std[k] = stdev ? stdev[k] : 0.0f; if (e->K.noise_std[k] > 0.0f) e->K.noise_on = 1; }
+  e->K.noise_seed = seed;
+}
 extern "C" void emu_reset(void* h, const uint8_t* mask, float* obs) {
   Emu* e = (Emu*)h;
+  e->K.noise_call = e->obs_calls++;
   for (int i = 0; i < e->N; i++) {
     if (mask && !mask[i]) continue;
     const float ox = e->reset_off.empty() ? 0.0f : e->reset_off[2 * i], oy = e->reset_off.empty() ? 0.0f : e->reset_off[2 * i + 1];
@@ -225,9 +241,11 @@ extern "C" void emu_reset(void* h, const uint8_t* mask, float* obs) {
       store_state(c, e->base.data(), e->leg.data(), L);
     }
   }
+  emu_obs_noise(e, mask, obs);
 }
 extern "C" void emu_step(void* h, const float* action, const uint8_t* donef, float* obs, float* reward, uint8_t* done, float* info) {
   Emu* e = (Emu*)h;
+  e->K.noise_call = e->obs_calls++;
   for (int i = 0; i < e->N; i++) {
     if (e->lanes == 16) {
       F16 r16, d16;
@@ -278,6 +296,7 @@ extern "C" void emu_step(void* h, const float* action, const uint8_t* donef, flo
     reward[i] = r.v[0];
     done[i] = d.v[0] > 0.5f;
   }
+  emu_obs_noise(e, nullptr, obs);
 }
 extern "C" void emu_get_state(void* h, float* st) {
   Emu* e = (Emu*)h;

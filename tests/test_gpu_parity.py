@@ -871,3 +871,62 @@ def test_reset_offsets_and_x_noise(lanes):
         assert np.abs(st[:, :7] - orc.get_state()[:, :7]).max() < 2e-3
     assert (env.get_state()[:, 2] - z0).abs().max() > 1e-3      # different ground under the feet
     env.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_sensor_noise_matches_oracle_and_fused_rollout(lanes):
+    """observation_noise_stdev (minitaur.py:102,1206-1211): same counter-based draws as the oracle, through env.step and
+    through the fused rollout kernels; the simulated state is the noise-free one."""
+    _need_gpu()
+    n = 64
+    std = [0.02, 0.3, 0.0, 0.01, 0.05]
+    W, B = _etg_params(n, seed=8)
+    env = _make(n, lanes_per_robot=lanes, observation_noise_stdev=std, seed=5)
+    clean = _make(n, lanes_per_robot=lanes)
+    orc = _oracle(n)
+    orc.set_params(etg_w=W, etg_b=B)
+    orc.set_sensor_noise(std, seed=5)
+    o = env.reset(ETG_w=W, ETG_b=B)[0]
+    clean.reset(ETG_w=W, ETG_b=B)
+    oo = orc.reset()
+    for k in range(4):
+        assert np.abs(o.cpu().numpy() - oo).max() < 5e-2
+        assert torch.equal(env.get_state(), clean.get_state())
+        o = env.step(None)[0]; clean.step(None)
+        oo = orc.step(np.zeros((n, 12)))[0]
+    d = (env.obs - clean.obs).cpu().numpy()
+    assert np.abs(d[:, :7]).max() == 0 and np.abs(d[:, 37:]).max() == 0
+    assert 0.5 * 0.2 < d[:, 13:25].std() < 1.5 * 0.2 and 0.5 * 0.3 < d[:, 25:37].std() < 1.5 * 0.3
+    # the fused rollout draws the same stream positions as stepping: run 3 more steps both ways
+    twin = _make(n, lanes_per_robot=lanes, observation_noise_stdev=std, seed=5)
+    twin.reset(ETG_w=W, ETG_b=B)
+    twin.rollout_openloop(4)
+    assert (twin.obs - env.obs).abs().max() < 1e-3
+    for _ in range(3):
+        env.step(None)
+    twin.rollout_openloop(3)
+    assert (twin.obs - env.obs).abs().max() < 2e-3
+    env.set_sensor_noise(None)
+    env.step(None); clean.step(None); clean.step(None); clean.step(None); clean.step(None)
+    assert torch.equal(env.obs, clean.obs)
+    for e in (env, clean, twin):
+        e.close()
+    if lanes == 16:   # closed loop: the actor inside the fused kernel sees the same noisy rows as policy.predict outside
+        from paddlerobotics_amd.policy import MfmaPolicy
+        pol = MfmaPolicy(49, 12)
+        pol.load_state_dict(MfmaPolicy.init_like_reference(49, 12, seed=3))
+        big = [10 * s_ for s_ in std]                              # large enough to steer the actions visibly
+        a, b, c = (_make(n, observation_noise_stdev=big, seed=9), _make(n, observation_noise_stdev=big, seed=9), _make(n))
+        for e in (a, b, c):
+            e.reset(ETG_w=W, ETG_b=B)
+        a.rollout_policy(pol, 6, 0.3)
+        c.rollout_policy(pol, 6, 0.3)
+        for _ in range(6):
+            b.step(pol.predict(b.obs, 0.3), want_info=False)
+        sa, sb, sc = (e.get_state().cpu().numpy() for e in (a, b, c))
+        assert np.median(np.abs(sa - sb)[:, 13:25].max(1)) < 5e-3
+        assert np.median(np.abs(sa - sc)[:, 13:25].max(1)) > 2e-2   # ... and the noise did change what the actor did
+        assert (a.obs - b.obs).abs().median() < 1e-2
+        for e in (a, b, c):
+            e.close()

@@ -235,3 +235,44 @@ def test_emulation_reset_offsets_match_oracle(lanes):
     # None clears the offsets again
     orc.set_reset_offsets(None); orc.reset()
     assert np.abs(orc.get_state()[:, 0] - orc.get_state()[0, 0]).max() < 1e-9
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_emulation_sensor_noise_matches_oracle(lanes):
+    """_AddSensorNoise (minitaur.py:1206-1211): the counter-based Gaussian noise lands on the same observation columns
+    with the same values in the kernels' code and in the oracle; the dynamics are untouched by it."""
+    from oracle.oracle import OracleSim
+    from tests.emu.emu import EmuSim
+    n = 3
+    std = np.array([0.02, 0.3, 0.0, 0.01, 0.05], dtype=np.float32)
+    cfg = A.default_config(n, solver_iters=4)
+    W, B = _params(n, seed=6)
+    clean, orc, emu = OracleSim(cfg), OracleSim(cfg), EmuSim(cfg, lanes=lanes)
+    for s in (clean, orc, emu):
+        s.set_params(etg_w=W, etg_b=B)
+    orc.set_sensor_noise(std, seed=11); emu.set_sensor_noise(std, seed=11)
+    oc, oo, oe = clean.reset(), orc.reset(), emu.reset()
+    devs = []
+    for k in range(6):
+        assert np.abs(oe - oo).max() < 5e-2
+        d = oo - oc
+        assert np.abs(d[:, :7]).max() == 0 and np.abs(d[:, 37:]).max() == 0     # displacement, contacts, ETG: no noise
+        devs.append(d)
+        assert np.abs(orc.get_state() - clean.get_state()).max() == 0            # the physics never sees the noise
+        oc = clean.step(np.zeros((n, 12)))[0]
+        oo = orc.step(np.zeros((n, 12)))[0]
+        oe = emu.step(np.zeros((n, 12)))[0]
+    d = np.stack(devs)                                                           # [6, n, 49] normalised units
+    # column scales: rpy /0.1, rpy rate /0.5, angle /0.1, velocity /1
+    for cols, sd in ((slice(7, 10), std[3] / 0.1), (slice(10, 13), std[4] / 0.5), (slice(13, 25), std[0] / 0.1),
+                     (slice(25, 37), std[1])):
+        got = d[:, :, cols].std()
+        assert 0.6 * sd < got < 1.5 * sd, (cols, got, sd)
+    assert np.abs(d[0] - d[1]).max() > 1e-3                                       # a fresh draw every observation
+    # same seed -> same stream; another seed -> another one
+    again = OracleSim(cfg); again.set_params(etg_w=W, etg_b=B); again.set_sensor_noise(std, seed=11)
+    other = OracleSim(cfg); other.set_params(etg_w=W, etg_b=B); other.set_sensor_noise(std, seed=12)
+    ref = OracleSim(cfg); ref.set_params(etg_w=W, etg_b=B); ref.set_sensor_noise(std, seed=11)
+    assert np.array_equal(again.reset(), ref.reset()) and not np.array_equal(other.reset(), ref.reset())
+    orc.set_sensor_noise(None)
+    assert np.abs(orc.step(np.zeros((n, 12)))[0] - clean.step(np.zeros((n, 12)))[0]).max() == 0
