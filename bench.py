@@ -88,6 +88,36 @@ def cpu_baseline(n_envs, steps, threads):
     return n_envs * steps / dt
 
 
+def es_generation_leg(env, world, rank, dist, barrier, max_step=400):
+    """two warm-up and three timed ES generations (mean) over the population of world x N candidates (candidate i = robot i)."""
+    from paddlerobotics_amd import rollout as R
+    from paddlerobotics_amd.es import SimpleGA
+    from paddlerobotics_amd.etg import ETG_layer, Opt_with_points
+    N = env.num_envs
+    layer = ETG_layer(0.5, 0.026, 20, 0.04, np.array([-np.pi / 2, 0]), 0.2, 0.5)
+    w0, b0, prior = Opt_with_points(layer, ETG_T=0.5, Footheight=0.1, Steplength=0.05)        # train.py:298-299
+    solver = SimpleGA(12, sigma_init=0.02, sigma_decay=0.99, sigma_limit=0.005, elite_ratio=0.1, weight_decay=0.005,
+                      popsize=world * N, param=np.zeros(12), device=str(env.device))           # train.py:288-295
+    evaluate = R.make_etg_evaluator(env, layer, 0.5, prior, w0, b0, max_step=max_step)
+    for _ in range(2):      # the first generation skips the elite merge: warm both code paths (lazy kernel loads)
+        R.es_generation(solver, evaluate, dist, rank, world)
+    GENS = 3
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(GENS):
+        fit = R.es_generation(solver, evaluate, dist, rank, world)
+    barrier()
+    dt = (time.perf_counter() - t0) / GENS
+    if dist is not None:
+        t = torch.tensor([dt], device=env.device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return {"value": world * N * (max_step + 1) / dt, "unit": "env-steps/s", "ms": dt * 1e3, "population": world * N,
+            "control_steps": max_step + 1, "fitness_mean": float(fit.mean().item()),
+            "includes": "SimpleGA.ask, etg_fit_etg (batched Opt_with_points), reset, fused open-loop rollout, "
+                        "all_gather of the returns, SimpleGA.tell"}
+
+
 def main():
     global SOLVER_ITERS
     ap = argparse.ArgumentParser()
@@ -215,6 +245,16 @@ def main():
         stepwise = {"value": world * N * args.steps / dt1, "ms_per_step": dt1 / args.steps * 1e3,
                     "note": "env.step() per control step (%s)" % ("k_step16" if lanes == 16 else "k_step") + (", policy.predict() before each" if policy is not None else "")}
 
+    # BASELINE configs[3] in miniature, reported next to `value` (never part of it): ONE full ES generation on the
+    # same robots -- SimpleGA.ask, batched Opt_with_points on the device, reset, 401 open-loop control steps, the
+    # all_gather of the returns (RCCL for N > 1), SimpleGA.tell replicated on every rank (train.py:398-418).
+    es_gen = None
+    if args.config != 3 and not args.stepwise:
+        try:
+            es_gen = es_generation_leg(env, world, rank, dist, barrier)
+        except Exception as e:                                   # noqa: BLE001 - an optional leg must not lose the line
+            es_gen = {"error": repr(e)[:200]}
+
     if rank == 0:
         total_steps = world * N * args.steps
         value = total_steps / elapsed
@@ -255,6 +295,8 @@ def main():
         }
         if stepwise is not None:
             out["stepwise"] = stepwise
+        if es_gen is not None:
+            out["es_generation"] = es_gen
         out["roofline"]["hbm_copy_measured_GBps"] = device_copy_bandwidth(dev) / 1e9
         if policy is not None:
             # the stand-alone policy kernel (what env.step-wise callers launch), 50 back-to-back launches in one event pair
