@@ -131,6 +131,7 @@ def main():
     ap.add_argument("--solver-iters", type=int, default=SOLVER_ITERS, help="PGS sweeps per tick")
     ap.add_argument("--lanes", type=int, default=0, choices=(0, 4, 16),
                     help="kernel mapping, lanes per robot (0 = library default: 16 up to 4096 robots, else 4)")
+    ap.add_argument("--body-contacts", action="store_true", help="knee spheres collide too (16-lane heightfield kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--stepwise", action="store_true",
                     help="open-loop configs: time env.step() per control step instead of the fused open-loop rollout")
@@ -158,7 +159,7 @@ def main():
         hf = np.random.default_rng(0).uniform(0.0, 0.05, size=(256, 256)).astype(np.float32)
         terrain_kw = dict(task="heightfield", heightfield=dict(heights=hf, cell=0.05, origin=(-6.4, -6.4)))
     env = make_env("Quadrupedal", num_envs=N, device=str(dev), solver_iters=args.solver_iters,
-                   lanes_per_robot=args.lanes, **terrain_kw)
+                   lanes_per_robot=args.lanes, body_contacts=args.body_contacts, **terrain_kw)
     lanes = env.lanes_per_robot
     w, b = etg_population(N, seed=rank, device=dev)
     env.reset(ETG_w=w, ETG_b=b)
@@ -275,7 +276,7 @@ def main():
                        ("configs[2]: %d parallel A1 per GPU, flat, ETG + residual MLP policy (random init, "
                         "precision %d)" % (N, args.precision)),
                        "robots_per_gpu": N, "action_repeat": 13, "sim_dt": 0.002, "solver_iters": args.solver_iters, "lanes_per_robot": lanes,
-                       "parallelism": "env-shard x%d" % world},
+                       "body_contacts": bool(args.body_contacts), "parallelism": "env-shard x%d" % world},
             "path": ("env.step per control step" if not fused else
                      "etg_rollout_openloop: fused kernel, up to 50 control steps per launch" if policy is None else
                      "etg_rollout_policy: policy MFMA tile + control step fused, up to 50 control steps per launch"),

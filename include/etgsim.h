@@ -141,6 +141,13 @@ typedef struct EtgConfig {
    * (the true angle is used; the reference reads its latency-delayed observation). 0 = off (the default
    * of the reference's constructor).                                                                  */
   double clip_motor_commands;
+  /* knee contacts (Bullet collides every link shape; here, besides the four foot spheres): when
+   * != 0, a sphere of knee_radius at every knee (the calf joint origin, attached to the thigh) collides with the
+   * ground through one frictionless normal row per leg, solved in the same projected Gauss-Seidel sweep right
+   * after the leg's foot rows. Served by the heightfield instantiations of the 16-lanes-per-robot kernels
+   * (terrain = 1; a flat heightfield is fine): the free 4th lane of every leg owns the row.               */
+  int32_t body_contacts;
+  double knee_radius;
 } EtgConfig;
 
 typedef struct EtgHandle EtgHandle;

@@ -553,9 +553,12 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
     mat3_mul_vec(Rw[p], Xup[i].r, o);
     for (int k = 0; k < 3; k++) pw[i][k] = pw[p][k] + o[k];
   }
-  T J[12][NV];
-  T target[12];
-  int active[4];
+  // rows 0..11: feet (n, t1, t2 per leg); rows 12..15: the frictionless knee row of leg l (cfg.body_contacts)
+  constexpr int NR = 16;
+  T J[NR][NV];
+  T target[NR];
+  int active[4], kactive[4];
+  T klam[4] = {0, 0, 0, 0};   // knee impulses: no warm start
   std::memset(J, 0, sizeof(J));
   const T rad = T(s.model.foot_radius);
   for (int l = 0; l < 4; l++) {
@@ -604,31 +607,69 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
     target[3 * l + 1] = 0; target[3 * l + 2] = 0;
     for (int k = 0; k < 3; k++) e.lam[3 * l + k] *= T(s.cfg.warmstart);
   }
+  // knees: a sphere at the calf joint origin, carried by the thigh (the calf joint does not move it)
+  for (int l = 0; l < 4; l++) {
+    kactive[l] = 0;
+    target[12 + l] = 0;
+    if (!s.cfg.body_contacts) continue;
+    const int c = 3 + 3 * l;
+    const T krad = T(s.cfg.knee_radius);
+    T h, n[3];
+    terrain_query(s, e.band, pw[c][0], pw[c][1], &h, n);
+    T phi = (pw[c][2] - h) * n[2] - krad;
+    kactive[l] = phi < T(s.cfg.contact_margin);
+    if (!kactive[l]) continue;
+    T cp[3], rel[3], rxd[3], tmp[3];
+    for (int k = 0; k < 3; k++) { cp[k] = pw[c][k] - krad * n[k]; rel[k] = cp[k] - e.pos[k]; }
+    T* row = J[12 + l];
+    cross(rel, n, rxd);
+    mat3T_mul_vec(R, rxd, tmp);
+    for (int k = 0; k < 3; k++) row[k] = tmp[k];
+    mat3T_mul_vec(R, n, tmp);
+    for (int k = 0; k < 3; k++) row[3 + k] = tmp[k];
+    for (int b = s.parent[c]; b > 0; b = s.parent[b]) {  // hip and thigh joints
+      T axw[3] = {Rw[b][0][s.axis[b]], Rw[b][1][s.axis[b]], Rw[b][2][s.axis[b]]};
+      T rj[3], cr[3];
+      for (int k = 0; k < 3; k++) rj[k] = cp[k] - pw[b][k];
+      cross(axw, rj, cr);
+      row[5 + b] = dot3(n, cr);
+    }
+    target[12 + l] = (phi > 0) ? -phi / dt : -T(s.cfg.erp) * phi / dt;
+  }
+  auto row_active = [&](int r) { return r < 12 ? active[r / 3] : kactive[r - 12]; };
+  auto lam_of = [&](int r) -> T& { return r < 12 ? e.lam[r] : klam[r - 12]; };
   // Delassus operator
-  T MiJt[12][NV];
-  T A[12][12];
-  for (int r = 0; r < 12; r++) {
-    if (!active[r / 3]) { std::memset(MiJt[r], 0, sizeof(MiJt[r])); continue; }
+  T MiJt[NR][NV];
+  T A[NR][NR];
+  for (int r = 0; r < NR; r++) {
+    if (!row_active(r)) { std::memset(MiJt[r], 0, sizeof(MiJt[r])); continue; }
     chol_solve(J[r], MiJt[r]);
   }
-  for (int r = 0; r < 12; r++)
-    for (int c = 0; c < 12; c++) {
+  for (int r = 0; r < NR; r++)
+    for (int c = 0; c < NR; c++) {
       T sum = 0;
       for (int k = 0; k < NV; k++) sum += J[r][k] * MiJt[c][k];
       A[r][c] = sum;
     }
-  T u[12];
-  for (int r = 0; r < 12; r++) {
+  T u[NR];
+  for (int r = 0; r < NR; r++) {
     T sum = 0;
     for (int k = 0; k < NV; k++) sum += J[r][k] * vel[k];
-    for (int c = 0; c < 12; c++) sum += A[r][c] * e.lam[c];
+    for (int c = 0; c < NR; c++) sum += A[r][c] * lam_of(c);
     u[r] = sum;
   }
   auto apply = [&](int row, T d) {
-    for (int r = 0; r < 12; r++) u[r] += A[r][row] * d;
+    for (int r = 0; r < NR; r++) u[r] += A[r][row] * d;
   };
   for (int it = 0; it < s.cfg.solver_iters; it++) {
     for (int l = 0; l < 4; l++) {
+      if (kactive[l] && !active[l]) {   // the knee row alone
+        const int rk = 12 + l;
+        T lk = klam[l] - (u[rk] - target[rk]) / A[rk][rk];
+        if (lk < 0) lk = 0;
+        apply(rk, lk - klam[l]);
+        klam[l] = lk;
+      }
       if (!active[l]) continue;
       int r0 = 3 * l;
       // normal
@@ -652,11 +693,18 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
           e.lam[r0 + k] = lt;
         }
       }
+      if (kactive[l]) {   // the leg's knee row comes after its foot rows
+        const int rk = 12 + l;
+        T lk = klam[l] - (u[rk] - target[rk]) / A[rk][rk];
+        if (lk < 0) lk = 0;
+        apply(rk, lk - klam[l]);
+        klam[l] = lk;
+      }
     }
   }
-  for (int r = 0; r < 12; r++) {
-    if (!active[r / 3]) continue;
-    for (int k = 0; k < NV; k++) vel[k] += MiJt[r][k] * e.lam[r];
+  for (int r = 0; r < NR; r++) {
+    if (!row_active(r)) continue;
+    for (int k = 0; k < NV; k++) vel[k] += MiJt[r][k] * lam_of(r);
   }
   for (int l = 0; l < 4; l++) e.contact[l] = active[l] && e.lam[3 * l] > 0;
 

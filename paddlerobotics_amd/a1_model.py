@@ -75,6 +75,8 @@ class EtgConfig(C.Structure):
         ("hf_bands", C.c_int32),
         ("motor_mode", C.c_int32),
         ("clip_motor_commands", C.c_double),
+        ("body_contacts", C.c_int32),
+        ("knee_radius", C.c_double),
     ]
 
 
@@ -172,7 +174,8 @@ def default_config(num_envs, *, action_repeat=13, sim_dt=0.002, settle_ticks=500
                    erp=0.2, contact_margin=0.02, warmstart=0.85, torque_limit=0.0,
                    ETG_T=0.5, ETG_T2=0.5, etg_amp=0.2, etg_sigma_sq=0.04,
                    etg_phase=(-math.pi / 2, 0.0), reward_param=None, reward_p=5.0, vel_d=0.5,
-                   heightfield=None, lanes_per_robot=0, motor_mode=0, clip_motor_commands=0.0):
+                   heightfield=None, lanes_per_robot=0, motor_mode=0, clip_motor_commands=0.0,
+                   body_contacts=0, knee_radius=0.02):
     """EtgConfig with the defaults of train.py:296-297,470-487 and SURVEY App. A."""
     c = EtgConfig()
     c.num_envs = int(num_envs)
@@ -201,6 +204,8 @@ def default_config(num_envs, *, action_repeat=13, sim_dt=0.002, settle_ticks=500
     c.lanes_per_robot = int(lanes_per_robot)
     c.motor_mode = int(motor_mode)
     c.clip_motor_commands = float(clip_motor_commands)
+    c.body_contacts = int(body_contacts)
+    c.knee_radius = float(knee_radius)
     if heightfield is not None:
         c.hf_ny, c.hf_nx = heightfield["heights"].shape
         c.hf_cell = heightfield["cell"]

@@ -220,17 +220,27 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   V wbs = L.wb + dt * ab.a, vbs = L.vb + dt * ab.l;
   F qds = L.qd + dt * qdd;
   c.phase(4);
-  // ---- foot contact: this lane owns contact row `sub` (n, t1, t2) of its leg
-  V fw = {L.p.x + dot(Rw.r0, g.pf), L.p.y + dot(Rw.r1, g.pf), L.p.z + dot(Rw.r2, g.pf)};
+  // ---- foot contact: this lane owns contact row `sub` (n, t1, t2) of its leg.  With K.knee (heightfield kernels only)
+  // the aux lane owns a 4th, frictionless row: a sphere at the knee (calf joint origin), carried by the thigh.
+  const bool knee = !Ctx::kFlat && K.knee != 0;
+  const auto s3 = c.sub_is(3);
+  const F f3 = sel_(s3, one, zero);
+  V pc = g.pf;
+  F rad(K.foot_radius);
+  if (knee) {
+    pc = {sel_(s3, g.o3.x, g.pf.x), sel_(s3, g.o3.y, g.pf.y), sel_(s3, g.o3.z, g.pf.z)};
+    rad = sel_(s3, F(K.knee_radius), F(K.foot_radius));
+  }
+  V fw = {L.p.x + dot(Rw.r0, pc), L.p.y + dot(Rw.r1, pc), L.p.z + dot(Rw.r2, pc)};
   F phi;
   V dn, d1, d2;
   if (Ctx::kFlat) {
-    phi = fw.z - F(K.foot_radius);
+    phi = fw.z - rad;
     dn = Rw.r2; d1 = Rw.r0; d2 = Rw.r1;
   } else {
     F hgt, nwx, nwy, nwz;
     c.terrain(K, fw.x, fw.y, hgt, nwx, nwy, nwz);
-    phi = (fw.z - hgt) * nwz - F(K.foot_radius);
+    phi = (fw.z - hgt) * nwz - rad;
     V nw = {nwx, nwy, nwz};
     V t1w = {one - nwx * nwx, -(nwx * nwy), -(nwx * nwz)};
     F it1 = rsqrt_(dot(t1w, t1w));
@@ -244,10 +254,14 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
           Rw.r0.z * t2w.x + Rw.r1.z * t2w.y + Rw.r2.z * t2w.z};
   }
   auto act = phi < F(K.margin);
-  const F rowf = mj * sel_(act, one, zero);                     // 1 on the rows of an active foot
-  V rc = g.pf - F(K.foot_radius) * dn;
+  const F rowf = (knee ? one : mj) * sel_(act, one, zero);      // 1 on the rows of an active foot (/ knee)
+  V rc = pc - rad * dn;
   V k1 = cross(xax, rc - g.o1), k2 = cross(g.yax, rc - g.o2), k3 = cross(g.yax, rc - g.o3);
   V dir = {sel_(s0, dn.x, sel_(s1, d1.x, d2.x)), sel_(s0, dn.y, sel_(s1, d1.y, d2.y)), sel_(s0, dn.z, sel_(s1, d1.z, d2.z))};
+  if (knee) {   // the knee row pushes along the normal; the calf joint does not move the knee
+    dir = {sel_(s3, dn.x, dir.x), sel_(s3, dn.y, dir.y), sel_(s3, dn.z, dir.z)};
+    k3 = mj * k3;
+  }
   F Jl0 = rowf * dot(dir, k1), Jl1 = rowf * dot(dir, k2), Jl2 = rowf * dot(dir, k3);
   F HJ0 = Hi11 * Jl0 + Hi12 * Jl1 + Hi13 * Jl2;
   F HJ1 = Hi12 * Jl0 + Hi22 * Jl1 + Hi23 * Jl2;
@@ -264,7 +278,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   // fused broadcast-FMA (v_fmac_f32_dpp row_newbcast); rows of the own leg add the leg compliance
   // J_l H^-1 J_l^T.  (The 4-lane kernel contracts the same products on the matrix pipe; with one row per
   // lane the DPP form needs no accumulator shuffles and no MFMA latency padding.)
-  F lam = rowf * F(K.warmstart) * L.lam;                        // warm start (defined here: DPP source below)
+  F lam = mj * rowf * F(K.warmstart) * L.lam;                   // warm start (defined here: DPP source below); knee rows start at 0
   F hj[3] = {HJ0, HJ1, HJ2};
   c.dpp_ready(Z, 6);
   c.dpp_ready(hj, 3);
@@ -291,6 +305,20 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
 #pragma unroll
     for (int lp = 0; lp < 4; lp++) A[lp][e] = A[lp][e] + ownl[lp] * own;
   }
+  F Ak[4] = {zero, zero, zero, zero};                           // column of the knee row of leg lp
+  if (knee) {
+#pragma unroll
+    for (int lp = 0; lp < 4; lp++) {
+      Ak[lp] = c.rbcast(Z[0], 4 * lp + 3) * Z[0];
+#pragma unroll
+      for (int k = 1; k < 6; k++) c.fmac_rbcast(Ak[lp], Z[k], Z[k], 4 * lp + 3);
+    }
+    F own = c.qb(hj[0], 3) * Jl0;
+    c.fmac_qb(own, hj[1], Jl1, 3);
+    c.fmac_qb(own, hj[2], Jl2, 3);
+#pragma unroll
+    for (int lp = 0; lp < 4; lp++) Ak[lp] = Ak[lp] + ownl[lp] * own;
+  }
   F Add = hj[0] * Jl0 + hj[1] * Jl1 + hj[2] * Jl2;              // own diagonal
 #pragma unroll
   for (int k = 0; k < 6; k++) Add = Add + Z[k] * Z[k];
@@ -301,7 +329,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   V vc = vbs + cross(wbs, rc) + qs0 * k1 + qs1 * k2 + qs2 * k3;
   F u = rowf * dot(dir, vc);
   const F idt(1.0f / K.dt);
-  const F tgt = f0 * sel_(phi > zero, -(phi * idt), -(F(K.erp) * phi * idt));   // only normal rows have a target
+  const F tgt = (knee ? f0 + f3 : f0) * sel_(phi > zero, -(phi * idt), -(F(K.erp) * phi * idt));   // only normal rows have a target
 #pragma unroll
   for (int lp = 0; lp < 4; lp++)
 #pragma unroll
@@ -345,6 +373,12 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
       F b1 = c.rbcast(dp, 4 * lp + 1), b2 = c.rbcast(dp, 4 * lp + 2);
       u = u + A[lp][1] * b1 + A[lp][2] * b2;
       lam = lam + dp;
+      if (knee) {   // the leg's knee row, after its foot rows: lk = max(0, lk - (u - tgt)/A)
+        F dlk = fmaxf_(zero, (lam + c0) - u * iA) - lam;
+        lam = lam + ownl[lp] * f3 * dlk;
+        F bk = c.rbcast(dlk, 4 * lp + 3);
+        u = u + Ak[lp] * bk;
+      }
     }
   }
   c.phase(8);

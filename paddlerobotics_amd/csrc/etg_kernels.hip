@@ -719,6 +719,13 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   // at a time: 16 lanes/robot fills it with 4096 robots and is faster per robot up to there; beyond
   // that the 4-lanes/robot kernel packs 4x the robots per wave (measured crossover).
   h->lanes = cfg->lanes_per_robot != 0 ? cfg->lanes_per_robot : (cfg->num_envs <= 4096 ? 16 : 4);
+  if (cfg->body_contacts) {   // the knee rows live on the 4th lane of every leg of the 16-lane heightfield kernels
+    if (cfg->terrain != 1 || cfg->lanes_per_robot == 4) {
+      delete h;
+      return fail(ETG_ERR_BAD_ARG, "etg_create: body_contacts needs terrain = 1 (a flat heightfield will do) and the 16-lanes-per-robot mapping");
+    }
+    h->lanes = 16;
+  }
   size_t N = h->N, NL = 4 * N;
   struct { void** p; size_t bytes; } allocs[] = {
       {(void**)&h->D.base, BS_N * N * 4},   {(void**)&h->D.leg, LG_N * NL * 4},   {(void**)&h->D.ctl, CT_N * N * 4},

@@ -58,6 +58,8 @@ struct KCfg {
   int ext_force;         // 1 once etg_set_external_force() installed a force (ctl[CT_FEXT..])
   int motor_mode;        // 0 POSITION (PD on a joint-angle command), 1 TORQUE (the command is the torque)
   float clip_cmd;        // > 0: clip the position command to q +- clip_cmd every tick (a1.py:439-457)
+  int knee;              // EtgConfig.body_contacts: knee spheres collide (16-lane heightfield kernels)
+  float knee_radius;
   // Gaussian sensor noise (minitaur.py:1206-1211): stdev of motor angle, motor velocity, motor torque (not part of
   // the 49-float observation), base rpy, base rpy rate -- the order of SENSOR_NOISE_STDDEV (minitaur.py:102)
   int noise_on;
@@ -282,6 +284,7 @@ inline KCfg make_kcfg(const EtgConfig& c, const EtgRobotModel& m) {
   for (int k = 0; k < 5; k++) K.noise_std[k] = 0.0f;
   K.motor_mode = c.motor_mode;
   K.clip_cmd = (float)c.clip_motor_commands;
+  K.knee = c.body_contacts; K.knee_radius = (float)c.knee_radius;
   K.hf_cell = (float)c.hf_cell; K.hf_x0 = (float)c.hf_x0; K.hf_y0 = (float)c.hf_y0;
   K.hf = nullptr;
   return K;

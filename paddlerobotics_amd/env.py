@@ -124,7 +124,7 @@ class BatchedQuadrupedEnv:
                  heightfield=None, lanes_per_robot=0, terrain_variants=16, terrain_seed=0,
                  random_dynamics_scale=0.3, random_force_prob=0.02, random_force_steps=8,
                  random_force_range=(5.0, 25.0), seed=0, enable_clip_motor_commands=False,
-                 observation_noise_stdev=None, **unused):
+                 observation_noise_stdev=None, body_contacts=False, knee_radius=0.02, **unused):
         if render:
             raise ValueError("render is not supported by the batched GPU simulator")
         if int(ETG_H) != A.RBF_H:
@@ -138,6 +138,9 @@ class BatchedQuadrupedEnv:
             heightfield = make_task_heightfield(task, variants=int(terrain_variants), seed=int(terrain_seed))
         elif (task == "heightfield") != (heightfield is not None):
             raise ValueError("task='heightfield' and the heightfield= argument go together")
+        if body_contacts and heightfield is None:
+            # the knee rows live in the heightfield kernels (include/etgsim.h: body_contacts): level ground as a grid
+            heightfield = dict(heights=np.zeros((65, 65), dtype=np.float32), cell=0.5, origin=(-16.0, -16.0))
         self.task = task
         self.terrain = heightfield
         # train.py:56-58 mode_map: "pose"/"traj" -> POSITION, "torque" -> TORQUE; enum values also accepted
@@ -179,7 +182,8 @@ class BatchedQuadrupedEnv:
             terrain=1 if heightfield is not None else 0, ETG_T=ETG_T, ETG_T2=ETG_T2,
             reward_param=reward_param, reward_p=reward_p, vel_d=vel_d, heightfield=heightfield,
             lanes_per_robot=lanes_per_robot, motor_mode=motor_mode,
-            clip_motor_commands=0.2 if enable_clip_motor_commands else 0.0)   # MAX_MOTOR_ANGLE_CHANGE_PER_STEP, a1.py
+            clip_motor_commands=0.2 if enable_clip_motor_commands else 0.0,   # MAX_MOTOR_ANGLE_CHANGE_PER_STEP, a1.py
+            body_contacts=1 if body_contacts else 0, knee_radius=knee_radius)
         self.model = A.default_model()
         if task == "balancebeam":
             # README "step_y: the foot position at y axis for balance beam task" (train.py:463): the ETG's nominal

@@ -930,3 +930,42 @@ def test_sensor_noise_matches_oracle_and_fused_rollout(lanes):
         assert (a.obs - b.obs).abs().median() < 1e-2
         for e in (a, b, c):
             e.close()
+
+
+@pytest.mark.gpu
+def test_knee_contacts_match_oracle():
+    """body_contacts=True: knee spheres as a 4th, frictionless contact row per leg (16-lane heightfield kernels)."""
+    _need_gpu()
+    n = 32
+    # (1) a limp robot folds onto its knees: same trajectory as the oracle, and the knees do carry it
+    env = _make(n, motor_control_mode="torque", body_contacts=True, solver_iters=4)
+    assert env.lanes_per_robot == 16 and env.cfg.terrain == 1
+    hf = env.terrain
+    orc = _oracle(n, motor_mode=1, body_contacts=1, terrain=1, heightfield=hf, solver_iters=4)
+    orc.set_heightfield(hf["heights"])
+    env.reset(); orc.reset()
+    act = np.zeros((n, 12), dtype=np.float32); act[1::2, 1::3] = 2.0
+    ta = torch.as_tensor(act, device="cuda:0")
+    for k in range(13):
+        env.step(ta); orc.step(act)
+        sg, so = env.get_state().cpu().numpy(), orc.get_state()
+        assert np.abs(sg[:, 13:25] - so[:, 13:25]).max() < 5e-3 and np.abs(sg[:, :3] - so[:, :3]).max() < 1e-3, k
+    assert so[0, 2] > -0.2
+    env.close()
+    # (2) walking up stairs with the knees enabled: fused rollout == oracle stepping over a short horizon
+    W, B = _etg_params(n, seed=21)
+    env = _make(n, task="stairstair", terrain_variants=4, terrain_seed=2, body_contacts=True)
+    hf = env.terrain
+    orc = _oracle(n, body_contacts=1, terrain=1, heightfield=hf)
+    orc.set_heightfield(hf["heights"])
+    orc.set_params(etg_w=W, etg_b=B)
+    env.reset(ETG_w=W, ETG_b=B); orc.reset()
+    env.rollout_openloop(10)
+    for _ in range(10):
+        orc.step(np.zeros((n, 12)))
+    err = np.abs(env.get_state().cpu().numpy()[:, 13:25] - orc.get_state()[:, 13:25]).max(1)
+    assert np.median(err) < 5e-3
+    env.close()
+    # (3) the 4-lane mapping has no lane for the knee rows
+    with pytest.raises(Exception):
+        _make(n, body_contacts=True, lanes_per_robot=4)

@@ -276,3 +276,31 @@ def test_emulation_sensor_noise_matches_oracle(lanes):
     assert np.array_equal(again.reset(), ref.reset()) and not np.array_equal(other.reset(), ref.reset())
     orc.set_sensor_noise(None)
     assert np.abs(orc.step(np.zeros((n, 12)))[0] - clean.step(np.zeros((n, 12)))[0]).max() == 0
+
+
+def test_emulation_knee_contacts_match_oracle():
+    """body_contacts: a limp robot (TORQUE mode, no torque) folds onto its knees; the knee spheres then carry it.  The
+    16-lane kernel source (4th lane of every leg owns the knee row) against the oracle's 16-row formulation."""
+    from oracle.oracle import OracleSim
+    from tests.emu.emu import EmuSim
+    n = 2
+    hf = {"heights": np.zeros((64, 64), dtype=np.float32), "cell": 0.1, "origin": (-3.2, -3.2)}
+    act = np.zeros((n, 12)); act[1, 1::3] = 2.0                       # robot 1: a little thigh torque, lands differently
+    finals = {}
+    for bc in (0, 1):
+        cfg = A.default_config(n, solver_iters=4, motor_mode=1, body_contacts=bc, terrain=1, heightfield=hf)
+        orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=16)
+        for s in (orc, emu):
+            s.set_heightfield(hf["heights"]); s.reset()
+        for k in range(13):
+            orc.step(act); emu.step(act)
+            so, se = orc.get_state(), emu.get_state()
+            assert np.abs(so[:, 13:25] - se[:, 13:25]).max() < 2e-3 and np.abs(so[:, :3] - se[:, :3]).max() < 1e-4, (bc, k)
+        finals[bc] = orc.get_state()
+    # without the knee rows the trunk keeps sinking through the floor (only feet collide); with them it is caught
+    assert finals[0][0, 2] < -0.3 and finals[1][0, 2] > -0.2
+
+
+def test_body_contacts_need_the_heightfield_kernels():
+    cfg = A.default_config(4, body_contacts=1)
+    assert cfg.body_contacts == 1 and abs(cfg.knee_radius - 0.02) < 1e-12
