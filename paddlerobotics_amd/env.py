@@ -39,7 +39,9 @@ def sensor_columns(sensor_mode):
     sm.update(sensor_mode or {})
     for k in ("ETG_obs", "footpose", "dynamic_vec", "force_vec", "noise"):
         if sm.get(k):
-            raise NotImplementedError("sensor_mode[%r] is not provided by the batched simulator" % k)
+            raise NotImplementedError("sensor_mode[%r] is not provided by the batched simulator%s" % (
+                k, " (its noise levels live in rlschool, which the reference tree does not ship: pass "
+                   "observation_noise_stdev=(angle, velocity, torque, rpy, rpy rate) instead)" if k == "noise" else ""))
     rnn = sm.get("RNN")
     if rnn and rnn.get("time_steps", 0) > 0 and rnn.get("mode", "stack") not in ("stack", "GRU"):
         raise NotImplementedError("sensor_mode['RNN']['mode'] must be 'stack' or 'GRU'")
