@@ -222,7 +222,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   c.phase(4);
   // ---- foot contact: this lane owns contact row `sub` (n, t1, t2) of its leg.  With K.knee (heightfield kernels only)
   // the aux lane owns a 4th, frictionless row: a sphere at the knee (calf joint origin), carried by the thigh.
-  const bool knee = !Ctx::kFlat && K.knee != 0;
+  constexpr bool knee = Ctx::kKnee;   // compile-time: the flat-ground and plain heightfield kernels do not contain the rows
   const auto s3 = c.sub_is(3);
   const F f3 = sel_(s3, one, zero);
   V pc = g.pf;

@@ -418,7 +418,8 @@ struct GpuCtx16 {
     else heightfield_query(K, env, x, y, h, nx, ny, nz);
   }
 };
-template <bool FLAT> struct GpuCtx16T : GpuCtx16 { static constexpr bool kFlat = FLAT; };
+// KNEE: the knee contact rows of EtgConfig.body_contacts (heightfield kernels only) are compiled in
+template <bool FLAT, bool KNEE = false> struct GpuCtx16T : GpuCtx16 { static constexpr bool kFlat = FLAT; static constexpr bool kKnee = KNEE; };
 
 // robot_block = index of the group of 4 robots this wave carries, lane = lane in the wave, lds_wave = the wave's
 // own [LDS16_FIELDS][64] parameter staging area
@@ -449,10 +450,10 @@ __device__ __forceinline__ bool make_ctx16(const KCfg& K, const DevState& D, Gpu
   return make_ctx16_at(K, D, c, lds_all, xcd_contiguous_block(), threadIdx.x);
 }
 
-template <bool FLAT>
+template <bool FLAT, bool KNEE>
 __global__ void __launch_bounds__(BLOCK) k_settle16(KCfg K, DevState D, const uint8_t* mask) {
   __shared__ float lds_par[LDS16_FIELDS * BLOCK];
-  GpuCtx16T<FLAT> c;
+  GpuCtx16T<FLAT, KNEE> c;
   if (!make_ctx16(K, D, c, lds_par)) return;
   if ((mask && !mask[c.env]) || settle_cached<FLAT>(K, D, c.env)) return;   // whole rows drop out together
   State16<float> L;
@@ -463,10 +464,10 @@ __global__ void __launch_bounds__(BLOCK) k_settle16(KCfg K, DevState D, const ui
   settle_mark_fresh(K, D, c.env, ox, oy);
 }
 
-template <bool FLAT>
+template <bool FLAT, bool KNEE>
 __global__ void __launch_bounds__(BLOCK) k_finish16(KCfg K, DevState D, const uint8_t* mask, float* obs) {
   __shared__ float lds_par[LDS16_FIELDS * BLOCK];
-  GpuCtx16T<FLAT> c;
+  GpuCtx16T<FLAT, KNEE> c;
   if (!make_ctx16(K, D, c, lds_par)) return;
   if (mask && !mask[c.env]) return;
   State16<float> L = load_state16<float>(c, D.base, D.leg);
@@ -474,11 +475,11 @@ __global__ void __launch_bounds__(BLOCK) k_finish16(KCfg K, DevState D, const ui
   store_state16(c, D.base, D.leg, L);
 }
 
-template <bool FLAT>
+template <bool FLAT, bool KNEE>
 __global__ void __launch_bounds__(BLOCK) k_step16(KCfg K, DevState D, const float* action, const uint8_t* donef, float* obs,
                                                    float* reward, uint8_t* done, float* info) {
   __shared__ float lds_par[LDS16_FIELDS * BLOCK];
-  GpuCtx16T<FLAT> c;
+  GpuCtx16T<FLAT, KNEE> c;
   if (!make_ctx16(K, D, c, lds_par)) return;
   State16<float> L = load_state16<float>(c, D.base, D.leg);
   const bool hybrid = K.motor_mode == 2 && action;   // rows of 60: per motor (q_des, kp, qd_des, kd, tau_ff)
@@ -509,10 +510,10 @@ __global__ void __launch_bounds__(BLOCK) k_step16(KCfg K, DevState D, const floa
 
 // n_steps open-loop control steps of every robot in one launch (rollout_steps16): state, control variables and
 // tick constants stay in registers between the steps
-template <bool FLAT>
+template <bool FLAT, bool KNEE>
 __global__ void __launch_bounds__(BLOCK) k_rollout16(KCfg K, DevState D, int n_steps, float* obs) {
   __shared__ float lds_par[LDS16_FIELDS * BLOCK];
-  GpuCtx16T<FLAT> c;
+  GpuCtx16T<FLAT, KNEE> c;
   if (!make_ctx16(K, D, c, lds_par)) return;
   State16<float> L = load_state16<float>(c, D.base, D.leg);
   rollout_steps16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, n_steps, obs);
@@ -525,7 +526,7 @@ __global__ void __launch_bounds__(BLOCK) k_rollout16(KCfg K, DevState D, int n_s
 // the next observation back to LDS.  Nothing but the final observation, the ring and the episode accumulators
 // touches HBM between steps.  (run_EStrain_episode / run_evaluate_episodes, train.py:182-249, with a fixed actor.)
 struct PolicyW { const float4 *w1, *w2, *w3; const float *b1, *b2, *b3; int in_dim, out_dim, col0; };   // col0: first observation column the actor sees
-template <bool FLAT, bool BF16>
+template <bool FLAT, bool BF16, bool KNEE>
 __global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, PolicyW P, int n_steps, float act_scale, float* obs) {
   using namespace pol;
   constexpr int NWP = 4;
@@ -537,7 +538,7 @@ __global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, Po
   __shared__ float lds_par[NWP][LDS16_FIELDS * 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int tile = xcd_contiguous_block();            // 16 robots; the host guarantees N % 16 == 0
-  GpuCtx16T<FLAT> c;
+  GpuCtx16T<FLAT, KNEE> c;
   make_ctx16_at(K, D, c, lds_par[wave], 4 * tile + wave, lane);
   State16<float> L = load_state16<float>(c, D.base, D.leg);
   StepCtl16<float> S = load_ctl16<float>(c, K, D.ctl, D.ictl, D.legctl);
@@ -779,6 +780,14 @@ static inline void launch_obs_noise(EtgHandle* h, int n, const uint8_t* mask, fl
   hipLaunchKernelGGL(k_add_noise, dim3((16 * h->N + 255) / 256), dim3(256), 0, s, h->K, h->K.noise_call + (unsigned)(n - 1), mask, obs);
 }
 
+// the three instantiations of a 16-lane kernel: flat ground, heightfield, heightfield + knee rows
+#define LAUNCH16(KERN, grid, stream, ...)                                                                     \
+  do {                                                                                                        \
+    if (h->K.terrain == 0) hipLaunchKernelGGL((KERN<true, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__); \
+    else if (!h->K.knee) hipLaunchKernelGGL((KERN<false, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);  \
+    else hipLaunchKernelGGL((KERN<false, true>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);                   \
+  } while (0)
+
 #define CHECK_HANDLE(h)                                         \
   if (!(h)) return fail(ETG_ERR_BAD_ARG, "null handle");       \
   HIP_TRY(hipSetDevice((h)->device));
@@ -849,8 +858,7 @@ extern "C" int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* st
   hipStream_t s = (hipStream_t)stream;
   const bool flat = h->K.terrain == 0;
   if (h->lanes == 16) {
-    if (flat) hipLaunchKernelGGL(k_settle16<true>, g16, dim3(BLOCK), 0, s, h->K, h->D, mask);
-    else hipLaunchKernelGGL(k_settle16<false>, g16, dim3(BLOCK), 0, s, h->K, h->D, mask);
+    LAUNCH16(k_settle16, g16, s, h->K, h->D, mask);
   } else {
     if (flat) hipLaunchKernelGGL(k_settle<true>, g4, dim3(BLOCK), 0, s, h->K, h->D, mask);
     else hipLaunchKernelGGL(k_settle<false>, g4, dim3(BLOCK), 0, s, h->K, h->D, mask);
@@ -858,8 +866,7 @@ extern "C" int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* st
   hipLaunchKernelGGL(k_cache_sync, gc, dim3(256), 0, s, h->K, h->D, mask);
   hipLaunchKernelGGL(k_cache_mark, ge, dim3(256), 0, s, h->K, h->D, mask);
   if (h->lanes == 16) {
-    if (flat) hipLaunchKernelGGL(k_finish16<true>, g16, dim3(BLOCK), 0, s, h->K, h->D, mask, obs);
-    else hipLaunchKernelGGL(k_finish16<false>, g16, dim3(BLOCK), 0, s, h->K, h->D, mask, obs);
+    LAUNCH16(k_finish16, g16, s, h->K, h->D, mask, obs);
   } else {
     if (flat) hipLaunchKernelGGL(k_finish<true>, g4, dim3(BLOCK), 0, s, h->K, h->D, mask, obs);
     else hipLaunchKernelGGL(k_finish<false>, g4, dim3(BLOCK), 0, s, h->K, h->D, mask, obs);
@@ -903,10 +910,7 @@ extern "C" int etg_step(EtgHandle* h, const float* action, const uint8_t* donef,
   advance_obs_stream(h, 1);
   const dim3 g16((h->N + 3) / 4);
   if (h->lanes == 16) {
-    if (h->K.terrain == 0)
-      hipLaunchKernelGGL(k_step16<true>, g16, dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, action, donef, obs, reward, done, info);
-    else
-      hipLaunchKernelGGL(k_step16<false>, g16, dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, action, donef, obs, reward, done, info);
+    LAUNCH16(k_step16, g16, (hipStream_t)stream, h->K, h->D, action, donef, obs, reward, done, info);
   } else if (h->K.terrain == 0)
     hipLaunchKernelGGL(k_step<true>, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, action, donef,
                        obs, reward, done, info);
@@ -943,8 +947,7 @@ extern "C" int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float
       float* o = (obs && done_steps + m == n_steps) ? obs : h->tmp_obs;
       advance_obs_stream(h, m);
       if (h->lanes == 16) {
-        if (flat) hipLaunchKernelGGL(k_rollout16<true>, g16, dim3(BLOCK), 0, s, h->K, h->D, m, o);
-        else hipLaunchKernelGGL(k_rollout16<false>, g16, dim3(BLOCK), 0, s, h->K, h->D, m, o);
+        LAUNCH16(k_rollout16, g16, s, h->K, h->D, m, o);
       } else {
         if (flat) hipLaunchKernelGGL(k_rollout<true>, g4, dim3(BLOCK), 0, s, h->K, h->D, m, o);
         else hipLaunchKernelGGL(k_rollout<false>, g4, dim3(BLOCK), 0, s, h->K, h->D, m, o);
@@ -980,10 +983,13 @@ extern "C" int etg_rollout_policy(EtgHandle* h, EtgPolicy* pol, int n_steps, flo
   for (int done_steps = 0; done_steps < n_steps; done_steps += ROLLOUT_CHUNK) {
     const int m = n_steps - done_steps < ROLLOUT_CHUNK ? n_steps - done_steps : ROLLOUT_CHUNK;
     advance_obs_stream(h, m);
-    if (flat && precision == 0) hipLaunchKernelGGL((k_rollout_policy16<true, false>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
-    else if (flat) hipLaunchKernelGGL((k_rollout_policy16<true, true>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
-    else if (precision == 0) hipLaunchKernelGGL((k_rollout_policy16<false, false>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
-    else hipLaunchKernelGGL((k_rollout_policy16<false, true>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
+    const bool kn = h->K.knee != 0;
+    if (flat && precision == 0) hipLaunchKernelGGL((k_rollout_policy16<true, false, false>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
+    else if (flat) hipLaunchKernelGGL((k_rollout_policy16<true, true, false>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
+    else if (precision == 0 && !kn) hipLaunchKernelGGL((k_rollout_policy16<false, false, false>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
+    else if (!kn) hipLaunchKernelGGL((k_rollout_policy16<false, true, false>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
+    else if (precision == 0) hipLaunchKernelGGL((k_rollout_policy16<false, false, true>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
+    else hipLaunchKernelGGL((k_rollout_policy16<false, true, true>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
     launch_obs_noise(h, m, nullptr, obs, s);   // every chunk ends in the caller's rows: the next chunk reads them
   }
   HIP_TRY(hipGetLastError());

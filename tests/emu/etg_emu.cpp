@@ -133,8 +133,9 @@ struct EmuCtx16Base {
     }
   }
 };
-template <bool FLAT> struct EmuCtx16T : EmuCtx16Base {
+template <bool FLAT, bool KNEE = false> struct EmuCtx16T : EmuCtx16Base {
   static constexpr bool kFlat = FLAT;
+  static constexpr bool kKnee = KNEE;
   EmuCtx16T(int e, int n, const float* p) { env = e; N = n; parp = p; }
 };
 
@@ -197,6 +198,23 @@ extern "C" void emu_set_reset_offsets(void* h, const float* xy) {
   e->reset_off.assign((size_t)2 * e->N, 0.0f);
   if (xy) std::copy(xy, xy + (size_t)2 * e->N, e->reset_off.begin());
 }
+template <class Ctx> static void emu_reset16(Emu* e, int i, float* obs, float ox, float oy) {
+  Ctx c(i, e->N, e->par.data());
+  State16<F16> S;
+  reset_row16(c, e->K, S, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs, F16(ox), F16(oy));
+  store_state16(c, e->base.data(), e->leg.data(), S);
+}
+template <class Ctx> static void emu_step16(Emu* e, int i, const float* action, F16 dn, float* obs, F16& r16, F16& d16, float* info) {
+  Ctx c(i, e->N, e->par.data());
+  State16<F16> S = load_state16<F16>(c, e->base.data(), e->leg.data());
+  const bool hybrid = e->K.motor_mode == 2;
+  F16 hyb[4];
+  for (int k = 0; k < 4; k++) hyb[k] = hybrid ? c.ld_row_motor(action, ETG_HYBRID_DIM, 5, 1 + k) : F16(0.0f);
+  control_step16(c, e->K, S, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(),
+                 hybrid ? c.ld_row_motor(action, ETG_HYBRID_DIM, 5, 0) : c.ld_row_joint(action, 12, 0), dn, obs, r16, d16,
+                 info, hybrid ? hyb : nullptr);
+  store_state16(c, e->base.data(), e->leg.data(), S);
+}
 // what k_add_noise does after the step / reset kernels
 static void emu_obs_noise(Emu* e, const uint8_t* mask, float* obs) {
   if (!e->K.noise_on) return;
@@ -218,16 +236,9 @@ extern "C" void emu_reset(void* h, const uint8_t* mask, float* obs) {
     if (mask && !mask[i]) continue;
     const float ox = e->reset_off.empty() ? 0.0f : e->reset_off[2 * i], oy = e->reset_off.empty() ? 0.0f : e->reset_off[2 * i + 1];
     if (e->lanes == 16) {
-      State16<F16> S;
-      if (e->K.terrain == 0) {
-        EmuCtx16T<true> c(i, e->N, e->par.data());
-        reset_row16(c, e->K, S, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs, F16(ox), F16(oy));
-        store_state16(c, e->base.data(), e->leg.data(), S);
-      } else {
-        EmuCtx16T<false> c(i, e->N, e->par.data());
-        reset_row16(c, e->K, S, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs, F16(ox), F16(oy));
-        store_state16(c, e->base.data(), e->leg.data(), S);
-      }
+      if (e->K.terrain == 0) emu_reset16<EmuCtx16T<true>>(e, i, obs, ox, oy);
+      else if (!e->K.knee) emu_reset16<EmuCtx16T<false>>(e, i, obs, ox, oy);
+      else emu_reset16<EmuCtx16T<false, true>>(e, i, obs, ox, oy);
       continue;
     }
     LaneState<F4> L;
@@ -250,27 +261,9 @@ extern "C" void emu_step(void* h, const float* action, const uint8_t* donef, flo
     if (e->lanes == 16) {
       F16 r16, d16;
       F16 dn(donef ? (float)donef[i] : 0.f);
-      if (e->K.terrain == 0) {
-        EmuCtx16T<true> c(i, e->N, e->par.data());
-        State16<F16> S = load_state16<F16>(c, e->base.data(), e->leg.data());
-        const bool hybrid = e->K.motor_mode == 2;
-        F16 hyb[4];
-        for (int k = 0; k < 4; k++) hyb[k] = hybrid ? c.ld_row_motor(action, ETG_HYBRID_DIM, 5, 1 + k) : F16(0.0f);
-        control_step16(c, e->K, S, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(),
-                       hybrid ? c.ld_row_motor(action, ETG_HYBRID_DIM, 5, 0) : c.ld_row_joint(action, 12, 0), dn, obs, r16, d16,
-                       info, hybrid ? hyb : nullptr);
-        store_state16(c, e->base.data(), e->leg.data(), S);
-      } else {
-        EmuCtx16T<false> c(i, e->N, e->par.data());
-        State16<F16> S = load_state16<F16>(c, e->base.data(), e->leg.data());
-        const bool hybrid = e->K.motor_mode == 2;
-        F16 hyb[4];
-        for (int k = 0; k < 4; k++) hyb[k] = hybrid ? c.ld_row_motor(action, ETG_HYBRID_DIM, 5, 1 + k) : F16(0.0f);
-        control_step16(c, e->K, S, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(),
-                       hybrid ? c.ld_row_motor(action, ETG_HYBRID_DIM, 5, 0) : c.ld_row_joint(action, 12, 0), dn, obs, r16, d16,
-                       info, hybrid ? hyb : nullptr);
-        store_state16(c, e->base.data(), e->leg.data(), S);
-      }
+      if (e->K.terrain == 0) emu_step16<EmuCtx16T<true>>(e, i, action, dn, obs, r16, d16, info);
+      else if (!e->K.knee) emu_step16<EmuCtx16T<false>>(e, i, action, dn, obs, r16, d16, info);
+      else emu_step16<EmuCtx16T<false, true>>(e, i, action, dn, obs, r16, d16, info);
       reward[i] = r16.v[0];
       done[i] = d16.v[0] > 0.5f;
       continue;
