@@ -124,9 +124,10 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   const F m2 = m1 - f1;                       // sub >= 2
 
   // ---- PD motor model (laikago_motor.py:165-173), this lane's joint
-  if (K.clip_cmd > 0.0f && !torque_cmd) qdes = fminf_(fmaxf_(qdes, L.q - F(K.clip_cmd)), L.q + F(K.clip_cmd));   // a1.py:439-457
-  F tau = torque_cmd ? mj * qdes : mj * ((-(tp.kp * (L.q - qdes)) - tp.kd * (L.qd - tp.qd_des)) + tp.tau_ff);   // TORQUE mode: pass-through
-  if (K.torque_limit > 0.0f) tau = fminf_(fmaxf_(tau, F(-K.torque_limit)), F(K.torque_limit));
+  if (!Ctx::kPlain && K.clip_cmd > 0.0f && !torque_cmd) qdes = fminf_(fmaxf_(qdes, L.q - F(K.clip_cmd)), L.q + F(K.clip_cmd));   // a1.py:439-457
+  F tau = Ctx::kPlain ? mj * (-(tp.kp * (L.q - qdes)) - tp.kd * L.qd)
+                      : (torque_cmd ? mj * qdes : mj * ((-(tp.kp * (L.q - qdes)) - tp.kd * (L.qd - tp.qd_des)) + tp.tau_ff));   // TORQUE mode: pass-through
+  if (!Ctx::kPlain && K.torque_limit > 0.0f) tau = fminf_(fmaxf_(tau, F(-K.torque_limit)), F(K.torque_limit));
 
   // ---- leg geometry, this lane's link frame R_s = Rx(a) Ry(theta_s), theta = (0, h, h+k)
   const LegGeo<F> g = leg_geometry(c, K, tp.o1, tp.sy, L.q);
@@ -201,7 +202,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   F rb[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) rb[i] = -comp(fb0, i) - c.sum16(comp(f, i) + rl * comp(P, i));
-  if (K.ext_force) {  // external force on the trunk COM (world frame) -> base frame: R^T f
+  if (!Ctx::kPlain && K.ext_force) {  // external force on the trunk COM (world frame) -> base frame: R^T f
     rb[3] = rb[3] + Rw.r0.x * tp.fext.x + Rw.r1.x * tp.fext.y + Rw.r2.x * tp.fext.z;
     rb[4] = rb[4] + Rw.r0.y * tp.fext.x + Rw.r1.y * tp.fext.y + Rw.r2.y * tp.fext.z;
     rb[5] = rb[5] + Rw.r0.z * tp.fext.x + Rw.r1.z * tp.fext.y + Rw.r2.z * tp.fext.z;
@@ -563,7 +564,7 @@ ETG_HD StepCtl16<F> load_ctl16(const Ctx& c, const KCfg& K, const float* ctl, co
   S.ret = c.ld_env(ctl, CT_RET); S.len = c.ld_env(ctl, CT_LEN); S.alive = c.ld_env(ctl, CT_ALIVE);
   S.r0 = c.ld_env(ctl, CT_FIRST_RPY + 0); S.r1 = c.ld_env(ctl, CT_FIRST_RPY + 1); S.r2 = c.ld_env(ctl, CT_FIRST_RPY + 2);
   S.fx0 = S.fx1 = S.fy0 = S.fy1 = F(0.0f);
-  if (K.enable_filter) {
+  if (!Ctx::kPlain && K.enable_filter) {
     S.fx0 = c.ld_joint(legctl, LC_FX0); S.fx1 = c.ld_joint(legctl, LC_FX1);
     S.fy0 = c.ld_joint(legctl, LC_FY0); S.fy1 = c.ld_joint(legctl, LC_FY1);
   }
@@ -578,7 +579,7 @@ ETG_HD void store_ctl16(const Ctx& c, const KCfg& K, const StepCtl16<F>& S, floa
   c.st_env(ctl, CT_LAST_BASE + 0, S.lbx); c.st_env(ctl, CT_LAST_BASE + 1, S.lby); c.st_env(ctl, CT_LAST_BASE + 2, S.lbz);
   c.st_legf(legctl, LC_LAST_FOOT_X, S.last_fwx);
   c.st_env(ctl, CT_RET, S.ret); c.st_env(ctl, CT_LEN, S.len); c.st_env(ctl, CT_ALIVE, S.alive);
-  if (K.enable_filter) {
+  if (!Ctx::kPlain && K.enable_filter) {
     c.st_joint(legctl, LC_FX0, S.fx0); c.st_joint(legctl, LC_FX1, S.fx1);
     c.st_joint(legctl, LC_FY0, S.fy0); c.st_joint(legctl, LC_FY1, S.fy1);
   }
@@ -591,10 +592,10 @@ ETG_HD void control_step16_core(const Ctx& c, const KCfg& K, TickPar<F>& tp, Sta
                                 const F* hyb = nullptr) {   // hyb: (kp, qd_des, kd, tau_ff) of this lane's motor, HYBRID mode
   const F mj = c.jointf();
   F etg = etg_action16<F>(c, K, etgp, (float)(S.step_count + 1) * K.etg_dt);
-  const bool torque_cmd = K.motor_mode == 1;
-  const bool hybrid_cmd = K.motor_mode == 2 && hyb != nullptr;
+  const bool torque_cmd = !Ctx::kPlain && K.motor_mode == 1;
+  const bool hybrid_cmd = !Ctx::kPlain && K.motor_mode == 2 && hyb != nullptr;
   F qdes = (torque_cmd || hybrid_cmd) ? mj * action : mj * (c.par_joint(PR_POSE) + etg + action);
-  if (K.enable_filter) {
+  if (!Ctx::kPlain && K.enable_filter) {
     F y = F(K.fb[0]) * qdes + F(K.fb[1]) * S.fx0 + F(K.fb[2]) * S.fx1 - F(K.fa[1]) * S.fy0 - F(K.fa[2]) * S.fy1;
     S.fx1 = S.fx0; S.fx0 = qdes;
     S.fy1 = S.fy0; S.fy0 = y;
@@ -602,7 +603,7 @@ ETG_HD void control_step16_core(const Ctx& c, const KCfg& K, TickPar<F>& tp, Sta
   }
   const F last = S.last, lbx = S.lbx, lby = S.lby, lbz = S.lbz, last_fwx = S.last_fwx;
   L.energy = F(0.0f);
-  const bool interp = K.enable_interp && S.has_last;
+  const bool interp = !Ctx::kPlain && K.enable_interp && S.has_last;
   // The observation at the end of the step reads ring slots tick_end - n and tick_end - n - 1 only, so
   // only the ticks that land there are pushed: i == ia or i == ib (one modulo per step, not two per tick).
   const int n_lat = c.uniform_int(c.par(PR_LAT_N));
@@ -686,7 +687,7 @@ ETG_HD void control_step16(const Ctx& c, const KCfg& K, State16<F>& L, float* ri
                            const F* hyb = nullptr) {
   StepCtl16<F> S = load_ctl16<F>(c, K, ctl, ictl, legctl);
   TickPar<F> tp = load_tick_par<F>(c);
-  if (K.ext_force) tp.fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
+  if (!Ctx::kPlain && K.ext_force) tp.fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
   control_step16_core(c, K, tp, L, S, ring, etgp, action, donef, obs, reward, done, info, hyb);
   store_ctl16(c, K, S, ctl, ictl, legctl);
 }
@@ -699,7 +700,7 @@ ETG_HD void rollout_steps16(const Ctx& c, const KCfg& K, State16<F>& L, float* r
                             const float* etgp, int n_steps, float* obs) {
   StepCtl16<F> S = load_ctl16<F>(c, K, ctl, ictl, legctl);
   TickPar<F> tp = load_tick_par<F>(c);
-  if (K.ext_force) tp.fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
+  if (!Ctx::kPlain && K.ext_force) tp.fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
   F reward, done;
   for (int s = 0; s < n_steps; s++)
     control_step16_core(c, K, tp, L, S, ring, etgp, F(0.0f), F(0.0f), obs, reward, done, (float*)nullptr);

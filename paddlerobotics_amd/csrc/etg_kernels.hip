@@ -418,8 +418,15 @@ struct GpuCtx16 {
     else heightfield_query(K, env, x, y, h, nx, ny, nz);
   }
 };
-// KNEE: the knee contact rows of EtgConfig.body_contacts (heightfield kernels only) are compiled in
-template <bool FLAT, bool KNEE = false> struct GpuCtx16T : GpuCtx16 { static constexpr bool kFlat = FLAT; static constexpr bool kKnee = KNEE; };
+// KNEE: the knee contact rows of EtgConfig.body_contacts (heightfield kernels only) are compiled in.
+// PLAIN: the default robot layer -- POSITION control, no action filter / interpolation, no torque limit, no command
+// clip, no external force (plain_config) -- with those options compiled out: their never-taken branches and the
+// registers they pin cost the step kernels ~3 % (measured A/B), so the common configuration gets its own instantiation.
+template <bool FLAT, bool KNEE = false, bool PLAIN = false> struct GpuCtx16T : GpuCtx16 {
+  static constexpr bool kFlat = FLAT;
+  static constexpr bool kKnee = KNEE;
+  static constexpr bool kPlain = PLAIN;
+};
 
 // robot_block = index of the group of 4 robots this wave carries, lane = lane in the wave, lds_wave = the wave's
 // own [LDS16_FIELDS][64] parameter staging area
@@ -450,10 +457,10 @@ __device__ __forceinline__ bool make_ctx16(const KCfg& K, const DevState& D, Gpu
   return make_ctx16_at(K, D, c, lds_all, xcd_contiguous_block(), threadIdx.x);
 }
 
-template <bool FLAT, bool KNEE>
+template <bool FLAT, bool KNEE, bool PLAIN>
 __global__ void __launch_bounds__(BLOCK) k_settle16(KCfg K, DevState D, const uint8_t* mask) {
   __shared__ float lds_par[LDS16_FIELDS * BLOCK];
-  GpuCtx16T<FLAT, KNEE> c;
+  GpuCtx16T<FLAT, KNEE, PLAIN> c;
   if (!make_ctx16(K, D, c, lds_par)) return;
   if ((mask && !mask[c.env]) || settle_cached<FLAT>(K, D, c.env)) return;   // whole rows drop out together
   State16<float> L;
@@ -464,10 +471,10 @@ __global__ void __launch_bounds__(BLOCK) k_settle16(KCfg K, DevState D, const ui
   settle_mark_fresh(K, D, c.env, ox, oy);
 }
 
-template <bool FLAT, bool KNEE>
+template <bool FLAT, bool KNEE, bool PLAIN>
 __global__ void __launch_bounds__(BLOCK) k_finish16(KCfg K, DevState D, const uint8_t* mask, float* obs) {
   __shared__ float lds_par[LDS16_FIELDS * BLOCK];
-  GpuCtx16T<FLAT, KNEE> c;
+  GpuCtx16T<FLAT, KNEE, PLAIN> c;
   if (!make_ctx16(K, D, c, lds_par)) return;
   if (mask && !mask[c.env]) return;
   State16<float> L = load_state16<float>(c, D.base, D.leg);
@@ -475,11 +482,11 @@ __global__ void __launch_bounds__(BLOCK) k_finish16(KCfg K, DevState D, const ui
   store_state16(c, D.base, D.leg, L);
 }
 
-template <bool FLAT, bool KNEE>
+template <bool FLAT, bool KNEE, bool PLAIN>
 __global__ void __launch_bounds__(BLOCK) k_step16(KCfg K, DevState D, const float* action, const uint8_t* donef, float* obs,
                                                    float* reward, uint8_t* done, float* info) {
   __shared__ float lds_par[LDS16_FIELDS * BLOCK];
-  GpuCtx16T<FLAT, KNEE> c;
+  GpuCtx16T<FLAT, KNEE, PLAIN> c;
   if (!make_ctx16(K, D, c, lds_par)) return;
   State16<float> L = load_state16<float>(c, D.base, D.leg);
   const bool hybrid = K.motor_mode == 2 && action;   // rows of 60: per motor (q_des, kp, qd_des, kd, tau_ff)
@@ -510,10 +517,10 @@ __global__ void __launch_bounds__(BLOCK) k_step16(KCfg K, DevState D, const floa
 
 // n_steps open-loop control steps of every robot in one launch (rollout_steps16): state, control variables and
 // tick constants stay in registers between the steps
-template <bool FLAT, bool KNEE>
+template <bool FLAT, bool KNEE, bool PLAIN>
 __global__ void __launch_bounds__(BLOCK) k_rollout16(KCfg K, DevState D, int n_steps, float* obs) {
   __shared__ float lds_par[LDS16_FIELDS * BLOCK];
-  GpuCtx16T<FLAT, KNEE> c;
+  GpuCtx16T<FLAT, KNEE, PLAIN> c;
   if (!make_ctx16(K, D, c, lds_par)) return;
   State16<float> L = load_state16<float>(c, D.base, D.leg);
   rollout_steps16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, n_steps, obs);
@@ -526,7 +533,7 @@ __global__ void __launch_bounds__(BLOCK) k_rollout16(KCfg K, DevState D, int n_s
 // the next observation back to LDS.  Nothing but the final observation, the ring and the episode accumulators
 // touches HBM between steps.  (run_EStrain_episode / run_evaluate_episodes, train.py:182-249, with a fixed actor.)
 struct PolicyW { const float4 *w1, *w2, *w3; const float *b1, *b2, *b3; int in_dim, out_dim, col0; };   // col0: first observation column the actor sees
-template <bool FLAT, bool BF16, bool KNEE>
+template <bool FLAT, bool BF16, bool KNEE, bool PLAIN>
 __global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, PolicyW P, int n_steps, float act_scale, float* obs) {
   using namespace pol;
   constexpr int NWP = 4;
@@ -538,12 +545,12 @@ __global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, Po
   __shared__ float lds_par[NWP][LDS16_FIELDS * 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int tile = xcd_contiguous_block();            // 16 robots; the host guarantees N % 16 == 0
-  GpuCtx16T<FLAT, KNEE> c;
+  GpuCtx16T<FLAT, KNEE, PLAIN> c;
   make_ctx16_at(K, D, c, lds_par[wave], 4 * tile + wave, lane);
   State16<float> L = load_state16<float>(c, D.base, D.leg);
   StepCtl16<float> S = load_ctl16<float>(c, K, D.ctl, D.ictl, D.legctl);
   TickPar<float> tp = load_tick_par<float>(c);
-  if (K.ext_force) tp.fext = {c.ld_env(D.ctl, CT_FEXT + 0), c.ld_env(D.ctl, CT_FEXT + 1), c.ld_env(D.ctl, CT_FEXT + 2)};
+  if (!PLAIN && K.ext_force) tp.fext = {c.ld_env(D.ctl, CT_FEXT + 0), c.ld_env(D.ctl, CT_FEXT + 1), c.ld_env(D.ctl, CT_FEXT + 2)};
   // current observation of the tile -> LDS
   for (int idx = tid; idx < TM * ETG_OBS_DIM; idx += 256) obs_lds[idx] = obs[(size_t)tile * TM * ETG_OBS_DIM + idx];
   float reward, done;
@@ -780,12 +787,16 @@ static inline void launch_obs_noise(EtgHandle* h, int n, const uint8_t* mask, fl
   hipLaunchKernelGGL(k_add_noise, dim3((16 * h->N + 255) / 256), dim3(256), 0, s, h->K, h->K.noise_call + (unsigned)(n - 1), mask, obs);
 }
 
-// the three instantiations of a 16-lane kernel: flat ground, heightfield, heightfield + knee rows
-#define LAUNCH16(KERN, grid, stream, ...)                                                                     \
-  do {                                                                                                        \
-    if (h->K.terrain == 0) hipLaunchKernelGGL((KERN<true, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__); \
-    else if (!h->K.knee) hipLaunchKernelGGL((KERN<false, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);  \
-    else hipLaunchKernelGGL((KERN<false, true>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);                   \
+// the instantiations of a 16-lane kernel: {flat ground, heightfield} x {plain robot layer, all options}, and
+// heightfield + knee rows
+#define LAUNCH16(KERN, grid, stream, ...)                                                                             \
+  do {                                                                                                                \
+    const bool pl_ = plain_config(h->K);                                                                              \
+    if (h->K.terrain == 0 && pl_) hipLaunchKernelGGL((KERN<true, false, true>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+    else if (h->K.terrain == 0) hipLaunchKernelGGL((KERN<true, false, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+    else if (h->K.knee) hipLaunchKernelGGL((KERN<false, true, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);           \
+    else if (pl_) hipLaunchKernelGGL((KERN<false, false, true>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);                 \
+    else hipLaunchKernelGGL((KERN<false, false, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);                         \
   } while (0)
 
 #define CHECK_HANDLE(h)                                         \
@@ -983,13 +994,18 @@ extern "C" int etg_rollout_policy(EtgHandle* h, EtgPolicy* pol, int n_steps, flo
   for (int done_steps = 0; done_steps < n_steps; done_steps += ROLLOUT_CHUNK) {
     const int m = n_steps - done_steps < ROLLOUT_CHUNK ? n_steps - done_steps : ROLLOUT_CHUNK;
     advance_obs_stream(h, m);
-    const bool kn = h->K.knee != 0;
-    if (flat && precision == 0) hipLaunchKernelGGL((k_rollout_policy16<true, false, false>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
-    else if (flat) hipLaunchKernelGGL((k_rollout_policy16<true, true, false>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
-    else if (precision == 0 && !kn) hipLaunchKernelGGL((k_rollout_policy16<false, false, false>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
-    else if (!kn) hipLaunchKernelGGL((k_rollout_policy16<false, true, false>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
-    else if (precision == 0) hipLaunchKernelGGL((k_rollout_policy16<false, false, true>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
-    else hipLaunchKernelGGL((k_rollout_policy16<false, true, true>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);
+    const bool kn = h->K.knee != 0, pl = plain_config(h->K);
+#define LAUNCH_POLICY16(F_, K_, P_)                                                                                   \
+  do {                                                                                                                \
+    if (precision == 0) hipLaunchKernelGGL((k_rollout_policy16<F_, false, K_, P_>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs); \
+    else hipLaunchKernelGGL((k_rollout_policy16<F_, true, K_, P_>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);    \
+  } while (0)
+    if (flat && pl) LAUNCH_POLICY16(true, false, true);
+    else if (flat) LAUNCH_POLICY16(true, false, false);
+    else if (kn) LAUNCH_POLICY16(false, true, false);
+    else if (pl) LAUNCH_POLICY16(false, false, true);
+    else LAUNCH_POLICY16(false, false, false);
+#undef LAUNCH_POLICY16
     launch_obs_noise(h, m, nullptr, obs, s);   // every chunk ends in the caller's rows: the next chunk reads them
   }
   HIP_TRY(hipGetLastError());

@@ -68,6 +68,12 @@ struct KCfg {
   unsigned noise_call;   // stream position of the first observation this launch writes
 };
 
+// the default robot layer (what train.py / pretrain.py run): the PLAIN kernel instantiations compile the options out
+inline bool plain_config(const KCfg& K) {
+  return K.motor_mode == 0 && !K.enable_filter && !K.enable_interp && !(K.torque_limit > 0.0f) && !(K.clip_cmd > 0.0f) &&
+         !K.ext_force && !K.knee;
+}
+
 // counter-based standard normal pair for (seed, robot, observation index, channel): splitmix64 finaliser twice, then
 // Box-Muller.  The same few lines are restated in the oracle (oracle/etgsim_oracle.cpp: gauss_pair).
 ETG_HD unsigned long long mix64_(unsigned long long z) {

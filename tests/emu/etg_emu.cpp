@@ -133,9 +133,10 @@ struct EmuCtx16Base {
     }
   }
 };
-template <bool FLAT, bool KNEE = false> struct EmuCtx16T : EmuCtx16Base {
+template <bool FLAT, bool KNEE = false, bool PLAIN = false> struct EmuCtx16T : EmuCtx16Base {
   static constexpr bool kFlat = FLAT;
   static constexpr bool kKnee = KNEE;
+  static constexpr bool kPlain = PLAIN;
   EmuCtx16T(int e, int n, const float* p) { env = e; N = n; parp = p; }
 };
 
@@ -236,9 +237,12 @@ extern "C" void emu_reset(void* h, const uint8_t* mask, float* obs) {
     if (mask && !mask[i]) continue;
     const float ox = e->reset_off.empty() ? 0.0f : e->reset_off[2 * i], oy = e->reset_off.empty() ? 0.0f : e->reset_off[2 * i + 1];
     if (e->lanes == 16) {
-      if (e->K.terrain == 0) emu_reset16<EmuCtx16T<true>>(e, i, obs, ox, oy);
-      else if (!e->K.knee) emu_reset16<EmuCtx16T<false>>(e, i, obs, ox, oy);
-      else emu_reset16<EmuCtx16T<false, true>>(e, i, obs, ox, oy);
+      const bool pl = plain_config(e->K);                       // same instantiation choice as LAUNCH16 in etg_kernels.hip
+      if (e->K.terrain == 0 && pl) emu_reset16<EmuCtx16T<true, false, true>>(e, i, obs, ox, oy);
+      else if (e->K.terrain == 0) emu_reset16<EmuCtx16T<true>>(e, i, obs, ox, oy);
+      else if (e->K.knee) emu_reset16<EmuCtx16T<false, true>>(e, i, obs, ox, oy);
+      else if (pl) emu_reset16<EmuCtx16T<false, false, true>>(e, i, obs, ox, oy);
+      else emu_reset16<EmuCtx16T<false>>(e, i, obs, ox, oy);
       continue;
     }
     LaneState<F4> L;
@@ -261,9 +265,12 @@ extern "C" void emu_step(void* h, const float* action, const uint8_t* donef, flo
     if (e->lanes == 16) {
       F16 r16, d16;
       F16 dn(donef ? (float)donef[i] : 0.f);
-      if (e->K.terrain == 0) emu_step16<EmuCtx16T<true>>(e, i, action, dn, obs, r16, d16, info);
-      else if (!e->K.knee) emu_step16<EmuCtx16T<false>>(e, i, action, dn, obs, r16, d16, info);
-      else emu_step16<EmuCtx16T<false, true>>(e, i, action, dn, obs, r16, d16, info);
+      const bool pl = plain_config(e->K);
+      if (e->K.terrain == 0 && pl) emu_step16<EmuCtx16T<true, false, true>>(e, i, action, dn, obs, r16, d16, info);
+      else if (e->K.terrain == 0) emu_step16<EmuCtx16T<true>>(e, i, action, dn, obs, r16, d16, info);
+      else if (e->K.knee) emu_step16<EmuCtx16T<false, true>>(e, i, action, dn, obs, r16, d16, info);
+      else if (pl) emu_step16<EmuCtx16T<false, false, true>>(e, i, action, dn, obs, r16, d16, info);
+      else emu_step16<EmuCtx16T<false>>(e, i, action, dn, obs, r16, d16, info);
       reward[i] = r16.v[0];
       done[i] = d16.v[0] > 0.5f;
       continue;
