@@ -206,9 +206,10 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
 #pragma unroll
   for (int j = 0; j < 3; j++) {
     F cmd = qdes[j];
-    if (K.clip_cmd > 0.0f && !torque_cmd) cmd = fminf_(fmaxf_(cmd, L.q[j] - F(K.clip_cmd)), L.q[j] + F(K.clip_cmd));   // a1.py:439-457
-    F t = torque_cmd ? cmd : (-(tp.kp[j] * (L.q[j] - cmd)) - tp.kd[j] * (L.qd[j] - tp.qd_des[j])) + tp.tau_ff[j];   // TORQUE mode: pass-through
-    if (K.torque_limit > 0.0f) t = fminf_(fmaxf_(t, F(-K.torque_limit)), F(K.torque_limit));
+    if (!Ctx::kPlain && K.clip_cmd > 0.0f && !torque_cmd) cmd = fminf_(fmaxf_(cmd, L.q[j] - F(K.clip_cmd)), L.q[j] + F(K.clip_cmd));   // a1.py:439-457
+    F t = Ctx::kPlain ? -(tp.kp[j] * (L.q[j] - cmd)) - tp.kd[j] * L.qd[j]
+                      : (torque_cmd ? cmd : (-(tp.kp[j] * (L.q[j] - cmd)) - tp.kd[j] * (L.qd[j] - tp.qd_des[j])) + tp.tau_ff[j]);   // TORQUE mode: pass-through
+    if (!Ctx::kPlain && K.torque_limit > 0.0f) t = fminf_(fmaxf_(t, F(-K.torque_limit)), F(K.torque_limit));
     tau[j] = t;
   }
 
@@ -307,7 +308,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   F rb[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) rb[i] = -(comp(f0, i) + c.qsum(comp(f1, i))) - c.qsum(comp(pb, i));
-  if (K.ext_force) {  // external force on the trunk COM (world frame) -> base frame: R^T f
+  if (!Ctx::kPlain && K.ext_force) {  // external force on the trunk COM (world frame) -> base frame: R^T f
     rb[3] = rb[3] + Rw.r0.x * fext_w.x + Rw.r1.x * fext_w.y + Rw.r2.x * fext_w.z;
     rb[4] = rb[4] + Rw.r0.y * fext_w.x + Rw.r1.y * fext_w.y + Rw.r2.y * fext_w.z;
     rb[5] = rb[5] + Rw.r0.z * fext_w.x + Rw.r1.z * fext_w.y + Rw.r2.z * fext_w.z;
@@ -682,7 +683,7 @@ ETG_HD StepCtl4<F> load_ctl4(const Ctx& c, const KCfg& K, const float* ctl, cons
   S.r0 = c.ld_env(ctl, CT_FIRST_RPY + 0); S.r1 = c.ld_env(ctl, CT_FIRST_RPY + 1); S.r2 = c.ld_env(ctl, CT_FIRST_RPY + 2);
   for (int j = 0; j < 3; j++) {
     S.fx0[j] = S.fx1[j] = S.fy0[j] = S.fy1[j] = F(0.0f);
-    if (K.enable_filter) {
+    if (!Ctx::kPlain && K.enable_filter) {
       S.fx0[j] = c.ld_lane(legctl, LC_FX0 + j); S.fx1[j] = c.ld_lane(legctl, LC_FX1 + j);
       S.fy0[j] = c.ld_lane(legctl, LC_FY0 + j); S.fy1[j] = c.ld_lane(legctl, LC_FY1 + j);
     }
@@ -698,7 +699,7 @@ ETG_HD void store_ctl4(const Ctx& c, const KCfg& K, const StepCtl4<F>& S, float*
   c.st_env(ctl, CT_LAST_BASE + 0, S.lbx); c.st_env(ctl, CT_LAST_BASE + 1, S.lby); c.st_env(ctl, CT_LAST_BASE + 2, S.lbz);
   c.st_lane(legctl, LC_LAST_FOOT_X, S.last_fwx);
   c.st_env(ctl, CT_RET, S.ret); c.st_env(ctl, CT_LEN, S.len); c.st_env(ctl, CT_ALIVE, S.alive);
-  if (K.enable_filter)
+  if (!Ctx::kPlain && K.enable_filter)
     for (int j = 0; j < 3; j++) {
       c.st_lane(legctl, LC_FX0 + j, S.fx0[j]); c.st_lane(legctl, LC_FX1 + j, S.fx1[j]);
       c.st_lane(legctl, LC_FY0 + j, S.fy0[j]); c.st_lane(legctl, LC_FY1 + j, S.fy1[j]);
@@ -716,11 +717,11 @@ ETG_HD void control_step_core(const Ctx& c, const KCfg& K, TickPar4<F>& tp, cons
   // ETG at t = (k+1) dt (fixture convention of gait_action_list_ETG_exp.npy)
   F etg[3], qdes[3];
   etg_action(c, K, etgp, (float)(step_count + 1) * K.etg_dt, etg);
-  const bool torque_cmd = K.motor_mode == 1;
-  const bool hybrid_cmd = K.motor_mode == 2 && hyb != nullptr;
+  const bool torque_cmd = !Ctx::kPlain && K.motor_mode == 1;
+  const bool hybrid_cmd = !Ctx::kPlain && K.motor_mode == 2 && hyb != nullptr;
 #pragma unroll
   for (int j = 0; j < 3; j++) qdes[j] = (torque_cmd || hybrid_cmd) ? action[j] : c.par(PR_POSE + j) + etg[j] + action[j];
-  if (K.enable_filter) {  // action_filter.py:111-120, order 2
+  if (!Ctx::kPlain && K.enable_filter) {  // action_filter.py:111-120, order 2
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       F y = F(K.fb[0]) * qdes[j] + F(K.fb[1]) * S.fx0[j] + F(K.fb[2]) * S.fx1[j] - F(K.fa[1]) * S.fy0[j] - F(K.fa[2]) * S.fy1[j];
@@ -732,7 +733,7 @@ ETG_HD void control_step_core(const Ctx& c, const KCfg& K, TickPar4<F>& tp, cons
   const F last[3] = {S.last[0], S.last[1], S.last[2]};
   const F lbx = S.lbx, lby = S.lby, lbz = S.lbz, last_fwx = S.last_fwx;
   L.energy = F(0.0f);
-  const bool interp = K.enable_interp && has_last;
+  const bool interp = !Ctx::kPlain && K.enable_interp && has_last;
   // Only the two readings a later observation will blend (minitaur.py:1185-1193: ticks T-n and
   // T-n-1 of some step end T) have to reach the ring: (i+1+n) mod R in {0, R-1}, i.e. i == ia or i == ib.
   const int n_lat = c.uniform_int(c.par(PR_LAT_N));
@@ -824,7 +825,7 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   StepCtl4<F> S = load_ctl4<F>(c, K, ctl, ictl, legctl);
   TickPar4<F> tp = load_tick_par4<F>(c);
   V3<F> fext = {F(0.0f), F(0.0f), F(0.0f)};
-  if (K.ext_force) fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
+  if (!Ctx::kPlain && K.ext_force) fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
   control_step_core(c, K, tp, fext, L, S, ring, etgp, action, donef, obs, reward, done, info, hyb);
   store_ctl4(c, K, S, ctl, ictl, legctl);
 }
@@ -836,7 +837,7 @@ ETG_HD void rollout_steps(const Ctx& c, const KCfg& K, LaneState<F>& L, float* r
   StepCtl4<F> S = load_ctl4<F>(c, K, ctl, ictl, legctl);
   TickPar4<F> tp = load_tick_par4<F>(c);
   V3<F> fext = {F(0.0f), F(0.0f), F(0.0f)};
-  if (K.ext_force) fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
+  if (!Ctx::kPlain && K.ext_force) fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
   const F zero3[3] = {F(0.0f), F(0.0f), F(0.0f)};
   F reward, done;
   for (int s = 0; s < n_steps; s++)

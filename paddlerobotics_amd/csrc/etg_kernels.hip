@@ -99,7 +99,7 @@ struct GpuCtx {
 };
 
 // FLAT selects the plane-z=0 fast path at compile time (contact frame = rows of R, no terrain lookup)
-template <bool FLAT> struct GpuCtxT : GpuCtx { static constexpr bool kFlat = FLAT; };
+template <bool FLAT, bool PLAIN = false> struct GpuCtxT : GpuCtx { static constexpr bool kFlat = FLAT; static constexpr bool kPlain = PLAIN; };   // PLAIN: see GpuCtx16T
 
 // Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its own L2.  Robots
 // of neighbouring blocks share 128 B lines of the SoA state (a block covers only 16-64 B of a field), so
@@ -184,9 +184,9 @@ __device__ __forceinline__ void settle_mark_fresh(const KCfg& K, const DevState&
   D.cache_off[K.n_env + env] = oy;
 }
 
-template <bool FLAT>
+template <bool FLAT, bool PLAIN>
 __global__ void __launch_bounds__(BLOCK) k_settle(KCfg K, DevState D, const uint8_t* mask) {
-  GpuCtxT<FLAT> c;
+  GpuCtxT<FLAT, PLAIN> c;
   if (!make_ctx(K, c)) return;
   if ((mask && !mask[c.env]) || settle_cached<FLAT>(K, D, c.env)) return;   // whole quads drop out together
   __shared__ float lds_par[PR_N * BLOCK];
@@ -226,9 +226,9 @@ __global__ void __launch_bounds__(256) k_cache_mark(KCfg K, DevState D, const ui
   D.cache_ok[env] = 1;
 }
 
-template <bool FLAT>
+template <bool FLAT, bool PLAIN>
 __global__ void __launch_bounds__(BLOCK) k_finish(KCfg K, DevState D, const uint8_t* mask, float* obs) {
-  GpuCtxT<FLAT> c;
+  GpuCtxT<FLAT, PLAIN> c;
   if (!make_ctx(K, c)) return;
   if (mask && !mask[c.env]) return;
   __shared__ float lds_par[PR_N * BLOCK];
@@ -238,10 +238,10 @@ __global__ void __launch_bounds__(BLOCK) k_finish(KCfg K, DevState D, const uint
   store_state(c, D.base, D.leg, L);
 }
 
-template <bool FLAT>
+template <bool FLAT, bool PLAIN>
 __global__ void __launch_bounds__(BLOCK) k_step(KCfg K, DevState D, const float* action, const uint8_t* donef, float* obs,
                                                  float* reward, uint8_t* done, float* info) {
-  GpuCtxT<FLAT> c;
+  GpuCtxT<FLAT, PLAIN> c;
   if (!make_ctx(K, c)) return;
   __shared__ float lds_par[PR_N * BLOCK];
   stage_params(c, D, lds_par);
@@ -276,9 +276,9 @@ __global__ void __launch_bounds__(BLOCK) k_step(KCfg K, DevState D, const float*
 }
 
 // n_steps open-loop control steps per launch (rollout_steps), the 4-lanes-per-robot counterpart of k_rollout16
-template <bool FLAT>
+template <bool FLAT, bool PLAIN>
 __global__ void __launch_bounds__(BLOCK) k_rollout(KCfg K, DevState D, int n_steps, float* obs) {
-  GpuCtxT<FLAT> c;
+  GpuCtxT<FLAT, PLAIN> c;
   if (!make_ctx(K, c)) return;
   __shared__ float lds_par[PR_N * BLOCK];
   stage_params(c, D, lds_par);
@@ -799,6 +799,16 @@ static inline void launch_obs_noise(EtgHandle* h, int n, const uint8_t* mask, fl
     else hipLaunchKernelGGL((KERN<false, false, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);                         \
   } while (0)
 
+// 4-lane kernels: {flat ground, heightfield} x {plain robot layer, all options}
+#define LAUNCH4(KERN, grid, stream, ...)                                                                              \
+  do {                                                                                                                \
+    const bool pl_ = plain_config(h->K);                                                                              \
+    if (h->K.terrain == 0 && pl_) hipLaunchKernelGGL((KERN<true, true>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);  \
+    else if (h->K.terrain == 0) hipLaunchKernelGGL((KERN<true, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+    else if (pl_) hipLaunchKernelGGL((KERN<false, true>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);                 \
+    else hipLaunchKernelGGL((KERN<false, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);                         \
+  } while (0)
+
 #define CHECK_HANDLE(h)                                         \
   if (!(h)) return fail(ETG_ERR_BAD_ARG, "null handle");       \
   HIP_TRY(hipSetDevice((h)->device));
@@ -871,16 +881,14 @@ extern "C" int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* st
   if (h->lanes == 16) {
     LAUNCH16(k_settle16, g16, s, h->K, h->D, mask);
   } else {
-    if (flat) hipLaunchKernelGGL(k_settle<true>, g4, dim3(BLOCK), 0, s, h->K, h->D, mask);
-    else hipLaunchKernelGGL(k_settle<false>, g4, dim3(BLOCK), 0, s, h->K, h->D, mask);
+    LAUNCH4(k_settle, g4, s, h->K, h->D, mask);
   }
   hipLaunchKernelGGL(k_cache_sync, gc, dim3(256), 0, s, h->K, h->D, mask);
   hipLaunchKernelGGL(k_cache_mark, ge, dim3(256), 0, s, h->K, h->D, mask);
   if (h->lanes == 16) {
     LAUNCH16(k_finish16, g16, s, h->K, h->D, mask, obs);
   } else {
-    if (flat) hipLaunchKernelGGL(k_finish<true>, g4, dim3(BLOCK), 0, s, h->K, h->D, mask, obs);
-    else hipLaunchKernelGGL(k_finish<false>, g4, dim3(BLOCK), 0, s, h->K, h->D, mask, obs);
+    LAUNCH4(k_finish, g4, s, h->K, h->D, mask, obs);
   }
   launch_obs_noise(h, 1, mask, obs, s);
   HIP_TRY(hipGetLastError());
@@ -922,12 +930,9 @@ extern "C" int etg_step(EtgHandle* h, const float* action, const uint8_t* donef,
   const dim3 g16((h->N + 3) / 4);
   if (h->lanes == 16) {
     LAUNCH16(k_step16, g16, (hipStream_t)stream, h->K, h->D, action, donef, obs, reward, done, info);
-  } else if (h->K.terrain == 0)
-    hipLaunchKernelGGL(k_step<true>, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, action, donef,
-                       obs, reward, done, info);
-  else
-    hipLaunchKernelGGL(k_step<false>, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, action, donef,
-                       obs, reward, done, info);
+  } else {
+    LAUNCH4(k_step, dim3(grid_for(h)), (hipStream_t)stream, h->K, h->D, action, donef, obs, reward, done, info);
+  }
   launch_obs_noise(h, 1, nullptr, obs, (hipStream_t)stream);
   HIP_TRY(hipGetLastError());
   return ETG_OK;
@@ -960,8 +965,7 @@ extern "C" int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float
       if (h->lanes == 16) {
         LAUNCH16(k_rollout16, g16, s, h->K, h->D, m, o);
       } else {
-        if (flat) hipLaunchKernelGGL(k_rollout<true>, g4, dim3(BLOCK), 0, s, h->K, h->D, m, o);
-        else hipLaunchKernelGGL(k_rollout<false>, g4, dim3(BLOCK), 0, s, h->K, h->D, m, o);
+        LAUNCH4(k_rollout, g4, s, h->K, h->D, m, o);
       }
       if (o == obs) launch_obs_noise(h, m, nullptr, obs, s);
     }

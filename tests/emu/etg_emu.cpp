@@ -54,8 +54,9 @@ struct EmuCtxBase {
   }
 };
 
-template <bool FLAT> struct EmuCtxT : EmuCtxBase {
+template <bool FLAT, bool PLAIN = false> struct EmuCtxT : EmuCtxBase {
   static constexpr bool kFlat = FLAT;
+  static constexpr bool kPlain = PLAIN;
   EmuCtxT(int e, int n, const float* p) { env = e; N = n; parp = p; }
 };
 typedef EmuCtxT<false> EmuCtx;   // generic-terrain instantiation; the flat fast path is EmuCtxT<true>
@@ -199,6 +200,16 @@ extern "C" void emu_set_reset_offsets(void* h, const float* xy) {
   e->reset_off.assign((size_t)2 * e->N, 0.0f);
   if (xy) std::copy(xy, xy + (size_t)2 * e->N, e->reset_off.begin());
 }
+template <class Ctx> static void emu_reset4(Emu* e, int i, float* obs, float ox, float oy) {
+  Ctx c(i, e->N, e->par.data());
+  LaneState<F4> L;
+  reset_quad(c, e->K, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs, F4(ox), F4(oy));
+  store_state(c, e->base.data(), e->leg.data(), L);
+}
+template <class Ctx> static void emu_step4(Emu* e, int i, LaneState<F4>& L, const F4* act, F4 dn, float* obs, F4& r, F4& d, float* info, const F4* hyb) {
+  Ctx c(i, e->N, e->par.data());
+  control_step(c, e->K, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), act, dn, obs, r, d, info, hyb);
+}
 template <class Ctx> static void emu_reset16(Emu* e, int i, float* obs, float ox, float oy) {
   Ctx c(i, e->N, e->par.data());
   State16<F16> S;
@@ -245,16 +256,11 @@ extern "C" void emu_reset(void* h, const uint8_t* mask, float* obs) {
       else emu_reset16<EmuCtx16T<false>>(e, i, obs, ox, oy);
       continue;
     }
-    LaneState<F4> L;
-    if (e->K.terrain == 0) {
-      EmuCtxT<true> c(i, e->N, e->par.data());
-      reset_quad(c, e->K, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs, F4(ox), F4(oy));
-      store_state(c, e->base.data(), e->leg.data(), L);
-    } else {
-      EmuCtxT<false> c(i, e->N, e->par.data());
-      reset_quad(c, e->K, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), obs, F4(ox), F4(oy));
-      store_state(c, e->base.data(), e->leg.data(), L);
-    }
+    const bool pl4 = plain_config(e->K);                        // same choice as LAUNCH4 in etg_kernels.hip
+    if (e->K.terrain == 0 && pl4) emu_reset4<EmuCtxT<true, true>>(e, i, obs, ox, oy);
+    else if (e->K.terrain == 0) emu_reset4<EmuCtxT<true>>(e, i, obs, ox, oy);
+    else if (pl4) emu_reset4<EmuCtxT<false, true>>(e, i, obs, ox, oy);
+    else emu_reset4<EmuCtxT<false>>(e, i, obs, ox, oy);
   }
   emu_obs_noise(e, mask, obs);
 }
@@ -284,14 +290,12 @@ extern "C" void emu_step(void* h, const float* action, const uint8_t* donef, flo
       for (int k = 0; k < 4; k++) hyb[4 * j + k] = hybrid ? c0.ld_row_lane(action, ETG_HYBRID_DIM, 5 * j + 1 + k, 15) : F4(0.0f);
     }
     F4 r, d;
-    if (e->K.terrain == 0) {
-      EmuCtxT<true> c(i, e->N, e->par.data());
-      control_step(c, e->K, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), act,
-                   F4(donef ? (float)donef[i] : 0.f), obs, r, d, info, hybrid ? hyb : nullptr);
-    } else {
-      control_step(c0, e->K, L, e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), act,
-                   F4(donef ? (float)donef[i] : 0.f), obs, r, d, info, hybrid ? hyb : nullptr);
-    }
+    const F4 dn4(donef ? (float)donef[i] : 0.f);
+    const bool pl4 = plain_config(e->K);
+    if (e->K.terrain == 0 && pl4) emu_step4<EmuCtxT<true, true>>(e, i, L, act, dn4, obs, r, d, info, hybrid ? hyb : nullptr);
+    else if (e->K.terrain == 0) emu_step4<EmuCtxT<true>>(e, i, L, act, dn4, obs, r, d, info, hybrid ? hyb : nullptr);
+    else if (pl4) emu_step4<EmuCtxT<false, true>>(e, i, L, act, dn4, obs, r, d, info, hybrid ? hyb : nullptr);
+    else emu_step4<EmuCtxT<false>>(e, i, L, act, dn4, obs, r, d, info, hybrid ? hyb : nullptr);
     store_state(c0, e->base.data(), e->leg.data(), L);
     reward[i] = r.v[0];
     done[i] = d.v[0] > 0.5f;
