@@ -281,9 +281,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   // lane the DPP form needs no accumulator shuffles and no MFMA latency padding.)
   F lam = mj * rowf * F(K.warmstart) * L.lam;                   // warm start (defined here: DPP source below); knee rows start at 0
   F hj[3] = {HJ0, HJ1, HJ2};
-  c.dpp_ready(Z, 6);
-  c.dpp_ready(hj, 3);
-  c.dpp_ready(&lam, 1);
+  c.dpp_ready10(Z, hj, &lam);                                   // one fence for all broadcast sources of this phase
   F A[4][3];
 #pragma unroll
   for (int lp = 0; lp < 4; lp++)
@@ -298,14 +296,18 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   F ownl[4];
 #pragma unroll
   for (int lp = 0; lp < 4; lp++) ownl[lp] = sel_(c.leg_is(lp), one, zero);
+  // (back-to-back DPP-FMAs into ONE accumulator cost a wait state each: the three sums advance side by side)
+  F own[3];                                                     // own[e] = sum_j HJ_e[j] Jl_sub[j]
 #pragma unroll
-  for (int e = 0; e < 3; e++) {
-    F own = c.qb(hj[0], e) * Jl0;                               // sum_j HJ_e[j] Jl_sub[j]
-    c.fmac_qb(own, hj[1], Jl1, e);
-    c.fmac_qb(own, hj[2], Jl2, e);
+  for (int e = 0; e < 3; e++) own[e] = c.qb(hj[0], e) * Jl0;
 #pragma unroll
-    for (int lp = 0; lp < 4; lp++) A[lp][e] = A[lp][e] + ownl[lp] * own;
-  }
+  for (int e = 0; e < 3; e++) c.fmac_qb(own[e], hj[1], Jl1, e);
+#pragma unroll
+  for (int e = 0; e < 3; e++) c.fmac_qb(own[e], hj[2], Jl2, e);
+#pragma unroll
+  for (int e = 0; e < 3; e++)
+#pragma unroll
+    for (int lp = 0; lp < 4; lp++) A[lp][e] = A[lp][e] + ownl[lp] * own[e];
   F Ak[4] = {zero, zero, zero, zero};                           // column of the knee row of leg lp
   if (knee) {
 #pragma unroll
@@ -331,10 +333,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   F u = rowf * dot(dir, vc);
   const F idt(1.0f / K.dt);
   const F tgt = (knee ? f0 + f3 : f0) * sel_(phi > zero, -(phi * idt), -(F(K.erp) * phi * idt));   // only normal rows have a target
-#pragma unroll
-  for (int lp = 0; lp < 4; lp++)
-#pragma unroll
-    for (int e = 0; e < 3; e++) c.fmac_rbcast(u, lam, A[lp][e], 4 * lp + e);
+  c.fmac_rbcast12(u, lam, &A[0][0]);                            // u += sum_(lp,e) lam@row(4 lp + e) * A[lp][e], one asm block
   c.phase(7);
   // ---- projected Gauss-Seidel, rows in the order (FR n,t1,t2), (FL ...), (RR ...), (RL ...): the owner
   // lane's candidate is broadcast over the row with row_newbcast and applied by every lane.
@@ -386,7 +385,10 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   // ---- apply impulses: base via the Schur factor, joints via H^-1
   F db[6];
 #pragma unroll
-  for (int k = 0; k < 6; k++) db[k] = c.sum16(lam * Z[k]) * sq[k];
+  for (int k = 0; k < 6; k++) db[k] = lam * Z[k];
+  c.sum16x6(db);                                                // the six reductions stage by stage (no DPP wait states)
+#pragma unroll
+  for (int k = 0; k < 6; k++) db[k] = db[k] * sq[k];
   bwd6(s, db);
   W dB = {{db[0], db[1], db[2]}, {db[3], db[4], db[5]}};
   L.wb = wbs + dB.a;

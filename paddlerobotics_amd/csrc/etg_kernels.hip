@@ -320,6 +320,17 @@ struct GpuCtx16 {
   __device__ __forceinline__ float qsum(float a) const { float t = a + dpp_<0xB1>(a); return t + dpp_<0x4E>(t); }
   // ---- row (= robot) exchanges: xor1, xor2, row_half_mirror, row_mirror -- order-symmetric, so the
   // result is bit-identical on the 16 lanes
+  // six row sums advanced stage by stage: every DPP reads a value written six instructions earlier
+  __device__ __forceinline__ void sum16x6(float* v) const {
+#pragma unroll
+    for (int k = 0; k < 6; k++) v[k] = v[k] + dpp_<0xB1>(v[k]);
+#pragma unroll
+    for (int k = 0; k < 6; k++) v[k] = v[k] + dpp_<0x4E>(v[k]);
+#pragma unroll
+    for (int k = 0; k < 6; k++) v[k] = v[k] + dpp_<0x141>(v[k]);
+#pragma unroll
+    for (int k = 0; k < 6; k++) v[k] = v[k] + dpp_<0x140>(v[k]);
+  }
   __device__ __forceinline__ float sum16(float a) const {
     float t = a + dpp_<0xB1>(a); t = t + dpp_<0x4E>(t); t = t + dpp_<0x141>(t); return t + dpp_<0x140>(t);
   }
@@ -368,9 +379,23 @@ struct GpuCtx16 {
       case 2: ETG_FMAC_DPP("quad_perm:[2,2,2,2]"); break; default: ETG_FMAC_DPP("quad_perm:[3,3,3,3]"); break;
     }
   }
+  // the 12 warm-start terms in one asm block: consecutive inline-asm statements that accumulate into one register
+  // get a compiler-inserted wait state each (it cannot see that the accumulator is not the DPP operand)
+  __device__ __forceinline__ void fmac_rbcast12(float& acc, float x, const float* a) const {
+#define ETG_L(R, N) "v_fmac_f32_dpp %0, %1, %" #N " row_newbcast:" #R " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    asm(ETG_L(0, 2) ETG_L(1, 3) ETG_L(2, 4) ETG_L(4, 5) ETG_L(5, 6) ETG_L(6, 7) ETG_L(8, 8) ETG_L(9, 9) ETG_L(10, 10)
+        ETG_L(12, 11) ETG_L(13, 12) ETG_L(14, 13)
+        : "+v"(acc)
+        : "v"(x), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),
+          "v"(a[10]), "v"(a[11]));
+#undef ETG_L
+  }
 #undef ETG_FMAC_DPP
   // every value that later feeds fmac_rbcast / fmac_qb as the broadcast source passes through here: the
   // asm "modifies" them, so their producers are ordered before it and the DPP reads after it
+  __device__ __forceinline__ void dpp_ready10(float* z, float* hj, float* lam) const {
+    asm volatile("s_nop 1" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]), "+v"(hj[0]), "+v"(hj[1]), "+v"(hj[2]), "+v"(lam[0]));
+  }
   __device__ __forceinline__ void dpp_ready(float* v, int n) const {
     if (n == 6) asm volatile("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
     else if (n == 3) asm volatile("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));
