@@ -29,19 +29,20 @@ from paddlerobotics_amd.etg_fit import opt_with_points_batched  # noqa: E402
 
 SOLVER_ITERS = 2           # library default (K=2 vs K=50 differ by <0.4 mm after 5 m)
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
-# PMC figures per CONTROL STEP at N = 4096 (profiles/r01_pmc_16lane_kernels.txt, r01_pmc_k_step_lanes4.txt; separate
+# PMC figures per CONTROL STEP at N = 4096 (profiles/r01_pmc_16lane_kernels.txt, r01_pmc_4lane_kernels.txt; separate
 # passes, FETCH_SIZE / WRITE_SIZE in KB).  Calibrated for this code's access width -- one dword per lane, coalesced
 # SoA -- with tools/ubench/pmc_calib.hip (a 512 MiB copy): FETCH_SIZE reports exactly 1/2 of the bytes read (as the
 # micro-arch guide found for wide reads), WRITE_SIZE is exact; hence the factor 2 on the fetch term.  k_rollout16
 # runs 50 control steps per launch, so its launch totals are divided by 50.  Scaled linearly with N.
-PMC_TRAFFIC_BYTES_AT_4096 = {"k_rollout16": (2 * 17553.0 + 30192.0) * 1024.0 / 50.0, "k_step16": (2 * 3982.5 + 4100.0) * 1024.0,
-                             "k_step": (2 * 4010.5 + 3076.0) * 1024.0, "k_rollout": None, "k_rollout_policy16": None}
+PMC_TRAFFIC_BYTES_AT_4096 = {"k_rollout16": (2 * 17534.0 + 30192.0) * 1024.0 / 50.0, "k_step16": (2 * 3851.0 + 3076.0) * 1024.0,
+                             "k_step": (2 * 3895.0 + 3076.0) * 1024.0, "k_rollout": (2 * 17559.8 + 30192.0) * 1024.0 / 50.0,
+                             "k_rollout_policy16": None}
 # VALU instructions one wave issues per control step (SQ_INSTS_VALU / SQ_WAVES, same files) and the VALU issue
 # capacity of a SIMD measured with tools/ubench/occupancy_rate.hip (8 resident waves of v_fma_f32: 0.384
 # wave-instructions per SIMD-cycle at the nominal 2.4 GHz; a lone wave issues one VALU instruction per 4.9-5.4
 # cycles, i.e. about 0.2 -- issue_rate2.hip).
-PMC_VALU_PER_WAVE = {"k_rollout16": 1072505267.0 / 1024.0 / 50.0, "k_step16": 22040485.5 / 1024.0, "k_step": 8008005.8 / 256.0,
-                     "k_rollout": 8008005.8 / 256.0, "k_rollout_policy16": 1072505267.0 / 1024.0 / 50.0}
+PMC_VALU_PER_WAVE = {"k_rollout16": 1043959219.0 / 1024.0 / 50.0, "k_step16": 20971429.5 / 1024.0, "k_step": 7742245.6 / 256.0,
+                     "k_rollout": 383982080.0 / 256.0 / 50.0, "k_rollout_policy16": 1043959219.0 / 1024.0 / 50.0}
 VALU_PEAK_PER_SIMD_CYCLE = 0.384
 NOMINAL_HZ = 2.4e9
 BYTES_PER_STEP_CFG2 = 816  # 564 B + 252 B per-env ETG w,b
@@ -133,6 +134,8 @@ def main():
                     help="kernel mapping, lanes per robot (0 = library default: 16 up to 4096 robots, else 4)")
     ap.add_argument("--body-contacts", action="store_true", help="knee spheres collide too (16-lane heightfield kernels)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-es-generation", action="store_true",
+                    help="skip the extra ES-generation leg (profiling runs: keeps the per-kernel averages clean)")
     ap.add_argument("--stepwise", action="store_true",
                     help="open-loop configs: time env.step() per control step instead of the fused open-loop rollout")
     args = ap.parse_args()
@@ -250,7 +253,7 @@ def main():
     # same robots -- SimpleGA.ask, batched Opt_with_points on the device, reset, 401 open-loop control steps, the
     # all_gather of the returns (RCCL for N > 1), SimpleGA.tell replicated on every rank (train.py:398-418).
     es_gen = None
-    if args.config != 3 and not args.stepwise:
+    if args.config != 3 and not args.stepwise and not args.no_es_generation:
         try:
             es_gen = es_generation_leg(env, world, rank, dist, barrier)
         except Exception as e:                                   # noqa: BLE001 - an optional leg must not lose the line

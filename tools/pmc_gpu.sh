@@ -6,7 +6,7 @@ OUT=/tmp/pmc_$1
 mkdir -p $OUT $R/gpurun_out
 run() { # name counters...
   name=$1; shift
-  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o pmc -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline $PMC_BENCH_ARGS > $OUT/$name.log 2>&1 || echo "pass $name failed"
+  rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o pmc -- python $R/bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-es-generation $PMC_BENCH_ARGS > $OUT/$name.log 2>&1 || echo "pass $name failed"
 }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
@@ -19,7 +19,7 @@ for name in ("fetch","write","valu","lds"):
     if not fs: print(name, "no output"); continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
-        m = re.search(r"etg::(k_step16|k_rollout16|k_step)<", r["Kernel_Name"])   # 16- / 4-lanes-per-robot step kernels
+        m = re.search(r"etg::(k_step16|k_rollout16|k_rollout_policy16|k_step|k_rollout)<", r["Kernel_Name"])   # 16- / 4-lanes-per-robot step kernels
         if m:
             acc[(m.group(1), r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (kern, k), v in sorted(acc.items()):
