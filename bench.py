@@ -182,6 +182,9 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    if dist is not None:   # warm the one collective of the path too (first-use setup of RCCL's all_gather is not the metric)
+        warm = torch.empty(world * N, device=dev)
+        dist.all_gather_into_tensor(warm, env.episode_stats()[0])
     # per-launch duration of the dynamics kernel: HIP event pairs on the launch stream inside the timed region,
     # one pair per EVENT_EVERY launches, spanning EVENT_SPAN back-to-back launches of the step kernel (1 when the
     # policy kernel runs in between).  A pair around EVERY launch costs ~7 us of stream time per step -- 13 % of
