@@ -126,8 +126,6 @@ ETG_HD float sel_(bool c, float a, float b) { return c ? a : b; }
 ETG_HD float fminf_(float a, float b) { return fminf(a, b); }
 ETG_HD float fmaxf_(float a, float b) { return fmaxf(a, b); }
 ETG_HD float fabsf_(float a) { return fabsf(a); }
-ETG_HD float cos_(float a) { return cosf(a); }
-ETG_HD float tanh_(float a) { return tanhf(a); }
 ETG_HD float acos_(float a) { return acosf(a); }
 ETG_HD float asin_(float a) { return asinf(a); }
 ETG_HD float atan2_(float a, float b) { return atan2f(a, b); }
@@ -163,10 +161,15 @@ ETG_HD void sincos_(float x, float& s, float& c) {
 // ETG phase sine (|argument| < 1e3: phase + 2 pi t / T over an episode) and the RBF / reward exponentials: the
 // bounded-range routine above and the hardware exp2 (1 ulp) instead of libm's full-range versions
 ETG_HD float sin_(float a) { float s, c; sincos_(a, s, c); return s; }
+ETG_HD float cos_(float a) { float s, c; sincos_(a, s, c); return c; }   // IK angles, within +-pi
 ETG_HD float exp_(float a) { return __builtin_amdgcn_exp2f(a * 1.44269504088896341f); }
+// tanh(a) = 1 - 2 / (e^{2a} + 1); the reward terms call it with a >= 0 (c_prec: a = x^2); |error| < 2e-7
+ETG_HD float tanh_(float a) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(__builtin_amdgcn_exp2f(fminf(a, 40.0f) * 2.88539008177792681f) + 1.0f); }
 #else
 ETG_HD float sin_(float a) { return sinf(a); }
+ETG_HD float cos_(float a) { return cosf(a); }
 ETG_HD float exp_(float a) { return expf(a); }
+ETG_HD float tanh_(float a) { return tanhf(a); }
 ETG_HD float rcp_(float a) { return 1.0f / a; }
 ETG_HD float rsqrt_(float a) { return 1.0f / sqrtf(a); }
 ETG_HD float sqrt_(float a) { return sqrtf(a); }
