@@ -89,6 +89,14 @@ def cpu_baseline(n_envs, steps, threads):
     return n_envs * steps / dt
 
 
+def max_over_ranks(seconds, dist, dev):
+    if dist is None:
+        return seconds
+    t = torch.tensor([seconds], dtype=torch.float64, device=dev if dist.get_backend() == "nccl" else "cpu")
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())
+
+
 def es_generation_leg(env, world, rank, dist, barrier, max_step=400):
     """two warm-up and three timed ES generations (mean) over the population of world x N candidates (candidate i = robot i)."""
     from paddlerobotics_amd import rollout as R
@@ -109,10 +117,7 @@ def es_generation_leg(env, world, rank, dist, barrier, max_step=400):
         fit = R.es_generation(solver, evaluate, dist, rank, world)
     barrier()
     dt = (time.perf_counter() - t0) / GENS
-    if dist is not None:
-        t = torch.tensor([dt], device=env.device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+    dt = max_over_ranks(dt, dist, env.device)
     return {"value": world * N * (max_step + 1) / dt, "unit": "env-steps/s", "ms": dt * 1e3, "population": world * N,
             "control_steps": max_step + 1, "fitness_mean": float(fit.mean().item()),
             "includes": "SimpleGA.ask, etg_fit_etg (batched Opt_with_points), reset, fused open-loop rollout, "
@@ -146,16 +151,25 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the simulator has no CPU path")
+    # ETG_BENCH_BACKEND=gloo is a dry-run aid (control flow of the N > 1 path on a box with fewer GPUs than ranks: ranks
+    # share devices, collectives are staged through the host); the measured configuration is always RCCL, one GPU per rank
+    backend = os.environ.get("ETG_BENCH_BACKEND", "nccl")
+    if backend == "gloo":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if backend == "gloo":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from paddlerobotics_amd.env import make_env
     from paddlerobotics_amd.policy import MfmaPolicy
+    from paddlerobotics_amd import rollout as R
     N = args.num_envs
     terrain_kw = {}
     if args.config == 5:   # BASELINE config 5: 256x256 grid, 0.05 m cells, heights U(0, 0.05) m from default_rng(0)
@@ -183,8 +197,7 @@ def main():
     for _ in range(args.warmup):
         one_step()
     if dist is not None:   # warm the one collective of the path too (first-use setup of RCCL's all_gather is not the metric)
-        warm = torch.empty(world * N, device=dev)
-        dist.all_gather_into_tensor(warm, env.episode_stats()[0])
+        R.gather_returns(env.episode_stats()[0], dist)
     # per-launch duration of the dynamics kernel: HIP event pairs on the launch stream inside the timed region,
     # one pair per EVENT_EVERY launches, spanning EVENT_SPAN back-to-back launches of the step kernel (1 when the
     # policy kernel runs in between).  A pair around EVERY launch costs ~7 us of stream time per step -- 13 % of
@@ -231,14 +244,9 @@ def main():
     # of model/Dynamic_parallel_model.py:157-160) -- is part of the timed region
     ret, length = env.episode_stats()
     if dist is not None:
-        allret = torch.empty(world * N, device=dev)
-        dist.all_gather_into_tensor(allret, ret)
+        allret = R.gather_returns(ret, dist)
     barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = max_over_ranks(time.perf_counter() - t0, dist, dev)
     kern_ms = float(np.mean([a.elapsed_time(b_) for a, b_ in ev])) / EVENT_SPAN if ev else float("nan")
     survivors = float((length == args.steps + args.warmup).float().mean().item())
     stepwise = None

@@ -47,6 +47,10 @@ def gather_returns(local_returns, dist=None):
     """The one exchange of the path: all ranks end up with the full [world*N] return vector."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
         return local_returns
+    if dist.get_backend() == "gloo" and local_returns.is_cuda:   # gloo has no device all_gather: stage through the host
+        out = torch.empty(local_returns.numel() * dist.get_world_size(), dtype=local_returns.dtype)
+        dist.all_gather_into_tensor(out, local_returns.detach().cpu().contiguous())
+        return out.to(local_returns.device)
     out = torch.empty(local_returns.numel() * dist.get_world_size(), dtype=local_returns.dtype,
                       device=local_returns.device)
     dist.all_gather_into_tensor(out, local_returns.contiguous())
