@@ -10,6 +10,8 @@
 // possible (v_add_f32_dpp by the compiler, v_fmac_f32_dpp by inline asm); the 4-lane contact operator's 4x4
 // blocks are v_mfma_f32_4x4x1.  LDS holds each lane's private per-step parameter column (no barriers anywhere);
 // the per-tick constants go straight from HBM to registers.  A reset restores the cached 500-tick settle.
+// Every step / rollout / reset kernel has compile-time variants picked per launch (LAUNCH16 / LAUNCH4): flat ground
+// vs heightfield, knee contact rows, and PLAIN (the default robot layer with its unused options compiled out).
 #include <hip/hip_runtime.h>
 
 #include <string>
