@@ -969,3 +969,26 @@ def test_knee_contacts_match_oracle():
     # (3) the 4-lane mapping has no lane for the knee rows
     with pytest.raises(Exception):
         _make(n, body_contacts=True, lanes_per_robot=4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_plain_and_full_kernel_variants_agree(lanes):
+    """The PLAIN instantiations (robot-layer options compiled out) against the full ones on the same workload: a zero
+    external force switches the library to the full kernels without changing the physics."""
+    _need_gpu()
+    n = 64
+    W, B = _etg_params(n, seed=23)
+    for kw in ({}, {"task": "stairstair", "terrain_variants": 4}):
+        a, b = _make(n, lanes_per_robot=lanes, **kw), _make(n, lanes_per_robot=lanes, **kw)
+        b.set_external_force(torch.zeros(n, 3, device="cuda:0"))          # K.ext_force = 1 -> not plain_config
+        a.reset(ETG_w=W, ETG_b=B); b.reset(ETG_w=W, ETG_b=B)
+        assert (a.get_state() - b.get_state()).abs().max() < 1e-4            # the settle ran in both variants too
+        for _ in range(8):
+            a.step(None); b.step(None)
+        sa, sb = a.get_state().cpu().numpy(), b.get_state().cpu().numpy()
+        assert np.median(np.abs(sa - sb)[:, 13:25].max(1)) < 1e-3 and np.abs(sa - sb)[:, :3].max() < 1e-2
+        assert (a.obs - b.obs).abs().median() < 1e-4
+        a.rollout_openloop(5); b.rollout_openloop(5)
+        assert np.median(np.abs(a.get_state().cpu().numpy() - b.get_state().cpu().numpy())[:, 13:25].max(1)) < 5e-3
+        a.close(); b.close()
