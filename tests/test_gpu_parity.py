@@ -2,6 +2,8 @@
 the golden fixtures.  Tolerances: ETG+IK+PD <= 1e-6..2e-5 abs in fp32; dynamics vs
 the fp64 oracle over short horizons: joint angles <= 1e-3 rad, base pose <= 1e-3 m,
 reward <= 1e-3 relative (+ abs floor); MLP fp32 <= 1e-5, bf16 <= 5e-2."""
+import os
+
 import numpy as np
 import pytest
 
@@ -992,3 +994,17 @@ def test_plain_and_full_kernel_variants_agree(lanes):
         a.rollout_openloop(5); b.rollout_openloop(5)
         assert np.median(np.abs(a.get_state().cpu().numpy() - b.get_state().cpu().numpy())[:, 13:25].max(1)) < 5e-3
         a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_examples_run(tmp_path):
+    """the three example scripts end to end (small sizes), from a scratch working directory"""
+    _need_gpu()
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for script, args in (("es_pretrain.py", ["--popsize", "256", "--generations", "2", "--max-step", "60"]),
+                         ("export_gait.py", []), ("evaluate_policy.py", [])):
+        r = subprocess.run([sys.executable, os.path.join(root, "examples", script)] + args, cwd=tmp_path,
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, (script, r.stderr[-600:])
+    assert (tmp_path / "es_pretrain_result.npz").exists()
