@@ -29,20 +29,20 @@ from paddlerobotics_amd.etg_fit import opt_with_points_batched  # noqa: E402
 
 SOLVER_ITERS = 2           # library default (K=2 vs K=50 differ by <0.4 mm after 5 m)
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
-# PMC figures per CONTROL STEP at N = 4096 (profiles/r01_pmc_16lane_kernels.txt, r01_pmc_4lane_kernels.txt; separate
+# PMC figures per CONTROL STEP at N = 4096 (profiles/r01_pmc_16lane_kernels.txt, r01_pmc_4lane_kernels.txt, r01_pmc_cfg3_kernels.txt; separate
 # passes, FETCH_SIZE / WRITE_SIZE in KB).  Calibrated for this code's access width -- one dword per lane, coalesced
 # SoA -- with tools/ubench/pmc_calib.hip (a 512 MiB copy): FETCH_SIZE reports exactly 1/2 of the bytes read (as the
 # micro-arch guide found for wide reads), WRITE_SIZE is exact; hence the factor 2 on the fetch term.  k_rollout16
 # runs 50 control steps per launch, so its launch totals are divided by 50.  Scaled linearly with N.
 PMC_TRAFFIC_BYTES_AT_4096 = {"k_rollout16": (2 * 17534.0 + 30192.0) * 1024.0 / 50.0, "k_step16": (2 * 3851.0 + 3076.0) * 1024.0,
                              "k_step": (2 * 3895.0 + 3076.0) * 1024.0, "k_rollout": (2 * 17559.8 + 30192.0) * 1024.0 / 50.0,
-                             "k_rollout_policy16": None}
+                             "k_rollout_policy16": (2 * 19356.0 + 30192.0) * 1024.0 / 50.0}
 # VALU instructions one wave issues per control step (SQ_INSTS_VALU / SQ_WAVES, same files) and the VALU issue
 # capacity of a SIMD measured with tools/ubench/occupancy_rate.hip (8 resident waves of v_fma_f32: 0.384
 # wave-instructions per SIMD-cycle at the nominal 2.4 GHz; a lone wave issues one VALU instruction per 4.9-5.4
 # cycles, i.e. about 0.2 -- issue_rate2.hip).
 PMC_VALU_PER_WAVE = {"k_rollout16": 1043959219.0 / 1024.0 / 50.0, "k_step16": 20971429.5 / 1024.0, "k_step": 7742245.6 / 256.0,
-                     "k_rollout": 383982080.0 / 256.0 / 50.0, "k_rollout_policy16": 1043959219.0 / 1024.0 / 50.0}
+                     "k_rollout": 383982080.0 / 256.0 / 50.0, "k_rollout_policy16": 1076485290.0 / 1024.0 / 50.0}
 VALU_PEAK_PER_SIMD_CYCLE = 0.384
 NOMINAL_HZ = 2.4e9
 BYTES_PER_STEP_CFG2 = 816  # 564 B + 252 B per-env ETG w,b
