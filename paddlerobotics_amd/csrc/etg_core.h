@@ -50,6 +50,54 @@ template <class F> ETG_HD F comp(const SV<F>& p, int i) {  // compile-time i aft
 template <class F> ETG_HD SV<F> crm(SV<F> v, SV<F> m) { return {cross(v.a, m.a), cross(v.a, m.l) + cross(v.l, m.a)}; }
 template <class F> ETG_HD SV<F> crf(SV<F> v, SV<F> f) { return {cross(v.a, f.a) + cross(v.l, f.l), cross(v.a, f.l)}; }
 
+#if defined(__HIPCC__)
+// ---- packed fp32 forms of the spatial-vector algebra (gfx950 v_pk_{mul,add,fma}_f32: two lanes' worth of FMA per
+// issue slot).  Every SV is treated as three (angular_k, linear_k) pairs -- ONE pairing everywhere, so the register
+// allocator can keep each pair in an aligned register pair without copies; scalar factors are broadcast by the
+// instruction's op_sel bits (tools/ubench/pk_codegen.hip).  Plain overloads for float: call sites are unchanged and
+// the test emulator (F = lane struct) keeps using the scalar templates above; results differ by rounding only.
+typedef float pk2 __attribute__((ext_vector_type(2)));
+ETG_HD pk2 pk_(float a, float b) { pk2 r = {a, b}; return r; }
+ETG_HD pk2 pkfma_(pk2 a, pk2 b, pk2 c) { return __builtin_elementwise_fma(a, b, c); }
+ETG_HD SV<float> unpk_(pk2 x, pk2 y, pk2 z) { return {{x.x, y.x, z.x}, {x.y, y.y, z.y}}; }
+ETG_HD SV<float> operator+(SV<float> p, SV<float> q) {
+  return unpk_(pk_(p.a.x, p.l.x) + pk_(q.a.x, q.l.x), pk_(p.a.y, p.l.y) + pk_(q.a.y, q.l.y), pk_(p.a.z, p.l.z) + pk_(q.a.z, q.l.z));
+}
+ETG_HD SV<float> operator-(SV<float> p, SV<float> q) {
+  return unpk_(pk_(p.a.x, p.l.x) - pk_(q.a.x, q.l.x), pk_(p.a.y, p.l.y) - pk_(q.a.y, q.l.y), pk_(p.a.z, p.l.z) - pk_(q.a.z, q.l.z));
+}
+ETG_HD SV<float> operator*(float s, SV<float> p) {
+  const pk2 ss = pk_(s, s);
+  return unpk_(ss * pk_(p.a.x, p.l.x), ss * pk_(p.a.y, p.l.y), ss * pk_(p.a.z, p.l.z));
+}
+ETG_HD float dot(SV<float> p, SV<float> q) {
+  pk2 d = pk_(p.a.x, p.l.x) * pk_(q.a.x, q.l.x);
+  d = pkfma_(pk_(p.a.y, p.l.y), pk_(q.a.y, q.l.y), d);
+  d = pkfma_(pk_(p.a.z, p.l.z), pk_(q.a.z, q.l.z), d);
+  return d.x + d.y;
+}
+// (v.a x m.a, v.a x m.l + v.l x m.a): the v.a x (m.a | m.l) part is packed, v.l x m.a lands on the linear halves
+ETG_HD SV<float> crm(SV<float> v, SV<float> m) {
+  const pk2 mx = pk_(m.a.x, m.l.x), my = pk_(m.a.y, m.l.y), mz = pk_(m.a.z, m.l.z);
+  const pk2 vx = pk_(v.a.x, v.a.x), vy = pk_(v.a.y, v.a.y), vz = pk_(v.a.z, v.a.z);
+  pk2 rx = pkfma_(vy, mz, -(vz * my)), ry = pkfma_(vz, mx, -(vx * mz)), rz = pkfma_(vx, my, -(vy * mx));
+  rx.y += v.l.y * m.a.z - v.l.z * m.a.y;
+  ry.y += v.l.z * m.a.x - v.l.x * m.a.z;
+  rz.y += v.l.x * m.a.y - v.l.y * m.a.x;
+  return unpk_(rx, ry, rz);
+}
+// (v.a x f.a + v.l x f.l, v.a x f.l): v.l x f.l lands on the angular halves
+ETG_HD SV<float> crf(SV<float> v, SV<float> f) {
+  const pk2 fx = pk_(f.a.x, f.l.x), fy = pk_(f.a.y, f.l.y), fz = pk_(f.a.z, f.l.z);
+  const pk2 vx = pk_(v.a.x, v.a.x), vy = pk_(v.a.y, v.a.y), vz = pk_(v.a.z, v.a.z);
+  pk2 rx = pkfma_(vy, fz, -(vz * fy)), ry = pkfma_(vz, fx, -(vx * fz)), rz = pkfma_(vx, fy, -(vy * fx));
+  rx.x += v.l.y * f.l.z - v.l.z * f.l.y;
+  ry.x += v.l.z * f.l.x - v.l.x * f.l.z;
+  rz.x += v.l.x * f.l.y - v.l.y * f.l.x;
+  return unpk_(rx, ry, rz);
+}
+#endif
+
 // rigid-body inertia about the base origin, in base axes
 template <class F> struct RBI { F m; V3<F> h; S3<F> I; };
 template <class F> ETG_HD RBI<F> operator+(RBI<F> a, RBI<F> b) {

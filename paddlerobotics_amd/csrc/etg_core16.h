@@ -194,14 +194,26 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
 #pragma unroll
   for (int i = 0; i < 6; i++)
 #pragma unroll
-    for (int j = 0; j <= i; j++) s[i * (i + 1) / 2 + j] = c.sum16(lm[i * (i + 1) / 2 + j] - comp(P, i) * comp(Fs, j));
+    for (int j = 0; j <= i; j++) s[i * (i + 1) / 2 + j] = lm[i * (i + 1) / 2 + j] - comp(P, i) * comp(Fs, j);
+  // Same arithmetic either way (per-entry butterflies).  On flat ground the scheduler interleaves the 21 chains by
+  // itself and shaves 16 instructions off the explicit form; in the heightfield kernels (more registers live) it
+  // serialises them -- 4 dependent DPP adds with an s_nop 1 between each -- unless they are written stage by stage.
+  if (Ctx::kFlat) {
+#pragma unroll
+    for (int i = 0; i < 21; i++) s[i] = c.sum16(s[i]);
+  } else {
+    c.sum16xn(s, 21);
+  }
   s[0] = s[0] + I0s.xx;
   s[1] = s[1] + I0s.xy; s[2] = s[2] + I0s.yy;
   s[3] = s[3] + I0s.xz; s[4] = s[4] + I0s.yz; s[5] = s[5] + I0s.zz;
   s[9] = s[9] + m0; s[14] = s[14] + m0; s[20] = s[20] + m0;
   F rb[6];
 #pragma unroll
-  for (int i = 0; i < 6; i++) rb[i] = -comp(fb0, i) - c.sum16(comp(f, i) + rl * comp(P, i));
+  for (int i = 0; i < 6; i++) rb[i] = comp(f, i) + rl * comp(P, i);
+  c.sum16x6(rb);
+#pragma unroll
+  for (int i = 0; i < 6; i++) rb[i] = -comp(fb0, i) - rb[i];
   if (!Ctx::kPlain && K.ext_force) {  // external force on the trunk COM (world frame) -> base frame: R^T f
     rb[3] = rb[3] + Rw.r0.x * tp.fext.x + Rw.r1.x * tp.fext.y + Rw.r2.x * tp.fext.z;
     rb[4] = rb[4] + Rw.r0.y * tp.fext.x + Rw.r1.y * tp.fext.y + Rw.r2.y * tp.fext.z;

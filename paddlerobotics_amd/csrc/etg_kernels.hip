@@ -323,6 +323,16 @@ struct GpuCtx16 {
   // ---- row (= robot) exchanges: xor1, xor2, row_half_mirror, row_mirror -- order-symmetric, so the
   // result is bit-identical on the 16 lanes
   // six row sums advanced stage by stage: every DPP reads a value written six instructions earlier
+  __device__ __forceinline__ void sum16xn(float* v, int n) const {   // n is a compile-time constant at the call sites
+#pragma unroll
+    for (int k = 0; k < n; k++) v[k] = v[k] + dpp_<0xB1>(v[k]);
+#pragma unroll
+    for (int k = 0; k < n; k++) v[k] = v[k] + dpp_<0x4E>(v[k]);
+#pragma unroll
+    for (int k = 0; k < n; k++) v[k] = v[k] + dpp_<0x141>(v[k]);
+#pragma unroll
+    for (int k = 0; k < n; k++) v[k] = v[k] + dpp_<0x140>(v[k]);
+  }
   __device__ __forceinline__ void sum16x6(float* v) const {
 #pragma unroll
     for (int k = 0; k < 6; k++) v[k] = v[k] + dpp_<0xB1>(v[k]);

@@ -103,6 +103,7 @@ struct EmuCtx16Base {
   void dpp_ready(F16*, int) const {}
   void dpp_ready10(F16*, F16*, F16*) const {}
   void sum16x6(F16* v) const { for (int k = 0; k < 6; k++) v[k] = sum16(v[k]); }
+  void sum16xn(F16* v, int n) const { for (int k = 0; k < n; k++) v[k] = sum16(v[k]); }
   void fmac_rbcast12(F16& acc, F16 x, const F16* a) const { for (int i = 0; i < 12; i++) fmac_rbcast(acc, x, a[i], 4 * (i / 3) + i % 3); }
   F16 legrot(F16 x, int kk) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = x.v[(r + 4 * kk) & 15]; return o; }
   void quad_outer(F16 a, F16 b, F16* acc) const {
