@@ -43,6 +43,9 @@ template <class F> ETG_HD SV<F> operator+(SV<F> p, SV<F> q) { return {p.a + q.a,
 template <class F> ETG_HD SV<F> operator-(SV<F> p, SV<F> q) { return {p.a - q.a, p.l - q.l}; }
 template <class F> ETG_HD SV<F> operator*(F s, SV<F> p) { return {s * p.a, s * p.l}; }
 template <class F> ETG_HD F dot(SV<F> p, SV<F> q) { return dot(p.a, q.a) + dot(p.l, q.l); }
+template <class F> ETG_HD SV<F> cmul(SV<F> p, SV<F> q) {  // component-wise product
+  return {{p.a.x * q.a.x, p.a.y * q.a.y, p.a.z * q.a.z}, {p.l.x * q.l.x, p.l.y * q.l.y, p.l.z * q.l.z}};
+}
 template <class F> ETG_HD F comp(const SV<F>& p, int i) {  // compile-time i after unrolling
   return i == 0 ? p.a.x : i == 1 ? p.a.y : i == 2 ? p.a.z : i == 3 ? p.l.x : i == 4 ? p.l.y : p.l.z;
 }
@@ -69,6 +72,9 @@ ETG_HD SV<float> operator-(SV<float> p, SV<float> q) {
 ETG_HD SV<float> operator*(float s, SV<float> p) {
   const pk2 ss = pk_(s, s);
   return unpk_(ss * pk_(p.a.x, p.l.x), ss * pk_(p.a.y, p.l.y), ss * pk_(p.a.z, p.l.z));
+}
+ETG_HD SV<float> cmul(SV<float> p, SV<float> q) {
+  return unpk_(pk_(p.a.x, p.l.x) * pk_(q.a.x, q.l.x), pk_(p.a.y, p.l.y) * pk_(q.a.y, q.l.y), pk_(p.a.z, p.l.z) * pk_(q.a.z, q.l.z));
 }
 ETG_HD float dot(SV<float> p, SV<float> q) {
   pk2 d = pk_(p.a.x, p.l.x) * pk_(q.a.x, q.l.x);
@@ -363,9 +369,13 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   }
   F dinv[6], sq[6];
   ldl6(s, dinv, sq);
+  const W sqv = {{sq[0], sq[1], sq[2]}, {sq[3], sq[4], sq[5]}};
   fwd6(s, rb);
+  {
+    const W rbd = cmul(W{{rb[0], rb[1], rb[2]}, {rb[3], rb[4], rb[5]}}, W{{dinv[0], dinv[1], dinv[2]}, {dinv[3], dinv[4], dinv[5]}});
 #pragma unroll
-  for (int i = 0; i < 6; i++) rb[i] = rb[i] * dinv[i];
+    for (int i = 0; i < 6; i++) rb[i] = comp(rbd, i);
+  }
   bwd6(s, rb);
   W ab = {{rb[0], rb[1], rb[2]}, {rb[3], rb[4], rb[5]}};
   F qdd1 = Hi11 * rl1 + Hi12 * rl2 + Hi13 * rl3 - dot(P1, ab);
@@ -423,7 +433,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
     W G = Jb - (Jl[d][0] * P1 + Jl[d][1] * P2 + Jl[d][2] * P3);
     F g6[6] = {G.a.x, G.a.y, G.a.z, G.l.x, G.l.y, G.l.z};
     fwd6(s, g6);
-    Z[d] = {{g6[0] * sq[0], g6[1] * sq[1], g6[2] * sq[2]}, {g6[3] * sq[3], g6[4] * sq[4], g6[5] * sq[5]}};
+    Z[d] = cmul(W{{g6[0], g6[1], g6[2]}, {g6[3], g6[4], g6[5]}}, sqv);   // packed on the GPU
   }
   c.phase(5);
   // Delassus blocks A[j][d][e] = Z_mine,d . Z_j,e (+ local leg compliance on the own block).
@@ -500,8 +510,8 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   c.phase(8);
   // ---- apply impulses: base via the Schur factor, leg via H^-1
   W zs = l0 * Z[0] + l1 * Z[1] + l2 * Z[2];
-  F db[6] = {c.qsum(zs.a.x) * sq[0], c.qsum(zs.a.y) * sq[1], c.qsum(zs.a.z) * sq[2],
-             c.qsum(zs.l.x) * sq[3], c.qsum(zs.l.y) * sq[4], c.qsum(zs.l.z) * sq[5]};
+  const W dbs = cmul(W{{c.qsum(zs.a.x), c.qsum(zs.a.y), c.qsum(zs.a.z)}, {c.qsum(zs.l.x), c.qsum(zs.l.y), c.qsum(zs.l.z)}}, sqv);
+  F db[6] = {dbs.a.x, dbs.a.y, dbs.a.z, dbs.l.x, dbs.l.y, dbs.l.z};
   bwd6(s, db);
   W dB = {{db[0], db[1], db[2]}, {db[3], db[4], db[5]}};
   L.wb = wbs + dB.a;

@@ -222,8 +222,11 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   F dinv[6], sq[6];
   ldl6(s, dinv, sq);
   fwd6(s, rb);
+  {
+    const W rbd = cmul(W{{rb[0], rb[1], rb[2]}, {rb[3], rb[4], rb[5]}}, W{{dinv[0], dinv[1], dinv[2]}, {dinv[3], dinv[4], dinv[5]}});
 #pragma unroll
-  for (int i = 0; i < 6; i++) rb[i] = rb[i] * dinv[i];
+    for (int i = 0; i < 6; i++) rb[i] = comp(rbd, i);
+  }
   bwd6(s, rb);
   W ab = {{rb[0], rb[1], rb[2]}, {rb[3], rb[4], rb[5]}};
   F qdd = -dot(P, ab);                                 // + row `sub` of H^-1 times (tau - C) of the leg
@@ -283,9 +286,9 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   W G = Jb - (HJ0 * Fj[0] + HJ1 * Fj[1] + HJ2 * Fj[2]);        // J_b^T - Fm H^-1 J_l^T
   F g6[6] = {G.a.x, G.a.y, G.a.z, G.l.x, G.l.y, G.l.z};
   fwd6(s, g6);
-  F Z[6];
-#pragma unroll
-  for (int k = 0; k < 6; k++) Z[k] = g6[k] * sq[k];
+  const W sqv = {{sq[0], sq[1], sq[2]}, {sq[3], sq[4], sq[5]}};
+  const W Zv = cmul(W{{g6[0], g6[1], g6[2]}, {g6[3], g6[4], g6[5]}}, sqv);
+  F Z[6] = {Zv.a.x, Zv.a.y, Zv.a.z, Zv.l.x, Zv.l.y, Zv.l.z};
   c.phase(5);
   // ---- Delassus row of this lane: A[l'][e] = Z_own . Z_(l',e) over the 6 base coordinates, every term one
   // fused broadcast-FMA (v_fmac_f32_dpp row_newbcast); rows of the own leg add the leg compliance
@@ -335,8 +338,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
     for (int lp = 0; lp < 4; lp++) Ak[lp] = Ak[lp] + ownl[lp] * own;
   }
   F Add = hj[0] * Jl0 + hj[1] * Jl1 + hj[2] * Jl2;              // own diagonal
-#pragma unroll
-  for (int k = 0; k < 6; k++) Add = Add + Z[k] * Z[k];
+  Add = Add + dot(W{{Z[0], Z[1], Z[2]}, {Z[3], Z[4], Z[5]}}, W{{Z[0], Z[1], Z[2]}, {Z[3], Z[4], Z[5]}});
   const F iA = sel_(rowf > F(0.5f), rcp_(Add), zero);
   c.phase(6);
   // ---- row velocity under the unconstrained motion, warm start
@@ -397,10 +399,13 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   // ---- apply impulses: base via the Schur factor, joints via H^-1
   F db[6];
 #pragma unroll
-  for (int k = 0; k < 6; k++) db[k] = lam * Z[k];
+  for (int k = 0; k < 6; k++) db[k] = comp(lam * W{{Z[0], Z[1], Z[2]}, {Z[3], Z[4], Z[5]}}, k);
   c.sum16x6(db);                                                // the six reductions stage by stage (no DPP wait states)
+  {
+    const W dbs = cmul(W{{db[0], db[1], db[2]}, {db[3], db[4], db[5]}}, sqv);
 #pragma unroll
-  for (int k = 0; k < 6; k++) db[k] = db[k] * sq[k];
+    for (int k = 0; k < 6; k++) db[k] = comp(dbs, k);
+  }
   bwd6(s, db);
   W dB = {{db[0], db[1], db[2]}, {db[3], db[4], db[5]}};
   L.wb = wbs + dB.a;
