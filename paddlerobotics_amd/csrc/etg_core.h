@@ -139,6 +139,46 @@ template <class F> ETG_HD RBI<F> link_inertia(F m, V3<F> com, S3<F> Ic, const Fr
   return {m, m * c, I};
 }
 
+// link_inertia16: what the 16-lane tick calls (one link per lane).  Generic F: the scalar routine above.
+template <class F> ETG_HD RBI<F> link_inertia16(F m, V3<F> com, S3<F> Ic, const Fr<F>& R, V3<F> o) { return link_inertia(m, com, Ic, R, o); }
+#if defined(__HIPCC__)
+// float: the 3-vector chains inside work on packed (x, y) pairs + z; inputs and outputs are scalars, so the pairing
+// stays local to this function (a global (x, y) pairing of all V3 algebra costs more register copies than it saves,
+// and so does this routine in the 4-lane tick, where one lane carries three links: 50 -> 89 AGPR spill moves)
+ETG_HD RBI<float> link_inertia16(float m, V3<float> com, S3<float> Ic, const Fr<float>& R, V3<float> o) {
+  const pk2 ex = pk_(R.ex.x, R.ex.y), ey = pk_(R.ey.x, R.ey.y), ez = pk_(R.ez.x, R.ez.y);
+  // c = o + R com
+  pk2 cxy = pkfma_(pk_(com.x, com.x), ex, pk_(o.x, o.y));
+  cxy = pkfma_(pk_(com.y, com.y), ey, cxy);
+  cxy = pkfma_(pk_(com.z, com.z), ez, cxy);
+  const float cz = o.z + com.x * R.ex.z + com.y * R.ey.z + com.z * R.ez.z;
+  // t_k = Ic row k in base axes: (xy pair, z)
+  pk2 txy = pkfma_(pk_(Ic.xz, Ic.xz), ez, pkfma_(pk_(Ic.xy, Ic.xy), ey, pk_(Ic.xx, Ic.xx) * ex));
+  pk2 tyy = pkfma_(pk_(Ic.yz, Ic.yz), ez, pkfma_(pk_(Ic.yy, Ic.yy), ey, pk_(Ic.xy, Ic.xy) * ex));
+  pk2 tzy = pkfma_(pk_(Ic.zz, Ic.zz), ez, pkfma_(pk_(Ic.yz, Ic.yz), ey, pk_(Ic.xz, Ic.xz) * ex));
+  const float txz = Ic.xx * R.ex.z + Ic.xy * R.ey.z + Ic.xz * R.ez.z;
+  const float tyz = Ic.xy * R.ex.z + Ic.yy * R.ey.z + Ic.yz * R.ez.z;
+  const float tzz = Ic.xz * R.ex.z + Ic.yz * R.ey.z + Ic.zz * R.ez.z;
+  // rows of R Ic R^T: row x -> (xx, xy), xz; row y -> (yx, yy), yz; zz
+  const pk2 rx = pkfma_(pk_(R.ez.x, R.ez.x), tzy, pkfma_(pk_(R.ey.x, R.ey.x), tyy, pk_(R.ex.x, R.ex.x) * txy));
+  const pk2 ry = pkfma_(pk_(R.ez.y, R.ez.y), tzy, pkfma_(pk_(R.ey.y, R.ey.y), tyy, pk_(R.ex.y, R.ex.y) * txy));
+  S3<float> I;
+  I.xx = rx.x; I.xy = rx.y; I.yy = ry.y;
+  I.xz = R.ex.x * txz + R.ey.x * tyz + R.ez.x * tzz;
+  I.yz = R.ex.y * txz + R.ey.y * tyz + R.ez.y * tzz;
+  I.zz = R.ex.z * txz + R.ey.z * tyz + R.ez.z * tzz;
+  const float cx = cxy.x, cy = cxy.y;
+  I.xx = I.xx + m * (cy * cy + cz * cz);
+  I.yy = I.yy + m * (cx * cx + cz * cz);
+  I.zz = I.zz + m * (cx * cx + cy * cy);
+  I.xy = I.xy - m * cx * cy;
+  I.xz = I.xz - m * cx * cz;
+  I.yz = I.yz - m * cy * cz;
+  const pk2 hxy = pk_(m, m) * cxy;
+  return {m, {hxy.x, hxy.y, m * cz}, I};
+}
+#endif
+
 // ------------------------------------------------------------------ per-lane parameters / state
 // Per-lane parameters are NOT held in registers: the context serves them from a
 // lane-private LDS column (GPU) / the par array (emulator) at the point of use:
@@ -429,7 +469,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
     HJ[d][0] = Hi11 * Jl[d][0] + Hi12 * Jl[d][1] + Hi13 * Jl[d][2];
     HJ[d][1] = Hi12 * Jl[d][0] + Hi22 * Jl[d][1] + Hi23 * Jl[d][2];
     HJ[d][2] = Hi13 * Jl[d][0] + Hi23 * Jl[d][1] + Hi33 * Jl[d][2];
-    W Jb = {actf * cross(rc, dir[d]), actf * dir[d]};
+    W Jb = actf * W{cross(rc, dir[d]), dir[d]};
     W G = Jb - (Jl[d][0] * P1 + Jl[d][1] * P2 + Jl[d][2] * P3);
     F g6[6] = {G.a.x, G.a.y, G.a.z, G.l.x, G.l.y, G.l.z};
     fwd6(s, g6);

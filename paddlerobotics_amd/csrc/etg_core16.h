@@ -137,7 +137,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
           sel_(s0, g.o1.z, sel_(s1, g.o2.z, g.o3.z))};
   V zs = {f0, m1 * g.ca, m1 * g.sa};          // joint axis: x for the hip, y' for thigh and calf
   W S = {zs, cross(os, zs)};
-  RBI<F> I = link_inertia(tp.link[0], V{tp.link[1], tp.link[2], tp.link[3]},
+  RBI<F> I = link_inertia16(tp.link[0], V{tp.link[1], tp.link[2], tp.link[3]},
                           S3<F>{tp.link[4], tp.link[5], tp.link[6], tp.link[7], tp.link[8], tp.link[9]}, R, os);
   c.phase(0);
   // ---- RNEA along the chain (prefix scans), bias forces (suffix scan)
@@ -282,7 +282,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   F HJ0 = Hi11 * Jl0 + Hi12 * Jl1 + Hi13 * Jl2;
   F HJ1 = Hi12 * Jl0 + Hi22 * Jl1 + Hi23 * Jl2;
   F HJ2 = Hi13 * Jl0 + Hi23 * Jl1 + Hi33 * Jl2;
-  W Jb = {rowf * cross(rc, dir), rowf * dir};
+  W Jb = rowf * W{cross(rc, dir), dir};
   W G = Jb - (HJ0 * Fj[0] + HJ1 * Fj[1] + HJ2 * Fj[2]);        // J_b^T - Fm H^-1 J_l^T
   F g6[6] = {G.a.x, G.a.y, G.a.z, G.l.x, G.l.y, G.l.z};
   fwd6(s, g6);
