@@ -34,15 +34,15 @@ HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
 # SoA -- with tools/ubench/pmc_calib.hip (a 512 MiB copy): FETCH_SIZE reports exactly 1/2 of the bytes read (as the
 # micro-arch guide found for wide reads), WRITE_SIZE is exact; hence the factor 2 on the fetch term.  k_rollout16
 # runs 50 control steps per launch, so its launch totals are divided by 50.  Scaled linearly with N.
-PMC_TRAFFIC_BYTES_AT_4096 = {"k_rollout16": (2 * 17511.0 + 30192.0) * 1024.0 / 50.0, "k_step16": (2 * 3845.0 + 3076.0) * 1024.0,
-                             "k_step": (2 * 3880.0 + 3076.0) * 1024.0, "k_rollout": (2 * 17545.8 + 30192.0) * 1024.0 / 50.0,
-                             "k_rollout_policy16": (2 * 19352.0 + 30192.0) * 1024.0 / 50.0}
+PMC_TRAFFIC_BYTES_AT_4096 = {"k_rollout16": (2 * 17514.5 + 30193.4) * 1024.0 / 50.0, "k_step16": (2 * 3838.5 + 3076.0) * 1024.0,
+                             "k_step": (2 * 3879.5 + 3076.0) * 1024.0, "k_rollout": (2 * 17543.8 + 30192.0) * 1024.0 / 50.0,
+                             "k_rollout_policy16": (2 * 20892.0 + 33264.0) * 1024.0 / 50.0}
 # VALU instructions one wave issues per control step (SQ_INSTS_VALU / SQ_WAVES, same files) and the VALU issue
 # capacity of a SIMD measured with tools/ubench/occupancy_rate.hip (8 resident waves of v_fma_f32: 0.384
 # wave-instructions per SIMD-cycle at the nominal 2.4 GHz; a lone wave issues one VALU instruction per 4.9-5.4
 # cycles, i.e. about 0.2 -- issue_rate2.hip).
-PMC_VALU_PER_WAVE = {"k_rollout16": 987397120.0 / 1024.0 / 50.0, "k_step16": 20012032.0 / 1024.0, "k_step": 7264256.0 / 256.0,
-                     "k_rollout": 359167232.0 / 256.0 / 50.0, "k_rollout_policy16": 1023562922.0 / 1024.0 / 50.0}
+PMC_VALU_PER_WAVE = {"k_rollout16": 974745600.0 / 1024.0 / 50.0, "k_step16": 19988480.0 / 1024.0, "k_step": 7204352.0 / 256.0,
+                     "k_rollout": 356351744.0 / 256.0 / 50.0, "k_rollout_policy16": 1013550265.0 / 1024.0 / 50.0}
 VALU_PEAK_PER_SIMD_CYCLE = 0.384
 NOMINAL_HZ = 2.4e9
 BYTES_PER_STEP_CFG2 = 816  # 564 B + 252 B per-env ETG w,b
