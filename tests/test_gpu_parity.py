@@ -1008,3 +1008,16 @@ def test_examples_run(tmp_path):
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (script, r.stderr[-600:])
     assert (tmp_path / "es_pretrain_result.npz").exists()
+
+
+@pytest.mark.gpu
+def test_option_matrix_stays_finite():
+    """tools/config_matrix_check.py: every robot-layer option x both lane mappings x flat / stairs, random actions with
+    auto-reset -- observations, rewards and states stay finite (the script exits non-zero otherwise)."""
+    _need_gpu()
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "config_matrix_check.py")], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-500:]
+    assert "all finite" in r.stdout
