@@ -267,5 +267,23 @@ def param2dynamic_rows(params):
     return out
 
 
+def param2dynamic_rows_torch(params):
+    """the same mapping for a [n,48] tensor on any device (random dynamics drawn on the GPU: no host RNG, no upload)"""
+    import torch
+    P = params.clamp(-1, 1).to(torch.float32)
+    dev = P.device
+    kd0 = torch.tensor([1., 2., 2.] * 4, device=dev)
+    out = torch.empty(P.shape[0], 48, device=dev)
+    out[:, 0] = (40 + 10 * P[:, 0]).clamp(0, 80)
+    out[:, 1] = (0.2 + 10 * P[:, 1]).clamp(0, 20)
+    out[:, 2] = (1.5 + P[:, 2]).clamp(0.5, 3)
+    out[:, 3:21] = (1 + P[:, 3:21]).clamp(0.1, 3)
+    out[:, 21:33] = (80 + 40 * P[:, 21:33]).clamp(20, 200)
+    out[:, 33:45] = (kd0 + P[:, 33:45] * kd0).clamp(0, 5)
+    g = torch.tensor([0., 0., -10.], device=dev) + P[:, 45:48] * torch.tensor([2., 2., 10.], device=dev)
+    out[:, 45:48] = torch.maximum(torch.minimum(g, torch.tensor([5., 5., -4.], device=dev)), torch.tensor([-5., -5., -20.], device=dev))
+    return out
+
+
 def default_dynamic_row():
     return dynamic_dict_to_row(param2dynamic_dict(np.zeros(48)))

@@ -211,6 +211,8 @@ class BatchedQuadrupedEnv:
         self.info_buf = torch.zeros(N, A.INFO_DIM, device=dev)
         self._col_idx = None if len(self._cols) == A.OBS_DIM else torch.tensor(self._cols, device=dev)
         self._push_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self._dyn_gen = torch.Generator(device=dev)
+        self._dyn_gen.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
         if observation_noise_stdev is not None:
             self.set_sensor_noise(observation_noise_stdev, seed=seed)
         self._dyn_stage = self._dyn_dev = self._dyn_evt = None
@@ -325,8 +327,9 @@ class BatchedQuadrupedEnv:
         elif self._rand_dyn:
             # random_param['random_dynamics'] (train.py:253): a fresh draw of the 48 dynamic parameters for
             # every robot being reset, param2dynamic_dict(U(-1,1) * scale) (train.py:112-126)
-            rows = A.param2dynamic_rows(self._np_rng.uniform(-1, 1, size=(self.num_envs, A.DYN_DIM)) * self._rand_dyn_scale)
-            self.set_dynamic_param(rows, env_ids)          # masked: only the robots being reset take their row
+            # drawn on the device (torch generator seeded from `seed`): no host RNG pass, no upload per reset
+            p = (torch.rand(self.num_envs, A.DYN_DIM, device=self.device, generator=self._dyn_gen) * 2 - 1) * self._rand_dyn_scale
+            self.set_dynamic_param(A.param2dynamic_rows_torch(p), env_ids)   # masked: only the robots being reset take their row
         m = self._mask(env_ids)
         if x_noise:
             # start-position jitter (train.py:131 `x_noise=args.x_noise`, an int flag there; rlschool's own

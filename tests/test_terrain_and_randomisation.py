@@ -304,3 +304,11 @@ def test_emulation_knee_contacts_match_oracle():
 def test_body_contacts_need_the_heightfield_kernels():
     cfg = A.default_config(4, body_contacts=1)
     assert cfg.body_contacts == 1 and abs(cfg.knee_radius - 0.02) < 1e-12
+
+
+def test_param2dynamic_rows_torch_equals_numpy():
+    import torch
+    p = np.random.default_rng(3).uniform(-1.3, 1.3, size=(64, 48))
+    a = A.param2dynamic_rows(p)
+    b = A.param2dynamic_rows_torch(torch.as_tensor(p)).numpy()
+    assert np.abs(a - b).max() < 1e-5
