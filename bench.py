@@ -201,7 +201,7 @@ def main():
     # per-launch duration of the dynamics kernel: HIP event pairs on the launch stream inside the timed region,
     # one pair per EVENT_EVERY launches, spanning EVENT_SPAN back-to-back launches of the step kernel (1 when the
     # policy kernel runs in between).  A pair around EVERY launch costs ~7 us of stream time per step -- 13 % of
-    # a 50 us step (tools/gap_test.py) -- while un-instrumented launches run gap-free, so per-launch pairs
+    # a 50 us step (tools/launch_gap_probe.py) -- while un-instrumented launches run gap-free, so per-launch pairs
     # would mostly measure the events.
     EVENT_EVERY = 16
     EVENT_SPAN = min(1 if args.config == 3 else 8, max(args.steps, 1))

@@ -63,6 +63,17 @@ extern "C" {
 #define ETG_INFO_ENERGY 61       /* 1 : sum_ticks sum_j |tau_j qd_j| dt            */
 #define ETG_INFO_STEPS 62        /* 1 : control steps since reset                  */
 
+/* optional sensors of train.py:268-271 (sensor_mode ETG_obs / footpose / dynamic_vec / force_vec): columns of the
+ * [N, ETG_EXTRA_DIM] row etg_extra_sensors() writes.  rlschool's own definitions are absent from the reference
+ * tree; these are this library's.                                                        */
+#define ETG_EXTRA_ETG_OBS 0      /* 20: RBF activations r(t) of the ETG layer at the time of the observation */
+#define ETG_EXTRA_FOOTPOSE 20    /* 12: foot positions in the base frame from the OBSERVED motor angles
+                                        (a1.py:113-140 foot_positions_in_base_frame)                         */
+#define ETG_EXTRA_DYNAMIC 32     /* 48: the robot's dynamic_param row mapped back to the [-1,1] box of
+                                        param2dynamic_dict (train.py:112-126)                                 */
+#define ETG_EXTRA_FORCE 80       /* 3 : external force on the trunk, world frame, newtons (set + random push) */
+#define ETG_EXTRA_DIM 84
+
 enum {
   ETG_OK = 0,
   ETG_ERR_BAD_ARG = -1,
@@ -148,6 +159,15 @@ typedef struct EtgConfig {
    * (terrain = 1; a flat heightfield is fine): the free 4th lane of every leg owns the row.               */
   int32_t body_contacts;
   double knee_radius;
+  /* `ETG` kwarg of make_env (train.py:305-309, Dynamic_parallel_model.py:49 runs with ETG=0): 0 switches the
+   * trajectory generator off -- the position command is pose_ori + action, info["ETG_act"] and the ETG
+   * observation columns are zero.  1 (the default of default_config) = pose_ori + ETG(t) + action.       */
+  int32_t enable_etg;
+  /* joint-limit stops (a1.py:186-195 UPPER_BOUND / LOWER_BOUND through the URDF limits Bullet enforces): when
+   * != 0 a joint that has left [joint_lower, joint_upper] and still moves outward is stopped inelastically
+   * (DESIGN.md section 2); 0 = no limits (round-1 model).                                                  */
+  int32_t joint_limits;
+  double joint_lower[3], joint_upper[3];   /* hip, thigh, calf (rad) */
 } EtgConfig;
 
 typedef struct EtgHandle EtgHandle;
@@ -218,6 +238,16 @@ int etg_episode_stats(EtgHandle* h, float* ret, int32_t* len, void* stream);
  * receives the final observation.                                            */
 int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float* ret, int32_t* len,
                          void* stream);
+
+/* ---- kinematics and optional sensors --------------------------------------- */
+/* leg FK + analytic Jacobian of n joint-angle rows q [n,12] (device pointers), through the SAME device routine the
+ * contact kinematics of the physics tick uses (leg_geometry): foot [n,12] = foot_positions_in_base_frame
+ * (a1.py:131-140: hip-frame foot position + HIP_OFFSETS), jac [n,4,3,3] (may be NULL) = analytical_leg_jacobian
+ * (a1.py:143-173), d foot / d (hip, thigh, calf angle) per leg.                                              */
+int etg_leg_kinematics(EtgHandle* h, const float* q, int n, float* foot, float* jac, void* stream);
+/* optional sensors (ETG_EXTRA_* columns) for the observation rows obs [N,49] the last etg_reset / etg_step /
+ * rollout wrote: out [N, ETG_EXTRA_DIM].                                                                     */
+int etg_extra_sensors(EtgHandle* h, const float* obs, float* out, void* stream);
 
 /* ---- state access for parity tests (device pointers, [N,37] f32) --------- */
 int etg_get_state(EtgHandle* h, float* state, void* stream);

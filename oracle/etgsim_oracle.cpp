@@ -708,6 +708,37 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
   }
   for (int l = 0; l < 4; l++) e.contact[l] = active[l] && e.lam[3 * l] > 0;
 
+  // ---- joint-limit stops (EtgConfig.joint_limits; bounds of a1.py:186-195).  This repo's model:
+  // a joint outside [lower, upper] whose post-contact velocity does not yet bring it back at the Baumgarte rate
+  // erp * penetration / dt receives the joint-space impulse that does, p_j = (target - qd_j) / (M^-1)_jj; all
+  // violated joints are treated at once from the same velocities (one Jacobi pass), and the impulses act on the whole
+  // multibody through M^-1 (reaction on the trunk and the other joints included).
+  if (s.cfg.joint_limits) {
+    T p[NV];
+    bool any = false;
+    for (int i = 0; i < NV; i++) p[i] = 0;
+    for (int j = 0; j < 12; j++) {
+      const T lo = T(s.cfg.joint_lower[j % 3]), hi = T(s.cfg.joint_upper[j % 3]);
+      const T qj = e.q[j], vj = vel[6 + j];
+      T tgt;
+      bool hit = false;
+      if (qj > hi) { tgt = -T(s.cfg.erp) * (qj - hi) / dt; hit = vj > tgt; }
+      else if (qj < lo) { tgt = -T(s.cfg.erp) * (qj - lo) / dt; hit = vj < tgt; }
+      if (!hit) continue;
+      T ej[NV], col[NV];
+      for (int i = 0; i < NV; i++) ej[i] = 0;
+      ej[6 + j] = 1;
+      chol_solve(ej, col);
+      p[6 + j] = (tgt - vj) / col[6 + j];
+      any = true;
+    }
+    if (any) {
+      T dv[NV];
+      chol_solve(p, dv);
+      for (int i = 0; i < NV; i++) vel[i] += dv[i];
+    }
+  }
+
   // ---- integrate (semi-implicit Euler)
   for (int k = 0; k < 3; k++) { e.wb[k] = vel[k]; e.vb[k] = vel[3 + k]; }
   for (int j = 0; j < 12; j++) { e.qd[j] = vel[6 + j]; e.q[j] += dt * e.qd[j]; }
@@ -924,7 +955,8 @@ template <class T> void reset_env(Sim<T>& s, Env<T>& e, T* obs) {
   T fb[12];
   foot_world(s, e, e.last_foot_w, fb);
   T act[12], imu[6];
-  etg_action(s, e, T(0), act);
+  if (s.cfg.enable_etg) etg_action(s, e, T(0), act);
+  else for (int j = 0; j < 12; j++) act[j] = 0;
   build_obs(s, e, act, obs, imu);
 }
 
@@ -943,7 +975,8 @@ void step_env(Sim<T>& s, Env<T>& e, const T* action, int donef, T* obs, T* rewar
   // ETG at t = (k+1) dt  (fixture convention of gait_action_list_ETG_exp.npy)
   T t = T(e.step_count + 1) * T(s.cfg.etg_dt);
   T etg[12], qdes[12];
-  etg_action(s, e, t, etg);
+  if (s.cfg.enable_etg) etg_action(s, e, t, etg);
+  else for (int j = 0; j < 12; j++) etg[j] = 0;     // `ETG=0` (Dynamic_parallel_model.py:49): command = pose_ori + action
   const bool torque_cmd = s.cfg.motor_mode == 1;
   const bool hybrid_cmd = s.cfg.motor_mode == 2;   // action row = 12 x (q_des, kp, qd_des, kd, tau_ff)
   T hyb[48];
@@ -1158,6 +1191,27 @@ template <class F> void par_for(int n, int threads, F f) {
       step_env(*s, s->env[i], action + (size_t)i * (s->cfg.motor_mode == 2 ? ETG_HYBRID_DIM : 12), donef ? donef[i] : 0,                        \
                obs + (size_t)i * ETG_OBS_DIM, reward + i, done + i,                                 \
                info ? info + (size_t)i * ETG_INFO_DIM : (T*)nullptr);                               \
+    });                                                                                             \
+  }                                                                                                 \
+  /* nsteps control steps with a constant action row set (action [N,12] or NULL = zeros), every thread running ITS   \
+   * slice of the robots through all the steps (no per-step thread spawn / join): the all-core CPU baseline of       \
+   * bench.py.  ret / len [N]: episode return and length with alive masking (frozen after the first done).          \
+   * Sensor noise is not drawn here (the counter-based stream is per call).                                          */ \
+  extern "C" void etgo_run_steps##SFX(void* h, const T* action, int nsteps, int threads, T* ret, int32_t* len) {     \
+    auto* s = (Sim<T>*)h;                                                                           \
+    const int adim = s->cfg.motor_mode == 2 ? ETG_HYBRID_DIM : 12;                                  \
+    par_for(s->N, threads, [=](int i) {                                                             \
+      std::vector<T> zero(adim, T(0));                                                              \
+      T obs[ETG_OBS_DIM], r, acc = 0;                                                               \
+      uint8_t d;                                                                                    \
+      int alive = 1, n = 0;                                                                         \
+      for (int k = 0; k < nsteps; k++) {                                                            \
+        step_env(*s, s->env[i], action ? action + (size_t)i * adim : zero.data(), 0, obs, &r, &d, (T*)nullptr); \
+        if (alive) { acc += r; n++; }                                                               \
+        if (d) alive = 0;                                                                           \
+      }                                                                                             \
+      if (ret) ret[i] = acc;                                                                        \
+      if (len) len[i] = n;                                                                          \
     });                                                                                             \
   }                                                                                                 \
   extern "C" void etgo_get_state##SFX(void* h, T* st) {                                             \

@@ -126,6 +126,15 @@ class OracleSim:
                         self.threads)
         return obs, rew, done, info
 
+    def run_steps(self, nsteps, action=None, threads=None):
+        """nsteps control steps with a constant action (None = zeros), every thread running its own slice of the
+        robots through all the steps (persistent workers: the all-core CPU baseline).  -> (return[N], length[N])"""
+        ret = np.zeros(self.N, dtype=self.dtype)
+        ln = np.zeros(self.N, dtype=np.int32)
+        a = None if action is None else self._arr(action, (self.N, 60 if self.cfg.motor_mode == 2 else 12))
+        self._f("run_steps")(self._h, _p(a), int(nsteps), int(threads or self.threads), _p(ret), _p(ln))
+        return ret, ln
+
     def get_state(self):
         st = np.zeros((self.N, A.STATE_DIM), dtype=self.dtype)
         self._f("get_state")(self._h, _p(st))

@@ -23,6 +23,8 @@ STATE_DIM = 37
 DYN_DIM = 48
 RBF_H = 20
 INFO_DIM = 64
+EXTRA_DIM = 84
+EXTRA_SLICES = {"ETG_obs": (0, 20), "footpose": (20, 32), "dynamic_vec": (32, 80), "force_vec": (80, 83)}
 
 INFO_SLICES = {
     "torso": (0, 1), "feet": (1, 2), "up": (2, 3), "tau": (3, 4), "stand": (4, 5),
@@ -77,6 +79,9 @@ class EtgConfig(C.Structure):
         ("clip_motor_commands", C.c_double),
         ("body_contacts", C.c_int32),
         ("knee_radius", C.c_double),
+        ("enable_etg", C.c_int32),
+        ("joint_limits", C.c_int32),
+        ("joint_lower", C.c_double * 3), ("joint_upper", C.c_double * 3),
     ]
 
 
@@ -99,6 +104,9 @@ ETG_STD = np.array([4.5967497e-02, 2.0340437e-01, 3.7410179e-01, 4.6187632e-02, 
                     3.9488649e-01, 4.5966785e-02, 2.0323379e-01, 3.7382501e-01, 4.6188373e-02,
                     1.9457331e-01, 3.9302582e-01])                        # EnvWrapper.py:54-55
 FOOT_RADIUS = 0.02
+# joint limits of (hip, thigh, calf): the bounds of ACTION_CONFIG, a1.py:186-195 (= the URDF limits Bullet enforces)
+JOINT_LOWER = (-0.802851455917, -1.0471975512, -2.69653369433)
+JOINT_UPPER = (0.802851455917, 4.18879020479, -0.916297857297)
 
 # ---- recalled URDF inertials (FR leg; mirrored below) -------------------------------
 _TRUNK = dict(mass=4.713, com=(0.0, 0.0, 0.0),
@@ -175,7 +183,7 @@ def default_config(num_envs, *, action_repeat=13, sim_dt=0.002, settle_ticks=500
                    ETG_T=0.5, ETG_T2=0.5, etg_amp=0.2, etg_sigma_sq=0.04,
                    etg_phase=(-math.pi / 2, 0.0), reward_param=None, reward_p=5.0, vel_d=0.5,
                    heightfield=None, lanes_per_robot=0, motor_mode=0, clip_motor_commands=0.0,
-                   body_contacts=0, knee_radius=0.02):
+                   body_contacts=0, knee_radius=0.02, enable_etg=1, joint_limits=0):
     """EtgConfig with the defaults of train.py:296-297,470-487 and SURVEY App. A."""
     c = EtgConfig()
     c.num_envs = int(num_envs)
@@ -206,6 +214,10 @@ def default_config(num_envs, *, action_repeat=13, sim_dt=0.002, settle_ticks=500
     c.clip_motor_commands = float(clip_motor_commands)
     c.body_contacts = int(body_contacts)
     c.knee_radius = float(knee_radius)
+    c.enable_etg = int(bool(enable_etg))
+    c.joint_limits = int(bool(joint_limits))
+    for k in range(3):
+        c.joint_lower[k], c.joint_upper[k] = JOINT_LOWER[k], JOINT_UPPER[k]
     if heightfield is not None:
         c.hf_ny, c.hf_nx = heightfield["heights"].shape
         c.hf_cell = heightfield["cell"]

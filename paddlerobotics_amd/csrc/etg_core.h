@@ -814,7 +814,8 @@ ETG_HD void control_step_core(const Ctx& c, const KCfg& K, TickPar4<F>& tp, cons
   const int has_last = S.has_last;
   // ETG at t = (k+1) dt (fixture convention of gait_action_list_ETG_exp.npy)
   F etg[3], qdes[3];
-  etg_action(c, K, etgp, (float)(step_count + 1) * K.etg_dt, etg);
+  if (Ctx::kPlain || K.etg_on) etg_action(c, K, etgp, (float)(step_count + 1) * K.etg_dt, etg);
+  else etg[0] = etg[1] = etg[2] = F(0.0f);   // EtgConfig.enable_etg = 0: the command is pose_ori + action
   const bool torque_cmd = !Ctx::kPlain && K.motor_mode == 1;
   const bool hybrid_cmd = !Ctx::kPlain && K.motor_mode == 2 && hyb != nullptr;
 #pragma unroll
@@ -923,7 +924,8 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   StepCtl4<F> S = load_ctl4<F>(c, K, ctl, ictl, legctl);
   TickPar4<F> tp = load_tick_par4<F>(c);
   V3<F> fext = {F(0.0f), F(0.0f), F(0.0f)};
-  if (!Ctx::kPlain && K.ext_force) fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
+  if (!Ctx::kPlain && K.ext_force) fext = {c.ld_env(ctl, CT_FEXT + 0) + c.ld_env(ctl, CT_PUSH + 0), c.ld_env(ctl, CT_FEXT + 1) + c.ld_env(ctl, CT_PUSH + 1),
+                                           c.ld_env(ctl, CT_FEXT + 2) + c.ld_env(ctl, CT_PUSH + 2)};   // set force + random push
   control_step_core(c, K, tp, fext, L, S, ring, etgp, action, donef, obs, reward, done, info, hyb);
   store_ctl4(c, K, S, ctl, ictl, legctl);
 }
@@ -935,7 +937,8 @@ ETG_HD void rollout_steps(const Ctx& c, const KCfg& K, LaneState<F>& L, float* r
   StepCtl4<F> S = load_ctl4<F>(c, K, ctl, ictl, legctl);
   TickPar4<F> tp = load_tick_par4<F>(c);
   V3<F> fext = {F(0.0f), F(0.0f), F(0.0f)};
-  if (!Ctx::kPlain && K.ext_force) fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
+  if (!Ctx::kPlain && K.ext_force) fext = {c.ld_env(ctl, CT_FEXT + 0) + c.ld_env(ctl, CT_PUSH + 0), c.ld_env(ctl, CT_FEXT + 1) + c.ld_env(ctl, CT_PUSH + 1),
+                                           c.ld_env(ctl, CT_FEXT + 2) + c.ld_env(ctl, CT_PUSH + 2)};   // set force + random push
   const F zero3[3] = {F(0.0f), F(0.0f), F(0.0f)};
   F reward, done;
   for (int s = 0; s < n_steps; s++)
@@ -987,7 +990,8 @@ ETG_HD void reset_finish(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   FootKin<F> fk = foot_kin(c, K, L);
   c.st_lane(legctl, LC_LAST_FOOT_X, fk.fwx);
   F etg[3], imu[6];
-  etg_action(c, K, etgp, 0.0f, etg);
+  if (Ctx::kPlain || K.etg_on) etg_action(c, K, etgp, 0.0f, etg);
+  else etg[0] = etg[1] = etg[2] = F(0.0f);
   // the first reading after reset defines the rpy reference (EnvWrapper.py:79-84)
   const Delayed<F> D0 = ring_read<F>(c, ring, tick);
   const V3<F> rpy0 = quat_rpy(D0.qx, D0.qy, D0.qz, D0.qw);

@@ -604,13 +604,20 @@ ETG_HD void store_ctl16(const Ctx& c, const KCfg& K, const StepCtl16<F>& S, floa
   }
 }
 
+// external trunk force of the step: the set force plus the current random push (separate columns of ctl)
+template <class F, class Ctx> ETG_HD V3<F> load_fext16(const Ctx& c, const float* ctl) {
+  return {c.ld_env(ctl, CT_FEXT + 0) + c.ld_env(ctl, CT_PUSH + 0), c.ld_env(ctl, CT_FEXT + 1) + c.ld_env(ctl, CT_PUSH + 1),
+          c.ld_env(ctl, CT_FEXT + 2) + c.ld_env(ctl, CT_PUSH + 2)};
+}
+
 // one env.step on the register-resident control state S and tick constants tp
 template <class F, class Ctx>
 ETG_HD void control_step16_core(const Ctx& c, const KCfg& K, TickPar<F>& tp, State16<F>& L, StepCtl16<F>& S, float* ring,
                                 const float* etgp, F action, F donef, float* obs, F& reward, F& done, float* info,
                                 const F* hyb = nullptr) {   // hyb: (kp, qd_des, kd, tau_ff) of this lane's motor, HYBRID mode
   const F mj = c.jointf();
-  F etg = etg_action16<F>(c, K, etgp, (float)(S.step_count + 1) * K.etg_dt);
+  // EtgConfig.enable_etg = 0 (Dynamic_parallel_model.py:49 `ETG=0`): no generator, the command is pose_ori + action
+  F etg = (Ctx::kPlain || K.etg_on) ? etg_action16<F>(c, K, etgp, (float)(S.step_count + 1) * K.etg_dt) : F(0.0f);
   const bool torque_cmd = !Ctx::kPlain && K.motor_mode == 1;
   const bool hybrid_cmd = !Ctx::kPlain && K.motor_mode == 2 && hyb != nullptr;
   F qdes = (torque_cmd || hybrid_cmd) ? mj * action : mj * (c.par_joint(PR_POSE) + etg + action);
@@ -706,7 +713,7 @@ ETG_HD void control_step16(const Ctx& c, const KCfg& K, State16<F>& L, float* ri
                            const F* hyb = nullptr) {
   StepCtl16<F> S = load_ctl16<F>(c, K, ctl, ictl, legctl);
   TickPar<F> tp = load_tick_par<F>(c);
-  if (!Ctx::kPlain && K.ext_force) tp.fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
+  if (!Ctx::kPlain && K.ext_force) tp.fext = load_fext16<F>(c, ctl);
   control_step16_core(c, K, tp, L, S, ring, etgp, action, donef, obs, reward, done, info, hyb);
   store_ctl16(c, K, S, ctl, ictl, legctl);
 }
@@ -719,7 +726,7 @@ ETG_HD void rollout_steps16(const Ctx& c, const KCfg& K, State16<F>& L, float* r
                             const float* etgp, int n_steps, float* obs) {
   StepCtl16<F> S = load_ctl16<F>(c, K, ctl, ictl, legctl);
   TickPar<F> tp = load_tick_par<F>(c);
-  if (!Ctx::kPlain && K.ext_force) tp.fext = {c.ld_env(ctl, CT_FEXT + 0), c.ld_env(ctl, CT_FEXT + 1), c.ld_env(ctl, CT_FEXT + 2)};
+  if (!Ctx::kPlain && K.ext_force) tp.fext = load_fext16<F>(c, ctl);
   F reward, done;
   for (int s = 0; s < n_steps; s++)
     control_step16_core(c, K, tp, L, S, ring, etgp, F(0.0f), F(0.0f), obs, reward, done, (float*)nullptr);
@@ -767,7 +774,7 @@ ETG_HD void reset_finish16(const Ctx& c, const KCfg& K, State16<F>& L, float* ri
   FootKin16<F> fk = foot_kin16(c, K, L);
   c.st_legf(legctl, LC_LAST_FOOT_X, fk.fwx);
   F imu[6];
-  F etg = etg_action16<F>(c, K, etgp, 0.0f);
+  F etg = (Ctx::kPlain || K.etg_on) ? etg_action16<F>(c, K, etgp, 0.0f) : F(0.0f);
   // the first reading after reset defines the rpy reference (EnvWrapper.py:79-84)
   const Delayed16<F> D0 = ring_read16<F>(c, ring, tick);
   const V3<F> rpy0 = quat_rpy(D0.qx, D0.qy, D0.qz, D0.qw);

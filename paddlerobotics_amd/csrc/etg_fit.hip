@@ -72,6 +72,14 @@ extern "C" int etg_fit_etg(const double* points, int nb, const double* feats, co
     etg_set_last_error_("etg_fit_etg: bad arguments");
     return ETG_ERR_BAD_ARG;
   }
+  // launch on the device that owns the buffers (the caller's current device may be another one): the other entry
+  // points bind their handle's device the same way
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, points) != hipSuccess || hipSetDevice(attr.device) != hipSuccess) {
+    (void)hipGetLastError();
+    etg_set_last_error_("etg_fit_etg: points is not a device pointer");
+    return ETG_ERR_BAD_ARG;
+  }
   const int threads = 2 * nb;
   hipLaunchKernelGGL(k_etg_fit, dim3((threads + 63) / 64), dim3(64), 0, (hipStream_t)stream, points, feats, w0, b0x, b0z,
                      precision, alpha, lamb, max_iter, nb, out_w, out_b);

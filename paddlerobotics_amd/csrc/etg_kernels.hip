@@ -147,6 +147,7 @@ __global__ void __launch_bounds__(BLOCK) k_set_params(KCfg K, ModelF M, DevState
     if (c.lane == 0) D.cache_ok[c.env] = 0;   // the settle depends on the dynamic parameters
     float row[ETG_DYN_DIM], out[PR_N];
     for (int k = 0; k < ETG_DYN_DIM; k++) row[k] = dyn[(size_t)c.env * ETG_DYN_DIM + k];
+    for (int k = c.lane; k < ETG_DYN_DIM; k += 4) D.dyn[(size_t)c.env * ETG_DYN_DIM + k] = row[k];   // kept for the dynamic_vec sensor
     derive_lane_params(M, row, c.lane, K.dt, out);
     for (int k = 0; k < PR_N; k++) D.par[(size_t)k * c.NL + c.gid] = out[k];
   }
@@ -587,7 +588,7 @@ __global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, Po
   State16<float> L = load_state16<float>(c, D.base, D.leg);
   StepCtl16<float> S = load_ctl16<float>(c, K, D.ctl, D.ictl, D.legctl);
   TickPar<float> tp = load_tick_par<float>(c);
-  if (!PLAIN && K.ext_force) tp.fext = {c.ld_env(D.ctl, CT_FEXT + 0), c.ld_env(D.ctl, CT_FEXT + 1), c.ld_env(D.ctl, CT_FEXT + 2)};
+  if (!PLAIN && K.ext_force) tp.fext = load_fext16<float>(c, D.ctl);
   // current observation of the tile -> LDS
   for (int idx = tid; idx < TM * ETG_OBS_DIM; idx += 256) obs_lds[idx] = obs[(size_t)tile * TM * ETG_OBS_DIM + idx];
   float reward, done;
@@ -654,7 +655,7 @@ __global__ void k_random_pushes(KCfg K, DevState D, unsigned long long seed, uns
   const int N = K.n_env;
   if (i >= N) return;
   int left = D.ictl[(size_t)IC_PUSH_LEFT * N + i];
-  float fx = D.ctl[(size_t)(CT_FEXT + 0) * N + i], fy = D.ctl[(size_t)(CT_FEXT + 1) * N + i];
+  float fx = D.ctl[(size_t)(CT_PUSH + 0) * N + i], fy = D.ctl[(size_t)(CT_PUSH + 1) * N + i];
   if (left > 0) {
     left--;
     if (left == 0) { fx = 0.0f; fy = 0.0f; }
@@ -665,16 +666,16 @@ __global__ void k_random_pushes(KCfg K, DevState D, unsigned long long seed, uns
     left = duration;
   }
   D.ictl[(size_t)IC_PUSH_LEFT * N + i] = left;
-  D.ctl[(size_t)(CT_FEXT + 0) * N + i] = fx;
-  D.ctl[(size_t)(CT_FEXT + 1) * N + i] = fy;
-  D.ctl[(size_t)(CT_FEXT + 2) * N + i] = 0.0f;
+  D.ctl[(size_t)(CT_PUSH + 0) * N + i] = fx;
+  D.ctl[(size_t)(CT_PUSH + 1) * N + i] = fy;
+  D.ctl[(size_t)(CT_PUSH + 2) * N + i] = 0.0f;
 }
 __global__ void k_clear_pushes(KCfg K, DevState D, const uint8_t* mask) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int N = K.n_env;
   if (i >= N || (mask && !mask[i])) return;
   D.ictl[(size_t)IC_PUSH_LEFT * N + i] = 0;
-  for (int k = 0; k < 3; k++) D.ctl[(size_t)(CT_FEXT + k) * N + i] = 0.0f;
+  for (int k = 0; k < 3; k++) D.ctl[(size_t)(CT_PUSH + k) * N + i] = 0.0f;   // the set force (CT_FEXT) stays
 }
 
 // copy out the per-robot episode accumulators (return, length) kept in ctl[]
@@ -699,6 +700,76 @@ __global__ void __launch_bounds__(BLOCK) k_set_state(KCfg K, DevState D, const f
   store_state(c, D.base, D.leg, L);
 }
 
+// leg FK + analytic Jacobian through the tick's own leg_geometry (etg_leg_kinematics): 4 joint-angle rows per
+// wave, lane r = 4*leg + sub of a 16-lane row like the step kernels.  Sub-lane s < 3 writes component s of the
+// foot position (base frame) and row s of d foot / d (hip, thigh, calf): the columns are the k1, k2, k3 lever
+// arms the contact rows of physics_tick16 are built from, evaluated at the foot centre.
+__global__ void __launch_bounds__(BLOCK) k_leg_kin(KCfg K, ModelF M, const float* q, int n, float* foot, float* jac) {
+  GpuCtx16T<true> c;
+  const int lane = threadIdx.x;
+  const int row = blockIdx.x * 4 + (lane >> 4);
+  const bool live = row < n;
+  const int rr = live ? row : n - 1;          // keep every quad complete for the DPP exchanges
+  c.r = lane & 15; c.leg = c.r >> 2; c.sub = c.r & 3; c.sc = c.sub < 2 ? c.sub : 2;
+  const float qo = c.sub < 3 ? q[(size_t)rr * 12 + 3 * c.leg + c.sub] : 0.0f;
+  const V3<float> o1 = {M.hip_origin[c.leg][0], M.hip_origin[c.leg][1], M.hip_origin[c.leg][2]};
+  const LegGeo<float> g = leg_geometry(c, K, o1, M.thigh_y[c.leg], qo);
+  const V3<float> xax = {1.0f, 0.0f, 0.0f};
+  const V3<float> k1 = cross(xax, g.pf - g.o1), k2 = cross(g.yax, g.pf - g.o2), k3 = cross(g.yax, g.pf - g.o3);
+  if (!live || c.sub == 3) return;
+  const int s = c.sub;
+  foot[(size_t)row * 12 + 3 * c.leg + s] = s == 0 ? g.pf.x : s == 1 ? g.pf.y : g.pf.z;
+  if (jac) {
+    float* J = jac + (((size_t)row * 4 + c.leg) * 3 + s) * 3;
+    J[0] = s == 0 ? k1.x : s == 1 ? k1.y : k1.z;
+    J[1] = s == 0 ? k2.x : s == 1 ? k2.y : k2.z;
+    J[2] = s == 0 ? k3.x : s == 1 ? k3.y : k3.z;
+  }
+}
+
+// optional sensors (include/etgsim.h ETG_EXTRA_*): one thread per (robot, column)
+__global__ void k_extra_sensors(KCfg K, ModelF M, DevState D, const float* obs, float* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int env = i / ETG_EXTRA_DIM, col = i % ETG_EXTRA_DIM;
+  const int N = K.n_env;
+  if (env >= N) return;
+  float v = 0.0f;
+  if (col < ETG_EXTRA_FOOTPOSE) {            // RBF activations at the ETG time of the row's observation
+    const int k = D.ictl[(size_t)IC_STEP * N + env];
+    const float t = (float)k * K.etg_dt;
+    const float x0 = K.etg_amp * sinf(K.etg_phase0 + t * K.etg_omega), x1 = K.etg_amp * sinf(K.etg_phase1 + t * K.etg_omega);
+    const float d0 = x0 - K.etg_u[col][0], d1 = x1 - K.etg_u[col][1];
+    v = expf(-(d0 * d0 + d1 * d1) / K.etg_sigma_sq);
+  } else if (col < ETG_EXTRA_DYNAMIC) {      // foot_positions_in_base_frame (a1.py:113-140) of the OBSERVED motor angles
+    const int j = col - ETG_EXTRA_FOOTPOSE, leg = j / 3, k = j % 3;
+    float a[3];
+    for (int m = 0; m < 3; m++) {
+      const float o = obs[(size_t)env * ETG_OBS_DIM + 13 + 3 * leg + m];
+      a[m] = K.obs_normal ? o * 0.1f + M.pose[3 * leg + m] : o;
+    }
+    const float l_hip = M.thigh_y[leg], lu = K.upper_len, ll = K.lower_len;
+    const float dist = sqrtf(lu * lu + ll * ll + 2.0f * lu * ll * cosf(a[2]));
+    const float sw = a[1] + 0.5f * a[2];
+    const float ox = -dist * sinf(sw), oz = -dist * cosf(sw), oy = l_hip;
+    const float p[3] = {ox, cosf(a[0]) * oy - sinf(a[0]) * oz, sinf(a[0]) * oy + cosf(a[0]) * oz};
+    v = p[k] + M.hip_origin[leg][k];
+  } else if (col < ETG_EXTRA_FORCE) {        // inverse of param2dynamic_dict's affine maps (train.py:112-126)
+    const int k = col - ETG_EXTRA_DYNAMIC;
+    const float d = D.dyn[(size_t)env * ETG_DYN_DIM + k];
+    if (k == 0) v = (d - 40.0f) * 0.1f;
+    else if (k == 1) v = (d - 0.2f) * 0.1f;
+    else if (k == 2) v = d - 1.5f;
+    else if (k < 21) v = d - 1.0f;
+    else if (k < 33) v = (d - 80.0f) * 0.025f;
+    else if (k < 45) { const float kd0 = ((k - 33) % 3 == 0) ? 1.0f : 2.0f; v = (d - kd0) / kd0; }
+    else { const float g0[3] = {0.0f, 0.0f, -10.0f}, gs[3] = {2.0f, 2.0f, 10.0f}; v = (d - g0[k - 45]) / gs[k - 45]; }
+  } else if (col < ETG_EXTRA_FORCE + 3) {
+    const int k = col - ETG_EXTRA_FORCE;
+    v = D.ctl[(size_t)(CT_FEXT + k) * N + env] + D.ctl[(size_t)(CT_PUSH + k) * N + env];
+  }
+  out[(size_t)env * ETG_EXTRA_DIM + col] = v;
+}
+
 }  // namespace etg
 
 // ====================================================================== C ABI
@@ -715,6 +786,7 @@ struct EtgHandle {
   unsigned long long push_calls;  // stream position of etg_random_pushes
   unsigned obs_calls;             // stream position of the sensor noise: observations written so far
   bool was_reset;                 // etg_step before the first etg_reset is a caller error (state undefined)
+  bool fext_set, push_on;         // a set force / random pushes are installed: K.ext_force = fext_set || push_on
   float *tmp_obs, *tmp_reward;  // sinks for etg_rollout_openloop
   uint8_t* tmp_done;
 };
@@ -756,6 +828,7 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   h->push_calls = 0;
   h->obs_calls = 0;
   h->was_reset = false;
+  h->fext_set = h->push_on = false;
   if (cfg->lanes_per_robot != 0 && cfg->lanes_per_robot != 4 && cfg->lanes_per_robot != 16) {
     delete h;
     return fail(ETG_ERR_BAD_ARG, "etg_create: lanes_per_robot must be 4 or 16");
@@ -775,7 +848,7 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   struct { void** p; size_t bytes; } allocs[] = {
       {(void**)&h->D.base, BS_N * N * 4},   {(void**)&h->D.leg, LG_N * NL * 4},   {(void**)&h->D.ctl, CT_N * N * 4},
       {(void**)&h->D.ictl, IC_N * N * 4},   {(void**)&h->D.legctl, LC_N * NL * 4}, {(void**)&h->D.etgp, EP_N * N * 4},
-      {(void**)&h->D.par, PR_N * NL * 4},   {(void**)&h->D.ring, (size_t)RING * 8 * NL * 4},
+      {(void**)&h->D.par, PR_N * NL * 4},   {(void**)&h->D.ring, (size_t)RING * 8 * NL * 4}, {(void**)&h->D.dyn, ETG_DYN_DIM * N * 4},
       {(void**)&h->D.cache_base, BS_N * N * 4}, {(void**)&h->D.cache_leg, LG_N * NL * 4},
       {(void**)&h->D.cache_ring, (size_t)RING * 8 * NL * 4}, {(void**)&h->D.cache_ok, N},
       {(void**)&h->D.reset_off, 2 * N * 4}, {(void**)&h->D.cache_off, 2 * N * 4},
@@ -804,7 +877,7 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
 extern "C" void etg_destroy(EtgHandle* h) {
   if (!h) return;
   (void)hipSetDevice(h->device);
-  void* ptrs[] = {h->D.base, h->D.leg, h->D.ctl, h->D.ictl, h->D.legctl, h->D.etgp, h->D.par, h->D.ring, h->hf,
+  void* ptrs[] = {h->D.base, h->D.leg, h->D.ctl, h->D.ictl, h->D.legctl, h->D.etgp, h->D.par, h->D.ring, h->hf, h->D.dyn,
                   h->D.cache_base, h->D.cache_leg, h->D.cache_ring, h->D.cache_ok, h->D.reset_off, h->D.cache_off,
                   h->tmp_obs, h->tmp_reward, h->tmp_done};
   for (void* p : ptrs)
@@ -876,11 +949,13 @@ extern "C" int etg_set_external_force(EtgHandle* h, const float* force, void* st
   float* dst = h->D.ctl + (size_t)CT_FEXT * h->N;      // ctl[CT_FEXT + k][N]
   if (!force) {
     HIP_TRY(hipMemsetAsync(dst, 0, (size_t)3 * h->N * 4, (hipStream_t)stream));
-    h->K.ext_force = 0;
+    h->fext_set = false;
+    h->K.ext_force = h->push_on;     // pending random pushes keep acting
     return ETG_OK;
   }
   hipLaunchKernelGGL(k_set_fext, dim3((h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->D, force);
   HIP_TRY(hipGetLastError());
+  h->fext_set = true;
   h->K.ext_force = 1;
   return ETG_OK;
 }
@@ -892,6 +967,7 @@ extern "C" int etg_random_pushes(EtgHandle* h, uint64_t seed, float prob, int du
   hipLaunchKernelGGL(k_random_pushes, dim3((h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->D,
                      (unsigned long long)seed, h->push_calls++, prob, duration_steps, fmin, fmax);
   HIP_TRY(hipGetLastError());
+  h->push_on = true;
   h->K.ext_force = 1;
   return ETG_OK;
 }
@@ -1051,6 +1127,23 @@ extern "C" int etg_rollout_policy(EtgHandle* h, EtgPolicy* pol, int n_steps, flo
   }
   HIP_TRY(hipGetLastError());
   if (ret || len) return etg_episode_stats(h, ret, len, stream);
+  return ETG_OK;
+}
+
+extern "C" int etg_leg_kinematics(EtgHandle* h, const float* q, int n, float* foot, float* jac, void* stream) {
+  CHECK_HANDLE(h);
+  if (!q || !foot || n <= 0) return fail(ETG_ERR_BAD_ARG, "etg_leg_kinematics: bad arguments");
+  hipLaunchKernelGGL(k_leg_kin, dim3((n + 3) / 4), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->M, q, n, foot, jac);
+  HIP_TRY(hipGetLastError());
+  return ETG_OK;
+}
+
+extern "C" int etg_extra_sensors(EtgHandle* h, const float* obs, float* out, void* stream) {
+  CHECK_HANDLE(h);
+  if (!obs || !out) return fail(ETG_ERR_BAD_ARG, "etg_extra_sensors: null argument");
+  const int total = h->N * ETG_EXTRA_DIM;
+  hipLaunchKernelGGL(k_extra_sensors, dim3((total + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->M, h->D, obs, out);
+  HIP_TRY(hipGetLastError());
   return ETG_OK;
 }
 

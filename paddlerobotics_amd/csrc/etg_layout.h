@@ -30,8 +30,9 @@ constexpr int RING = 64;  // ticks of history; latency <= 80 ms at dt = 2 ms nee
 enum { BS_PX, BS_PY, BS_PZ, BS_QX, BS_QY, BS_QZ, BS_QW, BS_WX, BS_WY, BS_WZ, BS_VX, BS_VY, BS_VZ, BS_N };
 enum { LG_Q = 0, LG_QD = 3, LG_LAM = 6, LG_CONTACT = 9, LG_N = 10 };
 // CT_RET/LEN/ALIVE: per-robot episode accumulators (return, length, alive mask) updated by every step
-// CT_FEXT: external force on the trunk COM (world frame, N), etg_set_external_force()
-enum { CT_FIRST_RPY = 0, CT_LAST_BASE = 3, CT_RET = 6, CT_LEN = 7, CT_ALIVE = 8, CT_FEXT = 9, CT_N = 12 };
+// CT_FEXT: external force on the trunk COM (world frame, N), etg_set_external_force(); CT_PUSH: the random push of
+// etg_random_pushes() -- separate columns, the kernels apply their sum (a set force survives pushes and their clearing)
+enum { CT_FIRST_RPY = 0, CT_LAST_BASE = 3, CT_RET = 6, CT_LEN = 7, CT_ALIVE = 8, CT_FEXT = 9, CT_PUSH = 12, CT_N = 15 };
 // IC_PUSH_LEFT: control steps the current random push still lasts (etg_random_pushes)
 enum { IC_STEP = 0, IC_TICK = 1, IC_HAS_LAST = 2, IC_PUSH_LEFT = 3, IC_N = 4 };
 enum { LC_LAST_QDES = 0, LC_FX0 = 3, LC_FX1 = 6, LC_FY0 = 9, LC_FY1 = 12, LC_LAST_FOOT_X = 15, LC_N = 16 };
@@ -55,7 +56,10 @@ struct KCfg {
   int hf_bands;          // bands stacked along y in the heights array; robot e uses band e % hf_bands
   float hf_cell, hf_x0, hf_y0;
   const float* hf;
-  int ext_force;         // 1 once etg_set_external_force() installed a force (ctl[CT_FEXT..])
+  int ext_force;         // 1 while a set force (ctl[CT_FEXT..]) or random pushes (ctl[CT_PUSH..]) are installed
+  int etg_on;            // EtgConfig.enable_etg: 0 = no trajectory generator (command = pose_ori + action)
+  int jlim;              // EtgConfig.joint_limits
+  float jlo[3], jhi[3];  // joint-limit stops (hip, thigh, calf)
   int motor_mode;        // 0 POSITION (PD on a joint-angle command), 1 TORQUE (the command is the torque)
   float clip_cmd;        // > 0: clip the position command to q +- clip_cmd every tick (a1.py:439-457)
   int knee;              // EtgConfig.body_contacts: knee spheres collide (16-lane heightfield kernels)
@@ -71,7 +75,7 @@ struct KCfg {
 // the default robot layer (what train.py / pretrain.py run): the PLAIN kernel instantiations compile the options out
 inline bool plain_config(const KCfg& K) {
   return K.motor_mode == 0 && !K.enable_filter && !K.enable_interp && !(K.torque_limit > 0.0f) && !(K.clip_cmd > 0.0f) &&
-         !K.ext_force && !K.knee;
+         !K.ext_force && !K.knee && K.etg_on && !K.jlim;
 }
 
 // counter-based standard normal pair for (seed, robot, observation index, channel): splitmix64 finaliser twice, then
@@ -111,6 +115,7 @@ ETG_HD void add_sensor_noise(const KCfg& K, unsigned env, unsigned call, unsigne
 
 struct DevState {
   float *base, *leg, *ctl, *legctl, *etgp, *par, *ring;
+  float* dyn;   // [N,48] the dynamic_param rows as etg_set_params received them (dynamic_vec sensor)
   int* ictl;
   // settle cache: the state (base, leg) and latency ring right after the 500-tick reset settle of each robot.
   // The settle only depends on the robot's dynamic parameters and terrain, so a later reset of the same robot
@@ -298,6 +303,9 @@ inline KCfg make_kcfg(const EtgConfig& c, const EtgRobotModel& m) {
   K.motor_mode = c.motor_mode;
   K.clip_cmd = (float)c.clip_motor_commands;
   K.knee = c.body_contacts; K.knee_radius = (float)c.knee_radius;
+  K.etg_on = c.enable_etg != 0;
+  K.jlim = c.joint_limits != 0;
+  for (int k = 0; k < 3; k++) { K.jlo[k] = (float)c.joint_lower[k]; K.jhi[k] = (float)c.joint_upper[k]; }
   K.hf_cell = (float)c.hf_cell; K.hf_x0 = (float)c.hf_x0; K.hf_y0 = (float)c.hf_y0;
   K.hf = nullptr;
   return K;

@@ -29,19 +29,22 @@ TASKS = ("ground", "heightfield") + TERRAIN_TASKS
 _OBS_COLS = {"dis": (0, 3), "contact": (3, 7), "imu_rpy": (7, 10), "imu_drpy": (10, 13), "motor_q": (13, 25),
              "motor_qd": (25, 37), "ETG": (37, 49)}
 DEFAULT_SENSOR_MODE = {"dis": 1, "motor": 1, "imu": 1, "contact": 1, "ETG": 1}
+# optional sensors of train.py:268-271: columns of the etg_extra_sensors() row (include/etgsim.h ETG_EXTRA_*), appended
+# after the 49-float row in this order.  rlschool's definitions are absent from the reference tree: DESIGN.md section 6.
+EXTRA_SENSORS = ("ETG_obs", "footpose", "dynamic_vec", "force_vec")
+# sensor_mode['noise'] (train.py:272 `--sensor_noise`): the noise levels the reference itself applies to these columns
+# when it perturbs observations (BCtrain.py:53-59 obs2noise): motor angle 1e-2 rad, motor velocity 0.5 rad/s, rpy 6e-2,
+# rpy rate 1e-1; order of observation_noise_stdev (minitaur.py:102): angle, velocity, torque, rpy, rpy rate
+SENSOR_NOISE_STDEV = (1e-2, 0.5, 0.0, 6e-2, 1e-1)
 
 
 def sensor_columns(sensor_mode):
-    """Columns of the full 49-float observation selected by a reference sensor_mode dict, following the
-    obs-dim rule of deployment/test.py:26-46 (motor 1 -> angles+velocities, 2 -> angles; imu 1 -> rpy+drpy,
-    2 -> rpy; dis / contact / ETG on-off).  Sensors this simulator does not provide raise."""
+    """Columns of the full 49-float observation selected by a reference sensor_mode dict, following
+    SimpleEnv.get_observation (deployment/envs/EnvWrapper.py:60-109) and the obs-dim rule of deployment/test.py:26-46:
+    motor 1 -> angles + velocities, 2 -> angles; imu 1 -> rpy + rpy rate, 2 -> the rpy RATE alone
+    (EnvWrapper.py:91-92 `sensors_dict["IMU"] = drpy`); dis / contact / ETG on-off."""
     sm = dict(DEFAULT_SENSOR_MODE)
     sm.update(sensor_mode or {})
-    for k in ("ETG_obs", "footpose", "dynamic_vec", "force_vec", "noise"):
-        if sm.get(k):
-            raise NotImplementedError("sensor_mode[%r] is not provided by the batched simulator%s" % (
-                k, " (its noise levels live in rlschool, which the reference tree does not ship: pass "
-                   "observation_noise_stdev=(angle, velocity, torque, rpy, rpy rate) instead)" if k == "noise" else ""))
     rnn = sm.get("RNN")
     if rnn and rnn.get("time_steps", 0) > 0 and rnn.get("mode", "stack") not in ("stack", "GRU"):
         raise NotImplementedError("sensor_mode['RNN']['mode'] must be 'stack' or 'GRU'")
@@ -53,16 +56,27 @@ def sensor_columns(sensor_mode):
         add("dis")
     if sm.get("contact"):
         add("contact")
-    if sm.get("imu") in (1, 2):
+    if sm.get("imu") == 1:
         add("imu_rpy")
-        if sm["imu"] == 1:
-            add("imu_drpy")
+        add("imu_drpy")
+    elif sm.get("imu") == 2:
+        add("imu_drpy")
     if sm.get("motor") in (1, 2):
         add("motor_q")
         if sm["motor"] == 1:
             add("motor_qd")
     if sm.get("ETG"):
         add("ETG")
+    return cols
+
+
+def extra_sensor_columns(sensor_mode):
+    """columns of the etg_extra_sensors() row selected by sensor_mode's optional sensors (train.py:268-271)"""
+    cols = []
+    for k in EXTRA_SENSORS:
+        if (sensor_mode or {}).get(k):
+            a, b = A.EXTRA_SLICES[k]
+            cols.extend(range(a, b))
     return cols
 
 
@@ -126,7 +140,8 @@ class BatchedQuadrupedEnv:
                  heightfield=None, lanes_per_robot=0, terrain_variants=16, terrain_seed=0,
                  random_dynamics_scale=0.3, random_force_prob=0.02, random_force_steps=8,
                  random_force_range=(5.0, 25.0), seed=0, enable_clip_motor_commands=False,
-                 observation_noise_stdev=None, body_contacts=False, knee_radius=0.02, **unused):
+                 observation_noise_stdev=None, body_contacts=False, knee_radius=0.02, joint_limits=False,
+                 auto_reset=False, **unused):
         if render:
             raise ValueError("render is not supported by the batched GPU simulator")
         if int(ETG_H) != A.RBF_H:
@@ -157,6 +172,10 @@ class BatchedQuadrupedEnv:
             raise NotImplementedError("motor_control_mode %r: POSITION, TORQUE and HYBRID exist" % (motor_control_mode,))
         self.motor_mode = motor_mode
         self._cols = sensor_columns(sensor_mode)
+        self._xcols = extra_sensor_columns(sensor_mode)
+        if (sensor_mode or {}).get("noise") and observation_noise_stdev is None:
+            observation_noise_stdev = SENSOR_NOISE_STDEV
+        self.auto_reset = bool(auto_reset)
         # observation history (ObservationWrapper, deployment/envs/EnvWrapper.py:195-238): the current reading
         # preceded by `time_steps` older ones taken `time_interval` control steps apart, flattened ("stack", obs
         # dim x (time_steps + 1), deployment/test.py:44-45) or kept as a sequence ("GRU")
@@ -171,7 +190,6 @@ class BatchedQuadrupedEnv:
         self._rand_force = bool(rp.get("random_force", 0))
         self._rand_dyn_scale = float(random_dynamics_scale)
         self._rf_prob, self._rf_steps, self._rf_range = float(random_force_prob), int(random_force_steps), random_force_range
-        self._np_rng = np.random.default_rng(seed)
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
         if self.device.type != "cuda":
@@ -185,14 +203,15 @@ class BatchedQuadrupedEnv:
             reward_param=reward_param, reward_p=reward_p, vel_d=vel_d, heightfield=heightfield,
             lanes_per_robot=lanes_per_robot, motor_mode=motor_mode,
             clip_motor_commands=0.2 if enable_clip_motor_commands else 0.0,   # MAX_MOTOR_ANGLE_CHANGE_PER_STEP, a1.py
-            body_contacts=1 if body_contacts else 0, knee_radius=knee_radius)
+            body_contacts=1 if body_contacts else 0, knee_radius=knee_radius,
+            enable_etg=1 if self.ETG else 0, joint_limits=1 if joint_limits else 0)
         self.model = A.default_model()
         if task == "balancebeam":
             # README "step_y: the foot position at y axis for balance beam task" (train.py:463): the ETG's nominal
             # foot positions are pulled in to y = -+step_y so the feet land on the beam (right legs negative y)
             for leg in range(4):
                 self.model.base_foot[3 * leg + 1] = (-1.0 if leg % 2 == 0 else 1.0) * float(step_y)
-        d = len(self._cols)
+        d = len(self._cols) + len(self._xcols)
         if self._hist_T > 0:
             shape = (d * (self._hist_T + 1),) if self._hist_mode == "stack" else (self._hist_T + 1, d)
         else:
@@ -210,6 +229,8 @@ class BatchedQuadrupedEnv:
         self.done = torch.zeros(N, dtype=torch.uint8, device=dev)
         self.info_buf = torch.zeros(N, A.INFO_DIM, device=dev)
         self._col_idx = None if len(self._cols) == A.OBS_DIM else torch.tensor(self._cols, device=dev)
+        self._xcol_idx = torch.tensor(self._xcols, device=dev) if self._xcols else None
+        self.extra = torch.zeros(N, A.EXTRA_DIM, device=dev) if self._xcols else None
         self._push_seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self._dyn_gen = torch.Generator(device=dev)
         self._dyn_gen.manual_seed(int(seed) & 0x7FFFFFFFFFFFFFFF)
@@ -247,10 +268,19 @@ class BatchedQuadrupedEnv:
         return t
 
     def _mask(self, env_ids):
+        """uint8 [N] mask of the robots a call applies to: `env_ids` is None (all robots), a list / array / tensor of
+        robot indices, or a boolean (or uint8) [N] mask such as the `done` tensor step() returns."""
         if env_ids is None:
             return None
+        t = torch.as_tensor(env_ids, device=self.device)
+        if t.dtype in (torch.bool, torch.uint8):
+            if tuple(t.shape) != (self.num_envs,):
+                raise ValueError("a boolean env_ids mask must have shape [N]")
+            return t.to(torch.uint8).contiguous()
+        if t.dim() > 1 or t.is_floating_point():
+            raise ValueError("env_ids must be robot indices or a boolean [N] mask")
         m = torch.zeros(self.num_envs, dtype=torch.uint8, device=self.device)
-        m[torch.as_tensor(env_ids, device=self.device, dtype=torch.long)] = 1
+        m[t.reshape(-1).long()] = 1
         return m
 
     def close(self):
@@ -334,8 +364,9 @@ class BatchedQuadrupedEnv:
         if x_noise:
             # start-position jitter (train.py:131 `x_noise=args.x_noise`, an int flag there; rlschool's own
             # distribution is absent): x0 ~ U(-0.1, 0.1) * x_noise metres for every robot being reset
+            # (drawn on the device from the env's seeded generator: no host RNG pass, no upload per reset)
             xy = torch.zeros(self.num_envs, 2, dtype=torch.float32, device=self.device)
-            xy[:, 0] = torch.as_tensor(self._np_rng.uniform(-0.1, 0.1, size=self.num_envs) * float(x_noise), dtype=torch.float32)
+            xy[:, 0] = (torch.rand(self.num_envs, device=self.device, generator=self._dyn_gen) * 0.2 - 0.1) * float(x_noise)
             self.set_reset_offsets(xy, env_ids)
             self._noise_offsets = True
         elif self._noise_offsets:       # an earlier reset jittered these robots: back to the nominal start
@@ -352,6 +383,9 @@ class BatchedQuadrupedEnv:
         """the observation the caller sees: sensor_mode column selection, then (optionally) the history stack.
         reset_mask: uint8 [N] of the robots that were just reset (None = all, with first=True)."""
         o = self.obs if self._col_idx is None else self.obs.index_select(1, self._col_idx)
+        if self._xcol_idx is not None:   # optional sensors (train.py:268-271), appended after the 49-float row's columns
+            _lib.check(self._lib.etg_extra_sensors(self._h, _ptr(self.obs), _ptr(self.extra), self._stream()))
+            o = torch.cat([o, self.extra.index_select(1, self._xcol_idx)], dim=1)
         if self._hist_T == 0:
             return o
         H = self._hist_T * self._hist_dt
@@ -412,6 +446,18 @@ class BatchedQuadrupedEnv:
                                                int(self._rf_steps), C.c_float(self._rf_range[0]),
                                                C.c_float(self._rf_range[1]), self._stream()))
 
+    def leg_kinematics(self, q, want_jacobian=True):
+        """foot_positions_in_base_frame [n,4,3] and analytical_leg_jacobian [n,4,3,3] (a1.py:113-173) of joint-angle
+        rows q [n,12], computed on the device by the routine the physics tick's contact rows use."""
+        t = torch.as_tensor(q, dtype=torch.float32, device=self.device).contiguous()
+        if t.dim() != 2 or t.shape[1] != A.NUM_MOTORS:
+            raise ValueError("q must be [n,12]")
+        n = t.shape[0]
+        foot = torch.empty(n, 4, 3, device=self.device)
+        jac = torch.empty(n, 4, 3, 3, device=self.device) if want_jacobian else None
+        _lib.check(self._lib.etg_leg_kinematics(self._h, _ptr(t), n, _ptr(foot), _ptr(jac), self._stream()))
+        return (foot, jac) if want_jacobian else foot
+
     def step(self, action, donef=None, want_info=True):
         a = None if action is None else self._f32(action, (self.num_envs, self.action_space.shape[0]), "action")   # NULL = zero residual
         df = None
@@ -430,9 +476,25 @@ class BatchedQuadrupedEnv:
         _lib.check(self._lib.etg_step(self._h, _ptr(a), _ptr(df), _ptr(self.obs), _ptr(self.reward), _ptr(self.done),
                                       _ptr(self.info_buf) if want_info else None, self._stream()))
         self._keep_step = (a, df)
-        self._last_view = self._obs_view()
-        return (self._last_view, self.reward, self.done.view(torch.bool) if want_info else self.done,
-                (self._info() if want_info else {}))
+        info = self._info() if want_info else {}
+        if self.auto_reset:
+            # robots whose episode just ended start the next one now (settle cache -> state, control state, first
+            # observation): their rows of `obs` are the reset observation, reward / done / info are the last step's;
+            # info["reset"] marks them.  The mask is read on the device: no host synchronisation.
+            self._reset_mask = self.done.clone()
+            if self._rand_force:
+                _lib.check(self._lib.etg_clear_pushes(self._h, _ptr(self._reset_mask), self._stream()))
+            _lib.check(self._lib.etg_reset(self._h, _ptr(self._reset_mask), _ptr(self.obs), self._stream()))
+            if want_info:
+                info["reset"] = self._reset_mask.view(torch.bool)
+            if self._hist_T > 0:
+                self._obs_view()                                             # the terminal reading enters the history ...
+                self._last_view = self._obs_view(reset_mask=self._reset_mask, first=True)   # ... and is cleared for the reset robots
+            else:
+                self._last_view = self._obs_view()
+        else:
+            self._last_view = self._obs_view()
+        return (self._last_view, self.reward, self.done.view(torch.bool) if want_info else self.done, info)
 
     def rollout_openloop(self, n_steps):
         """n_steps control steps with zero residual action (pretrain.py:129-154) enqueued back to

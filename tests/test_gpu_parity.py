@@ -661,7 +661,7 @@ def test_full_batch_free_flight_momentum_matches_oracle_drift():
     env.reset()
     env.set_state(torch.as_tensor(st, dtype=torch.float32))
     sample = rng.choice(n, 48, replace=False)
-    one = OracleSim(A.default_config(1, settle_ticks=0))
+    one = OracleSim(A.default_config(1, settle_ticks=0, enable_etg=0))
     one.set_params(dyn=row[None])
 
     def momentum(s):
@@ -676,7 +676,7 @@ def test_full_batch_free_flight_momentum_matches_oracle_drift():
     env.step(None)
     s1 = env.get_state().cpu().numpy().astype(np.float64)
     assert np.isfinite(s1).all()
-    orc = OracleSim(A.default_config(len(sample), settle_ticks=0))
+    orc = OracleSim(A.default_config(len(sample), settle_ticks=0, enable_etg=0))
     orc.set_params(dyn=np.tile(row, (len(sample), 1)))
     orc.reset()
     orc.set_state(s0[sample])

@@ -112,8 +112,14 @@ def test_sensor_mode_columns_follow_the_reference_obs_dim_rule():
     assert dim(dis=0, motor=2, imu=2, contact=0, ETG=0) == 15
     cols = sensor_columns({"dis": 0})
     assert cols == list(range(3, 49))
-    with pytest.raises(NotImplementedError):
-        sensor_columns({"footpose": 1})
+    # imu == 2 is the rpy RATE alone (EnvWrapper.py:91-92 `sensors_dict["IMU"] = drpy`), not rpy
+    assert sensor_columns({"dis": 0, "contact": 0, "motor": 0, "ETG": 0, "imu": 2}) == [10, 11, 12]
+    assert sensor_columns({"dis": 0, "contact": 0, "motor": 0, "ETG": 0, "imu": 1}) == [7, 8, 9, 10, 11, 12]
+    # the optional sensors of train.py:268-271 come from the etg_extra_sensors() row, appended after the 49-float row
+    from paddlerobotics_amd.env import extra_sensor_columns
+    assert extra_sensor_columns({}) == [] and len(extra_sensor_columns({"footpose": 1})) == 12
+    assert len(extra_sensor_columns({"ETG_obs": 1, "footpose": 1, "dynamic_vec": 1, "force_vec": 1})) == 20 + 12 + 48 + 3
+    assert extra_sensor_columns({"force_vec": 1}) == [80, 81, 82]
 
 
 def test_param2dynamic_rows_equal_the_dict_mapping():
