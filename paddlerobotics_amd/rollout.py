@@ -79,3 +79,45 @@ def make_etg_evaluator(env, etg_layer, ETG_T, prior_points, w0, b0, max_step=400
                               action_bound=action_bound)
         return ret
     return evaluate
+
+
+def dynamics_id_loss(drpy, motor, mean_dict, key):
+    """loss_func of model/Dynamic_parallel_model.py:30-42, batched: drpy [N,T,3], motor [N,T,12] -> loss [N].
+    Per candidate: max over the columns of the time-mean of the squared, std-normalised deviation from the recorded
+    means, averaged over the motor-angle and rpy-rate groups."""
+    def group(x, mean, std):
+        mean = torch.as_tensor(np.asarray(mean), dtype=x.dtype, device=x.device)
+        std = torch.as_tensor(np.asarray(std), dtype=x.dtype, device=x.device)
+        return (((x - mean) ** 2) / (std ** 2)).mean(dim=1).max(dim=1).values
+    loss_motor = group(motor, mean_dict[key + "_motor_mean"], mean_dict[key + "_motor_std"])
+    loss_drpy = group(drpy, mean_dict[key + "_drpy_mean"], mean_dict[key + "_drpy_std"])
+    return (loss_drpy + loss_motor) / 2.0
+
+
+def make_dynamics_id_evaluator(env, gait, mean_dict, e_steps=100, keys=("exp", "ori")):
+    """Fitness of dynamic-parameter candidates (48 numbers in [-1,1] per candidate = robot), the batched
+    RemoteESAgent.batch_sample_episodes of model/Dynamic_parallel_model.py:53-77: for every gait `key`, reset with
+    param2dynamic_dict(candidate), replay `e_steps` recorded joint targets (action = gait[key][i] - pose_ori, an
+    env made with ETG=0), record info["joint_angle"] and info["obs-IMU"][3:], reward = 30 - loss_func; the
+    candidate's fitness is the mean over the keys.  `env` must have been made with ETG=0."""
+    from . import a1_model as A
+    if getattr(env, "ETG", 1):
+        raise ValueError("the dynamics-identification replay needs an env made with ETG=0 (Dynamic_parallel_model.py:49)")
+    pose = torch.as_tensor(A.INIT_MOTOR_ANGLES, dtype=torch.float32, device=env.device)
+    acts = {k: (torch.as_tensor(np.asarray(gait[k])[:e_steps], dtype=torch.float32, device=env.device) - pose) for k in keys}
+
+    def evaluate(solutions):
+        rows = A.param2dynamic_rows_torch(solutions.to(env.device).float())
+        n = env.num_envs
+        fit = torch.zeros(n, dtype=torch.float32, device=env.device)
+        motor = torch.empty(n, e_steps, 12, device=env.device)
+        drpy = torch.empty(n, e_steps, 3, device=env.device)
+        for key in keys:
+            env.reset(dynamic_param=rows)
+            for i in range(e_steps):
+                _, _, _, info = env.step(acts[key][i].expand(n, 12), donef=False)
+                motor[:, i] = info["joint_angle"]
+                drpy[:, i] = info["obs-IMU"][:, 3:]
+            fit += 30.0 - dynamics_id_loss(drpy, motor, mean_dict, key)
+        return fit / len(keys)
+    return evaluate

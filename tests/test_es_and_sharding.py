@@ -77,3 +77,14 @@ def test_two_rank_generation_equals_single_rank():
         fits, best, sigma = out[r]
         assert np.array_equal(fits, torch.stack(ref).numpy())       # gather order = candidate order
         assert np.array_equal(best, ga.best_param.numpy()) and sigma == ga.sigma   # replicated tell
+
+
+def test_dynamics_id_loss_matches_reference_loss_func(golden):
+    """rollout.dynamics_id_loss, batched over candidates, against loss_func of model/Dynamic_parallel_model.py:30-42
+    (tests/golden/dynid.npz, produced by executing the reference function)."""
+    g = golden("dynid")
+    mean_dict = {k: g[k] for k in g.files if k.endswith(("_mean", "_std"))}
+    motor, drpy = torch.as_tensor(g["motor"]), torch.as_tensor(g["drpy"])
+    for key in ("exp", "ori"):
+        got = R.dynamics_id_loss(drpy, motor, mean_dict, key).numpy()
+        assert np.allclose(got, g["loss_" + key], rtol=1e-12, atol=1e-12), key

@@ -1,0 +1,398 @@
+"""-m gpu, round 2: the parity cases VERDICT r01 listed as untested.
+
+  * closed loop (configs[2]): the fused policy + control-step kernel and the predict()+step() loop against the ORACLE
+    (oracle mlp_forward + step, train.py:213-249), at n = 64 and at the full 4096 with a 256-robot oracle sample;
+  * robot-layer options on the GPU against the oracle and the reference's filter trace: Butterworth action filter
+    (action_filter.py:111-216), action interpolation (minitaur.py:1384-1401), command clip (a1.py:439-457);
+  * leg FK / analytic Jacobian on the device against tests/golden/kin.npz (a1.py:113-173) and the footpose sensor;
+  * 400-step statistics at the headline workload (configs[1] sampling): survival curve, return and travelled distance of
+    the GPU batch against the fp64 oracle, for K = 2 and K = 50 solver sweeps;
+  * ETG = 0, the optional sensors, auto-reset, boolean masks, set force vs random pushes, SimpleGA on the device against
+    the reference trace, the dynamics-identification evaluator (Dynamic_parallel_model.py:53-77).
+
+Tolerances are stated where they are asserted.  Short-horizon trajectories are NOT chaotic here: the fp32 build of the
+oracle stays within ~1e-6 rad of the fp64 one over 15 closed-loop steps, so the bounds below are absolute (a few 1e-4:
+hardware rcp/rsq, polynomial sincos and a different summation order), not multiples of an fp32 sensitivity.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from paddlerobotics_amd import a1_model as A
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from tests.test_gpu_parity import _need_gpu, _etg_params, _make, _oracle   # noqa: E402
+
+POSE = A.INIT_MOTOR_ANGLES
+
+
+def _say(*a):
+    print("[parity]", *a, flush=True)
+
+
+def _policy(obs_dim=49, seed=3):
+    from paddlerobotics_amd.policy import MfmaPolicy
+    sd = MfmaPolicy.init_like_reference(obs_dim, 12, seed=seed)
+    pol = MfmaPolicy(obs_dim, 12)
+    pol.load_state_dict(sd)
+    ws = [sd["actor_model." + k].numpy() for k in ("l1.weight", "l1.bias", "l2.weight", "l2.bias", "mean_linear.weight",
+                                                   "mean_linear.bias")]
+    return pol, ws
+
+
+def _oracle_closed_loop(orc, ws, steps):
+    """run_EStrain_episode (train.py:213-249) with a fixed actor on the oracle: a = tanh(mean(obs)) * 0.3, step."""
+    from oracle import oracle as O
+    obs = orc.reset()
+    ret = np.zeros(orc.N)
+    alive = np.ones(orc.N, bool)
+    ln = np.zeros(orc.N, int)
+    for _ in range(steps):
+        act = O.mlp_forward(obs, *ws, scale=0.3)
+        obs, r, d, _ = orc.step(act)
+        ret += alive * r
+        ln += alive
+        alive &= ~d.astype(bool)
+    return obs, ret, ln
+
+
+@pytest.mark.parametrize("n", [64, 4096])
+def test_closed_loop_fused_kernel_and_stepping_match_oracle(n):
+    """configs[2]: etg_rollout_policy (k_rollout_policy16) and predict()+step() against the oracle's closed loop.
+    Bounds after 12 control steps (156 ticks): joint angles 1e-3 rad, base position 1e-3 m, with the
+    median an order of magnitude tighter; returns 1e-3 relative + 5e-3."""
+    _need_gpu()
+    steps = 12
+    m = 64 if n == 64 else 256                      # oracle sample: the first m robots
+    W, B = _etg_params(m, seed=17)
+    reps = n // m
+    Wn, Bn = np.tile(W, (reps, 1, 1)), np.tile(B, (reps, 1))
+    pol, ws = _policy()
+    fused, stepped = _make(n), _make(n)
+    fused.reset(ETG_w=Wn, ETG_b=Bn); stepped.reset(ETG_w=Wn, ETG_b=Bn)
+    orc = _oracle(m)
+    orc.threads = os.cpu_count() or 1
+    orc.set_params(etg_w=W, etg_b=B)
+    obs_o, ret_o, ln_o = _oracle_closed_loop(orc, ws, steps)
+    ret_f, ln_f = fused.rollout_policy(pol, steps, 0.3)
+    for _ in range(steps):
+        stepped.step(pol.predict(stepped.obs, 0.3), want_info=False)
+    ret_s, ln_s = stepped.episode_stats()
+    so = orc.get_state()
+    for name, env, ret, ln in (("fused", fused, ret_f, ln_f), ("stepping", stepped, ret_s, ln_s)):
+        sg = env.get_state().cpu().numpy()[:m]
+        eq = np.abs(sg - so)[:, 13:25].max(1)
+        ep = np.abs(sg - so)[:, :3].max(1)
+        _say(name, n, "q err median %.2e max %.2e | pos err max %.2e" % (np.median(eq), eq.max(), ep.max()))
+        assert np.median(eq) < 1e-4 and eq.max() < 1e-3, name
+        assert ep.max() < 1e-3, name
+        assert np.abs(env.obs.cpu().numpy()[:m] - obs_o)[:, 13:25].max() < 1e-2, name      # normalised angles (x10)
+        ln = ln.cpu().numpy()[:m]; ret = ret.cpu().numpy()[:m]
+        same = ln == ln_o
+        assert same.mean() > 0.98, name
+        assert np.all(np.abs(ret - ret_o)[same] < 1e-3 * np.abs(ret_o[same]) + 5e-3), name
+    if n > m:      # every copy of the sample behaves like the sample (batch invariance of the fused kernel)
+        sg = fused.get_state().cpu().numpy()
+        assert np.abs(sg.reshape(reps, m, -1) - sg[:m][None]).max() == 0.0
+    fused.close(); stepped.close()
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+@pytest.mark.parametrize("option", ["filter", "interp", "clip"])
+def test_robot_layer_options_match_oracle(option, lanes):
+    """enable_action_filter / enable_action_interpolation / enable_clip_motor_commands through the non-PLAIN kernels vs the
+    oracle: 10 control steps of random residual actions; joint angles 1e-3 rad, base pose 1e-3, the filtered command
+    (info['real_action'], a pure function of the action history) 2e-5."""
+    _need_gpu()
+    n = 32
+    kw_env = {"filter": dict(enable_action_filter=True), "interp": dict(enable_action_interpolation=True),
+              "clip": dict(enable_clip_motor_commands=True)}[option]
+    kw_orc = {"filter": dict(enable_action_filter=True), "interp": dict(enable_action_interp=True),
+              "clip": dict(clip_motor_commands=0.2)}[option]
+    W, B = _etg_params(n, seed=31)
+    env = _make(n, lanes_per_robot=lanes, **kw_env)
+    orc = _oracle(n, **kw_orc)
+    env.reset(ETG_w=W, ETG_b=B)
+    orc.set_params(etg_w=W, etg_b=B); orc.reset()
+    rng = np.random.default_rng(7)
+    amp = 0.6 if option == "clip" else 0.25             # the clip only bites on commands > 0.2 rad from the joint
+    worst_q = worst_p = 0.0
+    for k in range(10):
+        act = rng.uniform(-amp, amp, size=(n, 12))
+        env.step(torch.as_tensor(act, dtype=torch.float32))
+        _, _, _, io = orc.step(act)
+        sg, so = env.get_state().cpu().numpy(), orc.get_state()
+        ig = env.info_buf.cpu().numpy()
+        worst_q = max(worst_q, np.abs(sg - so)[:, 13:25].max()); worst_p = max(worst_p, np.abs(sg - so)[:, :7].max())
+        assert np.abs(ig[:, 43:55] - io[:, 43:55]).max() < 2e-5, k          # real_action
+    _say(option, lanes, "q err max %.2e, pose err max %.2e" % (worst_q, worst_p))
+    assert worst_q < 1e-3 and worst_p < 1e-3
+    env.close()
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_action_filter_reproduces_reference_trace(golden, lanes):
+    """ActionFilterButter (action_filter.py:128-216) on the GPU against the reference's own trace (filter.npz): with
+    ETG = 0 the position command is pose_ori + action, so action = x - pose_ori feeds the filter exactly x."""
+    _need_gpu()
+    g = golden("filter")
+    n = 4
+    env = _make(n, ETG=0, enable_action_filter=True, lanes_per_robot=lanes)
+    env.reset()
+    assert np.allclose(g["init"], POSE)
+    for k in range(g["x"].shape[0]):
+        act = np.tile((g["x"][k] - POSE)[None], (n, 1))
+        env.step(torch.as_tensor(act, dtype=torch.float32))
+        got = env.info_buf[:, 43:55].cpu().numpy()
+        assert np.abs(got - g["y"][k][None]).max() < 1e-5, k
+    env.close()
+
+
+def test_leg_kinematics_matches_reference_fixture(golden):
+    """etg_leg_kinematics = the tick's leg_geometry + lever arms: foot_positions_in_base_frame and analytical_leg_jacobian
+    of the reference (a1.py:113-173, kin.npz) to 2e-6 m / 2e-6 m/rad in fp32."""
+    _need_gpu()
+    g = golden("kin")
+    env = _make(4)
+    foot, _ = env.leg_kinematics(g["ang12"])
+    assert np.abs(foot.cpu().numpy() - g["fbase"]).max() < 2e-6
+    n = g["ang"].shape[0]
+    q = np.tile(POSE[None], (n, 1))
+    for i in range(n):
+        q[i, 3 * g["legs"][i]: 3 * g["legs"][i] + 3] = g["ang"][i]
+    foot, jac = env.leg_kinematics(q)
+    foot, jac = foot.cpu().numpy(), jac.cpu().numpy()
+    for i in range(n):
+        l = int(g["legs"][i])
+        assert np.abs(foot[i, l] - (g["fk"][i] + g["hip_offsets"][l])).max() < 2e-6
+        assert np.abs(jac[i, l] - g["jac"][i]).max() < 2e-6
+    env.close()
+
+
+def test_optional_sensors():
+    """sensor_mode ETG_obs / footpose / dynamic_vec / force_vec (train.py:268-271) and `noise` (BCtrain.py:53-59)."""
+    _need_gpu()
+    from oracle import oracle as O
+    n = 16
+    rng = np.random.default_rng(11)
+    sm = {"ETG_obs": 1, "footpose": 1, "dynamic_vec": 1, "force_vec": 1}
+    env = _make(n, sensor_mode=sm)
+    assert env.observation_space.shape == (49 + 20 + 12 + 48 + 3,)
+    p = rng.uniform(-0.3, 0.3, size=(n, 48))
+    force = rng.normal(size=(n, 3)) * 5
+    env.set_external_force(torch.as_tensor(force, dtype=torch.float32))
+    W, B = _etg_params(n, seed=2)
+    obs, _ = env.reset(ETG_w=W, ETG_b=B, dynamic_param=A.param2dynamic_rows(p))
+    orc = _oracle(n)
+    for k in range(4):
+        o = obs.cpu().numpy()
+        assert np.abs(o[:, 49 + 32: 49 + 80] - p).max() < 2e-5                               # dynamic_vec: the [-1,1] box
+        assert np.abs(o[:, 49 + 80: 49 + 83] - force).max() < 1e-5                            # force_vec
+        assert np.abs(o[:, 49: 49 + 20] - orc.etg_rbf(k * 0.026)[None]).max() < 2e-5          # ETG_obs = r(t_obs)
+        q_obs = o[:, 13:25] * 0.1 + POSE                                                      # observed motor angles
+        fp = np.stack([np.concatenate([O.leg_fk(q_obs[i, 3 * l: 3 * l + 3], A.hip_sign(l)) + A.HIP_OFFSETS[l] for l in range(4)])
+                       for i in range(n)])
+        assert np.abs(o[:, 49 + 20: 49 + 32] - fp).max() < 1e-5                               # footpose
+        obs, _, _, _ = env.step(None)
+    env.close()
+    # the `noise` flag switches on the reference's own perturbation levels (BCtrain.py:53-59)
+    from paddlerobotics_amd.env import SENSOR_NOISE_STDEV
+    a, b = _make(n, sensor_mode={"noise": 1}, seed=3), _make(n, observation_noise_stdev=SENSOR_NOISE_STDEV, seed=3)
+    oa, _ = a.reset(); ob, _ = b.reset()
+    assert torch.equal(oa, ob)
+    c = _make(n)
+    oc, _ = c.reset()
+    d = (oa - oc).cpu().numpy()
+    assert np.abs(d[:, :7]).max() == 0 and 0.5 * 0.1 < d[:, 13:25].std() < 2.0 * 0.1       # 1e-2 rad / 0.1 normalisation
+    a.close(); b.close(); c.close()
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_etg_zero_commands_pose_plus_action(lanes):
+    """make_env(ETG=0) (Dynamic_parallel_model.py:49,58): the command is pose_ori + action, ETG_act is zero and the ETG
+    observation columns are (0 - mean) / std; trajectory vs the oracle with enable_etg = 0."""
+    _need_gpu()
+    n = 16
+    env = _make(n, ETG=0, lanes_per_robot=lanes)
+    orc = _oracle(n, enable_etg=0)
+    env.reset(); orc.reset()
+    rng = np.random.default_rng(4)
+    for k in range(6):
+        act = rng.uniform(-0.2, 0.2, size=(n, 12))
+        obs, _, _, info = env.step(torch.as_tensor(act, dtype=torch.float32))
+        orc.step(act)
+        assert info["ETG_act"].abs().max().item() == 0.0
+        assert np.abs(info["real_action"].cpu().numpy() - (POSE + act)).max() < 1e-6
+        assert np.abs(obs[:, 37:49].cpu().numpy() - (-A.ETG_MEAN / A.ETG_STD)[None]).max() < 1e-5
+    assert np.abs(env.get_state().cpu().numpy() - orc.get_state())[:, 13:25].max() < 1e-3
+    env.close()
+
+
+def _population(n, seed=0):
+    import bench
+    w, b = bench.etg_population(n, seed, torch.device("cuda:0"))
+    return w, b
+
+
+@pytest.mark.parametrize("K", [2, 50])
+def test_long_horizon_statistics_match_oracle(K):
+    """The headline workload over its whole horizon (configs[1] sampling: prior + N(0, 0.02^2), 4096 robots, 400 control
+    steps, open loop) against the fp64 oracle on the first 512 robots, for K = 2 and K = 50 PGS sweeps.  Compared: the
+    episode-length distribution (= the survival curve), the return and the travelled distance.  Same robots on both
+    sides, so the two-sample KS statistics must be far below the 0.122 critical value (alpha = 0.001, 512 vs 512)."""
+    _need_gpu()
+    from scipy.stats import ks_2samp
+    from oracle.oracle import OracleSim
+    n, m, steps = 4096, 512, 400
+    w, b = _population(n)
+    env = _make(n, solver_iters=K)
+    env.reset(ETG_w=w, ETG_b=b)
+    x0 = env.get_state()[:, 0].cpu().numpy()
+    ret_g, ln_g = env.rollout_openloop(steps)
+    ret_g, ln_g = ret_g.cpu().numpy().astype(np.float64), ln_g.cpu().numpy()
+    dx_g = env.get_state()[:, 0].cpu().numpy() - x0
+    orc = OracleSim(A.default_config(m, solver_iters=K), threads=os.cpu_count() or 1)
+    orc.set_params(etg_w=w[:m].double().cpu().numpy(), etg_b=b[:m].double().cpu().numpy())
+    orc.reset()
+    x0o = orc.get_state()[:, 0].copy()
+    ret_o, ln_o = orc.run_steps(steps)
+    dx_o = orc.get_state()[:, 0] - x0o
+    surv = lambda ln, t: float((ln > t).mean())
+    grid = list(range(25, steps, 25))
+    gap = max(abs(surv(ln_g[:m], t) - surv(ln_o, t)) for t in grid)
+    gap_full = max(abs(surv(ln_g, t) - surv(ln_o, t)) for t in grid)
+    agree = float((np.abs(ln_g[:m] - ln_o) <= 1).mean())
+    ks_len, ks_ret = ks_2samp(ln_g[:m], ln_o).statistic, ks_2samp(ret_g[:m], ret_o).statistic
+    alive = (ln_g[:m] == steps) & (ln_o == steps)
+    ks_dx = ks_2samp(dx_g[:m][alive], dx_o[alive]).statistic if alive.sum() > 20 else 0.0
+    _say("K=%d survivors gpu %.3f (full %.3f) oracle %.3f | survival-curve gap %.4f (full batch %.4f) | same length +-1: %.3f | "
+         "KS len %.4f ret %.4f dx %.4f | mean return gpu %.2f oracle %.2f" %
+         (K, surv(ln_g[:m], steps - 1), surv(ln_g, steps - 1), surv(ln_o, steps - 1), gap, gap_full, agree, ks_len, ks_ret,
+          ks_dx, ret_g[:m].mean(), ret_o.mean()))
+    assert np.isfinite(ret_g).all()
+    assert gap < 0.03                                   # survival curves of the same 512 robots
+    assert gap_full < 0.08                              # full batch vs the sample: + sampling error of 512 draws (3 sigma = 0.066)
+    assert agree > 0.90                                 # most robots end their episode at the same control step (+-1)
+    assert ks_len < 0.06 and ks_ret < 0.06 and ks_dx < 0.10
+    assert abs(ret_g[:m].mean() - ret_o.mean()) < 0.05 * ret_o.std()
+    env.close()
+
+
+def test_auto_reset_boolean_masks_and_force_columns():
+    """step(auto_reset): robots whose episode ended restart from the settle cache with the reset observation, flagged in
+    info['reset']; reset(env_ids=<bool mask>) resets exactly the masked robots; a set external force survives random
+    pushes and their clearing."""
+    _need_gpu()
+    n = 64
+    W, B = _etg_params(n, seed=9)
+    env = _make(n, auto_reset=True)
+    ref = _make(n)
+    obs0, _ = ref.reset(ETG_w=W, ETG_b=B)
+    obs0 = obs0.clone()
+    env.reset(ETG_w=W, ETG_b=B)
+    seen = torch.zeros(n, dtype=torch.bool, device="cuda:0")
+    limp = torch.zeros(n, 12, device="cuda:0"); limp[::2, 1::3] = 1.5          # every other robot is driven into a fall
+    for k in range(40):
+        obs, rew, done, info = env.step(limp)
+        r = info["reset"]
+        assert torch.equal(r, done)
+        if r.any():
+            assert torch.equal(obs[r], obs0[r])                                 # the reset observation, bit-identical
+            _, ln = env.episode_stats()
+            assert int(ln[r].max()) == 0
+        seen |= r
+    assert seen[::2].float().mean() > 0.5 and torch.isfinite(env.obs).all()
+    # boolean masks
+    m = torch.zeros(n, dtype=torch.bool, device="cuda:0"); m[5] = m[17] = True
+    before = env.get_state().clone()
+    env.reset(env_ids=m)
+    after = env.get_state()
+    changed = (before != after).any(dim=1)
+    assert torch.equal(changed, m)
+    with pytest.raises(ValueError):
+        env.reset(env_ids=torch.zeros(n - 1, dtype=torch.bool, device="cuda:0"))
+    env.close(); ref.close()
+    # set force + random pushes
+    e = _make(n, random_param={"random_force": 1}, sensor_mode={"force_vec": 1}, random_force_prob=1.0)
+    f = torch.zeros(n, 3, device="cuda:0"); f[:, 1] = 3.0
+    e.set_external_force(f)
+    obs, _ = e.reset()
+    assert torch.equal(obs[:, 49:52], f)
+    obs, _, _, _ = e.step(None)
+    push = obs[:, 49:52] - f
+    assert (push[:, :2].norm(dim=1) >= 5.0 - 1e-3).all() and push[:, 2].abs().max() == 0     # a push on top of the set force
+    obs, _ = e.reset()                                                           # clears the pushes, keeps the set force
+    assert torch.equal(obs[:, 49:52], f)
+    e.close()
+
+
+def test_simple_ga_on_device_matches_reference_trace(golden):
+    """SimpleGA (alg/es.py:214-326) with the population on the GPU replays the reference's seeded ask/tell trace (ga.npz)."""
+    _need_gpu()
+    from paddlerobotics_amd.es import SimpleGA
+    g = golden("ga")
+    ga = SimpleGA(12, sigma_init=0.02, sigma_decay=0.99, sigma_limit=0.005, elite_ratio=0.1, weight_decay=0.005,
+                  popsize=40, param=np.zeros(12), device="cuda:0")
+    np.random.seed(123)
+    for it in range(3):
+        normal = np.random.randn(40, 12)
+        parents = np.zeros((40, 2), dtype=np.int64)
+        mate_u = np.zeros((40, 12))
+        for i in range(40):
+            parents[i, 0] = np.random.choice(range(4))
+            parents[i, 1] = np.random.choice(range(4))
+            if it > 0:
+                mate_u[i] = np.random.rand(12)
+        sol = ga.ask(draws=(normal, parents, mate_u))
+        assert sol.is_cuda and np.allclose(sol.cpu().numpy(), g["sol%d" % it], atol=1e-14), it
+        ga.tell(torch.as_tensor(g["fit%d" % it], device="cuda:0"))
+        assert np.allclose(ga.elite_params.cpu().numpy(), g["elite%d" % it], atol=1e-14)
+        assert np.allclose(ga.elite_rewards.cpu().numpy(), g["elite_rewards%d" % it], atol=1e-12)
+        assert np.allclose(ga.best_param.cpu().numpy(), g["best%d" % it], atol=1e-14)
+        assert abs(ga.sigma - float(g["sigma%d" % it])) < 1e-15
+
+
+def test_dynamics_identification_evaluator(golden):
+    """The batched RemoteESAgent.batch_sample_episodes (Dynamic_parallel_model.py:53-77): the true dynamic parameters
+    score best, and the recorded sequences the evaluator builds its loss from equal the oracle's replay."""
+    _need_gpu()
+    from paddlerobotics_amd import rollout as R
+    n, T = 32, 40
+    g = golden("etg")
+    # two "recorded gaits" (joint targets): the reference's ETG gait rows (pose + action) and the standing pose
+    etg_rows = np.zeros((T, 12))
+    etg_rows[:] = POSE
+    rows = {int(r): a for r, a in zip(g["exp_rows"], g["exp_act"])}
+    last = np.zeros(12)
+    for k in range(T):
+        last = rows.get(k, last)
+        etg_rows[k] = POSE + last
+    gait = {"exp": etg_rows, "ori": np.tile(POSE[None], (T, 1))}
+    rng = np.random.default_rng(12)
+    truth = rng.uniform(-0.3, 0.3, size=48)
+    # "real robot" recording: the oracle with the true parameters
+    orc = _oracle(1, enable_etg=0)
+    mean_dict = {}
+    for key in ("exp", "ori"):
+        orc.set_params(dyn=A.param2dynamic_rows(truth[None]))
+        orc.reset()
+        mot, dr = [], []
+        for i in range(T):
+            _, _, _, info = orc.step((gait[key][i] - POSE)[None])
+            mot.append(info[0, 21:33]); dr.append(info[0, 36:39])
+        mean_dict[key + "_motor_mean"], mean_dict[key + "_drpy_mean"] = np.array(mot), np.array(dr)
+        mean_dict[key + "_motor_std"], mean_dict[key + "_drpy_std"] = np.full((T, 12), 0.05), np.full((T, 3), 0.5)
+    env = _make(n, ETG=0)
+    evaluate = R.make_dynamics_id_evaluator(env, gait, mean_dict, e_steps=T)
+    cand = rng.uniform(-0.6, 0.6, size=(n, 48))
+    cand[0] = truth
+    fit = evaluate(torch.as_tensor(cand)).cpu().numpy()
+    _say("dynamics-ID fitness: truth %.3f, others max %.3f median %.3f" % (fit[0], fit[1:].max(), np.median(fit[1:])))
+    assert fit[0] > 29.9 and fit[0] >= fit.max() - 1e-6          # 30 - loss, loss ~ 0 at the true parameters
+    assert np.median(fit[1:]) < fit[0] - 0.05
+    with pytest.raises(ValueError):
+        R.make_dynamics_id_evaluator(_make(4), gait, mean_dict)
+    env.close()
