@@ -85,6 +85,26 @@ def cpu_baseline(n_envs, steps, threads):
     return n_envs * steps / dt
 
 
+def usable_cpus():
+    """host threads this process may actually run on: the affinity mask, capped by the cgroup CPU quota if there is one"""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            txt = open(path).read().split()
+            if path.endswith("cpu.max"):
+                if txt[0] != "max":
+                    quota = float(txt[0]) / float(txt[1])
+            else:
+                q = float(txt[0])
+                if q > 0:
+                    quota = q / float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            break
+        except Exception:                                           # noqa: BLE001
+            continue
+    return n, quota
+
+
 def max_over_ranks(seconds, dist, dev):
     if dist is None:
         return seconds
@@ -407,15 +427,23 @@ def main():
                                       "peak": peak, "unit": "TFLOP/s", "frac": flops / (pol_ms * 1e-3) / 1e12 / peak,
                                       "kernel_ms": pol_ms, "dtype": "f32" if args.precision == 0 else "bf16"}
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is an N = 1 exercise
-            cores = os.cpu_count() or 1
+            logical = os.cpu_count() or 1
+            affinity, quota = usable_cpus()
             one = cpu_baseline(64, 60, 1)
-            n_all, s_all = max(64, 16 * cores), 100
-            allc = cpu_baseline(n_all, s_all, cores)
+            # the box reports `logical` CPUs, but a container may be allowed fewer (affinity mask / cgroup quota): probe the
+            # thread count instead of trusting cpu_count(), and report the best figure with the threads that produced it
+            n_all, s_all = max(64, 16 * logical), 50
+            cand = sorted({t for t in (logical, affinity, int(quota) if quota else 0, 128, 64, 32, 16) if 1 <= t <= logical}, reverse=True)
+            probe = {t: cpu_baseline(n_all, s_all, t) for t in cand}
+            cores = max(probe, key=probe.get)
+            allc = probe[cores]
             out["cpu_baseline"] = {"value": allc, "unit": "env-steps/s", "cores": cores, "kind": "port",
                                    "sample": "oracle/etgsim_oracle.cpp fp64, %d envs x %d steps on %d persistent threads (each runs "
-                                             "its robots through all the steps); single-thread: %.0f env-steps/s (64 envs x 60 steps)" %
-                                             (n_all, s_all, cores, one),
+                                             "its robots through all the steps; best of the thread counts probed); single-thread: "
+                                             "%.0f env-steps/s (64 envs x 60 steps)" % (n_all, s_all, cores, one),
                                    "single_thread": one,
+                                   "host": {"logical_cpus": logical, "affinity_cpus": affinity, "cgroup_cpu_quota": quota,
+                                            "threads_probed": {str(t): v for t, v in probe.items()}},
                                    "gpu_over_cpu": value / allc,
                                    "gpu_over_cpu_denominator": "port (this repo's fp64 oracle on all host threads); pybullet itself is "
                                                                "not available on the box, so the >=100x-over-pybullet clause is unmeasured"}

@@ -155,8 +155,8 @@ typedef struct EtgConfig {
   /* knee contacts (Bullet collides every link shape; here, besides the four foot spheres): when
    * != 0, a sphere of knee_radius at every knee (the calf joint origin, attached to the thigh) collides with the
    * ground through one frictionless normal row per leg, solved in the same projected Gauss-Seidel sweep right
-   * after the leg's foot rows. Served by the heightfield instantiations of the 16-lanes-per-robot kernels
-   * (terrain = 1; a flat heightfield is fine): the free 4th lane of every leg owns the row.               */
+   * after the leg's foot rows. Served by the 16-lanes-per-robot kernels (flat ground and heightfield): the free
+   * 4th lane of every leg owns the row.                                                                   */
   int32_t body_contacts;
   double knee_radius;
   /* `ETG` kwarg of make_env (train.py:305-309, Dynamic_parallel_model.py:49 runs with ETG=0): 0 switches the
@@ -228,6 +228,12 @@ int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* stream);
  * done [N] uint8, info [N,64] or NULL.                                       */
 int etg_step(EtgHandle* h, const float* action, const uint8_t* donef, float* obs,
              float* reward, uint8_t* done, float* info, void* stream);
+/* etg_step followed by the reset of every robot whose `done` byte the step set (Gym-style auto-reset, on the device,
+ * no host synchronisation): obs rows of those robots hold their reset observation, reward / done / info rows the
+ * finished step.  While every robot has a cached settle (after a full etg_reset, until dynamic parameters, terrain or
+ * heightfield start offsets change) this is one extra launch; otherwise it runs etg_reset(mask = done).             */
+int etg_step_autoreset(EtgHandle* h, const float* action, const uint8_t* donef, float* obs,
+                       float* reward, uint8_t* done, float* info, void* stream);
 /* per-robot episode statistics since the robot's last reset: return (sum of
  * rewards) and length (steps), both frozen after the first `done` (alive
  * masking; the batched counterpart of train.py:213-249 / pretrain.py:129-154).

@@ -16,16 +16,21 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB = None
 
 
-def build(force=False):
-    so = os.path.join(_HERE, "libetgsim_oracle.so")
-    src = os.path.join(_HERE, "etgsim_oracle.cpp")
-    hdr = os.path.join(_HERE, "..", "include", "etgsim.h")
+def build(force=False, target="libetgsim_oracle.so"):
+    so = os.path.join(_HERE, target)
+    srcs = [os.path.join(_HERE, "etgsim_oracle.cpp"), os.path.join(_HERE, "..", "include", "etgsim.h")]
+    if target == "libetgsim_cpu.so":
+        srcs.append(os.path.join(_HERE, "etgsim_cpu_abi.cpp"))
     stale = (not os.path.exists(so)) or any(
-        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(so) for p in (src, hdr))
+        os.path.exists(p) and os.path.getmtime(p) > os.path.getmtime(so) for p in srcs)
     if force or stale:
-        subprocess.check_call(["make", "-C", _HERE, "-B", "libetgsim_oracle.so"],
-                              stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, "-B", target], stdout=subprocess.DEVNULL)
     return so
+
+
+def build_cpu_abi(force=False):
+    """oracle/libetgsim_cpu.so: the C-ABI of include/etgsim.h on host pointers, device = -1 (etgsim_cpu_abi.cpp)"""
+    return build(force, "libetgsim_cpu.so")
 
 
 def lib():

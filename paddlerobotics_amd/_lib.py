@@ -15,7 +15,7 @@ SYMBOLS = [
     "etg_set_heightfield", "etg_set_external_force", "etg_random_pushes", "etg_clear_pushes", "etg_set_reset_offsets", "etg_set_sensor_noise", "etg_reset", "etg_step", "etg_episode_stats", "etg_rollout_openloop",
     "etg_get_state",
     "etg_set_state", "etg_policy_create", "etg_policy_load", "etg_policy_forward", "etg_policy_load_std", "etg_policy_sample",
-    "etg_policy_destroy", "etg_rollout_policy", "etg_fit_etg", "etg_leg_kinematics", "etg_extra_sensors",
+    "etg_policy_destroy", "etg_rollout_policy", "etg_fit_etg", "etg_leg_kinematics", "etg_extra_sensors", "etg_step_autoreset",
 ]
 
 
@@ -53,6 +53,7 @@ def load():
     lib.etg_set_sensor_noise.argtypes = [vp, vp, C.c_uint64]
     lib.etg_reset.argtypes = [vp, vp, vp, vp]
     lib.etg_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.etg_step_autoreset.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     lib.etg_episode_stats.argtypes = [vp, vp, vp, vp]
     lib.etg_rollout_openloop.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.etg_get_state.argtypes = [vp, vp, vp]

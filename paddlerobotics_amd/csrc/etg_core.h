@@ -561,6 +561,43 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   L.qd[2] = qds3 + HJ[0][2] * l0 + HJ[1][2] * l1 + HJ[2][2] * l2 - dot(P3, dB);
   L.lam[0] = l0; L.lam[1] = l1; L.lam[2] = l2;
   L.contact = sel_(act && (l0 > zero), one, zero);
+  // ---- joint-limit stops (EtgConfig.joint_limits; same model as physics_tick16 and the oracle)
+  if (!Ctx::kPlain && K.jlim) {
+    F jt[3], hitf[3];
+    auto anyhit = c.lane_is(0) && !c.lane_is(0);   // all-false mask
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const F lo(K.jlo[j]), hi(K.jhi[j]);
+      const F pen = sel_(L.q[j] > hi, L.q[j] - hi, sel_(L.q[j] < lo, L.q[j] - lo, zero));
+      jt[j] = -(F(K.erp) * pen * F(1.0f / K.dt));
+      const auto hit = ((pen > zero) && (L.qd[j] > jt[j])) || ((pen < zero) && (L.qd[j] < jt[j]));
+      hitf[j] = sel_(hit, one, zero);
+      anyhit = anyhit || hit;
+    }
+    if (c.any(anyhit)) {
+      const W Pc[3] = {P1, P2, P3};
+      const F Hd[3] = {Hi11, Hi22, Hi33};
+      F pj[3];
+      W zsum = {{zero, zero, zero}, {zero, zero, zero}};
+#pragma unroll
+      for (int j = 0; j < 3; j++) {
+        F z6[6] = {Pc[j].a.x, Pc[j].a.y, Pc[j].a.z, Pc[j].l.x, Pc[j].l.y, Pc[j].l.z};
+        fwd6(s, z6);
+        const W zj = cmul(W{{z6[0], z6[1], z6[2]}, {z6[3], z6[4], z6[5]}}, sqv);
+        pj[j] = hitf[j] * (jt[j] - L.qd[j]) * rcp_(Hd[j] + dot(zj, zj));
+        zsum = zsum - pj[j] * zj;
+      }
+      const W djs = cmul(W{{c.qsum(zsum.a.x), c.qsum(zsum.a.y), c.qsum(zsum.a.z)}, {c.qsum(zsum.l.x), c.qsum(zsum.l.y), c.qsum(zsum.l.z)}}, sqv);
+      F dj[6] = {djs.a.x, djs.a.y, djs.a.z, djs.l.x, djs.l.y, djs.l.z};
+      bwd6(s, dj);
+      const W dJ = {{dj[0], dj[1], dj[2]}, {dj[3], dj[4], dj[5]}};
+      L.wb = L.wb + dJ.a;
+      L.vb = L.vb + dJ.l;
+      L.qd[0] = L.qd[0] + (Hi11 * pj[0] + Hi12 * pj[1] + Hi13 * pj[2]) - dot(P1, dJ);
+      L.qd[1] = L.qd[1] + (Hi12 * pj[0] + Hi22 * pj[1] + Hi23 * pj[2]) - dot(P2, dJ);
+      L.qd[2] = L.qd[2] + (Hi13 * pj[0] + Hi23 * pj[1] + Hi33 * pj[2]) - dot(P3, dJ);
+    }
+  }
 
   c.phase(9);
   // ---- semi-implicit Euler on positions

@@ -416,6 +416,41 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   L.lam = lam;
   const F ln_leg = c.qb(lam, 0);
   L.contact = sel_(act && (ln_leg > zero), one, zero);
+  // ---- joint-limit stops (EtgConfig.joint_limits, bounds of a1.py:186-195; the oracle's physics_tick states the model):
+  // a joint outside its range that does not yet return at the Baumgarte rate gets the joint-space impulse
+  // p = (target - qd) / (M^-1)_jj, all violated joints at once (Jacobi), applied through M^-1 = the same Schur
+  // machinery as the contact impulses: base -S^-1 sum_j P_j p_j, joints H^-1 p - P^T dB.  Rare: the whole block sits
+  // behind one wave-uniform test.
+  if (!Ctx::kPlain && K.jlim) {
+    const F lo = sel_(s0, F(K.jlo[0]), sel_(s1, F(K.jlo[1]), F(K.jlo[2])));
+    const F hi = sel_(s0, F(K.jhi[0]), sel_(s1, F(K.jhi[1]), F(K.jhi[2])));
+    const F pen = sel_(L.q > hi, L.q - hi, sel_(L.q < lo, L.q - lo, zero));
+    const F jt = -(F(K.erp) * pen * F(1.0f / K.dt));
+    const auto hit = ((pen > zero) && (L.qd > jt)) || ((pen < zero) && (L.qd < jt));
+    const F hitf = mj * sel_(hit, one, zero);
+    if (c.any(hitf > F(0.5f))) {
+      F z6[6] = {P.a.x, P.a.y, P.a.z, P.l.x, P.l.y, P.l.z};
+      fwd6(s, z6);
+      const W zj = cmul(W{{z6[0], z6[1], z6[2]}, {z6[3], z6[4], z6[5]}}, sqv);
+      const F wjj = (f0 * Hi11 + f1 * Hi22 + f2 * Hi33) + dot(zj, zj) + (one - mj);    // (M^-1)_jj; 1 on the aux lane
+      const F pj = hitf * (jt - L.qd) * rcp_(wjj);
+      F dj[6];
+#pragma unroll
+      for (int k = 0; k < 6; k++) dj[k] = -(pj * comp(zj, k));
+      c.sum16x6(dj);
+      {
+        const W djs = cmul(W{{dj[0], dj[1], dj[2]}, {dj[3], dj[4], dj[5]}}, sqv);
+#pragma unroll
+        for (int k = 0; k < 6; k++) dj[k] = comp(djs, k);
+      }
+      bwd6(s, dj);
+      const W dJ = {{dj[0], dj[1], dj[2]}, {dj[3], dj[4], dj[5]}};
+      L.wb = L.wb + dJ.a;
+      L.vb = L.vb + dJ.l;
+      const F p0 = c.qb(pj, 0), p1 = c.qb(pj, 1), p2 = c.qb(pj, 2);
+      L.qd = L.qd + mj * ((h0 * p0 + h1 * p1 + h2 * p2) - dot(P, dJ));
+    }
+  }
   c.phase(9);
   // ---- semi-implicit Euler
   L.q = L.q + dt * L.qd;

@@ -241,6 +241,29 @@ __global__ void __launch_bounds__(BLOCK) k_finish(KCfg K, DevState D, const uint
   store_state(c, D.base, D.leg, L);
 }
 
+// auto-reset of the robots flagged in `mask` (the `done` bytes a step just wrote) when every robot has a cached settle:
+// cached state -> registers, first observation and control state from the CACHED ring (reset_finish), cached ring ->
+// live ring, pending random push cleared.  One launch instead of etg_reset's settle / cache_sync / cache_mark / finish.
+template <bool FLAT, bool PLAIN>
+__global__ void __launch_bounds__(BLOCK) k_autoreset(KCfg K, DevState D, const uint8_t* mask, float* obs) {
+  GpuCtxT<FLAT, PLAIN> c;
+  if (!make_ctx(K, c)) return;
+  if (!mask[c.env]) return;                                   // whole quads drop out together
+  __shared__ float lds_par[PR_N * BLOCK];
+  stage_params(c, D, lds_par);
+  LaneState<float> L = load_state<float>(c, D.cache_base, D.cache_leg);
+  const int N = K.n_env;
+  L.p.x += D.reset_off[c.env] - D.cache_off[c.env];          // non-zero only on flat ground (settle_cached)
+  L.p.y += D.reset_off[N + c.env] - D.cache_off[N + c.env];
+  reset_finish(c, K, L, D.cache_ring, D.ctl, D.ictl, D.legctl, D.etgp, obs);
+  store_state(c, D.base, D.leg, L);
+  for (int w = 0; w < RING * 8; w++) D.ring[(size_t)w * c.NL + c.gid] = D.cache_ring[(size_t)w * c.NL + c.gid];
+  if (c.lane == 0) {
+    D.ictl[(size_t)IC_PUSH_LEFT * N + c.env] = 0;
+    for (int k = 0; k < 3; k++) D.ctl[(size_t)(CT_PUSH + k) * N + c.env] = 0.0f;
+  }
+}
+
 template <bool FLAT, bool PLAIN>
 __global__ void __launch_bounds__(BLOCK) k_step(KCfg K, DevState D, const float* action, const uint8_t* donef, float* obs,
                                                  float* reward, uint8_t* done, float* info) {
@@ -520,6 +543,26 @@ __global__ void __launch_bounds__(BLOCK) k_finish16(KCfg K, DevState D, const ui
   store_state16(c, D.base, D.leg, L);
 }
 
+// the 16-lanes-per-robot auto-reset (see k_autoreset): the 4 sub-lanes of a leg share the copy of its ring column
+template <bool FLAT, bool KNEE, bool PLAIN>
+__global__ void __launch_bounds__(BLOCK) k_autoreset16(KCfg K, DevState D, const uint8_t* mask, float* obs) {
+  __shared__ float lds_par[LDS16_FIELDS * BLOCK];
+  GpuCtx16T<FLAT, KNEE, PLAIN> c;
+  if (!make_ctx16(K, D, c, lds_par)) return;
+  if (!mask[c.env]) return;                                   // whole rows drop out together
+  State16<float> L = load_state16<float>(c, D.cache_base, D.cache_leg);
+  const int N = K.n_env;
+  L.p.x += D.reset_off[c.env] - D.cache_off[c.env];
+  L.p.y += D.reset_off[N + c.env] - D.cache_off[N + c.env];
+  reset_finish16(c, K, L, D.cache_ring, D.ctl, D.ictl, D.legctl, D.etgp, obs);
+  store_state16(c, D.base, D.leg, L);
+  for (int w = c.sub; w < RING * 8; w += 4) D.ring[(size_t)w * c.NL + c.col] = D.cache_ring[(size_t)w * c.NL + c.col];
+  if (c.r == 0) {
+    D.ictl[(size_t)IC_PUSH_LEFT * N + c.env] = 0;
+    for (int k = 0; k < 3; k++) D.ctl[(size_t)(CT_PUSH + k) * N + c.env] = 0.0f;
+  }
+}
+
 template <bool FLAT, bool KNEE, bool PLAIN>
 __global__ void __launch_bounds__(BLOCK) k_step16(KCfg K, DevState D, const float* action, const uint8_t* donef, float* obs,
                                                    float* reward, uint8_t* done, float* info) {
@@ -787,6 +830,8 @@ struct EtgHandle {
   unsigned obs_calls;             // stream position of the sensor noise: observations written so far
   bool was_reset;                 // etg_step before the first etg_reset is a caller error (state undefined)
   bool fext_set, push_on;         // a set force / random pushes are installed: K.ext_force = fext_set || push_on
+  bool all_cached;                // every robot has a valid cached settle (true after a full etg_reset until parameters,
+                                  // terrain or -- on a heightfield -- start offsets change): etg_step_autoreset's fast path
   float *tmp_obs, *tmp_reward;  // sinks for etg_rollout_openloop
   uint8_t* tmp_done;
 };
@@ -829,6 +874,7 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   h->obs_calls = 0;
   h->was_reset = false;
   h->fext_set = h->push_on = false;
+  h->all_cached = false;
   if (cfg->lanes_per_robot != 0 && cfg->lanes_per_robot != 4 && cfg->lanes_per_robot != 16) {
     delete h;
     return fail(ETG_ERR_BAD_ARG, "etg_create: lanes_per_robot must be 4 or 16");
@@ -837,10 +883,10 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   // at a time: 16 lanes/robot fills it with 4096 robots and is faster per robot up to there; beyond
   // that the 4-lanes/robot kernel packs 4x the robots per wave (measured crossover).
   h->lanes = cfg->lanes_per_robot != 0 ? cfg->lanes_per_robot : (cfg->num_envs <= 4096 ? 16 : 4);
-  if (cfg->body_contacts) {   // the knee rows live on the 4th lane of every leg of the 16-lane heightfield kernels
-    if (cfg->terrain != 1 || cfg->lanes_per_robot == 4) {
+  if (cfg->body_contacts) {   // the knee rows live on the 4th lane of every leg of the 16-lane kernels
+    if (cfg->lanes_per_robot == 4) {
       delete h;
-      return fail(ETG_ERR_BAD_ARG, "etg_create: body_contacts needs terrain = 1 (a flat heightfield will do) and the 16-lanes-per-robot mapping");
+      return fail(ETG_ERR_BAD_ARG, "etg_create: body_contacts needs the 16-lanes-per-robot mapping");
     }
     h->lanes = 16;
   }
@@ -897,12 +943,12 @@ static inline void launch_obs_noise(EtgHandle* h, int n, const uint8_t* mask, fl
   hipLaunchKernelGGL(k_add_noise, dim3((16 * h->N + 255) / 256), dim3(256), 0, s, h->K, h->K.noise_call + (unsigned)(n - 1), mask, obs);
 }
 
-// the instantiations of a 16-lane kernel: {flat ground, heightfield} x {plain robot layer, all options}, and
-// heightfield + knee rows
+// the instantiations of a 16-lane kernel: {flat ground, heightfield} x {plain robot layer, all options, all options + knee rows}
 #define LAUNCH16(KERN, grid, stream, ...)                                                                             \
   do {                                                                                                                \
     const bool pl_ = plain_config(h->K);                                                                              \
     if (h->K.terrain == 0 && pl_) hipLaunchKernelGGL((KERN<true, false, true>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);   \
+    else if (h->K.terrain == 0 && h->K.knee) hipLaunchKernelGGL((KERN<true, true, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__); \
     else if (h->K.terrain == 0) hipLaunchKernelGGL((KERN<true, false, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);   \
     else if (h->K.knee) hipLaunchKernelGGL((KERN<false, true, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);           \
     else if (pl_) hipLaunchKernelGGL((KERN<false, false, true>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);                 \
@@ -927,6 +973,7 @@ extern "C" int etg_set_params(EtgHandle* h, const float* dyn, const float* etg_w
                               const uint8_t* mask, void* stream) {
   CHECK_HANDLE(h);
   if ((etg_w == nullptr) != (etg_b == nullptr)) return fail(ETG_ERR_BAD_ARG, "etg_set_params: pass both etg_w and etg_b or neither");
+  if (dyn) h->all_cached = false;   // the settle depends on the dynamic parameters
   hipLaunchKernelGGL(k_set_params, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->M, h->D, dyn, etg_w,
                      etg_b, per_env, mask);
   HIP_TRY(hipGetLastError());
@@ -940,6 +987,7 @@ extern "C" int etg_set_heightfield(EtgHandle* h, const float* heights, void* str
   if (!h->hf && hipMalloc((void**)&h->hf, bytes) != hipSuccess) return fail(ETG_ERR_ALLOC, "etg_set_heightfield: hipMalloc failed");
   HIP_TRY(hipMemcpyAsync(h->hf, heights, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   HIP_TRY(hipMemsetAsync(h->D.cache_ok, 0, h->N, (hipStream_t)stream));   // the settle depends on the terrain
+  h->all_cached = false;
   h->K.hf = h->hf;
   return ETG_OK;
 }
@@ -1005,6 +1053,7 @@ extern "C" int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* st
   }
   launch_obs_noise(h, 1, mask, obs, s);
   HIP_TRY(hipGetLastError());
+  if (!mask) h->all_cached = true;
   return ETG_OK;
 }
 
@@ -1030,6 +1079,7 @@ extern "C" int etg_set_reset_offsets(EtgHandle* h, const float* xy, const uint8_
   CHECK_HANDLE(h);
   hipLaunchKernelGGL(k_set_reset_offsets, dim3((h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->D, xy, mask);
   HIP_TRY(hipGetLastError());
+  if (h->K.terrain != 0) h->all_cached = false;   // a heightfield settle is only valid at the offset it ran at
   return ETG_OK;
 }
 
@@ -1047,6 +1097,26 @@ extern "C" int etg_step(EtgHandle* h, const float* action, const uint8_t* donef,
     LAUNCH4(k_step, dim3(grid_for(h)), (hipStream_t)stream, h->K, h->D, action, donef, obs, reward, done, info);
   }
   launch_obs_noise(h, 1, nullptr, obs, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return ETG_OK;
+}
+
+extern "C" int etg_step_autoreset(EtgHandle* h, const float* action, const uint8_t* donef, float* obs, float* reward,
+                                  uint8_t* done, float* info, void* stream) {
+  int rc = etg_step(h, action, donef, obs, reward, done, info, stream);
+  if (rc != ETG_OK) return rc;
+  if (!h->all_cached) {   // some robot needs a simulated settle: the general reset path, masked by the done bytes
+    if (h->push_on && (rc = etg_clear_pushes(h, done, stream)) != ETG_OK) return rc;
+    return etg_reset(h, done, obs, stream);
+  }
+  advance_obs_stream(h, 1);
+  hipStream_t s = (hipStream_t)stream;
+  if (h->lanes == 16) {
+    LAUNCH16(k_autoreset16, dim3((h->N + 3) / 4), s, h->K, h->D, done, obs);
+  } else {
+    LAUNCH4(k_autoreset, dim3(grid_for(h)), s, h->K, h->D, done, obs);
+  }
+  launch_obs_noise(h, 1, done, obs, s);
   HIP_TRY(hipGetLastError());
   return ETG_OK;
 }
@@ -1118,6 +1188,7 @@ extern "C" int etg_rollout_policy(EtgHandle* h, EtgPolicy* pol, int n_steps, flo
     else hipLaunchKernelGGL((k_rollout_policy16<F_, true, K_, P_>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);    \
   } while (0)
     if (flat && pl) LAUNCH_POLICY16(true, false, true);
+    else if (flat && kn) LAUNCH_POLICY16(true, true, false);
     else if (flat) LAUNCH_POLICY16(true, false, false);
     else if (kn) LAUNCH_POLICY16(false, true, false);
     else if (pl) LAUNCH_POLICY16(false, false, true);

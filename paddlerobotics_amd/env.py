@@ -155,9 +155,6 @@ class BatchedQuadrupedEnv:
             heightfield = make_task_heightfield(task, variants=int(terrain_variants), seed=int(terrain_seed))
         elif (task == "heightfield") != (heightfield is not None):
             raise ValueError("task='heightfield' and the heightfield= argument go together")
-        if body_contacts and heightfield is None:
-            # the knee rows live in the heightfield kernels (include/etgsim.h: body_contacts): level ground as a grid
-            heightfield = dict(heights=np.zeros((65, 65), dtype=np.float32), cell=0.5, origin=(-16.0, -16.0))
         self.task = task
         self.terrain = heightfield
         # train.py:56-58 mode_map: "pose"/"traj" -> POSITION, "torque" -> TORQUE; enum values also accepted
@@ -473,24 +470,28 @@ class BatchedQuadrupedEnv:
                     raise ValueError("donef must be a bool or have shape [N]")
         if self._rand_force:
             self._random_pushes()
-        _lib.check(self._lib.etg_step(self._h, _ptr(a), _ptr(df), _ptr(self.obs), _ptr(self.reward), _ptr(self.done),
-                                      _ptr(self.info_buf) if want_info else None, self._stream()))
+        # auto_reset: robots whose episode just ended start the next one inside the same call (settle cache -> state, control
+        # state, first observation): their rows of `obs` are the reset observation, reward / done / info are the finished
+        # step's, info["reset"] (= done) marks them.  The done bytes are read on the device: no host synchronisation.
+        # With random_dynamics the reset robots first draw new parameters, which needs the masked calls of reset().
+        fused_reset = self.auto_reset and not self._rand_dyn
+        step_fn = self._lib.etg_step_autoreset if fused_reset else self._lib.etg_step
+        _lib.check(step_fn(self._h, _ptr(a), _ptr(df), _ptr(self.obs), _ptr(self.reward), _ptr(self.done),
+                           _ptr(self.info_buf) if want_info else None, self._stream()))
         self._keep_step = (a, df)
         info = self._info() if want_info else {}
         if self.auto_reset:
-            # robots whose episode just ended start the next one now (settle cache -> state, control state, first
-            # observation): their rows of `obs` are the reset observation, reward / done / info are the last step's;
-            # info["reset"] marks them.  The mask is read on the device: no host synchronisation.
-            self._reset_mask = self.done.clone()
-            if self._rand_force:
-                _lib.check(self._lib.etg_clear_pushes(self._h, _ptr(self._reset_mask), self._stream()))
-            _lib.check(self._lib.etg_reset(self._h, _ptr(self._reset_mask), _ptr(self.obs), self._stream()))
+            if not fused_reset:
+                if self._hist_T > 0:
+                    self._obs_view()                                         # the terminal reading enters the history first
+                self._reset_mask = self.done.clone()
+                self.reset(env_ids=self._reset_mask)
             if want_info:
-                info["reset"] = self._reset_mask.view(torch.bool)
-            if self._hist_T > 0:
+                info["reset"] = self.done.view(torch.bool)
+            if self._hist_T > 0 and fused_reset:
                 self._obs_view()                                             # the terminal reading enters the history ...
-                self._last_view = self._obs_view(reset_mask=self._reset_mask, first=True)   # ... and is cleared for the reset robots
-            else:
+                self._last_view = self._obs_view(reset_mask=self.done, first=True)   # ... and is cleared for the reset robots
+            elif fused_reset:
                 self._last_view = self._obs_view()
         else:
             self._last_view = self._obs_view()

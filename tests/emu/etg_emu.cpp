@@ -254,6 +254,7 @@ extern "C" void emu_reset(void* h, const uint8_t* mask, float* obs) {
     if (e->lanes == 16) {
       const bool pl = plain_config(e->K);                       // same instantiation choice as LAUNCH16 in etg_kernels.hip
       if (e->K.terrain == 0 && pl) emu_reset16<EmuCtx16T<true, false, true>>(e, i, obs, ox, oy);
+      else if (e->K.terrain == 0 && e->K.knee) emu_reset16<EmuCtx16T<true, true>>(e, i, obs, ox, oy);
       else if (e->K.terrain == 0) emu_reset16<EmuCtx16T<true>>(e, i, obs, ox, oy);
       else if (e->K.knee) emu_reset16<EmuCtx16T<false, true>>(e, i, obs, ox, oy);
       else if (pl) emu_reset16<EmuCtx16T<false, false, true>>(e, i, obs, ox, oy);
@@ -277,6 +278,7 @@ extern "C" void emu_step(void* h, const float* action, const uint8_t* donef, flo
       F16 dn(donef ? (float)donef[i] : 0.f);
       const bool pl = plain_config(e->K);
       if (e->K.terrain == 0 && pl) emu_step16<EmuCtx16T<true, false, true>>(e, i, action, dn, obs, r16, d16, info);
+      else if (e->K.terrain == 0 && e->K.knee) emu_step16<EmuCtx16T<true, true>>(e, i, action, dn, obs, r16, d16, info);
       else if (e->K.terrain == 0) emu_step16<EmuCtx16T<true>>(e, i, action, dn, obs, r16, d16, info);
       else if (e->K.knee) emu_step16<EmuCtx16T<false, true>>(e, i, action, dn, obs, r16, d16, info);
       else if (pl) emu_step16<EmuCtx16T<false, false, true>>(e, i, action, dn, obs, r16, d16, info);

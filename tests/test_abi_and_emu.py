@@ -182,3 +182,79 @@ def test_both_lane_mappings_share_one_state_layout():
         a.step(np.zeros((n, 12)))
         b.step(np.zeros((n, 12)))
     assert np.abs(a.get_state()[:, 13:25] - b.get_state()[:, 13:25]).max() < 1e-3
+
+
+def _cpu_abi():
+    from oracle import oracle as O
+    lib = C.CDLL(O.build_cpu_abi())
+    lib.etg_last_error.restype = C.c_char_p
+    vp, i32 = C.c_void_p, C.c_int
+    lib.etg_create.argtypes = [vp, vp, i32, C.POINTER(vp)]
+    lib.etg_destroy.argtypes = [vp]; lib.etg_destroy.restype = None
+    lib.etg_set_params.argtypes = [vp, vp, vp, vp, i32, vp, vp]
+    lib.etg_reset.argtypes = [vp, vp, vp, vp]
+    lib.etg_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.etg_episode_stats.argtypes = [vp, vp, vp, vp]
+    lib.etg_rollout_openloop.argtypes = [vp, i32, vp, vp, vp, vp]
+    lib.etg_get_state.argtypes = [vp, vp, vp]
+    return lib
+
+
+def test_cpu_build_of_the_same_abi_runs_config_1(golden):
+    """"a CPU build of the same ABI (device = -1) is the oracle/baseline" -- oracle/libetgsim_cpu.so exports
+    every symbol of include/etgsim.h on HOST pointers.  BASELINE configs[0]: a single A1 on flat ground, ETG open loop
+    (w0, b0 = Opt_with_points prior, train.py:298-299), action 0, 400 control steps (pretrain.py:232) through
+    etg_create(-1) / etg_set_params / etg_reset / etg_step; identical to driving the oracle directly, and the ETG
+    actions it reports reproduce the reference's recorded gait."""
+    from oracle.oracle import OracleSim
+    from paddlerobotics_amd.etg import ETG_layer, Opt_with_points
+    lib = _cpu_abi()
+    for s in _declared_symbols():
+        assert hasattr(lib, s), s
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    cfg, model = A.default_config(1), A.default_model()
+    h = C.c_void_p()
+    assert lib.etg_create(C.byref(cfg), C.byref(model), 0, C.byref(h)) == -1          # only device = -1 here
+    assert b"device = -1" in lib.etg_last_error()
+    assert lib.etg_create(C.byref(cfg), C.byref(model), -1, C.byref(h)) == 0
+    obs, rew, done = np.zeros((1, 49), np.float32), np.zeros(1, np.float32), np.zeros(1, np.uint8)
+    info = np.zeros((1, 64), np.float32)
+    assert lib.etg_step(h, None, None, p(obs), p(rew), p(done), None, None) == -5       # ETG_ERR_STATE before the first reset
+    layer = ETG_layer(0.5, 0.026, 20, 0.04, np.array([-np.pi / 2, 0]), 0.2, 0.5)
+    w0, b0, _ = Opt_with_points(layer, ETG_T=0.5, Footheight=0.1, Steplength=0.05)
+    w32, b32 = np.ascontiguousarray(w0, np.float32), np.ascontiguousarray(b0, np.float32)
+    assert lib.etg_set_params(h, None, p(w32), p(b32), 0, None, None) == 0
+    assert lib.etg_reset(h, None, p(obs), None) == 0
+    orc = OracleSim(A.default_config(1))
+    orc.set_params(etg_w=w32.astype(np.float64), etg_b=b32.astype(np.float64))
+    obs_o = orc.reset()
+    assert np.abs(obs - obs_o).max() < 1e-5
+    ret_o, alive = 0.0, True
+    for k in range(400):
+        assert lib.etg_step(h, None, None, p(obs), p(rew), p(done), p(info), None) == 0
+        oo, ro, do, io = orc.step(np.zeros((1, 12)))
+        assert np.array_equal(obs, oo.astype(np.float32)) and rew[0] == np.float32(ro[0]) and done[0] == do[0], k
+        assert np.array_equal(info, io.astype(np.float32)), k
+        if alive:
+            ret_o += ro[0]
+        alive = alive and not do[0]
+    ret, ln = np.zeros(1, np.float32), np.zeros(1, np.int32)
+    assert lib.etg_episode_stats(h, p(ret), p(ln), None) == 0
+    assert abs(ret[0] - ret_o) < 1e-3 * (1 + abs(ret_o)) and 1 <= ln[0] <= 400
+    st = np.zeros((1, 37), np.float32)
+    assert lib.etg_get_state(h, p(st), None) == 0 and np.array_equal(st, orc.get_state().astype(np.float32))
+    lib.etg_destroy(h)
+    # the recorded gait of the reference through the same ABI: info["ETG_act"] rows = gait_action_list_ETG_exp.npy
+    g = golden("etg")
+    assert lib.etg_create(C.byref(cfg), C.byref(model), -1, C.byref(h)) == 0
+    ew, eb = np.ascontiguousarray(g["exp_w"], np.float32), np.ascontiguousarray(g["exp_b"], np.float32)
+    lib.etg_set_params(h, None, p(ew), p(eb), 0, None, None)
+    lib.etg_reset(h, None, p(obs), None)
+    rows = {int(r): a for r, a in zip(g["exp_rows"], g["exp_act"])}
+    for k in range(60):
+        lib.etg_step(h, None, None, p(obs), p(rew), p(done), p(info), None)
+        if k in rows:
+            assert np.abs(info[0, 9:21] - rows[k]).max() < 2e-6, k
+    # device-only entry points say so
+    assert lib.etg_random_pushes(h, C.c_uint64(0), C.c_float(0.1), 1, C.c_float(1), C.c_float(2), None) == -5
+    lib.etg_destroy(h)

@@ -39,6 +39,12 @@ def _oracle(n, dtype=np.float64, **kw):
     return OracleSim(A.default_config(n, **kw), dtype=dtype)
 
 
+def _lt(value, bound, what):
+    """assert value < bound and print the measured value (pytest -s), so that every bound can be audited against it"""
+    print("[parity] %-70s %.3e (bound %.1e)" % (what, float(value), bound), flush=True)
+    assert value < bound, what
+
+
 def _within(err_gpu, err_o32, floor):
     """GPU-vs-fp64-oracle error per robot must stay within the trajectory's own fp32 sensitivity
     (fp32-oracle vs fp64-oracle), plus the stated floor: contact events are chaotic, so a fixed
@@ -66,28 +72,38 @@ def test_reset_and_step_match_oracle():
     obs_o = orc.reset()
     obs_g = env.obs.cpu().numpy()
     st_g, st_o = env.get_state().cpu().numpy(), orc.get_state()
-    assert np.abs(st_g[:, :7] - st_o[:, :7]).max() < 1e-3          # base pose after the 500-tick settle
-    assert np.abs(st_g[:, 13:25] - st_o[:, 13:25]).max() < 1e-3    # joint angles
-    assert np.abs(obs_g - obs_o).max() < 2e-2                      # normalised obs (x10 scales)
+    _lt(np.abs(st_g[:, :7] - st_o[:, :7]).max(), 1e-4, "base pose after the 500-tick settle")
+    _lt(np.abs(st_g[:, 13:25] - st_o[:, 13:25]).max(), 1e-4, "joint angles after the settle")
+    _lt(np.abs(obs_g - obs_o).max(), 2e-3, "reset observation (normalised, x10 / x38 scales)")
     rng = np.random.default_rng(1)
-    for k in range(20):
+    worst = dict(q=0.0, pos=0.0, quat=0.0, obs=0.0, rew=0.0)
+    same_min = 1.0
+    for k in range(40):
         act = rng.uniform(-0.1, 0.1, size=(n, 12))
         og, rg, dg, ig = env.step(torch.as_tensor(act, dtype=torch.float32))
         oo, ro, do, io = orc.step(act)
         st_g, st_o = env.get_state().cpu().numpy(), orc.get_state()
-        assert np.abs(st_g[:, 13:25] - st_o[:, 13:25]).max() < 1e-3, k
-        assert np.abs(st_g[:, :3] - st_o[:, :3]).max() < 1e-3, k
-        assert np.abs(st_g[:, 3:7] - st_o[:, 3:7]).max() < 1e-3, k
+        worst["q"] = max(worst["q"], np.abs(st_g[:, 13:25] - st_o[:, 13:25]).max())
+        worst["pos"] = max(worst["pos"], np.abs(st_g[:, :3] - st_o[:, :3]).max())
+        worst["quat"] = max(worst["quat"], np.abs(st_g[:, 3:7] - st_o[:, 3:7]).max())
         rg = rg.cpu().numpy()
         ig = env.info_buf.cpu().numpy()
         # the reward has discrete terms (foot-contact / bad-foot counts): compare it where the contact
         # pattern agrees (a contact flipping one tick earlier in fp32 moves the reward by 0.5)
         same = np.all(ig[:, 39:43] == io[:, 39:43], axis=1) & (np.abs(ig[:, 5] - io[:, 5]) < 1e-6)
-        assert same.mean() > 0.8, k
-        assert np.all(np.abs(rg - ro)[same] < 1e-3 * (1 + np.abs(ro[same])) + 2e-3), k
+        same_min = min(same_min, same.mean())
+        worst["rew"] = max(worst["rew"], (np.abs(rg - ro)[same] / (1 + np.abs(ro[same]))).max())
+        worst["obs"] = max(worst["obs"], np.abs(og.cpu().numpy() - oo)[same].max())
         assert np.array_equal(dg.cpu().numpy().astype(np.uint8), do), k
         assert np.abs(ig[:, 9:21] - io[:, 9:21]).max() < 2e-5      # ETG_act (pure function)
         assert np.abs(ig[:, 43:55] - io[:, 43:55]).max() < 2e-5    # real_action
+    # 40 control steps = 520 ticks of random residual actions (SURVEY 8d asks 1e-3 rad / 1e-3 m / 1e-3 rel)
+    _lt(worst["q"], 1e-4, "joint angles, 40 steps")
+    _lt(worst["pos"], 1e-4, "base position, 40 steps")
+    _lt(worst["quat"], 1e-4, "base orientation, 40 steps")
+    _lt(worst["rew"], 1e-3, "reward (relative, robots with the same contact pattern)")
+    _lt(worst["obs"], 2e-2, "observation rows (normalised), same contact pattern")
+    _lt(1.0 - same_min, 0.1, "worst fraction of robots whose contact flags differ in a step")
     env.close()
 
 
@@ -314,13 +330,14 @@ def test_heightfield_terrain_matches_oracle():
     orc.set_params(etg_w=W, etg_b=B)
     env.reset(ETG_w=W, ETG_b=B)
     orc.reset()
-    assert np.abs(env.get_state().cpu().numpy()[:, :7] - orc.get_state()[:, :7]).max() < 2e-3
+    _lt(np.abs(env.get_state().cpu().numpy()[:, :7] - orc.get_state()[:, :7]).max(), 2e-3, "heightfield: settle pose")
     assert orc.get_state()[:, 2].min() > 0.2
     for _ in range(5):
         env.step(None)
         orc.step(np.zeros((n, 12)))
     err = np.abs(env.get_state().cpu().numpy()[:, 13:25] - orc.get_state()[:, 13:25]).max(1)
-    assert np.median(err) < 5e-3 and err.max() < 3e-2      # C0 terrain: normals jump at cell edges
+    _lt(np.median(err), 5e-3, "heightfield: median joint error, 5 steps")
+    _lt(err.max(), 3e-2, "heightfield: max joint error, 5 steps (C0 terrain: normals jump at cell edges)")
     env.close()
 
 
@@ -388,16 +405,18 @@ def test_both_kernel_mappings_match_oracle(lanes):
     env.reset(ETG_w=W, ETG_b=B)
     orc.set_params(etg_w=W, etg_b=B)
     obs_o = orc.reset()
-    assert np.abs(env.obs.cpu().numpy() - obs_o).max() < 2e-2
-    assert np.abs(env.get_state().cpu().numpy()[:, :7] - orc.get_state()[:, :7]).max() < 1e-3
+    _lt(np.abs(env.obs.cpu().numpy() - obs_o).max(), 2e-3, "lanes=%d reset observation" % lanes)
+    _lt(np.abs(env.get_state().cpu().numpy()[:, :7] - orc.get_state()[:, :7]).max(), 1e-4, "lanes=%d settle pose" % lanes)
     rng = np.random.default_rng(2)
+    wq = wp = 0.0
     for k in range(10):
         act = rng.uniform(-0.1, 0.1, size=(n, 12))
         env.step(torch.as_tensor(act, dtype=torch.float32))
         orc.step(act)
         st_g, st_o = env.get_state().cpu().numpy(), orc.get_state()
-        assert np.abs(st_g[:, 13:25] - st_o[:, 13:25]).max() < 1e-3, k
-        assert np.abs(st_g[:, :7] - st_o[:, :7]).max() < 1e-3, k
+        wq = max(wq, np.abs(st_g[:, 13:25] - st_o[:, 13:25]).max()); wp = max(wp, np.abs(st_g[:, :7] - st_o[:, :7]).max())
+    _lt(wq, 1e-4, "lanes=%d joint angles, 10 steps" % lanes)
+    _lt(wp, 1e-4, "lanes=%d base pose, 10 steps" % lanes)
     env.close()
 
 
@@ -497,9 +516,15 @@ def test_sensor_mode_selects_observation_columns():
     o_stud2, r, d, info = stud.step(None)
     o_full2, _, _, _ = full.step(None)
     assert torch.equal(o_stud2, o_full2[:, 3:])
-    with pytest.raises(NotImplementedError):
-        _make(n, sensor_mode={"footpose": 1})
-    full.close(); stud.close()
+    # imu == 2 selects the rpy RATE alone (EnvWrapper.py:91-92), not rpy
+    rate = _make(n, sensor_mode={"imu": 2})
+    assert rate.observation_space.shape == (46,)
+    o_rate, _ = rate.reset()
+    keep = list(range(0, 7)) + list(range(10, 49))
+    assert torch.equal(o_rate, o_full[:, keep])
+    o_rate2, _, _, _ = rate.step(None)
+    assert torch.equal(o_rate2, o_full2[:, keep])
+    full.close(); stud.close(); rate.close()
 
 
 def test_torque_mode_matches_oracle():
@@ -742,11 +767,13 @@ def test_short_control_latency_reads_this_steps_ring_slots(lanes):
     orc.set_params(dyn=dyn, etg_w=W, etg_b=B)
     obs_g = env.reset(ETG_w=W, ETG_b=B)[0].cpu().numpy()
     obs_o = orc.reset()
-    assert np.abs(obs_g - obs_o).max() < 2e-2
+    _lt(np.abs(obs_g - obs_o).max(), 2e-3, "lanes=%d latency sweep: reset observation" % lanes)
+    w = 0.0
     for _ in range(4):
         og = env.step(None)[0].cpu().numpy()
         oo = orc.step(np.zeros((n, 12)))[0]
-        assert np.abs(og - oo).max() < 5e-2, np.abs(og - oo).max(1)
+        w = max(w, np.abs(og - oo).max())
+    _lt(w, 5e-3, "lanes=%d latency sweep: observations over 4 steps (normalised)" % lanes)
     env.close()
 
 
@@ -940,7 +967,8 @@ def test_knee_contacts_match_oracle():
     _need_gpu()
     n = 32
     # (1) a limp robot folds onto its knees: same trajectory as the oracle, and the knees do carry it
-    env = _make(n, motor_control_mode="torque", body_contacts=True, solver_iters=4)
+    flat_grid = dict(heights=np.zeros((65, 65), dtype=np.float32), cell=0.5, origin=(-16.0, -16.0))
+    env = _make(n, motor_control_mode="torque", body_contacts=True, solver_iters=4, task="heightfield", heightfield=flat_grid)
     assert env.lanes_per_robot == 16 and env.cfg.terrain == 1
     hf = env.terrain
     orc = _oracle(n, motor_mode=1, body_contacts=1, terrain=1, heightfield=hf, solver_iters=4)

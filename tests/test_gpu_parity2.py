@@ -11,8 +11,9 @@
     the reference trace, the dynamics-identification evaluator (Dynamic_parallel_model.py:53-77).
 
 Tolerances are stated where they are asserted.  Short-horizon trajectories are NOT chaotic here: the fp32 build of the
-oracle stays within ~1e-6 rad of the fp64 one over 15 closed-loop steps, so the bounds below are absolute (a few 1e-4:
-hardware rcp/rsq, polynomial sincos and a different summation order), not multiples of an fp32 sensitivity.
+oracle stays within ~1e-6 rad of the fp64 one over 15 closed-loop steps and so does the GPU (measured: a few 1e-6 rad;
+profiles/r02_parity_report.txt), so the bounds below are absolute and ~10x the measured error, not multiples of an
+fp32 sensitivity.
 """
 import os
 
@@ -62,8 +63,8 @@ def _oracle_closed_loop(orc, ws, steps):
 @pytest.mark.parametrize("n", [64, 4096])
 def test_closed_loop_fused_kernel_and_stepping_match_oracle(n):
     """configs[2]: etg_rollout_policy (k_rollout_policy16) and predict()+step() against the oracle's closed loop.
-    Bounds after 12 control steps (156 ticks): joint angles 1e-3 rad, base position 1e-3 m, with the
-    median an order of magnitude tighter; returns 1e-3 relative + 5e-3."""
+    Bounds after 12 control steps (156 ticks): joint angles 5e-5 rad (median 1e-5), base position 1e-5 m -- 20-100x
+    inside the 1e-3 of SURVEY 8d and ~10x the measured error; returns 1e-3 relative + 5e-3."""
     _need_gpu()
     steps = 12
     m = 64 if n == 64 else 256                      # oracle sample: the first m robots
@@ -87,9 +88,9 @@ def test_closed_loop_fused_kernel_and_stepping_match_oracle(n):
         eq = np.abs(sg - so)[:, 13:25].max(1)
         ep = np.abs(sg - so)[:, :3].max(1)
         _say(name, n, "q err median %.2e max %.2e | pos err max %.2e" % (np.median(eq), eq.max(), ep.max()))
-        assert np.median(eq) < 1e-4 and eq.max() < 1e-3, name
-        assert ep.max() < 1e-3, name
-        assert np.abs(env.obs.cpu().numpy()[:m] - obs_o)[:, 13:25].max() < 1e-2, name      # normalised angles (x10)
+        assert np.median(eq) < 1e-5 and eq.max() < 5e-5, name       # measured: median 9e-7, max 6e-6
+        assert ep.max() < 1e-5, name                                # measured: 5e-7
+        assert np.abs(env.obs.cpu().numpy()[:m] - obs_o)[:, 13:25].max() < 1e-3, name      # normalised angles (x10)
         ln = ln.cpu().numpy()[:m]; ret = ret.cpu().numpy()[:m]
         same = ln == ln_o
         assert same.mean() > 0.98, name
@@ -104,7 +105,7 @@ def test_closed_loop_fused_kernel_and_stepping_match_oracle(n):
 @pytest.mark.parametrize("option", ["filter", "interp", "clip"])
 def test_robot_layer_options_match_oracle(option, lanes):
     """enable_action_filter / enable_action_interpolation / enable_clip_motor_commands through the non-PLAIN kernels vs the
-    oracle: 10 control steps of random residual actions; joint angles 1e-3 rad, base pose 1e-3, the filtered command
+    oracle: 10 control steps of random residual actions; joint angles 5e-5 rad, base pose 2e-5, the filtered command
     (info['real_action'], a pure function of the action history) 2e-5."""
     _need_gpu()
     n = 32
@@ -129,7 +130,7 @@ def test_robot_layer_options_match_oracle(option, lanes):
         worst_q = max(worst_q, np.abs(sg - so)[:, 13:25].max()); worst_p = max(worst_p, np.abs(sg - so)[:, :7].max())
         assert np.abs(ig[:, 43:55] - io[:, 43:55]).max() < 2e-5, k          # real_action
     _say(option, lanes, "q err max %.2e, pose err max %.2e" % (worst_q, worst_p))
-    assert worst_q < 1e-3 and worst_p < 1e-3
+    assert worst_q < 5e-5 and worst_p < 2e-5              # measured: <= 2.6e-6 / 1.6e-6
     env.close()
 
 
@@ -185,11 +186,20 @@ def test_optional_sensors():
     force = rng.normal(size=(n, 3)) * 5
     env.set_external_force(torch.as_tensor(force, dtype=torch.float32))
     W, B = _etg_params(n, seed=2)
-    obs, _ = env.reset(ETG_w=W, ETG_b=B, dynamic_param=A.param2dynamic_rows(p))
+    rows = A.param2dynamic_rows(p)
+    obs, _ = env.reset(ETG_w=W, ETG_b=B, dynamic_param=rows)
+    # what the row maps back to in the [-1,1] box of param2dynamic_dict: p itself wherever the forward map did not clip
+    # (foot friction 0.2 + 10 p is clipped at 0 for p < -0.02)
+    kd0 = np.array([1., 2., 2.] * 4)
+    back = np.concatenate([(rows[:, 0:1] - 40) / 10, (rows[:, 1:2] - 0.2) / 10, rows[:, 2:3] - 1.5, rows[:, 3:21] - 1,
+                           (rows[:, 21:33] - 80) / 40, (rows[:, 33:45] - kd0) / kd0,
+                           (rows[:, 45:48] - np.array([0, 0, -10])) / np.array([2, 2, 10])], axis=1)
+    unclipped = np.ones(48, bool); unclipped[1] = False
+    assert np.abs(back - p)[:, unclipped].max() < 1e-12
     orc = _oracle(n)
     for k in range(4):
         o = obs.cpu().numpy()
-        assert np.abs(o[:, 49 + 32: 49 + 80] - p).max() < 2e-5                               # dynamic_vec: the [-1,1] box
+        assert np.abs(o[:, 49 + 32: 49 + 80] - back).max() < 2e-5                            # dynamic_vec: the [-1,1] box
         assert np.abs(o[:, 49 + 80: 49 + 83] - force).max() < 1e-5                            # force_vec
         assert np.abs(o[:, 49: 49 + 20] - orc.etg_rbf(k * 0.026)[None]).max() < 2e-5          # ETG_obs = r(t_obs)
         q_obs = o[:, 13:25] * 0.1 + POSE                                                      # observed motor angles
@@ -273,10 +283,12 @@ def test_long_horizon_statistics_match_oracle(K):
          (K, surv(ln_g[:m], steps - 1), surv(ln_g, steps - 1), surv(ln_o, steps - 1), gap, gap_full, agree, ks_len, ks_ret,
           ks_dx, ret_g[:m].mean(), ret_o.mean()))
     assert np.isfinite(ret_g).all()
-    assert gap < 0.03                                   # survival curves of the same 512 robots
-    assert gap_full < 0.08                              # full batch vs the sample: + sampling error of 512 draws (3 sigma = 0.066)
-    assert agree > 0.90                                 # most robots end their episode at the same control step (+-1)
-    assert ks_len < 0.06 and ks_ret < 0.06 and ks_dx < 0.10
+    # measured on the MI355X (profiles/r02_parity_report.txt): gap 0.002 / 0.000, full batch 0.025, agreement 0.998 / 1.000,
+    # KS 0.002 / 0.004 / 0.012-0.024
+    assert gap < 0.01                                   # survival curves of the same 512 robots
+    assert gap_full < 0.07                              # full batch vs the sample: sampling error of 512 draws (3 sigma = 0.066)
+    assert agree > 0.98                                 # robots end their episode at the same control step (+-1)
+    assert ks_len < 0.02 and ks_ret < 0.02 and ks_dx < 0.06
     assert abs(ret_g[:m].mean() - ret_o.mean()) < 0.05 * ret_o.std()
     env.close()
 
@@ -395,4 +407,62 @@ def test_dynamics_identification_evaluator(golden):
     assert np.median(fit[1:]) < fit[0] - 0.05
     with pytest.raises(ValueError):
         R.make_dynamics_id_evaluator(_make(4), gait, mean_dict)
+    env.close()
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_joint_limits_match_oracle(lanes):
+    """EtgConfig.joint_limits (bounds of a1.py:186-195) on the GPU: constant torques drive hips and knees into their stops;
+    both kernel mappings against the oracle's model, and the stops hold."""
+    _need_gpu()
+    n = 32
+    act = np.zeros((n, 12), dtype=np.float32)
+    act[0::4, 0::3] = 6.0
+    act[1::4, 0::3] = -6.0
+    act[2::4, 2::3] = 8.0
+    act[3::4, 2::3] = -8.0; act[3::4, 1::3] = 3.0
+    env = _make(n, motor_control_mode="torque", joint_limits=True, solver_iters=4, lanes_per_robot=lanes)
+    orc = _oracle(n, motor_mode=1, joint_limits=1, solver_iters=4)
+    env.reset(); orc.reset()
+    ta = torch.as_tensor(act, device="cuda:0")
+    worst = 0.0
+    for k in range(12):
+        env.step(ta); orc.step(act)
+        sg, so = env.get_state().cpu().numpy(), orc.get_state()
+        worst = max(worst, np.abs(sg - so)[:, 13:25].max())
+        assert np.abs(sg - so)[:, :3].max() < 2e-3, k
+    _say("joint limits lanes=%d: q err max %.2e" % (lanes, worst))
+    assert worst < 5e-3
+    q = env.get_state()[:, 13:25].cpu().numpy().reshape(n, 4, 3)
+    lo, hi = np.array(A.JOINT_LOWER), np.array(A.JOINT_UPPER)
+    assert (q <= hi + 0.03).all() and (q >= lo - 0.03).all()
+    assert np.abs(q[0::4, :, 0] - hi[0]).max() < 0.03 and np.abs(q[1::4, :, 0] - lo[0]).max() < 0.03
+    # walking robots never reach the stops: the option leaves their trajectories alone
+    W, B = _etg_params(n, seed=5)
+    a, b = _make(n, joint_limits=True, lanes_per_robot=lanes), _make(n, lanes_per_robot=lanes)
+    a.reset(ETG_w=W, ETG_b=B); b.reset(ETG_w=W, ETG_b=B)
+    a.rollout_openloop(10); b.rollout_openloop(10)
+    assert (a.get_state() - b.get_state()).abs()[:, 13:25].max().item() < 1e-4
+    env.close(); a.close(); b.close()
+
+
+def test_flat_ground_knee_rows_match_oracle():
+    """body_contacts on the flat-ground instantiation of the 16-lane kernels (k_*16<true, true, false>): a limp robot folds
+    onto its knees and the knee spheres carry it, as in the oracle."""
+    _need_gpu()
+    n = 32
+    env = _make(n, motor_control_mode="torque", body_contacts=True, solver_iters=4)
+    assert env.lanes_per_robot == 16 and env.cfg.terrain == 0
+    orc = _oracle(n, motor_mode=1, body_contacts=1, solver_iters=4)
+    env.reset(); orc.reset()
+    act = np.zeros((n, 12), dtype=np.float32); act[1::2, 1::3] = 2.0
+    ta = torch.as_tensor(act, device="cuda:0")
+    worst = 0.0
+    for k in range(13):
+        env.step(ta); orc.step(act)
+        sg, so = env.get_state().cpu().numpy(), orc.get_state()
+        worst = max(worst, np.abs(sg - so)[:, 13:25].max())
+        assert np.abs(sg - so)[:, :3].max() < 1e-3, k
+    _say("flat knee rows: q err max %.2e" % worst)
+    assert worst < 5e-3 and so[0, 2] > -0.2
     env.close()

@@ -307,9 +307,57 @@ def test_emulation_knee_contacts_match_oracle():
     assert finals[0][0, 2] < -0.3 and finals[1][0, 2] > -0.2
 
 
-def test_body_contacts_need_the_heightfield_kernels():
+def test_body_contacts_config_and_flat_ground_knee_rows():
     cfg = A.default_config(4, body_contacts=1)
     assert cfg.body_contacts == 1 and abs(cfg.knee_radius - 0.02) < 1e-12
+    # the knee rows on the flat-ground instantiation (no heightfield): same limp-robot scenario as above
+    from oracle.oracle import OracleSim
+    from tests.emu.emu import EmuSim
+    n = 2
+    act = np.zeros((n, 12)); act[1, 1::3] = 2.0
+    cfg = A.default_config(n, solver_iters=4, motor_mode=1, body_contacts=1)
+    orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=16)
+    orc.reset(); emu.reset()
+    for k in range(13):
+        orc.step(act); emu.step(act)
+        so, se = orc.get_state(), emu.get_state()
+        assert np.abs(so[:, 13:25] - se[:, 13:25]).max() < 2e-3 and np.abs(so[:, :3] - se[:, :3]).max() < 1e-4, k
+    assert orc.get_state()[0, 2] > -0.2
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_emulation_joint_limits_match_oracle(lanes):
+    """EtgConfig.joint_limits (bounds of a1.py:186-195): constant torques drive the hip and knee joints into their stops
+    (TORQUE mode).  The kernel source of both mappings against the oracle's model; the stops hold; and without the option
+    the same torques run the joints far past the bounds."""
+    from oracle.oracle import OracleSim
+    from tests.emu.emu import EmuSim
+    n = 4
+    act = np.zeros((n, 12))
+    act[0, 0::3] = 6.0                       # abduction torque on every hip: upper hip bound 0.803
+    act[1, 0::3] = -6.0                      # lower hip bound
+    act[2, 2::3] = 8.0                       # knees extend: upper calf bound -0.916
+    act[3, 2::3] = -8.0; act[3, 1::3] = 3.0  # knees fold: lower calf bound -2.697
+    cfg = A.default_config(n, solver_iters=4, motor_mode=1, joint_limits=1)
+    orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=lanes)
+    orc.reset(); emu.reset()
+    worst = 0.0
+    for k in range(12):
+        orc.step(act); emu.step(act)
+        so, se = orc.get_state(), emu.get_state()
+        worst = max(worst, np.abs(so[:, 13:25] - se[:, 13:25]).max())
+        assert np.abs(so[:, :3] - se[:, :3]).max() < 2e-3, k
+    assert worst < 5e-3, worst
+    q = orc.get_state()[:, 13:25].reshape(n, 4, 3)
+    lo, hi = np.array(A.JOINT_LOWER), np.array(A.JOINT_UPPER)
+    assert (q <= hi + 0.03).all() and (q >= lo - 0.03).all()          # the stops hold (Baumgarte leaves a small overshoot)
+    assert np.abs(q[0, :, 0] - hi[0]).max() < 0.03 and np.abs(q[1, :, 0] - lo[0]).max() < 0.03   # and the hips sit on them
+    free = OracleSim(A.default_config(n, solver_iters=4, motor_mode=1))
+    free.reset()
+    for k in range(12):
+        free.step(act)
+    qf = free.get_state()[:, 13:25].reshape(n, 4, 3)
+    assert qf[0, :, 0].min() > hi[0] + 0.3                              # no stops: far past the bound
 
 
 def test_param2dynamic_rows_torch_equals_numpy():
