@@ -510,6 +510,7 @@ def test_sensor_mode_selects_observation_columns():
     stud = _make(n, sensor_mode={"dis": 0})                 # the student observation, BCtrain.py:53-59
     assert full.observation_space.shape == (49,) and stud.observation_space.shape == (46,)
     o_full, _ = full.reset()
+    o_full = o_full.clone()                                  # the returned view aliases the env's buffer: keep the reset row
     o_stud, _ = stud.reset()
     assert tuple(o_stud.shape) == (n, 46)
     assert torch.equal(o_stud, o_full[:, 3:])

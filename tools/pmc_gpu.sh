@@ -16,7 +16,7 @@ run fetch FETCH_SIZE
 run write WRITE_SIZE
 run valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES
 run lds SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
-run mfma SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES
+run mfma SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES
 rocprofv3 -L 2>/dev/null | grep -i -o "SQ_[A-Z_]*MFMA[A-Z_0-9]*" | sort -u > $R/gpurun_out/pmc_$1_mfma_counter_names.txt
 python - $1 $STEPS > $R/gpurun_out/pmc_$1.txt <<PY
 import csv, glob, collections, re, json, sys
@@ -31,8 +31,8 @@ for name in ("fetch", "write", "valu", "lds", "mfma"):
         if m:
             acc[(m.group(1), r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (kern, k), v in sorted(acc.items()):
-        # the timed launches cover `steps` control steps each for the fused kernels; the largest value group = those launches
-        big = [x for x in v if x > 0.5 * max(v)] if kern.startswith("k_rollout") else v
+        # the timed launches of the fused kernels cover STEPS control steps each; the largest value group = those launches
+        big = ([x for x in v if x >= 0.5 * max(v)] if kern.startswith("k_rollout") else v) or v
         means[kern][k] = sum(big) / len(big)
         print("%-18s %-26s mean per launch %14.1f  (n=%d of %d)" % (kern, k, means[kern][k], len(big), len(v)))
 js = {}
@@ -45,7 +45,7 @@ for kern, c in means.items():
     if "SQ_INSTS_VALU" in c and c.get("SQ_WAVES"):
         e["valu_insts_per_wave_per_control_step"] = c["SQ_INSTS_VALU"] / c["SQ_WAVES"] / per
         e["wave_cycles_per_wave_per_control_step"] = c.get("SQ_WAVE_CYCLES", 0.0) / c["SQ_WAVES"] / per
-    for k in ("SQ_INSTS_MFMA", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
+    for k in ("SQ_INSTS_MFMA", "SQ_INSTS_VALU_MFMA_MOPS_F32", "SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY"):
         if k in c: e[k.lower() + "_per_launch"] = c[k]
     e["control_steps_per_launch"] = per
     js[kern] = e
