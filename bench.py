@@ -329,6 +329,13 @@ def main():
             env50 = make_env("Quadrupedal", solver_iters=50, **env_kw)
             extra["solver_iters_50"] = leg(env50, None, True, "the same fused rollout with 50 PGS sweeps per tick", reps=2)
             env50.close()
+            if lanes == 16 and not (args.body_contacts and args.joint_limits):
+                # the model options the headline leaves off: knee spheres collide, joint-limit stops (non-PLAIN kernels)
+                kwf = dict(env_kw, body_contacts=True, joint_limits=True)
+                envf = make_env("Quadrupedal", solver_iters=args.solver_iters, **kwf)
+                extra["knees_and_joint_limits"] = leg(envf, None, True, "the same fused rollout with body_contacts (knee spheres) and "
+                                                      "joint_limits (a1.py:186-195 stops) switched on")
+                envf.close()
         if args.config == 2:
             pol3 = make_policy()
             wl, kn, sv = timed_repeats(env, pol3, True, 3, events=True)

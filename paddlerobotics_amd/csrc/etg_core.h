@@ -634,19 +634,23 @@ template <class F, class Ctx> ETG_HD void ring_push(const Ctx& c, float* ring, i
 }
 template <class F> struct Delayed { F q[3], qd[3]; F qx, qy, qz, qw; V3<F> w; };
 template <class F, class Ctx>
-ETG_HD Delayed<F> ring_read(const Ctx& c, const float* ring, int tick) {
-  // n_steps_ago / blend_alpha are env-uniform; lat_n < 0 encodes latency <= 0
+ETG_HD Delayed<F> ring_read(const Ctx& c, const KCfg& K, const float* ring, int tick) {
+  // n_steps_ago / blend_alpha are env-uniform; lat_n < 0 encodes latency <= 0.  Readings of ticks up to the reset tick come
+  // from the settle cache's ring (KCfg.cring), later ones from the live ring -- see etg_layout.h
   F v[8];
   int n = c.uniform_int(c.par(PR_LAT_N));
   const F alpha = c.par(PR_LAT_A);
   if (n < 0) {
+    const float* r0 = (K.cring != nullptr && tick <= K.settle_ticks) ? K.cring : ring;
 #pragma unroll
-    for (int k = 0; k < 8; k++) v[k] = c.ld_ring(ring, tick & (RING - 1), k);
+    for (int k = 0; k < 8; k++) v[k] = c.ld_ring(r0, tick & (RING - 1), k);
   } else {
     int sa = (tick - n) & (RING - 1), sb = (tick - n - 1) & (RING - 1);
+    const float* ra = (K.cring != nullptr && tick - n <= K.settle_ticks) ? K.cring : ring;
+    const float* rb_ = (K.cring != nullptr && tick - n - 1 <= K.settle_ticks) ? K.cring : ring;
 #pragma unroll
     for (int k = 0; k < 8; k++) {
-      F a = c.ld_ring(ring, sa, k), b = c.ld_ring(ring, sb, k);
+      F a = c.ld_ring(ra, sa, k), b = c.ld_ring(rb_, sb, k);
       v[k] = (F(1.0f) - alpha) * a + alpha * b;
     }
   }
@@ -896,7 +900,7 @@ ETG_HD void control_step_core(const Ctx& c, const KCfg& K, TickPar4<F>& tp, cons
   c.ring_fence();
 
   F imu[6];
-  write_obs(c, K, L, ring_read<F>(c, ring, tick), S.r0, S.r1, S.r2, etg, lbx, lby, lbz, obs, imu);
+  write_obs(c, K, L, ring_read<F>(c, K, ring, tick), S.r0, S.r1, S.r2, etg, lbx, lby, lbz, obs, imu);
 
   // ---- reward / termination (this repo's definitions)
   const float cdt = K.dt * (float)K.action_repeat;
@@ -1030,7 +1034,7 @@ ETG_HD void reset_finish(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   if (Ctx::kPlain || K.etg_on) etg_action(c, K, etgp, 0.0f, etg);
   else etg[0] = etg[1] = etg[2] = F(0.0f);
   // the first reading after reset defines the rpy reference (EnvWrapper.py:79-84)
-  const Delayed<F> D0 = ring_read<F>(c, ring, tick);
+  const Delayed<F> D0 = ring_read<F>(c, K, ring, tick);
   const V3<F> rpy0 = quat_rpy(D0.qx, D0.qy, D0.qz, D0.qw);
   c.st_env(ctl, CT_FIRST_RPY + 0, rpy0.x); c.st_env(ctl, CT_FIRST_RPY + 1, rpy0.y); c.st_env(ctl, CT_FIRST_RPY + 2, rpy0.z);
   write_obs(c, K, L, D0, rpy0.x, rpy0.y, rpy0.z, etg, L.p.x, L.p.y, L.p.z, obs, imu);
@@ -1059,7 +1063,7 @@ template <class F, class Ctx> ETG_HD void get_state_quad(const Ctx& c, const Lan
   }
 }
 template <class F, class Ctx>
-ETG_HD void set_state_quad(const Ctx& c, const float* st, LaneState<F>& L, float* ring, float* ctl, int* ictl) {
+ETG_HD void set_state_quad(const Ctx& c, const float* st, LaneState<F>& L, float* ring, float* ctl, int* ictl, int tick0 = 0) {
   L.p = {c.ld_row_env(st, ETG_STATE_DIM, 0), c.ld_row_env(st, ETG_STATE_DIM, 1), c.ld_row_env(st, ETG_STATE_DIM, 2)};
   F x = c.ld_row_env(st, ETG_STATE_DIM, 3), y = c.ld_row_env(st, ETG_STATE_DIM, 4);
   F z = c.ld_row_env(st, ETG_STATE_DIM, 5), w = c.ld_row_env(st, ETG_STATE_DIM, 6);
@@ -1080,7 +1084,9 @@ ETG_HD void set_state_quad(const Ctx& c, const float* st, LaneState<F>& L, float
   }
   L.contact = F(0.0f);
   for (int sl = 0; sl < RING; sl++) ring_push(c, ring, sl, L);  // re-seed the latency ring
-  c.st_env_i(ictl, IC_TICK, 0);
+  // tick0: the HIP library passes settle_ticks + RING, so that every later reading is newer than the reset tick and comes
+  // from the re-seeded LIVE ring, not from the settle cache (ring_read)
+  c.st_env_i(ictl, IC_TICK, tick0);
   c.st_env(ctl, CT_LAST_BASE + 0, L.p.x); c.st_env(ctl, CT_LAST_BASE + 1, L.p.y); c.st_env(ctl, CT_LAST_BASE + 2, L.p.z);
 }
 

@@ -152,10 +152,10 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   W a0 = {{zero, zero, zero}, {-gb.x, -gb.y, -gb.z}};
   W as = a0 + chain_prefix(c, L.qd * crm(Vpar, S), m1, m2);
   W f = apply(I, as) + crf(Vs, apply(I, Vs));
-  W fc = chain_suffix(c, f);
-  F C = dot(S, fc);
   const F m0 = tp.m0;
   const S3<F> I0s = tp.I0s;
+  W fc = chain_suffix(c, f);
+  F C = dot(S, fc);
   RBI<F> I0 = {m0, {zero, zero, zero}, I0s};
   W fb0 = apply(I0, a0) + crf(V0, apply(I0, V0));
   c.phase(1);
@@ -483,21 +483,25 @@ template <class F, class Ctx> ETG_HD void ring_push16(const Ctx& c, float* ring,
   c.st_ring_aux(ring, slot, 7, b1);
 }
 template <class F> struct Delayed16 { F q, qd; F qx, qy, qz, qw; V3<F> w; };
-template <class F, class Ctx> ETG_HD Delayed16<F> ring_read16(const Ctx& c, const float* ring, int tick) {
+// readings of ticks up to the reset tick come from the settle cache's ring (KCfg.cring), later ones from the live ring
+ETG_HD const float* ring_of_tick(const KCfg& K, const float* ring, int t) { return (K.cring != nullptr && t <= K.settle_ticks) ? K.cring : ring; }
+template <class F, class Ctx> ETG_HD Delayed16<F> ring_read16(const Ctx& c, const KCfg& K, const float* ring, int tick) {
   F vq, vqd, v6, v7;
   int n = c.uniform_int(c.par(PR_LAT_N));
   const F alpha = c.par(PR_LAT_A);
   if (n < 0) {
     int sl = tick & (RING - 1);
-    vq = c.ld_ring_joint(ring, sl, 0); vqd = c.ld_ring_joint(ring, sl, 3);
-    v6 = c.ld_ring_k(ring, sl, 6); v7 = c.ld_ring_k(ring, sl, 7);
+    const float* r0 = ring_of_tick(K, ring, tick);
+    vq = c.ld_ring_joint(r0, sl, 0); vqd = c.ld_ring_joint(r0, sl, 3);
+    v6 = c.ld_ring_k(r0, sl, 6); v7 = c.ld_ring_k(r0, sl, 7);
   } else {
     int sa = (tick - n) & (RING - 1), sb = (tick - n - 1) & (RING - 1);
+    const float *ra = ring_of_tick(K, ring, tick - n), *rb_ = ring_of_tick(K, ring, tick - n - 1);
     const F oma = F(1.0f) - alpha;
-    vq = oma * c.ld_ring_joint(ring, sa, 0) + alpha * c.ld_ring_joint(ring, sb, 0);
-    vqd = oma * c.ld_ring_joint(ring, sa, 3) + alpha * c.ld_ring_joint(ring, sb, 3);
-    v6 = oma * c.ld_ring_k(ring, sa, 6) + alpha * c.ld_ring_k(ring, sb, 6);
-    v7 = oma * c.ld_ring_k(ring, sa, 7) + alpha * c.ld_ring_k(ring, sb, 7);
+    vq = oma * c.ld_ring_joint(ra, sa, 0) + alpha * c.ld_ring_joint(rb_, sb, 0);
+    vqd = oma * c.ld_ring_joint(ra, sa, 3) + alpha * c.ld_ring_joint(rb_, sb, 3);
+    v6 = oma * c.ld_ring_k(ra, sa, 6) + alpha * c.ld_ring_k(rb_, sb, 6);
+    v7 = oma * c.ld_ring_k(ra, sa, 7) + alpha * c.ld_ring_k(rb_, sb, 7);
   }
   Delayed16<F> D;
   D.q = vq; D.qd = vqd;
@@ -581,7 +585,7 @@ ETG_HD void write_obs16(const Ctx& c, const KCfg& K, const State16<F>& L, const 
   F sdis(nrm ? 1.0f / cdt : 1.0f), srpy(nrm ? 10.0f : 1.0f), sdr(nrm ? 2.0f : 1.0f), sqn(nrm ? 10.0f : 1.0f);
   imu[0] = rpy.x - r0; imu[1] = rpy.y - r1; imu[2] = rpy.z - r2;
   imu[3] = D.w.x; imu[4] = D.w.y; imu[5] = D.w.z;
-  if (obs) {
+  {   // obs is never null on this path (every caller passes a row buffer: the caller's, the library's sink or the LDS tile)
     c.st_row_env(obs, ETG_OBS_DIM, 0, (L.p.x - lbx) * sdis);
     c.st_row_env(obs, ETG_OBS_DIM, 1, (L.p.y - lby) * sdis);
     c.st_row_env(obs, ETG_OBS_DIM, 2, (L.p.z - lbz) * sdis);
@@ -688,7 +692,7 @@ ETG_HD void control_step16_core(const Ctx& c, const KCfg& K, TickPar<F>& tp, Sta
   S.has_last = 1;
 
   F imu[6];
-  write_obs16(c, K, L, ring_read16<F>(c, ring, tick), S.r0, S.r1, S.r2, etg, lbx, lby, lbz, obs, imu);
+  write_obs16(c, K, L, ring_read16<F>(c, K, ring, tick), S.r0, S.r1, S.r2, etg, lbx, lby, lbz, obs, imu);
 
   const float cdt = K.dt * (float)K.action_repeat;
   Rows<F> Rw = quat_rows(L.qx, L.qy, L.qz, L.qw);
@@ -811,7 +815,7 @@ ETG_HD void reset_finish16(const Ctx& c, const KCfg& K, State16<F>& L, float* ri
   F imu[6];
   F etg = (Ctx::kPlain || K.etg_on) ? etg_action16<F>(c, K, etgp, 0.0f) : F(0.0f);
   // the first reading after reset defines the rpy reference (EnvWrapper.py:79-84)
-  const Delayed16<F> D0 = ring_read16<F>(c, ring, tick);
+  const Delayed16<F> D0 = ring_read16<F>(c, K, ring, tick);
   const V3<F> rpy0 = quat_rpy(D0.qx, D0.qy, D0.qz, D0.qw);
   c.st_env(ctl, CT_FIRST_RPY + 0, rpy0.x); c.st_env(ctl, CT_FIRST_RPY + 1, rpy0.y); c.st_env(ctl, CT_FIRST_RPY + 2, rpy0.z);
   write_obs16(c, K, L, D0, rpy0.x, rpy0.y, rpy0.z, etg, L.p.x, L.p.y, L.p.z, obs, imu);

@@ -159,13 +159,11 @@ __global__ void __launch_bounds__(BLOCK) k_set_params(KCfg K, ModelF M, DevState
 
 // ---- reset = settle (only for robots without a valid settle cache) -> restore from the cache -> finish
 // copy this lane's 8 ring words of all slots and its leg column between the live arrays and the cache
+// (the ring is NOT copied back from the cache: readings of ticks up to the reset tick are served from KCfg.cring)
 __device__ __forceinline__ void copy_leg_column(const DevState& D, size_t col, size_t NL, bool to_cache) {
   const float* src_leg = to_cache ? D.leg : D.cache_leg;
   float* dst_leg = to_cache ? D.cache_leg : D.leg;
   for (int f = 0; f < LG_N; f++) dst_leg[(size_t)f * NL + col] = src_leg[(size_t)f * NL + col];
-  const float* src = to_cache ? D.ring : D.cache_ring;
-  float* dst = to_cache ? D.cache_ring : D.ring;
-  for (int w = 0; w < RING * 8; w++) dst[(size_t)w * NL + col] = src[(size_t)w * NL + col];
 }
 __device__ __forceinline__ void copy_base_column(const DevState& D, int env, int N, bool to_cache) {
   const float* src = to_cache ? D.base : D.cache_base;
@@ -242,8 +240,9 @@ __global__ void __launch_bounds__(BLOCK) k_finish(KCfg K, DevState D, const uint
 }
 
 // auto-reset of the robots flagged in `mask` (the `done` bytes a step just wrote) when every robot has a cached settle:
-// cached state -> registers, first observation and control state from the CACHED ring (reset_finish), cached ring ->
-// live ring, pending random push cleared.  One launch instead of etg_reset's settle / cache_sync / cache_mark / finish.
+// cached state -> registers, first observation and control state (reset_finish; the pre-reset ring readings are served from
+// the cache, KCfg.cring), pending random push cleared.  One launch instead of etg_reset's settle / cache_sync / cache_mark /
+// finish, and no per-robot ring copy.
 template <bool FLAT, bool PLAIN>
 __global__ void __launch_bounds__(BLOCK) k_autoreset(KCfg K, DevState D, const uint8_t* mask, float* obs) {
   GpuCtxT<FLAT, PLAIN> c;
@@ -255,9 +254,8 @@ __global__ void __launch_bounds__(BLOCK) k_autoreset(KCfg K, DevState D, const u
   const int N = K.n_env;
   L.p.x += D.reset_off[c.env] - D.cache_off[c.env];          // non-zero only on flat ground (settle_cached)
   L.p.y += D.reset_off[N + c.env] - D.cache_off[N + c.env];
-  reset_finish(c, K, L, D.cache_ring, D.ctl, D.ictl, D.legctl, D.etgp, obs);
+  reset_finish(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, obs);    // its reading (tick = settle_ticks) comes from K.cring
   store_state(c, D.base, D.leg, L);
-  for (int w = 0; w < RING * 8; w++) D.ring[(size_t)w * c.NL + c.gid] = D.cache_ring[(size_t)w * c.NL + c.gid];
   if (c.lane == 0) {
     D.ictl[(size_t)IC_PUSH_LEFT * N + c.env] = 0;
     for (int k = 0; k < 3; k++) D.ctl[(size_t)(CT_PUSH + k) * N + c.env] = 0.0f;
@@ -543,7 +541,7 @@ __global__ void __launch_bounds__(BLOCK) k_finish16(KCfg K, DevState D, const ui
   store_state16(c, D.base, D.leg, L);
 }
 
-// the 16-lanes-per-robot auto-reset (see k_autoreset): the 4 sub-lanes of a leg share the copy of its ring column
+// the 16-lanes-per-robot auto-reset (see k_autoreset)
 template <bool FLAT, bool KNEE, bool PLAIN>
 __global__ void __launch_bounds__(BLOCK) k_autoreset16(KCfg K, DevState D, const uint8_t* mask, float* obs) {
   __shared__ float lds_par[LDS16_FIELDS * BLOCK];
@@ -554,9 +552,8 @@ __global__ void __launch_bounds__(BLOCK) k_autoreset16(KCfg K, DevState D, const
   const int N = K.n_env;
   L.p.x += D.reset_off[c.env] - D.cache_off[c.env];
   L.p.y += D.reset_off[N + c.env] - D.cache_off[N + c.env];
-  reset_finish16(c, K, L, D.cache_ring, D.ctl, D.ictl, D.legctl, D.etgp, obs);
+  reset_finish16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, obs);   // its reading (tick = settle_ticks) comes from K.cring
   store_state16(c, D.base, D.leg, L);
-  for (int w = c.sub; w < RING * 8; w += 4) D.ring[(size_t)w * c.NL + c.col] = D.cache_ring[(size_t)w * c.NL + c.col];
   if (c.r == 0) {
     D.ictl[(size_t)IC_PUSH_LEFT * N + c.env] = 0;
     for (int k = 0; k < 3; k++) D.ctl[(size_t)(CT_PUSH + k) * N + c.env] = 0.0f;
@@ -659,13 +656,15 @@ __global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, Po
     }
     __syncthreads();
     const float action = c.sub < 3 ? act_lds[4 * wave + (lane >> 4)][3 * c.leg + c.sub] : 0.0f;
-    // the step code addresses observation rows by robot index: rows of the LDS tile start at the tile's first robot
-    const bool last = s == n_steps - 1;
-    c.row_base = last ? 0 : tile * TM;
-    control_step16_core(c, K, tp, L, S, D.ring, D.etgp, action, 0.0f, last ? obs : obs_lds, reward, done, (float*)nullptr);
+    // the step code addresses observation rows by robot index: rows of the LDS tile start at the tile's first robot.
+    // Every step writes its observation to the tile (plain ds_write, no generic pointer); the last one is copied out below.
+    c.row_base = tile * TM;
+    control_step16_core(c, K, tp, L, S, D.ring, D.etgp, action, 0.0f, obs_lds, reward, done, (float*)nullptr);
   }
   store_ctl16(c, K, S, D.ctl, D.ictl, D.legctl);
   store_state16(c, D.base, D.leg, L);
+  __syncthreads();
+  for (int idx = tid; idx < TM * ETG_OBS_DIM; idx += 256) obs[(size_t)tile * TM * ETG_OBS_DIM + idx] = obs_lds[idx];   // coalesced
 }
 
 // Gaussian sensor noise on freshly written observation rows: one thread per (robot, channel).  A separate tiny
@@ -739,7 +738,7 @@ __global__ void __launch_bounds__(BLOCK) k_set_state(KCfg K, DevState D, const f
   GpuCtxT<true> c;
   if (!make_ctx(K, c)) return;
   LaneState<float> L;
-  set_state_quad(c, st, L, D.ring, D.ctl, D.ictl);
+  set_state_quad(c, st, L, D.ring, D.ctl, D.ictl, K.settle_ticks + RING);
   store_state(c, D.base, D.leg, L);
 }
 
@@ -903,6 +902,7 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
     if (hipMalloc(a.p, a.bytes) != hipSuccess) return fail(ETG_ERR_ALLOC, "etg_create: hipMalloc failed");
     HIP_TRY(hipMemset(*a.p, 0, a.bytes));
   }
+  h->K.cring = h->D.cache_ring;
   // default physical parameters = param2dynamic_dict(zeros(48)) (train.py:112-126)
   std::vector<float> row(ETG_DYN_DIM, 1.0f);
   row[0] = 40.0f; row[1] = 0.2f; row[2] = 1.5f;

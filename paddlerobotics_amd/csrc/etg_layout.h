@@ -56,6 +56,10 @@ struct KCfg {
   int hf_bands;          // bands stacked along y in the heights array; robot e uses band e % hf_bands
   float hf_cell, hf_x0, hf_y0;
   const float* hf;
+  // the settle cache's copy of the latency ring (DevState.cache_ring), or null (test emulation).  Ring slots of ticks up to
+  // the reset tick (settle_ticks) are READ FROM THE CACHE: a robot's history before its reset is its settle, which the cache
+  // holds, so a reset -- etg_reset from the cache, the auto-reset after a step -- never copies 8 KB of ring per robot.
+  const float* cring;
   int ext_force;         // 1 while a set force (ctl[CT_FEXT..]) or random pushes (ctl[CT_PUSH..]) are installed
   int etg_on;            // EtgConfig.enable_etg: 0 = no trajectory generator (command = pose_ori + action)
   int jlim;              // EtgConfig.joint_limits
@@ -308,6 +312,7 @@ inline KCfg make_kcfg(const EtgConfig& c, const EtgRobotModel& m) {
   for (int k = 0; k < 3; k++) { K.jlo[k] = (float)c.joint_lower[k]; K.jhi[k] = (float)c.joint_upper[k]; }
   K.hf_cell = (float)c.hf_cell; K.hf_x0 = (float)c.hf_x0; K.hf_y0 = (float)c.hf_y0;
   K.hf = nullptr;
+  K.cring = nullptr;
   return K;
 }
 

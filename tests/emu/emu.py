@@ -14,14 +14,16 @@ _LIB = None
 def lib():
     global _LIB
     if _LIB is None:
-        so = os.path.join(_HERE, "libetg_emu.so")
+        # ETG_EMU_FLAGS: extra compiler flags (e.g. -DETG_TRUNK_ON_AUX) to emulate a build variant of the kernel source
+        flags = os.environ.get("ETG_EMU_FLAGS", "").split()
+        so = os.path.join(_HERE, "libetg_emu%s.so" % ("_" + "".join(ch for ch in "".join(flags) if ch.isalnum()) if flags else ""))
         srcs = [os.path.join(_HERE, "etg_emu.cpp"), os.path.join(_HERE, "emu_lanes.h")] + [
             os.path.join(_HERE, "..", "..", "paddlerobotics_amd", "csrc", f)
             for f in ("etg_core.h", "etg_core16.h", "etg_layout.h") if os.path.exists(
                 os.path.join(_HERE, "..", "..", "paddlerobotics_amd", "csrc", f))]
         if not os.path.exists(so) or any(os.path.getmtime(s) > os.path.getmtime(so) for s in srcs):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off",
-                                   "-o", so, srcs[0]])
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-ffp-contract=off"] + flags +
+                                  ["-o", so, srcs[0]])
         _LIB = C.CDLL(so)
         _LIB.emu_create.restype = C.c_void_p
     return _LIB
