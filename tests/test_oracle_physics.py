@@ -6,6 +6,8 @@ that the oracle's model obeys mechanics and the reference's kinematics:
     reference's analytical_leg_jacobian (a1.py:132-160)
   - sliding decelerates at mu*g
 """
+import os
+
 import numpy as np
 
 from paddlerobotics_amd import a1_model as A
@@ -130,3 +132,24 @@ def test_fp32_oracle_tracks_fp64_short_horizon():
         ob, rb, db, _ = b.step(act)
     assert np.allclose(a.get_state(), b.get_state(), atol=2e-3)
     assert np.allclose(oa, ob, atol=5e-2)
+
+
+def test_pybullet_dump_format_and_comparison_tool(tmp_path):
+    """tools/pybullet_baseline.py + tests/pybullet_compare.py: the trajectory dump format a pybullet box would produce and the gap report against the
+    oracle.  No pybullet here: the oracle's own dump (K = 50) stands in for the file, so the gap against K = 50 is zero and
+    against K = 2 it is the solver-convergence gap (small, and it grows with the horizon)."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import pybullet_baseline
+    from tests import pybullet_compare as PB
+    assert "[steps, 19]" in pybullet_baseline.DUMP_FORMAT
+    traj = PB.oracle_trajectory(30, solver_iters=50)
+    assert traj.shape == (30, 19) and np.isfinite(traj).all()
+    assert np.abs(np.linalg.norm(traj[:, 3:7], axis=1) - 1).max() < 1e-9
+    f = str(tmp_path / "dump.npy")
+    np.save(f, traj)
+    same = PB.compare(f, solver_iters=50)
+    assert same["steps"] == 30 and max(same["joint_angle_gap_rad"].values()) == 0.0
+    k2 = PB.compare(f, solver_iters=2)
+    assert 0.0 < max(k2["joint_angle_gap_rad"].values()) < 5e-2
+    assert pybullet_baseline.run(1) is None or isinstance(pybullet_baseline.run(1), float)      # pybullet absent -> None

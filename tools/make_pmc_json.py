@@ -1,0 +1,16 @@
+"""profiles/r02_pmc.json (what bench.py reads for `roofline.traffic` / `valu_issue`) from the per-config outputs of
+tools/pmc_gpu.sh: gpurun_out/pmc_r02_cfg<N>.json -> {"config<N>": {kernel: {...}}}."""
+import json
+import os
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+out = {"_source": "tools/pmc_gpu.sh: separate rocprofv3 --pmc passes (FETCH_SIZE | WRITE_SIZE | SQ_INSTS_VALU ... | SQ_INSTS_LDS ... | "
+                  "SQ_INSTS_MFMA ...) of `python bench.py --steps 50 --warmup 5 --repeats 2 --no-cpu-baseline --no-extra-legs [--config N]` "
+                  "on one MI355X; FETCH_SIZE counts half the bytes of dword-per-lane coalesced reads (tools/ubench/pmc_calib.hip), hence "
+                  "traffic = 2 x FETCH_SIZE + WRITE_SIZE"}
+for cfg in (2, 3, 5):
+    p = os.path.join(ROOT, "gpurun_out", "pmc_r02_cfg%d.json" % cfg)
+    if os.path.exists(p):
+        out["config%d" % cfg] = json.load(open(p))
+json.dump(out, open(os.path.join(ROOT, "profiles", "r02_pmc.json"), "w"), indent=1)
+print(sorted(out))

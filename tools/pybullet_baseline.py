@@ -8,7 +8,10 @@ installed it times the loop the reference runs per control step -- restated from
 loop), :904-947 (PD -> TORQUE_CONTROL), :1151-1170 (state read-back) -- with this repo's own harness (no
 reference code is imported), and can dump joint/base trajectories for a parity look at the oracle.
 
-NOT exercised in this repository's CI: there is no pybullet here.  usage: pybullet_baseline.py [--steps 400]
+The pybullet leg is NOT exercised in this repository's CI (there is no pybullet here); the dump FORMAT and the comparison
+against the oracle are (tests/test_oracle_physics.py): `--dump f.npy` here on any box with pybullet, then
+`python tests/pybullet_compare.py f.npy` anywhere prints the measured gap (the comparison uses the oracle, so it lives under
+tests/).  usage: pybullet_baseline.py [--steps 400] [--dump F]
 """
 import argparse
 import json
@@ -73,10 +76,18 @@ def run(steps, action_repeat=13, dt=0.002, dump=None):
     return steps / elapsed
 
 
+DUMP_FORMAT = """trajectory dump, numpy .npy, float64 [steps, 19]: one row per CONTROL step (13 ticks of 2 ms), taken after the step:
+  [0:3] base position (world, m) | [3:7] base orientation quaternion xyzw | [7:19] motor angles, order FR hip/upper/lower,
+  FL, RR, RL (rad).  Scenario = BASELINE configs[0]: a1.urdf at (0, 0, 0.32), gravity (0, 0, -10), joints at
+  INIT_MOTOR_ANGLES, 500 settle ticks holding that pose, then per step q_des = pose + ETG(t = (k+1) 0.026 s) with the
+  Opt_with_points prior (ETG_T 0.5, Footheight 0.1, Steplength 0.05), PD kp = 100, kd = (1, 2, 2) (a1.py:75-80) applied as
+  torques every tick, foot friction as in the URDF."""
+
+
 if __name__ == "__main__":
-    ap = argparse.ArgumentParser()
+    ap = argparse.ArgumentParser(epilog=DUMP_FORMAT, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--dump", type=str, default=None, help="save [steps, 19] base pose + joint angles")
+    ap.add_argument("--dump", type=str, default=None, help="(needs pybullet) save the trajectory, format below")
     a = ap.parse_args()
     rate = run(a.steps, dump=a.dump)
     if rate is None:
