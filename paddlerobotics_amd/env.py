@@ -500,8 +500,8 @@ class BatchedQuadrupedEnv:
     def rollout_openloop(self, n_steps):
         """n_steps control steps with zero residual action (pretrain.py:129-154) enqueued back to
         back; returns (episode_return[N], episode_len[N]) since the last reset, alive-masked."""
-        ret = torch.zeros(self.num_envs, device=self.device)
-        ln = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        ret = torch.empty(self.num_envs, device=self.device)               # every entry is written by the kernel: no fill launch
+        ln = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
         _lib.check(self._lib.etg_rollout_openloop(self._h, int(n_steps), _ptr(self.obs), _ptr(ret), _ptr(ln),
                                                   self._stream()))
         return ret, ln
@@ -520,8 +520,8 @@ class BatchedQuadrupedEnv:
                 act = policy.predict(self._last_view.contiguous().view(self.num_envs, -1), act_scale, precision, out=act)
                 self.step(act, want_info=False)
             return self.episode_stats()
-        ret = torch.zeros(self.num_envs, device=self.device)
-        ln = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        ret = torch.empty(self.num_envs, device=self.device)               # every entry is written by the kernel: no fill launch
+        ln = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
         _lib.check(self._lib.etg_rollout_policy(self._h, policy._h, int(n_steps), C.c_float(act_scale), int(precision),
                                                 int(self._cols[0]), _ptr(self.obs), _ptr(ret), _ptr(ln), self._stream()))
         self._last_view = self._obs_view()
@@ -530,8 +530,8 @@ class BatchedQuadrupedEnv:
     def episode_stats(self):
         """(return[N], length[N]) accumulated on device since each robot's last reset, frozen at its
         first `done` (what run_episode / run_EStrain_episode return per candidate)."""
-        ret = torch.zeros(self.num_envs, device=self.device)
-        ln = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        ret = torch.empty(self.num_envs, device=self.device)               # every entry is written by the kernel: no fill launch
+        ln = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
         _lib.check(self._lib.etg_episode_stats(self._h, _ptr(ret), _ptr(ln), self._stream()))
         return ret, ln
 
