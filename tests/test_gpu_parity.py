@@ -1027,16 +1027,17 @@ def test_plain_and_full_kernel_variants_agree(lanes):
 
 @pytest.mark.gpu
 def test_examples_run(tmp_path):
-    """the three example scripts end to end (small sizes), from a scratch working directory"""
+    """the example scripts end to end (small sizes), from a scratch working directory"""
     _need_gpu()
     import subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     for script, args in (("es_pretrain.py", ["--popsize", "256", "--generations", "2", "--max-step", "60"]),
-                         ("export_gait.py", []), ("evaluate_policy.py", [])):
+                         ("export_gait.py", []), ("evaluate_policy.py", []),
+                         ("dynamics_id.py", ["--popsize", "128", "--generations", "2", "--steps", "20"])):
         r = subprocess.run([sys.executable, os.path.join(root, "examples", script)] + args, cwd=tmp_path,
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (script, r.stderr[-600:])
-    assert (tmp_path / "es_pretrain_result.npz").exists()
+    assert (tmp_path / "es_pretrain_result.npz").exists() and (tmp_path / "dynamic_param_identified.npy").exists()
 
 
 @pytest.mark.gpu

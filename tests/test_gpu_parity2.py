@@ -466,3 +466,30 @@ def test_flat_ground_knee_rows_match_oracle():
     _say("flat knee rows: q err max %.2e" % worst)
     assert worst < 5e-3 and so[0, 2] > -0.2
     env.close()
+
+
+@pytest.mark.parametrize("kw", [dict(lanes_per_robot=4), dict(task="stairstair", terrain_variants=4),
+                                dict(sensor_mode={"RNN": {"time_steps": 2, "time_interval": 1, "mode": "stack"}}),
+                                dict(random_param={"random_dynamics": 1})])
+def test_auto_reset_variants_equal_manual_reset(kw):
+    """step(auto_reset) == step() followed by reset(env_ids=done) on the paths the fast kernel does not cover alone: the
+    4-lane mapping, a heightfield task, the observation history stack, and random dynamics (new parameters per reset -> a
+    simulated settle through the general etg_reset path)."""
+    _need_gpu()
+    n = 32
+    W, B = _etg_params(n, seed=13)
+    a, b = _make(n, auto_reset=True, seed=4, **kw), _make(n, seed=4, **kw)
+    oa, _ = a.reset(ETG_w=W, ETG_b=B); ob, _ = b.reset(ETG_w=W, ETG_b=B)
+    assert torch.equal(oa, ob)
+    act = torch.zeros(n, 12, device="cuda:0"); act[::2, 1::3] = 1.5          # every other robot is driven into a fall
+    resets = 0
+    for k in range(25):
+        oa, ra, da, _ = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert torch.equal(da, db) and torch.equal(ra, rb), k
+        ob, _ = b.reset(env_ids=db)                    # every step, like the auto-reset (an empty mask resets nobody)
+        resets += int(db.sum())
+        assert torch.equal(oa, ob), k
+        assert torch.equal(a.get_state(), b.get_state()), k
+    assert resets > 0
+    a.close(); b.close()
