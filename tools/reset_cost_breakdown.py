@@ -12,8 +12,9 @@ def T(label, f, n=3):
         dt = (time.perf_counter() - t0) * 1e3
     print("%-40s %.3f ms" % (label, dt))
 T("mask build", lambda: env._mask(ids))
-T("np rng + param2dynamic_rows", lambda: A.param2dynamic_rows(env._np_rng.uniform(-1, 1, size=(N, 48)) * 0.3))
-rows = A.param2dynamic_rows(env._np_rng.uniform(-1, 1, size=(N, 48)) * 0.3)
+draw = lambda: A.param2dynamic_rows_torch((torch.rand(N, 48, device="cuda:0", generator=env._dyn_gen) * 2 - 1) * 0.3)
+T("device rng + param2dynamic_rows_torch", draw)
+rows = draw()
 T("set_dynamic_param(rows, ids)", lambda: env.set_dynamic_param(rows, ids))
 T("set_dynamic_param(rows)", lambda: env.set_dynamic_param(rows))
 env._rand_dyn = False
