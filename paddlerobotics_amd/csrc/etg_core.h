@@ -849,7 +849,8 @@ ETG_HD void store_ctl4(const Ctx& c, const KCfg& K, const StepCtl4<F>& S, float*
 template <class F, class Ctx>
 ETG_HD void control_step_core(const Ctx& c, const KCfg& K, TickPar4<F>& tp, const V3<F>& fext, LaneState<F>& L, StepCtl4<F>& S,
                               float* ring, const float* etgp, const F* action, F donef, float* obs, F& reward, F& done,
-                              float* info, const F* hyb = nullptr) {   // hyb[4*j + (kp, qd_des, kd, tau_ff)], HYBRID mode
+                              float* info, const F* hyb = nullptr,     // hyb[4*j + (kp, qd_des, kd, tau_ff)], HYBRID mode
+                              bool want_obs = true) {                  // false: inner steps of the open-loop rollout (row unread)
   int step_count = S.step_count;
   int tick = S.tick;
   const int has_last = S.has_last;
@@ -899,8 +900,8 @@ ETG_HD void control_step_core(const Ctx& c, const KCfg& K, TickPar4<F>& tp, cons
   S.step_count = step_count; S.tick = tick; S.has_last = 1;
   c.ring_fence();
 
-  F imu[6];
-  write_obs(c, K, L, ring_read<F>(c, K, ring, tick), S.r0, S.r1, S.r2, etg, lbx, lby, lbz, obs, imu);
+  F imu[6] = {F(0.0f), F(0.0f), F(0.0f), F(0.0f), F(0.0f), F(0.0f)};
+  if (want_obs || info) write_obs(c, K, L, ring_read<F>(c, K, ring, tick), S.r0, S.r1, S.r2, etg, lbx, lby, lbz, obs, imu);
 
   // ---- reward / termination (this repo's definitions)
   const float cdt = K.dt * (float)K.action_repeat;
@@ -982,8 +983,9 @@ ETG_HD void rollout_steps(const Ctx& c, const KCfg& K, LaneState<F>& L, float* r
                                            c.ld_env(ctl, CT_FEXT + 2) + c.ld_env(ctl, CT_PUSH + 2)};   // set force + random push
   const F zero3[3] = {F(0.0f), F(0.0f), F(0.0f)};
   F reward, done;
-  for (int s = 0; s < n_steps; s++)
-    control_step_core(c, K, tp, fext, L, S, ring, etgp, zero3, F(0.0f), obs, reward, done, (float*)nullptr);
+  for (int s = 0; s < n_steps; s++)   // only the last observation of the rollout is ever read (see rollout_steps16)
+    control_step_core(c, K, tp, fext, L, S, ring, etgp, zero3, F(0.0f), obs, reward, done, (float*)nullptr, (const F*)nullptr,
+                      s == n_steps - 1);
   store_ctl4(c, K, S, ctl, ictl, legctl);
 }
 

@@ -653,7 +653,9 @@ template <class F, class Ctx> ETG_HD V3<F> load_fext16(const Ctx& c, const float
 template <class F, class Ctx>
 ETG_HD void control_step16_core(const Ctx& c, const KCfg& K, TickPar<F>& tp, State16<F>& L, StepCtl16<F>& S, float* ring,
                                 const float* etgp, F action, F donef, float* obs, F& reward, F& done, float* info,
-                                const F* hyb = nullptr) {   // hyb: (kp, qd_des, kd, tau_ff) of this lane's motor, HYBRID mode
+                                const F* hyb = nullptr,     // hyb: (kp, qd_des, kd, tau_ff) of this lane's motor, HYBRID mode
+                                bool want_obs = true) {     // false (inner steps of the open-loop rollout): the observation row is not
+                                                            // read by anybody -- skip the delayed reading and the row (info needs it)
   const F mj = c.jointf();
   // EtgConfig.enable_etg = 0 (Dynamic_parallel_model.py:49 `ETG=0`): no generator, the command is pose_ori + action
   F etg = (Ctx::kPlain || K.etg_on) ? etg_action16<F>(c, K, etgp, (float)(S.step_count + 1) * K.etg_dt) : F(0.0f);
@@ -691,8 +693,8 @@ ETG_HD void control_step16_core(const Ctx& c, const KCfg& K, TickPar<F>& tp, Sta
   S.step_count++;
   S.has_last = 1;
 
-  F imu[6];
-  write_obs16(c, K, L, ring_read16<F>(c, K, ring, tick), S.r0, S.r1, S.r2, etg, lbx, lby, lbz, obs, imu);
+  F imu[6] = {F(0.0f), F(0.0f), F(0.0f), F(0.0f), F(0.0f), F(0.0f)};
+  if (want_obs || info) write_obs16(c, K, L, ring_read16<F>(c, K, ring, tick), S.r0, S.r1, S.r2, etg, lbx, lby, lbz, obs, imu);
 
   const float cdt = K.dt * (float)K.action_repeat;
   Rows<F> Rw = quat_rows(L.qx, L.qy, L.qz, L.qw);
@@ -767,8 +769,11 @@ ETG_HD void rollout_steps16(const Ctx& c, const KCfg& K, State16<F>& L, float* r
   TickPar<F> tp = load_tick_par<F>(c);
   if (!Ctx::kPlain && K.ext_force) tp.fext = load_fext16<F>(c, ctl);
   F reward, done;
+  // only the LAST observation of an open-loop rollout is ever read (etg_rollout_openloop hands it to the caller): the inner
+  // steps skip the delayed reading and the 49-float row; the ring itself is pushed every step, so the last reading is exact
   for (int s = 0; s < n_steps; s++)
-    control_step16_core(c, K, tp, L, S, ring, etgp, F(0.0f), F(0.0f), obs, reward, done, (float*)nullptr);
+    control_step16_core(c, K, tp, L, S, ring, etgp, F(0.0f), F(0.0f), obs, reward, done, (float*)nullptr, (const F*)nullptr,
+                        s == n_steps - 1);
   store_ctl16(c, K, S, ctl, ictl, legctl);
 }
 
