@@ -530,7 +530,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   F own[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) own[j] = sel_(c.lane_is(j), one, zero);
-  for (int it = 0; it < K.iters; it++) {
+  auto pgs_sweep = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
       F ln = fmaxf_(zero, (l0 + c0) - u0 * iA0);
@@ -546,6 +546,12 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
       u2 = u2 + A[j][2][0] * b0 + A[j][2][1] * b1 + A[j][2][2] * b2;
       l0 = l0 + own[j] * e0; l1 = l1 + own[j] * e1; l2 = l2 + own[j] * e2;  // the owner commits
     }
+  };
+  if (Ctx::kPlain) {   // plain_config: two sweeps, straight-line (see physics_tick16)
+    pgs_sweep();
+    pgs_sweep();
+  } else {
+    for (int it = 0; it < K.iters; it++) pgs_sweep();
   }
   c.phase(8);
   // ---- apply impulses: base via the Schur factor, leg via H^-1
@@ -709,16 +715,27 @@ ETG_HD void etg_action(const Ctx& c, const KCfg& K, const float* etgp, float t, 
   const F hipsign = c.par(PR_HIPSIGN);
   F ang[3] = {posev.x, posev.y, posev.z};
   auto pending = c.lane_is(0) || !c.lane_is(0);  // all-true mask
-  for (int it = 0; it < 200; it++) {
-    V3<F> foot = {bfoot.x + ax * scale - o1.x, bfoot.y + ay * scale - o1.y, bfoot.z + az * scale - o1.z};
+  {   // the target as commanded: all the common path executes (see etg_action16)
+    V3<F> foot = {bfoot.x + ax - o1.x, bfoot.y + ay - o1.y, bfoot.z + az - o1.z};
     F a[3];
     auto ok = pending;
     leg_ik(foot, hipsign, a, ok);
-    auto take = pending && ok;
-    ang[0] = sel_(take, a[0], ang[0]); ang[1] = sel_(take, a[1], ang[1]); ang[2] = sel_(take, a[2], ang[2]);
-    pending = pending && !ok;
-    scale = scale * F(0.95f);
-    if (!c.any(pending)) break;
+    ang[0] = sel_(ok, a[0], ang[0]); ang[1] = sel_(ok, a[1], ang[1]); ang[2] = sel_(ok, a[2], ang[2]);
+    pending = !ok;
+  }
+  if (c.any(pending)) {
+    scale = F(0.95f);
+    for (int it = 1; it < 200; it++) {
+      V3<F> foot = {bfoot.x + ax * scale - o1.x, bfoot.y + ay * scale - o1.y, bfoot.z + az * scale - o1.z};
+      F a[3];
+      auto ok = pending;
+      leg_ik(foot, hipsign, a, ok);
+      auto take = pending && ok;
+      ang[0] = sel_(take, a[0], ang[0]); ang[1] = sel_(take, a[1], ang[1]); ang[2] = sel_(take, a[2], ang[2]);
+      pending = pending && !ok;
+      scale = scale * F(0.95f);
+      if (!c.any(pending)) break;
+    }
   }
   act[0] = ang[0] - posev.x; act[1] = ang[1] - posev.y; act[2] = ang[2] - posev.z;
 }
