@@ -239,35 +239,12 @@ __global__ void __launch_bounds__(BLOCK) k_finish(KCfg K, DevState D, const uint
   store_state(c, D.base, D.leg, L);
 }
 
-// auto-reset of the robots flagged in `mask` (the `done` bytes a step just wrote) when every robot has a cached settle:
-// cached state -> registers, first observation and control state (reset_finish; the pre-reset ring readings are served from
-// the cache, KCfg.cring), pending random push cleared.  One launch instead of etg_reset's settle / cache_sync / cache_mark /
-// finish, and no per-robot ring copy.
-template <bool FLAT, bool PLAIN>
-__global__ void __launch_bounds__(BLOCK) k_autoreset(KCfg K, DevState D, const uint8_t* mask, float* obs) {
+// env.step for the 16 robots of a wave (one quad each); AUTO: see step16_body
+template <bool FLAT, bool PLAIN, bool AUTO>
+__device__ __forceinline__ void step4_body(const KCfg& K, const DevState& D, const float* action, const uint8_t* donef, float* obs,
+                                           float* reward, uint8_t* done, float* info, float* lds_par) {
   GpuCtxT<FLAT, PLAIN> c;
   if (!make_ctx(K, c)) return;
-  if (!mask[c.env]) return;                                   // whole quads drop out together
-  __shared__ float lds_par[PR_N * BLOCK];
-  stage_params(c, D, lds_par);
-  LaneState<float> L = load_state<float>(c, D.cache_base, D.cache_leg);
-  const int N = K.n_env;
-  L.p.x += D.reset_off[c.env] - D.cache_off[c.env];          // non-zero only on flat ground (settle_cached)
-  L.p.y += D.reset_off[N + c.env] - D.cache_off[N + c.env];
-  reset_finish(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, obs);    // its reading (tick = settle_ticks) comes from K.cring
-  store_state(c, D.base, D.leg, L);
-  if (c.lane == 0) {
-    D.ictl[(size_t)IC_PUSH_LEFT * N + c.env] = 0;
-    for (int k = 0; k < 3; k++) D.ctl[(size_t)(CT_PUSH + k) * N + c.env] = 0.0f;
-  }
-}
-
-template <bool FLAT, bool PLAIN>
-__global__ void __launch_bounds__(BLOCK) k_step(KCfg K, DevState D, const float* action, const uint8_t* donef, float* obs,
-                                                 float* reward, uint8_t* done, float* info) {
-  GpuCtxT<FLAT, PLAIN> c;
-  if (!make_ctx(K, c)) return;
-  __shared__ float lds_par[PR_N * BLOCK];
   stage_params(c, D, lds_par);
   LaneState<float> L = load_state<float>(c, D.base, D.leg);
   float act[3], hyb[12];
@@ -286,6 +263,17 @@ __global__ void __launch_bounds__(BLOCK) k_step(KCfg K, DevState D, const float*
 #endif
   control_step(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, act, donef ? (float)donef[c.env] : 0.0f, obs, r, d,
                info, hybrid ? hyb : nullptr);
+  if (AUTO && d > 0.5f) {   // whole quads take this branch together
+    const int N = K.n_env;
+    L = load_state<float>(c, D.cache_base, D.cache_leg);
+    L.p.x += D.reset_off[c.env] - D.cache_off[c.env];
+    L.p.y += D.reset_off[N + c.env] - D.cache_off[N + c.env];
+    reset_finish(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, obs);
+    if (c.lane == 0) {
+      D.ictl[(size_t)IC_PUSH_LEFT * N + c.env] = 0;
+      for (int k = 0; k < 3; k++) D.ctl[(size_t)(CT_PUSH + k) * N + c.env] = 0.0f;
+    }
+  }
   store_state(c, D.base, D.leg, L);
 #ifdef ETG_PROFILE_PHASES
   if (c.gid == 0 && info) {  // overwrite the first info row with the cycle breakdown (debug build only)
@@ -297,6 +285,18 @@ __global__ void __launch_bounds__(BLOCK) k_step(KCfg K, DevState D, const float*
     reward[c.env] = r;
     done[c.env] = d > 0.5f ? 1 : 0;
   }
+}
+template <bool FLAT, bool PLAIN>
+__global__ void __launch_bounds__(BLOCK) k_step(KCfg K, DevState D, const float* action, const uint8_t* donef, float* obs,
+                                                 float* reward, uint8_t* done, float* info) {
+  __shared__ float lds_par[PR_N * BLOCK];
+  step4_body<FLAT, PLAIN, false>(K, D, action, donef, obs, reward, done, info, lds_par);
+}
+template <bool FLAT, bool PLAIN>
+__global__ void __launch_bounds__(BLOCK) k_step_ar(KCfg K, DevState D, const float* action, const uint8_t* donef, float* obs,
+                                                    float* reward, uint8_t* done, float* info) {
+  __shared__ float lds_par[PR_N * BLOCK];
+  step4_body<FLAT, PLAIN, true>(K, D, action, donef, obs, reward, done, info, lds_par);
 }
 
 // n_steps open-loop control steps per launch (rollout_steps), the 4-lanes-per-robot counterpart of k_rollout16
@@ -541,29 +541,13 @@ __global__ void __launch_bounds__(BLOCK) k_finish16(KCfg K, DevState D, const ui
   store_state16(c, D.base, D.leg, L);
 }
 
-// the 16-lanes-per-robot auto-reset (see k_autoreset)
-template <bool FLAT, bool KNEE, bool PLAIN>
-__global__ void __launch_bounds__(BLOCK) k_autoreset16(KCfg K, DevState D, const uint8_t* mask, float* obs) {
-  __shared__ float lds_par[LDS16_FIELDS * BLOCK];
-  GpuCtx16T<FLAT, KNEE, PLAIN> c;
-  if (!make_ctx16(K, D, c, lds_par)) return;
-  if (!mask[c.env]) return;                                   // whole rows drop out together
-  State16<float> L = load_state16<float>(c, D.cache_base, D.cache_leg);
-  const int N = K.n_env;
-  L.p.x += D.reset_off[c.env] - D.cache_off[c.env];
-  L.p.y += D.reset_off[N + c.env] - D.cache_off[N + c.env];
-  reset_finish16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, obs);   // its reading (tick = settle_ticks) comes from K.cring
-  store_state16(c, D.base, D.leg, L);
-  if (c.r == 0) {
-    D.ictl[(size_t)IC_PUSH_LEFT * N + c.env] = 0;
-    for (int k = 0; k < 3; k++) D.ctl[(size_t)(CT_PUSH + k) * N + c.env] = 0.0f;
-  }
-}
-
-template <bool FLAT, bool KNEE, bool PLAIN>
-__global__ void __launch_bounds__(BLOCK) k_step16(KCfg K, DevState D, const float* action, const uint8_t* donef, float* obs,
-                                                   float* reward, uint8_t* done, float* info) {
-  __shared__ float lds_par[LDS16_FIELDS * BLOCK];
+// env.step for the 4 robots of a wave.  AUTO (etg_step_autoreset while every robot has a cached settle): a robot whose step
+// ended its episode restarts inside the same launch -- cached settle -> registers, reset_finish (control state, episode
+// accumulators, first observation over the step's row; the pre-reset ring readings come from KCfg.cring), pending push
+// cleared.  reward / done / info stay the finished step's.
+template <bool FLAT, bool KNEE, bool PLAIN, bool AUTO>
+__device__ __forceinline__ void step16_body(const KCfg& K, const DevState& D, const float* action, const uint8_t* donef, float* obs,
+                                            float* reward, uint8_t* done, float* info, float* lds_par) {
   GpuCtx16T<FLAT, KNEE, PLAIN> c;
   if (!make_ctx16(K, D, c, lds_par)) return;
   State16<float> L = load_state16<float>(c, D.base, D.leg);
@@ -580,6 +564,17 @@ __global__ void __launch_bounds__(BLOCK) k_step16(KCfg K, DevState D, const floa
 #endif
   control_step16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, act, donef ? (float)donef[c.env] : 0.0f, obs, r, d, info,
                  hybrid ? hyb : nullptr);
+  if (AUTO && d > 0.5f) {   // whole 16-lane rows take this branch together (d is the robot's)
+    const int N = K.n_env;
+    L = load_state16<float>(c, D.cache_base, D.cache_leg);
+    L.p.x += D.reset_off[c.env] - D.cache_off[c.env];        // non-zero only on flat ground (settle_cached)
+    L.p.y += D.reset_off[N + c.env] - D.cache_off[N + c.env];
+    reset_finish16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, obs);
+    if (c.r == 0) {
+      D.ictl[(size_t)IC_PUSH_LEFT * N + c.env] = 0;
+      for (int k = 0; k < 3; k++) D.ctl[(size_t)(CT_PUSH + k) * N + c.env] = 0.0f;
+    }
+  }
   store_state16(c, D.base, D.leg, L);
 #ifdef ETG_PROFILE_PHASES
   if (c.env == 0 && c.r == 0 && info) {
@@ -591,6 +586,18 @@ __global__ void __launch_bounds__(BLOCK) k_step16(KCfg K, DevState D, const floa
     reward[c.env] = r;
     done[c.env] = d > 0.5f ? 1 : 0;
   }
+}
+template <bool FLAT, bool KNEE, bool PLAIN>
+__global__ void __launch_bounds__(BLOCK) k_step16(KCfg K, DevState D, const float* action, const uint8_t* donef, float* obs,
+                                                   float* reward, uint8_t* done, float* info) {
+  __shared__ float lds_par[LDS16_FIELDS * BLOCK];
+  step16_body<FLAT, KNEE, PLAIN, false>(K, D, action, donef, obs, reward, done, info, lds_par);
+}
+template <bool FLAT, bool KNEE, bool PLAIN>
+__global__ void __launch_bounds__(BLOCK) k_step16_ar(KCfg K, DevState D, const float* action, const uint8_t* donef, float* obs,
+                                                      float* reward, uint8_t* done, float* info) {
+  __shared__ float lds_par[LDS16_FIELDS * BLOCK];
+  step16_body<FLAT, KNEE, PLAIN, true>(K, D, action, donef, obs, reward, done, info, lds_par);
 }
 
 // n_steps open-loop control steps of every robot in one launch (rollout_steps16): state, control variables and
@@ -669,10 +676,10 @@ __global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, Po
 
 // Gaussian sensor noise on freshly written observation rows: one thread per (robot, channel).  A separate tiny
 // kernel so that the step kernels' code (and register allocation) is the same with and without noise.
-__global__ void k_add_noise(KCfg K, unsigned call, const uint8_t* mask, float* obs) {
+__global__ void k_add_noise(KCfg K, unsigned call, const uint8_t* mask, int invert, float* obs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int env = i >> 4;
-  if (env >= K.n_env || (mask && !mask[env])) return;
+  if (env >= K.n_env || (mask && (mask[env] != 0) == (invert != 0))) return;   // mask: rows to touch (or, inverted, to leave)
   add_sensor_noise(K, env, call, i & 15, obs + (size_t)env * ETG_OBS_DIM);
 }
 
@@ -938,9 +945,10 @@ static inline void advance_obs_stream(EtgHandle* h, int n) {
 }
 
 // noise for the observation rows the launch before wrote last (stream position K.noise_call + n - 1)
-static inline void launch_obs_noise(EtgHandle* h, int n, const uint8_t* mask, float* obs, hipStream_t s) {
-  if (!h->K.noise_on || !obs) return;
-  hipLaunchKernelGGL(k_add_noise, dim3((16 * h->N + 255) / 256), dim3(256), 0, s, h->K, h->K.noise_call + (unsigned)(n - 1), mask, obs);
+static inline void launch_obs_noise(EtgHandle* h, int n, const uint8_t* mask, float* obs, hipStream_t s, int invert = 0, int back = 0) {
+  if (!h->K.noise_on || !obs) return;   // back: stream positions before the newest one (the step's row when a reset row follows it)
+  hipLaunchKernelGGL(k_add_noise, dim3((16 * h->N + 255) / 256), dim3(256), 0, s, h->K,
+                     h->K.noise_call + (unsigned)(n - 1) - (unsigned)back, mask, invert, obs);
 }
 
 // the instantiations of a 16-lane kernel: {flat ground, heightfield} x {plain robot layer, all options, all options + knee rows}
@@ -1083,12 +1091,17 @@ extern "C" int etg_set_reset_offsets(EtgHandle* h, const float* xy, const uint8_
   return ETG_OK;
 }
 
-extern "C" int etg_step(EtgHandle* h, const float* action, const uint8_t* donef, float* obs, float* reward,
-                        uint8_t* done, float* info, void* stream) {
-  CHECK_HANDLE(h);
+static int step_checks(EtgHandle* h, const float* action, float* obs, float* reward, uint8_t* done) {
   if (!obs || !reward || !done) return fail(ETG_ERR_BAD_ARG, "etg_step: obs/reward/done must be non-null");
   if (!h->was_reset) return fail(ETG_ERR_STATE, "etg_step: call etg_reset first");
   if (h->K.motor_mode == 2 && !action) return fail(ETG_ERR_BAD_ARG, "etg_step: the HYBRID motor mode needs a [N,60] command");
+  return ETG_OK;
+}
+
+extern "C" int etg_step(EtgHandle* h, const float* action, const uint8_t* donef, float* obs, float* reward,
+                        uint8_t* done, float* info, void* stream) {
+  CHECK_HANDLE(h);
+  if (int rc = step_checks(h, action, obs, reward, done)) return rc;
   advance_obs_stream(h, 1);
   const dim3 g16((h->N + 3) / 4);
   if (h->lanes == 16) {
@@ -1103,20 +1116,24 @@ extern "C" int etg_step(EtgHandle* h, const float* action, const uint8_t* donef,
 
 extern "C" int etg_step_autoreset(EtgHandle* h, const float* action, const uint8_t* donef, float* obs, float* reward,
                                   uint8_t* done, float* info, void* stream) {
-  int rc = etg_step(h, action, donef, obs, reward, done, info, stream);
-  if (rc != ETG_OK) return rc;
-  if (!h->all_cached) {   // some robot needs a simulated settle: the general reset path, masked by the done bytes
+  CHECK_HANDLE(h);
+  if (!h->all_cached) {   // some robot needs a simulated settle: step, then the general reset path masked by the done bytes
+    int rc = etg_step(h, action, donef, obs, reward, done, info, stream);
+    if (rc != ETG_OK) return rc;
     if (h->push_on && (rc = etg_clear_pushes(h, done, stream)) != ETG_OK) return rc;
     return etg_reset(h, done, obs, stream);
   }
-  advance_obs_stream(h, 1);
+  // every robot has a cached settle: step and restart in ONE launch (k_step16_ar / k_step_ar)
+  if (int rc = step_checks(h, action, obs, reward, done)) return rc;
+  advance_obs_stream(h, 2);                     // two rows per robot at most: the step's (position c) and the reset's (c + 1)
   hipStream_t s = (hipStream_t)stream;
   if (h->lanes == 16) {
-    LAUNCH16(k_autoreset16, dim3((h->N + 3) / 4), s, h->K, h->D, done, obs);
+    LAUNCH16(k_step16_ar, dim3((h->N + 3) / 4), s, h->K, h->D, action, donef, obs, reward, done, info);
   } else {
-    LAUNCH4(k_autoreset, dim3(grid_for(h)), s, h->K, h->D, done, obs);
+    LAUNCH4(k_step_ar, dim3(grid_for(h)), s, h->K, h->D, action, donef, obs, reward, done, info);
   }
-  launch_obs_noise(h, 1, done, obs, s);
+  launch_obs_noise(h, 2, done, obs, s, /*invert=*/1, /*back=*/1);   // the step's rows of the robots that go on
+  launch_obs_noise(h, 2, done, obs, s);                            // the reset rows
   HIP_TRY(hipGetLastError());
   return ETG_OK;
 }

@@ -483,13 +483,19 @@ def test_auto_reset_variants_equal_manual_reset(kw):
     assert torch.equal(oa, ob)
     act = torch.zeros(n, 12, device="cuda:0"); act[::2, 1::3] = 1.5          # every other robot is driven into a fall
     resets = 0
+    # the two envs run different instantiations of the step kernel (k_step*_ar restarts inside the launch), which differ
+    # in where the backend contracts multiply-adds: equal to rounding, not bit for bit
+    close = lambda x, y, tol: bool(((x - y).abs() <= tol * (1 + y.abs())).all())
     for k in range(25):
-        oa, ra, da, _ = a.step(act)
+        oa, ra, da, ia = a.step(act)
         ob, rb, db, _ = b.step(act)
-        assert torch.equal(da, db) and torch.equal(ra, rb), k
+        assert torch.equal(da, db) and close(ra, rb, 1e-4), k
+        assert torch.equal(ia["reset"], da)
         ob, _ = b.reset(env_ids=db)                    # every step, like the auto-reset (an empty mask resets nobody)
         resets += int(db.sum())
-        assert torch.equal(oa, ob), k
-        assert torch.equal(a.get_state(), b.get_state()), k
+        assert close(oa, ob, 1e-3), k
+        assert close(a.get_state(), b.get_state(), 1e-3), k
+        if db.any():                                   # the restarted robots: the reset observation and zeroed episode statistics
+            assert close(oa[db], ob[db], 1e-6) and int(a.episode_stats()[1][db].max()) == 0
     assert resets > 0
     a.close(); b.close()
