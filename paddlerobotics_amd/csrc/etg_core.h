@@ -550,6 +550,9 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   if (Ctx::kPlain) {   // plain_config: two sweeps, straight-line (see physics_tick16)
     pgs_sweep();
     pgs_sweep();
+  } else if (K.iters == 2) {   // the default sweep count, straight-line as well (a uniform, not-taken branch per tick)
+    pgs_sweep();
+    pgs_sweep();
   } else {
     for (int it = 0; it < K.iters; it++) pgs_sweep();
   }

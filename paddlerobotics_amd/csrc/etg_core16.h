@@ -400,6 +400,9 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
     // code, no loop back-edge inside the tick (a taken branch is expensive for a lone wave) -- 35.5 -> 34.2 us per step
     pgs_sweep();
     pgs_sweep();
+  } else if (K.iters == 2) {   // the default sweep count, straight-line as well (a uniform, not-taken branch per tick)
+    pgs_sweep();
+    pgs_sweep();
   } else {
     for (int it = 0; it < K.iters; it++) pgs_sweep();
   }
