@@ -88,3 +88,17 @@ def test_dynamics_id_loss_matches_reference_loss_func(golden):
     for key in ("exp", "ori"):
         got = R.dynamics_id_loss(drpy, motor, mean_dict, key).numpy()
         assert np.allclose(got, g["loss_" + key], rtol=1e-12, atol=1e-12), key
+
+
+def test_bench_refuses_to_fake_a_multi_gpu_run():
+    """`python bench.py --gpus N` starts its own N ranks, one GPU each: with fewer HIP devices than ranks it must stop with a
+    clear message instead of printing an n_gpus it did not use (`--gpus 8` silently ran one rank)."""
+    import subprocess, sys
+    if torch.cuda.is_available() and torch.cuda.device_count() >= 2:
+        pytest.skip("two GPUs present: the launch would succeed")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "ETG_BENCH_BACKEND")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert "HIP device(s) visible" in r.stderr and '"n_gpus"' not in r.stdout
