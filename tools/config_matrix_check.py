@@ -10,7 +10,11 @@ bad = 0
 opts = [dict(), dict(motor_control_mode="torque"), dict(motor_control_mode="hybrid"), dict(enable_action_filter=True),
         dict(enable_action_interpolation=True), dict(enable_clip_motor_commands=True),
         dict(observation_noise_stdev=[0.02, 0.3, 0.0, 0.01, 0.05]), dict(random_param={"random_dynamics": 1, "random_force": 1}),
-        dict(body_contacts=True), dict(sensor_mode={"dis": 0, "RNN": {"time_steps": 2, "mode": "stack", "time_interval": 1}})]
+        dict(body_contacts=True), dict(sensor_mode={"dis": 0, "RNN": {"time_steps": 2, "mode": "stack", "time_interval": 1}}),
+        # round 2: joint-limit stops, no trajectory generator, the optional sensors, auto-reset inside the step launch
+        dict(joint_limits=True), dict(joint_limits=True, body_contacts=True, motor_control_mode="torque"), dict(ETG=0),
+        dict(sensor_mode={"ETG_obs": 1, "footpose": 1, "dynamic_vec": 1, "force_vec": 1, "noise": 1}),
+        dict(auto_reset=True), dict(auto_reset=True, joint_limits=True, random_param={"random_force": 1})]
 for lanes, task, o in itertools.product((16, 4), ("ground", "stairstair"), opts):
     if o.get("body_contacts") and lanes == 4:
         continue
@@ -24,8 +28,8 @@ for lanes, task, o in itertools.product((16, 4), ("ground", "stairstair"), opts)
             a = a.view(N, 12, 5); a[..., 0] = torch.tensor([0.0, 0.9, -1.8] * 4, device="cuda:0") + 0.1 * a[..., 0]
             a[..., 1] = 80.0; a[..., 2] = 0.0; a[..., 3] = 1.5; a[..., 4] *= 2.0; a = a.reshape(N, 60)
         obs, rew, done, info = env.step(a)
-        if done.any():
-            env.reset(env_ids=done.nonzero().flatten())
+        if done.any() and not o.get("auto_reset"):
+            env.reset(env_ids=done)
     ok = bool(torch.isfinite(obs).all() and torch.isfinite(rew).all() and torch.isfinite(env.get_state()).all())
     ret, ln = env.episode_stats()
     print("%-5s lanes %2d %-11s %-70s finite=%s mean episode len %.0f" % ("ok" if ok else "BAD", lanes, task, str(o)[:70], ok, ln.float().mean().item()))
