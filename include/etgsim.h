@@ -157,7 +157,9 @@ typedef struct EtgConfig {
    * ground through one frictionless normal row per leg, solved in the same projected Gauss-Seidel sweep right
    * after the leg's foot rows. Served by the 16-lanes-per-robot kernels (flat ground and heightfield): the free
    * 4th lane of every leg owns the row.                                                                   */
-  int32_t body_contacts;
+  int32_t body_contacts;   /* 0 off; 1 the knee sphere; 2 the DEEPEST of three spheres of knee_radius per leg: knee, shin midpoint
+                            * (carried by the calf), trunk corner next to the leg's hip (trunk_half below) -- still one
+                            * frictionless row per leg, on the leg's 4th lane                                        */
   double knee_radius;
   /* `ETG` kwarg of make_env (train.py:305-309, Dynamic_parallel_model.py:49 runs with ETG=0): 0 switches the
    * trajectory generator off -- the position command is pose_ori + action, info["ETG_act"] and the ETG
@@ -168,6 +170,7 @@ typedef struct EtgConfig {
    * (DESIGN.md section 2); 0 = no limits (round-1 model).                                                  */
   int32_t joint_limits;
   double joint_lower[3], joint_upper[3];   /* hip, thigh, calf (rad) */
+  double trunk_half[3];                    /* half extents of the trunk's collision box (body_contacts = 2), base frame */
 } EtgConfig;
 
 typedef struct EtgHandle EtgHandle;

@@ -607,27 +607,51 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
     target[3 * l + 1] = 0; target[3 * l + 2] = 0;
     for (int k = 0; k < 3; k++) e.lam[3 * l + k] *= T(s.cfg.warmstart);
   }
-  // knees: a sphere at the calf joint origin, carried by the thigh (the calf joint does not move it)
+  // body contacts (cfg.body_contacts): one frictionless row per leg.  1: a sphere at the knee (the calf joint origin,
+  // carried by the thigh: the calf joint does not move it).  2: the DEEPEST of three spheres of knee_radius -- knee, shin
+  // midpoint (carried by the calf), trunk corner next to the leg's hip (carried by the base: no joint moves it).
   for (int l = 0; l < 4; l++) {
     kactive[l] = 0;
     target[12 + l] = 0;
     if (!s.cfg.body_contacts) continue;
     const int c = 3 + 3 * l;
     const T krad = T(s.cfg.knee_radius);
-    T h, n[3];
-    terrain_query(s, e.band, pw[c][0], pw[c][1], &h, n);
-    T phi = (pw[c][2] - h) * n[2] - krad;
+    struct Cand { T p[3]; int first_body; };   // first_body: the chain of joints moving the point starts at this body (0 = none)
+    Cand cand[3];
+    int ncand = 1;
+    for (int k = 0; k < 3; k++) cand[0].p[k] = pw[c][k];
+    cand[0].first_body = s.parent[c];
+    if (s.cfg.body_contacts >= 2) {
+      T sl[3] = {0, 0, T(-0.5 * s.model.lower_len)}, o[3];
+      mat3_mul_vec(Rw[c], sl, o);
+      for (int k = 0; k < 3; k++) cand[1].p[k] = pw[c][k] + o[k];
+      cand[1].first_body = c;
+      T corner[3] = {T(s.model.hip_origin[l][0] > 0 ? s.cfg.trunk_half[0] : -s.cfg.trunk_half[0]),
+                     T(s.model.hip_origin[l][1] > 0 ? s.cfg.trunk_half[1] : -s.cfg.trunk_half[1]), T(-s.cfg.trunk_half[2])};
+      mat3_mul_vec(R, corner, o);
+      for (int k = 0; k < 3; k++) cand[2].p[k] = e.pos[k] + o[k];
+      cand[2].first_body = 0;
+      ncand = 3;
+    }
+    int best = -1;
+    T phi = 0, n[3] = {0, 0, 1};
+    for (int q = 0; q < ncand; q++) {
+      T h, nq[3];
+      terrain_query(s, e.band, cand[q].p[0], cand[q].p[1], &h, nq);
+      const T pq = (cand[q].p[2] - h) * nq[2] - krad;
+      if (best < 0 || pq < phi) { best = q; phi = pq; for (int k = 0; k < 3; k++) n[k] = nq[k]; }
+    }
     kactive[l] = phi < T(s.cfg.contact_margin);
     if (!kactive[l]) continue;
     T cp[3], rel[3], rxd[3], tmp[3];
-    for (int k = 0; k < 3; k++) { cp[k] = pw[c][k] - krad * n[k]; rel[k] = cp[k] - e.pos[k]; }
+    for (int k = 0; k < 3; k++) { cp[k] = cand[best].p[k] - krad * n[k]; rel[k] = cp[k] - e.pos[k]; }
     T* row = J[12 + l];
     cross(rel, n, rxd);
     mat3T_mul_vec(R, rxd, tmp);
     for (int k = 0; k < 3; k++) row[k] = tmp[k];
     mat3T_mul_vec(R, n, tmp);
     for (int k = 0; k < 3; k++) row[3 + k] = tmp[k];
-    for (int b = s.parent[c]; b > 0; b = s.parent[b]) {  // hip and thigh joints
+    for (int b = cand[best].first_body; b > 0; b = s.parent[b]) {  // the joints that move the point
       T axw[3] = {Rw[b][0][s.axis[b]], Rw[b][1][s.axis[b]], Rw[b][2][s.axis[b]]};
       T rj[3], cr[3];
       for (int k = 0; k < 3; k++) rj[k] = cp[k] - pw[b][k];

@@ -82,6 +82,7 @@ class EtgConfig(C.Structure):
         ("enable_etg", C.c_int32),
         ("joint_limits", C.c_int32),
         ("joint_lower", C.c_double * 3), ("joint_upper", C.c_double * 3),
+        ("trunk_half", C.c_double * 3),
     ]
 
 
@@ -107,6 +108,8 @@ FOOT_RADIUS = 0.02
 # joint limits of (hip, thigh, calf): the bounds of ACTION_CONFIG, a1.py:186-195 (= the URDF limits Bullet enforces)
 JOINT_LOWER = (-0.802851455917, -1.0471975512, -2.69653369433)
 JOINT_UPPER = (0.802851455917, 4.18879020479, -0.916297857297)
+# half extents of the trunk's collision box (recalled from pybullet_data/a1/a1.urdf: box 0.267 x 0.194 x 0.114)
+TRUNK_HALF = (0.1335, 0.097, 0.057)
 
 # ---- recalled URDF inertials (FR leg; mirrored below) -------------------------------
 _TRUNK = dict(mass=4.713, com=(0.0, 0.0, 0.0),
@@ -218,6 +221,7 @@ def default_config(num_envs, *, action_repeat=13, sim_dt=0.002, settle_ticks=500
     c.joint_limits = int(bool(joint_limits))
     for k in range(3):
         c.joint_lower[k], c.joint_upper[k] = JOINT_LOWER[k], JOINT_UPPER[k]
+        c.trunk_half[k] = TRUNK_HALF[k]
     if heightfield is not None:
         c.hf_ny, c.hf_nx = heightfield["heights"].shape
         c.hf_cell = heightfield["cell"]

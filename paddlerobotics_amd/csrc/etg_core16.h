@@ -236,15 +236,42 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   V wbs = L.wb + dt * ab.a, vbs = L.vb + dt * ab.l;
   F qds = L.qd + dt * qdd;
   c.phase(4);
-  // ---- foot contact: this lane owns contact row `sub` (n, t1, t2) of its leg.  With K.knee (heightfield kernels only)
-  // the aux lane owns a 4th, frictionless row: a sphere at the knee (calf joint origin), carried by the thigh.
+  // ---- foot contact: this lane owns contact row `sub` (n, t1, t2) of its leg.  With K.knee the aux lane owns a 4th,
+  // frictionless row: a sphere at the knee (calf joint origin), carried by the thigh (K.knee >= 2: see below).
   constexpr bool knee = Ctx::kKnee;   // compile-time: the flat-ground and plain heightfield kernels do not contain the rows
   const auto s3 = c.sub_is(3);
   const F f3 = sel_(s3, one, zero);
   V pc = g.pf;
   F rad(K.foot_radius);
+  F jm12 = one, jm3 = mj;   // which joints move the point of this lane's row (hip & thigh, calf)
   if (knee) {
-    pc = {sel_(s3, g.o3.x, g.pf.x), sel_(s3, g.o3.y, g.pf.y), sel_(s3, g.o3.z, g.pf.z)};
+    V pb = g.o3;
+    if (K.knee >= 2) {
+      // the aux lane's row takes the DEEPEST of three spheres of knee_radius: knee, shin midpoint (moved by all three
+      // joints), trunk corner next to this leg's hip (moved by none); ties go to the earlier candidate, as in the oracle
+      const V ps = g.o3 - F(0.5f * K.lower_len) * g.ez3;
+      const V pt = {sel_(g.o1.x > zero, F(K.trunk_half[0]), F(-K.trunk_half[0])),
+                    sel_(g.o1.y > zero, F(K.trunk_half[1]), F(-K.trunk_half[1])), F(-K.trunk_half[2])};
+      auto depth = [&](const V& q) -> F {
+        const V w = {L.p.x + dot(Rw.r0, q), L.p.y + dot(Rw.r1, q), L.p.z + dot(Rw.r2, q)};
+        if (Ctx::kFlat) return w.z;
+        F hgt, nwx, nwy, nwz;
+        c.terrain(K, w.x, w.y, hgt, nwx, nwy, nwz);
+        return (w.z - hgt) * nwz;
+      };
+      F best = depth(pb);
+      const F ds = depth(ps);
+      const auto ms = ds < best;
+      pb = {sel_(ms, ps.x, pb.x), sel_(ms, ps.y, pb.y), sel_(ms, ps.z, pb.z)};
+      best = sel_(ms, ds, best);
+      F j3 = sel_(ms, one, zero);
+      const F dtk = depth(pt);
+      const auto mt = dtk < best;
+      pb = {sel_(mt, pt.x, pb.x), sel_(mt, pt.y, pb.y), sel_(mt, pt.z, pb.z)};
+      jm12 = sel_(s3, sel_(mt, zero, one), one);
+      jm3 = sel_(s3, sel_(mt, zero, j3), one);
+    }
+    pc = {sel_(s3, pb.x, g.pf.x), sel_(s3, pb.y, g.pf.y), sel_(s3, pb.z, g.pf.z)};
     rad = sel_(s3, F(K.knee_radius), F(K.foot_radius));
   }
   V fw = {L.p.x + dot(Rw.r0, pc), L.p.y + dot(Rw.r1, pc), L.p.z + dot(Rw.r2, pc)};
@@ -274,9 +301,10 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   V rc = pc - rad * dn;
   V k1 = cross(xax, rc - g.o1), k2 = cross(g.yax, rc - g.o2), k3 = cross(g.yax, rc - g.o3);
   V dir = {sel_(s0, dn.x, sel_(s1, d1.x, d2.x)), sel_(s0, dn.y, sel_(s1, d1.y, d2.y)), sel_(s0, dn.z, sel_(s1, d1.z, d2.z))};
-  if (knee) {   // the knee row pushes along the normal; the calf joint does not move the knee
+  if (knee) {   // the body row pushes along the normal; the calf joint does not move the knee (nor any joint the trunk)
     dir = {sel_(s3, dn.x, dir.x), sel_(s3, dn.y, dir.y), sel_(s3, dn.z, dir.z)};
-    k3 = mj * k3;
+    k3 = jm3 * k3;
+    if (K.knee >= 2) { k1 = jm12 * k1; k2 = jm12 * k2; }
   }
   F Jl0 = rowf * dot(dir, k1), Jl1 = rowf * dot(dir, k2), Jl2 = rowf * dot(dir, k3);
   F HJ0 = Hi11 * Jl0 + Hi12 * Jl1 + Hi13 * Jl2;

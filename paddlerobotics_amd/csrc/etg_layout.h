@@ -66,8 +66,9 @@ struct KCfg {
   float jlo[3], jhi[3];  // joint-limit stops (hip, thigh, calf)
   int motor_mode;        // 0 POSITION (PD on a joint-angle command), 1 TORQUE (the command is the torque)
   float clip_cmd;        // > 0: clip the position command to q +- clip_cmd every tick (a1.py:439-457)
-  int knee;              // EtgConfig.body_contacts: knee spheres collide (16-lane heightfield kernels)
+  int knee;              // EtgConfig.body_contacts: 1 knee spheres collide; 2 deepest of knee / shin / trunk corner (16-lane kernels)
   float knee_radius;
+  float trunk_half[3];   // knee == 2: half extents of the trunk box (its corners collide too)
   // Gaussian sensor noise (minitaur.py:1206-1211): stdev of motor angle, motor velocity, motor torque (not part of
   // the 49-float observation), base rpy, base rpy rate -- the order of SENSOR_NOISE_STDDEV (minitaur.py:102)
   int noise_on;
@@ -307,6 +308,7 @@ inline KCfg make_kcfg(const EtgConfig& c, const EtgRobotModel& m) {
   K.motor_mode = c.motor_mode;
   K.clip_cmd = (float)c.clip_motor_commands;
   K.knee = c.body_contacts; K.knee_radius = (float)c.knee_radius;
+  for (int k = 0; k < 3; k++) K.trunk_half[k] = (float)c.trunk_half[k];
   K.etg_on = c.enable_etg != 0;
   K.jlim = c.joint_limits != 0;
   for (int k = 0; k < 3; k++) { K.jlo[k] = (float)c.joint_lower[k]; K.jhi[k] = (float)c.joint_upper[k]; }

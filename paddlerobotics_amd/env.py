@@ -200,7 +200,8 @@ class BatchedQuadrupedEnv:
             reward_param=reward_param, reward_p=reward_p, vel_d=vel_d, heightfield=heightfield,
             lanes_per_robot=lanes_per_robot, motor_mode=motor_mode,
             clip_motor_commands=0.2 if enable_clip_motor_commands else 0.0,   # MAX_MOTOR_ANGLE_CHANGE_PER_STEP, a1.py
-            body_contacts=1 if body_contacts else 0, knee_radius=knee_radius,
+            # True / 1: knee spheres; 2 or "all": the deepest of knee, shin midpoint and trunk corner per leg
+            body_contacts=2 if body_contacts in (2, "all") else (1 if body_contacts else 0), knee_radius=knee_radius,
             enable_etg=1 if self.ETG else 0, joint_limits=1 if joint_limits else 0)
         self.model = A.default_model()
         if task == "balancebeam":

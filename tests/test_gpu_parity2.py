@@ -499,3 +499,46 @@ def test_auto_reset_variants_equal_manual_reset(kw):
             assert close(oa[db], ob[db], 1e-6) and int(a.episode_stats()[1][db].max()) == 0
     assert resets > 0
     a.close(); b.close()
+
+
+def test_trunk_and_shin_contacts_match_oracle():
+    """body_contacts = 2 on the GPU (both 16-lane instantiations with the body rows): the folded-legs belly landing of
+    tests/test_terrain_and_randomisation.py (trunk corners carry the robot, one of them across a step edge) against the
+    oracle, and the limp standing robot no longer sinks through the floor."""
+    from tests.test_terrain_and_randomisation import _folded_drop_state, _step_edge_heightfield
+    _need_gpu()
+    n = 64
+    for terrain in (0, 1):
+        hf = _step_edge_heightfield() if terrain else None
+        kw = dict(task="heightfield", heightfield=hf) if terrain else {}
+        env = _make(n, motor_control_mode="torque", body_contacts=2, solver_iters=4, **kw)
+        env.reset()
+        orc = _oracle(n, motor_mode=1, body_contacts=2, solver_iters=4, **(dict(terrain=1, heightfield=hf) if terrain else {}))
+        if terrain:
+            orc.set_heightfield(hf["heights"])
+        orc.reset()
+        st = _folded_drop_state(orc.get_state())
+        st[2:] = st[:2].repeat(n // 2 - 1, axis=0)
+        orc.set_state(st); env.set_state(torch.as_tensor(st, dtype=torch.float32, device="cuda:0"))
+        act = np.zeros((n, 12)); ta = torch.zeros(n, 12, device="cuda:0")
+        worst = 0.0
+        for k in range(12):
+            orc.step(act); env.step(ta)
+            so, se = orc.get_state(), env.get_state().double().cpu().numpy()
+            worst = max(worst, np.abs(so[:, 13:25] - se[:, 13:25]).max())
+            assert np.abs(so[:, 13:25] - se[:, 13:25]).max() < 1e-4 and np.abs(so[:, :3] - se[:, :3]).max() < 1e-5, (terrain, k)
+        rest = 0.057 + 0.02
+        assert abs(se[0, 2] - rest) < 5e-4
+        _say("body_contacts=2 terrain %d: belly landing q err max %.2e, rest height %.4f" % (terrain, worst, se[0, 2]))
+        env.close()
+        # limp standing robots, 40 control steps: the trunk never goes below its corner spheres
+        env = _make(n, motor_control_mode="torque", body_contacts=2, solver_iters=4, **kw)
+        env.reset()
+        low = torch.full((n,), 1.0, device="cuda:0")
+        for k in range(40):
+            env.step(ta)
+            low = torch.minimum(low, env.get_state()[:, 2])
+        assert low.min().item() > rest - 2e-3 and torch.isfinite(env.get_state()).all()
+        env.close()
+    with pytest.raises(Exception):
+        _make(n, body_contacts=2, lanes_per_robot=4)

@@ -325,6 +325,71 @@ def test_body_contacts_config_and_flat_ground_knee_rows():
     assert orc.get_state()[0, 2] > -0.2
 
 
+def _folded_drop_state(st):
+    """legs folded up beside the trunk (thigh 2.5, calf -2.6: knees above the back, feet level with the belly), dropped from
+    16 cm: the trunk's bottom corners reach the ground first.  Robot 1 lands across a 5 cm step edge."""
+    st = st.copy()
+    st[:, 2] = 0.16
+    st[:, 13:25] = np.tile([0.0, 2.5, -2.6], 4)
+    st[1, 13:25] = np.tile([0.3, 2.3, -2.5], 4); st[1, 0] = 0.15
+    return st
+
+
+def _step_edge_heightfield():
+    hf = {"heights": np.zeros((64, 64), dtype=np.float32), "cell": 0.1, "origin": (-3.2, -3.2)}
+    hf["heights"][:, 34:] = 0.05    # a 5 cm step ahead of x = 0.2
+    return hf
+
+
+@pytest.mark.parametrize("terrain", [0, 1])
+def test_emulation_trunk_and_shin_contacts_match_oracle(terrain):
+    """body_contacts = 2: the leg's 4th row takes the deepest of knee / shin midpoint / trunk corner.  (a) a limp robot with
+    folded legs lands on its belly: the trunk corners carry it at half height + radius, kernel source == oracle; (b) the limp
+    standing robot of the knee test is caught at the same height instead of sinking through the floor."""
+    from oracle.oracle import OracleSim
+    from tests.emu.emu import EmuSim
+    n = 2
+    hf = _step_edge_heightfield() if terrain else None
+    cfg = A.default_config(n, solver_iters=4, motor_mode=1, body_contacts=2, terrain=terrain, heightfield=hf)
+    assert cfg.body_contacts == 2 and tuple(cfg.trunk_half) == A.TRUNK_HALF
+    rest = A.TRUNK_HALF[2] + cfg.knee_radius
+    orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=16)
+    for s in (orc, emu):
+        if terrain:
+            s.set_heightfield(hf["heights"])
+        s.reset()
+    st = _folded_drop_state(orc.get_state())
+    orc.set_state(st); emu.set_state(st)
+    act = np.zeros((n, 12))
+    for k in range(12):
+        orc.step(act); emu.step(act)
+        so, se = orc.get_state(), emu.get_state()
+        assert np.abs(so[:, 13:25] - se[:, 13:25]).max() < 1e-4 and np.abs(so[:, :3] - se[:, :3]).max() < 1e-5, k
+    assert abs(so[0, 2] - rest) < 5e-4                      # flat part: belly rests on its corner spheres
+    if terrain:
+        assert rest + 0.01 < so[1, 2] < rest + 0.05 + 1e-3  # across the step edge: the front corners sit on the step
+    # (b) limp standing robot, 40 control steps: with the knee rows alone the trunk passes through the floor
+    lows = {}
+    for bc in (1, 2):
+        cfg = A.default_config(n, solver_iters=4, motor_mode=1, body_contacts=bc, terrain=terrain, heightfield=hf)
+        orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=16)
+        for s in (orc, emu):
+            if terrain:
+                s.set_heightfield(hf["heights"])
+            s.reset()
+        low = np.full(n, 1.0)
+        for k in range(40):
+            orc.step(act); emu.step(act)
+            so, se = orc.get_state(), emu.get_state()
+            low = np.minimum(low, np.minimum(so[:, 2], se[:, 2]))
+            if k < 8:
+                assert np.abs(so[:, 13:25] - se[:, 13:25]).max() < 1e-4 and np.abs(so[:, :3] - se[:, :3]).max() < 1e-5, (bc, k)
+        lows[bc] = low
+        if bc == 2:   # limp legs flop chaotically (fp32 vs fp64), the trunk does not
+            assert np.abs(so[:, :3] - se[:, :3]).max() < 5e-3
+    assert lows[1][0] < 0.0 and lows[2].min() > rest - 2e-3
+
+
 @pytest.mark.parametrize("lanes", [4, 16])
 def test_emulation_joint_limits_match_oracle(lanes):
     """EtgConfig.joint_limits (bounds of a1.py:186-195): constant torques drive the hip and knee joints into their stops

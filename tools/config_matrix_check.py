@@ -14,7 +14,7 @@ opts = [dict(), dict(motor_control_mode="torque"), dict(motor_control_mode="hybr
         # round 2: joint-limit stops, no trajectory generator, the optional sensors, auto-reset inside the step launch
         dict(joint_limits=True), dict(joint_limits=True, body_contacts=True, motor_control_mode="torque"), dict(ETG=0),
         dict(sensor_mode={"ETG_obs": 1, "footpose": 1, "dynamic_vec": 1, "force_vec": 1, "noise": 1}),
-        dict(auto_reset=True), dict(auto_reset=True, joint_limits=True, random_param={"random_force": 1})]
+        dict(body_contacts=2), dict(auto_reset=True), dict(auto_reset=True, joint_limits=True, random_param={"random_force": 1})]
 for lanes, task, o in itertools.product((16, 4), ("ground", "stairstair"), opts):
     if o.get("body_contacts") and lanes == 4:
         continue
