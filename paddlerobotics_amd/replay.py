@@ -1,0 +1,160 @@
+"""The transition side of the step boundary: what the reference's episode loops hand to its off-policy learner.
+
+  ReplayMemory(max_size, obs_dim, act_dim)          train.py:323-324 (parl.utils.ReplayMemory; parl is not vendored in
+  rpm.append(obs, action, reward, next_obs, terminal)  the reference tree: its interface is taken from these call sites)
+  rpm.size(), rpm.sample_batch(BATCH_SIZE)          train.py:141,159,163-165,240-241
+  terminal = 1 - float(done)                        train.py:148-149,229-230 (the stored flag is the BOOTSTRAP mask)
+
+One env here is thousands of robots, so one `step()` yields a BATCH of transitions: `append_batch` writes the rows of the
+robots whose episode is still running into a ring of transitions that lives in HBM next to the simulator -- no host copy,
+no host synchronisation (the write position is a device scalar; rows of finished robots go to a scratch slot).
+`collect_transitions` is the batched run_train_episode / run_EStrain_episode collection loop.
+"""
+import numpy as np
+import torch
+
+
+class DeviceReplayMemory:
+    def __init__(self, max_size, obs_dim, act_dim, device="cuda:0"):
+        self.max_size, self.obs_dim, self.act_dim = int(max_size), int(obs_dim), int(act_dim)
+        self.device = torch.device(device)
+        z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.device)
+        # row max_size of every array is the scratch slot masked-out rows are written to
+        self.obs, self.next_obs = z(self.max_size + 1, self.obs_dim), z(self.max_size + 1, self.obs_dim)
+        self.action = z(self.max_size + 1, self.act_dim)
+        self.reward, self.terminal = z(self.max_size + 1), z(self.max_size + 1)
+        self._pos = torch.zeros((), dtype=torch.int64, device=self.device)     # next slot to write
+        self._count = torch.zeros((), dtype=torch.int64, device=self.device)   # transitions ever appended
+
+    # ---- writing
+    def slots(self, n, mask=None):
+        """ring slots for the next batch of `n` rows (mask [n] bool/uint8: only those rows are stored) and advance the
+        write position; all on the device."""
+        if n > self.max_size:
+            raise ValueError("a batch of %d transitions does not fit a memory of %d" % (n, self.max_size))
+        if mask is None:
+            k = torch.arange(n, device=self.device)
+            slot = (self._pos + k) % self.max_size
+            took = n
+        else:
+            m = mask.to(self.device).view(-1).to(torch.int64)
+            if m.numel() != n:
+                raise ValueError("mask has %d entries for a batch of %d" % (m.numel(), n))
+            k = torch.cumsum(m, 0) - 1
+            slot = torch.where(m > 0, (self._pos + k) % self.max_size, torch.full_like(k, self.max_size))
+            took = m.sum()
+        self._pos = (self._pos + took) % self.max_size
+        self._count = self._count + took
+        return slot
+
+    def write_before(self, slot, obs, action):
+        self.obs.index_copy_(0, slot, self._rows(obs, self.obs_dim))
+        self.action.index_copy_(0, slot, self._rows(action, self.act_dim))
+
+    def write_after(self, slot, reward, next_obs, terminal):
+        self.reward.index_copy_(0, slot, self._vec(reward))
+        self.next_obs.index_copy_(0, slot, self._rows(next_obs, self.obs_dim))
+        self.terminal.index_copy_(0, slot, self._vec(terminal))
+
+    def append_batch(self, obs, action, reward, next_obs, terminal, mask=None):
+        slot = self.slots(self._rows(obs, self.obs_dim).shape[0], mask)
+        self.write_before(slot, obs, action)
+        self.write_after(slot, reward, next_obs, terminal)
+
+    def append(self, obs, action, reward, next_obs, terminal):
+        """one transition (the reference's call) or a batch of them"""
+        obs = torch.as_tensor(obs, dtype=torch.float32, device=self.device)
+        if obs.dim() == 1:
+            r = lambda x: torch.as_tensor(x, dtype=torch.float32, device=self.device).reshape(1, -1)
+            self.append_batch(r(obs), r(action), r(reward).view(1), r(next_obs), r(terminal).view(1))
+        else:
+            self.append_batch(obs, action, reward, next_obs, terminal)
+
+    # ---- reading
+    def size(self):
+        return int(min(int(self._count.item()), self.max_size))
+
+    def __len__(self):
+        return self.size()
+
+    def sample_batch(self, batch_size, generator=None):
+        """uniform over the stored transitions, with replacement (as the reference's memory draws indices):
+        (obs, action, reward, next_obs, terminal) on the device"""
+        n = torch.clamp(self._count, max=self.max_size)
+        u = torch.rand(int(batch_size), device=self.device, generator=generator)
+        idx = torch.clamp((u * n).to(torch.int64), max=self.max_size - 1)
+        return self.obs[idx], self.action[idx], self.reward[idx], self.next_obs[idx], self.terminal[idx]
+
+    # ---- on-disk format: one .npz with the arrays of the filled part, oldest rows first are NOT reordered (ring order)
+    def save(self, path):
+        n = self.size()
+        np.savez(path, obs=self.obs[:n].cpu().numpy(), action=self.action[:n].cpu().numpy(),
+                 reward=self.reward[:n].cpu().numpy(), terminal=self.terminal[:n].cpu().numpy(),
+                 next_obs=self.next_obs[:n].cpu().numpy(),
+                 other=np.array([n, int(self._pos.item())], dtype=np.int64))
+
+    def load(self, path):
+        d = np.load(path if str(path).endswith(".npz") else str(path) + ".npz")
+        n = int(d["other"][0])
+        if n > self.max_size or d["obs"].shape[1] != self.obs_dim or d["action"].shape[1] != self.act_dim:
+            raise ValueError("stored memory (%d x obs %d, act %d) does not fit this one" %
+                             (n, d["obs"].shape[1], d["action"].shape[1]))
+        for name in ("obs", "action", "reward", "terminal", "next_obs"):
+            getattr(self, name)[:n] = torch.as_tensor(d[name][:n], dtype=torch.float32, device=self.device)
+        self._pos = torch.tensor(int(d["other"][1]) % self.max_size, dtype=torch.int64, device=self.device)
+        self._count = torch.tensor(n, dtype=torch.int64, device=self.device)
+
+    # ---- helpers
+    def _rows(self, x, dim):
+        x = torch.as_tensor(x, dtype=torch.float32, device=self.device)
+        if x.dim() != 2 or x.shape[1] != dim:
+            raise ValueError("expected [n, %d], got %s" % (dim, tuple(x.shape)))
+        return x
+
+    def _vec(self, x):
+        return torch.as_tensor(x, device=self.device).to(torch.float32).view(-1)
+
+
+def collect_transitions(env, rpm, max_step, policy=None, action_bound=0.3, mode="predict", ETG_w=None, ETG_b=None,
+                        x_noise=0, precision=0, generator=None, info_keys=("torso", "feet", "up", "tau", "stand", "badfoot", "footcontact")):
+    """One episode of every robot with its transitions stored in `rpm` (run_train_episode train.py:129-179,
+    run_EStrain_episode train.py:213-249 with es_rpm), batched:
+
+      reset(ETG_w, ETG_b, x_noise); for steps = 1 .. max_step + 1:
+        action  = policy.predict(obs) | policy.sample(obs) | U(-1, 1)        (mode "predict" | "sample" | "uniform")
+        next_obs, reward, done, info = step(action * action_bound, donef = steps > max_step)
+        rpm.append(obs, action, reward, next_obs, 1 - done)   for the robots whose episode was still running
+        infos[key] += info[key], success += (info["velx"] >= 0.3)            (alive-masked)
+
+    The action stored is the UNSCALED one, as in the reference.  Returns (episode_return [N], episode_len [N], infos)
+    with infos[key] [N] the per-episode sums and infos["success_rate"] [N]."""
+    n, dev = env.num_envs, env.device
+    adim = env.action_space.shape[0]
+    obs, _ = env.reset(ETG_w=ETG_w, ETG_b=ETG_b, x_noise=x_noise)
+    alive = torch.ones(n, dtype=torch.bool, device=dev)
+    infos = {k: torch.zeros(n, device=dev) for k in info_keys}
+    success = torch.zeros(n, device=dev)
+    if mode not in ("predict", "sample", "uniform"):
+        raise ValueError("mode must be 'predict', 'sample' or 'uniform'")
+    if mode != "uniform" and policy is None:
+        raise ValueError("mode %r needs a policy" % mode)
+    for steps in range(1, max_step + 2):
+        if mode == "uniform":
+            action = torch.rand(n, adim, device=dev, generator=generator) * 2 - 1
+        elif mode == "sample":
+            action = policy.sample(obs, 1.0, precision, generator=generator, return_logp=False)
+        else:
+            action = policy.predict(obs, 1.0, precision)
+        slot = rpm.slots(n, alive)
+        rpm.write_before(slot, obs, action)          # the observation buffer is overwritten by the step
+        obs, reward, done, info = env.step(action * action_bound, donef=(steps > max_step))
+        rpm.write_after(slot, reward, obs, 1.0 - done.to(torch.float32))
+        af = alive.to(torch.float32)
+        for k in info_keys:
+            if k in info:
+                infos[k] += af * info[k]
+        success += af * (info["velx"] >= 0.3).to(torch.float32)
+        alive = alive & ~done.view(-1).to(torch.bool)
+    ret, ln = env.episode_stats()
+    infos["success_rate"] = success / ln.to(torch.float32).clamp(min=1)
+    return ret, ln, infos

@@ -1,0 +1,174 @@
+"""The transition hand-off of the step boundary (paddlerobotics_amd/replay.py): the reference's ReplayMemory call sites
+(train.py:141,159,163-165,240-241,323-324) served from a ring of transitions on the device, and the batched
+run_train_episode / run_EStrain_episode collection loop (train.py:129-179,213-249)."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from paddlerobotics_amd.replay import DeviceReplayMemory, collect_transitions
+
+
+def _batch(n, od, ad, base):
+    obs = torch.arange(n * od, dtype=torch.float32).view(n, od) + base
+    return obs, obs[:, :ad] * 0.5, obs[:, 0] * 2.0, obs + 0.25, (obs[:, 0] % 2 == 0).float()
+
+
+def test_memory_append_mask_wrap_sample_and_files(tmp_path):
+    od, ad = 5, 3
+    m = DeviceReplayMemory(10, od, ad, device="cpu")
+    assert m.size() == 0
+    # single transition, the reference's call (1-D numpy rows, python scalars)
+    m.append(np.arange(od, dtype=np.float64), np.ones(ad), 1.5, np.arange(od) + 1.0, 1.0)
+    assert m.size() == 1 and m.obs[0].tolist() == [0, 1, 2, 3, 4] and m.reward[0] == 1.5 and m.terminal[0] == 1.0
+    # masked batch: rows 0, 2, 3 of 4 are stored, in order, after the first transition
+    o, a, r, no, t = _batch(4, od, ad, 100.0)
+    m.append_batch(o, a, r, no, t, mask=torch.tensor([1, 0, 1, 1], dtype=torch.uint8))
+    assert m.size() == 4
+    assert torch.equal(m.obs[1:4], o[[0, 2, 3]]) and torch.equal(m.action[1:4], a[[0, 2, 3]])
+    assert torch.equal(m.reward[1:4], r[[0, 2, 3]]) and torch.equal(m.next_obs[1:4], no[[0, 2, 3]])
+    assert torch.equal(m.terminal[1:4], t[[0, 2, 3]])
+    # wrap around: 8 more rows into a ring of 10 -> slots 4..9, 0, 1; size saturates
+    o2, a2, r2, no2, t2 = _batch(8, od, ad, 1000.0)
+    m.append_batch(o2, a2, r2, no2, t2)
+    assert m.size() == 10 and int(m._pos) == 2
+    assert torch.equal(m.obs[4:10], o2[:6]) and torch.equal(m.obs[0:2], o2[6:]) and torch.equal(m.obs[2:4], o[[2, 3]])
+    # an all-false mask stores nothing
+    before = m.obs.clone()
+    m.append_batch(o, a, r, no, t, mask=torch.zeros(4, dtype=torch.bool))
+    assert torch.equal(m.obs[:10], before[:10]) and int(m._pos) == 2
+    # sampling: rows come from the stored set, consistent across the five arrays, roughly uniform
+    g = torch.Generator().manual_seed(0)
+    so, sa, sr, sno, st = m.sample_batch(4000, generator=g)
+    assert so.shape == (4000, od) and sa.shape == (4000, ad) and sr.shape == (4000,) and st.shape == (4000,)
+    assert torch.equal(sno, so + 0.25) and torch.equal(sr, so[:, 0] * 2.0)
+    _, counts = torch.unique(so[:, 0], return_counts=True)
+    assert counts.numel() == 10 and counts.min() > 300
+    # a partly filled memory only yields what it holds
+    p = DeviceReplayMemory(100, od, ad, device="cpu")
+    p.append_batch(*_batch(3, od, ad, 7.0))
+    assert set(p.sample_batch(200, generator=g)[0][:, 0].tolist()) <= {7.0, 12.0, 17.0}
+    # files
+    m.save(str(tmp_path / "rpm"))
+    q = DeviceReplayMemory(10, od, ad, device="cpu")
+    q.load(str(tmp_path / "rpm"))
+    assert q.size() == 10 and int(q._pos) == 2 and torch.equal(q.obs[:10], m.obs[:10]) and torch.equal(q.terminal[:10], m.terminal[:10])
+    with pytest.raises(ValueError):
+        DeviceReplayMemory(5, od, ad, device="cpu").load(str(tmp_path / "rpm"))
+    with pytest.raises(ValueError):
+        m.append_batch(*_batch(11, od, ad, 0.0))
+    with pytest.raises(ValueError):
+        m.append_batch(torch.zeros(2, od + 1), a[:2], r[:2], no[:2], t[:2])
+
+
+class _ToyEnv:
+    """deterministic stand-in with the env surface collect_transitions uses: robot i terminates at step i + 1; obs is ONE
+    buffer overwritten in place by every step (as the real env's is)"""
+
+    class _Space:
+        shape = (2,)
+
+    def __init__(self, n):
+        self.num_envs, self.device, self.action_space = n, torch.device("cpu"), self._Space()
+        self.obs = torch.zeros(n, 3)
+        self.t = 0
+
+    def reset(self, **kw):
+        self.t = 0
+        self.obs[:] = torch.arange(self.num_envs, dtype=torch.float32)[:, None]
+        self.ret = torch.zeros(self.num_envs); self.len = torch.zeros(self.num_envs, dtype=torch.int32)
+        self.alive = torch.ones(self.num_envs, dtype=torch.bool)
+        return self.obs, {}
+
+    def step(self, action, donef=False):
+        self.t += 1
+        self.obs += 100.0 + action.sum(1, keepdim=True)
+        done = (torch.arange(self.num_envs) + 1 <= self.t) | bool(donef)
+        rew = torch.full((self.num_envs,), float(self.t))
+        self.ret += self.alive * rew; self.len += self.alive.int(); self.alive &= ~done
+        info = {"torso": rew * 2, "velx": torch.where(torch.arange(self.num_envs) % 2 == 0, 0.5, 0.1)}
+        return self.obs, rew, done, info
+
+    def episode_stats(self):
+        return self.ret, self.len
+
+
+def test_collect_transitions_stores_live_rows_with_the_bootstrap_mask():
+    n, max_step = 6, 3
+    env, rpm = _ToyEnv(n), DeviceReplayMemory(64, 3, 2, device="cpu")
+    g = torch.Generator().manual_seed(1)
+    ret, ln, infos = collect_transitions(env, rpm, max_step, mode="uniform", action_bound=0.0, generator=g)
+    # robot i lives i + 1 steps, capped by the forced done of step max_step + 1
+    want_len = torch.tensor([1, 2, 3, 4, 4, 4], dtype=torch.int32)
+    assert torch.equal(ln, want_len) and rpm.size() == int(want_len.sum())
+    assert torch.equal(ret, torch.tensor([1.0, 3, 6, 10, 10, 10]))
+    assert torch.equal(infos["torso"], 2 * ret) and torch.equal(infos["success_rate"], torch.tensor([1.0, 0, 1, 0, 1, 0]))
+    k = rpm.size()
+    o, no, r, t, a = rpm.obs[:k], rpm.next_obs[:k], rpm.reward[:k], rpm.terminal[:k], rpm.action[:k]
+    # every stored row is one step of a live robot: next = obs + 100 (action_bound 0), obs is the PRE-step observation
+    assert torch.equal(no, o + 100.0) and (a.abs() <= 1).all() and a.abs().max() > 0.5
+    robot = (o[:, 0] % 100).long()
+    step = (o[:, 0] // 100).long() + 1
+    for i in range(n):
+        rows = step[robot == i]
+        assert rows.tolist() == list(range(1, int(want_len[i]) + 1))
+    # terminal is the bootstrap mask 1 - done: 0 exactly on each robot's last stored row (forced done included)
+    assert torch.equal(t == 0, step == want_len[robot].long())
+    assert torch.equal(r, step.float())
+    with pytest.raises(ValueError):
+        collect_transitions(env, rpm, max_step, mode="predict")
+
+
+@pytest.mark.gpu
+def test_collect_transitions_on_the_device_matches_a_stepping_loop_and_the_fused_rollout():
+    """GPU: the collection loop on the real env + MFMA policy.  (1) `predict` mode: the stored rows are exactly the
+    alive-masked trajectory of an identical env stepped by hand (step-major, robot-minor order), terminal = 1 - done, and
+    the episode returns equal the fused closed-loop kernel's (etg_rollout_policy).  (2) `sample` mode (SAC.sample,
+    alg/sac.py:65-76): stored actions are the squashed Gaussian draws, reproducible from the generator."""
+    from tests.test_gpu_parity import _need_gpu, _make
+    from tests.test_gpu_parity2 import _policy
+    _need_gpu()
+    n, max_step, bound = 256, 59, 0.3
+    pol, _ = _policy()
+    env, ref = _make(n, seed=5), _make(n, seed=5)
+    rpm = DeviceReplayMemory(n * (max_step + 1) + 7, 49, 12)
+    ret, ln, infos = collect_transitions(env, rpm, max_step, policy=pol, action_bound=bound)
+    # the same episode by hand
+    obs, _ = ref.reset()
+    alive = torch.ones(n, dtype=torch.bool, device="cuda:0")
+    rows = {k: [] for k in ("obs", "action", "reward", "next_obs", "terminal")}
+    torso = torch.zeros(n, device="cuda:0")
+    for steps in range(1, max_step + 2):
+        a = pol.predict(obs)
+        o0 = obs.clone()
+        obs, r, d, info = ref.step(a * bound, donef=(steps > max_step))
+        for k, v in (("obs", o0), ("action", a), ("reward", r), ("next_obs", obs), ("terminal", 1.0 - d.float())):
+            rows[k].append(v[alive].clone())
+        torso += alive.float() * info["torso"]
+        alive &= ~d
+    k = rpm.size()
+    assert k == int(ln.sum().item()) and 0 < k < n * (max_step + 1) + 7
+    for name in rows:
+        want = torch.cat(rows[name])
+        assert want.shape[0] == k and torch.equal(getattr(rpm, name)[:k], want), name
+    assert torch.equal(infos["torso"], torso) and ((infos["success_rate"] >= 0) & (infos["success_rate"] <= 1)).all()
+    assert int((rpm.terminal[:k] == 0).sum().item()) == n             # one closing row per robot
+    ref.reset()
+    ret_f, ln_f = ref.rollout_policy(pol, max_step + 1, bound)
+    assert torch.equal(ln_f, ln) and (ret_f - ret).abs().max().item() < 2e-3 * max(1.0, ret.abs().max().item())
+    # sampling from the memory on the device
+    so, sa, sr, sno, st = rpm.sample_batch(512)
+    assert so.is_cuda and so.shape == (512, 49) and sa.abs().max().item() <= 1.0 and torch.isfinite(sno).all()
+    # (2) stochastic actions
+    g = torch.Generator(device="cuda:0"); g.manual_seed(9)
+    rpm2 = DeviceReplayMemory(n * 12, 49, 12)
+    collect_transitions(env, rpm2, 9, policy=pol, action_bound=bound, mode="sample", generator=g)
+    g.manual_seed(9)
+    first = pol.sample(env.reset()[0], 1.0, generator=g, return_logp=False)
+    assert torch.equal(rpm2.action[:n], first) and (rpm2.action[:n] - pol.predict(env.obs)).abs().max().item() > 1e-2
+    # (3) warm-up collection with uniform actions (train.py:141-142)
+    rpm3 = DeviceReplayMemory(n * 12, 49, 12)
+    collect_transitions(env, rpm3, 9, mode="uniform")
+    a3 = rpm3.action[:rpm3.size()]
+    assert a3.min().item() < -0.9 and a3.max().item() > 0.9 and abs(a3.mean().item()) < 0.05
+    env.close(); ref.close()
