@@ -153,3 +153,116 @@ def test_pybullet_dump_format_and_comparison_tool(tmp_path):
     k2 = PB.compare(f, solver_iters=2)
     assert 0.0 < max(k2["joint_angle_gap_rad"].values()) < 5e-2
     assert pybullet_baseline.run(1) is None or isinstance(pybullet_baseline.run(1), float)      # pybullet absent -> None
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# An independent forward-dynamics algorithm.  The oracle (and the kernels) eliminate blocks of the joint-space mass matrix
+# (CRBA + RNEA, then M^-1); Bullet's multibody (the reference's engine, minitaur.py:244) propagates articulated-body
+# inertias instead (Featherstone's ABA).  Both must give the same accelerations for the same model: this ABA is written
+# from the textbook recursion in plain numpy, with its own inertia assembly (parallel-axis form) from a1_model's link table.
+def _skew(a):
+    return np.array([[0, -a[2], a[1]], [a[2], 0, -a[0]], [-a[1], a[0], 0.0]])
+
+
+def _inertia_about_origin(mass, com, inertia6, ratio_m, ratio_i, shift=(0, 0, 0)):
+    """6x6 inertia of a link about its frame origin, [angular; linear] order.  inertia6 = (xx, yy, zz, xy, xz, yz) about the
+    COM; the dynamic row scales the mass by ratio_m and the inertia axes by ratio_i (I' = S I S, S = diag sqrt(ratio))."""
+    xx, yy, zz, xy, xz, yz = inertia6
+    s = np.sqrt(np.asarray(ratio_i, dtype=float))
+    Ic = np.array([[xx, xy, xz], [xy, yy, yz], [xz, yz, zz]]) * np.outer(s, s)
+    m = mass * ratio_m
+    c = np.asarray(com, dtype=float) + np.asarray(shift, dtype=float)
+    Io = Ic + m * (c @ c * np.eye(3) - np.outer(c, c))            # parallel-axis theorem
+    out = np.zeros((6, 6))
+    out[:3, :3] = Io
+    out[:3, 3:] = m * _skew(c)
+    out[3:, :3] = m * _skew(c).T
+    out[3:, 3:] = m * np.eye(3)
+    return out
+
+
+def _a1_tree(dyn):
+    """bodies 0 (trunk), 1 + 3 leg + (0 hip, 1 thigh, 2 calf with the foot welded on): parent, joint axis, joint origin, inertia"""
+    m = A.default_model()
+    link = lambda L: (L.mass, tuple(L.com), tuple(L.inertia))
+    parent, axis, origin, inertia = [-1], [None], [None], [_inertia_about_origin(*link(m.trunk), dyn[2], dyn[3:6])]
+    for leg in range(4):
+        b = 1 + 3 * leg
+        parent += [0, b, b + 1]
+        axis += [0, 1, 1]
+        origin += [np.array(m.hip_origin[leg][:]), np.array([0, m.thigh_y[leg], 0.0]), np.array([0, 0, -m.upper_len])]
+        inertia.append(_inertia_about_origin(*link(m.hip[leg]), dyn[6], dyn[9:12]))
+        inertia.append(_inertia_about_origin(*link(m.thigh[leg]), dyn[7], dyn[12:15]))
+        inertia.append(_inertia_about_origin(*link(m.calf[leg]), dyn[8], dyn[15:18])
+                       + _inertia_about_origin(*link(m.foot[leg]), 1.0, dyn[18:21], shift=(0, 0, -m.lower_len)))
+    return parent, axis, origin, inertia
+
+
+def _aba(q, v_base, qd, tau, grav_body, tree):
+    """floating-base articulated-body algorithm: (spatial base acceleration in body coordinates, joint accelerations)"""
+    parent, axis, origin, inertia = tree
+    nb = len(parent)
+    crm = lambda v: np.block([[_skew(v[:3]), np.zeros((3, 3))], [_skew(v[3:]), _skew(v[:3])]])
+    X, S, v, c, IA, pA = [None] * nb, [None] * nb, [None] * nb, [None] * nb, [None] * nb, [None] * nb
+    v[0] = v_base
+    IA[0] = inertia[0].copy()
+    pA[0] = -crm(v[0]).T @ (inertia[0] @ v[0])
+    for i in range(1, nb):
+        a = q[i - 1]
+        cs, sn = np.cos(a), np.sin(a)
+        E = (np.array([[1, 0, 0], [0, cs, sn], [0, -sn, cs]]) if axis[i] == 0 else np.array([[cs, 0, -sn], [0, 1, 0], [sn, 0, cs]]))
+        X[i] = np.block([[E, np.zeros((3, 3))], [-E @ _skew(origin[i]), E]])      # parent -> child motion transform
+        S[i] = np.zeros(6); S[i][axis[i]] = 1.0
+        vj = S[i] * qd[i - 1]
+        v[i] = X[i] @ v[parent[i]] + vj
+        c[i] = crm(v[i]) @ vj
+        IA[i] = inertia[i].copy()
+        pA[i] = -crm(v[i]).T @ (inertia[i] @ v[i])
+    U, d, u = [None] * nb, [None] * nb, [None] * nb
+    for i in range(nb - 1, 0, -1):
+        U[i] = IA[i] @ S[i]
+        d[i] = S[i] @ U[i]
+        u[i] = tau[i - 1] - S[i] @ pA[i]
+        Ia = IA[i] - np.outer(U[i], U[i]) / d[i]
+        pa = pA[i] + Ia @ c[i] + U[i] * u[i] / d[i]
+        IA[parent[i]] += X[i].T @ Ia @ X[i]
+        pA[parent[i]] += X[i].T @ pa
+    acc = [None] * nb
+    acc[0] = -np.linalg.solve(IA[0], pA[0])
+    qdd = np.zeros(nb - 1)
+    for i in range(1, nb):
+        ap = X[i] @ acc[parent[i]] + c[i]
+        qdd[i - 1] = (u[i] - U[i] @ ap) / d[i]
+        acc[i] = ap + S[i] * qdd[i - 1]
+    a0 = acc[0].copy()
+    a0[3:] += grav_body                                           # gravity accelerates the whole tree uniformly
+    return a0, qdd
+
+
+def test_forward_dynamics_matches_an_independent_articulated_body_algorithm():
+    rng = np.random.default_rng(5)
+    for trial in range(6):
+        p = np.zeros(48) if trial == 0 else rng.uniform(-1, 1, 48)       # nominal and randomised dynamics (train.py:112-126)
+        row = A.dynamic_dict_to_row(A.param2dynamic_dict(p))
+        sim = O.OracleSim(A.default_config(1, settle_ticks=0))
+        sim.set_params(dyn=row[None])
+        st = np.zeros(37)
+        st[2] = 5.0                                                      # far above the ground: no contacts
+        qt = rng.normal(size=4)
+        st[3:7] = qt / np.linalg.norm(qt)
+        st[7:10] = rng.normal(size=3)
+        st[10:13] = rng.normal(size=3) * 2
+        st[13:25] = A.INIT_MOTOR_ANGLES + rng.normal(size=12) * 0.5
+        st[25:37] = rng.normal(size=12) * 4
+        sim.set_state(st[None])
+        tau = rng.normal(size=12) * 10
+        M, C = sim.dynamics_terms()
+        x = np.linalg.solve(M, np.concatenate([np.zeros(6), tau]) - C)  # the oracle's [a_base; qdd]
+        R = quat2mat(st[3:7])
+        vb = np.concatenate([R.T @ st[10:13], R.T @ st[7:10]])
+        a0, qdd = _aba(st[13:25], vb, st[25:37], tau, R.T @ row[45:48], _a1_tree(row))
+        scale = max(1.0, np.abs(x).max())
+        assert np.abs(x[6:] - qdd).max() < 1e-9 * scale and np.abs(x[:6] - a0).max() < 1e-9 * scale, trial
+        # and one explicit Euler tick of the oracle moves the joint rates by dt * qdd (free flight, semi-implicit Euler)
+        sim.tick(tau[None], 1)
+        assert np.abs((sim.get_state()[0, 25:37] - st[25:37]) / 0.002 - qdd).max() < 1e-8 * scale
