@@ -266,3 +266,70 @@ def test_forward_dynamics_matches_an_independent_articulated_body_algorithm():
         # and one explicit Euler tick of the oracle moves the joint rates by dt * qdd (free flight, semi-implicit Euler)
         sim.tick(tau[None], 1)
         assert np.abs((sim.get_state()[0, 25:37] - st[25:37]) / 0.002 - qdd).max() < 1e-8 * scale
+
+
+def _contact_kkt(mu, kick, solver_iters=3000, seed=2):
+    """one tick of a standing robot that was just given extra velocity `kick`, PGS run to convergence; returns per foot
+    (lambda_n, lambda_t[2], contact-point velocity u[3] AFTER the solve, normal target): the contact-point velocity is
+    rebuilt here from the post-tick state with the reference's analytic leg Jacobian (a1.py:132-160), not taken from
+    the oracle"""
+    cfg = A.default_config(1, settle_ticks=1500, solver_iters=solver_iters)
+    sim = O.OracleSim(cfg)
+    row = A.default_dynamic_row()
+    row[1] = mu
+    sim.set_params(dyn=row[None])
+    sim.reset()
+    m = A.default_model()
+    rng = np.random.default_rng(seed)
+    st = sim.get_state()
+    st[0, 7:10] += kick
+    st[0, 10:13] += rng.normal(size=3) * 0.5 * np.linalg.norm(kick)
+    st[0, 25:37] += rng.normal(size=12) * np.linalg.norm(kick)
+    sim.set_state(st)
+    s0 = sim.get_state()[0].copy()
+    tau = -row[21:33] * (s0[13:25] - A.INIT_MOTOR_ANGLES) - row[33:45] * s0[25:37]
+    sim.tick(tau[None], 1)
+    s1, lam = sim.get_state()[0], sim.get_lambda()[0]
+    R0, R1 = quat2mat(s0[3:7]), quat2mat(s1[3:7])
+    vb, wb, qd = R1.T @ s1[7:10], R1.T @ s1[10:13], s1[25:37]
+    out = []
+    for l in range(4):
+        ql = s0[13 + 3 * l:16 + 3 * l]
+        pf = np.array(m.hip_origin[l][:]) + O.leg_fk(ql, A.hip_sign(l))
+        off = -A.FOOT_RADIUS * (R0.T @ np.array([0, 0, 1.0]))
+        ca, sa = np.cos(ql[0]), np.sin(ql[0])
+        z1, z2 = np.array([1.0, 0, 0]), np.array([0, ca, sa])
+        Jc = O.leg_jacobian(ql, l) + np.stack([np.cross(z1, off), np.cross(z2, off), np.cross(z2, off)], axis=1)
+        u = R0 @ (vb + np.cross(wb, pf + off) + Jc @ qd[3 * l:3 * l + 3])
+        phi = s0[2] + (R0 @ pf)[2] - A.FOOT_RADIUS
+        tgt = -phi / cfg.sim_dt if phi > 0 else -cfg.erp * phi / cfg.sim_dt
+        out.append((lam[3 * l], lam[3 * l + 1:3 * l + 3], u, tgt, phi < cfg.contact_margin))
+    return out
+
+
+def test_converged_contact_solve_satisfies_the_coulomb_complementarity_conditions():
+    """The fixed point of the oracle's projected Gauss-Seidel is the contact problem Bullet's solver iterates on
+    (SURVEY 8 a10): Signorini (lambda_n >= 0, gap velocity >= target, complementary) and Coulomb friction (sticking:
+    no tangential velocity inside the cone; sliding: |lambda_t| = mu lambda_n, opposing the slip)."""
+    # sliding: a strong lateral kick on a slippery floor
+    feet = _contact_kkt(0.4, np.array([0.6, 0.25, -0.1]))
+    assert all(f[4] for f in feet)
+    for ln, lt, u, tgt, _ in feet:
+        assert ln > 1e-3 and abs(u[2] - tgt) < 1e-9                                   # contact holds: complementarity
+        assert abs(np.hypot(*lt) - 0.4 * ln) < 1e-9 and np.hypot(*u[:2]) > 0.05        # on the cone, slipping
+        assert lt @ u[:2] / (np.hypot(*lt) * np.hypot(*u[:2])) < -0.999               # friction opposes the slip
+    # sticking: a small kick on a grippy floor
+    feet = _contact_kkt(1.0, np.array([0.02, 0.01, 0.0]))
+    for ln, lt, u, tgt, _ in feet:
+        assert ln > 1e-3 and abs(u[2] - tgt) < 1e-9
+        assert np.hypot(*lt) < 1.0 * ln - 1e-4 and np.hypot(*u[:2]) < 1e-8            # inside the cone, no slip
+    # separating: an upward kick -- the feet leave, no impulse, no constraint on the velocity
+    feet = _contact_kkt(0.8, np.array([0.0, 0.0, 1.5]), seed=3)
+    for ln, lt, u, tgt, _ in feet:
+        assert ln == 0.0 and np.abs(lt).max() == 0.0 and u[2] > tgt
+    # the shipped default (2 sweeps, warm-started) is an approximation of that fixed point: report how far
+    ref = _contact_kkt(0.4, np.array([0.6, 0.25, -0.1]))
+    two = _contact_kkt(0.4, np.array([0.6, 0.25, -0.1]), solver_iters=2)
+    gap = max(abs(a[0] - b[0]) / b[0] for a, b in zip(two, ref))
+    print("[parity] K = 2 vs converged normal impulses after a kick: max relative gap %.3f" % gap)
+    assert gap < 0.5
