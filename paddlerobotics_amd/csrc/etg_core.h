@@ -334,6 +334,14 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   c.phase(0);
   // ---- velocities, bias accelerations (qdd = 0, a_base = -g), bias forces (RNEA)
   Rows<F> Rw = quat_rows(L.qx, L.qy, L.qz, L.qw);
+  // contact detection works on the start-of-tick pose: on a heightfield the foot point and the four corner loads of its
+  // terrain cell are issued HERE and consumed in phase 4 (a lone wave would otherwise sit out their latency every tick)
+  V fw;
+  F tap[6];
+  if (!Ctx::kFlat) {
+    fw = {L.p.x + dot(Rw.r0, pf), L.p.y + dot(Rw.r1, pf), L.p.z + dot(Rw.r2, pf)};
+    c.terrain_fetch(K, fw.x, fw.y, tap);
+  }
   V gb;  // R^T g: columns of R are (r0.x, r1.x, r2.x) ...
   V gw = tp.gw;
   gb.x = Rw.r0.x * gw.x + Rw.r1.x * gw.y + Rw.r2.x * gw.z;
@@ -429,7 +437,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
 
   c.phase(4);
   // ---- foot contact (sphere vs ground)
-  V fw = {L.p.x + dot(Rw.r0, pf), L.p.y + dot(Rw.r1, pf), L.p.z + dot(Rw.r2, pf)};
+  if (Ctx::kFlat) fw = {L.p.x + dot(Rw.r0, pf), L.p.y + dot(Rw.r1, pf), L.p.z + dot(Rw.r2, pf)};
   F phi;
   V dn, d1, d2;
   if (Ctx::kFlat) {
@@ -438,20 +446,19 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
     dn = Rw.r2; d1 = Rw.r0; d2 = Rw.r1;
   } else {
     F hgt, nwx, nwy, nwz;
-    c.terrain(K, fw.x, fw.y, hgt, nwx, nwy, nwz);
+    c.terrain_finish(K, tap, hgt, nwx, nwy, nwz);
     phi = (fw.z - hgt) * nwz - F(K.foot_radius);
     // contact frame in world: n, t1 = normalised (x_w - (x_w.n) n), t2 = n x t1; then to base coords
-    V nw = {nwx, nwy, nwz};
-    V t1w = {one - nwx * nwx, -(nwx * nwy), -(nwx * nwz)};
-    F it1 = rsqrt_(dot(t1w, t1w));
-    t1w = it1 * t1w;
-    V t2w = cross(nw, t1w);
+    // with |n| = 1: |x_w - nx n|^2 = 1 - nx^2 and n x t1 = (0, nz, -ny) / |..|
+    const F it1 = rsqrt_(one - nwx * nwx);
+    const V nw = {nwx, nwy, nwz};
+    const V t1w = {it1 * (one - nwx * nwx), -(it1 * (nwx * nwy)), -(it1 * (nwx * nwz))};
+    const F t2y = it1 * nwz, t2z = -(it1 * nwy);
     dn = {Rw.r0.x * nw.x + Rw.r1.x * nw.y + Rw.r2.x * nw.z, Rw.r0.y * nw.x + Rw.r1.y * nw.y + Rw.r2.y * nw.z,
           Rw.r0.z * nw.x + Rw.r1.z * nw.y + Rw.r2.z * nw.z};
     d1 = {Rw.r0.x * t1w.x + Rw.r1.x * t1w.y + Rw.r2.x * t1w.z, Rw.r0.y * t1w.x + Rw.r1.y * t1w.y + Rw.r2.y * t1w.z,
           Rw.r0.z * t1w.x + Rw.r1.z * t1w.y + Rw.r2.z * t1w.z};
-    d2 = {Rw.r0.x * t2w.x + Rw.r1.x * t2w.y + Rw.r2.x * t2w.z, Rw.r0.y * t2w.x + Rw.r1.y * t2w.y + Rw.r2.y * t2w.z,
-          Rw.r0.z * t2w.x + Rw.r1.z * t2w.y + Rw.r2.z * t2w.z};
+    d2 = {Rw.r1.x * t2y + Rw.r2.x * t2z, Rw.r1.y * t2y + Rw.r2.y * t2z, Rw.r1.z * t2y + Rw.r2.z * t2z};
   }
   auto act = phi < F(K.margin);
   F actf = sel_(act, one, zero);

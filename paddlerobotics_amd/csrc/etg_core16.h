@@ -142,6 +142,55 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   c.phase(0);
   // ---- RNEA along the chain (prefix scans), bias forces (suffix scan)
   Rows<F> Rw = quat_rows(L.qx, L.qy, L.qz, L.qw);
+  // ---- contact point of this lane's row: contact detection works on the start-of-tick pose, so on a heightfield the
+  // point and the four corner loads of its terrain cell are issued HERE and consumed in phase 4 -- a lone wave would
+  // otherwise sit out the load latency once per tick (flat ground: computed in phase 4, nothing to fetch).
+  // This lane owns contact row `sub` (n, t1, t2) of its leg.  With K.knee the aux lane owns a 4th, frictionless row: a
+  // sphere at the knee (calf joint origin), carried by the thigh (K.knee >= 2: see below).
+  constexpr bool knee = Ctx::kKnee;   // compile-time: the flat-ground and plain heightfield kernels do not contain the rows
+  const auto s3 = c.sub_is(3);
+  const F f3 = sel_(s3, one, zero);
+  V pc = g.pf, fw;
+  F rad(K.foot_radius);
+  F jm12 = one, jm3 = mj;   // which joints move the point of this lane's row (hip & thigh, calf)
+  F tap[6];
+  auto contact_point = [&]() {
+    if (knee) {
+      V pb = g.o3;
+      if (K.knee >= 2) {
+        // the aux lane's row takes the DEEPEST of three spheres of knee_radius: knee, shin midpoint (moved by all three
+        // joints), trunk corner next to this leg's hip (moved by none); ties go to the earlier candidate, as in the oracle
+        const V ps = g.o3 - F(0.5f * K.lower_len) * g.ez3;
+        const V pt = {sel_(g.o1.x > zero, F(K.trunk_half[0]), F(-K.trunk_half[0])),
+                      sel_(g.o1.y > zero, F(K.trunk_half[1]), F(-K.trunk_half[1])), F(-K.trunk_half[2])};
+        auto depth = [&](const V& q) -> F {
+          const V w = {L.p.x + dot(Rw.r0, q), L.p.y + dot(Rw.r1, q), L.p.z + dot(Rw.r2, q)};
+          if (Ctx::kFlat) return w.z;
+          F hgt, nwx, nwy, nwz;
+          c.terrain(K, w.x, w.y, hgt, nwx, nwy, nwz);
+          return (w.z - hgt) * nwz;
+        };
+        F best = depth(pb);
+        const F ds = depth(ps);
+        const auto ms = ds < best;
+        pb = {sel_(ms, ps.x, pb.x), sel_(ms, ps.y, pb.y), sel_(ms, ps.z, pb.z)};
+        best = sel_(ms, ds, best);
+        F j3 = sel_(ms, one, zero);
+        const F dtk = depth(pt);
+        const auto mt = dtk < best;
+        pb = {sel_(mt, pt.x, pb.x), sel_(mt, pt.y, pb.y), sel_(mt, pt.z, pb.z)};
+        jm12 = sel_(s3, sel_(mt, zero, one), one);
+        jm3 = sel_(s3, sel_(mt, zero, j3), one);
+      }
+      pc = {sel_(s3, pb.x, g.pf.x), sel_(s3, pb.y, g.pf.y), sel_(s3, pb.z, g.pf.z)};
+      rad = sel_(s3, F(K.knee_radius), F(K.foot_radius));
+    }
+    fw = {L.p.x + dot(Rw.r0, pc), L.p.y + dot(Rw.r1, pc), L.p.z + dot(Rw.r2, pc)};
+  };
+  if (!Ctx::kFlat) {
+    contact_point();
+    c.terrain_fetch(K, fw.x, fw.y, tap);
+  }
   const V gw = tp.gw;
   V gb = {Rw.r0.x * gw.x + Rw.r1.x * gw.y + Rw.r2.x * gw.z, Rw.r0.y * gw.x + Rw.r1.y * gw.y + Rw.r2.y * gw.z,
           Rw.r0.z * gw.x + Rw.r1.z * gw.y + Rw.r2.z * gw.z};
@@ -236,73 +285,39 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   V wbs = L.wb + dt * ab.a, vbs = L.vb + dt * ab.l;
   F qds = L.qd + dt * qdd;
   c.phase(4);
-  // ---- foot contact: this lane owns contact row `sub` (n, t1, t2) of its leg.  With K.knee the aux lane owns a 4th,
-  // frictionless row: a sphere at the knee (calf joint origin), carried by the thigh (K.knee >= 2: see below).
-  constexpr bool knee = Ctx::kKnee;   // compile-time: the flat-ground and plain heightfield kernels do not contain the rows
-  const auto s3 = c.sub_is(3);
-  const F f3 = sel_(s3, one, zero);
-  V pc = g.pf;
-  F rad(K.foot_radius);
-  F jm12 = one, jm3 = mj;   // which joints move the point of this lane's row (hip & thigh, calf)
-  if (knee) {
-    V pb = g.o3;
-    if (K.knee >= 2) {
-      // the aux lane's row takes the DEEPEST of three spheres of knee_radius: knee, shin midpoint (moved by all three
-      // joints), trunk corner next to this leg's hip (moved by none); ties go to the earlier candidate, as in the oracle
-      const V ps = g.o3 - F(0.5f * K.lower_len) * g.ez3;
-      const V pt = {sel_(g.o1.x > zero, F(K.trunk_half[0]), F(-K.trunk_half[0])),
-                    sel_(g.o1.y > zero, F(K.trunk_half[1]), F(-K.trunk_half[1])), F(-K.trunk_half[2])};
-      auto depth = [&](const V& q) -> F {
-        const V w = {L.p.x + dot(Rw.r0, q), L.p.y + dot(Rw.r1, q), L.p.z + dot(Rw.r2, q)};
-        if (Ctx::kFlat) return w.z;
-        F hgt, nwx, nwy, nwz;
-        c.terrain(K, w.x, w.y, hgt, nwx, nwy, nwz);
-        return (w.z - hgt) * nwz;
-      };
-      F best = depth(pb);
-      const F ds = depth(ps);
-      const auto ms = ds < best;
-      pb = {sel_(ms, ps.x, pb.x), sel_(ms, ps.y, pb.y), sel_(ms, ps.z, pb.z)};
-      best = sel_(ms, ds, best);
-      F j3 = sel_(ms, one, zero);
-      const F dtk = depth(pt);
-      const auto mt = dtk < best;
-      pb = {sel_(mt, pt.x, pb.x), sel_(mt, pt.y, pb.y), sel_(mt, pt.z, pb.z)};
-      jm12 = sel_(s3, sel_(mt, zero, one), one);
-      jm3 = sel_(s3, sel_(mt, zero, j3), one);
-    }
-    pc = {sel_(s3, pb.x, g.pf.x), sel_(s3, pb.y, g.pf.y), sel_(s3, pb.z, g.pf.z)};
-    rad = sel_(s3, F(K.knee_radius), F(K.foot_radius));
-  }
-  V fw = {L.p.x + dot(Rw.r0, pc), L.p.y + dot(Rw.r1, pc), L.p.z + dot(Rw.r2, pc)};
+  // ---- foot contact (the row's contact point: see `contact_point` above)
+  if (Ctx::kFlat) contact_point();
   F phi;
-  V dn, d1, d2;
+  V dn, dir;   // contact normal and this lane's row direction (n, t1, t2 by sub-lane; n on the aux lane), base coordinates
   if (Ctx::kFlat) {
     phi = fw.z - rad;
-    dn = Rw.r2; d1 = Rw.r0; d2 = Rw.r1;
+    dn = Rw.r2;
+    const V d1 = Rw.r0, d2 = Rw.r1;
+    dir = {sel_(s0, dn.x, sel_(s1, d1.x, d2.x)), sel_(s0, dn.y, sel_(s1, d1.y, d2.y)), sel_(s0, dn.z, sel_(s1, d1.z, d2.z))};
   } else {
     F hgt, nwx, nwy, nwz;
-    c.terrain(K, fw.x, fw.y, hgt, nwx, nwy, nwz);
+    c.terrain_finish(K, tap, hgt, nwx, nwy, nwz);
     phi = (fw.z - hgt) * nwz - rad;
-    V nw = {nwx, nwy, nwz};
-    V t1w = {one - nwx * nwx, -(nwx * nwy), -(nwx * nwz)};
-    F it1 = rsqrt_(dot(t1w, t1w));
-    t1w = it1 * t1w;
-    V t2w = cross(nw, t1w);
+    // contact frame in world coordinates: n, t1 = (x_w - (x_w.n) n) / |..|, t2 = n x t1.  With |n| = 1:
+    // |x_w - nx n|^2 = 1 - nx^2 and n x t1 = (0, nz, -ny) / |..|.  Each lane rotates only ITS row's direction (and n,
+    // which every lane needs for the contact point) into base coordinates.
+    const F it1 = rsqrt_(one - nwx * nwx);
+    const V nw = {nwx, nwy, nwz};
+    const V t1w = {it1 * (one - nwx * nwx), -(it1 * (nwx * nwy)), -(it1 * (nwx * nwz))};
+    const V t2w = {zero, it1 * nwz, -(it1 * nwy)};
+    const auto s2 = c.sub_is(2);
+    const V dw = {sel_(s1, t1w.x, sel_(s2, t2w.x, nw.x)), sel_(s1, t1w.y, sel_(s2, t2w.y, nw.y)), sel_(s1, t1w.z, sel_(s2, t2w.z, nw.z))};
     dn = {Rw.r0.x * nw.x + Rw.r1.x * nw.y + Rw.r2.x * nw.z, Rw.r0.y * nw.x + Rw.r1.y * nw.y + Rw.r2.y * nw.z,
           Rw.r0.z * nw.x + Rw.r1.z * nw.y + Rw.r2.z * nw.z};
-    d1 = {Rw.r0.x * t1w.x + Rw.r1.x * t1w.y + Rw.r2.x * t1w.z, Rw.r0.y * t1w.x + Rw.r1.y * t1w.y + Rw.r2.y * t1w.z,
-          Rw.r0.z * t1w.x + Rw.r1.z * t1w.y + Rw.r2.z * t1w.z};
-    d2 = {Rw.r0.x * t2w.x + Rw.r1.x * t2w.y + Rw.r2.x * t2w.z, Rw.r0.y * t2w.x + Rw.r1.y * t2w.y + Rw.r2.y * t2w.z,
-          Rw.r0.z * t2w.x + Rw.r1.z * t2w.y + Rw.r2.z * t2w.z};
+    dir = {Rw.r0.x * dw.x + Rw.r1.x * dw.y + Rw.r2.x * dw.z, Rw.r0.y * dw.x + Rw.r1.y * dw.y + Rw.r2.y * dw.z,
+           Rw.r0.z * dw.x + Rw.r1.z * dw.y + Rw.r2.z * dw.z};
   }
   auto act = phi < F(K.margin);
   const F rowf = (knee ? one : mj) * sel_(act, one, zero);      // 1 on the rows of an active foot (/ knee)
   V rc = pc - rad * dn;
   V k1 = cross(xax, rc - g.o1), k2 = cross(g.yax, rc - g.o2), k3 = cross(g.yax, rc - g.o3);
-  V dir = {sel_(s0, dn.x, sel_(s1, d1.x, d2.x)), sel_(s0, dn.y, sel_(s1, d1.y, d2.y)), sel_(s0, dn.z, sel_(s1, d1.z, d2.z))};
   if (knee) {   // the body row pushes along the normal; the calf joint does not move the knee (nor any joint the trunk)
-    dir = {sel_(s3, dn.x, dir.x), sel_(s3, dn.y, dir.y), sel_(s3, dn.z, dir.z)};
+    if (Ctx::kFlat) dir = {sel_(s3, dn.x, dir.x), sel_(s3, dn.y, dir.y), sel_(s3, dn.z, dir.z)};
     k3 = jm3 * k3;
     if (K.knee >= 2) { k1 = jm12 * k1; k2 = jm12 * k2; }
   }

@@ -98,6 +98,10 @@ struct GpuCtx {
     if (K.terrain == 0) { h = 0.0f; nx = 0.0f; ny = 0.0f; nz = 1.0f; }
     else heightfield_query(K, env, x, y, h, nx, ny, nz);
   }
+  __device__ __forceinline__ void terrain_fetch(const KCfg& K, float x, float y, float* tap) const { heightfield_fetch(K, env, x, y, tap); }
+  __device__ __forceinline__ void terrain_finish(const KCfg& K, const float* tap, float& h, float& nx, float& ny, float& nz) const {
+    heightfield_finish(K, tap, h, nx, ny, nz);
+  }
 };
 
 // FLAT selects the plane-z=0 fast path at compile time (contact frame = rows of R, no terrain lookup)
@@ -475,6 +479,10 @@ struct GpuCtx16 {
   __device__ __forceinline__ void terrain(const KCfg& K, float x, float y, float& h, float& nx, float& ny, float& nz) const {
     if (K.terrain == 0) { h = 0.0f; nx = 0.0f; ny = 0.0f; nz = 1.0f; }
     else heightfield_query(K, env, x, y, h, nx, ny, nz);
+  }
+  __device__ __forceinline__ void terrain_fetch(const KCfg& K, float x, float y, float* tap) const { heightfield_fetch(K, env, x, y, tap); }
+  __device__ __forceinline__ void terrain_finish(const KCfg& K, const float* tap, float& h, float& nx, float& ny, float& nz) const {
+    heightfield_finish(K, tap, h, nx, ny, nz);
   }
 };
 // KNEE: the knee contact rows of EtgConfig.body_contacts (heightfield kernels only) are compiled in.

@@ -54,7 +54,7 @@ struct KCfg {
   float fb[3], fa[3];
   int hf_nx, hf_ny;      // hf_ny = rows of ONE band
   int hf_bands;          // bands stacked along y in the heights array; robot e uses band e % hf_bands
-  float hf_cell, hf_x0, hf_y0;
+  float hf_cell, hf_x0, hf_y0, hf_inv_cell;
   const float* hf;
   // the settle cache's copy of the latency ring (DevState.cache_ring), or null (test emulation).  Ring slots of ticks up to
   // the reset tick (settle_ticks) are READ FROM THE CACHE: a robot's history before its reset is its settle, which the cache
@@ -313,6 +313,7 @@ inline KCfg make_kcfg(const EtgConfig& c, const EtgRobotModel& m) {
   K.jlim = c.joint_limits != 0;
   for (int k = 0; k < 3; k++) { K.jlo[k] = (float)c.joint_lower[k]; K.jhi[k] = (float)c.joint_upper[k]; }
   K.hf_cell = (float)c.hf_cell; K.hf_x0 = (float)c.hf_x0; K.hf_y0 = (float)c.hf_y0;
+  K.hf_inv_cell = c.hf_cell > 0 ? (float)(1.0 / c.hf_cell) : 0.0f;
   K.hf = nullptr;
   K.cring = nullptr;
   return K;
@@ -340,23 +341,33 @@ inline ModelF make_modelf(const EtgRobotModel& m) {
   return M;
 }
 
-// bilinear heightfield query shared by both builds (clamped at the border)
-ETG_HD void heightfield_query(const KCfg& K, int env, float x, float y, float& h, float& nx, float& ny, float& nz) {
+// bilinear heightfield query shared by both builds (clamped at the border), in two halves: the four corner loads
+// (`tap` = h00, h10, h01, h11, tx, ty) can be issued as soon as the query point is known -- contact detection works on the
+// start-of-tick pose -- and consumed phases later, so a lone wave does not sit out their latency (heightfield_finish)
+ETG_HD void heightfield_fetch(const KCfg& K, int env, float x, float y, float* tap) {
   const float* hf = K.hf + (size_t)(env % K.hf_bands) * K.hf_ny * K.hf_nx;
-  float fx = (x - K.hf_x0) / K.hf_cell, fy = (y - K.hf_y0) / K.hf_cell;
+  float fx = (x - K.hf_x0) * K.hf_inv_cell, fy = (y - K.hf_y0) * K.hf_inv_cell;   // (a true division is ~10 instructions)
   fx = fminf(fmaxf(fx, 0.0f), (float)(K.hf_nx - 1));
   fy = fminf(fmaxf(fy, 0.0f), (float)(K.hf_ny - 1));
   int ix = (int)fx, iy = (int)fy;
   if (ix > K.hf_nx - 2) ix = K.hf_nx - 2;
   if (iy > K.hf_ny - 2) iy = K.hf_ny - 2;
-  float tx = fx - (float)ix, ty = fy - (float)iy;
-  float h00 = hf[iy * K.hf_nx + ix], h10 = hf[iy * K.hf_nx + ix + 1];
-  float h01 = hf[(iy + 1) * K.hf_nx + ix], h11 = hf[(iy + 1) * K.hf_nx + ix + 1];
+  tap[4] = fx - (float)ix; tap[5] = fy - (float)iy;
+  tap[0] = hf[iy * K.hf_nx + ix]; tap[1] = hf[iy * K.hf_nx + ix + 1];
+  tap[2] = hf[(iy + 1) * K.hf_nx + ix]; tap[3] = hf[(iy + 1) * K.hf_nx + ix + 1];
+}
+ETG_HD void heightfield_finish(const KCfg& K, const float* tap, float& h, float& nx, float& ny, float& nz) {
+  const float h00 = tap[0], h10 = tap[1], h01 = tap[2], h11 = tap[3], tx = tap[4], ty = tap[5];
   h = (1 - tx) * (1 - ty) * h00 + tx * (1 - ty) * h10 + (1 - tx) * ty * h01 + tx * ty * h11;
-  float dhdx = ((1 - ty) * (h10 - h00) + ty * (h11 - h01)) / K.hf_cell;
-  float dhdy = ((1 - tx) * (h01 - h00) + tx * (h11 - h10)) / K.hf_cell;
-  float inv = 1.0f / sqrtf(dhdx * dhdx + dhdy * dhdy + 1.0f);
+  float dhdx = ((1 - ty) * (h10 - h00) + ty * (h11 - h01)) * K.hf_inv_cell;
+  float dhdy = ((1 - tx) * (h01 - h00) + tx * (h11 - h10)) * K.hf_inv_cell;
+  float inv = rsqrt_(dhdx * dhdx + dhdy * dhdy + 1.0f);
   nx = -dhdx * inv; ny = -dhdy * inv; nz = inv;
+}
+ETG_HD void heightfield_query(const KCfg& K, int env, float x, float y, float& h, float& nx, float& ny, float& nz) {
+  float tap[6];
+  heightfield_fetch(K, env, x, y, tap);
+  heightfield_finish(K, tap, h, nx, ny, nz);
 }
 
 }  // namespace etg

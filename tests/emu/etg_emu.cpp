@@ -52,6 +52,22 @@ struct EmuCtxBase {
       else heightfield_query(K, env, x.v[l], y.v[l], h.v[l], nx.v[l], ny.v[l], nz.v[l]);
     }
   }
+  // the two halves of the query (the kernels issue the corner loads early and finish phases later)
+  void terrain_fetch(const KCfg& K, F4 x, F4 y, F4* tap) const {
+    for (int l = 0; l < 4; l++) {
+      float t[6] = {0, 0, 0, 0, 0, 0};
+      if (!(K.terrain == 0 || K.hf == nullptr)) heightfield_fetch(K, env, x.v[l], y.v[l], t);
+      for (int k = 0; k < 6; k++) tap[k].v[l] = t[k];
+    }
+  }
+  void terrain_finish(const KCfg& K, const F4* tap, F4& h, F4& nx, F4& ny, F4& nz) const {
+    for (int l = 0; l < 4; l++) {
+      float t[6];
+      for (int k = 0; k < 6; k++) t[k] = tap[k].v[l];
+      if (K.terrain == 0 || K.hf == nullptr) { h.v[l] = 0; nx.v[l] = 0; ny.v[l] = 0; nz.v[l] = 1; }
+      else heightfield_finish(K, t, h.v[l], nx.v[l], ny.v[l], nz.v[l]);
+    }
+  }
 };
 
 template <bool FLAT, bool PLAIN = false> struct EmuCtxT : EmuCtxBase {
@@ -135,6 +151,21 @@ struct EmuCtx16Base {
     for (int r = 0; r < 16; r++) {
       if (K.terrain == 0 || K.hf == nullptr) { h.v[r] = 0; nx.v[r] = 0; ny.v[r] = 0; nz.v[r] = 1; }
       else heightfield_query(K, env, x.v[r], y.v[r], h.v[r], nx.v[r], ny.v[r], nz.v[r]);
+    }
+  }
+  void terrain_fetch(const KCfg& K, F16 x, F16 y, F16* tap) const {
+    for (int r = 0; r < 16; r++) {
+      float t[6] = {0, 0, 0, 0, 0, 0};
+      if (!(K.terrain == 0 || K.hf == nullptr)) heightfield_fetch(K, env, x.v[r], y.v[r], t);
+      for (int k = 0; k < 6; k++) tap[k].v[r] = t[k];
+    }
+  }
+  void terrain_finish(const KCfg& K, const F16* tap, F16& h, F16& nx, F16& ny, F16& nz) const {
+    for (int r = 0; r < 16; r++) {
+      float t[6];
+      for (int k = 0; k < 6; k++) t[k] = tap[k].v[r];
+      if (K.terrain == 0 || K.hf == nullptr) { h.v[r] = 0; nx.v[r] = 0; ny.v[r] = 0; nz.v[r] = 1; }
+      else heightfield_finish(K, t, h.v[r], nx.v[r], ny.v[r], nz.v[r]);
     }
   }
 };
