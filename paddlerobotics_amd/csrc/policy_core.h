@@ -37,7 +37,11 @@ __device__ __forceinline__ void hidden_layer(const float* in, const float4* __re
   // tile t of this wave: packed block ((TPW*wave + t) * nkb + kb); software-pipelined: the next k-block's
   // fragments are in flight while the MFMAs of the current one issue
   const float4* base = wp + (size_t)(TPW * wave) * nkb * 64 + lane;
+#ifdef ETG_PROBE_WEIGHTS_FROM_L1   // upper-bound probe (wrong results): every tile re-reads the same fragments -> L1 hits
+  const int tstride = 0;
+#else
   const int tstride = nkb * 64;
+#endif
   if (!BF16) {
     // weight fragments come from L2 (hundreds of ns) while one k-block is only 16 MFMAs (~0.2 us): keep PF
     // k-blocks in flight in a register ring; the loop is fully unrolled so the ring indices are static
