@@ -300,6 +300,26 @@ int etg_fit_etg(const double* points, int nb, const double* feats, const double*
                 double b0z, double precision, double alpha, double lamb, int max_iter,
                 double* out_w, double* out_b, void* stream);
 
+/* ---- transitions for the off-policy learner ---------------------------------- */
+/* The reference's loops append every transition to a replay memory: rpm.append(obs, action, reward, next_obs, terminal),
+ * terminal = 1 - done (train.py:148-149,159,240-241), and sum the reward terms of `info` (train.py:150-156).  Batched
+ * and masked: only robots whose episode is still running store a row.  The memory is five caller-owned device arrays of
+ * max_size + 1 rows (row max_size is scratch): mem_obs / mem_next_obs [max_size + 1, obs_dim], mem_act [.., act_dim],
+ * mem_reward / mem_terminal [max_size + 1]; pos_count [2] (device, int64) = next slot to write, transitions ever stored.
+ *
+ * etg_replay_begin (BEFORE the step overwrites the observation buffer): slot[i] = ring slot of robot i's row (alive [n]
+ * bytes, NULL = all), pos_count advanced, obs and act rows stored.  n must not exceed max_size.  act_scaled [n, act_dim]
+ * (may be NULL) receives act_scale * act: the command of the step (action * act_bound, train.py:147).               */
+int etg_replay_begin(const uint8_t* alive, int n, long long max_size, long long* pos_count, int32_t* slot,
+                     const float* obs, int obs_dim, const float* act, int act_dim, float* mem_obs, float* mem_act,
+                     float act_scale, float* act_scaled, void* stream);
+/* etg_replay_end (after the step): reward, next_obs and terminal = 1 - done stored at the same slots.  If alive is
+ * given: for alive robots the first n_sum columns of info [n, info_dim] are added to info_sum [n, n_sum + 1] and its last
+ * column counts info[velx_col] >= 0.3 (train.py:156; velx_col < 0: off); then alive &= !done.  info / info_sum may be NULL. */
+int etg_replay_end(const int32_t* slot, int n, const float* reward, const uint8_t* done, const float* next_obs, int obs_dim,
+                   float* mem_reward, float* mem_terminal, float* mem_next_obs, const float* info, int info_dim,
+                   int n_sum, int velx_col, float* info_sum, uint8_t* alive, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

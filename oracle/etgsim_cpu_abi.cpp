@@ -191,6 +191,48 @@ int etg_set_state(EtgHandle* h, const float* state, void*) {
   return ETG_OK;
 }
 
+/* ---- transitions for the off-policy learner (train.py:148-159,240-241), host pointers: the plain sequential statement of
+ * what paddlerobotics_amd/csrc/etg_replay.hip does with a prefix sum and scattered rows ------------------------------- */
+int etg_replay_begin(const uint8_t* alive, int n, long long max_size, long long* pos_count, int32_t* slot, const float* obs,
+                     int obs_dim, const float* act, int act_dim, float* mem_obs, float* mem_act, float act_scale, float* act_scaled,
+                     void*) {
+  if (n <= 0 || max_size <= 0 || n > max_size || !pos_count || !slot || !obs || !act || !mem_obs || !mem_act || obs_dim <= 0 || act_dim <= 0)
+    return cfail(ETG_ERR_BAD_ARG, "etg_replay_begin: bad arguments (a batch must fit the memory)");
+  long long pos = pos_count[0];
+  for (int i = 0; i < n; i++) {
+    const bool a = !alive || alive[i];
+    const long long s = a ? pos : max_size;      // finished robots write the scratch row
+    slot[i] = (int32_t)s;
+    std::memcpy(mem_obs + (size_t)s * obs_dim, obs + (size_t)i * obs_dim, sizeof(float) * obs_dim);
+    std::memcpy(mem_act + (size_t)s * act_dim, act + (size_t)i * act_dim, sizeof(float) * act_dim);
+    if (a) { pos = (pos + 1) % max_size; pos_count[1]++; }
+    if (act_scaled)
+      for (int k = 0; k < act_dim; k++) act_scaled[(size_t)i * act_dim + k] = act_scale * act[(size_t)i * act_dim + k];
+  }
+  pos_count[0] = pos;
+  return ETG_OK;
+}
+int etg_replay_end(const int32_t* slot, int n, const float* reward, const uint8_t* done, const float* next_obs, int obs_dim,
+                   float* mem_reward, float* mem_terminal, float* mem_next_obs, const float* info, int info_dim, int n_sum,
+                   int velx_col, float* info_sum, uint8_t* alive, void*) {
+  if (n <= 0 || !slot || !reward || !done || !next_obs || !mem_reward || !mem_terminal || !mem_next_obs || obs_dim <= 0)
+    return cfail(ETG_ERR_BAD_ARG, "etg_replay_end: bad arguments");
+  if (info && (info_dim <= 0 || n_sum < 0 || n_sum > info_dim || velx_col >= info_dim)) return cfail(ETG_ERR_BAD_ARG, "etg_replay_end: bad info layout");
+  for (int i = 0; i < n; i++) {
+    const size_t s = (size_t)slot[i];
+    mem_reward[s] = reward[i];
+    mem_terminal[s] = done[i] ? 0.0f : 1.0f;     // the stored flag is the bootstrap mask (train.py:148-149)
+    std::memcpy(mem_next_obs + s * obs_dim, next_obs + (size_t)i * obs_dim, sizeof(float) * obs_dim);
+    if (!alive) continue;
+    if (alive[i] && info && info_sum) {
+      for (int k = 0; k < n_sum; k++) info_sum[(size_t)i * (n_sum + 1) + k] += info[(size_t)i * info_dim + k];
+      if (velx_col >= 0 && info[(size_t)i * info_dim + velx_col] >= 0.3f) info_sum[(size_t)i * (n_sum + 1) + n_sum] += 1.0f;
+    }
+    alive[i] = (uint8_t)(alive[i] && !done[i]);
+  }
+  return ETG_OK;
+}
+
 /* ---- device-only entry points ------------------------------------------------------------------------------ */
 #define CPU_UNAVAILABLE(name) return cfail(ETG_ERR_STATE, name ": a device kernel of the HIP library, not part of the CPU build")
 int etg_random_pushes(EtgHandle*, uint64_t, float, int, float, float, void*) { CPU_UNAVAILABLE("etg_random_pushes"); }

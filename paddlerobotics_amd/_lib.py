@@ -16,6 +16,7 @@ SYMBOLS = [
     "etg_get_state",
     "etg_set_state", "etg_policy_create", "etg_policy_load", "etg_policy_forward", "etg_policy_load_std", "etg_policy_sample",
     "etg_policy_destroy", "etg_rollout_policy", "etg_fit_etg", "etg_leg_kinematics", "etg_extra_sensors", "etg_step_autoreset",
+    "etg_replay_begin", "etg_replay_end",
 ]
 
 
@@ -70,6 +71,9 @@ def load():
     lib.etg_policy_destroy.restype = None
     dbl = C.c_double
     lib.etg_fit_etg.argtypes = [vp, i32, vp, vp, dbl, dbl, dbl, dbl, dbl, i32, vp, vp, vp]
+    ll = C.c_longlong
+    lib.etg_replay_begin.argtypes = [vp, i32, ll, vp, vp, vp, i32, vp, i32, vp, vp, C.c_float, vp, vp]
+    lib.etg_replay_end.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
     _LIB = lib
     return lib
 

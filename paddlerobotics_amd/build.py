@@ -8,7 +8,7 @@ import shutil
 import subprocess
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["etg_kernels.hip", "policy_mlp.hip", "etg_fit.hip"]
+SOURCES = ["etg_kernels.hip", "policy_mlp.hip", "etg_fit.hip", "etg_replay.hip"]
 HEADERS = ["etg_core.h", "etg_core16.h", "etg_layout.h", "policy_core.h", os.path.join("..", "..", "include", "etgsim.h")]
 LIB = os.path.join(CSRC, "libetgsim.so")
 

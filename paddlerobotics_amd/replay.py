@@ -9,13 +9,23 @@ One env here is thousands of robots, so one `step()` yields a BATCH of transitio
 robots whose episode is still running into a ring of transitions that lives in HBM next to the simulator -- no host copy,
 no host synchronisation (the write position is a device scalar; rows of finished robots go to a scratch slot).
 `collect_transitions` is the batched run_train_episode / run_EStrain_episode collection loop.
+
+On a HIP device the appends go through etg_replay_begin / etg_replay_end (csrc/etg_replay.hip: prefix sum over the alive
+bytes + scattered rows, three launches per control step, the info sums and the alive update folded in); the torch
+indexing below is the definition of the same operation (host tensors, tests) and what the kernels are tested against.
 """
+import ctypes as C
+
 import numpy as np
 import torch
 
 
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
 class DeviceReplayMemory:
-    def __init__(self, max_size, obs_dim, act_dim, device="cuda:0"):
+    def __init__(self, max_size, obs_dim, act_dim, device="cuda:0", fused=None):
         self.max_size, self.obs_dim, self.act_dim = int(max_size), int(obs_dim), int(act_dim)
         self.device = torch.device(device)
         z = lambda *s: torch.zeros(*s, dtype=torch.float32, device=self.device)
@@ -23,8 +33,56 @@ class DeviceReplayMemory:
         self.obs, self.next_obs = z(self.max_size + 1, self.obs_dim), z(self.max_size + 1, self.obs_dim)
         self.action = z(self.max_size + 1, self.act_dim)
         self.reward, self.terminal = z(self.max_size + 1), z(self.max_size + 1)
-        self._pos = torch.zeros((), dtype=torch.int64, device=self.device)     # next slot to write
-        self._count = torch.zeros((), dtype=torch.int64, device=self.device)   # transitions ever appended
+        self._pc = torch.zeros(2, dtype=torch.int64, device=self.device)       # [next slot to write, transitions ever appended]
+        # HIP kernels (etg_replay.hip) on a GPU; fused=False keeps the torch definition there too (what the tests compare with)
+        self.fused = (self.device.type == "cuda") if fused is None else bool(fused)
+        if self.fused:
+            from . import _lib
+            self._lib, self._check = _lib.load(), _lib.check
+
+    @property
+    def _pos(self):
+        return self._pc[0]
+
+    @_pos.setter
+    def _pos(self, v):
+        self._pc[0] = v
+
+    @property
+    def _count(self):
+        return self._pc[1]
+
+    @_count.setter
+    def _count(self, v):
+        self._pc[1] = v
+
+    def _stream(self):
+        return C.c_void_p(torch.cuda.current_stream(self.device).cuda_stream)
+
+    # ---- fused path (HIP device): alive = uint8 [n] device tensor (or None); returns the int32 slot tensor
+    def begin(self, obs, action, alive=None, act_scale=1.0, act_scaled=None):
+        obs, action = self._rows(obs, self.obs_dim).contiguous(), self._rows(action, self.act_dim).contiguous()
+        n = obs.shape[0]
+        if action.shape[0] != n or (alive is not None and (alive.numel() != n or alive.dtype != torch.uint8)):
+            raise ValueError("begin(): obs / action / alive (uint8) must have one row per robot")
+        slot = torch.empty(n, dtype=torch.int32, device=self.device)
+        self._check(self._lib.etg_replay_begin(_ptr(alive), n, self.max_size, _ptr(self._pc), _ptr(slot), _ptr(obs), self.obs_dim,
+                                               _ptr(action), self.act_dim, _ptr(self.obs), _ptr(self.action), C.c_float(act_scale),
+                                               _ptr(act_scaled), self._stream()))
+        return slot
+
+    def end(self, slot, reward, done, next_obs, info_buf=None, n_sum=0, velx_col=-1, info_sum=None, alive=None):
+        next_obs = self._rows(next_obs, self.obs_dim).contiguous()
+        n = next_obs.shape[0]
+        reward = reward.to(torch.float32).contiguous().view(-1)
+        done = done.view(torch.uint8) if done.dtype == torch.bool else done.to(torch.uint8)
+        done = done.contiguous().view(-1)
+        if reward.numel() != n or done.numel() != n or slot.numel() != n:
+            raise ValueError("end(): one reward / done / slot per robot")
+        info_dim = 0 if info_buf is None else int(info_buf.shape[1])
+        self._check(self._lib.etg_replay_end(_ptr(slot), n, _ptr(reward), _ptr(done), _ptr(next_obs), self.obs_dim, _ptr(self.reward),
+                                             _ptr(self.terminal), _ptr(self.next_obs), _ptr(info_buf), info_dim, int(n_sum), int(velx_col),
+                                             _ptr(info_sum), _ptr(alive), self._stream()))
 
     # ---- writing
     def slots(self, n, mask=None):
@@ -57,6 +115,12 @@ class DeviceReplayMemory:
         self.terminal.index_copy_(0, slot, self._vec(terminal))
 
     def append_batch(self, obs, action, reward, next_obs, terminal, mask=None):
+        if self.fused:   # terminal is the bootstrap mask 1 - done
+            alive = None if mask is None else (mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)).contiguous().view(-1)
+            slot = self.begin(obs, action, alive)
+            done = (self._vec(terminal) == 0).view(torch.uint8)
+            self.end(slot, self._vec(reward), done, next_obs)
+            return
         slot = self.slots(self._rows(obs, self.obs_dim).shape[0], mask)
         self.write_before(slot, obs, action)
         self.write_after(slot, reward, next_obs, terminal)
@@ -130,21 +194,45 @@ def collect_transitions(env, rpm, max_step, policy=None, action_bound=0.3, mode=
     with infos[key] [N] the per-episode sums and infos["success_rate"] [N]."""
     n, dev = env.num_envs, env.device
     adim = env.action_space.shape[0]
-    obs, _ = env.reset(ETG_w=ETG_w, ETG_b=ETG_b, x_noise=x_noise)
-    alive = torch.ones(n, dtype=torch.bool, device=dev)
-    infos = {k: torch.zeros(n, device=dev) for k in info_keys}
-    success = torch.zeros(n, device=dev)
     if mode not in ("predict", "sample", "uniform"):
         raise ValueError("mode must be 'predict', 'sample' or 'uniform'")
     if mode != "uniform" and policy is None:
         raise ValueError("mode %r needs a policy" % mode)
-    for steps in range(1, max_step + 2):
+    obs, _ = env.reset(ETG_w=ETG_w, ETG_b=ETG_b, x_noise=x_noise)
+
+    def act(obs):
         if mode == "uniform":
-            action = torch.rand(n, adim, device=dev, generator=generator) * 2 - 1
-        elif mode == "sample":
-            action = policy.sample(obs, 1.0, precision, generator=generator, return_logp=False)
-        else:
-            action = policy.predict(obs, 1.0, precision)
+            return torch.rand(n, adim, device=dev, generator=generator) * 2 - 1
+        if mode == "sample":
+            return policy.sample(obs, 1.0, precision, generator=generator, return_logp=False)
+        return policy.predict(obs, 1.0, precision)
+
+    info_buf = getattr(env, "info_buf", None)
+    if getattr(rpm, "fused", False) and info_buf is not None:
+        # HIP path: three launches per control step next to predict + step; the summed info terms are the leading columns of
+        # the step's info buffer (a1_model.INFO_SLICES order), so one kernel adds them all
+        from . import a1_model as A
+        cols = [A.INFO_SLICES[k][0] for k in info_keys]
+        n_sum = max(cols) + 1 if cols else 0
+        velx = A.INFO_SLICES["velx"][0]
+        sums = torch.zeros(n, n_sum + 1, device=dev)
+        alive = torch.ones(n, dtype=torch.uint8, device=dev)
+        scaled = torch.empty(n, adim, device=dev)
+        for steps in range(1, max_step + 2):
+            action = act(obs)
+            slot = rpm.begin(obs, action, alive, float(action_bound), scaled)    # also writes scaled = action * action_bound
+            obs, reward, done, _ = env.step(scaled, donef=(steps > max_step))
+            rpm.end(slot, reward, done, obs, info_buf, n_sum, velx, sums, alive)
+        ret, ln = env.episode_stats()
+        infos = {k: sums[:, c] for k, c in zip(info_keys, cols)}
+        infos["success_rate"] = sums[:, n_sum] / ln.to(torch.float32).clamp(min=1)
+        return ret, ln, infos
+
+    alive = torch.ones(n, dtype=torch.bool, device=dev)
+    infos = {k: torch.zeros(n, device=dev) for k in info_keys}
+    success = torch.zeros(n, device=dev)
+    for steps in range(1, max_step + 2):
+        action = act(obs)
         slot = rpm.slots(n, alive)
         rpm.write_before(slot, obs, action)          # the observation buffer is overwritten by the step
         obs, reward, done, info = env.step(action * action_bound, donef=(steps > max_step))

@@ -172,3 +172,78 @@ def test_collect_transitions_on_the_device_matches_a_stepping_loop_and_the_fused
     a3 = rpm3.action[:rpm3.size()]
     assert a3.min().item() < -0.9 and a3.max().item() > 0.9 and abs(a3.mean().item()) < 0.05
     env.close(); ref.close()
+
+
+def _np_memory(max_size, od, ad):
+    z = lambda *s: np.zeros(s, dtype=np.float32)
+    return dict(obs=z(max_size + 1, od), next_obs=z(max_size + 1, od), action=z(max_size + 1, ad), reward=z(max_size + 1),
+                terminal=z(max_size + 1), pc=np.zeros(2, dtype=np.int64))
+
+
+def test_cpu_abi_statement_of_the_replay_entry_points_matches_the_torch_definition():
+    """oracle/libetgsim_cpu.so restates etg_replay_begin / etg_replay_end sequentially on host pointers; DeviceReplayMemory's
+    torch indexing (the definition used on host tensors) gives the same memory for random masked batches with wrap-around,
+    and the info sums / success counter / alive update follow train.py:150-156."""
+    import ctypes as C
+    from tests.test_abi_and_emu import _cpu_abi
+    lib = _cpu_abi()
+    ll = C.c_longlong
+    vp = C.c_void_p
+    lib.etg_replay_begin.argtypes = [vp, C.c_int, ll, vp, vp, vp, C.c_int, vp, C.c_int, vp, vp, C.c_float, vp, vp]
+    lib.etg_replay_end.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp, vp]
+    p = lambda a: a.ctypes.data_as(vp)
+    rng = np.random.default_rng(0)
+    n, od, ad, cap, idim = 37, 5, 3, 100, 9
+    ref = DeviceReplayMemory(cap, od, ad, device="cpu")
+    mem = _np_memory(cap, od, ad)
+    alive = np.ones(n, dtype=np.uint8)
+    sums, want_sums = np.zeros((n, 8), np.float32), np.zeros((n, 8), np.float32)
+    for step in range(9):
+        obs, act = rng.normal(size=(n, od)).astype(np.float32), rng.normal(size=(n, ad)).astype(np.float32)
+        nxt, rew = rng.normal(size=(n, od)).astype(np.float32), rng.normal(size=n).astype(np.float32)
+        done = (rng.random(n) < 0.15).astype(np.uint8)
+        info = rng.normal(size=(n, idim)).astype(np.float32)
+        slot = np.zeros(n, dtype=np.int32)
+        before = alive.copy()
+        scaled = np.zeros((n, ad), np.float32)
+        assert lib.etg_replay_begin(p(alive), n, cap, p(mem["pc"]), p(slot), p(obs), od, p(act), ad, p(mem["obs"]), p(mem["action"]), 0.3, p(scaled), None) == 0
+        assert np.array_equal(scaled, np.float32(0.3) * act)
+        assert lib.etg_replay_end(p(slot), n, p(rew), p(done), p(nxt), od, p(mem["reward"]), p(mem["terminal"]), p(mem["next_obs"]),
+                                  p(info), idim, 7, 8, p(sums), p(alive), None) == 0
+        ref.append_batch(torch.from_numpy(obs), torch.from_numpy(act), torch.from_numpy(rew), torch.from_numpy(nxt),
+                         torch.from_numpy(1.0 - done.astype(np.float32)), mask=torch.from_numpy(before))
+        want_sums[:, :7] += before[:, None] * info[:, :7]
+        want_sums[:, 7] += before * (info[:, 8] >= 0.3)
+        assert np.array_equal(alive, before & (1 - done))
+    for name in ("obs", "next_obs", "action", "reward", "terminal"):
+        assert np.array_equal(mem[name][:cap], getattr(ref, name)[:cap].numpy()), name
+    assert mem["pc"][0] == int(ref._pos) and mem["pc"][1] == int(ref._count) and mem["pc"][1] > cap   # wrapped
+    assert np.allclose(sums, want_sums, atol=1e-5)
+    assert lib.etg_replay_begin(p(alive), cap + 1, cap, p(mem["pc"]), p(slot), p(obs), od, p(act), ad, p(mem["obs"]), p(mem["action"]), 1.0, None, None) == -1
+
+
+@pytest.mark.gpu
+def test_fused_replay_kernels_match_the_torch_definition():
+    """GPU: etg_replay_begin / etg_replay_end (prefix sum + scattered rows) against the torch indexing on the same device:
+    random masked batches of 4096 and of a ragged size, wrap-around, all-dead and all-alive masks."""
+    from tests.test_gpu_parity import _need_gpu
+    _need_gpu()
+    g = torch.Generator(device="cuda:0"); g.manual_seed(3)
+    for n, cap in ((4096, 10000), (1000, 2999), (1, 3)):
+        a, b = DeviceReplayMemory(cap, 49, 12), DeviceReplayMemory(cap, 49, 12, fused=False)
+        assert a.fused and not b.fused
+        for step in range(7):
+            r = lambda *s: torch.randn(*s, device="cuda:0", generator=g)
+            obs, act, rew, nxt = r(n, 49), r(n, 12), r(n), r(n, 49)
+            term = (torch.rand(n, device="cuda:0", generator=g) < 0.8).float()
+            mask = None if step == 0 else (torch.zeros(n, dtype=torch.bool, device="cuda:0") if step == 1 else
+                                           torch.rand(n, device="cuda:0", generator=g) < 0.6)
+            for m in (a, b):
+                m.append_batch(obs, act, rew, nxt, term, mask=mask)
+        for name in ("obs", "next_obs", "action", "reward", "terminal"):
+            assert torch.equal(getattr(a, name)[:cap], getattr(b, name)[:cap]), (n, name)
+        assert int(a._pos) == int(b._pos) and int(a._count) == int(b._count) and a.size() == b.size()
+    with pytest.raises(Exception):
+        DeviceReplayMemory(10, 49, 12).append_batch(torch.zeros(11, 49, device="cuda:0"), torch.zeros(11, 12, device="cuda:0"),
+                                                   torch.zeros(11, device="cuda:0"), torch.zeros(11, 49, device="cuda:0"),
+                                                   torch.ones(11, device="cuda:0"))

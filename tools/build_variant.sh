@@ -4,4 +4,4 @@ R=$(cd "$(dirname "$0")/.." && pwd)
 name=$1; shift
 mkdir -p $R/gpurun_variants
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -fno-slp-vectorize -fno-signed-zeros -ffinite-math-only \
-  -Wno-unused-value "$@" -o $R/gpurun_variants/$name.so $R/paddlerobotics_amd/csrc/etg_kernels.hip $R/paddlerobotics_amd/csrc/policy_mlp.hip $R/paddlerobotics_amd/csrc/etg_fit.hip
+  -Wno-unused-value "$@" -o $R/gpurun_variants/$name.so $R/paddlerobotics_amd/csrc/etg_kernels.hip $R/paddlerobotics_amd/csrc/policy_mlp.hip $R/paddlerobotics_amd/csrc/etg_fit.hip $R/paddlerobotics_amd/csrc/etg_replay.hip
