@@ -548,8 +548,54 @@ class BatchedQuadrupedEnv:
         self._keep_state = st
 
 
-def make_env(name="Quadrupedal", **kwargs):
-    """rlschool.make_env('Quadrupedal', ...) stand-in (train.py:305-309) plus num_envs/device."""
+class SingleRobotEnv:
+    """The reference's own scalar surface over a batch of ONE robot, for the scripts that drive a single env object and
+    expect numpy / Python values (env_test.py:43-58, run_evaluate_episodes train.py:182-211, deployment/test.py):
+
+        obs, info = env.reset(ETG_w=w, ETG_b=b)            obs: np.ndarray [obs_dim] float32
+        obs, reward, done, info = env.step(action, donef)   reward: float, done: bool, info[key]: float / np.ndarray
+
+    Every call copies its results to the host (one synchronisation per step): this is the compatibility path, the
+    throughput path is the batched env.  The batched env is reachable as `.batched`."""
+
+    def __init__(self, **kwargs):
+        if kwargs.get("num_envs", 1) != 1:
+            raise ValueError("SingleRobotEnv drives exactly one robot (num_envs = 1)")
+        kwargs["num_envs"] = 1
+        self.batched = BatchedQuadrupedEnv(**kwargs)
+        self.observation_space, self.action_space = self.batched.observation_space, self.batched.action_space
+
+    def _info(self, info):
+        out = {}
+        for k in info.keys():
+            v = info[k]
+            if v is None:
+                out[k] = None
+                continue
+            v = v[0].detach().cpu().numpy()
+            out[k] = float(v) if v.ndim == 0 else v.astype(np.float64)
+        return out
+
+    def reset(self, **kwargs):
+        for k in ("ETG_w", "ETG_b"):
+            if kwargs.get(k) is not None:
+                kwargs[k] = np.asarray(kwargs[k], dtype=np.float32)
+        obs, info = self.batched.reset(**kwargs)
+        return obs[0].detach().cpu().numpy(), dict(info)
+
+    def step(self, action, donef=False):
+        b = self.batched
+        a = torch.as_tensor(np.asarray(action, dtype=np.float32).reshape(1, -1), device=b.device)
+        obs, reward, done, info = b.step(a, donef=bool(donef))
+        return obs[0].detach().cpu().numpy(), float(reward[0].item()), bool(done[0].item()), self._info(info)
+
+    def close(self):
+        self.batched.close()
+
+
+def make_env(name="Quadrupedal", single=False, **kwargs):
+    """rlschool.make_env('Quadrupedal', ...) stand-in (train.py:305-309) plus num_envs/device.  single=True: one robot
+    behind the reference's numpy / scalar surface (SingleRobotEnv) for unmodified single-env scripts."""
     if name != "Quadrupedal":
         raise ValueError("only the 'Quadrupedal' environment exists here")
-    return BatchedQuadrupedEnv(**kwargs)
+    return SingleRobotEnv(**kwargs) if single else BatchedQuadrupedEnv(**kwargs)

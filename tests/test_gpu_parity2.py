@@ -542,3 +542,59 @@ def test_trunk_and_shin_contacts_match_oracle():
         env.close()
     with pytest.raises(Exception):
         _make(n, body_contacts=2, lanes_per_robot=4)
+
+
+def test_single_robot_surface_runs_the_reference_loops_verbatim(golden):
+    """make_env(..., single=True): one robot behind the reference's numpy / scalar surface.  (1) the loop of env_test.py:47-54
+    (reset, 600 x step(zeros(12), donef=False), collect info["ETG_act"]) reproduces the recorded gait rows; (2) the body of
+    run_evaluate_episodes / run_episode (train.py:182-211, pretrain.py:129-154) runs unmodified on it: Python floats, bools,
+    per-key info sums; its return equals the batched env's for the same robot."""
+    _need_gpu()
+    from paddlerobotics_amd.env import make_env
+    g = golden("etg")
+    env = make_env("Quadrupedal", single=True, device="cuda:0", settle_ticks=50)
+    assert env.observation_space.shape[0] == 49 and env.action_space.shape[0] == 12
+    obs, info = env.reset(ETG_w=g["exp_w"], ETG_b=g["exp_b"])
+    assert isinstance(obs, np.ndarray) and obs.shape == (49,)
+    rows = {int(r): a for r, a in zip(g["exp_rows"], g["exp_act"])}
+    action_list = []
+    for i in range(60):
+        action = np.zeros(12)
+        obs, reward, done, info = env.step(action, donef=False)
+        action_list.append(info["ETG_act"])
+    assert isinstance(reward, float) and isinstance(done, bool) and obs.dtype == np.float32
+    for k, want in rows.items():
+        if k < 60:
+            assert np.abs(action_list[k] - want).max() < 2e-5, k
+    env.close()
+    # (2) run_episode, as written in the reference
+    Param_Dict = {"torso": 1.5, "feet": 0.3, "up": 0.6, "tau": 0.07, "stand": 0.0, "badfoot": 0.1, "footcontact": 0.1}
+    env = make_env("Quadrupedal", single=True, device="cuda:0")
+    W, B = _etg_params(1, seed=4)
+    max_step, action_bound = 40, 0.3
+    obs, info = env.reset(ETG_w=W[0], ETG_b=B[0])
+    done, episode_reward, episode_steps, infos, success_num = False, 0, 0, {}, 0
+    while not done:
+        episode_steps += 1
+        action = np.zeros(12)
+        next_obs, reward, done, info = env.step(action * action_bound, donef=(episode_steps > max_step))
+        for key in Param_Dict.keys():
+            if key in info.keys():
+                if key not in infos.keys():
+                    infos[key] = info[key]
+                else:
+                    infos[key] += info[key]
+        if info["velx"] >= 0.3:
+            success_num += 1
+        obs = next_obs
+        episode_reward += reward
+        if episode_steps > max_step:
+            break
+    env.close()
+    ref = _make(16)
+    W16, B16 = np.repeat(W, 16, axis=0), np.repeat(B, 16, axis=0)
+    from paddlerobotics_amd.rollout import run_episodes
+    ret, ln = run_episodes(ref, max_step, ETG_w=W16, ETG_b=B16)
+    assert episode_steps == int(ln[0].item()) and abs(episode_reward - float(ret[0].item())) < 1e-3 * max(1.0, abs(episode_reward))
+    assert set(infos) == set(Param_Dict) and all(isinstance(v, float) for v in infos.values())
+    ref.close()
