@@ -105,6 +105,13 @@ int fail(const char* msg) {
   etg_set_last_error_(msg);
   return ETG_ERR_BAD_ARG;
 }
+// launch on the device that owns the memory (the caller's current device may be another one)
+bool bind_device(const void* p) {
+  hipPointerAttribute_t attr;
+  if (hipPointerGetAttributes(&attr, p) == hipSuccess && hipSetDevice(attr.device) == hipSuccess) return true;
+  (void)hipGetLastError();
+  return false;
+}
 int hip_fail(const char* what) {
   hipError_t e = hipGetLastError();
   if (e == hipSuccess) return ETG_OK;
@@ -121,6 +128,7 @@ extern "C" int etg_replay_begin(const uint8_t* alive, int n, long long max_size,
                                 float act_scale, float* act_scaled, void* stream) {
   if (n <= 0 || max_size <= 0 || n > max_size || !pos_count || !slot || !obs || !act || !mem_obs || !mem_act || obs_dim <= 0 || act_dim <= 0)
     return fail("etg_replay_begin: bad arguments (a batch must fit the memory)");
+  if (!bind_device(mem_obs)) return fail("etg_replay_begin: mem_obs is not a device pointer");
   hipStream_t s = (hipStream_t)stream;
   hipLaunchKernelGGL(k_replay_slots, dim3(1), dim3(1024), 0, s, alive, n, max_size, pos_count, slot);
   const long long tot = (long long)n * (obs_dim + act_dim);
@@ -135,6 +143,7 @@ extern "C" int etg_replay_end(const int32_t* slot, int n, const float* reward, c
   if (n <= 0 || !slot || !reward || !done || !next_obs || !mem_reward || !mem_terminal || !mem_next_obs || obs_dim <= 0)
     return fail("etg_replay_end: bad arguments");
   if (info && (info_dim <= 0 || n_sum < 0 || n_sum > info_dim || velx_col >= info_dim)) return fail("etg_replay_end: bad info layout");
+  if (!bind_device(mem_next_obs)) return fail("etg_replay_end: mem_next_obs is not a device pointer");
   hipStream_t s = (hipStream_t)stream;
   const long long tot = (long long)n * obs_dim;
   hipLaunchKernelGGL(k_replay_end_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, slot, n, next_obs, obs_dim, mem_next_obs, reward,

@@ -43,6 +43,12 @@ def test_no_cpu_fallback_without_device():
     assert rc == -2 and b"no HIP device" in lib.etg_last_error()   # ETG_ERR_NO_DEVICE
     p = C.c_void_p()
     assert lib.etg_policy_create(49, 256, 12, 0, C.byref(p)) == -2
+    # the replay entry points take raw device pointers: host memory is refused, nothing is computed on the CPU
+    a, b = np.zeros((4, 5), np.float32), np.zeros((4, 3), np.float32)
+    mem, mema, pc, slot = np.zeros((11, 5), np.float32), np.zeros((11, 3), np.float32), np.zeros(2, np.int64), np.zeros(4, np.int32)
+    q = lambda x: x.ctypes.data_as(C.c_void_p)
+    assert lib.etg_replay_begin(None, 4, 10, q(pc), q(slot), q(a), 5, q(b), 3, q(mem), q(mema), C.c_float(1.0), None, None) == -1
+    assert b"not a device pointer" in lib.etg_last_error() and not mem.any() and pc[1] == 0
 
 
 def test_struct_sizes_match_header():
