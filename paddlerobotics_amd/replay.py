@@ -149,6 +149,22 @@ class DeviceReplayMemory:
         idx = torch.clamp((u * n).to(torch.int64), max=self.max_size - 1)
         return self.obs[idx], self.action[idx], self.reward[idx], self.next_obs[idx], self.terminal[idx]
 
+    def sample_batch_by_index(self, batch_idx):
+        """(obs, action) rows at the given indices: the pair memory of the behaviour-cloning loop (BCtrain.py:144-147,
+        rpm.append(agent_obs, ref_obs) / rpm.sample_batch_by_index)"""
+        idx = torch.as_tensor(batch_idx, dtype=torch.int64, device=self.device)
+        return self.obs[idx], self.action[idx]
+
+    def append_pairs(self, first, second, mask=None):
+        """rpm.append(agent_obs, ref_obs) of BCtrain.py:130, batched and masked: `first` rows go to the obs field, `second`
+        rows to the action field (the reference builds that memory with obs_dim = student dim, act_dim = teacher dim)"""
+        n = self._rows(first, self.obs_dim).shape[0]
+        if self.fused:
+            alive = None if mask is None else (mask.view(torch.uint8) if mask.dtype == torch.bool else mask.to(torch.uint8)).contiguous().view(-1)
+            self.begin(first, second, alive)
+        else:
+            self.write_before(self.slots(n, mask), first, second)
+
     # ---- on-disk format: one .npz with the arrays of the filled part, oldest rows first are NOT reordered (ring order)
     def save(self, path):
         n = self.size()
@@ -246,3 +262,42 @@ def collect_transitions(env, rpm, max_step, policy=None, action_bound=0.3, mode=
     ret, ln = env.episode_stats()
     infos["success_rate"] = success / ln.to(torch.float32).clamp(min=1)
     return ret, ln, infos
+
+
+def obs2noise(obs, generator=None):
+    """BCtrain.py:53-59 on a batch: Gaussian sensor noise on the normalised rpy (6e-2 / 0.1), rpy rate (1e-1 / 0.5), motor
+    angle (1e-2 / 0.1) and motor velocity (0.5) columns of the 49-float observation; returns a new tensor."""
+    out = obs.clone()
+    for a, b, sd in ((7, 10, 6e-2 / 0.1), (10, 13, 1e-1 / 0.5), (13, 25, 1e-2 / 0.1), (25, 37, 0.5)):
+        out[:, a:b] += torch.randn(obs.shape[0], b - a, device=obs.device, generator=generator) * sd
+    return out
+
+
+def collect_bc_pairs(env, rpm, max_step, student=None, action_bound=0.3, sensor_noise=True, mode="sample", x_noise=0,
+                     precision=0, generator=None):
+    """The collection half of BCtrain.py:87-131, batched: every control step the student acts on ITS observation
+    (cal_agent_obs: the 49-float row, optionally with obs2noise, without the 3 displacement columns) and the pair
+    (student observation [46], teacher observation [49]) of every robot whose episode is still running is stored
+    (rpm = DeviceReplayMemory(max_size, 46, 49)); the learner later labels the pairs with the teacher's action
+    (BClearn).  mode: "sample" | "predict" (student policy) | "uniform" (the warm-up phase, BCtrain.py:101-102).
+    Returns (episode_return [N], episode_len [N])."""
+    n, dev = env.num_envs, env.device
+    adim = env.action_space.shape[0]
+    if mode != "uniform" and student is None:
+        raise ValueError("mode %r needs the student policy" % mode)
+    obs, _ = env.reset(x_noise=x_noise)
+    if obs.shape[1] != rpm.act_dim or obs.shape[1] - 3 != rpm.obs_dim:
+        raise ValueError("the pair memory must be DeviceReplayMemory(max_size, %d, %d)" % (obs.shape[1] - 3, obs.shape[1]))
+    alive = torch.ones(n, dtype=torch.bool, device=dev)
+    for steps in range(1, max_step + 2):
+        agent_obs = (obs2noise(obs, generator) if sensor_noise else obs)[:, 3:].contiguous()
+        rpm.append_pairs(agent_obs, obs, alive)                 # before the step overwrites the observation buffer
+        if mode == "uniform":
+            action = torch.rand(n, adim, device=dev, generator=generator) * 2 - 1
+        elif mode == "sample":
+            action = student.sample(agent_obs, 1.0, precision, generator=generator, return_logp=False)
+        else:
+            action = student.predict(agent_obs, 1.0, precision)
+        obs, _, done, _ = env.step(action * action_bound, donef=(steps > max_step), want_info=False)
+        alive = alive & ~done.view(-1).to(torch.bool)
+    return env.episode_stats()

@@ -247,3 +247,54 @@ def test_fused_replay_kernels_match_the_torch_definition():
         DeviceReplayMemory(10, 49, 12).append_batch(torch.zeros(11, 49, device="cuda:0"), torch.zeros(11, 12, device="cuda:0"),
                                                    torch.zeros(11, device="cuda:0"), torch.zeros(11, 49, device="cuda:0"),
                                                    torch.ones(11, device="cuda:0"))
+
+
+def test_bc_pair_memory_and_noise_levels():
+    """BCtrain.py: rpm.append(agent_obs, ref_obs) / sample_batch_by_index on the pair memory, and obs2noise's per-column
+    levels (BCtrain.py:53-59)."""
+    from paddlerobotics_amd.replay import obs2noise
+    m = DeviceReplayMemory(20, 4, 7, device="cpu")
+    a, b = torch.arange(12.0).view(3, 4), torch.arange(21.0).view(3, 7) + 100
+    m.append_pairs(a, b, mask=torch.tensor([True, False, True]))
+    m.append_pairs(a + 50, b + 50)
+    assert m.size() == 5
+    o, r = m.sample_batch_by_index([0, 1, 4])
+    assert torch.equal(o, torch.stack([a[0], a[2], a[2] + 50])) and torch.equal(r, torch.stack([b[0], b[2], b[2] + 50]))
+    g = torch.Generator().manual_seed(0)
+    obs = torch.zeros(20000, 49)
+    d = obs2noise(obs, g)
+    assert d[:, :7].abs().max() == 0 and d[:, 37:].abs().max() == 0 and obs.abs().max() == 0
+    for (lo, hi, sd) in ((7, 10, 0.6), (10, 13, 0.2), (13, 25, 0.1), (25, 37, 0.5)):
+        assert abs(d[:, lo:hi].std().item() - sd) < 0.03 * sd and abs(d[:, lo:hi].mean().item()) < 0.02 * sd
+
+
+@pytest.mark.gpu
+def test_collect_bc_pairs_on_the_device():
+    """GPU: the behaviour-cloning collection loop (BCtrain.py:87-131) with a 46-input student: stored pairs are (noisy
+    observation without the displacement columns, clean teacher observation) of live robots only."""
+    from tests.test_gpu_parity import _need_gpu, _make
+    from paddlerobotics_amd.policy import MfmaPolicy
+    from paddlerobotics_amd.replay import collect_bc_pairs
+    _need_gpu()
+    n, max_step = 128, 29
+    student = MfmaPolicy(46, 12)
+    student.load_state_dict(MfmaPolicy.init_like_reference(46, 12, seed=1))
+    env = _make(n, seed=2)
+    rpm = DeviceReplayMemory(n * (max_step + 1), 46, 49)
+    g = torch.Generator(device="cuda:0"); g.manual_seed(4)
+    ret, ln = collect_bc_pairs(env, rpm, max_step, student=student, generator=g)
+    k = rpm.size()
+    assert k == int(ln.sum().item()) and torch.isfinite(ret).all()
+    stu, tea = rpm.sample_batch_by_index(torch.arange(k))
+    assert stu.shape == (k, 46) and tea.shape == (k, 49)
+    diff = stu - tea[:, 3:]
+    assert diff[:, :4].abs().max().item() == 0 and diff[:, 34:].abs().max().item() == 0      # contacts and ETG columns: clean
+    assert abs(diff[:, 4:7].std().item() - 0.6) < 0.06 and abs(diff[:, 22:34].std().item() - 0.5) < 0.05
+    # without the noise the student sees the teacher's row minus the displacement
+    rpm2 = DeviceReplayMemory(n * (max_step + 1), 46, 49)
+    collect_bc_pairs(env, rpm2, max_step, mode="uniform", sensor_noise=False)
+    s2, t2 = rpm2.sample_batch_by_index(torch.arange(rpm2.size()))
+    assert torch.equal(s2, t2[:, 3:])
+    with pytest.raises(ValueError):
+        collect_bc_pairs(env, DeviceReplayMemory(100, 49, 12), max_step, mode="uniform")
+    env.close()
