@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$1
 mkdir -p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python $R/bench.py --steps 200 --warmup 20 --repeats 3 --no-cpu-baseline --no-extra-legs ${@:2} > $OUT/bench.json 2> $OUT/stderr.log || true
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o bench -- python $R/bench.py --steps 200 --warmup 50 --repeats 3 --no-cpu-baseline --no-extra-legs ${@:2} > $OUT/bench.json 2> $OUT/stderr.log || true
 find $OUT -name "*kernel_stats*" | head -3
 f=$(find $OUT -name "*kernel_stats.csv" | head -1); [ -n "$f" ] && head -12 "$f"
 tail -1 $OUT/bench.json
