@@ -244,13 +244,15 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    stat_buf = (torch.empty(N, device=dev), torch.empty(N, dtype=torch.int32, device=dev))   # episode returns / lengths of a rollout
+
     def run_steps(e, pol, n, fused):
         """n control steps of the hot path: the fused rollouts (etg_rollout_openloop / etg_rollout_policy, <= 50 control steps
         per launch) or env.step() per control step (policy.predict() before each in closed loop)"""
         if n <= 0:
             return e.episode_stats()
         if fused:   # the fused entry points return the episode statistics themselves (etg_episode_stats inside the C call)
-            return e.rollout_openloop(n) if pol is None else e.rollout_policy(pol, n, 0.3, args.precision)
+            return e.rollout_openloop(n, out=stat_buf) if pol is None else e.rollout_policy(pol, n, 0.3, args.precision)
         for _ in range(n):
             if pol is not None:
                 pol.predict(e.obs, 0.3, args.precision, out=act)
@@ -274,9 +276,9 @@ def main():
             run_steps(warm_env, None, CLOCK_WARM_STEPS, True)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             barrier()
-            t0 = time.perf_counter()
             if events:
-                e0.record()
+                e0.record()        # (an empty stream: the event pair brackets the same device work as the host clock)
+            t0 = time.perf_counter()
             # episode returns / lengths are accumulated inside the kernels (alive-masked) and copied out by the same call; for
             # N > 1 the one exchange of the path -- all_gather of the returns (configs[3]; cf. the xparl scatter/gather of
             # model/Dynamic_parallel_model.py:157-160) -- is part of the timed region

@@ -498,11 +498,18 @@ class BatchedQuadrupedEnv:
             self._last_view = self._obs_view()
         return (self._last_view, self.reward, self.done.view(torch.bool) if want_info else self.done, info)
 
-    def rollout_openloop(self, n_steps):
+    def rollout_openloop(self, n_steps, out=None):
         """n_steps control steps with zero residual action (pretrain.py:129-154) enqueued back to
-        back; returns (episode_return[N], episode_len[N]) since the last reset, alive-masked."""
-        ret = torch.empty(self.num_envs, device=self.device)               # every entry is written by the kernel: no fill launch
-        ln = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
+        back; returns (episode_return[N], episode_len[N]) since the last reset, alive-masked.  out = (ret float32 [N],
+        len int32 [N]) reuses the caller's buffers."""
+        if out is not None:
+            ret, ln = out
+            if ret.dtype != torch.float32 or ln.dtype != torch.int32 or ret.numel() != self.num_envs or ln.numel() != self.num_envs \
+                    or ret.device.type != self.device.type or ln.device.type != self.device.type or not (ret.is_contiguous() and ln.is_contiguous()):
+                raise ValueError("out must be (float32 [N], int32 [N]) contiguous tensors on the env's device")
+        else:
+            ret = torch.empty(self.num_envs, device=self.device)           # every entry is written by the kernel: no fill launch
+            ln = torch.empty(self.num_envs, dtype=torch.int32, device=self.device)
         _lib.check(self._lib.etg_rollout_openloop(self._h, int(n_steps), _ptr(self.obs), _ptr(ret), _ptr(ln),
                                                   self._stream()))
         return ret, ln
