@@ -309,9 +309,9 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
 
   // ---- leg kinematics in the base frame
   F sa, ca, sh, ch, sk, ck;
-  sincos_(L.q[0], sa, ca);
-  sincos_(L.q[1], sh, ch);
-  sincos_(L.q[2], sk, ck);
+  sincos_tick_(L.q[0], sa, ca);
+  sincos_tick_(L.q[1], sh, ch);
+  sincos_tick_(L.q[2], sk, ck);
   const F shk = sh * ck + ch * sk, chk = ch * ck - sh * sk;  // angle addition instead of a third sincos
   Fr<F> R1 = {{one, zero, zero}, {zero, ca, sa}, {zero, -sa, ca}};
   Fr<F> R2 = {{ch, sa * sh, -(ca * sh)}, {zero, ca, sa}, {sh, -(sa * ch), ca * ch}};

@@ -94,7 +94,7 @@ template <class F> struct LegGeo { F sa, ca, sh, ch, shk, chk; V3<F> yax, o1, o2
 template <class F, class Ctx> ETG_HD LegGeo<F> leg_geometry(const Ctx& c, const KCfg& K, const V3<F>& o1, F sy, F q_own) {
   LegGeo<F> g;
   F sq, cq;
-  sincos_(q_own, sq, cq);  // one sincos per lane (its own joint), shared through the quad
+  sincos_tick_(q_own, sq, cq);  // one sincos per lane (its own joint), shared through the quad
   g.sa = c.qb(sq, 0); g.ca = c.qb(cq, 0);
   g.sh = c.qb(sq, 1); g.ch = c.qb(cq, 1);
   const F sk = c.qb(sq, 2), ck = c.qb(cq, 2);

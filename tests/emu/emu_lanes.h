@@ -31,6 +31,7 @@ template <int W> inline FW<W> fmaxf_(FW<W> a, FW<W> b) { FW<W> r; for (int i = 0
 template <int W> inline FW<W> atan2_(FW<W> a, FW<W> b) { FW<W> r; for (int i = 0; i < W; i++) r.v[i] = atan2f(a.v[i], b.v[i]); return r; }
 template <int W> inline BW<W> isfinite_(FW<W> a) { BW<W> r; for (int i = 0; i < W; i++) r.v[i] = std::isfinite(a.v[i]); return r; }
 template <int W> inline void sincos_(FW<W> a, FW<W>& s, FW<W>& c) { for (int i = 0; i < W; i++) { s.v[i] = sinf(a.v[i]); c.v[i] = cosf(a.v[i]); } }
+template <int W> inline void sincos_tick_(FW<W> a, FW<W>& s, FW<W>& c) { sincos_(a, s, c); }
 typedef FW<4> F4;
 typedef BW<4> B4;
 typedef FW<16> F16;
