@@ -172,6 +172,8 @@ ETG_HD void sincos_(float x, float& s, float& c) {
 // v_cos_f32 take the argument in revolutions; over the joint range (|x| < 4.2 rad) their error is 3.9e-7 / 3.5e-7 against
 // double precision and |s^2 + c^2 - 1| < 2.5e-7 (tools/ubench/hw_sincos.hip) -- the polynomial routine's accuracy for
 // 3 instructions instead of 27 (-1.5 % per control step).  NOT for the ETG phase: 160 revolutions leave 1e-4 rad.
+// Domain of the instructions: |x| < 256 revolutions = 1608 rad (beyond: sin -> 0, cos -> 1, still finite) -- only a
+// limit-less joint spun up by a constant torque for seconds gets there, on a robot that has long terminated.
 ETG_HD void sincos_tick_(float x, float& s, float& c) {
 #ifdef ETG_POLY_SINCOS_IN_TICK
   sincos_(x, s, c);
