@@ -873,6 +873,22 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   if (!cfg || !model || !out) return fail(ETG_ERR_BAD_ARG, "etg_create: null argument");
   if (cfg->num_envs <= 0 || cfg->num_envs > (1 << 20)) return fail(ETG_ERR_BAD_ARG, "etg_create: num_envs must be in 1..1048576");
   if (cfg->action_repeat <= 0 || cfg->sim_dt <= 0) return fail(ETG_ERR_BAD_ARG, "etg_create: bad action_repeat/sim_dt");
+  // the rest of the configuration is checked before a device is touched, so a bad one reads the same on any box
+  if (cfg->solver_iters <= 0 || cfg->solver_iters > 1000) return fail(ETG_ERR_BAD_ARG, "etg_create: solver_iters must be in 1..1000");
+  if (cfg->settle_ticks < 0) return fail(ETG_ERR_BAD_ARG, "etg_create: settle_ticks must not be negative");
+  if (cfg->motor_mode < 0 || cfg->motor_mode > 2) return fail(ETG_ERR_BAD_ARG, "etg_create: motor_mode must be 0 (POSITION), 1 (TORQUE) or 2 (HYBRID)");
+  if (cfg->body_contacts < 0 || cfg->body_contacts > 2) return fail(ETG_ERR_BAD_ARG, "etg_create: body_contacts must be 0, 1 or 2");
+  if (cfg->terrain != 0 && cfg->terrain != 1) return fail(ETG_ERR_BAD_ARG, "etg_create: terrain must be 0 (plane) or 1 (heightfield)");
+  if (cfg->terrain == 1 && (cfg->hf_nx < 2 || cfg->hf_ny < 2 || !(cfg->hf_cell > 0) || cfg->hf_bands < 0 ||
+                            (cfg->hf_bands > 1 && cfg->hf_ny % cfg->hf_bands != 0)))
+    return fail(ETG_ERR_BAD_ARG, "etg_create: a heightfield needs hf_nx, hf_ny >= 2 (per band), hf_cell > 0 and hf_ny divisible by hf_bands");
+  if (cfg->etg_dt <= 0 || cfg->etg_T <= 0) return fail(ETG_ERR_BAD_ARG, "etg_create: etg_dt and etg_T must be positive");
+  if (cfg->joint_limits)
+    for (int k = 0; k < 3; k++)
+      if (!(cfg->joint_lower[k] < cfg->joint_upper[k])) return fail(ETG_ERR_BAD_ARG, "etg_create: joint_lower must be below joint_upper");
+  if (cfg->lanes_per_robot != 0 && cfg->lanes_per_robot != 4 && cfg->lanes_per_robot != 16)
+    return fail(ETG_ERR_BAD_ARG, "etg_create: lanes_per_robot must be 0 (auto), 4 or 16");
+  if (cfg->body_contacts && cfg->lanes_per_robot == 4) return fail(ETG_ERR_BAD_ARG, "etg_create: body_contacts needs the 16-lanes-per-robot mapping");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(ETG_ERR_NO_DEVICE, "etg_create: no HIP device (this library has no CPU path)");
@@ -889,21 +905,11 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   h->was_reset = false;
   h->fext_set = h->push_on = false;
   h->all_cached = false;
-  if (cfg->lanes_per_robot != 0 && cfg->lanes_per_robot != 4 && cfg->lanes_per_robot != 16) {
-    delete h;
-    return fail(ETG_ERR_BAD_ARG, "etg_create: lanes_per_robot must be 4 or 16");
-  }
   // 0 = auto.  Both kernels hold one wave per SIMD (register footprint), so the chip runs 1024 waves
   // at a time: 16 lanes/robot fills it with 4096 robots and is faster per robot up to there; beyond
   // that the 4-lanes/robot kernel packs 4x the robots per wave (measured crossover).
   h->lanes = cfg->lanes_per_robot != 0 ? cfg->lanes_per_robot : (cfg->num_envs <= 4096 ? 16 : 4);
-  if (cfg->body_contacts) {   // the knee rows live on the 4th lane of every leg of the 16-lane kernels
-    if (cfg->lanes_per_robot == 4) {
-      delete h;
-      return fail(ETG_ERR_BAD_ARG, "etg_create: body_contacts needs the 16-lanes-per-robot mapping");
-    }
-    h->lanes = 16;
-  }
+  if (cfg->body_contacts) h->lanes = 16;   // the body rows live on the 4th lane of every leg of the 16-lane kernels
   size_t N = h->N, NL = 4 * N;
   struct { void** p; size_t bytes; } allocs[] = {
       {(void**)&h->D.base, BS_N * N * 4},   {(void**)&h->D.leg, LG_N * NL * 4},   {(void**)&h->D.ctl, CT_N * N * 4},

@@ -51,6 +51,34 @@ def test_no_cpu_fallback_without_device():
     assert b"not a device pointer" in lib.etg_last_error() and not mem.any() and pc[1] == 0
 
 
+def test_create_validates_the_configuration_before_touching_a_device():
+    """etg_create refuses an invalid configuration with ETG_ERR_BAD_ARG and a message naming the field -- checked before the
+    device lookup, so the same call fails the same way on a box without a GPU (sizes as the reference raises ValueError,
+    minitaur.py:1002-1005; modes, laikago_motor.py:131-133)."""
+    from paddlerobotics_amd import _lib
+    lib = _lib.load()
+
+    def create(**kw):
+        cfg, model = A.default_config(4), A.default_model()
+        for k, v in kw.items():
+            setattr(cfg, k, v)
+        h = C.c_void_p()
+        return lib.etg_create(C.byref(cfg), C.byref(model), 0, C.byref(h)), lib.etg_last_error().decode()
+
+    for kw, word in ((dict(num_envs=0), "num_envs"), (dict(num_envs=-3), "num_envs"), (dict(num_envs=(1 << 20) + 1), "num_envs"),
+                     (dict(action_repeat=0), "action_repeat"), (dict(sim_dt=0.0), "sim_dt"), (dict(solver_iters=0), "solver_iters"),
+                     (dict(settle_ticks=-1), "settle_ticks"), (dict(motor_mode=3), "motor_mode"), (dict(body_contacts=3), "body_contacts"),
+                     (dict(terrain=2), "terrain"), (dict(terrain=1), "heightfield"), (dict(lanes_per_robot=8), "lanes_per_robot"),
+                     (dict(body_contacts=1, lanes_per_robot=4), "16-lanes"), (dict(etg_dt=0.0), "etg_dt")):
+        rc, msg = create(**kw)
+        assert rc == -1 and word in msg, (kw, rc, msg)
+    cfg = A.default_config(4, joint_limits=1)
+    cfg.joint_lower[1] = 5.0
+    h = C.c_void_p()
+    assert lib.etg_create(C.byref(cfg), C.byref(A.default_model()), 0, C.byref(h)) == -1 and b"joint_lower" in lib.etg_last_error()
+    assert lib.etg_create(None, None, 0, C.byref(h)) == -1
+
+
 def test_struct_sizes_match_header():
     # sizeof() as the C compiler sees it (the oracle is built from the same header)
     import subprocess, tempfile
