@@ -598,3 +598,31 @@ def test_single_robot_surface_runs_the_reference_loops_verbatim(golden):
     assert episode_steps == int(ln[0].item()) and abs(episode_reward - float(ret[0].item())) < 1e-3 * max(1.0, abs(episode_reward))
     assert set(infos) == set(Param_Dict) and all(isinstance(v, float) for v in infos.values())
     ref.close()
+
+
+def test_friction_cone_on_an_inclined_heightfield_gpu():
+    """The analytic case of tests/test_oracle_physics.py::test_friction_cone_on_an_inclined_heightfield on the HIP heightfield
+    path (both lane mappings): sliding down z = tan(t) x with g (sin t - mu cos t) cos t along x within 1 %, holding below
+    the friction angle."""
+    _need_gpu()
+    n, cell, x0 = 512, 0.05, -12.8
+    for lanes in (16, 4):
+        for theta, mu, steps, settle in ((10.0, 0.1, 30, 400), (20.0, 0.25, 30, 400), (10.0, 0.6, 38, 3000)):
+            t = np.deg2rad(theta)
+            H = np.tile((np.tan(t) * (x0 + cell * np.arange(n)))[None, :], (n, 1)).astype(np.float32)
+            env = _make(16, task="heightfield", heightfield={"heights": H, "cell": cell, "origin": (x0, x0)}, ETG=0, solver_iters=50,
+                        settle_ticks=settle, lanes_per_robot=lanes)
+            row = A.default_dynamic_row()
+            row[1] = mu
+            env.reset(dynamic_param=row)
+            s0 = env.get_state().cpu().numpy()
+            for _ in range(steps):
+                env.step(None)
+            s1 = env.get_state().cpu().numpy()
+            if mu * np.cos(t) < np.sin(t):
+                want = -10.0 * (np.sin(t) - mu * np.cos(t)) * np.cos(t)
+                got = (s1[:, 7] - s0[:, 7]) / (steps * 0.026)
+                assert np.abs(got - want).max() < 0.01 * abs(want), (lanes, theta, mu, got[:3], want)
+            else:
+                assert np.abs(s1[:, 0] - s0[:, 0]).max() < 2e-3 and np.abs(s1[:, 7:10]).max() < 5e-3, (lanes, theta)
+            env.close()

@@ -333,3 +333,39 @@ def test_converged_contact_solve_satisfies_the_coulomb_complementarity_condition
     gap = max(abs(a[0] - b[0]) / b[0] for a, b in zip(two, ref))
     print("[parity] K = 2 vs converged normal impulses after a kick: max relative gap %.3f" % gap)
     assert gap < 0.5
+
+
+def _on_a_slope(theta_deg, mu, steps, settle_ticks):
+    """a standing robot (PD holds the pose, no trajectory generator) on the inclined plane z = tan(theta) x, given as a
+    heightfield; returns the states at the end of the settle and `steps` control steps later"""
+    th = np.deg2rad(theta_deg)
+    n, cell, x0 = 512, 0.05, -12.8
+    H = np.tile((np.tan(th) * (x0 + cell * np.arange(n)))[None, :], (n, 1)).astype(np.float32)
+    cfg = A.default_config(1, terrain=1, heightfield={"heights": H, "cell": cell, "origin": (x0, x0)}, enable_etg=0,
+                           solver_iters=50, settle_ticks=settle_ticks)
+    sim = O.OracleSim(cfg)
+    sim.set_heightfield(H)
+    row = A.default_dynamic_row()
+    row[1] = mu
+    sim.set_params(dyn=row[None])
+    sim.reset()
+    s0 = sim.get_state()[0].copy()
+    for _ in range(steps):
+        sim.step(np.zeros((1, 12)))
+    return s0, sim.get_state()[0].copy()
+
+
+def test_friction_cone_on_an_inclined_heightfield():
+    """Contact frame and Coulomb cone on a tilted normal (the heightfield path: bilinear normal, tangents, friction disc):
+    below the friction angle the robot stays put; above it the whole robot slides down with g (sin t - mu cos t), whose
+    x-component is that times cos t."""
+    T = 30 * 0.026
+    for theta, mu in ((10.0, 0.1), (20.0, 0.25), (15.0, 0.2)):
+        s0, s1 = _on_a_slope(theta, mu, 30, 400)
+        t = np.deg2rad(theta)
+        want = -10.0 * (np.sin(t) - mu * np.cos(t)) * np.cos(t)
+        got = (s1[7] - s0[7]) / T
+        assert abs(got - want) < 0.01 * abs(want), (theta, mu, got, want)
+        assert abs(s1[8] - s0[8]) < 2e-2                       # no sideways drift
+    s0, s1 = _on_a_slope(10.0, 0.6, 38, 3000)                # tan 10 deg = 0.18 < 0.6: holds
+    assert abs(s1[0] - s0[0]) < 2e-3 and np.abs(s1[7:10]).max() < 5e-3, (s1[0] - s0[0], s1[7:10])
