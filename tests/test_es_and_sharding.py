@@ -102,3 +102,26 @@ def test_bench_refuses_to_fake_a_multi_gpu_run():
                        capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0
     assert "HIP device(s) visible" in r.stderr and '"n_gpus"' not in r.stdout
+
+
+def test_rlschool_names_cover_what_the_drivers_import():
+    """paddlerobotics_amd.rlschool_names: every name train.py:19-27 / pretrain.py:24 / env_test.py:7 take from rlschool exists
+    with the keys and members the drivers use (train.py:54-58 mode_map, :253-272)."""
+    from copy import copy
+    from paddlerobotics_amd import rlschool_names as rlschool
+    from paddlerobotics_amd.rlschool_names import ETG_layer, ETG_model, Param_Dict, Random_Param_Dict, SENSOR_MODE, robot_config
+    assert callable(rlschool.make_env)
+    param, random_param, sensor_mode = copy(Param_Dict), copy(Random_Param_Dict), copy(SENSOR_MODE)
+    assert set(param) == {"torso", "feet", "up", "tau", "stand", "badfoot", "footcontact"}
+    assert set(random_param) == {"random_dynamics", "random_force"}
+    for k in ("dis", "motor", "imu", "contact", "ETG", "ETG_obs", "footpose", "dynamic_vec", "force_vec", "noise"):
+        assert k in sensor_mode
+    mode_map = {"pose": robot_config.MotorControlMode.POSITION, "torque": robot_config.MotorControlMode.TORQUE,
+                "traj": robot_config.MotorControlMode.POSITION}
+    assert mode_map["torque"].name == "TORQUE" and robot_config.MotorControlMode.HYBRID.value == 3
+    layer = ETG_layer(0.5, 0.026, 20, 0.04, np.array([-np.pi / 2, 0]), 0.2, 0.5)
+    from paddlerobotics_amd.etg import Opt_with_points
+    w0, b0, _ = Opt_with_points(layer, ETG_T=0.5, Footheight=0.1, Steplength=0.05)
+    assert ETG_model(layer, w0, b0).forward(0.026).shape == (12,)
+    from paddlerobotics_amd.env import sensor_columns
+    assert len(sensor_columns(sensor_mode)) == 49          # the drivers' default flags give the 49-float observation
