@@ -1,0 +1,7 @@
+#!/bin/bash
+# one bench.py --steps 200 round per build in gpurun_variants/ (+ the default), for screening many variants
+R=${GRAFT_REPO_ROOT:-/root/repo}
+for lib in default $(ls $R/gpurun_variants/*.so 2>/dev/null); do
+  if [ "$lib" = default ]; then unset ETG_LIB; else export ETG_LIB=$lib; fi
+  python $R/bench.py --steps 200 --warmup 20 --repeats 3 --no-cpu-baseline --no-extra-legs 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%-18s' % '$(basename $lib)', '%.2f M env-steps/s' % (d['value']/1e6), 'kernel %.2f us' % (d['roofline']['kernel_ms']*1e3))"
+done
