@@ -538,6 +538,50 @@ __global__ void __launch_bounds__(BLOCK) k_settle16(KCfg K, DevState D, const ui
   settle_mark_fresh(K, D, c.env, ox, oy);
 }
 
+// ---- cached restart (etg_step_autoreset, 16-lane kernels).  A launch lasts as long as its slowest wave, and with auto-reset
+// some wave restarts a robot in nearly every launch; recomputing reset_finish16 there (first ETG action, IK, foot kinematics,
+// rpy reference, first observation: ~1200 instructions) costs the whole batch ~3 us per step.  What reset_finish16 produces
+// depends only on the settled state, the robot's parameters and its ETG weights, so etg_reset keeps it per robot -- in rows
+// FIN_* of the block behind D.cache_off (rows 0, 1 are the offsets the cached settle ran at) -- and the in-kernel restart
+// copies it back.  Anything that changes an input clears the robot's FIN_OK flag (etg_set_params, etg_set_heightfield,
+// etg_set_reset_offsets); the restart then recomputes as before.
+enum { FIN_OBS = 2, FIN_RPY = FIN_OBS + ETG_OBS_DIM, FIN_FWX = FIN_RPY + 3, FIN_OK = FIN_FWX + 4, FIN_ROWS = FIN_OK + 1 };
+__global__ void __launch_bounds__(256) k_fin_store(KCfg K, DevState D, const uint8_t* mask, const float* obs) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = K.n_env;
+  if (env >= N || (mask && !mask[env])) return;
+  float* fin = D.cache_off;
+  for (int k = 0; k < ETG_OBS_DIM; k++) fin[(size_t)(FIN_OBS + k) * N + env] = obs[(size_t)env * ETG_OBS_DIM + k];
+  for (int k = 0; k < 3; k++) fin[(size_t)(FIN_RPY + k) * N + env] = D.ctl[(size_t)(CT_FIRST_RPY + k) * N + env];
+  for (int leg = 0; leg < 4; leg++) fin[(size_t)(FIN_FWX + leg) * N + env] = D.legctl[(size_t)LC_LAST_FOOT_X * 4 * N + 4 * env + leg];
+  fin[(size_t)FIN_OK * N + env] = 1.0f;
+}
+__global__ void __launch_bounds__(256) k_fin_clear(KCfg K, DevState D, const uint8_t* mask) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= K.n_env || (mask && !mask[env])) return;
+  D.cache_off[(size_t)FIN_OK * K.n_env + env] = 0.0f;
+}
+// reset_finish16 from the cache: same stores, no arithmetic
+template <class Ctx>
+__device__ __forceinline__ void restart_from_cache16(const Ctx& c, const KCfg& K, State16<float>& L, float* ctl, int* ictl, float* legctl,
+                                                     const float* fin, float* obs) {
+  const int N = K.n_env;
+  const float pose = c.jointf() * c.par_joint(PR_POSE);
+  L.energy = 0.0f;
+  c.st_env_i(ictl, IC_STEP, 0);
+  c.st_env_i(ictl, IC_TICK, K.settle_ticks);
+  c.st_env_i(ictl, IC_HAS_LAST, 0);
+  c.st_env(ctl, CT_RET, 0.0f); c.st_env(ctl, CT_LEN, 0.0f); c.st_env(ctl, CT_ALIVE, 1.0f);
+  c.st_env(ctl, CT_LAST_BASE + 0, L.p.x); c.st_env(ctl, CT_LAST_BASE + 1, L.p.y); c.st_env(ctl, CT_LAST_BASE + 2, L.p.z);
+  c.st_joint(legctl, LC_LAST_QDES, pose);
+  c.st_joint(legctl, LC_FX0, pose); c.st_joint(legctl, LC_FX1, pose);
+  c.st_joint(legctl, LC_FY0, pose); c.st_joint(legctl, LC_FY1, pose);
+  c.st_legf(legctl, LC_LAST_FOOT_X, fin[(size_t)(FIN_FWX + c.leg) * N + c.env]);
+#pragma unroll
+  for (int k = 0; k < 3; k++) c.st_env(ctl, CT_FIRST_RPY + k, fin[(size_t)(FIN_RPY + k) * N + c.env]);
+  for (int k = c.r; k < ETG_OBS_DIM; k += 16) obs[(size_t)(c.env - c.row_base) * ETG_OBS_DIM + k] = fin[(size_t)(FIN_OBS + k) * N + c.env];
+}
+
 template <bool FLAT, bool KNEE, bool PLAIN>
 __global__ void __launch_bounds__(BLOCK) k_finish16(KCfg K, DevState D, const uint8_t* mask, float* obs) {
   __shared__ float lds_par[LDS16_FIELDS * BLOCK];
@@ -577,7 +621,8 @@ __device__ __forceinline__ void step16_body(const KCfg& K, const DevState& D, co
     L = load_state16<float>(c, D.cache_base, D.cache_leg);
     L.p.x += D.reset_off[c.env] - D.cache_off[c.env];        // non-zero only on flat ground (settle_cached)
     L.p.y += D.reset_off[N + c.env] - D.cache_off[N + c.env];
-    reset_finish16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, obs);
+    if (D.cache_off[(size_t)FIN_OK * N + c.env] > 0.5f) restart_from_cache16(c, K, L, D.ctl, D.ictl, D.legctl, D.cache_off, obs);
+    else reset_finish16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, obs);
     if (c.r == 0) {
       D.ictl[(size_t)IC_PUSH_LEFT * N + c.env] = 0;
       for (int k = 0; k < 3; k++) D.ctl[(size_t)(CT_PUSH + k) * N + c.env] = 0.0f;
@@ -917,7 +962,7 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
       {(void**)&h->D.par, PR_N * NL * 4},   {(void**)&h->D.ring, (size_t)RING * 8 * NL * 4}, {(void**)&h->D.dyn, ETG_DYN_DIM * N * 4},
       {(void**)&h->D.cache_base, BS_N * N * 4}, {(void**)&h->D.cache_leg, LG_N * NL * 4},
       {(void**)&h->D.cache_ring, (size_t)RING * 8 * NL * 4}, {(void**)&h->D.cache_ok, N},
-      {(void**)&h->D.reset_off, 2 * N * 4}, {(void**)&h->D.cache_off, 2 * N * 4},
+      {(void**)&h->D.reset_off, 2 * N * 4}, {(void**)&h->D.cache_off, (size_t)FIN_ROWS * N * 4},
       {(void**)&h->tmp_obs, ETG_OBS_DIM * N * 4}, {(void**)&h->tmp_reward, N * 4}, {(void**)&h->tmp_done, N}};
   for (auto& a : allocs) {
     if (hipMalloc(a.p, a.bytes) != hipSuccess) return fail(ETG_ERR_ALLOC, "etg_create: hipMalloc failed");
@@ -996,6 +1041,7 @@ extern "C" int etg_set_params(EtgHandle* h, const float* dyn, const float* etg_w
   CHECK_HANDLE(h);
   if ((etg_w == nullptr) != (etg_b == nullptr)) return fail(ETG_ERR_BAD_ARG, "etg_set_params: pass both etg_w and etg_b or neither");
   if (dyn) h->all_cached = false;   // the settle depends on the dynamic parameters
+  hipLaunchKernelGGL(k_fin_clear, dim3((h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->D, mask);   // cached restarts: stale
   hipLaunchKernelGGL(k_set_params, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->M, h->D, dyn, etg_w,
                      etg_b, per_env, mask);
   HIP_TRY(hipGetLastError());
@@ -1009,6 +1055,7 @@ extern "C" int etg_set_heightfield(EtgHandle* h, const float* heights, void* str
   if (!h->hf && hipMalloc((void**)&h->hf, bytes) != hipSuccess) return fail(ETG_ERR_ALLOC, "etg_set_heightfield: hipMalloc failed");
   HIP_TRY(hipMemcpyAsync(h->hf, heights, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   HIP_TRY(hipMemsetAsync(h->D.cache_ok, 0, h->N, (hipStream_t)stream));   // the settle depends on the terrain
+  HIP_TRY(hipMemsetAsync(h->D.cache_off + (size_t)FIN_OK * h->N, 0, (size_t)h->N * 4, (hipStream_t)stream));
   h->all_cached = false;
   h->K.hf = h->hf;
   return ETG_OK;
@@ -1070,6 +1117,7 @@ extern "C" int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* st
   hipLaunchKernelGGL(k_cache_mark, ge, dim3(256), 0, s, h->K, h->D, mask);
   if (h->lanes == 16) {
     LAUNCH16(k_finish16, g16, s, h->K, h->D, mask, obs);
+    hipLaunchKernelGGL(k_fin_store, ge, dim3(256), 0, s, h->K, h->D, mask, (const float*)obs);   // the clean row: before the noise
   } else {
     LAUNCH4(k_finish, g4, s, h->K, h->D, mask, obs);
   }
@@ -1100,6 +1148,7 @@ extern "C" int etg_set_sensor_noise(EtgHandle* h, const float* stdev, uint64_t s
 extern "C" int etg_set_reset_offsets(EtgHandle* h, const float* xy, const uint8_t* mask, void* stream) {
   CHECK_HANDLE(h);
   hipLaunchKernelGGL(k_set_reset_offsets, dim3((h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->D, xy, mask);
+  hipLaunchKernelGGL(k_fin_clear, dim3((h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->D, mask);
   HIP_TRY(hipGetLastError());
   if (h->K.terrain != 0) h->all_cached = false;   // a heightfield settle is only valid at the offset it ran at
   return ETG_OK;

@@ -468,13 +468,15 @@ def test_flat_ground_knee_rows_match_oracle():
     env.close()
 
 
-@pytest.mark.parametrize("kw", [dict(lanes_per_robot=4), dict(task="stairstair", terrain_variants=4),
+@pytest.mark.parametrize("kw", [dict(), dict(observation_noise_stdev=[0.02, 0.3, 0.0, 0.01, 0.05]), dict(lanes_per_robot=4),
+                                dict(task="stairstair", terrain_variants=4),
                                 dict(sensor_mode={"RNN": {"time_steps": 2, "time_interval": 1, "mode": "stack"}}),
                                 dict(random_param={"random_dynamics": 1})])
 def test_auto_reset_variants_equal_manual_reset(kw):
-    """step(auto_reset) == step() followed by reset(env_ids=done) on the paths the fast kernel does not cover alone: the
-    4-lane mapping, a heightfield task, the observation history stack, and random dynamics (new parameters per reset -> a
-    simulated settle through the general etg_reset path)."""
+    """step(auto_reset) == step() followed by reset(env_ids=done): the default 16-lane kernel (restart copied from the per-robot
+    cache of reset_finish16's outputs), the same with sensor noise (the cache holds the clean row), and the paths the fast kernel
+    does not cover alone: the 4-lane mapping, a heightfield task, the observation history stack, random dynamics (new parameters
+    per reset -> a simulated settle through the general etg_reset path)."""
     _need_gpu()
     n = 32
     W, B = _etg_params(n, seed=13)
@@ -626,3 +628,47 @@ def test_friction_cone_on_an_inclined_heightfield_gpu():
             else:
                 assert np.abs(s1[:, 0] - s0[:, 0]).max() < 2e-3 and np.abs(s1[:, 7:10]).max() < 5e-3, (lanes, theta)
             env.close()
+
+
+
+def test_cached_restart_follows_parameter_changes():
+    """The in-kernel restart of step(auto_reset) copies cached reset_finish outputs; new ETG weights (set_etg without a reset),
+    new reset offsets and new dynamic parameters must invalidate them: robots that restart AFTER the change come back with the
+    reset observation of the new parameters."""
+    _need_gpu()
+    n = 64
+    W1, B1 = _etg_params(n, seed=21)
+    W2, B2 = _etg_params(n, seed=22)
+    env, ref = _make(n, auto_reset=True), _make(n)
+    env.reset(ETG_w=W1, ETG_b=B1)
+    limp = torch.zeros(n, 12, device="cuda:0"); limp[:, 1::3] = 1.5                 # everybody falls again and again
+    obs1 = ref.reset(ETG_w=W1, ETG_b=B1)[0].clone()
+    seen = 0
+    for _ in range(30):
+        obs, _, done, info = env.step(limp)
+        if done.any():
+            assert torch.equal(obs[done], obs1[done]); seen += int(done.sum())
+    assert seen > n // 2
+    env.set_etg(W2, B2)                                                              # no reset in between
+    obs2 = ref.reset(ETG_w=W2, ETG_b=B2)[0].clone()
+    assert (obs2 - obs1).abs().max().item() > 1e-3                                   # the ETG columns of the reset row differ
+    seen = 0
+    for _ in range(30):
+        obs, _, done, info = env.step(limp)
+        if done.any():
+            assert torch.equal(obs[done], obs2[done]); seen += int(done.sum())
+    assert seen > n // 2
+    # start offsets: restarts land at the new positions (flat ground shifts the cached settle)
+    xy = torch.zeros(n, 2, device="cuda:0"); xy[:, 0] = 0.05
+    env.set_reset_offsets(xy); ref.set_reset_offsets(xy)
+    obs3 = ref.reset()[0].clone()
+    st3 = ref.get_state().clone()
+    seen = 0
+    for _ in range(30):
+        obs, _, done, info = env.step(limp)
+        if done.any():
+            assert torch.equal(obs[done], obs3[done])
+            assert (env.get_state()[done][:, 0] - st3[done][:, 0]).abs().max().item() < 1e-6
+            seen += int(done.sum())
+    assert seen > n // 2
+    env.close(); ref.close()
