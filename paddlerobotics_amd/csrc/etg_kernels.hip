@@ -727,6 +727,74 @@ __global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, Po
   for (int idx = tid; idx < TM * ETG_OBS_DIM; idx += 256) obs[(size_t)tile * TM * ETG_OBS_DIM + idx] = obs_lds[idx];   // coalesced
 }
 
+// The same kernel with every step's (observation, unscaled action, reward, done) written out: [n_steps][N][...] arrays for
+// the replay memory of the ES-SAC loop (run_EStrain_episode with es_rpm, train.py:213-249).  A separate kernel, not a
+// template flag of k_rollout_policy16: that kernel sits at 512 registers and any change of its symbol shifts its allocation.
+struct RecOut { float *obs, *act, *rew; uint8_t* done; };
+template <bool FLAT, bool BF16, bool KNEE, bool PLAIN>
+__global__ void __launch_bounds__(256) k_rollout_policy16_rec(KCfg K, DevState D, PolicyW P, int n_steps, float act_scale, float* obs, RecOut R) {
+  using namespace pol;
+  constexpr int NWP = 4;
+  __shared__ __attribute__((aligned(16))) float bufA[TM * HS];
+  __shared__ __attribute__((aligned(16))) float bufB[TM * HS];
+  __shared__ float part[NWP][TM][16];
+  __shared__ float act_lds[TM][16];
+  __shared__ float obs_lds[TM * ETG_OBS_DIM];
+  __shared__ float lds_par[NWP][LDS16_FIELDS * 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tile = xcd_contiguous_block();            // 16 robots; the host guarantees N % 16 == 0
+  GpuCtx16T<FLAT, KNEE, PLAIN> c;
+  make_ctx16_at(K, D, c, lds_par[wave], 4 * tile + wave, lane);
+  State16<float> L = load_state16<float>(c, D.base, D.leg);
+  StepCtl16<float> S = load_ctl16<float>(c, K, D.ctl, D.ictl, D.legctl);
+  TickPar<float> tp = load_tick_par<float>(c);
+  if (!PLAIN && K.ext_force) tp.fext = load_fext16<float>(c, D.ctl);
+  // current observation of the tile -> LDS
+  for (int idx = tid; idx < TM * ETG_OBS_DIM; idx += 256) obs_lds[idx] = obs[(size_t)tile * TM * ETG_OBS_DIM + idx];
+  float reward, done;
+  for (int s = 0; s < n_steps; s++) {
+    __syncthreads();
+    if (K.noise_on && s > 0) {   // sensor noise on the row the previous step left in LDS (the last one: k_add_noise)
+      add_sensor_noise(K, tile * TM + (tid >> 4), K.noise_call + s - 1, tid & 15, &obs_lds[(tid >> 4) * ETG_OBS_DIM]);
+      __syncthreads();
+    }
+    for (int idx = tid; idx < TM * 64; idx += 256) {   // obs tile, zero padded to the 64-wide K of layer 1
+      const int r = idx >> 6, col = idx & 63;
+      bufA[r * HS + col] = col < P.in_dim ? obs_lds[r * ETG_OBS_DIM + P.col0 + col] : 0.0f;
+    }
+    // the observation the actor acts on at this step (noise included), rows of the tile's 16 robots: coalesced
+    for (int idx = tid; idx < TM * ETG_OBS_DIM; idx += 256) R.obs[((size_t)s * K.n_env + (size_t)tile * TM) * ETG_OBS_DIM + idx] = obs_lds[idx];
+    __syncthreads();
+    hidden_layer<BF16, 4, NWP>(bufA, P.w1, P.b1, bufB, wave, lane);
+    __syncthreads();
+    hidden_layer<BF16, HID / 16, NWP>(bufB, P.w2, P.b2, bufA, wave, lane);
+    __syncthreads();
+    output_partial<BF16, NWP>(bufA, P.w3, wave, lane, part);
+    __syncthreads();
+    {
+      const int r = tid >> 4, cidx = tid & 15;          // 256 threads = 16 rows x 16 columns
+      const float v = ((part[0][r][cidx] + part[1][r][cidx]) + (part[2][r][cidx] + part[3][r][cidx])) + (cidx < P.out_dim ? P.b3[cidx] : 0.0f);
+      const float t = tanhf(v);
+      act_lds[r][cidx] = t * act_scale;
+      if (cidx < ETG_ACT_DIM) R.act[((size_t)s * K.n_env + (size_t)tile * TM + r) * ETG_ACT_DIM + cidx] = t;   // the UNSCALED action (train.py:159)
+    }
+    __syncthreads();
+    const float action = c.sub < 3 ? act_lds[4 * wave + (lane >> 4)][3 * c.leg + c.sub] : 0.0f;
+    // the step code addresses observation rows by robot index: rows of the LDS tile start at the tile's first robot.
+    // Every step writes its observation to the tile (plain ds_write, no generic pointer); the last one is copied out below.
+    c.row_base = tile * TM;
+    control_step16_core(c, K, tp, L, S, D.ring, D.etgp, action, 0.0f, obs_lds, reward, done, (float*)nullptr);
+    if (c.r == 0) {
+      R.rew[(size_t)s * K.n_env + c.env] = reward;
+      R.done[(size_t)s * K.n_env + c.env] = done > 0.5f ? 1 : 0;
+    }
+  }
+  store_ctl16(c, K, S, D.ctl, D.ictl, D.legctl);
+  store_state16(c, D.base, D.leg, L);
+  __syncthreads();
+  for (int idx = tid; idx < TM * ETG_OBS_DIM; idx += 256) obs[(size_t)tile * TM * ETG_OBS_DIM + idx] = obs_lds[idx];   // coalesced
+}
+
 // Gaussian sensor noise on freshly written observation rows: one thread per (robot, channel).  A separate tiny
 // kernel so that the step kernels' code (and register allocation) is the same with and without noise.
 __global__ void k_add_noise(KCfg K, unsigned call, const uint8_t* mask, int invert, float* obs) {
@@ -1274,6 +1342,49 @@ extern "C" int etg_rollout_policy(EtgHandle* h, EtgPolicy* pol, int n_steps, flo
     else if (pl) LAUNCH_POLICY16(false, false, true);
     else LAUNCH_POLICY16(false, false, false);
 #undef LAUNCH_POLICY16
+    launch_obs_noise(h, m, nullptr, obs, s);   // every chunk ends in the caller's rows: the next chunk reads them
+  }
+  HIP_TRY(hipGetLastError());
+  if (ret || len) return etg_episode_stats(h, ret, len, stream);
+  return ETG_OK;
+}
+
+extern "C" int etg_rollout_policy_record(EtgHandle* h, EtgPolicy* pol, int n_steps, float act_scale, int precision, int obs_col0,
+                                         float* obs, float* rec_obs, float* rec_act, float* rec_reward, uint8_t* rec_done,
+                                         float* ret, int32_t* len, void* stream) {
+  CHECK_HANDLE(h);
+  if (!pol || n_steps <= 0 || !obs || !rec_obs || !rec_act || !rec_reward || !rec_done)
+    return fail(ETG_ERR_BAD_ARG, "etg_rollout_policy_record: bad arguments");
+  if (!h->was_reset) return fail(ETG_ERR_STATE, "etg_rollout_policy_record: call etg_reset first");
+  if (pol->device != h->device) return fail(ETG_ERR_BAD_ARG, "etg_rollout_policy_record: policy and simulator live on different devices");
+  if (obs_col0 < 0 || obs_col0 + pol->in_dim > ETG_OBS_DIM || pol->out_dim != ETG_ACT_DIM)
+    return fail(ETG_ERR_BAD_ARG, "etg_rollout_policy_record: the policy must map observation columns [col0, col0 + in_dim) to 12 actions");
+  if (h->lanes != 16 || h->N % 16 != 0 || h->K.motor_mode == 2)
+    return fail(ETG_ERR_STATE, "etg_rollout_policy_record: needs the 16-lanes-per-robot mapping, num_envs % 16 == 0, POSITION/TORQUE mode");
+  PolicyW P = {(const float4*)pol->w1, (const float4*)pol->w2, (const float4*)pol->w3, pol->b1, pol->b2, pol->b3, pol->in_dim, pol->out_dim, obs_col0};
+  constexpr int ROLLOUT_CHUNK = 50;
+  const dim3 g(h->N / 16), b(256);
+  hipStream_t s = (hipStream_t)stream;
+  const bool flat = h->K.terrain == 0;
+  const size_t N = h->N;
+  for (int done_steps = 0; done_steps < n_steps; done_steps += ROLLOUT_CHUNK) {
+    const int m = n_steps - done_steps < ROLLOUT_CHUNK ? n_steps - done_steps : ROLLOUT_CHUNK;
+    advance_obs_stream(h, m);
+    const bool kn = h->K.knee != 0, pl = plain_config(h->K);
+    const RecOut R = {rec_obs + (size_t)done_steps * N * ETG_OBS_DIM, rec_act + (size_t)done_steps * N * ETG_ACT_DIM,
+                      rec_reward + (size_t)done_steps * N, rec_done + (size_t)done_steps * N};
+#define LAUNCH_POLICY16R(F_, K_, P_)                                                                                  \
+  do {                                                                                                                \
+    if (precision == 0) hipLaunchKernelGGL((k_rollout_policy16_rec<F_, false, K_, P_>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs, R); \
+    else hipLaunchKernelGGL((k_rollout_policy16_rec<F_, true, K_, P_>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs, R);    \
+  } while (0)
+    if (flat && pl) LAUNCH_POLICY16R(true, false, true);
+    else if (flat && kn) LAUNCH_POLICY16R(true, true, false);
+    else if (flat) LAUNCH_POLICY16R(true, false, false);
+    else if (kn) LAUNCH_POLICY16R(false, true, false);
+    else if (pl) LAUNCH_POLICY16R(false, false, true);
+    else LAUNCH_POLICY16R(false, false, false);
+#undef LAUNCH_POLICY16R
     launch_obs_noise(h, m, nullptr, obs, s);   // every chunk ends in the caller's rows: the next chunk reads them
   }
   HIP_TRY(hipGetLastError());

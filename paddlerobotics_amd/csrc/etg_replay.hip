@@ -57,6 +57,68 @@ __global__ void __launch_bounds__(1024) k_replay_slots(const uint8_t* __restrict
   }
 }
 
+// The same slots for big batches (a recorded episode: n_steps x N rows at once) in three small launches, using slot[] itself
+// as scratch: (1) every 1024-row chunk leaves its number of live rows in slot[chunk * 1024]; (2) one workgroup turns those
+// into ring offsets (pos + exclusive prefix) % max_size and advances pos_count; (3) every chunk adds its in-chunk prefix.
+__global__ void __launch_bounds__(1024) k_replay_chunk_counts(const uint8_t* __restrict__ alive, int n, int* __restrict__ slot) {
+  __shared__ int wave_sum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long i = (long long)blockIdx.x * 1024 + tid;
+  const int a = (i < n) && (alive == nullptr || alive[i] != 0);
+  const unsigned long long bal = __ballot(a);
+  if (lane == 0) wave_sum[wave] = __popcll(bal);
+  __syncthreads();
+  if (tid == 0) {
+    int tot = 0;
+    for (int w = 0; w < 16; w++) tot += wave_sum[w];
+    slot[(size_t)blockIdx.x * 1024] = tot;
+  }
+}
+__global__ void __launch_bounds__(1024) k_replay_chunk_offsets(int n_chunks, long long max_size, long long* __restrict__ pos_count,
+                                                              int* __restrict__ slot) {
+  __shared__ long long part[1024];
+  __shared__ long long carry;
+  const int tid = threadIdx.x;
+  if (tid == 0) carry = 0;
+  __syncthreads();
+  const long long pos = pos_count[0];
+  for (int base = 0; base < n_chunks; base += 1024) {
+    const int b = base + tid;
+    const long long c = b < n_chunks ? slot[(size_t)b * 1024] : 0;
+    part[tid] = c;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {           // inclusive Hillis-Steele scan of the chunk counts
+      const long long v = tid >= off ? part[tid - off] : 0;
+      __syncthreads();
+      part[tid] += v;
+      __syncthreads();
+    }
+    if (b < n_chunks) slot[(size_t)b * 1024] = (int)((pos + carry + part[tid] - c) % max_size);
+    __syncthreads();
+    if (tid == 1023) carry += part[1023];
+    __syncthreads();
+  }
+  if (tid == 0) {
+    pos_count[0] = (pos + carry) % max_size;
+    pos_count[1] += carry;
+  }
+}
+__global__ void __launch_bounds__(1024) k_replay_chunk_slots(const uint8_t* __restrict__ alive, int n, long long max_size, int* __restrict__ slot) {
+  __shared__ int wave_sum[16];
+  __shared__ int chunk_off;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const long long i = (long long)blockIdx.x * 1024 + tid;
+  if (tid == 0) chunk_off = slot[(size_t)blockIdx.x * 1024];
+  const int a = (i < n) && (alive == nullptr || alive[i] != 0);
+  const unsigned long long bal = __ballot(a);
+  const int before = __popcll(bal & ((1ull << lane) - 1ull));
+  if (lane == 0) wave_sum[wave] = __popcll(bal);
+  __syncthreads();
+  int off = 0;
+  for (int w = 0; w < wave; w++) off += wave_sum[w];
+  if (i < n) slot[i] = a ? (int)(((long long)chunk_off + off + before) % max_size) : (int)max_size;
+}
+
 // mem_obs[slot[i], :] = obs[i, :], mem_act[slot[i], :] = act[i, :]; optionally act_scaled[i, :] = scale * act[i, :] (the
 // command the step receives is the stored action times act_bound, train.py:147: one launch less per control step)
 __global__ void k_replay_begin_rows(const int* __restrict__ slot, int n, const float* __restrict__ obs, int od, float* __restrict__ mem_obs,
@@ -130,7 +192,14 @@ extern "C" int etg_replay_begin(const uint8_t* alive, int n, long long max_size,
     return fail("etg_replay_begin: bad arguments (a batch must fit the memory)");
   if (!bind_device(mem_obs)) return fail("etg_replay_begin: mem_obs is not a device pointer");
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_replay_slots, dim3(1), dim3(1024), 0, s, alive, n, max_size, pos_count, slot);
+  if (n <= 8192) {
+    hipLaunchKernelGGL(k_replay_slots, dim3(1), dim3(1024), 0, s, alive, n, max_size, pos_count, slot);
+  } else {   // a recorded episode: hundreds of thousands of rows
+    const int chunks = (n + 1023) / 1024;
+    hipLaunchKernelGGL(k_replay_chunk_counts, dim3(chunks), dim3(1024), 0, s, alive, n, slot);
+    hipLaunchKernelGGL(k_replay_chunk_offsets, dim3(1), dim3(1024), 0, s, chunks, max_size, pos_count, slot);
+    hipLaunchKernelGGL(k_replay_chunk_slots, dim3(chunks), dim3(1024), 0, s, alive, n, max_size, slot);
+  }
   const long long tot = (long long)n * (obs_dim + act_dim);
   hipLaunchKernelGGL(k_replay_begin_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, slot, n, obs, obs_dim, mem_obs, act, act_dim,
                      mem_act, act_scale, act_scaled);

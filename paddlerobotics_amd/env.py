@@ -535,6 +535,30 @@ class BatchedQuadrupedEnv:
         self._last_view = self._obs_view()
         return ret, ln
 
+    def rollout_policy_record(self, policy, n_steps, act_scale=0.3, precision=0):
+        """rollout_policy that also records the episode (etg_rollout_policy_record): returns (ret [N], len [N], rec) with
+        rec = dict(obs [T,N,49] the rows the actor acted on, action [T,N,12] unscaled, reward [T,N], done [T,N] bool,
+        final_obs [N,49]).  The data half of run_EStrain_episode with es_rpm (train.py:213-249) at the fused kernel's speed;
+        replay.store_recorded() moves the rows of live robots into a DeviceReplayMemory.  Needs the configuration the
+        fused kernel needs (16-lane mapping, num_envs % 16 == 0, the full 49-float observation, POSITION / TORQUE mode)."""
+        if not (self.lanes_per_robot == 16 and self.num_envs % 16 == 0 and self.motor_mode != 2 and self._hist_T == 0
+                and not self._rand_force and self._cols == list(range(A.OBS_DIM)) and self._xcol_idx is None
+                and policy.obs_dim == A.OBS_DIM and policy.action_dim == A.NUM_MOTORS):
+            raise ValueError("rollout_policy_record needs the 16-lane mapping, num_envs % 16 == 0, the plain 49-float observation "
+                             "and a 49 -> 12 actor; use replay.collect_transitions() for the other configurations")
+        T, N = int(n_steps), self.num_envs
+        rec = {"obs": torch.empty(T, N, A.OBS_DIM, device=self.device), "action": torch.empty(T, N, A.NUM_MOTORS, device=self.device),
+               "reward": torch.empty(T, N, device=self.device), "done": torch.empty(T, N, dtype=torch.uint8, device=self.device)}
+        ret = torch.empty(N, device=self.device)
+        ln = torch.empty(N, dtype=torch.int32, device=self.device)
+        _lib.check(self._lib.etg_rollout_policy_record(self._h, policy._h, T, C.c_float(act_scale), int(precision), 0, _ptr(self.obs),
+                                                       _ptr(rec["obs"]), _ptr(rec["action"]), _ptr(rec["reward"]), _ptr(rec["done"]),
+                                                       _ptr(ret), _ptr(ln), self._stream()))
+        self._last_view = self._obs_view()
+        rec["done"] = rec["done"].view(torch.bool)
+        rec["final_obs"] = self.obs.clone()
+        return ret, ln, rec
+
     def episode_stats(self):
         """(return[N], length[N]) accumulated on device since each robot's last reset, frozen at its
         first `done` (what run_episode / run_EStrain_episode return per candidate)."""

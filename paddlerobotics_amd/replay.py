@@ -301,3 +301,29 @@ def collect_bc_pairs(env, rpm, max_step, student=None, action_bound=0.3, sensor_
         obs, _, done, _ = env.step(action * action_bound, donef=(steps > max_step), want_info=False)
         alive = alive & ~done.view(-1).to(torch.bool)
     return env.episode_stats()
+
+
+def store_recorded(rpm, rec):
+    """Move a recorded episode (env.rollout_policy_record) into the replay memory: step-major, robot-minor, only the steps up
+    to and including each robot's first `done` (what collect_transitions stores step by step), terminal = 1 - done.
+    Returns the number of rows offered (T * N); the memory must hold at least that many."""
+    obs, act, rew, done = rec["obs"], rec["action"], rec["reward"], rec["done"]
+    T, N = done.shape
+    dn = done.to(torch.int32)
+    alive = (torch.cumsum(dn, dim=0) - dn) == 0                       # no done BEFORE this step
+    nxt = torch.cat([obs[1:], rec["final_obs"][None]], dim=0)
+    rpm.append_batch(obs.reshape(T * N, -1), act.reshape(T * N, -1), rew.reshape(-1), nxt.reshape(T * N, -1),
+                     1.0 - done.reshape(-1).to(torch.float32), mask=alive.reshape(-1))
+    return T * N
+
+
+def collect_recorded(env, rpm, max_step, policy, action_bound=0.3, ETG_w=None, ETG_b=None, x_noise=0, precision=0):
+    """run_EStrain_episode with es_rpm (train.py:213-249) for all robots through the FUSED closed-loop kernel: reset, one
+    recorded rollout of max_step + 1 control steps (deterministic actor, as agent.predict there), rows into `rpm`.  The forced
+    `done` of the last step (donef = steps > max_step) is applied to the recorded flags.  Returns (ret [N], len [N])."""
+    env.reset(ETG_w=ETG_w, ETG_b=ETG_b, x_noise=x_noise)
+    ret, ln, rec = env.rollout_policy_record(policy, max_step + 1, action_bound, precision)
+    rec["done"] = rec["done"].clone()
+    rec["done"][-1] = True                                            # donef of the last step ends every running episode
+    store_recorded(rpm, rec)
+    return ret, ln

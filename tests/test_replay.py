@@ -229,7 +229,7 @@ def test_fused_replay_kernels_match_the_torch_definition():
     from tests.test_gpu_parity import _need_gpu
     _need_gpu()
     g = torch.Generator(device="cuda:0"); g.manual_seed(3)
-    for n, cap in ((4096, 10000), (1000, 2999), (1, 3)):
+    for n, cap in ((4096, 10000), (1000, 2999), (1, 3), (20000, 50000), (8193, 8200)):   # > 8192 rows: the three-launch slot computation
         a, b = DeviceReplayMemory(cap, 49, 12), DeviceReplayMemory(cap, 49, 12, fused=False)
         assert a.fused and not b.fused
         for step in range(7):
@@ -298,3 +298,51 @@ def test_collect_bc_pairs_on_the_device():
     with pytest.raises(ValueError):
         collect_bc_pairs(env, DeviceReplayMemory(100, 49, 12), max_step, mode="uniform")
     env.close()
+
+
+def test_store_recorded_masks_rows_after_the_first_done():
+    """replay.store_recorded on host tensors: [T, N] recordings -> the rows up to each robot's first done, step-major,
+    next_obs = the following step's observation (the final one for the last step), terminal = 1 - done."""
+    from paddlerobotics_amd.replay import store_recorded
+    T, N, od, ad = 5, 3, 4, 2
+    obs = torch.arange(T * N * od, dtype=torch.float32).view(T, N, od)
+    rec = {"obs": obs, "action": obs[..., :ad] * 0.1, "reward": obs[..., 0] * 2, "final_obs": torch.full((N, od), -1.0),
+           "done": torch.tensor([[0, 0, 0], [0, 1, 0], [0, 0, 0], [1, 1, 0], [0, 0, 1]], dtype=torch.bool)}
+    m = DeviceReplayMemory(100, od, ad, device="cpu")
+    assert store_recorded(m, rec) == T * N
+    # robot 0 lives steps 0..3, robot 1 steps 0..1, robot 2 steps 0..4
+    want = [(0, 0), (0, 1), (0, 2), (1, 0), (1, 1), (1, 2), (2, 0), (2, 2), (3, 0), (3, 2), (4, 2)]
+    assert m.size() == len(want)
+    for k, (t, i) in enumerate(want):
+        assert torch.equal(m.obs[k], obs[t, i]) and torch.equal(m.action[k], obs[t, i, :ad] * 0.1) and m.reward[k] == obs[t, i, 0] * 2
+        assert torch.equal(m.next_obs[k], obs[t + 1, i] if t + 1 < T else rec["final_obs"][i])
+        assert m.terminal[k] == (0.0 if rec["done"][t, i] else 1.0)
+
+
+@pytest.mark.gpu
+def test_recorded_fused_rollout_fills_the_memory_like_the_stepping_loop():
+    """GPU: etg_rollout_policy_record (the fused closed-loop kernel writing every step's observation / action / reward / done)
+    + store_recorded == collect_transitions(mode="predict") stepping the same robots: same number of rows in the same order,
+    observations / actions / rewards equal to the two kernels' rounding, identical terminal flags, identical episode lengths."""
+    from tests.test_gpu_parity import _need_gpu, _make
+    from tests.test_gpu_parity2 import _policy
+    from paddlerobotics_amd.replay import collect_recorded
+    _need_gpu()
+    n, max_step, bound = 256, 39, 0.3
+    pol, _ = _policy()
+    a, b = _make(n, seed=5), _make(n, seed=5)
+    ra, rb = DeviceReplayMemory(n * (max_step + 1), 49, 12), DeviceReplayMemory(n * (max_step + 1), 49, 12)
+    ret_a, ln_a, _ = collect_transitions(a, ra, max_step, policy=pol, action_bound=bound)
+    ret_b, ln_b = collect_recorded(b, rb, max_step, pol, action_bound=bound)
+    assert torch.equal(ln_a, ln_b) and ra.size() == rb.size() == int(ln_a.sum().item())
+    k = ra.size()
+    assert torch.equal(ra.terminal[:k], rb.terminal[:k])
+    close = lambda x, y, tol: bool(((x - y).abs() <= tol * (1 + y.abs())).all())
+    assert close(ra.obs[:k], rb.obs[:k], 2e-3) and close(ra.next_obs[:k], rb.next_obs[:k], 2e-3)
+    assert close(ra.action[:k], rb.action[:k], 1e-4) and close(ra.reward[:k], rb.reward[:k], 1e-3)
+    assert close(ret_a, ret_b, 2e-3)
+    # the first step's rows are the reset observation and the actor's answer to it, bit for bit
+    assert torch.equal(rb.obs[:n], ra.obs[:n]) and (rb.action[:n] - pol.predict(rb.obs[:n].contiguous())).abs().max().item() < 1e-6
+    with pytest.raises(ValueError):
+        _make(32, lanes_per_robot=4).rollout_policy_record(pol, 5)
+    a.close(); b.close()

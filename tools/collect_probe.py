@@ -5,7 +5,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from paddlerobotics_amd.env import make_env
 from paddlerobotics_amd.policy import MfmaPolicy
-from paddlerobotics_amd.replay import DeviceReplayMemory, collect_transitions
+from paddlerobotics_amd.replay import DeviceReplayMemory, collect_transitions, collect_recorded
 
 N, T = 4096, 400
 env = make_env("Quadrupedal", num_envs=N, device="cuda:0")
@@ -31,5 +31,9 @@ def bare():
 for mode in ("predict", "sample"):
     dt = timed(lambda: collect_transitions(env, rpm, T, policy=pol, mode=mode))
     print("collect_transitions(%s): %.1f us per control step, %.1f M env-steps/s" % (mode, dt / (T + 1) * 1e6, N * (T + 1) / dt / 1e6))
+dt = timed(lambda: collect_recorded(env, rpm, T, pol))
+print("collect_recorded (fused kernel): %.1f us per control step, %.1f M env-steps/s" % (dt / (T + 1) * 1e6, N * (T + 1) / dt / 1e6))
+dt = timed(lambda: (env.reset(), env.rollout_policy(pol, T + 1, 0.3)))
+print("fused rollout, nothing stored:   %.1f us per control step, %.1f M env-steps/s" % (dt / (T + 1) * 1e6, N * (T + 1) / dt / 1e6))
 dt = timed(bare)
 print("predict + step only:          %.1f us per control step, %.1f M env-steps/s" % (dt / (T + 1) * 1e6, N * (T + 1) / dt / 1e6))

@@ -1,0 +1,20 @@
+import os, sys, time, torch
+sys.path.insert(0, "/root/repo")
+from paddlerobotics_amd.env import make_env
+from paddlerobotics_amd.policy import MfmaPolicy
+from paddlerobotics_amd.replay import DeviceReplayMemory, store_recorded
+N, T = 4096, 401
+env = make_env("Quadrupedal", num_envs=N, device="cuda:0")
+pol = MfmaPolicy(49, 12); pol.load_state_dict(MfmaPolicy.init_like_reference(49, 12, seed=0))
+rpm = DeviceReplayMemory(N * T, 49, 12)
+def timed(fn, reps=3):
+    fn(); torch.cuda.synchronize(); ts=[]
+    for _ in range(reps):
+        t0=time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter()-t0)
+    return sorted(ts)[1]
+env.reset()
+print("rollout_policy        %.2f us/step" % (timed(lambda: env.rollout_policy(pol, T, 0.3)) / T * 1e6))
+print("rollout_policy_record %.2f us/step" % (timed(lambda: env.rollout_policy_record(pol, T, 0.3)) / T * 1e6))
+ret, ln, rec = env.rollout_policy_record(pol, T, 0.3)
+print("store_recorded        %.2f ms" % (timed(lambda: store_recorded(rpm, rec)) * 1e3))
+print("reset                 %.2f ms" % (timed(lambda: env.reset()) * 1e3))
