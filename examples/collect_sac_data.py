@@ -16,7 +16,7 @@ import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from paddlerobotics_amd.env import make_env  # noqa: E402
 from paddlerobotics_amd.policy import MfmaPolicy  # noqa: E402
-from paddlerobotics_amd.replay import DeviceReplayMemory, collect_transitions  # noqa: E402
+from paddlerobotics_amd.replay import DeviceReplayMemory, collect_recorded, collect_transitions  # noqa: E402
 
 
 def main():
@@ -45,6 +45,17 @@ def main():
         batch_obs, batch_action, batch_reward, batch_next_obs, batch_terminal = rpm.sample_batch(args.batch_size)
         # critic_loss, actor_loss = agent.learn(batch_obs, batch_action, batch_reward, batch_next_obs, batch_terminal)   # alg/sac.py
         assert batch_obs.shape == (args.batch_size, obs_dim) and batch_terminal.min().item() >= 0.0
+    # the ES phase (run_EStrain_episode with --es_rpm, train.py:213-249: deterministic actor, every candidate's episode kept for
+    # the learner) goes through the fused closed-loop kernel, which records the steps itself
+    flat = make_env("Quadrupedal", num_envs=args.num_envs, device=args.device)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ret, length = collect_recorded(flat, rpm, args.max_step, actor, action_bound=0.3)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print("recorded ES episode: %d transitions in %.1f ms (%.1f M/s), memory holds %d" % (int(length.sum().item()), dt * 1e3,
+                                                                                       int(length.sum().item()) / dt / 1e6, rpm.size()))
+    flat.close()
     env.close()
 
 
