@@ -68,13 +68,23 @@ def es_generation(solver, evaluate, dist=None, rank=0, world=1):
     return fitness
 
 
-def make_etg_evaluator(env, etg_layer, ETG_T, prior_points, w0, b0, max_step=400, policy=None, action_bound=0.3):
-    """Fitness of ETG control-point offsets (12 numbers per candidate), as in pretrain.py:226-233."""
+def make_etg_evaluator(env, etg_layer, ETG_T, prior_points, w0, b0, max_step=400, policy=None, action_bound=0.3, rpm=None):
+    """Fitness of ETG control-point offsets (12 numbers per candidate), as in pretrain.py:226-233.  With an actor and a
+    replay memory `rpm` the candidates' episodes are kept for the SAC learner, as run_EStrain_episode does with --es_rpm
+    (train.py:240-241, 404-409): recorded by the fused closed-loop kernel where it applies, by the stepping loop otherwise."""
     prior = torch.as_tensor(np.asarray(prior_points), dtype=torch.float64, device=env.device)
 
     def evaluate(solutions):
         pts = prior[None] + solutions.to(env.device).reshape(-1, 6, 2)
         w, b = opt_with_points_batched(etg_layer, ETG_T, pts, b0, w0, device=env.device)
+        if rpm is not None and policy is not None:
+            from . import replay
+            try:
+                ret, _ = replay.collect_recorded(env, rpm, max_step, policy, action_bound, ETG_w=w.float(), ETG_b=b.float())
+            except ValueError:          # a configuration the fused kernel does not cover
+                ret, _, _ = replay.collect_transitions(env, rpm, max_step, policy=policy, action_bound=action_bound,
+                                                       ETG_w=w.float(), ETG_b=b.float())
+            return ret
         ret, _ = run_episodes(env, max_step, ETG_w=w.float(), ETG_b=b.float(), policy=policy,
                               action_bound=action_bound)
         return ret

@@ -346,3 +346,29 @@ def test_recorded_fused_rollout_fills_the_memory_like_the_stepping_loop():
     with pytest.raises(ValueError):
         _make(32, lanes_per_robot=4).rollout_policy_record(pol, 5)
     a.close(); b.close()
+
+
+@pytest.mark.gpu
+def test_es_generation_with_an_actor_keeps_the_candidates_episodes():
+    """One ES generation over ETG control points with a fixed actor and a replay memory (train.py:398-418 with --es_rpm):
+    fitness = the fused closed-loop returns, and every live step of every candidate lands in the memory."""
+    from tests.test_gpu_parity import _need_gpu, _make
+    from tests.test_gpu_parity2 import _policy
+    from paddlerobotics_amd import rollout as R
+    from paddlerobotics_amd.es import SimpleGA
+    from paddlerobotics_amd.etg import ETG_layer, Opt_with_points
+    _need_gpu()
+    n, max_step = 256, 49
+    pol, _ = _policy()
+    layer = ETG_layer(0.5, 0.026, 20, 0.04, np.array([-np.pi / 2, 0]), 0.2, 0.5)
+    w0, b0, prior = Opt_with_points(layer, ETG_T=0.5, Footheight=0.1, Steplength=0.05)
+    solver = SimpleGA(12, sigma_init=0.02, popsize=n, param=np.zeros(12), device="cuda:0")
+    env, twin = _make(n), _make(n)
+    rpm = DeviceReplayMemory(n * (max_step + 1), 49, 12)
+    fit = R.es_generation(solver, R.make_etg_evaluator(env, layer, 0.5, prior, w0, b0, max_step=max_step, policy=pol, rpm=rpm))
+    solver2 = SimpleGA(12, sigma_init=0.02, popsize=n, param=np.zeros(12), device="cuda:0")
+    fit2 = R.es_generation(solver2, R.make_etg_evaluator(twin, layer, 0.5, prior, w0, b0, max_step=max_step, policy=pol))
+    assert torch.allclose(fit, fit2, rtol=1e-4, atol=1e-3)                      # same candidates, same fused kernel arithmetic
+    _, ln = env.episode_stats()
+    assert rpm.size() == int(ln.sum().item()) and int((rpm.terminal[:rpm.size()] == 0).sum().item()) == n
+    env.close(); twin.close()
