@@ -312,8 +312,15 @@ def store_recorded(rpm, rec):
     dn = done.to(torch.int32)
     alive = (torch.cumsum(dn, dim=0) - dn) == 0                       # no done BEFORE this step
     nxt = torch.cat([obs[1:], rec["final_obs"][None]], dim=0)
-    rpm.append_batch(obs.reshape(T * N, -1), act.reshape(T * N, -1), rew.reshape(-1), nxt.reshape(T * N, -1),
-                     1.0 - done.reshape(-1).to(torch.float32), mask=alive.reshape(-1))
+    term = 1.0 - done.to(torch.float32)
+    if N > rpm.max_size:
+        raise ValueError("a step of %d robots does not fit a memory of %d" % (N, rpm.max_size))
+    per = max(1, rpm.max_size // N)                                   # steps per append: a batch must fit the ring
+    for t0 in range(0, T, per):
+        t1 = min(T, t0 + per)
+        k = (t1 - t0) * N
+        rpm.append_batch(obs[t0:t1].reshape(k, -1), act[t0:t1].reshape(k, -1), rew[t0:t1].reshape(-1), nxt[t0:t1].reshape(k, -1),
+                         term[t0:t1].reshape(-1), mask=alive[t0:t1].reshape(-1))
     return T * N
 
 

@@ -317,6 +317,13 @@ def test_store_recorded_masks_rows_after_the_first_done():
         assert torch.equal(m.obs[k], obs[t, i]) and torch.equal(m.action[k], obs[t, i, :ad] * 0.1) and m.reward[k] == obs[t, i, 0] * 2
         assert torch.equal(m.next_obs[k], obs[t + 1, i] if t + 1 < T else rec["final_obs"][i])
         assert m.terminal[k] == (0.0 if rec["done"][t, i] else 1.0)
+    # a memory smaller than the episode: appended in slices of whole steps, the ring keeps the newest rows
+    small = DeviceReplayMemory(7, od, ad, device="cpu")
+    store_recorded(small, rec)
+    assert small.size() == 7 and int(small._count) == len(want)
+    newest = want[-7:]
+    stored = {tuple(small.obs[k].tolist()) for k in range(7)}
+    assert stored == {tuple(obs[t, i].tolist()) for t, i in newest}
 
 
 @pytest.mark.gpu
