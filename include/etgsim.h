@@ -313,11 +313,11 @@ int etg_fit_etg(const double* points, int nb, const double* feats, const double*
 /* The reference's loops append every transition to a replay memory: rpm.append(obs, action, reward, next_obs, terminal),
  * terminal = 1 - done (train.py:148-149,159,240-241), and sum the reward terms of `info` (train.py:150-156).  Batched
  * and masked: only robots whose episode is still running store a row.  The memory is five caller-owned device arrays of
- * max_size + 1 rows (row max_size is scratch): mem_obs / mem_next_obs [max_size + 1, obs_dim], mem_act [.., act_dim],
- * mem_reward / mem_terminal [max_size + 1]; pos_count [2] (device, int64) = next slot to write, transitions ever stored.
+ * max_size rows: mem_obs / mem_next_obs [max_size, obs_dim], mem_act [max_size, act_dim], mem_reward / mem_terminal
+ * [max_size]; pos_count [2] (device, int64) = next slot to write, transitions ever stored.
  *
- * etg_replay_begin (BEFORE the step overwrites the observation buffer): slot[i] = ring slot of robot i's row (alive [n]
- * bytes, NULL = all), pos_count advanced, obs and act rows stored.  n must not exceed max_size.  act_scaled [n, act_dim]
+ * etg_replay_begin (BEFORE the step overwrites the observation buffer): slot[i] = ring slot of robot i's row, -1 for a
+ * robot that is not alive (alive [n] bytes, NULL = all): its row is not stored; pos_count advanced, obs and act rows stored.  n must not exceed max_size.  act_scaled [n, act_dim]
  * (may be NULL) receives act_scale * act: the command of the step (action * act_bound, train.py:147).               */
 int etg_replay_begin(const uint8_t* alive, int n, long long max_size, long long* pos_count, int32_t* slot,
                      const float* obs, int obs_dim, const float* act, int act_dim, float* mem_obs, float* mem_act,

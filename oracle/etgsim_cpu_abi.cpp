@@ -201,11 +201,13 @@ int etg_replay_begin(const uint8_t* alive, int n, long long max_size, long long*
   long long pos = pos_count[0];
   for (int i = 0; i < n; i++) {
     const bool a = !alive || alive[i];
-    const long long s = a ? pos : max_size;      // finished robots write the scratch row
-    slot[i] = (int32_t)s;
-    std::memcpy(mem_obs + (size_t)s * obs_dim, obs + (size_t)i * obs_dim, sizeof(float) * obs_dim);
-    std::memcpy(mem_act + (size_t)s * act_dim, act + (size_t)i * act_dim, sizeof(float) * act_dim);
-    if (a) { pos = (pos + 1) % max_size; pos_count[1]++; }
+    slot[i] = a ? (int32_t)pos : -1;             // the row of a finished robot is not stored
+    if (a) {
+      std::memcpy(mem_obs + (size_t)pos * obs_dim, obs + (size_t)i * obs_dim, sizeof(float) * obs_dim);
+      std::memcpy(mem_act + (size_t)pos * act_dim, act + (size_t)i * act_dim, sizeof(float) * act_dim);
+      pos = (pos + 1) % max_size;
+      pos_count[1]++;
+    }
     if (act_scaled)
       for (int k = 0; k < act_dim; k++) act_scaled[(size_t)i * act_dim + k] = act_scale * act[(size_t)i * act_dim + k];
   }
@@ -219,6 +221,7 @@ int etg_replay_end(const int32_t* slot, int n, const float* reward, const uint8_
     return cfail(ETG_ERR_BAD_ARG, "etg_replay_end: bad arguments");
   if (info && (info_dim <= 0 || n_sum < 0 || n_sum > info_dim || velx_col >= info_dim)) return cfail(ETG_ERR_BAD_ARG, "etg_replay_end: bad info layout");
   for (int i = 0; i < n; i++) {
+    if (slot[i] < 0) continue;                   // a finished robot: nothing stored, nothing summed, alive stays 0
     const size_t s = (size_t)slot[i];
     mem_reward[s] = reward[i];
     mem_terminal[s] = done[i] ? 0.0f : 1.0f;     // the stored flag is the bootstrap mask (train.py:148-149)

@@ -7,7 +7,7 @@
 // simulator step itself (host-bound); here it is three launches per control step:
 //
 //   etg_replay_begin   ring slots of the robots whose episode is still running (prefix sum over the alive bytes, one
-//                      workgroup; rows of finished robots go to the scratch slot `max_size`), then obs / action rows
+//                      workgroup; rows of finished robots get slot -1 and are not stored), then obs / action rows
 //                      scattered to their slots -- BEFORE the step overwrites the observation buffer
 //   etg_replay_end     reward, next_obs, terminal = 1 - done scattered to the same slots; the alive-masked sums of the
 //                      info columns and the success counter (info["velx"] >= 0.3) accumulated; alive &= !done
@@ -24,7 +24,7 @@ extern "C" void etg_set_last_error_(const char* msg);
 
 namespace {
 
-// slot[i] = (pos + #alive before i) % max_size for alive robots, max_size (scratch row) otherwise; pos_count += #alive
+// slot[i] = (pos + #alive before i) % max_size for alive robots, -1 (row not stored) otherwise; pos_count += #alive
 __global__ void __launch_bounds__(1024) k_replay_slots(const uint8_t* __restrict__ alive, int n, long long max_size,
                                                         long long* __restrict__ pos_count, int* __restrict__ slot) {
   __shared__ int wave_sum[16];
@@ -42,7 +42,7 @@ __global__ void __launch_bounds__(1024) k_replay_slots(const uint8_t* __restrict
     __syncthreads();
     int off = carry;
     for (int w = 0; w < wave; w++) off += wave_sum[w];
-    if (i < n) slot[i] = a ? (int)((pos + off + before) % max_size) : (int)max_size;
+    if (i < n) slot[i] = a ? (int)((pos + off + before) % max_size) : -1;
     __syncthreads();
     if (tid == 0) {
       int tot = 0;
@@ -116,38 +116,61 @@ __global__ void __launch_bounds__(1024) k_replay_chunk_slots(const uint8_t* __re
   __syncthreads();
   int off = 0;
   for (int w = 0; w < wave; w++) off += wave_sum[w];
-  if (i < n) slot[i] = a ? (int)(((long long)chunk_off + off + before) % max_size) : (int)max_size;
+  if (i < n) slot[i] = a ? (int)(((long long)chunk_off + off + before) % max_size) : -1;
 }
 
 // mem_obs[slot[i], :] = obs[i, :], mem_act[slot[i], :] = act[i, :]; optionally act_scaled[i, :] = scale * act[i, :] (the
 // command the step receives is the stored action times act_bound, train.py:147: one launch less per control step)
+// Row copies are HBM-bound byte shuffling: one wave per row (lane = column, od + ad <= 64 for the 49 + 12 floats of a
+// transition), several rows per wave, no integer division on the way.  ROWWISE = false: the general element-per-thread form.
+template <bool ROWWISE>
 __global__ void k_replay_begin_rows(const int* __restrict__ slot, int n, const float* __restrict__ obs, int od, float* __restrict__ mem_obs,
                                     const float* __restrict__ act, int ad, float* __restrict__ mem_act, float scale,
                                     float* __restrict__ act_scaled) {
   const int dsum = od + ad;
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)n * dsum) return;
-  const int i = (int)(idx / dsum), c = (int)(idx - (long long)i * dsum);
-  const size_t s = (size_t)slot[i];
+  int i, c;
+  if (ROWWISE) {
+    i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    c = threadIdx.x & 63;
+    if (i >= n || c >= dsum) return;
+  } else {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n * dsum) return;
+    i = (int)(idx / dsum); c = (int)(idx - (long long)i * dsum);
+  }
+  const int sl = slot[i];
+  const size_t s = (size_t)sl;
+  // rows of finished robots are not stored (hundreds of thousands of writes to the one scratch row would serialise in a
+  // recorded episode); the scaled action is still produced for them: the step needs a command for every robot
   if (c < od) {
-    mem_obs[s * od + c] = obs[(size_t)i * od + c];
+    if (sl >= 0) mem_obs[s * od + c] = obs[(size_t)i * od + c];
   } else {
     const float a = act[(size_t)i * ad + (c - od)];
-    mem_act[s * ad + (c - od)] = a;
+    if (sl >= 0) mem_act[s * ad + (c - od)] = a;
     if (act_scaled) act_scaled[(size_t)i * ad + (c - od)] = scale * a;
   }
 }
 
 // mem_next_obs[slot[i], :] = next_obs[i, :]; the row's first thread also stores reward / terminal, adds the info terms and
 // updates the alive byte
+template <bool ROWWISE>
 __global__ void k_replay_end_rows(const int* __restrict__ slot, int n, const float* __restrict__ next_obs, int od,
                                   float* __restrict__ mem_next_obs, const float* __restrict__ reward, const uint8_t* __restrict__ done,
                                   float* __restrict__ mem_reward, float* __restrict__ mem_terminal, const float* __restrict__ info,
                                   int info_dim, int n_sum, int velx_col, float* __restrict__ info_sum, uint8_t* __restrict__ alive) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (long long)n * od) return;
-  const int i = (int)(idx / od), c = (int)(idx - (long long)i * od);
-  const size_t s = (size_t)slot[i];
+  int i, c;
+  if (ROWWISE) {
+    i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    c = threadIdx.x & 63;
+    if (i >= n || c >= od) return;
+  } else {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)n * od) return;
+    i = (int)(idx / od); c = (int)(idx - (long long)i * od);
+  }
+  const int sl = slot[i];
+  if (sl < 0) return;                    // a finished robot: nothing to store, nothing to sum, alive stays 0
+  const size_t s = (size_t)sl;
   mem_next_obs[s * od + c] = next_obs[(size_t)i * od + c];
   if (c != 0) return;
   const int d = done[i] != 0;
@@ -200,9 +223,14 @@ extern "C" int etg_replay_begin(const uint8_t* alive, int n, long long max_size,
     hipLaunchKernelGGL(k_replay_chunk_offsets, dim3(1), dim3(1024), 0, s, chunks, max_size, pos_count, slot);
     hipLaunchKernelGGL(k_replay_chunk_slots, dim3(chunks), dim3(1024), 0, s, alive, n, max_size, slot);
   }
-  const long long tot = (long long)n * (obs_dim + act_dim);
-  hipLaunchKernelGGL(k_replay_begin_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, slot, n, obs, obs_dim, mem_obs, act, act_dim,
-                     mem_act, act_scale, act_scaled);
+  if (obs_dim + act_dim <= 64) {
+    hipLaunchKernelGGL(k_replay_begin_rows<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, slot, n, obs, obs_dim, mem_obs, act, act_dim,
+                       mem_act, act_scale, act_scaled);
+  } else {
+    const long long tot = (long long)n * (obs_dim + act_dim);
+    hipLaunchKernelGGL(k_replay_begin_rows<false>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, slot, n, obs, obs_dim, mem_obs, act,
+                       act_dim, mem_act, act_scale, act_scaled);
+  }
   return hip_fail("etg_replay_begin");
 }
 
@@ -214,8 +242,13 @@ extern "C" int etg_replay_end(const int32_t* slot, int n, const float* reward, c
   if (info && (info_dim <= 0 || n_sum < 0 || n_sum > info_dim || velx_col >= info_dim)) return fail("etg_replay_end: bad info layout");
   if (!bind_device(mem_next_obs)) return fail("etg_replay_end: mem_next_obs is not a device pointer");
   hipStream_t s = (hipStream_t)stream;
-  const long long tot = (long long)n * obs_dim;
-  hipLaunchKernelGGL(k_replay_end_rows, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, slot, n, next_obs, obs_dim, mem_next_obs, reward,
-                     done, mem_reward, mem_terminal, info, info_dim, n_sum, velx_col, info_sum, alive);
+  if (obs_dim <= 64) {
+    hipLaunchKernelGGL(k_replay_end_rows<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, slot, n, next_obs, obs_dim, mem_next_obs, reward,
+                       done, mem_reward, mem_terminal, info, info_dim, n_sum, velx_col, info_sum, alive);
+  } else {
+    const long long tot = (long long)n * obs_dim;
+    hipLaunchKernelGGL(k_replay_end_rows<false>, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, s, slot, n, next_obs, obs_dim, mem_next_obs,
+                       reward, done, mem_reward, mem_terminal, info, info_dim, n_sum, velx_col, info_sum, alive);
+  }
   return hip_fail("etg_replay_end");
 }
