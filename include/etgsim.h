@@ -294,10 +294,12 @@ int etg_rollout_policy(EtgHandle* h, EtgPolicy* policy, int n_steps, float act_s
  * es_rpm, train.py:213-249): per control step s and robot i, rec_obs [n_steps,N,49] = the observation the actor acted on,
  * rec_act [n_steps,N,12] = tanh(mean) (unscaled, as the reference stores it), rec_reward [n_steps,N], rec_done [n_steps,N]
  * (bytes).  next_obs of step s is rec_obs of step s + 1, of the last step the final obs.  Robots keep stepping after their
- * episode ended: the caller masks rows after a robot's first done.                                                    */
+ * episode ended: the caller masks rows after a robot's first done.  noise [n_steps,N,12] (may be NULL): the caller's
+ * N(0,1) draws for the STOCHASTIC actor of run_train_episode (agent.sample, train.py:143-144; alg/sac.py:65-76): the
+ * action becomes tanh(mean + exp(clamp(log_std, -20, 2)) * noise) (needs etg_policy_load_std).                        */
 int etg_rollout_policy_record(EtgHandle* h, EtgPolicy* policy, int n_steps, float act_scale, int precision, int obs_col0,
-                              float* obs, float* rec_obs, float* rec_act, float* rec_reward, uint8_t* rec_done,
-                              float* ret, int32_t* len, void* stream);
+                              float* obs, const float* noise, float* rec_obs, float* rec_act, float* rec_reward,
+                              uint8_t* rec_done, float* ret, int32_t* len, void* stream);
 
 /* ---- ETG parameterisation (the step right before reset) ----
  * Batched Opt_with_points / LS_sol (train.py:59-110): for every candidate fit the

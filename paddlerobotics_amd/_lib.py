@@ -68,7 +68,7 @@ def load():
     lib.etg_policy_sample.argtypes = [vp, vp, i32, vp, C.c_float, i32, vp, vp, vp]
     lib.etg_policy_destroy.argtypes = [vp]
     lib.etg_rollout_policy.argtypes = [vp, vp, i32, C.c_float, i32, i32, vp, vp, vp, vp]
-    lib.etg_rollout_policy_record.argtypes = [vp, vp, i32, C.c_float, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.etg_rollout_policy_record.argtypes = [vp, vp, i32, C.c_float, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.etg_policy_destroy.restype = None
     dbl = C.c_double
     lib.etg_fit_etg.argtypes = [vp, i32, vp, vp, dbl, dbl, dbl, dbl, dbl, i32, vp, vp, vp]

@@ -730,7 +730,9 @@ __global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, Po
 // The same kernel with every step's (observation, unscaled action, reward, done) written out: [n_steps][N][...] arrays for
 // the replay memory of the ES-SAC loop (run_EStrain_episode with es_rpm, train.py:213-249).  A separate kernel, not a
 // template flag of k_rollout_policy16: that kernel sits at 512 registers and any change of its symbol shifts its allocation.
-struct RecOut { float *obs, *act, *rew; uint8_t* done; };
+// noise != NULL: the STOCHASTIC actor of SAC.sample (alg/sac.py:65-76) on the caller's N(0,1) draws [n_steps][N][12]:
+// x = mean + exp(clamp(log_std, -20, 2)) * noise, action = tanh(x); w3s / b3s = the packed log-std head (etg_policy_load_std)
+struct RecOut { float *obs, *act, *rew; uint8_t* done; const float* noise; const float4* w3s; const float* b3s; };
 template <bool FLAT, bool BF16, bool KNEE, bool PLAIN>
 __global__ void __launch_bounds__(256) k_rollout_policy16_rec(KCfg K, DevState D, PolicyW P, int n_steps, float act_scale, float* obs, RecOut R) {
   using namespace pol;
@@ -738,6 +740,7 @@ __global__ void __launch_bounds__(256) k_rollout_policy16_rec(KCfg K, DevState D
   __shared__ __attribute__((aligned(16))) float bufA[TM * HS];
   __shared__ __attribute__((aligned(16))) float bufB[TM * HS];
   __shared__ float part[NWP][TM][16];
+  __shared__ float part_s[NWP][TM][16];   // log-std head (stochastic actor only)
   __shared__ float act_lds[TM][16];
   __shared__ float obs_lds[TM * ETG_OBS_DIM];
   __shared__ float lds_par[NWP][LDS16_FIELDS * 64];
@@ -770,10 +773,16 @@ __global__ void __launch_bounds__(256) k_rollout_policy16_rec(KCfg K, DevState D
     hidden_layer<BF16, HID / 16, NWP>(bufB, P.w2, P.b2, bufA, wave, lane);
     __syncthreads();
     output_partial<BF16, NWP>(bufA, P.w3, wave, lane, part);
+    if (R.noise) output_partial<BF16, NWP>(bufA, R.w3s, wave, lane, part_s);
     __syncthreads();
     {
       const int r = tid >> 4, cidx = tid & 15;          // 256 threads = 16 rows x 16 columns
-      const float v = ((part[0][r][cidx] + part[1][r][cidx]) + (part[2][r][cidx] + part[3][r][cidx])) + (cidx < P.out_dim ? P.b3[cidx] : 0.0f);
+      float v = ((part[0][r][cidx] + part[1][r][cidx]) + (part[2][r][cidx] + part[3][r][cidx])) + (cidx < P.out_dim ? P.b3[cidx] : 0.0f);
+      if (R.noise && cidx < ETG_ACT_DIM) {
+        float ls = ((part_s[0][r][cidx] + part_s[1][r][cidx]) + (part_s[2][r][cidx] + part_s[3][r][cidx])) + R.b3s[cidx];
+        ls = fminf(fmaxf(ls, -20.0f), 2.0f);
+        v = v + expf(ls) * R.noise[((size_t)s * K.n_env + (size_t)tile * TM + r) * ETG_ACT_DIM + cidx];
+      }
       const float t = tanhf(v);
       act_lds[r][cidx] = t * act_scale;
       if (cidx < ETG_ACT_DIM) R.act[((size_t)s * K.n_env + (size_t)tile * TM + r) * ETG_ACT_DIM + cidx] = t;   // the UNSCALED action (train.py:159)
@@ -1350,12 +1359,13 @@ extern "C" int etg_rollout_policy(EtgHandle* h, EtgPolicy* pol, int n_steps, flo
 }
 
 extern "C" int etg_rollout_policy_record(EtgHandle* h, EtgPolicy* pol, int n_steps, float act_scale, int precision, int obs_col0,
-                                         float* obs, float* rec_obs, float* rec_act, float* rec_reward, uint8_t* rec_done,
-                                         float* ret, int32_t* len, void* stream) {
+                                         float* obs, const float* noise, float* rec_obs, float* rec_act, float* rec_reward,
+                                         uint8_t* rec_done, float* ret, int32_t* len, void* stream) {
   CHECK_HANDLE(h);
   if (!pol || n_steps <= 0 || !obs || !rec_obs || !rec_act || !rec_reward || !rec_done)
     return fail(ETG_ERR_BAD_ARG, "etg_rollout_policy_record: bad arguments");
   if (!h->was_reset) return fail(ETG_ERR_STATE, "etg_rollout_policy_record: call etg_reset first");
+  if (noise && !pol->has_std) return fail(ETG_ERR_STATE, "etg_rollout_policy_record: a stochastic rollout needs etg_policy_load_std() first");
   if (pol->device != h->device) return fail(ETG_ERR_BAD_ARG, "etg_rollout_policy_record: policy and simulator live on different devices");
   if (obs_col0 < 0 || obs_col0 + pol->in_dim > ETG_OBS_DIM || pol->out_dim != ETG_ACT_DIM)
     return fail(ETG_ERR_BAD_ARG, "etg_rollout_policy_record: the policy must map observation columns [col0, col0 + in_dim) to 12 actions");
@@ -1372,7 +1382,8 @@ extern "C" int etg_rollout_policy_record(EtgHandle* h, EtgPolicy* pol, int n_ste
     advance_obs_stream(h, m);
     const bool kn = h->K.knee != 0, pl = plain_config(h->K);
     const RecOut R = {rec_obs + (size_t)done_steps * N * ETG_OBS_DIM, rec_act + (size_t)done_steps * N * ETG_ACT_DIM,
-                      rec_reward + (size_t)done_steps * N, rec_done + (size_t)done_steps * N};
+                      rec_reward + (size_t)done_steps * N, rec_done + (size_t)done_steps * N,
+                      noise ? noise + (size_t)done_steps * N * ETG_ACT_DIM : nullptr, (const float4*)pol->w3s, pol->b3s};
 #define LAUNCH_POLICY16R(F_, K_, P_)                                                                                  \
   do {                                                                                                                \
     if (precision == 0) hipLaunchKernelGGL((k_rollout_policy16_rec<F_, false, K_, P_>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs, R); \

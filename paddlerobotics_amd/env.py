@@ -535,7 +535,7 @@ class BatchedQuadrupedEnv:
         self._last_view = self._obs_view()
         return ret, ln
 
-    def rollout_policy_record(self, policy, n_steps, act_scale=0.3, precision=0):
+    def rollout_policy_record(self, policy, n_steps, act_scale=0.3, precision=0, noise=None):
         """rollout_policy that also records the episode (etg_rollout_policy_record): returns (ret [N], len [N], rec) with
         rec = dict(obs [T,N,49] the rows the actor acted on, action [T,N,12] unscaled, reward [T,N], done [T,N] bool,
         final_obs [N,49]).  The data half of run_EStrain_episode with es_rpm (train.py:213-249) at the fused kernel's speed;
@@ -547,12 +547,16 @@ class BatchedQuadrupedEnv:
             raise ValueError("rollout_policy_record needs the 16-lane mapping, num_envs % 16 == 0, the plain 49-float observation "
                              "and a 49 -> 12 actor; use replay.collect_transitions() for the other configurations")
         T, N = int(n_steps), self.num_envs
+        if noise is not None:   # the stochastic actor (SAC.sample): tanh(mean + exp(clamp(log_std)) * noise), noise [T, N, 12] ~ N(0, 1)
+            noise = torch.as_tensor(noise, dtype=torch.float32, device=self.device).contiguous()
+            if tuple(noise.shape) != (T, N, A.NUM_MOTORS):
+                raise ValueError("noise must be [n_steps, num_envs, 12]")
         rec = {"obs": torch.empty(T, N, A.OBS_DIM, device=self.device), "action": torch.empty(T, N, A.NUM_MOTORS, device=self.device),
                "reward": torch.empty(T, N, device=self.device), "done": torch.empty(T, N, dtype=torch.uint8, device=self.device)}
         ret = torch.empty(N, device=self.device)
         ln = torch.empty(N, dtype=torch.int32, device=self.device)
         _lib.check(self._lib.etg_rollout_policy_record(self._h, policy._h, T, C.c_float(act_scale), int(precision), 0, _ptr(self.obs),
-                                                       _ptr(rec["obs"]), _ptr(rec["action"]), _ptr(rec["reward"]), _ptr(rec["done"]),
+                                                       _ptr(noise), _ptr(rec["obs"]), _ptr(rec["action"]), _ptr(rec["reward"]), _ptr(rec["done"]),
                                                        _ptr(ret), _ptr(ln), self._stream()))
         self._last_view = self._obs_view()
         rec["done"] = rec["done"].view(torch.bool)

@@ -196,7 +196,8 @@ class DeviceReplayMemory:
 
 
 def collect_transitions(env, rpm, max_step, policy=None, action_bound=0.3, mode="predict", ETG_w=None, ETG_b=None,
-                        x_noise=0, precision=0, generator=None, info_keys=("torso", "feet", "up", "tau", "stand", "badfoot", "footcontact")):
+                        x_noise=0, precision=0, generator=None, info_keys=("torso", "feet", "up", "tau", "stand", "badfoot", "footcontact"),
+                        noise=None):
     """One episode of every robot with its transitions stored in `rpm` (run_train_episode train.py:129-179,
     run_EStrain_episode train.py:213-249 with es_rpm), batched:
 
@@ -216,11 +217,15 @@ def collect_transitions(env, rpm, max_step, policy=None, action_bound=0.3, mode=
         raise ValueError("mode %r needs a policy" % mode)
     obs, _ = env.reset(ETG_w=ETG_w, ETG_b=ETG_b, x_noise=x_noise)
 
+    step_no = [0]
+
     def act(obs):
+        k = step_no[0]
+        step_no[0] += 1
         if mode == "uniform":
             return torch.rand(n, adim, device=dev, generator=generator) * 2 - 1
-        if mode == "sample":
-            return policy.sample(obs, 1.0, precision, generator=generator, return_logp=False)
+        if mode == "sample":   # noise [max_step + 1, N, 12]: explicit N(0,1) draws (reproducible against collect_recorded)
+            return policy.sample(obs, 1.0, precision, noise=None if noise is None else noise[k], generator=generator, return_logp=False)
         return policy.predict(obs, 1.0, precision)
 
     info_buf = getattr(env, "info_buf", None)
@@ -324,12 +329,19 @@ def store_recorded(rpm, rec):
     return T * N
 
 
-def collect_recorded(env, rpm, max_step, policy, action_bound=0.3, ETG_w=None, ETG_b=None, x_noise=0, precision=0):
-    """run_EStrain_episode with es_rpm (train.py:213-249) for all robots through the FUSED closed-loop kernel: reset, one
-    recorded rollout of max_step + 1 control steps (deterministic actor, as agent.predict there), rows into `rpm`.  The forced
-    `done` of the last step (donef = steps > max_step) is applied to the recorded flags.  Returns (ret [N], len [N])."""
+def collect_recorded(env, rpm, max_step, policy, action_bound=0.3, ETG_w=None, ETG_b=None, x_noise=0, precision=0, mode="predict",
+                     generator=None, noise=None):
+    """run_EStrain_episode with es_rpm (train.py:213-249; mode "predict": agent.predict) or the collection of run_train_episode
+    (train.py:129-161; mode "sample": agent.sample, the squashed-Gaussian actor on N(0,1) draws made here or passed as `noise`
+    [max_step + 1, N, 12]) for all robots through the FUSED closed-loop kernel: reset, one recorded rollout of max_step + 1
+    control steps, rows into `rpm`.  The forced `done` of the last step (donef = steps > max_step) is applied to the recorded
+    flags.  Returns (ret [N], len [N])."""
     env.reset(ETG_w=ETG_w, ETG_b=ETG_b, x_noise=x_noise)
-    ret, ln, rec = env.rollout_policy_record(policy, max_step + 1, action_bound, precision)
+    if mode == "sample" and noise is None:
+        noise = torch.randn(max_step + 1, env.num_envs, 12, device=env.device, generator=generator)
+    elif mode not in ("predict", "sample"):
+        raise ValueError("mode must be 'predict' or 'sample'")
+    ret, ln, rec = env.rollout_policy_record(policy, max_step + 1, action_bound, precision, noise=noise if mode == "sample" else None)
     rec["done"] = rec["done"].clone()
     rec["done"][-1] = True                                            # donef of the last step ends every running episode
     store_recorded(rpm, rec)

@@ -379,3 +379,37 @@ def test_es_generation_with_an_actor_keeps_the_candidates_episodes():
     _, ln = env.episode_stats()
     assert rpm.size() == int(ln.sum().item()) and int((rpm.terminal[:rpm.size()] == 0).sum().item()) == n
     env.close(); twin.close()
+
+
+@pytest.mark.gpu
+def test_recorded_stochastic_rollout_matches_the_sampling_loop():
+    """GPU: etg_rollout_policy_record with the caller's N(0,1) draws = the squashed-Gaussian actor of run_train_episode
+    (agent.sample, alg/sac.py:65-76) fused into the closed-loop kernel; the same draws fed to the stepping loop
+    (policy.sample + env.step) fill the memory with the same rows."""
+    from tests.test_gpu_parity import _need_gpu, _make
+    from tests.test_gpu_parity2 import _policy
+    from paddlerobotics_amd.replay import collect_recorded
+    _need_gpu()
+    n, max_step, bound = 128, 29, 0.3
+    pol, _ = _policy()
+    g = torch.Generator(device="cuda:0"); g.manual_seed(12)
+    noise = torch.randn(max_step + 1, n, 12, device="cuda:0", generator=g)
+    a, b = _make(n, seed=6), _make(n, seed=6)
+    ra, rb = DeviceReplayMemory(n * (max_step + 1), 49, 12), DeviceReplayMemory(n * (max_step + 1), 49, 12)
+    ret_a, ln_a, _ = collect_transitions(a, ra, max_step, policy=pol, action_bound=bound, mode="sample", noise=noise)
+    ret_b, ln_b = collect_recorded(b, rb, max_step, pol, action_bound=bound, mode="sample", noise=noise)
+    assert torch.equal(ln_a, ln_b) and ra.size() == rb.size()
+    k = ra.size()
+    close = lambda x, y, tol: bool(((x - y).abs() <= tol * (1 + y.abs())).all())
+    assert torch.equal(ra.terminal[:k], rb.terminal[:k])
+    assert close(ra.action[:k], rb.action[:k], 2e-4) and close(ra.obs[:k], rb.obs[:k], 2e-3) and close(ra.reward[:k], rb.reward[:k], 2e-3)
+    # the stochastic actions are not the deterministic ones, and they are what policy.sample gives for the first rows
+    det = pol.predict(rb.obs[:n].contiguous())
+    assert (rb.action[:n] - det).abs().max().item() > 1e-2
+    first = pol.sample(rb.obs[:n].contiguous(), 1.0, noise=noise[0], return_logp=False)
+    assert (rb.action[:n] - first).abs().max().item() < 1e-5
+    # drawn inside collect_recorded when no noise is passed
+    rc = DeviceReplayMemory(n * (max_step + 1), 49, 12)
+    collect_recorded(b, rc, max_step, pol, action_bound=bound, mode="sample", generator=g)
+    assert rc.size() > 0 and (rc.action[:n] - det).abs().max().item() > 1e-2
+    a.close(); b.close()

@@ -33,6 +33,8 @@ for mode in ("predict", "sample"):
     print("collect_transitions(%s): %.1f us per control step, %.1f M env-steps/s" % (mode, dt / (T + 1) * 1e6, N * (T + 1) / dt / 1e6))
 dt = timed(lambda: collect_recorded(env, rpm, T, pol))
 print("collect_recorded (fused kernel): %.1f us per control step, %.1f M env-steps/s" % (dt / (T + 1) * 1e6, N * (T + 1) / dt / 1e6))
+dt = timed(lambda: collect_recorded(env, rpm, T, pol, mode="sample"))
+print("collect_recorded (sample):       %.1f us per control step, %.1f M env-steps/s" % (dt / (T + 1) * 1e6, N * (T + 1) / dt / 1e6))
 dt = timed(lambda: (env.reset(), env.rollout_policy(pol, T + 1, 0.3)))
 print("fused rollout, nothing stored:   %.1f us per control step, %.1f M env-steps/s" % (dt / (T + 1) * 1e6, N * (T + 1) / dt / 1e6))
 dt = timed(bare)
