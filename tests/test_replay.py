@@ -243,6 +243,18 @@ def test_fused_replay_kernels_match_the_torch_definition():
         for name in ("obs", "next_obs", "action", "reward", "terminal"):
             assert torch.equal(getattr(a, name)[:cap], getattr(b, name)[:cap]), (n, name)
         assert int(a._pos) == int(b._pos) and int(a._count) == int(b._count) and a.size() == b.size()
+    # rows wider than a wave (history-stacked observations: 3 x 49 columns): the element-per-thread form of the copies
+    a, b = DeviceReplayMemory(5000, 147, 12), DeviceReplayMemory(5000, 147, 12, fused=False)
+    for step in range(4):
+        r = lambda *s: torch.randn(*s, device="cuda:0", generator=g)
+        obs, act, rew, nxt = r(1500, 147), r(1500, 12), r(1500), r(1500, 147)
+        term = (torch.rand(1500, device="cuda:0", generator=g) < 0.8).float()
+        mask = torch.rand(1500, device="cuda:0", generator=g) < 0.7
+        for m in (a, b):
+            m.append_batch(obs, act, rew, nxt, term, mask=mask)
+    for name in ("obs", "next_obs", "action", "reward", "terminal"):
+        assert torch.equal(getattr(a, name)[:5000], getattr(b, name)[:5000]), name
+    assert int(a._pos) == int(b._pos) and int(a._count) == int(b._count)
     with pytest.raises(Exception):
         DeviceReplayMemory(10, 49, 12).append_batch(torch.zeros(11, 49, device="cuda:0"), torch.zeros(11, 12, device="cuda:0"),
                                                    torch.zeros(11, device="cuda:0"), torch.zeros(11, 49, device="cuda:0"),
