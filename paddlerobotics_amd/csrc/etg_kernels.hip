@@ -243,6 +243,53 @@ __global__ void __launch_bounds__(BLOCK) k_finish(KCfg K, DevState D, const uint
   store_state(c, D.base, D.leg, L);
 }
 
+// ---- cached restart (etg_step_autoreset).  A launch lasts as long as its slowest wave, and with auto-reset
+// some wave restarts a robot in nearly every launch; recomputing reset_finish16 there (first ETG action, IK, foot kinematics,
+// rpy reference, first observation: ~1200 instructions) costs the whole batch ~3 us per step.  What reset_finish16 produces
+// depends only on the settled state, the robot's parameters and its ETG weights, so etg_reset keeps it per robot -- in rows
+// FIN_* of the block behind D.cache_off (rows 0, 1 are the offsets the cached settle ran at) -- and the in-kernel restart
+// copies it back.  Anything that changes an input clears the robot's FIN_OK flag (etg_set_params, etg_set_heightfield,
+// etg_set_reset_offsets); the restart then recomputes as before.  Both lane mappings share the SoA state layout, and this cache.
+enum { FIN_OBS = 2, FIN_RPY = FIN_OBS + ETG_OBS_DIM, FIN_FWX = FIN_RPY + 3, FIN_OK = FIN_FWX + 4, FIN_ROWS = FIN_OK + 1 };
+__global__ void __launch_bounds__(256) k_fin_store(KCfg K, DevState D, const uint8_t* mask, const float* obs) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = K.n_env;
+  if (env >= N || (mask && !mask[env])) return;
+  float* fin = D.cache_off;
+  for (int k = 0; k < ETG_OBS_DIM; k++) fin[(size_t)(FIN_OBS + k) * N + env] = obs[(size_t)env * ETG_OBS_DIM + k];
+  for (int k = 0; k < 3; k++) fin[(size_t)(FIN_RPY + k) * N + env] = D.ctl[(size_t)(CT_FIRST_RPY + k) * N + env];
+  for (int leg = 0; leg < 4; leg++) fin[(size_t)(FIN_FWX + leg) * N + env] = D.legctl[(size_t)LC_LAST_FOOT_X * 4 * N + 4 * env + leg];
+  fin[(size_t)FIN_OK * N + env] = 1.0f;
+}
+__global__ void __launch_bounds__(256) k_fin_clear(KCfg K, DevState D, const uint8_t* mask) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= K.n_env || (mask && !mask[env])) return;
+  D.cache_off[(size_t)FIN_OK * K.n_env + env] = 0.0f;
+}
+// reset_finish from the cache (4 lanes per robot: lane = leg): same stores, no arithmetic
+template <class Ctx>
+__device__ __forceinline__ void restart_from_cache4(const Ctx& c, const KCfg& K, LaneState<float>& L, float* ctl, int* ictl, float* legctl,
+                                                    const float* fin, float* obs) {
+  const int N = K.n_env;
+  L.energy = 0.0f;
+  c.st_env_i(ictl, IC_STEP, 0);
+  c.st_env_i(ictl, IC_TICK, K.settle_ticks);
+  c.st_env_i(ictl, IC_HAS_LAST, 0);
+  c.st_env(ctl, CT_RET, 0.0f); c.st_env(ctl, CT_LEN, 0.0f); c.st_env(ctl, CT_ALIVE, 1.0f);
+  c.st_env(ctl, CT_LAST_BASE + 0, L.p.x); c.st_env(ctl, CT_LAST_BASE + 1, L.p.y); c.st_env(ctl, CT_LAST_BASE + 2, L.p.z);
+#pragma unroll
+  for (int j = 0; j < 3; j++) {
+    const float pose = c.par(PR_POSE + j);
+    c.st_lane(legctl, LC_LAST_QDES + j, pose);
+    c.st_lane(legctl, LC_FX0 + j, pose); c.st_lane(legctl, LC_FX1 + j, pose);
+    c.st_lane(legctl, LC_FY0 + j, pose); c.st_lane(legctl, LC_FY1 + j, pose);
+  }
+  c.st_lane(legctl, LC_LAST_FOOT_X, fin[(size_t)(FIN_FWX + c.lane) * N + c.env]);
+#pragma unroll
+  for (int k = 0; k < 3; k++) c.st_env(ctl, CT_FIRST_RPY + k, fin[(size_t)(FIN_RPY + k) * N + c.env]);
+  for (int k = c.lane; k < ETG_OBS_DIM; k += 4) obs[(size_t)c.env * ETG_OBS_DIM + k] = fin[(size_t)(FIN_OBS + k) * N + c.env];
+}
+
 // env.step for the 16 robots of a wave (one quad each); AUTO: see step16_body
 template <bool FLAT, bool PLAIN, bool AUTO>
 __device__ __forceinline__ void step4_body(const KCfg& K, const DevState& D, const float* action, const uint8_t* donef, float* obs,
@@ -272,7 +319,8 @@ __device__ __forceinline__ void step4_body(const KCfg& K, const DevState& D, con
     L = load_state<float>(c, D.cache_base, D.cache_leg);
     L.p.x += D.reset_off[c.env] - D.cache_off[c.env];
     L.p.y += D.reset_off[N + c.env] - D.cache_off[N + c.env];
-    reset_finish(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, obs);
+    if (D.cache_off[(size_t)FIN_OK * N + c.env] > 0.5f) restart_from_cache4(c, K, L, D.ctl, D.ictl, D.legctl, D.cache_off, obs);
+    else reset_finish(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, obs);
     if (c.lane == 0) {
       D.ictl[(size_t)IC_PUSH_LEFT * N + c.env] = 0;
       for (int k = 0; k < 3; k++) D.ctl[(size_t)(CT_PUSH + k) * N + c.env] = 0.0f;
@@ -538,29 +586,6 @@ __global__ void __launch_bounds__(BLOCK) k_settle16(KCfg K, DevState D, const ui
   settle_mark_fresh(K, D, c.env, ox, oy);
 }
 
-// ---- cached restart (etg_step_autoreset, 16-lane kernels).  A launch lasts as long as its slowest wave, and with auto-reset
-// some wave restarts a robot in nearly every launch; recomputing reset_finish16 there (first ETG action, IK, foot kinematics,
-// rpy reference, first observation: ~1200 instructions) costs the whole batch ~3 us per step.  What reset_finish16 produces
-// depends only on the settled state, the robot's parameters and its ETG weights, so etg_reset keeps it per robot -- in rows
-// FIN_* of the block behind D.cache_off (rows 0, 1 are the offsets the cached settle ran at) -- and the in-kernel restart
-// copies it back.  Anything that changes an input clears the robot's FIN_OK flag (etg_set_params, etg_set_heightfield,
-// etg_set_reset_offsets); the restart then recomputes as before.
-enum { FIN_OBS = 2, FIN_RPY = FIN_OBS + ETG_OBS_DIM, FIN_FWX = FIN_RPY + 3, FIN_OK = FIN_FWX + 4, FIN_ROWS = FIN_OK + 1 };
-__global__ void __launch_bounds__(256) k_fin_store(KCfg K, DevState D, const uint8_t* mask, const float* obs) {
-  const int env = blockIdx.x * blockDim.x + threadIdx.x;
-  const int N = K.n_env;
-  if (env >= N || (mask && !mask[env])) return;
-  float* fin = D.cache_off;
-  for (int k = 0; k < ETG_OBS_DIM; k++) fin[(size_t)(FIN_OBS + k) * N + env] = obs[(size_t)env * ETG_OBS_DIM + k];
-  for (int k = 0; k < 3; k++) fin[(size_t)(FIN_RPY + k) * N + env] = D.ctl[(size_t)(CT_FIRST_RPY + k) * N + env];
-  for (int leg = 0; leg < 4; leg++) fin[(size_t)(FIN_FWX + leg) * N + env] = D.legctl[(size_t)LC_LAST_FOOT_X * 4 * N + 4 * env + leg];
-  fin[(size_t)FIN_OK * N + env] = 1.0f;
-}
-__global__ void __launch_bounds__(256) k_fin_clear(KCfg K, DevState D, const uint8_t* mask) {
-  const int env = blockIdx.x * blockDim.x + threadIdx.x;
-  if (env >= K.n_env || (mask && !mask[env])) return;
-  D.cache_off[(size_t)FIN_OK * K.n_env + env] = 0.0f;
-}
 // reset_finish16 from the cache: same stores, no arithmetic
 template <class Ctx>
 __device__ __forceinline__ void restart_from_cache16(const Ctx& c, const KCfg& K, State16<float>& L, float* ctl, int* ictl, float* legctl,
@@ -1194,10 +1219,10 @@ extern "C" int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* st
   hipLaunchKernelGGL(k_cache_mark, ge, dim3(256), 0, s, h->K, h->D, mask);
   if (h->lanes == 16) {
     LAUNCH16(k_finish16, g16, s, h->K, h->D, mask, obs);
-    hipLaunchKernelGGL(k_fin_store, ge, dim3(256), 0, s, h->K, h->D, mask, (const float*)obs);   // the clean row: before the noise
   } else {
     LAUNCH4(k_finish, g4, s, h->K, h->D, mask, obs);
   }
+  hipLaunchKernelGGL(k_fin_store, ge, dim3(256), 0, s, h->K, h->D, mask, (const float*)obs);   // the clean row: before the noise
   launch_obs_noise(h, 1, mask, obs, s);
   HIP_TRY(hipGetLastError());
   if (!mask) h->all_cached = true;

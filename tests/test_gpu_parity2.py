@@ -631,7 +631,8 @@ def test_friction_cone_on_an_inclined_heightfield_gpu():
 
 
 
-def test_cached_restart_follows_parameter_changes():
+@pytest.mark.parametrize("lanes", [16, 4])
+def test_cached_restart_follows_parameter_changes(lanes):
     """The in-kernel restart of step(auto_reset) copies cached reset_finish outputs; new ETG weights (set_etg without a reset),
     new reset offsets and new dynamic parameters must invalidate them: robots that restart AFTER the change come back with the
     reset observation of the new parameters."""
@@ -639,7 +640,7 @@ def test_cached_restart_follows_parameter_changes():
     n = 64
     W1, B1 = _etg_params(n, seed=21)
     W2, B2 = _etg_params(n, seed=22)
-    env, ref = _make(n, auto_reset=True), _make(n)
+    env, ref = _make(n, auto_reset=True, lanes_per_robot=lanes), _make(n, lanes_per_robot=lanes)
     env.reset(ETG_w=W1, ETG_b=B1)
     limp = torch.zeros(n, 12, device="cuda:0"); limp[:, 1::3] = 1.5                 # everybody falls again and again
     obs1 = ref.reset(ETG_w=W1, ETG_b=B1)[0].clone()
