@@ -121,33 +121,51 @@ __global__ void __launch_bounds__(1024) k_replay_chunk_slots(const uint8_t* __re
 
 // mem_obs[slot[i], :] = obs[i, :], mem_act[slot[i], :] = act[i, :]; optionally act_scaled[i, :] = scale * act[i, :] (the
 // command the step receives is the stored action times act_bound, train.py:147: one launch less per control step)
-// Row copies are HBM-bound byte shuffling: one wave per row (lane = column, od + ad <= 64 for the 49 + 12 floats of a
-// transition), several rows per wave, no integer division on the way.  ROWWISE = false: the general element-per-thread form.
+constexpr int BIG_BATCH = 65536;   // rows: above this (a recorded episode) a bounded grid walks the rows, skipping dead ones 64 at a time
+// Row copies are HBM-bound byte shuffling: a wave copies a row at a time (lane = column, od + ad <= 64 for the 49 + 12
+// floats of a transition) and skips the rows of finished robots 64 at a time.  ROWWISE = false: the general element-per-thread form.
 template <bool ROWWISE>
 __global__ void k_replay_begin_rows(const int* __restrict__ slot, int n, const float* __restrict__ obs, int od, float* __restrict__ mem_obs,
                                     const float* __restrict__ act, int ad, float* __restrict__ mem_act, float scale,
                                     float* __restrict__ act_scaled) {
   const int dsum = od + ad;
-  int i, c;
+  // rows of finished robots are not stored (hundreds of thousands of writes to one scratch row would serialise in a
+  // recorded episode); the scaled action is still produced for them: the step needs a command for every robot
+  auto copy = [&](int i, int c) {
+    const int sl = slot[i];
+    const size_t s = (size_t)sl;
+    if (c < od) {
+      if (sl >= 0) mem_obs[s * od + c] = obs[(size_t)i * od + c];
+    } else if (sl >= 0 || act_scaled) {
+      const float a = act[(size_t)i * ad + (c - od)];
+      if (sl >= 0) mem_act[s * ad + (c - od)] = a;
+      if (act_scaled) act_scaled[(size_t)i * ad + (c - od)] = scale * a;
+    }
+  };
   if (ROWWISE) {
-    i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    c = threadIdx.x & 63;
-    if (i >= n || c >= dsum) return;
+    // a bounded grid of waves walks the rows 64 at a time: one coalesced load of their slots, then only the rows that
+    // have something to do (stored, or every row when the scaled action is wanted) are copied, lane = column
+    const int lane = threadIdx.x & 63, per = blockDim.x >> 6;
+    if (n <= BIG_BATCH) {   // a step's worth of rows: a wave per row, all in flight at once
+      const int i = blockIdx.x * per + (threadIdx.x >> 6);
+      if (i < n && lane < dsum) copy(i, lane);
+      return;
+    }
+    for (int base = (blockIdx.x * per + (threadIdx.x >> 6)) * 64; base < n; base += gridDim.x * per * 64) {
+      const int row = base + lane;
+      const int sl = row < n ? slot[row] : -1;
+      unsigned long long todo = __ballot(row < n && (sl >= 0 || act_scaled != nullptr));
+      while (todo) {
+        const int r = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        if (lane < dsum) copy(base + r, lane);
+      }
+    }
   } else {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)n * dsum) return;
-    i = (int)(idx / dsum); c = (int)(idx - (long long)i * dsum);
-  }
-  const int sl = slot[i];
-  const size_t s = (size_t)sl;
-  // rows of finished robots are not stored (hundreds of thousands of writes to the one scratch row would serialise in a
-  // recorded episode); the scaled action is still produced for them: the step needs a command for every robot
-  if (c < od) {
-    if (sl >= 0) mem_obs[s * od + c] = obs[(size_t)i * od + c];
-  } else {
-    const float a = act[(size_t)i * ad + (c - od)];
-    if (sl >= 0) mem_act[s * ad + (c - od)] = a;
-    if (act_scaled) act_scaled[(size_t)i * ad + (c - od)] = scale * a;
+    const int i = (int)(idx / dsum);
+    copy(i, (int)(idx - (long long)i * dsum));
   }
 }
 
@@ -158,31 +176,45 @@ __global__ void k_replay_end_rows(const int* __restrict__ slot, int n, const flo
                                   float* __restrict__ mem_next_obs, const float* __restrict__ reward, const uint8_t* __restrict__ done,
                                   float* __restrict__ mem_reward, float* __restrict__ mem_terminal, const float* __restrict__ info,
                                   int info_dim, int n_sum, int velx_col, float* __restrict__ info_sum, uint8_t* __restrict__ alive) {
-  int i, c;
+  auto copy = [&](int i, int c) {
+    const int sl = slot[i];
+    if (sl < 0) return;                  // a finished robot: nothing to store, nothing to sum, alive stays 0
+    const size_t s = (size_t)sl;
+    mem_next_obs[s * od + c] = next_obs[(size_t)i * od + c];
+    if (c != 0) return;
+    const int d = done[i] != 0;
+    mem_reward[s] = reward[i];
+    mem_terminal[s] = d ? 0.0f : 1.0f;
+    if (alive) {
+      const int a = alive[i] != 0;
+      if (a && info && info_sum) {
+        for (int k = 0; k < n_sum; k++) info_sum[(size_t)i * (n_sum + 1) + k] += info[(size_t)i * info_dim + k];
+        if (velx_col >= 0 && info[(size_t)i * info_dim + velx_col] >= 0.3f) info_sum[(size_t)i * (n_sum + 1) + n_sum] += 1.0f;
+      }
+      alive[i] = (uint8_t)(a && !d);
+    }
+  };
   if (ROWWISE) {
-    i = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
-    c = threadIdx.x & 63;
-    if (i >= n || c >= od) return;
+    const int lane = threadIdx.x & 63, per = blockDim.x >> 6;
+    if (n <= BIG_BATCH) {
+      const int i = blockIdx.x * per + (threadIdx.x >> 6);
+      if (i < n && lane < od) copy(i, lane);
+      return;
+    }
+    for (int base = (blockIdx.x * per + (threadIdx.x >> 6)) * 64; base < n; base += gridDim.x * per * 64) {
+      const int row = base + lane;
+      unsigned long long todo = __ballot(row < n && slot[row] >= 0);
+      while (todo) {
+        const int r = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        if (lane < od) copy(base + r, lane);
+      }
+    }
   } else {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= (long long)n * od) return;
-    i = (int)(idx / od); c = (int)(idx - (long long)i * od);
-  }
-  const int sl = slot[i];
-  if (sl < 0) return;                    // a finished robot: nothing to store, nothing to sum, alive stays 0
-  const size_t s = (size_t)sl;
-  mem_next_obs[s * od + c] = next_obs[(size_t)i * od + c];
-  if (c != 0) return;
-  const int d = done[i] != 0;
-  mem_reward[s] = reward[i];
-  mem_terminal[s] = d ? 0.0f : 1.0f;
-  if (alive) {
-    const int a = alive[i] != 0;
-    if (a && info && info_sum) {
-      for (int k = 0; k < n_sum; k++) info_sum[(size_t)i * (n_sum + 1) + k] += info[(size_t)i * info_dim + k];
-      if (velx_col >= 0 && info[(size_t)i * info_dim + velx_col] >= 0.3f) info_sum[(size_t)i * (n_sum + 1) + n_sum] += 1.0f;
-    }
-    alive[i] = (uint8_t)(a && !d);
+    const int i = (int)(idx / od);
+    copy(i, (int)(idx - (long long)i * od));
   }
 }
 
@@ -224,7 +256,7 @@ extern "C" int etg_replay_begin(const uint8_t* alive, int n, long long max_size,
     hipLaunchKernelGGL(k_replay_chunk_slots, dim3(chunks), dim3(1024), 0, s, alive, n, max_size, slot);
   }
   if (obs_dim + act_dim <= 64) {
-    hipLaunchKernelGGL(k_replay_begin_rows<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, slot, n, obs, obs_dim, mem_obs, act, act_dim,
+    hipLaunchKernelGGL(k_replay_begin_rows<true>, dim3((unsigned)(n <= BIG_BATCH ? (n + 3) / 4 : 2048)), dim3(256), 0, s, slot, n, obs, obs_dim, mem_obs, act, act_dim,
                        mem_act, act_scale, act_scaled);
   } else {
     const long long tot = (long long)n * (obs_dim + act_dim);
@@ -243,7 +275,7 @@ extern "C" int etg_replay_end(const int32_t* slot, int n, const float* reward, c
   if (!bind_device(mem_next_obs)) return fail("etg_replay_end: mem_next_obs is not a device pointer");
   hipStream_t s = (hipStream_t)stream;
   if (obs_dim <= 64) {
-    hipLaunchKernelGGL(k_replay_end_rows<true>, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, slot, n, next_obs, obs_dim, mem_next_obs, reward,
+    hipLaunchKernelGGL(k_replay_end_rows<true>, dim3((unsigned)(n <= BIG_BATCH ? (n + 3) / 4 : 2048)), dim3(256), 0, s, slot, n, next_obs, obs_dim, mem_next_obs, reward,
                        done, mem_reward, mem_terminal, info, info_dim, n_sum, velx_col, info_sum, alive);
   } else {
     const long long tot = (long long)n * obs_dim;

@@ -229,7 +229,8 @@ def test_fused_replay_kernels_match_the_torch_definition():
     from tests.test_gpu_parity import _need_gpu
     _need_gpu()
     g = torch.Generator(device="cuda:0"); g.manual_seed(3)
-    for n, cap in ((4096, 10000), (1000, 2999), (1, 3), (20000, 50000), (8193, 8200)):   # > 8192 rows: the three-launch slot computation
+    # > 8192 rows: the three-launch slot computation; > 65536 rows: the bounded grid that skips dead rows 64 at a time
+    for n, cap in ((4096, 10000), (1000, 2999), (1, 3), (20000, 50000), (8193, 8200), (70001, 150000)):
         a, b = DeviceReplayMemory(cap, 49, 12), DeviceReplayMemory(cap, 49, 12, fused=False)
         assert a.fused and not b.fused
         for step in range(7):

@@ -15,6 +15,11 @@ def timed(fn, reps=3):
 env.reset()
 print("rollout_policy        %.2f us/step" % (timed(lambda: env.rollout_policy(pol, T, 0.3)) / T * 1e6))
 print("rollout_policy_record %.2f us/step" % (timed(lambda: env.rollout_policy_record(pol, T, 0.3)) / T * 1e6))
-ret, ln, rec = env.rollout_policy_record(pol, T, 0.3)
+env.reset()
+ret, ln, rec = env.rollout_policy_record(pol, T, 0.3)      # a fresh episode: live rows until each robot falls
 print("store_recorded        %.2f ms" % (timed(lambda: store_recorded(rpm, rec)) * 1e3))
 print("reset                 %.2f ms" % (timed(lambda: env.reset()) * 1e3))
+dn = rec["done"].to(torch.int32)
+alive = int(((torch.cumsum(dn, 0) - dn) == 0).sum().item())
+print("rows offered %d, rows of live robots %d (%.1f %%): k_replay_begin_rows moves %d B per live row each way (+ 4 B slot per offered row), "
+      "k_replay_end_rows %d B" % (T * N, alive, 100.0 * alive / (T * N), 61 * 4, 49 * 4 + 8))
