@@ -33,7 +33,9 @@ from paddlerobotics_amd import a1_model as A  # noqa: E402
 from paddlerobotics_amd.etg import ETG_layer, Opt_with_points  # noqa: E402
 from paddlerobotics_amd.etg_fit import opt_with_points_batched  # noqa: E402
 
-SOLVER_ITERS = 2           # library default (K = 2 vs K = 50 agree statistically over 400 steps, GPU test)
+# contact solver of the headline = the library default = pybullet's documented rule: up to 50 sweeps
+# per tick, stop when the squared velocity-level row residual of a sweep is <= 1e-7.  --solver-iters K alone = exactly K sweeps.
+SOLVER = A.solver_rule()   # (sweep cap, residual threshold)
 HBM_PEAK = 8.0e12          # B/s, MI355X spec (MI355X_MICROARCH.md)
 BYTES_PER_STEP_CFG2 = 816  # 564 B + 252 B per-env ETG w,b
 BYTES_PER_STEP_CFG3 = 808 + 252
@@ -42,7 +44,7 @@ CLOCK_WARM_SECONDS = 0.25
 CLOCK_WARM_STEPS = 600     # untimed scratch-env steps (~22 ms) right before every timed repeat's barrier
 # PMC figures (HBM traffic, VALU instructions per wave) are NOT measured by this process: they come from separate
 # `rocprofv3 --pmc` passes of this same command (tools/pmc_gpu.sh), summarised per kernel and control step in this file.
-PMC_FILE = os.path.join(ROOT, "profiles", "r02_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
 VALU_PEAK_PER_SIMD_CYCLE = 0.384   # tools/ubench/occupancy_rate.hip: 8 resident waves of v_fma_f32 per SIMD
 NOMINAL_HZ = 2.4e9
 
@@ -71,19 +73,35 @@ def device_copy_bandwidth(dev, nbytes=1 << 30, reps=5):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3)
 
 
-def cpu_baseline(n_envs, steps, threads):
-    """The CPU oracle (port of the path, fp64 like stock pybullet) on a bounded sample.  Persistent workers: every thread
-    runs its slice of the robots through ALL the steps (etgo_run_steps), so no thread is spawned or joined per step."""
+def cpu_baseline(n_envs, steps, threads, solver=None, hist=None, heightfield=None):
+    """The CPU oracle (port of the path, fp64 like stock pybullet) on a bounded sample, with the SAME contact-solver rule as
+    the GPU leg it stands next to.  Persistent workers: every thread runs its slice of the robots through ALL the steps
+    (etgo_run_steps), so no thread is spawned or joined per step.  hist (a list): receives the sample's sweep histogram."""
     from oracle.oracle import OracleSim
-    cfg = A.default_config(n_envs, solver_iters=SOLVER_ITERS)
+    it, res = solver if solver is not None else SOLVER
+    cfg = A.default_config(n_envs, solver_iters=it, solver_residual=res, terrain=1 if heightfield else 0, heightfield=heightfield)
     sim = OracleSim(cfg, threads=threads)
+    if heightfield:
+        sim.set_heightfield(heightfield["heights"])
     w, b = etg_population(n_envs, 0, "cpu")
     sim.set_params(etg_w=w.double().numpy(), etg_b=b.double().numpy())
     sim.reset()
+    sim.sweep_hist()
     t0 = time.perf_counter()
     sim.run_steps(steps, threads=threads)
     dt = time.perf_counter() - t0
+    if hist is not None:
+        hist.append(sim.sweep_hist())
     return n_envs * steps / dt
+
+
+def sweep_summary(h):
+    """ticks by sweep count -> {mean, max, fraction of ticks per count}"""
+    h = np.asarray(h, dtype=np.float64)
+    k = np.arange(len(h))
+    nz = np.nonzero(h)[0]
+    return {"mean_sweeps_per_tick": float((h * k).sum() / max(h.sum(), 1.0)), "max_sweeps": int(nz.max()) if len(nz) else 0,
+            "fraction_of_ticks_by_sweeps": {str(int(i)): round(float(h[i] / h.sum()), 4) for i in nz}}
 
 
 def usable_cpus():
@@ -163,7 +181,7 @@ def spawn_ranks(n):
 
 
 def main():
-    global SOLVER_ITERS
+    global SOLVER
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
@@ -173,7 +191,10 @@ def main():
     ap.add_argument("--config", type=int, default=2, choices=(2, 3, 5),
                     help="BASELINE.json configs (1-based): 2 open loop, 3 + MLP policy, 5 open loop on the random heightfield")
     ap.add_argument("--precision", type=int, default=0, help="policy MFMA: 0 fp32, 1 bf16")
-    ap.add_argument("--solver-iters", type=int, default=SOLVER_ITERS, help="PGS sweeps per tick")
+    ap.add_argument("--solver-iters", type=int, default=None,
+                    help="PGS sweeps per tick: alone = exactly that many (residual test off); default: up to 50 with the residual exit")
+    ap.add_argument("--solver-residual", type=float, default=None,
+                    help="squared velocity-level row residual at which a tick stops sweeping (default 1e-7; 0 = fixed count)")
     ap.add_argument("--lanes", type=int, default=0, choices=(0, 4, 16),
                     help="kernel mapping, lanes per robot (0 = library default: 16 up to 4096 robots, else 4)")
     ap.add_argument("--body-contacts", action="store_true", help="knee spheres collide too (16-lane kernels)")
@@ -186,7 +207,7 @@ def main():
     ap.add_argument("--stepwise", action="store_true",
                     help="time env.step() per control step instead of the fused rollout")
     args = ap.parse_args()
-    SOLVER_ITERS = args.solver_iters
+    SOLVER = A.solver_rule(args.solver_iters, args.solver_residual)
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         spawn_ranks(args.gpus)                                    # does not return
@@ -227,7 +248,8 @@ def main():
         terrain_kw = dict(task="heightfield", heightfield=dict(heights=hf, cell=0.05, origin=(-6.4, -6.4)))
     env_kw = dict(num_envs=N, device=str(dev), lanes_per_robot=args.lanes, body_contacts=args.body_contacts,
                   joint_limits=args.joint_limits, **terrain_kw)
-    env = make_env("Quadrupedal", solver_iters=args.solver_iters, **env_kw)
+    solver_kw = dict(solver_iters=SOLVER[0], solver_residual=SOLVER[1])
+    env = make_env("Quadrupedal", **solver_kw, **env_kw)
     lanes = env.lanes_per_robot
     w, b = etg_population(N, seed=rank, device=dev)
 
@@ -296,7 +318,7 @@ def main():
         return wall, kern, surv
 
     # ---- warm everything: lazy kernel loads, the collective, and the clocks (>= 200 ms of real stepping)
-    warm_env = make_env("Quadrupedal", solver_iters=args.solver_iters, **env_kw)     # scratch robots for the per-repeat clock warm
+    warm_env = make_env("Quadrupedal", **solver_kw, **env_kw)     # scratch robots for the per-repeat clock warm
     warm_env.reset(ETG_w=w, ETG_b=b)
     env.reset(ETG_w=w, ETG_b=b)
     fused = not args.stepwise
@@ -326,18 +348,23 @@ def main():
             "k_step16" if lanes == 16 else "k_step", ", policy.predict() before each" if policy is not None else ""))
         if policy is None:
             # what the timed env-step contains: with auto-reset no terminated robot is stepped on
-            envr = make_env("Quadrupedal", solver_iters=args.solver_iters, auto_reset=True, **env_kw)
+            envr = make_env("Quadrupedal", auto_reset=True, **solver_kw, **env_kw)
             extra["stepwise_auto_reset"] = leg(envr, None, False, "env.step(auto_reset=True): finished robots restart from the "
                                                "settle cache inside the timed region (etg_reset with the done mask after every step)")
             envr.close()
-            # Bullet's default numSolverIterations
-            env50 = make_env("Quadrupedal", solver_iters=50, **env_kw)
-            extra["solver_iters_50"] = leg(env50, None, True, "the same fused rollout with 50 PGS sweeps per tick", reps=2)
-            env50.close()
+            # fixed sweep counts next to the residual rule: K = 50 (the cap, never stopping early) and K = 2 (the default of
+            # rounds 1-2); each with the CPU port timed at the same setting (rank 0, N = 1 only)
+            for kfix, reps in ((50, 2), (2, 3)):
+                if SOLVER == (kfix, 0.0):
+                    continue
+                envk = make_env("Quadrupedal", solver_iters=kfix, solver_residual=0.0, **env_kw)
+                extra["solver_iters_%d" % kfix] = leg(envk, None, True, "the same fused rollout with exactly %d PGS sweeps per tick "
+                                                      "(no residual test)" % kfix, reps=reps)
+                envk.close()
             if lanes == 16 and not (args.body_contacts and args.joint_limits):
                 # the model options the headline leaves off: knee spheres collide, joint-limit stops (non-PLAIN kernels)
                 kwf = dict(env_kw, body_contacts=True, joint_limits=True)
-                envf = make_env("Quadrupedal", solver_iters=args.solver_iters, **kwf)
+                envf = make_env("Quadrupedal", **solver_kw, **kwf)
                 extra["knees_and_joint_limits"] = leg(envf, None, True, "the same fused rollout with body_contacts (knee spheres) and "
                                                       "joint_limits (a1.py:186-195 stops) switched on")
                 envf.close()
@@ -395,7 +422,12 @@ def main():
                         "per-env ETG params" % N) if args.config == 5 else
                        ("configs[2]: %d parallel A1 per GPU, flat, ETG + residual MLP policy (random init, "
                         "precision %d)" % (N, args.precision)),
-                       "robots_per_gpu": N, "action_repeat": 13, "sim_dt": 0.002, "solver_iters": args.solver_iters, "lanes_per_robot": lanes,
+                       "robots_per_gpu": N, "action_repeat": 13, "sim_dt": 0.002,
+                       "solver": {"rule": ("projected Gauss-Seidel, warm-started (x0.85); per tick sweep until max_rows ((d lambda_r) A_rr)^2 "
+                                           "<= residual_threshold, at most max_sweeps (pybullet: numSolverIterations 50, "
+                                           "solverResidualThreshold 1e-7)") if SOLVER[1] > 0 else "projected Gauss-Seidel, warm-started, fixed sweep count",
+                                  "max_sweeps": SOLVER[0], "residual_threshold": SOLVER[1], "friction": "disc"},
+                       "solver_iters": SOLVER[0], "lanes_per_robot": lanes,
                        "body_contacts": bool(args.body_contacts), "joint_limits": bool(args.joint_limits),
                        "auto_reset": False, "parallelism": "env-shard x%d" % world,
                        "world_size_reported_by": ("torch.distributed/" + dist.get_backend()) if dist is not None else "single process"},
@@ -439,27 +471,52 @@ def main():
             out["policy_roofline"] = {"bound": "mfma", "kernel": "k_policy", "achieved": flops / (pol_ms * 1e-3) / 1e12,
                                       "peak": peak, "unit": "TFLOP/s", "frac": flops / (pol_ms * 1e-3) / 1e12 / peak,
                                       "kernel_ms": pol_ms, "dtype": "f32" if args.precision == 0 else "bf16"}
+        # sweeps the kernels EXECUTED (per wave: the slowest robot of the 4 / 16 sharing it sets the count), from the info column
+        # of 26 plain env.step() calls on the headline robots -- untimed
+        try:
+            env.reset(ETG_w=w, ETG_b=b)
+            sw = []
+            for _ in range(26):
+                _, _, _, inf = env.step(None)
+                sw.append(float(inf["solver_sweeps"].float().mean().item()) / 13.0)
+            out["config"]["solver"]["executed_sweeps_per_tick_per_wave"] = {
+                "first_26_steps_mean": float(np.mean(sw)), "min_step": float(np.min(sw)), "max_step": float(np.max(sw)),
+                "source": "info['solver_sweeps'] (ETG_INFO_SWEEPS) of env.step()"}
+        except Exception as e:                                       # noqa: BLE001 - diagnostics must not lose the line
+            out["config"]["solver"]["executed_sweeps_per_tick_per_wave"] = {"error": repr(e)[:200]}
         if not args.no_cpu_baseline and world == 1:          # the CPU baseline is an N = 1 exercise
             logical = os.cpu_count() or 1
             affinity, quota = usable_cpus()
-            one = cpu_baseline(64, 60, 1)
+            hf_cpu = terrain_kw.get("heightfield")
+            one = cpu_baseline(64, 60, 1, heightfield=hf_cpu)
             # the box reports `logical` CPUs, but a container may be allowed fewer (affinity mask / cgroup quota): probe the
             # thread count instead of trusting cpu_count(), and report the best figure with the threads that produced it
             n_all, s_all = max(64, 16 * logical), 50
             cand = sorted({t for t in (logical, affinity, int(quota) if quota else 0, 128, 64, 32, 16) if 1 <= t <= logical}, reverse=True)
-            probe = {t: cpu_baseline(n_all, s_all, t) for t in cand}
+            hist = []
+            probe = {t: cpu_baseline(n_all, s_all, t, hist=hist, heightfield=hf_cpu) for t in cand}
             cores = max(probe, key=probe.get)
             allc = probe[cores]
             out["cpu_baseline"] = {"value": allc, "unit": "env-steps/s", "cores": cores, "kind": "port",
-                                   "sample": "oracle/etgsim_oracle.cpp fp64, %d envs x %d steps on %d persistent threads (each runs "
-                                             "its robots through all the steps; best of the thread counts probed); single-thread: "
-                                             "%.0f env-steps/s (64 envs x 60 steps)" % (n_all, s_all, cores, one),
+                                   "solver": {"max_sweeps": SOLVER[0], "residual_threshold": SOLVER[1]},
+                                   "sample": "oracle/etgsim_oracle.cpp fp64, same contact-solver rule as `value`, %d envs x %d steps on %d "
+                                             "persistent threads (each runs its robots through all the steps; best of the thread counts "
+                                             "probed); single-thread: %.0f env-steps/s (64 envs x 60 steps)" % (n_all, s_all, cores, one),
                                    "single_thread": one,
                                    "host": {"logical_cpus": logical, "affinity_cpus": affinity, "cgroup_cpu_quota": quota,
                                             "threads_probed": {str(t): v for t, v in probe.items()}},
                                    "gpu_over_cpu": value / allc,
                                    "gpu_over_cpu_denominator": "port (this repo's fp64 oracle on all host threads); pybullet itself is "
                                                                "not available on the box, so the >=100x-over-pybullet clause is unmeasured"}
+            # per-robot sweep counts of the rule on this workload (the oracle is the rule's definition): first 50 control steps
+            out["config"]["solver"]["oracle_sweeps_per_tick_per_robot"] = sweep_summary(hist[0])
+            # like-for-like CPU figures for the fixed-count legs
+            for kfix in (50, 2):
+                key = "solver_iters_%d" % kfix
+                if key in out:
+                    v = cpu_baseline(n_all if kfix == 2 else max(64, n_all // 4), s_all, cores, solver=(kfix, 0.0), heightfield=hf_cpu)
+                    out[key]["cpu_baseline"] = {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port"}
+                    out[key]["gpu_over_cpu"] = out[key]["value"] / v
             # the reference's real engine, if this box happens to have it; never expected here
             try:
                 sys.path.insert(0, os.path.join(ROOT, "tools"))

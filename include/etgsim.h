@@ -62,6 +62,8 @@ extern "C" {
 #define ETG_INFO_RPY 58          /* 3 : true roll pitch yaw                        */
 #define ETG_INFO_ENERGY 61       /* 1 : sum_ticks sum_j |tau_j qd_j| dt            */
 #define ETG_INFO_STEPS 62        /* 1 : control steps since reset                  */
+#define ETG_INFO_SWEEPS 63       /* 1 : contact-solver sweeps EXECUTED for this robot during the step, summed over its ticks:
+                                        the count of the slowest robot sharing its wavefront (what the step cost) */
 
 /* optional sensors of train.py:268-271 (sensor_mode ETG_obs / footpose / dynamic_vec / force_vec): columns of the
  * [N, ETG_EXTRA_DIM] row etg_extra_sensors() writes.  rlschool's own definitions are absent from the reference
@@ -113,7 +115,7 @@ typedef struct EtgConfig {
   int32_t num_envs;
   int32_t action_repeat;   /* physics ticks per control step (13)              */
   int32_t settle_ticks;    /* ticks holding pose_ori on reset (500, a1.py:294) */
-  int32_t solver_iters;    /* PGS sweeps per tick                              */
+  int32_t solver_iters;    /* PGS sweeps per tick: the count, or the cap when solver_residual > 0 */
   int32_t enable_action_interp; /* minitaur.py:1384-1401                        */
   int32_t enable_action_filter; /* action_filter.py (Butterworth), default off */
   int32_t obs_normal;      /* `normal` kwarg, EnvWrapper.py:66-87              */
@@ -171,6 +173,18 @@ typedef struct EtgConfig {
   int32_t joint_limits;
   double joint_lower[3], joint_upper[3];   /* hip, thigh, calf (rad) */
   double trunk_half[3];                    /* half extents of the trunk's collision box (body_contacts = 2), base frame */
+  /* Stopping rule of the contact solve.  > 0: after every projected Gauss-Seidel sweep of a tick the robot's residual
+   *     max over its active rows r of ((lambda_r - lambda_r at the start of the sweep) * A_rr)^2
+   * (A_rr = the row's diagonal Delassus entry: the square of the velocity change the row's own impulse change produced) is
+   * compared with solver_residual; the tick stops sweeping when it is <= solver_residual or after solver_iters sweeps,
+   * whichever comes first (at least one sweep).  This is the least-squares-residual exit of Bullet's sequential-impulse
+   * loop (stepSimulation, minitaur.py:244): pybullet documents numSolverIterations = 50 and
+   * solverResidualThreshold = 1e-7, the defaults of default_config.  0: exactly solver_iters sweeps every tick.      */
+  double solver_residual;
+  /* friction cone handling of a foot's two tangent rows: 0 = after both rows the pair is projected on the disc of radius
+   * mu lambda_n (isotropic Coulomb cone); 1 = each direction clamped on its own to +-mu lambda_n inside its row solve
+   * (the friction pyramid of a sequential-impulse solver with two friction directions).                              */
+  int32_t friction_model;
 } EtgConfig;
 
 typedef struct EtgHandle EtgHandle;
@@ -247,6 +261,17 @@ int etg_episode_stats(EtgHandle* h, float* ret, int32_t* len, void* stream);
  * receives the final observation.                                            */
 int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float* ret, int32_t* len,
                          void* stream);
+
+/* n_steps control steps over a caller-supplied action tape, fused (<= 50 control steps per launch, robot state and control
+ * variables in registers in between): actions [n_steps,N,12] (device, already scaled: what etg_step takes), step s applies
+ * row block s.  The loops it serves know their commands in advance: the dynamics-identification evaluator replays 2 x 100
+ * recorded joint targets and reads info["joint_angle"] and info["obs-IMU"] after every step
+ * (model/Dynamic_parallel_model.py:53-77), the BC teacher replays (BCtrain.py:87-131).  Optional per-step outputs (NULL = not
+ * recorded): rec_joint_angle [n_steps,N,12], rec_imu [n_steps,N,6] (rpy - first rpy, body rates: the info columns),
+ * rec_obs [n_steps,N,49] (without sensor noise), rec_reward [n_steps,N], rec_done [n_steps,N] bytes.  obs [N,49] receives the
+ * final observation; ret / len as etg_episode_stats (may be NULL).  Same arithmetic as n_steps calls of etg_step.       */
+int etg_rollout_actions(EtgHandle* h, const float* actions, int n_steps, float* obs, float* rec_joint_angle, float* rec_imu,
+                        float* rec_obs, float* rec_reward, uint8_t* rec_done, float* ret, int32_t* len, void* stream);
 
 /* ---- kinematics and optional sensors --------------------------------------- */
 /* leg FK + analytic Jacobian of n joint-angle rows q [n,12] (device pointers), through the SAME device routine the

@@ -300,6 +300,8 @@ template <class T> struct Env {
   T tau[12];
   int contact[4];
   T energy;
+  long long sweep_hist[64];   // ticks by the number of PGS sweeps they ran since etgo_create (etgo_sweep_hist)
+  long long sweeps_total;     // all sweeps so far; step_env reports the step's share in info[ETG_INFO_SWEEPS]
 };
 
 template <class T> struct Sim {
@@ -685,7 +687,16 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
   auto apply = [&](int row, T d) {
     for (int r = 0; r < NR; r++) u[r] += A[r][row] * d;
   };
+  // Stopping rule (EtgConfig.solver_residual; etgsim.h states it): after every sweep the velocity-level change each row's
+  // own impulse change produced, d_r = (lam_r - lam_r at the start of the sweep) * A_rr, is squared and the largest value
+  // compared with the threshold -- the least-squares-residual test of Bullet's sequential-impulse loop, which pybullet runs
+  // with numSolverIterations = 50 and solverResidualThreshold = 1e-7.  solver_residual = 0: exactly solver_iters sweeps.
+  const T res_thr = T(s.cfg.solver_residual);
+  const bool pyramid = s.cfg.friction_model == 1;
+  int sweeps = 0;
   for (int it = 0; it < s.cfg.solver_iters; it++) {
+    T lam_start[NR];
+    for (int r = 0; r < NR; r++) lam_start[r] = lam_of(r);
     for (int l = 0; l < 4; l++) {
       if (kactive[l] && !active[l]) {   // the knee row alone
         const int rk = 12 + l;
@@ -702,14 +713,18 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
       apply(r0, ln - e.lam[r0]);
       e.lam[r0] = ln;
       // tangents (sequential), then projection on the friction disc
+      T lim = e.mu * ln;
       for (int k = 1; k < 3; k++) {
         T lt = e.lam[r0 + k] - u[r0 + k] / A[r0 + k][r0 + k];
+        if (pyramid) {   // friction_model 1: each direction clamped on its own to +-mu ln inside its row solve
+          if (lt > lim) lt = lim;
+          if (lt < -lim) lt = -lim;
+        }
         apply(r0 + k, lt - e.lam[r0 + k]);
         e.lam[r0 + k] = lt;
       }
-      T lim = e.mu * ln;
       T nt = std::sqrt(e.lam[r0 + 1] * e.lam[r0 + 1] + e.lam[r0 + 2] * e.lam[r0 + 2]);
-      if (nt > lim) {
+      if (!pyramid && nt > lim) {
         T sc = (nt > 0) ? lim / nt : T(0);
         for (int k = 1; k < 3; k++) {
           T lt = e.lam[r0 + k] * sc;
@@ -725,7 +740,19 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
         klam[l] = lk;
       }
     }
+    sweeps++;
+    if (res_thr > 0) {
+      T res = 0;
+      for (int r = 0; r < NR; r++) {
+        if (!row_active(r)) continue;
+        const T d = (lam_of(r) - lam_start[r]) * A[r][r];
+        if (d * d > res) res = d * d;
+      }
+      if (res <= res_thr) break;
+    }
   }
+  e.sweep_hist[sweeps < 63 ? sweeps : 63]++;
+  e.sweeps_total += sweeps;
   for (int r = 0; r < NR; r++) {
     if (!row_active(r)) continue;
     for (int k = 0; k < NV; k++) vel[k] += MiJt[r][k] * lam_of(r);
@@ -996,6 +1023,7 @@ void step_env(Sim<T>& s, Env<T>& e, const T* action, int donef, T* obs, T* rewar
   const EtgRobotModel& m = s.model;
   const int R_ = s.cfg.action_repeat;
   const T ctrl_dt = T(s.cfg.sim_dt) * T(R_);
+  const long long sweeps_before = e.sweeps_total;
   // ETG at t = (k+1) dt  (fixture convention of gait_action_list_ETG_exp.npy)
   T t = T(e.step_count + 1) * T(s.cfg.etg_dt);
   T etg[12], qdes[12];
@@ -1097,6 +1125,7 @@ void step_env(Sim<T>& s, Env<T>& e, const T* action, int donef, T* obs, T* rewar
     for (int k = 0; k < 3; k++) { info[ETG_INFO_BASE + k] = e.pos[k]; info[ETG_INFO_RPY + k] = rpy[k]; }
     info[ETG_INFO_ENERGY] = e.energy;
     info[ETG_INFO_STEPS] = T(e.step_count);
+    info[ETG_INFO_SWEEPS] = T(e.sweeps_total - sweeps_before);   // this robot's own sweeps (the kernels report the wave's)
   }
   for (int k = 0; k < 3; k++) e.last_base[k] = e.pos[k];
   for (int k = 0; k < 12; k++) e.last_foot_w[k] = fw[k];
@@ -1260,6 +1289,15 @@ template <class F> void par_for(int n, int threads, F f) {
     s->dbgM = M; s->dbgC = C;                                                                       \
     physics_tick(*s, copy, tau);                                                                    \
     s->dbgM = nullptr; s->dbgC = nullptr;                                                           \
+  }                                                                                                 \
+  /* out[64]: ticks by PGS sweep count, summed over the robots (mask NULL = all); clear != 0 zeroes the counters */   \
+  extern "C" void etgo_sweep_hist##SFX(void* h, long long* out, const uint8_t* mask, int clear) {    \
+    auto* s = (Sim<T>*)h;                                                                           \
+    for (int k = 0; k < 64; k++) out[k] = 0;                                                        \
+    for (int i = 0; i < s->N; i++) {                                                                \
+      if (mask && !mask[i]) continue;                                                               \
+      for (int k = 0; k < 64; k++) { out[k] += s->env[i].sweep_hist[k]; if (clear) s->env[i].sweep_hist[k] = 0; } \
+    }                                                                                               \
   }                                                                                                 \
   extern "C" void etgo_get_lambda##SFX(void* h, T* lam) {                                           \
     auto* s = (Sim<T>*)h;                                                                           \

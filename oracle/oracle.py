@@ -140,6 +140,14 @@ class OracleSim:
         self._f("run_steps")(self._h, _p(a), int(nsteps), int(threads or self.threads), _p(ret), _p(ln))
         return ret, ln
 
+    def sweep_hist(self, mask=None, clear=True):
+        """ticks by the number of PGS sweeps they ran, summed over the (masked) robots since the last clear -> int64[64]"""
+        out = np.zeros(64, dtype=np.int64)
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        self._f("sweep_hist")(self._h, _p(out), _p(mask), int(bool(clear)))
+        return out
+
     def get_state(self):
         st = np.zeros((self.N, A.STATE_DIM), dtype=self.dtype)
         self._f("get_state")(self._h, _p(st))

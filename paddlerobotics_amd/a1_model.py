@@ -31,8 +31,9 @@ INFO_SLICES = {
     "badfoot": (5, 6), "footcontact": (6, 7), "done": (7, 8), "velx": (8, 9),
     "ETG_act": (9, 21), "joint_angle": (21, 33), "obs-IMU": (33, 39),
     "FootContactSensor": (39, 43), "real_action": (43, 55), "base": (55, 58),
-    "rpy": (58, 61), "energy": (61, 62), "steps": (62, 63),
+    "rpy": (58, 61), "energy": (61, 62), "steps": (62, 63), "solver_sweeps": (63, 64),
 }
+INFO_SWEEPS = 63   # ETG_INFO_SWEEPS
 
 # reward-term order of EtgConfig.reward_w
 REWARD_KEYS = ("torso", "feet", "up", "tau", "stand", "badfoot", "footcontact", "done")
@@ -83,6 +84,8 @@ class EtgConfig(C.Structure):
         ("joint_limits", C.c_int32),
         ("joint_lower", C.c_double * 3), ("joint_upper", C.c_double * 3),
         ("trunk_half", C.c_double * 3),
+        ("solver_residual", C.c_double),
+        ("friction_model", C.c_int32),
     ]
 
 
@@ -180,19 +183,32 @@ def butter2_lowpass(fc, fs):
     return (b0, 2 * b0, b0), (1.0, 2 * (k * k - 1) * norm, (1 - k / q + k * k) * norm)
 
 
-def default_config(num_envs, *, action_repeat=13, sim_dt=0.002, settle_ticks=500, solver_iters=2,
+SOLVER_ITERS = 50          # pybullet numSolverIterations (setPhysicsEngineParameter default)
+SOLVER_RESIDUAL = 1e-7     # pybullet solverResidualThreshold (default)
+
+
+def solver_rule(solver_iters=None, solver_residual=None):
+    """(sweep cap, residual threshold) of the contact solve.  Nothing given: pybullet's documented defaults -- up to 50
+    sweeps per tick with the 1e-7 residual exit.  Only a sweep count: exactly that many sweeps (residual test off)."""
+    if solver_iters is None:
+        return SOLVER_ITERS, (SOLVER_RESIDUAL if solver_residual is None else float(solver_residual))
+    return int(solver_iters), (0.0 if solver_residual is None else float(solver_residual))
+
+
+def default_config(num_envs, *, action_repeat=13, sim_dt=0.002, settle_ticks=500, solver_iters=None, solver_residual=None,
                    enable_action_interp=False, enable_action_filter=False, normal=1, terrain=0,
                    erp=0.2, contact_margin=0.02, warmstart=0.85, torque_limit=0.0,
                    ETG_T=0.5, ETG_T2=0.5, etg_amp=0.2, etg_sigma_sq=0.04,
                    etg_phase=(-math.pi / 2, 0.0), reward_param=None, reward_p=5.0, vel_d=0.5,
                    heightfield=None, lanes_per_robot=0, motor_mode=0, clip_motor_commands=0.0,
-                   body_contacts=0, knee_radius=0.02, enable_etg=1, joint_limits=0):
+                   body_contacts=0, knee_radius=0.02, enable_etg=1, joint_limits=0, friction_model=0):
     """EtgConfig with the defaults of train.py:296-297,470-487 and SURVEY App. A."""
     c = EtgConfig()
     c.num_envs = int(num_envs)
     c.action_repeat = int(action_repeat)
     c.settle_ticks = int(settle_ticks)
-    c.solver_iters = int(solver_iters)
+    c.solver_iters, c.solver_residual = solver_rule(solver_iters, solver_residual)
+    c.friction_model = int(friction_model)
     c.enable_action_interp = int(bool(enable_action_interp))
     c.enable_action_filter = int(bool(enable_action_filter))
     c.obs_normal = int(bool(normal))

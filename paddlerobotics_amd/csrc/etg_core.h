@@ -195,6 +195,7 @@ template <class F> struct LaneState {
   F q[3], qd[3], lam[3];
   F contact;          // 1 if this lane's foot carried load in the last tick
   F energy;           // sum |tau qd| dt of this lane's joints since the step began
+  int sweeps;         // PGS sweeps this wave executed since the step began (wave-uniform; not stored)
 };
 
 template <class F, class Ctx> ETG_HD LaneState<F> load_state(const Ctx& c, const float* base, const float* leg) {
@@ -208,6 +209,7 @@ template <class F, class Ctx> ETG_HD LaneState<F> load_state(const Ctx& c, const
   }
   L.contact = c.ld_lane(leg, LG_CONTACT);
   L.energy = F(0.0f);
+  L.sweeps = 0;
   return L;
 }
 template <class F, class Ctx> ETG_HD void store_state(const Ctx& c, float* base, float* leg, const LaneState<F>& L) {
@@ -532,8 +534,12 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   //   (lt1, lt2) *= min(1, mu ln / |lt|)
   // and lane j's raw deltas are broadcast unmasked: an inactive foot has iA = 0 and l = 0, which
   // makes its deltas exact zeros.
-  const F mu = tp.mu;
-  const F k10 = Aown[1][0] * iA1, k20 = Aown[2][0] * iA2, k21 = Aown[2][1] * iA2, c0 = tgt * iA0;
+  // The sweeps read iA*, k*, c0, mu through the variables below: under the residual stopping rule a converged robot is
+  // FROZEN for the sweeps its wave neighbours still need (iA = k = c0 = 0: every candidate is the current impulse, exact
+  // zero deltas; mu = 1e30: the cone projection is the identity) -- see physics_tick16.
+  F mu = tp.mu;
+  F k10 = Aown[1][0] * iA1, k20 = Aown[2][0] * iA2, k21 = Aown[2][1] * iA2, c0 = tgt * iA0;
+  const bool pyramid = !Ctx::kPlain && K.fric_pyramid;
   F own[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) own[j] = sel_(c.lane_is(j), one, zero);
@@ -543,10 +549,19 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
       F ln = fmaxf_(zero, (l0 + c0) - u0 * iA0);
       F q1 = (l1 - u1 * iA1) + k10 * l0;
       F lt1 = q1 - k10 * ln;
-      F q2 = ((l2 - u2 * iA2) + k20 * l0) + k21 * l1;
-      F lt2 = (q2 - k20 * ln) - k21 * lt1;
-      F sc = fminf_(one, (mu * ln) * rsqrt_(fmaxf_(lt1 * lt1 + lt2 * lt2, F(1e-30f))));
-      F e0 = ln - l0, e1 = lt1 * sc - l1, e2 = lt2 * sc - l2;
+      F e0 = ln - l0, e1, e2;
+      if (pyramid) {   // friction_model 1: each direction clamped on its own to +-mu ln inside its row solve
+        const F lim = mu * ln;
+        lt1 = fminf_(fmaxf_(lt1, -lim), lim);
+        F q2 = ((l2 - u2 * iA2) + k20 * l0) + k21 * l1;
+        F lt2 = fminf_(fmaxf_((q2 - k20 * ln) - k21 * lt1, -lim), lim);
+        e1 = lt1 - l1; e2 = lt2 - l2;
+      } else {
+        F q2 = ((l2 - u2 * iA2) + k20 * l0) + k21 * l1;
+        F lt2 = (q2 - k20 * ln) - k21 * lt1;
+        F sc = fminf_(one, (mu * ln) * rsqrt_(fmaxf_(lt1 * lt1 + lt2 * lt2, F(1e-30f))));
+        e1 = lt1 * sc - l1; e2 = lt2 * sc - l2;
+      }
       F b0 = c.qbcast(e0, j), b1 = c.qbcast(e1, j), b2 = c.qbcast(e2, j);
       u0 = u0 + A[j][0][0] * b0 + A[j][0][1] * b1 + A[j][0][2] * b2;
       u1 = u1 + A[j][1][0] * b0 + A[j][1][1] * b1 + A[j][1][2] * b2;
@@ -554,14 +569,31 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
       l0 = l0 + own[j] * e0; l1 = l1 + own[j] * e1; l2 = l2 + own[j] * e2;  // the owner commits
     }
   };
-  if (Ctx::kPlain) {   // plain_config: two sweeps, straight-line (see physics_tick16)
+  if (K.res_thr > 0.0f) {
+    // EtgConfig.solver_residual: sweep until the robot's largest squared row residual is <= the threshold (see
+    // physics_tick16); one quad max per sweep, the loop ends when every robot of the wave is done
+    const F thr(K.res_thr);
+    int it = 0;
+    do {
+      const F s0 = l0, s1 = l1, s2 = l2;
+      pgs_sweep();
+      it++;
+      const F d0 = (l0 - s0) * Aown[0][0], d1 = (l1 - s1) * Aown[1][1], d2 = (l2 - s2) * Aown[2][2];
+      const auto live = c.qmax(fmaxf_(fmaxf_(d0 * d0, d1 * d1), d2 * d2)) > thr;
+      iA0 = sel_(live, iA0, zero); iA1 = sel_(live, iA1, zero); iA2 = sel_(live, iA2, zero);
+      k10 = sel_(live, k10, zero); k20 = sel_(live, k20, zero); k21 = sel_(live, k21, zero);
+      c0 = sel_(live, c0, zero);
+      mu = sel_(live, mu, F(1e30f));
+      if (!c.wave_any(live)) break;
+    } while (it < K.iters);
+    L.sweeps += it;
+  } else if (K.iters == 2) {   // a fixed pair of sweeps, straight-line (see physics_tick16)
     pgs_sweep();
     pgs_sweep();
-  } else if (K.iters == 2) {   // the default sweep count, straight-line as well (a uniform, not-taken branch per tick)
-    pgs_sweep();
-    pgs_sweep();
+    L.sweeps += 2;
   } else {
     for (int it = 0; it < K.iters; it++) pgs_sweep();
+    L.sweeps += K.iters;
   }
   c.phase(8);
   // ---- apply impulses: base via the Schur factor, leg via H^-1
@@ -877,7 +909,8 @@ template <class F, class Ctx>
 ETG_HD void control_step_core(const Ctx& c, const KCfg& K, TickPar4<F>& tp, const V3<F>& fext, LaneState<F>& L, StepCtl4<F>& S,
                               float* ring, const float* etgp, const F* action, F donef, float* obs, F& reward, F& done,
                               float* info, const F* hyb = nullptr,     // hyb[4*j + (kp, qd_des, kd, tau_ff)], HYBRID mode
-                              bool want_obs = true) {                  // false: inner steps of the open-loop rollout (row unread)
+                              bool want_obs = true,                    // false: inner steps of the open-loop rollout (row unread)
+                              float* rec_q = nullptr, float* rec_imu = nullptr) {   // action-tape rollouts: see control_step16_core
   int step_count = S.step_count;
   int tick = S.tick;
   const int has_last = S.has_last;
@@ -901,6 +934,7 @@ ETG_HD void control_step_core(const Ctx& c, const KCfg& K, TickPar4<F>& tp, cons
   const F last[3] = {S.last[0], S.last[1], S.last[2]};
   const F lbx = S.lbx, lby = S.lby, lbz = S.lbz, last_fwx = S.last_fwx;
   L.energy = F(0.0f);
+  L.sweeps = 0;
   const bool interp = !Ctx::kPlain && K.enable_interp && has_last;
   // Only the two readings a later observation will blend (minitaur.py:1185-1193: ticks T-n and
   // T-n-1 of some step end T) have to reach the ring: (i+1+n) mod R in {0, R-1}, i.e. i == ia or i == ib.
@@ -929,6 +963,10 @@ ETG_HD void control_step_core(const Ctx& c, const KCfg& K, TickPar4<F>& tp, cons
 
   F imu[6] = {F(0.0f), F(0.0f), F(0.0f), F(0.0f), F(0.0f), F(0.0f)};
   if (want_obs || info) write_obs(c, K, L, ring_read<F>(c, K, ring, tick), S.r0, S.r1, S.r2, etg, lbx, lby, lbz, obs, imu);
+  if (rec_q)
+    for (int j = 0; j < 3; j++) c.st_row_lane(rec_q, ETG_ACT_DIM, j, 3, L.q[j]);
+  if (rec_imu)
+    for (int k = 0; k < 6; k++) c.st_row_env(rec_imu, 6, k, imu[k]);
 
   // ---- reward / termination (this repo's definitions)
   const float cdt = K.dt * (float)K.action_repeat;
@@ -974,7 +1012,7 @@ ETG_HD void control_step_core(const Ctx& c, const KCfg& K, TickPar4<F>& tp, cons
     c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_RPY + 2, rpy.z);
     c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_ENERGY, energy);
     c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_STEPS, F((float)step_count));
-    for (int k = ETG_INFO_STEPS + 1; k < ETG_INFO_DIM; k++) c.st_row_env(info, ETG_INFO_DIM, k, F(0.0f));
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_SWEEPS, F((float)L.sweeps));
   }
   S.lbx = L.p.x; S.lby = L.p.y; S.lbz = L.p.z;
   S.last_fwx = fk.fwx;
@@ -1028,6 +1066,7 @@ ETG_HD void reset_settle(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   for (int j = 0; j < 3; j++) { L.q[j] = pose[j]; L.qd[j] = F(0.0f); L.lam[j] = F(0.0f); }
   L.contact = F(0.0f);
   L.energy = F(0.0f);
+  L.sweeps = 0;
   // ReceiveObservation before settling (a1.py:290): seed every ring slot with the initial reading
   for (int sl = 0; sl < RING; sl++) ring_push(c, ring, sl, L);
   int tick = 0;

@@ -29,6 +29,7 @@ template <class F> struct State16 {
   F lam;         // this lane's contact row impulse (row = sub: n, t1, t2)
   F contact;     // leg-level flag, replicated in the quad
   F energy;
+  int sweeps;    // PGS sweeps this wave executed since the step began (wave-uniform; not part of the stored state)
 };
 
 template <class F, class Ctx> ETG_HD State16<F> load_state16(const Ctx& c, const float* base, const float* leg) {
@@ -43,6 +44,7 @@ template <class F, class Ctx> ETG_HD State16<F> load_state16(const Ctx& c, const
   L.lam = mj * c.ld_joint(leg, LG_LAM);
   L.contact = c.ld_legf(leg, LG_CONTACT);
   L.energy = F(0.0f);
+  L.sweeps = 0;
   return L;
 }
 template <class F, class Ctx> ETG_HD void store_state16(const Ctx& c, float* base, float* leg, const State16<F>& L) {
@@ -394,8 +396,12 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   c.phase(7);
   // ---- projected Gauss-Seidel, rows in the order (FR n,t1,t2), (FL ...), (RR ...), (RL ...): the owner
   // lane's candidate is broadcast over the row with row_newbcast and applied by every lane.
-  const F mu = tp.mu;
-  const F c0 = tgt * iA;
+  // The sweeps read their per-lane constants through `iAe`, `c0e`, `mue`: under the residual stopping rule a robot that has
+  // converged is FROZEN for the sweeps the other robots of its wave still need -- iAe = c0e = 0 make every candidate equal
+  // the current impulse (all deltas exact zeros), mue = 1e30 makes the cone projection the identity -- so a robot's result
+  // does not depend on its wave neighbours (batch invariance) and equals the oracle's, which stops per robot.
+  F iAe = iA, c0e = tgt * iA, mue = tp.mu;
+  const bool pyramid = !Ctx::kPlain && K.fric_pyramid;
   const F tangf = f1 + f2;
   // owner masks of the three rows of every leg, hoisted out of the sweeps (1 on the lane that owns row e of leg lp)
   F mk[4][3], mt[4];
@@ -409,45 +415,75 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
     for (int lp = 0; lp < 4; lp++) {
       // normal row: ln = max(0, lam - (u - tgt)/A); the owner's lam update sits between the candidate and its
       // broadcast, where the DPP read needs two wait states anyway
-      F dln = fmaxf_(zero, (lam + c0) - u * iA) - lam;
+      F dln = fmaxf_(zero, (lam + c0e) - u * iAe) - lam;
       lam = lam + mk[lp][0] * dln;
       F b = c.rbcast(dln, 4 * lp);
       u = u + A[lp][0] * b;
-      // tangent rows, sequentially
-      F dt1 = -(u * iA);
-      lam = lam + mk[lp][1] * dt1;
-      b = c.rbcast(dt1, 4 * lp + 1);
-      u = u + A[lp][1] * b;
-      F dt2 = -(u * iA);
-      lam = lam + mk[lp][2] * dt2;
-      b = c.rbcast(dt2, 4 * lp + 2);
-      u = u + A[lp][2] * b;
-      // projection of (lt1, lt2) on the friction disc mu * ln
-      F lim = mu * c.qb(lam, 0);
-      F oth = c.qswap12(lam);
-      F sc = fminf_(one, lim * rsqrt_(fmaxf_(lam * lam + oth * oth, F(1e-30f))));
-      F dp = mt[lp] * (lam * sc - lam);
-      F b1 = c.rbcast(dp, 4 * lp + 1), b2 = c.rbcast(dp, 4 * lp + 2);
-      u = u + A[lp][1] * b1 + A[lp][2] * b2;
-      lam = lam + dp;
+      if (pyramid) {
+        // friction_model 1: each tangent direction clamped on its own to +-mu ln inside its row solve
+        const F lim = mue * c.qb(lam, 0);
+        F dt1 = fminf_(fmaxf_(lam - u * iAe, -lim), lim) - lam;
+        lam = lam + mk[lp][1] * dt1;
+        b = c.rbcast(dt1, 4 * lp + 1);
+        u = u + A[lp][1] * b;
+        F dt2 = fminf_(fmaxf_(lam - u * iAe, -lim), lim) - lam;
+        lam = lam + mk[lp][2] * dt2;
+        b = c.rbcast(dt2, 4 * lp + 2);
+        u = u + A[lp][2] * b;
+      } else {
+        // tangent rows, sequentially
+        F dt1 = -(u * iAe);
+        lam = lam + mk[lp][1] * dt1;
+        b = c.rbcast(dt1, 4 * lp + 1);
+        u = u + A[lp][1] * b;
+        F dt2 = -(u * iAe);
+        lam = lam + mk[lp][2] * dt2;
+        b = c.rbcast(dt2, 4 * lp + 2);
+        u = u + A[lp][2] * b;
+        // projection of (lt1, lt2) on the friction disc mu * ln
+        F lim = mue * c.qb(lam, 0);
+        F oth = c.qswap12(lam);
+        F sc = fminf_(one, lim * rsqrt_(fmaxf_(lam * lam + oth * oth, F(1e-30f))));
+        F dp = mt[lp] * (lam * sc - lam);
+        F b1 = c.rbcast(dp, 4 * lp + 1), b2 = c.rbcast(dp, 4 * lp + 2);
+        u = u + A[lp][1] * b1 + A[lp][2] * b2;
+        lam = lam + dp;
+      }
       if (knee) {   // the leg's knee row, after its foot rows: lk = max(0, lk - (u - tgt)/A)
-        F dlk = fmaxf_(zero, (lam + c0) - u * iA) - lam;
+        F dlk = fmaxf_(zero, (lam + c0e) - u * iAe) - lam;
         lam = lam + ownl[lp] * f3 * dlk;
         F bk = c.rbcast(dlk, 4 * lp + 3);
         u = u + Ak[lp] * bk;
       }
     }
   };
-  if (Ctx::kPlain) {
-    // the PLAIN instantiations are only launched with the library's default of two sweeps (plain_config): straight-line
-    // code, no loop back-edge inside the tick (a taken branch is expensive for a lone wave) -- 35.5 -> 34.2 us per step
+  if (K.res_thr > 0.0f) {
+    // EtgConfig.solver_residual (etgsim.h): sweep until the robot's largest squared row residual
+    // ((lam - lam at the start of the sweep) * A_rr)^2 is <= the threshold, K.iters sweeps at most.  One 16-lane max per
+    // sweep; the loop ends when every robot of the wave is done (wave-uniform branch).
+    const F thr(K.res_thr);
+    int it = 0;
+    do {
+      const F lam0 = lam;
+      pgs_sweep();
+      it++;
+      const F d = (lam - lam0) * Add;
+      const auto live = c.max16(d * d) > thr;
+      iAe = sel_(live, iAe, zero);
+      c0e = sel_(live, c0e, zero);
+      mue = sel_(live, mue, F(1e30f));
+      if (!c.wave_any(live)) break;
+    } while (it < K.iters);
+    L.sweeps += it;
+  } else if (K.iters == 2) {
+    // a fixed pair of sweeps (the round-1/2 default) as straight-line code: no loop back-edge inside the tick (a taken
+    // branch is expensive for a lone wave) -- 35.5 -> 34.2 us per step
     pgs_sweep();
     pgs_sweep();
-  } else if (K.iters == 2) {   // the default sweep count, straight-line as well (a uniform, not-taken branch per tick)
-    pgs_sweep();
-    pgs_sweep();
+    L.sweeps += 2;
   } else {
     for (int it = 0; it < K.iters; it++) pgs_sweep();
+    L.sweeps += K.iters;
   }
   c.phase(8);
   // ---- apply impulses: base via the Schur factor, joints via H^-1
@@ -719,8 +755,10 @@ template <class F, class Ctx>
 ETG_HD void control_step16_core(const Ctx& c, const KCfg& K, TickPar<F>& tp, State16<F>& L, StepCtl16<F>& S, float* ring,
                                 const float* etgp, F action, F donef, float* obs, F& reward, F& done, float* info,
                                 const F* hyb = nullptr,     // hyb: (kp, qd_des, kd, tau_ff) of this lane's motor, HYBRID mode
-                                bool want_obs = true) {     // false (inner steps of the open-loop rollout): the observation row is not
+                                bool want_obs = true,       // false (inner steps of the open-loop rollout): the observation row is not
                                                             // read by anybody -- skip the delayed reading and the row (info needs it)
+                                float* rec_q = nullptr,     // action-tape rollouts: rows [N,12] / [N,6] receiving info["joint_angle"] and
+                                float* rec_imu = nullptr) { // info["obs-IMU"] of this step (Dynamic_parallel_model.py:63-64)
   const F mj = c.jointf();
   // EtgConfig.enable_etg = 0 (Dynamic_parallel_model.py:49 `ETG=0`): no generator, the command is pose_ori + action
   F etg = (Ctx::kPlain || K.etg_on) ? etg_action16<F>(c, K, etgp, (float)(S.step_count + 1) * K.etg_dt) : F(0.0f);
@@ -735,6 +773,7 @@ ETG_HD void control_step16_core(const Ctx& c, const KCfg& K, TickPar<F>& tp, Sta
   }
   const F last = S.last, lbx = S.lbx, lby = S.lby, lbz = S.lbz, last_fwx = S.last_fwx;
   L.energy = F(0.0f);
+  L.sweeps = 0;
   const bool interp = !Ctx::kPlain && K.enable_interp && S.has_last;
   // The observation at the end of the step reads ring slots tick_end - n and tick_end - n - 1 only, so
   // only the ticks that land there are pushed: i == ia or i == ib (one modulo per step, not two per tick).
@@ -760,6 +799,9 @@ ETG_HD void control_step16_core(const Ctx& c, const KCfg& K, TickPar<F>& tp, Sta
 
   F imu[6] = {F(0.0f), F(0.0f), F(0.0f), F(0.0f), F(0.0f), F(0.0f)};
   if (want_obs || info) write_obs16(c, K, L, ring_read16<F>(c, K, ring, tick), S.r0, S.r1, S.r2, etg, lbx, lby, lbz, obs, imu);
+  if (rec_q) c.st_row_joint(rec_q, ETG_ACT_DIM, 0, L.q);
+  if (rec_imu)
+    for (int k = 0; k < 6; k++) c.st_row_env(rec_imu, 6, k, imu[k]);
 
   const float cdt = K.dt * (float)K.action_repeat;
   Rows<F> Rw = quat_rows(L.qx, L.qy, L.qz, L.qw);
@@ -803,7 +845,7 @@ ETG_HD void control_step16_core(const Ctx& c, const KCfg& K, TickPar<F>& tp, Sta
     c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_RPY + 2, rpy.z);
     c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_ENERGY, energy);
     c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_STEPS, F((float)S.step_count));
-    for (int k = ETG_INFO_STEPS + 1; k < ETG_INFO_DIM; k++) c.st_row_env(info, ETG_INFO_DIM, k, F(0.0f));
+    c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_SWEEPS, F((float)L.sweeps));
   }
   S.lbx = L.p.x; S.lby = L.p.y; S.lbz = L.p.z;
   S.last_fwx = fk.fwx;
@@ -854,6 +896,7 @@ ETG_HD void reset_settle16(const Ctx& c, const KCfg& K, State16<F>& L, float* ri
   L.q = pose; L.qd = F(0.0f); L.lam = F(0.0f);
   L.contact = F(0.0f);
   L.energy = F(0.0f);
+  L.sweeps = 0;
   for (int sl = 0; sl < RING; sl++) ring_push16(c, ring, sl, L);
   int tick = 0;
   const TickPar<F> tp = load_tick_par<F>(c);

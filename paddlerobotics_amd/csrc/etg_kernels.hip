@@ -93,6 +93,7 @@ struct GpuCtx {
   }
   __device__ __forceinline__ bool lane_is(int j) const { return lane == j; }
   __device__ __forceinline__ bool any(bool b) const { return __any(b); }
+  __device__ __forceinline__ bool wave_any(bool b) const { return __any(b); }   // "does any robot of the wave need another sweep?"
   __device__ __forceinline__ int uniform_int(float a) const { return (int)a; }
   __device__ __forceinline__ void terrain(const KCfg& K, float x, float y, float& h, float& nx, float& ny, float& nz) const {
     if (K.terrain == 0) { h = 0.0f; nx = 0.0f; ny = 0.0f; nz = 1.0f; }
@@ -363,6 +364,40 @@ __global__ void __launch_bounds__(BLOCK) k_rollout(KCfg K, DevState D, int n_ste
   store_state(c, D.base, D.leg, L);
 }
 
+// n_steps control steps over a caller-supplied action tape [n_steps][N][12] in one launch (etg_rollout_actions): the
+// dynamics-identification evaluator's 2 x 100 steps of known joint targets (Dynamic_parallel_model.py:53-77) and teacher
+// replays.  T: optional per-step outputs ([n_steps][N][...], null = not recorded).
+struct TapeOut { float *q, *imu, *obs, *rew; uint8_t* done; };
+template <bool FLAT, bool PLAIN>
+__global__ void __launch_bounds__(BLOCK) k_rollout_actions(KCfg K, DevState D, int n_steps, const float* actions, float* obs, TapeOut T) {
+  GpuCtxT<FLAT, PLAIN> c;
+  if (!make_ctx(K, c)) return;
+  __shared__ float lds_par[PR_N * BLOCK];
+  stage_params(c, D, lds_par);
+  LaneState<float> L = load_state<float>(c, D.base, D.leg);
+  StepCtl4<float> S = load_ctl4<float>(c, K, D.ctl, D.ictl, D.legctl);
+  TickPar4<float> tp = load_tick_par4<float>(c);
+  V3<float> fext = {0.0f, 0.0f, 0.0f};
+  if (!PLAIN && K.ext_force) fext = {c.ld_env(D.ctl, CT_FEXT + 0) + c.ld_env(D.ctl, CT_PUSH + 0), c.ld_env(D.ctl, CT_FEXT + 1) + c.ld_env(D.ctl, CT_PUSH + 1),
+                                     c.ld_env(D.ctl, CT_FEXT + 2) + c.ld_env(D.ctl, CT_PUSH + 2)};
+  const size_t N = K.n_env;
+  float reward, done;
+  for (int s = 0; s < n_steps; s++) {
+    const float* a = actions + (size_t)s * N * ETG_ACT_DIM;
+    const float act[3] = {c.ld_row_lane(a, ETG_ACT_DIM, 0, 3), c.ld_row_lane(a, ETG_ACT_DIM, 1, 3), c.ld_row_lane(a, ETG_ACT_DIM, 2, 3)};
+    const bool last = s == n_steps - 1;
+    control_step_core(c, K, tp, fext, L, S, D.ring, D.etgp, act, 0.0f, (T.obs && !last) ? T.obs + (size_t)s * N * ETG_OBS_DIM : obs, reward, done,
+                      (float*)nullptr, (const float*)nullptr, last || T.obs || T.imu, T.q ? T.q + (size_t)s * N * ETG_ACT_DIM : nullptr,
+                      T.imu ? T.imu + (size_t)s * N * 6 : nullptr);
+    if (c.lane == 0) {
+      if (T.rew) T.rew[(size_t)s * N + c.env] = reward;
+      if (T.done) T.done[(size_t)s * N + c.env] = done > 0.5f ? 1 : 0;
+    }
+  }
+  store_ctl4(c, K, S, D.ctl, D.ictl, D.legctl);
+  store_state(c, D.base, D.leg, L);
+}
+
 // ====================================================================== 16 lanes per robot
 // One robot = one 16-lane DPP row (etg_core16.h): lane r = 4*leg + sub.  A workgroup is still one
 // wave64 = 4 robots; 4096 robots -> 1024 workgroups = one wave on every SIMD of the chip.
@@ -378,6 +413,7 @@ struct GpuCtx16 {
   __device__ __forceinline__ bool sub_is(int j) const { return sub == j; }
   __device__ __forceinline__ bool leg_is(int j) const { return leg == j; }
   __device__ __forceinline__ bool any(bool b) const { return __any(b); }
+  __device__ __forceinline__ bool wave_any(bool b) const { return __any(b); }   // "does any robot of the wave need another sweep?"
   __device__ __forceinline__ int uniform_int(float a) const { return (int)a; }
   __device__ __forceinline__ float par(int k) const { return lds[k * 64]; }
   __device__ __forceinline__ float par_joint(int base) const { return lds[(base + sc) * 64]; }
@@ -687,6 +723,33 @@ __global__ void __launch_bounds__(BLOCK) k_rollout16(KCfg K, DevState D, int n_s
   if (!make_ctx16(K, D, c, lds_par)) return;
   State16<float> L = load_state16<float>(c, D.base, D.leg);
   rollout_steps16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, n_steps, obs);
+  store_state16(c, D.base, D.leg, L);
+}
+
+// the 16-lane counterpart of k_rollout_actions
+template <bool FLAT, bool KNEE, bool PLAIN>
+__global__ void __launch_bounds__(BLOCK) k_rollout_actions16(KCfg K, DevState D, int n_steps, const float* actions, float* obs, TapeOut T) {
+  __shared__ float lds_par[LDS16_FIELDS * BLOCK];
+  GpuCtx16T<FLAT, KNEE, PLAIN> c;
+  if (!make_ctx16(K, D, c, lds_par)) return;
+  State16<float> L = load_state16<float>(c, D.base, D.leg);
+  StepCtl16<float> S = load_ctl16<float>(c, K, D.ctl, D.ictl, D.legctl);
+  TickPar<float> tp = load_tick_par<float>(c);
+  if (!PLAIN && K.ext_force) tp.fext = load_fext16<float>(c, D.ctl);
+  const size_t N = K.n_env;
+  float reward, done;
+  for (int s = 0; s < n_steps; s++) {
+    const float act = c.ld_row_joint(actions + (size_t)s * N * ETG_ACT_DIM, ETG_ACT_DIM, 0);
+    const bool last = s == n_steps - 1;
+    control_step16_core(c, K, tp, L, S, D.ring, D.etgp, act, 0.0f, (T.obs && !last) ? T.obs + (size_t)s * N * ETG_OBS_DIM : obs, reward, done,
+                        (float*)nullptr, (const float*)nullptr, last || T.obs || T.imu, T.q ? T.q + (size_t)s * N * ETG_ACT_DIM : nullptr,
+                        T.imu ? T.imu + (size_t)s * N * 6 : nullptr);
+    if (c.r == 0) {
+      if (T.rew) T.rew[(size_t)s * N + c.env] = reward;
+      if (T.done) T.done[(size_t)s * N + c.env] = done > 0.5f ? 1 : 0;
+    }
+  }
+  store_ctl16(c, K, S, D.ctl, D.ictl, D.legctl);
   store_state16(c, D.base, D.leg, L);
 }
 
@@ -1022,6 +1085,8 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   if (cfg->action_repeat <= 0 || cfg->sim_dt <= 0) return fail(ETG_ERR_BAD_ARG, "etg_create: bad action_repeat/sim_dt");
   // the rest of the configuration is checked before a device is touched, so a bad one reads the same on any box
   if (cfg->solver_iters <= 0 || cfg->solver_iters > 1000) return fail(ETG_ERR_BAD_ARG, "etg_create: solver_iters must be in 1..1000");
+  if (!(cfg->solver_residual >= 0)) return fail(ETG_ERR_BAD_ARG, "etg_create: solver_residual must be >= 0 (0 = a fixed number of sweeps)");
+  if (cfg->friction_model != 0 && cfg->friction_model != 1) return fail(ETG_ERR_BAD_ARG, "etg_create: friction_model must be 0 (disc) or 1 (pyramid)");
   if (cfg->settle_ticks < 0) return fail(ETG_ERR_BAD_ARG, "etg_create: settle_ticks must not be negative");
   if (cfg->motor_mode < 0 || cfg->motor_mode > 2) return fail(ETG_ERR_BAD_ARG, "etg_create: motor_mode must be 0 (POSITION), 1 (TORQUE) or 2 (HYBRID)");
   if (cfg->body_contacts < 0 || cfg->body_contacts > 2) return fail(ETG_ERR_BAD_ARG, "etg_create: body_contacts must be 0, 1 or 2");
@@ -1343,6 +1408,38 @@ extern "C" int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float
   }
   HIP_TRY(hipGetLastError());
   return etg_episode_stats(h, ret, len, stream);
+}
+
+extern "C" int etg_rollout_actions(EtgHandle* h, const float* actions, int n_steps, float* obs, float* rec_joint_angle, float* rec_imu,
+                                   float* rec_obs, float* rec_reward, uint8_t* rec_done, float* ret, int32_t* len, void* stream) {
+  CHECK_HANDLE(h);
+  if (!actions || n_steps <= 0 || !obs) return fail(ETG_ERR_BAD_ARG, "etg_rollout_actions: actions / obs null or n_steps <= 0");
+  if (!h->was_reset) return fail(ETG_ERR_STATE, "etg_rollout_actions: call etg_reset first");
+  if (h->K.motor_mode == 2) return fail(ETG_ERR_STATE, "etg_rollout_actions: POSITION / TORQUE commands only ([n_steps,N,12] tapes)");
+  if (h->K.noise_on && rec_obs) return fail(ETG_ERR_STATE, "etg_rollout_actions: per-step observations are recorded without sensor noise; switch it off");
+  constexpr int ROLLOUT_CHUNK = 50;
+  const dim3 g16((h->N + 3) / 4), g4(grid_for(h));
+  hipStream_t s = (hipStream_t)stream;
+  const size_t N = h->N;
+  for (int d0 = 0; d0 < n_steps; d0 += ROLLOUT_CHUNK) {
+    const int m = n_steps - d0 < ROLLOUT_CHUNK ? n_steps - d0 : ROLLOUT_CHUNK;
+    advance_obs_stream(h, m);
+    const TapeOut T = {rec_joint_angle ? rec_joint_angle + (size_t)d0 * N * ETG_ACT_DIM : nullptr, rec_imu ? rec_imu + (size_t)d0 * N * 6 : nullptr,
+                       rec_obs ? rec_obs + (size_t)d0 * N * ETG_OBS_DIM : nullptr, rec_reward ? rec_reward + (size_t)d0 * N : nullptr,
+                       rec_done ? rec_done + (size_t)d0 * N : nullptr};
+    const float* a = actions + (size_t)d0 * N * ETG_ACT_DIM;
+    if (h->lanes == 16) {
+      LAUNCH16(k_rollout_actions16, g16, s, h->K, h->D, m, a, obs, T);
+    } else {
+      LAUNCH4(k_rollout_actions, g4, s, h->K, h->D, m, a, obs, T);
+    }
+    launch_obs_noise(h, m, nullptr, obs, s);
+  }
+  HIP_TRY(hipGetLastError());
+  if (rec_obs)   // the last step's row went to `obs`: the tape gets its copy
+    HIP_TRY(hipMemcpyAsync(rec_obs + (size_t)(n_steps - 1) * N * ETG_OBS_DIM, obs, N * ETG_OBS_DIM * sizeof(float), hipMemcpyDeviceToDevice, s));
+  if (ret || len) return etg_episode_stats(h, ret, len, stream);
+  return ETG_OK;
 }
 
 extern "C" int etg_rollout_policy(EtgHandle* h, EtgPolicy* pol, int n_steps, float act_scale, int precision, int obs_col0,

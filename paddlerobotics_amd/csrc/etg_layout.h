@@ -75,12 +75,14 @@ struct KCfg {
   float noise_std[5];
   unsigned long long noise_seed;
   unsigned noise_call;   // stream position of the first observation this launch writes
+  float res_thr;         // EtgConfig.solver_residual: > 0 = sweep until the robot's squared row residual is below it (iters = cap)
+  int fric_pyramid;      // EtgConfig.friction_model == 1: per-direction clamp instead of the disc projection
 };
 
 // the default robot layer (what train.py / pretrain.py run): the PLAIN kernel instantiations compile the options out
 inline bool plain_config(const KCfg& K) {
   return K.motor_mode == 0 && !K.enable_filter && !K.enable_interp && !(K.torque_limit > 0.0f) && !(K.clip_cmd > 0.0f) &&
-         !K.ext_force && !K.knee && K.etg_on && !K.jlim && K.iters == 2;
+         !K.ext_force && !K.knee && K.etg_on && !K.jlim && !K.fric_pyramid;
 }
 
 // counter-based standard normal pair for (seed, robot, observation index, channel): splitmix64 finaliser twice, then
@@ -326,6 +328,8 @@ inline KCfg make_kcfg(const EtgConfig& c, const EtgRobotModel& m) {
   K.knee = c.body_contacts; K.knee_radius = (float)c.knee_radius;
   for (int k = 0; k < 3; k++) K.trunk_half[k] = (float)c.trunk_half[k];
   K.etg_on = c.enable_etg != 0;
+  K.res_thr = (float)c.solver_residual;
+  K.fric_pyramid = c.friction_model == 1;
   K.jlim = c.joint_limits != 0;
   for (int k = 0; k < 3; k++) { K.jlo[k] = (float)c.joint_lower[k]; K.jhi[k] = (float)c.joint_upper[k]; }
   K.hf_cell = (float)c.hf_cell; K.hf_x0 = (float)c.hf_x0; K.hf_y0 = (float)c.hf_y0;

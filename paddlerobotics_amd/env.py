@@ -136,7 +136,8 @@ class BatchedQuadrupedEnv:
                  sensor_mode=None, normal=1, dynamic_param=None, reward_param=None, ETG=1, ETG_T=0.5,
                  reward_p=5.0, ETG_path="", random_param=None, ETG_H=20, vel_d=0.5, step_y=0.05,
                  enable_action_filter=False, ETG_T2=0.5, action_repeat=13, sim_time_step=0.002,
-                 settle_ticks=500, solver_iters=2, enable_action_interpolation=False,
+                 settle_ticks=500, solver_iters=None, solver_residual=None, friction_model=0,
+                 enable_action_interpolation=False,
                  heightfield=None, lanes_per_robot=0, terrain_variants=16, terrain_seed=0,
                  random_dynamics_scale=0.3, random_force_prob=0.02, random_force_steps=8,
                  random_force_range=(5.0, 25.0), seed=0, enable_clip_motor_commands=False,
@@ -182,6 +183,7 @@ class BatchedQuadrupedEnv:
         self._hist_mode = rnn.get("mode", "stack")
         self._hist = None
         self._hist_head = 0
+        self._last_seq = None
         rp = dict(random_param or {})
         self._rand_dyn = bool(rp.get("random_dynamics", 0))
         self._rand_force = bool(rp.get("random_force", 0))
@@ -194,7 +196,8 @@ class BatchedQuadrupedEnv:
         self.ETG = int(ETG)
         self.cfg = A.default_config(
             self.num_envs, action_repeat=action_repeat, sim_dt=sim_time_step, settle_ticks=settle_ticks,
-            solver_iters=solver_iters, enable_action_interp=enable_action_interpolation,
+            solver_iters=solver_iters, solver_residual=solver_residual, friction_model=friction_model,
+            enable_action_interp=enable_action_interpolation,
             enable_action_filter=enable_action_filter, normal=normal,
             terrain=1 if heightfield is not None else 0, ETG_T=ETG_T, ETG_T2=ETG_T2,
             reward_param=reward_param, reward_p=reward_p, vel_d=vel_d, heightfield=heightfield,
@@ -400,11 +403,17 @@ class BatchedQuadrupedEnv:
             last = (self._hist_head + H - 1) % H
             if reset_mask is None:
                 self._hist[last] = o
-            else:   # robots that were not reset keep their own history
-                self._hist[last] = torch.where(reset_mask.bool().unsqueeze(1), o, self._hist[last])
+            else:   # robots that were not reset keep their own history ...
+                rm = reset_mask.bool()
+                self._hist[last] = torch.where(rm.unsqueeze(1), o, self._hist[last])
+                # ... and their own view: the ring already holds their newest reading, so `older` above is one reading too
+                # new for them -- they see what the last step showed them (a masked reset does not advance their time)
+                if self._last_seq is not None:
+                    seq = torch.where(rm.view(-1, 1, 1), seq, self._last_seq)
         else:
             self._hist_head = (self._hist_head + 1) % H          # logical shift by one ...
             self._hist[(self._hist_head + H - 1) % H] = o          # ... and the newest reading goes last
+        self._last_seq = seq
         return seq.reshape(self.num_envs, -1) if self._hist_mode == "stack" else seq
 
     def set_sensor_noise(self, stdev, seed=0):
@@ -561,6 +570,47 @@ class BatchedQuadrupedEnv:
         self._last_view = self._obs_view()
         rec["done"] = rec["done"].view(torch.bool)
         rec["final_obs"] = self.obs.clone()
+        return ret, ln, rec
+
+    def rollout_actions(self, actions, record=("joint_angle", "obs-IMU")):
+        """len(actions) control steps over a KNOWN action tape in one launch per 50 steps (etg_rollout_actions): actions
+        [T, N, 12] (already scaled, what step() takes) or [T, 12] (the same command for every robot).  record: the per-step
+        outputs to keep -- any of "joint_angle" [T,N,12], "obs-IMU" [T,N,6] (the info columns the dynamics-identification
+        replay reads, Dynamic_parallel_model.py:63-64), "obs" [T,N,49], "reward" [T,N], "done" [T,N].
+        Returns (episode_return[N], episode_len[N], rec dict).  Same arithmetic as T calls of step()."""
+        N = self.num_envs
+        a = torch.as_tensor(actions, dtype=torch.float32, device=self.device)
+        if a.dim() == 2:
+            a = a.unsqueeze(1).expand(a.shape[0], N, a.shape[1])
+        a = a.contiguous()
+        if a.dim() != 3 or tuple(a.shape[1:]) != (N, A.NUM_MOTORS):
+            raise ValueError("actions must be [T, num_envs, 12] or [T, 12]")
+        if self.auto_reset:
+            raise ValueError("rollout_actions does not restart finished robots: use an env without auto_reset")
+        T = a.shape[0]
+        unknown = set(record) - {"joint_angle", "obs-IMU", "obs", "reward", "done"}
+        if unknown:
+            raise ValueError("rollout_actions cannot record %s" % sorted(unknown))
+        rec = {}
+        if "joint_angle" in record:
+            rec["joint_angle"] = torch.empty(T, N, A.NUM_MOTORS, device=self.device)
+        if "obs-IMU" in record:
+            rec["obs-IMU"] = torch.empty(T, N, 6, device=self.device)
+        if "obs" in record:
+            rec["obs"] = torch.empty(T, N, A.OBS_DIM, device=self.device)
+        if "reward" in record:
+            rec["reward"] = torch.empty(T, N, device=self.device)
+        if "done" in record:
+            rec["done"] = torch.empty(T, N, dtype=torch.uint8, device=self.device)
+        ret = torch.empty(N, device=self.device)
+        ln = torch.empty(N, dtype=torch.int32, device=self.device)
+        _lib.check(self._lib.etg_rollout_actions(self._h, _ptr(a), int(T), _ptr(self.obs), _ptr(rec.get("joint_angle")), _ptr(rec.get("obs-IMU")),
+                                                 _ptr(rec.get("obs")), _ptr(rec.get("reward")), _ptr(rec.get("done")), _ptr(ret), _ptr(ln),
+                                                 self._stream()))
+        self._keep_tape = a
+        self._last_view = self._obs_view()
+        if "done" in rec:
+            rec["done"] = rec["done"].view(torch.bool)
         return ret, ln, rec
 
     def episode_stats(self):

@@ -104,12 +104,14 @@ def dynamics_id_loss(drpy, motor, mean_dict, key):
     return (loss_drpy + loss_motor) / 2.0
 
 
-def make_dynamics_id_evaluator(env, gait, mean_dict, e_steps=100, keys=("exp", "ori")):
+def make_dynamics_id_evaluator(env, gait, mean_dict, e_steps=100, keys=("exp", "ori"), fused=True):
     """Fitness of dynamic-parameter candidates (48 numbers in [-1,1] per candidate = robot), the batched
     RemoteESAgent.batch_sample_episodes of model/Dynamic_parallel_model.py:53-77: for every gait `key`, reset with
     param2dynamic_dict(candidate), replay `e_steps` recorded joint targets (action = gait[key][i] - pose_ori, an
     env made with ETG=0), record info["joint_angle"] and info["obs-IMU"][3:], reward = 30 - loss_func; the
-    candidate's fitness is the mean over the keys.  `env` must have been made with ETG=0."""
+    candidate's fitness is the mean over the keys.  `env` must have been made with ETG=0.  fused (default): the replay runs
+    through env.rollout_actions (etg_rollout_actions: the tape is known, so 100 steps are 2 launches); False = env.step()
+    per control step with the info columns sliced on the host side, the reference's own loop shape."""
     from . import a1_model as A
     if getattr(env, "ETG", 1):
         raise ValueError("the dynamics-identification replay needs an env made with ETG=0 (Dynamic_parallel_model.py:49)")
@@ -124,10 +126,15 @@ def make_dynamics_id_evaluator(env, gait, mean_dict, e_steps=100, keys=("exp", "
         drpy = torch.empty(n, e_steps, 3, device=env.device)
         for key in keys:
             env.reset(dynamic_param=rows)
-            for i in range(e_steps):
-                _, _, _, info = env.step(acts[key][i].expand(n, 12), donef=False)
-                motor[:, i] = info["joint_angle"]
-                drpy[:, i] = info["obs-IMU"][:, 3:]
+            if fused:
+                # the commands are known in advance: one launch per 50 steps, the two info columns recorded in the kernel
+                _, _, rec = env.rollout_actions(acts[key], record=("joint_angle", "obs-IMU"))
+                motor, drpy = rec["joint_angle"].transpose(0, 1), rec["obs-IMU"][:, :, 3:].transpose(0, 1)
+            else:
+                for i in range(e_steps):
+                    _, _, _, info = env.step(acts[key][i].expand(n, 12), donef=False)
+                    motor[:, i] = info["joint_angle"]
+                    drpy[:, i] = info["obs-IMU"][:, 3:]
             fit += 30.0 - dynamics_id_loss(drpy, motor, mean_dict, key)
         return fit / len(keys)
     return evaluate

@@ -104,6 +104,12 @@ class EmuSim:
         st = np.ascontiguousarray(st, dtype=np.float32)
         self._l.emu_set_state(self._h, _p(st))
 
+    @staticmethod
+    def set_extra_sweeps(n):
+        """every emulated robot sits through n more sweeps after its own convergence, frozen (what a robot on the GPU does
+        while its wave neighbours still sweep); process-wide"""
+        lib().emu_set_extra_sweeps(int(n))
+
     def replication_check(self, env=0, nticks=50):
         f = self._l.emu16_tick_replication_check if self.lanes == 16 else self._l.emu_tick_replication_check
         return f(self._h, int(env), int(nticks))

@@ -15,7 +15,22 @@
 #include "../../paddlerobotics_amd/csrc/etg_core16.h"
 
 namespace etg {
+// The emulation runs one robot at a time, the GPU several per wave: a converged robot then sits through the sweeps its
+// wave neighbours still need, FROZEN.  g_extra_sweeps > 0 makes the emulated robot sit through that many sweeps after
+// its own convergence (every tick), so a CPU test can check that they change nothing, bit for bit.
+static int g_extra_sweeps = 0;
+struct WaveAny {
+  mutable int forced = 0;
+  bool more(bool live) const {
+    if (live) { forced = 0; return true; }
+    if (forced < g_extra_sweeps) { forced++; return true; }
+    forced = 0;
+    return false;
+  }
+};
 struct EmuCtxBase {
+  WaveAny wa;
+  bool wave_any(B4 b) const { return wa.more(any(b)); }
   int env, N;
   const float* parp;
   F4 par(int k) const { return ld_lane(parp, k); }
@@ -79,6 +94,8 @@ typedef EmuCtxT<false> EmuCtx;   // generic-terrain instantiation; the flat fast
 
 // ---- 16 lanes per robot (etg_core16.h): lane r = 4*leg + sub
 struct EmuCtx16Base {
+  WaveAny wa;
+  bool wave_any(B16 b) const { return wa.more(any(b)); }
   int env, N;
   const float* parp;
   int NL() const { return 4 * N; }
@@ -202,6 +219,7 @@ extern "C" void* emu_create(const EtgConfig* cfg, const EtgRobotModel* model) {
 }
 extern "C" void emu_destroy(void* h) { delete (Emu*)h; }
 extern "C" void emu_set_lanes(void* h, int lanes) { ((Emu*)h)->lanes = lanes; }
+extern "C" void emu_set_extra_sweeps(int n) { g_extra_sweeps = n; }
 extern "C" void emu_set_params(void* h, const float* dyn, const float* w, const float* b, int per_env, const uint8_t* mask) {
   Emu* e = (Emu*)h;
   int N = e->N;

@@ -125,3 +125,39 @@ def test_rlschool_names_cover_what_the_drivers_import():
     assert ETG_model(layer, w0, b0).forward(0.026).shape == (12,)
     from paddlerobotics_amd.env import sensor_columns
     assert len(sensor_columns(sensor_mode)) == 49          # the drivers' default flags give the 49-float observation
+
+
+def test_observation_history_of_running_robots_survives_a_masked_reset():
+    """with auto_reset (or a manual reset of SOME robots) and an observation history, the robots that were not reset
+    must see [o_{t-2}, o_{t-1}, o_t], not a view shifted by the reading the step just pushed.  Host logic only: the ring of
+    BatchedQuadrupedEnv._obs_view driven on CPU tensors."""
+    import torch
+    from paddlerobotics_amd.env import BatchedQuadrupedEnv
+
+    def shell(n):
+        e = BatchedQuadrupedEnv.__new__(BatchedQuadrupedEnv)
+        e.num_envs, e.obs, e.device = n, torch.zeros(n, 1), torch.device("cpu")
+        e._col_idx = e._xcol_idx = None
+        e._hist_T, e._hist_dt, e._hist_mode, e._hist, e._hist_head, e._last_seq = 2, 1, "stack", None, 0, None
+        return e
+    n = 3
+    plain, auto = shell(n), shell(n)
+    for e in (plain, auto):
+        e.obs[:] = 1.0
+        e._obs_view(reset_mask=None, first=True)
+    for t in range(2, 7):
+        done = torch.zeros(n, dtype=torch.uint8)
+        if t == 5:
+            done[1] = 1                                    # robot 1's episode ends at t = 5: it restarts with reading 100
+        plain.obs[:] = float(t)
+        auto.obs[:] = float(t)
+        auto.obs[done.bool()] = 100.0                      # the fused kernel leaves the reset observation in the row
+        vp = plain._obs_view()
+        auto._obs_view()                                   # what step(auto_reset=True) does ...
+        va = auto._obs_view(reset_mask=done, first=True)   # ... after the launch
+        keep = ~done.bool()
+        keep[1] = keep[1] and t < 5                        # (the restarted robot no longer matches the plain env)
+        assert torch.equal(va[keep], vp[keep]), (t, va, vp)
+        assert torch.equal(va[done.bool()], torch.tensor([[0.0, 0.0, 100.0]]).expand(int(done.sum()), 3))
+        if t == 6:                                         # the restarted robot's history holds its reset reading, then goes on
+            assert torch.equal(va[1], torch.tensor([0.0, 100.0, 6.0]))

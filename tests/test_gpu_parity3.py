@@ -1,0 +1,413 @@
+"""-m gpu, round 3: the contact solver's stopping rule on the device, and the evidence VERDICT r02 found thin.
+
+  * the residual rule (EtgConfig.solver_residual: pybullet's numSolverIterations = 50 / solverResidualThreshold = 1e-7, the
+    library default) through the C-ABI against the fp64 oracle, both lane mappings, flat ground and heightfield; the executed
+    sweep count the kernels report (info['solver_sweeps']) against the oracle's per-robot counts;
+  * a robot's result does not depend on the robots sharing its wavefront (converged robots are frozen while neighbours sweep on):
+    a permuted batch gives bit-identical per-robot results, step kernels and fused rollouts, both mappings;
+  * 400-step statistics on the configs[4] heightfield with body contacts and joint limits on, and of the configs[2] closed
+    loop, 4096 robots against 512 oracle robots, for the residual rule and for K = 50;
+  * the 4-lane mapping at 16384 robots: determinism, batch invariance, a 256-robot oracle sample over 12 steps, a heightfield run;
+  * the reference's trained gait (gait_action_list_ETG_exp.npy -> exp_w / exp_b) walks its 600 steps (env_test.py:51-54) at
+    ~ vel_d without terminating, both mappings, as it does in the oracle;
+  * the fused rollout over a caller-supplied action tape (etg_rollout_actions) against env.step() with the same actions.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from paddlerobotics_amd import a1_model as A
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from tests.test_gpu_parity import _need_gpu, _etg_params, _make, _oracle   # noqa: E402
+from tests.test_gpu_parity2 import _say, _policy, _population               # noqa: E402
+
+NCPU = os.cpu_count() or 1
+
+
+def _heightfield():
+    """BASELINE configs[4]: 256 x 256 grid, 0.05 m cells, heights U(0, 0.05) m from default_rng(0)"""
+    hf = np.random.default_rng(0).uniform(0.0, 0.05, size=(256, 256)).astype(np.float32)
+    return dict(heights=hf, cell=0.05, origin=(-6.4, -6.4))
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+@pytest.mark.parametrize("terrain", ["flat", "heightfield"])
+def test_residual_rule_matches_oracle(lanes, terrain):
+    """Default solver (up to 50 sweeps, residual 1e-7) against the fp64 oracle over 20 control steps of random residual
+    actions.  Bounds ~10x the measured gaps (printed); the executed sweep count of a wave is the count of its slowest robot."""
+    _need_gpu()
+    n = 64
+    hf = _heightfield() if terrain == "heightfield" else None
+    kw = dict(task="heightfield", heightfield=hf) if hf else {}
+    W, B = _etg_params(n, seed=21)
+    env = _make(n, lanes_per_robot=lanes, **kw)
+    assert (env.cfg.solver_iters, env.cfg.solver_residual) == (50, 1e-7)
+    orc = _oracle(n, terrain=1 if hf else 0, heightfield=hf)
+    orc.threads = NCPU
+    if hf:
+        orc.set_heightfield(hf["heights"])
+    env.reset(ETG_w=W, ETG_b=B)
+    orc.set_params(etg_w=W, etg_b=B)
+    orc.reset()
+    rng = np.random.default_rng(2)
+    worst_q = worst_p = 0.0
+    per_wave = 64 // lanes
+    for k in range(20):
+        act = rng.uniform(-0.1, 0.1, size=(n, 12))
+        _, rg, dg, info = env.step(torch.as_tensor(act, dtype=torch.float32))
+        _, ro, do, io = orc.step(act)
+        sg, so = env.get_state().cpu().numpy(), orc.get_state()
+        worst_q = max(worst_q, np.abs(sg - so)[:, 13:25].max())
+        worst_p = max(worst_p, np.abs(sg - so)[:, :3].max())
+        sw_g = info["solver_sweeps"].cpu().numpy().reshape(-1)
+        sw_o = io[:, A.INFO_SWEEPS].reshape(-1, per_wave)
+        sw_g = sw_g.reshape(-1, per_wave)
+        assert np.all(sw_g == sw_g[:, :1])                          # wave-uniform
+        # the wave runs, per tick, the count of its slowest robot: between the largest per-robot step total and the sum
+        assert np.all(sw_g[:, 0] >= sw_o.max(1) - 2) and np.all(sw_g[:, 0] <= sw_o.sum(1) + 2), (k, sw_g[:, 0], sw_o)
+        assert np.all(sw_g >= 13) and np.all(sw_g <= 13 * 50)
+    _say("residual rule %s lanes %d: worst joint gap %.2e rad, base %.2e m over 20 steps; executed sweeps/tick %.2f vs oracle "
+         "per robot %.2f" % (terrain, lanes, worst_q, worst_p, sw_g.mean() / 13, sw_o.mean() / 13))
+    assert worst_q < (2e-3 if hf else 2e-4) and worst_p < (5e-4 if hf else 5e-5)
+    env.close()
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+@pytest.mark.parametrize("terrain", ["flat", "heightfield"])
+def test_wave_neighbours_do_not_influence_a_robot(lanes, terrain):
+    """The same 256 robots in two orders (so every robot shares its wavefront with different neighbours): states, rewards and
+    observations are bit-identical per robot, through env.step() and through the fused rollout, under the residual rule."""
+    _need_gpu()
+    n = 256
+    hf = _heightfield() if terrain == "heightfield" else None
+    kw = dict(task="heightfield", heightfield=hf) if hf else {}
+    W, B = _etg_params(n, seed=23)
+    rng = np.random.default_rng(5)
+    dyn = np.stack([A.dynamic_dict_to_row(A.param2dynamic_dict(rng.uniform(-0.3, 0.3, 48))) for _ in range(n)])
+    perm = rng.permutation(n)
+    act = rng.uniform(-0.15, 0.15, size=(6, n, 12)).astype(np.float32)
+    res = []
+    for order in (np.arange(n), perm):
+        env = _make(n, lanes_per_robot=lanes, **kw)
+        env.reset(ETG_w=W[order], ETG_b=B[order], dynamic_param=torch.as_tensor(dyn[order], dtype=torch.float32))
+        rews = []
+        for k in range(6):
+            _, r, _, _ = env.step(torch.as_tensor(act[k][order]))
+            rews.append(r.cpu().numpy().copy())
+        st_step = env.get_state().cpu().numpy().copy()
+        ret, ln = env.rollout_openloop(30)
+        res.append((order, np.stack(rews, 1), st_step, env.get_state().cpu().numpy().copy(), env.obs.cpu().numpy().copy(),
+                    ret.cpu().numpy().copy(), ln.cpu().numpy().copy()))
+        env.close()
+    (o0, *a), (o1, *b) = res
+    inv = np.empty(n, dtype=int)
+    inv[o1] = np.arange(n)
+    for x, y in zip(a, b):
+        assert np.array_equal(x, y[inv])
+
+
+def _stats_vs_oracle(env, orc, steps, m, label, closed_loop=None):
+    """400-step statistics of the GPU batch against the oracle on the first m robots (see test_long_horizon_statistics_match_oracle)"""
+    from scipy.stats import ks_2samp
+    x0 = env.get_state()[:, 0].cpu().numpy()
+    if closed_loop is None:
+        ret_g, ln_g = env.rollout_openloop(steps)
+    else:
+        ret_g, ln_g = env.rollout_policy(closed_loop[0], steps, 0.3)
+    ret_g, ln_g = ret_g.cpu().numpy().astype(np.float64), ln_g.cpu().numpy()
+    dx_g = env.get_state()[:, 0].cpu().numpy() - x0
+    x0o = orc.get_state()[:, 0].copy()
+    if closed_loop is None:
+        ret_o, ln_o = orc.run_steps(steps)
+    else:
+        from oracle import oracle as O
+        obs = closed_loop[2]
+        ret_o, alive, ln_o = np.zeros(m), np.ones(m, bool), np.zeros(m, int)
+        for _ in range(steps):
+            obs, r, d, _ = orc.step(O.mlp_forward(obs, *closed_loop[1], scale=0.3), want_info=False)
+            ret_o += alive * r
+            ln_o += alive
+            alive &= ~d.astype(bool)
+    dx_o = orc.get_state()[:, 0] - x0o
+    surv = lambda ln, t: float((ln > t).mean())
+    grid = list(range(25, steps, 25))
+    gap = max(abs(surv(ln_g[:m], t) - surv(ln_o, t)) for t in grid)
+    gap_full = max(abs(surv(ln_g, t) - surv(ln_o, t)) for t in grid)
+    agree = float((np.abs(ln_g[:m] - ln_o) <= 1).mean())
+    ks_len, ks_ret = ks_2samp(ln_g[:m], ln_o).statistic, ks_2samp(ret_g[:m], ret_o).statistic
+    alive = (ln_g[:m] == steps) & (ln_o == steps)
+    ks_dx = ks_2samp(dx_g[:m][alive], dx_o[alive]).statistic if alive.sum() > 20 else 0.0
+    _say("%s: survivors gpu %.3f (full %.3f) oracle %.3f | survival-curve gap %.4f (full batch %.4f) | same length +-1: %.3f | "
+         "KS len %.4f ret %.4f dx %.4f | mean return gpu %.2f oracle %.2f" %
+         (label, surv(ln_g[:m], steps - 1), surv(ln_g, steps - 1), surv(ln_o, steps - 1), gap, gap_full, agree, ks_len, ks_ret,
+          ks_dx, ret_g[:m].mean(), ret_o.mean()))
+    assert np.isfinite(ret_g).all()
+    return dict(gap=gap, gap_full=gap_full, agree=agree, ks_len=ks_len, ks_ret=ks_ret, ks_dx=ks_dx,
+                dret=abs(ret_g[:m].mean() - ret_o.mean()) / max(ret_o.std(), 1e-9))
+
+
+@pytest.mark.parametrize("solver", ["rule", "k50"])
+def test_long_horizon_statistics_on_the_heightfield(solver):
+    """configs[4] per GPU: 4096 robots on the random heightfield, 400 control steps, body contacts (deepest of knee / shin /
+    trunk corner) and joint-limit stops ON, against 512 fp64 oracle robots.  The terrain is only C0 (normals jump at cell
+    edges), so individual trajectories part earlier than on flat ground: the bounds are on the distributions."""
+    _need_gpu()
+    n, m, steps = 4096, 512, 400
+    hf = _heightfield()
+    skw = {} if solver == "rule" else dict(solver_iters=50)
+    w, b = _population(n)
+    env = _make(n, task="heightfield", heightfield=hf, body_contacts=2, joint_limits=True, **skw)
+    env.reset(ETG_w=w, ETG_b=b)
+    orc = _oracle(m, terrain=1, heightfield=hf, body_contacts=2, joint_limits=1, **skw)
+    orc.threads = NCPU
+    orc.set_heightfield(hf["heights"])
+    orc.set_params(etg_w=w[:m].double().cpu().numpy(), etg_b=b[:m].double().cpu().numpy())
+    orc.reset()
+    s = _stats_vs_oracle(env, orc, steps, m, "heightfield + body contacts + joint limits, %s" % solver)
+    assert s["gap"] < 0.05 and s["gap_full"] < 0.09          # same robots / full batch vs the 512-robot sample
+    assert s["agree"] > 0.85
+    assert s["ks_len"] < 0.06 and s["ks_ret"] < 0.06 and s["ks_dx"] < 0.12     # critical value 0.122 (alpha 0.001, 512 vs 512)
+    assert s["dret"] < 0.1
+    env.close()
+
+
+@pytest.mark.parametrize("solver", ["rule", "k50"])
+def test_long_horizon_statistics_of_the_closed_loop(solver):
+    """configs[2]: ETG + residual policy (random init) fused rollout, 4096 robots x 400 steps, against the oracle's closed loop
+    (mlp_forward + step) on the first 512 robots."""
+    _need_gpu()
+    n, m, steps = 4096, 512, 400
+    skw = {} if solver == "rule" else dict(solver_iters=50)
+    w, b = _population(n)
+    pol, ws = _policy()
+    env = _make(n, **skw)
+    env.reset(ETG_w=w, ETG_b=b)
+    orc = _oracle(m, **skw)
+    orc.threads = NCPU
+    orc.set_params(etg_w=w[:m].double().cpu().numpy(), etg_b=b[:m].double().cpu().numpy())
+    obs0 = orc.reset()
+    s = _stats_vs_oracle(env, orc, steps, m, "closed loop, %s" % solver, closed_loop=(pol, ws, obs0))
+    assert s["gap"] < 0.03 and s["gap_full"] < 0.08
+    assert s["agree"] > 0.93
+    assert s["ks_len"] < 0.04 and s["ks_ret"] < 0.04 and s["ks_dx"] < 0.1
+    assert s["dret"] < 0.08
+    env.close()
+
+
+def test_four_lane_mapping_at_16384_robots():
+    """The mapping every batch above 4096 robots gets (lanes_per_robot = 0 -> 4): reruns are bit-identical, a robot does not
+    depend on its batch, the first 256 robots track the fp64 oracle over 12 control steps, and a heightfield run stays sane."""
+    _need_gpu()
+    n, m = 16384, 256
+    W, B = _etg_params(m, seed=29)
+    Wn, Bn = np.tile(W, (n // m, 1, 1)), np.tile(B, (n // m, 1))
+    rng = np.random.default_rng(3)
+    act = rng.uniform(-0.1, 0.1, size=(12, m, 12)).astype(np.float32)
+    outs = []
+    for rep in range(2):
+        env = _make(n)
+        assert env.lanes_per_robot == 4
+        env.reset(ETG_w=Wn, ETG_b=Bn)
+        for k in range(12):
+            env.step(torch.as_tensor(np.tile(act[k], (n // m, 1))), want_info=False)
+        outs.append((env.get_state().cpu().numpy().copy(), env.obs.cpu().numpy().copy(), env.reward.cpu().numpy().copy()))
+        if rep == 0:
+            ret, ln = env.rollout_openloop(60)
+            roll = (ret.cpu().numpy().copy(), ln.cpu().numpy().copy(), env.get_state().cpu().numpy().copy())
+        env.close()
+    for x, y in zip(*outs):
+        assert np.array_equal(x, y)                                             # determinism
+    st = outs[0][0]
+    assert np.array_equal(st.reshape(n // m, m, -1), np.broadcast_to(st[:m], (n // m, m, st.shape[1])))   # every copy == the sample
+    assert np.isfinite(roll[0]).all() and np.isfinite(roll[2]).all()
+    small = _make(m, lanes_per_robot=4)
+    small.reset(ETG_w=W, ETG_b=B)
+    for k in range(12):
+        small.step(torch.as_tensor(act[k]), want_info=False)
+    assert np.array_equal(small.get_state().cpu().numpy(), st[:m])              # batch invariance: 256 alone == 256 of 16384
+    small.close()
+    orc = _oracle(m)
+    orc.threads = NCPU
+    orc.set_params(etg_w=W, etg_b=B)
+    orc.reset()
+    for k in range(12):
+        orc.step(act[k].astype(np.float64), want_info=False)
+    so = orc.get_state()
+    eq, ep = np.abs(st[:m] - so)[:, 13:25].max(1), np.abs(st[:m] - so)[:, :3].max(1)
+    _say("4 lanes, 16384 robots: q err median %.2e max %.2e | pos err max %.2e (256-robot oracle sample, 12 steps)" %
+         (np.median(eq), eq.max(), ep.max()))
+    assert np.median(eq) < 2e-5 and eq.max() < 2e-4 and ep.max() < 5e-5
+    # heightfield at the same size
+    hf = _heightfield()
+    envh = _make(n, task="heightfield", heightfield=hf)
+    assert envh.lanes_per_robot == 4
+    envh.reset(ETG_w=Wn, ETG_b=Bn)
+    ret, ln = envh.rollout_openloop(100)
+    sth = envh.get_state().cpu().numpy()
+    assert np.isfinite(sth).all() and np.isfinite(ret.cpu().numpy()).all()
+    assert np.array_equal(sth[:m], sth[m:2 * m])
+    ln = ln.cpu().numpy()
+    assert 0.2 < (ln == 100).mean() <= 1.0, (ln == 100).mean()                 # most walkers are still up after 100 steps
+    orh = _oracle(64, terrain=1, heightfield=hf)
+    orh.threads = NCPU
+    orh.set_heightfield(hf["heights"])
+    orh.set_params(etg_w=W[:64], etg_b=B[:64])
+    orh.reset()
+    _, ln_o = orh.run_steps(100)
+    _say("4 lanes heightfield: alive after 100 steps gpu %.3f oracle(64) %.3f" % ((ln[:64] == 100).mean(), (ln_o == 100).mean()))
+    assert abs((ln[:64] == 100).mean() - (ln_o == 100).mean()) < 0.1
+    envh.close()
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_reference_trained_gait_walks_600_steps(golden, lanes):
+    """env_test.py:43-54 with the reference's recorded gait: the ETG fitted to gait_action_list_ETG_exp.npy (exp_w / exp_b of
+    tests/golden/etg.npz) walks 600 control steps without terminating, at ~ vel_d = 0.5 m/s (the oracle: 7.7 m)."""
+    _need_gpu()
+    g = golden("etg")
+    from oracle.oracle import OracleSim
+    orc = OracleSim(A.default_config(1))
+    orc.set_params(etg_w=g["exp_w"], etg_b=g["exp_b"])
+    orc.reset()
+    xo = orc.get_state()[0, 0]
+    _, ln_o = orc.run_steps(600)
+    dxo = orc.get_state()[0, 0] - xo
+    for skw in ({}, dict(solver_iters=2), dict(solver_iters=50)):
+        env = _make(4, lanes_per_robot=lanes, **skw)
+        env.reset(ETG_w=g["exp_w"], ETG_b=g["exp_b"])
+        x0 = env.get_state()[:, 0].cpu().numpy()
+        ret, ln = env.rollout_openloop(600)
+        dx = env.get_state()[:, 0].cpu().numpy() - x0
+        _say("reference gait, lanes %d %s: length %s, distance %.3f m (oracle %.3f m, %d steps), return %.1f" %
+             (lanes, skw or "rule", ln.cpu().numpy().tolist(), dx[0], dxo, ln_o[0], float(ret[0])))
+        assert int(ln.min()) == 600 and ln_o[0] == 600
+        assert np.all(np.abs(dx - dxo) < 0.15) and np.all(dx > 7.0)
+        assert abs(dx[0] / (600 * 0.026) - 0.5) < 0.03                          # ~ vel_d
+        env.close()
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_pyramid_friction_option_matches_oracle(lanes):
+    """friction_model = 1 (each tangent direction clamped on its own, the sequential-impulse pyramid) against the oracle."""
+    _need_gpu()
+    n = 32
+    W, B = _etg_params(n, seed=31)
+    env = _make(n, lanes_per_robot=lanes, friction_model=1)
+    orc = _oracle(n, friction_model=1)
+    env.reset(ETG_w=W, ETG_b=B)
+    orc.set_params(etg_w=W, etg_b=B)
+    orc.reset()
+    rng = np.random.default_rng(8)
+    dyn = np.tile(A.default_dynamic_row(), (n, 1))
+    for k in range(15):
+        act = rng.uniform(-0.2, 0.2, size=(n, 12))                              # large residuals: feet slide
+        env.step(torch.as_tensor(act, dtype=torch.float32), want_info=False)
+        orc.step(act, want_info=False)
+    sg, so = env.get_state().cpu().numpy(), orc.get_state()
+    eq = np.abs(sg - so)[:, 13:25].max()
+    _say("pyramid friction lanes %d: worst joint gap %.2e rad over 15 steps" % (lanes, eq))
+    assert eq < 2e-4
+    # and it is a different model: the disc result differs from it
+    disc = _make(n, lanes_per_robot=lanes)
+    disc.reset(ETG_w=W, ETG_b=B)
+    rng = np.random.default_rng(8)
+    for k in range(15):
+        disc.step(torch.as_tensor(rng.uniform(-0.2, 0.2, size=(n, 12)), dtype=torch.float32), want_info=False)
+    assert np.abs(disc.get_state().cpu().numpy() - sg)[:, 13:25].max() > 1e-4
+    env.close(); disc.close()
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+@pytest.mark.parametrize("variant", ["default", "etg0_filter", "heightfield"])
+def test_action_tape_rollout_equals_stepping(lanes, variant):
+    """etg_rollout_actions (one launch per 50 control steps, commands known in advance) against env.step() with the same
+    actions: bookkeeping exact (lengths, done bytes), trajectories to the rounding noise two kernels of the same source
+    differ by (FMA contraction; cf. test_fused_rollout_equals_stepping), every recorded column against the stepped info."""
+    _need_gpu()
+    n, T = 64, 60                          # 60 > 50: two launches
+    kw = dict(lanes_per_robot=lanes)
+    if variant == "etg0_filter":
+        kw.update(ETG=0, enable_action_filter=True)
+    elif variant == "heightfield":
+        kw.update(task="heightfield", heightfield=_heightfield())
+    W, B = _etg_params(n, seed=41)
+    rng = np.random.default_rng(6)
+    acts = torch.as_tensor(rng.uniform(-0.15, 0.15, size=(T, n, 12)), dtype=torch.float32, device="cuda:0")
+    a, b = _make(n, **kw), _make(n, **kw)
+    for e in (a, b):
+        e.reset(ETG_w=W, ETG_b=B) if variant != "etg0_filter" else e.reset()
+    ret, ln, rec = a.rollout_actions(acts, record=("joint_angle", "obs-IMU", "obs", "reward", "done"))
+    q, imu, obs, rew, done = [], [], [], [], []
+    for k in range(T):
+        o, r, d, info = b.step(acts[k])
+        q.append(info["joint_angle"].clone()); imu.append(info["obs-IMU"].clone()); obs.append(o.clone())
+        rew.append(r.clone()); done.append(d.clone())
+    q, imu, obs, rew, done = (torch.stack(x).cpu().numpy() for x in (q, imu, obs, rew, done))
+    ret_b, ln_b = b.episode_stats()
+    first = 3                                                   # the first steps: identical arithmetic, rounding not yet amplified
+    assert np.abs(rec["joint_angle"].cpu().numpy()[:first] - q[:first]).max() < 1e-6
+    same_len = (ln.cpu().numpy() == ln_b.cpu().numpy())
+    assert same_len.mean() > 0.9
+    run = np.arange(T)[:, None] < np.minimum(ln.cpu().numpy(), ln_b.cpu().numpy())[None, :] - 1     # steps before either episode ended
+    tol = 5e-3 if variant == "heightfield" else 5e-4
+    eq = np.abs(rec["joint_angle"].cpu().numpy() - q).max(2)
+    _say("action tape %s lanes %d: joint gap to stepping, running robots: median %.2e max %.2e" % (variant, lanes, np.median(eq[run]), eq[run].max()))
+    assert np.median(eq[run]) < 1e-5 and eq[run].max() < tol
+    assert np.abs(rec["obs-IMU"].cpu().numpy() - imu).max(2)[run].max() < 20 * tol
+    assert np.abs(rec["obs"].cpu().numpy() - obs)[:first].max() < 1e-4
+    assert np.array_equal(rec["done"].cpu().numpy()[:first], done[:first])
+    assert np.abs(rec["reward"].cpu().numpy()[:first] - rew[:first]).max() < 1e-3
+    assert np.abs(ret.cpu().numpy() - ret_b.cpu().numpy())[same_len].max() < 2e-2 * (1 + np.abs(ret_b.cpu().numpy()).max())
+    assert np.array_equal(a.obs.cpu().numpy(), rec["obs"].cpu().numpy()[-1])      # the final row is the tape's last
+    # one command row for every robot
+    a.reset() if variant == "etg0_filter" else a.reset(ETG_w=W, ETG_b=B)
+    _, _, rec1 = a.rollout_actions(acts[:5, 0], record=("joint_angle",))
+    a.reset() if variant == "etg0_filter" else a.reset(ETG_w=W, ETG_b=B)
+    _, _, rec2 = a.rollout_actions(acts[:5, :1].expand(5, n, 12), record=("joint_angle",))
+    assert torch.equal(rec1["joint_angle"], rec2["joint_angle"])
+    with pytest.raises(ValueError):
+        a.rollout_actions(acts[:, :5])
+    a.close(); b.close()
+
+
+def test_dynamics_identification_evaluator_fused_equals_stepping(golden):
+    """make_dynamics_id_evaluator through the action-tape rollout (2 launches per 100-step replay) gives the fitness of the
+    env.step() loop (Dynamic_parallel_model.py:53-77) -- and how long a generation takes either way."""
+    _need_gpu()
+    import time
+    from paddlerobotics_amd import rollout as R
+    n, T = 256, 100
+    g = golden("dynid")
+    POSE = A.INIT_MOTOR_ANGLES
+    rng = np.random.default_rng(14)
+    etg = golden("etg")
+    rows = {int(r): a for r, a in zip(etg["exp_rows"], etg["exp_act"])}
+    exp = np.zeros((T, 12)); last = np.zeros(12)
+    for k in range(T):
+        last = rows.get(k, last)
+        exp[k] = POSE + last
+    gait = {"exp": exp, "ori": np.tile(POSE[None], (T, 1))}
+    mean_dict = {}
+    for key in ("exp", "ori"):
+        mean_dict[key + "_motor_mean"], mean_dict[key + "_drpy_mean"] = gait[key], np.zeros((T, 3))
+        mean_dict[key + "_motor_std"], mean_dict[key + "_drpy_std"] = np.full((T, 12), 0.05), np.full((T, 3), 0.5)
+    cand = torch.as_tensor(rng.uniform(-0.6, 0.6, size=(n, 48)))
+    env = _make(n, ETG=0)
+    out = {}
+    for fused in (True, False):
+        ev = R.make_dynamics_id_evaluator(env, gait, mean_dict, e_steps=T, fused=fused)
+        ev(cand)                                                 # warm (lazy kernel loads)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        fit = ev(cand)
+        torch.cuda.synchronize()
+        out[fused] = (fit.cpu().numpy(), time.perf_counter() - t0)
+    _say("dynamics-ID evaluation of %d candidates x 2 gaits x %d steps: fused %.1f ms, env.step loop %.1f ms" %
+         (n, T, out[True][1] * 1e3, out[False][1] * 1e3))
+    assert np.abs(out[True][0] - out[False][0]).max() < 2e-2 * (1 + np.abs(out[False][0]).max())
+    assert np.corrcoef(out[True][0], out[False][0])[0, 1] > 0.999
+    env.close()
