@@ -472,15 +472,18 @@ def main():
                                       "peak": peak, "unit": "TFLOP/s", "frac": flops / (pol_ms * 1e-3) / 1e12 / peak,
                                       "kernel_ms": pol_ms, "dtype": "f32" if args.precision == 0 else "bf16"}
         # sweeps the kernels EXECUTED (per wave: the slowest robot of the 4 / 16 sharing it sets the count), from the info column
-        # of 26 plain env.step() calls on the headline robots -- untimed
+        # of plain env.step() calls over the same K steps on the headline robots -- untimed
         try:
             env.reset(ETG_w=w, ETG_b=b)
-            sw = []
-            for _ in range(26):
+            acc = torch.zeros((), device=dev)
+            first = None
+            for k in range(K):
                 _, _, _, inf = env.step(None)
-                sw.append(float(inf["solver_sweeps"].float().mean().item()) / 13.0)
+                acc += inf["solver_sweeps"].float().mean()
+                if k == 25:
+                    first = float(acc.item()) / 26.0 / 13.0
             out["config"]["solver"]["executed_sweeps_per_tick_per_wave"] = {
-                "first_26_steps_mean": float(np.mean(sw)), "min_step": float(np.min(sw)), "max_step": float(np.max(sw)),
+                "mean_over_the_%d_steps" % K: float(acc.item()) / K / 13.0, "first_26_steps_mean": first,
                 "source": "info['solver_sweeps'] (ETG_INFO_SWEEPS) of env.step()"}
         except Exception as e:                                       # noqa: BLE001 - diagnostics must not lose the line
             out["config"]["solver"]["executed_sweeps_per_tick_per_wave"] = {"error": repr(e)[:200]}

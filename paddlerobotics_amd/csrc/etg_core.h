@@ -574,7 +574,8 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
     // physics_tick16); one quad max per sweep, the loop ends when every robot of the wave is done
     const F thr(K.res_thr);
     int it = 0;
-    do {
+    bool more;
+    auto sweep_and_test = [&]() {
       const F s0 = l0, s1 = l1, s2 = l2;
       pgs_sweep();
       it++;
@@ -584,8 +585,19 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
       k10 = sel_(live, k10, zero); k20 = sel_(live, k20, zero); k21 = sel_(live, k21, zero);
       c0 = sel_(live, c0, zero);
       mu = sel_(live, mu, F(1e30f));
-      if (!c.wave_any(live)) break;
-    } while (it < K.iters);
+      more = c.wave_any(live) && it < K.iters;
+    };
+    // nested forward exits instead of a loop for the first sweeps: see physics_tick16
+    sweep_and_test();
+    if (__builtin_expect(more, 1)) { sweep_and_test();
+    if (__builtin_expect(more, 1)) { sweep_and_test();
+    if (__builtin_expect(more, 1)) { sweep_and_test();
+    if (more) { sweep_and_test();
+    if (more) { sweep_and_test();
+    if (more) { sweep_and_test();
+    if (more) { sweep_and_test();
+      while (more) sweep_and_test();
+    }}}}}}}
     L.sweeps += it;
   } else if (K.iters == 2) {   // a fixed pair of sweeps, straight-line (see physics_tick16)
     pgs_sweep();

@@ -463,7 +463,8 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
     // sweep; the loop ends when every robot of the wave is done (wave-uniform branch).
     const F thr(K.res_thr);
     int it = 0;
-    do {
+    bool more;
+    auto sweep_and_test = [&]() {
       const F lam0 = lam;
       pgs_sweep();
       it++;
@@ -472,8 +473,22 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
       iAe = sel_(live, iAe, zero);
       c0e = sel_(live, c0e, zero);
       mue = sel_(live, mue, F(1e30f));
-      if (!c.wave_any(live)) break;
-    } while (it < K.iters);
+      more = c.wave_any(live) && it < K.iters;
+    };
+    // A taken branch costs a lone wave ~100 ns (the instruction buffer refills from the cache with nothing to hide it): a loop
+    // would pay that once per sweep.  The first sweeps are laid out as nested forward exits instead -- falling through costs
+    // nothing, the one taken branch per tick is the exit -- and only ticks that need more than 8 sweeps (a fraction of a
+    // percent) enter the loop at the bottom.
+    sweep_and_test();
+    if (__builtin_expect(more, 1)) { sweep_and_test();
+    if (__builtin_expect(more, 1)) { sweep_and_test();
+    if (__builtin_expect(more, 1)) { sweep_and_test();
+    if (more) { sweep_and_test();
+    if (more) { sweep_and_test();
+    if (more) { sweep_and_test();
+    if (more) { sweep_and_test();
+      while (more) sweep_and_test();
+    }}}}}}}
     L.sweeps += it;
   } else if (K.iters == 2) {
     // a fixed pair of sweeps (the round-1/2 default) as straight-line code: no loop back-edge inside the tick (a taken

@@ -72,9 +72,9 @@ def test_reset_and_step_match_oracle():
     obs_o = orc.reset()
     obs_g = env.obs.cpu().numpy()
     st_g, st_o = env.get_state().cpu().numpy(), orc.get_state()
-    _lt(np.abs(st_g[:, :7] - st_o[:, :7]).max(), 1e-4, "base pose after the 500-tick settle")
-    _lt(np.abs(st_g[:, 13:25] - st_o[:, 13:25]).max(), 1e-4, "joint angles after the settle")
-    _lt(np.abs(obs_g - obs_o).max(), 2e-3, "reset observation (normalised, x10 / x38 scales)")
+    _lt(np.abs(st_g[:, :7] - st_o[:, :7]).max(), 1e-6, "base pose after the 500-tick settle")
+    _lt(np.abs(st_g[:, 13:25] - st_o[:, 13:25]).max(), 3e-6, "joint angles after the settle")
+    _lt(np.abs(obs_g - obs_o).max(), 6e-4, "reset observation (normalised, x10 / x38 scales)")
     rng = np.random.default_rng(1)
     worst = dict(q=0.0, pos=0.0, quat=0.0, obs=0.0, rew=0.0)
     same_min = 1.0
@@ -99,7 +99,7 @@ def test_reset_and_step_match_oracle():
         assert np.abs(ig[:, 43:55] - io[:, 43:55]).max() < 2e-5    # real_action
     # 40 control steps = 520 ticks of random residual actions (SURVEY 8d asks 1e-3 rad / 1e-3 m / 1e-3 rel)
     _lt(worst["q"], 1e-4, "joint angles, 40 steps")
-    _lt(worst["pos"], 1e-4, "base position, 40 steps")
+    _lt(worst["pos"], 3e-5, "base position, 40 steps")
     _lt(worst["quat"], 1e-4, "base orientation, 40 steps")
     _lt(worst["rew"], 1e-3, "reward (relative, robots with the same contact pattern)")
     _lt(worst["obs"], 2e-2, "observation rows (normalised), same contact pattern")
@@ -300,7 +300,7 @@ def test_fused_rollout_equals_stepping(lanes):
     assert same_len.float().mean().item() > 0.9                       # a fall may flip by a step on a borderline robot
     assert torch.allclose(ret[same_len], ret_b[same_len], rtol=2e-2, atol=0.5)
     err = np.abs(a.get_state().cpu().numpy() - b.get_state().cpu().numpy())[:, 13:25].max(1)
-    assert np.median(err) < 2e-3
+    _lt(np.median(err), 2e-5, "lanes=%d fused rollout vs stepping, 30 steps: median joint gap" % lanes)
     a.close()
     b.close()
 
@@ -318,26 +318,46 @@ def test_bad_arguments_raise():
 
 
 def test_heightfield_terrain_matches_oracle():
-    """BASELINE config 5 terrain (256x256, 0.05 m cells, heights U(0,0.05), default_rng(0))."""
+    """BASELINE config 5 terrain (256x256, 0.05 m cells, heights U(0,0.05), default_rng(0)), 32 robots spread over it, a FIXED
+    sweep count (both sides do the same arithmetic and differ by rounding only).  The bilinear surface is C0 and its normals
+    jump by up to ~1 rad at cell edges: during the 500-tick settle a foot that comes to rest on an edge lands on one side or
+    the other depending on the last bit, so fp32 and fp64 either track each other (gap ~3e-7) or part by 1e-4 .. 1e-3 m.
+    The fp32 build of the ORACLE shows exactly that against the fp64 one (measured: 45 % of the spots track, median 5e-5,
+    max 1e-3), robot by robot not the same spots.  So the GPU is held to the fp32 oracle's OWN distribution of gaps: at least
+    as many tracking spots (minus 20 %), median and maximum within 3x; and the tracking spots track tightly.
+    The residual rule on terrain: tests/test_gpu_parity3.py (smooth heightfield; 400-step statistics on this one)."""
     _need_gpu()
-    n = 16
+    n = 32
     rng = np.random.default_rng(0)
     hf = dict(heights=rng.uniform(0, 0.05, size=(256, 256)).astype(np.float32), cell=0.05, origin=(-6.4, -6.4))
     W, B = _etg_params(n, seed=13)
-    env = _make(n, task="heightfield", heightfield=hf)
-    orc = _oracle(n, terrain=1, heightfield=hf)
-    orc.set_heightfield(hf["heights"])
-    orc.set_params(etg_w=W, etg_b=B)
+    xy = np.random.default_rng(4).uniform(-2.0, 2.0, size=(n, 2))
+    env = _make(n, task="heightfield", heightfield=hf, solver_iters=4)
+    orc, o32 = _oracle(n, terrain=1, heightfield=hf, solver_iters=4), _oracle(n, dtype=np.float32, terrain=1, heightfield=hf, solver_iters=4)
+    env.set_reset_offsets(torch.as_tensor(xy, dtype=torch.float32))
     env.reset(ETG_w=W, ETG_b=B)
-    orc.reset()
-    _lt(np.abs(env.get_state().cpu().numpy()[:, :7] - orc.get_state()[:, :7]).max(), 2e-3, "heightfield: settle pose")
+    for o in (orc, o32):
+        o.set_heightfield(hf["heights"])
+        o.set_params(etg_w=W, etg_b=B)
+        o.set_reset_offsets(xy)
+        o.reset()
     assert orc.get_state()[:, 2].min() > 0.2
+
+    def compare(what, eg, e32, track):
+        tg, t32 = float((eg < track).mean()), float((e32 < track).mean())
+        print("[parity] heightfield %s: gpu vs fp64 oracle median %.2e max %.2e tracking %.0f %% | fp32 oracle vs fp64 median %.2e max "
+              "%.2e tracking %.0f %%" % (what, np.median(eg), eg.max(), 100 * tg, np.median(e32), e32.max(), 100 * t32), flush=True)
+        assert tg >= t32 - 0.2
+        assert np.median(eg) <= 3.0 * np.median(e32) + track and eg.max() <= 3.0 * e32.max() + track
+        assert np.median(eg[eg < track]) < 0.2 * track                 # the spots that track do so to rounding level
+    pg, po, p32 = env.get_state().cpu().numpy()[:, :7], orc.get_state()[:, :7], o32.get_state()[:, :7]
+    compare("settle pose (m / quaternion)", np.abs(pg - po).max(1), np.abs(p32 - po).max(1), 5e-6)
     for _ in range(5):
         env.step(None)
         orc.step(np.zeros((n, 12)))
-    err = np.abs(env.get_state().cpu().numpy()[:, 13:25] - orc.get_state()[:, 13:25]).max(1)
-    _lt(np.median(err), 5e-3, "heightfield: median joint error, 5 steps")
-    _lt(err.max(), 3e-2, "heightfield: max joint error, 5 steps (C0 terrain: normals jump at cell edges)")
+        o32.step(np.zeros((n, 12)))
+    compare("joint angles after 5 steps (rad)", np.abs(env.get_state().cpu().numpy()[:, 13:25] - orc.get_state()[:, 13:25]).max(1),
+            np.abs(o32.get_state()[:, 13:25] - orc.get_state()[:, 13:25]).max(1), 2e-5)
     env.close()
 
 
@@ -406,7 +426,7 @@ def test_both_kernel_mappings_match_oracle(lanes):
     orc.set_params(etg_w=W, etg_b=B)
     obs_o = orc.reset()
     _lt(np.abs(env.obs.cpu().numpy() - obs_o).max(), 2e-3, "lanes=%d reset observation" % lanes)
-    _lt(np.abs(env.get_state().cpu().numpy()[:, :7] - orc.get_state()[:, :7]).max(), 1e-4, "lanes=%d settle pose" % lanes)
+    _lt(np.abs(env.get_state().cpu().numpy()[:, :7] - orc.get_state()[:, :7]).max(), 1e-6, "lanes=%d settle pose" % lanes)
     rng = np.random.default_rng(2)
     wq = wp = 0.0
     for k in range(10):
@@ -415,8 +435,8 @@ def test_both_kernel_mappings_match_oracle(lanes):
         orc.step(act)
         st_g, st_o = env.get_state().cpu().numpy(), orc.get_state()
         wq = max(wq, np.abs(st_g[:, 13:25] - st_o[:, 13:25]).max()); wp = max(wp, np.abs(st_g[:, :7] - st_o[:, :7]).max())
-    _lt(wq, 1e-4, "lanes=%d joint angles, 10 steps" % lanes)
-    _lt(wp, 1e-4, "lanes=%d base pose, 10 steps" % lanes)
+    _lt(wq, 3e-5, "lanes=%d joint angles, 10 steps" % lanes)
+    _lt(wp, 1e-5, "lanes=%d base pose, 10 steps" % lanes)
     env.close()
 
 
@@ -774,7 +794,7 @@ def test_short_control_latency_reads_this_steps_ring_slots(lanes):
         og = env.step(None)[0].cpu().numpy()
         oo = orc.step(np.zeros((n, 12)))[0]
         w = max(w, np.abs(og - oo).max())
-    _lt(w, 5e-3, "lanes=%d latency sweep: observations over 4 steps (normalised)" % lanes)
+    _lt(w, 2e-3, "lanes=%d latency sweep: observations over 4 steps (normalised)" % lanes)
     env.close()
 
 
