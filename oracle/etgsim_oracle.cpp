@@ -712,25 +712,27 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
       if (ln < 0) ln = 0;
       apply(r0, ln - e.lam[r0]);
       e.lam[r0] = ln;
-      // tangents (sequential), then projection on the friction disc
+      // tangents: both candidates from the SAME velocities (the two directions of a foot are solved as one block: their
+      // mutual coupling A[t1][t2] is a small anisotropy term), the pair projected on the friction disc mu ln (or, with
+      // friction_model 1, each clamped on its own), then both changes applied
       T lim = e.mu * ln;
-      for (int k = 1; k < 3; k++) {
-        T lt = e.lam[r0 + k] - u[r0 + k] / A[r0 + k][r0 + k];
-        if (pyramid) {   // friction_model 1: each direction clamped on its own to +-mu ln inside its row solve
-          if (lt > lim) lt = lim;
-          if (lt < -lim) lt = -lim;
-        }
-        apply(r0 + k, lt - e.lam[r0 + k]);
-        e.lam[r0 + k] = lt;
-      }
-      T nt = std::sqrt(e.lam[r0 + 1] * e.lam[r0 + 1] + e.lam[r0 + 2] * e.lam[r0 + 2]);
-      if (!pyramid && nt > lim) {
-        T sc = (nt > 0) ? lim / nt : T(0);
+      T cand[3];
+      for (int k = 1; k < 3; k++) cand[k] = e.lam[r0 + k] - u[r0 + k] / A[r0 + k][r0 + k];
+      if (pyramid) {
         for (int k = 1; k < 3; k++) {
-          T lt = e.lam[r0 + k] * sc;
-          apply(r0 + k, lt - e.lam[r0 + k]);
-          e.lam[r0 + k] = lt;
+          if (cand[k] > lim) cand[k] = lim;
+          if (cand[k] < -lim) cand[k] = -lim;
         }
+      } else {
+        T nt = std::sqrt(cand[1] * cand[1] + cand[2] * cand[2]);
+        if (nt > lim) {
+          T sc = (nt > 0) ? lim / nt : T(0);
+          cand[1] *= sc; cand[2] *= sc;
+        }
+      }
+      for (int k = 1; k < 3; k++) {
+        apply(r0 + k, cand[k] - e.lam[r0 + k]);
+        e.lam[r0 + k] = cand[k];
       }
       if (kactive[l]) {   // the leg's knee row comes after its foot rows
         const int rk = 12 + l;

@@ -538,7 +538,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   // FROZEN for the sweeps its wave neighbours still need (iA = k = c0 = 0: every candidate is the current impulse, exact
   // zero deltas; mu = 1e30: the cone projection is the identity) -- see physics_tick16.
   F mu = tp.mu;
-  F k10 = Aown[1][0] * iA1, k20 = Aown[2][0] * iA2, k21 = Aown[2][1] * iA2, c0 = tgt * iA0;
+  F k10 = Aown[1][0] * iA1, k20 = Aown[2][0] * iA2, c0 = tgt * iA0;
   const bool pyramid = !Ctx::kPlain && K.fric_pyramid;
   F own[4];
 #pragma unroll
@@ -546,19 +546,17 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   auto pgs_sweep = [&]() {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
+      // normal row, then the two tangent rows as ONE block: both candidates from the velocities after the normal update
+      // (u_t + A_t0 (ln - l0)), the pair projected on the friction disc (friction_model 1: each clamped on its own)
       F ln = fmaxf_(zero, (l0 + c0) - u0 * iA0);
-      F q1 = (l1 - u1 * iA1) + k10 * l0;
-      F lt1 = q1 - k10 * ln;
+      F lt1 = ((l1 - u1 * iA1) + k10 * l0) - k10 * ln;
+      F lt2 = ((l2 - u2 * iA2) + k20 * l0) - k20 * ln;
       F e0 = ln - l0, e1, e2;
-      if (pyramid) {   // friction_model 1: each direction clamped on its own to +-mu ln inside its row solve
+      if (pyramid) {
         const F lim = mu * ln;
-        lt1 = fminf_(fmaxf_(lt1, -lim), lim);
-        F q2 = ((l2 - u2 * iA2) + k20 * l0) + k21 * l1;
-        F lt2 = fminf_(fmaxf_((q2 - k20 * ln) - k21 * lt1, -lim), lim);
-        e1 = lt1 - l1; e2 = lt2 - l2;
+        e1 = fminf_(fmaxf_(lt1, -lim), lim) - l1;
+        e2 = fminf_(fmaxf_(lt2, -lim), lim) - l2;
       } else {
-        F q2 = ((l2 - u2 * iA2) + k20 * l0) + k21 * l1;
-        F lt2 = (q2 - k20 * ln) - k21 * lt1;
         F sc = fminf_(one, (mu * ln) * rsqrt_(fmaxf_(lt1 * lt1 + lt2 * lt2, F(1e-30f))));
         e1 = lt1 * sc - l1; e2 = lt2 * sc - l2;
       }
@@ -572,17 +570,18 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   if (K.res_thr > 0.0f) {
     // EtgConfig.solver_residual: sweep until the robot's largest squared row residual is <= the threshold (see
     // physics_tick16); one quad max per sweep, the loop ends when every robot of the wave is done
-    const F thr(K.res_thr);
+    // |l - l at the start of the sweep| > sqrt(thr) / A_rr per row (see physics_tick16); the tolerances are made from the
+    // unfrozen inverses once per tick
+    const F tol0 = F(K.res_sqrt) * iA0, tol1 = F(K.res_sqrt) * iA1, tol2 = F(K.res_sqrt) * iA2;
     int it = 0;
     bool more;
     auto sweep_and_test = [&]() {
       const F s0 = l0, s1 = l1, s2 = l2;
       pgs_sweep();
       it++;
-      const F d0 = (l0 - s0) * Aown[0][0], d1 = (l1 - s1) * Aown[1][1], d2 = (l2 - s2) * Aown[2][2];
-      const auto live = c.qmax(fmaxf_(fmaxf_(d0 * d0, d1 * d1), d2 * d2)) > thr;
+      const auto live = c.robot_any((fabsf_(l0 - s0) > tol0) || (fabsf_(l1 - s1) > tol1) || (fabsf_(l2 - s2) > tol2));
       iA0 = sel_(live, iA0, zero); iA1 = sel_(live, iA1, zero); iA2 = sel_(live, iA2, zero);
-      k10 = sel_(live, k10, zero); k20 = sel_(live, k20, zero); k21 = sel_(live, k21, zero);
+      k10 = sel_(live, k10, zero); k20 = sel_(live, k20, zero);
       c0 = sel_(live, c0, zero);
       mu = sel_(live, mu, F(1e30f));
       more = c.wave_any(live) && it < K.iters;

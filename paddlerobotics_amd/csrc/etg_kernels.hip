@@ -94,6 +94,13 @@ struct GpuCtx {
   __device__ __forceinline__ bool lane_is(int j) const { return lane == j; }
   __device__ __forceinline__ bool any(bool b) const { return __any(b); }
   __device__ __forceinline__ bool wave_any(bool b) const { return __any(b); }   // "does any robot of the wave need another sweep?"
+  // "does any lane of MY robot (quad) see b?" from the wave mask of the compare: two ANDs with this lane's quad field
+  __device__ __forceinline__ bool robot_any(bool b) const {
+    const unsigned long long m = __ballot(b);
+    const unsigned sh = (unsigned)(threadIdx.x & 28);           // first lane of the quad inside its 32-lane half
+    const unsigned f = 0xFu << sh;
+    return ((threadIdx.x & 32) ? ((unsigned)(m >> 32) & f) : ((unsigned)m & f)) != 0u;
+  }
   __device__ __forceinline__ int uniform_int(float a) const { return (int)a; }
   __device__ __forceinline__ void terrain(const KCfg& K, float x, float y, float& h, float& nx, float& ny, float& nz) const {
     if (K.terrain == 0) { h = 0.0f; nx = 0.0f; ny = 0.0f; nz = 1.0f; }
@@ -414,6 +421,12 @@ struct GpuCtx16 {
   __device__ __forceinline__ bool leg_is(int j) const { return leg == j; }
   __device__ __forceinline__ bool any(bool b) const { return __any(b); }
   __device__ __forceinline__ bool wave_any(bool b) const { return __any(b); }   // "does any robot of the wave need another sweep?"
+  // "does any lane of MY robot (16-lane row) see b?" from the wave mask of the compare
+  __device__ __forceinline__ bool robot_any(bool b) const {
+    const unsigned long long m = __ballot(b);
+    const unsigned f = (tid & 16) ? 0xFFFF0000u : 0x0000FFFFu;
+    return ((tid & 32) ? ((unsigned)(m >> 32) & f) : ((unsigned)m & f)) != 0u;
+  }
   __device__ __forceinline__ int uniform_int(float a) const { return (int)a; }
   __device__ __forceinline__ float par(int k) const { return lds[k * 64]; }
   __device__ __forceinline__ float par_joint(int base) const { return lds[(base + sc) * 64]; }

@@ -76,6 +76,7 @@ struct KCfg {
   unsigned long long noise_seed;
   unsigned noise_call;   // stream position of the first observation this launch writes
   float res_thr;         // EtgConfig.solver_residual: > 0 = sweep until the robot's squared row residual is below it (iters = cap)
+  float res_sqrt;        // sqrt(res_thr): the kernels compare |d lambda| with res_sqrt / A_rr
   int fric_pyramid;      // EtgConfig.friction_model == 1: per-direction clamp instead of the disc projection
 };
 
@@ -329,6 +330,7 @@ inline KCfg make_kcfg(const EtgConfig& c, const EtgRobotModel& m) {
   for (int k = 0; k < 3; k++) K.trunk_half[k] = (float)c.trunk_half[k];
   K.etg_on = c.enable_etg != 0;
   K.res_thr = (float)c.solver_residual;
+  K.res_sqrt = (float)sqrt(c.solver_residual > 0 ? c.solver_residual : 0.0);
   K.fric_pyramid = c.friction_model == 1;
   K.jlim = c.joint_limits != 0;
   for (int k = 0; k < 3; k++) { K.jlo[k] = (float)c.joint_lower[k]; K.jhi[k] = (float)c.joint_upper[k]; }

@@ -31,6 +31,7 @@ struct WaveAny {
 struct EmuCtxBase {
   WaveAny wa;
   bool wave_any(B4 b) const { return wa.more(any(b)); }
+  B4 robot_any(B4 b) const { const bool a = any(b); B4 r; for (int l = 0; l < 4; l++) r.v[l] = a; return r; }
   int env, N;
   const float* parp;
   F4 par(int k) const { return ld_lane(parp, k); }
@@ -96,6 +97,7 @@ typedef EmuCtxT<false> EmuCtx;   // generic-terrain instantiation; the flat fast
 struct EmuCtx16Base {
   WaveAny wa;
   bool wave_any(B16 b) const { return wa.more(any(b)); }
+  B16 robot_any(B16 b) const { const bool a = any(b); B16 r; for (int l = 0; l < 16; l++) r.v[l] = a; return r; }
   int env, N;
   const float* parp;
   int NL() const { return 4 * N; }
