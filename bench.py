@@ -267,6 +267,7 @@ def main():
         torch.cuda.synchronize(dev)
 
     stat_buf = (torch.empty(N, device=dev), torch.empty(N, dtype=torch.int32, device=dev))   # episode returns / lengths of a rollout
+    wall_local = []      # this rank's own wall seconds of the last timed_repeats() call (before the max over ranks)
 
     def run_steps(e, pol, n, fused):
         """n control steps of the hot path: the fused rollouts (etg_rollout_openloop / etg_rollout_policy, <= 50 control steps
@@ -288,6 +289,7 @@ def main():
         wall seconds (max over ranks), the per-repeat kernel milliseconds per control step (HIP event pair on the launch
         stream around the K steps) and the fraction of robots still alive after the last repeat."""
         wall, kern = [], []
+        wall_local.clear()
         surv = float("nan")
         for _ in range(repeats):
             e.reset(ETG_w=w, ETG_b=b)
@@ -310,7 +312,9 @@ def main():
             if dist is not None:
                 R.gather_returns(ret, dist)
             barrier()
-            wall.append(max_over_ranks(time.perf_counter() - t0, dist, dev))
+            local = time.perf_counter() - t0
+            wall.append(max_over_ranks(local, dist, dev))
+            wall_local.append(local)
             if events:
                 kern.append(e0.elapsed_time(e1) / K)
             if not getattr(e, "auto_reset", False):
@@ -336,6 +340,28 @@ def main():
     wall, kern, survivors = timed_repeats(env, policy, fused, repeats, events=True)
     elapsed = float(np.median(wall))
     kern_ms = float(np.median(kern))
+    # N > 1: every rank's own median step time, and the one exchange of the path (the all_gather of the returns) on its own
+    multi = None
+    if dist is not None:
+        mine = torch.tensor([float(np.median(wall_local)) / K * 1e3], dtype=torch.float64,
+                            device=dev if dist.get_backend() == "nccl" else "cpu")
+        allr = torch.empty(world, dtype=torch.float64, device=mine.device)
+        dist.all_gather_into_tensor(allr, mine)
+        ret_probe = env.episode_stats()[0]
+        for _ in range(3):
+            R.gather_returns(ret_probe, dist)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            g = R.gather_returns(ret_probe, dist)
+        torch.cuda.synchronize(dev)
+        gather_ms = (time.perf_counter() - t0) / 20 * 1e3
+        multi = {"ms_per_step_by_rank": [float(x) for x in allr.cpu().tolist()],
+                 "return_gather": {"ms": max_over_ranks(gather_ms, dist, dev), "elements": int(g.numel()), "bytes": int(g.numel()) * 4,
+                                   "collective": "all_gather_into_tensor", "backend": dist.get_backend(),
+                                   "note": "20 back-to-back gathers of the N x world fp32 returns, host clock, max over ranks; one such "
+                                           "gather is inside every timed repeat"},
+                 "world_size_reported_by": "torch.distributed/" + dist.get_backend(), "world_size": dist.get_world_size()}
 
     # ---- legs reported NEXT to `value`, never part of it
     extra = {}
@@ -457,6 +483,8 @@ def main():
                                              "frac": v / VALU_PEAK_PER_SIMD_CYCLE, "single_wave_limit": 0.2,
                                              "valu_insts_per_wave_step_source": "profiles/r02_pmc.json (SQ_INSTS_VALU / SQ_WAVES)"}
         out.update(extra)
+        if multi is not None:
+            out["multi_gpu"] = multi
         out["roofline"]["hbm_copy_measured_GBps"] = device_copy_bandwidth(dev) / 1e9
         if policy is not None:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

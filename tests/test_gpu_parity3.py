@@ -428,3 +428,57 @@ def test_dynamics_identification_evaluator_fused_equals_stepping(golden):
     assert gap[up].max() < 2e-2 * (1 + np.abs(out[False][0][up]).max())
     assert np.corrcoef(out[True][0][up], out[False][0][up])[0, 1] > 0.999
     env.close()
+
+
+def _rccl_worker(rank, world, port, n_per_rank, out):
+    """one rank of the 2-GPU ES generation: its own GPU, RCCL (backend "nccl"), its slice of the candidates"""
+    import torch.distributed as dist
+    from paddlerobotics_amd import rollout as R
+    from paddlerobotics_amd.es import SimpleGA
+    from paddlerobotics_amd.env import make_env
+    from paddlerobotics_amd.etg import ETG_layer, Opt_with_points
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    torch.cuda.set_device(rank)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", rank))
+    env = make_env("Quadrupedal", num_envs=n_per_rank, device="cuda:%d" % rank)
+    layer = ETG_layer(0.5, 0.026, 20, 0.04, np.array([-np.pi / 2, 0]), 0.2, 0.5)
+    w0, b0, prior = Opt_with_points(layer, ETG_T=0.5, Footheight=0.1, Steplength=0.05)
+    ga = SimpleGA(12, sigma_init=0.02, sigma_decay=0.99, sigma_limit=0.005, elite_ratio=0.1, weight_decay=0.005,
+                  popsize=world * n_per_rank, param=np.zeros(12), seed=5, device="cuda:%d" % rank)
+    ev = R.make_etg_evaluator(env, layer, 0.5, prior, w0, b0, max_step=60)
+    fits = [R.es_generation(ga, ev, dist, rank, world).cpu().numpy() for _ in range(2)]
+    out[rank] = (np.stack(fits), ga.best_param.cpu().numpy(), dist.get_world_size(), dist.get_backend())
+    env.close()
+    dist.destroy_process_group()
+
+
+def test_two_rank_es_generation_over_rccl():
+    """BASELINE configs[3] in miniature, the moment two GPUs exist: two ranks, one GPU each, RCCL all_gather of the returns,
+    replicated tell -- the gathered fitness vector and the next population equal the single-rank run of the same
+    candidates (robots do not depend on their batch).  Skipped on a 1-GPU box (the gloo world-size-2 CPU test covers the
+    control flow there: tests/test_es_and_sharding.py)."""
+    _need_gpu()
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two HIP devices (one rank per GPU over RCCL)")
+    import socket
+    import torch.multiprocessing as mp
+    from paddlerobotics_amd import rollout as R
+    from paddlerobotics_amd.es import SimpleGA
+    from paddlerobotics_amd.etg import ETG_layer, Opt_with_points
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    n_per_rank, world = 64, 2
+    out = mp.Manager().dict()
+    mp.spawn(_rccl_worker, args=(world, port, n_per_rank, out), nprocs=world, join=True)
+    env = _make(world * n_per_rank)
+    layer = ETG_layer(0.5, 0.026, 20, 0.04, np.array([-np.pi / 2, 0]), 0.2, 0.5)
+    w0, b0, prior = Opt_with_points(layer, ETG_T=0.5, Footheight=0.1, Steplength=0.05)
+    ga = SimpleGA(12, sigma_init=0.02, sigma_decay=0.99, sigma_limit=0.005, elite_ratio=0.1, weight_decay=0.005,
+                  popsize=world * n_per_rank, param=np.zeros(12), seed=5, device="cuda:0")
+    ev = R.make_etg_evaluator(env, layer, 0.5, prior, w0, b0, max_step=60)
+    ref = np.stack([R.es_generation(ga, ev).cpu().numpy() for _ in range(2)])
+    for r in range(world):
+        fits, best, ws, backend = out[r]
+        assert ws == world and backend == "nccl"
+        assert np.array_equal(fits, ref)                                  # gather order = candidate order, robots batch-invariant
+        assert np.array_equal(best, ga.best_param.cpu().numpy())          # replicated tell
+    env.close()

@@ -1,0 +1,119 @@
+"""Static ISA statistics of the kernels inside a built libetgsim.so (no GPU needed): registers, scratch and the instruction mix
+of a kernel, from the gfx950 code object llvm-objdump extracts.  The CPU suite pins the headline kernel's numbers with it
+(tests/test_kernel_isa.py) so that a toolchain bump or an innocent edit that moves the hot loop's code generation is caught.
+
+usage: python tools/kernel_isa_stats.py [libetgsim.so] [kernel-name-substring ...]"""
+import collections
+import glob
+import os
+import re
+import shutil
+import subprocess
+import sys
+import tempfile
+
+LLVM = "/opt/rocm/lib/llvm/bin"
+
+
+def code_objects(so):
+    """extract the gfx950 code objects of the fat binary into a temp dir -> (tmpdir, [paths])"""
+    tmp = tempfile.mkdtemp(prefix="etgisa_")
+    local = os.path.join(tmp, "lib.so")
+    shutil.copy(so, local)
+    subprocess.run([os.path.join(LLVM, "llvm-objdump"), "--offloading", local], check=True, capture_output=True)
+    return tmp, sorted(glob.glob(local + ".*gfx950*"))
+
+
+def disassemble(co):
+    r = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], check=True, capture_output=True, text=True)
+    return r.stdout
+
+
+def notes(co):
+    r = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True)
+    out = {}
+    for m in re.finditer(r"\.agpr_count:\s+(\d+).*?\.name:\s+(\S+).*?\.private_segment_fixed_size:\s+(\d+).*?\.sgpr_count:\s+(\d+).*?"
+                         r"\.vgpr_count:\s+(\d+)", r.stdout, re.S):
+        out[m.group(2)] = dict(agpr=int(m.group(1)), scratch=int(m.group(3)), sgpr=int(m.group(4)), vgpr=int(m.group(5)))
+    return out
+
+
+def kernel_bodies(asm):
+    """symbol -> list of instruction lines"""
+    out, cur = {}, None
+    for line in asm.split("\n"):
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+        if m:
+            cur = m.group(1)
+            out[cur] = []
+            continue
+        t = line.strip()
+        if cur is None or not t or t.startswith("Disassembly"):
+            continue
+        t = re.sub(r"^[0-9a-f]+:\s*", "", t)
+        out[cur].append(t)
+    return out
+
+
+def mix(lines):
+    c = collections.Counter()
+    for t in lines:
+        t = t.split("//")[0].strip()
+        if not t or t.startswith("<"):
+            continue
+        op = t.split()[0]
+        c["all"] += 1
+        if op.startswith("v_"):
+            c["valu"] += 1
+            if "dpp" in t or "row_" in t or "quad_perm" in t:
+                c["dpp"] += 1
+            if op.startswith("v_mfma"):
+                c["mfma"] += 1
+            if op.startswith("v_pk_"):
+                c["pk"] += 1
+            if re.match(r"v_(rcp|rsq|sqrt|sin|cos|exp|log)", op):
+                c["trans"] += 1
+            if "accvgpr" in op:
+                c["acc_moves"] += 1
+        elif op == "s_nop":
+            c["s_nop"] += 1
+        elif op.startswith("s_waitcnt"):
+            c["waitcnt"] += 1
+        elif op.startswith("ds_"):
+            c["lds"] += 1
+        elif op.startswith(("global_", "buffer_", "flat_")):
+            c["vmem"] += 1
+        elif op.startswith("scratch_"):
+            c["scratch_ops"] += 1
+        elif op.startswith(("s_cbranch", "s_branch")):
+            c["branch"] += 1
+        elif op.startswith("s_"):
+            c["salu"] += 1
+    return dict(c)
+
+
+def stats(so, want=()):
+    tmp, cos = code_objects(so)
+    try:
+        res = {}
+        for co in cos:
+            meta = notes(co)
+            bodies = kernel_bodies(disassemble(co))
+            for sym, lines in bodies.items():
+                if sym not in meta:
+                    continue
+                if want and not any(w in sym for w in want):
+                    continue
+                res[sym] = dict(meta[sym], **mix(lines))
+        return res
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    so = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].endswith(".so") else os.path.join(root, "paddlerobotics_amd", "csrc", "libetgsim.so")
+    want = [a for a in sys.argv[1:] if not a.endswith(".so")]
+    for sym, st in sorted(stats(so, want).items()):
+        print(sym)
+        print("   ", " ".join("%s=%s" % kv for kv in sorted(st.items())))
