@@ -548,16 +548,16 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
     for (int j = 0; j < 4; j++) {
       // normal row, then the two tangent rows as ONE block: both candidates from the velocities after the normal update
       // (u_t + A_t0 (ln - l0)), the pair projected on the friction disc (friction_model 1: each clamped on its own)
-      F ln = fmaxf_(zero, (l0 + c0) - u0 * iA0);
-      F lt1 = ((l1 - u1 * iA1) + k10 * l0) - k10 * ln;
-      F lt2 = ((l2 - u2 * iA2) + k20 * l0) - k20 * ln;
-      F e0 = ln - l0, e1, e2;
+      F e0 = fmaxf_(-l0, c0 - u0 * iA0), e1, e2;                      // = max(0, l0 + c0 - u0 / A00) - l0
+      F ln = l0 + e0;
+      F lt1 = (l1 - u1 * iA1) - k10 * e0;
+      F lt2 = (l2 - u2 * iA2) - k20 * e0;
       if (pyramid) {
         const F lim = mu * ln;
         e1 = fminf_(fmaxf_(lt1, -lim), lim) - l1;
         e2 = fminf_(fmaxf_(lt2, -lim), lim) - l2;
       } else {
-        F sc = fminf_(one, (mu * ln) * rsqrt_(fmaxf_(lt1 * lt1 + lt2 * lt2, F(1e-30f))));
+        F sc = fminf_(one, (mu * ln) * rsqrt_((lt1 * lt1 + F(1e-30f)) + lt2 * lt2));
         e1 = lt1 * sc - l1; e2 = lt2 * sc - l2;
       }
       F b0 = c.qbcast(e0, j), b1 = c.qbcast(e1, j), b2 = c.qbcast(e2, j);

@@ -413,11 +413,11 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   auto pgs_sweep = [&]() {
 #pragma unroll
     for (int lp = 0; lp < 4; lp++) {
-      // normal row: ln = max(0, lam - (u - tgt)/A); the owner's lam update sits between the candidate and its
-      // broadcast, where the DPP read needs two wait states anyway
-      F dln = fmaxf_(zero, (lam + c0e) - u * iAe) - lam;
+      // normal row: ln = max(0, lam - (u - tgt)/A), as a change: max(-lam, (tgt - u)/A); the owner's lam update sits
+      // between the candidate and its broadcast, where the DPP read needs two wait states anyway
+      F dln = fmaxf_(-lam, c0e - u * iAe);                          // = max(0, lam + c0 - u / A) - lam
       lam = lam + mk[lp][0] * dln;
-      F b = c.rbcast(dln, 4 * lp);
+      const F b = c.rbcast(dln, 4 * lp);
       u = u + A[lp][0] * b;
       // tangent rows t1, t2 of the foot as ONE block: each of the two lanes computes its row's candidate from the same
       // velocities in the same instruction, the pair is projected on the friction disc mu ln (friction_model 1: each clamped
@@ -430,14 +430,14 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
         dl = fminf_(fmaxf_(lc, -lim), lim) - lam;
       } else {
         const F oth = c.qswap12(lc);
-        const F sc = fminf_(one, lim * rsqrt_(fmaxf_(lc * lc + oth * oth, F(1e-30f))));
+        const F sc = fminf_(one, lim * rsqrt_((lc * lc + F(1e-30f)) + oth * oth));   // (the 1e-30 keeps 0 * rsq(0) off the table)
         dl = lc * sc - lam;
       }
       const F b1 = c.rbcast(dl, 4 * lp + 1), b2 = c.rbcast(dl, 4 * lp + 2);
       u = u + A[lp][1] * b1 + A[lp][2] * b2;
       lam = lam + mt[lp] * dl;
       if (knee) {   // the leg's knee row, after its foot rows: lk = max(0, lk - (u - tgt)/A)
-        F dlk = fmaxf_(zero, (lam + c0e) - u * iAe) - lam;
+        F dlk = fmaxf_(-lam, c0e - u * iAe);
         lam = lam + ownl[lp] * f3 * dlk;
         F bk = c.rbcast(dlk, 4 * lp + 3);
         u = u + Ak[lp] * bk;

@@ -2,7 +2,7 @@
 # PMC counters of the bench command, one counter group per pass (no trace domains mixed in; gpurun refuses --pmc with
 # sys/hip/hsa traces).  usage: tools/pmc_gpu.sh <tag> ; extra bench flags through PMC_BENCH_ARGS (e.g. "--config 3").
 # Writes gpurun_out/pmc_<tag>.txt (raw means per launch) and gpurun_out/pmc_<tag>.json (per kernel and control step,
-# the format bench.py reads from profiles/r02_pmc.json).
+# the format bench.py reads from profiles/r03_pmc.json).
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=/tmp/pmc_$1
