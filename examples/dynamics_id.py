@@ -30,6 +30,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)          # e_step of sample_episode, Dynamic_parallel_model.py:53
     ap.add_argument("--sigma", type=float, default=0.1)
     ap.add_argument("--device", type=str, default="cuda:0")
+    ap.add_argument("--step-loop", action="store_true",
+                    help="replay through env.step() per control step (the reference's loop shape) instead of the fused action-tape rollout")
     args = ap.parse_args()
     T, N = args.steps, args.popsize
     # two recorded joint-target sequences: the ETG prior gait ("exp") and standing still ("ori")
@@ -53,7 +55,7 @@ def main():
             mot.append(info["joint_angle"][0].cpu().numpy()); dr.append(info["obs-IMU"][0, 3:].cpu().numpy())
         mean_dict[key + "_motor_mean"], mean_dict[key + "_drpy_mean"] = np.array(mot), np.array(dr)
         mean_dict[key + "_motor_std"], mean_dict[key + "_drpy_std"] = np.full((T, 12), 0.05), np.full((T, 3), 0.5)
-    evaluate = R.make_dynamics_id_evaluator(env, gait, mean_dict, e_steps=T)
+    evaluate = R.make_dynamics_id_evaluator(env, gait, mean_dict, e_steps=T, fused=not args.step_loop)
     solver = SimpleGA(48, sigma_init=args.sigma, sigma_decay=0.995, sigma_limit=0.02, elite_ratio=0.1, weight_decay=0.005,
                       popsize=N, param=np.zeros(48), device=args.device)                     # ES_ParallelModel defaults
     for g in range(args.generations):

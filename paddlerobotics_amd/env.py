@@ -131,6 +131,10 @@ class _InfoView(dict):
         return len(A.INFO_SLICES)
 
 
+class FusedKernelUnavailable(ValueError):
+    """the configuration is outside what a fused rollout kernel covers (callers may fall back to the stepping loop)"""
+
+
 class BatchedQuadrupedEnv:
     def __init__(self, num_envs=1, device="cuda:0", task="ground", motor_control_mode=None, render=False,
                  sensor_mode=None, normal=1, dynamic_param=None, reward_param=None, ETG=1, ETG_T=0.5,
@@ -511,6 +515,9 @@ class BatchedQuadrupedEnv:
         """n_steps control steps with zero residual action (pretrain.py:129-154) enqueued back to
         back; returns (episode_return[N], episode_len[N]) since the last reset, alive-masked.  out = (ret float32 [N],
         len int32 [N]) reuses the caller's buffers."""
+        if self.auto_reset:
+            raise ValueError("rollout_openloop does not restart finished robots: step an auto_reset env with step(), or roll out an "
+                             "env made without auto_reset")
         if out is not None:
             ret, ln = out
             if ret.dtype != torch.float32 or ln.dtype != torch.int32 or ret.numel() != self.num_envs or ln.numel() != self.num_envs \
@@ -528,9 +535,10 @@ class BatchedQuadrupedEnv:
         steps; returns (episode_return[N], episode_len[N]).  The batched run_EStrain_episode / run_evaluate_episodes
         (train.py:182-249).  Falls back to stepping when the fused kernel does not apply."""
         contiguous = self._cols == list(range(self._cols[0], self._cols[0] + len(self._cols)))   # e.g. the student's 3..48
+        # (the fused kernels never restart a finished robot: an auto_reset env takes the stepping loop, which does)
         ok = (self.lanes_per_robot == 16 and self.num_envs % 16 == 0 and self.motor_mode != 2 and contiguous
               and self._hist_T == 0 and not self._rand_force and policy.obs_dim == len(self._cols)
-              and policy.action_dim == A.NUM_MOTORS)
+              and policy.action_dim == A.NUM_MOTORS and not self.auto_reset)
         if not ok:
             act = None
             for _ in range(int(n_steps)):
@@ -550,11 +558,13 @@ class BatchedQuadrupedEnv:
         final_obs [N,49]).  The data half of run_EStrain_episode with es_rpm (train.py:213-249) at the fused kernel's speed;
         replay.store_recorded() moves the rows of live robots into a DeviceReplayMemory.  Needs the configuration the
         fused kernel needs (16-lane mapping, num_envs % 16 == 0, the full 49-float observation, POSITION / TORQUE mode)."""
+        if self.auto_reset:
+            raise FusedKernelUnavailable("rollout_policy_record does not restart finished robots: use an env without auto_reset")
         if not (self.lanes_per_robot == 16 and self.num_envs % 16 == 0 and self.motor_mode != 2 and self._hist_T == 0
                 and not self._rand_force and self._cols == list(range(A.OBS_DIM)) and self._xcol_idx is None
                 and policy.obs_dim == A.OBS_DIM and policy.action_dim == A.NUM_MOTORS):
-            raise ValueError("rollout_policy_record needs the 16-lane mapping, num_envs % 16 == 0, the plain 49-float observation "
-                             "and a 49 -> 12 actor; use replay.collect_transitions() for the other configurations")
+            raise FusedKernelUnavailable("rollout_policy_record needs the 16-lane mapping, num_envs % 16 == 0, the plain 49-float "
+                                         "observation and a 49 -> 12 actor; use replay.collect_transitions() for the other configurations")
         T, N = int(n_steps), self.num_envs
         if noise is not None:   # the stochastic actor (SAC.sample): tanh(mean + exp(clamp(log_std)) * noise), noise [T, N, 12] ~ N(0, 1)
             noise = torch.as_tensor(noise, dtype=torch.float32, device=self.device).contiguous()

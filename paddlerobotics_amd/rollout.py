@@ -79,9 +79,10 @@ def make_etg_evaluator(env, etg_layer, ETG_T, prior_points, w0, b0, max_step=400
         w, b = opt_with_points_batched(etg_layer, ETG_T, pts, b0, w0, device=env.device)
         if rpm is not None and policy is not None:
             from . import replay
+            from .env import FusedKernelUnavailable
             try:
                 ret, _ = replay.collect_recorded(env, rpm, max_step, policy, action_bound, ETG_w=w.float(), ETG_b=b.float())
-            except ValueError:          # a configuration the fused kernel does not cover
+            except FusedKernelUnavailable:   # ONLY "the fused kernel does not cover this configuration": other errors surface
                 ret, _, _ = replay.collect_transitions(env, rpm, max_step, policy=policy, action_bound=action_bound,
                                                        ETG_w=w.float(), ETG_b=b.float())
             return ret

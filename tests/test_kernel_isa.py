@@ -1,0 +1,38 @@
+"""CPU suite: the code generation of the hot kernels is pinned ("nothing pins the hot loops ... a toolchain bump
+can silently move the headline").  The step time of these kernels is (instructions per wave) x ~4.4 cycles with one wave per
+SIMD, and their register allocation sits close to where hipcc starts spilling; profiles/r03_isa_baseline.json records, for the
+headline kernels, registers, scratch and the static instruction mix of the build the round's numbers were measured with.
+This test disassembles the library that was just built (llvm-objdump on its gfx950 code object) and compares:
+  * no scratch (spills) in the headline 16-lane kernels, registers within +8 of the recorded allocation;
+  * VALU / DPP-modified / s_nop / transcendental instruction counts within 3 % (s_nop 10 %) of the recorded ones.
+A deliberate change of the kernels regenerates the file: python tools/kernel_isa_stats.py --write-baseline."""
+import json
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BASE = os.path.join(ROOT, "profiles", "r03_isa_baseline.json")
+
+
+def test_hot_kernel_code_generation_matches_the_recorded_baseline():
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_isa_stats as K
+    from paddlerobotics_amd import build
+    if not os.path.exists(K.LLVM + "/llvm-objdump"):
+        pytest.skip("no llvm-objdump in this image")
+    so = build.build()
+    base = json.load(open(BASE))
+    got = K.stats(so, list(base["kernels"].keys()))
+    assert set(got) == set(base["kernels"]), sorted(set(base["kernels"]) - set(got))
+    report = []
+    for sym, want in base["kernels"].items():
+        g = got[sym]
+        if want["scratch"] == 0:
+            assert g["scratch"] == 0, "%s spills (%d B of scratch)" % (sym, g["scratch"])
+        assert g["vgpr"] <= want["vgpr"] + 8 and g["agpr"] <= want["agpr"] + 16, (sym, g["vgpr"], g["agpr"])
+        for key, tol in (("valu", 0.03), ("dpp", 0.03), ("trans", 0.03), ("s_nop", 0.10), ("all", 0.03)):
+            if abs(g.get(key, 0) - want[key]) > tol * want[key] + 2:
+                report.append("%s: %s %d, recorded %d" % (sym, key, g.get(key, 0), want[key]))
+    assert not report, "code generation moved (regenerate profiles/r03_isa_baseline.json if intended):\n" + "\n".join(report)
