@@ -185,6 +185,11 @@ typedef struct EtgConfig {
    * mu lambda_n (isotropic Coulomb cone); 1 = each direction clamped on its own to +-mu lambda_n inside its row solve
    * (the friction pyramid of a sequential-impulse solver with two friction directions).                              */
   int32_t friction_model;
+  /* pd_latency of the robot class (minitaur.py:100,130-132,1195-1199): the motor model's PD law reads the joint angles and
+   * velocities this many seconds old -- blended from the two history readings that bracket the latency, exactly like the
+   * control-latency observation (minitaur.py:1172-1193) -- instead of the current ones.  0 (the reference's default, A1
+   * passes none) = the true state.  Applies to every sub-step, the reset settle included.                            */
+  double pd_latency;
 } EtgConfig;
 
 typedef struct EtgHandle EtgHandle;

@@ -843,6 +843,20 @@ template <class T> void delayed_obs(const Sim<T>& s, const Env<T>& e, T* o) {
 // hyb (HYBRID mode, laikago_motor.py:152-167): 12 x (kp, qd_des, kd, tau_ff) replacing the model's gains
 template <class T> void sub_step(const Sim<T>& s, Env<T>& e, const T* qdes, bool torque_cmd = false, const T* hyb = nullptr) {
   T tau[12];
+  // _GetPDObservation (minitaur.py:1195-1199): with pd_latency the PD law reads the joint state of that long ago, blended
+  // from the two bracketing history entries like the control observation (minitaur.py:1172-1193)
+  T qm[12], qdm[12];
+  for (int j = 0; j < 12; j++) { qm[j] = e.q[j]; qdm[j] = e.qd[j]; }
+  if (s.cfg.pd_latency > 0) {
+    const T dt = T(s.cfg.sim_dt), lat = T(s.cfg.pd_latency);
+    int n = (int)(s.cfg.pd_latency / s.cfg.sim_dt);
+    if (n > RING - 2) n = RING - 2;
+    const T alpha = (lat - T(n) * dt) / dt;
+    const int64_t ta = e.tick - n < 0 ? 0 : e.tick - n, tb = e.tick - n - 1 < 0 ? 0 : e.tick - n - 1;   // before the first tick: the initial reading
+    const T* a = e.hist[ta % RING];
+    const T* b = e.hist[tb % RING];
+    for (int j = 0; j < 12; j++) { qm[j] = (T(1) - alpha) * a[j] + alpha * b[j]; qdm[j] = (T(1) - alpha) * a[12 + j] + alpha * b[12 + j]; }
+  }
   for (int j = 0; j < 12; j++) {
     // POSITION: laikago_motor.py:165-173; TORQUE: the command is the torque (laikago_motor.py:140-143)
     T cmd = qdes[j];
@@ -852,8 +866,8 @@ template <class T> void sub_step(const Sim<T>& s, Env<T>& e, const T* qdes, bool
       if (cmd < e.q[j] - lim) cmd = e.q[j] - lim;
     }
     T t = torque_cmd ? cmd
-          : hyb ? (-(hyb[4 * j] * (e.q[j] - cmd)) - hyb[4 * j + 2] * (e.qd[j] - hyb[4 * j + 1])) + hyb[4 * j + 3]
-                : -(e.kp[j] * (e.q[j] - cmd)) - e.kd[j] * e.qd[j];
+          : hyb ? (-(hyb[4 * j] * (qm[j] - cmd)) - hyb[4 * j + 2] * (qdm[j] - hyb[4 * j + 1])) + hyb[4 * j + 3]
+                : -(e.kp[j] * (qm[j] - cmd)) - e.kd[j] * qdm[j];
     if (s.cfg.torque_limit > 0) {
       T lim = T(s.cfg.torque_limit);
       if (t > lim) t = lim;

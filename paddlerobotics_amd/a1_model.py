@@ -86,6 +86,7 @@ class EtgConfig(C.Structure):
         ("trunk_half", C.c_double * 3),
         ("solver_residual", C.c_double),
         ("friction_model", C.c_int32),
+        ("pd_latency", C.c_double),
     ]
 
 
@@ -201,7 +202,7 @@ def default_config(num_envs, *, action_repeat=13, sim_dt=0.002, settle_ticks=500
                    ETG_T=0.5, ETG_T2=0.5, etg_amp=0.2, etg_sigma_sq=0.04,
                    etg_phase=(-math.pi / 2, 0.0), reward_param=None, reward_p=5.0, vel_d=0.5,
                    heightfield=None, lanes_per_robot=0, motor_mode=0, clip_motor_commands=0.0,
-                   body_contacts=0, knee_radius=0.02, enable_etg=1, joint_limits=0, friction_model=0):
+                   body_contacts=0, knee_radius=0.02, enable_etg=1, joint_limits=0, friction_model=0, pd_latency=0.0):
     """EtgConfig with the defaults of train.py:296-297,470-487 and SURVEY App. A."""
     c = EtgConfig()
     c.num_envs = int(num_envs)
@@ -209,6 +210,7 @@ def default_config(num_envs, *, action_repeat=13, sim_dt=0.002, settle_ticks=500
     c.settle_ticks = int(settle_ticks)
     c.solver_iters, c.solver_residual = solver_rule(solver_iters, solver_residual)
     c.friction_model = int(friction_model)
+    c.pd_latency = float(pd_latency)
     c.enable_action_interp = int(bool(enable_action_interp))
     c.enable_action_filter = int(bool(enable_action_filter))
     c.obs_normal = int(bool(normal))

@@ -292,7 +292,8 @@ template <class F, class Ctx> ETG_HD TickPar4<F> load_tick_par4(const Ctx& c) {
 // stepSimulation() + ApplyAction + ReceiveObservation of minitaur.py:242-246 for one quad.
 template <class F, class Ctx>
 ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, LaneState<F>& L, const F* qdes,
-                         const V3<F>& fext_w, bool torque_cmd = false) {
+                         const V3<F>& fext_w, bool torque_cmd = false,
+                         const F* pd = nullptr) {   // pd[0..2] angles, pd[3..5] velocities the PD law reads (EtgConfig.pd_latency)
   typedef V3<F> V;
   typedef SV<F> W;
   const F dt(K.dt), zero(0.0f), one(1.0f);
@@ -303,8 +304,9 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   for (int j = 0; j < 3; j++) {
     F cmd = qdes[j];
     if (!Ctx::kPlain && K.clip_cmd > 0.0f && !torque_cmd) cmd = fminf_(fmaxf_(cmd, L.q[j] - F(K.clip_cmd)), L.q[j] + F(K.clip_cmd));   // a1.py:439-457
+    const F qm = (!Ctx::kPlain && pd) ? pd[j] : L.q[j], qdm = (!Ctx::kPlain && pd) ? pd[3 + j] : L.qd[j];   // minitaur.py:1195-1199
     F t = Ctx::kPlain ? -(tp.kp[j] * (L.q[j] - cmd)) - tp.kd[j] * L.qd[j]
-                      : (torque_cmd ? cmd : (-(tp.kp[j] * (L.q[j] - cmd)) - tp.kd[j] * (L.qd[j] - tp.qd_des[j])) + tp.tau_ff[j]);   // TORQUE mode: pass-through
+                      : (torque_cmd ? cmd : (-(tp.kp[j] * (qm - cmd)) - tp.kd[j] * (qdm - tp.qd_des[j])) + tp.tau_ff[j]);   // TORQUE mode: pass-through
     if (!Ctx::kPlain && K.torque_limit > 0.0f) t = fminf_(fmaxf_(t, F(-K.torque_limit)), F(K.torque_limit));
     tau[j] = t;
   }
@@ -692,6 +694,16 @@ template <class F, class Ctx> ETG_HD void ring_push(const Ctx& c, float* ring, i
   c.st_ring(ring, slot, 6, b0); c.st_ring(ring, slot, 7, b1);
 }
 template <class F> struct Delayed { F q[3], qd[3]; F qx, qy, qz, qw; V3<F> w; };
+ETG_HD const float* ring_of_tick4(const KCfg& K, const float* ring, int t) { return (K.cring != nullptr && t <= K.settle_ticks) ? K.cring : ring; }
+// the PD law's reading under EtgConfig.pd_latency (see pd_reading16)
+template <class F, class Ctx> ETG_HD void pd_reading(const Ctx& c, const KCfg& K, const float* ring, int tick, bool live, F* pd) {
+  const int ta = tick - K.pd_n < 0 ? 0 : tick - K.pd_n, tb = tick - K.pd_n - 1 < 0 ? 0 : tick - K.pd_n - 1;
+  const float *ra = live ? ring : ring_of_tick4(K, ring, ta), *rb_ = live ? ring : ring_of_tick4(K, ring, tb);
+  const int sa = ta & (RING - 1), sb = tb & (RING - 1);
+  const F a(K.pd_a), oma(1.0f - K.pd_a);
+#pragma unroll
+  for (int k = 0; k < 6; k++) pd[k] = oma * c.ld_ring(ra, sa, k) + a * c.ld_ring(rb_, sb, k);
+}
 template <class F, class Ctx>
 ETG_HD Delayed<F> ring_read(const Ctx& c, const KCfg& K, const float* ring, int tick) {
   // n_steps_ago / blend_alpha are env-uniform; lat_n < 0 encodes latency <= 0.  Readings of ticks up to the reset tick come
@@ -957,14 +969,21 @@ ETG_HD void control_step_core(const Ctx& c, const KCfg& K, TickPar4<F>& tp, cons
   const int mlat = n_lat < 0 ? 0 : n_lat % R_;
   const int ia = R_ - 1 - mlat;
   const int ib = n_lat < 0 ? ia : (ia == 0 ? R_ - 1 : ia - 1);
+  const bool pdl = !Ctx::kPlain && K.pd_n >= 0;
   for (int i = 0; i < K.action_repeat; i++) {  // minitaur.py:254-258
     F proc[3];
     float lerp = (float)(i + 1) * inv_repeat;
 #pragma unroll
     for (int j = 0; j < 3; j++) proc[j] = interp ? last[j] + F(lerp) * (qdes[j] - last[j]) : qdes[j];
-    physics_tick(c, K, tp, L, proc, fext, torque_cmd);
+    if (pdl) {   // EtgConfig.pd_latency: see control_step16_core
+      F pd[6];
+      pd_reading(c, K, ring, tick, false, pd);
+      physics_tick(c, K, tp, L, proc, fext, torque_cmd, pd);
+    } else {
+      physics_tick(c, K, tp, L, proc, fext, torque_cmd);
+    }
     tick++;
-    if (i == ia || i == ib) ring_push(c, ring, tick & (RING - 1), L);
+    if (pdl || i == ia || i == ib) ring_push(c, ring, tick & (RING - 1), L);
   }
 #pragma unroll
   for (int j = 0; j < 3; j++) S.last[j] = qdes[j];
@@ -1083,7 +1102,13 @@ ETG_HD void reset_settle(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   int tick = 0;
   const TickPar4<F> tp = load_tick_par4<F>(c);
   for (int i = 0; i < K.settle_ticks; i++) {  // a1.py:294-297
-    physics_tick(c, K, tp, L, pose, V3<F>{F(0.0f), F(0.0f), F(0.0f)});
+    if (!Ctx::kPlain && K.pd_n >= 0) {
+      F pd[6];
+      pd_reading(c, K, ring, tick, true, pd);
+      physics_tick(c, K, tp, L, pose, V3<F>{F(0.0f), F(0.0f), F(0.0f)}, false, pd);
+    } else {
+      physics_tick(c, K, tp, L, pose, V3<F>{F(0.0f), F(0.0f), F(0.0f)});
+    }
     tick++;
     ring_push(c, ring, tick & (RING - 1), L);
   }

@@ -115,7 +115,8 @@ template <class F, class Ctx> ETG_HD LegGeo<F> leg_geometry(const Ctx& c, const 
 
 // ------------------------------------------------------------------ one physics tick, 16 lanes per robot
 template <class F, class Ctx>
-ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, State16<F>& L, F qdes, bool torque_cmd = false) {
+ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, State16<F>& L, F qdes, bool torque_cmd = false,
+                           const F* pd = nullptr) {   // pd: (angle, velocity) the PD law reads instead of the true ones (pd_latency)
   typedef V3<F> V;
   typedef SV<F> W;
   const F dt(K.dt), zero(0.0f), one(1.0f);
@@ -127,8 +128,9 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
 
   // ---- PD motor model (laikago_motor.py:165-173), this lane's joint
   if (!Ctx::kPlain && K.clip_cmd > 0.0f && !torque_cmd) qdes = fminf_(fmaxf_(qdes, L.q - F(K.clip_cmd)), L.q + F(K.clip_cmd));   // a1.py:439-457
+  const F qm = (!Ctx::kPlain && pd) ? pd[0] : L.q, qdm = (!Ctx::kPlain && pd) ? pd[1] : L.qd;   // _GetPDObservation, minitaur.py:1195-1199
   F tau = Ctx::kPlain ? mj * (-(tp.kp * (L.q - qdes)) - tp.kd * L.qd)
-                      : (torque_cmd ? mj * qdes : mj * ((-(tp.kp * (L.q - qdes)) - tp.kd * (L.qd - tp.qd_des)) + tp.tau_ff));   // TORQUE mode: pass-through
+                      : (torque_cmd ? mj * qdes : mj * ((-(tp.kp * (qm - qdes)) - tp.kd * (qdm - tp.qd_des)) + tp.tau_ff));   // TORQUE mode: pass-through
   if (!Ctx::kPlain && K.torque_limit > 0.0f) tau = fminf_(fmaxf_(tau, F(-K.torque_limit)), F(K.torque_limit));
 
   // ---- leg geometry, this lane's link frame R_s = Rx(a) Ry(theta_s), theta = (0, h, h+k)
@@ -577,6 +579,10 @@ template <class F, class Ctx> ETG_HD void ring_push16(const Ctx& c, float* ring,
   c.st_ring_aux(ring, slot, 7, b1);
 }
 template <class F> struct Delayed16 { F q, qd; F qx, qy, qz, qw; V3<F> w; };
+// the PD law's reading under EtgConfig.pd_latency (minitaur.py:1195-1199): this lane's joint angle and velocity K.pd_n ticks
+// ago, blended with the reading before it.  `tick` = ticks completed so far (the newest reading in the ring).  live: during the
+// reset settle every reading comes from the ring being written (the cache's copy is the PREVIOUS settle).
+template <class F, class Ctx> ETG_HD void pd_reading16(const Ctx& c, const KCfg& K, const float* ring, int tick, bool live, F* pd);
 // readings of ticks up to the reset tick come from the settle cache's ring (KCfg.cring), later ones from the live ring
 ETG_HD const float* ring_of_tick(const KCfg& K, const float* ring, int t) { return (K.cring != nullptr && t <= K.settle_ticks) ? K.cring : ring; }
 template <class F, class Ctx> ETG_HD Delayed16<F> ring_read16(const Ctx& c, const KCfg& K, const float* ring, int tick) {
@@ -604,6 +610,15 @@ template <class F, class Ctx> ETG_HD Delayed16<F> ring_read16(const Ctx& c, cons
   D.qz = c.rbcast(v6, 4); D.qw = c.rbcast(v7, 4);
   D.w = {c.rbcast(v6, 8), c.rbcast(v7, 8), c.rbcast(v6, 12)};
   return D;
+}
+
+template <class F, class Ctx> ETG_HD void pd_reading16(const Ctx& c, const KCfg& K, const float* ring, int tick, bool live, F* pd) {
+  const int ta = tick - K.pd_n < 0 ? 0 : tick - K.pd_n, tb = tick - K.pd_n - 1 < 0 ? 0 : tick - K.pd_n - 1;   // (slot 0.. hold the initial reading)
+  const float *ra = live ? ring : ring_of_tick(K, ring, ta), *rb_ = live ? ring : ring_of_tick(K, ring, tb);
+  const int sa = ta & (RING - 1), sb = tb & (RING - 1);
+  const F a(K.pd_a), oma(1.0f - K.pd_a);
+  pd[0] = oma * c.ld_ring_joint(ra, sa, 0) + a * c.ld_ring_joint(rb_, sb, 0);
+  pd[1] = oma * c.ld_ring_joint(ra, sa, 3) + a * c.ld_ring_joint(rb_, sb, 3);
 }
 
 // ------------------------------------------------------------------ ETG + IK: computed by every lane of the leg, each keeps its joint
@@ -788,13 +803,20 @@ ETG_HD void control_step16_core(const Ctx& c, const KCfg& K, TickPar<F>& tp, Sta
   const int ia = R_ - 1 - mlat;
   const int ib = n_lat < 0 ? ia : (ia == 0 ? R_ - 1 : ia - 1);
   if (hybrid_cmd) { tp.kp = hyb[0]; tp.qd_des = mj * hyb[1]; tp.kd = hyb[2]; tp.tau_ff = mj * hyb[3]; }
+  const bool pdl = !Ctx::kPlain && K.pd_n >= 0;
   int tick = S.tick;
   for (int i = 0; i < K.action_repeat; i++) {
     float lerp = (float)(i + 1) * inv_repeat;
     F proc = interp ? last + F(lerp) * (qdes - last) : qdes;
-    physics_tick16(c, K, tp, L, proc, torque_cmd);
+    if (pdl) {   // EtgConfig.pd_latency: the PD law reads a delayed joint state, so every tick's reading enters the ring
+      F pd[2];
+      pd_reading16(c, K, ring, tick, false, pd);
+      physics_tick16(c, K, tp, L, proc, torque_cmd, pd);
+    } else {
+      physics_tick16(c, K, tp, L, proc, torque_cmd);
+    }
     tick++;
-    if (i == ia || i == ib) ring_push16(c, ring, tick & (RING - 1), L);
+    if (pdl || i == ia || i == ib) ring_push16(c, ring, tick & (RING - 1), L);
   }
   S.tick = tick;
   S.last = qdes;
@@ -905,7 +927,13 @@ ETG_HD void reset_settle16(const Ctx& c, const KCfg& K, State16<F>& L, float* ri
   int tick = 0;
   const TickPar<F> tp = load_tick_par<F>(c);
   for (int i = 0; i < K.settle_ticks; i++) {
-    physics_tick16(c, K, tp, L, pose);
+    if (!Ctx::kPlain && K.pd_n >= 0) {
+      F pd[2];
+      pd_reading16(c, K, ring, tick, true, pd);
+      physics_tick16(c, K, tp, L, pose, false, pd);
+    } else {
+      physics_tick16(c, K, tp, L, pose);
+    }
     tick++;
     ring_push16(c, ring, tick & (RING - 1), L);
   }

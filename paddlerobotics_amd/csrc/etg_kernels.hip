@@ -1100,6 +1100,7 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   if (cfg->solver_iters <= 0 || cfg->solver_iters > 1000) return fail(ETG_ERR_BAD_ARG, "etg_create: solver_iters must be in 1..1000");
   if (!(cfg->solver_residual >= 0)) return fail(ETG_ERR_BAD_ARG, "etg_create: solver_residual must be >= 0 (0 = a fixed number of sweeps)");
   if (cfg->friction_model != 0 && cfg->friction_model != 1) return fail(ETG_ERR_BAD_ARG, "etg_create: friction_model must be 0 (disc) or 1 (pyramid)");
+  if (!(cfg->pd_latency >= 0)) return fail(ETG_ERR_BAD_ARG, "etg_create: pd_latency must be >= 0 seconds");
   if (cfg->settle_ticks < 0) return fail(ETG_ERR_BAD_ARG, "etg_create: settle_ticks must not be negative");
   if (cfg->motor_mode < 0 || cfg->motor_mode > 2) return fail(ETG_ERR_BAD_ARG, "etg_create: motor_mode must be 0 (POSITION), 1 (TORQUE) or 2 (HYBRID)");
   if (cfg->body_contacts < 0 || cfg->body_contacts > 2) return fail(ETG_ERR_BAD_ARG, "etg_create: body_contacts must be 0, 1 or 2");

@@ -78,12 +78,14 @@ struct KCfg {
   float res_thr;         // EtgConfig.solver_residual: > 0 = sweep until the robot's squared row residual is below it (iters = cap)
   float res_sqrt;        // sqrt(res_thr): the kernels compare |d lambda| with res_sqrt / A_rr
   int fric_pyramid;      // EtgConfig.friction_model == 1: per-direction clamp instead of the disc projection
+  int pd_n;              // EtgConfig.pd_latency: n_steps_ago of the PD law's reading (minitaur.py:1185), -1 = off (true state)
+  float pd_a;            // its blend_alpha (minitaur.py:1188)
 };
 
 // the default robot layer (what train.py / pretrain.py run): the PLAIN kernel instantiations compile the options out
 inline bool plain_config(const KCfg& K) {
   return K.motor_mode == 0 && !K.enable_filter && !K.enable_interp && !(K.torque_limit > 0.0f) && !(K.clip_cmd > 0.0f) &&
-         !K.ext_force && !K.knee && K.etg_on && !K.jlim && !K.fric_pyramid;
+         !K.ext_force && !K.knee && K.etg_on && !K.jlim && !K.fric_pyramid && K.pd_n < 0;
 }
 
 // counter-based standard normal pair for (seed, robot, observation index, channel): splitmix64 finaliser twice, then
@@ -332,6 +334,13 @@ inline KCfg make_kcfg(const EtgConfig& c, const EtgRobotModel& m) {
   K.res_thr = (float)c.solver_residual;
   K.res_sqrt = (float)sqrt(c.solver_residual > 0 ? c.solver_residual : 0.0);
   K.fric_pyramid = c.friction_model == 1;
+  K.pd_n = -1; K.pd_a = 0.0f;
+  if (c.pd_latency > 0) {   // minitaur.py:1185-1188 with the ring depth as the history length
+    int n = (int)(c.pd_latency / c.sim_dt);
+    if (n > RING - 2) n = RING - 2;
+    K.pd_n = n;
+    K.pd_a = (float)((c.pd_latency - n * c.sim_dt) / c.sim_dt);
+  }
   K.jlim = c.joint_limits != 0;
   for (int k = 0; k < 3; k++) { K.jlo[k] = (float)c.joint_lower[k]; K.jhi[k] = (float)c.joint_upper[k]; }
   K.hf_cell = (float)c.hf_cell; K.hf_x0 = (float)c.hf_x0; K.hf_y0 = (float)c.hf_y0;

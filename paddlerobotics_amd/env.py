@@ -140,7 +140,7 @@ class BatchedQuadrupedEnv:
                  sensor_mode=None, normal=1, dynamic_param=None, reward_param=None, ETG=1, ETG_T=0.5,
                  reward_p=5.0, ETG_path="", random_param=None, ETG_H=20, vel_d=0.5, step_y=0.05,
                  enable_action_filter=False, ETG_T2=0.5, action_repeat=13, sim_time_step=0.002,
-                 settle_ticks=500, solver_iters=None, solver_residual=None, friction_model=0,
+                 settle_ticks=500, solver_iters=None, solver_residual=None, friction_model=0, pd_latency=0.0,
                  enable_action_interpolation=False,
                  heightfield=None, lanes_per_robot=0, terrain_variants=16, terrain_seed=0,
                  random_dynamics_scale=0.3, random_force_prob=0.02, random_force_steps=8,
@@ -200,7 +200,7 @@ class BatchedQuadrupedEnv:
         self.ETG = int(ETG)
         self.cfg = A.default_config(
             self.num_envs, action_repeat=action_repeat, sim_dt=sim_time_step, settle_ticks=settle_ticks,
-            solver_iters=solver_iters, solver_residual=solver_residual, friction_model=friction_model,
+            solver_iters=solver_iters, solver_residual=solver_residual, friction_model=friction_model, pd_latency=pd_latency,
             enable_action_interp=enable_action_interpolation,
             enable_action_filter=enable_action_filter, normal=normal,
             terrain=1 if heightfield is not None else 0, ETG_T=ETG_T, ETG_T2=ETG_T2,

@@ -482,3 +482,34 @@ def test_two_rank_es_generation_over_rccl():
         assert np.array_equal(fits, ref)                                  # gather order = candidate order, robots batch-invariant
         assert np.array_equal(best, ga.best_param.cpu().numpy())          # replicated tell
     env.close()
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_pd_latency_matches_oracle(lanes):
+    """EtgConfig.pd_latency (minitaur.py:100,1195-1199; make_env(pd_latency=seconds)): the PD law reads the joint state of
+    1.3 ms ago, every sub-step and during the reset settle; cached resets reproduce the simulated one."""
+    _need_gpu()
+    n = 32
+    W, B = _etg_params(n, seed=43)
+    env = _make(n, lanes_per_robot=lanes, pd_latency=0.0013)
+    orc = _oracle(n, pd_latency=0.0013)
+    env.reset(ETG_w=W, ETG_b=B)
+    orc.set_params(etg_w=W, etg_b=B)
+    orc.reset()
+    s0 = env.get_state().cpu().numpy()
+    assert np.abs(s0 - orc.get_state())[:, 13:25].max() < 1e-5
+    rng = np.random.default_rng(9)
+    acts = rng.uniform(-0.1, 0.1, size=(12, n, 12))
+    for k in range(12):
+        env.step(torch.as_tensor(acts[k], dtype=torch.float32), want_info=False)
+        orc.step(acts[k], want_info=False)
+    sg, so = env.get_state().cpu().numpy(), orc.get_state()
+    eq = np.abs(sg - so)[:, 13:25].max()
+    _say("pd_latency 1.3 ms lanes %d: worst joint gap %.2e rad over 12 steps" % (lanes, eq))
+    assert eq < 1e-4
+    env.reset()                                             # from the settle cache
+    assert np.array_equal(env.get_state().cpu().numpy(), s0)
+    for k in range(12):
+        env.step(torch.as_tensor(acts[k], dtype=torch.float32), want_info=False)
+    assert np.array_equal(env.get_state().cpu().numpy(), sg)
+    env.close()
