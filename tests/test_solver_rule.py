@@ -188,3 +188,22 @@ def test_emulation_pd_latency_matches_oracle(lanes):
         orc.step(act); emu.step(act); ref.step(act)
     assert np.abs(emu.get_state() - orc.get_state())[:, 13:25].max() < 2e-4
     assert np.abs(ref.get_state() - orc.get_state())[:, 13:25].max() > 1e-3       # a delayed PD reading is a different controller
+
+
+def test_friction_model_choice_is_anchored_on_the_reference_gait(golden):
+    """Why the isotropic disc (friction_model = 0) is the default and the per-direction clamp of a two-direction sequential-impulse
+    solver (friction_model = 1) an option: the reference's own recorded gait (gait_action_list_ETG_exp.npy, fitted as
+    exp_w / exp_b in tests/golden/etg.npz) walks its 600 control steps (env_test.py:51-54) at ~ vel_d on the disc; on the
+    anisotropic pyramid it yaws until the |yaw| > 0.6 termination ends the episode early."""
+    from oracle.oracle import OracleSim
+    g = golden("etg")
+    out = {}
+    for fm in (0, 1):
+        orc = OracleSim(A.default_config(1, friction_model=fm))
+        orc.set_params(etg_w=g["exp_w"], etg_b=g["exp_b"])
+        orc.reset()
+        x0 = orc.get_state()[0, 0]
+        _, ln = orc.run_steps(600)
+        out[fm] = (int(ln[0]), orc.get_state()[0, 0] - x0)
+    assert out[0][0] == 600 and abs(out[0][1] / (600 * 0.026) - 0.5) < 0.03        # 7.7 m in 15.6 s
+    assert out[1][0] < 600

@@ -3,7 +3,7 @@
 # the default flags and with the driver's, rocprofv3 kernel-trace summaries and PMC passes for configs 2 / 3 / 5.
 # Outputs under gpurun_out/final/ (+ gpurun_out/pmc_<tag>.*, gpurun_out/prof_<tag>/); copy what is judged into profiles/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r02}
+TAG=${1:-r03}
 O=$R/gpurun_out/final
 mkdir -p $O
 cd $R
@@ -16,4 +16,6 @@ for cfg in 2 3 5; do
   PMC_BENCH_ARGS="--config $cfg" bash tools/pmc_gpu.sh ${TAG}_cfg$cfg > $O/pmc_cfg$cfg.log 2>&1
 done
 python tools/config_matrix_check.py > $O/config_matrix.log 2>&1; tail -1 $O/config_matrix.log
+bash tools/solver_cost_matrix.sh > $O/solver_cost_matrix.txt 2>&1
+bash tools/batch_sweep.sh > $O/batch_sweep.txt 2>&1
 ls $O
