@@ -316,7 +316,8 @@ void etg_policy_destroy(EtgPolicy* p);
  * control step; a workgroup keeps its 16 robots' observations, actions and states on chip between the steps.
  * obs [N,49]: in = the current observation (as left by etg_reset / etg_step), out = the final one.  The actor sees the
  * columns [obs_col0, obs_col0 + in_dim) of it (0 and 49 for the teacher, 3 and 46 for the student of BCtrain.py:53-59).
- * ret / len as etg_episode_stats (may be NULL).  Needs the 16-lanes-per-robot mapping and num_envs % 16 == 0.        */
+ * ret / len as etg_episode_stats (may be NULL).  Whole workgroups only: num_envs % 16 == 0 on the 16-lanes-per-robot mapping
+ * (16 robots per workgroup), num_envs % 64 == 0 on the 4-lane one (64 robots per workgroup, two stacked policy tiles per weight fetch). */
 int etg_rollout_policy(EtgHandle* h, EtgPolicy* policy, int n_steps, float act_scale, int precision, int obs_col0,
                        float* obs, float* ret, int32_t* len, void* stream);
 

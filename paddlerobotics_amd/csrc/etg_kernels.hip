@@ -61,10 +61,11 @@ struct GpuCtx {
   mutable long long prof[16];
   mutable long long prof_last;
 #endif
-  __device__ __forceinline__ void st_row_env(float* p, int rowlen, int col, float v) const { if (lane == 0) p[(size_t)env * rowlen + col] = v; }
-  __device__ __forceinline__ void st_row_lane(float* p, int rowlen, int col0, int stride, float v) const { p[(size_t)env * rowlen + col0 + stride * lane] = v; }
-  __device__ __forceinline__ float ld_row_env(const float* p, int rowlen, int col) const { return p[(size_t)env * rowlen + col]; }
-  __device__ __forceinline__ float ld_row_lane(const float* p, int rowlen, int col0, int stride) const { return p[(size_t)env * rowlen + col0 + stride * lane]; }
+  int row_base = 0;  // first robot of the [*, rowlen] row buffers (observation tile in LDS: the workgroup's first robot)
+  __device__ __forceinline__ void st_row_env(float* p, int rowlen, int col, float v) const { if (lane == 0) p[(size_t)(env - row_base) * rowlen + col] = v; }
+  __device__ __forceinline__ void st_row_lane(float* p, int rowlen, int col0, int stride, float v) const { p[(size_t)(env - row_base) * rowlen + col0 + stride * lane] = v; }
+  __device__ __forceinline__ float ld_row_env(const float* p, int rowlen, int col) const { return p[(size_t)(env - row_base) * rowlen + col]; }
+  __device__ __forceinline__ float ld_row_lane(const float* p, int rowlen, int col0, int stride) const { return p[(size_t)(env - row_base) * rowlen + col0 + stride * lane]; }
   // order-symmetric quad sum: (x0+x1)+(x2+x3) on every lane, bit-identical across the quad
   __device__ __forceinline__ float qsum(float a) const {
     float t = a + dpp_<0xB1>(a);  // quad_perm [1,0,3,2]
@@ -147,6 +148,17 @@ __device__ __forceinline__ void stage_params(GpuCtx& c, const DevState& D, float
 #pragma unroll
   for (int k : kStaged) lds_par[k * BLOCK + threadIdx.x] = D.par[(size_t)k * c.NL + c.gid];
   c.lds = lds_par + threadIdx.x;
+  c.gpar = D.par;
+}
+
+// the same staging for a wave of a multi-wave workgroup (its own [PR_N][64] area, lane = lane in the wave)
+__device__ __forceinline__ void stage_params_wave(GpuCtx& c, const DevState& D, float* lds_wave, int lane) {
+  constexpr int kStaged[] = {PR_O1, PR_O1 + 1, PR_O1 + 2, PR_SY, PR_LAT_N, PR_LAT_A, PR_BASE_FOOT, PR_BASE_FOOT + 1,
+                             PR_BASE_FOOT + 2, PR_POSE, PR_POSE + 1, PR_POSE + 2, PR_EMEAN, PR_EMEAN + 1, PR_EMEAN + 2,
+                             PR_ESTD, PR_ESTD + 1, PR_ESTD + 2, PR_HIPSIGN};
+#pragma unroll
+  for (int k : kStaged) lds_wave[k * 64 + lane] = D.par[(size_t)k * c.NL + c.gid];
+  c.lds = lds_wave + lane;
   c.gpar = D.par;
 }
 
@@ -828,6 +840,76 @@ __global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, Po
   for (int idx = tid; idx < TM * ETG_OBS_DIM; idx += 256) obs[(size_t)tile * TM * ETG_OBS_DIM + idx] = obs_lds[idx];   // coalesced
 }
 
+// Closed loop on the 4-lanes-per-robot mapping (the mapping of every batch above 4096 robots): a workgroup of 4 waves owns
+// 64 robots (16 per wave, one leg per lane).  The policy runs over TWO stacked 16-row tiles at a time (hidden_layer_rt): every
+// weight fragment fetched from L2 feeds two MFMAs, so the weight delivery per robot is half that of k_rollout_policy16, and a
+// workgroup does two such passes per control step.  Activations of the 32 rows of a pass, the 64 observation rows and the
+// actions stay in LDS; each wave then runs the control step of its 16 robots.  Same arithmetic per row as the 16-lane kernel.
+template <bool FLAT, bool BF16, bool PLAIN>
+__global__ void __launch_bounds__(256) k_rollout_policy4(KCfg K, DevState D, PolicyW P, int n_steps, float act_scale, float* obs) {
+  using namespace pol;
+  constexpr int NWP = 4, RT = 2, ROWS = 64;
+  __shared__ __attribute__((aligned(16))) float bufA[RT * TM * HS];
+  __shared__ __attribute__((aligned(16))) float bufB[RT * TM * HS];
+  __shared__ float part[NWP][RT * TM][16];
+  __shared__ float act_lds[ROWS][16];
+  __shared__ float obs_lds[ROWS * ETG_OBS_DIM];
+  __shared__ float lds_par[NWP][PR_N * 64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tile = xcd_contiguous_block();            // 64 robots; the host guarantees N % 64 == 0
+  GpuCtxT<FLAT, PLAIN> c;
+  c.gid = tile * 256 + tid;
+  c.N = K.n_env;
+  c.NL = 4 * K.n_env;
+  c.env = c.gid >> 2;
+  c.lane = c.gid & 3;
+  stage_params_wave(c, D, lds_par[wave], lane);
+  LaneState<float> L = load_state<float>(c, D.base, D.leg);
+  StepCtl4<float> S = load_ctl4<float>(c, K, D.ctl, D.ictl, D.legctl);
+  TickPar4<float> tp = load_tick_par4<float>(c);
+  V3<float> fext = {0.0f, 0.0f, 0.0f};
+  if (!PLAIN && K.ext_force) fext = {c.ld_env(D.ctl, CT_FEXT + 0) + c.ld_env(D.ctl, CT_PUSH + 0), c.ld_env(D.ctl, CT_FEXT + 1) + c.ld_env(D.ctl, CT_PUSH + 1),
+                                     c.ld_env(D.ctl, CT_FEXT + 2) + c.ld_env(D.ctl, CT_PUSH + 2)};
+  for (int idx = tid; idx < ROWS * ETG_OBS_DIM; idx += 256) obs_lds[idx] = obs[(size_t)tile * ROWS * ETG_OBS_DIM + idx];
+  c.row_base = tile * ROWS;
+  float reward, done;
+  for (int s = 0; s < n_steps; s++) {
+    __syncthreads();
+    if (K.noise_on && s > 0) {   // sensor noise on the rows the previous step left in LDS (the last ones: k_add_noise)
+      for (int idx = tid; idx < ROWS * 16; idx += 256)
+        add_sensor_noise(K, tile * ROWS + (idx >> 4), K.noise_call + s - 1, idx & 15, &obs_lds[(idx >> 4) * ETG_OBS_DIM]);
+      __syncthreads();
+    }
+    for (int pass = 0; pass < ROWS / (RT * TM); pass++) {
+      const int r0 = pass * RT * TM;
+      for (int idx = tid; idx < RT * TM * 64; idx += 256) {   // observation rows of the pass, zero padded to the 64-wide K of layer 1
+        const int r = idx >> 6, col = idx & 63;
+        bufA[r * HS + col] = col < P.in_dim ? obs_lds[(r0 + r) * ETG_OBS_DIM + P.col0 + col] : 0.0f;
+      }
+      __syncthreads();
+      hidden_layer_rt<BF16, 4, NWP, RT>(bufA, P.w1, P.b1, bufB, wave, lane);
+      __syncthreads();
+      hidden_layer_rt<BF16, HID / 16, NWP, RT>(bufB, P.w2, P.b2, bufA, wave, lane);
+      __syncthreads();
+      output_partial_rt<BF16, NWP, RT>(bufA, P.w3, wave, lane, part);
+      __syncthreads();
+      for (int idx = tid; idx < RT * TM * 16; idx += 256) {
+        const int r = idx >> 4, cidx = idx & 15;
+        const float v = ((part[0][r][cidx] + part[1][r][cidx]) + (part[2][r][cidx] + part[3][r][cidx])) + (cidx < P.out_dim ? P.b3[cidx] : 0.0f);
+        act_lds[r0 + r][cidx] = tanhf(v) * act_scale;
+      }
+      __syncthreads();
+    }
+    const int rl = 16 * wave + (lane >> 2), leg = lane & 3;
+    const float act[3] = {act_lds[rl][3 * leg + 0], act_lds[rl][3 * leg + 1], act_lds[rl][3 * leg + 2]};
+    control_step_core(c, K, tp, fext, L, S, D.ring, D.etgp, act, 0.0f, obs_lds, reward, done, (float*)nullptr);
+  }
+  store_ctl4(c, K, S, D.ctl, D.ictl, D.legctl);
+  store_state(c, D.base, D.leg, L);
+  __syncthreads();
+  for (int idx = tid; idx < ROWS * ETG_OBS_DIM; idx += 256) obs[(size_t)tile * ROWS * ETG_OBS_DIM + idx] = obs_lds[idx];   // coalesced
+}
+
 // The same kernel with every step's (observation, unscaled action, reward, done) written out: [n_steps][N][...] arrays for
 // the replay memory of the ES-SAC loop (run_EStrain_episode with es_rpm, train.py:213-249).  A separate kernel, not a
 // template flag of k_rollout_policy16: that kernel sits at 512 registers and any change of its symbol shifts its allocation.
@@ -1464,13 +1546,36 @@ extern "C" int etg_rollout_policy(EtgHandle* h, EtgPolicy* pol, int n_steps, flo
   if (pol->device != h->device) return fail(ETG_ERR_BAD_ARG, "etg_rollout_policy: policy and simulator live on different devices");
   if (obs_col0 < 0 || obs_col0 + pol->in_dim > ETG_OBS_DIM || pol->out_dim != ETG_ACT_DIM)
     return fail(ETG_ERR_BAD_ARG, "etg_rollout_policy: the policy must map observation columns [col0, col0 + in_dim) to 12 actions");
-  if (h->lanes != 16 || h->N % 16 != 0 || h->K.motor_mode == 2)
-    return fail(ETG_ERR_STATE, "etg_rollout_policy: needs the 16-lanes-per-robot mapping, num_envs % 16 == 0, POSITION/TORQUE mode");
+  if (h->K.motor_mode == 2 || (h->lanes == 16 ? h->N % 16 != 0 : h->N % 64 != 0))
+    return fail(ETG_ERR_STATE, "etg_rollout_policy: needs POSITION/TORQUE mode and whole workgroups: num_envs % 16 == 0 on the 16-lane "
+                               "mapping (16 robots per workgroup), num_envs % 64 == 0 on the 4-lane one (64 per workgroup)");
   PolicyW P = {(const float4*)pol->w1, (const float4*)pol->w2, (const float4*)pol->w3, pol->b1, pol->b2, pol->b3, pol->in_dim, pol->out_dim, obs_col0};
   constexpr int ROLLOUT_CHUNK = 50;
   const dim3 g(h->N / 16), b(256);
   hipStream_t s = (hipStream_t)stream;
   const bool flat = h->K.terrain == 0;
+  if (h->lanes == 4) {   // the 4-lane mapping: 64 robots per workgroup, two stacked policy tiles per pass (k_rollout_policy4)
+    const dim3 g4(h->N / 64);
+    const bool pl = plain_config(h->K);
+    for (int done_steps = 0; done_steps < n_steps; done_steps += ROLLOUT_CHUNK) {
+      const int m = n_steps - done_steps < ROLLOUT_CHUNK ? n_steps - done_steps : ROLLOUT_CHUNK;
+      advance_obs_stream(h, m);
+#define LAUNCH_POLICY4(F_, P_)                                                                                        \
+  do {                                                                                                                \
+    if (precision == 0) hipLaunchKernelGGL((k_rollout_policy4<F_, false, P_>), g4, b, 0, s, h->K, h->D, P, m, act_scale, obs); \
+    else hipLaunchKernelGGL((k_rollout_policy4<F_, true, P_>), g4, b, 0, s, h->K, h->D, P, m, act_scale, obs);        \
+  } while (0)
+      if (flat && pl) LAUNCH_POLICY4(true, true);
+      else if (flat) LAUNCH_POLICY4(true, false);
+      else if (pl) LAUNCH_POLICY4(false, true);
+      else LAUNCH_POLICY4(false, false);
+#undef LAUNCH_POLICY4
+      launch_obs_noise(h, m, nullptr, obs, s);
+    }
+    HIP_TRY(hipGetLastError());
+    if (ret || len) return etg_episode_stats(h, ret, len, stream);
+    return ETG_OK;
+  }
   for (int done_steps = 0; done_steps < n_steps; done_steps += ROLLOUT_CHUNK) {
     const int m = n_steps - done_steps < ROLLOUT_CHUNK ? n_steps - done_steps : ROLLOUT_CHUNK;
     advance_obs_stream(h, m);

@@ -27,6 +27,128 @@ __device__ __forceinline__ bf16x8 pack_bf16(float4 a, float4 b) {
 // out[16][this wave's 16*TPW columns] = relu(in[16][16*nkb] * W^T + b); wp = packed weights of the layer
 template <bool BF16, int NKB, int NW_>
 __device__ __forceinline__ void hidden_layer(const float* in, const float4* __restrict__ wp, const float* b,
+                                             float* out, int wave, int lane);
+
+// The same layer over RT stacked 16-row tiles (in / out hold 16 * RT rows): every weight fragment is fetched ONCE and feeds RT
+// MFMAs -- the weight delivery from L2 per robot falls by RT.  For the 4-lane closed-loop kernel (64 robots per workgroup).
+template <bool BF16, int NKB, int NW_, int RT>
+__device__ __forceinline__ void hidden_layer_rt(const float* in, const float4* __restrict__ wp, const float* b,
+                                                float* out, int wave, int lane) {
+  constexpr int nkb = NKB;
+  constexpr int TPW = (HID / 16) / NW_;
+  const int i = lane & 15, g = lane >> 4;
+  f32x4 acc[RT][TPW];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+    for (int t = 0; t < TPW; t++) acc[rt][t] = {0.f, 0.f, 0.f, 0.f};
+  const float4* base = wp + (size_t)(TPW * wave) * nkb * 64 + lane;
+  const int tstride = nkb * 64;
+  if (!BF16) {
+    constexpr int PF = NKB < 2 ? NKB : 2;
+    float4 w[PF + 1][TPW];
+#pragma unroll
+    for (int p = 0; p < PF; p++)
+#pragma unroll
+      for (int t = 0; t < TPW; t++) w[p][t] = base[t * tstride + p * 64];
+#pragma unroll
+    for (int kb = 0; kb < nkb; kb++) {
+      float4 a[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) a[rt] = *reinterpret_cast<const float4*>(&in[(16 * rt + i) * HS + kb * 16 + 4 * g]);
+      if (kb + PF < nkb) {
+#pragma unroll
+        for (int t = 0; t < TPW; t++) w[(kb + PF) % (PF + 1)][t] = base[t * tstride + (kb + PF) * 64];
+      }
+      const float4* w0 = w[kb % (PF + 1)];
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int t = 0; t < TPW; t++) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].x, w0[t].x, acc[rt][t], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int t = 0; t < TPW; t++) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].y, w0[t].y, acc[rt][t], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int t = 0; t < TPW; t++) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].z, w0[t].z, acc[rt][t], 0, 0, 0);
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+        for (int t = 0; t < TPW; t++) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].w, w0[t].w, acc[rt][t], 0, 0, 0);
+    }
+  } else {
+    for (int kb = 0; kb < nkb; kb += 2) {
+      bf16x8 av[RT];
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++)
+        av[rt] = pack_bf16(*reinterpret_cast<const float4*>(&in[(16 * rt + i) * HS + kb * 16 + 4 * g]),
+                           *reinterpret_cast<const float4*>(&in[(16 * rt + i) * HS + (kb + 1) * 16 + 4 * g]));
+#pragma unroll
+      for (int t = 0; t < TPW; t++) {
+        const bf16x8 bw = pack_bf16(base[t * tstride + kb * 64], base[t * tstride + (kb + 1) * 64]);
+#pragma unroll
+        for (int rt = 0; rt < RT; rt++) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[rt], bw, acc[rt][t], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+    for (int t = 0; t < TPW; t++) {
+      const int col = 16 * TPW * wave + 16 * t + i;
+      const float bias = b[col];
+#pragma unroll
+      for (int r = 0; r < 4; r++) out[(16 * rt + 4 * g + r) * HS + col] = fmaxf(acc[rt][t][r] + bias, 0.0f);
+    }
+}
+
+// output layer over RT stacked tiles: part[wave][16 * RT rows][16]
+template <bool BF16, int NW_, int RT>
+__device__ __forceinline__ void output_partial_rt(const float* bufA, const float4* __restrict__ whp, int wave, int lane,
+                                                  float (*part)[RT * TM][16]) {
+  constexpr int KPW = (HID / 16) / NW_;
+  const int i = lane & 15, g = lane >> 4;
+  f32x4 acc[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) acc[rt] = {0.f, 0.f, 0.f, 0.f};
+  const float4* base = whp + lane;
+  if (!BF16) {
+#pragma unroll
+    for (int kk = 0; kk < KPW; kk++) {
+      const int kb = KPW * wave + kk;
+      const float4 bw = base[kb * 64];
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++) {
+        const float4 a = *reinterpret_cast<const float4*>(&bufA[(16 * rt + i) * HS + kb * 16 + 4 * g]);
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bw.x, acc[rt], 0, 0, 0);
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bw.y, acc[rt], 0, 0, 0);
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bw.z, acc[rt], 0, 0, 0);
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a.w, bw.w, acc[rt], 0, 0, 0);
+      }
+    }
+  } else {
+    static_assert(KPW % 2 == 0, "the bf16 head needs an even number of k-blocks per wave");
+#pragma unroll
+    for (int kk = 0; kk < KPW; kk += 2) {
+      const int kb = KPW * wave + kk;
+      const bf16x8 bw = pack_bf16(base[kb * 64], base[(kb + 1) * 64]);
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++)
+        acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
+            pack_bf16(*reinterpret_cast<const float4*>(&bufA[(16 * rt + i) * HS + kb * 16 + 4 * g]),
+                      *reinterpret_cast<const float4*>(&bufA[(16 * rt + i) * HS + (kb + 1) * 16 + 4 * g])), bw, acc[rt], 0, 0, 0);
+    }
+  }
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+    for (int r = 0; r < 4; r++) part[wave][16 * rt + 4 * g + r][i] = acc[rt][r];
+}
+
+template <bool BF16, int NKB, int NW_>
+__device__ __forceinline__ void hidden_layer(const float* in, const float4* __restrict__ wp, const float* b,
                                              float* out, int wave, int lane) {
   constexpr int nkb = NKB;
   constexpr int TPW = (HID / 16) / NW_;   // 16-column output tiles per wave

@@ -536,7 +536,7 @@ class BatchedQuadrupedEnv:
         (train.py:182-249).  Falls back to stepping when the fused kernel does not apply."""
         contiguous = self._cols == list(range(self._cols[0], self._cols[0] + len(self._cols)))   # e.g. the student's 3..48
         # (the fused kernels never restart a finished robot: an auto_reset env takes the stepping loop, which does)
-        ok = (self.lanes_per_robot == 16 and self.num_envs % 16 == 0 and self.motor_mode != 2 and contiguous
+        ok = (self.num_envs % (16 if self.lanes_per_robot == 16 else 64) == 0 and self.motor_mode != 2 and contiguous
               and self._hist_T == 0 and not self._rand_force and policy.obs_dim == len(self._cols)
               and policy.action_dim == A.NUM_MOTORS and not self.auto_reset)
         if not ok:

@@ -513,3 +513,63 @@ def test_pd_latency_matches_oracle(lanes):
         env.step(torch.as_tensor(acts[k], dtype=torch.float32), want_info=False)
     assert np.array_equal(env.get_state().cpu().numpy(), sg)
     env.close()
+
+
+@pytest.mark.parametrize("variant", ["flat", "heightfield", "student", "bf16"])
+def test_four_lane_closed_loop_kernel(variant):
+    """etg_rollout_policy on the 4-lanes-per-robot mapping (k_rollout_policy4: 64 robots per workgroup, two stacked policy tiles
+    per weight fetch) against predict() + step() on the same mapping, against the 16-lane fused kernel, and against the oracle's
+    closed loop (mlp_forward + step, train.py:213-249)."""
+    _need_gpu()
+    from oracle import oracle as O
+    n, m, steps = 128, 64, 12
+    kw = {}
+    hf = None
+    if variant == "heightfield":
+        hf = _rolling_hills()
+        kw = dict(task="heightfield", heightfield=hf)
+    elif variant == "student":
+        kw = dict(sensor_mode={"dis": 0})                       # the 46-float observation of BCtrain.py:53-59 (columns 3..48)
+    prec = 1 if variant == "bf16" else 0
+    obs_dim = 46 if variant == "student" else 49
+    pol, ws = _policy(obs_dim)
+    W, B = _etg_params(m, seed=47)
+    Wn, Bn = np.tile(W, (n // m, 1, 1)), np.tile(B, (n // m, 1))
+    fused4, step4, fused16 = _make(n, lanes_per_robot=4, **kw), _make(n, lanes_per_robot=4, **kw), _make(n, lanes_per_robot=16, **kw)
+    for e in (fused4, step4, fused16):
+        e.reset(ETG_w=Wn, ETG_b=Bn)
+    ret4, ln4 = fused4.rollout_policy(pol, steps, 0.3, prec)
+    ret16, ln16 = fused16.rollout_policy(pol, steps, 0.3, prec)
+    for _ in range(steps):
+        view = step4.obs[:, 3:] if variant == "student" else step4.obs
+        step4.step(pol.predict(view.contiguous(), 0.3, prec), want_info=False)
+    rets, lns = step4.episode_stats()
+    s4, ss, s16 = (e.get_state().cpu().numpy() for e in (fused4, step4, fused16))
+    gap_step = np.abs(s4 - ss)[:, 13:25].max()
+    gap_16 = np.abs(s4 - s16)[:, 13:25].max()
+    _say("4-lane closed loop %s: joint gap to predict+step %.2e, to the 16-lane fused kernel %.2e (12 steps)" % (variant, gap_step, gap_16))
+    tol = 2e-2 if variant == "bf16" else 1e-4                   # bf16 operands: the two kernels round activations alike, the split of K differs
+    assert gap_step < tol and gap_16 < tol
+    assert np.array_equal(ln4.cpu().numpy(), lns.cpu().numpy())
+    assert np.abs(ret4.cpu().numpy() - rets.cpu().numpy()).max() < (0.5 if variant == "bf16" else 5e-3) * (1 + np.abs(rets.cpu().numpy()).max()) * 1e-1 + 5e-3
+    assert np.array_equal(s4[:m], s4[m:])                       # copies of the sample: batch invariance across workgroups
+    if variant in ("flat", "heightfield"):
+        orc = _oracle(m, terrain=1 if hf else 0, heightfield=hf)
+        orc.threads = NCPU
+        if hf:
+            orc.set_heightfield(hf["heights"])
+        orc.set_params(etg_w=W, etg_b=B)
+        obs = orc.reset()
+        for _ in range(steps):
+            obs, _, _, _ = orc.step(O.mlp_forward(obs, *ws, scale=0.3), want_info=False)
+        eq = np.abs(s4[:m] - orc.get_state())[:, 13:25].max(1)
+        _say("4-lane closed loop %s vs oracle: q err median %.2e max %.2e" % (variant, np.median(eq), eq.max()))
+        assert np.median(eq) < 1e-5 and eq.max() < 2e-4
+    with pytest.raises(Exception):
+        odd = _make(96, lanes_per_robot=4)                      # not a multiple of 64: the C-ABI refuses, env falls back to stepping
+        odd.reset()
+        import ctypes as C
+        from paddlerobotics_amd import _lib
+        _lib.check(odd._lib.etg_rollout_policy(odd._h, pol._h, 2, C.c_float(0.3), 0, 0, C.c_void_p(odd.obs.data_ptr()), None, None, None))
+    for e in (fused4, step4, fused16):
+        e.close()
