@@ -784,20 +784,26 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_actions16(KCfg K, DevState D,
 // the next observation back to LDS.  Nothing but the final observation, the ring and the episode accumulators
 // touches HBM between steps.  (run_EStrain_episode / run_evaluate_episodes, train.py:182-249, with a fixed actor.)
 struct PolicyW { const float4 *w1, *w2, *w3; const float *b1, *b2, *b3; int in_dim, out_dim, col0; };   // col0: first observation column the actor sees
-template <bool FLAT, bool BF16, bool KNEE, bool PLAIN>
-__global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, PolicyW P, int n_steps, float act_scale, float* obs) {
+// per-step outputs of the recording variant ([n_steps][N][...]); noise != NULL: the STOCHASTIC actor of SAC.sample
+// (alg/sac.py:65-76) on the caller's N(0,1) draws [n_steps][N][12]: x = mean + exp(clamp(log_std, -20, 2)) * noise,
+// action = tanh(x); w3s / b3s = the packed log-std head (etg_policy_load_std)
+struct RecOut { float *obs, *act, *rew; uint8_t* done; const float* noise; const float4* w3s; const float* b3s; };
+
+// ONE body for the closed-loop kernel and its recording variant (REC: every step's observation, unscaled action, reward and done
+// written out for the replay memory of the ES-SAC loop, run_EStrain_episode with es_rpm, train.py:213-249).  Two __global__
+// symbols instantiate it: REC is a compile-time constant in each, so the plain kernel contains none of the recording code (a
+// runtime flag in ONE kernel shifts its 512-register allocation; round 2 kept a 70-line copy for that reason, which let fixes
+// diverge).  ps_mem: the [NWP][TM][16] partial sums of the log-std head (REC only).
+template <bool FLAT, bool BF16, bool KNEE, bool PLAIN, bool REC>
+__device__ __forceinline__ void rollout_policy16_body(const KCfg& K, const DevState& D, const PolicyW& P, int n_steps, float act_scale,
+                                                      float* obs, const RecOut& R, float* bufA, float* bufB, float (*part)[pol::TM][16],
+                                                      float (*part_s)[pol::TM][16], float (*act_lds)[16], float* obs_lds, float* lds_par) {
   using namespace pol;
   constexpr int NWP = 4;
-  __shared__ __attribute__((aligned(16))) float bufA[TM * HS];
-  __shared__ __attribute__((aligned(16))) float bufB[TM * HS];
-  __shared__ float part[NWP][TM][16];
-  __shared__ float act_lds[TM][16];
-  __shared__ float obs_lds[TM * ETG_OBS_DIM];
-  __shared__ float lds_par[NWP][LDS16_FIELDS * 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int tile = xcd_contiguous_block();            // 16 robots; the host guarantees N % 16 == 0
   GpuCtx16T<FLAT, KNEE, PLAIN> c;
-  make_ctx16_at(K, D, c, lds_par[wave], 4 * tile + wave, lane);
+  make_ctx16_at(K, D, c, lds_par + wave * (LDS16_FIELDS * 64), 4 * tile + wave, lane);
   State16<float> L = load_state16<float>(c, D.base, D.leg);
   StepCtl16<float> S = load_ctl16<float>(c, K, D.ctl, D.ictl, D.legctl);
   TickPar<float> tp = load_tick_par<float>(c);
@@ -815,17 +821,27 @@ __global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, Po
       const int r = idx >> 6, col = idx & 63;
       bufA[r * HS + col] = col < P.in_dim ? obs_lds[r * ETG_OBS_DIM + P.col0 + col] : 0.0f;
     }
+    if (REC)   // the observation the actor acts on at this step (noise included), rows of the tile's 16 robots: coalesced
+      for (int idx = tid; idx < TM * ETG_OBS_DIM; idx += 256) R.obs[((size_t)s * K.n_env + (size_t)tile * TM) * ETG_OBS_DIM + idx] = obs_lds[idx];
     __syncthreads();
     hidden_layer<BF16, 4, NWP>(bufA, P.w1, P.b1, bufB, wave, lane);
     __syncthreads();
     hidden_layer<BF16, HID / 16, NWP>(bufB, P.w2, P.b2, bufA, wave, lane);
     __syncthreads();
     output_partial<BF16, NWP>(bufA, P.w3, wave, lane, part);
+    if (REC && R.noise) output_partial<BF16, NWP>(bufA, R.w3s, wave, lane, part_s);
     __syncthreads();
     {
       const int r = tid >> 4, cidx = tid & 15;          // 256 threads = 16 rows x 16 columns
-      const float v = ((part[0][r][cidx] + part[1][r][cidx]) + (part[2][r][cidx] + part[3][r][cidx])) + (cidx < P.out_dim ? P.b3[cidx] : 0.0f);
-      act_lds[r][cidx] = tanhf(v) * act_scale;
+      float v = ((part[0][r][cidx] + part[1][r][cidx]) + (part[2][r][cidx] + part[3][r][cidx])) + (cidx < P.out_dim ? P.b3[cidx] : 0.0f);
+      if (REC && R.noise && cidx < ETG_ACT_DIM) {
+        float ls = ((part_s[0][r][cidx] + part_s[1][r][cidx]) + (part_s[2][r][cidx] + part_s[3][r][cidx])) + R.b3s[cidx];
+        ls = fminf(fmaxf(ls, -20.0f), 2.0f);
+        v = v + expf(ls) * R.noise[((size_t)s * K.n_env + (size_t)tile * TM + r) * ETG_ACT_DIM + cidx];
+      }
+      const float t = tanhf(v);
+      act_lds[r][cidx] = t * act_scale;
+      if (REC && cidx < ETG_ACT_DIM) R.act[((size_t)s * K.n_env + (size_t)tile * TM + r) * ETG_ACT_DIM + cidx] = t;   // the UNSCALED action (train.py:159)
     }
     __syncthreads();
     const float action = c.sub < 3 ? act_lds[4 * wave + (lane >> 4)][3 * c.leg + c.sub] : 0.0f;
@@ -833,11 +849,27 @@ __global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, Po
     // Every step writes its observation to the tile (plain ds_write, no generic pointer); the last one is copied out below.
     c.row_base = tile * TM;
     control_step16_core(c, K, tp, L, S, D.ring, D.etgp, action, 0.0f, obs_lds, reward, done, (float*)nullptr);
+    if (REC && c.r == 0) {
+      R.rew[(size_t)s * K.n_env + c.env] = reward;
+      R.done[(size_t)s * K.n_env + c.env] = done > 0.5f ? 1 : 0;
+    }
   }
   store_ctl16(c, K, S, D.ctl, D.ictl, D.legctl);
   store_state16(c, D.base, D.leg, L);
   __syncthreads();
   for (int idx = tid; idx < TM * ETG_OBS_DIM; idx += 256) obs[(size_t)tile * TM * ETG_OBS_DIM + idx] = obs_lds[idx];   // coalesced
+}
+
+template <bool FLAT, bool BF16, bool KNEE, bool PLAIN>
+__global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, PolicyW P, int n_steps, float act_scale, float* obs) {
+  using namespace pol;
+  __shared__ __attribute__((aligned(16))) float bufA[TM * HS];
+  __shared__ __attribute__((aligned(16))) float bufB[TM * HS];
+  __shared__ float part[4][TM][16];
+  __shared__ float act_lds[TM][16];
+  __shared__ float obs_lds[TM * ETG_OBS_DIM];
+  __shared__ float lds_par[4 * LDS16_FIELDS * 64];
+  rollout_policy16_body<FLAT, BF16, KNEE, PLAIN, false>(K, D, P, n_steps, act_scale, obs, RecOut{}, bufA, bufB, part, nullptr, act_lds, obs_lds, lds_par);
 }
 
 // Closed loop on the 4-lanes-per-robot mapping (the mapping of every batch above 4096 robots): a workgroup of 4 waves owns
@@ -910,81 +942,18 @@ __global__ void __launch_bounds__(256) k_rollout_policy4(KCfg K, DevState D, Pol
   for (int idx = tid; idx < ROWS * ETG_OBS_DIM; idx += 256) obs[(size_t)tile * ROWS * ETG_OBS_DIM + idx] = obs_lds[idx];   // coalesced
 }
 
-// The same kernel with every step's (observation, unscaled action, reward, done) written out: [n_steps][N][...] arrays for
-// the replay memory of the ES-SAC loop (run_EStrain_episode with es_rpm, train.py:213-249).  A separate kernel, not a
-// template flag of k_rollout_policy16: that kernel sits at 512 registers and any change of its symbol shifts its allocation.
-// noise != NULL: the STOCHASTIC actor of SAC.sample (alg/sac.py:65-76) on the caller's N(0,1) draws [n_steps][N][12]:
-// x = mean + exp(clamp(log_std, -20, 2)) * noise, action = tanh(x); w3s / b3s = the packed log-std head (etg_policy_load_std)
-struct RecOut { float *obs, *act, *rew; uint8_t* done; const float* noise; const float4* w3s; const float* b3s; };
+// the recording variant of k_rollout_policy16 (etg_rollout_policy_record): the same body with REC = true
 template <bool FLAT, bool BF16, bool KNEE, bool PLAIN>
 __global__ void __launch_bounds__(256) k_rollout_policy16_rec(KCfg K, DevState D, PolicyW P, int n_steps, float act_scale, float* obs, RecOut R) {
   using namespace pol;
-  constexpr int NWP = 4;
   __shared__ __attribute__((aligned(16))) float bufA[TM * HS];
   __shared__ __attribute__((aligned(16))) float bufB[TM * HS];
-  __shared__ float part[NWP][TM][16];
-  __shared__ float part_s[NWP][TM][16];   // log-std head (stochastic actor only)
+  __shared__ float part[4][TM][16];
+  __shared__ float part_s[4][TM][16];   // log-std head (stochastic actor only)
   __shared__ float act_lds[TM][16];
   __shared__ float obs_lds[TM * ETG_OBS_DIM];
-  __shared__ float lds_par[NWP][LDS16_FIELDS * 64];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int tile = xcd_contiguous_block();            // 16 robots; the host guarantees N % 16 == 0
-  GpuCtx16T<FLAT, KNEE, PLAIN> c;
-  make_ctx16_at(K, D, c, lds_par[wave], 4 * tile + wave, lane);
-  State16<float> L = load_state16<float>(c, D.base, D.leg);
-  StepCtl16<float> S = load_ctl16<float>(c, K, D.ctl, D.ictl, D.legctl);
-  TickPar<float> tp = load_tick_par<float>(c);
-  if (!PLAIN && K.ext_force) tp.fext = load_fext16<float>(c, D.ctl);
-  // current observation of the tile -> LDS
-  for (int idx = tid; idx < TM * ETG_OBS_DIM; idx += 256) obs_lds[idx] = obs[(size_t)tile * TM * ETG_OBS_DIM + idx];
-  float reward, done;
-  for (int s = 0; s < n_steps; s++) {
-    __syncthreads();
-    if (K.noise_on && s > 0) {   // sensor noise on the row the previous step left in LDS (the last one: k_add_noise)
-      add_sensor_noise(K, tile * TM + (tid >> 4), K.noise_call + s - 1, tid & 15, &obs_lds[(tid >> 4) * ETG_OBS_DIM]);
-      __syncthreads();
-    }
-    for (int idx = tid; idx < TM * 64; idx += 256) {   // obs tile, zero padded to the 64-wide K of layer 1
-      const int r = idx >> 6, col = idx & 63;
-      bufA[r * HS + col] = col < P.in_dim ? obs_lds[r * ETG_OBS_DIM + P.col0 + col] : 0.0f;
-    }
-    // the observation the actor acts on at this step (noise included), rows of the tile's 16 robots: coalesced
-    for (int idx = tid; idx < TM * ETG_OBS_DIM; idx += 256) R.obs[((size_t)s * K.n_env + (size_t)tile * TM) * ETG_OBS_DIM + idx] = obs_lds[idx];
-    __syncthreads();
-    hidden_layer<BF16, 4, NWP>(bufA, P.w1, P.b1, bufB, wave, lane);
-    __syncthreads();
-    hidden_layer<BF16, HID / 16, NWP>(bufB, P.w2, P.b2, bufA, wave, lane);
-    __syncthreads();
-    output_partial<BF16, NWP>(bufA, P.w3, wave, lane, part);
-    if (R.noise) output_partial<BF16, NWP>(bufA, R.w3s, wave, lane, part_s);
-    __syncthreads();
-    {
-      const int r = tid >> 4, cidx = tid & 15;          // 256 threads = 16 rows x 16 columns
-      float v = ((part[0][r][cidx] + part[1][r][cidx]) + (part[2][r][cidx] + part[3][r][cidx])) + (cidx < P.out_dim ? P.b3[cidx] : 0.0f);
-      if (R.noise && cidx < ETG_ACT_DIM) {
-        float ls = ((part_s[0][r][cidx] + part_s[1][r][cidx]) + (part_s[2][r][cidx] + part_s[3][r][cidx])) + R.b3s[cidx];
-        ls = fminf(fmaxf(ls, -20.0f), 2.0f);
-        v = v + expf(ls) * R.noise[((size_t)s * K.n_env + (size_t)tile * TM + r) * ETG_ACT_DIM + cidx];
-      }
-      const float t = tanhf(v);
-      act_lds[r][cidx] = t * act_scale;
-      if (cidx < ETG_ACT_DIM) R.act[((size_t)s * K.n_env + (size_t)tile * TM + r) * ETG_ACT_DIM + cidx] = t;   // the UNSCALED action (train.py:159)
-    }
-    __syncthreads();
-    const float action = c.sub < 3 ? act_lds[4 * wave + (lane >> 4)][3 * c.leg + c.sub] : 0.0f;
-    // the step code addresses observation rows by robot index: rows of the LDS tile start at the tile's first robot.
-    // Every step writes its observation to the tile (plain ds_write, no generic pointer); the last one is copied out below.
-    c.row_base = tile * TM;
-    control_step16_core(c, K, tp, L, S, D.ring, D.etgp, action, 0.0f, obs_lds, reward, done, (float*)nullptr);
-    if (c.r == 0) {
-      R.rew[(size_t)s * K.n_env + c.env] = reward;
-      R.done[(size_t)s * K.n_env + c.env] = done > 0.5f ? 1 : 0;
-    }
-  }
-  store_ctl16(c, K, S, D.ctl, D.ictl, D.legctl);
-  store_state16(c, D.base, D.leg, L);
-  __syncthreads();
-  for (int idx = tid; idx < TM * ETG_OBS_DIM; idx += 256) obs[(size_t)tile * TM * ETG_OBS_DIM + idx] = obs_lds[idx];   // coalesced
+  __shared__ float lds_par[4 * LDS16_FIELDS * 64];
+  rollout_policy16_body<FLAT, BF16, KNEE, PLAIN, true>(K, D, P, n_steps, act_scale, obs, R, bufA, bufB, part, part_s, act_lds, obs_lds, lds_par);
 }
 
 // Gaussian sensor noise on freshly written observation rows: one thread per (robot, channel).  A separate tiny

@@ -1,9 +1,9 @@
 #!/bin/bash
-# A/B of build variants on configs[2] (closed loop, policy fused)
+# A/B the default build against gpurun_variants/*.so on the closed-loop workload (configs[2]), interleaved rounds
 R=${GRAFT_REPO_ROOT:-/root/repo}
 for round in 1 2; do
   for lib in default $(ls $R/gpurun_variants/*.so 2>/dev/null); do
     if [ "$lib" = default ]; then unset ETG_LIB; else export ETG_LIB=$lib; fi
-    python $R/bench.py --config 3 --steps 200 --warmup 20 --no-cpu-baseline --no-extra-legs 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$(basename $lib)', 'config 3: %.2f M env-steps/s' % (d['value']/1e6), 'kernel %.2f us' % (d['roofline']['kernel_ms']*1e3))"
+    python $R/bench.py --config 3 --steps 200 --warmup 20 --repeats 3 --no-cpu-baseline --no-extra-legs 2>/dev/null | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('%-12s' % '$(basename $lib)', '%.2f M env-steps/s' % (d['value']/1e6), 'kernel %.2f us' % (d['roofline']['kernel_ms']*1e3), 'k_policy %.2f us' % (d['policy_roofline']['kernel_ms']*1e3))"
   done
 done
