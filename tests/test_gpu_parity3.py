@@ -573,3 +573,25 @@ def test_four_lane_closed_loop_kernel(variant):
         _lib.check(odd._lib.etg_rollout_policy(odd._h, pol._h, 2, C.c_float(0.3), 0, 0, C.c_void_p(odd.obs.data_ptr()), None, None, None))
     for e in (fused4, step4, fused16):
         e.close()
+
+
+def test_long_horizon_statistics_on_the_stairs_task():
+    """The reference's default task (`stairstair`, train.py:462; 16 banded stair variants drawn from its STEP_HEIGHT / STEP_WIDTH
+    ranges), 4096 robots x 400 control steps under the residual rule against 512 fp64 oracle robots on the same bands."""
+    _need_gpu()
+    n, m, steps = 4096, 512, 400
+    w, b = _population(n)
+    env = _make(n, task="stairstair")
+    env.reset(ETG_w=w, ETG_b=b)
+    hf = env.terrain
+    orc = _oracle(m, terrain=1, heightfield=hf)
+    orc.threads = NCPU
+    orc.set_heightfield(hf["heights"])
+    orc.set_params(etg_w=w[:m].double().cpu().numpy(), etg_b=b[:m].double().cpu().numpy())
+    orc.reset()
+    s = _stats_vs_oracle(env, orc, steps, m, "stairstair, rule")
+    # the stair treads are flat, so trajectories stay together: measured gap 0.002, same length +-1 for 99.2 %, KS 0.002 / 0.004 / 0.03
+    assert s["gap"] < 0.02 and s["gap_full"] < 0.08 and s["agree"] > 0.95
+    assert s["ks_len"] < 0.03 and s["ks_ret"] < 0.03 and s["ks_dx"] < 0.1
+    assert s["z"] < 3.0
+    env.close()
