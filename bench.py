@@ -198,7 +198,8 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, choices=(0, 4, 16),
                     help="kernel mapping, lanes per robot (0 = library default: 16 up to 4096 robots, else 4)")
     ap.add_argument("--body-contacts", action="store_true", help="knee spheres collide too (16-lane kernels)")
-    ap.add_argument("--joint-limits", action="store_true", help="joint-limit stops (a1.py:186-195)")
+    ap.add_argument("--no-joint-limits", dest="joint_limits", action="store_false",
+                    help="switch the joint-limit stops (a1.py:186-195; on by default, as Bullet enforces the URDF's) off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra-legs", action="store_true",
                     help="skip the legs reported next to `value` (stepwise, auto-reset, K = 50, config 3, ES generation): "
@@ -387,12 +388,12 @@ def main():
                 extra["solver_iters_%d" % kfix] = leg(envk, None, True, "the same fused rollout with exactly %d PGS sweeps per tick "
                                                       "(no residual test)" % kfix, reps=reps)
                 envk.close()
-            if lanes == 16 and not (args.body_contacts and args.joint_limits):
-                # the model options the headline leaves off: knee spheres collide, joint-limit stops (non-PLAIN kernels)
-                kwf = dict(env_kw, body_contacts=True, joint_limits=True)
+            if lanes == 16 and not args.body_contacts:
+                # the model option the headline leaves off: body spheres collide too (deepest of knee / shin / trunk corner per leg)
+                kwf = dict(env_kw, body_contacts=2)
                 envf = make_env("Quadrupedal", **solver_kw, **kwf)
-                extra["knees_and_joint_limits"] = leg(envf, None, True, "the same fused rollout with body_contacts (knee spheres) and "
-                                                      "joint_limits (a1.py:186-195 stops) switched on")
+                extra["body_contacts"] = leg(envf, None, True, "the same fused rollout with body_contacts = 2 (one frictionless row per leg on "
+                                             "the deepest of knee / shin midpoint / trunk corner spheres) switched on")
                 envf.close()
         if args.config == 2:
             pol3 = make_policy()

@@ -169,7 +169,8 @@ typedef struct EtgConfig {
   int32_t enable_etg;
   /* joint-limit stops (a1.py:186-195 UPPER_BOUND / LOWER_BOUND through the URDF limits Bullet enforces): when
    * != 0 a joint that has left [joint_lower, joint_upper] and still moves outward is stopped inelastically
-   * (DESIGN.md section 2); 0 = no limits (round-1 model).                                                  */
+   * (DESIGN.md section 2); 0 = no limits.  default_config / make_env switch them ON (Bullet always enforces the URDF's;
+   * the reference's own recorded gait reaches the calf joint's upper bound).                                */
   int32_t joint_limits;
   double joint_lower[3], joint_upper[3];   /* hip, thigh, calf (rad) */
   double trunk_half[3];                    /* half extents of the trunk's collision box (body_contacts = 2), base frame */

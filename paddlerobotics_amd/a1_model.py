@@ -202,7 +202,7 @@ def default_config(num_envs, *, action_repeat=13, sim_dt=0.002, settle_ticks=500
                    ETG_T=0.5, ETG_T2=0.5, etg_amp=0.2, etg_sigma_sq=0.04,
                    etg_phase=(-math.pi / 2, 0.0), reward_param=None, reward_p=5.0, vel_d=0.5,
                    heightfield=None, lanes_per_robot=0, motor_mode=0, clip_motor_commands=0.0,
-                   body_contacts=0, knee_radius=0.02, enable_etg=1, joint_limits=0, friction_model=0, pd_latency=0.0):
+                   body_contacts=0, knee_radius=0.02, enable_etg=1, joint_limits=1, friction_model=0, pd_latency=0.0):
     """EtgConfig with the defaults of train.py:296-297,470-487 and SURVEY App. A."""
     c = EtgConfig()
     c.num_envs = int(num_envs)

@@ -623,15 +623,15 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   L.lam[0] = l0; L.lam[1] = l1; L.lam[2] = l2;
   L.contact = sel_(act && (l0 > zero), one, zero);
   // ---- joint-limit stops (EtgConfig.joint_limits; same model as physics_tick16 and the oracle)
-  if (!Ctx::kPlain && K.jlim) {
+  if (K.jlim) {   // (compiled into the PLAIN instantiations too: see physics_tick16)
     F jt[3], hitf[3];
     auto anyhit = c.lane_is(0) && !c.lane_is(0);   // all-false mask
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       const F lo(K.jlo[j]), hi(K.jhi[j]);
-      const F pen = sel_(L.q[j] > hi, L.q[j] - hi, sel_(L.q[j] < lo, L.q[j] - lo, zero));
+      const F pen = fmaxf_(L.q[j] - hi, zero) + fminf_(L.q[j] - lo, zero);
       jt[j] = -(F(K.erp) * pen * F(1.0f / K.dt));
-      const auto hit = ((pen > zero) && (L.qd[j] > jt[j])) || ((pen < zero) && (L.qd[j] < jt[j]));
+      const auto hit = pen * (L.qd[j] - jt[j]) > zero;
       hitf[j] = sel_(hit, one, zero);
       anyhit = anyhit || hit;
     }
@@ -975,13 +975,9 @@ ETG_HD void control_step_core(const Ctx& c, const KCfg& K, TickPar4<F>& tp, cons
     float lerp = (float)(i + 1) * inv_repeat;
 #pragma unroll
     for (int j = 0; j < 3; j++) proc[j] = interp ? last[j] + F(lerp) * (qdes[j] - last[j]) : qdes[j];
-    if (pdl) {   // EtgConfig.pd_latency: see control_step16_core
-      F pd[6];
-      pd_reading(c, K, ring, tick, false, pd);
-      physics_tick(c, K, tp, L, proc, fext, torque_cmd, pd);
-    } else {
-      physics_tick(c, K, tp, L, proc, fext, torque_cmd);
-    }
+    F pd[6] = {L.q[0], L.q[1], L.q[2], L.qd[0], L.qd[1], L.qd[2]};   // EtgConfig.pd_latency: see control_step16_core
+    if (pdl) pd_reading(c, K, ring, tick, false, pd);
+    physics_tick(c, K, tp, L, proc, fext, torque_cmd, Ctx::kPlain ? (const F*)nullptr : pd);
     tick++;
     if (pdl || i == ia || i == ib) ring_push(c, ring, tick & (RING - 1), L);
   }
@@ -1102,13 +1098,9 @@ ETG_HD void reset_settle(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   int tick = 0;
   const TickPar4<F> tp = load_tick_par4<F>(c);
   for (int i = 0; i < K.settle_ticks; i++) {  // a1.py:294-297
-    if (!Ctx::kPlain && K.pd_n >= 0) {
-      F pd[6];
-      pd_reading(c, K, ring, tick, true, pd);
-      physics_tick(c, K, tp, L, pose, V3<F>{F(0.0f), F(0.0f), F(0.0f)}, false, pd);
-    } else {
-      physics_tick(c, K, tp, L, pose, V3<F>{F(0.0f), F(0.0f), F(0.0f)});
-    }
+    F pd[6] = {L.q[0], L.q[1], L.q[2], L.qd[0], L.qd[1], L.qd[2]};
+    if (!Ctx::kPlain && K.pd_n >= 0) pd_reading(c, K, ring, tick, true, pd);
+    physics_tick(c, K, tp, L, pose, V3<F>{F(0.0f), F(0.0f), F(0.0f)}, false, Ctx::kPlain ? (const F*)nullptr : pd);
     tick++;
     ring_push(c, ring, tick & (RING - 1), L);
   }

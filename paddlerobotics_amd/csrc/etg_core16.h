@@ -517,13 +517,13 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   // p = (target - qd) / (M^-1)_jj, all violated joints at once (Jacobi), applied through M^-1 = the same Schur
   // machinery as the contact impulses: base -S^-1 sum_j P_j p_j, joints H^-1 p - P^T dB.  Rare: the whole block sits
   // behind one wave-uniform test.
-  if (!Ctx::kPlain && K.jlim) {
+  if (K.jlim) {   // (compiled into the PLAIN instantiations too: the stops are on by default, the test below is 9 instructions per tick)
     const F lo = sel_(s0, F(K.jlo[0]), sel_(s1, F(K.jlo[1]), F(K.jlo[2])));
     const F hi = sel_(s0, F(K.jhi[0]), sel_(s1, F(K.jhi[1]), F(K.jhi[2])));
-    const F pen = sel_(L.q > hi, L.q - hi, sel_(L.q < lo, L.q - lo, zero));
+    const F pen = fmaxf_(L.q - hi, zero) + fminf_(L.q - lo, zero);      // > 0 above the range, < 0 below it, 0 inside
     const F jt = -(F(K.erp) * pen * F(1.0f / K.dt));
-    const auto hit = ((pen > zero) && (L.qd > jt)) || ((pen < zero) && (L.qd < jt));
-    const F hitf = mj * sel_(hit, one, zero);
+    // outside and not yet returning at the Baumgarte rate: (pen > 0 and qd > jt) or (pen < 0 and qd < jt)  <=>  pen (qd - jt) > 0
+    const F hitf = mj * sel_(pen * (L.qd - jt) > zero, one, zero);
     if (c.any(hitf > F(0.5f))) {
       F z6[6] = {P.a.x, P.a.y, P.a.z, P.l.x, P.l.y, P.l.z};
       fwd6(s, z6);
@@ -808,13 +808,9 @@ ETG_HD void control_step16_core(const Ctx& c, const KCfg& K, TickPar<F>& tp, Sta
   for (int i = 0; i < K.action_repeat; i++) {
     float lerp = (float)(i + 1) * inv_repeat;
     F proc = interp ? last + F(lerp) * (qdes - last) : qdes;
-    if (pdl) {   // EtgConfig.pd_latency: the PD law reads a delayed joint state, so every tick's reading enters the ring
-      F pd[2];
-      pd_reading16(c, K, ring, tick, false, pd);
-      physics_tick16(c, K, tp, L, proc, torque_cmd, pd);
-    } else {
-      physics_tick16(c, K, tp, L, proc, torque_cmd);
-    }
+    F pd[2] = {L.q, L.qd};   // EtgConfig.pd_latency: the PD law reads a delayed joint state, so every tick's reading enters the ring
+    if (pdl) pd_reading16(c, K, ring, tick, false, pd);
+    physics_tick16(c, K, tp, L, proc, torque_cmd, Ctx::kPlain ? (const F*)nullptr : pd);   // (ONE inlined copy of the tick)
     tick++;
     if (pdl || i == ia || i == ib) ring_push16(c, ring, tick & (RING - 1), L);
   }
@@ -927,13 +923,9 @@ ETG_HD void reset_settle16(const Ctx& c, const KCfg& K, State16<F>& L, float* ri
   int tick = 0;
   const TickPar<F> tp = load_tick_par<F>(c);
   for (int i = 0; i < K.settle_ticks; i++) {
-    if (!Ctx::kPlain && K.pd_n >= 0) {
-      F pd[2];
-      pd_reading16(c, K, ring, tick, true, pd);
-      physics_tick16(c, K, tp, L, pose, false, pd);
-    } else {
-      physics_tick16(c, K, tp, L, pose);
-    }
+    F pd[2] = {L.q, L.qd};
+    if (!Ctx::kPlain && K.pd_n >= 0) pd_reading16(c, K, ring, tick, true, pd);
+    physics_tick16(c, K, tp, L, pose, false, Ctx::kPlain ? (const F*)nullptr : pd);
     tick++;
     ring_push16(c, ring, tick & (RING - 1), L);
   }

@@ -85,7 +85,7 @@ struct KCfg {
 // the default robot layer (what train.py / pretrain.py run): the PLAIN kernel instantiations compile the options out
 inline bool plain_config(const KCfg& K) {
   return K.motor_mode == 0 && !K.enable_filter && !K.enable_interp && !(K.torque_limit > 0.0f) && !(K.clip_cmd > 0.0f) &&
-         !K.ext_force && !K.knee && K.etg_on && !K.jlim && !K.fric_pyramid && K.pd_n < 0;
+         !K.ext_force && !K.knee && K.etg_on && !K.fric_pyramid && K.pd_n < 0;   // (joint limits: in every instantiation)
 }
 
 // counter-based standard normal pair for (seed, robot, observation index, channel): splitmix64 finaliser twice, then

@@ -145,7 +145,7 @@ class BatchedQuadrupedEnv:
                  heightfield=None, lanes_per_robot=0, terrain_variants=16, terrain_seed=0,
                  random_dynamics_scale=0.3, random_force_prob=0.02, random_force_steps=8,
                  random_force_range=(5.0, 25.0), seed=0, enable_clip_motor_commands=False,
-                 observation_noise_stdev=None, body_contacts=False, knee_radius=0.02, joint_limits=False,
+                 observation_noise_stdev=None, body_contacts=False, knee_radius=0.02, joint_limits=True,
                  auto_reset=False, **unused):
         if render:
             raise ValueError("render is not supported by the batched GPU simulator")

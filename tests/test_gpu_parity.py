@@ -992,10 +992,10 @@ def test_knee_contacts_match_oracle():
     n = 32
     # (1) a limp robot folds onto its knees: same trajectory as the oracle, and the knees do carry it
     flat_grid = dict(heights=np.zeros((65, 65), dtype=np.float32), cell=0.5, origin=(-16.0, -16.0))
-    env = _make(n, motor_control_mode="torque", body_contacts=True, solver_iters=4, task="heightfield", heightfield=flat_grid)
+    env = _make(n, motor_control_mode="torque", body_contacts=True, solver_iters=4, task="heightfield", heightfield=flat_grid, joint_limits=False)
     assert env.lanes_per_robot == 16 and env.cfg.terrain == 1
     hf = env.terrain
-    orc = _oracle(n, motor_mode=1, body_contacts=1, terrain=1, heightfield=hf, solver_iters=4)
+    orc = _oracle(n, motor_mode=1, body_contacts=1, terrain=1, heightfield=hf, solver_iters=4, joint_limits=0)
     orc.set_heightfield(hf["heights"])
     env.reset(); orc.reset()
     act = np.zeros((n, 12), dtype=np.float32); act[1::2, 1::3] = 2.0

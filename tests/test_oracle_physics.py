@@ -23,7 +23,7 @@ def quat2mat(q):
 
 def _free_flight_drift(dt, ticks):
     rng = np.random.default_rng(0)
-    sim = O.OracleSim(A.default_config(1, settle_ticks=0, sim_dt=dt))
+    sim = O.OracleSim(A.default_config(1, settle_ticks=0, sim_dt=dt, joint_limits=0))   # a free mechanism: the stops dissipate
     row = A.default_dynamic_row()
     row[45:48] = 0
     sim.set_params(dyn=row[None])
@@ -244,7 +244,7 @@ def test_forward_dynamics_matches_an_independent_articulated_body_algorithm():
     for trial in range(6):
         p = np.zeros(48) if trial == 0 else rng.uniform(-1, 1, 48)       # nominal and randomised dynamics (train.py:112-126)
         row = A.dynamic_dict_to_row(A.param2dynamic_dict(p))
-        sim = O.OracleSim(A.default_config(1, settle_ticks=0))
+        sim = O.OracleSim(A.default_config(1, settle_ticks=0, joint_limits=0))   # the free mechanism: no stop impulses
         sim.set_params(dyn=row[None])
         st = np.zeros(37)
         st[2] = 5.0                                                      # far above the ground: no contacts

@@ -294,7 +294,7 @@ def test_emulation_knee_contacts_match_oracle():
     act = np.zeros((n, 12)); act[1, 1::3] = 2.0                       # robot 1: a little thigh torque, lands differently
     finals = {}
     for bc in (0, 1):
-        cfg = A.default_config(n, solver_iters=4, motor_mode=1, body_contacts=bc, terrain=1, heightfield=hf)
+        cfg = A.default_config(n, solver_iters=4, motor_mode=1, body_contacts=bc, terrain=1, heightfield=hf, joint_limits=0)   # (a limp robot folds past the stops)
         orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=16)
         for s in (orc, emu):
             s.set_heightfield(hf["heights"]); s.reset()
@@ -315,7 +315,7 @@ def test_body_contacts_config_and_flat_ground_knee_rows():
     from tests.emu.emu import EmuSim
     n = 2
     act = np.zeros((n, 12)); act[1, 1::3] = 2.0
-    cfg = A.default_config(n, solver_iters=4, motor_mode=1, body_contacts=1)
+    cfg = A.default_config(n, solver_iters=4, motor_mode=1, body_contacts=1, joint_limits=0)
     orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=16)
     orc.reset(); emu.reset()
     for k in range(13):
@@ -350,7 +350,7 @@ def test_emulation_trunk_and_shin_contacts_match_oracle(terrain):
     from tests.emu.emu import EmuSim
     n = 2
     hf = _step_edge_heightfield() if terrain else None
-    cfg = A.default_config(n, solver_iters=4, motor_mode=1, body_contacts=2, terrain=terrain, heightfield=hf)
+    cfg = A.default_config(n, solver_iters=4, motor_mode=1, body_contacts=2, terrain=terrain, heightfield=hf, joint_limits=0)
     assert cfg.body_contacts == 2 and tuple(cfg.trunk_half) == A.TRUNK_HALF
     rest = A.TRUNK_HALF[2] + cfg.knee_radius
     orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=16)
@@ -371,7 +371,7 @@ def test_emulation_trunk_and_shin_contacts_match_oracle(terrain):
     # (b) limp standing robot, 40 control steps: with the knee rows alone the trunk passes through the floor
     lows = {}
     for bc in (1, 2):
-        cfg = A.default_config(n, solver_iters=4, motor_mode=1, body_contacts=bc, terrain=terrain, heightfield=hf)
+        cfg = A.default_config(n, solver_iters=4, motor_mode=1, body_contacts=bc, terrain=terrain, heightfield=hf, joint_limits=0)
         orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=16)
         for s in (orc, emu):
             if terrain:
@@ -417,7 +417,7 @@ def test_emulation_joint_limits_match_oracle(lanes):
     lo, hi = np.array(A.JOINT_LOWER), np.array(A.JOINT_UPPER)
     assert (q <= hi + 0.03).all() and (q >= lo - 0.03).all()          # the stops hold (Baumgarte leaves a small overshoot)
     assert np.abs(q[0, :, 0] - hi[0]).max() < 0.03 and np.abs(q[1, :, 0] - lo[0]).max() < 0.03   # and the hips sit on them
-    free = OracleSim(A.default_config(n, solver_iters=4, motor_mode=1))
+    free = OracleSim(A.default_config(n, solver_iters=4, motor_mode=1, joint_limits=0))
     free.reset()
     for k in range(12):
         free.step(act)

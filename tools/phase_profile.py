@@ -10,10 +10,11 @@ env.reset()
 for _ in range(20): env.step(None)
 env.step(None, want_info=True); torch.cuda.synchronize()
 row = env.info_buf[0].cpu().numpy()
-names = ["0 integ+ring+PD+trig+links", "1 RNEA", "2 CRBA/Hinv/P", "3 Schur+LDL+solve", "4 v*+contact setup+Z", "5 Delassus A", "6 u init/warm", "7 PGS", "8 apply impulses", "9 -", "10 -"]
+# prof[k] = cycles between phase marker k-1 and marker k of physics_tick16 / physics_tick (prof[0]: from the end of the previous tick)
+names = ["integration + ring + PD + trig + link inertias", "RNEA", "CRBA / H^-1 / P", "Schur + LDL^T + solve", "unconstrained velocity", "contact rows + Z", "Delassus rows", "row velocities + warm start", "PGS sweeps", "apply impulses (+ joint stops)", "-"]
 tot = row[16]
 print("lanes_per_robot", lanes)
 print("total cycles per control step (wave 0): %.0f  (%.1f us at 2.4 GHz)" % (tot, tot / 2400))
 for k in range(10):
-    print("  after-phase %-24s %9.0f cycles  %5.1f %%  (%.0f per tick)" % (names[k], row[k], 100 * row[k] / tot, row[k] / 13))
+    print("  %-48s %9.0f cycles  %5.1f %%  (%.0f per tick)" % (names[k], row[k], 100 * row[k] / tot, row[k] / 13))
 print("  outside ticks          %9.0f cycles  %5.1f %%" % (tot - row[:10].sum(), 100 * (tot - row[:10].sum()) / tot))
