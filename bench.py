@@ -455,7 +455,7 @@ def main():
                                            "solverResidualThreshold 1e-7)") if SOLVER[1] > 0 else "projected Gauss-Seidel, warm-started, fixed sweep count",
                                   "max_sweeps": SOLVER[0], "residual_threshold": SOLVER[1], "friction": "disc"},
                        "solver_iters": SOLVER[0], "lanes_per_robot": lanes,
-                       "body_contacts": bool(args.body_contacts), "joint_limits": bool(args.joint_limits),
+                       "body_contacts": bool(args.body_contacts), "joint_limits": bool(args.joint_limits),   # (the stops are on by default)
                        "auto_reset": False, "parallelism": "env-shard x%d" % world,
                        "world_size_reported_by": ("torch.distributed/" + dist.get_backend()) if dist is not None else "single process"},
             "timing": {"repeats": repeats, "value_is": "median repeat", "ms_per_step_min": min(wall) / K * 1e3,
@@ -469,7 +469,7 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "etg::" + kname, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK,
                          "traffic": (traffic * N / 4096.0) if traffic else None,
-                         "traffic_source": ("profiles/r02_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes of "
+                         "traffic_source": ("profiles/r03_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes of "
                                             "this command (tools/pmc_gpu.sh), not counters of this run") if traffic else None,
                          "kernel_ms": kern_ms, "kernel_ms_is": "per control step (median over the repeats; HIP event pair around "
                                                                "the K timed steps on the launch stream)",
@@ -482,7 +482,7 @@ def main():
             v = valu / (kern_ms * 1e-3 * NOMINAL_HZ)
             out["roofline"]["valu_issue"] = {"achieved": v, "peak": VALU_PEAK_PER_SIMD_CYCLE, "unit": "wave-instr/SIMD-cycle @2.4GHz",
                                              "frac": v / VALU_PEAK_PER_SIMD_CYCLE, "single_wave_limit": 0.2,
-                                             "valu_insts_per_wave_step_source": "profiles/r02_pmc.json (SQ_INSTS_VALU / SQ_WAVES)"}
+                                             "valu_insts_per_wave_step_source": "profiles/r03_pmc.json (SQ_INSTS_VALU / SQ_WAVES)"}
         out.update(extra)
         if multi is not None:
             out["multi_gpu"] = multi
