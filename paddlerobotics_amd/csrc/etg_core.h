@@ -20,6 +20,8 @@
 // complement 6x6), contacts by projected Gauss-Seidel over the 4 feet in lane order.
 #pragma once
 
+#include <type_traits>
+
 #include "etg_layout.h"
 
 namespace etg {
@@ -541,72 +543,82 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   // zero deltas; mu = 1e30: the cone projection is the identity) -- see physics_tick16.
   F mu = tp.mu;
   F k10 = Aown[1][0] * iA1, k20 = Aown[2][0] * iA2, c0 = tgt * iA0;
-  const bool pyramid = !Ctx::kPlain && K.fric_pyramid;
   F own[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) own[j] = sel_(c.lane_is(j), one, zero);
-  auto pgs_sweep = [&]() {
+  // instantiated per friction model (a compile-time constant inside the sweeps): see physics_tick16
+  auto solve = [&](auto pyramid_tag) {
+    constexpr bool pyramid = decltype(pyramid_tag)::value;
+    auto pgs_sweep = [&]() {
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
-      // normal row, then the two tangent rows as ONE block: both candidates from the velocities after the normal update
-      // (u_t + A_t0 (ln - l0)), the pair projected on the friction disc (friction_model 1: each clamped on its own)
-      F e0 = fmaxf_(-l0, c0 - u0 * iA0), e1, e2;                      // = max(0, l0 + c0 - u0 / A00) - l0
-      F ln = l0 + e0;
-      F lt1 = (l1 - u1 * iA1) - k10 * e0;
-      F lt2 = (l2 - u2 * iA2) - k20 * e0;
-      if (pyramid) {
-        const F lim = mu * ln;
-        e1 = fminf_(fmaxf_(lt1, -lim), lim) - l1;
-        e2 = fminf_(fmaxf_(lt2, -lim), lim) - l2;
-      } else {
-        F sc = fminf_(one, (mu * ln) * rsqrt_((lt1 * lt1 + F(1e-30f)) + lt2 * lt2));
-        e1 = lt1 * sc - l1; e2 = lt2 * sc - l2;
+      for (int j = 0; j < 4; j++) {
+        // normal row, then the two tangent rows as ONE block: both candidates from the velocities after the normal update
+        // (u_t + A_t0 (ln - l0)), the pair projected on the friction disc (friction_model 1: each clamped on its own)
+        F e0 = fmaxf_(-l0, c0 - u0 * iA0), e1, e2;                      // = max(0, l0 + c0 - u0 / A00) - l0
+        F ln = l0 + e0;
+        F lt1 = (l1 - u1 * iA1) - k10 * e0;
+        F lt2 = (l2 - u2 * iA2) - k20 * e0;
+        if (pyramid) {
+          const F lim = mu * ln;
+          e1 = fminf_(fmaxf_(lt1, -lim), lim) - l1;
+          e2 = fminf_(fmaxf_(lt2, -lim), lim) - l2;
+        } else {
+          F sc = fminf_(one, (mu * ln) * rsqrt_((lt1 * lt1 + F(1e-30f)) + lt2 * lt2));
+          e1 = lt1 * sc - l1; e2 = lt2 * sc - l2;
+        }
+        F b0 = c.qbcast(e0, j), b1 = c.qbcast(e1, j), b2 = c.qbcast(e2, j);
+        u0 = u0 + A[j][0][0] * b0 + A[j][0][1] * b1 + A[j][0][2] * b2;
+        u1 = u1 + A[j][1][0] * b0 + A[j][1][1] * b1 + A[j][1][2] * b2;
+        u2 = u2 + A[j][2][0] * b0 + A[j][2][1] * b1 + A[j][2][2] * b2;
+        l0 = l0 + own[j] * e0; l1 = l1 + own[j] * e1; l2 = l2 + own[j] * e2;  // the owner commits
       }
-      F b0 = c.qbcast(e0, j), b1 = c.qbcast(e1, j), b2 = c.qbcast(e2, j);
-      u0 = u0 + A[j][0][0] * b0 + A[j][0][1] * b1 + A[j][0][2] * b2;
-      u1 = u1 + A[j][1][0] * b0 + A[j][1][1] * b1 + A[j][1][2] * b2;
-      u2 = u2 + A[j][2][0] * b0 + A[j][2][1] * b1 + A[j][2][2] * b2;
-      l0 = l0 + own[j] * e0; l1 = l1 + own[j] * e1; l2 = l2 + own[j] * e2;  // the owner commits
+    };
+    if (K.res_thr > 0.0f) {
+      // EtgConfig.solver_residual: sweep until the robot's largest squared row residual is <= the threshold (see
+      // physics_tick16): |l - l at the start of the sweep| > sqrt(thr) / A_rr per row, tolerances from the unfrozen inverses
+      const F tol0 = F(K.res_sqrt) * iA0, tol1 = F(K.res_sqrt) * iA1, tol2 = F(K.res_sqrt) * iA2;
+      int it = 0;
+      bool more;
+      auto sweep_and_test = [&]() {
+        const F s0 = l0, s1 = l1, s2 = l2;
+        pgs_sweep();
+        it++;
+        const auto live = c.robot_any((fabsf_(l0 - s0) > tol0) || (fabsf_(l1 - s1) > tol1) || (fabsf_(l2 - s2) > tol2));
+        iA0 = sel_(live, iA0, zero); iA1 = sel_(live, iA1, zero); iA2 = sel_(live, iA2, zero);
+        k10 = sel_(live, k10, zero); k20 = sel_(live, k20, zero);
+        c0 = sel_(live, c0, zero);
+        mu = sel_(live, mu, F(1e30f));
+        more = c.wave_any(live) && it < K.iters;
+      };
+      if (Ctx::kPlain) {   // nested forward exits instead of a loop for the first sweeps: see physics_tick16
+        sweep_and_test();
+        if (__builtin_expect(more, 1)) { sweep_and_test();
+        if (__builtin_expect(more, 1)) { sweep_and_test();
+        if (__builtin_expect(more, 1)) { sweep_and_test();
+        if (more) { sweep_and_test();
+        if (more) { sweep_and_test();
+        if (more) { sweep_and_test();
+        if (more) { sweep_and_test();
+          while (more) sweep_and_test();
+        }}}}}}}
+      } else {
+        do sweep_and_test(); while (more);
+      }
+      L.sweeps += it;
+    } else if (K.iters == 2) {   // a fixed pair of sweeps, straight-line (see physics_tick16)
+      pgs_sweep();
+      pgs_sweep();
+      L.sweeps += 2;
+    } else {
+      for (int it = 0; it < K.iters; it++) pgs_sweep();
+      L.sweeps += K.iters;
     }
   };
-  if (K.res_thr > 0.0f) {
-    // EtgConfig.solver_residual: sweep until the robot's largest squared row residual is <= the threshold (see
-    // physics_tick16); one quad max per sweep, the loop ends when every robot of the wave is done
-    // |l - l at the start of the sweep| > sqrt(thr) / A_rr per row (see physics_tick16); the tolerances are made from the
-    // unfrozen inverses once per tick
-    const F tol0 = F(K.res_sqrt) * iA0, tol1 = F(K.res_sqrt) * iA1, tol2 = F(K.res_sqrt) * iA2;
-    int it = 0;
-    bool more;
-    auto sweep_and_test = [&]() {
-      const F s0 = l0, s1 = l1, s2 = l2;
-      pgs_sweep();
-      it++;
-      const auto live = c.robot_any((fabsf_(l0 - s0) > tol0) || (fabsf_(l1 - s1) > tol1) || (fabsf_(l2 - s2) > tol2));
-      iA0 = sel_(live, iA0, zero); iA1 = sel_(live, iA1, zero); iA2 = sel_(live, iA2, zero);
-      k10 = sel_(live, k10, zero); k20 = sel_(live, k20, zero);
-      c0 = sel_(live, c0, zero);
-      mu = sel_(live, mu, F(1e30f));
-      more = c.wave_any(live) && it < K.iters;
-    };
-    // nested forward exits instead of a loop for the first sweeps: see physics_tick16
-    sweep_and_test();
-    if (__builtin_expect(more, 1)) { sweep_and_test();
-    if (__builtin_expect(more, 1)) { sweep_and_test();
-    if (__builtin_expect(more, 1)) { sweep_and_test();
-    if (more) { sweep_and_test();
-    if (more) { sweep_and_test();
-    if (more) { sweep_and_test();
-    if (more) { sweep_and_test();
-      while (more) sweep_and_test();
-    }}}}}}}
-    L.sweeps += it;
-  } else if (K.iters == 2) {   // a fixed pair of sweeps, straight-line (see physics_tick16)
-    pgs_sweep();
-    pgs_sweep();
-    L.sweeps += 2;
+  if constexpr (Ctx::kPlain) {
+    solve(std::false_type{});
   } else {
-    for (int it = 0; it < K.iters; it++) pgs_sweep();
-    L.sweeps += K.iters;
+    if (K.fric_pyramid) solve(std::true_type{});
+    else solve(std::false_type{});
   }
   c.phase(8);
   // ---- apply impulses: base via the Schur factor, leg via H^-1

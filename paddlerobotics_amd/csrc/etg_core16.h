@@ -17,6 +17,8 @@
 // interchangeable on one handle.
 #pragma once
 
+#include <type_traits>
+
 #include "etg_core.h"
 
 namespace etg {
@@ -403,93 +405,103 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   // the current impulse (all deltas exact zeros), mue = 1e30 makes the cone projection the identity -- so a robot's result
   // does not depend on its wave neighbours (batch invariance) and equals the oracle's, which stops per robot.
   F iAe = iA, c0e = tgt * iA, mue = tp.mu;
-  const bool pyramid = !Ctx::kPlain && K.fric_pyramid;
   const F tangf = f1 + f2;
   // owner masks of the three rows of every leg, hoisted out of the sweeps (1 on the lane that owns row e of leg lp)
-  F mk[4][3], mt[4];
+  F mk0[4], mt[4];
 #pragma unroll
   for (int lp = 0; lp < 4; lp++) {
-    mk[lp][0] = ownl[lp] * f0; mk[lp][1] = ownl[lp] * f1; mk[lp][2] = ownl[lp] * f2;
+    mk0[lp] = ownl[lp] * f0;
     mt[lp] = ownl[lp] * tangf;
   }
-  auto pgs_sweep = [&]() {
+  // The whole solve is instantiated per friction model (PYRAMID is a compile-time constant inside): a runtime test per foot
+  // inside the sweeps' serial chain cost the all-options kernels 800 cycles per tick (phase profile: 2327 against 1504).
+  auto solve = [&](auto pyramid_tag) {
+    constexpr bool pyramid = decltype(pyramid_tag)::value;
+    auto pgs_sweep = [&]() {
 #pragma unroll
-    for (int lp = 0; lp < 4; lp++) {
-      // normal row: ln = max(0, lam - (u - tgt)/A), as a change: max(-lam, (tgt - u)/A); the owner's lam update sits
-      // between the candidate and its broadcast, where the DPP read needs two wait states anyway
-      F dln = fmaxf_(-lam, c0e - u * iAe);                          // = max(0, lam + c0 - u / A) - lam
-      lam = lam + mk[lp][0] * dln;
-      const F b = c.rbcast(dln, 4 * lp);
-      u = u + A[lp][0] * b;
-      // tangent rows t1, t2 of the foot as ONE block: each of the two lanes computes its row's candidate from the same
-      // velocities in the same instruction, the pair is projected on the friction disc mu ln (friction_model 1: each clamped
-      // on its own), and the two total changes are broadcast once -- 15 instructions instead of 23 for two sequential row
-      // updates plus a separate projection pass
-      const F lim = mue * c.qb(lam, 0);
-      const F lc = lam - u * iAe;                                   // this lane's candidate (meaningful on the tangent lanes)
-      F dl;
-      if (pyramid) {
-        dl = fminf_(fmaxf_(lc, -lim), lim) - lam;
-      } else {
-        const F oth = c.qswap12(lc);
-        const F sc = fminf_(one, lim * rsqrt_((lc * lc + F(1e-30f)) + oth * oth));   // (the 1e-30 keeps 0 * rsq(0) off the table)
-        dl = lc * sc - lam;
+      for (int lp = 0; lp < 4; lp++) {
+        // normal row: ln = max(0, lam - (u - tgt)/A), as a change: max(-lam, (tgt - u)/A); the owner's lam update sits
+        // between the candidate and its broadcast, where the DPP read needs two wait states anyway
+        F dln = fmaxf_(-lam, c0e - u * iAe);                          // = max(0, lam + c0 - u / A) - lam
+        lam = lam + mk0[lp] * dln;
+        const F b = c.rbcast(dln, 4 * lp);
+        u = u + A[lp][0] * b;
+        // tangent rows t1, t2 of the foot as ONE block: each of the two lanes computes its row's candidate from the same
+        // velocities in the same instruction, the pair is projected on the friction disc mu ln (friction_model 1: each clamped
+        // on its own), and the two total changes are broadcast once -- 15 instructions instead of 23 for two sequential row
+        // updates plus a separate projection pass
+        const F lim = mue * c.qb(lam, 0);
+        const F lc = lam - u * iAe;                                   // this lane's candidate (meaningful on the tangent lanes)
+        F dl;
+        if (pyramid) {
+          dl = fminf_(fmaxf_(lc, -lim), lim) - lam;
+        } else {
+          const F oth = c.qswap12(lc);
+          const F sc = fminf_(one, lim * rsqrt_((lc * lc + F(1e-30f)) + oth * oth));   // (the 1e-30 keeps 0 * rsq(0) off the table)
+          dl = lc * sc - lam;
+        }
+        const F b1 = c.rbcast(dl, 4 * lp + 1), b2 = c.rbcast(dl, 4 * lp + 2);
+        u = u + A[lp][1] * b1 + A[lp][2] * b2;
+        lam = lam + mt[lp] * dl;
+        if (knee) {   // the leg's knee row, after its foot rows: lk = max(0, lk - (u - tgt)/A)
+          F dlk = fmaxf_(-lam, c0e - u * iAe);
+          lam = lam + ownl[lp] * f3 * dlk;
+          F bk = c.rbcast(dlk, 4 * lp + 3);
+          u = u + Ak[lp] * bk;
+        }
       }
-      const F b1 = c.rbcast(dl, 4 * lp + 1), b2 = c.rbcast(dl, 4 * lp + 2);
-      u = u + A[lp][1] * b1 + A[lp][2] * b2;
-      lam = lam + mt[lp] * dl;
-      if (knee) {   // the leg's knee row, after its foot rows: lk = max(0, lk - (u - tgt)/A)
-        F dlk = fmaxf_(-lam, c0e - u * iAe);
-        lam = lam + ownl[lp] * f3 * dlk;
-        F bk = c.rbcast(dlk, 4 * lp + 3);
-        u = u + Ak[lp] * bk;
+    };
+    if (K.res_thr > 0.0f) {
+      // EtgConfig.solver_residual (etgsim.h): sweep until the robot's largest squared row residual
+      // ((lam - lam at the start of the sweep) * A_rr)^2 is <= the threshold, K.iters sweeps at most.
+      // ((lam - lam0) A_rr)^2 > thr  <=>  |lam - lam0| > sqrt(thr) / A_rr: one subtraction and one compare per lane and sweep
+      // against a tolerance made once per tick (inactive rows: iA = 0, no change, 0 > 0 is false); "any row of my robot"
+      // comes from the compare's wave mask (robot_any), not from a 4-stage lane reduction
+      const F tol = F(K.res_sqrt) * iA;
+      int it = 0;
+      bool more;
+      auto sweep_and_test = [&]() {
+        const F lam0 = lam;
+        pgs_sweep();
+        it++;
+        const auto live = c.robot_any(fabsf_(lam - lam0) > tol);
+        iAe = sel_(live, iAe, zero);
+        c0e = sel_(live, c0e, zero);
+        mue = sel_(live, mue, F(1e30f));
+        more = c.wave_any(live) && it < K.iters;
+      };
+      if (Ctx::kPlain) {
+        // The default robot layer: the first 8 sweeps as nested forward exits (falling through costs nothing, the one taken
+        // branch per tick is the exit); ticks that need more (a fraction of a percent) enter the loop at the bottom.
+        sweep_and_test();
+        if (__builtin_expect(more, 1)) { sweep_and_test();
+        if (__builtin_expect(more, 1)) { sweep_and_test();
+        if (__builtin_expect(more, 1)) { sweep_and_test();
+        if (more) { sweep_and_test();
+        if (more) { sweep_and_test();
+        if (more) { sweep_and_test();
+        if (more) { sweep_and_test();
+          while (more) sweep_and_test();
+        }}}}}}}
+      } else {   // the all-options instantiations: one copy per friction model (the unrolled form is worth 0.5 %)
+        do sweep_and_test(); while (more);
       }
+      L.sweeps += it;
+    } else if (K.iters == 2) {
+      // a fixed pair of sweeps (the round-1/2 default) as straight-line code: no loop back-edge inside the tick
+      pgs_sweep();
+      pgs_sweep();
+      L.sweeps += 2;
+    } else {
+      for (int it = 0; it < K.iters; it++) pgs_sweep();
+      L.sweeps += K.iters;
     }
   };
-  if (K.res_thr > 0.0f) {
-    // EtgConfig.solver_residual (etgsim.h): sweep until the robot's largest squared row residual
-    // ((lam - lam at the start of the sweep) * A_rr)^2 is <= the threshold, K.iters sweeps at most.  One 16-lane max per
-    // sweep; the loop ends when every robot of the wave is done (wave-uniform branch).
-    // ((lam - lam0) A_rr)^2 > thr  <=>  |lam - lam0| > sqrt(thr) / A_rr: one subtraction and one compare per lane and sweep
-    // against a tolerance made once per tick (inactive rows: iA = 0, no change, 0 > 0 is false); "any row of my robot"
-    // comes from the compare's wave mask (robot_any), not from a 4-stage lane reduction
-    const F tol = F(K.res_sqrt) * iA;
-    int it = 0;
-    bool more;
-    auto sweep_and_test = [&]() {
-      const F lam0 = lam;
-      pgs_sweep();
-      it++;
-      const auto live = c.robot_any(fabsf_(lam - lam0) > tol);
-      iAe = sel_(live, iAe, zero);
-      c0e = sel_(live, c0e, zero);
-      mue = sel_(live, mue, F(1e30f));
-      more = c.wave_any(live) && it < K.iters;
-    };
-    // A taken branch costs a lone wave ~100 ns (the instruction buffer refills from the cache with nothing to hide it): a loop
-    // would pay that once per sweep.  The first sweeps are laid out as nested forward exits instead -- falling through costs
-    // nothing, the one taken branch per tick is the exit -- and only ticks that need more than 8 sweeps (a fraction of a
-    // percent) enter the loop at the bottom.
-    sweep_and_test();
-    if (__builtin_expect(more, 1)) { sweep_and_test();
-    if (__builtin_expect(more, 1)) { sweep_and_test();
-    if (__builtin_expect(more, 1)) { sweep_and_test();
-    if (more) { sweep_and_test();
-    if (more) { sweep_and_test();
-    if (more) { sweep_and_test();
-    if (more) { sweep_and_test();
-      while (more) sweep_and_test();
-    }}}}}}}
-    L.sweeps += it;
-  } else if (K.iters == 2) {
-    // a fixed pair of sweeps (the round-1/2 default) as straight-line code: no loop back-edge inside the tick (a taken
-    // branch is expensive for a lone wave) -- 35.5 -> 34.2 us per step
-    pgs_sweep();
-    pgs_sweep();
-    L.sweeps += 2;
+  if constexpr (Ctx::kPlain) {
+    solve(std::false_type{});
   } else {
-    for (int it = 0; it < K.iters; it++) pgs_sweep();
-    L.sweeps += K.iters;
+    if (K.fric_pyramid) solve(std::true_type{});
+    else solve(std::false_type{});
   }
   c.phase(8);
   // ---- apply impulses: base via the Schur factor, joints via H^-1

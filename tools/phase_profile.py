@@ -5,7 +5,9 @@ os.environ["ETG_LIB"] = os.path.join(os.path.dirname(os.path.dirname(os.path.abs
 import numpy as np, torch
 from paddlerobotics_amd.env import make_env
 lanes = int(sys.argv[1]) if len(sys.argv) > 1 else 16
-env = make_env("Quadrupedal", num_envs=4096, device="cuda:0", lanes_per_robot=lanes)
+# a second argument switches the action filter on: the all-options (non-PLAIN) instantiation with the same physics
+kw = dict(enable_action_filter=True) if len(sys.argv) > 2 else {}
+env = make_env("Quadrupedal", num_envs=4096, device="cuda:0", lanes_per_robot=lanes, **kw)
 env.reset()
 for _ in range(20): env.step(None)
 env.step(None, want_info=True); torch.cuda.synchronize()
