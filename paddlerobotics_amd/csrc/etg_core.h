@@ -305,11 +305,17 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
 #pragma unroll
   for (int j = 0; j < 3; j++) {
     F cmd = qdes[j];
-    if (!Ctx::kPlain && K.clip_cmd > 0.0f && !torque_cmd) cmd = fminf_(fmaxf_(cmd, L.q[j] - F(K.clip_cmd)), L.q[j] + F(K.clip_cmd));   // a1.py:439-457
+    if (!Ctx::kPlain) {   // a1.py:439-457; branch-free: an option that is off clamps at +-1e30 (see physics_tick16)
+      const F clipv((K.clip_cmd > 0.0f && !torque_cmd) ? K.clip_cmd : 1e30f);
+      cmd = fminf_(fmaxf_(cmd, L.q[j] - clipv), L.q[j] + clipv);
+    }
     const F qm = (!Ctx::kPlain && pd) ? pd[j] : L.q[j], qdm = (!Ctx::kPlain && pd) ? pd[3 + j] : L.qd[j];   // minitaur.py:1195-1199
     F t = Ctx::kPlain ? -(tp.kp[j] * (L.q[j] - cmd)) - tp.kd[j] * L.qd[j]
                       : (torque_cmd ? cmd : (-(tp.kp[j] * (qm - cmd)) - tp.kd[j] * (qdm - tp.qd_des[j])) + tp.tau_ff[j]);   // TORQUE mode: pass-through
-    if (!Ctx::kPlain && K.torque_limit > 0.0f) t = fminf_(fmaxf_(t, F(-K.torque_limit)), F(K.torque_limit));
+    if (!Ctx::kPlain) {
+      const F tlim(K.torque_limit > 0.0f ? K.torque_limit : 1e30f);
+      t = fminf_(fmaxf_(t, -tlim), tlim);
+    }
     tau[j] = t;
   }
 
@@ -416,7 +422,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   F rb[6];
 #pragma unroll
   for (int i = 0; i < 6; i++) rb[i] = -(comp(f0, i) + c.qsum(comp(f1, i))) - c.qsum(comp(pb, i));
-  if (!Ctx::kPlain && K.ext_force) {  // external force on the trunk COM (world frame) -> base frame: R^T f
+  if (!Ctx::kPlain) {  // external force on the trunk COM (world frame; zero unless set) -> base frame: R^T f
     rb[3] = rb[3] + Rw.r0.x * fext_w.x + Rw.r1.x * fext_w.y + Rw.r2.x * fext_w.z;
     rb[4] = rb[4] + Rw.r0.y * fext_w.x + Rw.r1.y * fext_w.y + Rw.r2.y * fext_w.z;
     rb[5] = rb[5] + Rw.r0.z * fext_w.x + Rw.r1.z * fext_w.y + Rw.r2.z * fext_w.z;

@@ -129,11 +129,19 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   const F m2 = m1 - f1;                       // sub >= 2
 
   // ---- PD motor model (laikago_motor.py:165-173), this lane's joint
-  if (!Ctx::kPlain && K.clip_cmd > 0.0f && !torque_cmd) qdes = fminf_(fmaxf_(qdes, L.q - F(K.clip_cmd)), L.q + F(K.clip_cmd));   // a1.py:439-457
+  // The option code of the all-options instantiations is branch-free inside the tick (a uniform branch splits the scheduler's
+  // block: +160 / +200 cycles per tick in the PD and Schur phases): an option that is off clamps at +-1e30 / adds a zero force.
+  if (!Ctx::kPlain) {   // a1.py:439-457
+    const F clipv((K.clip_cmd > 0.0f && !torque_cmd) ? K.clip_cmd : 1e30f);
+    qdes = fminf_(fmaxf_(qdes, L.q - clipv), L.q + clipv);
+  }
   const F qm = (!Ctx::kPlain && pd) ? pd[0] : L.q, qdm = (!Ctx::kPlain && pd) ? pd[1] : L.qd;   // _GetPDObservation, minitaur.py:1195-1199
   F tau = Ctx::kPlain ? mj * (-(tp.kp * (L.q - qdes)) - tp.kd * L.qd)
                       : (torque_cmd ? mj * qdes : mj * ((-(tp.kp * (qm - qdes)) - tp.kd * (qdm - tp.qd_des)) + tp.tau_ff));   // TORQUE mode: pass-through
-  if (!Ctx::kPlain && K.torque_limit > 0.0f) tau = fminf_(fmaxf_(tau, F(-K.torque_limit)), F(K.torque_limit));
+  if (!Ctx::kPlain) {
+    const F tlim(K.torque_limit > 0.0f ? K.torque_limit : 1e30f);
+    tau = fminf_(fmaxf_(tau, -tlim), tlim);
+  }
 
   // ---- leg geometry, this lane's link frame R_s = Rx(a) Ry(theta_s), theta = (0, h, h+k)
   const LegGeo<F> g = leg_geometry(c, K, tp.o1, tp.sy, L.q);
@@ -269,7 +277,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   c.sum16x6(rb);
 #pragma unroll
   for (int i = 0; i < 6; i++) rb[i] = -comp(fb0, i) - rb[i];
-  if (!Ctx::kPlain && K.ext_force) {  // external force on the trunk COM (world frame) -> base frame: R^T f
+  if (!Ctx::kPlain) {  // external force on the trunk COM (world frame; zero unless set) -> base frame: R^T f
     rb[3] = rb[3] + Rw.r0.x * tp.fext.x + Rw.r1.x * tp.fext.y + Rw.r2.x * tp.fext.z;
     rb[4] = rb[4] + Rw.r0.y * tp.fext.x + Rw.r1.y * tp.fext.y + Rw.r2.y * tp.fext.z;
     rb[5] = rb[5] + Rw.r0.z * tp.fext.x + Rw.r1.z * tp.fext.y + Rw.r2.z * tp.fext.z;
