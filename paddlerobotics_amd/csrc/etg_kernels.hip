@@ -811,12 +811,23 @@ __device__ __forceinline__ void rollout_policy16_body(const KCfg& K, const DevSt
   // current observation of the tile -> LDS
   for (int idx = tid; idx < TM * ETG_OBS_DIM; idx += 256) obs_lds[idx] = obs[(size_t)tile * TM * ETG_OBS_DIM + idx];
   float reward, done;
+#ifdef ETG_PROFILE_PHASES
+  long long pp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pl = clock64();
+#endif
   for (int s = 0; s < n_steps; s++) {
     __syncthreads();
     if (K.noise_on && s > 0) {   // sensor noise on the row the previous step left in LDS (the last one: k_add_noise)
       add_sensor_noise(K, tile * TM + (tid >> 4), K.noise_call + s - 1, tid & 15, &obs_lds[(tid >> 4) * ETG_OBS_DIM]);
       __syncthreads();
     }
+    // fp32: every layer's first weight fragments are requested one stage EARLY (layer 1's before the observation tile is
+    // staged, layer 2's before layer 1's MFMAs, the head's before layer 2's): a lone wave per SIMD has nothing else to hide
+    // the L2 latency of a layer's first fragments behind
+    WRing<4, NWP> ring1;
+    WRing<HID / 16, NWP> ring2;
+    HeadFrag<NWP> head;
+    constexpr bool PRE = !BF16;
+    if (PRE) ring_prefetch(ring1, P.w1, wave, lane);
     for (int idx = tid; idx < TM * 64; idx += 256) {   // obs tile, zero padded to the 64-wide K of layer 1
       const int r = idx >> 6, col = idx & 63;
       bufA[r * HS + col] = col < P.in_dim ? obs_lds[r * ETG_OBS_DIM + P.col0 + col] : 0.0f;
@@ -824,13 +835,27 @@ __device__ __forceinline__ void rollout_policy16_body(const KCfg& K, const DevSt
     if (REC)   // the observation the actor acts on at this step (noise included), rows of the tile's 16 robots: coalesced
       for (int idx = tid; idx < TM * ETG_OBS_DIM; idx += 256) R.obs[((size_t)s * K.n_env + (size_t)tile * TM) * ETG_OBS_DIM + idx] = obs_lds[idx];
     __syncthreads();
-    hidden_layer<BF16, 4, NWP>(bufA, P.w1, P.b1, bufB, wave, lane);
+#ifdef ETG_PROFILE_PHASES
+    { long long t = clock64(); pp[0] += t - pl; pl = t; __builtin_amdgcn_sched_barrier(0); }
+#endif
+    if (PRE) ring_prefetch(ring2, P.w2, wave, lane);
+    hidden_layer<BF16, 4, NWP, PRE>(bufA, P.w1, P.b1, bufB, wave, lane, &ring1);
     __syncthreads();
-    hidden_layer<BF16, HID / 16, NWP>(bufB, P.w2, P.b2, bufA, wave, lane);
+#ifdef ETG_PROFILE_PHASES
+    { long long t = clock64(); pp[1] += t - pl; pl = t; __builtin_amdgcn_sched_barrier(0); }
+#endif
+    if (PRE) head_prefetch(head, P.w3, wave, lane);
+    hidden_layer<BF16, HID / 16, NWP, PRE>(bufB, P.w2, P.b2, bufA, wave, lane, &ring2);
     __syncthreads();
-    output_partial<BF16, NWP>(bufA, P.w3, wave, lane, part);
+#ifdef ETG_PROFILE_PHASES
+    { long long t = clock64(); pp[2] += t - pl; pl = t; __builtin_amdgcn_sched_barrier(0); }
+#endif
+    output_partial<BF16, NWP, PRE>(bufA, P.w3, wave, lane, part, &head);
     if (REC && R.noise) output_partial<BF16, NWP>(bufA, R.w3s, wave, lane, part_s);
     __syncthreads();
+#ifdef ETG_PROFILE_PHASES
+    { long long t = clock64(); pp[3] += t - pl; pl = t; __builtin_amdgcn_sched_barrier(0); }
+#endif
     {
       const int r = tid >> 4, cidx = tid & 15;          // 256 threads = 16 rows x 16 columns
       float v = ((part[0][r][cidx] + part[1][r][cidx]) + (part[2][r][cidx] + part[3][r][cidx])) + (cidx < P.out_dim ? P.b3[cidx] : 0.0f);
@@ -845,10 +870,16 @@ __device__ __forceinline__ void rollout_policy16_body(const KCfg& K, const DevSt
     }
     __syncthreads();
     const float action = c.sub < 3 ? act_lds[4 * wave + (lane >> 4)][3 * c.leg + c.sub] : 0.0f;
+#ifdef ETG_PROFILE_PHASES
+    { long long t = clock64(); pp[4] += t - pl; pl = t; __builtin_amdgcn_sched_barrier(0); }
+#endif
     // the step code addresses observation rows by robot index: rows of the LDS tile start at the tile's first robot.
     // Every step writes its observation to the tile (plain ds_write, no generic pointer); the last one is copied out below.
     c.row_base = tile * TM;
     control_step16_core(c, K, tp, L, S, D.ring, D.etgp, action, 0.0f, obs_lds, reward, done, (float*)nullptr);
+#ifdef ETG_PROFILE_PHASES
+    { long long t = clock64(); pp[5] += t - pl; pl = t; __builtin_amdgcn_sched_barrier(0); }
+#endif
     if (REC && c.r == 0) {
       R.rew[(size_t)s * K.n_env + c.env] = reward;
       R.done[(size_t)s * K.n_env + c.env] = done > 0.5f ? 1 : 0;
@@ -858,6 +889,10 @@ __device__ __forceinline__ void rollout_policy16_body(const KCfg& K, const DevSt
   store_state16(c, D.base, D.leg, L);
   __syncthreads();
   for (int idx = tid; idx < TM * ETG_OBS_DIM; idx += 256) obs[(size_t)tile * TM * ETG_OBS_DIM + idx] = obs_lds[idx];   // coalesced
+#ifdef ETG_PROFILE_PHASES
+  __syncthreads();
+  if (tile == 0 && tid == 0) for (int k = 0; k < 8; k++) obs[k] = (float)pp[k];   // debug build: cycle breakdown over row 0
+#endif
 }
 
 template <bool FLAT, bool BF16, bool KNEE, bool PLAIN>

@@ -24,11 +24,6 @@ __device__ __forceinline__ bf16x8 pack_bf16(float4 a, float4 b) {
   return v;
 }
 
-// out[16][this wave's 16*TPW columns] = relu(in[16][16*nkb] * W^T + b); wp = packed weights of the layer
-template <bool BF16, int NKB, int NW_>
-__device__ __forceinline__ void hidden_layer(const float* in, const float4* __restrict__ wp, const float* b,
-                                             float* out, int wave, int lane);
-
 // The same layer over RT stacked 16-row tiles (in / out hold 16 * RT rows): every weight fragment is fetched ONCE and feeds RT
 // MFMAs -- the weight delivery from L2 per robot falls by RT.  For the 4-lane closed-loop kernel (64 robots per workgroup).
 template <bool BF16, int NKB, int NW_, int RT>
@@ -147,9 +142,36 @@ __device__ __forceinline__ void output_partial_rt(const float* bufA, const float
     for (int r = 0; r < 4; r++) part[wave][16 * rt + 4 * g + r][i] = acc[rt][r];
 }
 
-template <bool BF16, int NKB, int NW_>
+// The register ring of a hidden layer's weight fragments (fp32 path): PF k-blocks of the wave's TPW tiles in flight.  A
+// caller that knows the NEXT layer can start its ring early (ring_prefetch before the current layer's MFMAs), so the L2
+// latency of a layer's first fragments hides behind the previous layer instead of stalling the lone wave at every layer.
+template <int NKB, int NW_>
+struct WRing {
+  static constexpr int PF = NKB < 3 ? NKB : 3;
+  static constexpr int TPW = (HID / 16) / NW_;
+  float4 w[PF + 1][TPW];
+};
+
+template <int NKB, int NW_>
+__device__ __forceinline__ const float4* ring_base(const float4* __restrict__ wp, int wave, int lane) {
+  return wp + (size_t)(WRing<NKB, NW_>::TPW * wave) * NKB * 64 + lane;
+}
+
+template <int NKB, int NW_>
+__device__ __forceinline__ void ring_prefetch(WRing<NKB, NW_>& r, const float4* __restrict__ wp, int wave, int lane) {
+  constexpr int PF = WRing<NKB, NW_>::PF, TPW = WRing<NKB, NW_>::TPW;
+  const float4* base = ring_base<NKB, NW_>(wp, wave, lane);
+#pragma unroll
+  for (int p = 0; p < PF; p++)
+#pragma unroll
+    for (int t = 0; t < TPW; t++) r.w[p][t] = base[t * NKB * 64 + p * 64];
+}
+
+// out[16][this wave's 16*TPW columns] = relu(in[16][16*nkb] * W^T + b); wp = packed weights of the layer.
+// PRE: the caller already started the ring (ring_prefetch)
+template <bool BF16, int NKB, int NW_, bool PRE = false>
 __device__ __forceinline__ void hidden_layer(const float* in, const float4* __restrict__ wp, const float* b,
-                                             float* out, int wave, int lane) {
+                                             float* out, int wave, int lane, WRing<NKB, NW_>* pre = nullptr) {
   constexpr int nkb = NKB;
   constexpr int TPW = (HID / 16) / NW_;   // 16-column output tiles per wave
   const int i = lane & 15, g = lane >> 4;
@@ -158,7 +180,7 @@ __device__ __forceinline__ void hidden_layer(const float* in, const float4* __re
   for (int t = 0; t < TPW; t++) acc[t] = {0.f, 0.f, 0.f, 0.f};
   // tile t of this wave: packed block ((TPW*wave + t) * nkb + kb); software-pipelined: the next k-block's
   // fragments are in flight while the MFMAs of the current one issue
-  const float4* base = wp + (size_t)(TPW * wave) * nkb * 64 + lane;
+  const float4* base = ring_base<NKB, NW_>(wp, wave, lane);
 #ifdef ETG_PROBE_WEIGHTS_FROM_L1   // upper-bound probe (wrong results): every tile re-reads the same fragments -> L1 hits
   const int tstride = 0;
 #else
@@ -167,12 +189,15 @@ __device__ __forceinline__ void hidden_layer(const float* in, const float4* __re
   if (!BF16) {
     // weight fragments come from L2 (hundreds of ns) while one k-block is only 16 MFMAs (~0.2 us): keep PF
     // k-blocks in flight in a register ring; the loop is fully unrolled so the ring indices are static
-    constexpr int PF = NKB < 3 ? NKB : 3;
-    float4 w[PF + 1][TPW];
+    constexpr int PF = WRing<NKB, NW_>::PF;
+    WRing<NKB, NW_> own;
+    WRing<NKB, NW_>& R = PRE ? *pre : own;
+    if (!PRE) {
 #pragma unroll
-    for (int p = 0; p < PF; p++)
+      for (int p = 0; p < PF; p++)
 #pragma unroll
-      for (int t = 0; t < TPW; t++) w[p][t] = base[t * tstride + p * 64];
+        for (int t = 0; t < TPW; t++) R.w[p][t] = base[t * tstride + p * 64];
+    }
     float4 av[2];   // the A fragment of the next k-block is read from LDS while this one's MFMAs issue
     av[0] = *reinterpret_cast<const float4*>(&in[i * HS + 4 * g]);
 #pragma unroll
@@ -181,9 +206,12 @@ __device__ __forceinline__ void hidden_layer(const float* in, const float4* __re
       if (kb + 1 < nkb) av[(kb + 1) & 1] = *reinterpret_cast<const float4*>(&in[i * HS + (kb + 1) * 16 + 4 * g]);
       if (kb + PF < nkb) {
 #pragma unroll
-        for (int t = 0; t < TPW; t++) w[(kb + PF) % (PF + 1)][t] = base[t * tstride + (kb + PF) * 64];
+        for (int t = 0; t < TPW; t++) R.w[(kb + PF) % (PF + 1)][t] = base[t * tstride + (kb + PF) * 64];
+        // under the fused kernel's register pressure the scheduler sinks these loads to just before their use (seen in the
+        // ISA: s_waitcnt vmcnt(0..2) in front of every k-block), which exposes the L2 latency per k-block: pin them here
+        __builtin_amdgcn_sched_barrier(0);
       }
-      const float4* w0 = w[kb % (PF + 1)];
+      const float4* w0 = R.w[kb % (PF + 1)];
       // k-component outer, tile inner: 4 independent accumulators back to back, so the 40-cycle
       // dependent-accumulator latency of v_mfma_f32_16x16x4_f32 never stalls the 32-cycle issue
 #pragma unroll
@@ -221,9 +249,19 @@ __device__ __forceinline__ void hidden_layer(const float* in, const float4* __re
 
 // output layer: one 16x16 tile of head weights `whp`, K split over the NW_ waves; every wave leaves its partial
 // 16x16 product in part[wave]
-template <bool BF16, int NW_>
+template <int NW_>
+struct HeadFrag { float4 w[(HID / 16) / NW_]; };   // this wave's k-blocks of the head tile, fetched ahead (head_prefetch)
+
+template <int NW_>
+__device__ __forceinline__ void head_prefetch(HeadFrag<NW_>& f, const float4* __restrict__ whp, int wave, int lane) {
+  constexpr int KPW = (HID / 16) / NW_;
+#pragma unroll
+  for (int kk = 0; kk < KPW; kk++) f.w[kk] = whp[lane + (KPW * wave + kk) * 64];
+}
+
+template <bool BF16, int NW_, bool PRE = false>
 __device__ __forceinline__ void output_partial(const float* bufA, const float4* __restrict__ whp, int wave, int lane,
-                                               float (*part)[TM][16]) {
+                                               float (*part)[TM][16], const HeadFrag<NW_>* pre = nullptr) {
   constexpr int KPW = (HID / 16) / NW_;   // k-blocks per wave
   const int i = lane & 15, g = lane >> 4;
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -233,7 +271,7 @@ __device__ __forceinline__ void output_partial(const float* bufA, const float4* 
     for (int kk = 0; kk < KPW; kk++) {
       const int kb = KPW * wave + kk;
       const float4 a = *reinterpret_cast<const float4*>(&bufA[i * HS + kb * 16 + 4 * g]);
-      const float4 bw = base[kb * 64];
+      const float4 bw = PRE ? pre->w[kk] : base[kb * 64];
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.x, bw.x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.y, bw.y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_16x16x4f32(a.z, bw.z, acc, 0, 0, 0);
