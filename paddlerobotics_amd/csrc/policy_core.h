@@ -54,6 +54,7 @@ __device__ __forceinline__ void hidden_layer_rt(const float* in, const float4* _
       if (kb + PF < nkb) {
 #pragma unroll
         for (int t = 0; t < TPW; t++) w[(kb + PF) % (PF + 1)][t] = base[t * tstride + (kb + PF) * 64];
+        __builtin_amdgcn_sched_barrier(0);   // keep the loads here (see hidden_layer)
       }
       const float4* w0 = w[kb % (PF + 1)];
 #pragma unroll

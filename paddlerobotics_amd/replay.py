@@ -3,7 +3,8 @@
   ReplayMemory(max_size, obs_dim, act_dim)          train.py:323-324 (parl.utils.ReplayMemory; parl is not vendored in
   rpm.append(obs, action, reward, next_obs, terminal)  the reference tree: its interface is taken from these call sites)
   rpm.size(), rpm.sample_batch(BATCH_SIZE)          train.py:141,159,163-165,240-241
-  terminal = 1 - float(done)                        train.py:148-149,229-230 (the stored flag is the BOOTSTRAP mask)
+  terminal = 1 - float(done), 1 from episode step 2000 on   train.py:148-149,229-230 (the stored flag is the BOOTSTRAP mask;
+                                                    bootstrap_mask() below)
 
 One env here is thousands of robots, so one `step()` yields a BATCH of transitions: `append_batch` writes the rows of the
 robots whose episode is still running into a ring of transitions that lives in HBM next to the simulator -- no host copy,
@@ -136,7 +137,14 @@ class DeviceReplayMemory:
 
     # ---- reading
     def size(self):
+        """number of stored transitions as a Python int (the reference's rpm.size()): a host synchronisation; hot loops use
+        size_tensor()"""
         return int(min(int(self._count.item()), self.max_size))
+
+    def size_tensor(self):
+        """the same count as a 0-d tensor on the memory's device: no host synchronisation (e.g.
+        torch.where(rpm.size_tensor() < WARMUP_STEPS, uniform_action, sampled_action) in a loop ported from train.py:141)"""
+        return torch.clamp(self._count, max=self.max_size)
 
     def __len__(self):
         return self.size()
@@ -195,6 +203,26 @@ class DeviceReplayMemory:
         return torch.as_tensor(x, device=self.device).to(torch.float32).view(-1)
 
 
+BOOTSTRAP_ALWAYS_FROM = 2000   # train.py:148: `terminal = float(done) if episode_steps < 2000 else 0`, then 1 - terminal
+
+
+def bootstrap_mask(done, episode_steps):
+    """the flag the reference stores with a transition (train.py:148-149, 229-230): 1 - done while the episode is younger than
+    2000 control steps, 1 (keep bootstrapping) from step 2000 on, whatever `done` says.  done [N] bool / uint8 / float,
+    episode_steps: the 1-based step count of the transition."""
+    if episode_steps >= BOOTSTRAP_ALWAYS_FROM:
+        return torch.ones(done.numel(), device=done.device)
+    return 1.0 - done.view(-1).to(torch.float32)
+
+
+def _scalar_info_columns(info_keys):
+    """info keys that can be summed per episode: the scalar (one-column) entries of a1_model.INFO_SLICES; like the reference's
+    `if key in info.keys()` (train.py:150-151) anything else is skipped, on both storage paths."""
+    from . import a1_model as A
+    keep = [k for k in info_keys if k in A.INFO_SLICES and A.INFO_SLICES[k][1] - A.INFO_SLICES[k][0] == 1]
+    return keep, [A.INFO_SLICES[k][0] for k in keep]
+
+
 def collect_transitions(env, rpm, max_step, policy=None, action_bound=0.3, mode="predict", ETG_w=None, ETG_b=None,
                         x_noise=0, precision=0, generator=None, info_keys=("torso", "feet", "up", "tau", "stand", "badfoot", "footcontact"),
                         noise=None):
@@ -233,7 +261,7 @@ def collect_transitions(env, rpm, max_step, policy=None, action_bound=0.3, mode=
         # HIP path: three launches per control step next to predict + step; the summed info terms are the leading columns of
         # the step's info buffer (a1_model.INFO_SLICES order), so one kernel adds them all
         from . import a1_model as A
-        cols = [A.INFO_SLICES[k][0] for k in info_keys]
+        info_keys, cols = _scalar_info_columns(info_keys)
         n_sum = max(cols) + 1 if cols else 0
         velx = A.INFO_SLICES["velx"][0]
         sums = torch.zeros(n, n_sum + 1, device=dev)
@@ -244,12 +272,15 @@ def collect_transitions(env, rpm, max_step, policy=None, action_bound=0.3, mode=
             slot = rpm.begin(obs, action, alive, float(action_bound), scaled)    # also writes scaled = action * action_bound
             obs, reward, done, _ = env.step(scaled, donef=(steps > max_step))
             rpm.end(slot, reward, done, obs, info_buf, n_sum, velx, sums, alive)
+            if steps >= BOOTSTRAP_ALWAYS_FROM:   # the kernel stored 1 - done; rows not stored carry slot -1 -> the spare row
+                rpm.terminal.index_fill_(0, torch.where(slot < 0, rpm.max_size, slot).to(torch.int64), 1.0)
         ret, ln = env.episode_stats()
         infos = {k: sums[:, c] for k, c in zip(info_keys, cols)}
         infos["success_rate"] = sums[:, n_sum] / ln.to(torch.float32).clamp(min=1)
         return ret, ln, infos
 
     alive = torch.ones(n, dtype=torch.bool, device=dev)
+    info_keys, _ = _scalar_info_columns(info_keys)
     infos = {k: torch.zeros(n, device=dev) for k in info_keys}
     success = torch.zeros(n, device=dev)
     for steps in range(1, max_step + 2):
@@ -257,11 +288,11 @@ def collect_transitions(env, rpm, max_step, policy=None, action_bound=0.3, mode=
         slot = rpm.slots(n, alive)
         rpm.write_before(slot, obs, action)          # the observation buffer is overwritten by the step
         obs, reward, done, info = env.step(action * action_bound, donef=(steps > max_step))
-        rpm.write_after(slot, reward, obs, 1.0 - done.to(torch.float32))
+        rpm.write_after(slot, reward, obs, bootstrap_mask(done, steps))
         af = alive.to(torch.float32)
         for k in info_keys:
             if k in info:
-                infos[k] += af * info[k]
+                infos[k] += af * info[k].view(-1)
         success += af * (info["velx"] >= 0.3).to(torch.float32)
         alive = alive & ~done.view(-1).to(torch.bool)
     ret, ln = env.episode_stats()
@@ -310,7 +341,7 @@ def collect_bc_pairs(env, rpm, max_step, student=None, action_bound=0.3, sensor_
 
 def store_recorded(rpm, rec):
     """Move a recorded episode (env.rollout_policy_record) into the replay memory: step-major, robot-minor, only the steps up
-    to and including each robot's first `done` (what collect_transitions stores step by step), terminal = 1 - done.
+    to and including each robot's first `done` (what collect_transitions stores step by step), terminal = bootstrap_mask(done, step).
     Returns the number of rows offered (T * N); the memory must hold at least that many."""
     obs, act, rew, done = rec["obs"], rec["action"], rec["reward"], rec["done"]
     T, N = done.shape
@@ -318,6 +349,7 @@ def store_recorded(rpm, rec):
     alive = (torch.cumsum(dn, dim=0) - dn) == 0                       # no done BEFORE this step
     nxt = torch.cat([obs[1:], rec["final_obs"][None]], dim=0)
     term = 1.0 - done.to(torch.float32)
+    term[BOOTSTRAP_ALWAYS_FROM - 1:] = 1.0                            # episode step = row + 1 (bootstrap_mask)
     if N > rpm.max_size:
         raise ValueError("a step of %d robots does not fit a memory of %d" % (N, rpm.max_size))
     per = max(1, rpm.max_size // N)                                   # steps per append: a batch must fit the ring
