@@ -62,32 +62,41 @@ def test_memory_append_mask_wrap_sample_and_files(tmp_path):
 
 
 class _ToyEnv:
-    """deterministic stand-in with the env surface collect_transitions uses: robot i terminates at step i + 1; obs is ONE
-    buffer overwritten in place by every step (as the real env's is)"""
+    """deterministic stand-in with the env surface collect_transitions uses: robot i terminates at step first_done + i + 1; obs is
+    ONE buffer overwritten in place by every step (as the real env's is).  On a GPU device it also carries the `info_buf` the
+    fused storage path reads (torso = 2 * reward, velx alternating 0.5 / 0.1)."""
 
     class _Space:
         shape = (2,)
 
-    def __init__(self, n, first_done=0):
-        self.num_envs, self.device, self.action_space = n, torch.device("cpu"), self._Space()
-        self.obs = torch.zeros(n, 3)
+    def __init__(self, n, first_done=0, device="cpu", obs_dim=3):
+        self.num_envs, self.device, self.action_space = n, torch.device(device), self._Space()
+        self.obs = torch.zeros(n, obs_dim, device=self.device)
+        self.idx = torch.arange(n, device=self.device)
         self.t = 0
-        self.first_done = first_done   # robot i terminates at step first_done + i + 1
+        self.first_done = first_done
+        if self.device.type == "cuda":
+            from paddlerobotics_amd import a1_model as A
+            self.info_buf = torch.zeros(n, A.INFO_DIM, device=self.device)
+            self._torso, self._velx = A.INFO_SLICES["torso"][0], A.INFO_SLICES["velx"][0]
 
     def reset(self, **kw):
         self.t = 0
-        self.obs[:] = torch.arange(self.num_envs, dtype=torch.float32)[:, None]
-        self.ret = torch.zeros(self.num_envs); self.len = torch.zeros(self.num_envs, dtype=torch.int32)
-        self.alive = torch.ones(self.num_envs, dtype=torch.bool)
+        self.obs[:] = self.idx.to(torch.float32)[:, None]
+        self.ret = torch.zeros(self.num_envs, device=self.device); self.len = torch.zeros(self.num_envs, dtype=torch.int32, device=self.device)
+        self.alive = torch.ones(self.num_envs, dtype=torch.bool, device=self.device)
         return self.obs, {}
 
     def step(self, action, donef=False):
         self.t += 1
         self.obs += 100.0 + action.sum(1, keepdim=True)
-        done = (torch.arange(self.num_envs) + 1 + self.first_done <= self.t) | bool(donef)
-        rew = torch.full((self.num_envs,), float(self.t))
+        done = (self.idx + 1 + self.first_done <= self.t) | bool(donef)
+        rew = torch.full((self.num_envs,), float(self.t), device=self.device)
         self.ret += self.alive * rew; self.len += self.alive.int(); self.alive &= ~done
-        info = {"torso": rew * 2, "velx": torch.where(torch.arange(self.num_envs) % 2 == 0, 0.5, 0.1)}
+        info = {"torso": rew * 2, "velx": torch.where(self.idx % 2 == 0, 0.5, 0.1)}
+        if hasattr(self, "info_buf"):
+            self.info_buf[:, self._torso] = info["torso"]
+            self.info_buf[:, self._velx] = info["velx"]
         return self.obs, rew, done, info
 
     def episode_stats(self):
@@ -122,18 +131,23 @@ def test_collect_transitions_stores_live_rows_with_the_bootstrap_mask():
 
 @pytest.mark.gpu
 def test_device_collection_keeps_bootstrapping_after_step_2000():
-    """GPU, the etg_replay_* kernels: robots that stand still through max_step = 2000 get their forced `done` at control step 2001;
-    from step 2000 on the stored flag stays 1 (train.py:148), so no stored row of these episodes carries terminal = 0."""
-    from tests.test_gpu_parity import _need_gpu, _make
+    """GPU, the etg_replay_* kernels under collect_transitions, on a toy env whose robots end at control steps 1999, 2000 and 2001:
+    the kernels store 1 - done; from episode step 2000 on the stored flag is put back to 1 (train.py:148), exactly as the host
+    path does (test_bootstrap_mask_stays_on_from_episode_step_2000)."""
+    from tests.test_gpu_parity import _need_gpu
     _need_gpu()
-    n, max_step = 32, 2000
-    env = _make(n, seed=9)
-    rpm = DeviceReplayMemory(n * (max_step + 1), 49, 12)
-    ret, ln, infos = collect_transitions(env, rpm, max_step, mode="uniform", action_bound=0.0, generator=torch.Generator(device="cuda:0").manual_seed(0))
-    assert (ln == max_step + 1).all(), "zero residual on the zero gait: the robots stand"
-    assert rpm.size() == n * (max_step + 1) and int(rpm.size_tensor()) == rpm.size()
-    assert (rpm.terminal[:rpm.size()] == 1).all()
-    env.close()
+    n = 3
+    env = _ToyEnv(n, first_done=1998, device="cuda:0")
+    rpm = DeviceReplayMemory(8192, 3, 2)
+    assert rpm.fused
+    ret, ln, infos = collect_transitions(env, rpm, 2005, mode="uniform", action_bound=0.0, generator=torch.Generator(device="cuda:0").manual_seed(0),
+                                         info_keys=("torso", "no_such_key"))
+    assert ln.tolist() == [1999, 2000, 2001] and rpm.size() == 6000 and int(rpm.size_tensor()) == 6000
+    assert set(infos) == {"torso", "success_rate"} and torch.equal(infos["torso"], 2 * ret)
+    k = rpm.size()
+    robot, t = (rpm.obs[:k, 0] % 100).long(), rpm.terminal[:k]
+    assert [(t[robot == i] == 0).sum().item() for i in range(n)] == [1, 0, 0]
+    assert (rpm.reward[:k] > 0).all()
 
 
 @pytest.mark.gpu
