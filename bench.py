@@ -197,7 +197,7 @@ def main():
                     help="squared velocity-level row residual at which a tick stops sweeping (default 1e-7; 0 = fixed count)")
     ap.add_argument("--lanes", type=int, default=0, choices=(0, 4, 16),
                     help="kernel mapping, lanes per robot (0 = library default: 16 up to 4096 robots, else 4)")
-    ap.add_argument("--body-contacts", action="store_true", help="knee spheres collide too (16-lane kernels)")
+    ap.add_argument("--body-contacts", action="store_true", help="knee spheres collide too (one frictionless body row per leg, both mappings)")
     ap.add_argument("--no-joint-limits", dest="joint_limits", action="store_false",
                     help="switch the joint-limit stops (a1.py:186-195; on by default, as Bullet enforces the URDF's) off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -388,7 +388,7 @@ def main():
                 extra["solver_iters_%d" % kfix] = leg(envk, None, True, "the same fused rollout with exactly %d PGS sweeps per tick "
                                                       "(no residual test)" % kfix, reps=reps)
                 envk.close()
-            if lanes == 16 and not args.body_contacts:
+            if not args.body_contacts:
                 # the model option the headline leaves off: body spheres collide too (deepest of knee / shin / trunk corner per leg)
                 kwf = dict(env_kw, body_contacts=2)
                 envf = make_env("Quadrupedal", **solver_kw, **kwf)

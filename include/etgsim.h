@@ -157,11 +157,11 @@ typedef struct EtgConfig {
   /* knee contacts (Bullet collides every link shape; here, besides the four foot spheres): when
    * != 0, a sphere of knee_radius at every knee (the calf joint origin, attached to the thigh) collides with the
    * ground through one frictionless normal row per leg, solved in the same projected Gauss-Seidel sweep right
-   * after the leg's foot rows. Served by the 16-lanes-per-robot kernels (flat ground and heightfield): the free
-   * 4th lane of every leg owns the row.                                                                   */
+   * after the leg's foot rows. Served by both lane mappings, flat ground and heightfield: on the 16-lanes-per-robot
+   * kernels the free 4th lane of every leg owns the row, on the 4-lanes-per-robot ones it is a 4th row of the leg's lane. */
   int32_t body_contacts;   /* 0 off; 1 the knee sphere; 2 the DEEPEST of three spheres of knee_radius per leg: knee, shin midpoint
                             * (carried by the calf), trunk corner next to the leg's hip (trunk_half below) -- still one
-                            * frictionless row per leg, on the leg's 4th lane                                        */
+                            * frictionless row per leg                                                              */
   double knee_radius;
   /* `ETG` kwarg of make_env (train.py:305-309, Dynamic_parallel_model.py:49 runs with ETG=0): 0 switches the
    * trajectory generator off -- the position command is pose_ori + action, info["ETG_act"] and the ETG

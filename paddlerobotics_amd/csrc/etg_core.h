@@ -476,19 +476,76 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   F actf = sel_(act, one, zero);
   V rc = pf - F(K.foot_radius) * dn;
   V k1 = cross(xax, rc - o1), k2 = cross(yax, rc - o2), k3 = cross(yax, rc - o3);
-  V dir[3] = {dn, d1, d2};
-  F Jl[3][3];     // [row d][joint]
-  F HJ[3][3];     // H^-1 Jl^T, [row d][joint]
-  W Z[3];         // D^-1/2 L^-1 G_d
+  // ---- body row (EtgConfig.body_contacts, KNEE instantiations): a 4th, frictionless row of this leg on a sphere of
+  // knee_radius -- 1: at the knee (calf joint origin, carried by the thigh: the calf joint does not move it); 2: the DEEPEST
+  // of knee / shin midpoint (moved by all three joints) / trunk corner next to this leg's hip (moved by none); ties go to the
+  // earlier candidate.  Same model as physics_tick16 and the oracle (one row per leg, no warm start).
+  constexpr bool knee = Ctx::kKnee;
+  constexpr int NRW = knee ? 4 : 3;
+  F phik = one;
+  V dnk = dn, rck = rc, kk1 = k1, kk2 = k2, kk3 = k3;
+  auto actk = act && !act;   // all-false mask
+  F actkf = zero;
+  if (knee) {
+    V pb = o3;
+    F jm12 = one, jm3 = zero;
+    // depth of a body point along the terrain normal (without the radius) and the normal there, world frame
+    auto depth = [&](const V& q, V& nw) -> F {
+      const V w = {L.p.x + dot(Rw.r0, q), L.p.y + dot(Rw.r1, q), L.p.z + dot(Rw.r2, q)};
+      if (Ctx::kFlat) { nw = {zero, zero, one}; return w.z; }
+      F hgt, nwx, nwy, nwz;
+      c.terrain(K, w.x, w.y, hgt, nwx, nwy, nwz);
+      nw = {nwx, nwy, nwz};
+      return (w.z - hgt) * nwz;
+    };
+    V nwk;
+    F best = depth(pb, nwk);
+    if (K.knee >= 2) {
+      const V ps = o3 - F(0.5f * K.lower_len) * R3.ez;
+      const V pt = {sel_(o1.x > zero, F(K.trunk_half[0]), F(-K.trunk_half[0])),
+                    sel_(o1.y > zero, F(K.trunk_half[1]), F(-K.trunk_half[1])), F(-K.trunk_half[2])};
+      V nws, nwt;
+      const F ds = depth(ps, nws);
+      const auto ms = ds < best;
+      pb = {sel_(ms, ps.x, pb.x), sel_(ms, ps.y, pb.y), sel_(ms, ps.z, pb.z)};
+      nwk = {sel_(ms, nws.x, nwk.x), sel_(ms, nws.y, nwk.y), sel_(ms, nws.z, nwk.z)};
+      best = sel_(ms, ds, best);
+      jm3 = sel_(ms, one, zero);
+      const F dtk = depth(pt, nwt);
+      const auto mt = dtk < best;
+      pb = {sel_(mt, pt.x, pb.x), sel_(mt, pt.y, pb.y), sel_(mt, pt.z, pb.z)};
+      nwk = {sel_(mt, nwt.x, nwk.x), sel_(mt, nwt.y, nwk.y), sel_(mt, nwt.z, nwk.z)};
+      best = sel_(mt, dtk, best);
+      jm12 = sel_(mt, zero, one);
+      jm3 = sel_(mt, zero, jm3);
+    }
+    phik = best - F(K.knee_radius);
+    if (Ctx::kFlat) dnk = Rw.r2;
+    else dnk = {Rw.r0.x * nwk.x + Rw.r1.x * nwk.y + Rw.r2.x * nwk.z, Rw.r0.y * nwk.x + Rw.r1.y * nwk.y + Rw.r2.y * nwk.z,
+                Rw.r0.z * nwk.x + Rw.r1.z * nwk.y + Rw.r2.z * nwk.z};
+    actk = phik < F(K.margin);
+    actkf = sel_(actk, one, zero);
+    rck = pb - F(K.knee_radius) * dnk;
+    kk1 = jm12 * cross(xax, rck - o1);
+    kk2 = jm12 * cross(yax, rck - o2);
+    kk3 = jm3 * cross(yax, rck - o3);
+  }
+  V dir[4] = {dn, d1, d2, dnk};
+  F Jl[NRW][3];   // [row d][joint]
+  F HJ[NRW][3];   // H^-1 Jl^T, [row d][joint]
+  W Z[NRW];       // D^-1/2 L^-1 G_d
 #pragma unroll
-  for (int d = 0; d < 3; d++) {
-    Jl[d][0] = actf * dot(dir[d], k1);
-    Jl[d][1] = actf * dot(dir[d], k2);
-    Jl[d][2] = actf * dot(dir[d], k3);
+  for (int d = 0; d < NRW; d++) {
+    const bool body = d == 3;
+    const F af = body ? actkf : actf;
+    const V rcd = body ? rck : rc;
+    Jl[d][0] = af * dot(dir[d], body ? kk1 : k1);
+    Jl[d][1] = af * dot(dir[d], body ? kk2 : k2);
+    Jl[d][2] = af * dot(dir[d], body ? kk3 : k3);
     HJ[d][0] = Hi11 * Jl[d][0] + Hi12 * Jl[d][1] + Hi13 * Jl[d][2];
     HJ[d][1] = Hi12 * Jl[d][0] + Hi22 * Jl[d][1] + Hi23 * Jl[d][2];
     HJ[d][2] = Hi13 * Jl[d][0] + Hi23 * Jl[d][1] + Hi33 * Jl[d][2];
-    W Jb = actf * W{cross(rc, dir[d]), dir[d]};
+    W Jb = af * W{cross(rcd, dir[d]), dir[d]};
     W G = Jb - (Jl[d][0] * P1 + Jl[d][1] * P2 + Jl[d][2] * P3);
     F g6[6] = {G.a.x, G.a.y, G.a.z, G.l.x, G.l.y, G.l.z};
     fwd6(s, g6);
@@ -499,11 +556,11 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   // Every block is a quad-wide outer product over the 4 lanes, contracted over the 6 base
   // coordinates: on the GPU that is 6 accumulating v_mfma_f32_4x4x1_16b_f32 per (d, e) pair
   // (one 4x4 block per robot, 16 robots per instruction) instead of 18 DPP broadcasts + 54 FMAs.
-  F A[4][3][3];
+  F A[4][NRW][NRW];
 #pragma unroll
-  for (int d = 0; d < 3; d++)
+  for (int d = 0; d < NRW; d++)
 #pragma unroll
-    for (int e = 0; e < 3; e++) {
+    for (int e = 0; e < NRW; e++) {
       F acc[4] = {zero, zero, zero, zero};
 #pragma unroll
       for (int k = 0; k < 6; k++) c.quad_outer(comp(Z[e], k), comp(Z[d], k), acc);  // acc[j] += Z_j,e[k] * Z_mine,d[k]
@@ -512,13 +569,15 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
       for (int j = 0; j < 4; j++) A[j][d][e] = acc[j] + sel_(c.lane_is(j), loc, zero);
     }
   // own diagonal inverses
-  F Aown[3][3];
+  F Aown[NRW][NRW];
 #pragma unroll
-  for (int d = 0; d < 3; d++)
+  for (int d = 0; d < NRW; d++)
 #pragma unroll
-    for (int e = 0; e < 3; e++)
+    for (int e = 0; e < NRW; e++)
       Aown[d][e] = sel_(c.lane_is(0), A[0][d][e], sel_(c.lane_is(1), A[1][d][e], sel_(c.lane_is(2), A[2][d][e], A[3][d][e])));
   F iA0 = sel_(act, rcp_(Aown[0][0]), zero), iA1 = sel_(act, rcp_(Aown[1][1]), zero), iA2 = sel_(act, rcp_(Aown[2][2]), zero);
+  F iA3 = zero;
+  if constexpr (knee) iA3 = sel_(actk, rcp_(Aown[3][3]), zero);
   c.phase(6);
   // contact-point velocity under the unconstrained motion
   V vc = vbs + cross(wbs, rc) + qds1 * k1 + qds2 * k2 + qds3 * k3;
@@ -527,12 +586,22 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   F tgt = sel_(phi > zero, -(phi * idt), -(F(K.erp) * phi * idt));
   // warm start (Bullet-style 0.85 factor); inactive feet forget their impulse
   F l0 = actf * F(K.warmstart) * L.lam[0], l1 = actf * F(K.warmstart) * L.lam[1], l2 = actf * F(K.warmstart) * L.lam[2];
+  // the body row: its own point's velocity, Baumgarte / speculative target like the foot's normal row, no warm start
+  F u3 = zero, l3 = zero, c3 = zero, k30 = zero, k31 = zero, k32 = zero;
+  if constexpr (knee) {
+    const V vck = vbs + cross(wbs, rck) + qds1 * kk1 + qds2 * kk2 + qds3 * kk3;
+    u3 = actkf * dot(dnk, vck);
+    const F tgtk = sel_(phik > zero, -(phik * idt), -(F(K.erp) * phik * idt));
+    c3 = tgtk * iA3;
+    k30 = Aown[3][0] * iA3; k31 = Aown[3][1] * iA3; k32 = Aown[3][2] * iA3;
+  }
 #pragma unroll
   for (int j = 0; j < 4; j++) {
     F b0 = c.qbcast(l0, j), b1 = c.qbcast(l1, j), b2 = c.qbcast(l2, j);
     u0 = u0 + A[j][0][0] * b0 + A[j][0][1] * b1 + A[j][0][2] * b2;
     u1 = u1 + A[j][1][0] * b0 + A[j][1][1] * b1 + A[j][1][2] * b2;
     u2 = u2 + A[j][2][0] * b0 + A[j][2][1] * b1 + A[j][2][2] * b2;
+    if constexpr (knee) u3 = u3 + A[j][3][0] * b0 + A[j][3][1] * b1 + A[j][3][2] * b2;
   }
   c.phase(7);
   // ---- projected Gauss-Seidel: feet in lane order, rows (n, t1, t2), disc projection.
@@ -577,23 +646,40 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
         u1 = u1 + A[j][1][0] * b0 + A[j][1][1] * b1 + A[j][1][2] * b2;
         u2 = u2 + A[j][2][0] * b0 + A[j][2][1] * b1 + A[j][2][2] * b2;
         l0 = l0 + own[j] * e0; l1 = l1 + own[j] * e1; l2 = l2 + own[j] * e2;  // the owner commits
+        if constexpr (knee) {
+          // the leg's body row comes after its foot rows (the oracle's order): its velocity with the foot's changes of
+          // this turn folded in (k3x = A3x / A33), clamped at zero impulse
+          const F e3 = fmaxf_(-l3, (c3 - u3 * iA3) - ((k30 * e0 + k31 * e1) + k32 * e2));
+          const F b3 = c.qbcast(e3, j);
+          u0 = u0 + A[j][0][3] * b3;
+          u1 = u1 + A[j][1][3] * b3;
+          u2 = u2 + A[j][2][3] * b3;
+          u3 = u3 + ((A[j][3][0] * b0 + A[j][3][1] * b1) + A[j][3][2] * b2) + A[j][3][3] * b3;
+          l3 = l3 + own[j] * e3;
+        }
       }
     };
     if (K.res_thr > 0.0f) {
       // EtgConfig.solver_residual: sweep until the robot's largest squared row residual is <= the threshold (see
       // physics_tick16): |l - l at the start of the sweep| > sqrt(thr) / A_rr per row, tolerances from the unfrozen inverses
-      const F tol0 = F(K.res_sqrt) * iA0, tol1 = F(K.res_sqrt) * iA1, tol2 = F(K.res_sqrt) * iA2;
+      const F tol0 = F(K.res_sqrt) * iA0, tol1 = F(K.res_sqrt) * iA1, tol2 = F(K.res_sqrt) * iA2, tol3 = F(K.res_sqrt) * iA3;
       int it = 0;
       bool more;
       auto sweep_and_test = [&]() {
-        const F s0 = l0, s1 = l1, s2 = l2;
+        const F s0 = l0, s1 = l1, s2 = l2, s3 = l3;
         pgs_sweep();
         it++;
-        const auto live = c.robot_any((fabsf_(l0 - s0) > tol0) || (fabsf_(l1 - s1) > tol1) || (fabsf_(l2 - s2) > tol2));
+        auto moved = (fabsf_(l0 - s0) > tol0) || (fabsf_(l1 - s1) > tol1) || (fabsf_(l2 - s2) > tol2);
+        if constexpr (knee) moved = moved || (fabsf_(l3 - s3) > tol3);
+        const auto live = c.robot_any(moved);
         iA0 = sel_(live, iA0, zero); iA1 = sel_(live, iA1, zero); iA2 = sel_(live, iA2, zero);
         k10 = sel_(live, k10, zero); k20 = sel_(live, k20, zero);
         c0 = sel_(live, c0, zero);
         mu = sel_(live, mu, F(1e30f));
+        if constexpr (knee) {
+          iA3 = sel_(live, iA3, zero); c3 = sel_(live, c3, zero);
+          k30 = sel_(live, k30, zero); k31 = sel_(live, k31, zero); k32 = sel_(live, k32, zero);
+        }
         more = c.wave_any(live) && it < K.iters;
       };
       if (Ctx::kPlain) {   // nested forward exits instead of a loop for the first sweeps: see physics_tick16
@@ -629,6 +715,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   c.phase(8);
   // ---- apply impulses: base via the Schur factor, leg via H^-1
   W zs = l0 * Z[0] + l1 * Z[1] + l2 * Z[2];
+  if constexpr (knee) zs = zs + l3 * Z[3];
   const W dbs = cmul(W{{c.qsum(zs.a.x), c.qsum(zs.a.y), c.qsum(zs.a.z)}, {c.qsum(zs.l.x), c.qsum(zs.l.y), c.qsum(zs.l.z)}}, sqv);
   F db[6] = {dbs.a.x, dbs.a.y, dbs.a.z, dbs.l.x, dbs.l.y, dbs.l.z};
   bwd6(s, db);
@@ -638,6 +725,9 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   L.qd[0] = qds1 + HJ[0][0] * l0 + HJ[1][0] * l1 + HJ[2][0] * l2 - dot(P1, dB);
   L.qd[1] = qds2 + HJ[0][1] * l0 + HJ[1][1] * l1 + HJ[2][1] * l2 - dot(P2, dB);
   L.qd[2] = qds3 + HJ[0][2] * l0 + HJ[1][2] * l1 + HJ[2][2] * l2 - dot(P3, dB);
+  if constexpr (knee) {
+    L.qd[0] = L.qd[0] + HJ[3][0] * l3; L.qd[1] = L.qd[1] + HJ[3][1] * l3; L.qd[2] = L.qd[2] + HJ[3][2] * l3;
+  }
   L.lam[0] = l0; L.lam[1] = l1; L.lam[2] = l2;
   L.contact = sel_(act && (l0 > zero), one, zero);
   // ---- joint-limit stops (EtgConfig.joint_limits; same model as physics_tick16 and the oracle)

@@ -114,7 +114,9 @@ struct GpuCtx {
 };
 
 // FLAT selects the plane-z=0 fast path at compile time (contact frame = rows of R, no terrain lookup)
-template <bool FLAT, bool PLAIN = false> struct GpuCtxT : GpuCtx { static constexpr bool kFlat = FLAT; static constexpr bool kPlain = PLAIN; };   // PLAIN: see GpuCtx16T
+template <bool FLAT, bool PLAIN = false, bool KNEE = false> struct GpuCtxT : GpuCtx {   // PLAIN, KNEE: see GpuCtx16T
+  static constexpr bool kFlat = FLAT; static constexpr bool kPlain = PLAIN; static constexpr bool kKnee = KNEE;
+};
 
 // Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its own L2.  Robots
 // of neighbouring blocks share 128 B lines of the SoA state (a block covers only 16-64 B of a field), so
@@ -209,9 +211,9 @@ __device__ __forceinline__ void settle_mark_fresh(const KCfg& K, const DevState&
   D.cache_off[K.n_env + env] = oy;
 }
 
-template <bool FLAT, bool PLAIN>
+template <bool FLAT, bool PLAIN, bool KNEE = false>
 __global__ void __launch_bounds__(BLOCK) k_settle(KCfg K, DevState D, const uint8_t* mask) {
-  GpuCtxT<FLAT, PLAIN> c;
+  GpuCtxT<FLAT, PLAIN, KNEE> c;
   if (!make_ctx(K, c)) return;
   if ((mask && !mask[c.env]) || settle_cached<FLAT>(K, D, c.env)) return;   // whole quads drop out together
   __shared__ float lds_par[PR_N * BLOCK];
@@ -251,9 +253,9 @@ __global__ void __launch_bounds__(256) k_cache_mark(KCfg K, DevState D, const ui
   D.cache_ok[env] = 1;
 }
 
-template <bool FLAT, bool PLAIN>
+template <bool FLAT, bool PLAIN, bool KNEE = false>
 __global__ void __launch_bounds__(BLOCK) k_finish(KCfg K, DevState D, const uint8_t* mask, float* obs) {
-  GpuCtxT<FLAT, PLAIN> c;
+  GpuCtxT<FLAT, PLAIN, KNEE> c;
   if (!make_ctx(K, c)) return;
   if (mask && !mask[c.env]) return;
   __shared__ float lds_par[PR_N * BLOCK];
@@ -311,10 +313,10 @@ __device__ __forceinline__ void restart_from_cache4(const Ctx& c, const KCfg& K,
 }
 
 // env.step for the 16 robots of a wave (one quad each); AUTO: see step16_body
-template <bool FLAT, bool PLAIN, bool AUTO>
+template <bool FLAT, bool PLAIN, bool AUTO, bool KNEE = false>
 __device__ __forceinline__ void step4_body(const KCfg& K, const DevState& D, const float* action, const uint8_t* donef, float* obs,
                                            float* reward, uint8_t* done, float* info, float* lds_par) {
-  GpuCtxT<FLAT, PLAIN> c;
+  GpuCtxT<FLAT, PLAIN, KNEE> c;
   if (!make_ctx(K, c)) return;
   stage_params(c, D, lds_par);
   LaneState<float> L = load_state<float>(c, D.base, D.leg);
@@ -358,23 +360,23 @@ __device__ __forceinline__ void step4_body(const KCfg& K, const DevState& D, con
     done[c.env] = d > 0.5f ? 1 : 0;
   }
 }
-template <bool FLAT, bool PLAIN>
+template <bool FLAT, bool PLAIN, bool KNEE = false>
 __global__ void __launch_bounds__(BLOCK) k_step(KCfg K, DevState D, const float* action, const uint8_t* donef, float* obs,
                                                  float* reward, uint8_t* done, float* info) {
   __shared__ float lds_par[PR_N * BLOCK];
-  step4_body<FLAT, PLAIN, false>(K, D, action, donef, obs, reward, done, info, lds_par);
+  step4_body<FLAT, PLAIN, false, KNEE>(K, D, action, donef, obs, reward, done, info, lds_par);
 }
-template <bool FLAT, bool PLAIN>
+template <bool FLAT, bool PLAIN, bool KNEE = false>
 __global__ void __launch_bounds__(BLOCK) k_step_ar(KCfg K, DevState D, const float* action, const uint8_t* donef, float* obs,
                                                     float* reward, uint8_t* done, float* info) {
   __shared__ float lds_par[PR_N * BLOCK];
-  step4_body<FLAT, PLAIN, true>(K, D, action, donef, obs, reward, done, info, lds_par);
+  step4_body<FLAT, PLAIN, true, KNEE>(K, D, action, donef, obs, reward, done, info, lds_par);
 }
 
 // n_steps open-loop control steps per launch (rollout_steps), the 4-lanes-per-robot counterpart of k_rollout16
-template <bool FLAT, bool PLAIN>
+template <bool FLAT, bool PLAIN, bool KNEE = false>
 __global__ void __launch_bounds__(BLOCK) k_rollout(KCfg K, DevState D, int n_steps, float* obs) {
-  GpuCtxT<FLAT, PLAIN> c;
+  GpuCtxT<FLAT, PLAIN, KNEE> c;
   if (!make_ctx(K, c)) return;
   __shared__ float lds_par[PR_N * BLOCK];
   stage_params(c, D, lds_par);
@@ -387,9 +389,9 @@ __global__ void __launch_bounds__(BLOCK) k_rollout(KCfg K, DevState D, int n_ste
 // dynamics-identification evaluator's 2 x 100 steps of known joint targets (Dynamic_parallel_model.py:53-77) and teacher
 // replays.  T: optional per-step outputs ([n_steps][N][...], null = not recorded).
 struct TapeOut { float *q, *imu, *obs, *rew; uint8_t* done; };
-template <bool FLAT, bool PLAIN>
+template <bool FLAT, bool PLAIN, bool KNEE = false>
 __global__ void __launch_bounds__(BLOCK) k_rollout_actions(KCfg K, DevState D, int n_steps, const float* actions, float* obs, TapeOut T) {
-  GpuCtxT<FLAT, PLAIN> c;
+  GpuCtxT<FLAT, PLAIN, KNEE> c;
   if (!make_ctx(K, c)) return;
   __shared__ float lds_par[PR_N * BLOCK];
   stage_params(c, D, lds_par);
@@ -912,7 +914,7 @@ __global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, Po
 // weight fragment fetched from L2 feeds two MFMAs, so the weight delivery per robot is half that of k_rollout_policy16, and a
 // workgroup does two such passes per control step.  Activations of the 32 rows of a pass, the 64 observation rows and the
 // actions stay in LDS; each wave then runs the control step of its 16 robots.  Same arithmetic per row as the 16-lane kernel.
-template <bool FLAT, bool BF16, bool PLAIN>
+template <bool FLAT, bool BF16, bool PLAIN, bool KNEE = false>
 __global__ void __launch_bounds__(256) k_rollout_policy4(KCfg K, DevState D, PolicyW P, int n_steps, float act_scale, float* obs) {
   using namespace pol;
   constexpr int NWP = 4, RT = 2, ROWS = 64;
@@ -924,7 +926,7 @@ __global__ void __launch_bounds__(256) k_rollout_policy4(KCfg K, DevState D, Pol
   __shared__ float lds_par[NWP][PR_N * 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int tile = xcd_contiguous_block();            // 64 robots; the host guarantees N % 64 == 0
-  GpuCtxT<FLAT, PLAIN> c;
+  GpuCtxT<FLAT, PLAIN, KNEE> c;
   c.gid = tile * 256 + tid;
   c.N = K.n_env;
   c.NL = 4 * K.n_env;
@@ -1200,7 +1202,6 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
       if (!(cfg->joint_lower[k] < cfg->joint_upper[k])) return fail(ETG_ERR_BAD_ARG, "etg_create: joint_lower must be below joint_upper");
   if (cfg->lanes_per_robot != 0 && cfg->lanes_per_robot != 4 && cfg->lanes_per_robot != 16)
     return fail(ETG_ERR_BAD_ARG, "etg_create: lanes_per_robot must be 0 (auto), 4 or 16");
-  if (cfg->body_contacts && cfg->lanes_per_robot == 4) return fail(ETG_ERR_BAD_ARG, "etg_create: body_contacts needs the 16-lanes-per-robot mapping");
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
     return fail(ETG_ERR_NO_DEVICE, "etg_create: no HIP device (this library has no CPU path)");
@@ -1221,7 +1222,6 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   // at a time: 16 lanes/robot fills it with 4096 robots and is faster per robot up to there; beyond
   // that the 4-lanes/robot kernel packs 4x the robots per wave (measured crossover).
   h->lanes = cfg->lanes_per_robot != 0 ? cfg->lanes_per_robot : (cfg->num_envs <= 4096 ? 16 : 4);
-  if (cfg->body_contacts) h->lanes = 16;   // the body rows live on the 4th lane of every leg of the 16-lane kernels
   size_t N = h->N, NL = 4 * N;
   struct { void** p; size_t bytes; } allocs[] = {
       {(void**)&h->D.base, BS_N * N * 4},   {(void**)&h->D.leg, LG_N * NL * 4},   {(void**)&h->D.ctl, CT_N * N * 4},
@@ -1289,11 +1289,13 @@ static inline void launch_obs_noise(EtgHandle* h, int n, const uint8_t* mask, fl
     else hipLaunchKernelGGL((KERN<false, false, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);                         \
   } while (0)
 
-// 4-lane kernels: {flat ground, heightfield} x {plain robot layer, all options}
+// 4-lane kernels: {flat ground, heightfield} x {plain robot layer, all options, all options + body rows}
 #define LAUNCH4(KERN, grid, stream, ...)                                                                              \
   do {                                                                                                                \
     const bool pl_ = plain_config(h->K);                                                                              \
-    if (h->K.terrain == 0 && pl_) hipLaunchKernelGGL((KERN<true, true>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);  \
+    if (h->K.knee && h->K.terrain == 0) hipLaunchKernelGGL((KERN<true, false, true>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);  \
+    else if (h->K.knee) hipLaunchKernelGGL((KERN<false, false, true>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);    \
+    else if (h->K.terrain == 0 && pl_) hipLaunchKernelGGL((KERN<true, true>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);  \
     else if (h->K.terrain == 0) hipLaunchKernelGGL((KERN<true, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);   \
     else if (pl_) hipLaunchKernelGGL((KERN<false, true>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);                 \
     else hipLaunchKernelGGL((KERN<false, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);                         \
@@ -1564,15 +1566,17 @@ extern "C" int etg_rollout_policy(EtgHandle* h, EtgPolicy* pol, int n_steps, flo
     for (int done_steps = 0; done_steps < n_steps; done_steps += ROLLOUT_CHUNK) {
       const int m = n_steps - done_steps < ROLLOUT_CHUNK ? n_steps - done_steps : ROLLOUT_CHUNK;
       advance_obs_stream(h, m);
-#define LAUNCH_POLICY4(F_, P_)                                                                                        \
+#define LAUNCH_POLICY4(F_, P_, K_)                                                                                    \
   do {                                                                                                                \
-    if (precision == 0) hipLaunchKernelGGL((k_rollout_policy4<F_, false, P_>), g4, b, 0, s, h->K, h->D, P, m, act_scale, obs); \
-    else hipLaunchKernelGGL((k_rollout_policy4<F_, true, P_>), g4, b, 0, s, h->K, h->D, P, m, act_scale, obs);        \
+    if (precision == 0) hipLaunchKernelGGL((k_rollout_policy4<F_, false, P_, K_>), g4, b, 0, s, h->K, h->D, P, m, act_scale, obs); \
+    else hipLaunchKernelGGL((k_rollout_policy4<F_, true, P_, K_>), g4, b, 0, s, h->K, h->D, P, m, act_scale, obs);    \
   } while (0)
-      if (flat && pl) LAUNCH_POLICY4(true, true);
-      else if (flat) LAUNCH_POLICY4(true, false);
-      else if (pl) LAUNCH_POLICY4(false, true);
-      else LAUNCH_POLICY4(false, false);
+      if (h->K.knee && flat) LAUNCH_POLICY4(true, false, true);
+      else if (h->K.knee) LAUNCH_POLICY4(false, false, true);
+      else if (flat && pl) LAUNCH_POLICY4(true, true, false);
+      else if (flat) LAUNCH_POLICY4(true, false, false);
+      else if (pl) LAUNCH_POLICY4(false, true, false);
+      else LAUNCH_POLICY4(false, false, false);
 #undef LAUNCH_POLICY4
       launch_obs_noise(h, m, nullptr, obs, s);
     }

@@ -986,14 +986,17 @@ def test_sensor_noise_matches_oracle_and_fused_rollout(lanes):
 
 
 @pytest.mark.gpu
-def test_knee_contacts_match_oracle():
-    """body_contacts=True: knee spheres as a 4th, frictionless contact row per leg (16-lane heightfield kernels)."""
+@pytest.mark.parametrize("lanes", [16, 4])
+def test_knee_contacts_match_oracle(lanes):
+    """body_contacts=True: knee spheres as a 4th, frictionless contact row per leg (heightfield kernels of both mappings: the
+    leg's 4th lane on the 16-lane one, a 4th row on the leg's lane with 4 x 4 Delassus blocks on the 4-lane one)."""
     _need_gpu()
     n = 32
     # (1) a limp robot folds onto its knees: same trajectory as the oracle, and the knees do carry it
     flat_grid = dict(heights=np.zeros((65, 65), dtype=np.float32), cell=0.5, origin=(-16.0, -16.0))
-    env = _make(n, motor_control_mode="torque", body_contacts=True, solver_iters=4, task="heightfield", heightfield=flat_grid, joint_limits=False)
-    assert env.lanes_per_robot == 16 and env.cfg.terrain == 1
+    env = _make(n, motor_control_mode="torque", body_contacts=True, solver_iters=4, task="heightfield", heightfield=flat_grid, joint_limits=False,
+                lanes_per_robot=lanes)
+    assert env.lanes_per_robot == lanes and env.cfg.terrain == 1
     hf = env.terrain
     orc = _oracle(n, motor_mode=1, body_contacts=1, terrain=1, heightfield=hf, solver_iters=4, joint_limits=0)
     orc.set_heightfield(hf["heights"])
@@ -1008,7 +1011,7 @@ def test_knee_contacts_match_oracle():
     env.close()
     # (2) walking up stairs with the knees enabled: fused rollout == oracle stepping over a short horizon
     W, B = _etg_params(n, seed=21)
-    env = _make(n, task="stairstair", terrain_variants=4, terrain_seed=2, body_contacts=True)
+    env = _make(n, task="stairstair", terrain_variants=4, terrain_seed=2, body_contacts=True, lanes_per_robot=lanes)
     hf = env.terrain
     orc = _oracle(n, body_contacts=1, terrain=1, heightfield=hf)
     orc.set_heightfield(hf["heights"])
@@ -1020,9 +1023,6 @@ def test_knee_contacts_match_oracle():
     err = np.abs(env.get_state().cpu().numpy()[:, 13:25] - orc.get_state()[:, 13:25]).max(1)
     assert np.median(err) < 5e-3
     env.close()
-    # (3) the 4-lane mapping has no lane for the knee rows
-    with pytest.raises(Exception):
-        _make(n, body_contacts=True, lanes_per_robot=4)
 
 
 @pytest.mark.gpu

@@ -446,13 +446,14 @@ def test_joint_limits_match_oracle(lanes):
     env.close(); a.close(); b.close()
 
 
-def test_flat_ground_knee_rows_match_oracle():
-    """body_contacts on the flat-ground instantiation of the 16-lane kernels (k_*16<true, true, false>): a limp robot folds
-    onto its knees and the knee spheres carry it, as in the oracle."""
+@pytest.mark.parametrize("lanes", [16, 4])
+def test_flat_ground_knee_rows_match_oracle(lanes):
+    """body_contacts on the flat-ground instantiations with the body rows (k_*16<true, true, false>, k_*<true, false, true>): a
+    limp robot folds onto its knees and the knee spheres carry it, as in the oracle."""
     _need_gpu()
     n = 32
-    env = _make(n, motor_control_mode="torque", body_contacts=True, solver_iters=4, joint_limits=False)
-    assert env.lanes_per_robot == 16 and env.cfg.terrain == 0
+    env = _make(n, motor_control_mode="torque", body_contacts=True, solver_iters=4, joint_limits=False, lanes_per_robot=lanes)
+    assert env.lanes_per_robot == lanes and env.cfg.terrain == 0
     orc = _oracle(n, motor_mode=1, body_contacts=1, solver_iters=4, joint_limits=0)
     env.reset(); orc.reset()
     act = np.zeros((n, 12), dtype=np.float32); act[1::2, 1::3] = 2.0
@@ -463,7 +464,7 @@ def test_flat_ground_knee_rows_match_oracle():
         sg, so = env.get_state().cpu().numpy(), orc.get_state()
         worst = max(worst, np.abs(sg - so)[:, 13:25].max())
         assert np.abs(sg - so)[:, :3].max() < 1e-3, k
-    _say("flat knee rows: q err max %.2e" % worst)
+    _say("flat knee rows, %d lanes per robot: q err max %.2e" % (lanes, worst))
     assert worst < 5e-3 and so[0, 2] > -0.2
     env.close()
 
@@ -503,8 +504,9 @@ def test_auto_reset_variants_equal_manual_reset(kw):
     a.close(); b.close()
 
 
-def test_trunk_and_shin_contacts_match_oracle():
-    """body_contacts = 2 on the GPU (both 16-lane instantiations with the body rows): the folded-legs belly landing of
+@pytest.mark.parametrize("lanes", [16, 4])
+def test_trunk_and_shin_contacts_match_oracle(lanes):
+    """body_contacts = 2 on the GPU (the instantiations with the body rows, both mappings): the folded-legs belly landing of
     tests/test_terrain_and_randomisation.py (trunk corners carry the robot, one of them across a step edge) against the
     oracle, and the limp standing robot no longer sinks through the floor."""
     from tests.test_terrain_and_randomisation import _folded_drop_state, _step_edge_heightfield
@@ -513,7 +515,7 @@ def test_trunk_and_shin_contacts_match_oracle():
     for terrain in (0, 1):
         hf = _step_edge_heightfield() if terrain else None
         kw = dict(task="heightfield", heightfield=hf) if terrain else {}
-        env = _make(n, motor_control_mode="torque", body_contacts=2, solver_iters=4, joint_limits=False, **kw)
+        env = _make(n, motor_control_mode="torque", body_contacts=2, solver_iters=4, joint_limits=False, lanes_per_robot=lanes, **kw)
         env.reset()
         orc = _oracle(n, motor_mode=1, body_contacts=2, solver_iters=4, joint_limits=0, **(dict(terrain=1, heightfield=hf) if terrain else {}))
         if terrain:
@@ -531,10 +533,10 @@ def test_trunk_and_shin_contacts_match_oracle():
             assert np.abs(so[:, 13:25] - se[:, 13:25]).max() < 1e-4 and np.abs(so[:, :3] - se[:, :3]).max() < 1e-5, (terrain, k)
         rest = 0.057 + 0.02
         assert abs(se[0, 2] - rest) < 5e-4
-        _say("body_contacts=2 terrain %d: belly landing q err max %.2e, rest height %.4f" % (terrain, worst, se[0, 2]))
+        _say("body_contacts=2 terrain %d, %d lanes per robot: belly landing q err max %.2e, rest height %.4f" % (terrain, lanes, worst, se[0, 2]))
         env.close()
         # limp standing robots, 40 control steps: the trunk never goes below its corner spheres
-        env = _make(n, motor_control_mode="torque", body_contacts=2, solver_iters=4, joint_limits=False, **kw)
+        env = _make(n, motor_control_mode="torque", body_contacts=2, solver_iters=4, joint_limits=False, lanes_per_robot=lanes, **kw)
         env.reset()
         low = torch.full((n,), 1.0, device="cuda:0")
         for k in range(40):
@@ -542,8 +544,6 @@ def test_trunk_and_shin_contacts_match_oracle():
             low = torch.minimum(low, env.get_state()[:, 2])
         assert low.min().item() > rest - 2e-3 and torch.isfinite(env.get_state()).all()
         env.close()
-    with pytest.raises(Exception):
-        _make(n, body_contacts=2, lanes_per_robot=4)
 
 
 def test_single_robot_surface_runs_the_reference_loops_verbatim(golden):

@@ -162,8 +162,8 @@ def _stats_vs_oracle(env, orc, steps, m, label, closed_loop=None):
                 dret=abs(ret_g[:m].mean() - ret_o.mean()) / max(ret_o.std(), 1e-9), z=z)
 
 
-@pytest.mark.parametrize("solver", ["rule", "k50"])
-def test_long_horizon_statistics_on_the_heightfield(solver):
+@pytest.mark.parametrize("solver,lanes", [("rule", 16), ("k50", 16), ("rule", 4)])
+def test_long_horizon_statistics_on_the_heightfield(solver, lanes):
     """configs[4] per GPU: 4096 robots on the random heightfield, 400 control steps, body contacts (deepest of knee / shin /
     trunk corner) and joint-limit stops ON, against 512 fp64 oracle robots.  The terrain is only C0 and its normals jump by
     up to ~1 rad at cell edges, so individual fp32 / fp64 trajectories part within tens of steps (only 20 % of the robots end
@@ -174,14 +174,15 @@ def test_long_horizon_statistics_on_the_heightfield(solver):
     hf = _heightfield()
     skw = {} if solver == "rule" else dict(solver_iters=50)
     w, b = _population(n)
-    env = _make(n, task="heightfield", heightfield=hf, body_contacts=2, joint_limits=True, **skw)
+    env = _make(n, task="heightfield", heightfield=hf, body_contacts=2, joint_limits=True, lanes_per_robot=lanes, **skw)
+    assert env.lanes_per_robot == lanes
     env.reset(ETG_w=w, ETG_b=b)
     orc = _oracle(m, terrain=1, heightfield=hf, body_contacts=2, joint_limits=1, **skw)
     orc.threads = NCPU
     orc.set_heightfield(hf["heights"])
     orc.set_params(etg_w=w[:m].double().cpu().numpy(), etg_b=b[:m].double().cpu().numpy())
     orc.reset()
-    s = _stats_vs_oracle(env, orc, steps, m, "heightfield + body contacts + joint limits, %s" % solver)
+    s = _stats_vs_oracle(env, orc, steps, m, "heightfield + body contacts + joint limits, %s, %d lanes per robot" % (solver, lanes))
     assert s["gap"] < 0.1 and s["gap_full"] < 0.1            # survival curves: same robots / full batch vs the 512-robot sample
     assert s["ks_len"] < 0.1 and s["ks_ret"] < 0.1 and s["ks_dx"] < 0.12       # measured 0.045-0.06 / 0.025-0.03 / 0
     assert s["z"] < 4.0

@@ -142,8 +142,6 @@ def test_a_converged_robot_is_frozen_while_wave_neighbours_sweep_on(lanes, varia
     """On the GPU a wave sweeps until its slowest robot is done.  The emulated robot is made to sit through 3 more sweeps
     after its own convergence on every tick: state and impulses must not move by a single bit."""
     from tests.emu.emu import EmuSim
-    if variant == "knee" and lanes == 4:
-        pytest.skip("body rows live in the 16-lane mapping")
     kw = dict(body_contacts=2, motor_mode=1) if variant == "knee" else dict(friction_model=1) if variant == "pyramid" else {}
     n = 3
     W, B = _params(n, seed=11)

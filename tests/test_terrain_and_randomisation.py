@@ -284,9 +284,11 @@ def test_emulation_sensor_noise_matches_oracle(lanes):
     assert np.abs(orc.step(np.zeros((n, 12)))[0] - clean.step(np.zeros((n, 12)))[0]).max() == 0
 
 
-def test_emulation_knee_contacts_match_oracle():
-    """body_contacts: a limp robot (TORQUE mode, no torque) folds onto its knees; the knee spheres then carry it.  The
-    16-lane kernel source (4th lane of every leg owns the knee row) against the oracle's 16-row formulation."""
+@pytest.mark.parametrize("lanes", [16, 4])
+def test_emulation_knee_contacts_match_oracle(lanes):
+    """body_contacts: a limp robot (TORQUE mode, no torque) folds onto its knees; the knee spheres then carry it.  The kernel
+    source of both mappings (16 lanes: the 4th lane of every leg owns the body row; 4 lanes: a 4th row on the leg's lane, 4 x 4
+    Delassus blocks) against the oracle's 16-row formulation."""
     from oracle.oracle import OracleSim
     from tests.emu.emu import EmuSim
     n = 2
@@ -295,7 +297,7 @@ def test_emulation_knee_contacts_match_oracle():
     finals = {}
     for bc in (0, 1):
         cfg = A.default_config(n, solver_iters=4, motor_mode=1, body_contacts=bc, terrain=1, heightfield=hf, joint_limits=0)   # (a limp robot folds past the stops)
-        orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=16)
+        orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=lanes)
         for s in (orc, emu):
             s.set_heightfield(hf["heights"]); s.reset()
         for k in range(13):
@@ -307,7 +309,8 @@ def test_emulation_knee_contacts_match_oracle():
     assert finals[0][0, 2] < -0.3 and finals[1][0, 2] > -0.2
 
 
-def test_body_contacts_config_and_flat_ground_knee_rows():
+@pytest.mark.parametrize("lanes", [16, 4])
+def test_body_contacts_config_and_flat_ground_knee_rows(lanes):
     cfg = A.default_config(4, body_contacts=1)
     assert cfg.body_contacts == 1 and abs(cfg.knee_radius - 0.02) < 1e-12
     # the knee rows on the flat-ground instantiation (no heightfield): same limp-robot scenario as above
@@ -316,7 +319,7 @@ def test_body_contacts_config_and_flat_ground_knee_rows():
     n = 2
     act = np.zeros((n, 12)); act[1, 1::3] = 2.0
     cfg = A.default_config(n, solver_iters=4, motor_mode=1, body_contacts=1, joint_limits=0)
-    orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=16)
+    orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=lanes)
     orc.reset(); emu.reset()
     for k in range(13):
         orc.step(act); emu.step(act)
@@ -341,8 +344,9 @@ def _step_edge_heightfield():
     return hf
 
 
+@pytest.mark.parametrize("lanes", [16, 4])
 @pytest.mark.parametrize("terrain", [0, 1])
-def test_emulation_trunk_and_shin_contacts_match_oracle(terrain):
+def test_emulation_trunk_and_shin_contacts_match_oracle(terrain, lanes):
     """body_contacts = 2: the leg's 4th row takes the deepest of knee / shin midpoint / trunk corner.  (a) a limp robot with
     folded legs lands on its belly: the trunk corners carry it at half height + radius, kernel source == oracle; (b) the limp
     standing robot of the knee test is caught at the same height instead of sinking through the floor."""
@@ -353,7 +357,7 @@ def test_emulation_trunk_and_shin_contacts_match_oracle(terrain):
     cfg = A.default_config(n, solver_iters=4, motor_mode=1, body_contacts=2, terrain=terrain, heightfield=hf, joint_limits=0)
     assert cfg.body_contacts == 2 and tuple(cfg.trunk_half) == A.TRUNK_HALF
     rest = A.TRUNK_HALF[2] + cfg.knee_radius
-    orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=16)
+    orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=lanes)
     for s in (orc, emu):
         if terrain:
             s.set_heightfield(hf["heights"])
@@ -372,7 +376,7 @@ def test_emulation_trunk_and_shin_contacts_match_oracle(terrain):
     lows = {}
     for bc in (1, 2):
         cfg = A.default_config(n, solver_iters=4, motor_mode=1, body_contacts=bc, terrain=terrain, heightfield=hf, joint_limits=0)
-        orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=16)
+        orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=lanes)
         for s in (orc, emu):
             if terrain:
                 s.set_heightfield(hf["heights"])
