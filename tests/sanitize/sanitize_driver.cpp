@@ -75,7 +75,7 @@ int main(int argc, char** argv) {
     void* e16 = emu_create(&cfg, &model);
     emu_set_lanes(e4, 4);
     emu_set_lanes(e16, 16);
-    const bool lanes4_ok = cfg.body_contacts == 0;     // body rows live in the 16-lane mapping
+    const bool lanes4_ok = true;                        // (body rows: both mappings carry them)
     etgo_set_params64(o64, dynd.data(), wd.data(), bd.data(), 0, nullptr);
     etgo_set_params32(o32, dynf.data(), w.data(), b.data(), 0, nullptr);
     emu_set_params(e4, dynf.data(), w.data(), b.data(), 0, nullptr);
