@@ -161,7 +161,9 @@ typedef struct EtgConfig {
    * kernels the free 4th lane of every leg owns the row, on the 4-lanes-per-robot ones it is a 4th row of the leg's lane. */
   int32_t body_contacts;   /* 0 off; 1 the knee sphere; 2 the DEEPEST of three spheres of knee_radius per leg: knee, shin midpoint
                             * (carried by the calf), trunk corner next to the leg's hip (trunk_half below) -- still one
-                            * frictionless row per leg                                                              */
+                            * frictionless row per leg; 3 all three spheres of every leg at once, a row each (24 rows per
+                            * robot; served by the 4-lanes-per-robot mapping, which the setting selects; the fused
+                            * closed-loop call is not available with it)                                            */
   double knee_radius;
   /* `ETG` kwarg of make_env (train.py:305-309, Dynamic_parallel_model.py:49 runs with ETG=0): 0 switches the
    * trajectory generator off -- the position command is pose_ori + action, info["ETG_act"] and the ETG

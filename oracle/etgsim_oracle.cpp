@@ -555,12 +555,18 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
     mat3_mul_vec(Rw[p], Xup[i].r, o);
     for (int k = 0; k < 3; k++) pw[i][k] = pw[p][k] + o[k];
   }
-  // rows 0..11: feet (n, t1, t2 per leg); rows 12..15: the frictionless knee row of leg l (cfg.body_contacts)
-  constexpr int NR = 16;
-  T J[NR][NV];
-  T target[NR];
-  int active[4], kactive[4];
-  T klam[4] = {0, 0, 0, 0};   // knee impulses: no warm start
+  // rows 0..11: feet (n, t1, t2 per leg); then the frictionless body rows (cfg.body_contacts): one per leg (rows 12..15) for
+  // body_contacts 1 / 2, three per leg (rows 12 + 3 l + b: knee, shin midpoint, trunk corner) for body_contacts 3
+  constexpr int NRMAX = 24;
+  const bool all_bodies = s.cfg.body_contacts == 3;
+  const int NR = all_bodies ? 24 : 16;
+  const int NB = all_bodies ? 3 : 1;                       // body rows per leg
+  auto body_row = [&](int l, int b) { return all_bodies ? 12 + 3 * l + b : 12 + l; };
+  T J[NRMAX][NV];
+  T target[NRMAX];
+  int active[4], kactive[NRMAX];                            // kactive / klam: indexed by row
+  T klam[NRMAX];                                            // body impulses: no warm start
+  for (int r = 0; r < NRMAX; r++) { kactive[r] = 0; klam[r] = 0; target[r] = 0; }
   std::memset(J, 0, sizeof(J));
   const T rad = T(s.model.foot_radius);
   for (int l = 0; l < 4; l++) {
@@ -609,12 +615,11 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
     target[3 * l + 1] = 0; target[3 * l + 2] = 0;
     for (int k = 0; k < 3; k++) e.lam[3 * l + k] *= T(s.cfg.warmstart);
   }
-  // body contacts (cfg.body_contacts): one frictionless row per leg.  1: a sphere at the knee (the calf joint origin,
-  // carried by the thigh: the calf joint does not move it).  2: the DEEPEST of three spheres of knee_radius -- knee, shin
-  // midpoint (carried by the calf), trunk corner next to the leg's hip (carried by the base: no joint moves it).
+  // body contacts (cfg.body_contacts): frictionless rows on spheres of knee_radius.  1: one row per leg on a sphere at the knee
+  // (the calf joint origin, carried by the thigh: the calf joint does not move it).  2: one row per leg on the DEEPEST of three
+  // spheres -- knee, shin midpoint (carried by the calf), trunk corner next to the leg's hip (carried by the base: no joint
+  // moves it).  3: all three spheres of every leg collide at once, a row each (solved in that order after the leg's foot rows).
   for (int l = 0; l < 4; l++) {
-    kactive[l] = 0;
-    target[12 + l] = 0;
     if (!s.cfg.body_contacts) continue;
     const int c = 3 + 3 * l;
     const T krad = T(s.cfg.knee_radius);
@@ -635,38 +640,47 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
       cand[2].first_body = 0;
       ncand = 3;
     }
-    int best = -1;
-    T phi = 0, n[3] = {0, 0, 1};
+    T cphi[3], cn[3][3];
     for (int q = 0; q < ncand; q++) {
-      T h, nq[3];
-      terrain_query(s, e.band, cand[q].p[0], cand[q].p[1], &h, nq);
-      const T pq = (cand[q].p[2] - h) * nq[2] - krad;
-      if (best < 0 || pq < phi) { best = q; phi = pq; for (int k = 0; k < 3; k++) n[k] = nq[k]; }
+      T h;
+      terrain_query(s, e.band, cand[q].p[0], cand[q].p[1], &h, cn[q]);
+      cphi[q] = (cand[q].p[2] - h) * cn[q][2] - krad;
     }
-    kactive[l] = phi < T(s.cfg.contact_margin);
-    if (!kactive[l]) continue;
-    T cp[3], rel[3], rxd[3], tmp[3];
-    for (int k = 0; k < 3; k++) { cp[k] = cand[best].p[k] - krad * n[k]; rel[k] = cp[k] - e.pos[k]; }
-    T* row = J[12 + l];
-    cross(rel, n, rxd);
-    mat3T_mul_vec(R, rxd, tmp);
-    for (int k = 0; k < 3; k++) row[k] = tmp[k];
-    mat3T_mul_vec(R, n, tmp);
-    for (int k = 0; k < 3; k++) row[3 + k] = tmp[k];
-    for (int b = cand[best].first_body; b > 0; b = s.parent[b]) {  // the joints that move the point
-      T axw[3] = {Rw[b][0][s.axis[b]], Rw[b][1][s.axis[b]], Rw[b][2][s.axis[b]]};
-      T rj[3], cr[3];
-      for (int k = 0; k < 3; k++) rj[k] = cp[k] - pw[b][k];
-      cross(axw, rj, cr);
-      row[5 + b] = dot3(n, cr);
+    for (int b = 0; b < NB; b++) {
+      int pick = b;                                   // body_contacts 3: slot b is candidate b
+      if (!all_bodies) {                              // 1 / 2: the deepest candidate, ties to the earlier one
+        pick = 0;
+        for (int q = 1; q < ncand; q++)
+          if (cphi[q] < cphi[pick]) pick = q;
+      }
+      const int rk = body_row(l, b);
+      const T phi = cphi[pick];
+      const T* n = cn[pick];
+      kactive[rk] = phi < T(s.cfg.contact_margin);
+      if (!kactive[rk]) continue;
+      T cp[3], rel[3], rxd[3], tmp[3];
+      for (int k = 0; k < 3; k++) { cp[k] = cand[pick].p[k] - krad * n[k]; rel[k] = cp[k] - e.pos[k]; }
+      T* row = J[rk];
+      cross(rel, n, rxd);
+      mat3T_mul_vec(R, rxd, tmp);
+      for (int k = 0; k < 3; k++) row[k] = tmp[k];
+      mat3T_mul_vec(R, n, tmp);
+      for (int k = 0; k < 3; k++) row[3 + k] = tmp[k];
+      for (int bd = cand[pick].first_body; bd > 0; bd = s.parent[bd]) {  // the joints that move the point
+        T axw[3] = {Rw[bd][0][s.axis[bd]], Rw[bd][1][s.axis[bd]], Rw[bd][2][s.axis[bd]]};
+        T rj[3], cr[3];
+        for (int k = 0; k < 3; k++) rj[k] = cp[k] - pw[bd][k];
+        cross(axw, rj, cr);
+        row[5 + bd] = dot3(n, cr);
+      }
+      target[rk] = (phi > 0) ? -phi / dt : -T(s.cfg.erp) * phi / dt;
     }
-    target[12 + l] = (phi > 0) ? -phi / dt : -T(s.cfg.erp) * phi / dt;
   }
-  auto row_active = [&](int r) { return r < 12 ? active[r / 3] : kactive[r - 12]; };
-  auto lam_of = [&](int r) -> T& { return r < 12 ? e.lam[r] : klam[r - 12]; };
+  auto row_active = [&](int r) { return r < 12 ? active[r / 3] : kactive[r]; };
+  auto lam_of = [&](int r) -> T& { return r < 12 ? e.lam[r] : klam[r]; };
   // Delassus operator
-  T MiJt[NR][NV];
-  T A[NR][NR];
+  T MiJt[NRMAX][NV];
+  T A[NRMAX][NRMAX];
   for (int r = 0; r < NR; r++) {
     if (!row_active(r)) { std::memset(MiJt[r], 0, sizeof(MiJt[r])); continue; }
     chol_solve(J[r], MiJt[r]);
@@ -677,7 +691,7 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
       for (int k = 0; k < NV; k++) sum += J[r][k] * MiJt[c][k];
       A[r][c] = sum;
     }
-  T u[NR];
+  T u[NRMAX];
   for (int r = 0; r < NR; r++) {
     T sum = 0;
     for (int k = 0; k < NV; k++) sum += J[r][k] * vel[k];
@@ -695,17 +709,20 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
   const bool pyramid = s.cfg.friction_model == 1;
   int sweeps = 0;
   for (int it = 0; it < s.cfg.solver_iters; it++) {
-    T lam_start[NR];
+    T lam_start[NRMAX];
     for (int r = 0; r < NR; r++) lam_start[r] = lam_of(r);
     for (int l = 0; l < 4; l++) {
-      if (kactive[l] && !active[l]) {   // the knee row alone
-        const int rk = 12 + l;
-        T lk = klam[l] - (u[rk] - target[rk]) / A[rk][rk];
-        if (lk < 0) lk = 0;
-        apply(rk, lk - klam[l]);
-        klam[l] = lk;
-      }
-      if (!active[l]) continue;
+      auto body_rows = [&]() {   // the leg's body rows, after its foot rows (or alone when the foot is off the ground)
+        for (int b = 0; b < NB; b++) {
+          const int rk = body_row(l, b);
+          if (!kactive[rk]) continue;
+          T lk = klam[rk] - (u[rk] - target[rk]) / A[rk][rk];
+          if (lk < 0) lk = 0;
+          apply(rk, lk - klam[rk]);
+          klam[rk] = lk;
+        }
+      };
+      if (!active[l]) { body_rows(); continue; }
       int r0 = 3 * l;
       // normal
       T ln = e.lam[r0] - (u[r0] - target[r0]) / A[r0][r0];
@@ -734,13 +751,7 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
         apply(r0 + k, cand[k] - e.lam[r0 + k]);
         e.lam[r0 + k] = cand[k];
       }
-      if (kactive[l]) {   // the leg's knee row comes after its foot rows
-        const int rk = 12 + l;
-        T lk = klam[l] - (u[rk] - target[rk]) / A[rk][rk];
-        if (lk < 0) lk = 0;
-        apply(rk, lk - klam[l]);
-        klam[l] = lk;
-      }
+      body_rows();
     }
     sweeps++;
     if (res_thr > 0) {

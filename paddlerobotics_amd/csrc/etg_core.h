@@ -476,19 +476,19 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   F actf = sel_(act, one, zero);
   V rc = pf - F(K.foot_radius) * dn;
   V k1 = cross(xax, rc - o1), k2 = cross(yax, rc - o2), k3 = cross(yax, rc - o3);
-  // ---- body row (EtgConfig.body_contacts, KNEE instantiations): a 4th, frictionless row of this leg on a sphere of
-  // knee_radius -- 1: at the knee (calf joint origin, carried by the thigh: the calf joint does not move it); 2: the DEEPEST
-  // of knee / shin midpoint (moved by all three joints) / trunk corner next to this leg's hip (moved by none); ties go to the
-  // earlier candidate.  Same model as physics_tick16 and the oracle (one row per leg, no warm start).
-  constexpr bool knee = Ctx::kKnee;
-  constexpr int NRW = knee ? 4 : 3;
-  F phik = one;
-  V dnk = dn, rck = rc, kk1 = k1, kk2 = k2, kk3 = k3;
-  auto actk = act && !act;   // all-false mask
-  F actkf = zero;
-  if (knee) {
-    V pb = o3;
-    F jm12 = one, jm3 = zero;
+  // ---- body rows (EtgConfig.body_contacts; the instantiations with Ctx::kBody > 0): frictionless rows of this leg on spheres
+  // of knee_radius, solved after the leg's foot rows.  kBody = 1 -- body_contacts 1: a sphere at the knee (calf joint origin,
+  // carried by the thigh: the calf joint does not move it); body_contacts 2: the DEEPEST of knee / shin midpoint (moved by all
+  // three joints) / trunk corner next to this leg's hip (moved by none), ties to the earlier candidate.  kBody = 3 --
+  // body_contacts 3: all three spheres collide at once, a row each, in that order.  Same model as the oracle (no warm start).
+  constexpr int NB = Ctx::kBody;
+  constexpr bool knee = NB > 0;
+  constexpr int NRW = 3 + NB;
+  constexpr int NBA = NB > 0 ? NB : 1;   // array extents (no zero-length arrays)
+  F phib[NBA], actbf[NBA];
+  V dnb[NBA], rcb[NBA], kb1[NBA], kb2[NBA], kb3[NBA];
+  decltype(act) actb[NBA];
+  if constexpr (knee) {
     // depth of a body point along the terrain normal (without the radius) and the normal there, world frame
     auto depth = [&](const V& q, V& nw) -> F {
       const V w = {L.p.x + dot(Rw.r0, q), L.p.y + dot(Rw.r1, q), L.p.z + dot(Rw.r2, q)};
@@ -498,50 +498,63 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
       nw = {nwx, nwy, nwz};
       return (w.z - hgt) * nwz;
     };
-    V nwk;
-    F best = depth(pb, nwk);
-    if (K.knee >= 2) {
+    V pbd[NBA], nwb[NBA];
+    F dep[NBA], jm12[NBA], jm3[NBA];
+    pbd[0] = o3; jm12[0] = one; jm3[0] = zero;
+    dep[0] = depth(pbd[0], nwb[0]);
+    if (NB == 3 || K.knee >= 2) {
       const V ps = o3 - F(0.5f * K.lower_len) * R3.ez;
       const V pt = {sel_(o1.x > zero, F(K.trunk_half[0]), F(-K.trunk_half[0])),
                     sel_(o1.y > zero, F(K.trunk_half[1]), F(-K.trunk_half[1])), F(-K.trunk_half[2])};
       V nws, nwt;
-      const F ds = depth(ps, nws);
-      const auto ms = ds < best;
-      pb = {sel_(ms, ps.x, pb.x), sel_(ms, ps.y, pb.y), sel_(ms, ps.z, pb.z)};
-      nwk = {sel_(ms, nws.x, nwk.x), sel_(ms, nws.y, nwk.y), sel_(ms, nws.z, nwk.z)};
-      best = sel_(ms, ds, best);
-      jm3 = sel_(ms, one, zero);
-      const F dtk = depth(pt, nwt);
-      const auto mt = dtk < best;
-      pb = {sel_(mt, pt.x, pb.x), sel_(mt, pt.y, pb.y), sel_(mt, pt.z, pb.z)};
-      nwk = {sel_(mt, nwt.x, nwk.x), sel_(mt, nwt.y, nwk.y), sel_(mt, nwt.z, nwk.z)};
-      best = sel_(mt, dtk, best);
-      jm12 = sel_(mt, zero, one);
-      jm3 = sel_(mt, zero, jm3);
+      const F ds = depth(ps, nws), dtk = depth(pt, nwt);
+      if constexpr (NB == 3) {
+        pbd[NB - 2] = ps; nwb[NB - 2] = nws; dep[NB - 2] = ds; jm12[NB - 2] = one; jm3[NB - 2] = one;
+        pbd[NB - 1] = pt; nwb[NB - 1] = nwt; dep[NB - 1] = dtk; jm12[NB - 1] = zero; jm3[NB - 1] = zero;
+      } else {
+        const auto ms = ds < dep[0];
+        pbd[0] = {sel_(ms, ps.x, pbd[0].x), sel_(ms, ps.y, pbd[0].y), sel_(ms, ps.z, pbd[0].z)};
+        nwb[0] = {sel_(ms, nws.x, nwb[0].x), sel_(ms, nws.y, nwb[0].y), sel_(ms, nws.z, nwb[0].z)};
+        dep[0] = sel_(ms, ds, dep[0]);
+        jm3[0] = sel_(ms, one, zero);
+        const auto mt = dtk < dep[0];
+        pbd[0] = {sel_(mt, pt.x, pbd[0].x), sel_(mt, pt.y, pbd[0].y), sel_(mt, pt.z, pbd[0].z)};
+        nwb[0] = {sel_(mt, nwt.x, nwb[0].x), sel_(mt, nwt.y, nwb[0].y), sel_(mt, nwt.z, nwb[0].z)};
+        dep[0] = sel_(mt, dtk, dep[0]);
+        jm12[0] = sel_(mt, zero, one);
+        jm3[0] = sel_(mt, zero, jm3[0]);
+      }
     }
-    phik = best - F(K.knee_radius);
-    if (Ctx::kFlat) dnk = Rw.r2;
-    else dnk = {Rw.r0.x * nwk.x + Rw.r1.x * nwk.y + Rw.r2.x * nwk.z, Rw.r0.y * nwk.x + Rw.r1.y * nwk.y + Rw.r2.y * nwk.z,
-                Rw.r0.z * nwk.x + Rw.r1.z * nwk.y + Rw.r2.z * nwk.z};
-    actk = phik < F(K.margin);
-    actkf = sel_(actk, one, zero);
-    rck = pb - F(K.knee_radius) * dnk;
-    kk1 = jm12 * cross(xax, rck - o1);
-    kk2 = jm12 * cross(yax, rck - o2);
-    kk3 = jm3 * cross(yax, rck - o3);
+#pragma unroll
+    for (int b = 0; b < NB; b++) {
+      phib[b] = dep[b] - F(K.knee_radius);
+      if (Ctx::kFlat) dnb[b] = Rw.r2;
+      else dnb[b] = {Rw.r0.x * nwb[b].x + Rw.r1.x * nwb[b].y + Rw.r2.x * nwb[b].z, Rw.r0.y * nwb[b].x + Rw.r1.y * nwb[b].y + Rw.r2.y * nwb[b].z,
+                     Rw.r0.z * nwb[b].x + Rw.r1.z * nwb[b].y + Rw.r2.z * nwb[b].z};
+      actb[b] = phib[b] < F(K.margin);
+      actbf[b] = sel_(actb[b], one, zero);
+      rcb[b] = pbd[b] - F(K.knee_radius) * dnb[b];
+      kb1[b] = jm12[b] * cross(xax, rcb[b] - o1);
+      kb2[b] = jm12[b] * cross(yax, rcb[b] - o2);
+      kb3[b] = jm3[b] * cross(yax, rcb[b] - o3);
+    }
   }
-  V dir[4] = {dn, d1, d2, dnk};
+  V dir[NRW];
+  dir[0] = dn; dir[1] = d1; dir[2] = d2;
+#pragma unroll
+  for (int b = 0; b < NB; b++) dir[3 + b] = dnb[b];
   F Jl[NRW][3];   // [row d][joint]
   F HJ[NRW][3];   // H^-1 Jl^T, [row d][joint]
   W Z[NRW];       // D^-1/2 L^-1 G_d
 #pragma unroll
   for (int d = 0; d < NRW; d++) {
-    const bool body = d == 3;
-    const F af = body ? actkf : actf;
-    const V rcd = body ? rck : rc;
-    Jl[d][0] = af * dot(dir[d], body ? kk1 : k1);
-    Jl[d][1] = af * dot(dir[d], body ? kk2 : k2);
-    Jl[d][2] = af * dot(dir[d], body ? kk3 : k3);
+    const bool body = d >= 3;
+    const int bi = body ? d - 3 : 0;
+    const F af = body ? actbf[bi] : actf;
+    const V rcd = body ? rcb[bi] : rc;
+    Jl[d][0] = af * dot(dir[d], body ? kb1[bi] : k1);
+    Jl[d][1] = af * dot(dir[d], body ? kb2[bi] : k2);
+    Jl[d][2] = af * dot(dir[d], body ? kb3[bi] : k3);
     HJ[d][0] = Hi11 * Jl[d][0] + Hi12 * Jl[d][1] + Hi13 * Jl[d][2];
     HJ[d][1] = Hi12 * Jl[d][0] + Hi22 * Jl[d][1] + Hi23 * Jl[d][2];
     HJ[d][2] = Hi13 * Jl[d][0] + Hi23 * Jl[d][1] + Hi33 * Jl[d][2];
@@ -576,8 +589,9 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
     for (int e = 0; e < NRW; e++)
       Aown[d][e] = sel_(c.lane_is(0), A[0][d][e], sel_(c.lane_is(1), A[1][d][e], sel_(c.lane_is(2), A[2][d][e], A[3][d][e])));
   F iA0 = sel_(act, rcp_(Aown[0][0]), zero), iA1 = sel_(act, rcp_(Aown[1][1]), zero), iA2 = sel_(act, rcp_(Aown[2][2]), zero);
-  F iA3 = zero;
-  if constexpr (knee) iA3 = sel_(actk, rcp_(Aown[3][3]), zero);
+  F iAb[NBA];
+#pragma unroll
+  for (int b = 0; b < NB; b++) iAb[b] = sel_(actb[b], rcp_(Aown[3 + b][3 + b]), zero);
   c.phase(6);
   // contact-point velocity under the unconstrained motion
   V vc = vbs + cross(wbs, rc) + qds1 * k1 + qds2 * k2 + qds3 * k3;
@@ -586,14 +600,18 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   F tgt = sel_(phi > zero, -(phi * idt), -(F(K.erp) * phi * idt));
   // warm start (Bullet-style 0.85 factor); inactive feet forget their impulse
   F l0 = actf * F(K.warmstart) * L.lam[0], l1 = actf * F(K.warmstart) * L.lam[1], l2 = actf * F(K.warmstart) * L.lam[2];
-  // the body row: its own point's velocity, Baumgarte / speculative target like the foot's normal row, no warm start
-  F u3 = zero, l3 = zero, c3 = zero, k30 = zero, k31 = zero, k32 = zero;
-  if constexpr (knee) {
-    const V vck = vbs + cross(wbs, rck) + qds1 * kk1 + qds2 * kk2 + qds3 * kk3;
-    u3 = actkf * dot(dnk, vck);
-    const F tgtk = sel_(phik > zero, -(phik * idt), -(F(K.erp) * phik * idt));
-    c3 = tgtk * iA3;
-    k30 = Aown[3][0] * iA3; k31 = Aown[3][1] * iA3; k32 = Aown[3][2] * iA3;
+  // the body rows: their own points' velocities, Baumgarte / speculative target like the foot's normal row, no warm start;
+  // kbf[b][x]: A[3+b][x] / A[3+b][3+b] for the rows x solved earlier in the leg's turn (foot rows 0..2, body rows 3..2+b)
+  F ub[NBA], lb[NBA], cb[NBA], kbf[NBA][3 + NBA];
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    const V vcb = vbs + cross(wbs, rcb[b]) + qds1 * kb1[b] + qds2 * kb2[b] + qds3 * kb3[b];
+    ub[b] = actbf[b] * dot(dnb[b], vcb);
+    lb[b] = zero;
+    const F tgtb = sel_(phib[b] > zero, -(phib[b] * idt), -(F(K.erp) * phib[b] * idt));
+    cb[b] = tgtb * iAb[b];
+#pragma unroll
+    for (int x = 0; x < 3 + b; x++) kbf[b][x] = Aown[3 + b][x] * iAb[b];
   }
 #pragma unroll
   for (int j = 0; j < 4; j++) {
@@ -601,7 +619,8 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
     u0 = u0 + A[j][0][0] * b0 + A[j][0][1] * b1 + A[j][0][2] * b2;
     u1 = u1 + A[j][1][0] * b0 + A[j][1][1] * b1 + A[j][1][2] * b2;
     u2 = u2 + A[j][2][0] * b0 + A[j][2][1] * b1 + A[j][2][2] * b2;
-    if constexpr (knee) u3 = u3 + A[j][3][0] * b0 + A[j][3][1] * b1 + A[j][3][2] * b2;
+#pragma unroll
+    for (int b = 0; b < NB; b++) ub[b] = ub[b] + A[j][3 + b][0] * b0 + A[j][3 + b][1] * b1 + A[j][3 + b][2] * b2;
   }
   c.phase(7);
   // ---- projected Gauss-Seidel: feet in lane order, rows (n, t1, t2), disc projection.
@@ -647,38 +666,60 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
         u2 = u2 + A[j][2][0] * b0 + A[j][2][1] * b1 + A[j][2][2] * b2;
         l0 = l0 + own[j] * e0; l1 = l1 + own[j] * e1; l2 = l2 + own[j] * e2;  // the owner commits
         if constexpr (knee) {
-          // the leg's body row comes after its foot rows (the oracle's order): its velocity with the foot's changes of
-          // this turn folded in (k3x = A3x / A33), clamped at zero impulse
-          const F e3 = fmaxf_(-l3, (c3 - u3 * iA3) - ((k30 * e0 + k31 * e1) + k32 * e2));
-          const F b3 = c.qbcast(e3, j);
-          u0 = u0 + A[j][0][3] * b3;
-          u1 = u1 + A[j][1][3] * b3;
-          u2 = u2 + A[j][2][3] * b3;
-          u3 = u3 + ((A[j][3][0] * b0 + A[j][3][1] * b1) + A[j][3][2] * b2) + A[j][3][3] * b3;
-          l3 = l3 + own[j] * e3;
+          // the leg's body rows come after its foot rows (the oracle's order): each row's velocity with the changes made
+          // earlier in this turn folded in (kbf), clamped at zero impulse
+          F eb[NB], bb[NB];
+#pragma unroll
+          for (int b = 0; b < NB; b++) {
+            F fold = (kbf[b][0] * e0 + kbf[b][1] * e1) + kbf[b][2] * e2;
+#pragma unroll
+            for (int x = 0; x < b; x++) fold = fold + kbf[b][3 + x] * eb[x];
+            eb[b] = fmaxf_(-lb[b], (cb[b] - ub[b] * iAb[b]) - fold);
+            bb[b] = c.qbcast(eb[b], j);
+          }
+#pragma unroll
+          for (int b = 0; b < NB; b++) {
+            u0 = u0 + A[j][0][3 + b] * bb[b];
+            u1 = u1 + A[j][1][3 + b] * bb[b];
+            u2 = u2 + A[j][2][3 + b] * bb[b];
+            F acc = (A[j][3 + b][0] * b0 + A[j][3 + b][1] * b1) + A[j][3 + b][2] * b2;
+#pragma unroll
+            for (int x = 0; x < NB; x++) acc = acc + A[j][3 + b][3 + x] * bb[x];
+            ub[b] = ub[b] + acc;
+            lb[b] = lb[b] + own[j] * eb[b];
+          }
         }
       }
     };
     if (K.res_thr > 0.0f) {
       // EtgConfig.solver_residual: sweep until the robot's largest squared row residual is <= the threshold (see
       // physics_tick16): |l - l at the start of the sweep| > sqrt(thr) / A_rr per row, tolerances from the unfrozen inverses
-      const F tol0 = F(K.res_sqrt) * iA0, tol1 = F(K.res_sqrt) * iA1, tol2 = F(K.res_sqrt) * iA2, tol3 = F(K.res_sqrt) * iA3;
+      const F tol0 = F(K.res_sqrt) * iA0, tol1 = F(K.res_sqrt) * iA1, tol2 = F(K.res_sqrt) * iA2;
+      F tolb[NBA];
+#pragma unroll
+      for (int b = 0; b < NB; b++) tolb[b] = F(K.res_sqrt) * iAb[b];
       int it = 0;
       bool more;
       auto sweep_and_test = [&]() {
-        const F s0 = l0, s1 = l1, s2 = l2, s3 = l3;
+        const F s0 = l0, s1 = l1, s2 = l2;
+        F sb[NBA];
+#pragma unroll
+        for (int b = 0; b < NB; b++) sb[b] = lb[b];
         pgs_sweep();
         it++;
         auto moved = (fabsf_(l0 - s0) > tol0) || (fabsf_(l1 - s1) > tol1) || (fabsf_(l2 - s2) > tol2);
-        if constexpr (knee) moved = moved || (fabsf_(l3 - s3) > tol3);
+#pragma unroll
+        for (int b = 0; b < NB; b++) moved = moved || (fabsf_(lb[b] - sb[b]) > tolb[b]);
         const auto live = c.robot_any(moved);
         iA0 = sel_(live, iA0, zero); iA1 = sel_(live, iA1, zero); iA2 = sel_(live, iA2, zero);
         k10 = sel_(live, k10, zero); k20 = sel_(live, k20, zero);
         c0 = sel_(live, c0, zero);
         mu = sel_(live, mu, F(1e30f));
-        if constexpr (knee) {
-          iA3 = sel_(live, iA3, zero); c3 = sel_(live, c3, zero);
-          k30 = sel_(live, k30, zero); k31 = sel_(live, k31, zero); k32 = sel_(live, k32, zero);
+#pragma unroll
+        for (int b = 0; b < NB; b++) {
+          iAb[b] = sel_(live, iAb[b], zero); cb[b] = sel_(live, cb[b], zero);
+#pragma unroll
+          for (int x = 0; x < 3 + b; x++) kbf[b][x] = sel_(live, kbf[b][x], zero);
         }
         more = c.wave_any(live) && it < K.iters;
       };
@@ -715,7 +756,8 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   c.phase(8);
   // ---- apply impulses: base via the Schur factor, leg via H^-1
   W zs = l0 * Z[0] + l1 * Z[1] + l2 * Z[2];
-  if constexpr (knee) zs = zs + l3 * Z[3];
+#pragma unroll
+  for (int b = 0; b < NB; b++) zs = zs + lb[b] * Z[3 + b];
   const W dbs = cmul(W{{c.qsum(zs.a.x), c.qsum(zs.a.y), c.qsum(zs.a.z)}, {c.qsum(zs.l.x), c.qsum(zs.l.y), c.qsum(zs.l.z)}}, sqv);
   F db[6] = {dbs.a.x, dbs.a.y, dbs.a.z, dbs.l.x, dbs.l.y, dbs.l.z};
   bwd6(s, db);
@@ -725,8 +767,9 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   L.qd[0] = qds1 + HJ[0][0] * l0 + HJ[1][0] * l1 + HJ[2][0] * l2 - dot(P1, dB);
   L.qd[1] = qds2 + HJ[0][1] * l0 + HJ[1][1] * l1 + HJ[2][1] * l2 - dot(P2, dB);
   L.qd[2] = qds3 + HJ[0][2] * l0 + HJ[1][2] * l1 + HJ[2][2] * l2 - dot(P3, dB);
-  if constexpr (knee) {
-    L.qd[0] = L.qd[0] + HJ[3][0] * l3; L.qd[1] = L.qd[1] + HJ[3][1] * l3; L.qd[2] = L.qd[2] + HJ[3][2] * l3;
+#pragma unroll
+  for (int b = 0; b < NB; b++) {
+    L.qd[0] = L.qd[0] + HJ[3 + b][0] * lb[b]; L.qd[1] = L.qd[1] + HJ[3 + b][1] * lb[b]; L.qd[2] = L.qd[2] + HJ[3 + b][2] * lb[b];
   }
   L.lam[0] = l0; L.lam[1] = l1; L.lam[2] = l2;
   L.contact = sel_(act && (l0 > zero), one, zero);

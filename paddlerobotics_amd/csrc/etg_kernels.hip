@@ -114,8 +114,9 @@ struct GpuCtx {
 };
 
 // FLAT selects the plane-z=0 fast path at compile time (contact frame = rows of R, no terrain lookup)
-template <bool FLAT, bool PLAIN = false, bool KNEE = false> struct GpuCtxT : GpuCtx {   // PLAIN, KNEE: see GpuCtx16T
-  static constexpr bool kFlat = FLAT; static constexpr bool kPlain = PLAIN; static constexpr bool kKnee = KNEE;
+// PLAIN: see GpuCtx16T.  BODY: body contact rows per leg compiled in (EtgConfig.body_contacts 1 / 2 -> 1, 3 -> 3)
+template <bool FLAT, bool PLAIN = false, int BODY = 0> struct GpuCtxT : GpuCtx {
+  static constexpr bool kFlat = FLAT; static constexpr bool kPlain = PLAIN; static constexpr int kBody = BODY;
 };
 
 // Workgroups are dealt round-robin to the 8 XCDs (block b -> XCD b % 8), each with its own L2.  Robots
@@ -211,9 +212,9 @@ __device__ __forceinline__ void settle_mark_fresh(const KCfg& K, const DevState&
   D.cache_off[K.n_env + env] = oy;
 }
 
-template <bool FLAT, bool PLAIN, bool KNEE = false>
+template <bool FLAT, bool PLAIN, int BODY = 0>
 __global__ void __launch_bounds__(BLOCK) k_settle(KCfg K, DevState D, const uint8_t* mask) {
-  GpuCtxT<FLAT, PLAIN, KNEE> c;
+  GpuCtxT<FLAT, PLAIN, BODY> c;
   if (!make_ctx(K, c)) return;
   if ((mask && !mask[c.env]) || settle_cached<FLAT>(K, D, c.env)) return;   // whole quads drop out together
   __shared__ float lds_par[PR_N * BLOCK];
@@ -253,9 +254,9 @@ __global__ void __launch_bounds__(256) k_cache_mark(KCfg K, DevState D, const ui
   D.cache_ok[env] = 1;
 }
 
-template <bool FLAT, bool PLAIN, bool KNEE = false>
+template <bool FLAT, bool PLAIN, int BODY = 0>
 __global__ void __launch_bounds__(BLOCK) k_finish(KCfg K, DevState D, const uint8_t* mask, float* obs) {
-  GpuCtxT<FLAT, PLAIN, KNEE> c;
+  GpuCtxT<FLAT, PLAIN, BODY> c;
   if (!make_ctx(K, c)) return;
   if (mask && !mask[c.env]) return;
   __shared__ float lds_par[PR_N * BLOCK];
@@ -313,10 +314,10 @@ __device__ __forceinline__ void restart_from_cache4(const Ctx& c, const KCfg& K,
 }
 
 // env.step for the 16 robots of a wave (one quad each); AUTO: see step16_body
-template <bool FLAT, bool PLAIN, bool AUTO, bool KNEE = false>
+template <bool FLAT, bool PLAIN, bool AUTO, int BODY = 0>
 __device__ __forceinline__ void step4_body(const KCfg& K, const DevState& D, const float* action, const uint8_t* donef, float* obs,
                                            float* reward, uint8_t* done, float* info, float* lds_par) {
-  GpuCtxT<FLAT, PLAIN, KNEE> c;
+  GpuCtxT<FLAT, PLAIN, BODY> c;
   if (!make_ctx(K, c)) return;
   stage_params(c, D, lds_par);
   LaneState<float> L = load_state<float>(c, D.base, D.leg);
@@ -360,23 +361,23 @@ __device__ __forceinline__ void step4_body(const KCfg& K, const DevState& D, con
     done[c.env] = d > 0.5f ? 1 : 0;
   }
 }
-template <bool FLAT, bool PLAIN, bool KNEE = false>
+template <bool FLAT, bool PLAIN, int BODY = 0>
 __global__ void __launch_bounds__(BLOCK) k_step(KCfg K, DevState D, const float* action, const uint8_t* donef, float* obs,
                                                  float* reward, uint8_t* done, float* info) {
   __shared__ float lds_par[PR_N * BLOCK];
-  step4_body<FLAT, PLAIN, false, KNEE>(K, D, action, donef, obs, reward, done, info, lds_par);
+  step4_body<FLAT, PLAIN, false, BODY>(K, D, action, donef, obs, reward, done, info, lds_par);
 }
-template <bool FLAT, bool PLAIN, bool KNEE = false>
+template <bool FLAT, bool PLAIN, int BODY = 0>
 __global__ void __launch_bounds__(BLOCK) k_step_ar(KCfg K, DevState D, const float* action, const uint8_t* donef, float* obs,
                                                     float* reward, uint8_t* done, float* info) {
   __shared__ float lds_par[PR_N * BLOCK];
-  step4_body<FLAT, PLAIN, true, KNEE>(K, D, action, donef, obs, reward, done, info, lds_par);
+  step4_body<FLAT, PLAIN, true, BODY>(K, D, action, donef, obs, reward, done, info, lds_par);
 }
 
 // n_steps open-loop control steps per launch (rollout_steps), the 4-lanes-per-robot counterpart of k_rollout16
-template <bool FLAT, bool PLAIN, bool KNEE = false>
+template <bool FLAT, bool PLAIN, int BODY = 0>
 __global__ void __launch_bounds__(BLOCK) k_rollout(KCfg K, DevState D, int n_steps, float* obs) {
-  GpuCtxT<FLAT, PLAIN, KNEE> c;
+  GpuCtxT<FLAT, PLAIN, BODY> c;
   if (!make_ctx(K, c)) return;
   __shared__ float lds_par[PR_N * BLOCK];
   stage_params(c, D, lds_par);
@@ -389,9 +390,9 @@ __global__ void __launch_bounds__(BLOCK) k_rollout(KCfg K, DevState D, int n_ste
 // dynamics-identification evaluator's 2 x 100 steps of known joint targets (Dynamic_parallel_model.py:53-77) and teacher
 // replays.  T: optional per-step outputs ([n_steps][N][...], null = not recorded).
 struct TapeOut { float *q, *imu, *obs, *rew; uint8_t* done; };
-template <bool FLAT, bool PLAIN, bool KNEE = false>
+template <bool FLAT, bool PLAIN, int BODY = 0>
 __global__ void __launch_bounds__(BLOCK) k_rollout_actions(KCfg K, DevState D, int n_steps, const float* actions, float* obs, TapeOut T) {
-  GpuCtxT<FLAT, PLAIN, KNEE> c;
+  GpuCtxT<FLAT, PLAIN, BODY> c;
   if (!make_ctx(K, c)) return;
   __shared__ float lds_par[PR_N * BLOCK];
   stage_params(c, D, lds_par);
@@ -914,7 +915,7 @@ __global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, Po
 // weight fragment fetched from L2 feeds two MFMAs, so the weight delivery per robot is half that of k_rollout_policy16, and a
 // workgroup does two such passes per control step.  Activations of the 32 rows of a pass, the 64 observation rows and the
 // actions stay in LDS; each wave then runs the control step of its 16 robots.  Same arithmetic per row as the 16-lane kernel.
-template <bool FLAT, bool BF16, bool PLAIN, bool KNEE = false>
+template <bool FLAT, bool BF16, bool PLAIN, int BODY = 0>
 __global__ void __launch_bounds__(256) k_rollout_policy4(KCfg K, DevState D, PolicyW P, int n_steps, float act_scale, float* obs) {
   using namespace pol;
   constexpr int NWP = 4, RT = 2, ROWS = 64;
@@ -926,7 +927,7 @@ __global__ void __launch_bounds__(256) k_rollout_policy4(KCfg K, DevState D, Pol
   __shared__ float lds_par[NWP][PR_N * 64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int tile = xcd_contiguous_block();            // 64 robots; the host guarantees N % 64 == 0
-  GpuCtxT<FLAT, PLAIN, KNEE> c;
+  GpuCtxT<FLAT, PLAIN, BODY> c;
   c.gid = tile * 256 + tid;
   c.N = K.n_env;
   c.NL = 4 * K.n_env;
@@ -1191,7 +1192,9 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   if (!(cfg->pd_latency >= 0)) return fail(ETG_ERR_BAD_ARG, "etg_create: pd_latency must be >= 0 seconds");
   if (cfg->settle_ticks < 0) return fail(ETG_ERR_BAD_ARG, "etg_create: settle_ticks must not be negative");
   if (cfg->motor_mode < 0 || cfg->motor_mode > 2) return fail(ETG_ERR_BAD_ARG, "etg_create: motor_mode must be 0 (POSITION), 1 (TORQUE) or 2 (HYBRID)");
-  if (cfg->body_contacts < 0 || cfg->body_contacts > 2) return fail(ETG_ERR_BAD_ARG, "etg_create: body_contacts must be 0, 1 or 2");
+  if (cfg->body_contacts < 0 || cfg->body_contacts > 3) return fail(ETG_ERR_BAD_ARG, "etg_create: body_contacts must be 0, 1, 2 or 3");
+  if (cfg->body_contacts == 3 && cfg->lanes_per_robot == 16)
+    return fail(ETG_ERR_BAD_ARG, "etg_create: body_contacts = 3 (three body rows per leg) needs the 4-lanes-per-robot mapping");
   if (cfg->terrain != 0 && cfg->terrain != 1) return fail(ETG_ERR_BAD_ARG, "etg_create: terrain must be 0 (plane) or 1 (heightfield)");
   if (cfg->terrain == 1 && (cfg->hf_nx < 2 || cfg->hf_ny < 2 || !(cfg->hf_cell > 0) || cfg->hf_bands < 0 ||
                             (cfg->hf_bands > 1 && cfg->hf_ny % cfg->hf_bands != 0)))
@@ -1222,6 +1225,7 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   // at a time: 16 lanes/robot fills it with 4096 robots and is faster per robot up to there; beyond
   // that the 4-lanes/robot kernel packs 4x the robots per wave (measured crossover).
   h->lanes = cfg->lanes_per_robot != 0 ? cfg->lanes_per_robot : (cfg->num_envs <= 4096 ? 16 : 4);
+  if (cfg->body_contacts == 3) h->lanes = 4;   // six rows per leg: the 16-lane mapping has one spare lane per leg
   size_t N = h->N, NL = 4 * N;
   struct { void** p; size_t bytes; } allocs[] = {
       {(void**)&h->D.base, BS_N * N * 4},   {(void**)&h->D.leg, LG_N * NL * 4},   {(void**)&h->D.ctl, CT_N * N * 4},
@@ -1289,12 +1293,14 @@ static inline void launch_obs_noise(EtgHandle* h, int n, const uint8_t* mask, fl
     else hipLaunchKernelGGL((KERN<false, false, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);                         \
   } while (0)
 
-// 4-lane kernels: {flat ground, heightfield} x {plain robot layer, all options, all options + body rows}
+// 4-lane kernels: {flat ground, heightfield} x {plain robot layer, all options, all options + 1 body row per leg, + 3 body rows}
 #define LAUNCH4(KERN, grid, stream, ...)                                                                              \
   do {                                                                                                                \
     const bool pl_ = plain_config(h->K);                                                                              \
-    if (h->K.knee && h->K.terrain == 0) hipLaunchKernelGGL((KERN<true, false, true>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);  \
-    else if (h->K.knee) hipLaunchKernelGGL((KERN<false, false, true>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);    \
+    if (h->K.knee == 3 && h->K.terrain == 0) hipLaunchKernelGGL((KERN<true, false, 3>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__); \
+    else if (h->K.knee == 3) hipLaunchKernelGGL((KERN<false, false, 3>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);  \
+    else if (h->K.knee && h->K.terrain == 0) hipLaunchKernelGGL((KERN<true, false, 1>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__); \
+    else if (h->K.knee) hipLaunchKernelGGL((KERN<false, false, 1>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);       \
     else if (h->K.terrain == 0 && pl_) hipLaunchKernelGGL((KERN<true, true>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);  \
     else if (h->K.terrain == 0) hipLaunchKernelGGL((KERN<true, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);   \
     else if (pl_) hipLaunchKernelGGL((KERN<false, true>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);                 \
@@ -1571,12 +1577,14 @@ extern "C" int etg_rollout_policy(EtgHandle* h, EtgPolicy* pol, int n_steps, flo
     if (precision == 0) hipLaunchKernelGGL((k_rollout_policy4<F_, false, P_, K_>), g4, b, 0, s, h->K, h->D, P, m, act_scale, obs); \
     else hipLaunchKernelGGL((k_rollout_policy4<F_, true, P_, K_>), g4, b, 0, s, h->K, h->D, P, m, act_scale, obs);    \
   } while (0)
-      if (h->K.knee && flat) LAUNCH_POLICY4(true, false, true);
-      else if (h->K.knee) LAUNCH_POLICY4(false, false, true);
-      else if (flat && pl) LAUNCH_POLICY4(true, true, false);
-      else if (flat) LAUNCH_POLICY4(true, false, false);
-      else if (pl) LAUNCH_POLICY4(false, true, false);
-      else LAUNCH_POLICY4(false, false, false);
+      if (h->K.knee == 3)   // (the closed-loop kernel is not instantiated with three body rows per leg: callers step instead)
+        return fail(ETG_ERR_STATE, "etg_rollout_policy: body_contacts = 3 is served by etg_step / etg_rollout_openloop / etg_rollout_actions");
+      if (h->K.knee && flat) LAUNCH_POLICY4(true, false, 1);
+      else if (h->K.knee) LAUNCH_POLICY4(false, false, 1);
+      else if (flat && pl) LAUNCH_POLICY4(true, true, 0);
+      else if (flat) LAUNCH_POLICY4(true, false, 0);
+      else if (pl) LAUNCH_POLICY4(false, true, 0);
+      else LAUNCH_POLICY4(false, false, 0);
 #undef LAUNCH_POLICY4
       launch_obs_noise(h, m, nullptr, obs, s);
     }

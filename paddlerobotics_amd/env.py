@@ -208,7 +208,8 @@ class BatchedQuadrupedEnv:
             lanes_per_robot=lanes_per_robot, motor_mode=motor_mode,
             clip_motor_commands=0.2 if enable_clip_motor_commands else 0.0,   # MAX_MOTOR_ANGLE_CHANGE_PER_STEP, a1.py
             # True / 1: knee spheres; 2 or "all": the deepest of knee, shin midpoint and trunk corner per leg
-            body_contacts=2 if body_contacts in (2, "all") else (1 if body_contacts else 0), knee_radius=knee_radius,
+            body_contacts=3 if body_contacts in (3, "simultaneous") else 2 if body_contacts in (2, "all") else (1 if body_contacts else 0),
+            knee_radius=knee_radius,
             enable_etg=1 if self.ETG else 0, joint_limits=1 if joint_limits else 0)
         self.model = A.default_model()
         if task == "balancebeam":
@@ -538,7 +539,8 @@ class BatchedQuadrupedEnv:
         # (the fused kernels never restart a finished robot: an auto_reset env takes the stepping loop, which does)
         ok = (self.num_envs % (16 if self.lanes_per_robot == 16 else 64) == 0 and self.motor_mode != 2 and contiguous
               and self._hist_T == 0 and not self._rand_force and policy.obs_dim == len(self._cols)
-              and policy.action_dim == A.NUM_MOTORS and not self.auto_reset)
+              and policy.action_dim == A.NUM_MOTORS and not self.auto_reset
+              and self.cfg.body_contacts != 3)   # (three body rows per leg: no closed-loop instantiation)
         if not ok:
             act = None
             for _ in range(int(n_steps)):

@@ -86,10 +86,10 @@ struct EmuCtxBase {
   }
 };
 
-template <bool FLAT, bool PLAIN = false, bool KNEE = false> struct EmuCtxT : EmuCtxBase {
+template <bool FLAT, bool PLAIN = false, int BODY = 0> struct EmuCtxT : EmuCtxBase {
   static constexpr bool kFlat = FLAT;
   static constexpr bool kPlain = PLAIN;
-  static constexpr bool kKnee = KNEE;
+  static constexpr int kBody = BODY;
   EmuCtxT(int e, int n, const float* p) { env = e; N = n; parp = p; }
 };
 typedef EmuCtxT<false> EmuCtx;   // generic-terrain instantiation; the flat fast path is EmuCtxT<true>
@@ -314,8 +314,10 @@ extern "C" void emu_reset(void* h, const uint8_t* mask, float* obs) {
       continue;
     }
     const bool pl4 = plain_config(e->K);                        // same choice as LAUNCH4 in etg_kernels.hip
-    if (e->K.knee && e->K.terrain == 0) emu_reset4<EmuCtxT<true, false, true>>(e, i, obs, ox, oy);
-    else if (e->K.knee) emu_reset4<EmuCtxT<false, false, true>>(e, i, obs, ox, oy);
+    if (e->K.knee == 3 && e->K.terrain == 0) emu_reset4<EmuCtxT<true, false, 3>>(e, i, obs, ox, oy);
+    else if (e->K.knee == 3) emu_reset4<EmuCtxT<false, false, 3>>(e, i, obs, ox, oy);
+    else if (e->K.knee && e->K.terrain == 0) emu_reset4<EmuCtxT<true, false, 1>>(e, i, obs, ox, oy);
+    else if (e->K.knee) emu_reset4<EmuCtxT<false, false, 1>>(e, i, obs, ox, oy);
     else if (e->K.terrain == 0 && pl4) emu_reset4<EmuCtxT<true, true>>(e, i, obs, ox, oy);
     else if (e->K.terrain == 0) emu_reset4<EmuCtxT<true>>(e, i, obs, ox, oy);
     else if (pl4) emu_reset4<EmuCtxT<false, true>>(e, i, obs, ox, oy);
@@ -352,8 +354,10 @@ extern "C" void emu_step(void* h, const float* action, const uint8_t* donef, flo
     F4 r, d;
     const F4 dn4(donef ? (float)donef[i] : 0.f);
     const bool pl4 = plain_config(e->K);
-    if (e->K.knee && e->K.terrain == 0) emu_step4<EmuCtxT<true, false, true>>(e, i, L, act, dn4, obs, r, d, info, hybrid ? hyb : nullptr);
-    else if (e->K.knee) emu_step4<EmuCtxT<false, false, true>>(e, i, L, act, dn4, obs, r, d, info, hybrid ? hyb : nullptr);
+    if (e->K.knee == 3 && e->K.terrain == 0) emu_step4<EmuCtxT<true, false, 3>>(e, i, L, act, dn4, obs, r, d, info, hybrid ? hyb : nullptr);
+    else if (e->K.knee == 3) emu_step4<EmuCtxT<false, false, 3>>(e, i, L, act, dn4, obs, r, d, info, hybrid ? hyb : nullptr);
+    else if (e->K.knee && e->K.terrain == 0) emu_step4<EmuCtxT<true, false, 1>>(e, i, L, act, dn4, obs, r, d, info, hybrid ? hyb : nullptr);
+    else if (e->K.knee) emu_step4<EmuCtxT<false, false, 1>>(e, i, L, act, dn4, obs, r, d, info, hybrid ? hyb : nullptr);
     else if (e->K.terrain == 0 && pl4) emu_step4<EmuCtxT<true, true>>(e, i, L, act, dn4, obs, r, d, info, hybrid ? hyb : nullptr);
     else if (e->K.terrain == 0) emu_step4<EmuCtxT<true>>(e, i, L, act, dn4, obs, r, d, info, hybrid ? hyb : nullptr);
     else if (pl4) emu_step4<EmuCtxT<false, true>>(e, i, L, act, dn4, obs, r, d, info, hybrid ? hyb : nullptr);

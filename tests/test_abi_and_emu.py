@@ -67,7 +67,8 @@ def test_create_validates_the_configuration_before_touching_a_device():
 
     for kw, word in ((dict(num_envs=0), "num_envs"), (dict(num_envs=-3), "num_envs"), (dict(num_envs=(1 << 20) + 1), "num_envs"),
                      (dict(action_repeat=0), "action_repeat"), (dict(sim_dt=0.0), "sim_dt"), (dict(solver_iters=0), "solver_iters"),
-                     (dict(settle_ticks=-1), "settle_ticks"), (dict(motor_mode=3), "motor_mode"), (dict(body_contacts=3), "body_contacts"),
+                     (dict(settle_ticks=-1), "settle_ticks"), (dict(motor_mode=3), "motor_mode"), (dict(body_contacts=4), "body_contacts"),
+                     (dict(body_contacts=3, lanes_per_robot=16), "4-lanes"),
                      (dict(terrain=2), "terrain"), (dict(terrain=1), "heightfield"), (dict(lanes_per_robot=8), "lanes_per_robot"),
                      (dict(etg_dt=0.0), "etg_dt")):
         rc, msg = create(**kw)

@@ -546,6 +546,64 @@ def test_trunk_and_shin_contacts_match_oracle(lanes):
         env.close()
 
 
+def test_simultaneous_body_rows_match_oracle():
+    """body_contacts = 3 on the GPU: knee, shin and trunk-corner spheres of every leg collide at once (k_*<flat, false, 3>: six
+    rows per lane, 6 x 6 Delassus blocks).  The folded-legs belly landing and the limp standing robot against the oracle's 24-row
+    system, flat ground and across a step edge; the setting selects the 4-lane mapping by itself, steps through env.step(),
+    the fused open-loop rollout and the action tape alike, and the closed-loop call falls back to stepping."""
+    from tests.test_terrain_and_randomisation import _folded_drop_state, _step_edge_heightfield
+    _need_gpu()
+    n = 64
+    for terrain in (0, 1):
+        hf = _step_edge_heightfield() if terrain else None
+        kw = dict(task="heightfield", heightfield=hf) if terrain else {}
+        env = _make(n, motor_control_mode="torque", body_contacts=3, solver_iters=4, joint_limits=False, **kw)
+        assert env.lanes_per_robot == 4 and env.cfg.body_contacts == 3
+        env.reset()
+        orc = _oracle(n, motor_mode=1, body_contacts=3, solver_iters=4, joint_limits=0, **(dict(terrain=1, heightfield=hf) if terrain else {}))
+        if terrain:
+            orc.set_heightfield(hf["heights"])
+        orc.reset()
+        st = _folded_drop_state(orc.get_state())
+        st[2:] = st[:2].repeat(n // 2 - 1, axis=0)
+        orc.set_state(st); env.set_state(torch.as_tensor(st, dtype=torch.float32, device="cuda:0"))
+        act = np.zeros((n, 12)); ta = torch.zeros(n, 12, device="cuda:0")
+        worst = 0.0
+        for k in range(30):
+            orc.step(act); env.step(ta)
+            so, se = orc.get_state(), env.get_state().double().cpu().numpy()
+            worst = max(worst, np.abs(so[:, 13:25] - se[:, 13:25]).max())
+            bound = (1e-4, 1e-5) if k < 12 else (1e-2, 1e-4)
+            assert np.abs(so[:, 13:25] - se[:, 13:25]).max() < bound[0] and np.abs(so[:, :3] - se[:, :3]).max() < bound[1], (terrain, k)
+        rest = 0.057 + 0.02
+        assert abs(se[0, 2] - rest) < 5e-4
+        _say("body_contacts=3 terrain %d: belly landing q err max over 30 steps %.2e, rest height %.4f" % (terrain, worst, se[0, 2]))
+        # the same 10 further steps through the fused rollout and through stepping
+        twin = _make(n, motor_control_mode="torque", body_contacts=3, solver_iters=4, joint_limits=False, **kw)
+        twin.reset(); twin.set_state(env.get_state())
+        env.rollout_openloop(10)
+        for _ in range(10):
+            twin.step(ta)
+        d = (env.get_state() - twin.get_state()).abs()   # two kernels, two code generations: fp32 rounding apart (limp legs amplify it)
+        assert d[:, :3].max().item() < 1e-5 and d[:, 13:25].max().item() < 1e-4
+        env.close(); twin.close()
+    # residual rule + 24 rows: limp standing robots never sink below the corner spheres, 40 steps, default solver
+    env = _make(n, motor_control_mode="torque", body_contacts="simultaneous", joint_limits=False)
+    env.reset()
+    low = torch.full((n,), 1.0, device="cuda:0")
+    for k in range(40):
+        env.step(torch.zeros(n, 12, device="cuda:0"))
+        low = torch.minimum(low, env.get_state()[:, 2])
+    assert low.min().item() > 0.077 - 2e-3 and torch.isfinite(env.get_state()).all()
+    pol, _ = _policy()
+    env.reset()
+    ret, ln = env.rollout_policy(pol, 5, 0.3)       # no closed-loop instantiation with three body rows: the stepping fallback
+    assert torch.isfinite(ret).all() and (ln >= 1).all()
+    env.close()
+    with pytest.raises(Exception):
+        _make(n, body_contacts=3, lanes_per_robot=16)
+
+
 def test_single_robot_surface_runs_the_reference_loops_verbatim(golden):
     """make_env(..., single=True): one robot behind the reference's numpy / scalar surface.  (1) the loop of env_test.py:47-54
     (reset, 600 x step(zeros(12), donef=False), collect info["ETG_act"]) reproduces the recorded gait rows; (2) the body of

@@ -344,6 +344,74 @@ def _step_edge_heightfield():
     return hf
 
 
+@pytest.mark.parametrize("terrain", [0, 1])
+def test_emulation_simultaneous_body_rows_match_oracle(terrain):
+    """body_contacts = 3: knee, shin-midpoint and trunk-corner spheres of every leg collide AT ONCE (three frictionless rows per
+    leg after its foot rows: 24 rows per robot in the oracle, six rows per lane with 6 x 6 Delassus blocks in the 4-lane kernel
+    source, which is the mapping that serves this setting).  (a) the folded-legs belly landing: kernel source == oracle, the
+    belly rests on the corner spheres; over 40 steps the trajectories stay closer than with the deepest-sphere row of
+    body_contacts = 2, whose choice of sphere flips between ticks; (b) the limp standing robot is caught at the same height;
+    (c) the two settings are different models (legs that rest on knee AND shin spheres end up elsewhere)."""
+    from oracle.oracle import OracleSim
+    from tests.emu.emu import EmuSim
+    n = 2
+    hf = _step_edge_heightfield() if terrain else None
+    rest = A.TRUNK_HALF[2] + 0.02
+    finals = {}
+    for bc in (2, 3):
+        cfg = A.default_config(n, solver_iters=4, motor_mode=1, body_contacts=bc, terrain=terrain, heightfield=hf, joint_limits=0)
+        orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=4)
+        for s in (orc, emu):
+            if terrain:
+                s.set_heightfield(hf["heights"])
+            s.reset()
+        st = _folded_drop_state(orc.get_state())
+        orc.set_state(st); emu.set_state(st)
+        act = np.zeros((n, 12))
+        for k in range(40):
+            orc.step(act); emu.step(act)
+            so, se = orc.get_state(), emu.get_state()
+            if bc == 3:
+                bound = (1e-4, 1e-5) if k < 12 else (1e-2, 1e-4)
+                assert np.abs(so[:, 13:25] - se[:, 13:25]).max() < bound[0] and np.abs(so[:, :3] - se[:, :3]).max() < bound[1], k
+        finals[bc] = so
+        assert abs(so[0, 2] - rest) < 5e-4
+    assert np.abs(finals[2][:, 13:25] - finals[3][:, 13:25]).max() > 0.05
+    # (b) limp standing robot
+    cfg = A.default_config(n, solver_iters=4, motor_mode=1, body_contacts=3, terrain=terrain, heightfield=hf, joint_limits=0)
+    orc, emu = OracleSim(cfg), EmuSim(cfg, lanes=4)
+    for s in (orc, emu):
+        if terrain:
+            s.set_heightfield(hf["heights"])
+        s.reset()
+    act = np.zeros((n, 12)); act[1, 1::3] = 2.0
+    low = np.full(n, 1.0)
+    for k in range(30):
+        orc.step(act); emu.step(act)
+        so, se = orc.get_state(), emu.get_state()
+        low = np.minimum(low, np.minimum(so[:, 2], se[:, 2]))
+        if k < 12:
+            assert np.abs(so[:, 13:25] - se[:, 13:25]).max() < 2e-4 and np.abs(so[:, :3] - se[:, :3]).max() < 1e-5, k
+    assert low.min() > rest - 2e-3 and np.abs(so[:, :3] - se[:, :3]).max() < 5e-3
+    # the residual stopping rule with 24 rows: a frozen robot does not move while its wave neighbours sweep on
+    cfg = A.default_config(n, motor_mode=1, body_contacts=3, terrain=terrain, heightfield=hf, joint_limits=0)
+    runs = []
+    for extra in (0, 3):
+        EmuSim.set_extra_sweeps(extra)
+        try:
+            emu = EmuSim(cfg, lanes=4)
+            if terrain:
+                emu.set_heightfield(hf["heights"])
+            emu.reset()
+            emu.set_state(_folded_drop_state(emu.get_state()))
+            for k in range(15):
+                emu.step(np.zeros((n, 12)))
+            runs.append(emu.get_state())
+        finally:
+            EmuSim.set_extra_sweeps(0)
+    assert np.array_equal(runs[0], runs[1])
+
+
 @pytest.mark.parametrize("lanes", [16, 4])
 @pytest.mark.parametrize("terrain", [0, 1])
 def test_emulation_trunk_and_shin_contacts_match_oracle(terrain, lanes):

@@ -114,7 +114,7 @@ BASELINE_KERNELS = (
     "_ZN3etg11k_rollout16ILb1ELb0ELb1EEEvNS_4KCfgENS_8DevStateEiPf",          # k_rollout16<flat, no body rows, plain>: the headline
     "_ZN3etg11k_rollout16ILb0ELb0ELb1EEEvNS_4KCfgENS_8DevStateEiPf",          # ... on the heightfield (configs[4])
     "_ZN3etg8k_step16ILb1ELb0ELb1EEEvNS_4KCfgENS_8DevStateEPKfPKhPfS7_PhS7_",  # k_step16<flat, plain>: env.step()
-    "_ZN3etg9k_rolloutILb1ELb1ELb0EEEvNS_4KCfgENS_8DevStateEiPf",                 # k_rollout<flat, plain>: the 4-lane mapping (> 4096 robots)
+    "_ZN3etg9k_rolloutILb1ELb1ELi0EEEvNS_4KCfgENS_8DevStateEiPf",                 # k_rollout<flat, plain>: the 4-lane mapping (> 4096 robots)
     "_ZN3etg18k_rollout_policy16ILb1ELb0ELb0ELb1EEEvNS_4KCfgENS_8DevStateENS_7PolicyWEifPf",   # closed loop (configs[2]), fp32 MFMA
 )
 
