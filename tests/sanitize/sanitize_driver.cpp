@@ -76,6 +76,7 @@ int main(int argc, char** argv) {
     emu_set_lanes(e4, 4);
     emu_set_lanes(e16, 16);
     const bool lanes4_ok = true;                        // (body rows: both mappings carry them)
+    const bool lanes16_ok = cfg.body_contacts != 3;     // three body rows per leg: the 4-lane mapping only
     etgo_set_params64(o64, dynd.data(), wd.data(), bd.data(), 0, nullptr);
     etgo_set_params32(o32, dynf.data(), w.data(), b.data(), 0, nullptr);
     emu_set_params(e4, dynf.data(), w.data(), b.data(), 0, nullptr);
@@ -87,7 +88,7 @@ int main(int argc, char** argv) {
     etgo_reset64(o64, nullptr, obsd.data(), 1);
     etgo_reset32(o32, nullptr, obsf.data(), 1);
     if (lanes4_ok) emu_reset(e4, nullptr, obsf.data());
-    emu_reset(e16, nullptr, obsf.data());
+    if (lanes16_ok) emu_reset(e16, nullptr, obsf.data());
     for (int k = 0; k < steps; k++) {
       for (size_t i = 0; i < actf.size(); i++) { actf[i] = (cfg.motor_mode == 1 ? 8.0f : 0.3f) * rnd(); actd[i] = actf[i]; }
       if (cfg.motor_mode == 2)
@@ -95,7 +96,7 @@ int main(int argc, char** argv) {
       etgo_step64(o64, actd.data(), nullptr, obsd.data(), rewd.data(), done.data(), infd.data(), 1);
       etgo_step32(o32, actf.data(), nullptr, obsf.data(), rewf.data(), done.data(), inff.data(), 1);
       if (lanes4_ok) emu_step(e4, actf.data(), nullptr, obsf.data(), rewf.data(), done.data(), inff.data());
-      emu_step(e16, actf.data(), nullptr, obsf.data(), rewf.data(), done.data(), inff.data());
+      if (lanes16_ok) emu_step(e16, actf.data(), nullptr, obsf.data(), rewf.data(), done.data(), inff.data());
     }
     etgo_destroy64(o64); etgo_destroy32(o32); emu_destroy(e4); emu_destroy(e16);
     std::printf("scenario %d ok (%d robots, %d steps)\n", s, n, steps);

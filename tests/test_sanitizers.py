@@ -23,6 +23,7 @@ def test_oracle_and_kernel_math_run_clean_under_asan_and_ubsan(tmp_path):
         (dict(terrain=1, heightfield=hf), 3),
         (dict(terrain=1, heightfield=hf, body_contacts=2, joint_limits=1, motor_mode=1), 3),
         (dict(body_contacts=1, friction_model=1), 2),
+        (dict(body_contacts=3, motor_mode=1, joint_limits=0), 3),
         (dict(motor_mode=2, enable_action_filter=True, enable_action_interp=True, torque_limit=30.0, clip_motor_commands=0.2), 2),
         (dict(enable_etg=0, solver_iters=2, solver_residual=1e-5), 2),
         (dict(pd_latency=0.0013), 2),
