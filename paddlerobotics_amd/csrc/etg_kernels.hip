@@ -608,8 +608,13 @@ template <bool FLAT, bool KNEE = false, bool PLAIN = false> struct GpuCtx16T : G
 };
 
 // robot_block = index of the group of 4 robots this wave carries, lane = lane in the wave, lds_wave = the wave's
-// own [LDS16_FIELDS][64] parameter staging area
-__device__ __forceinline__ bool make_ctx16_at(const KCfg& K, const DevState& D, GpuCtx16& c, float* lds_wave, int robot_block, int lane) {
+// own [LDS16_FIELDS][64] parameter staging area.  Three steps so that a caller can put its own loads between the staging
+// loads and the LDS writes that have to wait for them (step16_body: one HBM round trip at the head of the launch, not two).
+constexpr int kStaged16[] = {PR_O1, PR_O1 + 1, PR_O1 + 2, PR_SY, PR_LAT_N, PR_LAT_A, PR_BASE_FOOT, PR_BASE_FOOT + 1,
+                             PR_BASE_FOOT + 2, PR_POSE, PR_POSE + 1, PR_POSE + 2, PR_EMEAN, PR_EMEAN + 1, PR_EMEAN + 2,
+                             PR_ESTD, PR_ESTD + 1, PR_ESTD + 2, PR_HIPSIGN};
+constexpr int kNStaged16 = sizeof(kStaged16) / sizeof(int);
+__device__ __forceinline__ bool make_ctx16_fields(const KCfg& K, const DevState& D, GpuCtx16& c, float* lds_wave, int robot_block, int lane) {
   c.tid = lane;
   c.env = robot_block * 4 + (lane >> 4);
   c.r = lane & 15;
@@ -620,16 +625,26 @@ __device__ __forceinline__ bool make_ctx16_at(const KCfg& K, const DevState& D, 
   c.NL = 4 * K.n_env;
   if (c.env >= c.N) return false;   // whole rows drop out together, so every DPP/MFMA group stays complete
   c.col = (size_t)4 * c.env + c.leg;
-  // stage in LDS only the leg-level parameters that the once-per-step code reads (c.par / c.par_joint); the tick
-  // constants (gains, link block, gravity, trunk inertia, mu) go straight to registers through tpar*
-  float* mine = lds_wave + lane;
   c.gpar = D.par;
-  constexpr int kStaged[] = {PR_O1, PR_O1 + 1, PR_O1 + 2, PR_SY, PR_LAT_N, PR_LAT_A, PR_BASE_FOOT, PR_BASE_FOOT + 1,
-                             PR_BASE_FOOT + 2, PR_POSE, PR_POSE + 1, PR_POSE + 2, PR_EMEAN, PR_EMEAN + 1, PR_EMEAN + 2,
-                             PR_ESTD, PR_ESTD + 1, PR_ESTD + 2, PR_HIPSIGN};
+  c.lds = lds_wave + lane;
+  return true;
+}
+// stage in LDS only the leg-level parameters that the once-per-step code reads (c.par / c.par_joint); the tick
+// constants (gains, link block, gravity, trunk inertia, mu) go straight to registers through tpar*
+__device__ __forceinline__ void stage16_issue(const DevState& D, const GpuCtx16& c, float (&v)[kNStaged16]) {
 #pragma unroll
-  for (int k : kStaged) mine[k * 64] = D.par[(size_t)k * c.NL + c.col];
-  c.lds = mine;
+  for (int i = 0; i < kNStaged16; i++) v[i] = D.par[(size_t)kStaged16[i] * c.NL + c.col];
+}
+__device__ __forceinline__ void stage16_commit(const GpuCtx16& c, const float (&v)[kNStaged16]) {
+  float* mine = const_cast<float*>(c.lds);
+#pragma unroll
+  for (int i = 0; i < kNStaged16; i++) mine[kStaged16[i] * 64] = v[i];
+}
+__device__ __forceinline__ bool make_ctx16_at(const KCfg& K, const DevState& D, GpuCtx16& c, float* lds_wave, int robot_block, int lane) {
+  if (!make_ctx16_fields(K, D, c, lds_wave, robot_block, lane)) return false;
+  float v[kNStaged16];
+  stage16_issue(D, c, v);
+  stage16_commit(c, v);
   return true;
 }
 __device__ __forceinline__ bool make_ctx16(const KCfg& K, const DevState& D, GpuCtx16& c, float* lds_all) {
@@ -690,21 +705,31 @@ template <bool FLAT, bool KNEE, bool PLAIN, bool AUTO>
 __device__ __forceinline__ void step16_body(const KCfg& K, const DevState& D, const float* action, const uint8_t* donef, float* obs,
                                             float* reward, uint8_t* done, float* info, float* lds_par) {
   GpuCtx16T<FLAT, KNEE, PLAIN> c;
-  if (!make_ctx16(K, D, c, lds_par)) return;
+  if (!make_ctx16_fields(K, D, c, lds_par, xcd_contiguous_block(), threadIdx.x)) return;
+  // the head of a launch is a chain of cold loads (the L2s are invalidated at kernel boundaries): ALL of them -- staged
+  // parameters, state, control state, tick constants, action, done flag -- are requested before the first use, so the launch
+  // pays one HBM round trip here instead of one per group (the LDS writes of the staging used to wait in front of the rest)
+  float stg[kNStaged16];
+  stage16_issue(D, c, stg);
   State16<float> L = load_state16<float>(c, D.base, D.leg);
+  StepCtl16<float> S = load_ctl16<float>(c, K, D.ctl, D.ictl, D.legctl);
+  TickPar<float> tp = load_tick_par<float>(c);
+  if (!PLAIN && K.ext_force) tp.fext = load_fext16<float>(c, D.ctl);
   const bool hybrid = K.motor_mode == 2 && action;   // rows of 60: per motor (q_des, kp, qd_des, kd, tau_ff)
   float act = !action ? 0.0f : hybrid ? c.ld_row_motor(action, ETG_HYBRID_DIM, 5, 0) : c.ld_row_joint(action, ETG_ACT_DIM, 0);
   float hyb[4];
 #pragma unroll
   for (int k = 0; k < 4; k++) hyb[k] = hybrid ? c.ld_row_motor(action, ETG_HYBRID_DIM, 5, 1 + k) : 0.0f;
+  const float dflag = donef ? (float)donef[c.env] : 0.0f;
+  stage16_commit(c, stg);
   float r, d;
 #ifdef ETG_PROFILE_PHASES
   for (int k = 0; k < 16; k++) c.prof[k] = 0;
   c.prof_last = clock64();
   long long t_begin = c.prof_last;
 #endif
-  control_step16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, act, donef ? (float)donef[c.env] : 0.0f, obs, r, d, info,
-                 hybrid ? hyb : nullptr);
+  control_step16_core(c, K, tp, L, S, D.ring, D.etgp, act, dflag, obs, r, d, info, hybrid ? hyb : nullptr);
+  store_ctl16(c, K, S, D.ctl, D.ictl, D.legctl);
   if (AUTO && d > 0.5f) {   // whole 16-lane rows take this branch together (d is the robot's)
     const int N = K.n_env;
     L = load_state16<float>(c, D.cache_base, D.cache_leg);
