@@ -14,10 +14,13 @@ opts = [dict(), dict(motor_control_mode="torque"), dict(motor_control_mode="hybr
         # round 2: joint-limit stops, no trajectory generator, the optional sensors, auto-reset inside the step launch
         dict(joint_limits=True), dict(joint_limits=True, body_contacts=True, motor_control_mode="torque"), dict(ETG=0),
         dict(sensor_mode={"ETG_obs": 1, "footpose": 1, "dynamic_vec": 1, "force_vec": 1, "noise": 1}),
-        dict(body_contacts=2), dict(auto_reset=True), dict(auto_reset=True, joint_limits=True, random_param={"random_force": 1})]
+        dict(body_contacts=2), dict(auto_reset=True), dict(auto_reset=True, joint_limits=True, random_param={"random_force": 1}),
+        # round 3: all body spheres at once (4-lane kernels), pyramid friction, pd latency, the solver with a fixed count
+        dict(body_contacts=3), dict(body_contacts=3, motor_control_mode="torque"), dict(friction_model=1), dict(pd_latency=0.001),
+        dict(solver_iters=3), dict(body_contacts=2, friction_model=1, auto_reset=True)]
 for lanes, task, o in itertools.product((16, 4), ("ground", "stairstair"), opts):
-    if o.get("body_contacts") and lanes == 4:
-        continue
+    if o.get("body_contacts") == 3 and lanes == 16:
+        continue   # three body rows per leg: the 4-lane mapping only
     env = make_env("Quadrupedal", num_envs=N, device="cuda:0", lanes_per_robot=lanes, task=task, seed=3, **o)
     g = torch.Generator(device="cuda:0"); g.manual_seed(1)
     obs, _ = env.reset(x_noise=1)
