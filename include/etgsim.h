@@ -259,6 +259,19 @@ int etg_step(EtgHandle* h, const float* action, const uint8_t* donef, float* obs
  * heightfield start offsets change) step and restart are ONE launch; otherwise etg_step + etg_reset(mask = done).  */
 int etg_step_autoreset(EtgHandle* h, const float* action, const uint8_t* donef, float* obs,
                        float* reward, uint8_t* done, float* info, void* stream);
+/* Dynamics randomisation per EPISODE without a settle per control step (random_param["random_dynamics"], train.py:253: a new
+ * draw of the 48 dynamic parameters at every reset).  A reset with new parameters needs a simulated settle (settle_ticks
+ * ticks: tens of control steps' worth of time, whatever the number of robots), and with thousands of robots some episode
+ * ends on nearly every step.  etg_prepare_next_dynamics derives the rows dyn [N,48] (device; rows of robots outside `mask`
+ * are ignored, NULL = all) for the robots' NEXT episodes and runs their settle NOW, in one launch, on scratch state -- the
+ * robots keep running on their current parameters.  The settled state replaces the robot's settle cache; the rows are
+ * installed when the robot's episode ends inside etg_step_autoreset (same launch as the step, as before) or at its next
+ * etg_reset.  A robot whose episode ends again before the next call starts over with the same rows.  Needs a full etg_reset
+ * before (every robot with a cached settle); etg_set_params with new dynamics for a robot drops its pending rows.
+ * etg_next_dynamics_pending copies the pending flags (1 = rows still waiting) to pending [N] bytes (device): the robots with 0
+ * are the ones to draw new rows for.                                                                                   */
+int etg_prepare_next_dynamics(EtgHandle* h, const float* dyn, const uint8_t* mask, void* stream);
+int etg_next_dynamics_pending(EtgHandle* h, uint8_t* pending, void* stream);
 /* per-robot episode statistics since the robot's last reset: return (sum of
  * rewards) and length (steps), both frozen after the first `done` (alive
  * masking; the batched counterpart of train.py:213-249 / pretrain.py:129-154).

@@ -250,6 +250,8 @@ int etg_policy_sample(EtgPolicy*, const float*, int, const float*, float, int, f
 void etg_policy_destroy(EtgPolicy*) {}
 int etg_rollout_policy(EtgHandle*, EtgPolicy*, int, float, int, int, float*, float*, int32_t*, void*) { CPU_UNAVAILABLE("etg_rollout_policy"); }
 int etg_rollout_actions(EtgHandle*, const float*, int, float*, float*, float*, float*, float*, uint8_t*, float*, int32_t*, void*) { CPU_UNAVAILABLE("etg_rollout_actions"); }
+int etg_prepare_next_dynamics(EtgHandle*, const float*, const uint8_t*, void*) { CPU_UNAVAILABLE("etg_prepare_next_dynamics"); }
+int etg_next_dynamics_pending(EtgHandle*, uint8_t*, void*) { CPU_UNAVAILABLE("etg_next_dynamics_pending"); }
 int etg_rollout_policy_record(EtgHandle*, EtgPolicy*, int, float, int, int, float*, const float*, float*, float*, float*, uint8_t*, float*, int32_t*, void*) { CPU_UNAVAILABLE("etg_rollout_policy_record"); }
 int etg_fit_etg(const double*, int, const double*, const double*, double, double, double, double, double, int, double*, double*, void*) { CPU_UNAVAILABLE("etg_fit_etg"); }
 

@@ -17,6 +17,7 @@ SYMBOLS = [
     "etg_set_state", "etg_policy_create", "etg_policy_load", "etg_policy_forward", "etg_policy_load_std", "etg_policy_sample",
     "etg_policy_destroy", "etg_rollout_policy", "etg_fit_etg", "etg_leg_kinematics", "etg_extra_sensors", "etg_step_autoreset",
     "etg_replay_begin", "etg_replay_end", "etg_rollout_policy_record", "etg_rollout_actions",
+    "etg_prepare_next_dynamics", "etg_next_dynamics_pending",
 ]
 
 
@@ -70,6 +71,8 @@ def load():
     lib.etg_rollout_policy.argtypes = [vp, vp, i32, C.c_float, i32, i32, vp, vp, vp, vp]
     lib.etg_rollout_policy_record.argtypes = [vp, vp, i32, C.c_float, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
     lib.etg_rollout_actions.argtypes = [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.etg_prepare_next_dynamics.argtypes = [vp, vp, vp, vp]
+    lib.etg_next_dynamics_pending.argtypes = [vp, vp, vp]
     lib.etg_policy_destroy.restype = None
     dbl = C.c_double
     lib.etg_fit_etg.argtypes = [vp, i32, vp, vp, dbl, dbl, dbl, dbl, dbl, i32, vp, vp, vp]

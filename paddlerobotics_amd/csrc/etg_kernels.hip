@@ -140,6 +140,28 @@ __device__ __forceinline__ bool make_ctx(const KCfg& K, GpuCtx& c) {
 
 constexpr int BLOCK = 64;
 
+// Parameters waiting for a robot's NEXT episode (etg_prepare_next_dynamics): the derived per-leg rows, the dynamic_param row and a
+// pending flag per robot.  The settle that belongs to them already sits in the robot's settle cache; the restart inside
+// etg_step_autoreset (or the next etg_reset of the robot) installs the rows.  All null when the feature is unused.
+struct NextDyn { float* par; float* dyn; unsigned char* ok; };
+// install the pending rows of the masked robots (a reset of theirs is about to use the settle cache that belongs to the rows)
+__global__ void __launch_bounds__(256) k_next_take(KCfg K, DevState D, NextDyn NX, const uint8_t* mask) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = K.n_env, NL = 4 * N;
+  if (col >= NL) return;
+  const int env = col >> 2;
+  if ((mask && !mask[env]) || !NX.ok[env]) return;
+  for (int k = 0; k < PR_N; k++) D.par[(size_t)k * NL + col] = NX.par[(size_t)k * NL + col];
+  for (int k = col & 3; k < ETG_DYN_DIM; k += 4) D.dyn[(size_t)env * ETG_DYN_DIM + k] = NX.dyn[(size_t)env * ETG_DYN_DIM + k];
+}
+// ok[env] = value for the masked robots; scratch flags start as "not cached" so that the settle runs for them
+__global__ void __launch_bounds__(256) k_next_flags(KCfg K, unsigned char* ok, const uint8_t* mask, unsigned char value) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= K.n_env || (mask && !mask[env])) return;
+  ok[env] = value;
+}
+
+
 // Stage the lane's 66 derived parameters in LDS, [field][lane] (conflict-free: lane i hits
 // bank i).  Each lane reads back only its own column, so no barrier is needed -- the LDS
 // is a software-managed register file extension here, not a sharing medium.
@@ -316,7 +338,7 @@ __device__ __forceinline__ void restart_from_cache4(const Ctx& c, const KCfg& K,
 // env.step for the 16 robots of a wave (one quad each); AUTO: see step16_body
 template <bool FLAT, bool PLAIN, bool AUTO, int BODY = 0>
 __device__ __forceinline__ void step4_body(const KCfg& K, const DevState& D, const float* action, const uint8_t* donef, float* obs,
-                                           float* reward, uint8_t* done, float* info, float* lds_par) {
+                                           float* reward, uint8_t* done, float* info, float* lds_par, const NextDyn NX = NextDyn{nullptr, nullptr, nullptr}) {
   GpuCtxT<FLAT, PLAIN, BODY> c;
   if (!make_ctx(K, c)) return;
   stage_params(c, D, lds_par);
@@ -339,6 +361,14 @@ __device__ __forceinline__ void step4_body(const KCfg& K, const DevState& D, con
                info, hybrid ? hyb : nullptr);
   if (AUTO && d > 0.5f) {   // whole quads take this branch together
     const int N = K.n_env;
+    if (NX.ok && NX.ok[c.env]) {   // parameters prepared for the next episode: install them (the cached settle below is theirs)
+      for (int k = 0; k < PR_N; k++) D.par[(size_t)k * c.NL + c.gid] = NX.par[(size_t)k * c.NL + c.gid];
+      for (int k = c.lane; k < ETG_DYN_DIM; k += 4) D.dyn[(size_t)c.env * ETG_DYN_DIM + k] = NX.dyn[(size_t)c.env * ETG_DYN_DIM + k];
+      __builtin_amdgcn_s_waitcnt(0);          // the quad's reads of the flag are done before its lane 0 clears it
+      __builtin_amdgcn_wave_barrier();
+      if (c.lane == 0) NX.ok[c.env] = 0;
+      stage_params(c, D, lds_par);            // the restart below reads the staged leg parameters: the new ones
+    }
     L = load_state<float>(c, D.cache_base, D.cache_leg);
     L.p.x += D.reset_off[c.env] - D.cache_off[c.env];
     L.p.y += D.reset_off[N + c.env] - D.cache_off[N + c.env];
@@ -369,9 +399,9 @@ __global__ void __launch_bounds__(BLOCK) k_step(KCfg K, DevState D, const float*
 }
 template <bool FLAT, bool PLAIN, int BODY = 0>
 __global__ void __launch_bounds__(BLOCK) k_step_ar(KCfg K, DevState D, const float* action, const uint8_t* donef, float* obs,
-                                                    float* reward, uint8_t* done, float* info) {
+                                                    float* reward, uint8_t* done, float* info, NextDyn NX) {
   __shared__ float lds_par[PR_N * BLOCK];
-  step4_body<FLAT, PLAIN, true, BODY>(K, D, action, donef, obs, reward, done, info, lds_par);
+  step4_body<FLAT, PLAIN, true, BODY>(K, D, action, donef, obs, reward, done, info, lds_par, NX);
 }
 
 // n_steps open-loop control steps per launch (rollout_steps), the 4-lanes-per-robot counterpart of k_rollout16
@@ -703,7 +733,7 @@ __global__ void __launch_bounds__(BLOCK) k_finish16(KCfg K, DevState D, const ui
 // cleared.  reward / done / info stay the finished step's.
 template <bool FLAT, bool KNEE, bool PLAIN, bool AUTO>
 __device__ __forceinline__ void step16_body(const KCfg& K, const DevState& D, const float* action, const uint8_t* donef, float* obs,
-                                            float* reward, uint8_t* done, float* info, float* lds_par) {
+                                            float* reward, uint8_t* done, float* info, float* lds_par, const NextDyn NX = NextDyn{nullptr, nullptr, nullptr}) {
   GpuCtx16T<FLAT, KNEE, PLAIN> c;
   if (!make_ctx16_fields(K, D, c, lds_par, xcd_contiguous_block(), threadIdx.x)) return;
   // the head of a launch is a chain of cold loads (the L2s are invalidated at kernel boundaries): ALL of them -- staged
@@ -732,6 +762,16 @@ __device__ __forceinline__ void step16_body(const KCfg& K, const DevState& D, co
   store_ctl16(c, K, S, D.ctl, D.ictl, D.legctl);
   if (AUTO && d > 0.5f) {   // whole 16-lane rows take this branch together (d is the robot's)
     const int N = K.n_env;
+    if (NX.ok && NX.ok[c.env]) {   // parameters prepared for the next episode: install them (the cached settle below is theirs)
+      for (int k = c.sub; k < PR_N; k += 4) D.par[(size_t)k * c.NL + c.col] = NX.par[(size_t)k * c.NL + c.col];   // a leg's 4 lanes share its column
+      for (int k = c.r; k < ETG_DYN_DIM; k += 16) D.dyn[(size_t)c.env * ETG_DYN_DIM + k] = NX.dyn[(size_t)c.env * ETG_DYN_DIM + k];
+      __builtin_amdgcn_s_waitcnt(0);          // the row's reads of the flag and its stores are done before lane 0 clears it
+      __builtin_amdgcn_wave_barrier();
+      if (c.r == 0) NX.ok[c.env] = 0;
+      float stg2[kNStaged16];                 // the restart below reads the staged leg parameters: the new ones
+      stage16_issue(D, c, stg2);
+      stage16_commit(c, stg2);
+    }
     L = load_state16<float>(c, D.cache_base, D.cache_leg);
     L.p.x += D.reset_off[c.env] - D.cache_off[c.env];        // non-zero only on flat ground (settle_cached)
     L.p.y += D.reset_off[N + c.env] - D.cache_off[N + c.env];
@@ -762,9 +802,9 @@ __global__ void __launch_bounds__(BLOCK) k_step16(KCfg K, DevState D, const floa
 }
 template <bool FLAT, bool KNEE, bool PLAIN>
 __global__ void __launch_bounds__(BLOCK) k_step16_ar(KCfg K, DevState D, const float* action, const uint8_t* donef, float* obs,
-                                                      float* reward, uint8_t* done, float* info) {
+                                                      float* reward, uint8_t* done, float* info, NextDyn NX) {
   __shared__ float lds_par[LDS16_FIELDS * BLOCK];
-  step16_body<FLAT, KNEE, PLAIN, true>(K, D, action, donef, obs, reward, done, info, lds_par);
+  step16_body<FLAT, KNEE, PLAIN, true>(K, D, action, donef, obs, reward, done, info, lds_par, NX);
 }
 
 // n_steps open-loop control steps of every robot in one launch (rollout_steps16): state, control variables and
@@ -1185,6 +1225,10 @@ struct EtgHandle {
                                   // terrain or -- on a heightfield -- start offsets change): etg_step_autoreset's fast path
   float *tmp_obs, *tmp_reward;  // sinks for etg_rollout_openloop
   uint8_t* tmp_done;
+  // etg_prepare_next_dynamics: rows waiting for the robots' next episodes + the scratch state / ring / flags its settle runs on
+  NextDyn NX;
+  float *nx_base, *nx_leg, *nx_ring;
+  unsigned char* nx_cache_ok;
 };
 
 static thread_local std::string g_err;
@@ -1246,6 +1290,9 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   h->was_reset = false;
   h->fext_set = h->push_on = false;
   h->all_cached = false;
+  h->NX = NextDyn{nullptr, nullptr, nullptr};
+  h->nx_base = h->nx_leg = h->nx_ring = nullptr;
+  h->nx_cache_ok = nullptr;
   // 0 = auto.  Both kernels hold one wave per SIMD (register footprint), so the chip runs 1024 waves
   // at a time: 16 lanes/robot fills it with 4096 robots and is faster per robot up to there; beyond
   // that the 4-lanes/robot kernel packs 4x the robots per wave (measured crossover).
@@ -1287,7 +1334,7 @@ extern "C" void etg_destroy(EtgHandle* h) {
   (void)hipSetDevice(h->device);
   void* ptrs[] = {h->D.base, h->D.leg, h->D.ctl, h->D.ictl, h->D.legctl, h->D.etgp, h->D.par, h->D.ring, h->hf, h->D.dyn,
                   h->D.cache_base, h->D.cache_leg, h->D.cache_ring, h->D.cache_ok, h->D.reset_off, h->D.cache_off,
-                  h->tmp_obs, h->tmp_reward, h->tmp_done};
+                  h->tmp_obs, h->tmp_reward, h->tmp_done, h->NX.par, h->NX.dyn, h->NX.ok, h->nx_base, h->nx_leg, h->nx_ring, h->nx_cache_ok};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   delete h;
@@ -1341,6 +1388,8 @@ extern "C" int etg_set_params(EtgHandle* h, const float* dyn, const float* etg_w
   CHECK_HANDLE(h);
   if ((etg_w == nullptr) != (etg_b == nullptr)) return fail(ETG_ERR_BAD_ARG, "etg_set_params: pass both etg_w and etg_b or neither");
   if (dyn) h->all_cached = false;   // the settle depends on the dynamic parameters
+  if (dyn && h->NX.ok)              // (and rows prepared for the masked robots' next episodes came with a settle of their own)
+    hipLaunchKernelGGL(k_next_flags, dim3((h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->NX.ok, mask, (unsigned char)0);
   hipLaunchKernelGGL(k_fin_clear, dim3((h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->D, mask);   // cached restarts: stale
   hipLaunchKernelGGL(k_set_params, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->M, h->D, dyn, etg_w,
                      etg_b, per_env, mask);
@@ -1396,12 +1445,64 @@ extern "C" int etg_clear_pushes(EtgHandle* h, const uint8_t* mask, void* stream)
   return ETG_OK;
 }
 
+// ---- parameters for the NEXT episode (etg_prepare_next_dynamics)
+extern "C" int etg_prepare_next_dynamics(EtgHandle* h, const float* dyn, const uint8_t* mask, void* stream) {
+  CHECK_HANDLE(h);
+  if (!dyn) return fail(ETG_ERR_BAD_ARG, "etg_prepare_next_dynamics: dyn is null");
+  if (!h->was_reset || !h->all_cached)
+    return fail(ETG_ERR_STATE, "etg_prepare_next_dynamics: needs a full etg_reset first (every robot with a valid cached settle)");
+  const size_t N = h->N, NL = 4 * N;
+  if (!h->NX.par) {
+    struct { void** p; size_t bytes; } allocs[] = {
+        {(void**)&h->NX.par, PR_N * NL * 4}, {(void**)&h->NX.dyn, ETG_DYN_DIM * N * 4}, {(void**)&h->NX.ok, N},
+        {(void**)&h->nx_base, BS_N * N * 4}, {(void**)&h->nx_leg, LG_N * NL * 4}, {(void**)&h->nx_ring, (size_t)RING * 8 * NL * 4},
+        {(void**)&h->nx_cache_ok, N}};
+    for (auto& a : allocs) {
+      if (hipMalloc(a.p, a.bytes) != hipSuccess) return fail(ETG_ERR_ALLOC, "etg_prepare_next_dynamics: hipMalloc failed");
+      HIP_TRY(hipMemsetAsync(*a.p, 0, a.bytes, (hipStream_t)stream));
+    }
+  }
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 ge((h->N + 255) / 256), gc((4 * h->N + 255) / 256), g16((h->N + 3) / 4), g4(grid_for(h));
+  // a view of the robot arrays whose parameters are the NEXT rows, whose live state / ring are scratch (the robots keep running
+  // on theirs) and whose settle cache is the real one: k_settle* leaves the settled state of the new rows in the cache
+  DevState Dn = h->D;
+  Dn.par = h->NX.par;
+  Dn.dyn = h->NX.dyn;
+  Dn.base = h->nx_base; Dn.leg = h->nx_leg; Dn.ring = h->nx_ring;
+  Dn.cache_ok = h->nx_cache_ok;
+  hipLaunchKernelGGL(k_set_params, dim3(grid_for(h)), dim3(BLOCK), 0, s, h->K, h->M, Dn, dyn, (const float*)nullptr,
+                     (const float*)nullptr, 0, mask);   // (derives the rows; clears the scratch "cached" flag of the masked robots)
+  if (h->lanes == 16) {
+    LAUNCH16(k_settle16, g16, s, h->K, Dn, mask);
+  } else {
+    LAUNCH4(k_settle, g4, s, h->K, Dn, mask);
+  }
+  hipLaunchKernelGGL(k_cache_sync, gc, dim3(256), 0, s, h->K, Dn, mask);      // scratch ring -> the cache's ring
+  hipLaunchKernelGGL(k_fin_clear, ge, dim3(256), 0, s, h->K, h->D, mask);     // cached first observations: stale
+  hipLaunchKernelGGL(k_next_flags, ge, dim3(256), 0, s, h->K, h->NX.ok, mask, (unsigned char)1);
+  HIP_TRY(hipGetLastError());
+  return ETG_OK;
+}
+
+extern "C" int etg_next_dynamics_pending(EtgHandle* h, uint8_t* pending, void* stream) {
+  CHECK_HANDLE(h);
+  if (!pending) return fail(ETG_ERR_BAD_ARG, "etg_next_dynamics_pending: pending is null");
+  if (!h->NX.ok) { HIP_TRY(hipMemsetAsync(pending, 0, h->N, (hipStream_t)stream)); return ETG_OK; }
+  HIP_TRY(hipMemcpyAsync(pending, h->NX.ok, h->N, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return ETG_OK;
+}
+
 extern "C" int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* stream) {
   CHECK_HANDLE(h);
   if (!obs) return fail(ETG_ERR_BAD_ARG, "etg_reset: obs is null");
   if (h->K.terrain == 1 && !h->K.hf) return fail(ETG_ERR_STATE, "etg_reset: heightfield not set");
   h->was_reset = true;
   advance_obs_stream(h, 1);
+  if (h->NX.ok) {   // rows prepared for the next episode of the masked robots: this reset starts it
+    hipLaunchKernelGGL(k_next_take, dim3((4 * h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->D, h->NX, mask);
+    hipLaunchKernelGGL(k_next_flags, dim3((h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->NX.ok, mask, (unsigned char)0);
+  }
   // 1. settle the masked robots that have no valid settle cache (kernel exits at once for the others)
   // 2. snapshot their ring / restore state + ring of the cached ones, mark everything masked as cached
   // 3. the part after the settle: control state, episode accumulators, first observation
@@ -1491,9 +1592,9 @@ extern "C" int etg_step_autoreset(EtgHandle* h, const float* action, const uint8
   advance_obs_stream(h, 2);                     // two rows per robot at most: the step's (position c) and the reset's (c + 1)
   hipStream_t s = (hipStream_t)stream;
   if (h->lanes == 16) {
-    LAUNCH16(k_step16_ar, dim3((h->N + 3) / 4), s, h->K, h->D, action, donef, obs, reward, done, info);
+    LAUNCH16(k_step16_ar, dim3((h->N + 3) / 4), s, h->K, h->D, action, donef, obs, reward, done, info, h->NX);
   } else {
-    LAUNCH4(k_step_ar, dim3(grid_for(h)), s, h->K, h->D, action, donef, obs, reward, done, info);
+    LAUNCH4(k_step_ar, dim3(grid_for(h)), s, h->K, h->D, action, donef, obs, reward, done, info, h->NX);
   }
   launch_obs_noise(h, 2, done, obs, s, /*invert=*/1, /*back=*/1);   // the step's rows of the robots that go on
   launch_obs_noise(h, 2, done, obs, s);                            // the reset rows

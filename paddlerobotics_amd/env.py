@@ -146,7 +146,7 @@ class BatchedQuadrupedEnv:
                  random_dynamics_scale=0.3, random_force_prob=0.02, random_force_steps=8,
                  random_force_range=(5.0, 25.0), seed=0, enable_clip_motor_commands=False,
                  observation_noise_stdev=None, body_contacts=False, knee_radius=0.02, joint_limits=True,
-                 auto_reset=False, **unused):
+                 auto_reset=False, random_dynamics_refresh=256, **unused):
         if render:
             raise ValueError("render is not supported by the batched GPU simulator")
         if int(ETG_H) != A.RBF_H:
@@ -192,6 +192,11 @@ class BatchedQuadrupedEnv:
         self._rand_dyn = bool(rp.get("random_dynamics", 0))
         self._rand_force = bool(rp.get("random_force", 0))
         self._rand_dyn_scale = float(random_dynamics_scale)
+        # random_dynamics under auto_reset: the rows of the robots' NEXT episodes are drawn and settled every this many control
+        # steps in one launch (etg_prepare_next_dynamics) instead of one settle launch per control step; <= 1: a fresh draw at
+        # every single reset, through the masked-reset path (exact, ~70x slower at 4096 robots)
+        self._nx_refresh = int(random_dynamics_refresh)
+        self._nx_on, self._nx_count, self._nx_pending = False, 0, None
         self._rf_prob, self._rf_steps, self._rf_range = float(random_force_prob), int(random_force_steps), random_force_range
         self.num_envs = int(num_envs)
         self.device = torch.device(device)
@@ -381,9 +386,39 @@ class BatchedQuadrupedEnv:
         if self._rand_force:
             _lib.check(self._lib.etg_clear_pushes(self._h, _ptr(m), self._stream()))
         _lib.check(self._lib.etg_reset(self._h, _ptr(m), _ptr(self.obs), self._stream()))
+        if self._rand_dyn and self.auto_reset and self._nx_refresh > 1 and env_ids is None and dynamic_param is None:
+            self._nx_on = self._prepare_next_dynamics(None)
+            self._nx_count = 0
         info = {"ETG_act": None}
         self._last_view = self._obs_view(reset_mask=m, first=True)
         return self._last_view, info
+
+    def _draw_dynamics_rows(self):
+        """param2dynamic_dict(U(-1,1) * scale) rows for all robots (train.py:112-126, 253), drawn on the device"""
+        p = (torch.rand(self.num_envs, A.DYN_DIM, device=self.device, generator=self._dyn_gen) * 2 - 1) * self._rand_dyn_scale
+        return A.param2dynamic_rows_torch(p).to(torch.float32).contiguous()
+
+    def _prepare_next_dynamics(self, mask):
+        """draw + settle the dynamics of the NEXT episodes of the masked robots (uint8 [N] device tensor, None = all);
+        False when the library cannot (not every robot has a cached settle, e.g. a heightfield with start jitter)"""
+        rows = self._draw_dynamics_rows()
+        rc = self._lib.etg_prepare_next_dynamics(self._h, _ptr(rows), _ptr(mask), self._stream())
+        self._nx_rows = rows      # keep the buffer alive until the stream has consumed it
+        return rc == 0
+
+    def _refresh_next_dynamics(self):
+        """every random_dynamics_refresh control steps: the robots whose prepared rows were consumed by a restart get new ones"""
+        self._nx_count += 1
+        if self._nx_count < self._nx_refresh:
+            return
+        self._nx_count = 0
+        if self._nx_pending is None:
+            self._nx_pending = torch.empty(self.num_envs, dtype=torch.uint8, device=self.device)
+        _lib.check(self._lib.etg_next_dynamics_pending(self._h, _ptr(self._nx_pending), self._stream()))
+        consumed = (self._nx_pending == 0).to(torch.uint8)
+        self._nx_mask = consumed
+        if not self._prepare_next_dynamics(consumed):
+            self._nx_on = False
 
     def _obs_view(self, reset_mask=None, first=False):
         """the observation the caller sees: sensor_mode column selection, then (optionally) the history stack.
@@ -489,7 +524,7 @@ class BatchedQuadrupedEnv:
         # state, first observation): their rows of `obs` are the reset observation, reward / done / info are the finished
         # step's, info["reset"] (= done) marks them.  The done bytes are read on the device: no host synchronisation.
         # With random_dynamics the reset robots first draw new parameters, which needs the masked calls of reset().
-        fused_reset = self.auto_reset and not self._rand_dyn
+        fused_reset = self.auto_reset and (not self._rand_dyn or self._nx_on)   # (_nx_on: the next episodes' dynamics are prepared)
         step_fn = self._lib.etg_step_autoreset if fused_reset else self._lib.etg_step
         _lib.check(step_fn(self._h, _ptr(a), _ptr(df), _ptr(self.obs), _ptr(self.reward), _ptr(self.done),
                            _ptr(self.info_buf) if want_info else None, self._stream()))
@@ -508,6 +543,8 @@ class BatchedQuadrupedEnv:
                 self._last_view = self._obs_view(reset_mask=self.done, first=True)   # ... and is cleared for the reset robots
             elif fused_reset:
                 self._last_view = self._obs_view()
+            if self._nx_on:
+                self._refresh_next_dynamics()
         else:
             self._last_view = self._obs_view()
         return (self._last_view, self.reward, self.done.view(torch.bool) if want_info else self.done, info)
