@@ -30,7 +30,6 @@ struct CpuHandle {
   std::vector<double> dbuf;   // conversion scratch
 };
 CpuHandle* H(EtgHandle* h) { return reinterpret_cast<CpuHandle*>(h); }
-const CpuHandle* H(const EtgHandle* h) { return reinterpret_cast<const CpuHandle*>(h); }
 
 std::vector<double> to_d(const float* p, size_t n) { return std::vector<double>(p, p + n); }
 }  // namespace
