@@ -1687,7 +1687,9 @@ extern "C" int etg_rollout_policy(EtgHandle* h, EtgPolicy* pol, int n_steps, flo
   if (h->K.motor_mode == 2 || (h->lanes == 16 ? h->N % 16 != 0 : h->N % 64 != 0))
     return fail(ETG_ERR_STATE, "etg_rollout_policy: needs POSITION/TORQUE mode and whole workgroups: num_envs % 16 == 0 on the 16-lane "
                                "mapping (16 robots per workgroup), num_envs % 64 == 0 on the 4-lane one (64 per workgroup)");
-  PolicyW P = {(const float4*)pol->w1, (const float4*)pol->w2, (const float4*)pol->w3, pol->b1, pol->b2, pol->b3, pol->in_dim, pol->out_dim, obs_col0};
+  const bool bf = precision != 0;   // the bf16 kernels read the bf16 fragments packed at load time
+  PolicyW P = {(const float4*)(bf ? pol->w1h : pol->w1), (const float4*)(bf ? pol->w2h : pol->w2), (const float4*)(bf ? pol->w3h : pol->w3), pol->b1, pol->b2, pol->b3,
+               pol->in_dim, pol->out_dim, obs_col0};
   constexpr int ROLLOUT_CHUNK = 50;
   const dim3 g(h->N / 16), b(256);
   hipStream_t s = (hipStream_t)stream;
@@ -1754,7 +1756,9 @@ extern "C" int etg_rollout_policy_record(EtgHandle* h, EtgPolicy* pol, int n_ste
     return fail(ETG_ERR_BAD_ARG, "etg_rollout_policy_record: the policy must map observation columns [col0, col0 + in_dim) to 12 actions");
   if (h->lanes != 16 || h->N % 16 != 0 || h->K.motor_mode == 2)
     return fail(ETG_ERR_STATE, "etg_rollout_policy_record: needs the 16-lanes-per-robot mapping, num_envs % 16 == 0, POSITION/TORQUE mode");
-  PolicyW P = {(const float4*)pol->w1, (const float4*)pol->w2, (const float4*)pol->w3, pol->b1, pol->b2, pol->b3, pol->in_dim, pol->out_dim, obs_col0};
+  const bool bf = precision != 0;   // the bf16 kernels read the bf16 fragments packed at load time
+  PolicyW P = {(const float4*)(bf ? pol->w1h : pol->w1), (const float4*)(bf ? pol->w2h : pol->w2), (const float4*)(bf ? pol->w3h : pol->w3), pol->b1, pol->b2, pol->b3,
+               pol->in_dim, pol->out_dim, obs_col0};
   constexpr int ROLLOUT_CHUNK = 50;
   const dim3 g(h->N / 16), b(256);
   hipStream_t s = (hipStream_t)stream;
@@ -1766,7 +1770,7 @@ extern "C" int etg_rollout_policy_record(EtgHandle* h, EtgPolicy* pol, int n_ste
     const bool kn = h->K.knee != 0, pl = plain_config(h->K);
     const RecOut R = {rec_obs + (size_t)done_steps * N * ETG_OBS_DIM, rec_act + (size_t)done_steps * N * ETG_ACT_DIM,
                       rec_reward + (size_t)done_steps * N, rec_done + (size_t)done_steps * N,
-                      noise ? noise + (size_t)done_steps * N * ETG_ACT_DIM : nullptr, (const float4*)pol->w3s, pol->b3s};
+                      noise ? noise + (size_t)done_steps * N * ETG_ACT_DIM : nullptr, (const float4*)(bf ? pol->w3sh : pol->w3s), pol->b3s};
 #define LAUNCH_POLICY16R(F_, K_, P_)                                                                                  \
   do {                                                                                                                \
     if (precision == 0) hipLaunchKernelGGL((k_rollout_policy16_rec<F_, false, K_, P_>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs, R); \

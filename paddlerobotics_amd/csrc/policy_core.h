@@ -23,6 +23,9 @@ __device__ __forceinline__ bf16x8 pack_bf16(float4 a, float4 b) {
   bf16x8 v = {to_bf16(a.x), to_bf16(a.y), to_bf16(a.z), to_bf16(a.w), to_bf16(b.x), to_bf16(b.y), to_bf16(b.z), to_bf16(b.w)};
   return v;
 }
+// bf16 weights are packed ONCE at load time (k_pack_bf16): one 16-byte fragment = the bf16x8 B operand of a K = 32 MFMA, i.e.
+// pack_bf16 of the fp32 fragments of two consecutive k-blocks, stored at [(tile * nkb / 2 + kb / 2) * 64 + lane]
+__device__ __forceinline__ bf16x8 as_bf16x8(float4 v) { return __builtin_bit_cast(bf16x8, v); }
 
 // The same layer over RT stacked 16-row tiles (in / out hold 16 * RT rows): every weight fragment is fetched ONCE and feeds RT
 // MFMAs -- the weight delivery from L2 per robot falls by RT.  For the 4-lane closed-loop kernel (64 robots per workgroup).
@@ -75,15 +78,30 @@ __device__ __forceinline__ void hidden_layer_rt(const float* in, const float4* _
         for (int t = 0; t < TPW; t++) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[rt].w, w0[t].w, acc[rt][t], 0, 0, 0);
     }
   } else {
-    for (int kb = 0; kb < nkb; kb += 2) {
+    // wp = the bf16 fragments (as_bf16x8): half the bytes of the fp32 ones, no conversion of the weights here
+    constexpr int NKP = NKB / 2;
+    const float4* bh = wp + (size_t)(TPW * wave) * NKP * 64 + lane;
+    constexpr int PFH = NKP < 2 ? NKP : 2;
+    float4 w[PFH + 1][TPW];
+#pragma unroll
+    for (int p = 0; p < PFH; p++)
+#pragma unroll
+      for (int t = 0; t < TPW; t++) w[p][t] = bh[(t * NKP + p) * 64];
+#pragma unroll
+    for (int kp = 0; kp < NKP; kp++) {
       bf16x8 av[RT];
 #pragma unroll
       for (int rt = 0; rt < RT; rt++)
-        av[rt] = pack_bf16(*reinterpret_cast<const float4*>(&in[(16 * rt + i) * HS + kb * 16 + 4 * g]),
-                           *reinterpret_cast<const float4*>(&in[(16 * rt + i) * HS + (kb + 1) * 16 + 4 * g]));
+        av[rt] = pack_bf16(*reinterpret_cast<const float4*>(&in[(16 * rt + i) * HS + 2 * kp * 16 + 4 * g]),
+                           *reinterpret_cast<const float4*>(&in[(16 * rt + i) * HS + (2 * kp + 1) * 16 + 4 * g]));
+      if (kp + PFH < NKP) {
+#pragma unroll
+        for (int t = 0; t < TPW; t++) w[(kp + PFH) % (PFH + 1)][t] = bh[(t * NKP + kp + PFH) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+      }
 #pragma unroll
       for (int t = 0; t < TPW; t++) {
-        const bf16x8 bw = pack_bf16(base[t * tstride + kb * 64], base[t * tstride + (kb + 1) * 64]);
+        const bf16x8 bw = as_bf16x8(w[kp % (PFH + 1)][t]);
 #pragma unroll
         for (int rt = 0; rt < RT; rt++) acc[rt][t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av[rt], bw, acc[rt][t], 0, 0, 0);
       }
@@ -129,7 +147,7 @@ __device__ __forceinline__ void output_partial_rt(const float* bufA, const float
 #pragma unroll
     for (int kk = 0; kk < KPW; kk += 2) {
       const int kb = KPW * wave + kk;
-      const bf16x8 bw = pack_bf16(base[kb * 64], base[(kb + 1) * 64]);
+      const bf16x8 bw = as_bf16x8(base[(kb / 2) * 64]);   // (whp = the bf16 fragments of the head)
 #pragma unroll
       for (int rt = 0; rt < RT; rt++)
         acc[rt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(
@@ -226,17 +244,28 @@ __device__ __forceinline__ void hidden_layer(const float* in, const float4* __re
     }
   } else {
     // one bf16 MFMA (K = 32) consumes two consecutive 16-wide k-blocks; the k-slot order is free as
-    // long as A and B agree, so lane group g takes k = kb*16 + 4g..4g+3 from each block
-    for (int kb = 0; kb < nkb; kb += 2) {
-      const float4 a0 = *reinterpret_cast<const float4*>(&in[i * HS + kb * 16 + 4 * g]);
-      const float4 a1 = *reinterpret_cast<const float4*>(&in[i * HS + (kb + 1) * 16 + 4 * g]);
+    // long as A and B agree, so lane group g takes k = kb*16 + 4g..4g+3 from each block.  wp = the bf16 fragments packed at
+    // load time (as_bf16x8): half the bytes of the fp32 ones and no weight conversion here; the same register ring
+    constexpr int NKP = NKB / 2;
+    const float4* bh = wp + (size_t)(TPW * wave) * NKP * 64 + lane;
+    constexpr int PFH = NKP < 3 ? NKP : 3;
+    float4 w[PFH + 1][TPW];
+#pragma unroll
+    for (int p = 0; p < PFH; p++)
+#pragma unroll
+      for (int t = 0; t < TPW; t++) w[p][t] = bh[(t * NKP + p) * 64];
+#pragma unroll
+    for (int kp = 0; kp < NKP; kp++) {
+      const float4 a0 = *reinterpret_cast<const float4*>(&in[i * HS + 2 * kp * 16 + 4 * g]);
+      const float4 a1 = *reinterpret_cast<const float4*>(&in[i * HS + (2 * kp + 1) * 16 + 4 * g]);
+      if (kp + PFH < NKP) {
+#pragma unroll
+        for (int t = 0; t < TPW; t++) w[(kp + PFH) % (PFH + 1)][t] = bh[(t * NKP + kp + PFH) * 64];
+        __builtin_amdgcn_sched_barrier(0);
+      }
       const bf16x8 av = pack_bf16(a0, a1);
 #pragma unroll
-      for (int t = 0; t < TPW; t++) {
-        const float4 b0 = base[t * tstride + kb * 64];
-        const float4 b1 = base[t * tstride + (kb + 1) * 64];
-        acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, pack_bf16(b0, b1), acc[t], 0, 0, 0);
-      }
+      for (int t = 0; t < TPW; t++) acc[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, as_bf16x8(w[kp % (PFH + 1)][t]), acc[t], 0, 0, 0);
     }
   }
 #pragma unroll
@@ -287,7 +316,7 @@ __device__ __forceinline__ void output_partial(const float* bufA, const float4* 
       const int kb = KPW * wave + kk;
       const float4 a0 = *reinterpret_cast<const float4*>(&bufA[i * HS + kb * 16 + 4 * g]);
       const float4 a1 = *reinterpret_cast<const float4*>(&bufA[i * HS + (kb + 1) * 16 + 4 * g]);
-      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pack_bf16(a0, a1), pack_bf16(base[kb * 64], base[(kb + 1) * 64]), acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pack_bf16(a0, a1), as_bf16x8(base[(kb / 2) * 64]), acc, 0, 0, 0);   // whp = bf16 fragments
     }
   }
 #pragma unroll
@@ -302,4 +331,5 @@ struct EtgPolicy {
   float *w1, *b1, *w2, *b2, *w3, *b3;  // w1/w2/w3 hold the PACKED (MFMA-fragment order) copies
   float *w3s, *b3s;                    // log-std head (etg_policy_load_std), packed like w3
   int has_std;
+  float *w1h, *w2h, *w3h, *w3sh;       // the bf16 fragments (k_pack_bf16) behind precision = 1: half the size, no per-use conversion
 };

@@ -44,6 +44,18 @@ __global__ void k_pack_weights(const float* __restrict__ w, int nout, int kdim, 
   out[idx] = (n < nout && k < kdim) ? w[(size_t)n * kdim + k] : 0.0f;
 }
 
+// bf16 fragments from the fp32 ones: out[(tile * nkb / 2 + kp) * 64 + lane] = pack_bf16(in[(tile * nkb + 2 kp) * 64 + lane],
+// in[(tile * nkb + 2 kp + 1) * 64 + lane]) -- the B operand of v_mfma_f32_16x16x32_bf16 as the kernels used to build it per use
+__global__ void k_pack_bf16(const float4* __restrict__ in, int ntiles, int nkb, float4* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nkp = nkb / 2;
+  if (idx >= ntiles * nkp * 64) return;
+  const int lane = idx & 63, blk = idx >> 6;
+  const int kp = blk % nkp, tile = blk / nkp;
+  const bf16x8 v = pack_bf16(in[(size_t)(tile * nkb + 2 * kp) * 64 + lane], in[(size_t)(tile * nkb + 2 * kp + 1) * 64 + lane]);
+  out[idx] = __builtin_bit_cast(float4, v);
+}
+
 // SAMPLE = false: act = tanh(mean) * scale                                  (SAC.predict, alg/sac.py:60-63)
 // SAMPLE = true : x = mean + exp(clamp(log_std, -20, 2)) * eps, act = tanh(x) * scale, and optionally
 //                 logp = sum_j [N(x_j; mean_j, std_j) log-density - log(1 - tanh(x_j)^2 + 1e-6)]
@@ -131,7 +143,9 @@ extern "C" int etg_policy_create(int in_dim, int hidden, int out_dim, int device
   struct { float** q; size_t n; } a[] = {{&p->w1, packed_floats(HID / 16, 4)}, {&p->b1, (size_t)hidden},
                                          {&p->w2, packed_floats(HID / 16, HID / 16)}, {&p->b2, (size_t)hidden},
                                          {&p->w3, packed_floats(1, HID / 16)}, {&p->b3, (size_t)out_dim},
-                                         {&p->w3s, packed_floats(1, HID / 16)}, {&p->b3s, (size_t)out_dim}};
+                                         {&p->w3s, packed_floats(1, HID / 16)}, {&p->b3s, (size_t)out_dim},
+                                         {&p->w1h, packed_floats(HID / 16, 4) / 2}, {&p->w2h, packed_floats(HID / 16, HID / 16) / 2},
+                                         {&p->w3h, packed_floats(1, HID / 16) / 2}, {&p->w3sh, packed_floats(1, HID / 16) / 2}};
   p->has_std = 0;
   for (auto& x : a)
     if (hipMalloc((void**)x.q, x.n * 4) != hipSuccess) return pfail(ETG_ERR_ALLOC, "etg_policy_create: hipMalloc failed");
@@ -144,13 +158,15 @@ extern "C" int etg_policy_load(EtgPolicy* p, const float* w1, const float* b1, c
   if (!p || !w1 || !b1 || !w2 || !b2 || !w3 || !b3) return pfail(ETG_ERR_BAD_ARG, "etg_policy_load: null");
   if (hipSetDevice(p->device) != hipSuccess) return pfail(ETG_ERR_HIP, "hipSetDevice");
   hipStream_t s = (hipStream_t)stream;
-  struct { float* d; const float* src; int nout, kdim, ntiles, nkb; } pk[] = {
-      {p->w1, w1, p->hidden, p->in_dim, HID / 16, 4},
-      {p->w2, w2, p->hidden, p->hidden, HID / 16, HID / 16},
-      {p->w3, w3, p->out_dim, p->hidden, 1, HID / 16}};
+  struct { float* d; const float* src; int nout, kdim, ntiles, nkb; float* dh; } pk[] = {
+      {p->w1, w1, p->hidden, p->in_dim, HID / 16, 4, p->w1h},
+      {p->w2, w2, p->hidden, p->hidden, HID / 16, HID / 16, p->w2h},
+      {p->w3, w3, p->out_dim, p->hidden, 1, HID / 16, p->w3h}};
   for (auto& x : pk) {
     const int total = x.ntiles * x.nkb * 256;
     hipLaunchKernelGGL(k_pack_weights, dim3((total + 255) / 256), dim3(256), 0, s, x.src, x.nout, x.kdim, x.ntiles, x.nkb, x.d);
+    const int th = x.ntiles * (x.nkb / 2) * 64;
+    hipLaunchKernelGGL(k_pack_bf16, dim3((th + 255) / 256), dim3(256), 0, s, (const float4*)x.d, x.ntiles, x.nkb, (float4*)x.dh);
   }
   struct { float* d; const float* src; size_t n; } c[] = {{p->b1, b1, (size_t)p->hidden}, {p->b2, b2, (size_t)p->hidden},
                                                          {p->b3, b3, (size_t)p->out_dim}};
@@ -167,6 +183,7 @@ extern "C" int etg_policy_load_std(EtgPolicy* p, const float* w_std, const float
   hipStream_t s = (hipStream_t)stream;
   const int total = (HID / 16) * 256;
   hipLaunchKernelGGL(k_pack_weights, dim3((total + 255) / 256), dim3(256), 0, s, w_std, p->out_dim, p->hidden, 1, HID / 16, p->w3s);
+  hipLaunchKernelGGL(k_pack_bf16, dim3(((HID / 32) * 64 + 255) / 256), dim3(256), 0, s, (const float4*)p->w3s, 1, HID / 16, (float4*)p->w3sh);
   if (hipMemcpyAsync(p->b3s, b_std, (size_t)p->out_dim * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
     return pfail(ETG_ERR_HIP, "etg_policy_load_std: hipMemcpyAsync failed");
   if (hipGetLastError() != hipSuccess) return pfail(ETG_ERR_HIP, "etg_policy_load_std: pack launch failed");
@@ -176,6 +193,8 @@ extern "C" int etg_policy_load_std(EtgPolicy* p, const float* w_std, const float
 
 #define ETG_POLICY_ARGS obs, n, p->in_dim, (const float4*)p->w1, p->b1, (const float4*)p->w2, p->b2, (const float4*)p->w3, p->b3, \
                         (const float4*)p->w3s, p->b3s
+#define ETG_POLICY_ARGS_BF16 obs, n, p->in_dim, (const float4*)p->w1h, p->b1, (const float4*)p->w2h, p->b2, (const float4*)p->w3h, p->b3, \
+                             (const float4*)p->w3sh, p->b3s
 extern "C" int etg_policy_forward(EtgPolicy* p, const float* obs, int n, float act_scale, int precision, float* act,
                                   void* stream) {
   if (!p || !obs || !act || n <= 0) return pfail(ETG_ERR_BAD_ARG, "etg_policy_forward: bad arguments");
@@ -185,7 +204,7 @@ extern "C" int etg_policy_forward(EtgPolicy* p, const float* obs, int n, float a
     hipLaunchKernelGGL((k_policy<false, false>), grid, block, 0, (hipStream_t)stream, ETG_POLICY_ARGS, nullptr, p->out_dim,
                        act_scale, act, nullptr);
   else
-    hipLaunchKernelGGL((k_policy<true, false>), grid, block, 0, (hipStream_t)stream, ETG_POLICY_ARGS, nullptr, p->out_dim,
+    hipLaunchKernelGGL((k_policy<true, false>), grid, block, 0, (hipStream_t)stream, ETG_POLICY_ARGS_BF16, nullptr, p->out_dim,
                        act_scale, act, nullptr);
   if (hipGetLastError() != hipSuccess) return pfail(ETG_ERR_HIP, "etg_policy_forward: launch failed");
   return ETG_OK;
@@ -201,17 +220,18 @@ extern "C" int etg_policy_sample(EtgPolicy* p, const float* obs, int n, const fl
     hipLaunchKernelGGL((k_policy<false, true>), grid, block, 0, (hipStream_t)stream, ETG_POLICY_ARGS, noise, p->out_dim,
                        act_scale, act, logp);
   else
-    hipLaunchKernelGGL((k_policy<true, true>), grid, block, 0, (hipStream_t)stream, ETG_POLICY_ARGS, noise, p->out_dim,
+    hipLaunchKernelGGL((k_policy<true, true>), grid, block, 0, (hipStream_t)stream, ETG_POLICY_ARGS_BF16, noise, p->out_dim,
                        act_scale, act, logp);
   if (hipGetLastError() != hipSuccess) return pfail(ETG_ERR_HIP, "etg_policy_sample: launch failed");
   return ETG_OK;
 }
 #undef ETG_POLICY_ARGS
+#undef ETG_POLICY_ARGS_BF16
 
 extern "C" void etg_policy_destroy(EtgPolicy* p) {
   if (!p) return;
   (void)hipSetDevice(p->device);
-  float* ptrs[] = {p->w1, p->b1, p->w2, p->b2, p->w3, p->b3, p->w3s, p->b3s};
+  float* ptrs[] = {p->w1, p->b1, p->w2, p->b2, p->w3, p->b3, p->w3s, p->b3s, p->w1h, p->w2h, p->w3h, p->w3sh};
   for (float* q : ptrs)
     if (q) (void)hipFree(q);
   delete p;
