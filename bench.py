@@ -402,6 +402,17 @@ def main():
             extra["config3"] = {"value": world * N * K / m, "ms_per_step": m / K * 1e3, "kernel_ms_per_step": float(np.median(kn)),
                                 "survivors": sv, "note": "configs[2]: ETG + residual MLP policy (random init, fp32 MFMA), "
                                 "etg_rollout_policy: policy tile + control step fused, <= 50 control steps per launch"}
+            if args.precision == 0:     # the opt-in bf16 tile next to it (reduced precision: a side note, never the config-3 number)
+                args.precision = 1
+                try:
+                    wl, kn, sv = timed_repeats(env, pol3, True, 3, events=True)
+                finally:
+                    args.precision = 0
+                m = float(np.median(wl))
+                extra["config3_bf16_policy"] = {"value": world * N * K / m, "ms_per_step": m / K * 1e3, "kernel_ms_per_step": float(np.median(kn)),
+                                                "survivors": sv, "dtype": "bf16 policy tile, f32 physics",
+                                                "note": "the same fused closed loop with precision = 1: bf16 MFMA on fragments packed at load "
+                                                        "time; an opt-in arithmetic with its own tolerances, NOT the parity path"}
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(50):

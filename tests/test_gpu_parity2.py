@@ -472,12 +472,13 @@ def test_flat_ground_knee_rows_match_oracle(lanes):
 @pytest.mark.parametrize("kw", [dict(), dict(observation_noise_stdev=[0.02, 0.3, 0.0, 0.01, 0.05]), dict(lanes_per_robot=4),
                                 dict(task="stairstair", terrain_variants=4),
                                 dict(sensor_mode={"RNN": {"time_steps": 2, "time_interval": 1, "mode": "stack"}}),
-                                dict(random_param={"random_dynamics": 1})])
+                                dict(random_param={"random_dynamics": 1}, random_dynamics_refresh=1)])
 def test_auto_reset_variants_equal_manual_reset(kw):
     """step(auto_reset) == step() followed by reset(env_ids=done): the default 16-lane kernel (restart copied from the per-robot
     cache of reset_finish16's outputs), the same with sensor noise (the cache holds the clean row), and the paths the fast kernel
-    does not cover alone: the 4-lane mapping, a heightfield task, the observation history stack, random dynamics (new parameters
-    per reset -> a simulated settle through the general etg_reset path)."""
+    does not cover alone: the 4-lane mapping, a heightfield task, the observation history stack, random dynamics with a fresh draw at
+    every single reset (random_dynamics_refresh = 1: new parameters per reset -> a simulated settle through the general etg_reset path;
+    the default prepares the next episodes' rows ahead, test_next_episode_dynamics_are_prepared_ahead)."""
     _need_gpu()
     n = 32
     W, B = _etg_params(n, seed=13)
