@@ -17,7 +17,8 @@ opts = [dict(), dict(motor_control_mode="torque"), dict(motor_control_mode="hybr
         dict(body_contacts=2), dict(auto_reset=True), dict(auto_reset=True, joint_limits=True, random_param={"random_force": 1}),
         # round 3: all body spheres at once (4-lane kernels), pyramid friction, pd latency, the solver with a fixed count
         dict(body_contacts=3), dict(body_contacts=3, motor_control_mode="torque"), dict(friction_model=1), dict(pd_latency=0.001),
-        dict(solver_iters=3), dict(body_contacts=2, friction_model=1, auto_reset=True)]
+        dict(solver_iters=3), dict(body_contacts=2, friction_model=1, auto_reset=True),
+        dict(auto_reset=True, random_param={"random_dynamics": 1}, random_dynamics_refresh=32)]
 for lanes, task, o in itertools.product((16, 4), ("ground", "stairstair"), opts):
     if o.get("body_contacts") == 3 and lanes == 16:
         continue   # three body rows per leg: the 4-lane mapping only
