@@ -301,22 +301,31 @@ def param2dynamic_rows(params):
     return out
 
 
+_P2D_CACHE = {}
+
+
+def _p2d_tables():
+    """offset / scale / lower / upper of the 48 affine-then-clip maps of param2dynamic_dict (train.py:112-126), as numpy rows"""
+    kd0 = np.array([1., 2., 2.] * 4)
+    off = np.concatenate([[40.0, 0.2, 1.5], np.ones(18), 80 * np.ones(12), kd0, [0.0, 0.0, -10.0]])
+    scl = np.concatenate([[10.0, 10.0, 1.0], np.ones(18), 40 * np.ones(12), kd0, [2.0, 2.0, 10.0]])
+    lo = np.concatenate([[0.0, 0.0, 0.5], 0.1 * np.ones(18), 20 * np.ones(12), np.zeros(12), [-5.0, -5.0, -20.0]])
+    hi = np.concatenate([[80.0, 20.0, 3.0], 3 * np.ones(18), 200 * np.ones(12), 5 * np.ones(12), [5.0, 5.0, -4.0]])
+    return off, scl, lo, hi
+
+
 def param2dynamic_rows_torch(params):
-    """the same mapping for a [n,48] tensor on any device (random dynamics drawn on the GPU: no host RNG, no upload)"""
+    """the same mapping for a [n,48] tensor on any device (random dynamics drawn on the GPU: no host RNG, no upload): every
+    entry is clip(offset + scale * clip(p, -1, 1), lower, upper) -- three tensor ops with the four rows cached per device"""
     import torch
     P = params.clamp(-1, 1).to(torch.float32)
-    dev = P.device
-    kd0 = torch.tensor([1., 2., 2.] * 4, device=dev)
-    out = torch.empty(P.shape[0], 48, device=dev)
-    out[:, 0] = (40 + 10 * P[:, 0]).clamp(0, 80)
-    out[:, 1] = (0.2 + 10 * P[:, 1]).clamp(0, 20)
-    out[:, 2] = (1.5 + P[:, 2]).clamp(0.5, 3)
-    out[:, 3:21] = (1 + P[:, 3:21]).clamp(0.1, 3)
-    out[:, 21:33] = (80 + 40 * P[:, 21:33]).clamp(20, 200)
-    out[:, 33:45] = (kd0 + P[:, 33:45] * kd0).clamp(0, 5)
-    g = torch.tensor([0., 0., -10.], device=dev) + P[:, 45:48] * torch.tensor([2., 2., 10.], device=dev)
-    out[:, 45:48] = torch.maximum(torch.minimum(g, torch.tensor([5., 5., -4.], device=dev)), torch.tensor([-5., -5., -20.], device=dev))
-    return out
+    key = str(P.device)
+    if key not in _P2D_CACHE:
+        _P2D_CACHE[key] = tuple(torch.tensor(t, dtype=torch.float32, device=P.device) for t in _p2d_tables())
+    off, scl, lo, hi = _P2D_CACHE[key]
+    if P.shape[1] < 48:
+        P = torch.cat([P, torch.zeros(P.shape[0], 48 - P.shape[1], device=P.device)], dim=1)
+    return torch.minimum(torch.maximum(off + scl * P, lo), hi)
 
 
 def default_dynamic_row():
