@@ -165,15 +165,27 @@ __global__ void __launch_bounds__(256) k_next_flags(KCfg K, unsigned char* ok, c
 // Stage the lane's 66 derived parameters in LDS, [field][lane] (conflict-free: lane i hits
 // bank i).  Each lane reads back only its own column, so no barrier is needed -- the LDS
 // is a software-managed register file extension here, not a sharing medium.
-__device__ __forceinline__ void stage_params(GpuCtx& c, const DevState& D, float* lds_par) {
-  // only what the once-per-step code reads through c.par(); the tick constants go straight to registers (tpar)
-  constexpr int kStaged[] = {PR_O1, PR_O1 + 1, PR_O1 + 2, PR_SY, PR_LAT_N, PR_LAT_A, PR_BASE_FOOT, PR_BASE_FOOT + 1,
-                             PR_BASE_FOOT + 2, PR_POSE, PR_POSE + 1, PR_POSE + 2, PR_EMEAN, PR_EMEAN + 1, PR_EMEAN + 2,
-                             PR_ESTD, PR_ESTD + 1, PR_ESTD + 2, PR_HIPSIGN};
+// only what the once-per-step code reads through c.par(); the tick constants go straight to registers (tpar)
+constexpr int kStaged4[] = {PR_O1, PR_O1 + 1, PR_O1 + 2, PR_SY, PR_LAT_N, PR_LAT_A, PR_BASE_FOOT, PR_BASE_FOOT + 1,
+                            PR_BASE_FOOT + 2, PR_POSE, PR_POSE + 1, PR_POSE + 2, PR_EMEAN, PR_EMEAN + 1, PR_EMEAN + 2,
+                            PR_ESTD, PR_ESTD + 1, PR_ESTD + 2, PR_HIPSIGN};
+constexpr int kNStaged4 = sizeof(kStaged4) / sizeof(int);
+// issue / commit: a caller may put its own cold loads between the two (step4_body, like step16_body)
+__device__ __forceinline__ void stage4_issue(GpuCtx& c, const DevState& D, float* lds_par, float (&v)[kNStaged4]) {
 #pragma unroll
-  for (int k : kStaged) lds_par[k * BLOCK + threadIdx.x] = D.par[(size_t)k * c.NL + c.gid];
+  for (int i = 0; i < kNStaged4; i++) v[i] = D.par[(size_t)kStaged4[i] * c.NL + c.gid];
   c.lds = lds_par + threadIdx.x;
   c.gpar = D.par;
+}
+__device__ __forceinline__ void stage4_commit(const GpuCtx& c, const float (&v)[kNStaged4]) {
+  float* mine = const_cast<float*>(c.lds);
+#pragma unroll
+  for (int i = 0; i < kNStaged4; i++) mine[kStaged4[i] * BLOCK] = v[i];
+}
+__device__ __forceinline__ void stage_params(GpuCtx& c, const DevState& D, float* lds_par) {
+  float v[kNStaged4];
+  stage4_issue(c, D, lds_par, v);
+  stage4_commit(c, v);
 }
 
 // the same staging for a wave of a multi-wave workgroup (its own [PR_N][64] area, lane = lane in the wave)
@@ -341,8 +353,15 @@ __device__ __forceinline__ void step4_body(const KCfg& K, const DevState& D, con
                                            float* reward, uint8_t* done, float* info, float* lds_par, const NextDyn NX = NextDyn{nullptr, nullptr, nullptr}) {
   GpuCtxT<FLAT, PLAIN, BODY> c;
   if (!make_ctx(K, c)) return;
-  stage_params(c, D, lds_par);
+  // every cold load of the launch head is requested before the first wait (see step16_body)
+  float stg[kNStaged4];
+  stage4_issue(c, D, lds_par, stg);
   LaneState<float> L = load_state<float>(c, D.base, D.leg);
+  StepCtl4<float> S = load_ctl4<float>(c, K, D.ctl, D.ictl, D.legctl);
+  TickPar4<float> tp = load_tick_par4<float>(c);
+  V3<float> fext = {0.0f, 0.0f, 0.0f};
+  if (!PLAIN && K.ext_force) fext = {c.ld_env(D.ctl, CT_FEXT + 0) + c.ld_env(D.ctl, CT_PUSH + 0), c.ld_env(D.ctl, CT_FEXT + 1) + c.ld_env(D.ctl, CT_PUSH + 1),
+                                     c.ld_env(D.ctl, CT_FEXT + 2) + c.ld_env(D.ctl, CT_PUSH + 2)};   // set force + random push
   float act[3], hyb[12];
   const bool hybrid = K.motor_mode == 2 && action;   // rows of 60: per motor (q_des, kp, qd_des, kd, tau_ff)
 #pragma unroll
@@ -351,14 +370,16 @@ __device__ __forceinline__ void step4_body(const KCfg& K, const DevState& D, con
 #pragma unroll
     for (int k = 0; k < 4; k++) hyb[4 * j + k] = hybrid ? c.ld_row_lane(action, ETG_HYBRID_DIM, 5 * j + 1 + k, 15) : 0.0f;
   }
+  const float dflag = donef ? (float)donef[c.env] : 0.0f;
+  stage4_commit(c, stg);
   float r, d;
 #ifdef ETG_PROFILE_PHASES
   for (int k = 0; k < 16; k++) c.prof[k] = 0;
   c.prof_last = clock64();
   long long t_begin = c.prof_last;
 #endif
-  control_step(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, act, donef ? (float)donef[c.env] : 0.0f, obs, r, d,
-               info, hybrid ? hyb : nullptr);
+  control_step_core(c, K, tp, fext, L, S, D.ring, D.etgp, act, dflag, obs, r, d, info, hybrid ? hyb : nullptr);
+  store_ctl4(c, K, S, D.ctl, D.ictl, D.legctl);
   if (AUTO && d > 0.5f) {   // whole quads take this branch together
     const int N = K.n_env;
     if (NX.ok && NX.ok[c.env]) {   // parameters prepared for the next episode: install them (the cached settle below is theirs)
