@@ -360,7 +360,7 @@ class BatchedQuadrupedEnv:
     def _info(self):
         return _InfoView(self.info_buf)
 
-    def reset(self, env_ids=None, ETG_w=None, ETG_b=None, dynamic_param=None, x_noise=0, hardset=False, **kwargs):
+    def reset(self, env_ids=None, ETG_w=None, ETG_b=None, dynamic_param=None, x_noise=0, hardset=False, _keep_offsets=False, **kwargs):
         if ETG_w is not None:
             self.set_etg(ETG_w, ETG_b, env_ids)
         if dynamic_param is not None:
@@ -380,7 +380,9 @@ class BatchedQuadrupedEnv:
             xy[:, 0] = (torch.rand(self.num_envs, device=self.device, generator=self._dyn_gen) * 0.2 - 0.1) * float(x_noise)
             self.set_reset_offsets(xy, env_ids)
             self._noise_offsets = True
-        elif self._noise_offsets:       # an earlier reset jittered these robots: back to the nominal start
+        elif self._noise_offsets and not _keep_offsets:       # an earlier reset jittered these robots: back to the nominal start
+            # (_keep_offsets: the restart of step(auto_reset) -- finished robots start over where their last reset put them, on the
+            # fused path and on this one alike)
             self.set_reset_offsets(None, env_ids)
             self._noise_offsets = env_ids is not None
         if self._rand_force:
@@ -535,7 +537,7 @@ class BatchedQuadrupedEnv:
                 if self._hist_T > 0:
                     self._obs_view()                                         # the terminal reading enters the history first
                 self._reset_mask = self.done.clone()
-                self.reset(env_ids=self._reset_mask)
+                self.reset(env_ids=self._reset_mask, _keep_offsets=True)
             if want_info:
                 info["reset"] = self.done.view(torch.bool)
             if self._hist_T > 0 and fused_reset:

@@ -667,3 +667,30 @@ def test_next_episode_dynamics_are_prepared_ahead():
     _say("random dynamics + auto reset, 4096 robots, violent actions: %.1f us per env.step() (two refreshes of the next-episode rows included)" % per)
     assert per < 1000.0 and env._nx_on          # (the masked-reset path measures 3900 us)
     env.close()
+
+
+def test_auto_reset_keeps_the_start_jitter_on_both_paths():
+    """reset(x_noise=1) jitters the start positions; robots restarted by step(auto_reset) start over where their last reset put
+    them -- inside the fused launch (checked on the positions) and through the masked-reset path (random dynamics drawn at every
+    reset: the settle under new dynamics moves the robot by itself, so the check is that the offsets are not cleared)."""
+    _need_gpu()
+    n = 64
+    env = _make(n, auto_reset=True, seed=3)
+    env.reset(x_noise=1)
+    x0 = env.get_state()[:, 0].clone()
+    assert x0.abs().max().item() > 0.02 and x0.std().item() > 0.01
+    for _ in range(3):
+        env.step(None, want_info=False)
+    env.step(None, donef=True, want_info=False)
+    assert (env.get_state()[:, 0] - x0).abs().max().item() < 1e-4
+    env.close()
+    env = _make(n, auto_reset=True, seed=3, random_param={"random_dynamics": 1}, random_dynamics_refresh=1)
+    env.reset(x_noise=1)
+    calls = []
+    orig = env.set_reset_offsets
+    env.set_reset_offsets = lambda xy, ids=None: (calls.append(xy is None), orig(xy, ids))[1]
+    env.step(None, donef=True, want_info=False)
+    assert calls == [] and torch.isfinite(env.get_state()).all()
+    env.reset(env_ids=torch.ones(n, dtype=torch.bool, device="cuda:0"))        # a caller's own masked reset does go back to nominal
+    assert calls == [True]
+    env.close()
