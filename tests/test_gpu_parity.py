@@ -1063,7 +1063,8 @@ def test_examples_run(tmp_path):
     for script, args in (("es_pretrain.py", ["--popsize", "256", "--generations", "2", "--max-step", "60"]),
                          ("export_gait.py", []), ("evaluate_policy.py", []),
                          ("dynamics_id.py", ["--popsize", "128", "--generations", "2", "--steps", "20"]),
-                         ("collect_sac_data.py", ["--num-envs", "256", "--episodes", "2", "--max-step", "30"])):
+                         ("collect_sac_data.py", ["--num-envs", "256", "--episodes", "2", "--max-step", "30"]),
+                         ("domain_randomisation.py", ["--num-envs", "256", "--steps", "80", "--refresh", "16"])):
         r = subprocess.run([sys.executable, os.path.join(root, "examples", script)] + args, cwd=tmp_path,
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, (script, r.stderr[-600:])
