@@ -74,7 +74,7 @@ def test_no_contact_means_one_sweep():
 
 
 @pytest.mark.parametrize("lanes", [4, 16])
-@pytest.mark.parametrize("variant", ["flat", "heightfield", "pyramid", "loose"])
+@pytest.mark.parametrize("variant", ["flat", "heightfield", "pyramid", "loose", "body2", "body3"])
 def test_kernel_source_stops_on_the_same_sweep_as_the_oracle(lanes, variant):
     """The emulation runs the kernels' own tick one robot at a time, so its sweep count (info[ETG_INFO_SWEEPS]) must be the
     oracle's per-robot count exactly, step by step, and the states must agree."""
@@ -90,6 +90,10 @@ def test_kernel_source_stops_on_the_same_sweep_as_the_oracle(lanes, variant):
         kw = dict(friction_model=1)
     elif variant == "loose":
         kw = dict(solver_iters=3, solver_residual=1e-5)     # the cap binds on some ticks
+    elif variant in ("body2", "body3"):                     # limp robots (TORQUE mode) fold onto their body spheres: 16 / 24 rows
+        if variant == "body3" and lanes == 16:
+            pytest.skip("three body rows per leg: the 4-lane mapping")
+        kw = dict(body_contacts=int(variant[-1]), motor_mode=1, joint_limits=0)
     cfg = A.default_config(n, settle_ticks=150, **kw)
     W, B = _params(n, seed=5)
     orc, emu = OracleSim(cfg, dtype=np.float32), EmuSim(cfg, lanes=lanes)
@@ -103,7 +107,7 @@ def test_kernel_source_stops_on_the_same_sweep_as_the_oracle(lanes, variant):
     rng = np.random.default_rng(1)
     same = total = 0
     for k in range(10):
-        act = rng.uniform(-0.1, 0.1, size=(n, 12))
+        act = rng.uniform(-2.0, 2.0, size=(n, 12)) if variant.startswith("body") else rng.uniform(-0.1, 0.1, size=(n, 12))
         _, _, _, i1 = orc.step(act)
         _, _, _, i2 = emu.step(act)
         sw_o, sw_e = i1[:, A.INFO_SWEEPS], i2[:, A.INFO_SWEEPS]
@@ -114,7 +118,7 @@ def test_kernel_source_stops_on_the_same_sweep_as_the_oracle(lanes, variant):
         total += n
         # fp32 both sides: a residual within rounding of the threshold may flip a single tick's count
         assert np.abs(sw_o - sw_e).max() <= 2, (k, sw_o, sw_e)
-        tol = 1e-2 if variant == "heightfield" else 1e-3
+        tol = 1e-2 if variant == "heightfield" or variant.startswith("body") else 1e-3   # (limp legs amplify fp32 rounding)
         assert np.abs(emu.get_state()[:, 13:25] - orc.get_state()[:, 13:25]).max() < tol
     assert same >= 0.8 * total, (same, total)
 
