@@ -256,7 +256,8 @@ int etg_step(EtgHandle* h, const float* action, const uint8_t* donef, float* obs
 /* etg_step followed by the reset of every robot whose `done` byte the step set (Gym-style auto-reset, on the device,
  * no host synchronisation): obs rows of those robots hold their reset observation, reward / done / info rows the
  * finished step.  While every robot has a cached settle (after a full etg_reset, until dynamic parameters, terrain or
- * heightfield start offsets change) step and restart are ONE launch; otherwise etg_step + etg_reset(mask = done).  */
+ * heightfield start offsets change -- and again once masked etg_resets have settled every robot such a change touched)
+ * step and restart are ONE launch; otherwise etg_step + etg_reset(mask = done).                                        */
 int etg_step_autoreset(EtgHandle* h, const float* action, const uint8_t* donef, float* obs,
                        float* reward, uint8_t* done, float* info, void* stream);
 /* Dynamics randomisation per EPISODE without a settle per control step (random_param["random_dynamics"], train.py:253: a new

@@ -1250,6 +1250,12 @@ struct EtgHandle {
   NextDyn NX;
   float *nx_base, *nx_leg, *nx_ring;
   unsigned char* nx_cache_ok;
+  // all_cached again after MASKED resets: every invalidation bumps inval_seq; a masked etg_reset ends with a count of the robots
+  // still without a cached settle, written with the sequence number it ran under to pinned host memory (cached_report[0] = count,
+  // [1] = seq); the next etg_step_autoreset / etg_prepare_next_dynamics trusts a zero count only under the CURRENT number
+  unsigned inval_seq;
+  volatile unsigned* cached_report;   // pinned host memory, also mapped on the device (cached_report_dev)
+  unsigned* cached_report_dev;
 };
 
 static thread_local std::string g_err;
@@ -1312,6 +1318,9 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   h->fext_set = h->push_on = false;
   h->all_cached = false;
   h->NX = NextDyn{nullptr, nullptr, nullptr};
+  h->inval_seq = 1;
+  h->cached_report = nullptr;
+  h->cached_report_dev = nullptr;
   h->nx_base = h->nx_leg = h->nx_ring = nullptr;
   h->nx_cache_ok = nullptr;
   // 0 = auto.  Both kernels hold one wave per SIMD (register footprint), so the chip runs 1024 waves
@@ -1358,6 +1367,7 @@ extern "C" void etg_destroy(EtgHandle* h) {
                   h->tmp_obs, h->tmp_reward, h->tmp_done, h->NX.par, h->NX.dyn, h->NX.ok, h->nx_base, h->nx_leg, h->nx_ring, h->nx_cache_ok};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
+  if (h->cached_report) (void)hipHostFree((void*)h->cached_report);
   delete h;
 }
 
@@ -1408,7 +1418,7 @@ extern "C" int etg_set_params(EtgHandle* h, const float* dyn, const float* etg_w
                               const uint8_t* mask, void* stream) {
   CHECK_HANDLE(h);
   if ((etg_w == nullptr) != (etg_b == nullptr)) return fail(ETG_ERR_BAD_ARG, "etg_set_params: pass both etg_w and etg_b or neither");
-  if (dyn) h->all_cached = false;   // the settle depends on the dynamic parameters
+  if (dyn) { h->all_cached = false; h->inval_seq++; }   // the settle depends on the dynamic parameters
   if (dyn && h->NX.ok)              // (and rows prepared for the masked robots' next episodes came with a settle of their own)
     hipLaunchKernelGGL(k_next_flags, dim3((h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->NX.ok, mask, (unsigned char)0);
   hipLaunchKernelGGL(k_fin_clear, dim3((h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->D, mask);   // cached restarts: stale
@@ -1427,6 +1437,7 @@ extern "C" int etg_set_heightfield(EtgHandle* h, const float* heights, void* str
   HIP_TRY(hipMemsetAsync(h->D.cache_ok, 0, h->N, (hipStream_t)stream));   // the settle depends on the terrain
   HIP_TRY(hipMemsetAsync(h->D.cache_off + (size_t)FIN_OK * h->N, 0, (size_t)h->N * 4, (hipStream_t)stream));
   h->all_cached = false;
+  h->inval_seq++;
   h->K.hf = h->hf;
   return ETG_OK;
 }
@@ -1467,11 +1478,38 @@ extern "C" int etg_clear_pushes(EtgHandle* h, const uint8_t* mask, void* stream)
 }
 
 // ---- parameters for the NEXT episode (etg_prepare_next_dynamics)
+// robots without a valid cached settle, counted after a masked reset (one workgroup; see EtgHandle::cached_report)
+__global__ void __launch_bounds__(256) k_count_uncached(KCfg K, DevState D, unsigned seq, unsigned* report) {
+  __shared__ unsigned part[256];
+  unsigned n = 0;
+  for (int env = threadIdx.x; env < K.n_env; env += 256) n += D.cache_ok[env] ? 0u : 1u;
+  part[threadIdx.x] = n;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    __hip_atomic_store(&report[0], part[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __hip_atomic_store(&report[1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+// host side: has a masked reset, run under the current invalidation number, reported that every robot is cached again?
+static inline void refresh_all_cached(EtgHandle* h) {
+  if (h->all_cached || !h->cached_report) return;
+  const unsigned seq = h->cached_report[1];
+  __sync_synchronize();
+  if (seq == h->inval_seq && h->cached_report[0] == 0u) h->all_cached = true;
+}
+
 extern "C" int etg_prepare_next_dynamics(EtgHandle* h, const float* dyn, const uint8_t* mask, void* stream) {
   CHECK_HANDLE(h);
   if (!dyn) return fail(ETG_ERR_BAD_ARG, "etg_prepare_next_dynamics: dyn is null");
+  refresh_all_cached(h);
   if (!h->was_reset || !h->all_cached)
-    return fail(ETG_ERR_STATE, "etg_prepare_next_dynamics: needs a full etg_reset first (every robot with a valid cached settle)");
+    return fail(ETG_ERR_STATE, "etg_prepare_next_dynamics: every robot needs a valid cached settle (a full etg_reset, or masked resets "
+                               "that covered every robot whose parameters, terrain or start offset changed)");
   const size_t N = h->N, NL = 4 * N;
   if (!h->NX.par) {
     struct { void** p; size_t bytes; } allocs[] = {
@@ -1544,6 +1582,20 @@ extern "C" int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* st
   }
   hipLaunchKernelGGL(k_fin_store, ge, dim3(256), 0, s, h->K, h->D, mask, (const float*)obs);   // the clean row: before the noise
   launch_obs_noise(h, 1, mask, obs, s);
+  if (mask && !h->all_cached) {   // did this masked reset settle the last robots without a cache?  (answer read by a later call)
+    if (!h->cached_report) {
+      void* p = nullptr;
+      if (hipHostMalloc(&p, 2 * sizeof(unsigned), hipHostMallocMapped) == hipSuccess) {
+        h->cached_report = (volatile unsigned*)p;
+        h->cached_report[0] = 1u; h->cached_report[1] = 0u;
+        if (hipHostGetDevicePointer((void**)&h->cached_report_dev, p, 0) != hipSuccess) {
+          (void)hipHostFree(p);
+          h->cached_report = nullptr;
+        }
+      }
+    }
+    if (h->cached_report) hipLaunchKernelGGL(k_count_uncached, dim3(1), dim3(256), 0, s, h->K, h->D, h->inval_seq, h->cached_report_dev);
+  }
   HIP_TRY(hipGetLastError());
   if (!mask) h->all_cached = true;
   return ETG_OK;
@@ -1572,7 +1624,7 @@ extern "C" int etg_set_reset_offsets(EtgHandle* h, const float* xy, const uint8_
   hipLaunchKernelGGL(k_set_reset_offsets, dim3((h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->D, xy, mask);
   hipLaunchKernelGGL(k_fin_clear, dim3((h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->D, mask);
   HIP_TRY(hipGetLastError());
-  if (h->K.terrain != 0) h->all_cached = false;   // a heightfield settle is only valid at the offset it ran at
+  if (h->K.terrain != 0) { h->all_cached = false; h->inval_seq++; }   // a heightfield settle is only valid at the offset it ran at
   return ETG_OK;
 }
 
@@ -1602,6 +1654,7 @@ extern "C" int etg_step(EtgHandle* h, const float* action, const uint8_t* donef,
 extern "C" int etg_step_autoreset(EtgHandle* h, const float* action, const uint8_t* donef, float* obs, float* reward,
                                   uint8_t* done, float* info, void* stream) {
   CHECK_HANDLE(h);
+  refresh_all_cached(h);
   if (!h->all_cached) {   // some robot needs a simulated settle: step, then the general reset path masked by the done bytes
     int rc = etg_step(h, action, donef, obs, reward, done, info, stream);
     if (rc != ETG_OK) return rc;

@@ -694,3 +694,35 @@ def test_auto_reset_keeps_the_start_jitter_on_both_paths():
     env.reset(env_ids=torch.ones(n, dtype=torch.bool, device="cuda:0"))        # a caller's own masked reset does go back to nominal
     assert calls == [True]
     env.close()
+
+
+def test_fast_auto_reset_path_comes_back_after_masked_resets():
+    """The one-launch restart of etg_step_autoreset (and etg_prepare_next_dynamics) needs every robot to have a cached settle.
+    New dynamic parameters for SOME robots invalidate theirs; once masked resets have settled exactly those robots again, the
+    library notices (a count of uncached robots reported under the invalidation's sequence number) and returns to the fast path
+    -- it used to stay on step + masked reset until the next full reset."""
+    import ctypes as C
+    from paddlerobotics_amd import _lib as L
+    _need_gpu()
+    n = 64
+    env = _make(n, auto_reset=True, seed=2)
+    env.reset()
+    rows = torch.as_tensor(np.tile(A.default_dynamic_row(), (n, 1)), dtype=torch.float32, device="cuda:0").contiguous()
+    prep = lambda: env._lib.etg_prepare_next_dynamics(env._h, C.c_void_p(rows.data_ptr()), None, env._stream())
+    assert prep() == 0                                            # all cached after the full reset
+    half = torch.zeros(n, dtype=torch.bool, device="cuda:0"); half[::2] = True
+    heavy = rows.clone(); heavy[:, 2] *= 1.2                      # a heavier trunk for half of the robots
+    env.set_dynamic_param(heavy, half)
+    assert prep() != 0 and b"cached settle" in env._lib.etg_last_error()
+    df = half.to(torch.uint8)
+    env.step(None, donef=df, want_info=False)                     # the general path: step, then a masked reset that settles them
+    torch.cuda.synchronize()
+    env.step(None, want_info=False)                               # reads the report: every robot is cached again
+    assert prep() == 0
+    # a second invalidation that no reset has covered yet keeps the general path
+    env.set_dynamic_param(heavy, ~half)
+    env.step(None, want_info=False)
+    torch.cuda.synchronize()
+    assert prep() != 0
+    assert torch.isfinite(env.get_state()).all()
+    env.close()
