@@ -365,6 +365,8 @@ class BatchedQuadrupedEnv:
             self.set_etg(ETG_w, ETG_b, env_ids)
         if dynamic_param is not None:
             self.set_dynamic_param(dynamic_param, env_ids)
+            if env_ids is None:
+                self._nx_on = False      # explicit parameters for everybody: no prepared random rows until the next plain full reset
         elif self._rand_dyn:
             # random_param['random_dynamics'] (train.py:253): a fresh draw of the 48 dynamic parameters for
             # every robot being reset, param2dynamic_dict(U(-1,1) * scale) (train.py:112-126)
