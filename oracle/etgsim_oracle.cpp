@@ -560,7 +560,7 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
   constexpr int NRMAX = 24;
   const bool all_bodies = s.cfg.body_contacts == 3;
   const int NR = all_bodies ? 24 : 16;
-  const int NB = all_bodies ? 3 : 1;                       // body rows per leg
+  const int NBR = all_bodies ? 3 : 1;                      // body rows per leg
   auto body_row = [&](int l, int b) { return all_bodies ? 12 + 3 * l + b : 12 + l; };
   T J[NRMAX][NV];
   T target[NRMAX];
@@ -646,7 +646,7 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
       terrain_query(s, e.band, cand[q].p[0], cand[q].p[1], &h, cn[q]);
       cphi[q] = (cand[q].p[2] - h) * cn[q][2] - krad;
     }
-    for (int b = 0; b < NB; b++) {
+    for (int b = 0; b < NBR; b++) {
       int pick = b;                                   // body_contacts 3: slot b is candidate b
       if (!all_bodies) {                              // 1 / 2: the deepest candidate, ties to the earlier one
         pick = 0;
@@ -713,7 +713,7 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
     for (int r = 0; r < NR; r++) lam_start[r] = lam_of(r);
     for (int l = 0; l < 4; l++) {
       auto body_rows = [&]() {   // the leg's body rows, after its foot rows (or alone when the foot is off the ground)
-        for (int b = 0; b < NB; b++) {
+        for (int b = 0; b < NBR; b++) {
           const int rk = body_row(l, b);
           if (!kactive[rk]) continue;
           T lk = klam[rk] - (u[rk] - target[rk]) / A[rk][rk];
