@@ -388,11 +388,11 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
 #pragma unroll
       for (int k = 1; k < 6; k++) c.fmac_rbcast(Ak[lp], Z[k], Z[k], 4 * lp + 3);
     }
-    F own = c.qb(hj[0], 3) * Jl0;
-    c.fmac_qb(own, hj[1], Jl1, 3);
-    c.fmac_qb(own, hj[2], Jl2, 3);
+    F ownk = c.qb(hj[0], 3) * Jl0;
+    c.fmac_qb(ownk, hj[1], Jl1, 3);
+    c.fmac_qb(ownk, hj[2], Jl2, 3);
 #pragma unroll
-    for (int lp = 0; lp < 4; lp++) Ak[lp] = Ak[lp] + ownl[lp] * own;
+    for (int lp = 0; lp < 4; lp++) Ak[lp] = Ak[lp] + ownl[lp] * ownk;
   }
   F Add = hj[0] * Jl0 + hj[1] * Jl1 + hj[2] * Jl2;              // own diagonal
   Add = Add + dot(W{{Z[0], Z[1], Z[2]}, {Z[3], Z[4], Z[5]}}, W{{Z[0], Z[1], Z[2]}, {Z[3], Z[4], Z[5]}});
