@@ -1485,7 +1485,7 @@ __global__ void __launch_bounds__(256) k_count_uncached(KCfg K, DevState D, unsi
   for (int env = threadIdx.x; env < K.n_env; env += 256) n += D.cache_ok[env] ? 0u : 1u;
   part[threadIdx.x] = n;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (unsigned s = 128; s > 0; s >>= 1) {
     if (threadIdx.x < s) part[threadIdx.x] += part[threadIdx.x + s];
     __syncthreads();
   }
@@ -1567,7 +1567,6 @@ extern "C" int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* st
   // 3. the part after the settle: control state, episode accumulators, first observation
   const dim3 g16((h->N + 3) / 4), g4(grid_for(h)), gc((4 * h->N + 255) / 256), ge((h->N + 255) / 256);
   hipStream_t s = (hipStream_t)stream;
-  const bool flat = h->K.terrain == 0;
   if (h->lanes == 16) {
     LAUNCH16(k_settle16, g16, s, h->K, h->D, mask);
   } else {
@@ -1694,7 +1693,6 @@ extern "C" int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float
     // fused: up to ROLLOUT_CHUNK control steps per launch, everything in registers in between
     constexpr int ROLLOUT_CHUNK = 50;
     const dim3 g16((h->N + 3) / 4), g4(grid_for(h));
-    const bool flat = h->K.terrain == 0;
     hipStream_t s = (hipStream_t)stream;
     for (int done_steps = 0; done_steps < n_steps; done_steps += ROLLOUT_CHUNK) {
       const int m = n_steps - done_steps < ROLLOUT_CHUNK ? n_steps - done_steps : ROLLOUT_CHUNK;
