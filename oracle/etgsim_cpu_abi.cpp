@@ -28,6 +28,10 @@ struct CpuHandle {
   std::vector<double> ret, alive;
   std::vector<int32_t> len;
   std::vector<double> dbuf;   // conversion scratch
+  // etg_prepare_next_dynamics, sequential restatement: rows waiting for each robot's next episode (installed by its next reset;
+  // the settle is simulated then -- on the device it ran ahead of time on scratch state, with the same result)
+  std::vector<float> next_dyn;
+  std::vector<uint8_t> next_ok;
 };
 CpuHandle* H(EtgHandle* h) { return reinterpret_cast<CpuHandle*>(h); }
 
@@ -76,6 +80,9 @@ int etg_set_params(EtgHandle* h, const float* dyn, const float* etg_w, const flo
   if (dyn) d = to_d(dyn, N * ETG_DYN_DIM);
   if (etg_w) { w = to_d(etg_w, (per_env ? N : 1) * 3 * ETG_RBF_H); b = to_d(etg_b, (per_env ? N : 1) * 3); }
   etgo_set_params64(H(h)->sim, dyn ? d.data() : nullptr, etg_w ? w.data() : nullptr, etg_w ? b.data() : nullptr, per_env, mask);
+  if (dyn && !H(h)->next_ok.empty())     // new rows for a robot drop the ones waiting for its next episode
+    for (size_t i = 0; i < N; i++)
+      if (!mask || mask[i]) H(h)->next_ok[i] = 0;
   return ETG_OK;
 }
 
@@ -112,6 +119,16 @@ int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void*) {
   if (!h) return cfail(ETG_ERR_BAD_ARG, "null handle");
   if (!obs) return cfail(ETG_ERR_BAD_ARG, "etg_reset: obs is null");
   CpuHandle* c = H(h);
+  if (!c->next_ok.empty()) {   // rows prepared for the next episode of the robots being reset: this reset starts it
+    std::vector<uint8_t> take(c->N, 0);
+    bool any = false;
+    for (int i = 0; i < c->N; i++)
+      if ((!mask || mask[i]) && c->next_ok[i]) { take[i] = 1; c->next_ok[i] = 0; any = true; }
+    if (any) {
+      std::vector<double> d = to_d(c->next_dyn.data(), (size_t)c->N * ETG_DYN_DIM);
+      etgo_set_params64(c->sim, d.data(), nullptr, nullptr, 0, take.data());
+    }
+  }
   std::vector<double> o((size_t)c->N * ETG_OBS_DIM, 0.0);
   etgo_reset64(c->sim, mask, o.data(), 1);
   for (int i = 0; i < c->N; i++) {
@@ -249,8 +266,25 @@ int etg_policy_sample(EtgPolicy*, const float*, int, const float*, float, int, f
 void etg_policy_destroy(EtgPolicy*) {}
 int etg_rollout_policy(EtgHandle*, EtgPolicy*, int, float, int, int, float*, float*, int32_t*, void*) { CPU_UNAVAILABLE("etg_rollout_policy"); }
 int etg_rollout_actions(EtgHandle*, const float*, int, float*, float*, float*, float*, float*, uint8_t*, float*, int32_t*, void*) { CPU_UNAVAILABLE("etg_rollout_actions"); }
-int etg_prepare_next_dynamics(EtgHandle*, const float*, const uint8_t*, void*) { CPU_UNAVAILABLE("etg_prepare_next_dynamics"); }
-int etg_next_dynamics_pending(EtgHandle*, uint8_t*, void*) { CPU_UNAVAILABLE("etg_next_dynamics_pending"); }
+int etg_prepare_next_dynamics(EtgHandle* h, const float* dyn, const uint8_t* mask, void*) {
+  if (!h) return cfail(ETG_ERR_BAD_ARG, "null handle");
+  if (!dyn) return cfail(ETG_ERR_BAD_ARG, "etg_prepare_next_dynamics: dyn is null");
+  CpuHandle* c = H(h);
+  if (!c->was_reset) return cfail(ETG_ERR_STATE, "etg_prepare_next_dynamics: needs a full etg_reset first");
+  if (c->next_ok.empty()) { c->next_ok.assign(c->N, 0); c->next_dyn.assign((size_t)c->N * ETG_DYN_DIM, 0.0f); }
+  for (int i = 0; i < c->N; i++) {
+    if (mask && !mask[i]) continue;
+    for (int k = 0; k < ETG_DYN_DIM; k++) c->next_dyn[(size_t)i * ETG_DYN_DIM + k] = dyn[(size_t)i * ETG_DYN_DIM + k];
+    c->next_ok[i] = 1;
+  }
+  return ETG_OK;
+}
+int etg_next_dynamics_pending(EtgHandle* h, uint8_t* pending, void*) {
+  if (!h || !pending) return cfail(ETG_ERR_BAD_ARG, "etg_next_dynamics_pending: bad arguments");
+  CpuHandle* c = H(h);
+  for (int i = 0; i < c->N; i++) pending[i] = c->next_ok.empty() ? 0 : c->next_ok[i];
+  return ETG_OK;
+}
 int etg_rollout_policy_record(EtgHandle*, EtgPolicy*, int, float, int, int, float*, const float*, float*, float*, float*, uint8_t*, float*, int32_t*, void*) { CPU_UNAVAILABLE("etg_rollout_policy_record"); }
 int etg_fit_etg(const double*, int, const double*, const double*, double, double, double, double, double, int, double*, double*, void*) { CPU_UNAVAILABLE("etg_fit_etg"); }
 

@@ -293,3 +293,54 @@ def test_cpu_build_of_the_same_abi_runs_config_1(golden):
     # device-only entry points say so
     assert lib.etg_random_pushes(h, C.c_uint64(0), C.c_float(0.1), 1, C.c_float(1), C.c_float(2), None) == -5
     lib.etg_destroy(h)
+
+
+def test_cpu_abi_restatement_of_the_prepared_next_dynamics():
+    """etg_prepare_next_dynamics / etg_next_dynamics_pending on the CPU build of the ABI (sequential restatement: the rows wait per
+    robot and the robot's next reset installs them, settle simulated then): a robot that finishes inside etg_step_autoreset
+    restarts on the prepared rows -- its restart observation and the steps after it equal a handle that was given these rows
+    directly; robots outside the mask keep theirs; new rows through etg_set_params drop the pending ones."""
+    lib = _cpu_abi()
+    lib.etg_prepare_next_dynamics.argtypes = [C.c_void_p] * 4
+    lib.etg_next_dynamics_pending.argtypes = [C.c_void_p] * 3
+    lib.etg_step_autoreset.argtypes = [C.c_void_p] * 8
+    p = lambda a: a.ctypes.data_as(C.c_void_p)
+    n = 3
+    cfg, model = A.default_config(n, settle_ticks=120), A.default_model()
+    mk = lambda: C.c_void_p()
+    h, twin = mk(), mk()
+    assert lib.etg_create(C.byref(cfg), C.byref(model), -1, C.byref(h)) == 0
+    assert lib.etg_create(C.byref(cfg), C.byref(model), -1, C.byref(twin)) == 0
+    obs, rew, done = np.zeros((n, 49), np.float32), np.zeros(n, np.float32), np.zeros(n, np.uint8)
+    obs_t = np.zeros_like(obs)
+    rows = np.tile(A.default_dynamic_row(), (n, 1)).astype(np.float32)
+    rows[:, 2] *= np.array([1.3, 0.8, 1.1], np.float32)         # trunk masses for the next episodes
+    assert lib.etg_prepare_next_dynamics(h, p(rows), None, None) == -5          # before the first reset
+    assert lib.etg_reset(h, None, p(obs), None) == 0
+    mask = np.array([1, 1, 0], np.uint8)
+    assert lib.etg_prepare_next_dynamics(h, p(rows), p(mask), None) == 0
+    pend = np.zeros(n, np.uint8)
+    assert lib.etg_next_dynamics_pending(h, p(pend), None) == 0 and pend.tolist() == [1, 1, 0]
+    df = np.array([1, 0, 1], np.uint8)                                           # robots 0 and 2 finish now
+    assert lib.etg_step_autoreset(h, None, p(df), p(obs), p(rew), p(done), None, None) == 0
+    assert done.tolist() == [1, 0, 1]
+    lib.etg_next_dynamics_pending(h, p(pend), None)
+    assert pend.tolist() == [0, 1, 0]                                            # robot 0 consumed its rows, robot 1 still waits
+    # the twin gets robot 0's rows directly (robots 1, 2: the default rows)
+    rows_t = np.tile(A.default_dynamic_row(), (n, 1)).astype(np.float32)
+    rows_t[0] = rows[0]
+    m0 = np.array([1, 0, 0], np.uint8)          # (masked: the others keep the handle's own fp64 defaults, as in `h`)
+    assert lib.etg_set_params(twin, p(rows_t), None, None, 0, p(m0), None) == 0
+    assert lib.etg_reset(twin, None, p(obs_t), None) == 0
+    assert np.array_equal(obs[0], obs_t[0]) and np.array_equal(obs[2], obs_t[2])  # restart rows: prepared rows / unchanged rows
+    o2, ot2 = np.zeros_like(obs), np.zeros_like(obs)
+    for k in range(5):
+        lib.etg_step(h, None, None, p(o2), p(rew), p(done), None, None)
+        lib.etg_step(twin, None, None, p(ot2), p(rew), p(done), None, None)
+    assert np.array_equal(o2[0], ot2[0]) and np.array_equal(o2[2], ot2[2])
+    # explicit new rows for robot 1 drop its pending ones
+    m1 = np.array([0, 1, 0], np.uint8)
+    assert lib.etg_set_params(h, p(rows_t), None, None, 0, p(m1), None) == 0
+    lib.etg_next_dynamics_pending(h, p(pend), None)
+    assert pend.tolist() == [0, 0, 0]
+    lib.etg_destroy(h); lib.etg_destroy(twin)
