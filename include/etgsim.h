@@ -123,7 +123,7 @@ typedef struct EtgConfig {
   double sim_dt;           /* 0.002                                            */
   double erp;              /* Baumgarte factor for penetrating contacts (0.2)  */
   double contact_margin;   /* speculative contact distance (0.02)             */
-  double warmstart;        /* impulse warm-start factor (0.85)                */
+  double warmstart;        /* warm-start factor of the normal impulses (pybullet's server: 0.1; Bullet's own default 0.85) */
   double torque_limit;     /* <=0: none (A1 passes none, a1.py:256-274)        */
   double etg_T, etg_T2, etg_amp, etg_sigma_sq, etg_phase[2]; /* train.py:296-297 */
   double etg_dt;           /* control period 0.026                             */
@@ -193,6 +193,18 @@ typedef struct EtgConfig {
    * control-latency observation (minitaur.py:1172-1193) -- instead of the current ones.  0 (the reference's default, A1
    * passes none) = the true state.  Applies to every sub-step, the reset settle included.                            */
   double pd_latency;
+  /* Warm start of a foot's two friction rows: their impulses of the previous tick times this factor start the solve.  0 (the
+   * default) = Bullet's multibody solver, which warm-starts the normal row only (with `warmstart`) and restarts friction rows
+   * from zero.                                                                                                        */
+  double warmstart_friction;
+  /* Added to a contact's distance before the velocity target is formed (Bullet: penetration = distance + m_linearSlop;
+   * pybullet's physics server sets the slop to 1e-5 m, the default of default_config).                                */
+  double contact_slop;
+  /* Combined coefficient of restitution of foot and ground (SetFootRestitution, minitaur.py:1112-1122; Bullet multiplies the
+   * two bodies' coefficients, so with the reference's ground plane at its default 0 the product is 0 = the default here):
+   * when a foot approaches the ground faster than Bullet's restitution velocity threshold (0.2 m/s) at the start of a tick,
+   * its normal row's velocity target is raised by restitution x the approach speed.                                   */
+  double foot_restitution;
 } EtgConfig;
 
 typedef struct EtgHandle EtgHandle;

@@ -557,9 +557,11 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
   }
   // rows 0..11: feet (n, t1, t2 per leg); then the frictionless body rows (cfg.body_contacts): one per leg (rows 12..15) for
   // body_contacts 1 / 2, three per leg (rows 12 + 3 l + b: knee, shin midpoint, trunk corner) for body_contacts 3
-  constexpr int NRMAX = 24;
+  // then 12 joint-limit rows (cfg.joint_limits), one per joint, row NRC + j
+  constexpr int NRMAX = 36;
   const bool all_bodies = s.cfg.body_contacts == 3;
-  const int NR = all_bodies ? 24 : 16;
+  const int NRC = all_bodies ? 24 : 16;                    // contact rows
+  const int NR = NRC + 12;
   const int NBR = all_bodies ? 3 : 1;                      // body rows per leg
   auto body_row = [&](int l, int b) { return all_bodies ? 12 + 3 * l + b : 12 + l; };
   T J[NRMAX][NV];
@@ -611,9 +613,23 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
       }
     }
     // normal target velocity: speculative for a gap, Baumgarte for penetration
-    target[3 * l] = (phi > 0) ? -phi / dt : -T(s.cfg.erp) * phi / dt;
+    // (Bullet: penetration = distance + m_linearSlop; pybullet's server sets the slop to 1e-5 m: cfg.contact_slop)
+    const T pen = phi + T(s.cfg.contact_slop);
+    target[3 * l] = (pen > 0) ? -pen / dt : -T(s.cfg.erp) * pen / dt;
     target[3 * l + 1] = 0; target[3 * l + 2] = 0;
-    for (int k = 0; k < 3; k++) e.lam[3 * l + k] *= T(s.cfg.warmstart);
+    // restitution (cfg.foot_restitution = the COMBINED coefficient of foot and ground, Bullet multiplies the two bodies'):
+    // an approach faster than Bullet's restitutionVelocityThreshold (0.2 m/s) at the start of the tick adds e * (-u_n)
+    if (s.cfg.foot_restitution > 0) {
+      T un0 = 0;
+      const T* row = J[3 * l];
+      for (int k = 0; k < 3; k++) un0 += row[k] * e.wb[k] + row[3 + k] * e.vb[k];
+      for (int j = 0; j < 12; j++) un0 += row[6 + j] * e.qd[j];
+      if (un0 < -T(0.2)) target[3 * l] += T(s.cfg.foot_restitution) * (-un0);
+    }
+    // warm start: the previous tick's normal impulse x cfg.warmstart, the friction impulses x cfg.warmstart_friction
+    // (Bullet's multibody solver restarts friction rows from zero: setupMultiBodyContactConstraint, isFriction ? 0 : ...)
+    e.lam[3 * l] *= T(s.cfg.warmstart);
+    for (int k = 1; k < 3; k++) e.lam[3 * l + k] *= T(s.cfg.warmstart_friction);
   }
   // body contacts (cfg.body_contacts): frictionless rows on spheres of knee_radius.  1: one row per leg on a sphere at the knee
   // (the calf joint origin, carried by the thigh: the calf joint does not move it).  2: one row per leg on the DEEPEST of three
@@ -673,8 +689,25 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
         cross(axw, rj, cr);
         row[5 + bd] = dot3(n, cr);
       }
-      target[rk] = (phi > 0) ? -phi / dt : -T(s.cfg.erp) * phi / dt;
+      const T pen = phi + T(s.cfg.contact_slop);
+      target[rk] = (pen > 0) ? -pen / dt : -T(s.cfg.erp) * pen / dt;
     }
+  }
+  // joint-limit rows (cfg.joint_limits; bounds of a1.py:186-195 = the URDF limits Bullet turns into btMultiBodyJointLimitConstraint
+  // rows): a joint at or beyond a bound gets a unilateral row along the joint coordinate, pushing back into the range, with the
+  // velocity target erp * violation / dt; no warm start.  Solved INSIDE the sweeps, before the contact rows (Bullet's
+  // solveSingleIteration: non-contact constraints, then normal contacts, then friction).
+  for (int j = 0; j < 12; j++) {
+    if (!s.cfg.joint_limits) break;
+    const T lo = T(s.cfg.joint_lower[j % 3]), hi = T(s.cfg.joint_upper[j % 3]);
+    T sgn = 0, viol = 0;
+    if (e.q[j] >= hi) { sgn = -1; viol = e.q[j] - hi; }
+    else if (e.q[j] <= lo) { sgn = 1; viol = lo - e.q[j]; }
+    if (sgn == 0) continue;
+    const int rk = NRC + j;
+    kactive[rk] = 1;
+    J[rk][6 + j] = sgn;
+    target[rk] = T(s.cfg.erp) * viol / dt;
   }
   auto row_active = [&](int r) { return r < 12 ? active[r / 3] : kactive[r]; };
   auto lam_of = [&](int r) -> T& { return r < 12 ? e.lam[r] : klam[r]; };
@@ -711,27 +744,38 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
   for (int it = 0; it < s.cfg.solver_iters; it++) {
     T lam_start[NRMAX];
     for (int r = 0; r < NR; r++) lam_start[r] = lam_of(r);
+    // One sweep in the order of Bullet's btMultiBodyConstraintSolver::solveSingleIteration (what stepSimulation() runs,
+    // minitaur.py:244): (1) the non-contact constraints = joint-limit rows, (2) every NORMAL contact row -- feet FR, FL, RR, RL,
+    // then the body rows -- (3) the friction rows of every foot, their limits taken from the normal impulse of this sweep.
+    auto unilateral = [&](int rk) {
+      T lk = klam[rk] - (u[rk] - target[rk]) / A[rk][rk];
+      if (lk < 0) lk = 0;
+      apply(rk, lk - klam[rk]);
+      klam[rk] = lk;
+    };
+    for (int j = 0; j < 12; j++)
+      if (kactive[NRC + j]) unilateral(NRC + j);
     for (int l = 0; l < 4; l++) {
-      auto body_rows = [&]() {   // the leg's body rows, after its foot rows (or alone when the foot is off the ground)
-        for (int b = 0; b < NBR; b++) {
-          const int rk = body_row(l, b);
-          if (!kactive[rk]) continue;
-          T lk = klam[rk] - (u[rk] - target[rk]) / A[rk][rk];
-          if (lk < 0) lk = 0;
-          apply(rk, lk - klam[rk]);
-          klam[rk] = lk;
-        }
-      };
-      if (!active[l]) { body_rows(); continue; }
-      int r0 = 3 * l;
-      // normal
+      if (!active[l]) continue;
+      const int r0 = 3 * l;
       T ln = e.lam[r0] - (u[r0] - target[r0]) / A[r0][r0];
       if (ln < 0) ln = 0;
       apply(r0, ln - e.lam[r0]);
       e.lam[r0] = ln;
-      // tangents: both candidates from the SAME velocities (the two directions of a foot are solved as one block: their
-      // mutual coupling A[t1][t2] is a small anisotropy term), the pair projected on the friction disc mu ln (or, with
-      // friction_model 1, each clamped on its own), then both changes applied
+    }
+    for (int l = 0; l < 4; l++)
+      for (int b = 0; b < NBR; b++)
+        if (kactive[body_row(l, b)]) unilateral(body_row(l, b));
+    for (int l = 0; l < 4; l++) {
+      if (!active[l]) continue;
+      const int r0 = 3 * l;
+      const T ln = e.lam[r0];
+      // Bullet solves a contact's friction rows only while its normal impulse is positive (`if (totalImpulse > 0)`): a foot
+      // whose normal impulse is zero keeps the friction impulses it has
+      if (!(ln > 0)) continue;
+      // both candidates from the SAME velocities, the pair projected on the friction disc mu ln, then both changes applied:
+      // the implicit cone friction of pybullet's default (resolveConeFrictionConstraintRows; enableConeFriction = 1).
+      // friction_model 1: each direction clamped on its own to +-mu ln (the pyramid of enableConeFriction = 0).
       T lim = e.mu * ln;
       T cand[3];
       for (int k = 1; k < 3; k++) cand[k] = e.lam[r0 + k] - u[r0 + k] / A[r0 + k][r0 + k];
@@ -751,7 +795,6 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
         apply(r0 + k, cand[k] - e.lam[r0 + k]);
         e.lam[r0 + k] = cand[k];
       }
-      body_rows();
     }
     sweeps++;
     if (res_thr > 0) {
@@ -771,37 +814,6 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
     for (int k = 0; k < NV; k++) vel[k] += MiJt[r][k] * lam_of(r);
   }
   for (int l = 0; l < 4; l++) e.contact[l] = active[l] && e.lam[3 * l] > 0;
-
-  // ---- joint-limit stops (EtgConfig.joint_limits; bounds of a1.py:186-195).  This repo's model:
-  // a joint outside [lower, upper] whose post-contact velocity does not yet bring it back at the Baumgarte rate
-  // erp * penetration / dt receives the joint-space impulse that does, p_j = (target - qd_j) / (M^-1)_jj; all
-  // violated joints are treated at once from the same velocities (one Jacobi pass), and the impulses act on the whole
-  // multibody through M^-1 (reaction on the trunk and the other joints included).
-  if (s.cfg.joint_limits) {
-    T p[NV];
-    bool any = false;
-    for (int i = 0; i < NV; i++) p[i] = 0;
-    for (int j = 0; j < 12; j++) {
-      const T lo = T(s.cfg.joint_lower[j % 3]), hi = T(s.cfg.joint_upper[j % 3]);
-      const T qj = e.q[j], vj = vel[6 + j];
-      T tgt;
-      bool hit = false;
-      if (qj > hi) { tgt = -T(s.cfg.erp) * (qj - hi) / dt; hit = vj > tgt; }
-      else if (qj < lo) { tgt = -T(s.cfg.erp) * (qj - lo) / dt; hit = vj < tgt; }
-      if (!hit) continue;
-      T ej[NV], col[NV];
-      for (int i = 0; i < NV; i++) ej[i] = 0;
-      ej[6 + j] = 1;
-      chol_solve(ej, col);
-      p[6 + j] = (tgt - vj) / col[6 + j];
-      any = true;
-    }
-    if (any) {
-      T dv[NV];
-      chol_solve(p, dv);
-      for (int i = 0; i < NV; i++) vel[i] += dv[i];
-    }
-  }
 
   // ---- integrate (semi-implicit Euler)
   for (int k = 0; k < 3; k++) { e.wb[k] = vel[k]; e.vb[k] = vel[3 + k]; }

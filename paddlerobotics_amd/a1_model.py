@@ -87,6 +87,9 @@ class EtgConfig(C.Structure):
         ("solver_residual", C.c_double),
         ("friction_model", C.c_int32),
         ("pd_latency", C.c_double),
+        ("warmstart_friction", C.c_double),
+        ("contact_slop", C.c_double),
+        ("foot_restitution", C.c_double),
     ]
 
 
@@ -198,7 +201,8 @@ def solver_rule(solver_iters=None, solver_residual=None):
 
 def default_config(num_envs, *, action_repeat=13, sim_dt=0.002, settle_ticks=500, solver_iters=None, solver_residual=None,
                    enable_action_interp=False, enable_action_filter=False, normal=1, terrain=0,
-                   erp=0.2, contact_margin=0.02, warmstart=0.85, torque_limit=0.0,
+                   erp=0.2, contact_margin=0.02, warmstart=0.1, warmstart_friction=0.0, contact_slop=1e-5,
+                   foot_restitution=0.0, torque_limit=0.0,
                    ETG_T=0.5, ETG_T2=0.5, etg_amp=0.2, etg_sigma_sq=0.04,
                    etg_phase=(-math.pi / 2, 0.0), reward_param=None, reward_p=5.0, vel_d=0.5,
                    heightfield=None, lanes_per_robot=0, motor_mode=0, clip_motor_commands=0.0,
@@ -217,6 +221,7 @@ def default_config(num_envs, *, action_repeat=13, sim_dt=0.002, settle_ticks=500
     c.terrain = int(terrain)
     c.sim_dt, c.erp, c.contact_margin = sim_dt, erp, contact_margin
     c.warmstart, c.torque_limit = warmstart, torque_limit
+    c.warmstart_friction, c.contact_slop, c.foot_restitution = warmstart_friction, contact_slop, foot_restitution
     c.etg_T, c.etg_T2, c.etg_amp, c.etg_sigma_sq = ETG_T, ETG_T2, etg_amp, etg_sigma_sq
     c.etg_phase[0], c.etg_phase[1] = etg_phase
     c.etg_dt = sim_dt * action_repeat

@@ -302,7 +302,8 @@ def _contact_kkt(mu, kick, solver_iters=3000, seed=2):
         Jc = O.leg_jacobian(ql, l) + np.stack([np.cross(z1, off), np.cross(z2, off), np.cross(z2, off)], axis=1)
         u = R0 @ (vb + np.cross(wb, pf + off) + Jc @ qd[3 * l:3 * l + 3])
         phi = s0[2] + (R0 @ pf)[2] - A.FOOT_RADIUS
-        tgt = -phi / cfg.sim_dt if phi > 0 else -cfg.erp * phi / cfg.sim_dt
+        pen = phi + cfg.contact_slop          # Bullet: penetration = distance + m_linearSlop
+        tgt = -pen / cfg.sim_dt if pen > 0 else -cfg.erp * pen / cfg.sim_dt
         out.append((lam[3 * l], lam[3 * l + 1:3 * l + 3], u, tgt, phi < cfg.contact_margin))
     return out
 
