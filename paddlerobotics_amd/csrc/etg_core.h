@@ -597,21 +597,30 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   V vc = vbs + cross(wbs, rc) + qds1 * k1 + qds2 * k2 + qds3 * k3;
   F u0 = actf * dot(dn, vc), u1 = actf * dot(d1, vc), u2 = actf * dot(d2, vc);
   const F idt(1.0f / K.dt);
-  F tgt = sel_(phi > zero, -(phi * idt), -(F(K.erp) * phi * idt));
-  // warm start (Bullet-style 0.85 factor); inactive feet forget their impulse
-  F l0 = actf * F(K.warmstart) * L.lam[0], l1 = actf * F(K.warmstart) * L.lam[1], l2 = actf * F(K.warmstart) * L.lam[2];
+  const F pen = phi + F(K.slop);                                  // Bullet: penetration = distance + m_linearSlop
+  F tgt = sel_(pen > zero, -(pen * idt), -(F(K.erp) * pen * idt));
+  if (!Ctx::kPlain) {
+    // EtgConfig.foot_restitution: a foot that approaches faster than 0.2 m/s at the START of the tick bounces (see physics_tick16)
+    const V vc0 = L.vb + cross(L.wb, rc) + L.qd[0] * k1 + L.qd[1] * k2 + L.qd[2] * k3;
+    const F un0 = actf * dot(dn, vc0);
+    tgt = tgt + sel_(un0 < F(-0.2f), -(F(K.restitution) * un0), zero);
+  }
+  // warm start: the normal impulse x K.warmstart, the friction impulses x K.warmstart_t (Bullet's multibody solver restarts
+  // them from zero); inactive feet forget their impulse
+  F l0 = actf * F(K.warmstart) * L.lam[0], l1 = actf * F(K.warmstart_t) * L.lam[1], l2 = actf * F(K.warmstart_t) * L.lam[2];
   // the body rows: their own points' velocities, Baumgarte / speculative target like the foot's normal row, no warm start;
-  // kbf[b][x]: A[3+b][x] / A[3+b][3+b] for the rows x solved earlier in the leg's turn (foot rows 0..2, body rows 3..2+b)
-  F ub[NBA], lb[NBA], cb[NBA], kbf[NBA][3 + NBA];
+  // kbf[b][x]: A[3+b][3+x] / A[3+b][3+b] for the body rows x < b solved earlier in the leg's turn
+  F ub[NBA], lb[NBA], cb[NBA], kbf[NBA][NBA];
 #pragma unroll
   for (int b = 0; b < NB; b++) {
     const V vcb = vbs + cross(wbs, rcb[b]) + qds1 * kb1[b] + qds2 * kb2[b] + qds3 * kb3[b];
     ub[b] = actbf[b] * dot(dnb[b], vcb);
     lb[b] = zero;
-    const F tgtb = sel_(phib[b] > zero, -(phib[b] * idt), -(F(K.erp) * phib[b] * idt));
+    const F penb = phib[b] + F(K.slop);
+    const F tgtb = sel_(penb > zero, -(penb * idt), -(F(K.erp) * penb * idt));
     cb[b] = tgtb * iAb[b];
 #pragma unroll
-    for (int x = 0; x < 3 + b; x++) kbf[b][x] = Aown[3 + b][x] * iAb[b];
+    for (int x = 0; x < b; x++) kbf[b][x] = Aown[3 + b][3 + x] * iAb[b];
   }
 #pragma unroll
   for (int j = 0; j < 4; j++) {
@@ -623,57 +632,119 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
     for (int b = 0; b < NB; b++) ub[b] = ub[b] + A[j][3 + b][0] * b0 + A[j][3 + b][1] * b1 + A[j][3 + b][2] * b2;
   }
   c.phase(7);
-  // ---- projected Gauss-Seidel: feet in lane order, rows (n, t1, t2), disc projection.
-  // The serial chain of a turn is what bounds this loop, so the row updates are written with the
-  // impulse history folded into per-lane constants (k10 = A10/A11, ...):
-  //   ln  = max(0, l0 - (u0 - tgt)/A00)
-  //   lt1 = l1 - (u1 + A10 (ln - l0))/A11                    (sequential within the foot)
-  //   lt2 = l2 - (u2 + A20 (ln - l0) + A21 (lt1 - l1))/A22
-  //   (lt1, lt2) *= min(1, mu ln / |lt|)
-  // and lane j's raw deltas are broadcast unmasked: an inactive foot has iA = 0 and l = 0, which
+  // ---- projected Gauss-Seidel in the order of Bullet's btMultiBodyConstraintSolver::solveSingleIteration (the oracle's
+  // physics_tick states it): per sweep (1) the joint-limit rows, (2) the NORMAL rows -- feet in lane order, then the body
+  // rows, leg by leg --, (3) the friction rows of the feet in lane order: both candidates of a foot from the same
+  // velocities, the pair projected on the disc mu ln (friction_model 1: each clamped on its own), skipped while the foot's
+  // normal impulse is not positive.  Lane j's raw deltas are broadcast unmasked: an inactive foot has iA = 0 and l = 0, which
   // makes its deltas exact zeros.
-  // The sweeps read iA*, k*, c0, mu through the variables below: under the residual stopping rule a converged robot is
-  // FROZEN for the sweeps its wave neighbours still need (iA = k = c0 = 0: every candidate is the current impulse, exact
+  // The sweeps read iA*, c0, mu through the variables below: under the residual stopping rule a converged robot is
+  // FROZEN for the sweeps its wave neighbours still need (iA = c0 = 0: every candidate is the current impulse, exact
   // zero deltas; mu = 1e30: the cone projection is the identity) -- see physics_tick16.
   F mu = tp.mu;
-  F k10 = Aown[1][0] * iA1, k20 = Aown[2][0] * iA2, c0 = tgt * iA0;
+  F c0 = tgt * iA0;
   F own[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) own[j] = sel_(c.lane_is(j), one, zero);
+  // ---- joint-limit rows (EtgConfig.joint_limits; see physics_tick16): this lane owns the rows of ITS three joints
+  bool anyj = false;
+  F jactf[3] = {zero, zero, zero};
+  if (K.jlim) {   // (compiled into the PLAIN instantiations too: the stops are on by default)
+    auto anyhit = c.lane_is(0) && !c.lane_is(0);   // all-false mask
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      const auto hit = (L.q[j] >= F(K.jhi[j])) || (L.q[j] <= F(K.jlo[j]));
+      jactf[j] = sel_(hit, one, zero);
+      anyhit = anyhit || hit;
+    }
+    anyj = c.any(anyhit);
+  }
+  // solve + apply, instantiated with and without the joint rows: without them their variables are compile-time zeros
+  auto finish_tick = [&](auto joints_tag) {
+  constexpr bool joints = decltype(joints_tag)::value;
+  const F Hinv[3][3] = {{Hi11, Hi12, Hi13}, {Hi12, Hi22, Hi23}, {Hi13, Hi23, Hi33}};
+  F sgn[3] = {zero, zero, zero}, lamq[3] = {zero, zero, zero}, iAq[3] = {zero, zero, zero}, c0q[3] = {zero, zero, zero};
+  W zj[3];
+  if (joints) {
+    const W Pc[3] = {P1, P2, P3};
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+      F z6[6] = {Pc[j].a.x, Pc[j].a.y, Pc[j].a.z, Pc[j].l.x, Pc[j].l.y, Pc[j].l.z};
+      fwd6(s, z6);
+      zj[j] = cmul(W{{z6[0], z6[1], z6[2]}, {z6[3], z6[4], z6[5]}}, sqv);
+      const F lo(K.jlo[j]), hi(K.jhi[j]);
+      sgn[j] = jactf[j] * sel_(L.q[j] >= hi, -one, one);
+      const F viol = fmaxf_(L.q[j] - hi, lo - L.q[j]);
+      iAq[j] = jactf[j] * rcp_(Hinv[j][j] + dot(zj[j], zj[j]));
+      c0q[j] = (F(K.erp) * viol * idt) * iAq[j];
+    }
+  }
   // instantiated per friction model (a compile-time constant inside the sweeps): see physics_tick16
   auto solve = [&](auto pyramid_tag) {
     constexpr bool pyramid = decltype(pyramid_tag)::value;
+    F iAqe[3] = {iAq[0], iAq[1], iAq[2]}, c0qe[3] = {c0q[0], c0q[1], c0q[2]};
+    auto joint_phase = [&]() {
+      // ZL = sum over the robot's rows of lam_r Z_r (the joint rows' Z-vectors are -sgn zj)
+      W zs = l0 * Z[0] + l1 * Z[1] + l2 * Z[2];
+#pragma unroll
+      for (int b = 0; b < NB; b++) zs = zs + lb[b] * Z[3 + b];
+#pragma unroll
+      for (int i = 0; i < 3; i++) zs = zs - (sgn[i] * lamq[i]) * zj[i];
+      F zl[6] = {c.qsum(zs.a.x), c.qsum(zs.a.y), c.qsum(zs.a.z), c.qsum(zs.l.x), c.qsum(zs.l.y), c.qsum(zs.l.z)};
+      const W zl0 = {{zl[0], zl[1], zl[2]}, {zl[3], zl[4], zl[5]}};
+      F qc[3] = {qds1, qds2, qds3};          // unconstrained joint velocities + the contact impulses' leg part (fixed during the phase)
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        qc[i] = qc[i] + HJ[0][i] * l0 + HJ[1][i] * l1 + HJ[2][i] * l2;
+#pragma unroll
+        for (int b = 0; b < NB; b++) qc[i] = qc[i] + HJ[3 + b][i] * lb[b];
+      }
+      const F lamq0[3] = {lamq[0], lamq[1], lamq[2]};
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+          if (!c.any(own[j] * jactf[i] > F(0.5f))) continue;         // no robot of the wave has this joint at a stop
+          const F qj = qc[i] + Hinv[i][0] * (sgn[0] * lamq[0]) + Hinv[i][1] * (sgn[1] * lamq[1]) + Hinv[i][2] * (sgn[2] * lamq[2]);
+          const W zlw = {{zl[0], zl[1], zl[2]}, {zl[3], zl[4], zl[5]}};
+          const F uq = sgn[i] * (qj - dot(zj[i], zlw));
+          const F dq = own[j] * fmaxf_(-lamq[i], c0qe[i] - uq * iAqe[i]);
+          lamq[i] = lamq[i] + dq;
+          const F sd = -(sgn[i] * dq);
+#pragma unroll
+          for (int k = 0; k < 6; k++) zl[k] = zl[k] + c.qbcast(sd * comp(zj[i], k), j);
+        }
+      // the contact rows see the joint impulses' changes: A[c][q] d lam_q = Z_c . dZL + HJ_c[joint] sgn d lam_q
+      const W dZ = W{{zl[0], zl[1], zl[2]}, {zl[3], zl[4], zl[5]}} - zl0;
+      const F w0 = sgn[0] * (lamq[0] - lamq0[0]), w1 = sgn[1] * (lamq[1] - lamq0[1]), w2 = sgn[2] * (lamq[2] - lamq0[2]);
+      u0 = u0 + (dot(Z[0], dZ) + (HJ[0][0] * w0 + HJ[0][1] * w1 + HJ[0][2] * w2));
+      u1 = u1 + (dot(Z[1], dZ) + (HJ[1][0] * w0 + HJ[1][1] * w1 + HJ[1][2] * w2));
+      u2 = u2 + (dot(Z[2], dZ) + (HJ[2][0] * w0 + HJ[2][1] * w1 + HJ[2][2] * w2));
+#pragma unroll
+      for (int b = 0; b < NB; b++) ub[b] = ub[b] + (dot(Z[3 + b], dZ) + (HJ[3 + b][0] * w0 + HJ[3 + b][1] * w1 + HJ[3 + b][2] * w2));
+    };
     auto pgs_sweep = [&]() {
+      if (joints) joint_phase();
+      // (2) normal rows of the feet: ln = max(0, l0 - (u0 - tgt)/A00), as a change
 #pragma unroll
       for (int j = 0; j < 4; j++) {
-        // normal row, then the two tangent rows as ONE block: both candidates from the velocities after the normal update
-        // (u_t + A_t0 (ln - l0)), the pair projected on the friction disc (friction_model 1: each clamped on its own)
-        F e0 = fmaxf_(-l0, c0 - u0 * iA0), e1, e2;                      // = max(0, l0 + c0 - u0 / A00) - l0
-        F ln = l0 + e0;
-        F lt1 = (l1 - u1 * iA1) - k10 * e0;
-        F lt2 = (l2 - u2 * iA2) - k20 * e0;
-        if (pyramid) {
-          const F lim = mu * ln;
-          e1 = fminf_(fmaxf_(lt1, -lim), lim) - l1;
-          e2 = fminf_(fmaxf_(lt2, -lim), lim) - l2;
-        } else {
-          F sc = fminf_(one, (mu * ln) * rsqrt_((lt1 * lt1 + F(1e-30f)) + lt2 * lt2));
-          e1 = lt1 * sc - l1; e2 = lt2 * sc - l2;
-        }
-        F b0 = c.qbcast(e0, j), b1 = c.qbcast(e1, j), b2 = c.qbcast(e2, j);
-        u0 = u0 + A[j][0][0] * b0 + A[j][0][1] * b1 + A[j][0][2] * b2;
-        u1 = u1 + A[j][1][0] * b0 + A[j][1][1] * b1 + A[j][1][2] * b2;
-        u2 = u2 + A[j][2][0] * b0 + A[j][2][1] * b1 + A[j][2][2] * b2;
-        l0 = l0 + own[j] * e0; l1 = l1 + own[j] * e1; l2 = l2 + own[j] * e2;  // the owner commits
-        if constexpr (knee) {
-          // the leg's body rows come after its foot rows (the oracle's order): each row's velocity with the changes made
-          // earlier in this turn folded in (kbf), clamped at zero impulse
+        const F e0 = fmaxf_(-l0, c0 - u0 * iA0);
+        const F b0 = c.qbcast(e0, j);
+        u0 = u0 + A[j][0][0] * b0; u1 = u1 + A[j][1][0] * b0; u2 = u2 + A[j][2][0] * b0;
+#pragma unroll
+        for (int b = 0; b < NB; b++) ub[b] = ub[b] + A[j][3 + b][0] * b0;
+        l0 = l0 + own[j] * e0;                                           // the owner commits
+      }
+      if constexpr (knee) {
+        // the body rows (normal rows too), leg by leg; within a leg each row sees the changes of the earlier ones (kbf)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
           F eb[NB], bb[NB];
 #pragma unroll
           for (int b = 0; b < NB; b++) {
-            F fold = (kbf[b][0] * e0 + kbf[b][1] * e1) + kbf[b][2] * e2;
+            F fold = zero;
 #pragma unroll
-            for (int x = 0; x < b; x++) fold = fold + kbf[b][3 + x] * eb[x];
+            for (int x = 0; x < b; x++) fold = fold + kbf[b][x] * eb[x];
             eb[b] = fmaxf_(-lb[b], (cb[b] - ub[b] * iAb[b]) - fold);
             bb[b] = c.qbcast(eb[b], j);
           }
@@ -682,13 +753,36 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
             u0 = u0 + A[j][0][3 + b] * bb[b];
             u1 = u1 + A[j][1][3 + b] * bb[b];
             u2 = u2 + A[j][2][3 + b] * bb[b];
-            F acc = (A[j][3 + b][0] * b0 + A[j][3 + b][1] * b1) + A[j][3 + b][2] * b2;
+            F acc = zero;
 #pragma unroll
             for (int x = 0; x < NB; x++) acc = acc + A[j][3 + b][3 + x] * bb[x];
             ub[b] = ub[b] + acc;
             lb[b] = lb[b] + own[j] * eb[b];
           }
         }
+      }
+      // (3) friction rows
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const F lt1 = l1 - u1 * iA1, lt2 = l2 - u2 * iA2;
+        const F lim = mu * l0;
+        F e1, e2;
+        if (pyramid) {
+          e1 = fminf_(fmaxf_(lt1, -lim), lim) - l1;
+          e2 = fminf_(fmaxf_(lt2, -lim), lim) - l2;
+        } else {
+          const F sc = fminf_(one, lim * rsqrt_((lt1 * lt1 + F(1e-30f)) + lt2 * lt2));
+          e1 = lt1 * sc - l1; e2 = lt2 * sc - l2;
+        }
+        const auto grip = l0 > zero;                                     // Bullet: `if (totalImpulse > 0)`
+        e1 = sel_(grip, e1, zero); e2 = sel_(grip, e2, zero);
+        const F b1 = c.qbcast(e1, j), b2 = c.qbcast(e2, j);
+        u0 = u0 + A[j][0][1] * b1 + A[j][0][2] * b2;
+        u1 = u1 + A[j][1][1] * b1 + A[j][1][2] * b2;
+        u2 = u2 + A[j][2][1] * b1 + A[j][2][2] * b2;
+#pragma unroll
+        for (int b = 0; b < NB; b++) ub[b] = ub[b] + A[j][3 + b][1] * b1 + A[j][3 + b][2] * b2;
+        l1 = l1 + own[j] * e1; l2 = l2 + own[j] * e2;
       }
     };
     if (K.res_thr > 0.0f) {
@@ -698,6 +792,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
       F tolb[NBA];
 #pragma unroll
       for (int b = 0; b < NB; b++) tolb[b] = F(K.res_sqrt) * iAb[b];
+      const F tolq[3] = {F(K.res_sqrt) * iAq[0], F(K.res_sqrt) * iAq[1], F(K.res_sqrt) * iAq[2]};
       int it = 0;
       bool more;
       auto sweep_and_test = [&]() {
@@ -705,25 +800,33 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
         F sb[NBA];
 #pragma unroll
         for (int b = 0; b < NB; b++) sb[b] = lb[b];
+        const F sq_[3] = {lamq[0], lamq[1], lamq[2]};
         pgs_sweep();
         it++;
         auto moved = (fabsf_(l0 - s0) > tol0) || (fabsf_(l1 - s1) > tol1) || (fabsf_(l2 - s2) > tol2);
 #pragma unroll
         for (int b = 0; b < NB; b++) moved = moved || (fabsf_(lb[b] - sb[b]) > tolb[b]);
+        if (joints) {
+#pragma unroll
+          for (int i = 0; i < 3; i++) moved = moved || (fabsf_(lamq[i] - sq_[i]) > tolq[i]);
+        }
         const auto live = c.robot_any(moved);
         iA0 = sel_(live, iA0, zero); iA1 = sel_(live, iA1, zero); iA2 = sel_(live, iA2, zero);
-        k10 = sel_(live, k10, zero); k20 = sel_(live, k20, zero);
         c0 = sel_(live, c0, zero);
         mu = sel_(live, mu, F(1e30f));
 #pragma unroll
         for (int b = 0; b < NB; b++) {
           iAb[b] = sel_(live, iAb[b], zero); cb[b] = sel_(live, cb[b], zero);
 #pragma unroll
-          for (int x = 0; x < 3 + b; x++) kbf[b][x] = sel_(live, kbf[b][x], zero);
+          for (int x = 0; x < b; x++) kbf[b][x] = sel_(live, kbf[b][x], zero);
+        }
+        if (joints) {
+#pragma unroll
+          for (int i = 0; i < 3; i++) { iAqe[i] = sel_(live, iAqe[i], zero); c0qe[i] = sel_(live, c0qe[i], zero); }
         }
         more = c.wave_any(live) && it < K.iters;
       };
-      if (Ctx::kPlain) {   // nested forward exits instead of a loop for the first sweeps: see physics_tick16
+      if (Ctx::kPlain && !joints) {   // nested forward exits instead of a loop for the first sweeps: see physics_tick16
         sweep_and_test();
         if (__builtin_expect(more, 1)) { sweep_and_test();
         if (__builtin_expect(more, 1)) { sweep_and_test();
@@ -738,7 +841,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
         do sweep_and_test(); while (more);
       }
       L.sweeps += it;
-    } else if (K.iters == 2) {   // a fixed pair of sweeps, straight-line (see physics_tick16)
+    } else if (K.iters == 2 && !joints) {   // a fixed pair of sweeps, straight-line (see physics_tick16)
       pgs_sweep();
       pgs_sweep();
       L.sweeps += 2;
@@ -758,6 +861,10 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   W zs = l0 * Z[0] + l1 * Z[1] + l2 * Z[2];
 #pragma unroll
   for (int b = 0; b < NB; b++) zs = zs + lb[b] * Z[3 + b];
+  if (joints) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) zs = zs - (sgn[i] * lamq[i]) * zj[i];
+  }
   const W dbs = cmul(W{{c.qsum(zs.a.x), c.qsum(zs.a.y), c.qsum(zs.a.z)}, {c.qsum(zs.l.x), c.qsum(zs.l.y), c.qsum(zs.l.z)}}, sqv);
   F db[6] = {dbs.a.x, dbs.a.y, dbs.a.z, dbs.l.x, dbs.l.y, dbs.l.z};
   bwd6(s, db);
@@ -771,45 +878,16 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   for (int b = 0; b < NB; b++) {
     L.qd[0] = L.qd[0] + HJ[3 + b][0] * lb[b]; L.qd[1] = L.qd[1] + HJ[3 + b][1] * lb[b]; L.qd[2] = L.qd[2] + HJ[3 + b][2] * lb[b];
   }
+  if (joints) {
+    const F sl0 = sgn[0] * lamq[0], sl1 = sgn[1] * lamq[1], sl2 = sgn[2] * lamq[2];
+#pragma unroll
+    for (int i = 0; i < 3; i++) L.qd[i] = L.qd[i] + (Hinv[i][0] * sl0 + Hinv[i][1] * sl1 + Hinv[i][2] * sl2);
+  }
   L.lam[0] = l0; L.lam[1] = l1; L.lam[2] = l2;
   L.contact = sel_(act && (l0 > zero), one, zero);
-  // ---- joint-limit stops (EtgConfig.joint_limits; same model as physics_tick16 and the oracle)
-  if (K.jlim) {   // (compiled into the PLAIN instantiations too: see physics_tick16)
-    F jt[3], hitf[3];
-    auto anyhit = c.lane_is(0) && !c.lane_is(0);   // all-false mask
-#pragma unroll
-    for (int j = 0; j < 3; j++) {
-      const F lo(K.jlo[j]), hi(K.jhi[j]);
-      const F pen = fmaxf_(L.q[j] - hi, zero) + fminf_(L.q[j] - lo, zero);
-      jt[j] = -(F(K.erp) * pen * F(1.0f / K.dt));
-      const auto hit = pen * (L.qd[j] - jt[j]) > zero;
-      hitf[j] = sel_(hit, one, zero);
-      anyhit = anyhit || hit;
-    }
-    if (c.any(anyhit)) {
-      const W Pc[3] = {P1, P2, P3};
-      const F Hd[3] = {Hi11, Hi22, Hi33};
-      F pj[3];
-      W zsum = {{zero, zero, zero}, {zero, zero, zero}};
-#pragma unroll
-      for (int j = 0; j < 3; j++) {
-        F z6[6] = {Pc[j].a.x, Pc[j].a.y, Pc[j].a.z, Pc[j].l.x, Pc[j].l.y, Pc[j].l.z};
-        fwd6(s, z6);
-        const W zj = cmul(W{{z6[0], z6[1], z6[2]}, {z6[3], z6[4], z6[5]}}, sqv);
-        pj[j] = hitf[j] * (jt[j] - L.qd[j]) * rcp_(Hd[j] + dot(zj, zj));
-        zsum = zsum - pj[j] * zj;
-      }
-      const W djs = cmul(W{{c.qsum(zsum.a.x), c.qsum(zsum.a.y), c.qsum(zsum.a.z)}, {c.qsum(zsum.l.x), c.qsum(zsum.l.y), c.qsum(zsum.l.z)}}, sqv);
-      F dj[6] = {djs.a.x, djs.a.y, djs.a.z, djs.l.x, djs.l.y, djs.l.z};
-      bwd6(s, dj);
-      const W dJ = {{dj[0], dj[1], dj[2]}, {dj[3], dj[4], dj[5]}};
-      L.wb = L.wb + dJ.a;
-      L.vb = L.vb + dJ.l;
-      L.qd[0] = L.qd[0] + (Hi11 * pj[0] + Hi12 * pj[1] + Hi13 * pj[2]) - dot(P1, dJ);
-      L.qd[1] = L.qd[1] + (Hi12 * pj[0] + Hi22 * pj[1] + Hi23 * pj[2]) - dot(P2, dJ);
-      L.qd[2] = L.qd[2] + (Hi13 * pj[0] + Hi23 * pj[1] + Hi33 * pj[2]) - dot(P3, dJ);
-    }
-  }
+  };   // finish_tick
+  if (anyj) finish_tick(std::true_type{});
+  else finish_tick(std::false_type{});
 
   c.phase(9);
   // ---- semi-implicit Euler on positions

@@ -351,7 +351,9 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   // fused broadcast-FMA (v_fmac_f32_dpp row_newbcast); rows of the own leg add the leg compliance
   // J_l H^-1 J_l^T.  (The 4-lane kernel contracts the same products on the matrix pipe; with one row per
   // lane the DPP form needs no accumulator shuffles and no MFMA latency padding.)
-  F lam = mj * rowf * F(K.warmstart) * L.lam;                   // warm start (defined here: DPP source below); knee rows start at 0
+  // warm start (defined here: DPP source below): the normal row x K.warmstart, the friction rows x K.warmstart_t (Bullet's
+  // multibody solver restarts friction rows from zero); knee rows start at 0
+  F lam = mj * rowf * sel_(s0, F(K.warmstart), F(K.warmstart_t)) * L.lam;
   F hj[3] = {HJ0, HJ1, HJ2};
   c.dpp_ready10(Z, hj, &lam);                                   // one fence for all broadcast sources of this phase
   F A[4][3];
@@ -403,11 +405,20 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   V vc = vbs + cross(wbs, rc) + qs0 * k1 + qs1 * k2 + qs2 * k3;
   F u = rowf * dot(dir, vc);
   const F idt(1.0f / K.dt);
-  const F tgt = (knee ? f0 + f3 : f0) * sel_(phi > zero, -(phi * idt), -(F(K.erp) * phi * idt));   // only normal rows have a target
+  const F pen = phi + F(K.slop);                                // Bullet: penetration = distance + m_linearSlop
+  F tgt = (knee ? f0 + f3 : f0) * sel_(pen > zero, -(pen * idt), -(F(K.erp) * pen * idt));   // only normal rows have a target
+  if (!Ctx::kPlain) {
+    // EtgConfig.foot_restitution: a foot that approaches faster than 0.2 m/s at the START of the tick bounces (branch-free: e = 0 adds 0)
+    const V vc0 = L.vb + cross(L.wb, rc) + c.qb(L.qd, 0) * k1 + c.qb(L.qd, 1) * k2 + c.qb(L.qd, 2) * k3;
+    const F un0 = rowf * dot(dir, vc0);
+    tgt = tgt + f0 * sel_(un0 < F(-0.2f), -(F(K.restitution) * un0), zero);
+  }
   c.fmac_rbcast12(u, lam, &A[0][0]);                            // u += sum_(lp,e) lam@row(4 lp + e) * A[lp][e], one asm block
   c.phase(7);
-  // ---- projected Gauss-Seidel, rows in the order (FR n,t1,t2), (FL ...), (RR ...), (RL ...): the owner
-  // lane's candidate is broadcast over the row with row_newbcast and applied by every lane.
+  // ---- projected Gauss-Seidel in the order of Bullet's btMultiBodyConstraintSolver::solveSingleIteration (the oracle's
+  // physics_tick states it): per sweep (1) the joint-limit rows, (2) the NORMAL rows of the four feet FR, FL, RR, RL, then the
+  // body rows, (3) the friction rows of the four feet.  The owner lane's candidate is broadcast over the row with
+  // row_newbcast and applied by every lane.
   // The sweeps read their per-lane constants through `iAe`, `c0e`, `mue`: under the residual stopping rule a robot that has
   // converged is FROZEN for the sweeps the other robots of its wave still need -- iAe = c0e = 0 make every candidate equal
   // the current impulse (all deltas exact zeros), mue = 1e30 makes the cone projection the identity -- so a robot's result
@@ -421,24 +432,109 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
     mk0[lp] = ownl[lp] * f0;
     mt[lp] = ownl[lp] * tangf;
   }
+  // ---- joint-limit rows (EtgConfig.joint_limits, bounds of a1.py:186-195 = the URDF limits Bullet enforces with
+  // btMultiBodyJointLimitConstraint rows): a joint at or beyond a bound gets a unilateral row along its coordinate, pushing
+  // back into the range with the velocity target erp * violation / dt, solved inside the sweeps before the contact rows.
+  // Rare: everything about them sits behind ONE wave-uniform test per tick (`anyj`); the common tick runs the sweeps below
+  // without them.  This lane owns the row of ITS joint: Z-vector -sgn * zj (zj = D^-1/2 L^-1 P, P = column `sub` of Fm H^-1),
+  // leg part sgn * (row `sub` of H^-1).  The row's velocity is rebuilt from the current impulses (no Delassus columns are
+  // kept for these rows): u_q = sgn (qd* + [H^-1 J_l^T lam]_sub - zj . ZL), ZL = sum over the robot's rows of lam_r Z_r.
+  bool anyj = false;
+  F jactf = zero, jlo = zero, jhi = zero;
+  if (K.jlim) {   // (compiled into the PLAIN instantiations too: the stops are on by default)
+    jlo = sel_(s0, F(K.jlo[0]), sel_(s1, F(K.jlo[1]), F(K.jlo[2])));
+    jhi = sel_(s0, F(K.jhi[0]), sel_(s1, F(K.jhi[1]), F(K.jhi[2])));
+    jactf = mj * sel_((L.q >= jhi) || (L.q <= jlo), one, zero);
+    anyj = c.any(jactf > F(0.5f));
+  }
+  // solve + apply, instantiated with and without the joint rows: without them their variables are compile-time zeros
+  auto finish_tick = [&](auto joints_tag) {
+  constexpr bool joints = decltype(joints_tag)::value;
+  F sgn = zero, lamq = zero, iAq = zero, c0q = zero;
+  F zj[6] = {zero, zero, zero, zero, zero, zero};
+  if (joints) {
+    F z6[6] = {P.a.x, P.a.y, P.a.z, P.l.x, P.l.y, P.l.z};
+    fwd6(s, z6);
+    const W zv = cmul(W{{z6[0], z6[1], z6[2]}, {z6[3], z6[4], z6[5]}}, sqv);
+#pragma unroll
+    for (int k = 0; k < 6; k++) zj[k] = comp(zv, k);
+    sgn = jactf * sel_(L.q >= jhi, -one, one);
+    const F viol = fmaxf_(L.q - jhi, jlo - L.q);
+    const F Aqq = (f0 * Hi11 + f1 * Hi22 + f2 * Hi33) + dot(zv, zv) + (one - mj);    // (M^-1)_jj; 1 on the aux lane
+    iAq = jactf * rcp_(Aqq);
+    c0q = (F(K.erp) * viol * idt) * iAq;
+  }
   // The whole solve is instantiated per friction model (PYRAMID is a compile-time constant inside): a runtime test per foot
-  // inside the sweeps' serial chain cost the all-options kernels 800 cycles per tick (phase profile: 2327 against 1504).
+  // inside the sweeps' serial chain cost the all-options kernels 800 cycles per tick (phase profile: 2327 against 1504);
+  // and with / without the joint rows.
   auto solve = [&](auto pyramid_tag) {
     constexpr bool pyramid = decltype(pyramid_tag)::value;
+    F iAqe = iAq, c0qe = c0q;
+    auto joint_phase = [&]() {
+      F zl[6], zl0[6];
+      const F slq = sgn * lamq;
+#pragma unroll
+      for (int k = 0; k < 6; k++) zl[k] = lam * Z[k] - slq * zj[k];
+      c.sum16x6(zl);
+#pragma unroll
+      for (int k = 0; k < 6; k++) zl0[k] = zl[k];
+      const F dj0 = c.qsum(hj[0] * lam), dj1 = c.qsum(hj[1] * lam), dj2 = c.qsum(hj[2] * lam);   // the contact impulses do not change here
+      const F qc = qds + (f0 * dj0 + f1 * dj1 + f2 * dj2);
+      const F lamq0 = lamq;
+#pragma unroll
+      for (int lp = 0; lp < 4; lp++)
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+          const F me = ownl[lp] * (e == 0 ? f0 : (e == 1 ? f1 : f2));
+          if (!c.any(me * jactf > F(0.5f))) continue;                  // no robot of the wave has this joint at a stop
+          const F sl = sgn * lamq;
+          const F qj = qc + (h0 * c.qb(sl, 0) + h1 * c.qb(sl, 1) + h2 * c.qb(sl, 2));
+          F zz = zj[0] * zl[0];
+#pragma unroll
+          for (int k = 1; k < 6; k++) zz = zz + zj[k] * zl[k];
+          const F uq = sgn * (qj - zz);
+          const F dq = me * fmaxf_(-lamq, c0qe - uq * iAqe);
+          lamq = lamq + dq;
+          const F sd = -(sgn * dq);
+#pragma unroll
+          for (int k = 0; k < 6; k++) zl[k] = zl[k] + c.rbcast(sd * zj[k], 4 * lp + e);
+        }
+      // the contact rows see the joint impulses' changes: A[c][q] d lam_q = Z_c . dZL + HJ_c[joint] sgn d lam_q
+      const F w = sgn * (lamq - lamq0);
+      F du = hj[0] * c.qb(w, 0) + hj[1] * c.qb(w, 1) + hj[2] * c.qb(w, 2);
+#pragma unroll
+      for (int k = 0; k < 6; k++) du = du + Z[k] * (zl[k] - zl0[k]);
+      u = u + du;
+    };
     auto pgs_sweep = [&]() {
+      if (joints) joint_phase();
+      // (2) normal rows: ln = max(0, lam - (u - tgt)/A), as a change: max(-lam, (tgt - u)/A); the owner's lam update sits
+      // between the candidate and its broadcast, where the DPP read needs two wait states anyway
 #pragma unroll
       for (int lp = 0; lp < 4; lp++) {
-        // normal row: ln = max(0, lam - (u - tgt)/A), as a change: max(-lam, (tgt - u)/A); the owner's lam update sits
-        // between the candidate and its broadcast, where the DPP read needs two wait states anyway
         F dln = fmaxf_(-lam, c0e - u * iAe);                          // = max(0, lam + c0 - u / A) - lam
         lam = lam + mk0[lp] * dln;
         const F b = c.rbcast(dln, 4 * lp);
         u = u + A[lp][0] * b;
-        // tangent rows t1, t2 of the foot as ONE block: each of the two lanes computes its row's candidate from the same
-        // velocities in the same instruction, the pair is projected on the friction disc mu ln (friction_model 1: each clamped
-        // on its own), and the two total changes are broadcast once -- 15 instructions instead of 23 for two sequential row
-        // updates plus a separate projection pass
-        const F lim = mue * c.qb(lam, 0);
+      }
+      if (knee) {   // the body rows are normal rows too: lk = max(0, lk - (u - tgt)/A)
+#pragma unroll
+        for (int lp = 0; lp < 4; lp++) {
+          F dlk = fmaxf_(-lam, c0e - u * iAe);
+          lam = lam + ownl[lp] * f3 * dlk;
+          F bk = c.rbcast(dlk, 4 * lp + 3);
+          u = u + Ak[lp] * bk;
+        }
+      }
+      // (3) friction rows t1, t2 of a foot as ONE block: each of the two lanes computes its row's candidate from the same
+      // velocities in the same instruction, the pair is projected on the friction disc mu ln (Bullet's implicit cone,
+      // resolveConeFrictionConstraintRows; friction_model 1: each clamped on its own), and the two total changes are
+      // broadcast once.  A foot whose normal impulse is not positive keeps its friction impulses (`if (totalImpulse > 0)`).
+      const F lnq = c.qb(lam, 0);
+      const F lim = mue * lnq;
+      const auto grip = lnq > zero;
+#pragma unroll
+      for (int lp = 0; lp < 4; lp++) {
         const F lc = lam - u * iAe;                                   // this lane's candidate (meaningful on the tangent lanes)
         F dl;
         if (pyramid) {
@@ -448,15 +544,10 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
           const F sc = fminf_(one, lim * rsqrt_((lc * lc + F(1e-30f)) + oth * oth));   // (the 1e-30 keeps 0 * rsq(0) off the table)
           dl = lc * sc - lam;
         }
+        dl = sel_(grip, dl, zero);
         const F b1 = c.rbcast(dl, 4 * lp + 1), b2 = c.rbcast(dl, 4 * lp + 2);
         u = u + A[lp][1] * b1 + A[lp][2] * b2;
         lam = lam + mt[lp] * dl;
-        if (knee) {   // the leg's knee row, after its foot rows: lk = max(0, lk - (u - tgt)/A)
-          F dlk = fmaxf_(-lam, c0e - u * iAe);
-          lam = lam + ownl[lp] * f3 * dlk;
-          F bk = c.rbcast(dlk, 4 * lp + 3);
-          u = u + Ak[lp] * bk;
-        }
       }
     };
     if (K.res_thr > 0.0f) {
@@ -466,19 +557,22 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
       // against a tolerance made once per tick (inactive rows: iA = 0, no change, 0 > 0 is false); "any row of my robot"
       // comes from the compare's wave mask (robot_any), not from a 4-stage lane reduction
       const F tol = F(K.res_sqrt) * iA;
+      const F tolq = F(K.res_sqrt) * iAq;
       int it = 0;
       bool more;
       auto sweep_and_test = [&]() {
-        const F lam0 = lam;
+        const F lam0 = lam, lamq0 = lamq;
         pgs_sweep();
         it++;
-        const auto live = c.robot_any(fabsf_(lam - lam0) > tol);
+        const auto live = joints ? c.robot_any((fabsf_(lam - lam0) > tol) || (fabsf_(lamq - lamq0) > tolq))
+                                 : c.robot_any(fabsf_(lam - lam0) > tol);
         iAe = sel_(live, iAe, zero);
         c0e = sel_(live, c0e, zero);
         mue = sel_(live, mue, F(1e30f));
+        if (joints) { iAqe = sel_(live, iAqe, zero); c0qe = sel_(live, c0qe, zero); }
         more = c.wave_any(live) && it < K.iters;
       };
-      if (Ctx::kPlain) {
+      if (Ctx::kPlain && !joints) {
         // The default robot layer: the first 8 sweeps as nested forward exits (falling through costs nothing, the one taken
         // branch per tick is the exit); ticks that need more (a fraction of a percent) enter the loop at the bottom.
         sweep_and_test();
@@ -495,7 +589,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
         do sweep_and_test(); while (more);
       }
       L.sweeps += it;
-    } else if (K.iters == 2) {
+    } else if (K.iters == 2 && !joints) {
       // a fixed pair of sweeps (the round-1/2 default) as straight-line code: no loop back-edge inside the tick
       pgs_sweep();
       pgs_sweep();
@@ -516,6 +610,11 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   F db[6];
 #pragma unroll
   for (int k = 0; k < 6; k++) db[k] = comp(lam * W{{Z[0], Z[1], Z[2]}, {Z[3], Z[4], Z[5]}}, k);
+  const F slq = sgn * lamq;                                     // the joint rows' impulses along the joint coordinates
+  if (joints) {
+#pragma unroll
+    for (int k = 0; k < 6; k++) db[k] = db[k] - slq * zj[k];
+  }
   c.sum16x6(db);                                                // the six reductions stage by stage (no DPP wait states)
   {
     const W dbs = cmul(W{{db[0], db[1], db[2]}, {db[3], db[4], db[5]}}, sqv);
@@ -529,44 +628,13 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   // joint j of this leg receives sum_d HJ_d[j] lam_d
   const F dj0 = c.qsum(hj[0] * lam), dj1 = c.qsum(hj[1] * lam), dj2 = c.qsum(hj[2] * lam);
   L.qd = mj * (qds + (f0 * dj0 + f1 * dj1 + f2 * dj2) - dot(P, dB));
+  if (joints) L.qd = L.qd + mj * (h0 * c.qb(slq, 0) + h1 * c.qb(slq, 1) + h2 * c.qb(slq, 2));
   L.lam = lam;
   const F ln_leg = c.qb(lam, 0);
   L.contact = sel_(act && (ln_leg > zero), one, zero);
-  // ---- joint-limit stops (EtgConfig.joint_limits, bounds of a1.py:186-195; the oracle's physics_tick states the model):
-  // a joint outside its range that does not yet return at the Baumgarte rate gets the joint-space impulse
-  // p = (target - qd) / (M^-1)_jj, all violated joints at once (Jacobi), applied through M^-1 = the same Schur
-  // machinery as the contact impulses: base -S^-1 sum_j P_j p_j, joints H^-1 p - P^T dB.  Rare: the whole block sits
-  // behind one wave-uniform test.
-  if (K.jlim) {   // (compiled into the PLAIN instantiations too: the stops are on by default, the test below is 9 instructions per tick)
-    const F lo = sel_(s0, F(K.jlo[0]), sel_(s1, F(K.jlo[1]), F(K.jlo[2])));
-    const F hi = sel_(s0, F(K.jhi[0]), sel_(s1, F(K.jhi[1]), F(K.jhi[2])));
-    const F pen = fmaxf_(L.q - hi, zero) + fminf_(L.q - lo, zero);      // > 0 above the range, < 0 below it, 0 inside
-    const F jt = -(F(K.erp) * pen * F(1.0f / K.dt));
-    // outside and not yet returning at the Baumgarte rate: (pen > 0 and qd > jt) or (pen < 0 and qd < jt)  <=>  pen (qd - jt) > 0
-    const F hitf = mj * sel_(pen * (L.qd - jt) > zero, one, zero);
-    if (c.any(hitf > F(0.5f))) {
-      F z6[6] = {P.a.x, P.a.y, P.a.z, P.l.x, P.l.y, P.l.z};
-      fwd6(s, z6);
-      const W zj = cmul(W{{z6[0], z6[1], z6[2]}, {z6[3], z6[4], z6[5]}}, sqv);
-      const F wjj = (f0 * Hi11 + f1 * Hi22 + f2 * Hi33) + dot(zj, zj) + (one - mj);    // (M^-1)_jj; 1 on the aux lane
-      const F pj = hitf * (jt - L.qd) * rcp_(wjj);
-      F dj[6];
-#pragma unroll
-      for (int k = 0; k < 6; k++) dj[k] = -(pj * comp(zj, k));
-      c.sum16x6(dj);
-      {
-        const W djs = cmul(W{{dj[0], dj[1], dj[2]}, {dj[3], dj[4], dj[5]}}, sqv);
-#pragma unroll
-        for (int k = 0; k < 6; k++) dj[k] = comp(djs, k);
-      }
-      bwd6(s, dj);
-      const W dJ = {{dj[0], dj[1], dj[2]}, {dj[3], dj[4], dj[5]}};
-      L.wb = L.wb + dJ.a;
-      L.vb = L.vb + dJ.l;
-      const F p0 = c.qb(pj, 0), p1 = c.qb(pj, 1), p2 = c.qb(pj, 2);
-      L.qd = L.qd + mj * ((h0 * p0 + h1 * p1 + h2 * p2) - dot(P, dJ));
-    }
-  }
+  };   // finish_tick
+  if (anyj) finish_tick(std::true_type{});
+  else finish_tick(std::false_type{});
   c.phase(9);
   // ---- semi-implicit Euler
   L.q = L.q + dt * L.qd;

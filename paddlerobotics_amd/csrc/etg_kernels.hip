@@ -1286,6 +1286,12 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   if (!(cfg->solver_residual >= 0)) return fail(ETG_ERR_BAD_ARG, "etg_create: solver_residual must be >= 0 (0 = a fixed number of sweeps)");
   if (cfg->friction_model != 0 && cfg->friction_model != 1) return fail(ETG_ERR_BAD_ARG, "etg_create: friction_model must be 0 (disc) or 1 (pyramid)");
   if (!(cfg->pd_latency >= 0)) return fail(ETG_ERR_BAD_ARG, "etg_create: pd_latency must be >= 0 seconds");
+  // (beyond the ring depth the blend of minitaur.py:1185-1188 would extrapolate between aliased slots)
+  if (cfg->pd_latency >= (etg::RING - 2) * cfg->sim_dt)
+    return fail(ETG_ERR_BAD_ARG, "etg_create: pd_latency must be below (ring depth - 2) * sim_dt = 62 ticks");
+  if (!(cfg->warmstart >= 0) || !(cfg->warmstart_friction >= 0)) return fail(ETG_ERR_BAD_ARG, "etg_create: warm-start factors must be >= 0");
+  if (!(cfg->contact_slop >= 0)) return fail(ETG_ERR_BAD_ARG, "etg_create: contact_slop must be >= 0");
+  if (!(cfg->foot_restitution >= 0) || cfg->foot_restitution > 1) return fail(ETG_ERR_BAD_ARG, "etg_create: foot_restitution must be in [0, 1]");
   if (cfg->settle_ticks < 0) return fail(ETG_ERR_BAD_ARG, "etg_create: settle_ticks must not be negative");
   if (cfg->motor_mode < 0 || cfg->motor_mode > 2) return fail(ETG_ERR_BAD_ARG, "etg_create: motor_mode must be 0 (POSITION), 1 (TORQUE) or 2 (HYBRID)");
   if (cfg->body_contacts < 0 || cfg->body_contacts > 3) return fail(ETG_ERR_BAD_ARG, "etg_create: body_contacts must be 0, 1, 2 or 3");

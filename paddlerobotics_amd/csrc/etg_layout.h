@@ -80,12 +80,15 @@ struct KCfg {
   int fric_pyramid;      // EtgConfig.friction_model == 1: per-direction clamp instead of the disc projection
   int pd_n;              // EtgConfig.pd_latency: n_steps_ago of the PD law's reading (minitaur.py:1185), -1 = off (true state)
   float pd_a;            // its blend_alpha (minitaur.py:1188)
+  float warmstart_t;     // EtgConfig.warmstart_friction: warm-start factor of the friction rows (warmstart: the normal rows)
+  float slop;            // EtgConfig.contact_slop: added to a contact's distance before the velocity target is formed
+  float restitution;     // EtgConfig.foot_restitution (combined coefficient; 0 = off)
 };
 
 // the default robot layer (what train.py / pretrain.py run): the PLAIN kernel instantiations compile the options out
 inline bool plain_config(const KCfg& K) {
   return K.motor_mode == 0 && !K.enable_filter && !K.enable_interp && !(K.torque_limit > 0.0f) && !(K.clip_cmd > 0.0f) &&
-         !K.ext_force && !K.knee && K.etg_on && !K.fric_pyramid && K.pd_n < 0;   // (joint limits: in every instantiation)
+         !K.ext_force && !K.knee && K.etg_on && !K.fric_pyramid && K.pd_n < 0 && !(K.restitution > 0.0f);   // (joint limits: in every instantiation)
 }
 
 // counter-based standard normal pair for (seed, robot, observation index, channel): splitmix64 finaliser twice, then
@@ -341,6 +344,7 @@ inline KCfg make_kcfg(const EtgConfig& c, const EtgRobotModel& m) {
     K.pd_n = n;
     K.pd_a = (float)((c.pd_latency - n * c.sim_dt) / c.sim_dt);
   }
+  K.warmstart_t = (float)c.warmstart_friction; K.slop = (float)c.contact_slop; K.restitution = (float)c.foot_restitution;
   K.jlim = c.joint_limits != 0;
   for (int k = 0; k < 3; k++) { K.jlo[k] = (float)c.joint_lower[k]; K.jhi[k] = (float)c.joint_upper[k]; }
   K.hf_cell = (float)c.hf_cell; K.hf_x0 = (float)c.hf_x0; K.hf_y0 = (float)c.hf_y0;

@@ -146,7 +146,8 @@ class BatchedQuadrupedEnv:
                  random_dynamics_scale=0.3, random_force_prob=0.02, random_force_steps=8,
                  random_force_range=(5.0, 25.0), seed=0, enable_clip_motor_commands=False,
                  observation_noise_stdev=None, body_contacts=False, knee_radius=0.02, joint_limits=True,
-                 auto_reset=False, random_dynamics_refresh=256, **unused):
+                 auto_reset=False, random_dynamics_refresh=256, warmstart=0.1, warmstart_friction=0.0, contact_slop=1e-5,
+                 foot_restitution=0.0, **unused):
         if render:
             raise ValueError("render is not supported by the batched GPU simulator")
         if int(ETG_H) != A.RBF_H:
@@ -215,7 +216,10 @@ class BatchedQuadrupedEnv:
             # True / 1: knee spheres; 2 or "all": the deepest of knee, shin midpoint and trunk corner per leg
             body_contacts=3 if body_contacts in (3, "simultaneous") else 2 if body_contacts in (2, "all") else (1 if body_contacts else 0),
             knee_radius=knee_radius,
-            enable_etg=1 if self.ETG else 0, joint_limits=1 if joint_limits else 0)
+            enable_etg=1 if self.ETG else 0, joint_limits=1 if joint_limits else 0,
+            # contact-solver settings: the defaults are pybullet's (a1_model.default_config)
+            warmstart=warmstart, warmstart_friction=warmstart_friction, contact_slop=contact_slop,
+            foot_restitution=foot_restitution)
         self.model = A.default_model()
         if task == "balancebeam":
             # README "step_y: the foot position at y axis for balance beam task" (train.py:463): the ETG's nominal

@@ -431,12 +431,14 @@ def test_joint_limits_match_oracle(lanes):
         sg, so = env.get_state().cpu().numpy(), orc.get_state()
         worst = max(worst, np.abs(sg - so)[:, 13:25].max())
         assert np.abs(sg - so)[:, :3].max() < 2e-3, k
+        if k == 5:      # before the splayed robot sinks into the floor (no body contacts here) and its feet push a hip off its stop
+            q6 = sg[:, 13:25].reshape(n, 4, 3)
     _say("joint limits lanes=%d: q err max %.2e" % (lanes, worst))
     assert worst < 5e-3
     q = env.get_state()[:, 13:25].cpu().numpy().reshape(n, 4, 3)
     lo, hi = np.array(A.JOINT_LOWER), np.array(A.JOINT_UPPER)
     assert (q <= hi + 0.03).all() and (q >= lo - 0.03).all()
-    assert np.abs(q[0::4, :, 0] - hi[0]).max() < 0.03 and np.abs(q[1::4, :, 0] - lo[0]).max() < 0.03
+    assert np.abs(q6[0::4, :, 0] - hi[0]).max() < 0.03 and np.abs(q6[1::4, :, 0] - lo[0]).max() < 0.03
     # robots standing at the prior gait's first steps stay inside the range: switching the stops off changes nothing there
     W, B = _etg_params(n, seed=5)
     a, b = _make(n, joint_limits=True, lanes_per_robot=lanes), _make(n, joint_limits=False, lanes_per_robot=lanes)

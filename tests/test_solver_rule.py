@@ -29,6 +29,9 @@ def test_default_rule_is_pybullets_documented_one():
     assert A.solver_rule(8, 1e-5) == (8, 1e-5)
     c = A.default_config(4)
     assert (c.solver_iters, c.solver_residual, c.friction_model) == (50, 1e-7, 0)
+    # pybullet's server settings (PhysicsServerCommandProcessor): warm-start factor 0.1, friction rows restart from zero
+    # (btMultiBodyConstraintSolver), linear slop 1e-5, non-contact erp 0.2
+    assert (c.warmstart, c.warmstart_friction, c.contact_slop, c.erp, c.foot_restitution) == (0.1, 0.0, 1e-5, 0.2, 0.0)
     c = A.default_config(4, solver_iters=2)
     assert (c.solver_iters, c.solver_residual) == (2, 0.0)
 
@@ -192,20 +195,31 @@ def test_emulation_pd_latency_matches_oracle(lanes):
     assert np.abs(ref.get_state() - orc.get_state())[:, 13:25].max() > 1e-3       # a delayed PD reading is a different controller
 
 
-def test_friction_model_choice_is_anchored_on_the_reference_gait(golden):
-    """Why the isotropic disc (friction_model = 0) is the default and the per-direction clamp of a two-direction sequential-impulse
-    solver (friction_model = 1) an option: the reference's own recorded gait (gait_action_list_ETG_exp.npy, fitted as
-    exp_w / exp_b in tests/golden/etg.npz) walks its 600 control steps (env_test.py:51-54) at ~ vel_d on the disc; on the
-    anisotropic pyramid it yaws until the |yaw| > 0.6 termination ends the episode early."""
+def test_friction_models_differ_only_where_the_feet_slide(golden):
+    """pybullet's default friction handling is the implicit cone (setPhysicsEngineParameter(enableConeFriction=1):
+    btMultiBodyConstraintSolver::resolveConeFrictionConstraintRows, the pair of friction impulses projected on the disc
+    mu * lambda_n) = friction_model 0, the default here; enableConeFriction=0 is the per-direction pyramid = friction_model 1.
+    Root cause of the yaw drift the pyramid shows on the reference's recorded gait (profiles/r04_yaw_rootcause.txt): the gait
+    is replayed open loop on param2dynamic_dict(zeros)'s foot friction 0.2 (train.py:116), on which the feet SLIDE through
+    most of every stance; a sliding foot on the pyramid feels up to sqrt(2) mu lambda_n, not opposed to the slip and tied to
+    the world axes.  Where the feet stick (mu >= 0.7) the two models walk the same path; nothing here says which one Bullet
+    would agree with -- the default follows pybullet's documented setting, not an outcome."""
     from oracle.oracle import OracleSim
     g = golden("etg")
-    out = {}
-    for fm in (0, 1):
+
+    def walk(mu, fm):
         orc = OracleSim(A.default_config(1, friction_model=fm))
-        orc.set_params(etg_w=g["exp_w"], etg_b=g["exp_b"])
+        dyn = A.default_dynamic_row()[None].copy()
+        dyn[0, 1] = mu
+        orc.set_params(dyn=dyn, etg_w=g["exp_w"], etg_b=g["exp_b"])
         orc.reset()
         x0 = orc.get_state()[0, 0]
-        _, ln = orc.run_steps(600)
-        out[fm] = (int(ln[0]), orc.get_state()[0, 0] - x0)
-    assert out[0][0] == 600 and abs(out[0][1] / (600 * 0.026) - 0.5) < 0.03        # 7.7 m in 15.6 s
-    assert out[1][0] < 600
+        orc.run_steps(600)
+        st = orc.get_state()[0]
+        x, y, z, w = st[3:7]
+        return st[0] - x0, np.arctan2(2 * (w * z + x * y), 1 - 2 * (y * y + z * z))
+
+    (d0, yaw0), (d1, yaw1) = walk(1.0, 0), walk(1.0, 1)
+    assert abs(yaw0 - yaw1) < 0.05 and abs(d0 - d1) < 0.02 * d0 and d0 > 7.0        # sticking feet: same walk
+    (d0, yaw0), (d1, yaw1) = walk(0.2, 0), walk(0.2, 1)
+    assert abs(yaw0 - yaw1) > 0.3                                                    # sliding feet: the cone's shape matters
