@@ -44,8 +44,11 @@ CLOCK_WARM_SECONDS = 0.25
 CLOCK_WARM_STEPS = 600     # untimed scratch-env steps (~22 ms) right before every timed repeat's barrier
 # PMC figures (HBM traffic, VALU instructions per wave) are NOT measured by this process: they come from separate
 # `rocprofv3 --pmc` passes of this same command (tools/pmc_gpu.sh), summarised per kernel and control step in this file.
-PMC_FILE = os.path.join(ROOT, "profiles", "r03_pmc.json")
-VALU_PEAK_PER_SIMD_CYCLE = 0.384   # tools/ubench/occupancy_rate.hip: 8 resident waves of v_fma_f32 per SIMD
+# The file is stamped with the hash of the kernel sources it was collected on (tools/make_pmc_json.py); when the sources have
+# changed since, the figures are reported as STALE (roofline.traffic = null) instead of being passed off as this build's.
+PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
+VALU_PEAK_GUIDE = 0.5              # MI355X_MICROARCH.md: a SIMD issues one wave64 VALU instruction every 2 cycles
+VALU_PEAK_MEASURED = 0.384         # tools/ubench/occupancy_rate.hip: 8 resident waves of v_fma_f32 per SIMD
 NOMINAL_HZ = 2.4e9
 
 
@@ -358,11 +361,13 @@ def main():
         torch.cuda.synchronize(dev)
         gather_ms = (time.perf_counter() - t0) / 20 * 1e3
         multi = {"ms_per_step_by_rank": [float(x) for x in allr.cpu().tolist()],
+                 "env_steps_per_s_by_rank": [N / (float(x) * 1e-3) for x in allr.cpu().tolist()],
                  "return_gather": {"ms": max_over_ranks(gather_ms, dist, dev), "elements": int(g.numel()), "bytes": int(g.numel()) * 4,
                                    "collective": "all_gather_into_tensor", "backend": dist.get_backend(),
                                    "note": "20 back-to-back gathers of the N x world fp32 returns, host clock, max over ranks; one such "
                                            "gather is inside every timed repeat"},
-                 "world_size_reported_by": "torch.distributed/" + dist.get_backend(), "world_size": dist.get_world_size()}
+                 "world_size_reported_by": "rccl (torch.distributed backend nccl)" if dist.get_backend() == "nccl" else "torch.distributed/" + dist.get_backend(),
+                 "world_size": dist.get_world_size()}
 
     # ---- legs reported NEXT to `value`, never part of it
     extra = {}
@@ -442,9 +447,15 @@ def main():
         if fused and policy is not None:
             kname = "k_rollout_policy16"
         achieved = bytes_per * N / (kern_ms * 1e-3)
-        pmc = {}
+        pmc, pmc_state = {}, "absent"
         try:
-            pmc = json.load(open(PMC_FILE)).get("config%d" % args.config, {}).get(kname, {})
+            from paddlerobotics_amd.build import kernel_source_hash
+            pj = json.load(open(PMC_FILE))
+            if pj.get("kernel_source_hash") == kernel_source_hash():
+                pmc, pmc_state = pj.get("config%d" % args.config, {}).get(kname, {}), "current"
+            else:
+                pmc_state = "stale: %s was collected on kernel sources %s, this run's are %s" % (
+                    os.path.relpath(PMC_FILE, ROOT), pj.get("kernel_source_hash"), kernel_source_hash())
         except Exception:                                           # noqa: BLE001 - the counters file is optional
             pmc = {}
         traffic = pmc.get("traffic_bytes_per_control_step_at_4096")
@@ -461,10 +472,15 @@ def main():
                        ("configs[2]: %d parallel A1 per GPU, flat, ETG + residual MLP policy (random init, "
                         "precision %d)" % (N, args.precision)),
                        "robots_per_gpu": N, "action_repeat": 13, "sim_dt": 0.002,
-                       "solver": {"rule": ("projected Gauss-Seidel, warm-started (x0.85); per tick sweep until max_rows ((d lambda_r) A_rr)^2 "
-                                           "<= residual_threshold, at most max_sweeps (pybullet: numSolverIterations 50, "
-                                           "solverResidualThreshold 1e-7)") if SOLVER[1] > 0 else "projected Gauss-Seidel, warm-started, fixed sweep count",
-                                  "max_sweeps": SOLVER[0], "residual_threshold": SOLVER[1], "friction": "disc"},
+                       "solver": {"rule": ("projected Gauss-Seidel in Bullet's order (joint-limit rows, all normal rows, then the friction "
+                                           "pairs); per tick sweep until max_rows ((d lambda_r) A_rr)^2 <= residual_threshold, at most "
+                                           "max_sweeps (pybullet: numSolverIterations 50, solverResidualThreshold 1e-7)") if SOLVER[1] > 0
+                                  else "projected Gauss-Seidel in Bullet's order, fixed sweep count",
+                                  "max_sweeps": SOLVER[0], "residual_threshold": SOLVER[1],
+                                  "settings": {"friction": "implicit cone: the friction pair projected on the disc mu * lambda_n (pybullet enableConeFriction = 1)",
+                                               "warmstart_normal": env.cfg.warmstart, "warmstart_friction": env.cfg.warmstart_friction,
+                                               "contact_slop": env.cfg.contact_slop, "erp": env.cfg.erp, "contact_margin": env.cfg.contact_margin,
+                                               "joint_limits": "unilateral rows inside the sweeps", "source": "DESIGN.md section 2 (pybullet's server settings)"}},
                        "solver_iters": SOLVER[0], "lanes_per_robot": lanes,
                        "body_contacts": bool(args.body_contacts), "joint_limits": bool(args.joint_limits),   # (the stops are on by default)
                        "auto_reset": False, "parallelism": "env-shard x%d" % world,
@@ -480,8 +496,10 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "etg::" + kname, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK,
                          "traffic": (traffic * N / 4096.0) if traffic else None,
-                         "traffic_source": ("profiles/r03_pmc.json: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes of "
-                                            "this command (tools/pmc_gpu.sh), not counters of this run") if traffic else None,
+                         "traffic_source": ("%s: 2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc passes of this command "
+                                            "(tools/pmc_gpu.sh) on the same kernel sources (hash checked), not counters of this run"
+                                            % os.path.relpath(PMC_FILE, ROOT)) if traffic else None,
+                         "pmc_file": pmc_state,
                          "kernel_ms": kern_ms, "kernel_ms_is": "per control step (median over the repeats; HIP event pair around "
                                                                "the K timed steps on the launch stream)",
                          "algorithmic_bytes_per_env_step": bytes_per,
@@ -491,10 +509,19 @@ def main():
         if valu and N * lanes <= 1024 * 64:
             # the ceiling that actually binds: VALU issue of one wave per SIMD
             v = valu / (kern_ms * 1e-3 * NOMINAL_HZ)
-            out["roofline"]["valu_issue"] = {"achieved": v, "peak": VALU_PEAK_PER_SIMD_CYCLE, "unit": "wave-instr/SIMD-cycle @2.4GHz",
-                                             "frac": v / VALU_PEAK_PER_SIMD_CYCLE, "single_wave_limit": 0.2,
-                                             "valu_insts_per_wave_step_source": "profiles/r03_pmc.json (SQ_INSTS_VALU / SQ_WAVES)"}
+            out["roofline"]["valu_issue"] = {"achieved": v, "peak": VALU_PEAK_GUIDE, "unit": "wave-instr/SIMD-cycle @2.4GHz",
+                                             "frac": v / VALU_PEAK_GUIDE, "peak_is": "MI355X_MICROARCH.md: one wave64 VALU instruction per 2 SIMD cycles",
+                                             "peak_measured": VALU_PEAK_MEASURED, "frac_of_measured": v / VALU_PEAK_MEASURED,
+                                             "peak_measured_is": "tools/ubench/occupancy_rate.hip: 8 resident waves of v_fma_f32 per SIMD",
+                                             "single_wave_limit": 0.2,
+                                             "valu_insts_per_wave_step_source": "%s (SQ_INSTS_VALU / SQ_WAVES)" % os.path.relpath(PMC_FILE, ROOT)}
         out.update(extra)
+        if "stepwise" in extra:
+            # the Gym surface itself, next to the fused headline, as plain top-level scalars (north_star names env.step())
+            front = {"stepwise_env_step_value": extra["stepwise"]["value"], "stepwise_env_step_ms_per_step": extra["stepwise"]["ms_per_step"]}
+            keys = list(out)
+            i = keys.index("ms_per_step") + 1
+            out = {**{k: out[k] for k in keys[:i]}, **front, "survivors": out["survivors"], **{k: out[k] for k in keys[i:] if k != "survivors"}}
         if multi is not None:
             out["multi_gpu"] = multi
         out["roofline"]["hbm_copy_measured_GBps"] = device_copy_bandwidth(dev) / 1e9

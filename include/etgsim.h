@@ -150,9 +150,10 @@ typedef struct EtgConfig {
    * The reset settle always runs under POSITION control like a1.py:289-304.                          */
   int32_t motor_mode;
   /* A1._ClipMotorCommands (deployment/robots/a1.py:439-457, MAX_MOTOR_ANGLE_CHANGE_PER_STEP = 0.2): when
-   * > 0, every sub-step's position command is clipped to the current motor angle +- this many radians
-   * (the true angle is used; the reference reads its latency-delayed observation). 0 = off (the default
-   * of the reference's constructor).                                                                  */
+   * > 0, every sub-step's position command is clipped to GetMotorAngles() +- this many radians -- the motor angle as the
+   * control observation sees it: delayed by the robot's control latency (the blend of minitaur.py:1172-1193) and wrapped to
+   * [-pi, pi], without the sensor noise the reference adds to every reading.  0 = off (the default of the reference's
+   * constructor).                                                                                      */
   double clip_motor_commands;
   /* knee contacts (Bullet collides every link shape; here, besides the four foot spheres): when
    * != 0, a sphere of knee_radius at every knee (the calf joint origin, attached to the thigh) collides with the
@@ -232,6 +233,13 @@ int etg_set_heightfield(EtgHandle* h, const float* heights, void* stream);
  * README "Add external random force").                                                              */
 int etg_set_external_force(EtgHandle* h, const float* force, void* stream);
 
+/* motor strength ratios (Minitaur.SetMotorStrengthRatios, minitaur.py:1280-1294 -> LaikagoMotorModel.set_strength_ratios,
+ * laikago_motor.py:67-76): ratios [N,12] float32 device pointer, one factor per motor on the motor model's output torque
+ * (laikago_motor.py:138,167: before the torque clip; in TORQUE mode on the commanded torque); NULL = 1 for everybody.
+ * mask [N] bytes or NULL = all.  The reset settle runs under the motor model, so the touched robots settle again at their
+ * next reset.                                                                                                        */
+int etg_set_motor_strength(EtgHandle* h, const float* ratios, const uint8_t* mask, void* stream);
+
 /* random pushes, sampled on the device (random_param['random_force'], train.py:254; rlschool's own schedule is
  * absent, this one is the repo's): call once per control step before etg_step. A robot without an active push
  * starts one with probability `prob`: a horizontal force of magnitude U(fmin, fmax) N in a uniform direction,
@@ -279,7 +287,9 @@ int etg_step_autoreset(EtgHandle* h, const float* action, const uint8_t* donef, 
  * are ignored, NULL = all) for the robots' NEXT episodes and runs their settle NOW, in one launch, on scratch state -- the
  * robots keep running on their current parameters.  The settled state replaces the robot's settle cache; the rows are
  * installed when the robot's episode ends inside etg_step_autoreset (same launch as the step, as before) or at its next
- * etg_reset.  A robot whose episode ends again before the next call starts over with the same rows.  Needs a full etg_reset
+ * etg_reset.  A robot whose episode ends again before the next call starts over with the same rows.  Robots in the first 64
+ * physics ticks of their episode are left out of the call (they still read their pre-reset history from the settle cache the
+ * call replaces): their pending flag stays 0 and the caller's next refresh covers them.  Needs a full etg_reset
  * before (every robot with a cached settle); etg_set_params with new dynamics for a robot drops its pending rows.
  * etg_next_dynamics_pending copies the pending flags (1 = rows still waiting) to pending [N] bytes (device): the robots with 0
  * are the ones to draw new rows for.                                                                                   */

@@ -32,6 +32,7 @@ struct CpuHandle {
   // the settle is simulated then -- on the device it ran ahead of time on scratch state, with the same result)
   std::vector<float> next_dyn;
   std::vector<uint8_t> next_ok;
+  std::vector<int> age_ticks;   // physics ticks since each robot's reset (etg_prepare_next_dynamics leaves young robots out)
 };
 CpuHandle* H(EtgHandle* h) { return reinterpret_cast<CpuHandle*>(h); }
 
@@ -48,11 +49,14 @@ int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int device, Etg
   if (!cfg || !model || !out) return cfail(ETG_ERR_BAD_ARG, "etg_create: null argument");
   if (device != -1) return cfail(ETG_ERR_BAD_ARG, "etg_create: the CPU build of the ABI serves device = -1 only");
   if (cfg->num_envs <= 0 || cfg->action_repeat <= 0 || cfg->sim_dt <= 0) return cfail(ETG_ERR_BAD_ARG, "etg_create: bad config");
+  if (!(cfg->pd_latency >= 0) || cfg->pd_latency >= 62 * cfg->sim_dt)   /* ring depth 64: the same bound as the device library */
+    return cfail(ETG_ERR_BAD_ARG, "etg_create: pd_latency must be in [0, 62 ticks)");
   auto* h = new CpuHandle();
   h->sim = (Sim<double>*)etgo_create64(cfg, model);
   h->N = cfg->num_envs;
   h->was_reset = false;
   h->ret.assign(h->N, 0.0); h->alive.assign(h->N, 1.0); h->len.assign(h->N, 0);
+  h->age_ticks.assign(h->N, 0);
   /* default physical parameters = param2dynamic_dict(zeros(48)) (train.py:112-126), like the HIP library */
   std::vector<double> dyn((size_t)h->N * ETG_DYN_DIM, 1.0);
   for (int i = 0; i < h->N; i++) {
@@ -101,6 +105,14 @@ int etg_set_external_force(EtgHandle* h, const float* force, void*) {
   return ETG_OK;
 }
 
+int etg_set_motor_strength(EtgHandle* h, const float* ratios, const uint8_t* mask, void*) {
+  if (!h) return cfail(ETG_ERR_BAD_ARG, "null handle");
+  if (!ratios) { etgo_set_motor_strength64(H(h)->sim, nullptr, mask); return ETG_OK; }
+  std::vector<double> r = to_d(ratios, (size_t)H(h)->N * ETG_NUM_MOTORS);
+  etgo_set_motor_strength64(H(h)->sim, r.data(), mask);
+  return ETG_OK;
+}
+
 int etg_set_sensor_noise(EtgHandle* h, const float* stdev, uint64_t seed) {
   if (!h) return cfail(ETG_ERR_BAD_ARG, "null handle");
   etgo_set_sensor_noise64(H(h)->sim, stdev, seed);
@@ -135,6 +147,7 @@ int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void*) {
     if (mask && !mask[i]) continue;
     for (int k = 0; k < ETG_OBS_DIM; k++) obs[(size_t)i * ETG_OBS_DIM + k] = (float)o[(size_t)i * ETG_OBS_DIM + k];
     c->ret[i] = 0.0; c->alive[i] = 1.0; c->len[i] = 0;
+    c->age_ticks[i] = 0;
   }
   c->was_reset = true;
   return ETG_OK;
@@ -157,6 +170,7 @@ int etg_step(EtgHandle* h, const float* action, const uint8_t* donef, float* obs
     c->ret[i] += c->alive[i] * r[i];
     c->len[i] += (int32_t)c->alive[i];
     if (done[i]) c->alive[i] = 0.0;
+    c->age_ticks[i] += c->sim->cfg.action_repeat;
   }
   if (info) for (size_t k = 0; k < N * ETG_INFO_DIM; k++) info[k] = (float)inf[k];
   return ETG_OK;
@@ -274,6 +288,9 @@ int etg_prepare_next_dynamics(EtgHandle* h, const float* dyn, const uint8_t* mas
   if (c->next_ok.empty()) { c->next_ok.assign(c->N, 0); c->next_dyn.assign((size_t)c->N * ETG_DYN_DIM, 0.0f); }
   for (int i = 0; i < c->N; i++) {
     if (mask && !mask[i]) continue;
+    // the device library leaves out robots in the first RING = 64 ticks of their episode (they still read the settle cache's
+    // copy of the latency ring, which the call replaces); their pending flag stays 0 and the caller's next refresh covers them
+    if (c->age_ticks[i] < 64) continue;
     for (int k = 0; k < ETG_DYN_DIM; k++) c->next_dyn[(size_t)i * ETG_DYN_DIM + k] = dyn[(size_t)i * ETG_DYN_DIM + k];
     c->next_ok[i] = 1;
   }

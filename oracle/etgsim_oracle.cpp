@@ -294,6 +294,7 @@ template <class T> struct Env {
   T I[NB][6][6];  // link spatial inertias (link frame)
   T kp[12], kd[12], mu, latency, grav[3];
   T fext[3];  // external force on the trunk COM, world frame (etg_set_external_force)
+  T strength[12];  // motor strength ratios (laikago_motor.py:67-76,138,167; etg_set_motor_strength), 1 unless set
   T reset_off[2];  // start offset (x, y) of the next reset (etg_set_reset_offsets)
   int band;   // terrain band of this robot (env index % hf_bands)
   // outputs of the last tick
@@ -862,6 +863,28 @@ template <class T> void delayed_obs(const Sim<T>& s, const Env<T>& e, T* o) {
   for (int k = 0; k < HIST; k++) o[k] = (T(1) - alpha) * a[k] + alpha * b[k];
 }
 
+// LaikagoMotorModel.convert_to_torque (laikago_motor.py:103-175): POSITION / HYBRID  tau = -kp (q - q_des) - kd (qd - qd_des) + tau_ff,
+// TORQUE the command itself (passed as tau_ff); then x strength_ratio (:138,:167), then the optional clip to +-limit (:168-173;
+// the TORQUE branch returns before the clip, :137-139)
+template <class T> inline T motor_torque(T q, T qd, T q_des, T kp, T kd, T qd_des, T tau_ff, T strength, T limit, bool torque_cmd) {
+  if (torque_cmd) return strength * tau_ff;
+  T t = ((-(kp * (q - q_des))) - kd * (qd - qd_des)) + tau_ff;
+  t = strength * t;
+  if (limit > 0) {
+    if (t > limit) t = limit;
+    if (t < -limit) t = -limit;
+  }
+  return t;
+}
+// MapToMinusPiToPi (minitaur.py:67-83)
+template <class T> inline T wrap_to_pi(T a) {
+  const T two_pi = T(6.283185307179586), pi = T(3.141592653589793);
+  a = std::fmod(a, two_pi);
+  if (a >= pi) a -= two_pi;
+  else if (a < -pi) a += two_pi;
+  return a;
+}
+
 // one sub-step: ApplyAction (PD, laikago_motor.py:165-173; pd_latency = 0) -> tick -> history
 // hyb (HYBRID mode, laikago_motor.py:152-167): 12 x (kp, qd_des, kd, tau_ff) replacing the model's gains
 template <class T> void sub_step(const Sim<T>& s, Env<T>& e, const T* qdes, bool torque_cmd = false, const T* hyb = nullptr) {
@@ -880,22 +903,25 @@ template <class T> void sub_step(const Sim<T>& s, Env<T>& e, const T* qdes, bool
     const T* b = e.hist[tb % RING];
     for (int j = 0; j < 12; j++) { qm[j] = (T(1) - alpha) * a[j] + alpha * b[j]; qdm[j] = (T(1) - alpha) * a[12 + j] + alpha * b[12 + j]; }
   }
+  // A1._ClipMotorCommands (a1.py:439-457) clips against GetMotorAngles() = the control-latency-delayed reading of the motor
+  // angles, wrapped to [-pi, pi] (minitaur.py:753-764, 67-83) -- without the sensor noise the reference adds to every reading
+  T qclip[12];
+  if (s.cfg.clip_motor_commands > 0 && !torque_cmd) {
+    T dl[HIST];
+    delayed_obs(s, e, dl);
+    for (int j = 0; j < 12; j++) qclip[j] = wrap_to_pi(dl[j]);
+  }
   for (int j = 0; j < 12; j++) {
     // POSITION: laikago_motor.py:165-173; TORQUE: the command is the torque (laikago_motor.py:140-143)
     T cmd = qdes[j];
-    if (s.cfg.clip_motor_commands > 0 && !torque_cmd) {   // A1._ClipMotorCommands, a1.py:439-457
+    if (s.cfg.clip_motor_commands > 0 && !torque_cmd) {
       const T lim = T(s.cfg.clip_motor_commands);
-      if (cmd > e.q[j] + lim) cmd = e.q[j] + lim;
-      if (cmd < e.q[j] - lim) cmd = e.q[j] - lim;
+      if (cmd > qclip[j] + lim) cmd = qclip[j] + lim;
+      if (cmd < qclip[j] - lim) cmd = qclip[j] - lim;
     }
-    T t = torque_cmd ? cmd
-          : hyb ? (-(hyb[4 * j] * (qm[j] - cmd)) - hyb[4 * j + 2] * (qdm[j] - hyb[4 * j + 1])) + hyb[4 * j + 3]
-                : -(e.kp[j] * (qm[j] - cmd)) - e.kd[j] * qdm[j];
-    if (s.cfg.torque_limit > 0) {
-      T lim = T(s.cfg.torque_limit);
-      if (t > lim) t = lim;
-      if (t < -lim) t = -lim;
-    }
+    const T t = torque_cmd ? motor_torque<T>(0, 0, 0, 0, 0, 0, cmd, e.strength[j], T(s.cfg.torque_limit), true)
+                : hyb ? motor_torque<T>(qm[j], qdm[j], cmd, hyb[4 * j], hyb[4 * j + 2], hyb[4 * j + 1], hyb[4 * j + 3], e.strength[j], T(s.cfg.torque_limit), false)
+                      : motor_torque<T>(qm[j], qdm[j], cmd, e.kp[j], e.kd[j], T(0), T(0), e.strength[j], T(s.cfg.torque_limit), false);
     tau[j] = t;
     e.tau[j] = t;
   }
@@ -1226,6 +1252,7 @@ template <class F> void par_for(int n, int threads, F f) {
       auto& e = s->env[i];                                                                          \
       std::memset((void*)&e, 0, sizeof(e));                                                         \
       e.quat[3] = 1;                                                                                \
+      for (int j = 0; j < 12; j++) e.strength[j] = 1;                                               \
       e.band = i % (cfg->hf_bands > 1 ? cfg->hf_bands : 1);                                         \
     }                                                                                               \
     return s;                                                                                       \
@@ -1246,6 +1273,20 @@ template <class F> void par_for(int n, int threads, F f) {
     auto* s = (Sim<T>*)h;                                                                           \
     for (int i = 0; i < s->N; i++)                                                                  \
       for (int k = 0; k < 3; k++) s->env[i].fext[k] = force ? force[(size_t)i * 3 + k] : T(0);      \
+  }                                                                                                 \
+  extern "C" void etgo_set_motor_strength##SFX(void* h, const T* ratios, const uint8_t* mask) {     \
+    auto* s = (Sim<T>*)h;                                                                           \
+    for (int i = 0; i < s->N; i++) {                                                                \
+      if (mask && !mask[i]) continue;                                                               \
+      for (int j = 0; j < 12; j++) s->env[i].strength[j] = ratios ? ratios[(size_t)i * 12 + j] : T(1); \
+    }                                                                                               \
+  }                                                                                                 \
+  /* the motor model alone (golden tests): POSITION law with strength ratios and a torque limit */ \
+  extern "C" void etgo_motor_torque##SFX(const T* qdes, const T* q, const T* qd, const T* kp, const T* kd,  \
+                                          const T* strength, T limit, int torque_mode, int n, T* tau) {      \
+    for (int j = 0; j < n; j++)                                                                     \
+      tau[j] = torque_mode ? motor_torque<T>(0, 0, 0, 0, 0, 0, qdes[j], strength[j], limit, true)   \
+                           : motor_torque<T>(q[j], qd[j], qdes[j], kp[j], kd[j], T(0), T(0), strength[j], limit, false); \
   }                                                                                                 \
   extern "C" void etgo_set_reset_offsets##SFX(void* h, const T* xy, const uint8_t* mask) {           \
     auto* s = (Sim<T>*)h;                                                                           \

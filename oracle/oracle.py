@@ -99,6 +99,13 @@ class OracleSim:
         f = None if force is None else self._arr(force, (self.N, 3))
         self._f("set_external_force")(self._h, _p(f))
 
+    def set_motor_strength(self, ratios, mask=None):
+        """motor strength ratios [N,12] (laikago_motor.py:67-76; None = all ones) of the masked robots"""
+        a = None if ratios is None else self._arr(ratios, (self.N, 12))
+        if mask is not None:
+            mask = np.ascontiguousarray(mask, dtype=np.uint8)
+        self._f("set_motor_strength")(self._h, _p(a), _p(mask))
+
     def set_sensor_noise(self, stdev, seed=0):
         """stdev[5]: motor angle, velocity, torque, rpy, rpy rate (minitaur.py:102 order); None switches it off."""
         a = None if stdev is None else np.ascontiguousarray(stdev, dtype=np.float32)
@@ -218,6 +225,16 @@ def pd_torque(qdes, q, qd, kp, kd, dtype=np.float64):
     arrs = [np.ascontiguousarray(a, dtype=dtype) for a in (qdes, q, qd, kp, kd)]
     out = np.zeros(len(arrs[0]), dtype=dtype)
     getattr(lib(), "etgo_pd_torque" + sfx)(*[_p(a) for a in arrs], len(out), _p(out))
+    return out
+
+
+def motor_torque(qdes, q, qd, kp, kd, strength, limit=0.0, torque_mode=False, dtype=np.float64):
+    """the motor model with strength ratios and torque limit (laikago_motor.py:103-175)"""
+    sfx = "64" if np.dtype(dtype) == np.float64 else "32"
+    arrs = [np.ascontiguousarray(a, dtype=dtype) for a in (qdes, q, qd, kp, kd, strength)]
+    out = np.zeros(len(arrs[0]), dtype=dtype)
+    ct = C.c_double if sfx == "64" else C.c_float
+    getattr(lib(), "etgo_motor_torque" + sfx)(*[_p(a) for a in arrs], ct(limit), int(bool(torque_mode)), len(out), _p(out))
     return out
 
 

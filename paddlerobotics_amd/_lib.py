@@ -12,7 +12,7 @@ _LIB = None
 
 SYMBOLS = [
     "etg_create", "etg_destroy", "etg_last_error", "etg_version", "etg_lanes_per_robot", "etg_set_params",
-    "etg_set_heightfield", "etg_set_external_force", "etg_random_pushes", "etg_clear_pushes", "etg_set_reset_offsets", "etg_set_sensor_noise", "etg_reset", "etg_step", "etg_episode_stats", "etg_rollout_openloop",
+    "etg_set_heightfield", "etg_set_external_force", "etg_set_motor_strength", "etg_random_pushes", "etg_clear_pushes", "etg_set_reset_offsets", "etg_set_sensor_noise", "etg_reset", "etg_step", "etg_episode_stats", "etg_rollout_openloop",
     "etg_get_state",
     "etg_set_state", "etg_policy_create", "etg_policy_load", "etg_policy_forward", "etg_policy_load_std", "etg_policy_sample",
     "etg_policy_destroy", "etg_rollout_policy", "etg_fit_etg", "etg_leg_kinematics", "etg_extra_sensors", "etg_step_autoreset",
@@ -49,6 +49,7 @@ def load():
     lib.etg_set_params.argtypes = [vp, vp, vp, vp, i32, vp, vp]
     lib.etg_set_heightfield.argtypes = [vp, vp, vp]
     lib.etg_set_external_force.argtypes = [vp, vp, vp]
+    lib.etg_set_motor_strength.argtypes = [vp, vp, vp, vp]
     lib.etg_random_pushes.argtypes = [vp, C.c_uint64, C.c_float, i32, C.c_float, C.c_float, vp]
     lib.etg_clear_pushes.argtypes = [vp, vp, vp]
     lib.etg_set_reset_offsets.argtypes = [vp, vp, vp, vp]
@@ -81,6 +82,9 @@ def load():
     lib.etg_replay_end.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
     _LIB = lib
     return lib
+
+
+ETG_ERR_STATE = -5   # include/etgsim.h
 
 
 def check(code):

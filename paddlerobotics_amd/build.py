@@ -20,6 +20,24 @@ def hipcc_path():
     raise RuntimeError("hipcc not found: the MI355X library cannot be built")
 
 
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+         "-fno-slp-vectorize", "-fno-signed-zeros", "-ffinite-math-only", "-Wno-unused-value"]
+
+
+def kernel_source_hash():
+    """sha256 (16 hex digits) over the kernel sources, headers and compiler flags the library is built from: profile
+    artefacts that describe a kernel (profiles/r0N_pmc.json) are stamped with it and bench.py marks them stale when the
+    sources have moved on since."""
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for f in sorted(SOURCES + HEADERS):
+        path = os.path.join(CSRC, f)
+        if os.path.exists(path):
+            h.update(f.encode())
+            h.update(open(path, "rb").read())
+    return h.hexdigest()[:16]
+
+
 def is_stale():
     if not os.path.exists(LIB):
         return True
@@ -38,8 +56,7 @@ def build(force=False, verbose=False):
     # -fno-signed-zeros -ffinite-math-only: lets the compiler fold the x*0 / x*1 terms that the
     # structured link frames (axes (1,0,0), (0,c,s)) put into the generic vector algebra (-6 %
     # instructions); NaN guards use an exponent bit test, IK validity an explicit domain test.
-    cmd = [hipcc_path(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
-           "-fno-slp-vectorize", "-fno-signed-zeros", "-ffinite-math-only", "-Wno-unused-value", "-o", LIB] + srcs
+    cmd = [hipcc_path()] + FLAGS + ["-o", LIB] + srcs
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

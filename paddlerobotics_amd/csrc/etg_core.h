@@ -277,11 +277,14 @@ template <class F> ETG_HD void bwd6(const F* L, F* b) {  // b <- L^-T b
 
 // per-lane constants of a physics tick, fetched from the LDS parameter column ONCE per kernel (the compiler
 // parks them in AGPRs): a lone wave per SIMD cannot hide the LDS latency of re-reading them every tick
-template <class F> struct TickPar4 { F kp[3], kd[3], qd_des[3], tau_ff[3], sy, m0, mu, link[30]; V3<F> o1, gw; S3<F> I0s; };
+template <class F> struct TickPar4 { F kp[3], kd[3], qd_des[3], tau_ff[3], str[3], sy, m0, mu, link[30]; V3<F> o1, gw; S3<F> I0s; };
 template <class F, class Ctx> ETG_HD TickPar4<F> load_tick_par4(const Ctx& c) {
   // tpar: straight from the HBM parameter array into registers (no LDS hop)
   TickPar4<F> t;
-  for (int j = 0; j < 3; j++) { t.kp[j] = c.tpar(PR_KP + j); t.kd[j] = c.tpar(PR_KD + j); t.qd_des[j] = F(0.0f); t.tau_ff[j] = F(0.0f); }
+  for (int j = 0; j < 3; j++) {
+    t.kp[j] = c.tpar(PR_KP + j); t.kd[j] = c.tpar(PR_KD + j); t.qd_des[j] = F(0.0f); t.tau_ff[j] = F(0.0f);
+    t.str[j] = Ctx::kPlain ? F(1.0f) : c.tpar(PR_STR + j);   // motor strength ratios (laikago_motor.py:67-76), 1 unless set
+  }
   t.sy = c.tpar(PR_SY); t.m0 = c.tpar(PR_M0); t.mu = c.tpar(PR_MU);
   for (int k = 0; k < 30; k++) t.link[k] = c.tpar(PR_LINK + k);
   t.o1 = {c.tpar(PR_O1), c.tpar(PR_O1 + 1), c.tpar(PR_O1 + 2)};
@@ -295,7 +298,7 @@ template <class F, class Ctx> ETG_HD TickPar4<F> load_tick_par4(const Ctx& c) {
 template <class F, class Ctx>
 ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, LaneState<F>& L, const F* qdes,
                          const V3<F>& fext_w, bool torque_cmd = false,
-                         const F* pd = nullptr) {   // pd[0..2] angles, pd[3..5] velocities the PD law reads (EtgConfig.pd_latency)
+                         const F* pd = nullptr) {   // pd[0..2] angles, pd[3..5] velocities the PD law reads (EtgConfig.pd_latency), pd[6..8] the angles the command clip refers to
   typedef V3<F> V;
   typedef SV<F> W;
   const F dt(K.dt), zero(0.0f), one(1.0f);
@@ -305,15 +308,17 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
 #pragma unroll
   for (int j = 0; j < 3; j++) {
     F cmd = qdes[j];
-    if (!Ctx::kPlain) {   // a1.py:439-457; branch-free: an option that is off clamps at +-1e30 (see physics_tick16)
+    if (!Ctx::kPlain) {   // a1.py:439-457 around GetMotorAngles() = the delayed reading pd[6 + j]; branch-free: an option that is off clamps at +-1e30 (see physics_tick16)
       const F clipv((K.clip_cmd > 0.0f && !torque_cmd) ? K.clip_cmd : 1e30f);
-      cmd = fminf_(fmaxf_(cmd, L.q[j] - clipv), L.q[j] + clipv);
+      const F qref = pd ? pd[6 + j] : L.q[j];
+      cmd = fminf_(fmaxf_(cmd, qref - clipv), qref + clipv);
     }
     const F qm = (!Ctx::kPlain && pd) ? pd[j] : L.q[j], qdm = (!Ctx::kPlain && pd) ? pd[3 + j] : L.qd[j];   // minitaur.py:1195-1199
+    // laikago_motor.py:103-175: the law, x strength ratio, then the clip to +-torque_limit; TORQUE mode: ratio x command, no clip
     F t = Ctx::kPlain ? -(tp.kp[j] * (L.q[j] - cmd)) - tp.kd[j] * L.qd[j]
-                      : (torque_cmd ? cmd : (-(tp.kp[j] * (qm - cmd)) - tp.kd[j] * (qdm - tp.qd_des[j])) + tp.tau_ff[j]);   // TORQUE mode: pass-through
+                      : (torque_cmd ? tp.str[j] * cmd : tp.str[j] * ((-(tp.kp[j] * (qm - cmd)) - tp.kd[j] * (qdm - tp.qd_des[j])) + tp.tau_ff[j]));
     if (!Ctx::kPlain) {
-      const F tlim(K.torque_limit > 0.0f ? K.torque_limit : 1e30f);
+      const F tlim((K.torque_limit > 0.0f && !torque_cmd) ? K.torque_limit : 1e30f);
       t = fminf_(fmaxf_(t, -tlim), tlim);
     }
     tau[j] = t;
@@ -462,7 +467,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
     phi = (fw.z - hgt) * nwz - F(K.foot_radius);
     // contact frame in world: n, t1 = normalised (x_w - (x_w.n) n), t2 = n x t1; then to base coords
     // with |n| = 1: |x_w - nx n|^2 = 1 - nx^2 and n x t1 = (0, nz, -ny) / |..|
-    const F it1 = rsqrt_(one - nwx * nwx);
+    const F it1 = rsqrt_hf_(one - nwx * nwx);
     const V nw = {nwx, nwy, nwz};
     const V t1w = {it1 * (one - nwx * nwx), -(it1 * (nwx * nwy)), -(it1 * (nwx * nwz))};
     const F t2y = it1 * nwz, t2z = -(it1 * nwy);
@@ -933,6 +938,20 @@ template <class F, class Ctx> ETG_HD void pd_reading(const Ctx& c, const KCfg& K
 #pragma unroll
   for (int k = 0; k < 6; k++) pd[k] = oma * c.ld_ring(ra, sa, k) + a * c.ld_ring(rb_, sb, k);
 }
+// GetMotorAngles() for A1._ClipMotorCommands: see clip_reading16
+template <class F, class Ctx> ETG_HD void clip_reading(const Ctx& c, const KCfg& K, const float* ring, int tick, bool live, const F* now, F* out) {
+  const int n = c.uniform_int(c.par(PR_LAT_N));
+  if (n < 0) {
+#pragma unroll
+    for (int k = 0; k < 3; k++) out[k] = wrap_pi_(now[k]);
+    return;
+  }
+  const F alpha = c.par(PR_LAT_A);
+  const int ta = tick - n < 0 ? 0 : tick - n, tb = tick - n - 1 < 0 ? 0 : tick - n - 1;
+  const float *ra = live ? ring : ring_of_tick4(K, ring, ta), *rb_ = live ? ring : ring_of_tick4(K, ring, tb);
+#pragma unroll
+  for (int k = 0; k < 3; k++) out[k] = wrap_pi_((F(1.0f) - alpha) * c.ld_ring(ra, ta & (RING - 1), k) + alpha * c.ld_ring(rb_, tb & (RING - 1), k));
+}
 template <class F, class Ctx>
 ETG_HD Delayed<F> ring_read(const Ctx& c, const KCfg& K, const float* ring, int tick) {
   // n_steps_ago / blend_alpha are env-uniform; lat_n < 0 encodes latency <= 0.  Readings of ticks up to the reset tick come
@@ -1199,16 +1218,18 @@ ETG_HD void control_step_core(const Ctx& c, const KCfg& K, TickPar4<F>& tp, cons
   const int ia = R_ - 1 - mlat;
   const int ib = n_lat < 0 ? ia : (ia == 0 ? R_ - 1 : ia - 1);
   const bool pdl = !Ctx::kPlain && K.pd_n >= 0;
+  const bool cl = !Ctx::kPlain && K.clip_cmd > 0.0f && !torque_cmd;   // the command clip reads the delayed angles of every tick
   for (int i = 0; i < K.action_repeat; i++) {  // minitaur.py:254-258
     F proc[3];
     float lerp = (float)(i + 1) * inv_repeat;
 #pragma unroll
     for (int j = 0; j < 3; j++) proc[j] = interp ? last[j] + F(lerp) * (qdes[j] - last[j]) : qdes[j];
-    F pd[6] = {L.q[0], L.q[1], L.q[2], L.qd[0], L.qd[1], L.qd[2]};   // EtgConfig.pd_latency: see control_step16_core
+    F pd[9] = {L.q[0], L.q[1], L.q[2], L.qd[0], L.qd[1], L.qd[2], L.q[0], L.q[1], L.q[2]};   // EtgConfig.pd_latency: see control_step16_core
     if (pdl) pd_reading(c, K, ring, tick, false, pd);
+    if (cl) clip_reading(c, K, ring, tick, false, L.q, pd + 6);
     physics_tick(c, K, tp, L, proc, fext, torque_cmd, Ctx::kPlain ? (const F*)nullptr : pd);
     tick++;
-    if (pdl || i == ia || i == ib) ring_push(c, ring, tick & (RING - 1), L);
+    if (pdl || cl || i == ia || i == ib) ring_push(c, ring, tick & (RING - 1), L);
   }
 #pragma unroll
   for (int j = 0; j < 3; j++) S.last[j] = qdes[j];
@@ -1327,8 +1348,9 @@ ETG_HD void reset_settle(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   int tick = 0;
   const TickPar4<F> tp = load_tick_par4<F>(c);
   for (int i = 0; i < K.settle_ticks; i++) {  // a1.py:294-297
-    F pd[6] = {L.q[0], L.q[1], L.q[2], L.qd[0], L.qd[1], L.qd[2]};
+    F pd[9] = {L.q[0], L.q[1], L.q[2], L.qd[0], L.qd[1], L.qd[2], L.q[0], L.q[1], L.q[2]};
     if (!Ctx::kPlain && K.pd_n >= 0) pd_reading(c, K, ring, tick, true, pd);
+    if (!Ctx::kPlain && K.clip_cmd > 0.0f) clip_reading(c, K, ring, tick, true, L.q, pd + 6);
     physics_tick(c, K, tp, L, pose, V3<F>{F(0.0f), F(0.0f), F(0.0f)}, false, Ctx::kPlain ? (const F*)nullptr : pd);
     tick++;
     ring_push(c, ring, tick & (RING - 1), L);

@@ -78,7 +78,7 @@ template <class F, class Ctx> ETG_HD SV<F> quad_bcast(const Ctx& c, SV<F> v, int
 // per-lane constants of a physics tick, read from the LDS parameter column ONCE per kernel and kept in
 // registers over the 13 (step) / 500 (settle) ticks: a lone wave per SIMD cannot hide the LDS latency of
 // re-reading them at the top of every tick (phase profile: +~1000 cycles per tick)
-template <class F> struct TickPar { F kp, kd, qd_des, tau_ff, sy, m0, mu, link[10]; V3<F> o1, gw, fext; S3<F> I0s; };
+template <class F> struct TickPar { F kp, kd, qd_des, tau_ff, str, sy, m0, mu, link[10]; V3<F> o1, gw, fext; S3<F> I0s; };
 template <class F, class Ctx> ETG_HD TickPar<F> load_tick_par(const Ctx& c) {
   TickPar<F> t;
   // tpar*: straight from the HBM parameter array into registers (no LDS hop) -- issued at kernel start, consumed in
@@ -90,6 +90,7 @@ template <class F, class Ctx> ETG_HD TickPar<F> load_tick_par(const Ctx& c) {
   t.I0s = {c.tpar(PR_I0), c.tpar(PR_I0 + 1), c.tpar(PR_I0 + 2), c.tpar(PR_I0 + 3), c.tpar(PR_I0 + 4), c.tpar(PR_I0 + 5)};
   t.fext = {F(0.0f), F(0.0f), F(0.0f)};   // external trunk force (world frame); control_step16 fills it in
   t.qd_des = F(0.0f); t.tau_ff = F(0.0f); // HYBRID motor commands only (laikago_motor.py:152-167)
+  t.str = Ctx::kPlain ? F(1.0f) : c.tpar_joint(PR_STR);   // motor strength ratio (laikago_motor.py:67-76), 1 unless set
   return t;
 }
 
@@ -118,7 +119,7 @@ template <class F, class Ctx> ETG_HD LegGeo<F> leg_geometry(const Ctx& c, const 
 // ------------------------------------------------------------------ one physics tick, 16 lanes per robot
 template <class F, class Ctx>
 ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, State16<F>& L, F qdes, bool torque_cmd = false,
-                           const F* pd = nullptr) {   // pd: (angle, velocity) the PD law reads instead of the true ones (pd_latency)
+                           const F* pd = nullptr) {   // pd: (angle, velocity) the PD law reads instead of the true ones (pd_latency), pd[2]: the angle the command clip refers to
   typedef V3<F> V;
   typedef SV<F> W;
   const F dt(K.dt), zero(0.0f), one(1.0f);
@@ -131,15 +132,17 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   // ---- PD motor model (laikago_motor.py:165-173), this lane's joint
   // The option code of the all-options instantiations is branch-free inside the tick (a uniform branch splits the scheduler's
   // block: +160 / +200 cycles per tick in the PD and Schur phases): an option that is off clamps at +-1e30 / adds a zero force.
-  if (!Ctx::kPlain) {   // a1.py:439-457
+  if (!Ctx::kPlain) {   // a1.py:439-457: the command is clipped to +-clip_cmd around GetMotorAngles(), the delayed reading (pd[2])
     const F clipv((K.clip_cmd > 0.0f && !torque_cmd) ? K.clip_cmd : 1e30f);
-    qdes = fminf_(fmaxf_(qdes, L.q - clipv), L.q + clipv);
+    const F qref = pd ? pd[2] : L.q;
+    qdes = fminf_(fmaxf_(qdes, qref - clipv), qref + clipv);
   }
   const F qm = (!Ctx::kPlain && pd) ? pd[0] : L.q, qdm = (!Ctx::kPlain && pd) ? pd[1] : L.qd;   // _GetPDObservation, minitaur.py:1195-1199
+  // laikago_motor.py:103-175: the law, x strength ratio, then the clip to +-torque_limit; TORQUE mode: ratio x command, no clip
   F tau = Ctx::kPlain ? mj * (-(tp.kp * (L.q - qdes)) - tp.kd * L.qd)
-                      : (torque_cmd ? mj * qdes : mj * ((-(tp.kp * (qm - qdes)) - tp.kd * (qdm - tp.qd_des)) + tp.tau_ff));   // TORQUE mode: pass-through
+                      : (torque_cmd ? mj * (tp.str * qdes) : mj * (tp.str * ((-(tp.kp * (qm - qdes)) - tp.kd * (qdm - tp.qd_des)) + tp.tau_ff)));
   if (!Ctx::kPlain) {
-    const F tlim(K.torque_limit > 0.0f ? K.torque_limit : 1e30f);
+    const F tlim((K.torque_limit > 0.0f && !torque_cmd) ? K.torque_limit : 1e30f);
     tau = fminf_(fmaxf_(tau, -tlim), tlim);
   }
 
@@ -315,7 +318,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
     // contact frame in world coordinates: n, t1 = (x_w - (x_w.n) n) / |..|, t2 = n x t1.  With |n| = 1:
     // |x_w - nx n|^2 = 1 - nx^2 and n x t1 = (0, nz, -ny) / |..|.  Each lane rotates only ITS row's direction (and n,
     // which every lane needs for the contact point) into base coordinates.
-    const F it1 = rsqrt_(one - nwx * nwx);
+    const F it1 = rsqrt_hf_(one - nwx * nwx);
     const V nw = {nwx, nwy, nwz};
     const V t1w = {it1 * (one - nwx * nwx), -(it1 * (nwx * nwy)), -(it1 * (nwx * nwz))};
     const V t2w = {zero, it1 * nwz, -(it1 * nwy)};
@@ -708,6 +711,17 @@ template <class F, class Ctx> ETG_HD void pd_reading16(const Ctx& c, const KCfg&
   pd[0] = oma * c.ld_ring_joint(ra, sa, 0) + a * c.ld_ring_joint(rb_, sb, 0);
   pd[1] = oma * c.ld_ring_joint(ra, sa, 3) + a * c.ld_ring_joint(rb_, sb, 3);
 }
+// GetMotorAngles() for A1._ClipMotorCommands (a1.py:439-457; minitaur.py:753-764): this lane's joint angle as the control
+// observation sees it -- the robot's control latency (PR_LAT_N / PR_LAT_A, the blend of minitaur.py:1172-1193) -- wrapped to
+// [-pi, pi].  `now`: the true angle (latency 0).  Every tick's reading must be in the ring (the caller pushes every tick).
+template <class F, class Ctx> ETG_HD F clip_reading16(const Ctx& c, const KCfg& K, const float* ring, int tick, bool live, F now) {
+  const int n = c.uniform_int(c.par(PR_LAT_N));
+  if (n < 0) return wrap_pi_(now);
+  const F alpha = c.par(PR_LAT_A);
+  const int ta = tick - n < 0 ? 0 : tick - n, tb = tick - n - 1 < 0 ? 0 : tick - n - 1;
+  const float *ra = live ? ring : ring_of_tick(K, ring, ta), *rb_ = live ? ring : ring_of_tick(K, ring, tb);
+  return wrap_pi_((F(1.0f) - alpha) * c.ld_ring_joint(ra, ta & (RING - 1), 0) + alpha * c.ld_ring_joint(rb_, tb & (RING - 1), 0));
+}
 
 // ------------------------------------------------------------------ ETG + IK: computed by every lane of the leg, each keeps its joint
 template <class F, class Ctx>
@@ -892,15 +906,17 @@ ETG_HD void control_step16_core(const Ctx& c, const KCfg& K, TickPar<F>& tp, Sta
   const int ib = n_lat < 0 ? ia : (ia == 0 ? R_ - 1 : ia - 1);
   if (hybrid_cmd) { tp.kp = hyb[0]; tp.qd_des = mj * hyb[1]; tp.kd = hyb[2]; tp.tau_ff = mj * hyb[3]; }
   const bool pdl = !Ctx::kPlain && K.pd_n >= 0;
+  const bool cl = !Ctx::kPlain && K.clip_cmd > 0.0f && !torque_cmd;   // the command clip reads the delayed angle of every tick
   int tick = S.tick;
   for (int i = 0; i < K.action_repeat; i++) {
     float lerp = (float)(i + 1) * inv_repeat;
     F proc = interp ? last + F(lerp) * (qdes - last) : qdes;
-    F pd[2] = {L.q, L.qd};   // EtgConfig.pd_latency: the PD law reads a delayed joint state, so every tick's reading enters the ring
+    F pd[3] = {L.q, L.qd, L.q};   // EtgConfig.pd_latency: the PD law reads a delayed joint state, so every tick's reading enters the ring
     if (pdl) pd_reading16(c, K, ring, tick, false, pd);
+    if (cl) pd[2] = clip_reading16(c, K, ring, tick, false, L.q);
     physics_tick16(c, K, tp, L, proc, torque_cmd, Ctx::kPlain ? (const F*)nullptr : pd);   // (ONE inlined copy of the tick)
     tick++;
-    if (pdl || i == ia || i == ib) ring_push16(c, ring, tick & (RING - 1), L);
+    if (pdl || cl || i == ia || i == ib) ring_push16(c, ring, tick & (RING - 1), L);
   }
   S.tick = tick;
   S.last = qdes;
@@ -1011,8 +1027,9 @@ ETG_HD void reset_settle16(const Ctx& c, const KCfg& K, State16<F>& L, float* ri
   int tick = 0;
   const TickPar<F> tp = load_tick_par<F>(c);
   for (int i = 0; i < K.settle_ticks; i++) {
-    F pd[2] = {L.q, L.qd};
+    F pd[3] = {L.q, L.qd, L.q};
     if (!Ctx::kPlain && K.pd_n >= 0) pd_reading16(c, K, ring, tick, true, pd);
+    if (!Ctx::kPlain && K.clip_cmd > 0.0f) pd[2] = clip_reading16(c, K, ring, tick, true, L.q);
     physics_tick16(c, K, tp, L, pose, false, Ctx::kPlain ? (const F*)nullptr : pd);
     tick++;
     ring_push16(c, ring, tick & (RING - 1), L);

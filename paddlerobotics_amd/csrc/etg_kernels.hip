@@ -151,8 +151,18 @@ __global__ void __launch_bounds__(256) k_next_take(KCfg K, DevState D, NextDyn N
   if (col >= NL) return;
   const int env = col >> 2;
   if ((mask && !mask[env]) || !NX.ok[env]) return;
-  for (int k = 0; k < PR_N; k++) D.par[(size_t)k * NL + col] = NX.par[(size_t)k * NL + col];
+  for (int k = 0; k < PR_DERIVED; k++) D.par[(size_t)k * NL + col] = NX.par[(size_t)k * NL + col];
   for (int k = col & 3; k < ETG_DYN_DIM; k += 4) D.dyn[(size_t)env * ETG_DYN_DIM + k] = NX.dyn[(size_t)env * ETG_DYN_DIM + k];
+}
+// etg_prepare_next_dynamics replaces a robot's settle cache -- cached state AND the cache's copy of the latency ring -- while the
+// robot keeps running.  A running robot still READS that ring copy for every delayed reading of a tick at or before its reset
+// tick (ring_of_tick / KCfg.cring), i.e. during the first RING ticks of its episode.  Such YOUNG robots are left out of the
+// call: out[env] = masked && the robot's episode is at least RING ticks old.  Their pending flag stays 0, so the caller's next
+// refresh draws rows for them again.
+__global__ void __launch_bounds__(256) k_next_old_enough(KCfg K, DevState D, const uint8_t* mask, uint8_t* out) {
+  const int env = blockIdx.x * blockDim.x + threadIdx.x;
+  if (env >= K.n_env) return;
+  out[env] = ((!mask || mask[env]) && D.ictl[(size_t)IC_TICK * K.n_env + env] - K.settle_ticks >= RING) ? 1 : 0;
 }
 // ok[env] = value for the masked robots; scratch flags start as "not cached" so that the settle runs for them
 __global__ void __launch_bounds__(256) k_next_flags(KCfg K, unsigned char* ok, const uint8_t* mask, unsigned char value) {
@@ -206,11 +216,11 @@ __global__ void __launch_bounds__(BLOCK) k_set_params(KCfg K, ModelF M, DevState
   if (mask && !mask[c.env]) return;
   if (dyn) {
     if (c.lane == 0) D.cache_ok[c.env] = 0;   // the settle depends on the dynamic parameters
-    float row[ETG_DYN_DIM], out[PR_N];
+    float row[ETG_DYN_DIM], out[PR_DERIVED];
     for (int k = 0; k < ETG_DYN_DIM; k++) row[k] = dyn[(size_t)c.env * ETG_DYN_DIM + k];
     for (int k = c.lane; k < ETG_DYN_DIM; k += 4) D.dyn[(size_t)c.env * ETG_DYN_DIM + k] = row[k];   // kept for the dynamic_vec sensor
     derive_lane_params(M, row, c.lane, K.dt, out);
-    for (int k = 0; k < PR_N; k++) D.par[(size_t)k * c.NL + c.gid] = out[k];
+    for (int k = 0; k < PR_DERIVED; k++) D.par[(size_t)k * c.NL + c.gid] = out[k];   // (the strength ratios PR_STR.. are not derived: etg_set_motor_strength)
   }
   // the 63 ETG floats of a robot are copied by its 4 lanes (16 each)
   for (int k = c.lane; k < 60; k += 4)
@@ -318,6 +328,20 @@ __global__ void __launch_bounds__(256) k_fin_store(KCfg K, DevState D, const uin
   for (int leg = 0; leg < 4; leg++) fin[(size_t)(FIN_FWX + leg) * N + env] = D.legctl[(size_t)LC_LAST_FOOT_X * 4 * N + 4 * env + leg];
   fin[(size_t)FIN_OK * N + env] = 1.0f;
 }
+// motor strength ratios (etg_set_motor_strength): par[PR_STR + j][4 env + leg] = ratios[env][3 leg + j], or 1 when ratios is null
+__global__ void __launch_bounds__(256) k_set_strength(KCfg K, DevState D, const float* ratios, const uint8_t* mask) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  const int NL = 4 * K.n_env;
+  if (col >= NL) return;
+  const int env = col >> 2, leg = col & 3;
+  if (mask && !mask[env]) return;
+  for (int j = 0; j < 3; j++) D.par[(size_t)(PR_STR + j) * NL + col] = ratios ? ratios[(size_t)env * ETG_NUM_MOTORS + 3 * leg + j] : 1.0f;
+  if (leg == 0) {   // the reset settle runs under the motor model: the robot's cached settle and cached restart are stale
+    D.cache_ok[env] = 0;
+    D.cache_off[(size_t)FIN_OK * K.n_env + env] = 0.0f;
+  }
+}
+
 __global__ void __launch_bounds__(256) k_fin_clear(KCfg K, DevState D, const uint8_t* mask) {
   const int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= K.n_env || (mask && !mask[env])) return;
@@ -383,7 +407,7 @@ __device__ __forceinline__ void step4_body(const KCfg& K, const DevState& D, con
   if (AUTO && d > 0.5f) {   // whole quads take this branch together
     const int N = K.n_env;
     if (NX.ok && NX.ok[c.env]) {   // parameters prepared for the next episode: install them (the cached settle below is theirs)
-      for (int k = 0; k < PR_N; k++) D.par[(size_t)k * c.NL + c.gid] = NX.par[(size_t)k * c.NL + c.gid];
+      for (int k = 0; k < PR_DERIVED; k++) D.par[(size_t)k * c.NL + c.gid] = NX.par[(size_t)k * c.NL + c.gid];
       for (int k = c.lane; k < ETG_DYN_DIM; k += 4) D.dyn[(size_t)c.env * ETG_DYN_DIM + k] = NX.dyn[(size_t)c.env * ETG_DYN_DIM + k];
       __builtin_amdgcn_s_waitcnt(0);          // the quad's reads of the flag are done before its lane 0 clears it
       __builtin_amdgcn_wave_barrier();
@@ -784,7 +808,7 @@ __device__ __forceinline__ void step16_body(const KCfg& K, const DevState& D, co
   if (AUTO && d > 0.5f) {   // whole 16-lane rows take this branch together (d is the robot's)
     const int N = K.n_env;
     if (NX.ok && NX.ok[c.env]) {   // parameters prepared for the next episode: install them (the cached settle below is theirs)
-      for (int k = c.sub; k < PR_N; k += 4) D.par[(size_t)k * c.NL + c.col] = NX.par[(size_t)k * c.NL + c.col];   // a leg's 4 lanes share its column
+      for (int k = c.sub; k < PR_DERIVED; k += 4) D.par[(size_t)k * c.NL + c.col] = NX.par[(size_t)k * c.NL + c.col];   // a leg's 4 lanes share its column
       for (int k = c.r; k < ETG_DYN_DIM; k += 16) D.dyn[(size_t)c.env * ETG_DYN_DIM + k] = NX.dyn[(size_t)c.env * ETG_DYN_DIM + k];
       __builtin_amdgcn_s_waitcnt(0);          // the row's reads of the flag and its stores are done before lane 0 clears it
       __builtin_amdgcn_wave_barrier();
@@ -1250,6 +1274,7 @@ struct EtgHandle {
   NextDyn NX;
   float *nx_base, *nx_leg, *nx_ring;
   unsigned char* nx_cache_ok;
+  uint8_t* nx_mask;       // etg_prepare_next_dynamics: the call's mask without the robots whose episode is younger than the ring
   // all_cached again after MASKED resets: every invalidation bumps inval_seq; a masked etg_reset ends with a count of the robots
   // still without a cached settle, written with the sequence number it ran under to pinned host memory (cached_report[0] = count,
   // [1] = seq); the next etg_step_autoreset / etg_prepare_next_dynamics trusts a zero count only under the CURRENT number
@@ -1329,6 +1354,7 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   h->cached_report_dev = nullptr;
   h->nx_base = h->nx_leg = h->nx_ring = nullptr;
   h->nx_cache_ok = nullptr;
+  h->nx_mask = nullptr;
   // 0 = auto.  Both kernels hold one wave per SIMD (register footprint), so the chip runs 1024 waves
   // at a time: 16 lanes/robot fills it with 4096 robots and is faster per robot up to there; beyond
   // that the 4-lanes/robot kernel packs 4x the robots per wave (measured crossover).
@@ -1359,6 +1385,7 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   if (hipMalloc((void**)&ddyn, dyn.size() * 4) != hipSuccess) return fail(ETG_ERR_ALLOC, "etg_create: hipMalloc failed");
   HIP_TRY(hipMemcpy(ddyn, dyn.data(), dyn.size() * 4, hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_set_params, dim3(grid_for(h)), dim3(BLOCK), 0, 0, h->K, h->M, h->D, ddyn, nullptr, nullptr, 0, nullptr);
+  hipLaunchKernelGGL(k_set_strength, dim3((4 * h->N + 255) / 256), dim3(256), 0, 0, h->K, h->D, (const float*)nullptr, (const uint8_t*)nullptr);
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipFree(ddyn));
   *out = h;
@@ -1370,7 +1397,7 @@ extern "C" void etg_destroy(EtgHandle* h) {
   (void)hipSetDevice(h->device);
   void* ptrs[] = {h->D.base, h->D.leg, h->D.ctl, h->D.ictl, h->D.legctl, h->D.etgp, h->D.par, h->D.ring, h->hf, h->D.dyn,
                   h->D.cache_base, h->D.cache_leg, h->D.cache_ring, h->D.cache_ok, h->D.reset_off, h->D.cache_off,
-                  h->tmp_obs, h->tmp_reward, h->tmp_done, h->NX.par, h->NX.dyn, h->NX.ok, h->nx_base, h->nx_leg, h->nx_ring, h->nx_cache_ok};
+                  h->tmp_obs, h->tmp_reward, h->tmp_done, h->NX.par, h->NX.dyn, h->NX.ok, h->nx_base, h->nx_leg, h->nx_ring, h->nx_cache_ok, h->nx_mask};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->cached_report) (void)hipHostFree((void*)h->cached_report);
@@ -1464,6 +1491,22 @@ extern "C" int etg_set_external_force(EtgHandle* h, const float* force, void* st
   return ETG_OK;
 }
 
+extern "C" int etg_set_motor_strength(EtgHandle* h, const float* ratios, const uint8_t* mask, void* stream) {
+  CHECK_HANDLE(h);
+  hipLaunchKernelGGL(k_set_strength, dim3((4 * h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->D, ratios, mask);
+  HIP_TRY(hipGetLastError());
+  // ratios installed for anybody: the kernels with the robot-layer options read them (a later NULL for everybody switches back)
+  h->K.strength_on = ratios ? 1 : (mask ? h->K.strength_on : 0);
+  // the reset settle runs under the motor model too: cached settles of the touched robots are stale (k_set_strength cleared
+  // their flags), and so are the settles prepared for their next episodes
+  h->all_cached = false;
+  h->inval_seq++;
+  if (h->NX.ok)
+    hipLaunchKernelGGL(k_next_flags, dim3((h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->NX.ok, mask, (unsigned char)0);
+  HIP_TRY(hipGetLastError());
+  return ETG_OK;
+}
+
 extern "C" int etg_random_pushes(EtgHandle* h, uint64_t seed, float prob, int duration_steps, float fmin, float fmax,
                                  void* stream) {
   CHECK_HANDLE(h);
@@ -1521,7 +1564,7 @@ extern "C" int etg_prepare_next_dynamics(EtgHandle* h, const float* dyn, const u
     struct { void** p; size_t bytes; } allocs[] = {
         {(void**)&h->NX.par, PR_N * NL * 4}, {(void**)&h->NX.dyn, ETG_DYN_DIM * N * 4}, {(void**)&h->NX.ok, N},
         {(void**)&h->nx_base, BS_N * N * 4}, {(void**)&h->nx_leg, LG_N * NL * 4}, {(void**)&h->nx_ring, (size_t)RING * 8 * NL * 4},
-        {(void**)&h->nx_cache_ok, N}};
+        {(void**)&h->nx_cache_ok, N}, {(void**)&h->nx_mask, N}};
     for (auto& a : allocs) {
       if (hipMalloc(a.p, a.bytes) != hipSuccess) return fail(ETG_ERR_ALLOC, "etg_prepare_next_dynamics: hipMalloc failed");
       HIP_TRY(hipMemsetAsync(*a.p, 0, a.bytes, (hipStream_t)stream));
@@ -1536,6 +1579,8 @@ extern "C" int etg_prepare_next_dynamics(EtgHandle* h, const float* dyn, const u
   Dn.dyn = h->NX.dyn;
   Dn.base = h->nx_base; Dn.leg = h->nx_leg; Dn.ring = h->nx_ring;
   Dn.cache_ok = h->nx_cache_ok;
+  hipLaunchKernelGGL(k_next_old_enough, ge, dim3(256), 0, s, h->K, h->D, mask, h->nx_mask);
+  mask = h->nx_mask;   // robots in the first RING ticks of their episode still read the cache's ring: not this time
   hipLaunchKernelGGL(k_set_params, dim3(grid_for(h)), dim3(BLOCK), 0, s, h->K, h->M, Dn, dyn, (const float*)nullptr,
                      (const float*)nullptr, 0, mask);   // (derives the rows; clears the scratch "cached" flag of the masked robots)
   if (h->lanes == 16) {
@@ -1746,10 +1791,12 @@ extern "C" int etg_rollout_actions(EtgHandle* h, const float* actions, int n_ste
       LAUNCH4(k_rollout_actions, g4, s, h->K, h->D, m, a, obs, T);
     }
     launch_obs_noise(h, m, nullptr, obs, s);
+    // the last step of EVERY launch writes its row to `obs`, not to the tape: the tape gets its copy per chunk (rows 49, 99,
+    // ... and n_steps - 1; recorded observations carry no sensor noise, which the check above enforces)
+    if (rec_obs)
+      HIP_TRY(hipMemcpyAsync(rec_obs + (size_t)(d0 + m - 1) * N * ETG_OBS_DIM, obs, N * ETG_OBS_DIM * sizeof(float), hipMemcpyDeviceToDevice, s));
   }
   HIP_TRY(hipGetLastError());
-  if (rec_obs)   // the last step's row went to `obs`: the tape gets its copy
-    HIP_TRY(hipMemcpyAsync(rec_obs + (size_t)(n_steps - 1) * N * ETG_OBS_DIM, obs, N * ETG_OBS_DIM * sizeof(float), hipMemcpyDeviceToDevice, s));
   if (ret || len) return etg_episode_stats(h, ret, len, stream);
   return ETG_OK;
 }

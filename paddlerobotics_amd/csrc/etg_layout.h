@@ -40,7 +40,8 @@ enum { EP_W = 0, EP_B = 60, EP_N = 63 };
 // per-lane derived parameters, in the order derive_lane_params() writes them
 enum { PR_LINK = 0 /* 3 x (m, com3, Ic6) */, PR_O1 = 30, PR_SY = 33, PR_KP = 34, PR_KD = 37, PR_MU = 40, PR_M0 = 41,
        PR_I0 = 42, PR_G = 48, PR_LAT_N = 51, PR_LAT_A = 52, PR_BASE_FOOT = 53, PR_POSE = 56, PR_EMEAN = 59,
-       PR_ESTD = 62, PR_HIPSIGN = 65, PR_N = 66 };
+       PR_ESTD = 62, PR_HIPSIGN = 65, PR_DERIVED = 66 /* derive_lane_params() writes [0, PR_DERIVED) */,
+       PR_STR = 66 /* 3: motor strength ratios of the leg's joints (etg_set_motor_strength), 1 unless set */, PR_N = 69 };
 
 struct KCfg {
   int n_env;
@@ -83,12 +84,13 @@ struct KCfg {
   float warmstart_t;     // EtgConfig.warmstart_friction: warm-start factor of the friction rows (warmstart: the normal rows)
   float slop;            // EtgConfig.contact_slop: added to a contact's distance before the velocity target is formed
   float restitution;     // EtgConfig.foot_restitution (combined coefficient; 0 = off)
+  int strength_on;       // motor strength ratios other than 1 are installed (etg_set_motor_strength)
 };
 
 // the default robot layer (what train.py / pretrain.py run): the PLAIN kernel instantiations compile the options out
 inline bool plain_config(const KCfg& K) {
   return K.motor_mode == 0 && !K.enable_filter && !K.enable_interp && !(K.torque_limit > 0.0f) && !(K.clip_cmd > 0.0f) &&
-         !K.ext_force && !K.knee && K.etg_on && !K.fric_pyramid && K.pd_n < 0 && !(K.restitution > 0.0f);   // (joint limits: in every instantiation)
+         !K.ext_force && !K.knee && K.etg_on && !K.fric_pyramid && K.pd_n < 0 && !(K.restitution > 0.0f) && !K.strength_on;   // (joint limits: in every instantiation)
 }
 
 // counter-based standard normal pair for (seed, robot, observation index, channel): splitmix64 finaliser twice, then
@@ -157,9 +159,15 @@ ETG_HD bool isfinite_(float a) {
 #if defined(__HIPCC__)
 // Hardware 1-ulp reciprocal / rsqrt / sqrt: the IEEE-exact expansions cost 10-15 dependent
 // instructions each and sit on the serial critical path of the LDL^T and of every PGS turn.
+#if defined(ETG_IEEE_ALL)   // A/B build variant (tools/hf_tracking_probe.py): IEEE division / square root everywhere
+ETG_HD float rcp_(float a) { return 1.0f / a; }
+ETG_HD float rsqrt_(float a) { return 1.0f / sqrtf(a); }
+ETG_HD float sqrt_(float a) { return sqrtf(a); }
+#else
 ETG_HD float rcp_(float a) { return __builtin_amdgcn_rcpf(a); }
 ETG_HD float rsqrt_(float a) { return __builtin_amdgcn_rsqf(a); }
 ETG_HD float sqrt_(float a) { return __builtin_amdgcn_sqrtf(a); }
+#endif
 // sin/cos for joint angles: Cody-Waite reduction by pi/2 + cephes minimax polynomials
 // (|error| < 2e-7 for |x| < 1e3; joint angles are within +-4.2 rad).  libm's sincosf carries a
 // Payne-Hanek slow path whose branches alone cost more than this whole routine.
@@ -209,6 +217,14 @@ ETG_HD float sqrt_(float a) { return sqrtf(a); }
 ETG_HD void sincos_(float a, float& s, float& c) { s = sinf(a); c = cosf(a); }
 ETG_HD void sincos_tick_(float a, float& s, float& c) { s = sinf(a); c = cosf(a); }
 #endif
+// 1 / sqrt in the terrain normal and the contact frame: the hardware's v_rsq_f32, or (A/B build variant ETG_IEEE_HF) IEEE ops
+ETG_HD float rsqrt_hf_(float a) {
+#if defined(ETG_IEEE_HF) || defined(ETG_IEEE_ALL)
+  return 1.0f / sqrtf(a);
+#else
+  return rsqrt_(a);
+#endif
+}
 // MapToMinusPiToPi (minitaur.py:67-83)
 ETG_HD float wrap_pi_(float a) {
   const float two_pi = 6.283185307179586f, pi = 3.141592653589793f;
@@ -235,7 +251,7 @@ ETG_HD void scale_inertia(const float* I, const float* r, float* o) {
   o[3] = I[3] * s0 * s1; o[4] = I[4] * s0 * s2; o[5] = I[5] * s1 * s2;
 }
 
-ETG_HD void derive_lane_params(const ModelF& M, const float* dyn, int leg, float sim_dt, float* out /*PR_N*/) {
+ETG_HD void derive_lane_params(const ModelF& M, const float* dyn, int leg, float sim_dt, float* out /*PR_DERIVED*/) {
   int k = 0;
   // hip, thigh
   for (int i = 0; i < 2; i++) {
@@ -345,6 +361,7 @@ inline KCfg make_kcfg(const EtgConfig& c, const EtgRobotModel& m) {
     K.pd_a = (float)((c.pd_latency - n * c.sim_dt) / c.sim_dt);
   }
   K.warmstart_t = (float)c.warmstart_friction; K.slop = (float)c.contact_slop; K.restitution = (float)c.foot_restitution;
+  K.strength_on = 0;
   K.jlim = c.joint_limits != 0;
   for (int k = 0; k < 3; k++) { K.jlo[k] = (float)c.joint_lower[k]; K.jhi[k] = (float)c.joint_upper[k]; }
   K.hf_cell = (float)c.hf_cell; K.hf_x0 = (float)c.hf_x0; K.hf_y0 = (float)c.hf_y0;
@@ -381,7 +398,11 @@ inline ModelF make_modelf(const EtgRobotModel& m) {
 // start-of-tick pose -- and consumed phases later, so a lone wave does not sit out their latency (heightfield_finish)
 ETG_HD void heightfield_fetch(const KCfg& K, int env, float x, float y, float* tap) {
   const float* hf = K.hf + (size_t)(env % K.hf_bands) * K.hf_ny * K.hf_nx;
+#if defined(ETG_IEEE_HF) || defined(ETG_IEEE_ALL)
+  float fx = (x - K.hf_x0) / K.hf_cell, fy = (y - K.hf_y0) / K.hf_cell;
+#else
   float fx = (x - K.hf_x0) * K.hf_inv_cell, fy = (y - K.hf_y0) * K.hf_inv_cell;   // (a true division is ~10 instructions)
+#endif
   fx = fminf(fmaxf(fx, 0.0f), (float)(K.hf_nx - 1));
   fy = fminf(fmaxf(fy, 0.0f), (float)(K.hf_ny - 1));
   int ix = (int)fx, iy = (int)fy;
@@ -394,9 +415,14 @@ ETG_HD void heightfield_fetch(const KCfg& K, int env, float x, float y, float* t
 ETG_HD void heightfield_finish(const KCfg& K, const float* tap, float& h, float& nx, float& ny, float& nz) {
   const float h00 = tap[0], h10 = tap[1], h01 = tap[2], h11 = tap[3], tx = tap[4], ty = tap[5];
   h = (1 - tx) * (1 - ty) * h00 + tx * (1 - ty) * h10 + (1 - tx) * ty * h01 + tx * ty * h11;
+#if defined(ETG_IEEE_HF) || defined(ETG_IEEE_ALL)
+  float dhdx = ((1 - ty) * (h10 - h00) + ty * (h11 - h01)) / K.hf_cell;
+  float dhdy = ((1 - tx) * (h01 - h00) + tx * (h11 - h10)) / K.hf_cell;
+#else
   float dhdx = ((1 - ty) * (h10 - h00) + ty * (h11 - h01)) * K.hf_inv_cell;
   float dhdy = ((1 - tx) * (h01 - h00) + tx * (h11 - h10)) * K.hf_inv_cell;
-  float inv = rsqrt_(dhdx * dhdx + dhdy * dhdy + 1.0f);
+#endif
+  float inv = rsqrt_hf_(dhdx * dhdx + dhdy * dhdy + 1.0f);
   nx = -dhdx * inv; ny = -dhdy * inv; nz = inv;
 }
 ETG_HD void heightfield_query(const KCfg& K, int env, float x, float y, float& h, float& nx, float& ny, float& nz) {

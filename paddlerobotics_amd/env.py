@@ -147,7 +147,7 @@ class BatchedQuadrupedEnv:
                  random_force_range=(5.0, 25.0), seed=0, enable_clip_motor_commands=False,
                  observation_noise_stdev=None, body_contacts=False, knee_radius=0.02, joint_limits=True,
                  auto_reset=False, random_dynamics_refresh=256, warmstart=0.1, warmstart_friction=0.0, contact_slop=1e-5,
-                 foot_restitution=0.0, **unused):
+                 foot_restitution=0.0, motor_torque_limits=None, **unused):
         if render:
             raise ValueError("render is not supported by the batched GPU simulator")
         if int(ETG_H) != A.RBF_H:
@@ -219,7 +219,9 @@ class BatchedQuadrupedEnv:
             enable_etg=1 if self.ETG else 0, joint_limits=1 if joint_limits else 0,
             # contact-solver settings: the defaults are pybullet's (a1_model.default_config)
             warmstart=warmstart, warmstart_friction=warmstart_friction, contact_slop=contact_slop,
-            foot_restitution=foot_restitution)
+            foot_restitution=foot_restitution,
+            # motor_torque_limits of the robot class (minitaur.py:99,127; one value for all motors): the clip of laikago_motor.py:168-173
+            torque_limit=0.0 if motor_torque_limits is None else float(motor_torque_limits))
         self.model = A.default_model()
         if task == "balancebeam":
             # README "step_y: the foot position at y axis for balance beam task" (train.py:463): the ETG's nominal
@@ -395,8 +397,13 @@ class BatchedQuadrupedEnv:
             _lib.check(self._lib.etg_clear_pushes(self._h, _ptr(m), self._stream()))
         _lib.check(self._lib.etg_reset(self._h, _ptr(m), _ptr(self.obs), self._stream()))
         if self._rand_dyn and self.auto_reset and self._nx_refresh > 1 and env_ids is None and dynamic_param is None:
-            self._nx_on = self._prepare_next_dynamics(None)
-            self._nx_count = 0
+            # the next episodes' rows are prepared ahead of time (etg_prepare_next_dynamics); the library leaves out robots in the
+            # first 64 ticks of their episode (they still read their pre-reset history from the settle cache the call replaces),
+            # so the FIRST call waits until the fresh episodes are that old; a robot that finishes before it restarts on its
+            # current rows (same draw again), through the same fused launch
+            self._nx_on = True
+            self._nx_first = -(-64 // int(self.cfg.action_repeat))          # control steps until every robot is old enough
+            self._nx_count = max(self._nx_refresh - self._nx_first, 0)
         info = {"ETG_act": None}
         self._last_view = self._obs_view(reset_mask=m, first=True)
         return self._last_view, info
@@ -412,6 +419,8 @@ class BatchedQuadrupedEnv:
         rows = self._draw_dynamics_rows()
         rc = self._lib.etg_prepare_next_dynamics(self._h, _ptr(rows), _ptr(mask), self._stream())
         self._nx_rows = rows      # keep the buffer alive until the stream has consumed it
+        if rc not in (0, _lib.ETG_ERR_STATE):
+            _lib.check(rc)        # allocation / launch errors are errors, not "cannot prepare"
         return rc == 0
 
     def _refresh_next_dynamics(self):
@@ -427,6 +436,10 @@ class BatchedQuadrupedEnv:
         self._nx_mask = consumed
         if not self._prepare_next_dynamics(consumed):
             self._nx_on = False
+            import warnings
+            warnings.warn("random_dynamics under auto_reset: the library cannot prepare the next episodes' dynamics ahead of time "
+                          "(%s); falling back to a masked reset per control step, which is much slower"
+                          % self._lib.etg_last_error().decode(), RuntimeWarning)
 
     def _obs_view(self, reset_mask=None, first=False):
         """the observation the caller sees: sensor_mode column selection, then (optionally) the history stack.
@@ -470,10 +483,12 @@ class BatchedQuadrupedEnv:
         observation rows (through step() and the fused rollouts alike); the dynamics never see it."""
         if stdev is None:
             _lib.check(self._lib.etg_set_sensor_noise(self._h, None, C.c_uint64(0)))
+            self._noise_on = False
             return
         a = np.ascontiguousarray(stdev, dtype=np.float32)
         if a.shape != (5,):
             raise ValueError("observation_noise_stdev needs 5 values (angle, velocity, torque, rpy, rpy rate)")
+        self._noise_on = bool(np.any(a != 0))
         _lib.check(self._lib.etg_set_sensor_noise(self._h, a.ctypes.data_as(C.c_void_p), C.c_uint64(int(seed) & 0xFFFFFFFFFFFFFFFF)))
 
     def set_reset_offsets(self, xy, env_ids=None):
@@ -493,6 +508,26 @@ class BatchedQuadrupedEnv:
             return
         self._force = self._f32(force, (self.num_envs, 3), "force").clone()   # kept alive until the copy ran
         _lib.check(self._lib.etg_set_external_force(self._h, _ptr(self._force), self._stream()))
+
+    def set_motor_strength_ratios(self, ratios, env_ids=None):
+        """Minitaur.SetMotorStrengthRatios / SetMotorStrengthRatio (minitaur.py:1280-1294): per-motor factors on the motor
+        model's output torque (laikago_motor.py:67-76,138,167).  ratios: a scalar, [12] or [N,12]; None = 1 for everybody.
+        The touched robots settle again at their next reset (the settle runs under the motor model)."""
+        m = self._mask(env_ids)
+        if ratios is None:
+            _lib.check(self._lib.etg_set_motor_strength(self._h, None, _ptr(m), self._stream()))
+            return
+        r = torch.as_tensor(ratios, dtype=torch.float32, device=self.device)
+        if r.dim() == 0:
+            r = r.expand(A.NUM_MOTORS)
+        if r.dim() == 1:
+            r = r.unsqueeze(0).expand(self.num_envs, -1)
+        if tuple(r.shape) != (self.num_envs, A.NUM_MOTORS):
+            raise ValueError("motor strength ratios must be a scalar, [12] or [N,12]")
+        self._strength = r.contiguous().clone()             # kept alive until the copy ran
+        _lib.check(self._lib.etg_set_motor_strength(self._h, _ptr(self._strength), _ptr(m), self._stream()))
+
+    SetMotorStrengthRatios = set_motor_strength_ratios      # the robot class's own name (minitaur.py:1288)
 
     def _random_pushes(self):
         """random_param['random_force'] (train.py:254): one tiny kernel per control step samples / expires the
@@ -642,8 +677,13 @@ class BatchedQuadrupedEnv:
         a = a.contiguous()
         if a.dim() != 3 or tuple(a.shape[1:]) != (N, A.NUM_MOTORS):
             raise ValueError("actions must be [T, num_envs, 12] or [T, 12]")
+        # configurations the fused kernel does not cover: callers that can step instead catch FusedKernelUnavailable
         if self.auto_reset:
-            raise ValueError("rollout_actions does not restart finished robots: use an env without auto_reset")
+            raise FusedKernelUnavailable("rollout_actions does not restart finished robots: use an env without auto_reset")
+        if self.motor_mode == 2:
+            raise FusedKernelUnavailable("rollout_actions: POSITION / TORQUE commands only (HYBRID rows have 60 columns)")
+        if "obs" in record and getattr(self, "_noise_on", False):
+            raise FusedKernelUnavailable("rollout_actions records observations without sensor noise: switch it off or step")
         T = a.shape[0]
         unknown = set(record) - {"joint_angle", "obs-IMU", "obs", "reward", "done"}
         if unknown:

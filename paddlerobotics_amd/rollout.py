@@ -114,6 +114,7 @@ def make_dynamics_id_evaluator(env, gait, mean_dict, e_steps=100, keys=("exp", "
     through env.rollout_actions (etg_rollout_actions: the tape is known, so 100 steps are 2 launches); False = env.step()
     per control step with the info columns sliced on the host side, the reference's own loop shape."""
     from . import a1_model as A
+    from .env import FusedKernelUnavailable
     if getattr(env, "ETG", 1):
         raise ValueError("the dynamics-identification replay needs an env made with ETG=0 (Dynamic_parallel_model.py:49)")
     pose = torch.as_tensor(A.INIT_MOTOR_ANGLES, dtype=torch.float32, device=env.device)
@@ -123,15 +124,22 @@ def make_dynamics_id_evaluator(env, gait, mean_dict, e_steps=100, keys=("exp", "
         rows = A.param2dynamic_rows_torch(solutions.to(env.device).float())
         n = env.num_envs
         fit = torch.zeros(n, dtype=torch.float32, device=env.device)
-        motor = torch.empty(n, e_steps, 12, device=env.device)
-        drpy = torch.empty(n, e_steps, 3, device=env.device)
+        motor = drpy = None
         for key in keys:
             env.reset(dynamic_param=rows)
+            rec = None
             if fused:
-                # the commands are known in advance: one launch per 50 steps, the two info columns recorded in the kernel
-                _, _, rec = env.rollout_actions(acts[key], record=("joint_angle", "obs-IMU"))
-                motor, drpy = rec["joint_angle"].transpose(0, 1), rec["obs-IMU"][:, :, 3:].transpose(0, 1)
-            else:
+                # the commands are known in advance: one launch per 50 steps, the two info columns recorded in the kernel;
+                # configurations the fused kernel does not cover (HYBRID commands, auto_reset envs) take the stepping loop
+                try:
+                    _, _, rec = env.rollout_actions(acts[key], record=("joint_angle", "obs-IMU"))
+                    motor, drpy = rec["joint_angle"].transpose(0, 1), rec["obs-IMU"][:, :, 3:].transpose(0, 1)
+                except FusedKernelUnavailable:
+                    rec = None
+            if rec is None:
+                if motor is None or motor.shape != (n, e_steps, 12) or not motor.is_contiguous():
+                    motor = torch.empty(n, e_steps, 12, device=env.device)
+                    drpy = torch.empty(n, e_steps, 3, device=env.device)
                 for i in range(e_steps):
                     _, _, _, info = env.step(acts[key][i].expand(n, 12), donef=False)
                     motor[:, i] = info["joint_angle"]

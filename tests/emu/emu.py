@@ -68,6 +68,10 @@ class EmuSim:
         f = None if force is None else np.ascontiguousarray(force, dtype=np.float32)
         self._l.emu_set_external_force(self._h, _p(f))
 
+    def set_motor_strength(self, ratios):
+        a = None if ratios is None else np.ascontiguousarray(ratios, dtype=np.float32)
+        self._l.emu_set_motor_strength(self._h, _p(a))
+
     def set_sensor_noise(self, stdev, seed=0):
         import ctypes
         a = None if stdev is None else np.ascontiguousarray(stdev, dtype=np.float32)

@@ -24,7 +24,7 @@ template <int W> inline BW<W> operator||(BW<W> a, BW<W> b) { BW<W> r; for (int i
 template <int W> inline BW<W> operator!(BW<W> a) { BW<W> r; for (int i = 0; i < W; i++) r.v[i] = !a.v[i]; return r; }
 template <int W> inline FW<W> sel_(BW<W> c, FW<W> a, FW<W> b) { FW<W> r; for (int i = 0; i < W; i++) r.v[i] = c.v[i] ? a.v[i] : b.v[i]; return r; }
 #define ETG_FN1(name) template <int W> inline FW<W> name(FW<W> a) { FW<W> r; for (int i = 0; i < W; i++) r.v[i] = name(a.v[i]); return r; }
-ETG_FN1(fabsf_) ETG_FN1(sqrt_) ETG_FN1(rsqrt_) ETG_FN1(rcp_) ETG_FN1(sin_) ETG_FN1(cos_) ETG_FN1(exp_) ETG_FN1(tanh_) ETG_FN1(acos_) ETG_FN1(asin_) ETG_FN1(wrap_pi_)
+ETG_FN1(fabsf_) ETG_FN1(sqrt_) ETG_FN1(rsqrt_) ETG_FN1(rsqrt_hf_) ETG_FN1(rcp_) ETG_FN1(sin_) ETG_FN1(cos_) ETG_FN1(exp_) ETG_FN1(tanh_) ETG_FN1(acos_) ETG_FN1(asin_) ETG_FN1(wrap_pi_)
 #undef ETG_FN1
 template <int W> inline FW<W> fminf_(FW<W> a, FW<W> b) { FW<W> r; for (int i = 0; i < W; i++) r.v[i] = fminf(a.v[i], b.v[i]); return r; }
 template <int W> inline FW<W> fmaxf_(FW<W> a, FW<W> b) { FW<W> r; for (int i = 0; i < W; i++) r.v[i] = fmaxf(a.v[i], b.v[i]); return r; }

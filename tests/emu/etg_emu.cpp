@@ -218,6 +218,8 @@ extern "C" void* emu_create(const EtgConfig* cfg, const EtgRobotModel* model) {
   e->base.assign(BS_N * N, 0.f); e->leg.assign(LG_N * NL, 0.f); e->ctl.assign(CT_N * N, 0.f);
   e->ictl.assign(IC_N * N, 0); e->legctl.assign(LC_N * NL, 0.f); e->etgp.assign(EP_N * N, 0.f);
   e->par.assign(PR_N * NL, 0.f); e->ring.assign((size_t)RING * 8 * NL, 0.f);
+  for (size_t k = PR_STR; k < PR_N; k++)
+    for (size_t c = 0; c < NL; c++) e->par[k * NL + c] = 1.0f;   // motor strength ratios: 1 unless set
   return e;
 }
 extern "C" void emu_destroy(void* h) { delete (Emu*)h; }
@@ -230,9 +232,9 @@ extern "C" void emu_set_params(void* h, const float* dyn, const float* w, const 
     if (mask && !mask[i]) continue;
     if (dyn)
       for (int l = 0; l < 4; l++) {
-        float out[PR_N];
+        float out[PR_DERIVED];
         derive_lane_params(e->M, dyn + (size_t)i * ETG_DYN_DIM, l, e->K.dt, out);
-        for (int k = 0; k < PR_N; k++) e->par[(size_t)k * 4 * N + 4 * i + l] = out[k];
+        for (int k = 0; k < PR_DERIVED; k++) e->par[(size_t)k * 4 * N + 4 * i + l] = out[k];
       }
     if (w)
       for (int k = 0; k < 60; k++) e->etgp[(size_t)(EP_W + k) * N + i] = w[(per_env ? (size_t)i * 60 : 0) + k];
@@ -250,6 +252,14 @@ extern "C" void emu_set_external_force(void* h, const float* force) {
   for (int i = 0; i < e->N; i++)
     for (int k = 0; k < 3; k++) e->ctl[(size_t)(CT_FEXT + k) * e->N + i] = force ? force[(size_t)i * 3 + k] : 0.0f;
   e->K.ext_force = force ? 1 : 0;
+}
+extern "C" void emu_set_motor_strength(void* h, const float* ratios) {
+  Emu* e = (Emu*)h;
+  const size_t N = e->N;
+  for (size_t i = 0; i < N; i++)
+    for (int l = 0; l < 4; l++)
+      for (int j = 0; j < 3; j++) e->par[(size_t)(PR_STR + j) * 4 * N + 4 * i + l] = ratios ? ratios[i * 12 + 3 * l + j] : 1.0f;
+  e->K.strength_on = ratios ? 1 : 0;
 }
 extern "C" void emu_set_reset_offsets(void* h, const float* xy) {
   Emu* e = (Emu*)h;

@@ -318,8 +318,12 @@ def test_cpu_abi_restatement_of_the_prepared_next_dynamics():
     assert lib.etg_prepare_next_dynamics(h, p(rows), None, None) == -5          # before the first reset
     assert lib.etg_reset(h, None, p(obs), None) == 0
     mask = np.array([1, 1, 0], np.uint8)
+    pend = np.ones(n, np.uint8)
+    assert lib.etg_prepare_next_dynamics(h, p(rows), p(mask), None) == 0         # robots younger than the ring (64 ticks) are left out
+    assert lib.etg_next_dynamics_pending(h, p(pend), None) == 0 and pend.tolist() == [0, 0, 0]
+    for k in range(5):                                                           # 65 ticks: old enough (the twin steps along below)
+        assert lib.etg_step(h, None, None, p(obs), p(rew), p(done), None, None) == 0
     assert lib.etg_prepare_next_dynamics(h, p(rows), p(mask), None) == 0
-    pend = np.zeros(n, np.uint8)
     assert lib.etg_next_dynamics_pending(h, p(pend), None) == 0 and pend.tolist() == [1, 1, 0]
     df = np.array([1, 0, 1], np.uint8)                                           # robots 0 and 2 finish now
     assert lib.etg_step_autoreset(h, None, p(df), p(obs), p(rew), p(done), None, None) == 0

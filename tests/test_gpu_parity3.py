@@ -372,6 +372,12 @@ def test_action_tape_rollout_equals_stepping(lanes, variant):
     assert np.median(eq[run]) < 1e-5 and eq[run].max() < tol
     assert np.abs(rec["obs-IMU"].cpu().numpy() - imu).max(2)[run].max() < 20 * tol
     assert np.abs(rec["obs"].cpu().numpy() - obs)[:first].max() < 2e-3            # normalised rows (x10 / x38); measured 1.5e-4
+    # EVERY recorded observation row of a running robot, the last row of each 50-step launch included (row 49: it is written
+    # to `obs` by the kernel and copied onto the tape by the host -- ADVICE r3)
+    og = np.abs(rec["obs"].cpu().numpy() - obs).max(2)
+    assert np.isfinite(rec["obs"].cpu().numpy()).all()
+    assert og[run].max() < 400 * tol, (og[run].max(), np.argwhere(og * run > 400 * tol)[:4])
+    assert og[49][run[49]].max() < 400 * tol and og[49][run[49]].max() <= 3 * max(og[48][run[48]].max(), og[50][run[50]].max(), 1e-4)
     assert np.array_equal(rec["done"].cpu().numpy()[:first], done[:first])
     assert np.abs(rec["reward"].cpu().numpy()[:first] - rew[:first]).max() < 1e-3
     assert np.abs(ret.cpu().numpy() - ret_b.cpu().numpy())[same_len].max() < 2e-2 * (1 + np.abs(ret_b.cpu().numpy()).max())
@@ -613,9 +619,21 @@ def test_next_episode_dynamics_are_prepared_ahead():
         env = _make(n, auto_reset=True, random_param={"random_dynamics": 1}, random_dynamics_refresh=1000, seed=5, lanes_per_robot=lanes)
         env.reset()
         assert env._nx_on
-        rows_now = None
-        rows_next = env._nx_rows.clone()
         pend = torch.empty(n, dtype=torch.uint8, device="cuda:0")
+        # robots in the first 64 ticks of their episode still read their pre-reset history from the settle cache that the call
+        # replaces: the library leaves them out, so a call right after the reset prepares nothing ...
+        assert env._prepare_next_dynamics(None)
+        L.check(env._lib.etg_next_dynamics_pending(env._h, C.c_void_p(pend.data_ptr()), env._stream()))
+        assert bool((pend == 0).all())
+        # ... and their first delayed observations are those of a twin that never called it (same rows, same kernels: bit for bit)
+        same = _make(n, auto_reset=True, random_param={"random_dynamics": 1}, random_dynamics_refresh=1000, seed=5, lanes_per_robot=lanes)
+        same.reset()
+        for _ in range(env._nx_first):            # the env's own first call comes when every robot is old enough
+            o1 = env.step(None, want_info=False)[0].clone()
+            o2 = same.step(None, want_info=False)[0]
+            assert torch.equal(o1, o2)
+        same.close()
+        rows_next = env._nx_rows.clone()
         L.check(env._lib.etg_next_dynamics_pending(env._h, C.c_void_p(pend.data_ptr()), env._stream()))
         assert bool((pend == 1).all())
         for _ in range(3):
@@ -641,14 +659,22 @@ def test_next_episode_dynamics_are_prepared_ahead():
         # (2) refresh every 4 steps: only consumed robots get new rows, and they are pending again afterwards
         env = _make(n, auto_reset=True, random_param={"random_dynamics": 1}, random_dynamics_refresh=4, seed=6, lanes_per_robot=lanes)
         env.reset()
+        for _ in range(env._nx_first):
+            env.step(None, want_info=False)                   # the first call: every robot is old enough, all get rows
+        L.check(env._lib.etg_next_dynamics_pending(env._h, C.c_void_p(pend.data_ptr()), env._stream()))
+        assert bool((pend == 1).all())
         df = torch.zeros(n, dtype=torch.uint8, device="cuda:0"); df[::3] = 1
         env.step(None, donef=df, want_info=False)             # a third of the robots restart (step 1 of the refresh period)
         L.check(env._lib.etg_next_dynamics_pending(env._h, C.c_void_p(pend.data_ptr()), env._stream()))
         assert torch.equal(pend == 0, df.bool())
         for _ in range(3):
-            env.step(None, want_info=False)                   # step 4: the refresh
+            env.step(None, want_info=False)                   # step 4: a refresh, but the restarted robots are 39 ticks old: left out
         L.check(env._lib.etg_next_dynamics_pending(env._h, C.c_void_p(pend.data_ptr()), env._stream()))
-        assert bool((pend == 1).all()) and torch.equal(env._nx_mask.bool(), df.bool())
+        assert torch.equal(pend == 0, df.bool()) and torch.equal(env._nx_mask.bool(), df.bool())
+        for _ in range(4):
+            env.step(None, want_info=False)                   # step 8: the next refresh takes them (91 ticks old)
+        L.check(env._lib.etg_next_dynamics_pending(env._h, C.c_void_p(pend.data_ptr()), env._stream()))
+        assert bool((pend == 1).all())
         assert torch.isfinite(env.get_state()).all()
         env.close()
     # (4) cost: random dynamics + auto reset steps at the fused auto-reset cost (the masked-reset path: ~4 ms per step at 4096)

@@ -1,0 +1,116 @@
+"""-m gpu, round 4: the contact model with Bullet's sweep order and in-loop joint limits (the library default), and the
+robot-layer gaps VERDICT r03 listed -- all through the C-ABI against the fp64 oracle, both lane mappings.
+
+  * joint-limit rows INSIDE the sweeps (btMultiBodyJointLimitConstraint rows before the contact rows): a walking robot whose calf
+    joints ride their upper stop, against the oracle, sweep counts included;
+  * motor strength ratios (laikago_motor.py:67-76,138,167), the command clip around the delayed reading (a1.py:439-457),
+    foot restitution (minitaur.py:1112-1122);
+  * the settings the default follows: warm start 0.1 on the normal rows only, contact slop, friction rows skipped while the
+    normal impulse is zero -- each switched to its other value changes the trajectory AND still matches the oracle.
+"""
+import numpy as np
+import pytest
+
+from paddlerobotics_amd import a1_model as A
+
+pytestmark = pytest.mark.gpu
+torch = pytest.importorskip("torch")
+
+from tests.test_gpu_parity import _need_gpu, _etg_params, _make, _oracle, _lt   # noqa: E402
+from tests.test_gpu_parity2 import _say                                       # noqa: E402
+
+
+def _run_pair(env, orc, acts, strength=None, W=None, B=None):
+    if strength is not None:
+        env.set_motor_strength_ratios(torch.as_tensor(strength, dtype=torch.float32))
+        orc.set_motor_strength(strength)
+    if W is not None:
+        env.reset(ETG_w=W, ETG_b=B)
+        orc.set_params(etg_w=W, etg_b=B)
+    else:
+        env.reset()
+    orc.reset()
+    worst_q = worst_p = 0.0
+    for a in acts:
+        env.step(torch.as_tensor(a, dtype=torch.float32))
+        orc.step(a)
+        sg, so = env.get_state().cpu().numpy(), orc.get_state()
+        worst_q = max(worst_q, np.abs(sg - so)[:, 13:25].max())
+        worst_p = max(worst_p, np.abs(sg - so)[:, :3].max())
+    return worst_q, worst_p
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+@pytest.mark.parametrize("option", ["strength", "strength_torque_mode", "clip_delayed", "restitution", "warmstart_085", "pyramid_no_slop"])
+def test_round4_options_match_oracle(lanes, option):
+    _need_gpu()
+    n = 64
+    rng = np.random.default_rng(31)
+    W, B = _etg_params(n, seed=31)
+    mk, ok, strength, scale = dict(lanes_per_robot=lanes), {}, None, 0.15
+    if option == "strength":
+        mk.update(motor_torque_limits=12.0); ok.update(torque_limit=12.0)
+        strength = rng.uniform(0.4, 1.0, size=(n, 12))
+    elif option == "strength_torque_mode":
+        mk.update(motor_control_mode="torque", motor_torque_limits=2.0); ok.update(motor_mode=1, torque_limit=2.0)
+        strength = rng.uniform(0.4, 1.0, size=(n, 12))
+        scale, W, B = 6.0, None, None
+    elif option == "clip_delayed":
+        mk.update(enable_clip_motor_commands=True); ok.update(clip_motor_commands=0.2)
+        scale = 0.6
+    elif option == "restitution":
+        mk.update(foot_restitution=0.6); ok.update(foot_restitution=0.6)
+    elif option == "warmstart_085":      # Bullet's own default factor, on the friction rows too
+        mk.update(warmstart=0.85, warmstart_friction=0.85); ok.update(warmstart=0.85, warmstart_friction=0.85)
+    else:
+        mk.update(friction_model=1, contact_slop=0.0); ok.update(friction_model=1, contact_slop=0.0)
+    env, orc = _make(n, **mk), _oracle(n, **ok)
+    acts = [rng.uniform(-scale, scale, size=(n, 12)) for _ in range(12)]
+    wq, wp = _run_pair(env, orc, acts, strength, W, B)
+    _say("round-4 option %-22s lanes %2d: joints %.2e rad, base %.2e m vs the oracle over 12 steps" % (option, lanes, wq, wp))
+    _lt(wq, 5e-4 if option != "strength_torque_mode" else 5e-3, "round-4 option %s lanes %d: joint angles" % (option, lanes))
+    _lt(wp, 1e-4 if option != "strength_torque_mode" else 1e-3, "round-4 option %s lanes %d: base position" % (option, lanes))
+    # and the option matters: the default configuration moves differently
+    ref = _oracle(n, **({"motor_mode": 1} if option == "strength_torque_mode" else {}))
+    if W is not None:
+        ref.set_params(etg_w=W, etg_b=B)
+    ref.reset()
+    for a in acts:
+        ref.step(a)
+    assert np.abs(ref.get_state() - orc.get_state())[:, :25].max() > 1e-4
+    env.close()
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_joint_limit_rows_inside_the_sweeps_match_oracle(lanes):
+    """A gait whose calf joints ride their upper stop (-0.916 rad: residual actions straighten the knees) while the feet carry
+    the robot: joint-limit rows and contact rows are solved in the same sweeps (the rare branch of the tick).  State, sweep
+    counts and the stops themselves against the oracle under the default stopping rule."""
+    _need_gpu()
+    n = 64
+    W, B = _etg_params(n, seed=9)
+    env, orc = _make(n, lanes_per_robot=lanes), _oracle(n)
+    env.reset(ETG_w=W, ETG_b=B)
+    orc.set_params(etg_w=W, etg_b=B)
+    orc.reset()
+    rng = np.random.default_rng(12)
+    worst = 0.0
+    at_stop = 0
+    per_wave = 64 // lanes
+    for k in range(16):
+        act = rng.uniform(-0.05, 0.05, size=(n, 12))
+        act[:, 2::3] += 0.95                      # knees towards straight: the PD target is past the calf joint's upper bound
+        _, _, _, info = env.step(torch.as_tensor(act, dtype=torch.float32))
+        _, _, _, io = orc.step(act)
+        sg, so = env.get_state().cpu().numpy(), orc.get_state()
+        worst = max(worst, np.abs(sg - so)[:, 13:25].max())
+        at_stop += int((so[:, 15:25:3] >= A.JOINT_UPPER[2] - 1e-3).sum())
+        sw_g = info["solver_sweeps"].cpu().numpy().reshape(-1, per_wave)
+        sw_o = io[:, A.INFO_SWEEPS].reshape(-1, per_wave)
+        assert np.all(sw_g[:, 0] >= sw_o.max(1) - 2) and np.all(sw_g[:, 0] <= sw_o.sum(1) + 2), (k, sw_g[:, 0], sw_o.max(1))
+    q = env.get_state()[:, 13:25].cpu().numpy().reshape(n, 4, 3)
+    _say("joint-limit rows in the sweeps, lanes %d: joints %.2e rad vs the oracle; %d joint-steps at the calf stop" % (lanes, worst, at_stop))
+    assert at_stop > 100                                             # the rows were there
+    assert (q[:, :, 2] <= A.JOINT_UPPER[2] + 0.02).all()              # and held
+    _lt(worst, 1e-3, "joint-limit rows inside the sweeps, lanes %d" % lanes)
+    env.close()

@@ -505,3 +505,52 @@ def test_param2dynamic_rows_torch_equals_numpy():
     a = A.param2dynamic_rows(p)
     b = A.param2dynamic_rows_torch(torch.as_tensor(p)).numpy()
     assert np.abs(a - b).max() < 1e-5
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+@pytest.mark.parametrize("option", ["strength", "strength_torque_mode", "clip_delayed", "restitution"])
+def test_emulation_robot_layer_gaps_match_oracle(lanes, option):
+    """Round-4 robot-layer options, kernel source (emulation, both mappings) against the oracle:
+    * strength: per-motor strength ratios (laikago_motor.py:67-76,138,167; Minitaur.SetMotorStrengthRatios) with a torque limit
+      -- the ratio acts before the clip; strength_torque_mode: ratio x commanded torque, no clip (laikago_motor.py:137-139);
+    * clip_delayed: A1._ClipMotorCommands (a1.py:439-457) clips around GetMotorAngles(), the control-latency-delayed reading;
+    * restitution: EtgConfig.foot_restitution on a robot dropped from 8 cm above its stance."""
+    from oracle.oracle import OracleSim
+    from tests.emu.emu import EmuSim
+    n = 3
+    rng = np.random.default_rng(21)
+    kw, strength = dict(settle_ticks=120, solver_iters=4), None
+    if option == "strength":
+        kw.update(torque_limit=12.0)
+        strength = rng.uniform(0.4, 1.0, size=(n, 12))
+    elif option == "strength_torque_mode":
+        kw.update(motor_mode=1, torque_limit=2.0)
+        strength = rng.uniform(0.4, 1.0, size=(n, 12))
+    elif option == "clip_delayed":
+        kw.update(clip_motor_commands=0.05)
+    else:
+        kw.update(foot_restitution=0.6)
+    cfg = A.default_config(n, **kw)
+    # `plain`: the same run without the option (strength ratios 1 / no clip / no restitution)
+    ref_cfg = A.default_config(n, **{k: v for k, v in kw.items() if k not in ("foot_restitution", "clip_motor_commands")})
+    orc, emu, plain = OracleSim(cfg), EmuSim(cfg, lanes=lanes), OracleSim(ref_cfg)
+    for s in (orc, emu, plain):
+        if strength is not None and s is not plain:
+            s.set_motor_strength(strength)
+        s.reset()
+    assert np.abs(emu.get_state() - orc.get_state())[:, 13:25].max() < 5e-5
+    if option == "restitution":
+        st = orc.get_state().copy()
+        st[:, 2] += 0.08
+        for s in (orc, emu, plain):
+            s.set_state(st)
+    worst = 0.0
+    for k in range(8):
+        if option == "strength_torque_mode":
+            act = rng.uniform(-6.0, 6.0, size=(n, 12))
+        else:
+            act = rng.uniform(-0.4, 0.4, size=(n, 12)) if option == "clip_delayed" else rng.uniform(-0.15, 0.15, size=(n, 12))
+        orc.step(act); emu.step(act); plain.step(act)
+        worst = max(worst, np.abs(emu.get_state() - orc.get_state())[:, 13:25].max())
+    assert worst < 3e-4, worst
+    assert np.abs(plain.get_state() - orc.get_state())[:, :25].max() > 1e-3      # the option does change the motion
