@@ -403,7 +403,7 @@ class BatchedQuadrupedEnv:
             # current rows (same draw again), through the same fused launch
             self._nx_on = True
             self._nx_first = -(-64 // int(self.cfg.action_repeat))          # control steps until every robot is old enough
-            self._nx_count = max(self._nx_refresh - self._nx_first, 0)
+            self._nx_count = self._nx_refresh - self._nx_first              # (the first call after exactly _nx_first steps)
         info = {"ETG_act": None}
         self._last_view = self._obs_view(reset_mask=m, first=True)
         return self._last_view, info

