@@ -511,6 +511,15 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
     };
     auto pgs_sweep = [&]() {
       if (joints) joint_phase();
+      if constexpr (Ctx::kAsmSweep && !knee && !pyramid) {
+        // the device build's hand-scheduled sweep (GpuCtx16::pgs_normals / pgs_tangents_disc state why): the same arithmetic
+        // as the C++ below; the friction skip is folded into the per-lane constants of the friction phase
+        c.pgs_normals(lam, u, iAe, c0e, A, mk0);
+        const F lnq = c.qb(lam, 0);
+        const auto grip = lnq > zero;
+        c.pgs_tangents_disc(lam, u, sel_(grip, iAe, zero), sel_(grip, mue * lnq, F(1e30f)), A, mt);
+        return;
+      }
       // (2) normal rows: ln = max(0, lam - (u - tgt)/A), as a change: max(-lam, (tgt - u)/A); the owner's lam update sits
       // between the candidate and its broadcast, where the DPP read needs two wait states anyway
 #pragma unroll

@@ -616,6 +616,53 @@ struct GpuCtx16 {
 #undef ETG_L
   }
 #undef ETG_FMAC_DPP
+  // ---- the contact solve's sweep, hand-scheduled (etg_core16.h: pgs_sweep; kAsmSweep).  The sweep is one serial chain --
+  // candidate -> broadcast -> apply, row after row -- and every broadcast reads a register the instruction before wrote: the
+  // hardware wants 2 wait states between a VALU write and a DPP read of it.  The compiler's version spends a v_mov_b32_dpp plus
+  // an s_nop 1 per broadcast (17 + 16 of 104 instructions, 120 issue slots per sweep); here the broadcast is the DPP operand
+  // of the applying v_fmac itself and the owner's own impulse update sits in one of the two wait states: 5 slots per normal row,
+  // 16 per friction pair, 84 per sweep.  Same arithmetic as the C++ statement in pgs_sweep (which the emulation, the body-row
+  // and the pyramid instantiations keep).
+#define ETG_DPPC " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+  __device__ __forceinline__ void pgs_normals(float& lam, float& u, float iA, float c0, const float (&A)[4][3], const float* mk0) const {
+    float t, d;
+#define ETG_ROW(LP, AOP, MOP)                                                    \
+    "v_fma_f32 %[t], -%[u], %[iA], %[c0]\n"        /* t = c0 - u / A            */ \
+    "v_max_f32_e64 %[d], -%[lam], %[t]\n"          /* d = max(-lam, t)          */ \
+    "v_fmac_f32_e32 %[lam], %[" MOP "], %[d]\n"    /* the owner commits         */ \
+    "s_nop 0\n"                                                                    \
+    "v_fmac_f32_dpp %[u], %[d], %[" AOP "] row_newbcast:" #LP ETG_DPPC
+    asm(ETG_ROW(0, "a0", "m0") ETG_ROW(4, "a1", "m1") ETG_ROW(8, "a2", "m2") ETG_ROW(12, "a3", "m3")
+        : [lam] "+v"(lam), [u] "+v"(u), [t] "=&v"(t), [d] "=&v"(d)
+        : [iA] "v"(iA), [c0] "v"(c0), [a0] "v"(A[0][0]), [a1] "v"(A[1][0]), [a2] "v"(A[2][0]), [a3] "v"(A[3][0]),
+          [m0] "v"(mk0[0]), [m1] "v"(mk0[1]), [m2] "v"(mk0[2]), [m3] "v"(mk0[3]));
+#undef ETG_ROW
+  }
+  // friction pairs of the four feet on the disc: iA / lim already carry the "normal impulse > 0" condition (iA = 0 and
+  // lim = 1e30 where it does not hold: the candidate is the current impulse, the scale 1, the change an exact zero)
+  __device__ __forceinline__ void pgs_tangents_disc(float& lam, float& u, float iA, float lim, const float (&A)[4][3], const float* mt) const {
+    float lc, sq, sc, dl;
+#define ETG_PAIR(R1, R2, A1, A2, MOP)                                                                  \
+    "v_fma_f32 %[lc], -%[u], %[iA], %[lam]\n"                /* candidate of this lane's row        */ \
+    "v_fmaak_f32 %[sq], %[lc], %[lc], 0x0da24260\n"          /* lc^2 + 1e-30                       */ \
+    "s_nop 1\n"                                                                                        \
+    "v_add_f32_dpp %[sq], %[sq], %[sq] quad_perm:[0,2,1,3]" ETG_DPPC /* + the other row's           */ \
+    "v_rsq_f32_e32 %[sq], %[sq]\n"                                                                     \
+    "s_nop 0\n"                                                                                        \
+    "v_mul_f32_e32 %[sc], %[lim], %[sq]\n"                                                             \
+    "v_min_f32_e32 %[sc], 1.0, %[sc]\n"                      /* projection on the disc             */ \
+    "v_fma_f32 %[dl], %[lc], %[sc], -%[lam]\n"                                                         \
+    "v_fmac_f32_e32 %[lam], %[" MOP "], %[dl]\n"             /* the owners commit                  */ \
+    "s_nop 0\n"                                                                                        \
+    "v_fmac_f32_dpp %[u], %[dl], %[" A1 "] row_newbcast:" #R1 ETG_DPPC                                  \
+    "v_fmac_f32_dpp %[u], %[dl], %[" A2 "] row_newbcast:" #R2 ETG_DPPC
+    asm(ETG_PAIR(1, 2, "a01", "a02", "m0") ETG_PAIR(5, 6, "a11", "a12", "m1") ETG_PAIR(9, 10, "a21", "a22", "m2") ETG_PAIR(13, 14, "a31", "a32", "m3")
+        : [lam] "+v"(lam), [u] "+v"(u), [lc] "=&v"(lc), [sq] "=&v"(sq), [sc] "=&v"(sc), [dl] "=&v"(dl)
+        : [iA] "v"(iA), [lim] "v"(lim), [a01] "v"(A[0][1]), [a02] "v"(A[0][2]), [a11] "v"(A[1][1]), [a12] "v"(A[1][2]), [a21] "v"(A[2][1]),
+          [a22] "v"(A[2][2]), [a31] "v"(A[3][1]), [a32] "v"(A[3][2]), [m0] "v"(mt[0]), [m1] "v"(mt[1]), [m2] "v"(mt[2]), [m3] "v"(mt[3]));
+#undef ETG_PAIR
+  }
+#undef ETG_DPPC
   // every value that later feeds fmac_rbcast / fmac_qb as the broadcast source passes through here: the
   // asm "modifies" them, so their producers are ordered before it and the DPP reads after it
   __device__ __forceinline__ void dpp_ready10(float* z, float* hj, float* lam) const {
@@ -680,6 +727,11 @@ template <bool FLAT, bool KNEE = false, bool PLAIN = false> struct GpuCtx16T : G
   static constexpr bool kFlat = FLAT;
   static constexpr bool kKnee = KNEE;
   static constexpr bool kPlain = PLAIN;
+#ifdef ETG_NO_ASM_SWEEP
+  static constexpr bool kAsmSweep = false;
+#else
+  static constexpr bool kAsmSweep = true;     // pgs_normals / pgs_tangents_disc: the hand-scheduled sweep
+#endif
 };
 
 // robot_block = index of the group of 4 robots this wave carries, lane = lane in the wave, lds_wave = the wave's

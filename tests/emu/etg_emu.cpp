@@ -193,6 +193,9 @@ template <bool FLAT, bool KNEE = false, bool PLAIN = false> struct EmuCtx16T : E
   static constexpr bool kFlat = FLAT;
   static constexpr bool kKnee = KNEE;
   static constexpr bool kPlain = PLAIN;
+  static constexpr bool kAsmSweep = false;   // the C++ statement of the sweep (the device build hand-schedules it)
+  template <class A> void pgs_normals(F16&, F16&, F16, F16, const A&, const F16*) const {}
+  template <class A> void pgs_tangents_disc(F16&, F16&, F16, F16, const A&, const F16*) const {}
   EmuCtx16T(int e, int n, const float* p) { env = e; N = n; parp = p; }
 };
 
