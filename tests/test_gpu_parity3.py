@@ -186,6 +186,25 @@ def test_long_horizon_statistics_on_the_heightfield(solver, lanes):
     assert s["gap"] < 0.1 and s["gap_full"] < 0.1            # survival curves: same robots / full batch vs the 512-robot sample
     assert s["ks_len"] < 0.1 and s["ks_ret"] < 0.1 and s["ks_dx"] < 0.12       # measured 0.045-0.06 / 0.025-0.03 / 0
     assert s["z"] < 4.0
+    if solver == "rule" and lanes == 16:
+        # the same-length floor: how often does ANY fp32 evaluation end a robot's episode on the fp64 oracle's step
+        # (+-1) on this terrain?  The oracle's own fp32 build sets the yardstick; the GPU must reach it within 3 standard errors
+        # of the difference (tools/hf_tracking_probe.py: no hardware approximation separates the two)
+        o32 = _oracle(m, dtype=np.float32, terrain=1, heightfield=hf, body_contacts=2, joint_limits=1, **skw)
+        o32.threads = NCPU
+        o32.set_heightfield(hf["heights"])
+        o32.set_params(etg_w=w[:m].double().cpu().numpy(), etg_b=b[:m].double().cpu().numpy())
+        o32.reset()
+        _, ln32 = o32.run_steps(steps)
+        _, ln64 = orc.episode_lengths() if hasattr(orc, "episode_lengths") else (None, None)
+        if ln64 is None:                                     # the fp64 lengths: rerun (the first run's were consumed inside the helper)
+            orc.reset()
+            _, ln64 = orc.run_steps(steps)
+        a32 = float((np.abs(ln32 - ln64) <= 1).mean())
+        se = np.sqrt((a32 * (1 - a32) + s["agree"] * (1 - s["agree"])) / m)
+        _say("heightfield + body contacts: same episode length +-1 as the fp64 oracle: gpu %.3f, fp32 oracle %.3f (standard error of "
+             "the difference %.3f)" % (s["agree"], a32, se))
+        assert s["agree"] >= a32 - 3.0 * se
     env.close()
 
 
