@@ -572,7 +572,28 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
       const F tolq = F(K.res_sqrt) * iAq;
       int it = 0;
       bool more;
+      auto frozen = lam < lam;                                        // (all false) robots that have converged
       auto sweep_and_test = [&]() {
+#ifdef ETG_EAGER_FREEZE   // A/B build variant: the round-3 form (constants zeroed before the next sweep)
+        constexpr bool lazy = false;
+#else
+        constexpr bool lazy = !joints;
+#endif
+        if constexpr (lazy) {
+          // Without joint rows a converged robot is frozen LAZILY: it sweeps on with its real constants and is put back to its
+          // values at convergence afterwards (two selects) -- the same result bit for bit as zeroed constants, but the
+          // per-robot mask (ballot -> shift -> and -> compare: a 6-deep chain) is only needed AFTER the next sweep, so it
+          // leaves the sweep's critical path; the wave's exit test is the compare's wave mask alone.
+          const F lam0 = lam, u0 = u;
+          pgs_sweep();
+          it++;
+          lam = sel_(frozen, lam0, lam);
+          u = sel_(frozen, u0, u);
+          const auto moved = fabsf_(lam - lam0) > tol;
+          more = c.wave_any(moved) && it < K.iters;
+          frozen = !c.robot_any(moved);
+          return;
+        }
         const F lam0 = lam, lamq0 = lamq;
         pgs_sweep();
         it++;

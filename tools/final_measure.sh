@@ -3,7 +3,7 @@
 # the default flags and with the driver's, rocprofv3 kernel-trace summaries and PMC passes for configs 2 / 3 / 5.
 # Outputs under gpurun_out/final/ (+ gpurun_out/pmc_<tag>.*, gpurun_out/prof_<tag>/); copy what is judged into profiles/.
 R=${GRAFT_REPO_ROOT:-/root/repo}
-TAG=${1:-r03}
+TAG=${1:-r04}
 O=$R/gpurun_out/final
 mkdir -p $O
 cd $R

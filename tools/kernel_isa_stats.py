@@ -126,7 +126,7 @@ def write_baseline(so, path):
     if missing:
         raise SystemExit("kernels not found in %s: %s" % (so, sorted(missing)))
     hipcc = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True).stdout.strip().split("\n")
-    json.dump({"what": "static ISA statistics of the hot kernels in the library build the round-3 numbers were measured with "
+    json.dump({"what": "static ISA statistics of the hot kernels in the library build the round-4 numbers were measured with "
                        "(tools/kernel_isa_stats.py; compared by tests/test_kernel_isa.py)",
                "toolchain": hipcc[:2], "kernels": st}, open(path, "w"), indent=1, sort_keys=True)
     print("wrote", path)
@@ -135,7 +135,7 @@ def write_baseline(so, path):
 if __name__ == "__main__":
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if "--write-baseline" in sys.argv:
-        write_baseline(os.path.join(root, "paddlerobotics_amd", "csrc", "libetgsim.so"), os.path.join(root, "profiles", "r03_isa_baseline.json"))
+        write_baseline(os.path.join(root, "paddlerobotics_amd", "csrc", "libetgsim.so"), os.path.join(root, "profiles", "r04_isa_baseline.json"))
         sys.exit(0)
     so = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].endswith(".so") else os.path.join(root, "paddlerobotics_amd", "csrc", "libetgsim.so")
     want = [a for a in sys.argv[1:] if not a.endswith(".so")]

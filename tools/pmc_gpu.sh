@@ -2,7 +2,7 @@
 # PMC counters of the bench command, one counter group per pass (no trace domains mixed in; gpurun refuses --pmc with
 # sys/hip/hsa traces).  usage: tools/pmc_gpu.sh <tag> ; extra bench flags through PMC_BENCH_ARGS (e.g. "--config 3").
 # Writes gpurun_out/pmc_<tag>.txt (raw means per launch) and gpurun_out/pmc_<tag>.json (per kernel and control step,
-# the format bench.py reads from profiles/r03_pmc.json).
+# the format bench.py reads from profiles/r04_pmc.json).
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=/tmp/pmc_$1
@@ -12,11 +12,17 @@ run() { # name counters...
   name=$1; shift
   rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $OUT/$name -o pmc -- python $R/bench.py --steps $STEPS --warmup 5 --repeats 2 --no-cpu-baseline --no-extra-legs $PMC_BENCH_ARGS > $OUT/$name.log 2>&1 || echo "pass $name failed"
 }
-run fetch FETCH_SIZE
-run write WRITE_SIZE
-run valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES
-run lds SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
-run mfma SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES
+# PMC_PASSES selects the counter groups (default: all five)
+PASSES=${PMC_PASSES:-"fetch write valu lds mfma"}
+for p in $PASSES; do
+  case $p in
+    fetch) run fetch FETCH_SIZE ;;
+    write) run write WRITE_SIZE ;;
+    valu) run valu SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAVES ;;
+    lds) run lds SQ_INSTS_LDS SQ_INSTS_SALU SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY ;;
+    mfma) run mfma SQ_INSTS_MFMA SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES ;;
+  esac
+done
 rocprofv3 -L 2>/dev/null | grep -i -o "SQ_[A-Z_]*MFMA[A-Z_0-9]*" | sort -u > $R/gpurun_out/pmc_$1_mfma_counter_names.txt
 python - $1 $STEPS > $R/gpurun_out/pmc_$1.txt <<PY
 import csv, glob, collections, re, json, sys
