@@ -27,6 +27,7 @@ def test_oracle_and_kernel_math_run_clean_under_asan_and_ubsan(tmp_path):
         (dict(motor_mode=2, enable_action_filter=True, enable_action_interp=True, torque_limit=30.0, clip_motor_commands=0.2), 2),
         (dict(enable_etg=0, solver_iters=2, solver_residual=1e-5), 2),
         (dict(pd_latency=0.0013), 2),
+        (dict(foot_restitution=0.5, warmstart=0.85, warmstart_friction=0.85, contact_slop=0.0, clip_motor_commands=0.1), 2),
     ]
     model = A.default_model()
     path = tmp_path / "scenarios.bin"
