@@ -1631,6 +1631,9 @@ extern "C" int etg_prepare_next_dynamics(EtgHandle* h, const float* dyn, const u
   Dn.dyn = h->NX.dyn;
   Dn.base = h->nx_base; Dn.leg = h->nx_leg; Dn.ring = h->nx_ring;
   Dn.cache_ok = h->nx_cache_ok;
+  // the motor strength ratios are not derived from the dynamic_param row: the scratch settle runs under the robots' own
+  // (found by the round-4 soak run: zeros there left the robot limp during the prepared settle whenever a non-plain kernel ran it)
+  HIP_TRY(hipMemcpyAsync(h->NX.par + (size_t)PR_STR * NL, h->D.par + (size_t)PR_STR * NL, (size_t)(PR_N - PR_STR) * NL * 4, hipMemcpyDeviceToDevice, s));
   hipLaunchKernelGGL(k_next_old_enough, ge, dim3(256), 0, s, h->K, h->D, mask, h->nx_mask);
   mask = h->nx_mask;   // robots in the first RING ticks of their episode still read the cache's ring: not this time
   hipLaunchKernelGGL(k_set_params, dim3(grid_for(h)), dim3(BLOCK), 0, s, h->K, h->M, Dn, dyn, (const float*)nullptr,

@@ -137,3 +137,28 @@ def test_joint_limit_rows_inside_the_sweeps_match_oracle(lanes):
     assert np.mean(eg <= 1e-4 + 4.0 * e32) >= 0.9, (eg, e32)
     assert eg.max() <= 3.0 * e32.max() + 1e-3
     env.close()
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_prepared_next_dynamics_under_the_all_options_kernels(lanes):
+    """etg_prepare_next_dynamics settles the next episodes on scratch state with the NEXT dynamic rows -- and with the robots' own
+    motor strength ratios, which are not part of those rows.  Found by the round-4 soak run: with any robot-layer option on
+    (random pushes here: the non-PLAIN kernels read the ratios) the scratch settle ran on zeroed ratios, left the robot limp, and
+    every restarted episode ended after one step.  Restarted robots must stand, and their episodes must last."""
+    _need_gpu()
+    n = 128
+    env = _make(n, auto_reset=True, lanes_per_robot=lanes, seed=4, random_dynamics_refresh=1000,
+                random_param={"random_dynamics": 1, "random_force": 1})
+    env.reset()
+    for _ in range(env._nx_first):                     # the env's first prepare call
+        env.step(None, want_info=False)
+    obs, _, d, _ = env.step(None, donef=True)           # everybody restarts on the prepared rows and the prepared settle
+    assert bool(d.all())
+    z = env.get_state()[:, 2]
+    assert float(z.min()) > 0.2, float(z.min())         # standing (a limp settle leaves the trunk at ~0.06 m)
+    alive = torch.ones(n, dtype=torch.bool, device="cuda:0")
+    for _ in range(6):
+        _, _, d, _ = env.step(None, want_info=False)
+        alive &= ~d.view(-1).bool()
+    assert float(alive.float().mean()) > 0.9            # the zero-residual gait walks on for the next steps
+    env.close()
