@@ -18,11 +18,20 @@ opts = [dict(), dict(motor_control_mode="torque"), dict(motor_control_mode="hybr
         # round 3: all body spheres at once (4-lane kernels), pyramid friction, pd latency, the solver with a fixed count
         dict(body_contacts=3), dict(body_contacts=3, motor_control_mode="torque"), dict(friction_model=1), dict(pd_latency=0.001),
         dict(solver_iters=3), dict(body_contacts=2, friction_model=1, auto_reset=True),
-        dict(auto_reset=True, random_param={"random_dynamics": 1}, random_dynamics_refresh=32)]
+        dict(auto_reset=True, random_param={"random_dynamics": 1}, random_dynamics_refresh=32),
+        # round 4: torque limits, restitution, Bullet's own warm start on both row kinds, no slop, strength ratios (set below)
+        dict(motor_torque_limits=20.0), dict(foot_restitution=0.5), dict(warmstart=0.85, warmstart_friction=0.85, contact_slop=0.0),
+        dict(strength=0.7), dict(strength=0.7, auto_reset=True, random_param={"random_dynamics": 1, "random_force": 1}, random_dynamics_refresh=16),
+        dict(motor_control_mode="torque", motor_torque_limits=3.0, strength=0.8)]
 for lanes, task, o in itertools.product((16, 4), ("ground", "stairstair"), opts):
     if o.get("body_contacts") == 3 and lanes == 16:
         continue   # three body rows per leg: the 4-lane mapping only
+    o = dict(o)
+    strength = o.pop("strength", None)
     env = make_env("Quadrupedal", num_envs=N, device="cuda:0", lanes_per_robot=lanes, task=task, seed=3, **o)
+    if strength is not None:
+        env.set_motor_strength_ratios(strength)
+        o["strength"] = strength
     g = torch.Generator(device="cuda:0"); g.manual_seed(1)
     obs, _ = env.reset(x_noise=1)
     adim = env.action_space.shape[0]
