@@ -192,7 +192,9 @@ typedef struct EtgConfig {
   /* pd_latency of the robot class (minitaur.py:100,130-132,1195-1199): the motor model's PD law reads the joint angles and
    * velocities this many seconds old -- blended from the two history readings that bracket the latency, exactly like the
    * control-latency observation (minitaur.py:1172-1193) -- instead of the current ones.  0 (the reference's default, A1
-   * passes none) = the true state.  Applies to every sub-step, the reset settle included.                            */
+   * passes none) = the true state.  Applies to every sub-step, the reset settle included.  The delayed damping term is
+   * physics, not a defect: with the default gains the loop is marginal from ~2.5 ms (two fp32 evaluations settle 1e-3 rad
+   * apart) and unstable from ~4 ms (the settle ends in non-finite numbers and the robot reports done).                 */
   double pd_latency;
   /* Warm start of a foot's two friction rows: their impulses of the previous tick times this factor start the solve.  0 (the
    * default) = Bullet's multibody solver, which warm-starts the normal row only (with `warmstart`) and restarts friction rows
@@ -313,7 +315,8 @@ int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float* ret, int3
  * (model/Dynamic_parallel_model.py:53-77), the BC teacher replays (BCtrain.py:87-131).  Optional per-step outputs (NULL = not
  * recorded): rec_joint_angle [n_steps,N,12], rec_imu [n_steps,N,6] (rpy - first rpy, body rates: the info columns),
  * rec_obs [n_steps,N,49] (without sensor noise), rec_reward [n_steps,N], rec_done [n_steps,N] bytes.  obs [N,49] receives the
- * final observation; ret / len as etg_episode_stats (may be NULL).  Same arithmetic as n_steps calls of etg_step.       */
+ * final observation; ret / len as etg_episode_stats (may be NULL).  The same source as n_steps calls of etg_step compiled
+ * into another kernel: equal to rounding noise (multiply-add contraction differs between the two), not bit for bit.   */
 int etg_rollout_actions(EtgHandle* h, const float* actions, int n_steps, float* obs, float* rec_joint_angle, float* rec_imu,
                         float* rec_obs, float* rec_reward, uint8_t* rec_done, float* ret, int32_t* len, void* stream);
 

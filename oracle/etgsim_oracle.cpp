@@ -392,8 +392,8 @@ template <class T> inline void terrain_query(const Sim<T>& s, int band, T x, T y
   const int nx = s.cfg.hf_nx, ny = s.cfg.hf_ny / bands;
   const float* hts = s.heights.data() + (size_t)band * ny * nx;
   T fx = (x - T(s.cfg.hf_x0)) / T(s.cfg.hf_cell), fy = (y - T(s.cfg.hf_y0)) / T(s.cfg.hf_cell);
-  if (fx < 0) fx = 0;
-  if (fy < 0) fy = 0;
+  if (!(fx > 0)) fx = 0;   // (also a NaN coordinate of a robot that blew up: max(NaN, 0) = 0, what the kernels' fmaxf does)
+  if (!(fy > 0)) fy = 0;
   if (fx > T(nx - 1)) fx = T(nx - 1);
   if (fy > T(ny - 1)) fy = T(ny - 1);
   int ix = (int)fx, iy = (int)fy;

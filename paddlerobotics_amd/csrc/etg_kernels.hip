@@ -1789,8 +1789,9 @@ extern "C" int etg_episode_stats(EtgHandle* h, float* ret, int32_t* len, void* s
 }
 
 // n_steps x env.step(action = 0) enqueued back-to-back on the stream (pretrain.py:129-154).
-// Bit-identical to calling etg_step n_steps times; the per-robot return/length since the last
-// etg_reset are accumulated inside the step kernel with alive masking.
+// The same source as etg_step in another kernel: the compiler contracts multiply-adds differently in the two contexts, so the
+// two agree to rounding noise amplified by the contacts (joints ~1e-6 rad after one control step), not bit for bit.  The
+// per-robot return/length since the last etg_reset are accumulated inside the kernels with alive masking.
 extern "C" int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float* ret, int32_t* len, void* stream) {
   CHECK_HANDLE(h);
   if (n_steps <= 0 || !ret || !len) return fail(ETG_ERR_BAD_ARG, "etg_rollout_openloop: bad arguments");

@@ -669,7 +669,8 @@ class BatchedQuadrupedEnv:
         [T, N, 12] (already scaled, what step() takes) or [T, 12] (the same command for every robot).  record: the per-step
         outputs to keep -- any of "joint_angle" [T,N,12], "obs-IMU" [T,N,6] (the info columns the dynamics-identification
         replay reads, Dynamic_parallel_model.py:63-64), "obs" [T,N,49], "reward" [T,N], "done" [T,N].
-        Returns (episode_return[N], episode_len[N], rec dict).  Same arithmetic as T calls of step()."""
+        Returns (episode_return[N], episode_len[N], rec dict).  The same source as T calls of step() in another kernel: equal to
+        rounding noise (the compiler contracts multiply-adds differently), not bit for bit."""
         N = self.num_envs
         a = torch.as_tensor(actions, dtype=torch.float32, device=self.device)
         if a.dim() == 2:

@@ -554,3 +554,23 @@ def test_emulation_robot_layer_gaps_match_oracle(lanes, option):
         worst = max(worst, np.abs(emu.get_state() - orc.get_state())[:, 13:25].max())
     assert worst < 3e-4, worst
     assert np.abs(plain.get_state() - orc.get_state())[:, :25].max() > 1e-3      # the option does change the motion
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_a_robot_that_blew_up_does_not_take_the_heightfield_lookup_with_it(lanes):
+    """A pd_latency of 6 ms makes the delayed damping term of the PD law unstable (kd * latency / link inertia > ~1): the settle
+    blows up to non-finite numbers -- physics, not a defect, and the library only rejects latencies its ring cannot hold.  The
+    heightfield lookup then gets a NaN coordinate: both the oracle and the kernel source must clamp it like max(NaN, 0) = 0 does
+    (found by tools/fuzz_parity.py: the oracle's `if (fx < 0)` let the NaN through to the index), and the step reports the
+    robot as terminated."""
+    from oracle.oracle import OracleSim
+    from tests.emu.emu import EmuSim
+    n = 4
+    hf = dict(heights=np.random.default_rng(3).uniform(0, 0.04, size=(64, 64)).astype(np.float32), cell=0.05, origin=(-1.6, -1.6))
+    cfg = A.default_config(n, pd_latency=0.006, terrain=1, heightfield=hf)
+    for sim in (OracleSim(cfg, dtype=np.float64), OracleSim(cfg, dtype=np.float32), EmuSim(cfg, lanes=lanes)):
+        sim.set_heightfield(hf["heights"])
+        sim.reset()
+        assert not np.isfinite(sim.get_state()).all()
+        _, _, done, _ = sim.step(np.zeros((n, 12), dtype=np.float32))
+        assert np.asarray(done).astype(bool).all()

@@ -1,0 +1,189 @@
+"""Differential fuzz of the HIP path against the oracle through the C-ABI (one MI355X; test infrastructure, like tests/).
+
+Every trial draws a random combination of the robot-layer / solver / terrain options, a lane mapping, per-robot ETG
+parameters, dynamic rows, strength ratios and pushes; builds the env with make_env() and the fp64 + fp32 oracles FROM THE ENV'S
+OWN EtgConfig (so the keyword -> config mapping is under test too); steps both through random actions and compares joints,
+base pose, observation rows, rewards and done flags.  A robot passes when its GPU-vs-fp64 joint gap is within the trajectory's
+own fp32 sensitivity (4 x the fp32 oracle's gap + floor); a trial passes when 90 % of its robots do and the median gap is
+small.  Prints one line per trial and the failing configurations at the end; exit code 1 on any failure.
+
+  python tools/fuzz_parity.py [--trials 60] [--seed 0] [--n 32] [--steps 8]
+"""
+import argparse, os, sys, time
+import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from paddlerobotics_amd import a1_model as A
+from paddlerobotics_amd.env import make_env
+from oracle.oracle import OracleSim
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--trials", type=int, default=60)
+ap.add_argument("--seed", type=int, default=0)
+ap.add_argument("--n", type=int, default=32)
+ap.add_argument("--steps", type=int, default=8)
+args = ap.parse_args()
+N = args.n
+
+
+def etg_params(rng, n):
+    from paddlerobotics_amd.etg import ETG_layer, Opt_with_points
+    layer = ETG_layer(0.5, 0.026, 20, 0.04, np.array([-np.pi / 2, 0]), 0.2, 0.5)
+    w0, b0, prior = Opt_with_points(layer, ETG_T=0.5, Footheight=0.1, Steplength=0.05)
+    W, B = np.zeros((n, 3, 20)), np.zeros((n, 3))
+    for i in range(n):
+        W[i], B[i], _ = Opt_with_points(layer, ETG_T=0.5, w0=w0, b0=b0, points=prior + 0.02 * rng.normal(size=(6, 2)))
+    return W, B
+
+
+def draw(rng):
+    kw = {}
+    lanes = int(rng.choice([16, 4]))
+    mode = rng.choice(["pose", "pose", "pose", "torque", "hybrid"])
+    if mode != "pose":
+        kw["motor_control_mode"] = str(mode)
+    if rng.random() < 0.25: kw["enable_action_filter"] = True
+    if rng.random() < 0.25: kw["enable_action_interpolation"] = True
+    if mode == "pose" and rng.random() < 0.25: kw["enable_clip_motor_commands"] = True
+    bc = int(rng.choice([0, 0, 0, 1, 2, 3]))
+    if bc == 3 and lanes == 16: bc = 2
+    if bc: kw["body_contacts"] = bc
+    if rng.random() < 0.3: kw["joint_limits"] = False
+    if rng.random() < 0.3: kw["friction_model"] = 1
+    s = rng.random()
+    if s < 0.2: kw["solver_iters"] = int(rng.integers(2, 6))
+    elif s < 0.35: kw["solver_residual"] = 1e-5
+    if rng.random() < 0.3: kw["pd_latency"] = float(rng.choice([0.0005, 0.001, 0.002]))   # (the delayed kd term: marginal from ~2.5 ms -- settles differ by 1e-3 between any two
+        # fp32 evaluations -- and a physical blow-up from ~4 ms with the default gains, where both sides go NaN)
+    if rng.random() < 0.2: kw.update(warmstart=0.85, warmstart_friction=float(rng.choice([0.0, 0.85])))
+    if rng.random() < 0.15: kw["contact_slop"] = 0.0
+    if rng.random() < 0.2: kw["foot_restitution"] = float(rng.uniform(0.1, 0.8))
+    if rng.random() < 0.25: kw["motor_torque_limits"] = float(rng.uniform(8.0, 30.0))
+    if rng.random() < 0.2: kw["ETG"] = 0
+    t = rng.random()
+    if t < 0.2: kw["task"] = "stairstair"; kw["terrain_seed"] = int(rng.integers(0, 5))
+    elif t < 0.4:
+        hf = rng.uniform(0.0, 0.04, size=(64, 64)).astype(np.float32)
+        kw.update(task="heightfield", heightfield=dict(heights=hf, cell=0.05, origin=(-1.6, -1.6)))
+    extras = dict(dyn=rng.random() < 0.5, strength=rng.random() < 0.3, push=rng.random() < 0.3)
+    if extras["dyn"] and kw.get("pd_latency", 0.0) > 0.001:
+        kw["pd_latency"] = 0.001       # (random kd up to 2.6 on lighter links: the delayed damping term blows up earlier)
+    return lanes, kw, extras
+
+
+def short(kw):
+    return {k: (v if k != "heightfield" else "64x64") for k, v in kw.items()}
+
+
+fails = []
+t_start = time.time()
+for trial in range(args.trials):
+    rng = np.random.default_rng(1000 * args.seed + trial)
+    lanes, kw, ex = draw(rng)
+    env = make_env("Quadrupedal", num_envs=N, device="cuda:0", lanes_per_robot=lanes, seed=trial, **kw)
+    cfg = type(env.cfg).from_buffer_copy(env.cfg)
+    orcs = [OracleSim(type(cfg).from_buffer_copy(cfg), dtype=np.float64), OracleSim(type(cfg).from_buffer_copy(cfg), dtype=np.float32)]
+    if env.terrain is not None:
+        for o in orcs: o.set_heightfield(env.terrain["heights"])
+    W = B = None
+    if kw.get("ETG", 1):      # (make_env installs the prior gait by default: the oracles get the same per-robot parameters)
+        W, B = etg_params(rng, N)
+        for o in orcs: o.set_params(etg_w=W, etg_b=B)
+    if ex["dyn"]:
+        p = torch.as_tensor(rng.uniform(-0.3, 0.3, size=(N, A.DYN_DIM)), dtype=torch.float32)
+        rows = A.param2dynamic_rows_torch(p).numpy().astype(np.float64)
+        rows[:, 1] = np.maximum(rows[:, 1], 0.05)          # (frictionless feet are legal but chaotic within a step or two)
+        env.set_dynamic_param(torch.as_tensor(rows, dtype=torch.float32, device="cuda:0"))
+        for o in orcs: o.set_params(dyn=rows)
+    sr = None
+    if ex["strength"]:
+        sr = rng.uniform(0.5, 1.0, size=(N, 12))
+        env.set_motor_strength_ratios(torch.as_tensor(sr, dtype=torch.float32))
+        for o in orcs: o.set_motor_strength(sr)
+    if W is not None:
+        env.reset(ETG_w=W, ETG_b=B)
+    else:
+        env.reset()
+    for o in orcs: o.reset()
+    f = None
+    if ex["push"]:
+        f = np.zeros((N, 3)); f[:, :2] = rng.uniform(-15, 15, size=(N, 2))
+        env.set_external_force(torch.as_tensor(f, dtype=torch.float32))
+        for o in orcs: o.set_external_force(f)
+    r0g = np.abs(env.get_state().cpu().numpy() - orcs[0].get_state())[:, :25].max(1)
+    r032 = np.abs(orcs[1].get_state() - orcs[0].get_state())[:, :25].max(1)
+    s0 = float(np.median(r0g))
+    # (a looser residual threshold stops the sweeps on a last-bit decision worth ~sqrt(threshold) m/s: the floor follows it)
+    loose = max(1.0, float(np.sqrt(env.cfg.solver_residual / 1e-7)))
+    # (a heightfield keeps fp32 evaluations on one trajectory for ~45 % of the robots only: profiles/r04_hf_tracking.txt)
+    need = 0.6 if kw.get("task") == "heightfield" else 0.9
+    reset_ok = np.mean(r0g <= 2e-3 * loose + 4.0 * r032) >= need
+    adim = env.action_space.shape[0]
+    mode = kw.get("motor_control_mode", "pose")
+    eg, e32 = np.zeros(N), np.zeros(N)
+    eobs, erew, ddiff = 0.0, 0.0, 0
+    for k in range(4 if mode == "torque" else args.steps):   # (random torques on every joint are chaotic within ~6 steps)
+        if mode == "hybrid":
+            a = rng.uniform(-1, 1, size=(N, 12, 5))
+            a[..., 0] = np.array([0.0, 0.9, -1.8] * 4) + 0.15 * a[..., 0]; a[..., 1] = 80.0; a[..., 2] = 0.0; a[..., 3] = 1.5; a[..., 4] *= 2.0
+            a = a.reshape(N, 60)
+        elif mode == "torque":
+            a = rng.uniform(-4.0, 4.0, size=(N, adim))
+        else:
+            a = rng.uniform(-0.2, 0.2, size=(N, adim))
+        obs, rew, done, _ = env.step(torch.as_tensor(a, dtype=torch.float32))
+        outs = [o.step(a) for o in orcs]
+        sg, so, s3 = env.get_state().cpu().numpy(), orcs[0].get_state(), orcs[1].get_state()
+        eg = np.maximum(eg, np.abs(sg - so)[:, 13:25].max(1))
+        e32 = np.maximum(e32, np.abs(s3 - so)[:, 13:25].max(1))
+        good = np.abs(sg - so)[:, 13:25].max(1) <= 1e-4 * loose + 4.0 * np.abs(s3 - so)[:, 13:25].max(1)
+        og = obs.cpu().numpy().reshape(N, -1)
+        oo = np.asarray(outs[0][0]).reshape(N, -1)
+        if og.shape == oo.shape and good.any():
+            eobs = max(eobs, float(np.median(np.abs(og - oo)[good].max(1))))
+            erew = max(erew, float(np.median(np.abs(rew.cpu().numpy() - np.asarray(outs[0][1]))[good])))
+        ddiff += int((done.cpu().numpy().astype(bool) != np.asarray(outs[0][2]).astype(bool))[good].sum())
+    finite = bool(np.isfinite(sg).all())
+    frac = float(np.mean(eg <= 1e-4 * loose + 4.0 * e32))
+    # torque commands and limp limbs are chaotic within a handful of steps: the fp32 oracle's own gap is the yardstick there
+    checks = dict(finite=finite, robots=frac >= need, median=np.median(eg) < max(5e-5 * loose, 4.0 * np.median(e32)), reset=bool(reset_ok),
+                  obs=eobs < max(5e-3, 300 * np.median(eg)))   # (velocity columns: ~100 x the angle gap)
+    ok = all(checks.values())
+    print("%s trial %3d lanes %2d reset gap %.1e | joints vs fp64 oracle: median %.1e max %.1e (fp32 oracle %.1e / %.1e) within-sensitivity %.2f | obs %.1e reward %.1e done-mismatch %d | %s %s"
+          % ("ok  " if ok else "FAIL", trial, lanes, s0, np.median(eg), eg.max(), np.median(e32), e32.max(), frac, eobs, erew, ddiff,
+             short(kw), {k: v for k, v in ex.items() if v}) + ("" if ok else " failed: %s" % [k for k, v in checks.items() if not v]), flush=True)
+    # ---- the fused tape kernel against stepping (the same options; HYBRID rows are not a tape format)
+    fused = "-"
+    if mode != "hybrid":
+        env2 = make_env("Quadrupedal", num_envs=N, device="cuda:0", lanes_per_robot=lanes, seed=trial, **kw)
+        for e in (env, env2):
+            e.set_external_force(None)
+            if ex["dyn"]: e.set_dynamic_param(torch.as_tensor(rows, dtype=torch.float32, device="cuda:0"))
+            if ex["strength"]: e.set_motor_strength_ratios(torch.as_tensor(sr, dtype=torch.float32))
+            e.reset(ETG_w=W, ETG_b=B) if W is not None else e.reset()
+            if ex["push"]: e.set_external_force(torch.as_tensor(f, dtype=torch.float32))
+        T = 5
+        tape = torch.as_tensor(rng.uniform(-0.2, 0.2, size=(T, N, 12)) * (20.0 if mode == "torque" else 1.0), dtype=torch.float32, device="cuda:0")
+        _, _, rec = env.rollout_actions(tape, record=("obs", "reward", "done"))
+        # (same source, two kernels: the compiler contracts multiply-adds differently in the two contexts, so the comparison is
+        # to rounding noise amplified by the contacts -- tests/test_gpu_parity.py::test_fused_rollout_equals_stepping -- plus
+        # exact agreement of the first observation row's bookkeeping columns)
+        gap, dsame = np.zeros(N), 0
+        for k in range(T):
+            o2, r2, d2, _ = env2.step(tape[k])
+            gap = np.maximum(gap, (rec["obs"][k].view(N, -1) - o2.view(N, -1))[:, 13:25].abs().max(1).values.cpu().numpy())
+            dsame += int((rec["done"][k].bool() == d2.view(-1).bool()).sum().item())
+        gap = np.maximum(gap, (env.get_state() - env2.get_state())[:, 13:25].abs().max(1).values.cpu().numpy())
+        same = np.median(gap) < (2e-4 if mode == "torque" else 2e-5) * loose and dsame >= 0.97 * T * N
+        fused = "joints median %.1e max %.1e, done flags equal %d / %d%s" % (np.median(gap), gap.max(), dsame, T * N, "" if same else "  DIFFERS")
+        if not same:
+            ok = False
+            checks["fused_tape"] = False
+        env2.close()
+    print("     trial %3d fused tape vs stepping: %s" % (trial, fused), flush=True)
+    if not ok:
+        fails.append((trial, lanes, short(kw), ex, [k for k, v in checks.items() if not v]))
+    env.close()
+print("fuzz: %d trials, %d failed, %.0f s" % (args.trials, len(fails), time.time() - t_start))
+for f in fails:
+    print("  FAILED:", f)
+sys.exit(1 if fails else 0)
