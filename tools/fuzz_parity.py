@@ -180,6 +180,38 @@ for trial in range(args.trials):
             checks["fused_tape"] = False
         env2.close()
     print("     trial %3d fused tape vs stepping: %s" % (trial, fused), flush=True)
+    # ---- step(auto_reset) against step() + reset(env_ids=done), restarts forced on a random third of the robots per step
+    ea = make_env("Quadrupedal", num_envs=N, device="cuda:0", lanes_per_robot=lanes, seed=trial, auto_reset=True, **kw)
+    eb = make_env("Quadrupedal", num_envs=N, device="cuda:0", lanes_per_robot=lanes, seed=trial, **kw)
+    for e in (ea, eb):
+        if ex["dyn"]: e.set_dynamic_param(torch.as_tensor(rows, dtype=torch.float32, device="cuda:0"))
+        if ex["strength"]: e.set_motor_strength_ratios(torch.as_tensor(sr, dtype=torch.float32))
+        e.reset(ETG_w=W, ETG_b=B) if W is not None else e.reset()
+        if ex["push"]: e.set_external_force(torch.as_tensor(f, dtype=torch.float32))
+    ar_gap, ar_done, ar_n = 0.0, 0, 0
+    for k in range(6):
+        if mode == "hybrid":
+            a = rng.uniform(-1, 1, size=(N, 12, 5))
+            a[..., 0] = np.array([0.0, 0.9, -1.8] * 4) + 0.15 * a[..., 0]; a[..., 1] = 80.0; a[..., 2] = 0.0; a[..., 3] = 1.5; a[..., 4] *= 2.0
+            a = a.reshape(N, 60)
+        else:
+            a = rng.uniform(-0.2, 0.2, size=(N, adim)) * (20.0 if mode == "torque" else 1.0)
+        a = torch.as_tensor(a, dtype=torch.float32, device="cuda:0")
+        force = torch.as_tensor(rng.random(N) < 0.33, device="cuda:0")
+        oa, ra, da, ia = ea.step(a, donef=force)
+        ob, rb, db, _ = eb.step(a, donef=force)
+        ar_done += int((da.view(-1).bool() == db.view(-1).bool()).sum().item()); ar_n += N
+        eb.reset(env_ids=db.view(-1).bool())
+        ar_gap = max(ar_gap, float(np.median((ea.get_state() - eb.get_state())[:, 13:25].abs().max(1).values.cpu().numpy())))
+        restarted = db.view(-1).bool()
+        if restarted.any():
+            ar_gap = max(ar_gap, float((oa.view(N, -1)[restarted] - eb.obs.view(N, -1)[restarted]).abs().max().item()))
+    ar_ok = ar_gap < (5e-4 if mode == "torque" else 5e-5) * loose and ar_done >= 0.97 * ar_n
+    print("     trial %3d auto_reset vs manual reset: median joint / restart-row gap %.1e, done flags equal %d / %d%s" % (trial, ar_gap, ar_done, ar_n, "" if ar_ok else "  DIFFERS"), flush=True)
+    if not ar_ok:
+        ok = False
+        checks["auto_reset"] = False
+    ea.close(); eb.close()
     if not ok:
         fails.append((trial, lanes, short(kw), ex, [k for k, v in checks.items() if not v]))
     env.close()
