@@ -16,7 +16,7 @@ def test_random_option_combinations_match_the_oracle():
     import torch
     if not torch.cuda.is_available():
         pytest.fail("no HIP device visible: -m gpu tests must run on the MI355X box")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--trials", "24", "--seed", "2"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--trials", "24", "--seed", "3"],
                        capture_output=True, text=True, timeout=900, cwd=ROOT)
     print(r.stdout[-3000:])
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])
