@@ -1,6 +1,7 @@
 """-m gpu: a short run of the differential fuzzer (tools/fuzz_parity.py) -- random combinations of the robot-layer, solver and
 terrain options, both lane mappings, per-robot ETG parameters / dynamic rows / strength ratios / pushes -- through the C-ABI
-against the fp64 and fp32 oracles built from the env's own EtgConfig, plus the fused tape kernel against stepping.  The long
+against the fp64 and fp32 oracles built from the env's own EtgConfig, plus the fused tape kernel and the fused closed loop against
+stepping and step(auto_reset) against manual resets.  The long
 runs (hundreds of trials, other seeds) are a tool invocation; their last result is profiles/r04_fuzz.txt."""
 import os
 import subprocess

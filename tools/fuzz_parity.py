@@ -14,6 +14,7 @@ import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from paddlerobotics_amd import a1_model as A
 from paddlerobotics_amd.env import make_env
+from paddlerobotics_amd.policy import MfmaPolicy
 from oracle.oracle import OracleSim
 
 ap = argparse.ArgumentParser()
@@ -212,6 +213,34 @@ for trial in range(args.trials):
         ok = False
         checks["auto_reset"] = False
     ea.close(); eb.close()
+    # ---- the fused closed loop (etg_rollout_policy: actor MLP + control step in one kernel) against predict() + step()
+    pol_txt = "-"
+    if mode != "hybrid" and kw.get("body_contacts", 0) != 3:
+        NP = 64                                   # (the fused kernels take whole wavefronts of robots)
+        ec = make_env("Quadrupedal", num_envs=NP, device="cuda:0", lanes_per_robot=lanes, seed=trial, **kw)
+        ed = make_env("Quadrupedal", num_envs=NP, device="cuda:0", lanes_per_robot=lanes, seed=trial, **kw)
+        pol = MfmaPolicy(A.OBS_DIM, 12, device="cuda:0")
+        pol.load_state_dict(MfmaPolicy.init_like_reference(A.OBS_DIM, 12, seed=trial))
+        rep = lambda x: None if x is None else np.concatenate([x, x])[:NP]
+        for e in (ec, ed):
+            if ex["dyn"]: e.set_dynamic_param(torch.as_tensor(rep(rows), dtype=torch.float32, device="cuda:0"))
+            if ex["strength"]: e.set_motor_strength_ratios(torch.as_tensor(rep(sr), dtype=torch.float32))
+            e.reset(ETG_w=rep(W), ETG_b=rep(B)) if W is not None else e.reset()
+            if ex["push"]: e.set_external_force(torch.as_tensor(rep(f), dtype=torch.float32))
+        scale = 6.0 if mode == "torque" else 0.3
+        ret_c, len_c = ec.rollout_policy(pol, 6, scale)
+        for k in range(6):
+            ed.step(pol.predict(ed.obs, scale), want_info=False)
+        ret_d, len_d = ed.episode_stats()
+        pg = (ec.get_state() - ed.get_state())[:, 13:25].abs().max(1).values.cpu().numpy()
+        lsame = int((len_c == len_d).sum().item())
+        pol_ok = np.median(pg) < (5e-4 if mode == "torque" else 5e-5) * loose and lsame >= 0.95 * NP
+        pol_txt = "joints median %.1e max %.1e, episode lengths equal %d / %d%s" % (np.median(pg), pg.max(), lsame, NP, "" if pol_ok else "  DIFFERS")
+        if not pol_ok:
+            ok = False
+            checks["fused_policy"] = False
+        ec.close(); ed.close()
+    print("     trial %3d fused closed loop vs predict + step: %s" % (trial, pol_txt), flush=True)
     if not ok:
         fails.append((trial, lanes, short(kw), ex, [k for k, v in checks.items() if not v]))
     env.close()
