@@ -2,7 +2,7 @@
 """Gap between a pybullet trajectory dump (tools/pybullet_baseline.py --dump, format in its DUMP_FORMAT) and this repo's
 oracle on the same scenario: the measured replacement for "parity unpinned"  on the first box that has
 pybullet.  TEST INFRASTRUCTURE (it drives oracle/): lives under tests/.  Needs no pybullet itself.
-    python tests/pybullet_compare.py dump.npy [--solver-iters 50]
+    python tests/pybullet_compare.py dump.npy [--solver-iters N]
     python tests/pybullet_compare.py --oracle-dump out.npy --steps 400     (the oracle's own trajectory in the dump format)
 """
 import argparse
@@ -17,11 +17,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
-def oracle_trajectory(steps, solver_iters=50, kp=100.0, friction=None):
+def oracle_trajectory(steps, solver_iters=None, kp=100.0, friction=None):
     """the same scenario on this repo's oracle -> [steps, 19] in the dump format"""
     from paddlerobotics_amd import a1_model as A
     from paddlerobotics_amd.etg import ETG_layer, Opt_with_points
     from oracle.oracle import OracleSim
+    # solver_iters None = the library default = pybullet's own: up to 50 iterations with the 1e-7 residual exit (a count
+    # alone switches the exit off)
     sim = OracleSim(A.default_config(1, solver_iters=solver_iters))
     row = A.default_dynamic_row()
     row[21:33] = kp                          # a1.py:75-80 simulation gains (the identified default is 80)
@@ -40,7 +42,7 @@ def oracle_trajectory(steps, solver_iters=50, kp=100.0, friction=None):
     return out
 
 
-def compare(dump_path, solver_iters=50, friction=None):
+def compare(dump_path, solver_iters=None, friction=None):
     """gap between a pybullet dump (--dump on a box that has pybullet) and the oracle on the same scenario: the measured
     replacement for "parity unpinned" (DESIGN.md section 3).  Needs no pybullet."""
     ref = np.load(dump_path)
@@ -62,7 +64,7 @@ if __name__ == "__main__":
     ap.add_argument("dump", nargs="?", default=None)
     ap.add_argument("--oracle-dump", type=str, default=None)
     ap.add_argument("--steps", type=int, default=400)
-    ap.add_argument("--solver-iters", type=int, default=50)
+    ap.add_argument("--solver-iters", type=int, default=None, help="exactly this many sweeps per tick instead of pybullet's rule (<= 50, residual 1e-7)")
     a = ap.parse_args()
     if a.oracle_dump:
         np.save(a.oracle_dump, oracle_trajectory(a.steps, a.solver_iters))
