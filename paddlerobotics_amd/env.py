@@ -611,17 +611,24 @@ class BatchedQuadrupedEnv:
                                                   self._stream()))
         return ret, ln
 
-    def rollout_policy(self, policy, n_steps, act_scale=0.3, precision=0):
-        """n_steps closed-loop control steps with a fixed actor (policy.predict semantics) fused into one kernel per 50
-        steps; returns (episode_return[N], episode_len[N]).  The batched run_EStrain_episode / run_evaluate_episodes
-        (train.py:182-249).  Falls back to stepping when the fused kernel does not apply."""
+    def rollout_policy(self, policy, n_steps, act_scale=0.3, precision=0, fused=None):
+        """n_steps closed-loop control steps with a fixed actor (policy.predict semantics); returns (episode_return[N],
+        episode_len[N]).  The batched run_EStrain_episode / run_evaluate_episodes (train.py:182-249).  fused: True = the
+        fused kernel (actor MLP + control step, 50 steps per launch; FusedKernelUnavailable when the configuration is outside
+        it), False = policy.predict() + step() per control step, None = whichever is faster for this env: the fused kernel
+        on the 16-lane mapping (7-13 % ahead), and on the 4-lane mapping only without body rows (there it is level with
+        stepping; with body rows its 512-register budget spills and it is 25 % behind -- tools/closed_loop_probe.py)."""
         contiguous = self._cols == list(range(self._cols[0], self._cols[0] + len(self._cols)))   # e.g. the student's 3..48
         # (the fused kernels never restart a finished robot: an auto_reset env takes the stepping loop, which does)
         ok = (self.num_envs % (16 if self.lanes_per_robot == 16 else 64) == 0 and self.motor_mode != 2 and contiguous
               and self._hist_T == 0 and not self._rand_force and policy.obs_dim == len(self._cols)
               and policy.action_dim == A.NUM_MOTORS and not self.auto_reset
               and self.cfg.body_contacts != 3)   # (three body rows per leg: no closed-loop instantiation)
-        if not ok:
+        if fused and not ok:
+            raise FusedKernelUnavailable("rollout_policy(fused=True): this configuration is outside the fused closed-loop kernel")
+        if fused is None:
+            fused = ok and (self.lanes_per_robot == 16 or self.cfg.body_contacts == 0)
+        if not fused:
             act = None
             for _ in range(int(n_steps)):
                 act = policy.predict(self._last_view.contiguous().view(self.num_envs, -1), act_scale, precision, out=act)

@@ -564,8 +564,8 @@ def test_four_lane_closed_loop_kernel(variant):
     fused4, step4, fused16 = _make(n, lanes_per_robot=4, **kw), _make(n, lanes_per_robot=4, **kw), _make(n, lanes_per_robot=16, **kw)
     for e in (fused4, step4, fused16):
         e.reset(ETG_w=Wn, ETG_b=Bn)
-    ret4, ln4 = fused4.rollout_policy(pol, steps, 0.3, prec)
-    ret16, ln16 = fused16.rollout_policy(pol, steps, 0.3, prec)
+    ret4, ln4 = fused4.rollout_policy(pol, steps, 0.3, prec, fused=True)
+    ret16, ln16 = fused16.rollout_policy(pol, steps, 0.3, prec, fused=True)
     for _ in range(steps):
         view = step4.obs[:, 3:] if variant == "student" else step4.obs
         step4.step(pol.predict(view.contiguous(), 0.3, prec), want_info=False)

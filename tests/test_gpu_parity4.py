@@ -162,3 +162,32 @@ def test_prepared_next_dynamics_under_the_all_options_kernels(lanes):
         alive &= ~d.view(-1).bool()
     assert float(alive.float().mean()) > 0.9            # the zero-residual gait walks on for the next steps
     env.close()
+
+
+def test_rollout_policy_takes_the_faster_route_and_says_so_when_forced():
+    """env.rollout_policy(fused=None) runs the fused closed-loop kernel where it is ahead (the 16-lane mapping; the 4-lane one
+    without body rows) and predict() + step() where the kernel's register budget spills (4 lanes with body rows: 25 % behind,
+    tools/closed_loop_probe.py); fused=True insists on the kernel -- same trajectory to rounding -- and raises outside it."""
+    _need_gpu()
+    from paddlerobotics_amd.env import FusedKernelUnavailable
+    from paddlerobotics_amd.policy import MfmaPolicy
+    n = 64
+    pol = MfmaPolicy(49, 12)
+    pol.load_state_dict(MfmaPolicy.init_like_reference(49, 12, seed=2))
+    auto, forced, stepped = (_make(n, lanes_per_robot=4, body_contacts=2) for _ in range(3))
+    for e in (auto, forced, stepped):
+        e.reset()
+    ra, la = auto.rollout_policy(pol, 8, 0.3)
+    rf, lf = forced.rollout_policy(pol, 8, 0.3, fused=True)
+    for _ in range(8):
+        stepped.step(pol.predict(stepped.obs, 0.3), want_info=False)
+    assert torch.equal(auto.get_state(), stepped.get_state())                      # the auto route IS the stepping loop here
+    gap = (forced.get_state() - stepped.get_state())[:, 13:25].abs().max().item()
+    _lt(gap, 5e-5, "4 lanes + body rows, fused closed loop forced vs predict + step: joint gap after 8 steps")
+    assert torch.equal(la, lf) and torch.allclose(ra, rf, rtol=1e-3, atol=1e-3)
+    hyb = _make(n, motor_control_mode="hybrid")
+    hyb.reset()
+    with pytest.raises(FusedKernelUnavailable):
+        hyb.rollout_policy(pol, 2, 0.3, fused=True)
+    for e in (auto, forced, stepped, hyb):
+        e.close()

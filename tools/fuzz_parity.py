@@ -228,7 +228,7 @@ for trial in range(args.trials):
             e.reset(ETG_w=rep(W), ETG_b=rep(B)) if W is not None else e.reset()
             if ex["push"]: e.set_external_force(torch.as_tensor(rep(f), dtype=torch.float32))
         scale = 6.0 if mode == "torque" else 0.3
-        ret_c, len_c = ec.rollout_policy(pol, 6, scale)
+        ret_c, len_c = ec.rollout_policy(pol, 6, scale, fused=True)   # (the kernel itself: env's own choice may be the stepping loop)
         for k in range(6):
             ed.step(pol.predict(ed.obs, scale), want_info=False)
         ret_d, len_d = ed.episode_stats()
