@@ -37,8 +37,14 @@ def ls_sol_batched(A, b, precision=1e-4, alpha=0.05, lamb=1.0, w0=None, max_iter
 def opt_with_points_batched(ETG, ETG_T, points, b0, w0, precision=1e-4, lamb=0.5, device="cpu"):
     """points [B,6,2] (prior + candidate offsets), b0 [3], w0 [3,20] -> (w [B,3,20], b [B,3]).
     Same as calling Opt_with_points(ETG, ETG_T, points=points[i], b0=b0, w0=w0) for every i."""
-    feats = torch.as_tensor(np.array([ETG.update(t) for t in control_times(ETG_T)]), dtype=torch.float64,
-                            device=device)
+    # the 6 x 20 feature matrix depends on the layer and the period alone: built and uploaded once per device
+    cache = ETG.__dict__.setdefault("_fit_feats", {})
+    key = (float(ETG_T), str(device))
+    if key not in cache:
+        cache[key] = torch.as_tensor(np.array([ETG.update(t) for t in control_times(ETG_T)]), dtype=torch.float64, device=device)
+    else:
+        ETG.t += ETG.dt * len(control_times(ETG_T))       # (what the update() calls of the uncached path do to the layer's clock)
+    feats = cache[key]
     pts = torch.as_tensor(points, dtype=torch.float64, device=device)
     if pts.is_cuda:
         return _fit_hip(pts.contiguous(), feats.contiguous(), b0, w0, precision, lamb)
