@@ -65,7 +65,7 @@ def draw(rng):
     elif t < 0.4:
         hf = rng.uniform(0.0, 0.04, size=(64, 64)).astype(np.float32)
         kw.update(task="heightfield", heightfield=dict(heights=hf, cell=0.05, origin=(-1.6, -1.6)))
-    extras = dict(dyn=rng.random() < 0.5, strength=rng.random() < 0.3, push=rng.random() < 0.3)
+    extras = dict(dyn=rng.random() < 0.5, strength=rng.random() < 0.3, push=rng.random() < 0.3, noise=rng.random() < 0.2, offsets=rng.random() < 0.25)
     if extras["dyn"] and kw.get("pd_latency", 0.0) > 0.001:
         kw["pd_latency"] = 0.001       # (random kd up to 2.6 on lighter links: the delayed damping term blows up earlier)
     return lanes, kw, extras
@@ -80,11 +80,20 @@ t_start = time.time()
 for trial in range(args.trials):
     rng = np.random.default_rng(1000 * args.seed + trial)
     lanes, kw, ex = draw(rng)
+    NOISE = [0.02, 0.3, 0.0, 0.01, 0.05]
+    if ex["noise"]:
+        kw["observation_noise_stdev"] = NOISE      # (counter-based draws: the oracle's stream is seeded like the env's)
+    offs = rng.uniform(-0.3, 0.3, size=(64, 2)) if ex["offsets"] else None
     env = make_env("Quadrupedal", num_envs=N, device="cuda:0", lanes_per_robot=lanes, seed=trial, **kw)
     cfg = type(env.cfg).from_buffer_copy(env.cfg)
     orcs = [OracleSim(type(cfg).from_buffer_copy(cfg), dtype=np.float64), OracleSim(type(cfg).from_buffer_copy(cfg), dtype=np.float32)]
     if env.terrain is not None:
         for o in orcs: o.set_heightfield(env.terrain["heights"])
+    if ex["noise"]:
+        for o in orcs: o.set_sensor_noise(NOISE, seed=trial)
+    if offs is not None:
+        env.set_reset_offsets(torch.as_tensor(offs[:N], dtype=torch.float32))
+        for o in orcs: o.set_reset_offsets(offs[:N])
     W = B = None
     if kw.get("ETG", 1):      # (make_env installs the prior gait by default: the oracles get the same per-robot parameters)
         W, B = etg_params(rng, N)
@@ -158,20 +167,23 @@ for trial in range(args.trials):
         env2 = make_env("Quadrupedal", num_envs=N, device="cuda:0", lanes_per_robot=lanes, seed=trial, **kw)
         for e in (env, env2):
             e.set_external_force(None)
+            if offs is not None: e.set_reset_offsets(torch.as_tensor(offs[:N], dtype=torch.float32))
             if ex["dyn"]: e.set_dynamic_param(torch.as_tensor(rows, dtype=torch.float32, device="cuda:0"))
             if ex["strength"]: e.set_motor_strength_ratios(torch.as_tensor(sr, dtype=torch.float32))
             e.reset(ETG_w=W, ETG_b=B) if W is not None else e.reset()
             if ex["push"]: e.set_external_force(torch.as_tensor(f, dtype=torch.float32))
         T = 5
         tape = torch.as_tensor(rng.uniform(-0.2, 0.2, size=(T, N, 12)) * (20.0 if mode == "torque" else 1.0), dtype=torch.float32, device="cuda:0")
-        _, _, rec = env.rollout_actions(tape, record=("obs", "reward", "done"))
+        # (the tape records observations without sensor noise and says so: with noise on, rewards and done flags only)
+        _, _, rec = env.rollout_actions(tape, record=("reward", "done") if ex["noise"] else ("obs", "reward", "done"))
         # (same source, two kernels: the compiler contracts multiply-adds differently in the two contexts, so the comparison is
         # to rounding noise amplified by the contacts -- tests/test_gpu_parity.py::test_fused_rollout_equals_stepping -- plus
         # exact agreement of the first observation row's bookkeeping columns)
         gap, dsame = np.zeros(N), 0
         for k in range(T):
             o2, r2, d2, _ = env2.step(tape[k])
-            gap = np.maximum(gap, (rec["obs"][k].view(N, -1) - o2.view(N, -1))[:, 13:25].abs().max(1).values.cpu().numpy())
+            if "obs" in rec:
+                gap = np.maximum(gap, (rec["obs"][k].view(N, -1) - o2.view(N, -1))[:, 13:25].abs().max(1).values.cpu().numpy())
             dsame += int((rec["done"][k].bool() == d2.view(-1).bool()).sum().item())
         gap = np.maximum(gap, (env.get_state() - env2.get_state())[:, 13:25].abs().max(1).values.cpu().numpy())
         same = np.median(gap) < (2e-4 if mode == "torque" else 2e-5) * loose and dsame >= 0.97 * T * N
@@ -185,6 +197,7 @@ for trial in range(args.trials):
     ea = make_env("Quadrupedal", num_envs=N, device="cuda:0", lanes_per_robot=lanes, seed=trial, auto_reset=True, **kw)
     eb = make_env("Quadrupedal", num_envs=N, device="cuda:0", lanes_per_robot=lanes, seed=trial, **kw)
     for e in (ea, eb):
+        if offs is not None: e.set_reset_offsets(torch.as_tensor(offs[:N], dtype=torch.float32))
         if ex["dyn"]: e.set_dynamic_param(torch.as_tensor(rows, dtype=torch.float32, device="cuda:0"))
         if ex["strength"]: e.set_motor_strength_ratios(torch.as_tensor(sr, dtype=torch.float32))
         e.reset(ETG_w=W, ETG_b=B) if W is not None else e.reset()
@@ -223,6 +236,7 @@ for trial in range(args.trials):
         pol.load_state_dict(MfmaPolicy.init_like_reference(A.OBS_DIM, 12, seed=trial))
         rep = lambda x: None if x is None else np.concatenate([x, x])[:NP]
         for e in (ec, ed):
+            if offs is not None: e.set_reset_offsets(torch.as_tensor(offs[:NP], dtype=torch.float32))
             if ex["dyn"]: e.set_dynamic_param(torch.as_tensor(rep(rows), dtype=torch.float32, device="cuda:0"))
             if ex["strength"]: e.set_motor_strength_ratios(torch.as_tensor(rep(sr), dtype=torch.float32))
             e.reset(ETG_w=rep(W), ETG_b=rep(B)) if W is not None else e.reset()
