@@ -688,6 +688,16 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   auto solve = [&](auto pyramid_tag) {
     constexpr bool pyramid = decltype(pyramid_tag)::value;
     F iAqe[3] = {iAq[0], iAq[1], iAq[2]}, c0qe[3] = {c0q[0], c0q[1], c0q[2]};
+    // which of the 12 joint rows exist for SOME robot of the wave: one wave-uniform bit each, made once per tick (etg_core16.h)
+    unsigned jrows = 0u;
+    if (joints) {
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+          if (c.any(own[j] * jactf[i] > F(0.5f))) jrows |= 1u << (3 * j + i);
+      jrows = c.uniform_bits(jrows);
+    }
     auto joint_phase = [&]() {
       // ZL = sum over the robot's rows of lam_r Z_r (the joint rows' Z-vectors are -sgn zj)
       W zs = l0 * Z[0] + l1 * Z[1] + l2 * Z[2];
@@ -709,7 +719,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
       for (int j = 0; j < 4; j++)
 #pragma unroll
         for (int i = 0; i < 3; i++) {
-          if (!c.any(own[j] * jactf[i] > F(0.5f))) continue;         // no robot of the wave has this joint at a stop
+          if (!(jrows & (1u << (3 * j + i)))) continue;              // no robot of the wave has this joint at a stop
           const F qj = qc[i] + Hinv[i][0] * (sgn[0] * lamq[0]) + Hinv[i][1] * (sgn[1] * lamq[1]) + Hinv[i][2] * (sgn[2] * lamq[2]);
           const W zlw = {{zl[0], zl[1], zl[2]}, {zl[3], zl[4], zl[5]}};
           const F uq = sgn[i] * (qj - dot(zj[i], zlw));

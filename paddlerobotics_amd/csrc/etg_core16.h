@@ -473,6 +473,19 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   auto solve = [&](auto pyramid_tag) {
     constexpr bool pyramid = decltype(pyramid_tag)::value;
     F iAqe = iAq, c0qe = c0q;
+    // which of the 12 joint rows exist for SOME robot of the wave: one wave-uniform bit each, made once per tick (the sweeps
+    // test a scalar bit; twelve lane-mask tests per sweep cost ~240 cycles of a 840-cycle sweep)
+    unsigned jrows = 0u;
+    if (joints) {
+#pragma unroll
+      for (int lp = 0; lp < 4; lp++)
+#pragma unroll
+        for (int e = 0; e < 3; e++) {
+          const F me = ownl[lp] * (e == 0 ? f0 : (e == 1 ? f1 : f2));
+          if (c.any(me * jactf > F(0.5f))) jrows |= 1u << (3 * lp + e);
+        }
+      jrows = c.uniform_bits(jrows);
+    }
     auto joint_phase = [&]() {
       F zl[6], zl0[6];
       const F slq = sgn * lamq;
@@ -488,8 +501,8 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
       for (int lp = 0; lp < 4; lp++)
 #pragma unroll
         for (int e = 0; e < 3; e++) {
+          if (!(jrows & (1u << (3 * lp + e)))) continue;               // no robot of the wave has this joint at a stop
           const F me = ownl[lp] * (e == 0 ? f0 : (e == 1 ? f1 : f2));
-          if (!c.any(me * jactf > F(0.5f))) continue;                  // no robot of the wave has this joint at a stop
           const F sl = sgn * lamq;
           const F qj = qc + (h0 * c.qb(sl, 0) + h1 * c.qb(sl, 1) + h2 * c.qb(sl, 2));
           F zz = zj[0] * zl[0];
@@ -577,19 +590,20 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
 #ifdef ETG_EAGER_FREEZE   // A/B build variant: the round-3 form (constants zeroed before the next sweep)
         constexpr bool lazy = false;
 #else
-        constexpr bool lazy = !joints;
+        constexpr bool lazy = true;
 #endif
         if constexpr (lazy) {
-          // Without joint rows a converged robot is frozen LAZILY: it sweeps on with its real constants and is put back to its
-          // values at convergence afterwards (two selects) -- the same result bit for bit as zeroed constants, but the
-          // per-robot mask (ballot -> shift -> and -> compare: a 6-deep chain) is only needed AFTER the next sweep, so it
-          // leaves the sweep's critical path; the wave's exit test is the compare's wave mask alone.
-          const F lam0 = lam, u0 = u;
+          // A converged robot is frozen LAZILY: it sweeps on with its real constants and is put back to its values at
+          // convergence afterwards (two selects, three with joint rows) -- the same result bit for bit as zeroed constants,
+          // but the per-robot mask (ballot -> shift -> and -> compare: a 6-deep chain) is only needed AFTER the next sweep,
+          // so it leaves the sweep's critical path; the wave's exit test is the compare's wave mask alone.
+          const F lam0 = lam, u0 = u, lamq0 = lamq;
           pgs_sweep();
           it++;
           lam = sel_(frozen, lam0, lam);
           u = sel_(frozen, u0, u);
-          const auto moved = fabsf_(lam - lam0) > tol;
+          if (joints) lamq = sel_(frozen, lamq0, lamq);
+          const auto moved = joints ? ((fabsf_(lam - lam0) > tol) || (fabsf_(lamq - lamq0) > tolq)) : (fabsf_(lam - lam0) > tol);
           more = c.wave_any(moved) && it < K.iters;
           frozen = !c.robot_any(moved);
           return;

@@ -94,6 +94,7 @@ struct GpuCtx {
   }
   __device__ __forceinline__ bool lane_is(int j) const { return lane == j; }
   __device__ __forceinline__ bool any(bool b) const { return __any(b); }
+  __device__ __forceinline__ unsigned uniform_bits(unsigned v) const { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }   // a wave-uniform value, kept in an SGPR
   __device__ __forceinline__ bool wave_any(bool b) const { return __any(b); }   // "does any robot of the wave need another sweep?"
   // "does any lane of MY robot (quad) see b?" from the wave mask of the compare: two ANDs with this lane's quad field
   __device__ __forceinline__ bool robot_any(bool b) const {
@@ -510,6 +511,7 @@ struct GpuCtx16 {
   __device__ __forceinline__ bool sub_is(int j) const { return sub == j; }
   __device__ __forceinline__ bool leg_is(int j) const { return leg == j; }
   __device__ __forceinline__ bool any(bool b) const { return __any(b); }
+  __device__ __forceinline__ unsigned uniform_bits(unsigned v) const { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }   // a wave-uniform value, kept in an SGPR
   __device__ __forceinline__ bool wave_any(bool b) const { return __any(b); }   // "does any robot of the wave need another sweep?"
   // "does any lane of MY robot (16-lane row) see b?" from the wave mask of the compare
   __device__ __forceinline__ bool robot_any(bool b) const {

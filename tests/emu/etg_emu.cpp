@@ -61,6 +61,7 @@ struct EmuCtxBase {
   }
   B4 lane_is(int j) const { B4 r; for (int l = 0; l < 4; l++) r.v[l] = (l == j); return r; }
   bool any(B4 b) const { return b.v[0] || b.v[1] || b.v[2] || b.v[3]; }
+  unsigned uniform_bits(unsigned v) const { return v; }
   int uniform_int(F4 a) const { return (int)a.v[0]; }
   void terrain(const KCfg& K, F4 x, F4 y, F4& h, F4& nx, F4& ny, F4& nz) const {
     for (int l = 0; l < 4; l++) {
@@ -110,6 +111,7 @@ struct EmuCtx16Base {
   B16 sub_is(int j) const { B16 o; for (int r = 0; r < 16; r++) o.v[r] = sub(r) == j; return o; }
   B16 leg_is(int j) const { B16 o; for (int r = 0; r < 16; r++) o.v[r] = leg(r) == j; return o; }
   bool any(B16 b) const { for (int r = 0; r < 16; r++) if (b.v[r]) return true; return false; }
+  unsigned uniform_bits(unsigned v) const { return v; }
   int uniform_int(F16 a) const { return (int)a.v[0]; }
   F16 par(int k) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = parp[(size_t)k * NL() + col(r)]; return o; }
   F16 par_link(int k) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = sub(r) < 3 ? parp[(size_t)(PR_LINK + 10 * sub(r) + k) * NL() + col(r)] : 0.f; return o; }
