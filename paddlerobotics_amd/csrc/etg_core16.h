@@ -422,10 +422,11 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   // physics_tick states it): per sweep (1) the joint-limit rows, (2) the NORMAL rows of the four feet FR, FL, RR, RL, then the
   // body rows, (3) the friction rows of the four feet.  The owner lane's candidate is broadcast over the row with
   // row_newbcast and applied by every lane.
-  // The sweeps read their per-lane constants through `iAe`, `c0e`, `mue`: under the residual stopping rule a robot that has
-  // converged is FROZEN for the sweeps the other robots of its wave still need -- iAe = c0e = 0 make every candidate equal
-  // the current impulse (all deltas exact zeros), mue = 1e30 makes the cone projection the identity -- so a robot's result
-  // does not depend on its wave neighbours (batch invariance) and equals the oracle's, which stops per robot.
+  // Under the residual stopping rule a robot that has converged is FROZEN for the sweeps the other robots of its wave still
+  // need, so its result does not depend on its wave neighbours (batch invariance) and equals the oracle's, which stops per
+  // robot.  The default does it lazily (sweep_and_test below: sweep on, then put the values at convergence back); the sweeps
+  // still read their per-lane constants through `iAe`, `c0e`, `mue` for the ETG_EAGER_FREEZE build variant, which zeroes them
+  // instead (iAe = c0e = 0: every candidate equals the current impulse; mue = 1e30: the cone projection is the identity).
   F iAe = iA, c0e = tgt * iA, mue = tp.mu;
   const F tangf = f1 + f2;
   // owner masks of the three rows of every leg, hoisted out of the sweeps (1 on the lane that owns row e of leg lp)

@@ -48,7 +48,7 @@ struct GpuCtx {
   __device__ __forceinline__ void ring_fence() const {}
   // phase boundary: keep the machine scheduler from interleaving whole phases of the tick
   // (it otherwise stretches live ranges to >500 registers and spills)
-  __device__ __forceinline__ void phase(int id) const {
+  __device__ __forceinline__ void phase([[maybe_unused]] int id) const {
     __builtin_amdgcn_sched_barrier(0);
 #ifdef ETG_PROFILE_PHASES  // tools/phase_profile.py: per-phase s_memtime deltas of one wave
     long long t = clock64();
@@ -697,7 +697,7 @@ struct GpuCtx16 {
   __device__ __forceinline__ void st_row_leg(float* p, int rowlen, int col0, float v) const { if (sub == 0) p[(size_t)(env - row_base) * rowlen + col0 + leg] = v; }
   __device__ __forceinline__ void st_row_env(float* p, int rowlen, int c_, float v) const { if (r == 0) p[(size_t)(env - row_base) * rowlen + c_] = v; }
   __device__ __forceinline__ float ld_row_env(const float* p, int rowlen, int c_) const { return p[(size_t)(env - row_base) * rowlen + c_]; }
-  __device__ __forceinline__ void phase(int id) const {
+  __device__ __forceinline__ void phase([[maybe_unused]] int id) const {
 #ifndef ETG_NO_PHASE_BARRIER16
     __builtin_amdgcn_sched_barrier(0);
 #endif
