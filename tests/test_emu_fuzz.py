@@ -1,0 +1,105 @@
+"""CPU suite: a differential fuzz of the KERNEL SOURCE (tests/emu: etg_core.h / etg_core16.h compiled for the host) against the
+oracle -- random combinations of the robot-layer, solver and terrain options, both lane mappings, per-robot ETG parameters,
+dynamic rows, strength ratios, pushes and start offsets.  The GPU counterpart (tools/fuzz_parity.py, tests/test_gpu_fuzz.py)
+adds what only the device has (the keyword -> EtgConfig mapping of make_env, hardware rcp / rsq, the fused kernels); this one
+runs wherever the CPU suite runs, so a logic slip in an option combination shows before the code reaches a GPU.
+
+A robot passes when its emulation-vs-fp64-oracle joint gap is within the trajectory's own fp32 sensitivity (4 x the fp32
+oracle's gap + a floor); a trial passes when 90 % of its robots do (60 % on a heightfield, where fp32 evaluations share a
+trajectory on ~45 % of the spots) and the median gap is small."""
+import numpy as np
+import pytest
+
+from paddlerobotics_amd import a1_model as A
+
+
+def _draw(rng):
+    kw = {}
+    lanes = int(rng.choice([16, 4]))
+    mode = int(rng.choice([0, 0, 0, 1, 2]))
+    if mode:
+        kw["motor_mode"] = mode
+    if rng.random() < 0.25: kw["enable_action_filter"] = True
+    if rng.random() < 0.25: kw["enable_action_interp"] = True
+    if mode == 0 and rng.random() < 0.25: kw["clip_motor_commands"] = 0.2
+    bc = int(rng.choice([0, 0, 0, 1, 2, 3]))
+    if bc == 3 and lanes == 16: bc = 2
+    if bc: kw["body_contacts"] = bc
+    if rng.random() < 0.3: kw["joint_limits"] = 0
+    if rng.random() < 0.3: kw["friction_model"] = 1
+    s = rng.random()
+    if s < 0.2: kw["solver_iters"] = int(rng.integers(2, 6))
+    elif s < 0.35: kw["solver_residual"] = 1e-5
+    if rng.random() < 0.3: kw["pd_latency"] = float(rng.choice([0.0005, 0.001, 0.002]))
+    if rng.random() < 0.2: kw.update(warmstart=0.85, warmstart_friction=float(rng.choice([0.0, 0.85])))
+    if rng.random() < 0.15: kw["contact_slop"] = 0.0
+    if rng.random() < 0.2: kw["foot_restitution"] = float(rng.uniform(0.1, 0.8))
+    if rng.random() < 0.25: kw["torque_limit"] = float(rng.uniform(8.0, 30.0))
+    if rng.random() < 0.2: kw["enable_etg"] = 0
+    hf = None
+    if rng.random() < 0.3:
+        hf = dict(heights=rng.uniform(0.0, 0.04, size=(64, 64)).astype(np.float32), cell=0.05, origin=(-1.6, -1.6))
+        kw.update(terrain=1, heightfield=hf)
+    ex = dict(dyn=rng.random() < 0.5, strength=rng.random() < 0.3, push=rng.random() < 0.3, offsets=rng.random() < 0.25)
+    if ex["dyn"] and kw.get("pd_latency", 0.0) > 0.001:
+        kw["pd_latency"] = 0.001          # (random kd on lighter links: the delayed damping term goes unstable earlier)
+    return lanes, kw, hf, ex
+
+
+@pytest.mark.parametrize("block", range(8))
+def test_kernel_source_matches_the_oracle_under_random_option_combinations(block):
+    import torch
+    from oracle.oracle import OracleSim
+    from tests.emu.emu import EmuSim
+    from tests.test_terrain_and_randomisation import _params
+    n, steps = 8, 6
+    for trial in range(10 * block, 10 * block + 10):
+        rng = np.random.default_rng(4000 + trial)
+        lanes, kw, hf, ex = _draw(rng)
+        cfg = A.default_config(n, **kw)
+        sims = [OracleSim(cfg, dtype=np.float64), OracleSim(cfg, dtype=np.float32), EmuSim(cfg, lanes=lanes)]
+        mode = kw.get("motor_mode", 0)
+        W = B = None
+        if kw.get("enable_etg", 1):
+            W, B = _params(n, seed=trial)
+        rows = sr = f = offs = None
+        if ex["dyn"]:
+            p = torch.as_tensor(rng.uniform(-0.3, 0.3, size=(n, A.DYN_DIM)), dtype=torch.float32)
+            rows = A.param2dynamic_rows_torch(p).numpy().astype(np.float64)
+            rows[:, 1] = np.maximum(rows[:, 1], 0.05)
+        if ex["strength"]: sr = rng.uniform(0.5, 1.0, size=(n, 12))
+        if ex["offsets"]: offs = rng.uniform(-0.3, 0.3, size=(n, 2))
+        if ex["push"]:
+            f = np.zeros((n, 3)); f[:, :2] = rng.uniform(-15, 15, size=(n, 2))
+        for s in sims:
+            if hf is not None: s.set_heightfield(hf["heights"])
+            if W is not None: s.set_params(etg_w=W, etg_b=B)
+            if rows is not None: s.set_params(dyn=rows)
+            if sr is not None: s.set_motor_strength(sr)
+            if offs is not None: s.set_reset_offsets(offs)
+            s.reset()
+            if f is not None: s.set_external_force(f)
+        loose = max(1.0, float(np.sqrt(cfg.solver_residual / 1e-7)))
+        need = 0.6 if hf is not None else 0.9
+        r0 = np.abs(sims[2].get_state() - sims[0].get_state())[:, :25].max(1)
+        r032 = np.abs(sims[1].get_state() - sims[0].get_state())[:, :25].max(1)
+        assert np.mean(r0 <= 2e-3 * loose + 4.0 * r032) >= need, (trial, lanes, kw.keys(), ex, r0, r032)
+        eg, e32 = np.zeros(n), np.zeros(n)
+        for k in range(4 if mode == 1 else steps):
+            if mode == 2:
+                a = rng.uniform(-1, 1, size=(n, 12, 5))
+                a[..., 0] = np.array([0.0, 0.9, -1.8] * 4) + 0.15 * a[..., 0]; a[..., 1] = 80.0; a[..., 2] = 0.0; a[..., 3] = 1.5; a[..., 4] *= 2.0
+                a = a.reshape(n, 60)
+            elif mode == 1:
+                a = rng.uniform(-4.0, 4.0, size=(n, 12))
+            else:
+                a = rng.uniform(-0.2, 0.2, size=(n, 12))
+            outs = [s.step(a.astype(np.float32) if i == 2 else a) for i, s in enumerate(sims)]
+            so, s3, se = sims[0].get_state(), sims[1].get_state(), sims[2].get_state()
+            eg = np.maximum(eg, np.abs(se - so)[:, 13:25].max(1))
+            e32 = np.maximum(e32, np.abs(s3 - so)[:, 13:25].max(1))
+        frac = float(np.mean(eg <= 1e-4 * loose + 4.0 * e32))
+        what = (trial, lanes, sorted(kw.keys() - {"heightfield"}), {k: v for k, v in ex.items() if v}, np.median(eg), eg.max(), np.median(e32), e32.max())
+        assert np.isfinite(se).all(), what
+        assert frac >= need, what
+        assert np.median(eg) < max(5e-5 * loose, 4.0 * np.median(e32)), what
