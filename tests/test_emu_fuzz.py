@@ -85,6 +85,7 @@ def test_kernel_source_matches_the_oracle_under_random_option_combinations(block
         r032 = np.abs(sims[1].get_state() - sims[0].get_state())[:, :25].max(1)
         assert np.mean(r0 <= 2e-3 * loose + 4.0 * r032) >= need, (trial, lanes, kw.keys(), ex, r0, r032)
         eg, e32 = np.zeros(n), np.zeros(n)
+        eobs, erew, dmis = 0.0, 0.0, 0
         for k in range(4 if mode == 1 else steps):
             if mode == 2:
                 a = rng.uniform(-1, 1, size=(n, 12, 5))
@@ -98,8 +99,15 @@ def test_kernel_source_matches_the_oracle_under_random_option_combinations(block
             so, s3, se = sims[0].get_state(), sims[1].get_state(), sims[2].get_state()
             eg = np.maximum(eg, np.abs(se - so)[:, 13:25].max(1))
             e32 = np.maximum(e32, np.abs(s3 - so)[:, 13:25].max(1))
+            good = np.abs(se - so)[:, 13:25].max(1) <= 1e-4 * loose + 4.0 * np.abs(s3 - so)[:, 13:25].max(1)
+            if good.any():      # the observation row, the reward and the done flag of the robots that are on the oracle's trajectory
+                eobs = max(eobs, float(np.median(np.abs(np.asarray(outs[2][0]) - np.asarray(outs[0][0]))[good].max(1))))
+                erew = max(erew, float(np.median(np.abs(np.asarray(outs[2][1]) - np.asarray(outs[0][1]))[good])))
+                dmis += int((np.asarray(outs[2][2]).astype(bool) != np.asarray(outs[0][2]).astype(bool))[good].sum())
         frac = float(np.mean(eg <= 1e-4 * loose + 4.0 * e32))
         what = (trial, lanes, sorted(kw.keys() - {"heightfield"}), {k: v for k, v in ex.items() if v}, np.median(eg), eg.max(), np.median(e32), e32.max())
         assert np.isfinite(se).all(), what
         assert frac >= need, what
         assert np.median(eg) < max(5e-5 * loose, 4.0 * np.median(e32)), what
+        assert eobs < max(5e-3, 300 * np.median(eg)) and erew < max(5e-3, 300 * np.median(eg)), (what, eobs, erew)   # (velocity columns: ~100 x the angle gap)
+        assert dmis <= 1, (what, dmis)
