@@ -41,6 +41,8 @@ def _draw(rng):
         hf = dict(heights=rng.uniform(0.0, 0.04, size=(64, 64)).astype(np.float32), cell=0.05, origin=(-1.6, -1.6))
         kw.update(terrain=1, heightfield=hf)
     ex = dict(dyn=rng.random() < 0.5, strength=rng.random() < 0.3, push=rng.random() < 0.3, offsets=rng.random() < 0.25)
+    if hf is not None:
+        ex["offsets"] = True              # (identical robots on ONE spot make a terrain trial all-or-nothing: spread them)
     if ex["dyn"] and kw.get("pd_latency", 0.0) > 0.001:
         kw["pd_latency"] = 0.001          # (random kd on lighter links: the delayed damping term goes unstable earlier)
     return lanes, kw, hf, ex
@@ -108,6 +110,9 @@ def test_kernel_source_matches_the_oracle_under_random_option_combinations(block
         what = (trial, lanes, sorted(kw.keys() - {"heightfield"}), {k: v for k, v in ex.items() if v}, np.median(eg), eg.max(), np.median(e32), e32.max())
         assert np.isfinite(se).all(), what
         assert frac >= need, what
-        assert np.median(eg) < max(5e-5 * loose, 4.0 * np.median(e32)), what
+        # (on a terrain up to half of a handful of spread robots may be on a sensitive spot: the lower quartile stands for "the
+        # robots that are on the oracle's trajectory are ON it" there; a wrong kernel moves every robot)
+        mid = (lambda x: np.percentile(x, 25)) if hf is not None else np.median
+        assert mid(eg) < max(5e-5 * loose, 4.0 * mid(e32)), what
         assert eobs < max(5e-3, 300 * np.median(eg)) and erew < max(5e-3, 300 * np.median(eg)), (what, eobs, erew)   # (velocity columns: ~100 x the angle gap)
         assert dmis <= 1, (what, dmis)
