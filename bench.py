@@ -76,13 +76,14 @@ def device_copy_bandwidth(dev, nbytes=1 << 30, reps=5):
     return 2.0 * nbytes * reps / (e0.elapsed_time(e1) * 1e-3)
 
 
-def cpu_baseline(n_envs, steps, threads, solver=None, hist=None, heightfield=None):
+def cpu_baseline(n_envs, steps, threads, solver=None, hist=None, heightfield=None, body_contacts=2):
     """The CPU oracle (port of the path, fp64 like stock pybullet) on a bounded sample, with the SAME contact-solver rule as
     the GPU leg it stands next to.  Persistent workers: every thread runs its slice of the robots through ALL the steps
     (etgo_run_steps), so no thread is spawned or joined per step.  hist (a list): receives the sample's sweep histogram."""
     from oracle.oracle import OracleSim
     it, res = solver if solver is not None else SOLVER
-    cfg = A.default_config(n_envs, solver_iters=it, solver_residual=res, terrain=1 if heightfield else 0, heightfield=heightfield)
+    cfg = A.default_config(n_envs, solver_iters=it, solver_residual=res, terrain=1 if heightfield else 0, heightfield=heightfield,
+                           body_contacts=body_contacts)
     sim = OracleSim(cfg, threads=threads)
     if heightfield:
         sim.set_heightfield(heightfield["heights"])
@@ -200,7 +201,11 @@ def main():
                     help="squared velocity-level row residual at which a tick stops sweeping (default 1e-7; 0 = fixed count)")
     ap.add_argument("--lanes", type=int, default=0, choices=(0, 4, 16),
                     help="kernel mapping, lanes per robot (0 = library default: 16 up to 4096 robots, else 4)")
-    ap.add_argument("--body-contacts", action="store_true", help="knee spheres collide too (one frictionless body row per leg, both mappings)")
+    ap.add_argument("--body-contacts", type=int, default=2, choices=(0, 1, 2),
+                    help="link shapes that collide besides the toe spheres (EtgConfig.body_contacts; default 2 = the library default: one "
+                         "contact per leg, with friction, on the deepest of knee / shin midpoint / trunk corner; 0 = toe spheres only)")
+    ap.add_argument("--foot-friction", type=float, default=None,
+                    help="foot friction coefficient of every robot (default: param2dynamic_dict(zeros) = 0.2, on which the open-loop gait skates)")
     ap.add_argument("--no-joint-limits", dest="joint_limits", action="store_false",
                     help="switch the joint-limit stops (a1.py:186-195; on by default, as Bullet enforces the URDF's) off")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -256,6 +261,11 @@ def main():
     env = make_env("Quadrupedal", **solver_kw, **env_kw)
     lanes = env.lanes_per_robot
     w, b = etg_population(N, seed=rank, device=dev)
+    dyn_row = None
+    if args.foot_friction is not None:
+        row = A.default_dynamic_row().copy()
+        row[1] = args.foot_friction
+        dyn_row = torch.as_tensor(np.tile(row, (N, 1)), dtype=torch.float32, device=dev)
 
     def make_policy():
         p = MfmaPolicy(A.OBS_DIM, 12, device=str(dev))
@@ -296,7 +306,7 @@ def main():
         wall_local.clear()
         surv = float("nan")
         for _ in range(repeats):
-            e.reset(ETG_w=w, ETG_b=b)
+            e.reset(ETG_w=w, ETG_b=b, **({} if dyn_row is None else {'dynamic_param': dyn_row}))
             run_steps(e, pol, args.warmup, fused)
             # the reset and a short warm-up leave the GPU mostly idle for a millisecond or more and its clocks drop: a timed
             # region of K = 20 steps (0.8 ms) then runs 14 % slower than the same steps inside a long run.  Keep the chip
@@ -393,12 +403,12 @@ def main():
                 extra["solver_iters_%d" % kfix] = leg(envk, None, True, "the same fused rollout with exactly %d PGS sweeps per tick "
                                                       "(no residual test)" % kfix, reps=reps)
                 envk.close()
-            if not args.body_contacts:
-                # the model option the headline leaves off: body spheres collide too (deepest of knee / shin / trunk corner per leg)
-                kwf = dict(env_kw, body_contacts=2)
+            if args.body_contacts:
+                # rounds 1-4's model for continuity: only the toe spheres collide (shins and trunk pass through the floor)
+                kwf = dict(env_kw, body_contacts=0)
                 envf = make_env("Quadrupedal", **solver_kw, **kwf)
-                extra["body_contacts"] = leg(envf, None, True, "the same fused rollout with body_contacts = 2 (one frictionless row per leg on "
-                                             "the deepest of knee / shin midpoint / trunk corner spheres) switched on")
+                extra["toe_spheres_only"] = leg(envf, None, True, "the same fused rollout with body_contacts = 0: the headline model of rounds "
+                                                "1-4 (no body rows; the robots sink instead of kneeling)")
                 envf.close()
         if args.config == 2:
             pol3 = make_policy()
@@ -482,7 +492,7 @@ def main():
                                                "contact_slop": env.cfg.contact_slop, "erp": env.cfg.erp, "contact_margin": env.cfg.contact_margin,
                                                "joint_limits": "unilateral rows inside the sweeps", "source": "DESIGN.md section 2 (pybullet's server settings)"}},
                        "solver_iters": SOLVER[0], "lanes_per_robot": lanes,
-                       "body_contacts": bool(args.body_contacts), "joint_limits": bool(args.joint_limits),   # (the stops are on by default)
+                       "body_contacts": int(args.body_contacts), "body_friction": env.cfg.body_friction, "foot_friction": args.foot_friction if args.foot_friction is not None else 0.2, "joint_limits": bool(args.joint_limits),   # (the stops are on by default)
                        "auto_reset": False, "parallelism": "env-shard x%d" % world,
                        "world_size_reported_by": ("torch.distributed/" + dist.get_backend()) if dist is not None else "single process"},
             "timing": {"repeats": repeats, "value_is": "median repeat", "ms_per_step_min": min(wall) / K * 1e3,
@@ -558,13 +568,13 @@ def main():
             logical = os.cpu_count() or 1
             affinity, quota = usable_cpus()
             hf_cpu = terrain_kw.get("heightfield")
-            one = cpu_baseline(64, 60, 1, heightfield=hf_cpu)
+            one = cpu_baseline(64, 60, 1, heightfield=hf_cpu, body_contacts=args.body_contacts)
             # the box reports `logical` CPUs, but a container may be allowed fewer (affinity mask / cgroup quota): probe the
             # thread count instead of trusting cpu_count(), and report the best figure with the threads that produced it
             n_all, s_all = max(64, 16 * logical), 50
             cand = sorted({t for t in (logical, affinity, int(quota) if quota else 0, 128, 64, 32, 16) if 1 <= t <= logical}, reverse=True)
             hist = []
-            probe = {t: cpu_baseline(n_all, s_all, t, hist=hist, heightfield=hf_cpu) for t in cand}
+            probe = {t: cpu_baseline(n_all, s_all, t, hist=hist, heightfield=hf_cpu, body_contacts=args.body_contacts) for t in cand}
             cores = max(probe, key=probe.get)
             allc = probe[cores]
             out["cpu_baseline"] = {"value": allc, "unit": "env-steps/s", "cores": cores, "kind": "port",
@@ -584,7 +594,8 @@ def main():
             for kfix in (50, 2):
                 key = "solver_iters_%d" % kfix
                 if key in out:
-                    v = cpu_baseline(n_all if kfix == 2 else max(64, n_all // 4), s_all, cores, solver=(kfix, 0.0), heightfield=hf_cpu)
+                    v = cpu_baseline(n_all if kfix == 2 else max(64, n_all // 4), s_all, cores, solver=(kfix, 0.0), heightfield=hf_cpu,
+                                     body_contacts=args.body_contacts)
                     out[key]["cpu_baseline"] = {"value": v, "unit": "env-steps/s", "cores": cores, "kind": "port"}
                     out[key]["gpu_over_cpu"] = out[key]["value"] / v
             # the reference's real engine, if this box happens to have it; never expected here

@@ -155,16 +155,16 @@ typedef struct EtgConfig {
    * [-pi, pi], without the sensor noise the reference adds to every reading.  0 = off (the default of the reference's
    * constructor).                                                                                      */
   double clip_motor_commands;
-  /* knee contacts (Bullet collides every link shape; here, besides the four foot spheres): when
-   * != 0, a sphere of knee_radius at every knee (the calf joint origin, attached to the thigh) collides with the
-   * ground through one frictionless normal row per leg, solved in the same projected Gauss-Seidel sweep right
-   * after the leg's foot rows. Served by both lane mappings, flat ground and heightfield: on the 16-lanes-per-robot
-   * kernels the free 4th lane of every leg owns the row, on the 4-lanes-per-robot ones it is a 4th row of the leg's lane. */
-  int32_t body_contacts;   /* 0 off; 1 the knee sphere; 2 the DEEPEST of three spheres of knee_radius per leg: knee, shin midpoint
-                            * (carried by the calf), trunk corner next to the leg's hip (trunk_half below) -- still one
-                            * frictionless row per leg; 3 all three spheres of every leg at once, a row each (24 rows per
-                            * robot; served by the 4-lanes-per-robot mapping, which the setting selects; the fused
-                            * closed-loop call is not available with it)                                            */
+  /* body contacts (Bullet collides every link's URDF shape with the ground, a1.py:276-287; here spheres of
+   * knee_radius stand in for the link shapes, besides the four foot spheres).  Served by both lane mappings, flat ground and
+   * heightfield.  default_config / make_env switch mode 2 ON (the reference's robot cannot pass its shins through the floor). */
+  int32_t body_contacts;   /* 0 off (toe spheres only); 1 one contact per leg on a sphere at the knee (the calf joint origin,
+                            * carried by the thigh); 2 one contact per leg on the DEEPEST of three spheres: knee, shin midpoint
+                            * (carried by the calf), trunk corner next to the leg's hip (trunk_half below).  A contact of modes
+                            * 1 / 2 has a normal row and two friction rows (body_friction) like a foot's, solved after the feet's
+                            * rows of the same kind; not warm-started.  3 all three spheres of every leg at once, a FRICTIONLESS
+                            * normal row each (24 contact rows per robot; served by the 4-lanes-per-robot mapping, which the
+                            * setting selects; the fused closed-loop call is not available with it)                      */
   double knee_radius;
   /* `ETG` kwarg of make_env (train.py:305-309, Dynamic_parallel_model.py:49 runs with ETG=0): 0 switches the
    * trajectory generator off -- the position command is pose_ori + action, info["ETG_act"] and the ETG
@@ -208,6 +208,11 @@ typedef struct EtgConfig {
    * when a foot approaches the ground faster than Bullet's restitution velocity threshold (0.2 m/s) at the start of a tick,
    * its normal row's velocity target is raised by restitution x the approach speed.                                   */
   double foot_restitution;
+  /* Friction coefficient of the body contacts of body_contacts 1 / 2 (their two friction rows are solved like a foot's, on the
+   * disc body_friction x the contact's normal impulse; friction_model 1: the pyramid).  Bullet: the product of the two bodies'
+   * lateralFriction -- 0.5 for a URDF link without a <contact> element (btCollisionObject's default; the reference only ever
+   * changes the FEET's, minitaur.py:1100-1110) x the ground's 1.0 = 0.5, the default of default_config.  0 = frictionless. */
+  double body_friction;
 } EtgConfig;
 
 typedef struct EtgHandle EtgHandle;

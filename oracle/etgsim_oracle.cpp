@@ -303,6 +303,7 @@ template <class T> struct Env {
   T energy;
   long long sweep_hist[64];   // ticks by the number of PGS sweeps they ran since etgo_create (etgo_sweep_hist)
   long long sweeps_total;     // all sweeps so far; step_env reports the step's share in info[ETG_INFO_SWEEPS]
+  long long body_ticks[3];    // ticks with a body row inside the margin / with a loaded body row (normal impulse > 0) / all ticks (etgo_body_stats)
 };
 
 template <class T> struct Sim {
@@ -556,15 +557,16 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
     mat3_mul_vec(Rw[p], Xup[i].r, o);
     for (int k = 0; k < 3; k++) pw[i][k] = pw[p][k] + o[k];
   }
-  // rows 0..11: feet (n, t1, t2 per leg); then the frictionless body rows (cfg.body_contacts): one per leg (rows 12..15) for
-  // body_contacts 1 / 2, three per leg (rows 12 + 3 l + b: knee, shin midpoint, trunk corner) for body_contacts 3
-  // then 12 joint-limit rows (cfg.joint_limits), one per joint, row NRC + j
+  // rows 0..11: feet (n, t1, t2 per leg); rows 12 + 3 l + b: the body rows of leg l (cfg.body_contacts) -- for body_contacts 1 / 2
+  // ONE contact per leg with its normal and two friction rows (b = n, t1, t2), for body_contacts 3 three frictionless normal
+  // rows (b = knee, shin midpoint, trunk corner); then 12 joint-limit rows (cfg.joint_limits), one per joint, row NRC + j
   constexpr int NRMAX = 36;
   const bool all_bodies = s.cfg.body_contacts == 3;
-  const int NRC = all_bodies ? 24 : 16;                    // contact rows
+  const bool body_fric = s.cfg.body_contacts == 1 || s.cfg.body_contacts == 2;   // the leg's body contact has friction rows
+  const int NRC = 24;                                      // contact rows
   const int NR = NRC + 12;
-  const int NBR = all_bodies ? 3 : 1;                      // body rows per leg
-  auto body_row = [&](int l, int b) { return all_bodies ? 12 + 3 * l + b : 12 + l; };
+  const int NBR = all_bodies ? 3 : 1;                      // body contact points per leg
+  auto body_row = [&](int l, int b) { return 12 + 3 * l + b; };
   T J[NRMAX][NV];
   T target[NRMAX];
   int active[4], kactive[NRMAX];                            // kactive / klam: indexed by row
@@ -632,10 +634,16 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
     e.lam[3 * l] *= T(s.cfg.warmstart);
     for (int k = 1; k < 3; k++) e.lam[3 * l + k] *= T(s.cfg.warmstart_friction);
   }
-  // body contacts (cfg.body_contacts): frictionless rows on spheres of knee_radius.  1: one row per leg on a sphere at the knee
-  // (the calf joint origin, carried by the thigh: the calf joint does not move it).  2: one row per leg on the DEEPEST of three
+  // body contacts (cfg.body_contacts): spheres of knee_radius standing in for the link shapes Bullet collides (a1.py:276-287 loads
+  // the URDF with every link's collision shape; no self-collision).  1: one contact per leg on a sphere at the knee (the calf
+  // joint origin, carried by the thigh: the calf joint does not move it).  2: one contact per leg on the DEEPEST of three
   // spheres -- knee, shin midpoint (carried by the calf), trunk corner next to the leg's hip (carried by the base: no joint
-  // moves it).  3: all three spheres of every leg collide at once, a row each (solved in that order after the leg's foot rows).
+  // moves it).  A contact of modes 1 / 2 has a normal row and two friction rows like a foot's (Bullet gives every contact point
+  // friction), with the coefficient cfg.body_friction (the product of the link's and the ground's lateralFriction: only the
+  // FEET's is ever changed by the reference, minitaur.py:1100-1110).  3: all three spheres of every leg collide at once, a
+  // frictionless normal row each (solved in that order).  Body rows are not warm-started: the deepest-of-three point changes
+  // identity from tick to tick, so no contact point persists the way a Bullet manifold point does.
+  bool any_margin = false;
   for (int l = 0; l < 4; l++) {
     if (!s.cfg.body_contacts) continue;
     const int c = 3 + 3 * l;
@@ -673,22 +681,36 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
       const int rk = body_row(l, b);
       const T phi = cphi[pick];
       const T* n = cn[pick];
-      kactive[rk] = phi < T(s.cfg.contact_margin);
-      if (!kactive[rk]) continue;
-      T cp[3], rel[3], rxd[3], tmp[3];
+      const bool on = phi < T(s.cfg.contact_margin);
+      kactive[rk] = on;
+      if (body_fric) kactive[rk + 1] = kactive[rk + 2] = on;
+      if (!on) continue;
+      any_margin = true;
+      T cp[3], rel[3];
       for (int k = 0; k < 3; k++) { cp[k] = cand[pick].p[k] - krad * n[k]; rel[k] = cp[k] - e.pos[k]; }
-      T* row = J[rk];
-      cross(rel, n, rxd);
-      mat3T_mul_vec(R, rxd, tmp);
-      for (int k = 0; k < 3; k++) row[k] = tmp[k];
-      mat3T_mul_vec(R, n, tmp);
-      for (int k = 0; k < 3; k++) row[3 + k] = tmp[k];
-      for (int bd = cand[pick].first_body; bd > 0; bd = s.parent[bd]) {  // the joints that move the point
-        T axw[3] = {Rw[bd][0][s.axis[bd]], Rw[bd][1][s.axis[bd]], Rw[bd][2][s.axis[bd]]};
-        T rj[3], cr[3];
-        for (int k = 0; k < 3; k++) rj[k] = cp[k] - pw[bd][k];
-        cross(axw, rj, cr);
-        row[5 + bd] = dot3(n, cr);
+      // contact frame as for a foot: n, t1 = normalised projection of world x, t2 = n x t1
+      T t1[3] = {1 - n[0] * n[0], -n[0] * n[1], -n[0] * n[2]};
+      T inv = T(1) / std::sqrt(dot3(t1, t1));
+      for (int k = 0; k < 3; k++) t1[k] *= inv;
+      T t2[3];
+      cross(n, t1, t2);
+      const T* dirs[3] = {n, t1, t2};
+      for (int r = 0; r < (body_fric ? 3 : 1); r++) {
+        const T* d = dirs[r];
+        T* row = J[rk + r];
+        T rxd[3], tmp[3];
+        cross(rel, d, rxd);
+        mat3T_mul_vec(R, rxd, tmp);
+        for (int k = 0; k < 3; k++) row[k] = tmp[k];
+        mat3T_mul_vec(R, d, tmp);
+        for (int k = 0; k < 3; k++) row[3 + k] = tmp[k];
+        for (int bd = cand[pick].first_body; bd > 0; bd = s.parent[bd]) {  // the joints that move the point
+          T axw[3] = {Rw[bd][0][s.axis[bd]], Rw[bd][1][s.axis[bd]], Rw[bd][2][s.axis[bd]]};
+          T rj[3], cr[3];
+          for (int k = 0; k < 3; k++) rj[k] = cp[k] - pw[bd][k];
+          cross(axw, rj, cr);
+          row[5 + bd] = dot3(d, cr);
+        }
       }
       const T pen = phi + T(s.cfg.contact_slop);
       target[rk] = (pen > 0) ? -pen / dt : -T(s.cfg.erp) * pen / dt;
@@ -767,19 +789,12 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
     for (int l = 0; l < 4; l++)
       for (int b = 0; b < NBR; b++)
         if (kactive[body_row(l, b)]) unilateral(body_row(l, b));
-    for (int l = 0; l < 4; l++) {
-      if (!active[l]) continue;
-      const int r0 = 3 * l;
-      const T ln = e.lam[r0];
-      // Bullet solves a contact's friction rows only while its normal impulse is positive (`if (totalImpulse > 0)`): a foot
-      // whose normal impulse is zero keeps the friction impulses it has
-      if (!(ln > 0)) continue;
-      // both candidates from the SAME velocities, the pair projected on the friction disc mu ln, then both changes applied:
-      // the implicit cone friction of pybullet's default (resolveConeFrictionConstraintRows; enableConeFriction = 1).
-      // friction_model 1: each direction clamped on its own to +-mu ln (the pyramid of enableConeFriction = 0).
-      T lim = e.mu * ln;
+    // both candidates from the SAME velocities, the pair projected on the friction disc `lim`, then both changes applied:
+    // the implicit cone friction of pybullet's default (resolveConeFrictionConstraintRows; enableConeFriction = 1).
+    // friction_model 1: each direction clamped on its own to +-lim (the pyramid of enableConeFriction = 0).
+    auto friction_pair = [&](int r0, T lim, T* lamv) {
       T cand[3];
-      for (int k = 1; k < 3; k++) cand[k] = e.lam[r0 + k] - u[r0 + k] / A[r0 + k][r0 + k];
+      for (int k = 1; k < 3; k++) cand[k] = lamv[r0 + k] - u[r0 + k] / A[r0 + k][r0 + k];
       if (pyramid) {
         for (int k = 1; k < 3; k++) {
           if (cand[k] > lim) cand[k] = lim;
@@ -793,9 +808,26 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
         }
       }
       for (int k = 1; k < 3; k++) {
-        apply(r0 + k, cand[k] - e.lam[r0 + k]);
-        e.lam[r0 + k] = cand[k];
+        apply(r0 + k, cand[k] - lamv[r0 + k]);
+        lamv[r0 + k] = cand[k];
       }
+    };
+    for (int l = 0; l < 4; l++) {
+      if (!active[l]) continue;
+      const int r0 = 3 * l;
+      const T ln = e.lam[r0];
+      // Bullet solves a contact's friction rows only while its normal impulse is positive (`if (totalImpulse > 0)`): a foot
+      // whose normal impulse is zero keeps the friction impulses it has
+      if (!(ln > 0)) continue;
+      friction_pair(r0, e.mu * ln, e.lam);
+    }
+    // the friction pairs of the body contacts (body_contacts 1 / 2), after the feet's, same rule with cfg.body_friction
+    for (int l = 0; l < 4 && body_fric; l++) {
+      const int r0 = body_row(l, 0);
+      if (!kactive[r0]) continue;
+      const T ln = klam[r0];
+      if (!(ln > 0)) continue;
+      friction_pair(r0, T(s.cfg.body_friction) * ln, klam);
     }
     sweeps++;
     if (res_thr > 0) {
@@ -810,6 +842,12 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
   }
   e.sweep_hist[sweeps < 63 ? sweeps : 63]++;
   e.sweeps_total += sweeps;
+  {
+    bool loaded = false;
+    for (int l = 0; l < 4; l++)
+      for (int b = 0; b < NBR; b++) loaded = loaded || (kactive[body_row(l, b)] && klam[body_row(l, b)] > 0);
+    e.body_ticks[0] += any_margin; e.body_ticks[1] += loaded; e.body_ticks[2] += 1;
+  }
   for (int r = 0; r < NR; r++) {
     if (!row_active(r)) continue;
     for (int k = 0; k < NV; k++) vel[k] += MiJt[r][k] * lam_of(r);
@@ -1378,6 +1416,12 @@ template <class F> void par_for(int n, int threads, F f) {
       if (mask && !mask[i]) continue;                                                               \
       for (int k = 0; k < 64; k++) { out[k] += s->env[i].sweep_hist[k]; if (clear) s->env[i].sweep_hist[k] = 0; } \
     }                                                                                               \
+  }                                                                                                 \
+  /* out[N][3]: per robot, ticks with a body row inside the margin / with a loaded body row / all ticks; clear != 0 zeroes them */ \
+  extern "C" void etgo_body_stats##SFX(void* h, long long* out, int clear) {                        \
+    auto* s = (Sim<T>*)h;                                                                           \
+    for (int i = 0; i < s->N; i++)                                                                  \
+      for (int k = 0; k < 3; k++) { out[3 * i + k] = s->env[i].body_ticks[k]; if (clear) s->env[i].body_ticks[k] = 0; } \
   }                                                                                                 \
   extern "C" void etgo_get_lambda##SFX(void* h, T* lam) {                                           \
     auto* s = (Sim<T>*)h;                                                                           \

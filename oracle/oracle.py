@@ -155,6 +155,12 @@ class OracleSim:
         self._f("sweep_hist")(self._h, _p(out), _p(mask), int(bool(clear)))
         return out
 
+    def body_stats(self, clear=True):
+        """per robot: ticks with a body row inside the margin, ticks with a loaded body row, all ticks -> int64[N,3]"""
+        out = np.zeros((self.N, 3), dtype=np.int64)
+        self._f("body_stats")(self._h, _p(out), int(bool(clear)))
+        return out
+
     def get_state(self):
         st = np.zeros((self.N, A.STATE_DIM), dtype=self.dtype)
         self._f("get_state")(self._h, _p(st))

@@ -481,18 +481,23 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   F actf = sel_(act, one, zero);
   V rc = pf - F(K.foot_radius) * dn;
   V k1 = cross(xax, rc - o1), k2 = cross(yax, rc - o2), k3 = cross(yax, rc - o3);
-  // ---- body rows (EtgConfig.body_contacts; the instantiations with Ctx::kBody > 0): frictionless rows of this leg on spheres
-  // of knee_radius, solved after the leg's foot rows.  kBody = 1 -- body_contacts 1: a sphere at the knee (calf joint origin,
-  // carried by the thigh: the calf joint does not move it); body_contacts 2: the DEEPEST of knee / shin midpoint (moved by all
-  // three joints) / trunk corner next to this leg's hip (moved by none), ties to the earlier candidate.  kBody = 3 --
-  // body_contacts 3: all three spheres collide at once, a row each, in that order.  Same model as the oracle (no warm start).
+  // ---- body rows (EtgConfig.body_contacts; the instantiations with Ctx::kBody > 0): rows of this leg on spheres of knee_radius,
+  // solved after the feet's rows of the same kind.  kBody = 1 -- ONE contact per leg with a normal row and two friction rows
+  // (rows 3, 4, 5 of the lane): body_contacts 1: a sphere at the knee (calf joint origin, carried by the thigh: the calf joint
+  // does not move it); body_contacts 2: the DEEPEST of knee / shin midpoint (moved by all three joints) / trunk corner next to
+  // this leg's hip (moved by none), ties to the earlier candidate.  kBody = 3 -- body_contacts 3: all three spheres collide at
+  // once, a FRICTIONLESS normal row each (rows 3, 4, 5), in that order.  Same model as the oracle (no warm start).
   constexpr int NB = Ctx::kBody;
   constexpr bool knee = NB > 0;
-  constexpr int NRW = 3 + NB;
-  constexpr int NBA = NB > 0 ? NB : 1;   // array extents (no zero-length arrays)
-  F phib[NBA], actbf[NBA];
-  V dnb[NBA], rcb[NBA], kb1[NBA], kb2[NBA], kb3[NBA];
-  decltype(act) actb[NBA];
+  constexpr bool bfric = NB == 1;              // the leg's one body contact has friction rows
+  constexpr int NP = NB;                       // body contact points per leg
+  constexpr int NBR = bfric ? 3 : NB;          // body rows per leg
+  constexpr int NRW = 3 + NBR;
+  constexpr int NBA = NBR > 0 ? NBR : 1;       // array extents (no zero-length arrays)
+  constexpr int NPA = NP > 0 ? NP : 1;
+  F phib[NPA], actbf[NPA];
+  V dnb[NPA], rcb[NPA], kb1[NPA], kb2[NPA], kb3[NPA], nwb[NPA];
+  decltype(act) actb[NPA];
   if constexpr (knee) {
     // depth of a body point along the terrain normal (without the radius) and the normal there, world frame
     auto depth = [&](const V& q, V& nw) -> F {
@@ -503,8 +508,8 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
       nw = {nwx, nwy, nwz};
       return (w.z - hgt) * nwz;
     };
-    V pbd[NBA], nwb[NBA];
-    F dep[NBA], jm12[NBA], jm3[NBA];
+    V pbd[NPA];
+    F dep[NPA], jm12[NPA], jm3[NPA];
     pbd[0] = o3; jm12[0] = one; jm3[0] = zero;
     dep[0] = depth(pbd[0], nwb[0]);
     if (NB == 3 || K.knee >= 2) {
@@ -531,7 +536,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
       }
     }
 #pragma unroll
-    for (int b = 0; b < NB; b++) {
+    for (int b = 0; b < NP; b++) {
       phib[b] = dep[b] - F(K.knee_radius);
       if (Ctx::kFlat) dnb[b] = Rw.r2;
       else dnb[b] = {Rw.r0.x * nwb[b].x + Rw.r1.x * nwb[b].y + Rw.r2.x * nwb[b].z, Rw.r0.y * nwb[b].x + Rw.r1.y * nwb[b].y + Rw.r2.y * nwb[b].z,
@@ -546,15 +551,30 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   }
   V dir[NRW];
   dir[0] = dn; dir[1] = d1; dir[2] = d2;
+  if constexpr (bfric) {
+    // the body contact's frame, as for a foot: n, t1 = x_w projected on the tangent plane, t2 = n x t1 (flat ground: the foot's)
+    dir[3] = dnb[0];
+    if (Ctx::kFlat) { dir[4] = d1; dir[5] = d2; }
+    else {
+      const V nb = nwb[0];
+      const F it1 = rsqrt_hf_(one - nb.x * nb.x);
+      const V t1w = {it1 * (one - nb.x * nb.x), -(it1 * (nb.x * nb.y)), -(it1 * (nb.x * nb.z))};
+      const F t2y = it1 * nb.z, t2z = -(it1 * nb.y);
+      dir[4] = {Rw.r0.x * t1w.x + Rw.r1.x * t1w.y + Rw.r2.x * t1w.z, Rw.r0.y * t1w.x + Rw.r1.y * t1w.y + Rw.r2.y * t1w.z,
+                Rw.r0.z * t1w.x + Rw.r1.z * t1w.y + Rw.r2.z * t1w.z};
+      dir[5] = {Rw.r1.x * t2y + Rw.r2.x * t2z, Rw.r1.y * t2y + Rw.r2.y * t2z, Rw.r1.z * t2y + Rw.r2.z * t2z};
+    }
+  } else {
 #pragma unroll
-  for (int b = 0; b < NB; b++) dir[3 + b] = dnb[b];
+    for (int b = 0; b < NB; b++) dir[3 + b] = dnb[b];
+  }
   F Jl[NRW][3];   // [row d][joint]
   F HJ[NRW][3];   // H^-1 Jl^T, [row d][joint]
   W Z[NRW];       // D^-1/2 L^-1 G_d
 #pragma unroll
   for (int d = 0; d < NRW; d++) {
     const bool body = d >= 3;
-    const int bi = body ? d - 3 : 0;
+    const int bi = (body && !bfric) ? d - 3 : 0;   // the body POINT of row d (kBody = 1: one point, three rows)
     const F af = body ? actbf[bi] : actf;
     const V rcd = body ? rcb[bi] : rc;
     Jl[d][0] = af * dot(dir[d], body ? kb1[bi] : k1);
@@ -596,7 +616,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   F iA0 = sel_(act, rcp_(Aown[0][0]), zero), iA1 = sel_(act, rcp_(Aown[1][1]), zero), iA2 = sel_(act, rcp_(Aown[2][2]), zero);
   F iAb[NBA];
 #pragma unroll
-  for (int b = 0; b < NB; b++) iAb[b] = sel_(actb[b], rcp_(Aown[3 + b][3 + b]), zero);
+  for (int b = 0; b < NBR; b++) iAb[b] = sel_(actb[bfric ? 0 : b], rcp_(Aown[3 + b][3 + b]), zero);
   c.phase(6);
   // contact-point velocity under the unconstrained motion
   V vc = vbs + cross(wbs, rc) + qds1 * k1 + qds2 * k2 + qds3 * k3;
@@ -617,13 +637,14 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   // kbf[b][x]: A[3+b][3+x] / A[3+b][3+b] for the body rows x < b solved earlier in the leg's turn
   F ub[NBA], lb[NBA], cb[NBA], kbf[NBA][NBA];
 #pragma unroll
-  for (int b = 0; b < NB; b++) {
-    const V vcb = vbs + cross(wbs, rcb[b]) + qds1 * kb1[b] + qds2 * kb2[b] + qds3 * kb3[b];
-    ub[b] = actbf[b] * dot(dnb[b], vcb);
+  for (int b = 0; b < NBR; b++) {
+    const int pt = bfric ? 0 : b;
+    const V vcb = vbs + cross(wbs, rcb[pt]) + qds1 * kb1[pt] + qds2 * kb2[pt] + qds3 * kb3[pt];
+    ub[b] = actbf[pt] * dot(dir[3 + b], vcb);
     lb[b] = zero;
-    const F penb = phib[b] + F(K.slop);
+    const F penb = phib[pt] + F(K.slop);
     const F tgtb = sel_(penb > zero, -(penb * idt), -(F(K.erp) * penb * idt));
-    cb[b] = tgtb * iAb[b];
+    cb[b] = (bfric && b > 0) ? zero : tgtb * iAb[b];         // only normal rows have a target
 #pragma unroll
     for (int x = 0; x < b; x++) kbf[b][x] = Aown[3 + b][3 + x] * iAb[b];
   }
@@ -634,7 +655,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
     u1 = u1 + A[j][1][0] * b0 + A[j][1][1] * b1 + A[j][1][2] * b2;
     u2 = u2 + A[j][2][0] * b0 + A[j][2][1] * b1 + A[j][2][2] * b2;
 #pragma unroll
-    for (int b = 0; b < NB; b++) ub[b] = ub[b] + A[j][3 + b][0] * b0 + A[j][3 + b][1] * b1 + A[j][3 + b][2] * b2;
+    for (int b = 0; b < NBR; b++) ub[b] = ub[b] + A[j][3 + b][0] * b0 + A[j][3 + b][1] * b1 + A[j][3 + b][2] * b2;
   }
   c.phase(7);
   // ---- projected Gauss-Seidel in the order of Bullet's btMultiBodyConstraintSolver::solveSingleIteration (the oracle's
@@ -647,6 +668,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   // FROZEN for the sweeps its wave neighbours still need (iA = c0 = 0: every candidate is the current impulse, exact
   // zero deltas; mu = 1e30: the cone projection is the identity) -- see physics_tick16.
   F mu = tp.mu;
+  F mub(K.body_mu);      // friction coefficient of the body contact (kBody = 1)
   F c0 = tgt * iA0;
   F own[4];
 #pragma unroll
@@ -702,7 +724,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
       // ZL = sum over the robot's rows of lam_r Z_r (the joint rows' Z-vectors are -sgn zj)
       W zs = l0 * Z[0] + l1 * Z[1] + l2 * Z[2];
 #pragma unroll
-      for (int b = 0; b < NB; b++) zs = zs + lb[b] * Z[3 + b];
+      for (int b = 0; b < NBR; b++) zs = zs + lb[b] * Z[3 + b];
 #pragma unroll
       for (int i = 0; i < 3; i++) zs = zs - (sgn[i] * lamq[i]) * zj[i];
       F zl[6] = {c.qsum(zs.a.x), c.qsum(zs.a.y), c.qsum(zs.a.z), c.qsum(zs.l.x), c.qsum(zs.l.y), c.qsum(zs.l.z)};
@@ -712,7 +734,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
       for (int i = 0; i < 3; i++) {
         qc[i] = qc[i] + HJ[0][i] * l0 + HJ[1][i] * l1 + HJ[2][i] * l2;
 #pragma unroll
-        for (int b = 0; b < NB; b++) qc[i] = qc[i] + HJ[3 + b][i] * lb[b];
+        for (int b = 0; b < NBR; b++) qc[i] = qc[i] + HJ[3 + b][i] * lb[b];
       }
       const F lamq0[3] = {lamq[0], lamq[1], lamq[2]};
 #pragma unroll
@@ -736,7 +758,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
       u1 = u1 + (dot(Z[1], dZ) + (HJ[1][0] * w0 + HJ[1][1] * w1 + HJ[1][2] * w2));
       u2 = u2 + (dot(Z[2], dZ) + (HJ[2][0] * w0 + HJ[2][1] * w1 + HJ[2][2] * w2));
 #pragma unroll
-      for (int b = 0; b < NB; b++) ub[b] = ub[b] + (dot(Z[3 + b], dZ) + (HJ[3 + b][0] * w0 + HJ[3 + b][1] * w1 + HJ[3 + b][2] * w2));
+      for (int b = 0; b < NBR; b++) ub[b] = ub[b] + (dot(Z[3 + b], dZ) + (HJ[3 + b][0] * w0 + HJ[3 + b][1] * w1 + HJ[3 + b][2] * w2));
     };
     auto pgs_sweep = [&]() {
       if (joints) joint_phase();
@@ -747,10 +769,21 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
         const F b0 = c.qbcast(e0, j);
         u0 = u0 + A[j][0][0] * b0; u1 = u1 + A[j][1][0] * b0; u2 = u2 + A[j][2][0] * b0;
 #pragma unroll
-        for (int b = 0; b < NB; b++) ub[b] = ub[b] + A[j][3 + b][0] * b0;
+        for (int b = 0; b < NBR; b++) ub[b] = ub[b] + A[j][3 + b][0] * b0;
         l0 = l0 + own[j] * e0;                                           // the owner commits
       }
-      if constexpr (knee) {
+      if constexpr (bfric) {
+        // the body contacts' normal rows, leg by leg
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const F eb0 = fmaxf_(-lb[0], cb[0] - ub[0] * iAb[0]);
+          const F bb0 = c.qbcast(eb0, j);
+          u0 = u0 + A[j][0][3] * bb0; u1 = u1 + A[j][1][3] * bb0; u2 = u2 + A[j][2][3] * bb0;
+#pragma unroll
+          for (int b = 0; b < NBR; b++) ub[b] = ub[b] + A[j][3 + b][3] * bb0;
+          lb[0] = lb[0] + own[j] * eb0;
+        }
+      } else if constexpr (knee) {
         // the body rows (normal rows too), leg by leg; within a leg each row sees the changes of the earlier ones (kbf)
 #pragma unroll
         for (int j = 0; j < 4; j++) {
@@ -786,7 +819,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
           e1 = fminf_(fmaxf_(lt1, -lim), lim) - l1;
           e2 = fminf_(fmaxf_(lt2, -lim), lim) - l2;
         } else {
-          const F sc = fminf_(one, lim * rsqrt_((lt1 * lt1 + F(1e-30f)) + lt2 * lt2));
+          const F sc = fminf_(one, lim * rsqrt_((lt1 * lt1 + F(1e-30f)) + (lt2 * lt2 + F(1e-30f))));   // (as the 16-lane sweep: each row adds its 1e-30)
           e1 = lt1 * sc - l1; e2 = lt2 * sc - l2;
         }
         const auto grip = l0 > zero;                                     // Bullet: `if (totalImpulse > 0)`
@@ -796,8 +829,33 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
         u1 = u1 + A[j][1][1] * b1 + A[j][1][2] * b2;
         u2 = u2 + A[j][2][1] * b1 + A[j][2][2] * b2;
 #pragma unroll
-        for (int b = 0; b < NB; b++) ub[b] = ub[b] + A[j][3 + b][1] * b1 + A[j][3 + b][2] * b2;
+        for (int b = 0; b < NBR; b++) ub[b] = ub[b] + A[j][3 + b][1] * b1 + A[j][3 + b][2] * b2;
         l1 = l1 + own[j] * e1; l2 = l2 + own[j] * e2;
+      }
+      if constexpr (bfric) {
+        // (4) the friction pairs of the body contacts, after the feet's: the same rule with the coefficient K.body_mu
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const F lt1 = lb[1] - ub[1] * iAb[1], lt2 = lb[2] - ub[2] * iAb[2];
+          const F lim = mub * lb[0];
+          F e1, e2;
+          if (pyramid) {
+            e1 = fminf_(fmaxf_(lt1, -lim), lim) - lb[1];
+            e2 = fminf_(fmaxf_(lt2, -lim), lim) - lb[2];
+          } else {
+            const F sc = fminf_(one, lim * rsqrt_((lt1 * lt1 + F(1e-30f)) + (lt2 * lt2 + F(1e-30f))));
+            e1 = lt1 * sc - lb[1]; e2 = lt2 * sc - lb[2];
+          }
+          const auto grip = lb[0] > zero;
+          e1 = sel_(grip, e1, zero); e2 = sel_(grip, e2, zero);
+          const F b1 = c.qbcast(e1, j), b2 = c.qbcast(e2, j);
+          u0 = u0 + A[j][0][4] * b1 + A[j][0][5] * b2;
+          u1 = u1 + A[j][1][4] * b1 + A[j][1][5] * b2;
+          u2 = u2 + A[j][2][4] * b1 + A[j][2][5] * b2;
+#pragma unroll
+          for (int b = 0; b < NBR; b++) ub[b] = ub[b] + A[j][3 + b][4] * b1 + A[j][3 + b][5] * b2;
+          lb[1] = lb[1] + own[j] * e1; lb[2] = lb[2] + own[j] * e2;
+        }
       }
     };
     if (K.res_thr > 0.0f) {
@@ -806,7 +864,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
       const F tol0 = F(K.res_sqrt) * iA0, tol1 = F(K.res_sqrt) * iA1, tol2 = F(K.res_sqrt) * iA2;
       F tolb[NBA];
 #pragma unroll
-      for (int b = 0; b < NB; b++) tolb[b] = F(K.res_sqrt) * iAb[b];
+      for (int b = 0; b < NBR; b++) tolb[b] = F(K.res_sqrt) * iAb[b];
       const F tolq[3] = {F(K.res_sqrt) * iAq[0], F(K.res_sqrt) * iAq[1], F(K.res_sqrt) * iAq[2]};
       int it = 0;
       bool more;
@@ -814,13 +872,13 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
         const F s0 = l0, s1 = l1, s2 = l2;
         F sb[NBA];
 #pragma unroll
-        for (int b = 0; b < NB; b++) sb[b] = lb[b];
+        for (int b = 0; b < NBR; b++) sb[b] = lb[b];
         const F sq_[3] = {lamq[0], lamq[1], lamq[2]};
         pgs_sweep();
         it++;
         auto moved = (fabsf_(l0 - s0) > tol0) || (fabsf_(l1 - s1) > tol1) || (fabsf_(l2 - s2) > tol2);
 #pragma unroll
-        for (int b = 0; b < NB; b++) moved = moved || (fabsf_(lb[b] - sb[b]) > tolb[b]);
+        for (int b = 0; b < NBR; b++) moved = moved || (fabsf_(lb[b] - sb[b]) > tolb[b]);
         if (joints) {
 #pragma unroll
           for (int i = 0; i < 3; i++) moved = moved || (fabsf_(lamq[i] - sq_[i]) > tolq[i]);
@@ -829,8 +887,9 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
         iA0 = sel_(live, iA0, zero); iA1 = sel_(live, iA1, zero); iA2 = sel_(live, iA2, zero);
         c0 = sel_(live, c0, zero);
         mu = sel_(live, mu, F(1e30f));
+        if (bfric) mub = sel_(live, mub, F(1e30f));
 #pragma unroll
-        for (int b = 0; b < NB; b++) {
+        for (int b = 0; b < NBR; b++) {
           iAb[b] = sel_(live, iAb[b], zero); cb[b] = sel_(live, cb[b], zero);
 #pragma unroll
           for (int x = 0; x < b; x++) kbf[b][x] = sel_(live, kbf[b][x], zero);
@@ -875,7 +934,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   // ---- apply impulses: base via the Schur factor, leg via H^-1
   W zs = l0 * Z[0] + l1 * Z[1] + l2 * Z[2];
 #pragma unroll
-  for (int b = 0; b < NB; b++) zs = zs + lb[b] * Z[3 + b];
+  for (int b = 0; b < NBR; b++) zs = zs + lb[b] * Z[3 + b];
   if (joints) {
 #pragma unroll
     for (int i = 0; i < 3; i++) zs = zs - (sgn[i] * lamq[i]) * zj[i];
@@ -890,7 +949,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   L.qd[1] = qds2 + HJ[0][1] * l0 + HJ[1][1] * l1 + HJ[2][1] * l2 - dot(P2, dB);
   L.qd[2] = qds3 + HJ[0][2] * l0 + HJ[1][2] * l1 + HJ[2][2] * l2 - dot(P3, dB);
 #pragma unroll
-  for (int b = 0; b < NB; b++) {
+  for (int b = 0; b < NBR; b++) {
     L.qd[0] = L.qd[0] + HJ[3 + b][0] * lb[b]; L.qd[1] = L.qd[1] + HJ[3 + b][1] * lb[b]; L.qd[2] = L.qd[2] + HJ[3 + b][2] * lb[b];
   }
   if (joints) {

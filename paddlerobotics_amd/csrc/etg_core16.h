@@ -162,43 +162,52 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   // ---- contact point of this lane's row: contact detection works on the start-of-tick pose, so on a heightfield the
   // point and the four corner loads of its terrain cell are issued HERE and consumed in phase 4 -- a lone wave would
   // otherwise sit out the load latency once per tick (flat ground: computed in phase 4, nothing to fetch).
-  // This lane owns contact row `sub` (n, t1, t2) of its leg.  With K.knee the aux lane owns a 4th, frictionless row: a
-  // sphere at the knee (calf joint origin), carried by the thigh (K.knee >= 2: see below).
-  constexpr bool knee = Ctx::kKnee;   // compile-time: the flat-ground and plain heightfield kernels do not contain the rows
+  // This lane owns contact row `sub` (n, t1, t2) of its leg.  With body contacts (EtgConfig.body_contacts, the KNEE
+  // instantiations) the aux lane owns a 4th row of the leg: the NORMAL row of the leg's body contact -- a sphere of knee_radius at
+  // the knee (calf joint origin, carried by the thigh; body_contacts 1) or the deepest of knee / shin midpoint / trunk corner
+  // (body_contacts 2).  The contact's two FRICTION rows are a second row set on the leg's t1 / t2 lanes, built lazily inside the
+  // sweeps the first time a body normal of the wave carries load (finish_tick: `build_b`).
+  constexpr bool knee = Ctx::kKnee;   // compile-time: the toe-spheres-only kernels do not contain the rows
+  const bool bodies = knee && K.knee != 0;   // (a KNEE instantiation also serves body_contacts = 0 of the all-options layer)
   const auto s3 = c.sub_is(3);
   const F f3 = sel_(s3, one, zero);
   V pc = g.pf, fw;
   F rad(K.foot_radius);
-  F jm12 = one, jm3 = mj;   // which joints move the point of this lane's row (hip & thigh, calf)
+  F jm12 = one, jm3 = one;   // which joints move the point of this lane's row (hip & thigh, calf)
+  V pb = g.o3;               // centre of the leg's body sphere and the joints that move it (replicated in the quad)
+  F bj12 = one, bj3 = zero;
   F tap[6];
   auto contact_point = [&]() {
-    if (knee) {
-      V pb = g.o3;
+    if (bodies) {
       if (K.knee >= 2) {
-        // the aux lane's row takes the DEEPEST of three spheres of knee_radius: knee, shin midpoint (moved by all three
-        // joints), trunk corner next to this leg's hip (moved by none); ties go to the earlier candidate, as in the oracle
+        // the DEEPEST of three spheres of knee_radius: knee, shin midpoint (moved by all three joints), trunk corner next to
+        // this leg's hip (moved by none); ties go to the earlier candidate, as in the oracle
         const V ps = g.o3 - F(0.5f * K.lower_len) * g.ez3;
         const V pt = {sel_(g.o1.x > zero, F(K.trunk_half[0]), F(-K.trunk_half[0])),
                       sel_(g.o1.y > zero, F(K.trunk_half[1]), F(-K.trunk_half[1])), F(-K.trunk_half[2])};
-        auto depth = [&](const V& q) -> F {
+        F d0, d1, d2;
+        if (Ctx::kFlat) {
+          d0 = L.p.z + dot(Rw.r2, g.o3); d1 = L.p.z + dot(Rw.r2, ps); d2 = L.p.z + dot(Rw.r2, pt);
+        } else {
+          // ONE terrain query per lane: sub-lane j looks up candidate j (the aux lane repeats the knee), the three depths are
+          // shared through the quad
+          const auto s2 = c.sub_is(2);
+          const V q = {sel_(s1, ps.x, sel_(s2, pt.x, g.o3.x)), sel_(s1, ps.y, sel_(s2, pt.y, g.o3.y)), sel_(s1, ps.z, sel_(s2, pt.z, g.o3.z))};
           const V w = {L.p.x + dot(Rw.r0, q), L.p.y + dot(Rw.r1, q), L.p.z + dot(Rw.r2, q)};
-          if (Ctx::kFlat) return w.z;
           F hgt, nwx, nwy, nwz;
           c.terrain(K, w.x, w.y, hgt, nwx, nwy, nwz);
-          return (w.z - hgt) * nwz;
-        };
-        F best = depth(pb);
-        const F ds = depth(ps);
-        const auto ms = ds < best;
-        pb = {sel_(ms, ps.x, pb.x), sel_(ms, ps.y, pb.y), sel_(ms, ps.z, pb.z)};
-        best = sel_(ms, ds, best);
-        F j3 = sel_(ms, one, zero);
-        const F dtk = depth(pt);
-        const auto mt = dtk < best;
-        pb = {sel_(mt, pt.x, pb.x), sel_(mt, pt.y, pb.y), sel_(mt, pt.z, pb.z)};
-        jm12 = sel_(s3, sel_(mt, zero, one), one);
-        jm3 = sel_(s3, sel_(mt, zero, j3), one);
+          const F d = (w.z - hgt) * nwz;
+          d0 = c.qb(d, 0); d1 = c.qb(d, 1); d2 = c.qb(d, 2);
+        }
+        const auto ms = d1 < d0;
+        const F best = sel_(ms, d1, d0);
+        const auto mt = d2 < best;
+        pb = {sel_(mt, pt.x, sel_(ms, ps.x, g.o3.x)), sel_(mt, pt.y, sel_(ms, ps.y, g.o3.y)), sel_(mt, pt.z, sel_(ms, ps.z, g.o3.z))};
+        bj12 = sel_(mt, zero, one);
+        bj3 = sel_(mt, zero, sel_(ms, one, zero));
       }
+      jm12 = sel_(s3, bj12, one);
+      jm3 = sel_(s3, bj3, one);
       pc = {sel_(s3, pb.x, g.pf.x), sel_(s3, pb.y, g.pf.y), sel_(s3, pb.z, g.pf.z)};
       rad = sel_(s3, F(K.knee_radius), F(K.foot_radius));
     }
@@ -306,6 +315,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   if (Ctx::kFlat) contact_point();
   F phi;
   V dn, dir;   // contact normal and this lane's row direction (n, t1, t2 by sub-lane; n on the aux lane), base coordinates
+  V nwo = {zero, zero, one};   // terrain normal under this lane's row point, world frame (the aux lane: under the body sphere)
   if (Ctx::kFlat) {
     phi = fw.z - rad;
     dn = Rw.r2;
@@ -320,6 +330,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
     // which every lane needs for the contact point) into base coordinates.
     const F it1 = rsqrt_hf_(one - nwx * nwx);
     const V nw = {nwx, nwy, nwz};
+    nwo = nw;
     const V t1w = {it1 * (one - nwx * nwx), -(it1 * (nwx * nwy)), -(it1 * (nwx * nwz))};
     const V t2w = {zero, it1 * nwz, -(it1 * nwy)};
     const auto s2 = c.sub_is(2);
@@ -330,7 +341,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
            Rw.r0.z * dw.x + Rw.r1.z * dw.y + Rw.r2.z * dw.z};
   }
   auto act = phi < F(K.margin);
-  const F rowf = (knee ? one : mj) * sel_(act, one, zero);      // 1 on the rows of an active foot (/ knee)
+  const F rowf = (bodies ? one : mj) * sel_(act, one, zero);    // 1 on the rows of an active foot (/ body sphere)
   V rc = pc - rad * dn;
   V k1 = cross(xax, rc - g.o1), k2 = cross(g.yax, rc - g.o2), k3 = cross(g.yax, rc - g.o3);
   if (knee) {   // the body row pushes along the normal; the calf joint does not move the knee (nor any joint the trunk)
@@ -338,6 +349,9 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
     k3 = jm3 * k3;
     if (K.knee >= 2) { k1 = jm12 * k1; k2 = jm12 * k2; }
   }
+  // wave-uniform: does ANY robot of the wave have a body sphere inside the margin this tick?  If not, the tick finishes on the
+  // toe-spheres path (hand-scheduled sweeps, no body columns); a robot's result does not depend on which path its wave takes.
+  const bool anyb = bodies && c.any_body((rowf * f3) > F(0.5f));
   F Jl0 = rowf * dot(dir, k1), Jl1 = rowf * dot(dir, k2), Jl2 = rowf * dot(dir, k3);
   F HJ0 = Hi11 * Jl0 + Hi12 * Jl1 + Hi13 * Jl2;
   F HJ1 = Hi12 * Jl0 + Hi22 * Jl1 + Hi23 * Jl2;
@@ -385,20 +399,6 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   for (int e = 0; e < 3; e++)
 #pragma unroll
     for (int lp = 0; lp < 4; lp++) A[lp][e] = A[lp][e] + ownl[lp] * own[e];
-  F Ak[4] = {zero, zero, zero, zero};                           // column of the knee row of leg lp
-  if (knee) {
-#pragma unroll
-    for (int lp = 0; lp < 4; lp++) {
-      Ak[lp] = c.rbcast(Z[0], 4 * lp + 3) * Z[0];
-#pragma unroll
-      for (int k = 1; k < 6; k++) c.fmac_rbcast(Ak[lp], Z[k], Z[k], 4 * lp + 3);
-    }
-    F ownk = c.qb(hj[0], 3) * Jl0;
-    c.fmac_qb(ownk, hj[1], Jl1, 3);
-    c.fmac_qb(ownk, hj[2], Jl2, 3);
-#pragma unroll
-    for (int lp = 0; lp < 4; lp++) Ak[lp] = Ak[lp] + ownl[lp] * ownk;
-  }
   F Add = hj[0] * Jl0 + hj[1] * Jl1 + hj[2] * Jl2;              // own diagonal
   Add = Add + dot(W{{Z[0], Z[1], Z[2]}, {Z[3], Z[4], Z[5]}}, W{{Z[0], Z[1], Z[2]}, {Z[3], Z[4], Z[5]}});
   const F iA = sel_(rowf > F(0.5f), rcp_(Add), zero);
@@ -430,11 +430,12 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   F iAe = iA, c0e = tgt * iA, mue = tp.mu;
   const F tangf = f1 + f2;
   // owner masks of the three rows of every leg, hoisted out of the sweeps (1 on the lane that owns row e of leg lp)
-  F mk0[4], mt[4];
+  F mk0[4], mt[4], mk3[4];
 #pragma unroll
   for (int lp = 0; lp < 4; lp++) {
     mk0[lp] = ownl[lp] * f0;
     mt[lp] = ownl[lp] * tangf;
+    mk3[lp] = ownl[lp] * f3;
   }
   // ---- joint-limit rows (EtgConfig.joint_limits, bounds of a1.py:186-195 = the URDF limits Bullet enforces with
   // btMultiBodyJointLimitConstraint rows): a joint at or beyond a bound gets a unilateral row along its coordinate, pushing
@@ -452,8 +453,115 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
     anyj = c.any(jactf > F(0.5f));
   }
   // solve + apply, instantiated with and without the joint rows: without them their variables are compile-time zeros
-  auto finish_tick = [&](auto joints_tag) {
+  auto finish_tick = [&](auto joints_tag, auto body_tag) {
   constexpr bool joints = decltype(joints_tag)::value;
+  constexpr bool body = knee && decltype(body_tag)::value;      // some robot of the wave has a body sphere inside the margin
+  F Ak[4] = {zero, zero, zero, zero};                           // column of the body normal row of leg lp
+  if (body) {
+#pragma unroll
+    for (int lp = 0; lp < 4; lp++) {
+      Ak[lp] = c.rbcast(Z[0], 4 * lp + 3) * Z[0];
+#pragma unroll
+      for (int k = 1; k < 6; k++) c.fmac_rbcast(Ak[lp], Z[k], Z[k], 4 * lp + 3);
+    }
+    F ownk = c.qb(hj[0], 3) * Jl0;
+    c.fmac_qb(ownk, hj[1], Jl1, 3);
+    c.fmac_qb(ownk, hj[2], Jl2, 3);
+#pragma unroll
+    for (int lp = 0; lp < 4; lp++) Ak[lp] = Ak[lp] + ownl[lp] * ownk;
+    c.phase_p(10);
+  }
+  // ---- the SECOND row set (body == true only): the two friction rows of the leg's body contact, t1 on sub-lane 1, t2 on
+  // sub-lane 2 (nothing on sub-lane 0 and the aux lane).  Bullet solves a contact's friction rows only while its normal impulse
+  // is positive, so nothing of this exists until a body normal of the wave carries load: `build_b` runs inside the sweeps, at
+  // most once per tick, behind a wave-uniform test.  Everything it makes depends on the tick's start state alone, and the rows'
+  // velocity `u2` is rebuilt from the current impulses at every friction phase (not tracked through the other phases), so a
+  // robot's result does not depend on WHEN a wave neighbour triggered the build.
+  F Z2[6] = {zero, zero, zero, zero, zero, zero}, hj2[3] = {zero, zero, zero};
+  F BA[4][4], BB[4][2], AT[4][2];   // Delassus columns: second row x (n, t1, t2, body n) of leg lp; second row x second rows of leg lp; first row x second rows of leg lp
+#pragma unroll
+  for (int lp = 0; lp < 4; lp++) {
+#pragma unroll
+    for (int e = 0; e < 4; e++) BA[lp][e] = zero;
+    BB[lp][0] = zero; BB[lp][1] = zero; AT[lp][0] = zero; AT[lp][1] = zero;
+  }
+  F u2s = zero, lam2 = zero, iA2 = zero;
+  bool built = false;
+  auto build_b = [&]() {
+    const F rowf2 = tangf * c.qb(rowf, 3);                       // t1 / t2 lane of a leg whose body sphere is inside the margin
+    V dnb, dir2;
+    if (Ctx::kFlat) {
+      dnb = Rw.r2;                                               // flat ground: the body contact's frame is the foot's (world axes)
+      dir2 = dir;
+    } else {
+      // the terrain normal under the body sphere is the aux lane's row normal; frame as for a foot (t1 = x_w projected, t2 = n x t1)
+      const V nb = {c.qb(nwo.x, 3), c.qb(nwo.y, 3), c.qb(nwo.z, 3)};
+      const F it1 = rsqrt_hf_(one - nb.x * nb.x);
+      const V t1w = {it1 * (one - nb.x * nb.x), -(it1 * (nb.x * nb.y)), -(it1 * (nb.x * nb.z))};
+      const V t2w = {zero, it1 * nb.z, -(it1 * nb.y)};
+      const V dw = {sel_(s1, t1w.x, t2w.x), sel_(s1, t1w.y, t2w.y), sel_(s1, t1w.z, t2w.z)};
+      dnb = {Rw.r0.x * nb.x + Rw.r1.x * nb.y + Rw.r2.x * nb.z, Rw.r0.y * nb.x + Rw.r1.y * nb.y + Rw.r2.y * nb.z,
+             Rw.r0.z * nb.x + Rw.r1.z * nb.y + Rw.r2.z * nb.z};
+      dir2 = {Rw.r0.x * dw.x + Rw.r1.x * dw.y + Rw.r2.x * dw.z, Rw.r0.y * dw.x + Rw.r1.y * dw.y + Rw.r2.y * dw.z,
+              Rw.r0.z * dw.x + Rw.r1.z * dw.y + Rw.r2.z * dw.z};
+    }
+    const V rc2 = pb - F(K.knee_radius) * dnb;
+    const V kb1 = bj12 * cross(xax, rc2 - g.o1), kb2 = bj12 * cross(g.yax, rc2 - g.o2), kb3 = bj3 * cross(g.yax, rc2 - g.o3);
+    const F Jb0 = rowf2 * dot(dir2, kb1), Jb1 = rowf2 * dot(dir2, kb2), Jb2_ = rowf2 * dot(dir2, kb3);
+    hj2[0] = Hi11 * Jb0 + Hi12 * Jb1 + Hi13 * Jb2_;
+    hj2[1] = Hi12 * Jb0 + Hi22 * Jb1 + Hi23 * Jb2_;
+    hj2[2] = Hi13 * Jb0 + Hi23 * Jb1 + Hi33 * Jb2_;
+    const W Jbb = rowf2 * W{cross(rc2, dir2), dir2};
+    const W G2 = Jbb - (hj2[0] * Fj[0] + hj2[1] * Fj[1] + hj2[2] * Fj[2]);
+    F g2[6] = {G2.a.x, G2.a.y, G2.a.z, G2.l.x, G2.l.y, G2.l.z};
+    fwd6(s, g2);
+    const W Z2v = cmul(W{{g2[0], g2[1], g2[2]}, {g2[3], g2[4], g2[5]}}, sqv);
+#pragma unroll
+    for (int k = 0; k < 6; k++) Z2[k] = comp(Z2v, k);
+    const V vc2 = vbs + cross(wbs, rc2) + qs0 * kb1 + qs1 * kb2 + qs2 * kb3;
+    u2s = rowf2 * dot(dir2, vc2);
+    c.dpp_ready(Z2, 6);
+    c.dpp_ready(hj2, 3);
+#pragma unroll
+    for (int lp = 0; lp < 4; lp++) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) {
+        BA[lp][e] = c.rbcast(Z[0], 4 * lp + e) * Z2[0];
+#pragma unroll
+        for (int k = 1; k < 6; k++) c.fmac_rbcast(BA[lp][e], Z[k], Z2[k], 4 * lp + e);
+      }
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        BB[lp][t] = c.rbcast(Z2[0], 4 * lp + 1 + t) * Z2[0];
+        AT[lp][t] = c.rbcast(Z2[0], 4 * lp + 1 + t) * Z[0];
+#pragma unroll
+        for (int k = 1; k < 6; k++) {
+          c.fmac_rbcast(BB[lp][t], Z2[k], Z2[k], 4 * lp + 1 + t);
+          c.fmac_rbcast(AT[lp][t], Z2[k], Z[k], 4 * lp + 1 + t);
+        }
+      }
+    }
+    // rows of the own leg add the leg compliance J_l H^-1 J_l^T
+    F oa[4], ob[2], ot[2];
+#pragma unroll
+    for (int e = 0; e < 4; e++) oa[e] = c.qb(hj[0], e) * Jb0 + c.qb(hj[1], e) * Jb1 + c.qb(hj[2], e) * Jb2_;
+#pragma unroll
+    for (int t = 0; t < 2; t++) {
+      ob[t] = c.qb(hj2[0], 1 + t) * Jb0 + c.qb(hj2[1], 1 + t) * Jb1 + c.qb(hj2[2], 1 + t) * Jb2_;
+      ot[t] = c.qb(hj2[0], 1 + t) * Jl0 + c.qb(hj2[1], 1 + t) * Jl1 + c.qb(hj2[2], 1 + t) * Jl2;
+    }
+#pragma unroll
+    for (int lp = 0; lp < 4; lp++) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) BA[lp][e] = BA[lp][e] + ownl[lp] * oa[e];
+#pragma unroll
+      for (int t = 0; t < 2; t++) { BB[lp][t] = BB[lp][t] + ownl[lp] * ob[t]; AT[lp][t] = AT[lp][t] + ownl[lp] * ot[t]; }
+    }
+    F Add2 = hj2[0] * Jb0 + hj2[1] * Jb1 + hj2[2] * Jb2_;
+    Add2 = Add2 + dot(Z2v, Z2v);
+    iA2 = sel_(rowf2 > F(0.5f), rcp_(Add2), zero);
+    built = true;
+  };
   F sgn = zero, lamq = zero, iAq = zero, c0q = zero;
   F zj[6] = {zero, zero, zero, zero, zero, zero};
   if (joints) {
@@ -491,11 +599,12 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
       F zl[6], zl0[6];
       const F slq = sgn * lamq;
 #pragma unroll
-      for (int k = 0; k < 6; k++) zl[k] = lam * Z[k] - slq * zj[k];
+      for (int k = 0; k < 6; k++) zl[k] = (body ? lam * Z[k] + lam2 * Z2[k] : lam * Z[k]) - slq * zj[k];
       c.sum16x6(zl);
 #pragma unroll
       for (int k = 0; k < 6; k++) zl0[k] = zl[k];
-      const F dj0 = c.qsum(hj[0] * lam), dj1 = c.qsum(hj[1] * lam), dj2 = c.qsum(hj[2] * lam);   // the contact impulses do not change here
+      const F dj0 = c.qsum(body ? hj[0] * lam + hj2[0] * lam2 : hj[0] * lam), dj1 = c.qsum(body ? hj[1] * lam + hj2[1] * lam2 : hj[1] * lam),
+              dj2 = c.qsum(body ? hj[2] * lam + hj2[2] * lam2 : hj[2] * lam);   // the contact impulses do not change here
       const F qc = qds + (f0 * dj0 + f1 * dj1 + f2 * dj2);
       const F lamq0 = lamq;
 #pragma unroll
@@ -523,15 +632,61 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
       for (int k = 0; k < 6; k++) du = du + Z[k] * (zl[k] - zl0[k]);
       u = u + du;
     };
+    // (4) the friction pairs of the body contacts, after the feet's (Bullet: every normal row, then every friction row): the
+    // same rule on the second row set, with the coefficient K.body_mu and the leg's body normal impulse (aux lane).  Skipped --
+    // and the rows not even built -- while no body normal of the wave carries load.
+    auto body_friction = [&]() {
+      c.phase_p(8);
+      const F lbn = c.qb(lam, 3);
+      const auto grip2 = lbn > zero;
+      if (!c.any_body(grip2)) return;
+      if (!built) { build_b(); c.phase_p(12); }
+      // velocity of the second rows under the current impulses: first rows (16 columns), second rows (8), joint rows
+      F u2 = u2s;
+      c.fmac_rbcast16(u2, lam, &BA[0][0]);
+      c.fmac_rbcast8t(u2, lam2, &BB[0][0]);
+      if (joints) {
+        const F slq = sgn * lamq;
+        F zq[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) zq[k] = -(slq * zj[k]);
+        c.sum16x6(zq);
+        F du2 = hj2[0] * c.qb(slq, 0) + hj2[1] * c.qb(slq, 1) + hj2[2] * c.qb(slq, 2);
+#pragma unroll
+        for (int k = 0; k < 6; k++) du2 = du2 + Z2[k] * zq[k];
+        u2 = u2 + du2;
+      }
+      const F lim2 = F(K.body_mu) * lbn;
+#pragma unroll
+      for (int lp = 0; lp < 4; lp++) {
+        const F lc = lam2 - u2 * iA2;
+        F dl;
+        if (pyramid) {
+          dl = fminf_(fmaxf_(lc, -lim2), lim2) - lam2;
+        } else {
+          const F sq1 = lc * lc + F(1e-30f);
+          const F sc = fminf_(one, lim2 * rsqrt_(sq1 + c.qswap12(sq1)));
+          dl = lc * sc - lam2;
+        }
+        dl = sel_(grip2, dl, zero);
+        const F b1 = c.rbcast(dl, 4 * lp + 1), b2 = c.rbcast(dl, 4 * lp + 2);
+        u = u + AT[lp][0] * b1 + AT[lp][1] * b2;
+        u2 = u2 + BB[lp][0] * b1 + BB[lp][1] * b2;
+        lam2 = lam2 + mt[lp] * dl;
+      }
+      c.phase_p(11);
+    };
     auto pgs_sweep = [&]() {
       if (joints) joint_phase();
-      if constexpr (Ctx::kAsmSweep && !knee && !pyramid) {
+      if constexpr (Ctx::kAsmSweep && !pyramid) {
         // the device build's hand-scheduled sweep (GpuCtx16::pgs_normals / pgs_tangents_disc state why): the same arithmetic
         // as the C++ below; the friction skip is folded into the per-lane constants of the friction phase
-        c.pgs_normals(lam, u, iAe, c0e, A, mk0);
+        if constexpr (body) c.pgs_normals_body(lam, u, iAe, c0e, A, Ak, mk0, mk3);
+        else c.pgs_normals(lam, u, iAe, c0e, A, mk0);
         const F lnq = c.qb(lam, 0);
         const auto grip = lnq > zero;
         c.pgs_tangents_disc(lam, u, sel_(grip, iAe, zero), sel_(grip, mue * lnq, F(1e30f)), A, mt);
+        if constexpr (body) body_friction();
         return;
       }
       // (2) normal rows: ln = max(0, lam - (u - tgt)/A), as a change: max(-lam, (tgt - u)/A); the owner's lam update sits
@@ -543,11 +698,11 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
         const F b = c.rbcast(dln, 4 * lp);
         u = u + A[lp][0] * b;
       }
-      if (knee) {   // the body rows are normal rows too: lk = max(0, lk - (u - tgt)/A)
+      if (body) {   // the body normal rows: lk = max(0, lk - (u - tgt)/A)
 #pragma unroll
         for (int lp = 0; lp < 4; lp++) {
           F dlk = fmaxf_(-lam, c0e - u * iAe);
-          lam = lam + ownl[lp] * f3 * dlk;
+          lam = lam + mk3[lp] * dlk;
           F bk = c.rbcast(dlk, 4 * lp + 3);
           u = u + Ak[lp] * bk;
         }
@@ -566,8 +721,8 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
         if (pyramid) {
           dl = fminf_(fmaxf_(lc, -lim), lim) - lam;
         } else {
-          const F oth = c.qswap12(lc);
-          const F sc = fminf_(one, lim * rsqrt_((lc * lc + F(1e-30f)) + oth * oth));   // (the 1e-30 keeps 0 * rsq(0) off the table)
+          const F sq1 = lc * lc + F(1e-30f);                          // (the 1e-30 keeps 0 * rsq(0) off the table)
+          const F sc = fminf_(one, lim * rsqrt_(sq1 + c.qswap12(sq1)));     // both lanes add it, as in pgs_tangents_disc
           dl = lc * sc - lam;
         }
         dl = sel_(grip, dl, zero);
@@ -575,6 +730,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
         u = u + A[lp][1] * b1 + A[lp][2] * b2;
         lam = lam + mt[lp] * dl;
       }
+      if constexpr (body) body_friction();
     };
     if (K.res_thr > 0.0f) {
       // EtgConfig.solver_residual (etgsim.h): sweep until the robot's largest squared row residual
@@ -598,17 +754,22 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
           // convergence afterwards (two selects, three with joint rows) -- the same result bit for bit as zeroed constants,
           // but the per-robot mask (ballot -> shift -> and -> compare: a 6-deep chain) is only needed AFTER the next sweep,
           // so it leaves the sweep's critical path; the wave's exit test is the compare's wave mask alone.
-          const F lam0 = lam, u0 = u, lamq0 = lamq;
+          const F lam0 = lam, u0 = u, lamq0 = lamq, lam20 = lam2;
           pgs_sweep();
           it++;
           lam = sel_(frozen, lam0, lam);
           u = sel_(frozen, u0, u);
           if (joints) lamq = sel_(frozen, lamq0, lamq);
-          const auto moved = joints ? ((fabsf_(lam - lam0) > tol) || (fabsf_(lamq - lamq0) > tolq)) : (fabsf_(lam - lam0) > tol);
+          auto moved = joints ? ((fabsf_(lam - lam0) > tol) || (fabsf_(lamq - lamq0) > tolq)) : (fabsf_(lam - lam0) > tol);
+          if (body) {   // the second rows (zeros until built: 0 > 0 is false)
+            lam2 = sel_(frozen, lam20, lam2);
+            moved = moved || (fabsf_(lam2 - lam20) > F(K.res_sqrt) * iA2);
+          }
           more = c.wave_any(moved) && it < K.iters;
           frozen = !c.robot_any(moved);
           return;
         }
+        static_assert(!body || lazy, "the eager-freeze A/B variant predates the body friction rows");
         const F lam0 = lam, lamq0 = lamq;
         pgs_sweep();
         it++;
@@ -620,7 +781,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
         if (joints) { iAqe = sel_(live, iAqe, zero); c0qe = sel_(live, c0qe, zero); }
         more = c.wave_any(live) && it < K.iters;
       };
-      if (Ctx::kPlain && !joints) {
+      if (Ctx::kPlain && !joints && !body) {
         // The default robot layer: the first 8 sweeps as nested forward exits (falling through costs nothing, the one taken
         // branch per tick is the exit); ticks that need more (a fraction of a percent) enter the loop at the bottom.
         sweep_and_test();
@@ -637,7 +798,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
         do sweep_and_test(); while (more);
       }
       L.sweeps += it;
-    } else if (K.iters == 2 && !joints) {
+    } else if (K.iters == 2 && !joints && !body) {
       // a fixed pair of sweeps (the round-1/2 default) as straight-line code: no loop back-edge inside the tick
       pgs_sweep();
       pgs_sweep();
@@ -657,7 +818,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   // ---- apply impulses: base via the Schur factor, joints via H^-1
   F db[6];
 #pragma unroll
-  for (int k = 0; k < 6; k++) db[k] = comp(lam * W{{Z[0], Z[1], Z[2]}, {Z[3], Z[4], Z[5]}}, k);
+  for (int k = 0; k < 6; k++) db[k] = body ? lam * Z[k] + lam2 * Z2[k] : lam * Z[k];
   const F slq = sgn * lamq;                                     // the joint rows' impulses along the joint coordinates
   if (joints) {
 #pragma unroll
@@ -674,15 +835,21 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   L.wb = wbs + dB.a;
   L.vb = vbs + dB.l;
   // joint j of this leg receives sum_d HJ_d[j] lam_d
-  const F dj0 = c.qsum(hj[0] * lam), dj1 = c.qsum(hj[1] * lam), dj2 = c.qsum(hj[2] * lam);
+  const F dj0 = c.qsum(body ? hj[0] * lam + hj2[0] * lam2 : hj[0] * lam), dj1 = c.qsum(body ? hj[1] * lam + hj2[1] * lam2 : hj[1] * lam),
+          dj2 = c.qsum(body ? hj[2] * lam + hj2[2] * lam2 : hj[2] * lam);
   L.qd = mj * (qds + (f0 * dj0 + f1 * dj1 + f2 * dj2) - dot(P, dB));
   if (joints) L.qd = L.qd + mj * (h0 * c.qb(slq, 0) + h1 * c.qb(slq, 1) + h2 * c.qb(slq, 2));
   L.lam = lam;
   const F ln_leg = c.qb(lam, 0);
   L.contact = sel_(act && (ln_leg > zero), one, zero);
   };   // finish_tick
-  if (anyj) finish_tick(std::true_type{});
-  else finish_tick(std::false_type{});
+  if (anyb) {
+    if (anyj) finish_tick(std::true_type{}, std::true_type{});
+    else finish_tick(std::false_type{}, std::true_type{});
+  } else {
+    if (anyj) finish_tick(std::true_type{}, std::false_type{});
+    else finish_tick(std::false_type{}, std::false_type{});
+  }
   c.phase(9);
   // ---- semi-implicit Euler
   L.q = L.q + dt * L.qd;

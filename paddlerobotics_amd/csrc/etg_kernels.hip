@@ -94,6 +94,7 @@ struct GpuCtx {
   }
   __device__ __forceinline__ bool lane_is(int j) const { return lane == j; }
   __device__ __forceinline__ bool any(bool b) const { return __any(b); }
+  __device__ __forceinline__ bool any_body(bool b) const { return __any(b); }   // the wave-uniform tests of the body paths (the emulation can force them)
   __device__ __forceinline__ unsigned uniform_bits(unsigned v) const { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }   // a wave-uniform value, kept in an SGPR
   __device__ __forceinline__ bool wave_any(bool b) const { return __any(b); }   // "does any robot of the wave need another sweep?"
   // "does any lane of MY robot (quad) see b?" from the wave mask of the compare: two ANDs with this lane's quad field
@@ -511,6 +512,7 @@ struct GpuCtx16 {
   __device__ __forceinline__ bool sub_is(int j) const { return sub == j; }
   __device__ __forceinline__ bool leg_is(int j) const { return leg == j; }
   __device__ __forceinline__ bool any(bool b) const { return __any(b); }
+  __device__ __forceinline__ bool any_body(bool b) const { return __any(b); }   // the wave-uniform tests of the body paths (the emulation can force them)
   __device__ __forceinline__ unsigned uniform_bits(unsigned v) const { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }   // a wave-uniform value, kept in an SGPR
   __device__ __forceinline__ bool wave_any(bool b) const { return __any(b); }   // "does any robot of the wave need another sweep?"
   // "does any lane of MY robot (16-lane row) see b?" from the wave mask of the compare
@@ -617,6 +619,22 @@ struct GpuCtx16 {
           "v"(a[10]), "v"(a[11]));
 #undef ETG_L
   }
+  // body friction rows (etg_core16.h: body_friction): acc += sum over the 16 first rows of x@lane * a[lane], and over the eight
+  // second rows (the t1 / t2 lanes of the four legs) of x@lane * a[2 leg + t]
+  __device__ __forceinline__ void fmac_rbcast16(float& acc, float x, const float* a) const {
+#define ETG_L(R, N) "v_fmac_f32_dpp %0, %1, %" #N " row_newbcast:" #R " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    asm(ETG_L(0, 2) ETG_L(1, 3) ETG_L(2, 4) ETG_L(3, 5) ETG_L(4, 6) ETG_L(5, 7) ETG_L(6, 8) ETG_L(7, 9) ETG_L(8, 10) ETG_L(9, 11)
+        ETG_L(10, 12) ETG_L(11, 13) ETG_L(12, 14) ETG_L(13, 15) ETG_L(14, 16) ETG_L(15, 17)
+        : "+v"(acc)
+        : "v"(x), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),
+          "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15]));
+  }
+  __device__ __forceinline__ void fmac_rbcast8t(float& acc, float x, const float* a) const {
+    asm(ETG_L(1, 2) ETG_L(2, 3) ETG_L(5, 4) ETG_L(6, 5) ETG_L(9, 6) ETG_L(10, 7) ETG_L(13, 8) ETG_L(14, 9)
+        : "+v"(acc)
+        : "v"(x), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
+#undef ETG_L
+  }
 #undef ETG_FMAC_DPP
   // ---- the contact solve's sweep, hand-scheduled (etg_core16.h: pgs_sweep; kAsmSweep).  The sweep is one serial chain --
   // candidate -> broadcast -> apply, row after row -- and every broadcast reads a register the instruction before wrote: the
@@ -638,6 +656,18 @@ struct GpuCtx16 {
         : [lam] "+v"(lam), [u] "+v"(u), [t] "=&v"(t), [d] "=&v"(d)
         : [iA] "v"(iA), [c0] "v"(c0), [a0] "v"(A[0][0]), [a1] "v"(A[1][0]), [a2] "v"(A[2][0]), [a3] "v"(A[3][0]),
           [m0] "v"(mk0[0]), [m1] "v"(mk0[1]), [m2] "v"(mk0[2]), [m3] "v"(mk0[3]));
+  }
+  // the same with the four body normal rows (aux lanes) after the feet's: Bullet's order -- every normal row, then friction
+  __device__ __forceinline__ void pgs_normals_body(float& lam, float& u, float iA, float c0, const float (&A)[4][3], const float* Ak,
+                                                   const float* mk0, const float* mk3) const {
+    float t, d;
+    asm(ETG_ROW(0, "a0", "m0") ETG_ROW(4, "a1", "m1") ETG_ROW(8, "a2", "m2") ETG_ROW(12, "a3", "m3")
+        ETG_ROW(3, "k0", "n0") ETG_ROW(7, "k1", "n1") ETG_ROW(11, "k2", "n2") ETG_ROW(15, "k3", "n3")
+        : [lam] "+v"(lam), [u] "+v"(u), [t] "=&v"(t), [d] "=&v"(d)
+        : [iA] "v"(iA), [c0] "v"(c0), [a0] "v"(A[0][0]), [a1] "v"(A[1][0]), [a2] "v"(A[2][0]), [a3] "v"(A[3][0]),
+          [m0] "v"(mk0[0]), [m1] "v"(mk0[1]), [m2] "v"(mk0[2]), [m3] "v"(mk0[3]),
+          [k0] "v"(Ak[0]), [k1] "v"(Ak[1]), [k2] "v"(Ak[2]), [k3] "v"(Ak[3]),
+          [n0] "v"(mk3[0]), [n1] "v"(mk3[1]), [n2] "v"(mk3[2]), [n3] "v"(mk3[3]));
 #undef ETG_ROW
   }
   // friction pairs of the four feet on the disc: iA / lim already carry the "normal impulse > 0" condition (iA = 0 and
@@ -706,6 +736,12 @@ struct GpuCtx16 {
     prof[id] += t - prof_last;
     prof_last = t;
     __builtin_amdgcn_sched_barrier(0);
+#endif
+  }
+  // a marker that exists in the profiling build only (no scheduling barrier in the product build)
+  __device__ __forceinline__ void phase_p([[maybe_unused]] int id) const {
+#ifdef ETG_PROFILE_PHASES
+    phase(id);
 #endif
   }
 #ifdef ETG_PROFILE_PHASES
@@ -1374,6 +1410,7 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   if (cfg->settle_ticks < 0) return fail(ETG_ERR_BAD_ARG, "etg_create: settle_ticks must not be negative");
   if (cfg->motor_mode < 0 || cfg->motor_mode > 2) return fail(ETG_ERR_BAD_ARG, "etg_create: motor_mode must be 0 (POSITION), 1 (TORQUE) or 2 (HYBRID)");
   if (cfg->body_contacts < 0 || cfg->body_contacts > 3) return fail(ETG_ERR_BAD_ARG, "etg_create: body_contacts must be 0, 1, 2 or 3");
+  if (!(cfg->body_friction >= 0.0)) return fail(ETG_ERR_BAD_ARG, "etg_create: body_friction must be >= 0");
   if (cfg->body_contacts == 3 && cfg->lanes_per_robot == 16)
     return fail(ETG_ERR_BAD_ARG, "etg_create: body_contacts = 3 (three body rows per leg) needs the 4-lanes-per-robot mapping");
   if (cfg->terrain != 0 && cfg->terrain != 1) return fail(ETG_ERR_BAD_ARG, "etg_create: terrain must be 0 (plane) or 1 (heightfield)");
@@ -1471,17 +1508,27 @@ static inline void launch_obs_noise(EtgHandle* h, int n, const uint8_t* mask, fl
                      h->K.noise_call + (unsigned)(n - 1) - (unsigned)back, mask, invert, obs);
 }
 
-// the instantiations of a 16-lane kernel: {flat ground, heightfield} x {plain robot layer, all options, all options + knee rows}
+// the instantiations of a 16-lane kernel: {flat ground, heightfield} x {plain robot layer + body rows (the default), plain
+// robot layer with toe spheres only, all options + body rows}.  The last one also serves body_contacts = 0 of the all-options
+// layer (the rows are switched off at run time: KCfg.knee == 0), so a kernel still has six instantiations.
+#define DISPATCH16(X)                                                                                                 \
+  do {                                                                                                                \
+    const bool pl_ = plain_config(h->K), kn_ = h->K.knee != 0, fl_ = h->K.terrain == 0;                               \
+    if (fl_ && pl_ && kn_) X(true, true, true);                                                                       \
+    else if (fl_ && pl_) X(true, false, true);                                                                        \
+    else if (fl_) X(true, true, false);                                                                               \
+    else if (pl_ && kn_) X(false, true, true);                                                                        \
+    else if (pl_) X(false, false, true);                                                                              \
+    else X(false, true, false);                                                                                       \
+  } while (0)
 #define LAUNCH16(KERN, grid, stream, ...)                                                                             \
   do {                                                                                                                \
-    const bool pl_ = plain_config(h->K);                                                                              \
-    if (h->K.terrain == 0 && pl_) hipLaunchKernelGGL((KERN<true, false, true>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);   \
-    else if (h->K.terrain == 0 && h->K.knee) hipLaunchKernelGGL((KERN<true, true, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__); \
-    else if (h->K.terrain == 0) hipLaunchKernelGGL((KERN<true, false, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);   \
-    else if (h->K.knee) hipLaunchKernelGGL((KERN<false, true, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);           \
-    else if (pl_) hipLaunchKernelGGL((KERN<false, false, true>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);                 \
-    else hipLaunchKernelGGL((KERN<false, false, false>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__);                         \
+    auto launch_ = [&](auto f_, auto k_, auto p_) {                                                                   \
+      hipLaunchKernelGGL((KERN<decltype(f_)::value, decltype(k_)::value, decltype(p_)::value>), grid, dim3(BLOCK), 0, stream, __VA_ARGS__); \
+    };                                                                                                                \
+    DISPATCH16(LAUNCH16_X_);                                                                                          \
   } while (0)
+#define LAUNCH16_X_(F_, K_, P_) launch_(std::integral_constant<bool, F_>{}, std::integral_constant<bool, K_>{}, std::integral_constant<bool, P_>{})
 
 // 4-lane kernels: {flat ground, heightfield} x {plain robot layer, all options, all options + 1 body row per leg, + 3 body rows}
 #define LAUNCH4(KERN, grid, stream, ...)                                                                              \
@@ -1906,18 +1953,12 @@ extern "C" int etg_rollout_policy(EtgHandle* h, EtgPolicy* pol, int n_steps, flo
   for (int done_steps = 0; done_steps < n_steps; done_steps += ROLLOUT_CHUNK) {
     const int m = n_steps - done_steps < ROLLOUT_CHUNK ? n_steps - done_steps : ROLLOUT_CHUNK;
     advance_obs_stream(h, m);
-    const bool kn = h->K.knee != 0, pl = plain_config(h->K);
 #define LAUNCH_POLICY16(F_, K_, P_)                                                                                   \
   do {                                                                                                                \
     if (precision == 0) hipLaunchKernelGGL((k_rollout_policy16<F_, false, K_, P_>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs); \
     else hipLaunchKernelGGL((k_rollout_policy16<F_, true, K_, P_>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);    \
   } while (0)
-    if (flat && pl) LAUNCH_POLICY16(true, false, true);
-    else if (flat && kn) LAUNCH_POLICY16(true, true, false);
-    else if (flat) LAUNCH_POLICY16(true, false, false);
-    else if (kn) LAUNCH_POLICY16(false, true, false);
-    else if (pl) LAUNCH_POLICY16(false, false, true);
-    else LAUNCH_POLICY16(false, false, false);
+    DISPATCH16(LAUNCH_POLICY16);
 #undef LAUNCH_POLICY16
     launch_obs_noise(h, m, nullptr, obs, s);   // every chunk ends in the caller's rows: the next chunk reads them
   }
@@ -1959,12 +2000,7 @@ extern "C" int etg_rollout_policy_record(EtgHandle* h, EtgPolicy* pol, int n_ste
     if (precision == 0) hipLaunchKernelGGL((k_rollout_policy16_rec<F_, false, K_, P_>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs, R); \
     else hipLaunchKernelGGL((k_rollout_policy16_rec<F_, true, K_, P_>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs, R);    \
   } while (0)
-    if (flat && pl) LAUNCH_POLICY16R(true, false, true);
-    else if (flat && kn) LAUNCH_POLICY16R(true, true, false);
-    else if (flat) LAUNCH_POLICY16R(true, false, false);
-    else if (kn) LAUNCH_POLICY16R(false, true, false);
-    else if (pl) LAUNCH_POLICY16R(false, false, true);
-    else LAUNCH_POLICY16R(false, false, false);
+    DISPATCH16(LAUNCH_POLICY16R);
 #undef LAUNCH_POLICY16R
     launch_obs_noise(h, m, nullptr, obs, s);   // every chunk ends in the caller's rows: the next chunk reads them
   }

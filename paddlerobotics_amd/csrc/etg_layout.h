@@ -69,6 +69,7 @@ struct KCfg {
   float clip_cmd;        // > 0: clip the position command to q +- clip_cmd every tick (a1.py:439-457)
   int knee;              // EtgConfig.body_contacts: 1 knee spheres collide; 2 deepest of knee / shin / trunk corner (16-lane kernels)
   float knee_radius;
+  float body_mu;         // EtgConfig.body_friction: friction coefficient of the body contacts (body_contacts 1 / 2)
   float trunk_half[3];   // knee == 2: half extents of the trunk box (its corners collide too)
   // Gaussian sensor noise (minitaur.py:1206-1211): stdev of motor angle, motor velocity, motor torque (not part of
   // the 49-float observation), base rpy, base rpy rate -- the order of SENSOR_NOISE_STDDEV (minitaur.py:102)
@@ -90,7 +91,7 @@ struct KCfg {
 // the default robot layer (what train.py / pretrain.py run): the PLAIN kernel instantiations compile the options out
 inline bool plain_config(const KCfg& K) {
   return K.motor_mode == 0 && !K.enable_filter && !K.enable_interp && !(K.torque_limit > 0.0f) && !(K.clip_cmd > 0.0f) &&
-         !K.ext_force && !K.knee && K.etg_on && !K.fric_pyramid && K.pd_n < 0 && !(K.restitution > 0.0f) && !K.strength_on;   // (joint limits: in every instantiation)
+         !K.ext_force && K.knee != 3 && K.etg_on && !K.fric_pyramid && K.pd_n < 0 && !(K.restitution > 0.0f) && !K.strength_on;   // (joint limits: in every instantiation)
 }
 
 // counter-based standard normal pair for (seed, robot, observation index, channel): splitmix64 finaliser twice, then
@@ -347,7 +348,7 @@ inline KCfg make_kcfg(const EtgConfig& c, const EtgRobotModel& m) {
   for (int k = 0; k < 5; k++) K.noise_std[k] = 0.0f;
   K.motor_mode = c.motor_mode;
   K.clip_cmd = (float)c.clip_motor_commands;
-  K.knee = c.body_contacts; K.knee_radius = (float)c.knee_radius;
+  K.knee = c.body_contacts; K.knee_radius = (float)c.knee_radius; K.body_mu = (float)c.body_friction;
   for (int k = 0; k < 3; k++) K.trunk_half[k] = (float)c.trunk_half[k];
   K.etg_on = c.enable_etg != 0;
   K.res_thr = (float)c.solver_residual;

@@ -135,6 +135,38 @@ class FusedKernelUnavailable(ValueError):
     """the configuration is outside what a fused rollout kernel covers (callers may fall back to the stepping loop)"""
 
 
+def _body_contacts_mode(v):
+    """make_env's body_contacts keyword -> EtgConfig.body_contacts"""
+    if v in (3, "simultaneous"):
+        return 3
+    if v in (2, "all"):
+        return 2
+    if isinstance(v, str):
+        raise ValueError("body_contacts=%r: 0 / False, 1 / True, 2 / 'all' or 3 / 'simultaneous'" % (v,))
+    if v is True or v == 1:
+        return 1
+    if v is False or v is None or v == 0:
+        return 0
+    raise ValueError("body_contacts=%r: 0 / False, 1 / True, 2 / 'all' or 3 / 'simultaneous'" % (v,))
+
+
+def _uniform_torque_limit(limits):
+    """motor_torque_limits of the robot class (minitaur.py:209-214): a scalar or one value per motor.  The kernels clip every
+    motor with ONE limit, so a sequence is accepted when its entries agree and refused (not silently collapsed) otherwise."""
+    if limits is None:
+        return 0.0
+    a = np.asarray(limits, dtype=np.float64)
+    if a.ndim == 0:
+        return float(a)
+    a = a.reshape(-1)
+    if a.size not in (1, A.NUM_MOTORS):
+        raise ValueError("motor_torque_limits: a scalar or %d values (minitaur.py:209-214), got %d" % (A.NUM_MOTORS, a.size))
+    if not np.all(a == a[0]):
+        raise ValueError("motor_torque_limits: per-motor limits that differ are not supported (the motor model clips every "
+                         "motor with one limit); pass a scalar or equal entries")
+    return float(a[0])
+
+
 class BatchedQuadrupedEnv:
     def __init__(self, num_envs=1, device="cuda:0", task="ground", motor_control_mode=None, render=False,
                  sensor_mode=None, normal=1, dynamic_param=None, reward_param=None, ETG=1, ETG_T=0.5,
@@ -145,7 +177,7 @@ class BatchedQuadrupedEnv:
                  heightfield=None, lanes_per_robot=0, terrain_variants=16, terrain_seed=0,
                  random_dynamics_scale=0.3, random_force_prob=0.02, random_force_steps=8,
                  random_force_range=(5.0, 25.0), seed=0, enable_clip_motor_commands=False,
-                 observation_noise_stdev=None, body_contacts=False, knee_radius=0.02, joint_limits=True,
+                 observation_noise_stdev=None, body_contacts=2, body_friction=0.5, knee_radius=0.02, joint_limits=True,
                  auto_reset=False, random_dynamics_refresh=256, warmstart=0.1, warmstart_friction=0.0, contact_slop=1e-5,
                  foot_restitution=0.0, motor_torque_limits=None, **unused):
         if render:
@@ -213,15 +245,17 @@ class BatchedQuadrupedEnv:
             reward_param=reward_param, reward_p=reward_p, vel_d=vel_d, heightfield=heightfield,
             lanes_per_robot=lanes_per_robot, motor_mode=motor_mode,
             clip_motor_commands=0.2 if enable_clip_motor_commands else 0.0,   # MAX_MOTOR_ANGLE_CHANGE_PER_STEP, a1.py
-            # True / 1: knee spheres; 2 or "all": the deepest of knee, shin midpoint and trunk corner per leg
-            body_contacts=3 if body_contacts in (3, "simultaneous") else 2 if body_contacts in (2, "all") else (1 if body_contacts else 0),
+            # which link shapes collide besides the toe spheres (Bullet: every link's, a1.py:276-287).  2 or "all" (the default):
+            # one contact per leg, with friction, on the deepest of knee / shin midpoint / trunk corner; 1 / True: the knee
+            # sphere only; 0 / False: toe spheres only; 3 or "simultaneous": all three spheres at once, frictionless
+            body_contacts=_body_contacts_mode(body_contacts), body_friction=float(body_friction),
             knee_radius=knee_radius,
             enable_etg=1 if self.ETG else 0, joint_limits=1 if joint_limits else 0,
             # contact-solver settings: the defaults are pybullet's (a1_model.default_config)
             warmstart=warmstart, warmstart_friction=warmstart_friction, contact_slop=contact_slop,
             foot_restitution=foot_restitution,
             # motor_torque_limits of the robot class (minitaur.py:99,127; one value for all motors): the clip of laikago_motor.py:168-173
-            torque_limit=0.0 if motor_torque_limits is None else float(motor_torque_limits))
+            torque_limit=_uniform_torque_limit(motor_torque_limits))
         self.model = A.default_model()
         if task == "balancebeam":
             # README "step_y: the foot position at y axis for balance beam task" (train.py:463): the ETG's nominal

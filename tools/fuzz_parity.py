@@ -47,7 +47,8 @@ def draw(rng):
     if mode == "pose" and rng.random() < 0.25: kw["enable_clip_motor_commands"] = True
     bc = int(rng.choice([0, 0, 0, 1, 2, 3]))
     if bc == 3 and lanes == 16: bc = 2
-    if bc: kw["body_contacts"] = bc
+    kw["body_contacts"] = bc          # (always explicit: the library default is 2)
+    if bc in (1, 2) and rng.random() < 0.4: kw["body_friction"] = float(rng.choice([0.0, 0.2, 1.0]))
     if rng.random() < 0.3: kw["joint_limits"] = False
     if rng.random() < 0.3: kw["friction_model"] = 1
     s = rng.random()
