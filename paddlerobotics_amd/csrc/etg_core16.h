@@ -599,12 +599,19 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
       F zl[6], zl0[6];
       const F slq = sgn * lamq;
 #pragma unroll
-      for (int k = 0; k < 6; k++) zl[k] = (body ? lam * Z[k] + lam2 * Z2[k] : lam * Z[k]) - slq * zj[k];
+      for (int k = 0; k < 6; k++) {
+        F t = lam * Z[k];
+        c.opaque(t);          // (see the impulse application below: the same bits whichever instantiation the wave runs)
+        if (body) t = t + lam2 * Z2[k];
+        zl[k] = t - slq * zj[k];
+      }
       c.sum16x6(zl);
 #pragma unroll
       for (int k = 0; k < 6; k++) zl0[k] = zl[k];
-      const F dj0 = c.qsum(body ? hj[0] * lam + hj2[0] * lam2 : hj[0] * lam), dj1 = c.qsum(body ? hj[1] * lam + hj2[1] * lam2 : hj[1] * lam),
-              dj2 = c.qsum(body ? hj[2] * lam + hj2[2] * lam2 : hj[2] * lam);   // the contact impulses do not change here
+      F dl[3] = {hj[0] * lam, hj[1] * lam, hj[2] * lam};
+      c.opaque3(dl);
+      if (body) { dl[0] = dl[0] + hj2[0] * lam2; dl[1] = dl[1] + hj2[1] * lam2; dl[2] = dl[2] + hj2[2] * lam2; }
+      const F dj0 = c.qsum(dl[0]), dj1 = c.qsum(dl[1]), dj2 = c.qsum(dl[2]);   // the contact impulses do not change here
       const F qc = qds + (f0 * dj0 + f1 * dj1 + f2 * dj2);
       const F lamq0 = lamq;
 #pragma unroll
@@ -818,7 +825,15 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   // ---- apply impulses: base via the Schur factor, joints via H^-1
   F db[6];
 #pragma unroll
-  for (int k = 0; k < 6; k++) db[k] = body ? lam * Z[k] + lam2 * Z2[k] : lam * Z[k];
+  for (int k = 0; k < 6; k++) {
+    // A robot's result must not depend on which instantiation of this tail its WAVE runs (with / without body rows, joint rows):
+    // the terms the other instantiations add are exact zeros for a robot without such rows, but under -ffp-contract=fast the
+    // compiler fuses a product into whatever add follows it, and that differs between the instantiations.  The product common to
+    // all of them is therefore made opaque (no instruction: an empty asm) before anything is added to it.
+    F t = lam * Z[k];
+    c.opaque(t);
+    db[k] = body ? t + lam2 * Z2[k] : t;
+  }
   const F slq = sgn * lamq;                                     // the joint rows' impulses along the joint coordinates
   if (joints) {
 #pragma unroll
@@ -835,8 +850,10 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   L.wb = wbs + dB.a;
   L.vb = vbs + dB.l;
   // joint j of this leg receives sum_d HJ_d[j] lam_d
-  const F dj0 = c.qsum(body ? hj[0] * lam + hj2[0] * lam2 : hj[0] * lam), dj1 = c.qsum(body ? hj[1] * lam + hj2[1] * lam2 : hj[1] * lam),
-          dj2 = c.qsum(body ? hj[2] * lam + hj2[2] * lam2 : hj[2] * lam);
+  F dl[3] = {hj[0] * lam, hj[1] * lam, hj[2] * lam};
+  c.opaque3(dl);
+  if (body) { dl[0] = dl[0] + hj2[0] * lam2; dl[1] = dl[1] + hj2[1] * lam2; dl[2] = dl[2] + hj2[2] * lam2; }
+  const F dj0 = c.qsum(dl[0]), dj1 = c.qsum(dl[1]), dj2 = c.qsum(dl[2]);
   L.qd = mj * (qds + (f0 * dj0 + f1 * dj1 + f2 * dj2) - dot(P, dB));
   if (joints) L.qd = L.qd + mj * (h0 * c.qb(slq, 0) + h1 * c.qb(slq, 1) + h2 * c.qb(slq, 2));
   L.lam = lam;

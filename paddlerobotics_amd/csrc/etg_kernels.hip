@@ -94,7 +94,11 @@ struct GpuCtx {
   }
   __device__ __forceinline__ bool lane_is(int j) const { return lane == j; }
   __device__ __forceinline__ bool any(bool b) const { return __any(b); }
+#ifdef ETG_FORCE_BODY   // A/B build variant: every tick takes the body-row paths (what the emulation's force_body knob does)
+  __device__ __forceinline__ bool any_body(bool) const { return true; }
+#else
   __device__ __forceinline__ bool any_body(bool b) const { return __any(b); }   // the wave-uniform tests of the body paths (the emulation can force them)
+#endif
   __device__ __forceinline__ unsigned uniform_bits(unsigned v) const { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }   // a wave-uniform value, kept in an SGPR
   __device__ __forceinline__ bool wave_any(bool b) const { return __any(b); }   // "does any robot of the wave need another sweep?"
   // "does any lane of MY robot (quad) see b?" from the wave mask of the compare: two ANDs with this lane's quad field
@@ -512,7 +516,11 @@ struct GpuCtx16 {
   __device__ __forceinline__ bool sub_is(int j) const { return sub == j; }
   __device__ __forceinline__ bool leg_is(int j) const { return leg == j; }
   __device__ __forceinline__ bool any(bool b) const { return __any(b); }
+#ifdef ETG_FORCE_BODY   // A/B build variant: every tick takes the body-row paths (what the emulation's force_body knob does)
+  __device__ __forceinline__ bool any_body(bool) const { return true; }
+#else
   __device__ __forceinline__ bool any_body(bool b) const { return __any(b); }   // the wave-uniform tests of the body paths (the emulation can force them)
+#endif
   __device__ __forceinline__ unsigned uniform_bits(unsigned v) const { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }   // a wave-uniform value, kept in an SGPR
   __device__ __forceinline__ bool wave_any(bool b) const { return __any(b); }   // "does any robot of the wave need another sweep?"
   // "does any lane of MY robot (16-lane row) see b?" from the wave mask of the compare
@@ -700,6 +708,9 @@ struct GpuCtx16 {
   __device__ __forceinline__ void dpp_ready10(float* z, float* hj, float* lam) const {
     asm volatile("s_nop 1" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]), "+v"(hj[0]), "+v"(hj[1]), "+v"(hj[2]), "+v"(lam[0]));
   }
+  // an optimisation barrier without an instruction: the value's producer cannot be fused into its consumers (etg_core16.h)
+  __device__ __forceinline__ void opaque(float& v) const { asm volatile("" : "+v"(v)); }
+  __device__ __forceinline__ void opaque3(float* v) const { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])); }
   __device__ __forceinline__ void dpp_ready(float* v, int n) const {
     if (n == 6) asm volatile("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]));
     else if (n == 3) asm volatile("s_nop 1" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]));

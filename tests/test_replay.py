@@ -161,7 +161,7 @@ def test_collect_transitions_on_the_device_matches_a_stepping_loop_and_the_fused
     _need_gpu()
     n, max_step, bound = 256, 59, 0.3
     pol, _ = _policy()
-    env, ref = _make(n, seed=5), _make(n, seed=5)
+    env, ref = _make(n, seed=5, body_contacts=0), _make(n, seed=5, body_contacts=0)   # (toe spheres only: two kernels of one source, equal to rounding; a gripping knee sphere amplifies it)
     rpm = DeviceReplayMemory(n * (max_step + 1) + 7, 49, 12)
     ret, ln, infos = collect_transitions(env, rpm, max_step, policy=pol, action_bound=bound)
     # the same episode by hand
@@ -411,7 +411,7 @@ def test_recorded_fused_rollout_fills_the_memory_like_the_stepping_loop():
     _need_gpu()
     n, max_step, bound = 256, 39, 0.3
     pol, _ = _policy()
-    a, b = _make(n, seed=5), _make(n, seed=5)
+    a, b = _make(n, seed=5, body_contacts=0), _make(n, seed=5, body_contacts=0)   # (toe spheres only: see above)
     ra, rb = DeviceReplayMemory(n * (max_step + 1), 49, 12), DeviceReplayMemory(n * (max_step + 1), 49, 12)
     ret_a, ln_a, _ = collect_transitions(a, ra, max_step, policy=pol, action_bound=bound)
     ret_b, ln_b = collect_recorded(b, rb, max_step, pol, action_bound=bound)
@@ -423,7 +423,8 @@ def test_recorded_fused_rollout_fills_the_memory_like_the_stepping_loop():
     # on its stop: tests/test_gpu_parity4.py) -- the typical row is held tight, 2 % of the rows may sit further out
     def close(x, y, tol):
         d = (x - y).abs() / (1 + y.abs())
-        return bool(d.median() <= 0.1 * tol) and float((d > tol).float().mean()) < 0.02
+        # (the rows allowed outside `tol` -- robots at a contact bifurcation -- are capped too: finite, and off by less than their own size)
+        return bool(torch.isfinite(d).all()) and bool(d.median() <= 0.1 * tol) and float((d > tol).float().mean()) < 0.02 and float(d.max()) <= 1.0
     assert close(ra.obs[:k], rb.obs[:k], 2e-3) and close(ra.next_obs[:k], rb.next_obs[:k], 2e-3)
     assert close(ra.action[:k], rb.action[:k], 1e-4) and close(ra.reward[:k], rb.reward[:k], 1e-3)
     assert close(ret_a, ret_b, 2e-3)
@@ -473,7 +474,7 @@ def test_recorded_stochastic_rollout_matches_the_sampling_loop():
     pol, _ = _policy()
     g = torch.Generator(device="cuda:0"); g.manual_seed(12)
     noise = torch.randn(max_step + 1, n, 12, device="cuda:0", generator=g)
-    a, b = _make(n, seed=6), _make(n, seed=6)
+    a, b = _make(n, seed=6, body_contacts=0), _make(n, seed=6, body_contacts=0)   # (toe spheres only: see above)
     ra, rb = DeviceReplayMemory(n * (max_step + 1), 49, 12), DeviceReplayMemory(n * (max_step + 1), 49, 12)
     ret_a, ln_a, _ = collect_transitions(a, ra, max_step, policy=pol, action_bound=bound, mode="sample", noise=noise)
     ret_b, ln_b = collect_recorded(b, rb, max_step, pol, action_bound=bound, mode="sample", noise=noise)
