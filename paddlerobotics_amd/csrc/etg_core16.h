@@ -456,6 +456,9 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   auto finish_tick = [&](auto joints_tag, auto body_tag) {
   constexpr bool joints = decltype(joints_tag)::value;
   constexpr bool body = knee && decltype(body_tag)::value;      // some robot of the wave has a body sphere inside the margin
+  // ---- body normal rows (body == true only): the columns of the four body normal rows (aux lanes).  (Measured and dropped:
+  // making these columns and solving the rows only in sweeps where some body normal row of the wave would change its impulse --
+  // the per-leg scalar tests cost a lone wave more than the four rows they skip: profiles/r05_ab_experiments.txt section 2.)
   F Ak[4] = {zero, zero, zero, zero};                           // column of the body normal row of leg lp
   if (body) {
 #pragma unroll
@@ -646,12 +649,13 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
       c.phase_p(8);
       const F lbn = c.qb(lam, 3);
       const auto grip2 = lbn > zero;
-      if (!c.any_body(grip2)) return;
+      // which legs carry a loaded body contact for SOME robot of the wave (the pairs of the other legs would change nothing for
+      // any robot: skipped)
+      const auto gm = c.body_mask(grip2);
+      if (!c.mask_any(gm)) return;
       if (!built) { build_b(); c.phase_p(12); }
       // velocity of the second rows under the current impulses: first rows (16 columns), second rows (8), joint rows
-      F u2 = u2s;
-      c.fmac_rbcast16(u2, lam, &BA[0][0]);
-      c.fmac_rbcast8t(u2, lam2, &BB[0][0]);
+      F u2 = c.row2_velocity(u2s, lam, &BA[0][0], lam2, &BB[0][0]);
       if (joints) {
         const F slq = sgn * lamq;
         F zq[6];
@@ -666,6 +670,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
       const F lim2 = F(K.body_mu) * lbn;
 #pragma unroll
       for (int lp = 0; lp < 4; lp++) {
+        if (!c.mask_leg(gm, lp)) continue;
         const F lc = lam2 - u2 * iA2;
         F dl;
         if (pyramid) {

@@ -94,11 +94,6 @@ struct GpuCtx {
   }
   __device__ __forceinline__ bool lane_is(int j) const { return lane == j; }
   __device__ __forceinline__ bool any(bool b) const { return __any(b); }
-#ifdef ETG_FORCE_BODY   // A/B build variant: every tick takes the body-row paths (what the emulation's force_body knob does)
-  __device__ __forceinline__ bool any_body(bool) const { return true; }
-#else
-  __device__ __forceinline__ bool any_body(bool b) const { return __any(b); }   // the wave-uniform tests of the body paths (the emulation can force them)
-#endif
   __device__ __forceinline__ unsigned uniform_bits(unsigned v) const { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }   // a wave-uniform value, kept in an SGPR
   __device__ __forceinline__ bool wave_any(bool b) const { return __any(b); }   // "does any robot of the wave need another sweep?"
   // "does any lane of MY robot (quad) see b?" from the wave mask of the compare: two ANDs with this lane's quad field
@@ -516,11 +511,17 @@ struct GpuCtx16 {
   __device__ __forceinline__ bool sub_is(int j) const { return sub == j; }
   __device__ __forceinline__ bool leg_is(int j) const { return leg == j; }
   __device__ __forceinline__ bool any(bool b) const { return __any(b); }
+  // the wave-uniform tests of the body paths work on the wave mask of a compare: "any lane", "any lane of leg lp (in any robot
+  // of the wave)" are one scalar AND against a constant each
 #ifdef ETG_FORCE_BODY   // A/B build variant: every tick takes the body-row paths (what the emulation's force_body knob does)
   __device__ __forceinline__ bool any_body(bool) const { return true; }
+  __device__ __forceinline__ unsigned long long body_mask(bool) const { return ~0ull; }
 #else
-  __device__ __forceinline__ bool any_body(bool b) const { return __any(b); }   // the wave-uniform tests of the body paths (the emulation can force them)
+  __device__ __forceinline__ bool any_body(bool b) const { return __any(b); }
+  __device__ __forceinline__ unsigned long long body_mask(bool b) const { return __ballot(b); }
 #endif
+  __device__ __forceinline__ bool mask_any(unsigned long long m) const { return m != 0ull; }
+  __device__ __forceinline__ bool mask_leg(unsigned long long m, int lp) const { return (m & (0x000F000F000F000Full << (4 * lp))) != 0ull; }
   __device__ __forceinline__ unsigned uniform_bits(unsigned v) const { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }   // a wave-uniform value, kept in an SGPR
   __device__ __forceinline__ bool wave_any(bool b) const { return __any(b); }   // "does any robot of the wave need another sweep?"
   // "does any lane of MY robot (16-lane row) see b?" from the wave mask of the compare
@@ -627,21 +628,21 @@ struct GpuCtx16 {
           "v"(a[10]), "v"(a[11]));
 #undef ETG_L
   }
-  // body friction rows (etg_core16.h: body_friction): acc += sum over the 16 first rows of x@lane * a[lane], and over the eight
-  // second rows (the t1 / t2 lanes of the four legs) of x@lane * a[2 leg + t]
-  __device__ __forceinline__ void fmac_rbcast16(float& acc, float x, const float* a) const {
-#define ETG_L(R, N) "v_fmac_f32_dpp %0, %1, %" #N " row_newbcast:" #R " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
-    asm(ETG_L(0, 2) ETG_L(1, 3) ETG_L(2, 4) ETG_L(3, 5) ETG_L(4, 6) ETG_L(5, 7) ETG_L(6, 8) ETG_L(7, 9) ETG_L(8, 10) ETG_L(9, 11)
-        ETG_L(10, 12) ETG_L(11, 13) ETG_L(12, 14) ETG_L(13, 15) ETG_L(14, 16) ETG_L(15, 17)
-        : "+v"(acc)
-        : "v"(x), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),
-          "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15]));
-  }
-  __device__ __forceinline__ void fmac_rbcast8t(float& acc, float x, const float* a) const {
-    asm(ETG_L(1, 2) ETG_L(2, 3) ETG_L(5, 4) ETG_L(6, 5) ETG_L(9, 6) ETG_L(10, 7) ETG_L(13, 8) ETG_L(14, 9)
-        : "+v"(acc)
-        : "v"(x), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]));
+  // body friction rows (etg_core16.h: body_friction): acc + sum over the 16 first rows of x@lane * a[lane] + sum over the eight
+  // second rows (the t1 / t2 lanes of the four legs) of y@lane * b[2 leg + t].  24 broadcast-FMAs into ONE register would be a
+  // dependent chain (a lone wave sits out every link): four partial sums advance side by side and are added at the end.
+  __device__ __forceinline__ float row2_velocity(float acc, float x, const float* a, float y, const float* b) const {
+    float p1 = 0.0f, p2 = 0.0f, p3 = 0.0f;
+#define ETG_L(ACC, SRC, R, N) "v_fmac_f32_dpp %" #ACC ", %" #SRC ", %" #N " row_newbcast:" #R " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
+    asm(ETG_L(0, 4, 0, 6) ETG_L(1, 4, 1, 7) ETG_L(2, 4, 2, 8) ETG_L(3, 4, 3, 9) ETG_L(0, 4, 4, 10) ETG_L(1, 4, 5, 11) ETG_L(2, 4, 6, 12) ETG_L(3, 4, 7, 13)
+        ETG_L(0, 4, 8, 14) ETG_L(1, 4, 9, 15) ETG_L(2, 4, 10, 16) ETG_L(3, 4, 11, 17) ETG_L(0, 4, 12, 18) ETG_L(1, 4, 13, 19) ETG_L(2, 4, 14, 20) ETG_L(3, 4, 15, 21)
+        ETG_L(0, 5, 1, 22) ETG_L(1, 5, 2, 23) ETG_L(2, 5, 5, 24) ETG_L(3, 5, 6, 25) ETG_L(0, 5, 9, 26) ETG_L(1, 5, 10, 27) ETG_L(2, 5, 13, 28) ETG_L(3, 5, 14, 29)
+        : "+v"(acc), "+v"(p1), "+v"(p2), "+v"(p3)
+        : "v"(x), "v"(y), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),
+          "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]),
+          "v"(b[5]), "v"(b[6]), "v"(b[7]));
 #undef ETG_L
+    return (acc + p1) + (p2 + p3);
   }
 #undef ETG_FMAC_DPP
   // ---- the contact solve's sweep, hand-scheduled (etg_core16.h: pgs_sweep; kAsmSweep).  The sweep is one serial chain --
@@ -676,8 +677,8 @@ struct GpuCtx16 {
           [m0] "v"(mk0[0]), [m1] "v"(mk0[1]), [m2] "v"(mk0[2]), [m3] "v"(mk0[3]),
           [k0] "v"(Ak[0]), [k1] "v"(Ak[1]), [k2] "v"(Ak[2]), [k3] "v"(Ak[3]),
           [n0] "v"(mk3[0]), [n1] "v"(mk3[1]), [n2] "v"(mk3[2]), [n3] "v"(mk3[3]));
-#undef ETG_ROW
   }
+#undef ETG_ROW
   // friction pairs of the four feet on the disc: iA / lim already carry the "normal impulse > 0" condition (iA = 0 and
   // lim = 1e30 where it does not hold: the candidate is the current impulse, the scale 1, the change an exact zero)
   __device__ __forceinline__ void pgs_tangents_disc(float& lam, float& u, float iA, float lim, const float (&A)[4][3], const float* mt) const {
@@ -930,9 +931,10 @@ __device__ __forceinline__ void step16_body(const KCfg& K, const DevState& D, co
   }
   store_state16(c, D.base, D.leg, L);
 #ifdef ETG_PROFILE_PHASES
-  if (c.env == 0 && c.r == 0 && info) {
-    for (int k = 0; k < 16; k++) info[k] = (float)c.prof[k];
-    info[16] = (float)(clock64() - t_begin);
+  if ((c.env & 3) == 0 && c.r == 0 && info) {   // every wave reports, in the info row of its first robot
+    float* row = info + (size_t)c.env * ETG_INFO_DIM;
+    for (int k = 0; k < 16; k++) row[k] = (float)c.prof[k];
+    row[16] = (float)(clock64() - t_begin);
   }
 #endif
   if (c.r == 0) {

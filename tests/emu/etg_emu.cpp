@@ -116,6 +116,15 @@ struct EmuCtx16Base {
   B16 leg_is(int j) const { B16 o; for (int r = 0; r < 16; r++) o.v[r] = leg(r) == j; return o; }
   bool any(B16 b) const { for (int r = 0; r < 16; r++) if (b.v[r]) return true; return false; }
   bool any_body(B16 b) const { return g_force_body != 0 || any(b); }   // the two wave-uniform tests of the body paths
+  unsigned long long body_mask(B16 b) const {
+    if (g_force_body) return ~0ull;
+    unsigned long long r = 0;
+    for (int l = 0; l < 16; l++) if (b.v[l]) r |= 1ull << l;
+    return r;
+  }
+  bool mask_any(unsigned long long m) const { return m != 0ull; }
+  bool mask_leg(unsigned long long m, int lp) const { return (m & (0x000F000F000F000Full << (4 * lp))) != 0ull; }
+
   unsigned uniform_bits(unsigned v) const { return v; }
   int uniform_int(F16 a) const { return (int)a.v[0]; }
   F16 par(int k) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = parp[(size_t)k * NL() + col(r)]; return o; }
@@ -150,8 +159,12 @@ struct EmuCtx16Base {
   void sum16x6(F16* v) const { for (int k = 0; k < 6; k++) v[k] = sum16(v[k]); }
   void sum16xn(F16* v, int n) const { for (int k = 0; k < n; k++) v[k] = sum16(v[k]); }
   void fmac_rbcast12(F16& acc, F16 x, const F16* a) const { for (int i = 0; i < 12; i++) fmac_rbcast(acc, x, a[i], 4 * (i / 3) + i % 3); }
-  void fmac_rbcast16(F16& acc, F16 x, const F16* a) const { for (int i = 0; i < 16; i++) fmac_rbcast(acc, x, a[i], i); }
-  void fmac_rbcast8t(F16& acc, F16 x, const F16* a) const { for (int i = 0; i < 8; i++) fmac_rbcast(acc, x, a[i], 4 * (i / 2) + 1 + i % 2); }
+  F16 row2_velocity(F16 acc, F16 x, const F16* a, F16 y, const F16* b) const {   // same four partial sums as the device's asm block
+    F16 p[4] = {acc, F16(0.0f), F16(0.0f), F16(0.0f)};
+    for (int i = 0; i < 16; i++) fmac_rbcast(p[i & 3], x, a[i], i);
+    for (int i = 0; i < 8; i++) fmac_rbcast(p[i & 3], y, b[i], 4 * (i / 2) + 1 + i % 2);
+    return (p[0] + p[1]) + (p[2] + p[3]);
+  }
   F16 legrot(F16 x, int kk) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = x.v[(r + 4 * kk) & 15]; return o; }
   void quad_outer(F16 a, F16 b, F16* acc) const {
     for (int i = 0; i < 4; i++)

@@ -418,6 +418,57 @@ def _bullet_order_solve(sim, s0, lam_prev, tau, cfg, mu, sweeps):
             tgt.append((-pen / dt if pen > 0 else -cfg.erp * pen / dt) if k == 0 else 0.0)
             kind.append(("n" if k == 0 else "t", l))
             lam0.append(lam_prev[3 * l + k] * (cfg.warmstart if k == 0 else cfg.warmstart_friction))
+    # body contacts (EtgConfig.body_contacts 1 / 2), stated independently of the oracle's row construction: the sphere centres from
+    # plain rotation matrices, the deepest-of-three pick, and the joint columns of a row by CENTRAL DIFFERENCES of the contact
+    # point's base-frame position (the point rides on its link); rows ("bn" | "bt", leg), not warm-started
+    if cfg.body_contacts in (1, 2):
+        Rx = lambda a: np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
+        Ry = lambda a: np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        for l in range(4):
+            ql = s0[13 + 3 * l:16 + 3 * l].copy()
+            hip = np.array(m.hip_origin[l][:])
+
+            def frames(q):   # (thigh frame, knee = calf joint origin, calf frame) in base coordinates
+                Rt = Rx(q[0]) @ Ry(q[1])
+                knee = hip + Rx(q[0]) @ np.array([0.0, m.thigh_y[l], 0.0]) + Rt @ np.array([0.0, 0.0, -m.upper_len])
+                return Rt, knee, Rx(q[0]) @ Ry(q[1] + q[2])
+
+            Rt, knee, Rc = frames(ql)
+            cands = [("thigh", knee)]
+            if cfg.body_contacts == 2:
+                cands.append(("calf", knee + Rc @ np.array([0.0, 0.0, -0.5 * m.lower_len])))
+                cands.append(("trunk", np.array([np.sign(hip[0]) * cfg.trunk_half[0], np.sign(hip[1]) * cfg.trunk_half[1], -cfg.trunk_half[2]])))
+            depth = [s0[2] + (R @ c)[2] - cfg.knee_radius for _, c in cands]
+            pick = int(np.argmin(depth))                           # (np.argmin returns the FIRST minimum: ties to the earlier candidate)
+            phi = depth[pick]
+            if not phi < cfg.contact_margin:
+                continue
+            link, centre = cands[pick]
+            cp = centre - cfg.knee_radius * nb                     # contact point, base frame
+            if link == "trunk":
+                point = lambda q: cp
+            else:
+                R0 = Rt if link == "thigh" else Rc
+                c0 = knee
+                local = R0.T @ (cp - c0)                           # the point in its link's frame (origin: the knee)
+
+                def point(q, local=local, link=link):
+                    Rt_, knee_, Rc_ = frames(q)
+                    return knee_ + (Rt_ if link == "thigh" else Rc_) @ local
+            Jc = np.zeros((3, 3))
+            h = 1e-6
+            for j in range(3):
+                dq = np.zeros(3); dq[j] = h
+                Jc[:, j] = (point(ql + dq) - point(ql - dq)) / (2 * h)
+            pen = phi + cfg.contact_slop
+            for k, dw in enumerate(dirs_w):
+                db = R.T @ dw
+                r = np.zeros(18)
+                r[0:3] = np.cross(cp, db); r[3:6] = db; r[6 + 3 * l:9 + 3 * l] = db @ Jc
+                rows.append(r)
+                tgt.append((-pen / dt if pen > 0 else -cfg.erp * pen / dt) if k == 0 else 0.0)
+                kind.append(("bn" if k == 0 else "bt", l))
+                lam0.append(0.0)
     J = np.array(rows).reshape(-1, 18)
     lam = np.array(lam0)
     A_ = J @ Mi @ J.T
@@ -427,20 +478,22 @@ def _bullet_order_solve(sim, s0, lam_prev, tau, cfg, mu, sweeps):
         for i, k in enumerate(kind):                               # (1) non-contact rows
             if k[0] == "j":
                 lam[i] = max(0.0, lam[i] - (u()[i] - tgt[i]) / A_[i, i])
-        for i, k in enumerate(kind):                               # (2) all normal rows
-            if k[0] == "n":
-                lam[i] = max(0.0, lam[i] - (u()[i] - tgt[i]) / A_[i, i])
-        for l in range(4):                                         # (3) friction pairs
-            n_i, t_i = idx(("n", l)), idx(("t", l))
-            if not n_i or not lam[n_i[0]] > 0:
-                continue
-            uu = u()
-            cand = np.array([lam[i] - uu[i] / A_[i, i] for i in t_i])
-            lim = mu * lam[n_i[0]]
-            nrm = np.hypot(*cand)
-            if nrm > lim:
-                cand *= lim / nrm
-            lam[t_i] = cand
+        for nk in ("n", "bn"):                                     # (2) all normal rows: the feet's, then the body contacts'
+            for i, k in enumerate(kind):
+                if k[0] == nk:
+                    lam[i] = max(0.0, lam[i] - (u()[i] - tgt[i]) / A_[i, i])
+        for nk, tk, coef in (("n", "t", mu), ("bn", "bt", cfg.body_friction)):   # (3) friction pairs: feet, then body contacts
+            for l in range(4):
+                n_i, t_i = idx((nk, l)), idx((tk, l))
+                if not n_i or not lam[n_i[0]] > 0:
+                    continue
+                uu = u()
+                cand = np.array([lam[i] - uu[i] / A_[i, i] for i in t_i])
+                lim = coef * lam[n_i[0]]
+                nrm = np.hypot(*cand)
+                if nrm > lim:
+                    cand *= lim / nrm
+                lam[t_i] = cand
     out, jl = np.zeros(12), np.zeros(12)
     for i, k in enumerate(kind):
         if k[0] == "j":
@@ -448,10 +501,11 @@ def _bullet_order_solve(sim, s0, lam_prev, tau, cfg, mu, sweeps):
     for l in range(4):
         for slot, i in enumerate(idx(("n", l)) + idx(("t", l))):
             out[3 * l + slot] = lam[i]
+    _bullet_order_solve.body_impulses = {k: lam[i] for i, k in enumerate(kind) if k[0] in ("bn", "bt")}
     return out, jl, vstar + Mi @ J.T @ lam
 
 
-@pytest.mark.parametrize("case", ["kick", "sliding", "calf_at_its_stop"])
+@pytest.mark.parametrize("case", ["kick", "sliding", "calf_at_its_stop", "kneeling", "belly"])
 def test_sweeps_follow_bullets_row_order_in_an_independent_numpy_statement(case):
     """The oracle's contact solve after exactly K = 1, 2, 3, 6 sweeps against the compact numpy statement above: row order,
     warm-start factors (normal 0.1, friction 0), slop / erp targets, the friction skip while lambda_n = 0 and the disc projection
@@ -472,6 +526,19 @@ def test_sweeps_follow_bullets_row_order_in_an_independent_numpy_statement(case)
         st[0, 25:37] += rng.normal(size=12) * 0.3
         if case == "calf_at_its_stop":
             st[0, 15:25:3] = -1.80                         # (the settle left the calves resting ON the stop: 0.01 rad past it)
+        if case == "kneeling":
+            # front legs folded under the trunk: the front KNEE spheres and the hind feet carry the robot, sliding forward and
+            # yawing -- loaded body rows with gripping / sliding friction next to loaded foot rows (body_contacts = 2, the default)
+            st[0, 13:19] = np.array([0.05, 1.45, -2.55, -0.05, 1.45, -2.55])
+            st[0, 2] = 0.118
+            st[0, 3:7] = np.array([0.0, np.sin(0.17), 0.0, np.cos(0.17)])     # pitched nose-down onto the knees
+            st[0, 7:10] = np.array([0.4, 0.1, -0.3]); st[0, 10:13] = np.array([0.0, 0.5, 0.8])
+        if case == "belly":
+            # legs folded beside the trunk, dropped flat: the four TRUNK-CORNER spheres take the landing (no joint moves them)
+            st[0, 13:25] = np.tile([0.0, 2.5, -2.6], 4)
+            st[0, 2] = A.TRUNK_HALF[2] + 0.02 + 0.001
+            st[0, 3:7] = np.array([0.0, 0.0, 0.0, 1.0])
+            st[0, 7:10] = np.array([0.3, -0.2, -0.5]); st[0, 10:13] = np.array([0.0, 0.0, 0.6])
         sim.set_state(st)
         s0, lam_prev = sim.get_state()[0].copy(), sim.get_lambda()[0].copy()
         tau = -row[21:33] * (s0[13:25] - A.INIT_MOTOR_ANGLES) - row[33:45] * s0[25:37]
@@ -485,5 +552,9 @@ def test_sweeps_follow_bullets_row_order_in_an_independent_numpy_statement(case)
         assert np.abs(R1.T @ s1[7:10] - v_ref[3:6]).max() < 1e-8 and np.abs(R1.T @ s1[10:13] - v_ref[0:3]).max() < 1e-8
         if case == "calf_at_its_stop":
             assert (jl_ref[2::3] > 0).sum() >= 3          # the stops pushed back
+        if case in ("kneeling", "belly") and K >= 2:
+            bi = _bullet_order_solve.body_impulses       # the scenario does load body rows, normal and friction
+            assert sum(1 for k, v in bi.items() if k[0] == "bn" and v > 1e-3) >= 2, bi
+            assert any(k[0] == "bt" and abs(v) > 1e-4 for k, v in bi.items()), bi
         if case == "sliding" and K == 6:
             assert any(abs(np.hypot(lam[3 * l + 1], lam[3 * l + 2]) - mu * lam[3 * l]) < 1e-9 for l in range(4) if lam[3 * l] > 0)

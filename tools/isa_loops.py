@@ -13,7 +13,7 @@ def kernel_lines(path, sym):
             on = m.group(1) == sym
             continue
         if on:
-            m = re.match(r"\s+(\S.*?)\s+// ([0-9A-F]+):", l)
+            m = re.match(r"\s+(\S.*?)\s*// ([0-9A-F]+):", l)
             if m:
                 out.append((int(m.group(2), 16), m.group(1)))
     return out

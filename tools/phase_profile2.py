@@ -16,19 +16,22 @@ w, b = bench.etg_population(N, 0, "cuda:0")
 names = ["integration + ring + PD + trig + link inertias", "RNEA", "CRBA / H^-1 / P", "Schur + LDL^T + solve", "unconstrained velocity",
          "contact rows + Z (+ body candidates)", "Delassus rows", "row velocities + warm start", "PGS sweeps (feet + body normals)", "apply impulses",
          "body normal columns (Ak)", "body friction phases", "body friction build (build_b)"]
-acc = np.zeros(17); sweeps = 0.0
 env = make_env("Quadrupedal", num_envs=N, device="cuda:0", lanes_per_robot=16, body_contacts=bc)
+env.reset(ETG_w=w, ETG_b=b)
+for _ in range(first): env.step(None)
+rows = []
 for s in range(nsamp):
-    sh = 4 * 37 * s
-    env.reset(ETG_w=torch.roll(w, sh, 0), ETG_b=torch.roll(b, sh, 0))
-    for _ in range(first + 3 * s): env.step(None)
     _, _, _, info = env.step(None, want_info=True); torch.cuda.synchronize()
-    acc += env.info_buf[0, :17].cpu().numpy().astype(np.float64)
-    sweeps += float(info["solver_sweeps"].float().mean().item()) / 13.0
-acc /= nsamp
-tot = acc[16]
-print("body_contacts", bc, "| control steps %d.. after reset, %d sampled waves | executed sweeps per tick (all waves) %.2f" % (first, nsamp, sweeps / nsamp))
-print("total cycles per control step: %.0f  (%.1f us at 2.4 GHz)" % (tot, tot / 2400))
+    rows.append(env.info_buf[0::4, :17].cpu().numpy().astype(np.float64))      # one row per wave (its first robot's info row)
+R = np.stack(rows)                     # [steps, waves, 17]
+tot = R[:, :, 16]
+print("body_contacts", bc, "| control steps %d..%d after reset, all %d waves" % (first, first + nsamp - 1, R.shape[1]))
+print("cycles per control step and wave: mean %.0f  median %.0f  p90 %.0f  p99 %.0f  max %.0f  | mean over steps of the slowest wave %.0f (%.1f us at 2.4 GHz)" % (
+    tot.mean(), np.median(tot), np.percentile(tot, 90), np.percentile(tot, 99), tot.max(), tot.max(1).mean(), tot.max(1).mean() / 2400))
+worst = np.stack([R[s, np.argmax(tot[s])] for s in range(nsamp)]).mean(0)
+mean = R.mean((0, 1))
+print("  %-52s %12s %12s" % ("cycles per control step", "mean wave", "slowest wave"))
 for k in range(13):
-    print("  %-52s %9.0f cycles  %5.1f %%  (%.0f per tick)" % (names[k], acc[k], 100 * acc[k] / tot, acc[k] / 13))
-print("  outside ticks %9.0f cycles  %5.1f %%" % (tot - acc[:13].sum(), 100 * (tot - acc[:13].sum()) / tot))
+    print("  %-52s %12.0f %12.0f" % (names[k], mean[k], worst[k]))
+print("  %-52s %12.0f %12.0f" % ("outside ticks", mean[16] - mean[:13].sum(), worst[16] - worst[:13].sum()))
+print("  %-52s %12.0f %12.0f" % ("total", mean[16], worst[16]))
