@@ -46,7 +46,7 @@ CLOCK_WARM_STEPS = 600     # untimed scratch-env steps (~22 ms) right before eve
 # `rocprofv3 --pmc` passes of this same command (tools/pmc_gpu.sh), summarised per kernel and control step in this file.
 # The file is stamped with the hash of the kernel sources it was collected on (tools/make_pmc_json.py); when the sources have
 # changed since, the figures are reported as STALE (roofline.traffic = null) instead of being passed off as this build's.
-PMC_FILE = os.path.join(ROOT, "profiles", "r04_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")
 VALU_PEAK_GUIDE = 0.5              # MI355X_MICROARCH.md: a SIMD issues one wave64 VALU instruction every 2 cycles
 VALU_PEAK_MEASURED = 0.384         # tools/ubench/occupancy_rate.hip: 8 resident waves of v_fma_f32 per SIMD
 NOMINAL_HZ = 2.4e9
@@ -403,6 +403,14 @@ def main():
                 extra["solver_iters_%d" % kfix] = leg(envk, None, True, "the same fused rollout with exactly %d PGS sweeps per tick "
                                                       "(no residual test)" % kfix, reps=reps)
                 envk.close()
+            if SOLVER == A.solver_rule():
+                # the OTHER candidate for the absent env layer's engine settings (a1_model.solver_preset): the
+                # locomotion_gym_env lineage's int(300 / action_repeat) = 23 iterations with the friction pyramid
+                ps = A.solver_preset("locomotion_gym", 13)
+                envp = make_env("Quadrupedal", solver_preset="locomotion_gym", **env_kw)
+                extra["locomotion_gym_preset"] = leg(envp, None, True, "the same fused rollout with solver_preset = 'locomotion_gym': at most %d "
+                                                     "sweeps per tick (residual exit 1e-7 still on), friction pyramid" % ps["solver_iters"])
+                envp.close()
             if args.body_contacts:
                 # rounds 1-4's model for continuity: only the toe spheres collide (shins and trunk pass through the floor)
                 kwf = dict(env_kw, body_contacts=0)

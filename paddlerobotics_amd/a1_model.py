@@ -192,6 +192,24 @@ SOLVER_ITERS = 50          # pybullet numSolverIterations (setPhysicsEngineParam
 SOLVER_RESIDUAL = 1e-7     # pybullet solverResidualThreshold (default)
 
 
+def solver_preset(name, action_repeat=13):
+    """Named contact-solver settings -> dict(solver_iters, solver_residual, friction_model).
+
+    The env layer of the reference (rlschool.quadrupedal) is NOT in /root/reference, so which engine parameters it sets in its
+    reset() cannot be read off a file; both candidates are stated here and selectable:
+      * "pybullet" (the library default): pybullet's own defaults left untouched -- numSolverIterations 50,
+        solverResidualThreshold 1e-7, enableConeFriction 1 (the implicit cone);
+      * "locomotion_gym": what the motion_imitation / minitaur locomotion_gym_env lineage (which rlschool's env derives from) is
+        recalled to set in reset(): numSolverIterations = int(300 / action_repeat) (23 at 13 sub-steps) and enableConeFriction = 0
+        (the per-direction friction pyramid); the residual exit stays pybullet's 1e-7.
+    ASSUMPTION, stated as such in DESIGN.md section 2: the default is "pybullet"; re-check against rlschool's source when it is at hand."""
+    if name in (None, "pybullet"):
+        return dict(solver_iters=SOLVER_ITERS, solver_residual=SOLVER_RESIDUAL, friction_model=0)
+    if name == "locomotion_gym":
+        return dict(solver_iters=max(1, 300 // int(action_repeat)), solver_residual=SOLVER_RESIDUAL, friction_model=1)
+    raise ValueError("solver_preset %r: 'pybullet' or 'locomotion_gym'" % (name,))
+
+
 def solver_rule(solver_iters=None, solver_residual=None):
     """(sweep cap, residual threshold) of the contact solve.  Nothing given: pybullet's documented defaults -- up to 50
     sweeps per tick with the 1e-7 residual exit.  Only a sweep count: exactly that many sweeps (residual test off)."""

@@ -476,21 +476,26 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   }
   // ---- the SECOND row set (body == true only): the two friction rows of the leg's body contact, t1 on sub-lane 1, t2 on
   // sub-lane 2 (nothing on sub-lane 0 and the aux lane).  Bullet solves a contact's friction rows only while its normal impulse
-  // is positive, so nothing of this exists until a body normal of the wave carries load: `build_b` runs inside the sweeps, at
-  // most once per tick, behind a wave-uniform test.  Everything it makes depends on the tick's start state alone, and the rows'
-  // velocity `u2` is rebuilt from the current impulses at every friction phase (not tracked through the other phases), so a
-  // robot's result does not depend on WHEN a wave neighbour triggered the build.
+  // is positive: the friction PHASE of these rows is behind a wave-uniform test in every sweep, but the rows themselves are
+  // built here, at the start of the tail.  (Built lazily inside the sweeps they cost the average wave less -- a third of the
+  // ticks with a sphere inside the margin ever load it -- but everything the build reads, ~100 registers of leg geometry,
+  // Schur factor and unconstrained velocities, then stays alive through the sweeps: the closed-loop kernels spilled 140 dwords
+  // per lane to scratch memory, and a launch lasts as long as its SLOWEST wave, whose ticks all build the rows anyway:
+  // profiles/r05_ab_experiments.txt section 3.)  The rows' velocity `u2` is rebuilt from the current impulses at every friction
+  // phase (not tracked through the other phases).
   F Z2[6] = {zero, zero, zero, zero, zero, zero}, hj2[3] = {zero, zero, zero};
-  F BA[4][4], BB[4][2], AT[4][2];   // Delassus columns: second row x (n, t1, t2, body n) of leg lp; second row x second rows of leg lp; first row x second rows of leg lp
+  // The 32 Delassus columns of the second rows -- BA[lp][e]: second row x (n, t1, t2, body n) of leg lp; BB[lp][t]: second row x
+  // second rows of leg lp; AT[lp][t]: FIRST row x second rows of leg lp -- live from the build to the end of the tick.  In the
+  // kernels that have registers to spare they stay in registers (`sb`); the closed-loop kernels, whose policy tile shares the
+  // 512-register budget with the tick, park them in free slots of the lane's LDS parameter column (Ctx::kSlotBLds) and read them
+  // back where a friction phase needs them: without that the allocator spills 130 dwords per lane to scratch memory.
+  constexpr bool b_lds = Ctx::kSlotBLds;
+  F sb[32];
 #pragma unroll
-  for (int lp = 0; lp < 4; lp++) {
-#pragma unroll
-    for (int e = 0; e < 4; e++) BA[lp][e] = zero;
-    BB[lp][0] = zero; BB[lp][1] = zero; AT[lp][0] = zero; AT[lp][1] = zero;
-  }
+  for (int k = 0; k < 32; k++) sb[k] = zero;
   F u2s = zero, lam2 = zero, iA2 = zero;
-  bool built = false;
-  auto build_b = [&]() {
+  if constexpr (body) {
+    F BA[4][4], BB[4][2], AT[4][2];
     const F rowf2 = tangf * c.qb(rowf, 3);                       // t1 / t2 lane of a leg whose body sphere is inside the margin
     V dnb, dir2;
     if (Ctx::kFlat) {
@@ -563,8 +568,18 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
     F Add2 = hj2[0] * Jb0 + hj2[1] * Jb1 + hj2[2] * Jb2_;
     Add2 = Add2 + dot(Z2v, Z2v);
     iA2 = sel_(rowf2 > F(0.5f), rcp_(Add2), zero);
-    built = true;
-  };
+#pragma unroll
+    for (int lp = 0; lp < 4; lp++) {
+#pragma unroll
+      for (int e = 0; e < 4; e++) { if (b_lds) c.slotb_st(4 * lp + e, BA[lp][e]); else sb[4 * lp + e] = BA[lp][e]; }
+#pragma unroll
+      for (int t = 0; t < 2; t++) {
+        if (b_lds) { c.slotb_st(16 + 2 * lp + t, BB[lp][t]); c.slotb_st(24 + 2 * lp + t, AT[lp][t]); }
+        else { sb[16 + 2 * lp + t] = BB[lp][t]; sb[24 + 2 * lp + t] = AT[lp][t]; }
+      }
+    }
+    c.phase_p(12);
+  }
   F sgn = zero, lamq = zero, iAq = zero, c0q = zero;
   F zj[6] = {zero, zero, zero, zero, zero, zero};
   if (joints) {
@@ -653,9 +668,18 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
       // any robot: skipped)
       const auto gm = c.body_mask(grip2);
       if (!c.mask_any(gm)) return;
-      if (!built) { build_b(); c.phase_p(12); }
       // velocity of the second rows under the current impulses: first rows (16 columns), second rows (8), joint rows
-      F u2 = c.row2_velocity(u2s, lam, &BA[0][0], lam2, &BB[0][0]);
+      F BA[16], BB[4][2], AT[4][2];
+#pragma unroll
+      for (int k = 0; k < 16; k++) BA[k] = b_lds ? c.slotb_ld(k) : sb[k];
+#pragma unroll
+      for (int lp = 0; lp < 4; lp++)
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          BB[lp][t] = b_lds ? c.slotb_ld(16 + 2 * lp + t) : sb[16 + 2 * lp + t];
+          AT[lp][t] = b_lds ? c.slotb_ld(24 + 2 * lp + t) : sb[24 + 2 * lp + t];
+        }
+      F u2 = c.row2_velocity(u2s, lam, BA, lam2, &BB[0][0]);
       if (joints) {
         const F slq = sgn * lamq;
         F zq[6];

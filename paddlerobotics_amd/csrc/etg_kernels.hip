@@ -450,9 +450,10 @@ __global__ void __launch_bounds__(BLOCK) k_step_ar(KCfg K, DevState D, const flo
   step4_body<FLAT, PLAIN, true, BODY>(K, D, action, donef, obs, reward, done, info, lds_par, NX);
 }
 
+struct StatOut { float* ret; int* len; };   // episode returns / lengths [N] for the caller, or nulls
 // n_steps open-loop control steps per launch (rollout_steps), the 4-lanes-per-robot counterpart of k_rollout16
 template <bool FLAT, bool PLAIN, int BODY = 0>
-__global__ void __launch_bounds__(BLOCK) k_rollout(KCfg K, DevState D, int n_steps, float* obs) {
+__global__ void __launch_bounds__(BLOCK) k_rollout(KCfg K, DevState D, int n_steps, float* obs, StatOut so) {
   GpuCtxT<FLAT, PLAIN, BODY> c;
   if (!make_ctx(K, c)) return;
   __shared__ float lds_par[PR_N * BLOCK];
@@ -460,6 +461,10 @@ __global__ void __launch_bounds__(BLOCK) k_rollout(KCfg K, DevState D, int n_ste
   LaneState<float> L = load_state<float>(c, D.base, D.leg);
   rollout_steps(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, n_steps, obs);
   store_state(c, D.base, D.leg, L);
+  if (so.ret && c.lane == 0) {   // the last launch of a rollout hands the episode statistics to the caller itself (no extra launch)
+    so.ret[c.env] = D.ctl[(size_t)CT_RET * K.n_env + c.env];
+    so.len[c.env] = (int)D.ctl[(size_t)CT_LEN * K.n_env + c.env];
+  }
 }
 
 // n_steps control steps over a caller-supplied action tape [n_steps][N][12] in one launch (etg_rollout_actions): the
@@ -709,6 +714,11 @@ struct GpuCtx16 {
   __device__ __forceinline__ void dpp_ready10(float* z, float* hj, float* lam) const {
     asm volatile("s_nop 1" : "+v"(z[0]), "+v"(z[1]), "+v"(z[2]), "+v"(z[3]), "+v"(z[4]), "+v"(z[5]), "+v"(hj[0]), "+v"(hj[1]), "+v"(hj[2]), "+v"(lam[0]));
   }
+  // 32 floats of per-lane scratch in the lane's LDS parameter column: the fields that the 16-lane kernels never stage
+  // (kStaged16 below: the link block PR_LINK..PR_LINK+29 and the gains go straight to registers through tpar*)
+  __device__ __forceinline__ static int slotb_field(int k) { return k < 30 ? PR_LINK + k : PR_KP + (k - 30); }
+  __device__ __forceinline__ void slotb_st(int k, float v) const { const_cast<float*>(lds)[slotb_field(k) * 64] = v; }
+  __device__ __forceinline__ float slotb_ld(int k) const { return lds[slotb_field(k) * 64]; }
   // an optimisation barrier without an instruction: the value's producer cannot be fused into its consumers (etg_core16.h)
   __device__ __forceinline__ void opaque(float& v) const { asm volatile("" : "+v"(v)); }
   __device__ __forceinline__ void opaque3(float* v) const { asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2])); }
@@ -773,10 +783,11 @@ struct GpuCtx16 {
 // PLAIN: the default robot layer -- POSITION control, no action filter / interpolation, no torque limit, no command
 // clip, no external force (plain_config) -- with those options compiled out: their never-taken branches and the
 // registers they pin cost the step kernels ~3 % (measured A/B), so the common configuration gets its own instantiation.
-template <bool FLAT, bool KNEE = false, bool PLAIN = false> struct GpuCtx16T : GpuCtx16 {
+template <bool FLAT, bool KNEE = false, bool PLAIN = false, bool SLOTB_LDS = false> struct GpuCtx16T : GpuCtx16 {
   static constexpr bool kFlat = FLAT;
   static constexpr bool kKnee = KNEE;
   static constexpr bool kPlain = PLAIN;
+  static constexpr bool kSlotBLds = SLOTB_LDS;   // the body friction rows' Delassus columns live in LDS (etg_core16.h: finish_tick)
 #ifdef ETG_NO_ASM_SWEEP
   static constexpr bool kAsmSweep = false;
 #else
@@ -958,13 +969,17 @@ __global__ void __launch_bounds__(BLOCK) k_step16_ar(KCfg K, DevState D, const f
 // n_steps open-loop control steps of every robot in one launch (rollout_steps16): state, control variables and
 // tick constants stay in registers between the steps
 template <bool FLAT, bool KNEE, bool PLAIN>
-__global__ void __launch_bounds__(BLOCK) k_rollout16(KCfg K, DevState D, int n_steps, float* obs) {
+__global__ void __launch_bounds__(BLOCK) k_rollout16(KCfg K, DevState D, int n_steps, float* obs, StatOut so) {
   __shared__ float lds_par[LDS16_FIELDS * BLOCK];
   GpuCtx16T<FLAT, KNEE, PLAIN> c;
   if (!make_ctx16(K, D, c, lds_par)) return;
   State16<float> L = load_state16<float>(c, D.base, D.leg);
   rollout_steps16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, n_steps, obs);
   store_state16(c, D.base, D.leg, L);
+  if (so.ret && c.r == 0) {   // the last launch of a rollout hands the episode statistics to the caller itself (no extra launch):
+    so.ret[c.env] = D.ctl[(size_t)CT_RET * K.n_env + c.env];        // lane 0 of the robot's row re-reads what it has just stored
+    so.len[c.env] = (int)D.ctl[(size_t)CT_LEN * K.n_env + c.env];
+  }
 }
 
 // the 16-lane counterpart of k_rollout_actions
@@ -1018,7 +1033,7 @@ __device__ __forceinline__ void rollout_policy16_body(const KCfg& K, const DevSt
   constexpr int NWP = 4;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int tile = xcd_contiguous_block();            // 16 robots; the host guarantees N % 16 == 0
-  GpuCtx16T<FLAT, KNEE, PLAIN> c;
+  GpuCtx16T<FLAT, KNEE, PLAIN, true> c;
   make_ctx16_at(K, D, c, lds_par + wave * (LDS16_FIELDS * 64), 4 * tile + wave, lane);
   State16<float> L = load_state16<float>(c, D.base, D.leg);
   StepCtl16<float> S = load_ctl16<float>(c, K, D.ctl, D.ictl, D.legctl);
@@ -1865,15 +1880,19 @@ extern "C" int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float
     hipStream_t s = (hipStream_t)stream;
     for (int done_steps = 0; done_steps < n_steps; done_steps += ROLLOUT_CHUNK) {
       const int m = n_steps - done_steps < ROLLOUT_CHUNK ? n_steps - done_steps : ROLLOUT_CHUNK;
-      float* o = (obs && done_steps + m == n_steps) ? obs : h->tmp_obs;
+      const bool last = done_steps + m == n_steps;
+      float* o = (obs && last) ? obs : h->tmp_obs;
+      const StatOut so = last ? StatOut{ret, (int*)len} : StatOut{nullptr, nullptr};
       advance_obs_stream(h, m);
       if (h->lanes == 16) {
-        LAUNCH16(k_rollout16, g16, s, h->K, h->D, m, o);
+        LAUNCH16(k_rollout16, g16, s, h->K, h->D, m, o, so);
       } else {
-        LAUNCH4(k_rollout, g4, s, h->K, h->D, m, o);
+        LAUNCH4(k_rollout, g4, s, h->K, h->D, m, o, so);
       }
       if (o == obs) launch_obs_noise(h, m, nullptr, obs, s);
     }
+    HIP_TRY(hipGetLastError());
+    return ETG_OK;
   } else {
     for (int k = 0; k < n_steps; k++) {
       float* o = (obs && k == n_steps - 1) ? obs : h->tmp_obs;

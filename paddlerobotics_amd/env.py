@@ -179,7 +179,7 @@ class BatchedQuadrupedEnv:
                  random_force_range=(5.0, 25.0), seed=0, enable_clip_motor_commands=False,
                  observation_noise_stdev=None, body_contacts=2, body_friction=0.5, knee_radius=0.02, joint_limits=True,
                  auto_reset=False, random_dynamics_refresh=256, warmstart=0.1, warmstart_friction=0.0, contact_slop=1e-5,
-                 foot_restitution=0.0, motor_torque_limits=None, **unused):
+                 foot_restitution=0.0, motor_torque_limits=None, solver_preset=None, **unused):
         if render:
             raise ValueError("render is not supported by the batched GPU simulator")
         if int(ETG_H) != A.RBF_H:
@@ -236,6 +236,12 @@ class BatchedQuadrupedEnv:
         if self.device.type != "cuda":
             raise ValueError("BatchedQuadrupedEnv runs on a HIP device only (device='cuda:N')")
         self.ETG = int(ETG)
+        if solver_preset is not None:      # named engine settings (a1_model.solver_preset); explicit solver_* / friction_model keywords win
+            ps = A.solver_preset(solver_preset, action_repeat)
+            if solver_iters is None and solver_residual is None:
+                solver_iters, solver_residual = ps["solver_iters"], ps["solver_residual"]
+            if friction_model == 0:
+                friction_model = ps["friction_model"]
         self.cfg = A.default_config(
             self.num_envs, action_repeat=action_repeat, sim_dt=sim_time_step, settle_ticks=settle_ticks,
             solver_iters=solver_iters, solver_residual=solver_residual, friction_model=friction_model, pd_latency=pd_latency,

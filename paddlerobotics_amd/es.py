@@ -71,7 +71,9 @@ class SimpleGA:
         else:
             reward = torch.cat([reward_table, self.elite_rewards])
             solution = torch.cat([self.solutions, self.elite_params])
-        idx = torch.argsort(reward, descending=True, stable=True)[: self.elite_popsize]
+        # alg/es.py:300 `np.argsort(reward)[::-1][0:elite_popsize]`: the REVERSE of an ascending sort, so among equal rewards the
+        # later index comes first (a descending stable sort would put the earlier one first)
+        idx = torch.argsort(reward, stable=True).flip(0)[: self.elite_popsize]
         self.elite_rewards = reward[idx]
         self.elite_params = solution[idx]
         self.curr_best_reward = float(self.elite_rewards[0])

@@ -39,7 +39,9 @@ def opt_with_points_batched(ETG, ETG_T, points, b0, w0, precision=1e-4, lamb=0.5
     Same as calling Opt_with_points(ETG, ETG_T, points=points[i], b0=b0, w0=w0) for every i."""
     # the 6 x 20 feature matrix depends on the layer and the period alone: built and uploaded once per device
     cache = ETG.__dict__.setdefault("_fit_feats", {})
-    key = (float(ETG_T), str(device))
+    # (keyed by everything the matrix depends on: a layer whose dt / sigma / amplitude / phase is changed after a fit gets a new one)
+    key = (float(ETG_T), str(device)) + tuple(repr(np.asarray(getattr(ETG, a, None)).tolist()) for a in
+                                              ("dt", "T", "H", "sigma_sq", "amp", "phase", "omega", "u"))
     if key not in cache:
         cache[key] = torch.as_tensor(np.array([ETG.update(t) for t in control_times(ETG_T)]), dtype=torch.float64, device=device)
     else:

@@ -153,6 +153,9 @@ struct EmuCtx16Base {
   void fmac_rbcast(F16& acc, F16 x, F16 y, int r0) const { for (int r = 0; r < 16; r++) acc.v[r] = std::fmaf(x.v[r0], y.v[r], acc.v[r]); }
   void fmac_qb(F16& acc, F16 x, F16 y, int j) const { for (int r = 0; r < 16; r++) acc.v[r] = std::fmaf(x.v[(r & ~3) + j], y.v[r], acc.v[r]); }
   void dpp_ready(F16*, int) const {}
+  mutable F16 slotb_[32];
+  void slotb_st(int k, F16 v) const { slotb_[k] = v; }
+  F16 slotb_ld(int k) const { return slotb_[k]; }
   void opaque(F16&) const {}
   void opaque3(F16*) const {}
   void dpp_ready10(F16*, F16*, F16*) const {}
@@ -219,6 +222,11 @@ template <bool FLAT, bool KNEE = false, bool PLAIN = false> struct EmuCtx16T : E
   static constexpr bool kKnee = KNEE;
   static constexpr bool kPlain = PLAIN;
   static constexpr bool kAsmSweep = false;   // the C++ statement of the sweep (the device build hand-schedules it)
+#ifdef ETG_EMU_SLOTB_LDS
+  static constexpr bool kSlotBLds = true;    // (build variant: the parked form of the body friction rows' Delassus columns)
+#else
+  static constexpr bool kSlotBLds = false;
+#endif
   template <class A> void pgs_normals(F16&, F16&, F16, F16, const A&, const F16*) const {}
   template <class A> void pgs_tangents_disc(F16&, F16&, F16, F16, const A&, const F16*) const {}
   template <class A> void pgs_normals_body(F16&, F16&, F16, F16, const A&, const F16*, const F16*, const F16*) const {}

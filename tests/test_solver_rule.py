@@ -225,3 +225,29 @@ def test_friction_models_differ_only_where_the_feet_slide(golden):
     assert abs(yaw0 - yaw1) < 0.05 and abs(d0 - d1) < 0.02 * d0 and d0 > 7.0        # sticking feet: same walk
     (d0, yaw0), (d1, yaw1) = walk(0.2, 0), walk(0.2, 1)
     assert abs(yaw0 - yaw1) > 0.3                                                    # sliding feet: the cone's shape matters
+
+
+def test_solver_presets_state_both_candidate_engine_settings(golden):
+    """The reference's env layer (rlschool) is absent, so its setPhysicsEngineParameter calls are an ASSUMPTION:
+    a1_model.solver_preset names both candidates -- pybullet's untouched defaults (the library default) and the
+    locomotion_gym_env lineage's (int(300 / action_repeat) iterations, friction pyramid) -- and both walk the reference's
+    recorded gait on sticking feet to the same place."""
+    from oracle.oracle import OracleSim
+    assert A.solver_preset("pybullet") == dict(solver_iters=50, solver_residual=1e-7, friction_model=0)
+    assert A.solver_preset("locomotion_gym", 13) == dict(solver_iters=23, solver_residual=1e-7, friction_model=1)
+    assert A.solver_preset("locomotion_gym", 33)["solver_iters"] == 9
+    with pytest.raises(ValueError):
+        A.solver_preset("mujoco")
+    g = golden("etg")
+    out = {}
+    for name in ("pybullet", "locomotion_gym"):
+        orc = OracleSim(A.default_config(1, **A.solver_preset(name)))
+        dyn = A.default_dynamic_row()[None].copy()
+        dyn[0, 1] = 1.0
+        orc.set_params(dyn=dyn, etg_w=g["exp_w"], etg_b=g["exp_b"])
+        orc.reset()
+        x0 = orc.get_state()[0, 0]
+        _, ln = orc.run_steps(300)
+        out[name] = (orc.get_state()[0, 0] - x0, int(ln[0]))
+    assert out["pybullet"][1] == 300 and out["locomotion_gym"][1] == 300
+    assert abs(out["pybullet"][0] - out["locomotion_gym"][0]) < 0.03 * out["pybullet"][0] and out["pybullet"][0] > 3.5

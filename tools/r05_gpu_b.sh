@@ -15,3 +15,5 @@ one bc0_k20 --steps 20 --warmup 5 --body-contacts 0
 one bc2_k20_step --steps 20 --warmup 5 --body-contacts 2 --stepwise
 one bc2_k20_i23 --steps 20 --warmup 5 --body-contacts 2 --solver-iters 23 --solver-residual 1e-7
 one bc2_k20_i8 --steps 20 --warmup 5 --body-contacts 2 --solver-iters 8 --solver-residual 1e-7
+one cfg3_k20 --steps 20 --warmup 5 --config 3
+one bc2_k100 --steps 100 --warmup 5 --repeats 3
