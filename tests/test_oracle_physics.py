@@ -373,7 +373,7 @@ def test_friction_cone_on_an_inclined_heightfield():
     assert abs(s1[0] - s0[0]) < 2e-3 and np.abs(s1[7:10]).max() < 5e-3, (s1[0] - s0[0], s1[7:10])
 
 
-def _bullet_order_solve(sim, s0, lam_prev, tau, cfg, mu, sweeps):
+def _bullet_order_solve(sim, s0, lam_prev, tau, cfg, mu, sweeps, trace=None):
     """An independent, plain numpy statement of ONE tick's contact solve in the order of Bullet's
     btMultiBodyConstraintSolver::solveSingleIteration (what stepSimulation() runs, minitaur.py:244) -- joint-limit rows, then
     every normal contact row, then the friction pair of every foot whose normal impulse is positive, projected on the disc
@@ -475,6 +475,10 @@ def _bullet_order_solve(sim, s0, lam_prev, tau, cfg, mu, sweeps):
     u = lambda: J @ vstar + A_ @ lam          # row velocities under the current impulses (recomputed: no incremental bookkeeping)
     idx = lambda kd: [i for i, k in enumerate(kind) if k == kd]
     for _ in range(sweeps):
+        lam_start = lam.copy()
+        if trace is not None and _ > 0:
+            trace.append(float(np.max(((lam_start - lam_before) * np.diag(A_)) ** 2)) if len(lam) else 0.0)
+        lam_before = lam_start
         for i, k in enumerate(kind):                               # (1) non-contact rows
             if k[0] == "j":
                 lam[i] = max(0.0, lam[i] - (u()[i] - tgt[i]) / A_[i, i])

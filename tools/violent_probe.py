@@ -26,6 +26,11 @@ def run(name, amp, cycle, steps=300, **kw):
 
 
 run("amp 0.3, 8 actions cycled", 0.3, 8)
+run("amp 0.3, 8 cycled, toe spheres only (rounds 1-4)", 0.3, 8, body_contacts=0)
+run("amp 0.3, 8 cycled, solver_preset locomotion_gym", 0.3, 8, solver_preset="locomotion_gym")
+run("amp 0.3, 64 cycled, random_dynamics", 0.3, 64, random_param={"random_dynamics": 1})
+run("amp 0.3, 64 cycled, random_dynamics, toe spheres only", 0.3, 64, random_param={"random_dynamics": 1}, body_contacts=0)
+run("amp 0.3, 64 cycled, random_dynamics, locomotion_gym", 0.3, 64, random_param={"random_dynamics": 1}, solver_preset="locomotion_gym")
 run("amp 0.3, 64 cycled, random_dynamics + random_force", 0.3, 64, random_param={"random_dynamics": 1, "random_force": 1})
 run("amp 0.3, 64 cycled, random_dynamics, joint_limits off", 0.3, 64, random_param={"random_dynamics": 1}, joint_limits=False)
 run("amp 0.6, 64 cycled, random_dynamics", 0.6, 64, random_param={"random_dynamics": 1})
