@@ -692,6 +692,18 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
         u2 = u2 + du2;
       }
       const F lim2 = F(K.body_mu) * lbn;
+      if constexpr (Ctx::kAsmSweep && !pyramid) {
+        // the device build's hand-scheduled pair (GpuCtx16::pgs_pair_body): the same arithmetic as the C++ below, the grip
+        // condition folded into the per-lane constants as in the feet's friction phase
+        const F iA2g = sel_(grip2, iA2, zero), lim2g = sel_(grip2, lim2, F(1e30f));
+#pragma unroll
+        for (int lp = 0; lp < 4; lp++) {
+          if (!c.mask_leg(gm, lp)) continue;
+          c.pgs_pair_body(lam2, u2, u, iA2g, lim2g, AT[lp][0], AT[lp][1], BB[lp][0], BB[lp][1], mt[lp], lp);
+        }
+        c.phase_p(11);
+        return;
+      }
 #pragma unroll
       for (int lp = 0; lp < 4; lp++) {
         if (!c.mask_leg(gm, lp)) continue;

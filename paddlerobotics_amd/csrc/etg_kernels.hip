@@ -708,6 +708,32 @@ struct GpuCtx16 {
           [a22] "v"(A[2][2]), [a31] "v"(A[3][1]), [a32] "v"(A[3][2]), [m0] "v"(mt[0]), [m1] "v"(mt[1]), [m2] "v"(mt[2]), [m3] "v"(mt[3]));
 #undef ETG_PAIR
   }
+  // ONE friction pair of a body contact (second rows of leg lp, on its t1 / t2 lanes): the pair of pgs_tangents_disc on (lam2, u2),
+  // its two changes applied to the second rows' velocity u2 AND to the first rows' u (etg_core16.h: body_friction)
+  __device__ __forceinline__ void pgs_pair_body(float& lam2, float& u2, float& u, float iA, float lim, float at0, float at1, float bb0,
+                                                float bb1, float mk, int lp) const {
+    float lc, sq, sc, dl;
+#define ETG_PAIRB(R1, R2)                                                                             \
+    asm("v_fma_f32 %[lc], -%[u2], %[iA], %[lam]\n"                                                      \
+        "v_fmaak_f32 %[sq], %[lc], %[lc], 0x0da24260\n"                                                 \
+        "s_nop 1\n"                                                                                     \
+        "v_add_f32_dpp %[sq], %[sq], %[sq] quad_perm:[0,2,1,3]" ETG_DPPC                                \
+        "v_rsq_f32_e32 %[sq], %[sq]\n"                                                                  \
+        "s_nop 0\n"                                                                                     \
+        "v_mul_f32_e32 %[sc], %[lim], %[sq]\n"                                                          \
+        "v_min_f32_e32 %[sc], 1.0, %[sc]\n"                                                             \
+        "v_fma_f32 %[dl], %[lc], %[sc], -%[lam]\n"                                                      \
+        "v_fmac_f32_e32 %[lam], %[mk], %[dl]\n"                                                         \
+        "s_nop 0\n"                                                                                     \
+        "v_fmac_f32_dpp %[u], %[dl], %[at0] row_newbcast:" #R1 ETG_DPPC                                 \
+        "v_fmac_f32_dpp %[u2], %[dl], %[bb0] row_newbcast:" #R1 ETG_DPPC                                \
+        "v_fmac_f32_dpp %[u], %[dl], %[at1] row_newbcast:" #R2 ETG_DPPC                                 \
+        "v_fmac_f32_dpp %[u2], %[dl], %[bb1] row_newbcast:" #R2 ETG_DPPC                                \
+        : [lam] "+v"(lam2), [u2] "+v"(u2), [u] "+v"(u), [lc] "=&v"(lc), [sq] "=&v"(sq), [sc] "=&v"(sc), [dl] "=&v"(dl)           \
+        : [iA] "v"(iA), [lim] "v"(lim), [at0] "v"(at0), [at1] "v"(at1), [bb0] "v"(bb0), [bb1] "v"(bb1), [mk] "v"(mk))
+    switch (lp) { case 0: ETG_PAIRB(1, 2); break; case 1: ETG_PAIRB(5, 6); break; case 2: ETG_PAIRB(9, 10); break; default: ETG_PAIRB(13, 14); break; }
+#undef ETG_PAIRB
+  }
 #undef ETG_DPPC
   // every value that later feeds fmac_rbcast / fmac_qb as the broadcast source passes through here: the
   // asm "modifies" them, so their producers are ordered before it and the DPP reads after it
