@@ -136,6 +136,35 @@ def max_over_ranks(seconds, dist, dev):
     return float(t.item())
 
 
+def multi_gpu_report(local_seconds, K, N, dist, dev, ret_probe, barrier):
+    """`multi_gpu` of the bench line (N > 1 ranks): every rank's own median time per control step and env-steps/s, the one
+    exchange of the path -- the all_gather of the N x world fp32 episode returns -- timed on its own, and who reports the world
+    size (the collective library, not the flags).  Works on any backend (the CPU suite runs it under gloo, world size 2)."""
+    from paddlerobotics_amd import rollout as R
+    world = dist.get_world_size()
+    on_dev = dist.get_backend() == "nccl"
+    mine = torch.tensor([local_seconds / K * 1e3], dtype=torch.float64, device=dev if on_dev else "cpu")
+    allr = torch.empty(world, dtype=torch.float64, device=mine.device)
+    dist.all_gather_into_tensor(allr, mine)
+    for _ in range(3):
+        R.gather_returns(ret_probe, dist)
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(20):
+        g = R.gather_returns(ret_probe, dist)
+    if ret_probe.is_cuda:
+        torch.cuda.synchronize(ret_probe.device)
+    gather_ms = (time.perf_counter() - t0) / 20 * 1e3
+    return {"ms_per_step_by_rank": [float(x) for x in allr.cpu().tolist()],
+            "env_steps_per_s_by_rank": [N / (float(x) * 1e-3) for x in allr.cpu().tolist()],
+            "return_gather": {"ms": max_over_ranks(gather_ms, dist, dev), "elements": int(g.numel()), "bytes": int(g.numel()) * 4,
+                              "collective": "all_gather_into_tensor", "backend": dist.get_backend(),
+                              "note": "20 back-to-back gathers of the N x world fp32 returns, host clock, max over ranks; one such "
+                                      "gather is inside every timed repeat"},
+            "world_size_reported_by": "rccl (torch.distributed backend nccl)" if on_dev else "torch.distributed/" + dist.get_backend(),
+            "world_size": world}
+
+
 def es_generation_leg(env, world, rank, dist, barrier, max_step=400):
     """two warm-up and three timed ES generations (mean) over the population of world x N candidates (candidate i = robot i)."""
     from paddlerobotics_amd import rollout as R
@@ -357,27 +386,7 @@ def main():
     # N > 1: every rank's own median step time, and the one exchange of the path (the all_gather of the returns) on its own
     multi = None
     if dist is not None:
-        mine = torch.tensor([float(np.median(wall_local)) / K * 1e3], dtype=torch.float64,
-                            device=dev if dist.get_backend() == "nccl" else "cpu")
-        allr = torch.empty(world, dtype=torch.float64, device=mine.device)
-        dist.all_gather_into_tensor(allr, mine)
-        ret_probe = env.episode_stats()[0]
-        for _ in range(3):
-            R.gather_returns(ret_probe, dist)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(20):
-            g = R.gather_returns(ret_probe, dist)
-        torch.cuda.synchronize(dev)
-        gather_ms = (time.perf_counter() - t0) / 20 * 1e3
-        multi = {"ms_per_step_by_rank": [float(x) for x in allr.cpu().tolist()],
-                 "env_steps_per_s_by_rank": [N / (float(x) * 1e-3) for x in allr.cpu().tolist()],
-                 "return_gather": {"ms": max_over_ranks(gather_ms, dist, dev), "elements": int(g.numel()), "bytes": int(g.numel()) * 4,
-                                   "collective": "all_gather_into_tensor", "backend": dist.get_backend(),
-                                   "note": "20 back-to-back gathers of the N x world fp32 returns, host clock, max over ranks; one such "
-                                           "gather is inside every timed repeat"},
-                 "world_size_reported_by": "rccl (torch.distributed backend nccl)" if dist.get_backend() == "nccl" else "torch.distributed/" + dist.get_backend(),
-                 "world_size": dist.get_world_size()}
+        multi = multi_gpu_report(float(np.median(wall_local)), K, N, dist, dev, env.episode_stats()[0], barrier)
 
     # ---- legs reported NEXT to `value`, never part of it
     extra = {}
@@ -416,7 +425,7 @@ def main():
                 kwf = dict(env_kw, body_contacts=0)
                 envf = make_env("Quadrupedal", **solver_kw, **kwf)
                 extra["toe_spheres_only"] = leg(envf, None, True, "the same fused rollout with body_contacts = 0: the headline model of rounds "
-                                                "1-4 (no body rows; the robots sink instead of kneeling)")
+                                                "1-4 (no body rows; the robots sink instead of kneeling)", reps=5)
                 envf.close()
         if args.config == 2:
             pol3 = make_policy()

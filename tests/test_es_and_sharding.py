@@ -161,3 +161,36 @@ def test_observation_history_of_running_robots_survives_a_masked_reset():
         assert torch.equal(va[done.bool()], torch.tensor([[0.0, 0.0, 100.0]]).expand(int(done.sum()), 3))
         if t == 6:                                         # the restarted robot's history holds its reset reading, then goes on
             assert torch.equal(va[1], torch.tensor([0.0, 100.0, 6.0]))
+
+
+def _multi_gpu_report_worker(rank, world, port, out):
+    import torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import bench
+    ret = torch.arange(8, dtype=torch.float32) + 100 * rank           # this rank's 8 episode returns
+    rep = bench.multi_gpu_report(0.020 * (1 + rank), 20, 8, dist, torch.device("cpu"), ret, dist.barrier)
+    if rank == 0:
+        out.put(rep)
+    dist.destroy_process_group()
+
+
+def test_bench_multi_gpu_report_keys_under_gloo():
+    """The `multi_gpu` object of the bench line, assembled by bench.multi_gpu_report on two gloo ranks: per-rank
+    step times and rates, the return gather timed alone with its size, and the world size as the collective library reports it."""
+    import torch.multiprocessing as mp
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    out = ctx.Queue()
+    procs = [ctx.Process(target=_multi_gpu_report_worker, args=(r, 2, port, out)) for r in range(2)]
+    for p in procs:
+        p.start()
+    rep = out.get(timeout=120)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert rep["world_size"] == 2 and rep["world_size_reported_by"] == "torch.distributed/gloo"
+    assert rep["ms_per_step_by_rank"] == pytest.approx([1.0, 2.0]) and rep["env_steps_per_s_by_rank"] == pytest.approx([8000.0, 4000.0])
+    g = rep["return_gather"]
+    assert g["elements"] == 16 and g["bytes"] == 64 and g["collective"] == "all_gather_into_tensor" and g["backend"] == "gloo" and g["ms"] > 0
