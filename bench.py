@@ -229,7 +229,7 @@ def main():
     ap.add_argument("--solver-residual", type=float, default=None,
                     help="squared velocity-level row residual at which a tick stops sweeping (default 1e-7; 0 = fixed count)")
     ap.add_argument("--lanes", type=int, default=0, choices=(0, 4, 16),
-                    help="kernel mapping, lanes per robot (0 = library default: 16 up to 4096 robots, else 4)")
+                    help="kernel mapping, lanes per robot (0 = library default: 16 up to 4096 robots -- 8192 with body rows -- else 4)")
     ap.add_argument("--body-contacts", type=int, default=2, choices=(0, 1, 2),
                     help="link shapes that collide besides the toe spheres (EtgConfig.body_contacts; default 2 = the library default: one "
                          "contact per leg, with friction, on the deepest of knee / shin midpoint / trunk corner; 0 = toe spheres only)")

@@ -135,8 +135,8 @@ typedef struct EtgConfig {
   int32_t hf_nx, hf_ny;
   double hf_cell, hf_x0, hf_y0;
   /* kernel mapping: 16 = one robot per 16-lane DPP row (fills the chip at 4096 robots), 4 = one
-   * robot per quad (one leg per lane; 4x the robots per wave, for batches > 4096), 0 = auto
-   * (16 if num_envs <= 4096 else 4). Same results to fp32 roundoff, same state layout.         */
+   * robot per quad (one leg per lane; 4x the robots per wave, for bigger batches), 0 = auto
+   * (16 if num_envs <= 4096 -- <= 8192 with body_contacts 1 / 2 -- else 4). Same results to fp32 roundoff, same state layout. */
   int32_t lanes_per_robot;
   /* terrain variants: the heightfield's hf_ny rows are hf_bands equal bands stacked along y; robot e
    * walks on band e % hf_bands (its own y axis, clamped inside the band). 0 or 1 = one shared terrain.

@@ -1503,7 +1503,11 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   // 0 = auto.  Both kernels hold one wave per SIMD (register footprint), so the chip runs 1024 waves
   // at a time: 16 lanes/robot fills it with 4096 robots and is faster per robot up to there; beyond
   // that the 4-lanes/robot kernel packs 4x the robots per wave (measured crossover).
-  h->lanes = cfg->lanes_per_robot != 0 ? cfg->lanes_per_robot : (cfg->num_envs <= 4096 ? 16 : 4);
+  // auto: the 16-lane mapping while it fills the chip once (4096 robots = one wave per SIMD); with body rows (modes 1 / 2) up to
+  // 8192 -- two rounds of the 16-lane kernel (45 M env-steps/s) still beat the half-filled 4-lane one, whose wave waits for the
+  // slowest of SIXTEEN robots (36 M; profiles/r05_ab_experiments.txt section 8); above that the 4-lane mapping (16384: 72 M vs 41 M)
+  const int auto16 = (cfg->body_contacts == 1 || cfg->body_contacts == 2) ? 8192 : 4096;
+  h->lanes = cfg->lanes_per_robot != 0 ? cfg->lanes_per_robot : (cfg->num_envs <= auto16 ? 16 : 4);
   if (cfg->body_contacts == 3) h->lanes = 4;   // six rows per leg: the 16-lane mapping has one spare lane per leg
   size_t N = h->N, NL = 4 * N;
   struct { void** p; size_t bytes; } allocs[] = {
