@@ -165,8 +165,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   // This lane owns contact row `sub` (n, t1, t2) of its leg.  With body contacts (EtgConfig.body_contacts, the KNEE
   // instantiations) the aux lane owns a 4th row of the leg: the NORMAL row of the leg's body contact -- a sphere of knee_radius at
   // the knee (calf joint origin, carried by the thigh; body_contacts 1) or the deepest of knee / shin midpoint / trunk corner
-  // (body_contacts 2).  The contact's two FRICTION rows are a second row set on the leg's t1 / t2 lanes, built lazily inside the
-  // sweeps the first time a body normal of the wave carries load (finish_tick: `build_b`).
+  // (body_contacts 2).  The contact's two FRICTION rows are a second row set on the leg's t1 / t2 lanes (finish_tick).
   constexpr bool knee = Ctx::kKnee;   // compile-time: the toe-spheres-only kernels do not contain the rows
   const bool bodies = knee && K.knee != 0;   // (a KNEE instantiation also serves body_contacts = 0 of the all-options layer)
   const auto s3 = c.sub_is(3);
@@ -369,7 +368,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   // J_l H^-1 J_l^T.  (The 4-lane kernel contracts the same products on the matrix pipe; with one row per
   // lane the DPP form needs no accumulator shuffles and no MFMA latency padding.)
   // warm start (defined here: DPP source below): the normal row x K.warmstart, the friction rows x K.warmstart_t (Bullet's
-  // multibody solver restarts friction rows from zero); knee rows start at 0
+  // multibody solver restarts friction rows from zero); body rows start at 0
   F lam = mj * rowf * sel_(s0, F(K.warmstart), F(K.warmstart_t)) * L.lam;
   F hj[3] = {HJ0, HJ1, HJ2};
   c.dpp_ready10(Z, hj, &lam);                                   // one fence for all broadcast sources of this phase

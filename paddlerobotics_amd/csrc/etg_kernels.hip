@@ -11,7 +11,7 @@
 // blocks are v_mfma_f32_4x4x1.  LDS holds each lane's private per-step parameter column (no barriers anywhere);
 // the per-tick constants go straight from HBM to registers.  A reset restores the cached 500-tick settle.
 // Every step / rollout / reset kernel has compile-time variants picked per launch (LAUNCH16 / LAUNCH4): flat ground
-// vs heightfield, knee contact rows, and PLAIN (the default robot layer with its unused options compiled out).
+// vs heightfield, body contacts, and PLAIN (the default robot layer with its unused options compiled out).
 #include <hip/hip_runtime.h>
 
 #include <string>
@@ -805,7 +805,7 @@ struct GpuCtx16 {
     heightfield_finish(K, tap, h, nx, ny, nz);
   }
 };
-// KNEE: the knee contact rows of EtgConfig.body_contacts (heightfield kernels only) are compiled in.
+// KNEE: the body contacts of EtgConfig.body_contacts 1 / 2 (etg_core16.h) are compiled in; SLOTB_LDS: see kSlotBLds.
 // PLAIN: the default robot layer -- POSITION control, no action filter / interpolation, no torque limit, no command
 // clip, no external force (plain_config) -- with those options compiled out: their never-taken branches and the
 // registers they pin cost the step kernels ~3 % (measured A/B), so the common configuration gets its own instantiation.
