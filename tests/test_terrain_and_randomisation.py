@@ -577,3 +577,29 @@ def test_a_robot_that_blew_up_does_not_take_the_heightfield_lookup_with_it(lanes
         assert not np.isfinite(sim.get_state()).all()
         _, _, done, _ = sim.step(np.zeros((n, 12), dtype=np.float32))
         assert np.asarray(done).astype(bool).all()
+
+
+def test_emulated_body_paths_leave_a_robot_bit_identical():
+    """The 16-lane tick takes its body-row paths when ANY robot of the wave has a body sphere inside the margin / a loaded body
+    normal: a robot without such rows must come out bit-identical whichever path its wave takes, and a converged robot must sit
+    through its neighbours' extra sweeps unchanged.  The emulation runs one robot per "wave", so the wave-uniform tests are forced
+    (EmuSim.set_force_body) and extra sweeps appended (set_extra_sweeps): same states and rewards, bit for bit, on the skating
+    gait of configs[1] (knee spheres inside the margin on half of the ticks, loaded on a tenth)."""
+    from tests.emu.emu import EmuSim
+    n = 6
+    W, B = _params(n, seed=3)
+    runs = {}
+    try:
+        for tag, fb, ex in (("plain", 0, 0), ("forced", 1, 0), ("forced+3", 1, 3)):
+            EmuSim.set_force_body(fb); EmuSim.set_extra_sweeps(ex)
+            emu = EmuSim(A.default_config(n), lanes=16)
+            emu.set_params(etg_w=W, etg_b=B)
+            emu.reset()
+            rews = []
+            for k in range(40):
+                rews.append(emu.step(np.zeros((n, 12)))[1].copy())
+            runs[tag] = (emu.get_state(), np.stack(rews))
+    finally:
+        EmuSim.set_force_body(0); EmuSim.set_extra_sweeps(0)
+    for tag in ("forced", "forced+3"):
+        assert np.array_equal(runs["plain"][0], runs[tag][0]) and np.array_equal(runs["plain"][1], runs[tag][1]), tag
