@@ -28,10 +28,14 @@ tot = R[:, :, 16]
 print("body_contacts", bc, "| control steps %d..%d after reset, all %d waves" % (first, first + nsamp - 1, R.shape[1]))
 print("cycles per control step and wave: mean %.0f  median %.0f  p90 %.0f  p99 %.0f  max %.0f  | mean over steps of the slowest wave %.0f (%.1f us at 2.4 GHz)" % (
     tot.mean(), np.median(tot), np.percentile(tot, 90), np.percentile(tot, 99), tot.max(), tot.max(1).mean(), tot.max(1).mean() / 2400))
-worst = np.stack([R[s, np.argmax(tot[s])] for s in range(nsamp)]).mean(0)
+worst = np.stack([R[s, np.argmax(tot[s])] for s in range(nsamp)]).mean(0)    # the slowest wave of EVERY step (what a Gym step waits for)
 mean = R.mean((0, 1))
-print("  %-52s %12s %12s" % ("cycles per control step", "mean wave", "slowest wave"))
+wsum = tot.sum(0)                                                                # per wave over all sampled steps (what a fused launch waits for)
+fused = R[:, np.argmax(wsum)].mean(0)
+print("the wave with the largest total over the %d steps: %.0f cycles per step (%.2f x the mean wave); p90 of the waves' totals %.2f x" % (
+    nsamp, wsum.max() / nsamp, wsum.max() / wsum.mean(), np.percentile(wsum, 90) / wsum.mean()))
+print("  %-52s %12s %14s %16s" % ("cycles per control step", "mean wave", "slowest / step", "slowest in total"))
 for k in range(13):
-    print("  %-52s %12.0f %12.0f" % (names[k], mean[k], worst[k]))
-print("  %-52s %12.0f %12.0f" % ("outside ticks", mean[16] - mean[:13].sum(), worst[16] - worst[:13].sum()))
-print("  %-52s %12.0f %12.0f" % ("total", mean[16], worst[16]))
+    print("  %-52s %12.0f %14.0f %16.0f" % (names[k], mean[k], worst[k], fused[k]))
+print("  %-52s %12.0f %14.0f %16.0f" % ("outside ticks", mean[16] - mean[:13].sum(), worst[16] - worst[:13].sum(), fused[16] - fused[:13].sum()))
+print("  %-52s %12.0f %14.0f %16.0f" % ("total", mean[16], worst[16], fused[16]))
