@@ -1,6 +1,6 @@
 """Per-phase cycle breakdown of k_step16 on the walking workload of configs[1] (debug build with -DETG_PROFILE_PHASES: gpurun_variants/lib_prof.so).
 The kernel reports the counters of robot 0's wave; to sample several waves the population is rotated between runs.
-usage: phase_profile2.py [body_contacts] [first_step] [n_samples]"""
+usage: phase_profile2.py [body_contacts] [first_step] [n_samples] [hf]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -12,11 +12,14 @@ bc = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 first = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 nsamp = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 N = 4096
+hf_kw = {}
+if len(sys.argv) > 4 and sys.argv[4] == "hf":      # BASELINE config 5's terrain
+    hf_kw = dict(task="heightfield", heightfield=dict(heights=np.random.default_rng(0).uniform(0.0, 0.05, size=(256, 256)).astype(np.float32), cell=0.05, origin=(-6.4, -6.4)))
 w, b = bench.etg_population(N, 0, "cuda:0")
 names = ["integration + ring + PD + trig + link inertias", "RNEA", "CRBA / H^-1 / P", "Schur + LDL^T + solve", "unconstrained velocity",
          "contact rows + Z (+ body candidates)", "Delassus rows", "row velocities + warm start", "PGS sweeps (feet + body normals)", "apply impulses",
          "body normal columns (Ak)", "body friction phases", "body friction build (build_b)"]
-env = make_env("Quadrupedal", num_envs=N, device="cuda:0", lanes_per_robot=16, body_contacts=bc)
+env = make_env("Quadrupedal", num_envs=N, device="cuda:0", lanes_per_robot=16, body_contacts=bc, **hf_kw)
 env.reset(ETG_w=w, ETG_b=b)
 for _ in range(first): env.step(None)
 rows = []
