@@ -480,8 +480,10 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   // ticks with a sphere inside the margin ever load it -- but everything the build reads, ~100 registers of leg geometry,
   // Schur factor and unconstrained velocities, then stays alive through the sweeps: the closed-loop kernels spilled 140 dwords
   // per lane to scratch memory, and a launch lasts as long as its SLOWEST wave, whose ticks all build the rows anyway:
-  // profiles/r05_ab_experiments.txt section 3.)  The rows' velocity `u2` is rebuilt from the current impulses at every friction
-  // phase (not tracked through the other phases).
+  // profiles/r05_ab_experiments.txt section 3.)  The rows' velocity `u2` is made once, before the first sweep, and then TRACKED:
+  // every impulse change of every phase is applied to it as well (one more broadcast-FMA per row, in a wait state the row's own
+  // broadcast needs anyway: GpuCtx16::pgs_normals_body2).  Rebuilding it at every friction phase instead (24 broadcast-FMAs per
+  // sweep) cost the slowest wave 12 % of its sweep: profiles/r05_ab_experiments.txt section 11.
   F Z2[6] = {zero, zero, zero, zero, zero, zero}, hj2[3] = {zero, zero, zero};
   // The 32 Delassus columns of the second rows -- BA[lp][e]: second row x (n, t1, t2, body n) of leg lp; BB[lp][t]: second row x
   // second rows of leg lp; AT[lp][t]: FIRST row x second rows of leg lp -- live from the build to the end of the tick.  In the
@@ -600,6 +602,30 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   auto solve = [&](auto pyramid_tag) {
     constexpr bool pyramid = decltype(pyramid_tag)::value;
     F iAqe = iAq, c0qe = c0q;
+    // the second rows' columns as the sweeps use them -- Bn: second row x the 8 normal rows (feet, then body); Bt: x the feet's
+    // friction rows (t1, t2 of leg 0, ...); BBr / ATr: the body pairs' own -- and the second rows' velocity under the impulses
+    // the sweeps start from (warm-started foot normals; lam2 = 0)
+    F Bn[8], Bt[8], BBr[4][2], ATr[4][2], u2 = zero;
+#pragma unroll
+    for (int k = 0; k < 8; k++) Bn[k] = Bt[k] = zero;
+#pragma unroll
+    for (int lp = 0; lp < 4; lp++) BBr[lp][0] = BBr[lp][1] = ATr[lp][0] = ATr[lp][1] = zero;
+    if constexpr (body) {
+      F BA[16];
+#pragma unroll
+      for (int k = 0; k < 16; k++) BA[k] = b_lds ? c.slotb_ld(k) : sb[k];
+#pragma unroll
+      for (int lp = 0; lp < 4; lp++) {
+        Bn[lp] = BA[4 * lp]; Bn[4 + lp] = BA[4 * lp + 3];
+        Bt[2 * lp] = BA[4 * lp + 1]; Bt[2 * lp + 1] = BA[4 * lp + 2];
+#pragma unroll
+        for (int t = 0; t < 2; t++) {
+          BBr[lp][t] = b_lds ? c.slotb_ld(16 + 2 * lp + t) : sb[16 + 2 * lp + t];
+          ATr[lp][t] = b_lds ? c.slotb_ld(24 + 2 * lp + t) : sb[24 + 2 * lp + t];
+        }
+      }
+      u2 = c.row2_velocity(u2s, lam, BA, lam2, &BBr[0][0]);
+    }
     // which of the 12 joint rows exist for SOME robot of the wave: one wave-uniform bit each, made once per tick (the sweeps
     // test a scalar bit; twelve lane-mask tests per sweep cost ~240 cycles of a 840-cycle sweep)
     unsigned jrows = 0u;
@@ -656,10 +682,16 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
 #pragma unroll
       for (int k = 0; k < 6; k++) du = du + Z[k] * (zl[k] - zl0[k]);
       u = u + du;
+      if (body) {   // and so do the second rows
+        F du2 = hj2[0] * c.qb(w, 0) + hj2[1] * c.qb(w, 1) + hj2[2] * c.qb(w, 2);
+#pragma unroll
+        for (int k = 0; k < 6; k++) du2 = du2 + Z2[k] * (zl[k] - zl0[k]);
+        u2 = u2 + du2;
+      }
     };
     // (4) the friction pairs of the body contacts, after the feet's (Bullet: every normal row, then every friction row): the
-    // same rule on the second row set, with the coefficient K.body_mu and the leg's body normal impulse (aux lane).  Skipped --
-    // and the rows not even built -- while no body normal of the wave carries load.
+    // same rule on the second row set, with the coefficient K.body_mu and the leg's body normal impulse (aux lane).  Skipped
+    // while no body normal of the wave carries load.
     auto body_friction = [&]() {
       c.phase_p(8);
       const F lbn = c.qb(lam, 3);
@@ -668,29 +700,6 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
       // any robot: skipped)
       const auto gm = c.body_mask(grip2);
       if (!c.mask_any(gm)) return;
-      // velocity of the second rows under the current impulses: first rows (16 columns), second rows (8), joint rows
-      F BA[16], BB[4][2], AT[4][2];
-#pragma unroll
-      for (int k = 0; k < 16; k++) BA[k] = b_lds ? c.slotb_ld(k) : sb[k];
-#pragma unroll
-      for (int lp = 0; lp < 4; lp++)
-#pragma unroll
-        for (int t = 0; t < 2; t++) {
-          BB[lp][t] = b_lds ? c.slotb_ld(16 + 2 * lp + t) : sb[16 + 2 * lp + t];
-          AT[lp][t] = b_lds ? c.slotb_ld(24 + 2 * lp + t) : sb[24 + 2 * lp + t];
-        }
-      F u2 = c.row2_velocity(u2s, lam, BA, lam2, &BB[0][0]);
-      if (joints) {
-        const F slq = sgn * lamq;
-        F zq[6];
-#pragma unroll
-        for (int k = 0; k < 6; k++) zq[k] = -(slq * zj[k]);
-        c.sum16x6(zq);
-        F du2 = hj2[0] * c.qb(slq, 0) + hj2[1] * c.qb(slq, 1) + hj2[2] * c.qb(slq, 2);
-#pragma unroll
-        for (int k = 0; k < 6; k++) du2 = du2 + Z2[k] * zq[k];
-        u2 = u2 + du2;
-      }
       const F lim2 = F(K.body_mu) * lbn;
       if constexpr (Ctx::kAsmSweep && !pyramid) {
         // the device build's hand-scheduled pair (GpuCtx16::pgs_pair_body): the same arithmetic as the C++ below, the grip
@@ -699,7 +708,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
 #pragma unroll
         for (int lp = 0; lp < 4; lp++) {
           if (!c.mask_leg(gm, lp)) continue;
-          c.pgs_pair_body(lam2, u2, u, iA2g, lim2g, AT[lp][0], AT[lp][1], BB[lp][0], BB[lp][1], mt[lp], lp);
+          c.pgs_pair_body(lam2, u2, u, iA2g, lim2g, ATr[lp][0], ATr[lp][1], BBr[lp][0], BBr[lp][1], mt[lp], lp);
         }
         c.phase_p(11);
         return;
@@ -718,8 +727,8 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
         }
         dl = sel_(grip2, dl, zero);
         const F b1 = c.rbcast(dl, 4 * lp + 1), b2 = c.rbcast(dl, 4 * lp + 2);
-        u = u + AT[lp][0] * b1 + AT[lp][1] * b2;
-        u2 = u2 + BB[lp][0] * b1 + BB[lp][1] * b2;
+        u = u + ATr[lp][0] * b1 + ATr[lp][1] * b2;
+        u2 = u2 + BBr[lp][0] * b1 + BBr[lp][1] * b2;
         lam2 = lam2 + mt[lp] * dl;
       }
       c.phase_p(11);
@@ -729,12 +738,16 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
       if constexpr (Ctx::kAsmSweep && !pyramid) {
         // the device build's hand-scheduled sweep (GpuCtx16::pgs_normals / pgs_tangents_disc state why): the same arithmetic
         // as the C++ below; the friction skip is folded into the per-lane constants of the friction phase
-        if constexpr (body) c.pgs_normals_body(lam, u, iAe, c0e, A, Ak, mk0, mk3);
+        if constexpr (body) c.pgs_normals_body2(lam, u, u2, iAe, c0e, A, Ak, mk0, mk3, Bn);
         else c.pgs_normals(lam, u, iAe, c0e, A, mk0);
         const F lnq = c.qb(lam, 0);
         const auto grip = lnq > zero;
-        c.pgs_tangents_disc(lam, u, sel_(grip, iAe, zero), sel_(grip, mue * lnq, F(1e30f)), A, mt);
-        if constexpr (body) body_friction();
+        if constexpr (body) {
+          c.pgs_tangents_disc2(lam, u, u2, sel_(grip, iAe, zero), sel_(grip, mue * lnq, F(1e30f)), A, mt, Bt);
+          body_friction();
+        } else {
+          c.pgs_tangents_disc(lam, u, sel_(grip, iAe, zero), sel_(grip, mue * lnq, F(1e30f)), A, mt);
+        }
         return;
       }
       // (2) normal rows: ln = max(0, lam - (u - tgt)/A), as a change: max(-lam, (tgt - u)/A); the owner's lam update sits
@@ -745,6 +758,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
         lam = lam + mk0[lp] * dln;
         const F b = c.rbcast(dln, 4 * lp);
         u = u + A[lp][0] * b;
+        if (body) u2 = u2 + Bn[lp] * b;
       }
       if (body) {   // the body normal rows: lk = max(0, lk - (u - tgt)/A)
 #pragma unroll
@@ -753,6 +767,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
           lam = lam + mk3[lp] * dlk;
           F bk = c.rbcast(dlk, 4 * lp + 3);
           u = u + Ak[lp] * bk;
+          u2 = u2 + Bn[4 + lp] * bk;
         }
       }
       // (3) friction rows t1, t2 of a foot as ONE block: each of the two lanes computes its row's candidate from the same
@@ -776,6 +791,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
         dl = sel_(grip, dl, zero);
         const F b1 = c.rbcast(dl, 4 * lp + 1), b2 = c.rbcast(dl, 4 * lp + 2);
         u = u + A[lp][1] * b1 + A[lp][2] * b2;
+        if (body) u2 = u2 + Bt[2 * lp] * b1 + Bt[2 * lp + 1] * b2;
         lam = lam + mt[lp] * dl;
       }
       if constexpr (body) body_friction();
@@ -802,7 +818,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
           // convergence afterwards (two selects, three with joint rows) -- the same result bit for bit as zeroed constants,
           // but the per-robot mask (ballot -> shift -> and -> compare: a 6-deep chain) is only needed AFTER the next sweep,
           // so it leaves the sweep's critical path; the wave's exit test is the compare's wave mask alone.
-          const F lam0 = lam, u0 = u, lamq0 = lamq, lam20 = lam2;
+          const F lam0 = lam, u0 = u, lamq0 = lamq, lam20 = lam2, u20 = u2;
           pgs_sweep();
           it++;
           lam = sel_(frozen, lam0, lam);
@@ -811,6 +827,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
           auto moved = joints ? ((fabsf_(lam - lam0) > tol) || (fabsf_(lamq - lamq0) > tolq)) : (fabsf_(lam - lam0) > tol);
           if (body) {   // the second rows (zeros until built: 0 > 0 is false)
             lam2 = sel_(frozen, lam20, lam2);
+            u2 = sel_(frozen, u20, u2);
             moved = moved || (fabsf_(lam2 - lam20) > F(K.res_sqrt) * iA2);
           }
           more = c.wave_any(moved) && it < K.iters;

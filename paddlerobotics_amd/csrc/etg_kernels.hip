@@ -684,6 +684,37 @@ struct GpuCtx16 {
           [n0] "v"(mk3[0]), [n1] "v"(mk3[1]), [n2] "v"(mk3[2]), [n3] "v"(mk3[3]));
   }
 #undef ETG_ROW
+  // The sweeps of a tick with body rows track the velocity `u2` of the SECOND row set (the body contacts' friction rows,
+  // etg_core16.h: finish_tick) through every phase: each impulse change is applied to u2 as well, by one more broadcast-FMA
+  // that sits in a wait state the row needs anyway (the change of row i is applied to u2 while row i + 1 waits for its own
+  // broadcast: the two changes alternate between the registers dA / dB).  8 rows: 41 issue slots, as many as without u2.
+  __device__ __forceinline__ void pgs_normals_body2(float& lam, float& u, float& u2, float iA, float c0, const float (&A)[4][3],
+                                                    const float* Ak, const float* mk0, const float* mk3, const float* bn) const {
+    float t, dA, dB;
+#define ETG_ROW2(D, LP, AOP, MOP, FILL)                                            \
+    "v_fma_f32 %[t], -%[u], %[iA], %[c0]\n"                                        \
+    "v_max_f32_e64 %[" D "], -%[lam], %[t]\n"                                      \
+    "v_fmac_f32_e32 %[lam], %[" MOP "], %[" D "]\n"                                \
+    FILL                                                                           \
+    "v_fmac_f32_dpp %[u], %[" D "], %[" AOP "] row_newbcast:" #LP ETG_DPPC
+#define ETG_U2(D, LP, BOP) "v_fmac_f32_dpp %[u2], %[" D "], %[" BOP "] row_newbcast:" #LP ETG_DPPC
+    asm(ETG_ROW2("dA", 0, "a0", "m0", "s_nop 0\n")
+        ETG_ROW2("dB", 4, "a1", "m1", ETG_U2("dA", 0, "b0"))
+        ETG_ROW2("dA", 8, "a2", "m2", ETG_U2("dB", 4, "b1"))
+        ETG_ROW2("dB", 12, "a3", "m3", ETG_U2("dA", 8, "b2"))
+        ETG_ROW2("dA", 3, "k0", "n0", ETG_U2("dB", 12, "b3"))
+        ETG_ROW2("dB", 7, "k1", "n1", ETG_U2("dA", 3, "b4"))
+        ETG_ROW2("dA", 11, "k2", "n2", ETG_U2("dB", 7, "b5"))
+        ETG_ROW2("dB", 15, "k3", "n3", ETG_U2("dA", 11, "b6"))
+        ETG_U2("dB", 15, "b7")
+        : [lam] "+v"(lam), [u] "+v"(u), [u2] "+v"(u2), [t] "=&v"(t), [dA] "=&v"(dA), [dB] "=&v"(dB)
+        : [iA] "v"(iA), [c0] "v"(c0), [a0] "v"(A[0][0]), [a1] "v"(A[1][0]), [a2] "v"(A[2][0]), [a3] "v"(A[3][0]),
+          [m0] "v"(mk0[0]), [m1] "v"(mk0[1]), [m2] "v"(mk0[2]), [m3] "v"(mk0[3]),
+          [k0] "v"(Ak[0]), [k1] "v"(Ak[1]), [k2] "v"(Ak[2]), [k3] "v"(Ak[3]),
+          [n0] "v"(mk3[0]), [n1] "v"(mk3[1]), [n2] "v"(mk3[2]), [n3] "v"(mk3[3]),
+          [b0] "v"(bn[0]), [b1] "v"(bn[1]), [b2] "v"(bn[2]), [b3] "v"(bn[3]), [b4] "v"(bn[4]), [b5] "v"(bn[5]), [b6] "v"(bn[6]), [b7] "v"(bn[7]));
+#undef ETG_ROW2
+  }
   // friction pairs of the four feet on the disc: iA / lim already carry the "normal impulse > 0" condition (iA = 0 and
   // lim = 1e30 where it does not hold: the candidate is the current impulse, the scale 1, the change an exact zero)
   __device__ __forceinline__ void pgs_tangents_disc(float& lam, float& u, float iA, float lim, const float (&A)[4][3], const float* mt) const {
@@ -707,6 +738,37 @@ struct GpuCtx16 {
         : [iA] "v"(iA), [lim] "v"(lim), [a01] "v"(A[0][1]), [a02] "v"(A[0][2]), [a11] "v"(A[1][1]), [a12] "v"(A[1][2]), [a21] "v"(A[2][1]),
           [a22] "v"(A[2][2]), [a31] "v"(A[3][1]), [a32] "v"(A[3][2]), [m0] "v"(mt[0]), [m1] "v"(mt[1]), [m2] "v"(mt[2]), [m3] "v"(mt[3]));
 #undef ETG_PAIR
+  }
+  // the same with `u2` tracked (pgs_normals_body2): the two changes of pair p reach u2 in the two wait states pair p + 1 spends
+  // between its squares and their exchange
+  __device__ __forceinline__ void pgs_tangents_disc2(float& lam, float& u, float& u2, float iA, float lim, const float (&A)[4][3],
+                                                     const float* mt, const float* bt) const {
+    float lc, sq, sc, dA, dB;
+#define ETG_PAIR2(D, R1, R2, A1, A2, MOP, FILL)                                                        \
+    "v_fma_f32 %[lc], -%[u], %[iA], %[lam]\n"                                                          \
+    "v_fmaak_f32 %[sq], %[lc], %[lc], 0x0da24260\n"                                                    \
+    FILL                                                                                               \
+    "v_add_f32_dpp %[sq], %[sq], %[sq] quad_perm:[0,2,1,3]" ETG_DPPC                                   \
+    "v_rsq_f32_e32 %[sq], %[sq]\n"                                                                     \
+    "s_nop 0\n"                                                                                        \
+    "v_mul_f32_e32 %[sc], %[lim], %[sq]\n"                                                             \
+    "v_min_f32_e32 %[sc], 1.0, %[sc]\n"                                                                \
+    "v_fma_f32 %[" D "], %[lc], %[sc], -%[lam]\n"                                                      \
+    "v_fmac_f32_e32 %[lam], %[" MOP "], %[" D "]\n"                                                    \
+    "s_nop 0\n"                                                                                        \
+    "v_fmac_f32_dpp %[u], %[" D "], %[" A1 "] row_newbcast:" #R1 ETG_DPPC                              \
+    "v_fmac_f32_dpp %[u], %[" D "], %[" A2 "] row_newbcast:" #R2 ETG_DPPC
+    asm(ETG_PAIR2("dA", 1, 2, "a01", "a02", "m0", "s_nop 1\n")
+        ETG_PAIR2("dB", 5, 6, "a11", "a12", "m1", ETG_U2("dA", 1, "b0") ETG_U2("dA", 2, "b1"))
+        ETG_PAIR2("dA", 9, 10, "a21", "a22", "m2", ETG_U2("dB", 5, "b2") ETG_U2("dB", 6, "b3"))
+        ETG_PAIR2("dB", 13, 14, "a31", "a32", "m3", ETG_U2("dA", 9, "b4") ETG_U2("dA", 10, "b5"))
+        ETG_U2("dB", 13, "b6") ETG_U2("dB", 14, "b7")
+        : [lam] "+v"(lam), [u] "+v"(u), [u2] "+v"(u2), [lc] "=&v"(lc), [sq] "=&v"(sq), [sc] "=&v"(sc), [dA] "=&v"(dA), [dB] "=&v"(dB)
+        : [iA] "v"(iA), [lim] "v"(lim), [a01] "v"(A[0][1]), [a02] "v"(A[0][2]), [a11] "v"(A[1][1]), [a12] "v"(A[1][2]), [a21] "v"(A[2][1]),
+          [a22] "v"(A[2][2]), [a31] "v"(A[3][1]), [a32] "v"(A[3][2]), [m0] "v"(mt[0]), [m1] "v"(mt[1]), [m2] "v"(mt[2]), [m3] "v"(mt[3]),
+          [b0] "v"(bt[0]), [b1] "v"(bt[1]), [b2] "v"(bt[2]), [b3] "v"(bt[3]), [b4] "v"(bt[4]), [b5] "v"(bt[5]), [b6] "v"(bt[6]), [b7] "v"(bt[7]));
+#undef ETG_PAIR2
+#undef ETG_U2
   }
   // ONE friction pair of a body contact (second rows of leg lp, on its t1 / t2 lanes): the pair of pgs_tangents_disc on (lam2, u2),
   // its two changes applied to the second rows' velocity u2 AND to the first rows' u (etg_core16.h: body_friction)

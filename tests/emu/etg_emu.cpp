@@ -231,6 +231,8 @@ template <bool FLAT, bool KNEE = false, bool PLAIN = false> struct EmuCtx16T : E
   template <class A> void pgs_tangents_disc(F16&, F16&, F16, F16, const A&, const F16*) const {}
   void pgs_pair_body(F16&, F16&, F16&, F16, F16, F16, F16, F16, F16, F16, int) const {}
   template <class A> void pgs_normals_body(F16&, F16&, F16, F16, const A&, const F16*, const F16*, const F16*) const {}
+  template <class A> void pgs_normals_body2(F16&, F16&, F16&, F16, F16, const A&, const F16*, const F16*, const F16*, const F16*) const {}
+  template <class A> void pgs_tangents_disc2(F16&, F16&, F16&, F16, F16, const A&, const F16*, const F16*) const {}
   EmuCtx16T(int e, int n, const float* p) { env = e; N = n; parp = p; }
 };
 
