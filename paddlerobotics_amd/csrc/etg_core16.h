@@ -692,9 +692,8 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
     // (4) the friction pairs of the body contacts, after the feet's (Bullet: every normal row, then every friction row): the
     // same rule on the second row set, with the coefficient K.body_mu and the leg's body normal impulse (aux lane).  Skipped
     // while no body normal of the wave carries load.
-    auto body_friction = [&]() {
+    auto body_friction = [&](F lbn) {     // lbn: the leg's body normal impulse (aux lane) on its four lanes
       c.phase_p(8);
-      const F lbn = c.qb(lam, 3);
       const auto grip2 = lbn > zero;
       // which legs carry a loaded body contact for SOME robot of the wave (the pairs of the other legs would change nothing for
       // any robot: skipped)
@@ -738,14 +737,16 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
       if constexpr (Ctx::kAsmSweep && !pyramid) {
         // the device build's hand-scheduled sweep (GpuCtx16::pgs_normals / pgs_tangents_disc state why): the same arithmetic
         // as the C++ below; the friction skip is folded into the per-lane constants of the friction phase
-        if constexpr (body) c.pgs_normals_body2(lam, u, u2, iAe, c0e, A, Ak, mk0, mk3, Bn);
-        else c.pgs_normals(lam, u, iAe, c0e, A, mk0);
-        const F lnq = c.qb(lam, 0);
-        const auto grip = lnq > zero;
         if constexpr (body) {
+          F lnq, lbn;
+          c.pgs_normals_body2(lam, u, u2, iAe, c0e, A, Ak, mk0, mk3, Bn, lnq, lbn);
+          const auto grip = lnq > zero;
           c.pgs_tangents_disc2(lam, u, u2, sel_(grip, iAe, zero), sel_(grip, mue * lnq, F(1e30f)), A, mt, Bt);
-          body_friction();
+          body_friction(lbn);
         } else {
+          c.pgs_normals(lam, u, iAe, c0e, A, mk0);
+          const F lnq = c.qb(lam, 0);
+          const auto grip = lnq > zero;
           c.pgs_tangents_disc(lam, u, sel_(grip, iAe, zero), sel_(grip, mue * lnq, F(1e30f)), A, mt);
         }
         return;
@@ -794,7 +795,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
         if (body) u2 = u2 + Bt[2 * lp] * b1 + Bt[2 * lp + 1] * b2;
         lam = lam + mt[lp] * dl;
       }
-      if constexpr (body) body_friction();
+      if constexpr (body) body_friction(c.qb(lam, 3));
     };
     if (K.res_thr > 0.0f) {
       // EtgConfig.solver_residual (etgsim.h): sweep until the robot's largest squared row residual
@@ -802,7 +803,10 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
       // ((lam - lam0) A_rr)^2 > thr  <=>  |lam - lam0| > sqrt(thr) / A_rr: one subtraction and one compare per lane and sweep
       // against a tolerance made once per tick (inactive rows: iA = 0, no change, 0 > 0 is false); "any row of my robot"
       // comes from the compare's wave mask (robot_any), not from a 4-stage lane reduction
-      const F tol = F(K.res_sqrt) * iA;
+      // (the votes are taken compare by compare and OR-ed as wave masks: a vote on `a || b` goes through a 0/1 register and a
+      // second compare -- three issue slots per sweep)
+      F tol = F(K.res_sqrt) * iA, tol2 = F(K.res_sqrt) * iA2;
+      if (body) { c.opaque(tol); c.opaque(tol2); }                    // (kept, not re-multiplied in every sweep)
       const F tolq = F(K.res_sqrt) * iAq;
       int it = 0;
       bool more;
@@ -824,14 +828,22 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
           lam = sel_(frozen, lam0, lam);
           u = sel_(frozen, u0, u);
           if (joints) lamq = sel_(frozen, lamq0, lamq);
-          auto moved = joints ? ((fabsf_(lam - lam0) > tol) || (fabsf_(lamq - lamq0) > tolq)) : (fabsf_(lam - lam0) > tol);
-          if (body) {   // the second rows (zeros until built: 0 > 0 is false)
+          auto moved = c.vote(fabsf_(lam - lam0) > tol);
+          if (joints) moved = c.vote_or(moved, c.vote(fabsf_(lamq - lamq0) > tolq));
+          if (body) {   // the second rows (inactive rows: iA2 = 0, no change, 0 > 0 is false)
             lam2 = sel_(frozen, lam20, lam2);
             u2 = sel_(frozen, u20, u2);
-            moved = moved || (fabsf_(lam2 - lam20) > F(K.res_sqrt) * iA2);
+            moved = c.vote_or(moved, c.vote(fabsf_(lam2 - lam20) > tol2));
           }
-          more = c.wave_any(moved) && it < K.iters;
-          frozen = !c.robot_any(moved);
+          if constexpr (body) {
+            more = c.vote_wave(moved);
+            if (more) { c.fence(); more = it < K.iters; }               // two scalar branches (merged into one condition the two tests
+                                                                        // go through lane masks: 7 scalar instructions instead of 4;
+                                                                        // the toe-spheres tick's unrolled exits lose 1 % with it)
+          } else {
+            more = c.vote_wave(moved) && it < K.iters;
+          }
+          frozen = !c.vote_robot(moved);
           return;
         }
         static_assert(!body || lazy, "the eager-freeze A/B variant predates the body friction rows");

@@ -93,12 +93,12 @@ struct GpuCtx {
     acc[0] = v[0]; acc[1] = v[1]; acc[2] = v[2]; acc[3] = v[3];
   }
   __device__ __forceinline__ bool lane_is(int j) const { return lane == j; }
-  __device__ __forceinline__ bool any(bool b) const { return __any(b); }
+  __device__ __forceinline__ bool any(bool b) const { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
   __device__ __forceinline__ unsigned uniform_bits(unsigned v) const { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }   // a wave-uniform value, kept in an SGPR
-  __device__ __forceinline__ bool wave_any(bool b) const { return __any(b); }   // "does any robot of the wave need another sweep?"
+  __device__ __forceinline__ bool wave_any(bool b) const { return __builtin_amdgcn_ballot_w64(b) != 0ull; }   // "does any robot of the wave need another sweep?"
   // "does any lane of MY robot (quad) see b?" from the wave mask of the compare: two ANDs with this lane's quad field
   __device__ __forceinline__ bool robot_any(bool b) const {
-    const unsigned long long m = __ballot(b);
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(b);
     const unsigned sh = (unsigned)(threadIdx.x & 28);           // first lane of the quad inside its 32-lane half
     const unsigned f = 0xFu << sh;
     return ((threadIdx.x & 32) ? ((unsigned)(m >> 32) & f) : ((unsigned)m & f)) != 0u;
@@ -515,26 +515,38 @@ struct GpuCtx16 {
   __device__ __forceinline__ float jointf() const { return sub < 3 ? 1.0f : 0.0f; }
   __device__ __forceinline__ bool sub_is(int j) const { return sub == j; }
   __device__ __forceinline__ bool leg_is(int j) const { return leg == j; }
-  __device__ __forceinline__ bool any(bool b) const { return __any(b); }
+  __device__ __forceinline__ bool any(bool b) const { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
   // the wave-uniform tests of the body paths work on the wave mask of a compare: "any lane", "any lane of leg lp (in any robot
   // of the wave)" are one scalar AND against a constant each
 #ifdef ETG_FORCE_BODY   // A/B build variant: every tick takes the body-row paths (what the emulation's force_body knob does)
   __device__ __forceinline__ bool any_body(bool) const { return true; }
-  __device__ __forceinline__ unsigned long long body_mask(bool) const { return ~0ull; }
+  __device__ __forceinline__ unsigned body_mask(bool) const { return ~0u; }
 #else
-  __device__ __forceinline__ bool any_body(bool b) const { return __any(b); }
-  __device__ __forceinline__ unsigned long long body_mask(bool b) const { return __ballot(b); }
+  __device__ __forceinline__ bool any_body(bool b) const { return __builtin_amdgcn_ballot_w64(b) != 0ull; }
+  // the wave mask folded to 32 bits (a leg's four lanes sit at the same bits of both halves): a leg's test is ONE s_and_b32
+  // against a 32-bit literal that sets SCC (a 64-bit mask needs two ANDs and a compare)
+  __device__ __forceinline__ unsigned body_mask(bool b) const {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(b);
+    return (unsigned)m | (unsigned)(m >> 32);
+  }
 #endif
-  __device__ __forceinline__ bool mask_any(unsigned long long m) const { return m != 0ull; }
-  __device__ __forceinline__ bool mask_leg(unsigned long long m, int lp) const { return (m & (0x000F000F000F000Full << (4 * lp))) != 0ull; }
+  __device__ __forceinline__ bool mask_any(unsigned m) const { return m != 0u; }
+  __device__ __forceinline__ bool mask_leg(unsigned m, int lp) const { return (m & (0x000F000Fu << (4 * lp))) != 0u; }
   __device__ __forceinline__ unsigned uniform_bits(unsigned v) const { return (unsigned)__builtin_amdgcn_readfirstlane((int)v); }   // a wave-uniform value, kept in an SGPR
-  __device__ __forceinline__ bool wave_any(bool b) const { return __any(b); }   // "does any robot of the wave need another sweep?"
+  // (the builtin on the i1 itself: HIP's __any / __ballot take an int, and the compare's wave mask went through a
+  // v_cndmask 0/1 + v_cmp_ne + a wait state on its way in -- three issue slots per sweep)
+  __device__ __forceinline__ bool wave_any(bool b) const { return __builtin_amdgcn_ballot_w64(b) != 0ull; }   // "does any robot of the wave need another sweep?"
   // "does any lane of MY robot (16-lane row) see b?" from the wave mask of the compare
-  __device__ __forceinline__ bool robot_any(bool b) const {
-    const unsigned long long m = __ballot(b);
+  __device__ __forceinline__ bool vote_robot(unsigned long long m) const {
     const unsigned f = (tid & 16) ? 0xFFFF0000u : 0x0000FFFFu;
     return ((tid & 32) ? ((unsigned)(m >> 32) & f) : ((unsigned)m & f)) != 0u;
   }
+  __device__ __forceinline__ bool robot_any(bool b) const { return vote_robot(__builtin_amdgcn_ballot_w64(b)); }
+  // the residual rule's votes (etg_core16.h: sweep_and_test): one wave mask per compare, OR-ed as scalars
+  __device__ __forceinline__ unsigned long long vote(bool b) const { return __builtin_amdgcn_ballot_w64(b); }
+  __device__ __forceinline__ unsigned long long vote_or(unsigned long long a, unsigned long long b) const { return a | b; }
+  __device__ __forceinline__ bool vote_wave(unsigned long long m) const { return m != 0ull; }
+  __device__ __forceinline__ void fence() const { asm volatile(""); }   // keeps two tests two branches
   __device__ __forceinline__ int uniform_int(float a) const { return (int)a; }
   __device__ __forceinline__ float par(int k) const { return lds[k * 64]; }
   __device__ __forceinline__ float par_joint(int base) const { return lds[(base + sc) * 64]; }
@@ -688,8 +700,12 @@ struct GpuCtx16 {
   // etg_core16.h: finish_tick) through every phase: each impulse change is applied to u2 as well, by one more broadcast-FMA
   // that sits in a wait state the row needs anyway (the change of row i is applied to u2 while row i + 1 waits for its own
   // broadcast: the two changes alternate between the registers dA / dB).  8 rows: 41 issue slots, as many as without u2.
+  // The block ends with the two quad broadcasts the friction phases start from -- the leg's foot normal impulse `lnq` and body
+  // normal impulse `lbn` -- where the last rows' tails are their wait states (after the block the compiler fences each with an
+  // s_nop 1: it does not see into the asm).
   __device__ __forceinline__ void pgs_normals_body2(float& lam, float& u, float& u2, float iA, float c0, const float (&A)[4][3],
-                                                    const float* Ak, const float* mk0, const float* mk3, const float* bn) const {
+                                                    const float* Ak, const float* mk0, const float* mk3, const float* bn, float& lnq,
+                                                    float& lbn) const {
     float t, dA, dB;
 #define ETG_ROW2(D, LP, AOP, MOP, FILL)                                            \
     "v_fma_f32 %[t], -%[u], %[iA], %[c0]\n"                                        \
@@ -707,7 +723,9 @@ struct GpuCtx16 {
         ETG_ROW2("dA", 11, "k2", "n2", ETG_U2("dB", 7, "b5"))
         ETG_ROW2("dB", 15, "k3", "n3", ETG_U2("dA", 11, "b6"))
         ETG_U2("dB", 15, "b7")
-        : [lam] "+v"(lam), [u] "+v"(u), [u2] "+v"(u2), [t] "=&v"(t), [dA] "=&v"(dA), [dB] "=&v"(dB)
+        "v_mov_b32_dpp %[lnq], %[lam] quad_perm:[0,0,0,0]" ETG_DPPC
+        "v_mov_b32_dpp %[lbn], %[lam] quad_perm:[3,3,3,3]" ETG_DPPC
+        : [lam] "+v"(lam), [u] "+v"(u), [u2] "+v"(u2), [t] "=&v"(t), [dA] "=&v"(dA), [dB] "=&v"(dB), [lnq] "=&v"(lnq), [lbn] "=&v"(lbn)
         : [iA] "v"(iA), [c0] "v"(c0), [a0] "v"(A[0][0]), [a1] "v"(A[1][0]), [a2] "v"(A[2][0]), [a3] "v"(A[3][0]),
           [m0] "v"(mk0[0]), [m1] "v"(mk0[1]), [m2] "v"(mk0[2]), [m3] "v"(mk0[3]),
           [k0] "v"(Ak[0]), [k1] "v"(Ak[1]), [k2] "v"(Ak[2]), [k3] "v"(Ak[3]),

@@ -104,6 +104,11 @@ struct EmuCtx16Base {
   WaveAny wa;
   bool wave_any(B16 b) const { return wa.more(any(b)); }
   B16 robot_any(B16 b) const { const bool a = any(b); B16 r; for (int l = 0; l < 16; l++) r.v[l] = a; return r; }
+  B16 vote(B16 b) const { return b; }
+  B16 vote_or(B16 a, B16 b) const { return a || b; }
+  bool vote_wave(B16 b) const { return wave_any(b); }
+  B16 vote_robot(B16 b) const { return robot_any(b); }
+  void fence() const {}
   int env, N;
   const float* parp;
   int NL() const { return 4 * N; }
@@ -231,7 +236,7 @@ template <bool FLAT, bool KNEE = false, bool PLAIN = false> struct EmuCtx16T : E
   template <class A> void pgs_tangents_disc(F16&, F16&, F16, F16, const A&, const F16*) const {}
   void pgs_pair_body(F16&, F16&, F16&, F16, F16, F16, F16, F16, F16, F16, int) const {}
   template <class A> void pgs_normals_body(F16&, F16&, F16, F16, const A&, const F16*, const F16*, const F16*) const {}
-  template <class A> void pgs_normals_body2(F16&, F16&, F16&, F16, F16, const A&, const F16*, const F16*, const F16*, const F16*) const {}
+  template <class A> void pgs_normals_body2(F16&, F16&, F16&, F16, F16, const A&, const F16*, const F16*, const F16*, const F16*, F16&, F16&) const {}
   template <class A> void pgs_tangents_disc2(F16&, F16&, F16&, F16, F16, const A&, const F16*, const F16*) const {}
   EmuCtx16T(int e, int n, const float* p) { env = e; N = n; parp = p; }
 };
