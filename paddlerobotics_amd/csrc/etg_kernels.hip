@@ -640,7 +640,7 @@ struct GpuCtx16 {
 #define ETG_L(R, N) "v_fmac_f32_dpp %0, %1, %" #N " row_newbcast:" #R " row_mask:0xf bank_mask:0xf bound_ctrl:1\n"
     asm(ETG_L(0, 2) ETG_L(1, 3) ETG_L(2, 4) ETG_L(4, 5) ETG_L(5, 6) ETG_L(6, 7) ETG_L(8, 8) ETG_L(9, 9) ETG_L(10, 10)
         ETG_L(12, 11) ETG_L(13, 12) ETG_L(14, 13)
-        : "+v"(acc)
+        : "+&v"(acc)
         : "v"(x), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),
           "v"(a[10]), "v"(a[11]));
 #undef ETG_L
@@ -654,7 +654,8 @@ struct GpuCtx16 {
     asm(ETG_L(0, 4, 0, 6) ETG_L(1, 4, 1, 7) ETG_L(2, 4, 2, 8) ETG_L(3, 4, 3, 9) ETG_L(0, 4, 4, 10) ETG_L(1, 4, 5, 11) ETG_L(2, 4, 6, 12) ETG_L(3, 4, 7, 13)
         ETG_L(0, 4, 8, 14) ETG_L(1, 4, 9, 15) ETG_L(2, 4, 10, 16) ETG_L(3, 4, 11, 17) ETG_L(0, 4, 12, 18) ETG_L(1, 4, 13, 19) ETG_L(2, 4, 14, 20) ETG_L(3, 4, 15, 21)
         ETG_L(0, 5, 1, 22) ETG_L(1, 5, 2, 23) ETG_L(2, 5, 5, 24) ETG_L(3, 5, 6, 25) ETG_L(0, 5, 9, 26) ETG_L(1, 5, 10, 27) ETG_L(2, 5, 13, 28) ETG_L(3, 5, 14, 29)
-        : "+v"(acc), "+v"(p1), "+v"(p2), "+v"(p3)
+        : "+&v"(acc), "+&v"(p1), "+&v"(p2), "+&v"(p3)     // (early-clobber: an input holding the same VALUE as an accumulator's start --
+                                                            // y = 0 and p3 = 0 -- must not share its register: it is read after the writes)
         : "v"(x), "v"(y), "v"(a[0]), "v"(a[1]), "v"(a[2]), "v"(a[3]), "v"(a[4]), "v"(a[5]), "v"(a[6]), "v"(a[7]), "v"(a[8]), "v"(a[9]),
           "v"(a[10]), "v"(a[11]), "v"(a[12]), "v"(a[13]), "v"(a[14]), "v"(a[15]), "v"(b[0]), "v"(b[1]), "v"(b[2]), "v"(b[3]), "v"(b[4]),
           "v"(b[5]), "v"(b[6]), "v"(b[7]));
@@ -679,7 +680,7 @@ struct GpuCtx16 {
     "s_nop 0\n"                                                                    \
     "v_fmac_f32_dpp %[u], %[d], %[" AOP "] row_newbcast:" #LP ETG_DPPC
     asm(ETG_ROW(0, "a0", "m0") ETG_ROW(4, "a1", "m1") ETG_ROW(8, "a2", "m2") ETG_ROW(12, "a3", "m3")
-        : [lam] "+v"(lam), [u] "+v"(u), [t] "=&v"(t), [d] "=&v"(d)
+        : [lam] "+&v"(lam), [u] "+&v"(u), [t] "=&v"(t), [d] "=&v"(d)
         : [iA] "v"(iA), [c0] "v"(c0), [a0] "v"(A[0][0]), [a1] "v"(A[1][0]), [a2] "v"(A[2][0]), [a3] "v"(A[3][0]),
           [m0] "v"(mk0[0]), [m1] "v"(mk0[1]), [m2] "v"(mk0[2]), [m3] "v"(mk0[3]));
   }
@@ -689,7 +690,7 @@ struct GpuCtx16 {
     float t, d;
     asm(ETG_ROW(0, "a0", "m0") ETG_ROW(4, "a1", "m1") ETG_ROW(8, "a2", "m2") ETG_ROW(12, "a3", "m3")
         ETG_ROW(3, "k0", "n0") ETG_ROW(7, "k1", "n1") ETG_ROW(11, "k2", "n2") ETG_ROW(15, "k3", "n3")
-        : [lam] "+v"(lam), [u] "+v"(u), [t] "=&v"(t), [d] "=&v"(d)
+        : [lam] "+&v"(lam), [u] "+&v"(u), [t] "=&v"(t), [d] "=&v"(d)
         : [iA] "v"(iA), [c0] "v"(c0), [a0] "v"(A[0][0]), [a1] "v"(A[1][0]), [a2] "v"(A[2][0]), [a3] "v"(A[3][0]),
           [m0] "v"(mk0[0]), [m1] "v"(mk0[1]), [m2] "v"(mk0[2]), [m3] "v"(mk0[3]),
           [k0] "v"(Ak[0]), [k1] "v"(Ak[1]), [k2] "v"(Ak[2]), [k3] "v"(Ak[3]),
@@ -725,7 +726,7 @@ struct GpuCtx16 {
         ETG_U2("dB", 15, "b7")
         "v_mov_b32_dpp %[lnq], %[lam] quad_perm:[0,0,0,0]" ETG_DPPC
         "v_mov_b32_dpp %[lbn], %[lam] quad_perm:[3,3,3,3]" ETG_DPPC
-        : [lam] "+v"(lam), [u] "+v"(u), [u2] "+v"(u2), [t] "=&v"(t), [dA] "=&v"(dA), [dB] "=&v"(dB), [lnq] "=&v"(lnq), [lbn] "=&v"(lbn)
+        : [lam] "+&v"(lam), [u] "+&v"(u), [u2] "+&v"(u2), [t] "=&v"(t), [dA] "=&v"(dA), [dB] "=&v"(dB), [lnq] "=&v"(lnq), [lbn] "=&v"(lbn)
         : [iA] "v"(iA), [c0] "v"(c0), [a0] "v"(A[0][0]), [a1] "v"(A[1][0]), [a2] "v"(A[2][0]), [a3] "v"(A[3][0]),
           [m0] "v"(mk0[0]), [m1] "v"(mk0[1]), [m2] "v"(mk0[2]), [m3] "v"(mk0[3]),
           [k0] "v"(Ak[0]), [k1] "v"(Ak[1]), [k2] "v"(Ak[2]), [k3] "v"(Ak[3]),
@@ -752,7 +753,7 @@ struct GpuCtx16 {
     "v_fmac_f32_dpp %[u], %[dl], %[" A1 "] row_newbcast:" #R1 ETG_DPPC                                  \
     "v_fmac_f32_dpp %[u], %[dl], %[" A2 "] row_newbcast:" #R2 ETG_DPPC
     asm(ETG_PAIR(1, 2, "a01", "a02", "m0") ETG_PAIR(5, 6, "a11", "a12", "m1") ETG_PAIR(9, 10, "a21", "a22", "m2") ETG_PAIR(13, 14, "a31", "a32", "m3")
-        : [lam] "+v"(lam), [u] "+v"(u), [lc] "=&v"(lc), [sq] "=&v"(sq), [sc] "=&v"(sc), [dl] "=&v"(dl)
+        : [lam] "+&v"(lam), [u] "+&v"(u), [lc] "=&v"(lc), [sq] "=&v"(sq), [sc] "=&v"(sc), [dl] "=&v"(dl)
         : [iA] "v"(iA), [lim] "v"(lim), [a01] "v"(A[0][1]), [a02] "v"(A[0][2]), [a11] "v"(A[1][1]), [a12] "v"(A[1][2]), [a21] "v"(A[2][1]),
           [a22] "v"(A[2][2]), [a31] "v"(A[3][1]), [a32] "v"(A[3][2]), [m0] "v"(mt[0]), [m1] "v"(mt[1]), [m2] "v"(mt[2]), [m3] "v"(mt[3]));
 #undef ETG_PAIR
@@ -781,7 +782,7 @@ struct GpuCtx16 {
         ETG_PAIR2("dA", 9, 10, "a21", "a22", "m2", ETG_U2("dB", 5, "b2") ETG_U2("dB", 6, "b3"))
         ETG_PAIR2("dB", 13, 14, "a31", "a32", "m3", ETG_U2("dA", 9, "b4") ETG_U2("dA", 10, "b5"))
         ETG_U2("dB", 13, "b6") ETG_U2("dB", 14, "b7")
-        : [lam] "+v"(lam), [u] "+v"(u), [u2] "+v"(u2), [lc] "=&v"(lc), [sq] "=&v"(sq), [sc] "=&v"(sc), [dA] "=&v"(dA), [dB] "=&v"(dB)
+        : [lam] "+&v"(lam), [u] "+&v"(u), [u2] "+&v"(u2), [lc] "=&v"(lc), [sq] "=&v"(sq), [sc] "=&v"(sc), [dA] "=&v"(dA), [dB] "=&v"(dB)
         : [iA] "v"(iA), [lim] "v"(lim), [a01] "v"(A[0][1]), [a02] "v"(A[0][2]), [a11] "v"(A[1][1]), [a12] "v"(A[1][2]), [a21] "v"(A[2][1]),
           [a22] "v"(A[2][2]), [a31] "v"(A[3][1]), [a32] "v"(A[3][2]), [m0] "v"(mt[0]), [m1] "v"(mt[1]), [m2] "v"(mt[2]), [m3] "v"(mt[3]),
           [b0] "v"(bt[0]), [b1] "v"(bt[1]), [b2] "v"(bt[2]), [b3] "v"(bt[3]), [b4] "v"(bt[4]), [b5] "v"(bt[5]), [b6] "v"(bt[6]), [b7] "v"(bt[7]));
@@ -809,7 +810,7 @@ struct GpuCtx16 {
         "v_fmac_f32_dpp %[u2], %[dl], %[bb0] row_newbcast:" #R1 ETG_DPPC                                \
         "v_fmac_f32_dpp %[u], %[dl], %[at1] row_newbcast:" #R2 ETG_DPPC                                 \
         "v_fmac_f32_dpp %[u2], %[dl], %[bb1] row_newbcast:" #R2 ETG_DPPC                                \
-        : [lam] "+v"(lam2), [u2] "+v"(u2), [u] "+v"(u), [lc] "=&v"(lc), [sq] "=&v"(sq), [sc] "=&v"(sc), [dl] "=&v"(dl)           \
+        : [lam] "+&v"(lam2), [u2] "+&v"(u2), [u] "+&v"(u), [lc] "=&v"(lc), [sq] "=&v"(sq), [sc] "=&v"(sc), [dl] "=&v"(dl)           \
         : [iA] "v"(iA), [lim] "v"(lim), [at0] "v"(at0), [at1] "v"(at1), [bb0] "v"(bb0), [bb1] "v"(bb1), [mk] "v"(mk))
     switch (lp) { case 0: ETG_PAIRB(1, 2); break; case 1: ETG_PAIRB(5, 6); break; case 2: ETG_PAIRB(9, 10); break; default: ETG_PAIRB(13, 14); break; }
 #undef ETG_PAIRB

@@ -38,3 +38,31 @@ def test_hot_kernel_code_generation_matches_the_recorded_baseline():
             if abs(g.get(key, 0) - want[key]) > tol * want[key] + 2:
                 report.append("%s: %s %d, recorded %d" % (sym, key, g.get(key, 0), want[key]))
     assert not report, "code generation moved (regenerate profiles/r05_isa_baseline.json if intended):\n" + "\n".join(report)
+
+
+def test_no_accumulator_is_its_own_broadcast_source():
+    """The multi-instruction asm blocks of the sweeps accumulate into read-write operands and read their broadcast sources LATER
+    in the block.  An input that holds the same value as an accumulator's start (the second rows' impulses and three of
+    row2_velocity's partial sums all start at 0) may be given the accumulator's register unless the accumulator is early-clobber
+    ("+&v"): the block then reads its own partial sum as the broadcast source -- `v_fmac_f32_dpp vN, vN, ...`.  Round 5 shipped
+    that for one build (the non-plain kernels were 1e-2 rad off the oracle on the GPU while the emulation was right); no code of
+    ours wants such an instruction, so none may exist in the library."""
+    import re
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_isa_stats as K
+    from paddlerobotics_amd import build
+    if not os.path.exists(K.LLVM + "/llvm-objdump"):
+        pytest.skip("no llvm-objdump in this image")
+    tmp, cos = K.code_objects(build.build())
+    bad = []
+    for co in cos:
+        sym = None
+        for line in K.disassemble(co).splitlines():
+            m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+            if m:
+                sym = m.group(1)
+            elif re.search(r"v_fmac_f32_dpp v(\d+), v\1,", line):
+                bad.append((sym, line.strip()))
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    assert not bad, bad[:8]
