@@ -196,3 +196,49 @@ def test_rollout_policy_takes_the_faster_route_and_says_so_when_forced():
         hyb.rollout_policy(pol, 2, 0.3, fused=True)
     for e in (auto, forced, stepped, hyb):
         e.close()
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_collapsed_robots_joint_stops_and_body_rows_match_oracle(lanes):
+    """The heaviest tail of the tick on the device: robots that collapse onto folded legs (torque mode, small random torques from a
+    crouch) run joint-limit rows, foot rows and the body contacts' normal + friction rows in one solve, up to the 50-sweep cap, on
+    every tick -- through the all-options kernels, whose body tail tracks the second rows' velocity through the joint phase too.
+    Same scenario as the CPU suite's test_joint_stops_under_loaded_body_rows_match_oracle (the emulation), here through the C-ABI;
+    64 robots so that waves mix robots with and without such rows."""
+    _need_gpu()
+    n = 64
+    env = _make(n, lanes_per_robot=lanes, motor_control_mode="torque")
+    orc, o32 = _oracle(n, motor_mode=1), _oracle(n, dtype=np.float32, motor_mode=1)
+    env.reset()
+    for o in (orc, o32):
+        o.reset()
+    rng = np.random.default_rng(5)
+    st = orc.get_state().copy()
+    st[:, 2] = 0.16 + 0.01 * rng.uniform(size=n)
+    st[:, 7:13] = 0.0
+    st[:, 13:25] = np.tile([0.0, 1.2, -2.55], 4)[None, :] + 0.03 * rng.normal(size=(n, 12))
+    st[:, 25:37] = 0.0
+    st[n // 2:, 2] += 0.12                                           # half of the robots start higher: they land a step or two later
+    env.set_state(torch.as_tensor(st, dtype=torch.float32))
+    for o in (orc, o32):
+        o.set_state(st)
+    orc.body_stats()
+    lo, hi = np.array(A.JOINT_LOWER * 4), np.array(A.JOINT_UPPER * 4)
+    eg, e32, both = np.zeros(n), np.zeros(n), 0
+    for k in range(6):
+        a = rng.uniform(-1.0, 1.0, size=(n, 12))
+        env.step(torch.as_tensor(a, dtype=torch.float32))
+        for o in (orc, o32):
+            o.step(a)
+        sg, so, s3 = env.get_state().cpu().numpy(), orc.get_state(), o32.get_state()
+        eg = np.maximum(eg, np.abs(sg - so)[:, 13:25].max(1))
+        e32 = np.maximum(e32, np.abs(s3 - so)[:, 13:25].max(1))
+        at_stop = ((so[:, 13:25] >= hi - 1e-9) | (so[:, 13:25] <= lo + 1e-9)).any(1)
+        both += int((at_stop & (orc.body_stats()[:, 1] > 0)).sum())
+    _say("collapsed robots, lanes %2d: joints vs the fp64 oracle median %.2e q90 %.2e max %.2e rad (fp32 oracle: %.2e / %.2e / %.2e), %d robot-steps with a joint at a stop AND a loaded body row"
+         % (lanes, np.median(eg), np.quantile(eg, 0.9), eg.max(), np.median(e32), np.quantile(e32, 0.9), e32.max(), both))
+    assert both >= 40, both
+    _lt(np.median(eg), 3e-5, "collapsed robots lanes %d: median joint gap" % lanes)
+    assert np.mean(eg <= 5e-5 + 4.0 * e32) >= 0.8, (np.sort(eg)[-4:], np.sort(e32)[-4:])
+    assert eg.max() <= 3.0 * e32.max() + 1e-3
+    env.close()

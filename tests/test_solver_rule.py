@@ -251,3 +251,50 @@ def test_solver_presets_state_both_candidate_engine_settings(golden):
         out[name] = (orc.get_state()[0, 0] - x0, int(ln[0]))
     assert out["pybullet"][1] == 300 and out["locomotion_gym"][1] == 300
     assert abs(out["pybullet"][0] - out["locomotion_gym"][0]) < 0.03 * out["pybullet"][0] and out["pybullet"][0] > 3.5
+
+
+@pytest.mark.parametrize("lanes", [4, 16])
+def test_joint_stops_under_loaded_body_rows_match_oracle(lanes):
+    """The heaviest tail of the tick: joint-limit rows, foot rows and body rows (normal + friction pair per leg) in one solve,
+    up to the 50-sweep cap -- what a robot that has collapsed onto folded legs runs every tick (torque mode with small random
+    torques from a crouch: calves reach their lower stop, knees and trunk load their spheres).  The kernel source, executed by
+    the emulation, follows the fp64 oracle through it: joints to 1e-4 rad over 6 control steps, the same sweeps tick for tick
+    (within the last-bit decisions of the residual test).  The 16-lane mapping TRACKS the velocity of the body contacts'
+    friction rows through every phase of the sweep, joint rows included (etg_core16.h: joint_phase's `du2`); this is the CPU
+    test that walks that path."""
+    from oracle.oracle import OracleSim
+    from tests.emu.emu import EmuSim
+    n = 8
+    orc = OracleSim(A.default_config(n, motor_mode=1))
+    emu = EmuSim(A.default_config(n, motor_mode=1), lanes=lanes)
+    for s in (orc, emu):
+        s.reset()
+    rng = np.random.default_rng(5)
+    st = orc.get_state().copy()
+    st[:, 2] = 0.16 + 0.01 * rng.uniform(size=n)
+    st[:, 7:13] = 0.0
+    st[:, 13:25] = np.tile([0.0, 1.2, -2.55], 4)[None, :] + 0.03 * rng.normal(size=(n, 12))
+    st[:, 25:37] = 0.0
+    for s in (orc, emu):
+        s.set_state(st)
+    orc.body_stats()
+    lo, hi = np.array(A.JOINT_LOWER * 4), np.array(A.JOINT_UPPER * 4)
+    both, worst, sw_gap = 0, 0.0, 0.0
+    for k in range(6):
+        a = rng.uniform(-1.0, 1.0, size=(n, 12))
+        _, _, _, io = orc.step(a)
+        _, _, _, ie = emu.step(a)
+        so, se = orc.get_state(), emu.get_state()
+        worst = max(worst, np.abs(se - so)[:, 13:25].max())
+        assert np.abs(se - so)[:, :3].max() < 1e-5
+        at_stop = ((so[:, 13:25] >= hi - 1e-9) | (so[:, 13:25] <= lo + 1e-9)).any(1)
+        loaded = orc.body_stats()[:, 1] > 0
+        both += int((at_stop & loaded).sum())
+        sw_gap = max(sw_gap, np.abs(ie[:, A.INFO_SWEEPS] - io[:, A.INFO_SWEEPS]).max())
+        if k >= 3:
+            assert io[:, A.INFO_SWEEPS].max() > 13 * 20          # the long solves are in the comparison
+    print("[parity] joint stops + loaded body rows, lanes %d: joints %.2e rad, %d robot-steps with both, sweep-count gap %d of 650" % (lanes, worst, both, sw_gap))
+    assert both >= 8, both
+    assert worst < 1e-4, worst
+    # one robot of a wave-less emulation stops exactly where the oracle's stops, up to the residual test's last-bit decisions
+    assert sw_gap <= 13, sw_gap
