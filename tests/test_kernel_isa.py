@@ -66,3 +66,35 @@ def test_no_accumulator_is_its_own_broadcast_source():
     import shutil
     shutil.rmtree(tmp, ignore_errors=True)
     assert not bad, bad[:8]
+
+
+def test_no_dpp_operand_is_read_inside_its_writers_wait_states():
+    """A VALU write needs 2 wait states before a DPP instruction reads the register as its DPP operand; the asm blocks of the
+    sweeps pad by hand (an independent instruction or s_nop in each slot) and the compiler cannot check them, nor the values it
+    hands them.  tools/kernel_isa_stats.dpp_hazards walks the disassembly of every kernel of the library; the checker itself is
+    checked on a synthetic listing first."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_isa_stats as K
+    from paddlerobotics_amd import build
+    c = "  // 000000001000: 00000000"
+    dpp = " row_newbcast:0 row_mask:0xf bank_mask:0xf bound_ctrl:1"
+    listing = "\n".join(["0000 <k>:",
+                         "\tv_mul_f32_e32 v1, v2, v3" + c, "\tv_add_f32_e32 v9, v2, v3" + c, "\tv_fmac_f32_dpp v4, v1, v5" + dpp + c,   # 1 slot: hazard
+                         "\tv_mul_f32_e32 v1, v2, v3" + c, "\ts_nop 1" + c, "\tv_fmac_f32_dpp v4, v1, v5" + dpp + c,                   # 2 slots: fine
+                         "\tv_pk_mul_f32 v[6:7], v[2:3], v[4:5]" + c, "\tv_mov_b32_dpp v8, v7 quad_perm:[0,0,0,0] row_mask:0xf" + c,   # pair write: hazard
+                         "\tv_mul_f32_e32 v1, v2, v3" + c, "\tv_add_f32_e32 v9, v2, v3" + c, "\tv_add_f32_e32 v10, v2, v3" + c,
+                         "\tv_add_f32_dpp v1, v1, v1 quad_perm:[0,2,1,3] row_mask:0xf" + c])                                         # 2 instructions: fine
+    n, bad = K.dpp_hazards(listing)
+    assert n == 4 and len(bad) == 2, (n, bad)
+    if not os.path.exists(K.LLVM + "/llvm-objdump"):
+        pytest.skip("no llvm-objdump in this image")
+    import shutil
+    tmp, cos = K.code_objects(build.build())
+    total, bad = 0, []
+    for co in cos:
+        n, b = K.dpp_hazards(K.disassemble(co))
+        total += n
+        bad += b
+    shutil.rmtree(tmp, ignore_errors=True)
+    assert total > 20000, total          # (the 16-lane kernels alone hold ~2000 DPP instructions each)
+    assert not bad, bad[:8]

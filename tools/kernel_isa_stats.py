@@ -29,6 +29,52 @@ def disassemble(co):
     return r.stdout
 
 
+def _vregs(tok):
+    m = re.match(r"^-?\|?v(\d+)\|?$", tok)
+    if m:
+        return [int(m.group(1))]
+    m = re.match(r"^v\[(\d+):(\d+)\]$", tok)
+    return list(range(int(m.group(1)), int(m.group(2)) + 1)) if m else []
+
+
+def dpp_hazards(text):
+    """gfx9 data hazard: a VALU write of a VGPR needs 2 wait states before a DPP instruction reads that VGPR as its DPP operand.
+    The compiler pads its own code; the hand-written asm blocks of the sweeps (etg_kernels.hip) pad by construction, and the
+    compiler does not see into them -- so the finished code is checked: in straight-line code (the window is dropped at every
+    branch) no DPP operand may have been written in the 2 preceding wait states (an instruction = 1, s_nop N = N + 1).
+    -> (number of DPP instructions checked, [(kernel, writer, reader)])"""
+    bad, sym, hist, n = [], None, [], 0
+    for line in text.splitlines():
+        m = re.match(r"^[0-9a-f]+ <([^>]+)>:", line)
+        if m:
+            sym, hist = m.group(1), []
+            continue
+        m = re.match(r"^\s+(\S+)\s*(.*?)\s*//", line)
+        if not m:
+            continue
+        op, rest = m.group(1), m.group(2)
+        toks = [t.strip() for t in re.split(r",\s*", re.split(r" (?:quad_perm|row_|wave_)", rest)[0])] if rest else []
+        if op.startswith(("s_branch", "s_cbranch", "s_setpc", "s_endpgm", "s_barrier")):
+            hist = []
+            continue
+        if op.startswith("v_") and re.search(r" (?:quad_perm:|row_\w+)", rest) and len(toks) >= 2:
+            n += 1
+            src, need, i = set(_vregs(toks[1])), 2, len(hist) - 1
+            while need > 0 and i >= 0:
+                slots, wr, l = hist[i]
+                if src & set(wr):
+                    bad.append((sym, l.split("//")[0].strip(), line.split("//")[0].strip()))
+                need -= slots
+                i -= 1
+        slots, wr = 1, []
+        if op == "s_nop":
+            slots = int(toks[0]) + 1 if toks and toks[0].isdigit() else 1
+        elif op.startswith("v_") and not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")) and toks:
+            wr = _vregs(toks[0])
+        hist = (hist + [(slots, wr, line)])[-6:]
+    return n, bad
+
+
 def notes(co):
     r = subprocess.run([os.path.join(LLVM, "llvm-readelf"), "--notes", co], check=True, capture_output=True, text=True)
     out = {}
