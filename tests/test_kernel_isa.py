@@ -69,7 +69,8 @@ def test_no_accumulator_is_its_own_broadcast_source():
 
 
 def test_no_dpp_operand_is_read_inside_its_writers_wait_states():
-    """A VALU write needs 2 wait states before a DPP instruction reads the register as its DPP operand; the asm blocks of the
+    """A VALU write needs 2 wait states before a DPP instruction reads the register as its DPP operand (and a transcendental's
+    result 1 before any VALU instruction reads it); the asm blocks of the
     sweeps pad by hand (an independent instruction or s_nop in each slot) and the compiler cannot check them, nor the values it
     hands them.  tools/kernel_isa_stats.dpp_hazards walks the disassembly of every kernel of the library; the checker itself is
     checked on a synthetic listing first."""
@@ -83,9 +84,11 @@ def test_no_dpp_operand_is_read_inside_its_writers_wait_states():
                          "\tv_mul_f32_e32 v1, v2, v3" + c, "\ts_nop 1" + c, "\tv_fmac_f32_dpp v4, v1, v5" + dpp + c,                   # 2 slots: fine
                          "\tv_pk_mul_f32 v[6:7], v[2:3], v[4:5]" + c, "\tv_mov_b32_dpp v8, v7 quad_perm:[0,0,0,0] row_mask:0xf" + c,   # pair write: hazard
                          "\tv_mul_f32_e32 v1, v2, v3" + c, "\tv_add_f32_e32 v9, v2, v3" + c, "\tv_add_f32_e32 v10, v2, v3" + c,
-                         "\tv_add_f32_dpp v1, v1, v1 quad_perm:[0,2,1,3] row_mask:0xf" + c])                                         # 2 instructions: fine
+                         "\tv_add_f32_dpp v1, v1, v1 quad_perm:[0,2,1,3] row_mask:0xf" + c,                                          # 2 instructions: fine
+                         "\tv_rsq_f32_e32 v11, v2" + c, "\tv_mul_f32_e32 v3, v4, v11" + c,                                               # transcendental read at once: hazard
+                         "\tv_rsq_f32_e32 v11, v2" + c, "\ts_nop 0" + c, "\tv_mul_f32_e32 v3, v4, v11" + c])                             # 1 wait state: fine
     n, bad = K.dpp_hazards(listing)
-    assert n == 4 and len(bad) == 2, (n, bad)
+    assert n == 4 and len(bad) == 3, (n, bad)
     if not os.path.exists(K.LLVM + "/llvm-objdump"):
         pytest.skip("no llvm-objdump in this image")
     import shutil

@@ -41,7 +41,8 @@ def dpp_hazards(text):
     """gfx9 data hazard: a VALU write of a VGPR needs 2 wait states before a DPP instruction reads that VGPR as its DPP operand.
     The compiler pads its own code; the hand-written asm blocks of the sweeps (etg_kernels.hip) pad by construction, and the
     compiler does not see into them -- so the finished code is checked: in straight-line code (the window is dropped at every
-    branch) no DPP operand may have been written in the 2 preceding wait states (an instruction = 1, s_nop N = N + 1).
+    branch) no DPP operand may have been written in the 2 preceding wait states (an instruction = 1, s_nop N = N + 1), and no
+    VALU instruction may read a transcendental's result in the very next slot (gfx940+: 1 wait state).
     -> (number of DPP instructions checked, [(kernel, writer, reader)])"""
     bad, sym, hist, n = [], None, [], 0
     for line in text.splitlines():
@@ -61,17 +62,25 @@ def dpp_hazards(text):
             n += 1
             src, need, i = set(_vregs(toks[1])), 2, len(hist) - 1
             while need > 0 and i >= 0:
-                slots, wr, l = hist[i]
+                slots, wr, l = hist[i][:3]
                 if src & set(wr):
                     bad.append((sym, l.split("//")[0].strip(), line.split("//")[0].strip()))
                 need -= slots
                 i -= 1
+        # second rule (gfx940+): the result of a transcendental needs 1 wait state before another VALU instruction reads it
+        if op.startswith("v_") and hist and hist[-1][0] == 1 and hist[-1][3]:
+            rd = set(r for t in toks[1:] for r in _vregs(t))
+            if op.startswith(("v_fmac", "v_mac", "v_fmaak")) or op.endswith("_dpp") and "fmac" in op:
+                rd |= set(_vregs(toks[0]))
+            if rd & set(hist[-1][1]):
+                bad.append((sym, hist[-1][2].split("//")[0].strip(), line.split("//")[0].strip()))
         slots, wr = 1, []
         if op == "s_nop":
             slots = int(toks[0]) + 1 if toks and toks[0].isdigit() else 1
         elif op.startswith("v_") and not op.startswith(("v_cmp", "v_readlane", "v_readfirstlane")) and toks:
             wr = _vregs(toks[0])
-        hist = (hist + [(slots, wr, line)])[-6:]
+        trans = op.startswith(("v_rsq_", "v_rcp_", "v_sqrt_", "v_exp_", "v_log_", "v_sin_", "v_cos_"))
+        hist = (hist + [(slots, wr, line, trans)])[-6:]
     return n, bad
 
 
