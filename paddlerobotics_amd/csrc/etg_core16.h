@@ -488,8 +488,8 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   // The 32 Delassus columns of the second rows -- BA[lp][e]: second row x (n, t1, t2, body n) of leg lp; BB[lp][t]: second row x
   // second rows of leg lp; AT[lp][t]: FIRST row x second rows of leg lp -- live from the build to the end of the tick.  In the
   // open-loop and step kernels they stay in registers (`sb`); the closed-loop kernels, whose policy tile shares the 512-register
-  // budget with the tick, park them in free slots of the lane's LDS parameter column (Ctx::kSlotBLds) and read them back where a
-  // friction phase needs them (it takes 32 long-lived values out of the allocator's hands; the kernels' scratch use sits around
+  // budget with the tick, park them in free slots of the lane's LDS parameter column (Ctx::kSlotBLds) and read them back at the
+  // start of the solve (it separates the build's register pressure from the sweeps'; the kernels' scratch use sits around
   // the policy tile, not in the tick, and did not move: profiles/r05_ab_experiments.txt section 4).
   constexpr bool b_lds = Ctx::kSlotBLds;
   F sb[32];
