@@ -20,6 +20,17 @@
 #include "etg_core16.h"
 #include "policy_core.h"
 
+// ---- translation units.  The device code of this file is ~120 instantiations of the physics tick: four minutes of
+// single-threaded code generation.  paddlerobotics_amd/build.py therefore compiles the file ETG_TU_PARTS times in parallel:
+// part 0 holds the host side (the C-ABI) and the small kernels and declares the tick kernels `extern template`; parts 1..
+// hold their explicit instantiations (the table at the end of namespace etg).  Without the macros -- tools/build_variant.sh, a
+// plain `hipcc etg_kernels.hip` -- the file is one unit and every kernel is instantiated where it is launched, as before.
+#ifndef ETG_TU_PARTS
+#define ETG_TU_PARTS 1
+#define ETG_TU_PART 0
+#endif
+#define ETG_TU_HOST (ETG_TU_PART == 0)
+
 namespace etg {
 
 // ---- DPP quad helpers -------------------------------------------------------------
@@ -146,6 +157,7 @@ constexpr int BLOCK = 64;
 // etg_step_autoreset (or the next etg_reset of the robot) installs the rows.  All null when the feature is unused.
 struct NextDyn { float* par; float* dyn; unsigned char* ok; };
 // install the pending rows of the masked robots (a reset of theirs is about to use the settle cache that belongs to the rows)
+#if ETG_TU_HOST   // small kernels: compiled with the host side only (part 0)
 __global__ void __launch_bounds__(256) k_next_take(KCfg K, DevState D, NextDyn NX, const uint8_t* mask) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   const int N = K.n_env, NL = 4 * N;
@@ -171,6 +183,7 @@ __global__ void __launch_bounds__(256) k_next_flags(KCfg K, unsigned char* ok, c
   if (env >= K.n_env || (mask && !mask[env])) return;
   ok[env] = value;
 }
+#endif
 
 
 // Stage the lane's 66 derived parameters in LDS, [field][lane] (conflict-free: lane i hits
@@ -210,6 +223,7 @@ __device__ __forceinline__ void stage_params_wave(GpuCtx& c, const DevState& D, 
   c.gpar = D.par;
 }
 
+#if ETG_TU_HOST   // small kernels: compiled with the host side only (part 0)
 __global__ void __launch_bounds__(BLOCK) k_set_params(KCfg K, ModelF M, DevState D, const float* dyn, const float* w,
                                                        const float* b, int per_env, const uint8_t* mask) {
   GpuCtx c;
@@ -228,6 +242,7 @@ __global__ void __launch_bounds__(BLOCK) k_set_params(KCfg K, ModelF M, DevState
     if (w) D.etgp[(size_t)(EP_W + k) * c.N + c.env] = w[(per_env ? (size_t)c.env * 60 : 0) + k];
   if (b && c.lane < 3) D.etgp[(size_t)(EP_B + c.lane) * c.N + c.env] = b[(per_env ? (size_t)c.env * 3 : 0) + c.lane];
 }
+#endif
 
 // ---- reset = settle (only for robots without a valid settle cache) -> restore from the cache -> finish
 // copy this lane's 8 ring words of all slots and its leg column between the live arrays and the cache
@@ -274,6 +289,7 @@ __global__ void __launch_bounds__(BLOCK) k_settle(KCfg K, DevState D, const uint
 
 // one thread per leg column: after a settle, snapshot the ring into the cache and mark the robot cached;
 // for every masked robot, bring state + ring back from the cache
+#if ETG_TU_HOST   // small kernels: compiled with the host side only (part 0)
 __global__ void __launch_bounds__(256) k_cache_sync(KCfg K, DevState D, const uint8_t* mask) {
   const int col = blockIdx.x * blockDim.x + threadIdx.x;
   const int N = K.n_env, NL = 4 * N;
@@ -298,6 +314,7 @@ __global__ void __launch_bounds__(256) k_cache_mark(KCfg K, DevState D, const ui
   if (mask && !mask[env]) return;
   D.cache_ok[env] = 1;
 }
+#endif
 
 template <bool FLAT, bool PLAIN, int BODY = 0>
 __global__ void __launch_bounds__(BLOCK) k_finish(KCfg K, DevState D, const uint8_t* mask, float* obs) {
@@ -319,6 +336,7 @@ __global__ void __launch_bounds__(BLOCK) k_finish(KCfg K, DevState D, const uint
 // copies it back.  Anything that changes an input clears the robot's FIN_OK flag (etg_set_params, etg_set_heightfield,
 // etg_set_reset_offsets); the restart then recomputes as before.  Both lane mappings share the SoA state layout, and this cache.
 enum { FIN_OBS = 2, FIN_RPY = FIN_OBS + ETG_OBS_DIM, FIN_FWX = FIN_RPY + 3, FIN_OK = FIN_FWX + 4, FIN_ROWS = FIN_OK + 1 };
+#if ETG_TU_HOST   // small kernels: compiled with the host side only (part 0)
 __global__ void __launch_bounds__(256) k_fin_store(KCfg K, DevState D, const uint8_t* mask, const float* obs) {
   const int env = blockIdx.x * blockDim.x + threadIdx.x;
   const int N = K.n_env;
@@ -348,6 +366,7 @@ __global__ void __launch_bounds__(256) k_fin_clear(KCfg K, DevState D, const uin
   if (env >= K.n_env || (mask && !mask[env])) return;
   D.cache_off[(size_t)FIN_OK * K.n_env + env] = 0.0f;
 }
+#endif
 // reset_finish from the cache (4 lanes per robot: lane = leg): same stores, no arithmetic
 template <class Ctx>
 __device__ __forceinline__ void restart_from_cache4(const Ctx& c, const KCfg& K, LaneState<float>& L, float* ctl, int* ictl, float* legctl,
@@ -1331,6 +1350,7 @@ __global__ void __launch_bounds__(256) k_rollout_policy16_rec(KCfg K, DevState D
 
 // Gaussian sensor noise on freshly written observation rows: one thread per (robot, channel).  A separate tiny
 // kernel so that the step kernels' code (and register allocation) is the same with and without noise.
+#if ETG_TU_HOST   // small kernels: compiled with the host side only (part 0)
 __global__ void k_add_noise(KCfg K, unsigned call, const uint8_t* mask, int invert, float* obs) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int env = i >> 4;
@@ -1344,6 +1364,7 @@ __global__ void k_set_fext(KCfg K, DevState D, const float* force) {
   if (i >= K.n_env) return;
   for (int k = 0; k < 3; k++) D.ctl[(size_t)(CT_FEXT + k) * K.n_env + i] = force[(size_t)i * 3 + k];
 }
+#endif
 
 // counter-based uniform in [0,1): a 64-bit mix (splitmix64 finaliser) of (seed, robot, call, stream)
 __device__ __forceinline__ float push_uniform(unsigned long long seed, unsigned env, unsigned long long call, unsigned k) {
@@ -1353,6 +1374,7 @@ __device__ __forceinline__ float push_uniform(unsigned long long seed, unsigned 
   z = z ^ (z >> 31);
   return (float)(z >> 40) * (1.0f / 16777216.0f);
 }
+#if ETG_TU_HOST   // small kernels: compiled with the host side only (part 0)
 __global__ void k_random_pushes(KCfg K, DevState D, unsigned long long seed, unsigned long long call, float prob, int duration,
                                 float fmin, float fmax) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1473,9 +1495,114 @@ __global__ void k_extra_sensors(KCfg K, ModelF M, DevState D, const float* obs, 
   }
   out[(size_t)env * ETG_EXTRA_DIM + col] = v;
 }
+#endif
+
+// ---- the tick kernels' instantiations, one row per kernel family, one SLOT per instantiation.  A slot belongs to part
+// 1 + (slot - 1) % (ETG_TU_PARTS - 1): that part instantiates the kernel, every other part (the host side included) only
+// declares it.  The combinations are the ones DISPATCH16 / LAUNCH4 / LAUNCH_POLICY* launch; a launch of a combination that
+// is missing here fails at link time (undefined __device_stub__), not at run time.
+#define ETG_ARGS_SETTLE KCfg, DevState, const uint8_t*
+#define ETG_ARGS_FINISH KCfg, DevState, const uint8_t*, float*
+#define ETG_ARGS_STEP KCfg, DevState, const float*, const uint8_t*, float*, float*, uint8_t*, float*
+#define ETG_ARGS_STEP_AR KCfg, DevState, const float*, const uint8_t*, float*, float*, uint8_t*, float*, NextDyn
+#define ETG_ARGS_ROLLOUT KCfg, DevState, int, float*, StatOut
+#define ETG_ARGS_TAPE KCfg, DevState, int, const float*, float*, TapeOut
+#define ETG_ARGS_POLICY KCfg, DevState, PolicyW, int, float, float*
+#define ETG_ARGS_POLICY_REC KCfg, DevState, PolicyW, int, float, float*, RecOut
+#if ETG_TU_PARTS > 1
+#define ETG_SLOT_OWNER(S) (1 + ((S) - 1) % (ETG_TU_PARTS - 1))
+#if ETG_SLOT_OWNER(1) == ETG_TU_PART
+#define ETG_TPL_1 template
+#else
+#define ETG_TPL_1 extern template
+#endif
+#if ETG_SLOT_OWNER(2) == ETG_TU_PART
+#define ETG_TPL_2 template
+#else
+#define ETG_TPL_2 extern template
+#endif
+#if ETG_SLOT_OWNER(3) == ETG_TU_PART
+#define ETG_TPL_3 template
+#else
+#define ETG_TPL_3 extern template
+#endif
+#if ETG_SLOT_OWNER(4) == ETG_TU_PART
+#define ETG_TPL_4 template
+#else
+#define ETG_TPL_4 extern template
+#endif
+#if ETG_SLOT_OWNER(5) == ETG_TU_PART
+#define ETG_TPL_5 template
+#else
+#define ETG_TPL_5 extern template
+#endif
+#if ETG_SLOT_OWNER(6) == ETG_TU_PART
+#define ETG_TPL_6 template
+#else
+#define ETG_TPL_6 extern template
+#endif
+#if ETG_SLOT_OWNER(7) == ETG_TU_PART
+#define ETG_TPL_7 template
+#else
+#define ETG_TPL_7 extern template
+#endif
+// 16-lane families: <FLAT, KNEE, PLAIN> in the order of DISPATCH16
+#define ETG_INST16(KERN, S0, S1, S2, S3, S4, S5, ...)                          \
+  ETG_TPL_##S0 __global__ void KERN<true, true, true>(__VA_ARGS__);            \
+  ETG_TPL_##S1 __global__ void KERN<true, false, true>(__VA_ARGS__);           \
+  ETG_TPL_##S2 __global__ void KERN<true, true, false>(__VA_ARGS__);           \
+  ETG_TPL_##S3 __global__ void KERN<false, true, true>(__VA_ARGS__);           \
+  ETG_TPL_##S4 __global__ void KERN<false, false, true>(__VA_ARGS__);          \
+  ETG_TPL_##S5 __global__ void KERN<false, true, false>(__VA_ARGS__);
+// closed-loop 16-lane families: <FLAT, BF16, KNEE, PLAIN>, one precision per row
+#define ETG_INSTP16(KERN, BF, S0, S1, S2, S3, S4, S5, ...)                     \
+  ETG_TPL_##S0 __global__ void KERN<true, BF, true, true>(__VA_ARGS__);        \
+  ETG_TPL_##S1 __global__ void KERN<true, BF, false, true>(__VA_ARGS__);       \
+  ETG_TPL_##S2 __global__ void KERN<true, BF, true, false>(__VA_ARGS__);       \
+  ETG_TPL_##S3 __global__ void KERN<false, BF, true, true>(__VA_ARGS__);       \
+  ETG_TPL_##S4 __global__ void KERN<false, BF, false, true>(__VA_ARGS__);      \
+  ETG_TPL_##S5 __global__ void KERN<false, BF, true, false>(__VA_ARGS__);
+// 4-lane families: <FLAT, PLAIN, BODY> in the order of LAUNCH4
+#define ETG_INST4(KERN, S0, S1, S2, S3, S4, S5, S6, S7, ...)                   \
+  ETG_TPL_##S0 __global__ void KERN<true, false, 3>(__VA_ARGS__);              \
+  ETG_TPL_##S1 __global__ void KERN<false, false, 3>(__VA_ARGS__);             \
+  ETG_TPL_##S2 __global__ void KERN<true, false, 1>(__VA_ARGS__);              \
+  ETG_TPL_##S3 __global__ void KERN<false, false, 1>(__VA_ARGS__);             \
+  ETG_TPL_##S4 __global__ void KERN<true, true, 0>(__VA_ARGS__);               \
+  ETG_TPL_##S5 __global__ void KERN<true, false, 0>(__VA_ARGS__);              \
+  ETG_TPL_##S6 __global__ void KERN<false, true, 0>(__VA_ARGS__);              \
+  ETG_TPL_##S7 __global__ void KERN<false, false, 0>(__VA_ARGS__);
+// closed-loop 4-lane family: <FLAT, BF16, PLAIN, BODY> in the order of LAUNCH_POLICY4
+#define ETG_INSTP4(KERN, BF, S0, S1, S2, S3, S4, S5, ...)                      \
+  ETG_TPL_##S0 __global__ void KERN<true, BF, false, 1>(__VA_ARGS__);          \
+  ETG_TPL_##S1 __global__ void KERN<false, BF, false, 1>(__VA_ARGS__);         \
+  ETG_TPL_##S2 __global__ void KERN<true, BF, true, 0>(__VA_ARGS__);           \
+  ETG_TPL_##S3 __global__ void KERN<true, BF, false, 0>(__VA_ARGS__);          \
+  ETG_TPL_##S4 __global__ void KERN<false, BF, true, 0>(__VA_ARGS__);          \
+  ETG_TPL_##S5 __global__ void KERN<false, BF, false, 0>(__VA_ARGS__);
+ETG_INST16(k_settle16, 1, 2, 3, 4, 5, 6, ETG_ARGS_SETTLE)
+ETG_INST16(k_finish16, 7, 1, 2, 3, 4, 5, ETG_ARGS_FINISH)
+ETG_INST16(k_step16, 6, 7, 1, 2, 3, 4, ETG_ARGS_STEP)
+ETG_INST16(k_step16_ar, 5, 6, 7, 1, 2, 3, ETG_ARGS_STEP_AR)
+ETG_INST16(k_rollout16, 4, 5, 6, 7, 1, 2, ETG_ARGS_ROLLOUT)
+ETG_INST16(k_rollout_actions16, 3, 4, 5, 6, 7, 1, ETG_ARGS_TAPE)
+ETG_INSTP16(k_rollout_policy16, false, 2, 3, 4, 5, 6, 7, ETG_ARGS_POLICY)
+ETG_INSTP16(k_rollout_policy16, true, 1, 2, 3, 4, 5, 6, ETG_ARGS_POLICY)
+ETG_INSTP16(k_rollout_policy16_rec, false, 7, 1, 2, 3, 4, 5, ETG_ARGS_POLICY_REC)
+ETG_INSTP16(k_rollout_policy16_rec, true, 6, 7, 1, 2, 3, 4, ETG_ARGS_POLICY_REC)
+ETG_INST4(k_settle, 5, 6, 7, 1, 2, 3, 4, 5, ETG_ARGS_SETTLE)
+ETG_INST4(k_finish, 6, 7, 1, 2, 3, 4, 5, 6, ETG_ARGS_FINISH)
+ETG_INST4(k_step, 7, 1, 2, 3, 4, 5, 6, 7, ETG_ARGS_STEP)
+ETG_INST4(k_step_ar, 1, 2, 3, 4, 5, 6, 7, 1, ETG_ARGS_STEP_AR)
+ETG_INST4(k_rollout, 2, 3, 4, 5, 6, 7, 1, 2, ETG_ARGS_ROLLOUT)
+ETG_INST4(k_rollout_actions, 3, 4, 5, 6, 7, 1, 2, 3, ETG_ARGS_TAPE)
+ETG_INSTP4(k_rollout_policy4, false, 4, 5, 6, 7, 1, 2, ETG_ARGS_POLICY)
+ETG_INSTP4(k_rollout_policy4, true, 3, 4, 5, 6, 7, 1, ETG_ARGS_POLICY)
+#endif   // ETG_TU_PARTS > 1
 
 }  // namespace etg
 
+#if ETG_TU_HOST
 // ====================================================================== C ABI
 using namespace etg;
 
@@ -1768,6 +1895,7 @@ extern "C" int etg_clear_pushes(EtgHandle* h, const uint8_t* mask, void* stream)
 
 // ---- parameters for the NEXT episode (etg_prepare_next_dynamics)
 // robots without a valid cached settle, counted after a masked reset (one workgroup; see EtgHandle::cached_report)
+#if ETG_TU_HOST   // small kernels: compiled with the host side only (part 0)
 __global__ void __launch_bounds__(256) k_count_uncached(KCfg K, DevState D, unsigned seq, unsigned* report) {
   __shared__ unsigned part[256];
   unsigned n = 0;
@@ -1784,6 +1912,7 @@ __global__ void __launch_bounds__(256) k_count_uncached(KCfg K, DevState D, unsi
     __hip_atomic_store(&report[1], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+#endif
 // host side: has a masked reset, run under the current invalidation number, reported that every robot is cached again?
 static inline void refresh_all_cached(EtgHandle* h) {
   if (h->all_cached || !h->cached_report) return;
@@ -1894,12 +2023,14 @@ extern "C" int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* st
   return ETG_OK;
 }
 
+#if ETG_TU_HOST   // small kernels: compiled with the host side only (part 0)
 __global__ void k_set_reset_offsets(KCfg K, DevState D, const float* xy, const uint8_t* mask) {
   const int env = blockIdx.x * blockDim.x + threadIdx.x;
   if (env >= K.n_env || (mask && !mask[env])) return;
   D.reset_off[env] = xy ? xy[2 * env] : 0.0f;
   D.reset_off[K.n_env + env] = xy ? xy[2 * env + 1] : 0.0f;
 }
+#endif
 extern "C" int etg_set_sensor_noise(EtgHandle* h, const float* stdev, uint64_t seed) {
   CHECK_HANDLE(h);
   h->K.noise_on = 0;
@@ -2184,3 +2315,4 @@ extern "C" int etg_set_state(EtgHandle* h, const float* state, void* stream) {
   HIP_TRY(hipGetLastError());
   return ETG_OK;
 }
+#endif   // ETG_TU_HOST
