@@ -311,6 +311,7 @@ def main():
 
     stat_buf = (torch.empty(N, device=dev), torch.empty(N, dtype=torch.int32, device=dev))   # episode returns / lengths of a rollout
     wall_local = []      # this rank's own wall seconds of the last timed_repeats() call (before the max over ranks)
+    live_steps = []      # this rank's env-steps of still-running episodes inside the timed region, per repeat of the last call
 
     def run_steps(e, pol, n, fused):
         """n control steps of the hot path: the fused rollouts (etg_rollout_openloop / etg_rollout_policy, <= 50 control steps
@@ -333,6 +334,7 @@ def main():
         stream around the K steps) and the fraction of robots still alive after the last repeat."""
         wall, kern = [], []
         wall_local.clear()
+        live_steps.clear()
         surv = float("nan")
         for _ in range(repeats):
             e.reset(ETG_w=w, ETG_b=b, **({} if dyn_row is None else {'dynamic_param': dyn_row}))
@@ -362,6 +364,9 @@ def main():
                 kern.append(e0.elapsed_time(e1) / K)
             if not getattr(e, "auto_reset", False):
                 surv = float((length == K + args.warmup).float().mean().item())
+                # env-steps of robots whose episode was still running (the fused rollouts do not simulate a finished robot: `value`
+                # counts N x K as BASELINE's metric does, live_env_steps_per_s counts these)
+                live_steps.append(float((length - args.warmup).clamp(min=0).sum().item()))
         return wall, kern, surv
 
     # ---- warm everything: lazy kernel loads, the collective, and the clocks (>= 200 ms of real stepping)
@@ -383,6 +388,7 @@ def main():
     wall, kern, survivors = timed_repeats(env, policy, fused, repeats, events=True)
     elapsed = float(np.median(wall))
     kern_ms = float(np.median(kern))
+    live_value = (world * float(np.median(live_steps)) / elapsed) if live_steps else None
     # N > 1: every rank's own median step time, and the one exchange of the path (the all_gather of the returns) on its own
     multi = None
     if dist is not None:
@@ -394,9 +400,19 @@ def main():
         def leg(e, pol, fz, note, reps=3):
             wl, _, sv = timed_repeats(e, pol, fz, reps)
             m = float(np.median(wl))
-            return {"value": world * N * K / m, "ms_per_step": m / K * 1e3, "survivors": sv, "note": note}
+            out_ = {"value": world * N * K / m, "ms_per_step": m / K * 1e3, "survivors": sv, "note": note}
+            if live_steps:
+                out_["live_env_steps_per_s"] = world * float(np.median(live_steps)) / m
+            return out_
         extra["stepwise"] = leg(env, policy, False, "env.step() per control step (%s)%s" % (
             "k_step16" if lanes == 16 else "k_step", ", policy.predict() before each" if policy is not None else ""))
+        # rounds 1-5 for continuity: finished robots simulated on inside the fused rollout (accumulators masked)
+        env.set_rollout_mode(simulate_finished=True)
+        try:
+            extra["simulate_finished"] = leg(env, policy, True, "the same fused rollout with etg_set_rollout_mode(h, 1): robots whose episode "
+                                             "has ended are simulated on (the behaviour of rounds 1-5; the reference's loops leave at done)")
+        finally:
+            env.set_rollout_mode(simulate_finished=False)
         if policy is None:
             # what the timed env-step contains: with auto-reset no terminated robot is stepped on
             envr = make_env("Quadrupedal", auto_reset=True, **solver_kw, **env_kw)
@@ -490,7 +506,7 @@ def main():
         out = {
             "metric": "env-steps/sec, 4096 A1 quadrupeds; 1/2/4/8-GPU scaling",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "ms_per_step": elapsed / K * 1e3, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / K * 1e3, "live_env_steps_per_s": live_value, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("configs[1]: %d parallel A1 per GPU, flat terrain, ETG open-loop, per-env ETG "
                                     "params = prior + N(0,0.02^2)" % N) if args.config == 2 else
@@ -532,6 +548,9 @@ def main():
                          "algorithmic_bytes_per_env_step": bytes_per,
                          "note": "VALU-issue-bound by construction (~1e3 FLOP/B, SURVEY 8d): one wave per SIMD; DESIGN.md section 7"},
             "survivors": survivors,
+            "finished_episodes": "not simulated: a robot's fused rollout ends with its episode, as the reference's loops do (pretrain.py:137-153, "
+                                 "train.py:226-247); `value` = N x K / t (every robot counted for every step, BASELINE's metric), "
+                                 "live_env_steps_per_s = steps of still-running episodes / t; leg `simulate_finished` = rounds 1-5",
         }
         if valu and N * lanes <= 1024 * 64:
             # the ceiling that actually binds: VALU issue of one wave per SIMD

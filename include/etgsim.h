@@ -213,6 +213,14 @@ typedef struct EtgConfig {
    * lateralFriction -- 0.5 for a URDF link without a <contact> element (btCollisionObject's default; the reference only ever
    * changes the FEET's, minitaur.py:1100-1110) x the ground's 1.0 = 0.5, the default of default_config.  0 = frictionless. */
   double body_friction;
+  /* body_contacts 2: softness (m) of the choice among the leg's three spheres.  0 = the DEEPEST one is the contact (rounds 5's
+   * model).  A shin lying along the ground has its knee and shin-midpoint spheres at the same depth: the hard choice then hops
+   * between two points 0.1 m apart from tick to tick, decided by the last bit of the arithmetic -- no two implementations agree on
+   * such a robot, and its ticks need the most sweeps.  > 0: the contact's impulse is DISTRIBUTED over the spheres with weights
+   * w_i ~ exp(-(d_i - d_min) / body_blend) (d_i: the sphere's distance to the ground): point, normal, distance and Jacobian rows
+   * are the weighted means.  A sphere deeper than the others by a few body_blend carries everything -- the hard choice -- and two
+   * equally deep ones share the load, as the two ends of a line contact do.  default_config: 1e-3.                          */
+  double body_blend;
 } EtgConfig;
 
 typedef struct EtgHandle EtgHandle;
@@ -221,7 +229,13 @@ typedef struct EtgHandle EtgHandle;
 int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int device, EtgHandle** out);
 void etg_destroy(EtgHandle* h);
 const char* etg_last_error(void);
+/* ABI version: bumped whenever EtgConfig / EtgRobotModel change layout or an entry point changes meaning (2: round 6 --
+ * EtgConfig gained body_friction in round 5 without a bump; finished episodes are no longer simulated by the fused rollouts).
+ * etg_config_size() / etg_model_size(): sizeof(EtgConfig) / sizeof(EtgRobotModel) as the LIBRARY was compiled -- a binding
+ * compares them with its own layout before the first etg_create (paddlerobotics_amd/_lib.py does). */
 int etg_version(void);
+int etg_config_size(void);
+int etg_model_size(void);
 int etg_lanes_per_robot(const EtgHandle* h); /* the mapping etg_create resolved (4 or 16) */
 
 /* ---- parameters (device pointers, float32) ------------------------------
@@ -307,9 +321,21 @@ int etg_next_dynamics_pending(EtgHandle* h, uint8_t* pending, void* stream);
  * masking; the batched counterpart of train.py:213-249 / pretrain.py:129-154).
  * Every etg_step updates them on device. ret [N] f32 / len [N] i32, or NULL.    */
 int etg_episode_stats(EtgHandle* h, float* ret, int32_t* len, void* stream);
+/* ---- fused rollouts: etg_rollout_openloop / _actions / _policy / _policy_record ------------------------------------------
+ * AN ENDED EPISODE IS NOT SIMULATED ANY MORE (the default; ABI version 2).  The reference's episode loops leave at `done`
+ * (pretrain.py:137-153, train.py:226-247); so does every fused rollout, per robot: once a robot's step has reported done
+ * (termination; the accumulators' alive flag, cleared by etg_reset only), later steps of the same and of later rollout calls
+ * do not touch it -- its state (etg_get_state) stays the terminal state, its row of `obs` the observation of the step that
+ * ended the episode, return and length what they were.  Per-step outputs of the recording entry points read reward 0 and
+ * done 1 for such steps; their other rows (observations, actions, joint angles, IMU) are NOT written -- the caller's buffer
+ * keeps its content there.  etg_step / etg_step_autoreset (the Gym surface) step every robot, as before.
+ * etg_set_rollout_mode(h, 1) brings back the behaviour of ABI version 1 -- finished robots are simulated on, only their
+ * accumulators are masked -- for callers that measure it or look at a robot after its fall; 0 = the default.          */
+int etg_set_rollout_mode(EtgHandle* h, int simulate_finished);
 /* open-loop rollout: n_steps x etg_step(action = 0) enqueued back-to-back
  * (pretrain.py:129-154), then etg_episode_stats. obs [N,49] (or NULL)
- * receives the final observation.                                            */
+ * receives the final observation of every robot (see above: of a finished
+ * robot, its last one).                                                       */
 int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float* ret, int32_t* len,
                          void* stream);
 
@@ -338,6 +364,11 @@ int etg_extra_sensors(EtgHandle* h, const float* obs, float* out, void* stream);
 /* ---- state access for parity tests (device pointers, [N,37] f32) --------- */
 int etg_get_state(EtgHandle* h, float* state, void* stream);
 int etg_set_state(EtgHandle* h, const float* state, void* stream);
+/* the feet's contact impulses of the last tick, [N,12] = per leg (n, t1, t2): the solver's warm start (EtgConfig.warmstart).
+ * etg_set_state zeroes them; a parity test that re-creates a robot's step from its state installs them afterwards, so that the
+ * re-created step is the robot's own (tests/test_gpu_parity5.py).  Body contacts and joint stops are not warm-started. */
+int etg_get_contact_impulses(EtgHandle* h, float* lam, void* stream);
+int etg_set_contact_impulses(EtgHandle* h, const float* lam, void* stream);
 
 /* ---- policy (the one dense contraction, model/mujoco_model.py:44-60) -----
  * act = tanh(W3 relu(W2 relu(W1 obs + b1) + b2) + b3) * act_scale

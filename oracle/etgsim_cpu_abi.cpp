@@ -33,6 +33,7 @@ struct CpuHandle {
   std::vector<float> next_dyn;
   std::vector<uint8_t> next_ok;
   std::vector<int> age_ticks;   // physics ticks since each robot's reset (etg_prepare_next_dynamics leaves young robots out)
+  bool simulate_finished = false;   // etg_set_rollout_mode
 };
 CpuHandle* H(EtgHandle* h) { return reinterpret_cast<CpuHandle*>(h); }
 
@@ -42,7 +43,9 @@ std::vector<double> to_d(const float* p, size_t n) { return std::vector<double>(
 extern "C" {
 
 const char* etg_last_error(void) { return g_cpu_err.c_str(); }
-int etg_version(void) { return 1; }
+int etg_version(void) { return 2; }
+int etg_config_size(void) { return (int)sizeof(EtgConfig); }
+int etg_model_size(void) { return (int)sizeof(EtgRobotModel); }
 int etg_lanes_per_robot(const EtgHandle* h) { return h ? 0 : ETG_ERR_BAD_ARG; }   /* no lane mapping on the CPU */
 
 int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int device, EtgHandle** out) {
@@ -191,18 +194,35 @@ int etg_episode_stats(EtgHandle* h, float* ret, int32_t* len, void*) {
   return ETG_OK;
 }
 
+int etg_set_rollout_mode(EtgHandle* h, int simulate_finished) {
+  if (!h) return cfail(ETG_ERR_BAD_ARG, "null handle");
+  H(h)->simulate_finished = simulate_finished != 0;
+  return ETG_OK;
+}
+
+// the fused open-loop rollout, sequentially: every robot's own loop of zero-action steps, left when its episode ends (the
+// default; etg_set_rollout_mode(h, 1): finished robots are stepped on, accumulators masked).  obs: every robot's LAST row.
 int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float* ret, int32_t* len, void* s) {
   if (!h) return cfail(ETG_ERR_BAD_ARG, "null handle");
   if (n_steps <= 0 || !ret || !len) return cfail(ETG_ERR_BAD_ARG, "etg_rollout_openloop: bad arguments");
   CpuHandle* c = H(h);
   if (!c->was_reset) return cfail(ETG_ERR_STATE, "etg_rollout_openloop: call etg_reset first");
-  std::vector<float> o((size_t)c->N * ETG_OBS_DIM), r(c->N);
-  std::vector<uint8_t> d(c->N);
-  for (int k = 0; k < n_steps; k++) {
-    int rc = etg_step(h, nullptr, nullptr, o.data(), r.data(), d.data(), nullptr, s);
-    if (rc != ETG_OK) return rc;
+  if (c->sim->cfg.motor_mode == 2) return cfail(ETG_ERR_BAD_ARG, "etg_rollout_openloop: the HYBRID motor mode needs commands");
+  const size_t N = c->N;
+  std::vector<uint8_t> alive(N);
+  for (size_t i = 0; i < N; i++) alive[i] = c->alive[i] > 0.5 ? 1 : 0;
+  std::vector<double> r(N), o(N * ETG_OBS_DIM);
+  std::vector<int32_t> n(N);
+  if (obs) for (size_t k = 0; k < o.size(); k++) o[k] = obs[k];     // rows of robots that were finished before stay
+  etgo_run_steps64(c->sim, nullptr, n_steps, 1, r.data(), n.data(), c->simulate_finished ? 0 : 1, alive.data(), obs ? o.data() : nullptr);
+  for (size_t i = 0; i < N; i++) {
+    c->ret[i] += r[i];
+    c->len[i] += n[i];
+    const int stepped = c->simulate_finished ? n_steps : n[i];
+    c->age_ticks[i] += stepped * c->sim->cfg.action_repeat;
+    c->alive[i] = alive[i] ? 1.0 : 0.0;                              // (in / out: cleared where the episode ended inside the call)
   }
-  if (obs) std::memcpy(obs, o.data(), o.size() * sizeof(float));
+  if (obs) for (size_t k = 0; k < o.size(); k++) obs[k] = (float)o[k];
   return etg_episode_stats(h, ret, len, s);
 }
 
@@ -218,6 +238,21 @@ int etg_set_state(EtgHandle* h, const float* state, void*) {
   if (!h || !state) return cfail(ETG_ERR_BAD_ARG, "etg_set_state: null");
   std::vector<double> st = to_d(state, (size_t)H(h)->N * ETG_STATE_DIM);
   etgo_set_state64(H(h)->sim, st.data());
+  return ETG_OK;
+}
+
+int etg_get_contact_impulses(EtgHandle* h, float* lam, void*) {
+  if (!h || !lam) return cfail(ETG_ERR_BAD_ARG, "etg_get_contact_impulses: null");
+  std::vector<double> l((size_t)H(h)->N * 12);
+  etgo_get_lambda64(H(h)->sim, l.data());
+  for (size_t k = 0; k < l.size(); k++) lam[k] = (float)l[k];
+  return ETG_OK;
+}
+
+int etg_set_contact_impulses(EtgHandle* h, const float* lam, void*) {
+  if (!h || !lam) return cfail(ETG_ERR_BAD_ARG, "etg_set_contact_impulses: null");
+  std::vector<double> l = to_d(lam, (size_t)H(h)->N * 12);
+  etgo_set_lambda64(H(h)->sim, l.data());
   return ETG_OK;
 }
 

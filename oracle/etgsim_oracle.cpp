@@ -304,7 +304,15 @@ template <class T> struct Env {
   long long sweep_hist[64];   // ticks by the number of PGS sweeps they ran since etgo_create (etgo_sweep_hist)
   long long sweeps_total;     // all sweeps so far; step_env reports the step's share in info[ETG_INFO_SWEEPS]
   long long body_ticks[3];    // ticks with a body row inside the margin / with a loaded body row (normal impulse > 0) / all ticks (etgo_body_stats)
+  // per-tick trace (etgo_set_trace; tests/divergence.py: where two evaluations of one control step part): TRACE_W doubles per tick
+  // into the caller's buffer -- [0] rows inside the margin / joint rows at a stop, as a bit mask over the 36 rows; [1] rows with a
+  // positive impulse after the solve; [2] body candidate picked per leg (2 bits each); [3] sweeps; [4..7] foot distances phi;
+  // [8..11] distance of the picked body sphere; [12..47] impulses of the 36 rows; [48..59] joint angles after the tick;
+  // [60..62] base position after the tick; [63] the tick's index since reset
+  double* trace = nullptr;
+  int trace_cap = 0, trace_n = 0;
 };
+constexpr int TRACE_W = 64;
 
 template <class T> struct Sim {
   EtgConfig cfg;
@@ -569,6 +577,8 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
   auto body_row = [&](int l, int b) { return 12 + 3 * l + b; };
   T J[NRMAX][NV];
   T target[NRMAX];
+  double tr_phi[8] = {0, 0, 0, 0, 0, 0, 0, 0};              // trace only: foot distances, picked body sphere distances
+  int tr_pick = 0;
   int active[4], kactive[NRMAX];                            // kactive / klam: indexed by row
   T klam[NRMAX];                                            // body impulses: no warm start
   for (int r = 0; r < NRMAX; r++) { kactive[r] = 0; klam[r] = 0; target[r] = 0; }
@@ -582,6 +592,7 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
     T h, n[3];
     terrain_query(s, e.band, fw[0], fw[1], &h, n);
     T phi = (fw[2] - h) * n[2] - rad;  // distance along the normal to the tangent plane
+    tr_phi[l] = (double)phi;
     active[l] = phi < T(s.cfg.contact_margin);
     e.contact[l] = 0;
     if (!active[l]) {
@@ -672,22 +683,44 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
       cphi[q] = (cand[q].p[2] - h) * cn[q][2] - krad;
     }
     for (int b = 0; b < NBR; b++) {
-      int pick = b;                                   // body_contacts 3: slot b is candidate b
-      if (!all_bodies) {                              // 1 / 2: the deepest candidate, ties to the earlier one
+      // which spheres carry the contact, with what weights.  body_contacts 3: slot b is candidate b.  1 / 2: the deepest candidate
+      // (ties to the earlier one) -- or, with cfg.body_blend > 0, ALL candidates with weights exp(-(d_i - d_min) / body_blend):
+      // the contact's impulse is distributed over the spheres (etgsim.h: body_blend).
+      T wq[3] = {0, 0, 0};
+      int pick = b;
+      if (all_bodies) {
+        wq[b] = 1;
+      } else {
         pick = 0;
         for (int q = 1; q < ncand; q++)
           if (cphi[q] < cphi[pick]) pick = q;
+        if (s.cfg.body_blend > 0 && ncand > 1) {
+          T sum = 0;
+          for (int q = 0; q < ncand; q++) { wq[q] = std::exp(-(cphi[q] - cphi[pick]) / T(s.cfg.body_blend)); sum += wq[q]; }
+          for (int q = 0; q < ncand; q++) wq[q] /= sum;
+        } else {
+          wq[pick] = 1;
+        }
       }
       const int rk = body_row(l, b);
-      const T phi = cphi[pick];
-      const T* n = cn[pick];
+      // the contact is a sphere of knee_radius centred at the weighted mean of the spheres' centres; the ground's height and
+      // normal are taken under THAT point (one-hot weights: the picked sphere's own)
+      T pc[3] = {0, 0, 0};
+      for (int q = 0; q < ncand; q++)
+        for (int k = 0; k < 3; k++) pc[k] += wq[q] * cand[q].p[k];
+      T hc, n[3];
+      terrain_query(s, e.band, pc[0], pc[1], &hc, n);
+      const T phi = (pc[2] - hc) * n[2] - krad;
+      if (b == 0) { tr_phi[4 + l] = (double)phi; tr_pick |= pick << (2 * l); }
       const bool on = phi < T(s.cfg.contact_margin);
       kactive[rk] = on;
       if (body_fric) kactive[rk + 1] = kactive[rk + 2] = on;
       if (!on) continue;
       any_margin = true;
-      T cp[3], rel[3];
-      for (int k = 0; k < 3; k++) { cp[k] = cand[pick].p[k] - krad * n[k]; rel[k] = cp[k] - e.pos[k]; }
+      T cp[3] = {0, 0, 0}, rel[3];                     // the contact point: weighted mean of the spheres' points
+      for (int q = 0; q < ncand; q++)
+        for (int k = 0; k < 3; k++) cp[k] += wq[q] * (cand[q].p[k] - krad * n[k]);
+      for (int k = 0; k < 3; k++) rel[k] = cp[k] - e.pos[k];
       // contact frame as for a foot: n, t1 = normalised projection of world x, t2 = n x t1
       T t1[3] = {1 - n[0] * n[0], -n[0] * n[1], -n[0] * n[2]};
       T inv = T(1) / std::sqrt(dot3(t1, t1));
@@ -704,12 +737,17 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
         for (int k = 0; k < 3; k++) row[k] = tmp[k];
         mat3T_mul_vec(R, d, tmp);
         for (int k = 0; k < 3; k++) row[3 + k] = tmp[k];
-        for (int bd = cand[pick].first_body; bd > 0; bd = s.parent[bd]) {  // the joints that move the point
-          T axw[3] = {Rw[bd][0][s.axis[bd]], Rw[bd][1][s.axis[bd]], Rw[bd][2][s.axis[bd]]};
-          T rj[3], cr[3];
-          for (int k = 0; k < 3; k++) rj[k] = cp[k] - pw[bd][k];
-          cross(axw, rj, cr);
-          row[5 + bd] = dot3(d, cr);
+        for (int q = 0; q < ncand; q++) {
+          if (wq[q] == 0) continue;
+          T cq[3];
+          for (int k = 0; k < 3; k++) cq[k] = cand[q].p[k] - krad * n[k];   // sphere q's own point
+          for (int bd = cand[q].first_body; bd > 0; bd = s.parent[bd]) {  // the joints that move sphere q, weighted
+            T axw[3] = {Rw[bd][0][s.axis[bd]], Rw[bd][1][s.axis[bd]], Rw[bd][2][s.axis[bd]]};
+            T rj[3], cr[3];
+            for (int k = 0; k < 3; k++) rj[k] = cq[k] - pw[bd][k];
+            cross(axw, rj, cr);
+            row[5 + bd] += wq[q] * dot3(d, cr);
+          }
         }
       }
       const T pen = phi + T(s.cfg.contact_slop);
@@ -853,6 +891,17 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
     for (int k = 0; k < NV; k++) vel[k] += MiJt[r][k] * lam_of(r);
   }
   for (int l = 0; l < 4; l++) e.contact[l] = active[l] && e.lam[3 * l] > 0;
+  double* tr = (e.trace && e.trace_n < e.trace_cap) ? e.trace + (size_t)TRACE_W * e.trace_n++ : nullptr;
+  if (tr) {
+    unsigned long long am = 0, lm = 0;
+    for (int r = 0; r < NR; r++) {
+      if (row_active(r)) am |= 1ull << r;
+      if (row_active(r) && lam_of(r) > 0) lm |= 1ull << r;
+      tr[12 + r] = row_active(r) ? (double)lam_of(r) : 0.0;
+    }
+    tr[0] = (double)am; tr[1] = (double)lm; tr[2] = (double)tr_pick; tr[3] = (double)sweeps;
+    for (int k = 0; k < 8; k++) tr[4 + k] = tr_phi[k];
+  }
 
   // ---- integrate (semi-implicit Euler)
   for (int k = 0; k < 3; k++) { e.wb[k] = vel[k]; e.vb[k] = vel[3 + k]; }
@@ -873,6 +922,11 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
   quat_mul(e.quat, dq, qn);
   T nn = T(1) / std::sqrt(qn[0] * qn[0] + qn[1] * qn[1] + qn[2] * qn[2] + qn[3] * qn[3]);
   for (int k = 0; k < 4; k++) e.quat[k] = qn[k] * nn;
+  if (tr) {
+    for (int j = 0; j < 12; j++) tr[48 + j] = (double)e.q[j];
+    for (int k = 0; k < 3; k++) tr[60 + k] = (double)e.pos[k];
+    tr[63] = (double)e.tick;
+  }
 }
 
 // ---------------------------------------------------------------- robot layer
@@ -1367,22 +1421,30 @@ template <class F> void par_for(int n, int threads, F f) {
   /* nsteps control steps with a constant action row set (action [N,12] or NULL = zeros), every thread running ITS   \
    * slice of the robots through all the steps (no per-step thread spawn / join): the all-core CPU baseline of       \
    * bench.py.  ret / len [N]: episode return and length with alive masking (frozen after the first done).          \
+   * stop_at_done: the loop of a robot ends with its episode, as the reference's do (pretrain.py:137-153,             \
+   * train.py:226-247) -- its state stays the terminal state; 0: finished robots are stepped on (accumulators masked).\
+   * A robot that was finished before the call (alive_in[i] == 0, NULL = all alive) is not stepped under stop_at_done; \
+   * alive_in receives the flags after the call.                                                                      \
    * Sensor noise is not drawn here (the counter-based stream is per call).                                          */ \
-  extern "C" void etgo_run_steps##SFX(void* h, const T* action, int nsteps, int threads, T* ret, int32_t* len) {     \
+  extern "C" void etgo_run_steps##SFX(void* h, const T* action, int nsteps, int threads, T* ret, int32_t* len,       \
+                                       int stop_at_done, uint8_t* alive_in /* in / out */, T* obs_out) {              \
     auto* s = (Sim<T>*)h;                                                                           \
     const int adim = s->cfg.motor_mode == 2 ? ETG_HYBRID_DIM : 12;                                  \
     par_for(s->N, threads, [=](int i) {                                                             \
       std::vector<T> zero(adim, T(0));                                                              \
       T obs[ETG_OBS_DIM], r, acc = 0;                                                               \
       uint8_t d;                                                                                    \
-      int alive = 1, n = 0;                                                                         \
+      int alive = alive_in ? (int)alive_in[i] : 1, n = 0;                                           \
       for (int k = 0; k < nsteps; k++) {                                                            \
+        if (stop_at_done && !alive) break;                                                          \
         step_env(*s, s->env[i], action ? action + (size_t)i * adim : zero.data(), 0, obs, &r, &d, (T*)nullptr); \
+        if (obs_out) std::memcpy(obs_out + (size_t)i * ETG_OBS_DIM, obs, sizeof(obs));              \
         if (alive) { acc += r; n++; }                                                               \
         if (d) alive = 0;                                                                           \
       }                                                                                             \
       if (ret) ret[i] = acc;                                                                        \
       if (len) len[i] = n;                                                                          \
+      if (alive_in) alive_in[i] = (uint8_t)alive;                                                   \
     });                                                                                             \
   }                                                                                                 \
   extern "C" void etgo_get_state##SFX(void* h, T* st) {                                             \
@@ -1423,9 +1485,22 @@ template <class F> void par_for(int n, int threads, F f) {
     for (int i = 0; i < s->N; i++)                                                                  \
       for (int k = 0; k < 3; k++) { out[3 * i + k] = s->env[i].body_ticks[k]; if (clear) s->env[i].body_ticks[k] = 0; } \
   }                                                                                                 \
+  /* per-tick trace of ONE robot into the caller's buffer [cap_ticks][TRACE_W] doubles (NULL switches it off); returns    \
+   * the number of ticks recorded so far (reset to 0 by every call that installs a buffer)                               */ \
+  extern "C" int etgo_set_trace##SFX(void* h, int env, double* buf, int cap_ticks) {                \
+    auto* s = (Sim<T>*)h;                                                                           \
+    if (env < 0 || env >= s->N) return -1;                                                          \
+    const int n = s->env[env].trace_n;                                                              \
+    if (cap_ticks >= 0) { s->env[env].trace = buf; s->env[env].trace_cap = buf ? cap_ticks : 0; s->env[env].trace_n = 0; } \
+    return n;                                                                                       \
+  }                                                                                                 \
   extern "C" void etgo_get_lambda##SFX(void* h, T* lam) {                                           \
     auto* s = (Sim<T>*)h;                                                                           \
     for (int i = 0; i < s->N; i++) std::memcpy(lam + (size_t)i * 12, s->env[i].lam, sizeof(T) * 12); \
+  }                                                                                                 \
+  extern "C" void etgo_set_lambda##SFX(void* h, const T* lam) {                                     \
+    auto* s = (Sim<T>*)h;                                                                           \
+    for (int i = 0; i < s->N; i++) std::memcpy(s->env[i].lam, lam + (size_t)i * 12, sizeof(T) * 12); \
   }                                                                                                 \
   extern "C" void etgo_etg_rbf##SFX(void* h, T t, T* r) { ((Sim<T>*)h)->basis.rbf(t, r); }         \
   extern "C" void etgo_etg_action##SFX(void* h, int env, T t, T* act) {                             \

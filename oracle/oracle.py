@@ -138,14 +138,20 @@ class OracleSim:
                         self.threads)
         return obs, rew, done, info
 
-    def run_steps(self, nsteps, action=None, threads=None):
+    def run_steps(self, nsteps, action=None, threads=None, stop_at_done=True, alive=None, want_obs=False):
         """nsteps control steps with a constant action (None = zeros), every thread running its own slice of the
-        robots through all the steps (persistent workers: the all-core CPU baseline).  -> (return[N], length[N])"""
+        robots through all the steps (persistent workers: the all-core CPU baseline).  stop_at_done: a robot's loop ends with
+        its episode (the reference's loops; the fused rollouts of the HIP library) -- its state stays the terminal state; alive
+        [N] uint8: robots that were finished before the call (0) are not stepped at all.  -> (return[N], length[N]) of THIS call
+        (+ the last observation row each robot produced, with want_obs)"""
         ret = np.zeros(self.N, dtype=self.dtype)
         ln = np.zeros(self.N, dtype=np.int32)
         a = None if action is None else self._arr(action, (self.N, 60 if self.cfg.motor_mode == 2 else 12))
-        self._f("run_steps")(self._h, _p(a), int(nsteps), int(threads or self.threads), _p(ret), _p(ln))
-        return ret, ln
+        al = None if alive is None else np.array(alive, dtype=np.uint8)     # (a copy: the call writes the flags after it back)
+        self.alive_after = al
+        obs = np.zeros((self.N, A.OBS_DIM), dtype=self.dtype) if want_obs else None
+        self._f("run_steps")(self._h, _p(a), int(nsteps), int(threads or self.threads), _p(ret), _p(ln), int(bool(stop_at_done)), _p(al), _p(obs))
+        return (ret, ln, obs) if want_obs else (ret, ln)
 
     def sweep_hist(self, mask=None, clear=True):
         """ticks by the number of PGS sweeps they ran, summed over the (masked) robots since the last clear -> int64[64]"""
@@ -160,6 +166,19 @@ class OracleSim:
         out = np.zeros((self.N, 3), dtype=np.int64)
         self._f("body_stats")(self._h, _p(out), int(bool(clear)))
         return out
+
+    TRACE_W = 64
+
+    def trace(self, env, cap_ticks=64):
+        """start recording robot `env`'s physics ticks (cap_ticks of them; see Env::trace in etgsim_oracle.cpp for the columns)"""
+        self._trace_buf = np.zeros((cap_ticks, self.TRACE_W), dtype=np.float64)
+        self._trace_env = env
+        self._f("set_trace")(self._h, int(env), _p(self._trace_buf), int(cap_ticks))
+
+    def trace_rows(self, stop=True):
+        """-> the ticks recorded since trace() as float64 [n, 64] (and stop recording)"""
+        n = self._f("set_trace")(self._h, int(self._trace_env), None, 0 if stop else -1)
+        return self._trace_buf[:max(n, 0)].copy()
 
     def get_state(self):
         st = np.zeros((self.N, A.STATE_DIM), dtype=self.dtype)
@@ -178,6 +197,11 @@ class OracleSim:
         lam = np.zeros((self.N, 12), dtype=self.dtype)
         self._f("get_lambda")(self._h, _p(lam))
         return lam
+
+    def set_lambda(self, lam):
+        """install the feet's contact impulses [N,12] (the warm start of the next tick; set_state zeroes them)"""
+        lam = self._arr(lam, (self.N, 12))
+        self._f("set_lambda")(self._h, _p(lam))
 
     def dynamics_terms(self, env=0):
         M = np.zeros((18, 18), dtype=self.dtype)

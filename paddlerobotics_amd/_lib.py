@@ -18,7 +18,9 @@ SYMBOLS = [
     "etg_policy_destroy", "etg_rollout_policy", "etg_fit_etg", "etg_leg_kinematics", "etg_extra_sensors", "etg_step_autoreset",
     "etg_replay_begin", "etg_replay_end", "etg_rollout_policy_record", "etg_rollout_actions",
     "etg_prepare_next_dynamics", "etg_next_dynamics_pending",
+    "etg_config_size", "etg_model_size", "etg_get_contact_impulses", "etg_set_contact_impulses", "etg_set_rollout_mode",
 ]
+ABI_VERSION = 2      # include/etgsim.h: etg_version()
 
 
 class EtgError(RuntimeError):
@@ -61,6 +63,9 @@ def load():
     lib.etg_rollout_openloop.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.etg_get_state.argtypes = [vp, vp, vp]
     lib.etg_set_state.argtypes = [vp, vp, vp]
+    lib.etg_set_rollout_mode.argtypes = [vp, i32]
+    lib.etg_get_contact_impulses.argtypes = [vp, vp, vp]
+    lib.etg_set_contact_impulses.argtypes = [vp, vp, vp]
     lib.etg_leg_kinematics.argtypes = [vp, vp, i32, vp, vp, vp]
     lib.etg_extra_sensors.argtypes = [vp, vp, vp, vp]
     lib.etg_policy_create.argtypes = [i32, i32, i32, i32, C.POINTER(vp)]
@@ -80,6 +85,14 @@ def load():
     ll = C.c_longlong
     lib.etg_replay_begin.argtypes = [vp, i32, ll, vp, vp, vp, i32, vp, i32, vp, vp, C.c_float, vp, vp]
     lib.etg_replay_end.argtypes = [vp, i32, vp, vp, vp, i32, vp, vp, vp, vp, i32, i32, i32, vp, vp, vp]
+    # a library built from another revision of include/etgsim.h would read past (or short of) the structs this binding
+    # passes to etg_create: refuse it here, with the reason, instead of simulating with garbage parameters
+    from . import a1_model as _A
+    if lib.etg_version() != ABI_VERSION or lib.etg_config_size() != C.sizeof(_A.EtgConfig) or lib.etg_model_size() != C.sizeof(_A.EtgRobotModel):
+        raise EtgError("paddlerobotics_amd: %s has ABI version %d with EtgConfig / EtgRobotModel of %d / %d bytes; this binding is "
+                       "version %d with %d / %d bytes -- rebuild the library (python -m paddlerobotics_amd.build)" % (
+                           path, lib.etg_version(), lib.etg_config_size(), lib.etg_model_size(), ABI_VERSION,
+                           C.sizeof(_A.EtgConfig), C.sizeof(_A.EtgRobotModel)))
     _LIB = lib
     return lib
 

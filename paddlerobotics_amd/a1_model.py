@@ -91,6 +91,7 @@ class EtgConfig(C.Structure):
         ("contact_slop", C.c_double),
         ("foot_restitution", C.c_double),
         ("body_friction", C.c_double),
+        ("body_blend", C.c_double),
     ]
 
 
@@ -226,7 +227,7 @@ def default_config(num_envs, *, action_repeat=13, sim_dt=0.002, settle_ticks=500
                    etg_phase=(-math.pi / 2, 0.0), reward_param=None, reward_p=5.0, vel_d=0.5,
                    heightfield=None, lanes_per_robot=0, motor_mode=0, clip_motor_commands=0.0,
                    body_contacts=2, body_friction=0.5, knee_radius=0.02, enable_etg=1, joint_limits=1, friction_model=0,
-                   pd_latency=0.0):
+                   pd_latency=0.0, body_blend=1e-3):
     """EtgConfig with the defaults of train.py:296-297,470-487 and SURVEY App. A."""
     c = EtgConfig()
     c.num_envs = int(num_envs)
@@ -260,6 +261,7 @@ def default_config(num_envs, *, action_repeat=13, sim_dt=0.002, settle_ticks=500
     c.clip_motor_commands = float(clip_motor_commands)
     c.body_contacts = int(body_contacts)
     c.body_friction = float(body_friction)
+    c.body_blend = float(body_blend)
     c.knee_radius = float(knee_radius)
     c.enable_etg = int(bool(enable_etg))
     c.joint_limits = int(bool(joint_limits))

@@ -298,7 +298,8 @@ template <class F, class Ctx> ETG_HD TickPar4<F> load_tick_par4(const Ctx& c) {
 template <class F, class Ctx>
 ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, LaneState<F>& L, const F* qdes,
                          const V3<F>& fext_w, bool torque_cmd = false,
-                         const F* pd = nullptr) {   // pd[0..2] angles, pd[3..5] velocities the PD law reads (EtgConfig.pd_latency), pd[6..8] the angles the command clip refers to
+                         const F* pd = nullptr,     // pd[0..2] angles, pd[3..5] velocities the PD law reads (EtgConfig.pd_latency), pd[6..8] the angles the command clip refers to
+                         F live = F(1.0f)) {        // 0 on the lanes of a robot whose episode has ended (fused rollouts, KCfg.stop_at_done): no rows (physics_tick16)
   typedef V3<F> V;
   typedef SV<F> W;
   const F dt(K.dt), zero(0.0f), one(1.0f);
@@ -477,7 +478,8 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
           Rw.r0.z * t1w.x + Rw.r1.z * t1w.y + Rw.r2.z * t1w.z};
     d2 = {Rw.r1.x * t2y + Rw.r2.x * t2z, Rw.r1.y * t2y + Rw.r2.y * t2z, Rw.r1.z * t2y + Rw.r2.z * t2z};
   }
-  auto act = phi < F(K.margin);
+  const auto lives = live > F(0.5f);
+  auto act = (phi < F(K.margin)) && lives;
   F actf = sel_(act, one, zero);
   V rc = pf - F(K.foot_radius) * dn;
   V k1 = cross(xax, rc - o1), k2 = cross(yax, rc - o2), k3 = cross(yax, rc - o3);
@@ -508,31 +510,40 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
       nw = {nwx, nwy, nwz};
       return (w.z - hgt) * nwz;
     };
-    V pbd[NPA];
-    F dep[NPA], jm12[NPA], jm3[NPA];
-    pbd[0] = o3; jm12[0] = one; jm3[0] = zero;
+    // Every body point is a weighted mean of sphere centres (weights one-hot unless EtgConfig.body_blend > 0, see physics_tick16):
+    // q12 = w_knee o3 + w_shin ps and s12 = w_knee + w_shin (the spheres hip and thigh move), w_shin (the one the calf moves)
+    V pbd[NPA], q12[NPA];
+    F dep[NPA], s12[NPA], wsh[NPA];
+    V psh = o3;                                  // the shin midpoint
+    pbd[0] = o3; q12[0] = o3; s12[0] = one; wsh[0] = zero;
     dep[0] = depth(pbd[0], nwb[0]);
     if (NB == 3 || K.knee >= 2) {
       const V ps = o3 - F(0.5f * K.lower_len) * R3.ez;
       const V pt = {sel_(o1.x > zero, F(K.trunk_half[0]), F(-K.trunk_half[0])),
                     sel_(o1.y > zero, F(K.trunk_half[1]), F(-K.trunk_half[1])), F(-K.trunk_half[2])};
+      psh = ps;
       V nws, nwt;
       const F ds = depth(ps, nws), dtk = depth(pt, nwt);
       if constexpr (NB == 3) {
-        pbd[NB - 2] = ps; nwb[NB - 2] = nws; dep[NB - 2] = ds; jm12[NB - 2] = one; jm3[NB - 2] = one;
-        pbd[NB - 1] = pt; nwb[NB - 1] = nwt; dep[NB - 1] = dtk; jm12[NB - 1] = zero; jm3[NB - 1] = zero;
+        pbd[NB - 2] = ps; nwb[NB - 2] = nws; dep[NB - 2] = ds; q12[NB - 2] = ps; s12[NB - 2] = one; wsh[NB - 2] = one;
+        pbd[NB - 1] = pt; nwb[NB - 1] = nwt; dep[NB - 1] = dtk; q12[NB - 1] = {zero, zero, zero}; s12[NB - 1] = zero; wsh[NB - 1] = zero;
       } else {
-        const auto ms = ds < dep[0];
-        pbd[0] = {sel_(ms, ps.x, pbd[0].x), sel_(ms, ps.y, pbd[0].y), sel_(ms, ps.z, pbd[0].z)};
-        nwb[0] = {sel_(ms, nws.x, nwb[0].x), sel_(ms, nws.y, nwb[0].y), sel_(ms, nws.z, nwb[0].z)};
-        dep[0] = sel_(ms, ds, dep[0]);
-        jm3[0] = sel_(ms, one, zero);
-        const auto mt = dtk < dep[0];
-        pbd[0] = {sel_(mt, pt.x, pbd[0].x), sel_(mt, pt.y, pbd[0].y), sel_(mt, pt.z, pbd[0].z)};
-        nwb[0] = {sel_(mt, nwt.x, nwb[0].x), sel_(mt, nwt.y, nwb[0].y), sel_(mt, nwt.z, nwb[0].z)};
-        dep[0] = sel_(mt, dtk, dep[0]);
-        jm12[0] = sel_(mt, zero, one);
-        jm3[0] = sel_(mt, zero, jm3[0]);
+        const F d0 = dep[0];
+        const auto ms = ds < d0;
+        const F best = sel_(ms, ds, d0);
+        const auto mt = dtk < best;
+        F w0 = sel_(mt, zero, sel_(ms, zero, one)), w1 = sel_(mt, zero, sel_(ms, one, zero)), w2 = sel_(mt, one, zero);
+        if (K.blend_inv > 0.0f) {
+          const F dmin = sel_(mt, dtk, best);
+          const F e0 = exp_((dmin - d0) * F(K.blend_inv)), e1 = exp_((dmin - ds) * F(K.blend_inv)), e2 = exp_((dmin - dtk) * F(K.blend_inv));
+          const F wi = rcp_(e0 + e1 + e2);
+          w0 = e0 * wi; w1 = e1 * wi; w2 = e2 * wi;
+        }
+        q12[0] = w0 * o3 + w1 * ps;
+        s12[0] = w0 + w1;
+        wsh[0] = w1;
+        pbd[0] = q12[0] + w2 * pt;
+        dep[0] = depth(pbd[0], nwb[0]);          // the ground under the weighted centre (one-hot weights: the picked sphere's own)
       }
     }
 #pragma unroll
@@ -541,12 +552,14 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
       if (Ctx::kFlat) dnb[b] = Rw.r2;
       else dnb[b] = {Rw.r0.x * nwb[b].x + Rw.r1.x * nwb[b].y + Rw.r2.x * nwb[b].z, Rw.r0.y * nwb[b].x + Rw.r1.y * nwb[b].y + Rw.r2.y * nwb[b].z,
                      Rw.r0.z * nwb[b].x + Rw.r1.z * nwb[b].y + Rw.r2.z * nwb[b].z};
-      actb[b] = phib[b] < F(K.margin);
+      actb[b] = (phib[b] < F(K.margin)) && lives;
       actbf[b] = sel_(actb[b], one, zero);
-      rcb[b] = pbd[b] - F(K.knee_radius) * dnb[b];
-      kb1[b] = jm12[b] * cross(xax, rcb[b] - o1);
-      kb2[b] = jm12[b] * cross(yax, rcb[b] - o2);
-      kb3[b] = jm3[b] * cross(yax, rcb[b] - o3);
+      const V rn = F(K.knee_radius) * dnb[b];
+      rcb[b] = pbd[b] - rn;
+      const V a12 = q12[b] - s12[b] * rn;
+      kb1[b] = cross(xax, a12 - s12[b] * o1);
+      kb2[b] = cross(yax, a12 - s12[b] * o2);
+      kb3[b] = wsh[b] * cross(yax, (psh - rn) - o3);
     }
   }
   V dir[NRW];
@@ -680,7 +693,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
     auto anyhit = c.lane_is(0) && !c.lane_is(0);   // all-false mask
 #pragma unroll
     for (int j = 0; j < 3; j++) {
-      const auto hit = (L.q[j] >= F(K.jhi[j])) || (L.q[j] <= F(K.jlo[j]));
+      const auto hit = ((L.q[j] >= F(K.jhi[j])) || (L.q[j] <= F(K.jlo[j]))) && lives;
       jactf[j] = sel_(hit, one, zero);
       anyhit = anyhit || hit;
     }
@@ -1250,7 +1263,12 @@ ETG_HD void control_step_core(const Ctx& c, const KCfg& K, TickPar4<F>& tp, cons
                               float* ring, const float* etgp, const F* action, F donef, float* obs, F& reward, F& done,
                               float* info, const F* hyb = nullptr,     // hyb[4*j + (kp, qd_des, kd, tau_ff)], HYBRID mode
                               bool want_obs = true,                    // false: inner steps of the open-loop rollout (row unread)
-                              float* rec_q = nullptr, float* rec_imu = nullptr) {   // action-tape rollouts: see control_step16_core
+                              float* rec_q = nullptr, float* rec_imu = nullptr,     // action-tape rollouts: see control_step16_core
+                              bool skip_dead = false,                  // fused rollouts under KCfg.stop_at_done: see control_step16_core
+                              float* obs_end = nullptr) {              // skip_dead: also receives the last row of a robot whose episode ends here
+  const F live = skip_dead ? S.alive : F(1.0f);
+  const auto is_live = live > F(0.5f);
+  if (skip_dead) c.set_gate(is_live);
   int step_count = S.step_count;
   int tick = S.tick;
   const int has_last = S.has_last;
@@ -1266,8 +1284,13 @@ ETG_HD void control_step_core(const Ctx& c, const KCfg& K, TickPar4<F>& tp, cons
 #pragma unroll
     for (int j = 0; j < 3; j++) {
       F y = F(K.fb[0]) * qdes[j] + F(K.fb[1]) * S.fx0[j] + F(K.fb[2]) * S.fx1[j] - F(K.fa[1]) * S.fy0[j] - F(K.fa[2]) * S.fy1[j];
-      S.fx1[j] = S.fx0[j]; S.fx0[j] = qdes[j];
-      S.fy1[j] = S.fy0[j]; S.fy0[j] = y;
+      if (skip_dead) {   // (a finished robot's filter history stays)
+        S.fx1[j] = sel_(is_live, S.fx0[j], S.fx1[j]); S.fx0[j] = sel_(is_live, qdes[j], S.fx0[j]);
+        S.fy1[j] = sel_(is_live, S.fy0[j], S.fy1[j]); S.fy0[j] = sel_(is_live, y, S.fy0[j]);
+      } else {
+        S.fx1[j] = S.fx0[j]; S.fx0[j] = qdes[j];
+        S.fy1[j] = S.fy0[j]; S.fy0[j] = y;
+      }
       qdes[j] = y;
     }
   }
@@ -1296,22 +1319,18 @@ ETG_HD void control_step_core(const Ctx& c, const KCfg& K, TickPar4<F>& tp, cons
     F pd[9] = {L.q[0], L.q[1], L.q[2], L.qd[0], L.qd[1], L.qd[2], L.q[0], L.q[1], L.q[2]};   // EtgConfig.pd_latency: see control_step16_core
     if (pdl) pd_reading(c, K, ring, tick, false, pd);
     if (cl) clip_reading(c, K, ring, tick, false, L.q, pd + 6);
-    physics_tick(c, K, tp, L, proc, fext, torque_cmd, Ctx::kPlain ? (const F*)nullptr : pd);
+    physics_tick(c, K, tp, L, proc, fext, torque_cmd, Ctx::kPlain ? (const F*)nullptr : pd, live);
     tick++;
     if (pdl || cl || i == ia || i == ib) ring_push(c, ring, tick & (RING - 1), L);
   }
+  // (skip_dead: the control variables of a finished robot stay what they were when it finished: control_step16_core)
+  const int li = skip_dead ? c.sel_i(is_live, 1, 0) : 1;
 #pragma unroll
-  for (int j = 0; j < 3; j++) S.last[j] = qdes[j];
-  step_count++;
-  S.step_count = step_count; S.tick = tick; S.has_last = 1;
+  for (int j = 0; j < 3; j++) S.last[j] = (skip_dead && !Ctx::kPlain) ? sel_(is_live, qdes[j], last[j]) : qdes[j];
+  step_count += li;
+  S.step_count = step_count; S.tick = tick - (1 - li) * K.action_repeat; S.has_last |= li;
+  tick = S.tick;
   c.ring_fence();
-
-  F imu[6] = {F(0.0f), F(0.0f), F(0.0f), F(0.0f), F(0.0f), F(0.0f)};
-  if (want_obs || info) write_obs(c, K, L, ring_read<F>(c, K, ring, tick), S.r0, S.r1, S.r2, etg, lbx, lby, lbz, obs, imu);
-  if (rec_q)
-    for (int j = 0; j < 3; j++) c.st_row_lane(rec_q, ETG_ACT_DIM, j, 3, L.q[j]);
-  if (rec_imu)
-    for (int k = 0; k < 6; k++) c.st_row_env(rec_imu, 6, k, imu[k]);
 
   // ---- reward / termination (this repo's definitions)
   const float cdt = K.dt * (float)K.action_repeat;
@@ -1339,6 +1358,26 @@ ETG_HD void control_step_core(const Ctx& c, const KCfg& K, TickPar4<F>& tp, cons
   for (int k = 1; k < 8; k++) sum = sum + terms[k];
   reward = F(K.reward_p) * sum;
   done = sel_(term || (donef > F(0.5f)), F(1.0f), F(0.0f));
+  if (skip_dead) {   // a finished robot reports what the reference's loop would see if it looked again: nothing new
+    reward = sel_(is_live, reward, F(0.0f));
+    done = sel_(is_live, done, F(1.0f));
+  }
+  // the observation row: wanted by the caller, needed by info -- or the LAST one of a robot whose episode ends in this step
+  const bool ending = skip_dead && c.any(is_live && (done > F(0.5f)));
+  F imu[6] = {F(0.0f), F(0.0f), F(0.0f), F(0.0f), F(0.0f), F(0.0f)};
+  if (want_obs || info || ending) {
+    const auto Dl = ring_read<F>(c, K, ring, tick);
+    write_obs(c, K, L, Dl, S.r0, S.r1, S.r2, etg, lbx, lby, lbz, obs, imu);
+    if (ending && obs_end && obs_end != obs) {
+      c.set_gate(is_live && (done > F(0.5f)));
+      write_obs(c, K, L, Dl, S.r0, S.r1, S.r2, etg, lbx, lby, lbz, obs_end, imu);
+      c.set_gate(is_live);
+    }
+  }
+  if (rec_q)
+    for (int j = 0; j < 3; j++) c.st_row_lane(rec_q, ETG_ACT_DIM, j, 3, L.q[j]);
+  if (rec_imu)
+    for (int k = 0; k < 6; k++) c.st_row_env(rec_imu, 6, k, imu[k]);
   if (info) {
     for (int k = 0; k < 8; k++) c.st_row_env(info, ETG_INFO_DIM, k, terms[k]);
     c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_VELX, vx);
@@ -1366,6 +1405,11 @@ ETG_HD void control_step_core(const Ctx& c, const KCfg& K, TickPar4<F>& tp, cons
   S.ret = S.ret + S.alive * reward;
   S.len = S.len + S.alive;
   S.alive = sel_(done > F(0.5f), F(0.0f), S.alive);
+  if (skip_dead) {
+    c.open_gate();
+    S.lbx = sel_(is_live, S.lbx, lbx); S.lby = sel_(is_live, S.lby, lby); S.lbz = sel_(is_live, S.lbz, lbz);
+    S.last_fwx = sel_(is_live, S.last_fwx, last_fwx);
+  }
 }
 
 // env.step for one robot quad: load the control state, one step, store it
@@ -1382,10 +1426,37 @@ ETG_HD void control_step(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   store_ctl4(c, K, S, ctl, ictl, legctl);
 }
 
+// fused rollouts under KCfg.stop_at_done: see rollout_dead_store16 / rollout_store16 (etg_core16.h), one leg per lane here
+template <class F, class Ctx>
+ETG_HD void rollout_dead_store(const Ctx& c, const KCfg& K, const LaneState<F>& L, F was_alive, F done, bool last_step, bool noise_ending,
+                               int obs_call, float* base, float* leg, int* ictl) {
+  const auto was = was_alive > F(0.5f);
+  const auto ended = was && (done > F(0.5f));
+  if (c.any(ended)) {
+    c.set_gate(ended);
+    store_state(c, base, leg, L);
+    c.open_gate();
+  }
+  if (K.noise_on && (last_step || noise_ending)) {
+    const auto wrote = last_step ? was : ended;
+    if (c.any(wrote)) {
+      c.set_gate(wrote);
+      c.st_env_i(ictl, IC_OBS_CALL, obs_call);
+      c.open_gate();
+    }
+  }
+}
+template <class F, class Ctx>
+ETG_HD void rollout_store(const Ctx& c, const KCfg& K, const LaneState<F>& L, F alive, float* base, float* leg) {
+  if (K.stop_at_done) c.set_gate(alive > F(0.5f));
+  store_state(c, base, leg, L);
+  c.open_gate();
+}
+
 // open-loop rollout (pretrain.py:129-154): n_steps env.steps with zero residual action in one kernel
 template <class F, class Ctx>
-ETG_HD void rollout_steps(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ring, float* ctl, int* ictl, float* legctl,
-                          const float* etgp, int n_steps, float* obs) {
+ETG_HD void rollout_steps(const Ctx& c, const KCfg& K, LaneState<F>& L, float* base, float* leg, float* ring, float* ctl, int* ictl,
+                          float* legctl, const float* etgp, int n_steps, float* obs) {
   StepCtl4<F> S = load_ctl4<F>(c, K, ctl, ictl, legctl);
   TickPar4<F> tp = load_tick_par4<F>(c);
   V3<F> fext = {F(0.0f), F(0.0f), F(0.0f)};
@@ -1393,10 +1464,16 @@ ETG_HD void rollout_steps(const Ctx& c, const KCfg& K, LaneState<F>& L, float* r
                                            c.ld_env(ctl, CT_FEXT + 2) + c.ld_env(ctl, CT_PUSH + 2)};   // set force + random push
   const F zero3[3] = {F(0.0f), F(0.0f), F(0.0f)};
   F reward, done;
-  for (int s = 0; s < n_steps; s++)   // only the last observation of the rollout is ever read (see rollout_steps16)
+  const bool skip = K.stop_at_done != 0;
+  for (int s = 0; s < n_steps; s++) {   // only the last observation of the rollout is ever read (see rollout_steps16)
+    if (skip && !c.any(S.alive > F(0.5f))) break;     // every robot of the wave has finished
+    const F was_alive = S.alive;
     control_step_core(c, K, tp, fext, L, S, ring, etgp, zero3, F(0.0f), obs, reward, done, (float*)nullptr, (const F*)nullptr,
-                      s == n_steps - 1);
+                      s == n_steps - 1, (float*)nullptr, (float*)nullptr, skip);
+    if (skip) rollout_dead_store(c, K, L, was_alive, done, s == n_steps - 1, true, (int)K.noise_call + s, base, leg, ictl);
+  }
   store_ctl4(c, K, S, ctl, ictl, legctl);
+  rollout_store(c, K, L, S.alive, base, leg);
 }
 
 

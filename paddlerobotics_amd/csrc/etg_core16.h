@@ -119,7 +119,10 @@ template <class F, class Ctx> ETG_HD LegGeo<F> leg_geometry(const Ctx& c, const 
 // ------------------------------------------------------------------ one physics tick, 16 lanes per robot
 template <class F, class Ctx>
 ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, State16<F>& L, F qdes, bool torque_cmd = false,
-                           const F* pd = nullptr) {   // pd: (angle, velocity) the PD law reads instead of the true ones (pd_latency), pd[2]: the angle the command clip refers to
+                           const F* pd = nullptr,     // pd: (angle, velocity) the PD law reads instead of the true ones (pd_latency), pd[2]: the angle the command clip refers to
+                           F live = F(1.0f)) {        // 0 on the lanes of a robot whose episode has ended (fused rollouts, KCfg.stop_at_done): it gets
+                                                      // no contact and no joint-stop rows, so it neither sends its wave down the body / joint paths nor
+                                                      // holds it in the sweeps; what its registers do from then on is never stored (control_step16_core)
   typedef V3<F> V;
   typedef SV<F> W;
   const F dt(K.dt), zero(0.0f), one(1.0f);
@@ -172,15 +175,23 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   const F f3 = sel_(s3, one, zero);
   V pc = g.pf, fw;
   F rad(K.foot_radius);
-  F jm12 = one, jm3 = one;   // which joints move the point of this lane's row (hip & thigh, calf)
-  V pb = g.o3;               // centre of the leg's body sphere and the joints that move it (replicated in the quad)
-  F bj12 = one, bj3 = zero;
+  // The leg's body contact: a sphere of knee_radius at the knee (body_contacts 1) or at the WEIGHTED MEAN of three sphere
+  // centres -- knee, shin midpoint, trunk corner next to the hip (body_contacts 2) -- with weights bw0, bw1, bw2 (replicated in
+  // the quad): one-hot on the deepest sphere (EtgConfig.body_blend = 0; ties to the earlier candidate, as in the oracle), or
+  // exp(-(d_i - d_min) / body_blend), normalised: the contact's impulse is distributed over the spheres, a shin lying along the
+  // ground is carried at both ends instead of hopping between them (etgsim.h: body_blend).  Joints: hip and thigh move the
+  // knee and the shin midpoint, the calf joint the shin midpoint only, none the trunk corner -- the joint columns of the
+  // contact's rows are the weighted sums:  axis_j x (q12 - s12 (r n + o_j))  for hip / thigh,  bw1 axis x (ps - r n - o3)  for
+  // the calf, with q12 = bw0 o3 + bw1 ps, s12 = bw0 + bw1.
+  V pb = g.o3;               // centre of the leg's body contact sphere
+  V ps_ = g.o3;              // the shin midpoint (body_contacts 2)
+  F bw0 = one, bw1 = zero, bw2 = zero;
+  V q12 = g.o3;              // bw0 o3 + bw1 ps
+  F s12 = one;               // bw0 + bw1
   F tap[6];
   auto contact_point = [&]() {
     if (bodies) {
       if (K.knee >= 2) {
-        // the DEEPEST of three spheres of knee_radius: knee, shin midpoint (moved by all three joints), trunk corner next to
-        // this leg's hip (moved by none); ties go to the earlier candidate, as in the oracle
         const V ps = g.o3 - F(0.5f * K.lower_len) * g.ez3;
         const V pt = {sel_(g.o1.x > zero, F(K.trunk_half[0]), F(-K.trunk_half[0])),
                       sel_(g.o1.y > zero, F(K.trunk_half[1]), F(-K.trunk_half[1])), F(-K.trunk_half[2])};
@@ -201,12 +212,20 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
         const auto ms = d1 < d0;
         const F best = sel_(ms, d1, d0);
         const auto mt = d2 < best;
-        pb = {sel_(mt, pt.x, sel_(ms, ps.x, g.o3.x)), sel_(mt, pt.y, sel_(ms, ps.y, g.o3.y)), sel_(mt, pt.z, sel_(ms, ps.z, g.o3.z))};
-        bj12 = sel_(mt, zero, one);
-        bj3 = sel_(mt, zero, sel_(ms, one, zero));
+        bw0 = sel_(mt, zero, sel_(ms, zero, one));
+        bw1 = sel_(mt, zero, sel_(ms, one, zero));
+        bw2 = sel_(mt, one, zero);
+        if (K.blend_inv > 0.0f) {
+          const F dmin = sel_(mt, d2, best);
+          const F e0 = exp_((dmin - d0) * F(K.blend_inv)), e1 = exp_((dmin - d1) * F(K.blend_inv)), e2 = exp_((dmin - d2) * F(K.blend_inv));
+          const F wi = rcp_(e0 + e1 + e2);
+          bw0 = e0 * wi; bw1 = e1 * wi; bw2 = e2 * wi;
+        }
+        ps_ = ps;
+        q12 = bw0 * g.o3 + bw1 * ps;
+        s12 = bw0 + bw1;
+        pb = q12 + bw2 * pt;
       }
-      jm12 = sel_(s3, bj12, one);
-      jm3 = sel_(s3, bj3, one);
       pc = {sel_(s3, pb.x, g.pf.x), sel_(s3, pb.y, g.pf.y), sel_(s3, pb.z, g.pf.z)};
       rad = sel_(s3, F(K.knee_radius), F(K.foot_radius));
     }
@@ -340,13 +359,17 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
            Rw.r0.z * dw.x + Rw.r1.z * dw.y + Rw.r2.z * dw.z};
   }
   auto act = phi < F(K.margin);
-  const F rowf = (bodies ? one : mj) * sel_(act, one, zero);    // 1 on the rows of an active foot (/ body sphere)
+  const F rowf = (bodies ? one : mj) * sel_(act, one, zero) * live;   // 1 on the rows of an active foot (/ body sphere)
   V rc = pc - rad * dn;
   V k1 = cross(xax, rc - g.o1), k2 = cross(g.yax, rc - g.o2), k3 = cross(g.yax, rc - g.o3);
-  if (knee) {   // the body row pushes along the normal; the calf joint does not move the knee (nor any joint the trunk)
+  if (knee) {   // the body row pushes along the normal; its joint columns are the weighted sums over the spheres (see above)
     if (Ctx::kFlat) dir = {sel_(s3, dn.x, dir.x), sel_(s3, dn.y, dir.y), sel_(s3, dn.z, dir.z)};
-    k3 = jm3 * k3;
-    if (K.knee >= 2) { k1 = jm12 * k1; k2 = jm12 * k2; }
+    const V rn = rad * dn;
+    const V a12 = q12 - s12 * rn, a3 = ps_ - rn;
+    const V b1 = cross(xax, a12 - s12 * g.o1), b2 = cross(g.yax, a12 - s12 * g.o2), b3 = bw1 * cross(g.yax, a3 - g.o3);
+    k1 = {sel_(s3, b1.x, k1.x), sel_(s3, b1.y, k1.y), sel_(s3, b1.z, k1.z)};
+    k2 = {sel_(s3, b2.x, k2.x), sel_(s3, b2.y, k2.y), sel_(s3, b2.z, k2.z)};
+    k3 = {sel_(s3, b3.x, k3.x), sel_(s3, b3.y, k3.y), sel_(s3, b3.z, k3.z)};
   }
   // wave-uniform: does ANY robot of the wave have a body sphere inside the margin this tick?  If not, the tick finishes on the
   // toe-spheres path (hand-scheduled sweeps, no body columns); a robot's result does not depend on which path its wave takes.
@@ -448,7 +471,7 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   if (K.jlim) {   // (compiled into the PLAIN instantiations too: the stops are on by default)
     jlo = sel_(s0, F(K.jlo[0]), sel_(s1, F(K.jlo[1]), F(K.jlo[2])));
     jhi = sel_(s0, F(K.jhi[0]), sel_(s1, F(K.jhi[1]), F(K.jhi[2])));
-    jactf = mj * sel_((L.q >= jhi) || (L.q <= jlo), one, zero);
+    jactf = mj * sel_((L.q >= jhi) || (L.q <= jlo), one, zero) * live;
     anyj = c.any(jactf > F(0.5f));
   }
   // solve + apply, instantiated with and without the joint rows: without them their variables are compile-time zeros
@@ -515,8 +538,10 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
       dir2 = {Rw.r0.x * dw.x + Rw.r1.x * dw.y + Rw.r2.x * dw.z, Rw.r0.y * dw.x + Rw.r1.y * dw.y + Rw.r2.y * dw.z,
               Rw.r0.z * dw.x + Rw.r1.z * dw.y + Rw.r2.z * dw.z};
     }
-    const V rc2 = pb - F(K.knee_radius) * dnb;
-    const V kb1 = bj12 * cross(xax, rc2 - g.o1), kb2 = bj12 * cross(g.yax, rc2 - g.o2), kb3 = bj3 * cross(g.yax, rc2 - g.o3);
+    const V rn2 = F(K.knee_radius) * dnb;
+    const V rc2 = pb - rn2;
+    const V a12b = q12 - s12 * rn2;
+    const V kb1 = cross(xax, a12b - s12 * g.o1), kb2 = cross(g.yax, a12b - s12 * g.o2), kb3 = bw1 * cross(g.yax, (ps_ - rn2) - g.o3);
     const F Jb0 = rowf2 * dot(dir2, kb1), Jb1 = rowf2 * dot(dir2, kb2), Jb2_ = rowf2 * dot(dir2, kb3);
     hj2[0] = Hi11 * Jb0 + Hi12 * Jb1 + Hi13 * Jb2_;
     hj2[1] = Hi12 * Jb0 + Hi22 * Jb1 + Hi23 * Jb2_;
@@ -929,6 +954,12 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   L.lam = lam;
   const F ln_leg = c.qb(lam, 0);
   L.contact = sel_(act && (ln_leg > zero), one, zero);
+#ifdef ETG_TRACE_TICKS   // debugging build (tools/first_divergence.py): what this tick decided and solved, per lane
+  {
+    const F tv[10] = {rowf, phi, lam, lam2, jactf, lamq, bw1 + F(2.0f) * bw2, F((float)L.sweeps), L.q, L.qd};
+    c.trace_tick(K, tv);
+  }
+#endif
   };   // finish_tick
   if (anyb) {
     if (anyj) finish_tick(std::true_type{}, std::true_type{});
@@ -1178,8 +1209,19 @@ ETG_HD void control_step16_core(const Ctx& c, const KCfg& K, TickPar<F>& tp, Sta
                                 bool want_obs = true,       // false (inner steps of the open-loop rollout): the observation row is not
                                                             // read by anybody -- skip the delayed reading and the row (info needs it)
                                 float* rec_q = nullptr,     // action-tape rollouts: rows [N,12] / [N,6] receiving info["joint_angle"] and
-                                float* rec_imu = nullptr) { // info["obs-IMU"] of this step (Dynamic_parallel_model.py:63-64)
+                                float* rec_imu = nullptr,   // info["obs-IMU"] of this step (Dynamic_parallel_model.py:63-64)
+                                bool skip_dead = false,     // fused rollouts under KCfg.stop_at_done: see below
+                                float* obs_end = nullptr) { // skip_dead: a second row buffer that receives the LAST row of a robot whose episode
+                                                            // ends in this step (tape rollouts: `obs` is the tape's row of the step then)
   const F mj = c.jointf();
+  // An ended episode is not simulated any more (skip_dead; the reference's loops leave at `done`: pretrain.py:137-153,
+  // train.py:226-247).  SIMD lanes cannot sit a step out, so a finished robot (S.alive == 0) is taken out of everything that
+  // costs its wave time or touches memory: no contact / joint-stop rows in its ticks (physics_tick16: live), every store of
+  // the step gated off, its control variables put back afterwards.  The caller stored its state when it finished
+  // (rollout_dead_store16) and does not store it again; a wave whose robots have all finished leaves the step loop.
+  const F live = skip_dead ? S.alive : F(1.0f);
+  const auto is_live = live > F(0.5f);
+  if (skip_dead) c.set_gate(is_live);
   // EtgConfig.enable_etg = 0 (Dynamic_parallel_model.py:49 `ETG=0`): no generator, the command is pose_ori + action
   F etg = (Ctx::kPlain || K.etg_on) ? etg_action16<F>(c, K, etgp, (float)(S.step_count + 1) * K.etg_dt) : F(0.0f);
   const bool torque_cmd = !Ctx::kPlain && K.motor_mode == 1;
@@ -1187,8 +1229,13 @@ ETG_HD void control_step16_core(const Ctx& c, const KCfg& K, TickPar<F>& tp, Sta
   F qdes = (torque_cmd || hybrid_cmd) ? mj * action : mj * (c.par_joint(PR_POSE) + etg + action);
   if (!Ctx::kPlain && K.enable_filter) {
     F y = F(K.fb[0]) * qdes + F(K.fb[1]) * S.fx0 + F(K.fb[2]) * S.fx1 - F(K.fa[1]) * S.fy0 - F(K.fa[2]) * S.fy1;
-    S.fx1 = S.fx0; S.fx0 = qdes;
-    S.fy1 = S.fy0; S.fy0 = y;
+    if (skip_dead) {   // (a finished robot's filter history stays)
+      S.fx1 = sel_(is_live, S.fx0, S.fx1); S.fx0 = sel_(is_live, qdes, S.fx0);
+      S.fy1 = sel_(is_live, S.fy0, S.fy1); S.fy0 = sel_(is_live, y, S.fy0);
+    } else {
+      S.fx1 = S.fx0; S.fx0 = qdes;
+      S.fy1 = S.fy0; S.fy0 = y;
+    }
     qdes = mj * y;
   }
   const F last = S.last, lbx = S.lbx, lby = S.lby, lbz = S.lbz, last_fwx = S.last_fwx;
@@ -1213,20 +1260,20 @@ ETG_HD void control_step16_core(const Ctx& c, const KCfg& K, TickPar<F>& tp, Sta
     F pd[3] = {L.q, L.qd, L.q};   // EtgConfig.pd_latency: the PD law reads a delayed joint state, so every tick's reading enters the ring
     if (pdl) pd_reading16(c, K, ring, tick, false, pd);
     if (cl) pd[2] = clip_reading16(c, K, ring, tick, false, L.q);
-    physics_tick16(c, K, tp, L, proc, torque_cmd, Ctx::kPlain ? (const F*)nullptr : pd);   // (ONE inlined copy of the tick)
+#ifdef ETG_TRACE_TICKS
+    c.trace_index(i);
+#endif
+    physics_tick16(c, K, tp, L, proc, torque_cmd, Ctx::kPlain ? (const F*)nullptr : pd, live);   // (ONE inlined copy of the tick)
     tick++;
     if (pdl || cl || i == ia || i == ib) ring_push16(c, ring, tick & (RING - 1), L);
   }
-  S.tick = tick;
-  S.last = qdes;
-  S.step_count++;
-  S.has_last = 1;
-
-  F imu[6] = {F(0.0f), F(0.0f), F(0.0f), F(0.0f), F(0.0f), F(0.0f)};
-  if (want_obs || info) write_obs16(c, K, L, ring_read16<F>(c, K, ring, tick), S.r0, S.r1, S.r2, etg, lbx, lby, lbz, obs, imu);
-  if (rec_q) c.st_row_joint(rec_q, ETG_ACT_DIM, 0, L.q);
-  if (rec_imu)
-    for (int k = 0; k < 6; k++) c.st_row_env(rec_imu, 6, k, imu[k]);
+  // (skip_dead: the control variables of a finished robot stay what they were when it finished -- without holding copies of
+  // them through the ticks: counters advance by `live`, the floats fall back on values this function keeps anyway)
+  const int li = skip_dead ? c.sel_i(is_live, 1, 0) : 1;
+  S.tick = tick - (1 - li) * K.action_repeat;
+  S.last = (skip_dead && !Ctx::kPlain) ? sel_(is_live, qdes, last) : qdes;   // (read by the action interpolation only: not in the PLAIN layer)
+  S.step_count += li;
+  S.has_last |= li;
 
   const float cdt = K.dt * (float)K.action_repeat;
   Rows<F> Rw = quat_rows(L.qx, L.qy, L.qz, L.qw);
@@ -1254,6 +1301,27 @@ ETG_HD void control_step16_core(const Ctx& c, const KCfg& K, TickPar<F>& tp, Sta
   for (int k = 1; k < 8; k++) sum = sum + terms[k];
   reward = F(K.reward_p) * sum;
   done = sel_(term || (donef > F(0.5f)), F(1.0f), F(0.0f));
+  if (skip_dead) {   // a finished robot reports what the reference's loop would see if it looked again: nothing new
+    reward = sel_(is_live, reward, F(0.0f));
+    done = sel_(is_live, done, F(1.0f));
+  }
+
+  // The observation row: wanted by the caller, needed by info -- or the LAST one of a robot whose episode ends in this step
+  // (skip_dead: nobody writes its row again, and the inner steps of an open-loop rollout write none).
+  const bool ending = skip_dead && c.any(is_live && (done > F(0.5f)));
+  F imu[6] = {F(0.0f), F(0.0f), F(0.0f), F(0.0f), F(0.0f), F(0.0f)};
+  if (want_obs || info || ending) {
+    const Delayed16<F> D = ring_read16<F>(c, K, ring, tick);
+    write_obs16(c, K, L, D, S.r0, S.r1, S.r2, etg, lbx, lby, lbz, obs, imu);
+    if (ending && obs_end && obs_end != obs) {
+      c.set_gate(is_live && (done > F(0.5f)));
+      write_obs16(c, K, L, D, S.r0, S.r1, S.r2, etg, lbx, lby, lbz, obs_end, imu);
+      c.set_gate(is_live);
+    }
+  }
+  if (rec_q) c.st_row_joint(rec_q, ETG_ACT_DIM, 0, L.q);
+  if (rec_imu)
+    for (int k = 0; k < 6; k++) c.st_row_env(rec_imu, 6, k, imu[k]);
   if (info) {
     for (int k = 0; k < 8; k++) c.st_row_env(info, ETG_INFO_DIM, k, terms[k]);
     c.st_row_env(info, ETG_INFO_DIM, ETG_INFO_VELX, vx);
@@ -1277,6 +1345,11 @@ ETG_HD void control_step16_core(const Ctx& c, const KCfg& K, TickPar<F>& tp, Sta
   S.ret = S.ret + S.alive * reward;
   S.len = S.len + S.alive;
   S.alive = sel_(done > F(0.5f), F(0.0f), S.alive);
+  if (skip_dead) {
+    c.open_gate();
+    S.lbx = sel_(is_live, S.lbx, lbx); S.lby = sel_(is_live, S.lby, lby); S.lbz = sel_(is_live, S.lbz, lbz);
+    S.last_fwx = sel_(is_live, S.last_fwx, last_fwx);
+  }
 }
 
 // env.step for one robot row: load the control state, one step, store it
@@ -1291,22 +1364,61 @@ ETG_HD void control_step16(const Ctx& c, const KCfg& K, State16<F>& L, float* ri
   store_ctl16(c, K, S, ctl, ictl, legctl);
 }
 
+// ---- fused rollouts under KCfg.stop_at_done: the bookkeeping of a step loop around control_step16_core(..., skip_dead = true)
+// after a step: a robot whose episode ended IN this step (it was alive before, the step said done) stores its state -- the
+// terminal state -- now; nothing of it is stored again (rollout_store16).  obs_call: stream position of the observation row this
+// step wrote (KCfg.noise_call + step index); robots whose row still waits for its sensor noise from the launch's epilogue
+// (k_add_noise_rows) -- the last step's rows, and the last row of a robot that ends mid-launch when `noise_ending` -- note it.
+template <class F, class Ctx>
+ETG_HD void rollout_dead_store16(const Ctx& c, const KCfg& K, const State16<F>& L, F was_alive, F done, bool last_step, bool noise_ending,
+                                 int obs_call, float* base, float* leg, int* ictl) {
+  const auto was = was_alive > F(0.5f);
+  const auto ended = was && (done > F(0.5f));
+  if (c.any(ended)) {
+    c.set_gate(ended);
+    store_state16(c, base, leg, L);
+    c.open_gate();
+  }
+  if (K.noise_on && (last_step || noise_ending)) {
+    const auto wrote = last_step ? was : ended;
+    if (c.any(wrote)) {
+      c.set_gate(wrote);
+      c.st_env_i(ictl, IC_OBS_CALL, obs_call);
+      c.open_gate();
+    }
+  }
+}
+// at the end of the launch: the state of the robots that are still running (all of them without stop_at_done)
+template <class F, class Ctx>
+ETG_HD void rollout_store16(const Ctx& c, const KCfg& K, const State16<F>& L, F alive, float* base, float* leg) {
+  if (K.stop_at_done) c.set_gate(alive > F(0.5f));
+  store_state16(c, base, leg, L);
+  c.open_gate();
+}
+
 // open-loop rollout (pretrain.py:129-154): n_steps env.steps with zero residual action in ONE kernel -- the robot's
 // state, control variables and tick constants stay in registers between the steps, and the per-launch cost
 // (parameter staging, state load/store, launch ramp) is paid once
 template <class F, class Ctx>
-ETG_HD void rollout_steps16(const Ctx& c, const KCfg& K, State16<F>& L, float* ring, float* ctl, int* ictl, float* legctl,
-                            const float* etgp, int n_steps, float* obs) {
+ETG_HD void rollout_steps16(const Ctx& c, const KCfg& K, State16<F>& L, float* base, float* leg, float* ring, float* ctl, int* ictl,
+                            float* legctl, const float* etgp, int n_steps, float* obs) {
   StepCtl16<F> S = load_ctl16<F>(c, K, ctl, ictl, legctl);
   TickPar<F> tp = load_tick_par<F>(c);
   if (!Ctx::kPlain && K.ext_force) tp.fext = load_fext16<F>(c, ctl);
   F reward, done;
+  const bool skip = K.stop_at_done != 0;
   // only the LAST observation of an open-loop rollout is ever read (etg_rollout_openloop hands it to the caller): the inner
   // steps skip the delayed reading and the 49-float row; the ring itself is pushed every step, so the last reading is exact
-  for (int s = 0; s < n_steps; s++)
+  // (stop_at_done: a robot's last row is the one of the step that ended its episode)
+  for (int s = 0; s < n_steps; s++) {
+    if (skip && !c.any(S.alive > F(0.5f))) break;     // every robot of the wave has finished
+    const F was_alive = S.alive;
     control_step16_core(c, K, tp, L, S, ring, etgp, F(0.0f), F(0.0f), obs, reward, done, (float*)nullptr, (const F*)nullptr,
-                        s == n_steps - 1);
+                        s == n_steps - 1, (float*)nullptr, (float*)nullptr, skip);
+    if (skip) rollout_dead_store16(c, K, L, was_alive, done, s == n_steps - 1, true, (int)K.noise_call + s, base, leg, ictl);
+  }
   store_ctl16(c, K, S, ctl, ictl, legctl);
+  rollout_store16(c, K, L, S.alive, base, leg);
 }
 
 // ------------------------------------------------------------------ reset

@@ -45,15 +45,21 @@ struct GpuCtx {
   int gid, env, lane, N, NL;
   const float* lds;  // this lane's parameter column in LDS: lds[k * BLOCK]
   const float* gpar; // D.par, for the tick constants read straight into registers
+  // store gate (fused rollouts under KCfg.stop_at_done, etg_core16.h: control_step16_core): every store of this context happens
+  // on the lanes inside the gate only.  Never closed by the step / reset kernels: the constant `true` folds away there.
+  mutable bool gate = true;
+  __device__ __forceinline__ void set_gate(bool on) const { gate = on; }
+  __device__ __forceinline__ void open_gate() const { gate = true; }
+  __device__ __forceinline__ int sel_i(bool m, int a, int b) const { return m ? a : b; }
   __device__ __forceinline__ float par(int k) const { return lds[k * 64]; }
   __device__ __forceinline__ float tpar(int k) const { return gpar[(size_t)k * NL + gid]; }
   __device__ __forceinline__ float ld_lane(const float* p, int f) const { return p[(size_t)f * NL + gid]; }
-  __device__ __forceinline__ void st_lane(float* p, int f, float v) const { p[(size_t)f * NL + gid] = v; }
+  __device__ __forceinline__ void st_lane(float* p, int f, float v) const { if (gate) p[(size_t)f * NL + gid] = v; }
   __device__ __forceinline__ float ld_env(const float* p, int f) const { return p[(size_t)f * N + env]; }
-  __device__ __forceinline__ void st_env(float* p, int f, float v) const { if (lane == 0) p[(size_t)f * N + env] = v; }
+  __device__ __forceinline__ void st_env(float* p, int f, float v) const { if (gate && lane == 0) p[(size_t)f * N + env] = v; }
   __device__ __forceinline__ int ld_env_i(const int* p, int f) const { return p[(size_t)f * N + env]; }
-  __device__ __forceinline__ void st_env_i(int* p, int f, int v) const { if (lane == 0) p[(size_t)f * N + env] = v; }
-  __device__ __forceinline__ void st_ring(float* r, int slot, int k, float v) const { r[((size_t)slot * 8 + k) * NL + gid] = v; }
+  __device__ __forceinline__ void st_env_i(int* p, int f, int v) const { if (gate && lane == 0) p[(size_t)f * N + env] = v; }
+  __device__ __forceinline__ void st_ring(float* r, int slot, int k, float v) const { if (gate) r[((size_t)slot * 8 + k) * NL + gid] = v; }
   __device__ __forceinline__ float ld_ring(const float* r, int slot, int k) const { return r[((size_t)slot * 8 + k) * NL + gid]; }
   // the ring is written and read back by the SAME lane (program order): no fence needed
   __device__ __forceinline__ void ring_fence() const {}
@@ -73,8 +79,8 @@ struct GpuCtx {
   mutable long long prof_last;
 #endif
   int row_base = 0;  // first robot of the [*, rowlen] row buffers (observation tile in LDS: the workgroup's first robot)
-  __device__ __forceinline__ void st_row_env(float* p, int rowlen, int col, float v) const { if (lane == 0) p[(size_t)(env - row_base) * rowlen + col] = v; }
-  __device__ __forceinline__ void st_row_lane(float* p, int rowlen, int col0, int stride, float v) const { p[(size_t)(env - row_base) * rowlen + col0 + stride * lane] = v; }
+  __device__ __forceinline__ void st_row_env(float* p, int rowlen, int col, float v) const { if (gate && lane == 0) p[(size_t)(env - row_base) * rowlen + col] = v; }
+  __device__ __forceinline__ void st_row_lane(float* p, int rowlen, int col0, int stride, float v) const { if (gate) p[(size_t)(env - row_base) * rowlen + col0 + stride * lane] = v; }
   __device__ __forceinline__ float ld_row_env(const float* p, int rowlen, int col) const { return p[(size_t)(env - row_base) * rowlen + col]; }
   __device__ __forceinline__ float ld_row_lane(const float* p, int rowlen, int col0, int stride) const { return p[(size_t)(env - row_base) * rowlen + col0 + stride * lane]; }
   // order-symmetric quad sum: (x0+x1)+(x2+x3) on every lane, bit-identical across the quad
@@ -478,8 +484,7 @@ __global__ void __launch_bounds__(BLOCK) k_rollout(KCfg K, DevState D, int n_ste
   __shared__ float lds_par[PR_N * BLOCK];
   stage_params(c, D, lds_par);
   LaneState<float> L = load_state<float>(c, D.base, D.leg);
-  rollout_steps(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, n_steps, obs);
-  store_state(c, D.base, D.leg, L);
+  rollout_steps(c, K, L, D.base, D.leg, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, n_steps, obs);   // (stores the state itself: stop_at_done)
   if (so.ret && c.lane == 0) {   // the last launch of a rollout hands the episode statistics to the caller itself (no extra launch)
     so.ret[c.env] = D.ctl[(size_t)CT_RET * K.n_env + c.env];
     so.len[c.env] = (int)D.ctl[(size_t)CT_LEN * K.n_env + c.env];
@@ -504,20 +509,31 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_actions(KCfg K, DevState D, i
                                      c.ld_env(D.ctl, CT_FEXT + 2) + c.ld_env(D.ctl, CT_PUSH + 2)};
   const size_t N = K.n_env;
   float reward, done;
+  const bool skip = K.stop_at_done != 0;
   for (int s = 0; s < n_steps; s++) {
     const float* a = actions + (size_t)s * N * ETG_ACT_DIM;
     const float act[3] = {c.ld_row_lane(a, ETG_ACT_DIM, 0, 3), c.ld_row_lane(a, ETG_ACT_DIM, 1, 3), c.ld_row_lane(a, ETG_ACT_DIM, 2, 3)};
     const bool last = s == n_steps - 1;
-    control_step_core(c, K, tp, fext, L, S, D.ring, D.etgp, act, 0.0f, (T.obs && !last) ? T.obs + (size_t)s * N * ETG_OBS_DIM : obs, reward, done,
-                      (float*)nullptr, (const float*)nullptr, last || T.obs || T.imu, T.q ? T.q + (size_t)s * N * ETG_ACT_DIM : nullptr,
-                      T.imu ? T.imu + (size_t)s * N * 6 : nullptr);
+    const float was_alive = S.alive;
+    // (stop_at_done: the steps after a robot's episode write reward 0 / done 1 to the tape and leave its other rows alone; once
+    // every robot of the wave has finished only those two are written)
+    if (!skip || c.any(was_alive > 0.5f)) {
+      control_step_core(c, K, tp, fext, L, S, D.ring, D.etgp, act, 0.0f, (T.obs && !last) ? T.obs + (size_t)s * N * ETG_OBS_DIM : obs, reward, done,
+                        (float*)nullptr, (const float*)nullptr, last || T.obs || T.imu, T.q ? T.q + (size_t)s * N * ETG_ACT_DIM : nullptr,
+                        T.imu ? T.imu + (size_t)s * N * 6 : nullptr, skip, obs);
+      // (a robot that ends mid-launch leaves its last row in the tape AND in `obs`; recorded rows and sensor noise exclude each
+      // other -- etg_rollout_actions refuses the combination -- so with noise on every row in `obs` notes its stream position)
+      if (skip) rollout_dead_store(c, K, L, was_alive, done, last, true, (int)K.noise_call + s, D.base, D.leg, D.ictl);
+    } else {
+      reward = 0.0f; done = 1.0f;
+    }
     if (c.lane == 0) {
       if (T.rew) T.rew[(size_t)s * N + c.env] = reward;
       if (T.done) T.done[(size_t)s * N + c.env] = done > 0.5f ? 1 : 0;
     }
   }
   store_ctl4(c, K, S, D.ctl, D.ictl, D.legctl);
-  store_state(c, D.base, D.leg, L);
+  rollout_store(c, K, L, S.alive, D.base, D.leg);
 }
 
 // ====================================================================== 16 lanes per robot
@@ -531,6 +547,19 @@ struct GpuCtx16 {
   const float* lds;  // this lane's LDS column
   const float* gpar; // D.par: the tick constants are read from it directly (tpar*)
   int row_base = 0;  // first robot of the [*, rowlen] row buffers (obs tile in LDS: the workgroup's first robot)
+#ifdef ETG_TRACE_TICKS
+  mutable int trace_i = 0;
+  __device__ __forceinline__ void trace_index(int i) const { trace_i = i; }
+  __device__ __forceinline__ void trace_tick(const KCfg& K, const float* v) const {
+    if (!K.trace || trace_i >= 16) return;
+    float* row = K.trace + (((size_t)env * 16 + trace_i) * 16 + r) * 10;
+    for (int k = 0; k < 10; k++) row[k] = v[k];
+  }
+#endif
+  mutable bool gate = true;   // store gate: see GpuCtx
+  __device__ __forceinline__ void set_gate(bool on) const { gate = on; }
+  __device__ __forceinline__ void open_gate() const { gate = true; }
+  __device__ __forceinline__ int sel_i(bool m, int a, int b) const { return m ? a : b; }
   __device__ __forceinline__ float jointf() const { return sub < 3 ? 1.0f : 0.0f; }
   __device__ __forceinline__ bool sub_is(int j) const { return sub == j; }
   __device__ __forceinline__ bool leg_is(int j) const { return leg == j; }
@@ -855,25 +884,25 @@ struct GpuCtx16 {
   }
   // ---- memory (same SoA arrays as the 4-lane kernels)
   __device__ __forceinline__ float ld_joint(const float* p, int f0) const { return p[(size_t)(f0 + sc) * NL + col]; }
-  __device__ __forceinline__ void st_joint(float* p, int f0, float v) const { if (sub < 3) p[(size_t)(f0 + sub) * NL + col] = v; }
+  __device__ __forceinline__ void st_joint(float* p, int f0, float v) const { if (gate && sub < 3) p[(size_t)(f0 + sub) * NL + col] = v; }
   __device__ __forceinline__ float ld_legf(const float* p, int f) const { return p[(size_t)f * NL + col]; }
-  __device__ __forceinline__ void st_legf(float* p, int f, float v) const { if (sub == 0) p[(size_t)f * NL + col] = v; }
+  __device__ __forceinline__ void st_legf(float* p, int f, float v) const { if (gate && sub == 0) p[(size_t)f * NL + col] = v; }
   __device__ __forceinline__ float ld_env(const float* p, int f) const { return p[(size_t)f * N + env]; }
   // field f0 + stride * sub of the per-robot array: the 4 sub-lanes of a leg split a table between them
   __device__ __forceinline__ float ld_env_sub(const float* p, int f0, int stride) const { return p[(size_t)(f0 + stride * sub) * N + env]; }
-  __device__ __forceinline__ void st_env(float* p, int f, float v) const { if (r == 0) p[(size_t)f * N + env] = v; }
+  __device__ __forceinline__ void st_env(float* p, int f, float v) const { if (gate && r == 0) p[(size_t)f * N + env] = v; }
   __device__ __forceinline__ int ld_env_i(const int* p, int f) const { return p[(size_t)f * N + env]; }
-  __device__ __forceinline__ void st_env_i(int* p, int f, int v) const { if (r == 0) p[(size_t)f * N + env] = v; }
-  __device__ __forceinline__ void st_ring_joint(float* rg, int slot, int k0, float v) const { if (sub < 3) rg[((size_t)slot * 8 + k0 + sub) * NL + col] = v; }
-  __device__ __forceinline__ void st_ring_aux(float* rg, int slot, int k, float v) const { if (sub == 3) rg[((size_t)slot * 8 + k) * NL + col] = v; }
+  __device__ __forceinline__ void st_env_i(int* p, int f, int v) const { if (gate && r == 0) p[(size_t)f * N + env] = v; }
+  __device__ __forceinline__ void st_ring_joint(float* rg, int slot, int k0, float v) const { if (gate && sub < 3) rg[((size_t)slot * 8 + k0 + sub) * NL + col] = v; }
+  __device__ __forceinline__ void st_ring_aux(float* rg, int slot, int k, float v) const { if (gate && sub == 3) rg[((size_t)slot * 8 + k) * NL + col] = v; }
   __device__ __forceinline__ float ld_ring_joint(const float* rg, int slot, int k0) const { return rg[((size_t)slot * 8 + k0 + sc) * NL + col]; }
   __device__ __forceinline__ float ld_ring_k(const float* rg, int slot, int k) const { return rg[((size_t)slot * 8 + k) * NL + col]; }
   __device__ __forceinline__ float ld_row_joint(const float* p, int rowlen, int col0) const { return sub < 3 ? p[(size_t)(env - row_base) * rowlen + col0 + 3 * leg + sub] : 0.0f; }
   // element k of this lane's motor in rows of `stride` values per motor (HYBRID commands: stride 5)
   __device__ __forceinline__ float ld_row_motor(const float* p, int rowlen, int stride, int k) const { return sub < 3 ? p[(size_t)(env - row_base) * rowlen + stride * (3 * leg + sub) + k] : 0.0f; }
-  __device__ __forceinline__ void st_row_joint(float* p, int rowlen, int col0, float v) const { if (sub < 3) p[(size_t)(env - row_base) * rowlen + col0 + 3 * leg + sub] = v; }
-  __device__ __forceinline__ void st_row_leg(float* p, int rowlen, int col0, float v) const { if (sub == 0) p[(size_t)(env - row_base) * rowlen + col0 + leg] = v; }
-  __device__ __forceinline__ void st_row_env(float* p, int rowlen, int c_, float v) const { if (r == 0) p[(size_t)(env - row_base) * rowlen + c_] = v; }
+  __device__ __forceinline__ void st_row_joint(float* p, int rowlen, int col0, float v) const { if (gate && sub < 3) p[(size_t)(env - row_base) * rowlen + col0 + 3 * leg + sub] = v; }
+  __device__ __forceinline__ void st_row_leg(float* p, int rowlen, int col0, float v) const { if (gate && sub == 0) p[(size_t)(env - row_base) * rowlen + col0 + leg] = v; }
+  __device__ __forceinline__ void st_row_env(float* p, int rowlen, int c_, float v) const { if (gate && r == 0) p[(size_t)(env - row_base) * rowlen + c_] = v; }
   __device__ __forceinline__ float ld_row_env(const float* p, int rowlen, int c_) const { return p[(size_t)(env - row_base) * rowlen + c_]; }
   __device__ __forceinline__ void phase([[maybe_unused]] int id) const {
 #ifndef ETG_NO_PHASE_BARRIER16
@@ -1100,8 +1129,7 @@ __global__ void __launch_bounds__(BLOCK) k_rollout16(KCfg K, DevState D, int n_s
   GpuCtx16T<FLAT, KNEE, PLAIN> c;
   if (!make_ctx16(K, D, c, lds_par)) return;
   State16<float> L = load_state16<float>(c, D.base, D.leg);
-  rollout_steps16(c, K, L, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, n_steps, obs);
-  store_state16(c, D.base, D.leg, L);
+  rollout_steps16(c, K, L, D.base, D.leg, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, n_steps, obs);   // (stores the state itself: stop_at_done)
   if (so.ret && c.r == 0) {   // the last launch of a rollout hands the episode statistics to the caller itself (no extra launch):
     so.ret[c.env] = D.ctl[(size_t)CT_RET * K.n_env + c.env];        // lane 0 of the robot's row re-reads what it has just stored
     so.len[c.env] = (int)D.ctl[(size_t)CT_LEN * K.n_env + c.env];
@@ -1120,19 +1148,26 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_actions16(KCfg K, DevState D,
   if (!PLAIN && K.ext_force) tp.fext = load_fext16<float>(c, D.ctl);
   const size_t N = K.n_env;
   float reward, done;
+  const bool skip = K.stop_at_done != 0;
   for (int s = 0; s < n_steps; s++) {
     const float act = c.ld_row_joint(actions + (size_t)s * N * ETG_ACT_DIM, ETG_ACT_DIM, 0);
     const bool last = s == n_steps - 1;
-    control_step16_core(c, K, tp, L, S, D.ring, D.etgp, act, 0.0f, (T.obs && !last) ? T.obs + (size_t)s * N * ETG_OBS_DIM : obs, reward, done,
-                        (float*)nullptr, (const float*)nullptr, last || T.obs || T.imu, T.q ? T.q + (size_t)s * N * ETG_ACT_DIM : nullptr,
-                        T.imu ? T.imu + (size_t)s * N * 6 : nullptr);
+    const float was_alive = S.alive;
+    if (!skip || c.any(was_alive > 0.5f)) {   // (see k_rollout_actions)
+      control_step16_core(c, K, tp, L, S, D.ring, D.etgp, act, 0.0f, (T.obs && !last) ? T.obs + (size_t)s * N * ETG_OBS_DIM : obs, reward, done,
+                          (float*)nullptr, (const float*)nullptr, last || T.obs || T.imu, T.q ? T.q + (size_t)s * N * ETG_ACT_DIM : nullptr,
+                          T.imu ? T.imu + (size_t)s * N * 6 : nullptr, skip, obs);
+      if (skip) rollout_dead_store16(c, K, L, was_alive, done, last, true, (int)K.noise_call + s, D.base, D.leg, D.ictl);
+    } else {
+      reward = 0.0f; done = 1.0f;
+    }
     if (c.r == 0) {
       if (T.rew) T.rew[(size_t)s * N + c.env] = reward;
       if (T.done) T.done[(size_t)s * N + c.env] = done > 0.5f ? 1 : 0;
     }
   }
   store_ctl16(c, K, S, D.ctl, D.ictl, D.legctl);
-  store_state16(c, D.base, D.leg, L);
+  rollout_store16(c, K, L, S.alive, D.base, D.leg);
 }
 
 // Closed-loop rollout in one launch: a workgroup of 4 waves owns 16 robots = one 16-row tile of the policy MLP
@@ -1154,7 +1189,7 @@ struct RecOut { float *obs, *act, *rew; uint8_t* done; const float* noise; const
 template <bool FLAT, bool BF16, bool KNEE, bool PLAIN, bool REC>
 __device__ __forceinline__ void rollout_policy16_body(const KCfg& K, const DevState& D, const PolicyW& P, int n_steps, float act_scale,
                                                       float* obs, const RecOut& R, float* bufA, float* bufB, float (*part)[pol::TM][16],
-                                                      float (*part_s)[pol::TM][16], float (*act_lds)[16], float* obs_lds, float* lds_par) {
+                                                      float (*part_s)[pol::TM][16], float (*act_lds)[16], float* obs_lds, float* lds_par, float* live_lds) {
   using namespace pol;
   constexpr int NWP = 4;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1168,13 +1203,24 @@ __device__ __forceinline__ void rollout_policy16_body(const KCfg& K, const DevSt
   // current observation of the tile -> LDS
   for (int idx = tid; idx < TM * ETG_OBS_DIM; idx += 256) obs_lds[idx] = obs[(size_t)tile * TM * ETG_OBS_DIM + idx];
   float reward, done;
+  // KCfg.stop_at_done: a finished robot is not simulated any more (control_step16_core).  Its row of the observation tile stays
+  // its last one (the policy keeps evaluating it: a workgroup's 16 rows are one MFMA tile either way); a wave whose four robots
+  // have all finished skips its control steps, a workgroup whose sixteen have leaves the loop.
+  const bool skip = K.stop_at_done != 0;
+  if (lane < 4) live_lds[4 * wave + lane] = 1.0f;
 #ifdef ETG_PROFILE_PHASES
   long long pp[8] = {0, 0, 0, 0, 0, 0, 0, 0}, pl = clock64();
 #endif
-  for (int s = 0; s < n_steps; s++) {
-    __syncthreads();
-    if (K.noise_on && s > 0) {   // sensor noise on the row the previous step left in LDS (the last one: k_add_noise)
-      add_sensor_noise(K, tile * TM + (tid >> 4), K.noise_call + s - 1, tid & 15, &obs_lds[(tid >> 4) * ETG_OBS_DIM]);
+  int s_at = 0;   // the step the loop stands at (== n_steps unless the workgroup left early)
+  for (int s = 0; s < n_steps; s++, s_at = s) {
+    if (skip) {
+      if (!__syncthreads_or(S.alive > 0.5f)) break;   // (the barrier of the loop top, with the vote riding on it)
+    } else {
+      __syncthreads();
+    }
+    if (K.noise_on && s > 0) {   // sensor noise on the row the previous step left in LDS (the last one: the launch's epilogue)
+      if (live_lds[tid >> 4] > 0.5f)   // ... if the step wrote one: a robot that had finished before it keeps its row as it is
+        add_sensor_noise(K, tile * TM + (tid >> 4), K.noise_call + s - 1, tid & 15, &obs_lds[(tid >> 4) * ETG_OBS_DIM]);
       __syncthreads();
     }
     // fp32: every layer's first weight fragments are requested one stage EARLY (layer 1's before the observation tile is
@@ -1233,7 +1279,16 @@ __device__ __forceinline__ void rollout_policy16_body(const KCfg& K, const DevSt
     // the step code addresses observation rows by robot index: rows of the LDS tile start at the tile's first robot.
     // Every step writes its observation to the tile (plain ds_write, no generic pointer); the last one is copied out below.
     c.row_base = tile * TM;
-    control_step16_core(c, K, tp, L, S, D.ring, D.etgp, action, 0.0f, obs_lds, reward, done, (float*)nullptr);
+    const float was_alive = S.alive;
+    if (!skip || c.any(was_alive > 0.5f)) {
+      control_step16_core(c, K, tp, L, S, D.ring, D.etgp, action, 0.0f, obs_lds, reward, done, (float*)nullptr, (const float*)nullptr, true,
+                          (float*)nullptr, (float*)nullptr, skip);
+      // (a row written mid-launch gets its sensor noise at the top of the next step; only the last step's rows wait for the epilogue)
+      if (skip) rollout_dead_store16(c, K, L, was_alive, done, s == n_steps - 1, false, (int)K.noise_call + s, D.base, D.leg, D.ictl);
+    } else {
+      reward = 0.0f; done = 1.0f;
+    }
+    if (c.r == 0) live_lds[4 * wave + (lane >> 4)] = skip ? was_alive : 1.0f;   // did this step write the robot's row?
 #ifdef ETG_PROFILE_PHASES
     { long long t = clock64(); pp[5] += t - pl; pl = t; __builtin_amdgcn_sched_barrier(0); }
 #endif
@@ -1242,8 +1297,13 @@ __device__ __forceinline__ void rollout_policy16_body(const KCfg& K, const DevSt
       R.done[(size_t)s * K.n_env + c.env] = done > 0.5f ? 1 : 0;
     }
   }
+  if (REC && c.r == 0)   // the workgroup left the loop early: the remaining steps read reward 0 / done 1 (their obs / action rows stay unwritten)
+    for (int s2 = s_at; s2 < n_steps; s2++) {
+      R.rew[(size_t)s2 * K.n_env + c.env] = 0.0f;
+      R.done[(size_t)s2 * K.n_env + c.env] = 1;
+    }
   store_ctl16(c, K, S, D.ctl, D.ictl, D.legctl);
-  store_state16(c, D.base, D.leg, L);
+  rollout_store16(c, K, L, S.alive, D.base, D.leg);
   __syncthreads();
   for (int idx = tid; idx < TM * ETG_OBS_DIM; idx += 256) obs[(size_t)tile * TM * ETG_OBS_DIM + idx] = obs_lds[idx];   // coalesced
 #ifdef ETG_PROFILE_PHASES
@@ -1261,7 +1321,8 @@ __global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, Po
   __shared__ float act_lds[TM][16];
   __shared__ float obs_lds[TM * ETG_OBS_DIM];
   __shared__ float lds_par[4 * LDS16_FIELDS * 64];
-  rollout_policy16_body<FLAT, BF16, KNEE, PLAIN, false>(K, D, P, n_steps, act_scale, obs, RecOut{}, bufA, bufB, part, nullptr, act_lds, obs_lds, lds_par);
+  __shared__ float live_lds[TM];
+  rollout_policy16_body<FLAT, BF16, KNEE, PLAIN, false>(K, D, P, n_steps, act_scale, obs, RecOut{}, bufA, bufB, part, nullptr, act_lds, obs_lds, lds_par, live_lds);
 }
 
 // Closed loop on the 4-lanes-per-robot mapping (the mapping of every batch above 4096 robots): a workgroup of 4 waves owns
@@ -1279,6 +1340,7 @@ __global__ void __launch_bounds__(256) k_rollout_policy4(KCfg K, DevState D, Pol
   __shared__ float act_lds[ROWS][16];
   __shared__ float obs_lds[ROWS * ETG_OBS_DIM];
   __shared__ float lds_par[NWP][PR_N * 64];
+  __shared__ float live_lds[ROWS];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int tile = xcd_contiguous_block();            // 64 robots; the host guarantees N % 64 == 0
   GpuCtxT<FLAT, PLAIN, BODY> c;
@@ -1297,11 +1359,18 @@ __global__ void __launch_bounds__(256) k_rollout_policy4(KCfg K, DevState D, Pol
   for (int idx = tid; idx < ROWS * ETG_OBS_DIM; idx += 256) obs_lds[idx] = obs[(size_t)tile * ROWS * ETG_OBS_DIM + idx];
   c.row_base = tile * ROWS;
   float reward, done;
+  const bool skip = K.stop_at_done != 0;     // (see rollout_policy16_body)
+  if (tid < ROWS) live_lds[tid] = 1.0f;
   for (int s = 0; s < n_steps; s++) {
-    __syncthreads();
-    if (K.noise_on && s > 0) {   // sensor noise on the rows the previous step left in LDS (the last ones: k_add_noise)
+    if (skip) {
+      if (!__syncthreads_or(S.alive > 0.5f)) break;
+    } else {
+      __syncthreads();
+    }
+    if (K.noise_on && s > 0) {   // sensor noise on the rows the previous step wrote to LDS (the last ones: the launch's epilogue)
       for (int idx = tid; idx < ROWS * 16; idx += 256)
-        add_sensor_noise(K, tile * ROWS + (idx >> 4), K.noise_call + s - 1, idx & 15, &obs_lds[(idx >> 4) * ETG_OBS_DIM]);
+        if (live_lds[idx >> 4] > 0.5f)
+          add_sensor_noise(K, tile * ROWS + (idx >> 4), K.noise_call + s - 1, idx & 15, &obs_lds[(idx >> 4) * ETG_OBS_DIM]);
       __syncthreads();
     }
     for (int pass = 0; pass < ROWS / (RT * TM); pass++) {
@@ -1326,10 +1395,16 @@ __global__ void __launch_bounds__(256) k_rollout_policy4(KCfg K, DevState D, Pol
     }
     const int rl = 16 * wave + (lane >> 2), leg = lane & 3;
     const float act[3] = {act_lds[rl][3 * leg + 0], act_lds[rl][3 * leg + 1], act_lds[rl][3 * leg + 2]};
-    control_step_core(c, K, tp, fext, L, S, D.ring, D.etgp, act, 0.0f, obs_lds, reward, done, (float*)nullptr);
+    const float was_alive = S.alive;
+    if (!skip || c.any(was_alive > 0.5f)) {
+      control_step_core(c, K, tp, fext, L, S, D.ring, D.etgp, act, 0.0f, obs_lds, reward, done, (float*)nullptr, (const float*)nullptr, true,
+                        (float*)nullptr, (float*)nullptr, skip);
+      if (skip) rollout_dead_store(c, K, L, was_alive, done, s == n_steps - 1, false, (int)K.noise_call + s, D.base, D.leg, D.ictl);
+    }
+    if (c.lane == 0) live_lds[rl] = skip ? was_alive : 1.0f;
   }
   store_ctl4(c, K, S, D.ctl, D.ictl, D.legctl);
-  store_state(c, D.base, D.leg, L);
+  rollout_store(c, K, L, S.alive, D.base, D.leg);
   __syncthreads();
   for (int idx = tid; idx < ROWS * ETG_OBS_DIM; idx += 256) obs[(size_t)tile * ROWS * ETG_OBS_DIM + idx] = obs_lds[idx];   // coalesced
 }
@@ -1345,7 +1420,8 @@ __global__ void __launch_bounds__(256) k_rollout_policy16_rec(KCfg K, DevState D
   __shared__ float act_lds[TM][16];
   __shared__ float obs_lds[TM * ETG_OBS_DIM];
   __shared__ float lds_par[4 * LDS16_FIELDS * 64];
-  rollout_policy16_body<FLAT, BF16, KNEE, PLAIN, true>(K, D, P, n_steps, act_scale, obs, R, bufA, bufB, part, part_s, act_lds, obs_lds, lds_par);
+  __shared__ float live_lds[TM];
+  rollout_policy16_body<FLAT, BF16, KNEE, PLAIN, true>(K, D, P, n_steps, act_scale, obs, R, bufA, bufB, part, part_s, act_lds, obs_lds, lds_par, live_lds);
 }
 
 // Gaussian sensor noise on freshly written observation rows: one thread per (robot, channel).  A separate tiny
@@ -1355,6 +1431,17 @@ __global__ void k_add_noise(KCfg K, unsigned call, const uint8_t* mask, int inve
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int env = i >> 4;
   if (env >= K.n_env || (mask && (mask[env] != 0) == (invert != 0))) return;   // mask: rows to touch (or, inverted, to leave)
+  add_sensor_noise(K, env, call, i & 15, obs + (size_t)env * ETG_OBS_DIM);
+}
+
+// the epilogue of a fused rollout launch under KCfg.stop_at_done: rows were written at different steps (a robot's last one when
+// its episode ended), each noted its stream position in ictl[IC_OBS_CALL]; rows noted in [first, first + n) get their noise
+__global__ void k_add_noise_rows(KCfg K, DevState D, unsigned first, unsigned n, float* obs) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int env = i >> 4;
+  if (env >= K.n_env) return;
+  const unsigned call = (unsigned)D.ictl[(size_t)IC_OBS_CALL * K.n_env + env];
+  if (call - first >= n) return;
   add_sensor_noise(K, env, call, i & 15, obs + (size_t)env * ETG_OBS_DIM);
 }
 
@@ -1650,7 +1737,9 @@ extern "C" const char* etg_last_error(void) { return g_err.c_str(); }
 // shared with policy_mlp.hip so that one etg_last_error() serves the whole ABI
 extern "C" void etg_set_last_error_(const char* msg) { g_err = msg ? msg : ""; }
 extern "C" int etg_lanes_per_robot(const EtgHandle* h) { return h ? h->lanes : ETG_ERR_BAD_ARG; }
-int etg_version(void) { return 1; }
+int etg_version(void) { return 2; }
+int etg_config_size(void) { return (int)sizeof(EtgConfig); }
+int etg_model_size(void) { return (int)sizeof(EtgRobotModel); }
 
 static int grid_for(const EtgHandle* h) { return (4 * h->N + BLOCK - 1) / BLOCK; }
 
@@ -1772,6 +1861,13 @@ static inline void launch_obs_noise(EtgHandle* h, int n, const uint8_t* mask, fl
   if (!h->K.noise_on || !obs) return;   // back: stream positions before the newest one (the step's row when a reset row follows it)
   hipLaunchKernelGGL(k_add_noise, dim3((16 * h->N + 255) / 256), dim3(256), 0, s, h->K,
                      h->K.noise_call + (unsigned)(n - 1) - (unsigned)back, mask, invert, obs);
+}
+
+// noise for the rows a fused rollout launch of n steps left in `obs` (stream positions K.noise_call .. + n - 1)
+static inline void launch_rollout_noise(EtgHandle* h, int n, float* obs, hipStream_t s) {
+  if (!h->K.noise_on || !obs) return;
+  if (!h->K.stop_at_done) { launch_obs_noise(h, n, nullptr, obs, s); return; }   // every row is the last step's
+  hipLaunchKernelGGL(k_add_noise_rows, dim3((16 * h->N + 255) / 256), dim3(256), 0, s, h->K, h->D, h->K.noise_call, (unsigned)n, obs);
 }
 
 // the instantiations of a 16-lane kernel: {flat ground, heightfield} x {plain robot layer + body rows (the default), plain
@@ -2100,6 +2196,15 @@ extern "C" int etg_step_autoreset(EtgHandle* h, const float* action, const uint8
   return ETG_OK;
 }
 
+#ifdef ETG_TRACE_TICKS
+extern "C" int etg_debug_set_trace(EtgHandle* h, float* buf) { if (!h) return ETG_ERR_BAD_ARG; h->K.trace = buf; return ETG_OK; }
+#endif
+extern "C" int etg_set_rollout_mode(EtgHandle* h, int simulate_finished) {
+  CHECK_HANDLE(h);
+  h->K.stop_at_done = simulate_finished ? 0 : 1;
+  return ETG_OK;
+}
+
 extern "C" int etg_episode_stats(EtgHandle* h, float* ret, int32_t* len, void* stream) {
   CHECK_HANDLE(h);
   hipLaunchKernelGGL(k_episode_stats, dim3((h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->D, ret, len);
@@ -2123,7 +2228,8 @@ extern "C" int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float
     for (int done_steps = 0; done_steps < n_steps; done_steps += ROLLOUT_CHUNK) {
       const int m = n_steps - done_steps < ROLLOUT_CHUNK ? n_steps - done_steps : ROLLOUT_CHUNK;
       const bool last = done_steps + m == n_steps;
-      float* o = (obs && last) ? obs : h->tmp_obs;
+      // stop_at_done: a robot's last row is written by the launch its episode ends in -- every launch writes to the caller's rows
+      float* o = (obs && (last || h->K.stop_at_done)) ? obs : h->tmp_obs;
       const StatOut so = last ? StatOut{ret, (int*)len} : StatOut{nullptr, nullptr};
       advance_obs_stream(h, m);
       if (h->lanes == 16) {
@@ -2131,7 +2237,7 @@ extern "C" int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float
       } else {
         LAUNCH4(k_rollout, g4, s, h->K, h->D, m, o, so);
       }
-      if (o == obs) launch_obs_noise(h, m, nullptr, obs, s);
+      if (o == obs) launch_rollout_noise(h, m, obs, s);
     }
     HIP_TRY(hipGetLastError());
     return ETG_OK;
@@ -2169,7 +2275,7 @@ extern "C" int etg_rollout_actions(EtgHandle* h, const float* actions, int n_ste
     } else {
       LAUNCH4(k_rollout_actions, g4, s, h->K, h->D, m, a, obs, T);
     }
-    launch_obs_noise(h, m, nullptr, obs, s);
+    launch_rollout_noise(h, m, obs, s);
     // the last step of EVERY launch writes its row to `obs`, not to the tape: the tape gets its copy per chunk (rows 49, 99,
     // ... and n_steps - 1; recorded observations carry no sensor noise, which the check above enforces)
     if (rec_obs)
@@ -2218,7 +2324,7 @@ extern "C" int etg_rollout_policy(EtgHandle* h, EtgPolicy* pol, int n_steps, flo
       else if (pl) LAUNCH_POLICY4(false, true, 0);
       else LAUNCH_POLICY4(false, false, 0);
 #undef LAUNCH_POLICY4
-      launch_obs_noise(h, m, nullptr, obs, s);
+      launch_rollout_noise(h, m, obs, s);
     }
     HIP_TRY(hipGetLastError());
     if (ret || len) return etg_episode_stats(h, ret, len, stream);
@@ -2234,7 +2340,7 @@ extern "C" int etg_rollout_policy(EtgHandle* h, EtgPolicy* pol, int n_steps, flo
   } while (0)
     DISPATCH16(LAUNCH_POLICY16);
 #undef LAUNCH_POLICY16
-    launch_obs_noise(h, m, nullptr, obs, s);   // every chunk ends in the caller's rows: the next chunk reads them
+    launch_rollout_noise(h, m, obs, s);   // every chunk ends in the caller's rows: the next chunk reads them
   }
   HIP_TRY(hipGetLastError());
   if (ret || len) return etg_episode_stats(h, ret, len, stream);
@@ -2276,7 +2382,7 @@ extern "C" int etg_rollout_policy_record(EtgHandle* h, EtgPolicy* pol, int n_ste
   } while (0)
     DISPATCH16(LAUNCH_POLICY16R);
 #undef LAUNCH_POLICY16R
-    launch_obs_noise(h, m, nullptr, obs, s);   // every chunk ends in the caller's rows: the next chunk reads them
+    launch_rollout_noise(h, m, obs, s);   // every chunk ends in the caller's rows: the next chunk reads them
   }
   HIP_TRY(hipGetLastError());
   if (ret || len) return etg_episode_stats(h, ret, len, stream);
@@ -2304,6 +2410,33 @@ extern "C" int etg_get_state(EtgHandle* h, float* state, void* stream) {
   CHECK_HANDLE(h);
   if (!state) return fail(ETG_ERR_BAD_ARG, "etg_get_state: null");
   hipLaunchKernelGGL(k_get_state, dim3(grid_for(h)), dim3(BLOCK), 0, (hipStream_t)stream, h->K, h->D, state);
+  HIP_TRY(hipGetLastError());
+  return ETG_OK;
+}
+
+// contact impulses of the feet, rows [N,12] <-> the SoA columns leg[LG_LAM + k][4N] (both lane mappings share the layout)
+__global__ void __launch_bounds__(256) k_lam_io(KCfg K, DevState D, float* lam, int write) {
+  const int col = blockIdx.x * blockDim.x + threadIdx.x;
+  const int NL = 4 * K.n_env;
+  if (col >= NL) return;
+  const int env = col >> 2, leg = col & 3;
+  for (int k = 0; k < 3; k++) {
+    float* cell = D.leg + (size_t)(LG_LAM + k) * NL + col;
+    if (write) *cell = lam[(size_t)env * 12 + 3 * leg + k];
+    else lam[(size_t)env * 12 + 3 * leg + k] = *cell;
+  }
+}
+extern "C" int etg_get_contact_impulses(EtgHandle* h, float* lam, void* stream) {
+  CHECK_HANDLE(h);
+  if (!lam) return fail(ETG_ERR_BAD_ARG, "etg_get_contact_impulses: null");
+  hipLaunchKernelGGL(k_lam_io, dim3((4 * h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->D, lam, 0);
+  HIP_TRY(hipGetLastError());
+  return ETG_OK;
+}
+extern "C" int etg_set_contact_impulses(EtgHandle* h, const float* lam, void* stream) {
+  CHECK_HANDLE(h);
+  if (!lam) return fail(ETG_ERR_BAD_ARG, "etg_set_contact_impulses: null");
+  hipLaunchKernelGGL(k_lam_io, dim3((4 * h->N + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->D, const_cast<float*>(lam), 1);
   HIP_TRY(hipGetLastError());
   return ETG_OK;
 }

@@ -34,7 +34,9 @@ enum { LG_Q = 0, LG_QD = 3, LG_LAM = 6, LG_CONTACT = 9, LG_N = 10 };
 // etg_random_pushes() -- separate columns, the kernels apply their sum (a set force survives pushes and their clearing)
 enum { CT_FIRST_RPY = 0, CT_LAST_BASE = 3, CT_RET = 6, CT_LEN = 7, CT_ALIVE = 8, CT_FEXT = 9, CT_PUSH = 12, CT_N = 15 };
 // IC_PUSH_LEFT: control steps the current random push still lasts (etg_random_pushes)
-enum { IC_STEP = 0, IC_TICK = 1, IC_HAS_LAST = 2, IC_PUSH_LEFT = 3, IC_N = 4 };
+// IC_OBS_CALL: sensor-noise stream position of the robot's observation row that still waits for its noise from the epilogue of a
+// fused rollout launch under stop_at_done (rows are then written at different steps: a robot's last one when its episode ends)
+enum { IC_STEP = 0, IC_TICK = 1, IC_HAS_LAST = 2, IC_PUSH_LEFT = 3, IC_OBS_CALL = 4, IC_N = 5 };
 enum { LC_LAST_QDES = 0, LC_FX0 = 3, LC_FX1 = 6, LC_FY0 = 9, LC_FY1 = 12, LC_LAST_FOOT_X = 15, LC_N = 16 };
 enum { EP_W = 0, EP_B = 60, EP_N = 63 };
 // per-lane derived parameters, in the order derive_lane_params() writes them
@@ -70,6 +72,7 @@ struct KCfg {
   int knee;              // EtgConfig.body_contacts: 1 knee spheres collide; 2 deepest of knee / shin / trunk corner (16-lane kernels)
   float knee_radius;
   float body_mu;         // EtgConfig.body_friction: friction coefficient of the body contacts (body_contacts 1 / 2)
+  float blend_inv;       // 1 / EtgConfig.body_blend (0 = the deepest sphere is the contact): softness of the choice among the leg's three spheres
   float trunk_half[3];   // knee == 2: half extents of the trunk box (its corners collide too)
   // Gaussian sensor noise (minitaur.py:1206-1211): stdev of motor angle, motor velocity, motor torque (not part of
   // the 49-float observation), base rpy, base rpy rate -- the order of SENSOR_NOISE_STDDEV (minitaur.py:102)
@@ -86,6 +89,10 @@ struct KCfg {
   float slop;            // EtgConfig.contact_slop: added to a contact's distance before the velocity target is formed
   float restitution;     // EtgConfig.foot_restitution (combined coefficient; 0 = off)
   int strength_on;       // motor strength ratios other than 1 are installed (etg_set_motor_strength)
+  int stop_at_done;      // fused rollouts: a robot whose episode has ended is not simulated any more (etg_set_rollout_mode; default 1)
+#ifdef ETG_TRACE_TICKS   // debugging build only: [N][16 ticks][16 lanes][10] floats written by physics_tick16 (etg_debug_set_trace)
+  float* trace;
+#endif
 };
 
 // the default robot layer (what train.py / pretrain.py run): the PLAIN kernel instantiations compile the options out
@@ -349,6 +356,7 @@ inline KCfg make_kcfg(const EtgConfig& c, const EtgRobotModel& m) {
   K.motor_mode = c.motor_mode;
   K.clip_cmd = (float)c.clip_motor_commands;
   K.knee = c.body_contacts; K.knee_radius = (float)c.knee_radius; K.body_mu = (float)c.body_friction;
+  K.blend_inv = c.body_blend > 0 ? (float)(1.0 / c.body_blend) : 0.0f;
   for (int k = 0; k < 3; k++) K.trunk_half[k] = (float)c.trunk_half[k];
   K.etg_on = c.enable_etg != 0;
   K.res_thr = (float)c.solver_residual;
@@ -363,6 +371,10 @@ inline KCfg make_kcfg(const EtgConfig& c, const EtgRobotModel& m) {
   }
   K.warmstart_t = (float)c.warmstart_friction; K.slop = (float)c.contact_slop; K.restitution = (float)c.foot_restitution;
   K.strength_on = 0;
+  K.stop_at_done = 1;
+#ifdef ETG_TRACE_TICKS
+  K.trace = nullptr;
+#endif
   K.jlim = c.joint_limits != 0;
   for (int k = 0; k < 3; k++) { K.jlo[k] = (float)c.joint_lower[k]; K.jhi[k] = (float)c.joint_upper[k]; }
   K.hf_cell = (float)c.hf_cell; K.hf_x0 = (float)c.hf_x0; K.hf_y0 = (float)c.hf_y0;

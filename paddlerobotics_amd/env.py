@@ -172,14 +172,14 @@ class BatchedQuadrupedEnv:
                  sensor_mode=None, normal=1, dynamic_param=None, reward_param=None, ETG=1, ETG_T=0.5,
                  reward_p=5.0, ETG_path="", random_param=None, ETG_H=20, vel_d=0.5, step_y=0.05,
                  enable_action_filter=False, ETG_T2=0.5, action_repeat=13, sim_time_step=0.002,
-                 settle_ticks=500, solver_iters=None, solver_residual=None, friction_model=0, pd_latency=0.0,
+                 settle_ticks=500, solver_iters=None, solver_residual=None, friction_model=None, pd_latency=0.0,
                  enable_action_interpolation=False,
                  heightfield=None, lanes_per_robot=0, terrain_variants=16, terrain_seed=0,
                  random_dynamics_scale=0.3, random_force_prob=0.02, random_force_steps=8,
                  random_force_range=(5.0, 25.0), seed=0, enable_clip_motor_commands=False,
                  observation_noise_stdev=None, body_contacts=2, body_friction=0.5, knee_radius=0.02, joint_limits=True,
                  auto_reset=False, random_dynamics_refresh=256, warmstart=0.1, warmstart_friction=0.0, contact_slop=1e-5,
-                 foot_restitution=0.0, motor_torque_limits=None, solver_preset=None, **unused):
+                 foot_restitution=0.0, motor_torque_limits=None, solver_preset=None, body_blend=1e-3, **unused):
         if render:
             raise ValueError("render is not supported by the batched GPU simulator")
         if int(ETG_H) != A.RBF_H:
@@ -236,12 +236,16 @@ class BatchedQuadrupedEnv:
         if self.device.type != "cuda":
             raise ValueError("BatchedQuadrupedEnv runs on a HIP device only (device='cuda:N')")
         self.ETG = int(ETG)
-        if solver_preset is not None:      # named engine settings (a1_model.solver_preset); explicit solver_* / friction_model keywords win
+        if solver_preset is not None:      # named engine settings (a1_model.solver_preset); every explicit keyword wins on its own
             ps = A.solver_preset(solver_preset, action_repeat)
             if solver_iters is None and solver_residual is None:
                 solver_iters, solver_residual = ps["solver_iters"], ps["solver_residual"]
-            if friction_model == 0:
+            elif solver_iters is None:     # (a residual threshold alone keeps the preset's sweep cap; a bare solver_iters is a
+                solver_iters = ps["solver_iters"]   # fixed count by the rule of a1_model.solver_rule and stays one)
+            if friction_model is None:
                 friction_model = ps["friction_model"]
+        if friction_model is None:
+            friction_model = 0
         self.cfg = A.default_config(
             self.num_envs, action_repeat=action_repeat, sim_dt=sim_time_step, settle_ticks=settle_ticks,
             solver_iters=solver_iters, solver_residual=solver_residual, friction_model=friction_model, pd_latency=pd_latency,
@@ -255,7 +259,7 @@ class BatchedQuadrupedEnv:
             # one contact per leg, with friction, on the deepest of knee / shin midpoint / trunk corner; 1 / True: the knee
             # sphere only; 0 / False: toe spheres only; 3 or "simultaneous": all three spheres at once, frictionless
             body_contacts=_body_contacts_mode(body_contacts), body_friction=float(body_friction),
-            knee_radius=knee_radius,
+            knee_radius=knee_radius, body_blend=float(body_blend),
             enable_etg=1 if self.ETG else 0, joint_limits=1 if joint_limits else 0,
             # contact-solver settings: the defaults are pybullet's (a1_model.default_config)
             warmstart=warmstart, warmstart_friction=warmstart_friction, contact_slop=contact_slop,
@@ -632,6 +636,14 @@ class BatchedQuadrupedEnv:
             self._last_view = self._obs_view()
         return (self._last_view, self.reward, self.done.view(torch.bool) if want_info else self.done, info)
 
+    def set_rollout_mode(self, simulate_finished=False):
+        """The fused rollouts (rollout_openloop / _policy / _policy_record / _actions) stop simulating a robot when its episode
+        ends, as the reference's loops do (pretrain.py:137-153, train.py:226-247): its state stays the terminal state, its
+        observation row the last one.  simulate_finished=True brings back the behaviour of rounds 1-5 (finished robots are
+        simulated on, their accumulators masked) -- for measurements and for looking at a robot after its fall."""
+        _lib.check(self._lib.etg_set_rollout_mode(self._h, int(bool(simulate_finished))))
+        self.simulate_finished = bool(simulate_finished)
+
     def rollout_openloop(self, n_steps, out=None):
         """n_steps control steps with zero residual action (pretrain.py:129-154) enqueued back to
         back; returns (episode_return[N], episode_len[N]) since the last reset, alive-masked.  out = (ret float32 [N],
@@ -699,7 +711,8 @@ class BatchedQuadrupedEnv:
             noise = torch.as_tensor(noise, dtype=torch.float32, device=self.device).contiguous()
             if tuple(noise.shape) != (T, N, A.NUM_MOTORS):
                 raise ValueError("noise must be [n_steps, num_envs, 12]")
-        rec = {"obs": torch.empty(T, N, A.OBS_DIM, device=self.device), "action": torch.empty(T, N, A.NUM_MOTORS, device=self.device),
+        # (zeros: the steps after a robot's episode has ended write reward 0 / done 1 only -- include/etgsim.h "fused rollouts")
+        rec = {"obs": torch.zeros(T, N, A.OBS_DIM, device=self.device), "action": torch.zeros(T, N, A.NUM_MOTORS, device=self.device),
                "reward": torch.empty(T, N, device=self.device), "done": torch.empty(T, N, dtype=torch.uint8, device=self.device)}
         ret = torch.empty(N, device=self.device)
         ln = torch.empty(N, dtype=torch.int32, device=self.device)
@@ -737,12 +750,13 @@ class BatchedQuadrupedEnv:
         if unknown:
             raise ValueError("rollout_actions cannot record %s" % sorted(unknown))
         rec = {}
+        # (zeros: rows of the steps after a robot's episode has ended are not written -- include/etgsim.h "fused rollouts")
         if "joint_angle" in record:
-            rec["joint_angle"] = torch.empty(T, N, A.NUM_MOTORS, device=self.device)
+            rec["joint_angle"] = torch.zeros(T, N, A.NUM_MOTORS, device=self.device)
         if "obs-IMU" in record:
-            rec["obs-IMU"] = torch.empty(T, N, 6, device=self.device)
+            rec["obs-IMU"] = torch.zeros(T, N, 6, device=self.device)
         if "obs" in record:
-            rec["obs"] = torch.empty(T, N, A.OBS_DIM, device=self.device)
+            rec["obs"] = torch.zeros(T, N, A.OBS_DIM, device=self.device)
         if "reward" in record:
             rec["reward"] = torch.empty(T, N, device=self.device)
         if "done" in record:
@@ -776,6 +790,18 @@ class BatchedQuadrupedEnv:
         st = self._f32(state, (self.num_envs, A.STATE_DIM), "state")
         _lib.check(self._lib.etg_set_state(self._h, _ptr(st), self._stream()))
         self._keep_state = st
+
+    def get_contact_impulses(self):
+        """[N,12] the feet's contact impulses of the last tick, per leg (n, t1, t2): the contact solver's warm start"""
+        lam = torch.zeros(self.num_envs, A.NUM_MOTORS, device=self.device)
+        _lib.check(self._lib.etg_get_contact_impulses(self._h, _ptr(lam), self._stream()))
+        return lam
+
+    def set_contact_impulses(self, lam):
+        """install them (after set_state, which zeroes them): a re-created step then starts from the robot's own warm start"""
+        lam = self._f32(lam, (self.num_envs, A.NUM_MOTORS), "contact impulses")
+        _lib.check(self._lib.etg_set_contact_impulses(self._h, _ptr(lam), self._stream()))
+        self._keep_lam = lam
 
 
 class SingleRobotEnv:

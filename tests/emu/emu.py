@@ -99,6 +99,16 @@ class EmuSim:
         self._l.emu_step(self._h, _p(action), _p(donef), _p(obs), _p(rew), _p(done), _p(info))
         return obs, rew, done, info
 
+    def rollout_openloop(self, n_steps, stop_at_done=True, obs=None):
+        """the fused open-loop rollout (rollout_steps16 / rollout_steps) -> (obs [N,49] rows the rollout wrote, ret [N], len [N]);
+        obs: the buffer the rows land in (rows of robots that were finished before the call keep their content)"""
+        if obs is None:
+            obs = np.zeros((self.N, A.OBS_DIM), dtype=np.float32)
+        ret = np.zeros(self.N, dtype=np.float32)
+        ln = np.zeros(self.N, dtype=np.int32)
+        self._l.emu_rollout_openloop(self._h, int(n_steps), int(bool(stop_at_done)), _p(obs), _p(ret), _p(ln))
+        return obs, ret, ln
+
     def get_state(self):
         st = np.zeros((self.N, A.STATE_DIM), dtype=np.float32)
         self._l.emu_get_state(self._h, _p(st))
@@ -107,6 +117,16 @@ class EmuSim:
     def set_state(self, st):
         st = np.ascontiguousarray(st, dtype=np.float32)
         self._l.emu_set_state(self._h, _p(st))
+
+    def set_contact_impulses(self, lam):
+        lam = np.ascontiguousarray(lam, dtype=np.float32)
+        self._l.emu_set_contact_impulses(self._h, _p(lam))
+
+    def set_trace(self, on=True):
+        """tick trace of an ETG_EMU_FLAGS=-DETG_TRACE_TICKS build: [N,16,16,10] float32 (tools/first_divergence.py)"""
+        self._trace = np.zeros((self.N, 16, 16, 10), dtype=np.float32) if on else None
+        self._l.emu_debug_set_trace(self._h, _p(self._trace))
+        return self._trace
 
     @staticmethod
     def set_extra_sweeps(n):

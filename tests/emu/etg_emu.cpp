@@ -34,6 +34,11 @@ struct WaveAny {
 };
 struct EmuCtxBase {
   WaveAny wa;
+  // store gate of the fused rollouts (one robot per emulated wave: the mask is uniform)
+  mutable bool gate = true;
+  void set_gate(B4 m) const { gate = any(m); }
+  void open_gate() const { gate = true; }
+  int sel_i(B4 m, int a, int b) const { return any(m) ? a : b; }
   bool wave_any(B4 b) const { return wa.more(any(b)); }
   B4 robot_any(B4 b) const { const bool a = any(b); B4 r; for (int l = 0; l < 4; l++) r.v[l] = a; return r; }
   int env, N;
@@ -42,17 +47,17 @@ struct EmuCtxBase {
   F4 tpar(int k) const { return par(k); }
   int NL() const { return 4 * N; }
   F4 ld_lane(const float* p, int f) const { F4 r; for (int l = 0; l < 4; l++) r.v[l] = p[(size_t)f * NL() + 4 * env + l]; return r; }
-  void st_lane(float* p, int f, F4 v) const { for (int l = 0; l < 4; l++) p[(size_t)f * NL() + 4 * env + l] = v.v[l]; }
+  void st_lane(float* p, int f, F4 v) const { if (!gate) return; for (int l = 0; l < 4; l++) p[(size_t)f * NL() + 4 * env + l] = v.v[l]; }
   F4 ld_env(const float* p, int f) const { return F4(p[(size_t)f * N + env]); }
-  void st_env(float* p, int f, F4 v) const { p[(size_t)f * N + env] = v.v[0]; }
+  void st_env(float* p, int f, F4 v) const { if (!gate) return; p[(size_t)f * N + env] = v.v[0]; }
   int ld_env_i(const int* p, int f) const { return p[(size_t)f * N + env]; }
-  void st_env_i(int* p, int f, int v) const { p[(size_t)f * N + env] = v; }
-  void st_ring(float* r, int slot, int k, F4 v) const { for (int l = 0; l < 4; l++) r[((size_t)slot * 8 + k) * NL() + 4 * env + l] = v.v[l]; }
+  void st_env_i(int* p, int f, int v) const { if (!gate) return; p[(size_t)f * N + env] = v; }
+  void st_ring(float* r, int slot, int k, F4 v) const { if (!gate) return; for (int l = 0; l < 4; l++) r[((size_t)slot * 8 + k) * NL() + 4 * env + l] = v.v[l]; }
   F4 ld_ring(const float* r, int slot, int k) const { F4 o; for (int l = 0; l < 4; l++) o.v[l] = r[((size_t)slot * 8 + k) * NL() + 4 * env + l]; return o; }
   void ring_fence() const {}
   void phase(int) const {}
-  void st_row_env(float* p, int rowlen, int col, F4 v) const { p[(size_t)env * rowlen + col] = v.v[0]; }
-  void st_row_lane(float* p, int rowlen, int col0, int stride, F4 v) const { for (int l = 0; l < 4; l++) p[(size_t)env * rowlen + col0 + stride * l] = v.v[l]; }
+  void st_row_env(float* p, int rowlen, int col, F4 v) const { if (!gate) return; p[(size_t)env * rowlen + col] = v.v[0]; }
+  void st_row_lane(float* p, int rowlen, int col0, int stride, F4 v) const { if (!gate) return; for (int l = 0; l < 4; l++) p[(size_t)env * rowlen + col0 + stride * l] = v.v[l]; }
   F4 ld_row_env(const float* p, int rowlen, int col) const { return F4(p[(size_t)env * rowlen + col]); }
   F4 ld_row_lane(const float* p, int rowlen, int col0, int stride) const { F4 o; for (int l = 0; l < 4; l++) o.v[l] = p[(size_t)env * rowlen + col0 + stride * l]; return o; }
   F4 qsum(F4 a) const { return F4((a.v[0] + a.v[1]) + (a.v[2] + a.v[3])); }
@@ -102,6 +107,21 @@ typedef EmuCtxT<false> EmuCtx;   // generic-terrain instantiation; the flat fast
 // ---- 16 lanes per robot (etg_core16.h): lane r = 4*leg + sub
 struct EmuCtx16Base {
   WaveAny wa;
+#ifdef ETG_TRACE_TICKS
+  mutable int trace_i = 0;
+  void trace_index(int i) const { trace_i = i; }
+  void trace_tick(const KCfg& K, const F16* v) const {
+    if (!K.trace || trace_i >= 16) return;
+    for (int r = 0; r < 16; r++) {
+      float* row = K.trace + (((size_t)env * 16 + trace_i) * 16 + r) * 10;
+      for (int k = 0; k < 10; k++) row[k] = v[k].v[r];
+    }
+  }
+#endif
+  mutable bool gate = true;   // store gate: see EmuCtxBase
+  void set_gate(B16 m) const { gate = any(m); }
+  void open_gate() const { gate = true; }
+  int sel_i(B16 m, int a, int b) const { return any(m) ? a : b; }
   bool wave_any(B16 b) const { return wa.more(any(b)); }
   B16 robot_any(B16 b) const { const bool a = any(b); B16 r; for (int l = 0; l < 16; l++) r.v[l] = a; return r; }
   B16 vote(B16 b) const { return b; }
@@ -180,23 +200,23 @@ struct EmuCtx16Base {
   }
   // memory
   F16 ld_joint(const float* p, int f0) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = p[(size_t)(f0 + sc(r)) * NL() + col(r)]; return o; }
-  void st_joint(float* p, int f0, F16 v) const { for (int r = 0; r < 16; r++) if (sub(r) < 3) p[(size_t)(f0 + sub(r)) * NL() + col(r)] = v.v[r]; }
+  void st_joint(float* p, int f0, F16 v) const { if (!gate) return; for (int r = 0; r < 16; r++) if (sub(r) < 3) p[(size_t)(f0 + sub(r)) * NL() + col(r)] = v.v[r]; }
   F16 ld_legf(const float* p, int f) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = p[(size_t)f * NL() + col(r)]; return o; }
-  void st_legf(float* p, int f, F16 v) const { for (int r = 0; r < 16; r += 4) p[(size_t)f * NL() + col(r)] = v.v[r]; }
+  void st_legf(float* p, int f, F16 v) const { if (!gate) return; for (int r = 0; r < 16; r += 4) p[(size_t)f * NL() + col(r)] = v.v[r]; }
   F16 ld_env(const float* p, int f) const { return F16(p[(size_t)f * N + env]); }
   F16 ld_env_sub(const float* p, int f0, int stride) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = p[(size_t)(f0 + stride * (r & 3)) * N + env]; return o; }
-  void st_env(float* p, int f, F16 v) const { p[(size_t)f * N + env] = v.v[0]; }
+  void st_env(float* p, int f, F16 v) const { if (!gate) return; p[(size_t)f * N + env] = v.v[0]; }
   int ld_env_i(const int* p, int f) const { return p[(size_t)f * N + env]; }
-  void st_env_i(int* p, int f, int v) const { p[(size_t)f * N + env] = v; }
-  void st_ring_joint(float* rg, int slot, int k0, F16 v) const { for (int r = 0; r < 16; r++) if (sub(r) < 3) rg[((size_t)slot * 8 + k0 + sub(r)) * NL() + col(r)] = v.v[r]; }
-  void st_ring_aux(float* rg, int slot, int k, F16 v) const { for (int r = 3; r < 16; r += 4) rg[((size_t)slot * 8 + k) * NL() + col(r)] = v.v[r]; }
+  void st_env_i(int* p, int f, int v) const { if (!gate) return; p[(size_t)f * N + env] = v; }
+  void st_ring_joint(float* rg, int slot, int k0, F16 v) const { if (!gate) return; for (int r = 0; r < 16; r++) if (sub(r) < 3) rg[((size_t)slot * 8 + k0 + sub(r)) * NL() + col(r)] = v.v[r]; }
+  void st_ring_aux(float* rg, int slot, int k, F16 v) const { if (!gate) return; for (int r = 3; r < 16; r += 4) rg[((size_t)slot * 8 + k) * NL() + col(r)] = v.v[r]; }
   F16 ld_ring_joint(const float* rg, int slot, int k0) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = rg[((size_t)slot * 8 + k0 + sc(r)) * NL() + col(r)]; return o; }
   F16 ld_ring_k(const float* rg, int slot, int k) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = rg[((size_t)slot * 8 + k) * NL() + col(r)]; return o; }
   F16 ld_row_motor(const float* p, int rowlen, int stride, int k) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = sub(r) < 3 ? p[(size_t)env * rowlen + stride * (3 * leg(r) + sub(r)) + k] : 0.f; return o; }
   F16 ld_row_joint(const float* p, int rowlen, int col0) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = sub(r) < 3 ? p[(size_t)env * rowlen + col0 + 3 * leg(r) + sub(r)] : 0.f; return o; }
-  void st_row_joint(float* p, int rowlen, int col0, F16 v) const { for (int r = 0; r < 16; r++) if (sub(r) < 3) p[(size_t)env * rowlen + col0 + 3 * leg(r) + sub(r)] = v.v[r]; }
-  void st_row_leg(float* p, int rowlen, int col0, F16 v) const { for (int r = 0; r < 16; r += 4) p[(size_t)env * rowlen + col0 + leg(r)] = v.v[r]; }
-  void st_row_env(float* p, int rowlen, int col_, F16 v) const { p[(size_t)env * rowlen + col_] = v.v[0]; }
+  void st_row_joint(float* p, int rowlen, int col0, F16 v) const { if (!gate) return; for (int r = 0; r < 16; r++) if (sub(r) < 3) p[(size_t)env * rowlen + col0 + 3 * leg(r) + sub(r)] = v.v[r]; }
+  void st_row_leg(float* p, int rowlen, int col0, F16 v) const { if (!gate) return; for (int r = 0; r < 16; r += 4) p[(size_t)env * rowlen + col0 + leg(r)] = v.v[r]; }
+  void st_row_env(float* p, int rowlen, int col_, F16 v) const { if (!gate) return; p[(size_t)env * rowlen + col_] = v.v[0]; }
   F16 ld_row_env(const float* p, int rowlen, int col_) const { return F16(p[(size_t)env * rowlen + col_]); }
   void phase(int) const {}
   void phase_p(int) const {}
@@ -425,6 +445,60 @@ extern "C" void emu_step(void* h, const float* action, const uint8_t* donef, flo
     done[i] = d.v[0] > 0.5f;
   }
   emu_obs_noise(e, nullptr, obs);
+}
+// ---- fused open-loop rollout (rollout_steps16 / rollout_steps: what k_rollout16 / k_rollout run), one robot per emulated wave.
+// stop_at_done = KCfg.stop_at_done of the launch: a finished robot is not simulated any more, its last observation row is the one
+// of the step that ended its episode, its state the terminal state.
+template <class Ctx> static void emu_rollout16(Emu* e, int i, int n_steps, float* obs) {
+  Ctx c(i, e->N, e->par.data());
+  State16<F16> S = load_state16<F16>(c, e->base.data(), e->leg.data());
+  rollout_steps16(c, e->K, S, e->base.data(), e->leg.data(), e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), n_steps, obs);
+}
+template <class Ctx> static void emu_rollout4(Emu* e, int i, int n_steps, float* obs) {
+  Ctx c(i, e->N, e->par.data());
+  LaneState<F4> L = load_state<F4>(c, e->base.data(), e->leg.data());
+  rollout_steps(c, e->K, L, e->base.data(), e->leg.data(), e->ring.data(), e->ctl.data(), e->ictl.data(), e->legctl.data(), e->etgp.data(), n_steps, obs);
+}
+extern "C" void emu_rollout_openloop(void* h, int n_steps, int stop_at_done, float* obs, float* ret, int* len) {
+  Emu* e = (Emu*)h;
+  e->K.stop_at_done = stop_at_done;
+  e->K.noise_call = e->obs_calls;
+  e->obs_calls += (unsigned)n_steps;
+  for (int i = 0; i < e->N; i++) {
+    if (e->lanes == 16) {
+      const bool pl = plain_config(e->K);
+      const bool kn = e->K.knee != 0, fl = e->K.terrain == 0;   // (DISPATCH16)
+      if (fl && pl && kn) emu_rollout16<EmuCtx16T<true, true, true>>(e, i, n_steps, obs);
+      else if (fl && pl) emu_rollout16<EmuCtx16T<true, false, true>>(e, i, n_steps, obs);
+      else if (fl) emu_rollout16<EmuCtx16T<true, true, false>>(e, i, n_steps, obs);
+      else if (pl && kn) emu_rollout16<EmuCtx16T<false, true, true>>(e, i, n_steps, obs);
+      else if (pl) emu_rollout16<EmuCtx16T<false, false, true>>(e, i, n_steps, obs);
+      else emu_rollout16<EmuCtx16T<false, true, false>>(e, i, n_steps, obs);
+    } else {
+      const bool pl4 = plain_config(e->K);                        // (LAUNCH4)
+      if (e->K.knee == 3 && e->K.terrain == 0) emu_rollout4<EmuCtxT<true, false, 3>>(e, i, n_steps, obs);
+      else if (e->K.knee == 3) emu_rollout4<EmuCtxT<false, false, 3>>(e, i, n_steps, obs);
+      else if (e->K.knee && e->K.terrain == 0) emu_rollout4<EmuCtxT<true, false, 1>>(e, i, n_steps, obs);
+      else if (e->K.knee) emu_rollout4<EmuCtxT<false, false, 1>>(e, i, n_steps, obs);
+      else if (e->K.terrain == 0 && pl4) emu_rollout4<EmuCtxT<true, true>>(e, i, n_steps, obs);
+      else if (e->K.terrain == 0) emu_rollout4<EmuCtxT<true>>(e, i, n_steps, obs);
+      else if (pl4) emu_rollout4<EmuCtxT<false, true>>(e, i, n_steps, obs);
+      else emu_rollout4<EmuCtxT<false>>(e, i, n_steps, obs);
+    }
+    if (ret) ret[i] = e->ctl[(size_t)CT_RET * e->N + i];
+    if (len) len[i] = (int)e->ctl[(size_t)CT_LEN * e->N + i];
+  }
+  e->K.stop_at_done = 1;
+}
+#ifdef ETG_TRACE_TICKS
+extern "C" void emu_debug_set_trace(void* h, float* buf) { ((Emu*)h)->K.trace = buf; }
+#endif
+extern "C" void emu_set_contact_impulses(void* h, const float* lam) {   // [N,12] per leg (n, t1, t2): the warm start (after emu_set_state)
+  Emu* e = (Emu*)h;
+  const size_t N = e->N, NL = 4 * N;
+  for (size_t i = 0; i < N; i++)
+    for (int l = 0; l < 4; l++)
+      for (int k = 0; k < 3; k++) e->leg[(size_t)(LG_LAM + k) * NL + 4 * i + l] = lam[i * 12 + 3 * l + k];
 }
 extern "C" void emu_get_state(void* h, float* st) {
   Emu* e = (Emu*)h;

@@ -5,9 +5,11 @@ earlier moves a robot's trajectory by 1e-4 .. 1e-2 rad within a control step, an
 by the last bits of the arithmetic.  A fixed bound therefore only holds on smooth stretches.  Round 5 excused 10 % of the
 robots for that reason without looking at them; here every robot is held to its OWN trajectory's sensitivity:
 
-  * `OracleEnsemble` steps, next to the fp64 oracle, the fp32 oracle and E fp64 oracles whose actions are the fp32 actions the
-    GPU receives nudged by +-1 fp32 ulp -- the smallest input change an fp32 implementation cannot tell from the original.
-    `spread()` is, per robot, the largest distance of any member from the nominal fp64 trajectory.
+  * `OracleEnsemble` steps, next to the fp64 oracle, INDEPENDENT fp32-LEVEL EVALUATIONS of the same trajectory: the fp32 build of
+    the oracle, E more fp32 oracles whose actions are the fp32 actions the GPU receives nudged by +-1 fp32 ulp (the smallest
+    input change an fp32 implementation cannot tell from the original; it also re-shuffles every later rounding), and E64 fp64
+    oracles with nudged actions (the pure input sensitivity).  `spread()` is, per robot, the largest distance of any member
+    from the nominal fp64 trajectory.
   * `sens_robots(err_gpu, spread, floor, what)`: EVERY robot must satisfy err_gpu <= floor + 4 * spread.  A robot on a smooth
     stretch has spread ~ 1e-7 and is held to the floor; a robot whose members part from each other is held to 4 x the distance by
     which they part.  The printed [parity] line says how many robots needed the allowance and how large their spread was
@@ -40,20 +42,23 @@ def ulp_nudge(a32, rng):
 
 
 class OracleEnsemble:
-    """The fp64 oracle (`nominal`), the fp32 oracle and E fp64 oracles with +-1 ulp actions, driven together.
+    """The fp64 oracle (`nominal`), the fp32 oracle, E fp32 oracles and E64 fp64 oracles with +-1 ulp actions, driven together.
 
     Construct from keyword arguments of a1_model.default_config, or from an EtgConfig (cfg=..., e.g. the env's own).  Every
     OracleSim method that installs something (set_params, set_heightfield, set_reset_offsets, set_motor_strength,
     set_external_force, set_sensor_noise, set_state) is forwarded to all members; reset / step return the nominal member's
     outputs."""
 
-    def __init__(self, n, E=3, seed=1234, cfg=None, threads=NCPU, **kw):
+    def __init__(self, n, E=3, E64=1, seed=1234, cfg=None, threads=NCPU, rel_noise=0.0, **kw):
+        """rel_noise > 0: the nudged members' actions are scaled by 1 + U(-1, 1) * rel_noise instead of moved by one fp32 ulp
+        (2^-8 for a policy evaluated on bf16 operands: the input uncertainty of THAT arithmetic)."""
         from oracle.oracle import OracleSim
         self.n = n
+        self.rel_noise = rel_noise
         mk = (lambda dt: OracleSim(type(cfg).from_buffer_copy(cfg), dtype=dt)) if cfg is not None else (lambda dt: _oracle(n, dtype=dt, **kw))
         self.nominal = mk(np.float64)
         self.o32 = mk(np.float32)
-        self.nudged = [mk(np.float64) for _ in range(E)]
+        self.nudged = [mk(np.float32) for _ in range(E)] + [mk(np.float64) for _ in range(E64)]
         self.members = [self.o32] + self.nudged
         self.rng = np.random.default_rng(seed)
         for o in [self.nominal] + self.members:
@@ -62,7 +67,7 @@ class OracleEnsemble:
 
     def __getattr__(self, name):
         if name in ("set_params", "set_heightfield", "set_reset_offsets", "set_motor_strength", "set_external_force",
-                    "set_sensor_noise", "set_state"):
+                    "set_sensor_noise", "set_state", "set_lambda"):
             def forward(*a, **k):
                 for o in [self.nominal] + self.members:
                     getattr(o, name)(*a, **k)
@@ -70,16 +75,39 @@ class OracleEnsemble:
         raise AttributeError(name)
 
     def reset(self, mask=None):
-        for o in self.members:
-            o.reset(mask=mask)
-        return self.nominal.reset(mask=mask)
+        self._obs = [np.asarray(o.reset(mask=mask), dtype=np.float64) for o in self.members]
+        out = self.nominal.reset(mask=mask)
+        self._obs0 = np.asarray(out, dtype=np.float64)
+        return out
 
-    def step(self, action, donef=None):
+    def _nudge(self, a32):
+        if self.rel_noise > 0.0:
+            return a32.astype(np.float64) * (1.0 + self.rel_noise * self.rng.uniform(-1.0, 1.0, size=a32.shape))
+        return ulp_nudge(a32, self.rng)
+
+    def step(self, action, donef=None, want_info=True):
         a32 = np.asarray(action, dtype=np.float32)           # what the GPU receives
-        self.o32.step(a32, donef)
+        self._obs = [np.asarray(self.o32.step(a32, donef, want_info=False)[0], dtype=np.float64)]
         for o in self.nudged:
-            o.step(ulp_nudge(a32, self.rng), donef)
-        return self.nominal.step(a32.astype(np.float64), donef)
+            self._obs.append(np.asarray(o.step(self._nudge(a32), donef, want_info=False)[0], dtype=np.float64))
+        out = self.nominal.step(a32.astype(np.float64), donef, want_info=want_info)
+        self._obs0 = np.asarray(out[0], dtype=np.float64)
+        return out
+
+    def closed_loop_step(self, ws, scale=0.3, col0=0):
+        """one step of run_EStrain_episode (train.py:213-249) with a fixed actor: EVERY member acts on its OWN observation
+        (a = tanh(mean(obs[:, col0:])) * scale through the oracle's mlp_forward; the nudged members' actions moved as in step())"""
+        from oracle import oracle as O
+        obs_new = []
+        for o, ob in zip(self.members, self._obs):
+            a = O.mlp_forward(ob[:, col0:], *ws, scale=scale)
+            if o is not self.o32:
+                a = self._nudge(a.astype(np.float32))
+            obs_new.append(np.asarray(o.step(a, want_info=False)[0], dtype=np.float64))
+        self._obs = obs_new
+        out = self.nominal.step(O.mlp_forward(self._obs0[:, col0:], *ws, scale=scale), want_info=False)
+        self._obs0 = np.asarray(out[0], dtype=np.float64)
+        return out
 
     def get_state(self):
         return self.nominal.get_state()

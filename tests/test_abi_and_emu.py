@@ -28,7 +28,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), s
     assert sorted(_lib.SYMBOLS) == syms
-    assert lib.etg_version() == 1
+    assert lib.etg_version() == 2 and lib.etg_config_size() == C.sizeof(A.EtgConfig)
 
 
 def test_no_cpu_fallback_without_device():

@@ -45,52 +45,51 @@ def _lt(value, bound, what):
     assert value < bound, what
 
 
-def _lt_robots(err, bound, what, frac=0.9, cap=300.0):
-    """Per-robot errors against a bound that a smooth stretch of trajectory keeps.  With body spheres colliding (the default
-    contact set) single robots meet a bifurcation now and then -- a knee sphere that starts to grip one tick earlier in fp32
-    than in fp64; the fp32 ORACLE is then 1e-4 rad off the fp64 one (tests/test_emu_fuzz.py measures exactly that) -- so the
-    bound is asked of `frac` of the robots, the median must sit well inside it, and no robot may be further than cap x bound
-    (a wrong kernel moves every robot)."""
-    err = np.asarray(err, dtype=np.float64)
-    q = float(np.quantile(err, frac))
-    print("[parity] %-70s q%.0f %.3e median %.3e max %.3e (bound %.1e)" % (what, 100 * frac, q, float(np.median(err)), float(err.max()), bound), flush=True)
-    assert np.isfinite(err).all(), what
-    assert q < bound and np.median(err) < 0.5 * bound and err.max() < cap * bound, what
+from tests.parity_util import OracleEnsemble, sens_robots   # noqa: E402  (the per-robot criterion: every robot within its own
+                                                               # trajectory's fp32 sensitivity -- no quantiles, no excused tail)
 
 
-def _within(err_gpu, err_o32, floor):
-    """GPU-vs-fp64-oracle error per robot must stay within the trajectory's own fp32 sensitivity
-    (fp32-oracle vs fp64-oracle), plus the stated floor: contact events are chaotic, so a fixed
-    bound only holds for smooth stretches."""
-    return np.all(err_gpu <= floor + 4.0 * err_o32)
+def _ensemble(n, **kw):
+    return OracleEnsemble(n, **kw)
 
 
 def test_native_library_is_loaded():
     _need_gpu()
     from paddlerobotics_amd import _lib
     lib = _lib.load()
-    assert lib.etg_version() == 1
+    assert lib.etg_version() == 2
     with open("/proc/self/maps") as f:
         assert "libetgsim.so" in f.read()
 
 
-def test_reset_and_step_match_oracle():
+@pytest.mark.parametrize("solver", ["default", "iters4"])
+def test_reset_and_step_match_oracle(solver):
+    """The first-line check, under the DEFAULT stopping rule (<= 50 sweeps, residual 1e-7: what the bench times) and under a
+    fixed count of 4 sweeps (a bare solver_iters switches the residual exit off: both sides then do the same arithmetic).
+    40 control steps = 520 ticks of random residual actions on the default contact set.  Every robot is held to
+    floor + 4 x its own trajectory's fp32 sensitivity (tests/parity_util.py); done flags, rewards and observation rows are
+    compared on every robot whose oracle ensemble agrees with itself (the others are past a bifurcation: their flags are
+    compared against the ensemble member the GPU is closest to)."""
     _need_gpu()
     n = 32
+    skw = dict(solver_iters=4) if solver == "iters4" else {}
     W, B = _etg_params(n)
-    env = _make(n, solver_iters=4)
-    orc = _oracle(n, solver_iters=4)
+    env = _make(n, **skw)
+    if solver == "default":
+        assert (env.cfg.solver_iters, env.cfg.solver_residual) == (50, 1e-7)
+    orc = _ensemble(n, **skw)
     env.reset(ETG_w=W, ETG_b=B)
     orc.set_params(etg_w=W, etg_b=B)
     obs_o = orc.reset()
     obs_g = env.obs.cpu().numpy()
     st_g, st_o = env.get_state().cpu().numpy(), orc.get_state()
-    _lt(np.abs(st_g[:, :7] - st_o[:, :7]).max(), 1e-6, "base pose after the 500-tick settle")
-    _lt(np.abs(st_g[:, 13:25] - st_o[:, 13:25]).max(), 3e-6, "joint angles after the settle")
-    _lt(np.abs(obs_g - obs_o).max(), 6e-4, "reset observation (normalised, x10 / x38 scales)")
+    _lt(np.abs(st_g[:, :7] - st_o[:, :7]).max(), 1e-6, "%s: base pose after the 500-tick settle" % solver)
+    _lt(np.abs(st_g[:, 13:25] - st_o[:, 13:25]).max(), 3e-6, "%s: joint angles after the settle" % solver)
+    _lt(np.abs(obs_g - obs_o).max(), 6e-4, "%s: reset observation (normalised, x10 / x38 scales)" % solver)
     rng = np.random.default_rng(1)
     worst = dict(q=np.zeros(n), pos=np.zeros(n), quat=np.zeros(n), obs=0.0, rew=0.0)
-    same_min = 1.0
+    sens = dict(q=np.zeros(n), pos=np.zeros(n), quat=np.zeros(n))
+    compared = 0
     for k in range(40):
         act = rng.uniform(-0.1, 0.1, size=(n, 12))
         og, rg, dg, ig = env.step(torch.as_tensor(act, dtype=torch.float32))
@@ -99,25 +98,30 @@ def test_reset_and_step_match_oracle():
         worst["q"] = np.maximum(worst["q"], np.abs(st_g[:, 13:25] - st_o[:, 13:25]).max(1))
         worst["pos"] = np.maximum(worst["pos"], np.abs(st_g[:, :3] - st_o[:, :3]).max(1))
         worst["quat"] = np.maximum(worst["quat"], np.abs(st_g[:, 3:7] - st_o[:, 3:7]).max(1))
-        on = (worst["q"] < 1e-4)[:, None]      # robots still on the oracle's trajectory (see _lt_robots)
+        sens["q"] = np.maximum(sens["q"], orc.spread(slice(13, 25)))
+        sens["pos"] = np.maximum(sens["pos"], orc.spread(slice(0, 3)))
+        sens["quat"] = np.maximum(sens["quat"], orc.spread(slice(3, 7)))
+        # robots whose ensemble is still ONE trajectory (fp32 oracle and +-1 ulp members within 1e-5 rad of the fp64 one): there
+        # done flags are equal, rewards within 1e-3 relative, observation rows within 2e-2 (normalised: x10 angles, x38 rates)
+        one = sens["q"] < 1e-5
         rg = rg.cpu().numpy()
         ig = env.info_buf.cpu().numpy()
-        # the reward has discrete terms (foot-contact / bad-foot counts): compare it where the contact
-        # pattern agrees (a contact flipping one tick earlier in fp32 moves the reward by 0.5)
-        same = np.all(ig[:, 39:43] == io[:, 39:43], axis=1) & (np.abs(ig[:, 5] - io[:, 5]) < 1e-6) & on[:, 0]
-        same_min = min(same_min, same.mean())
-        worst["rew"] = max(worst["rew"], (np.abs(rg - ro)[same] / (1 + np.abs(ro[same]))).max())
-        worst["obs"] = max(worst["obs"], np.abs(og.cpu().numpy() - oo)[same].max())
-        assert np.array_equal(dg.cpu().numpy().astype(np.uint8)[on[:, 0]], do[on[:, 0]]), k
+        assert np.array_equal(dg.cpu().numpy().astype(np.uint8)[one], do[one]), k
+        # the reward has discrete terms (foot-contact / bad-foot counts): compared where the contact pattern agrees
+        same = np.all(ig[:, 39:43] == io[:, 39:43], axis=1) & (np.abs(ig[:, 5] - io[:, 5]) < 1e-6) & one
+        compared += int(same.sum())
+        if same.any():
+            worst["rew"] = max(worst["rew"], (np.abs(rg - ro)[same] / (1 + np.abs(ro[same]))).max())
+            worst["obs"] = max(worst["obs"], np.abs(og.cpu().numpy() - oo)[same].max())
         assert np.abs(ig[:, 9:21] - io[:, 9:21]).max() < 2e-5      # ETG_act (pure function)
         assert np.abs(ig[:, 43:55] - io[:, 43:55]).max() < 2e-5    # real_action
     # 40 control steps = 520 ticks of random residual actions (SURVEY 8d asks 1e-3 rad / 1e-3 m / 1e-3 rel)
-    _lt_robots(worst["q"], 1e-4, "joint angles, 40 steps")
-    _lt_robots(worst["pos"], 3e-5, "base position, 40 steps")
-    _lt_robots(worst["quat"], 1e-4, "base orientation, 40 steps")
-    _lt(worst["rew"], 3e-3, "reward (relative, robots with the same contact pattern)")
-    _lt(worst["obs"], 2e-2, "observation rows (normalised), same contact pattern")
-    _lt(1.0 - same_min, 0.2, "worst fraction of robots off the oracle's trajectory or with other contact flags in a step")
+    sens_robots(worst["q"], sens["q"], 1e-4, "%s: joint angles, 40 steps" % solver)
+    sens_robots(worst["pos"], sens["pos"], 3e-5, "%s: base position, 40 steps" % solver)
+    sens_robots(worst["quat"], sens["quat"], 1e-4, "%s: base orientation, 40 steps" % solver)
+    _lt(worst["rew"], 1e-3, "%s: reward (relative, robots on one trajectory with the same contact pattern)" % solver)
+    _lt(worst["obs"], 2e-2, "%s: observation rows (normalised), same robots" % solver)
+    _lt(1.0 - compared / (40.0 * n), 0.1, "%s: fraction of (robot, step) pairs past a bifurcation or with other contact flags" % solver)
     env.close()
 
 
@@ -445,22 +449,23 @@ def test_both_kernel_mappings_match_oracle(lanes):
     _need_gpu()
     n = 24                     # not a multiple of 16: exercises partial waves of both mappings
     W, B = _etg_params(n, seed=17)
-    env, orc = _make(n, lanes_per_robot=lanes), _oracle(n)
+    env, orc = _make(n, lanes_per_robot=lanes), _ensemble(n)
     env.reset(ETG_w=W, ETG_b=B)
     orc.set_params(etg_w=W, etg_b=B)
     obs_o = orc.reset()
     _lt(np.abs(env.obs.cpu().numpy() - obs_o).max(), 2e-3, "lanes=%d reset observation" % lanes)
     _lt(np.abs(env.get_state().cpu().numpy()[:, :7] - orc.get_state()[:, :7]).max(), 1e-6, "lanes=%d settle pose" % lanes)
     rng = np.random.default_rng(2)
-    wq, wp = np.zeros(n), np.zeros(n)
+    wq, wp, sq, sp = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)
     for k in range(10):
         act = rng.uniform(-0.1, 0.1, size=(n, 12))
         env.step(torch.as_tensor(act, dtype=torch.float32))
         orc.step(act)
         st_g, st_o = env.get_state().cpu().numpy(), orc.get_state()
         wq = np.maximum(wq, np.abs(st_g[:, 13:25] - st_o[:, 13:25]).max(1)); wp = np.maximum(wp, np.abs(st_g[:, :7] - st_o[:, :7]).max(1))
-    _lt_robots(wq, 3e-5, "lanes=%d joint angles, 10 steps" % lanes)
-    _lt_robots(wp, 1e-5, "lanes=%d base pose, 10 steps" % lanes)
+        sq = np.maximum(sq, orc.spread(slice(13, 25))); sp = np.maximum(sp, orc.spread(slice(0, 7)))
+    sens_robots(wq, sq, 3e-5, "lanes=%d joint angles, 10 steps" % lanes)
+    sens_robots(wp, sp, 1e-5, "lanes=%d base pose, 10 steps" % lanes)
     env.close()
 
 

@@ -22,7 +22,8 @@ from paddlerobotics_amd import a1_model as A
 pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
-from tests.test_gpu_parity import _need_gpu, _etg_params, _make, _oracle, _lt, _lt_robots   # noqa: E402
+from tests.test_gpu_parity import _need_gpu, _etg_params, _make, _oracle, _lt, _ensemble   # noqa: E402
+from tests.parity_util import sens_robots   # noqa: E402
 from tests.test_gpu_parity2 import _say, _policy, _population               # noqa: E402
 
 NCPU = os.cpu_count() or 1
@@ -55,15 +56,14 @@ def test_residual_rule_matches_oracle(lanes, terrain):
     W, B = _etg_params(n, seed=21)
     env = _make(n, lanes_per_robot=lanes, **kw)
     assert (env.cfg.solver_iters, env.cfg.solver_residual) == (50, 1e-7)
-    orc = _oracle(n, terrain=1 if hf else 0, heightfield=hf)
-    orc.threads = NCPU
+    orc = _ensemble(n, terrain=1 if hf else 0, heightfield=hf)
     if hf:
         orc.set_heightfield(hf["heights"])
     env.reset(ETG_w=W, ETG_b=B)
     orc.set_params(etg_w=W, etg_b=B)
     orc.reset()
     rng = np.random.default_rng(2)
-    worst_q, worst_p = np.zeros(n), np.zeros(n)
+    worst_q, worst_p, sq, sp = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)
     per_wave = 64 // lanes
     for k in range(20):
         act = rng.uniform(-0.1, 0.1, size=(n, 12))
@@ -72,19 +72,20 @@ def test_residual_rule_matches_oracle(lanes, terrain):
         sg, so = env.get_state().cpu().numpy(), orc.get_state()
         worst_q = np.maximum(worst_q, np.abs(sg - so)[:, 13:25].max(1))
         worst_p = np.maximum(worst_p, np.abs(sg - so)[:, :3].max(1))
+        sq = np.maximum(sq, orc.spread(slice(13, 25))); sp = np.maximum(sp, orc.spread(slice(0, 3)))
         sw_g = info["solver_sweeps"].cpu().numpy().reshape(-1)
         sw_o = io[:, A.INFO_SWEEPS].reshape(-1, per_wave)
         sw_g = sw_g.reshape(-1, per_wave)
         assert np.all(sw_g == sw_g[:, :1])                          # wave-uniform
         # the wave runs, per tick, the count of its slowest robot: between the largest per-robot step total and the sum
-        # (waves whose robots are all still on the oracle's trajectory: a robot past a grip bifurcation counts its own sweeps)
-        on = (worst_q < 2e-5).reshape(-1, per_wave).all(1)
+        # (waves whose robots' ensembles are all still one trajectory: a robot past a grip bifurcation counts its own sweeps)
+        on = (sq < 1e-5).reshape(-1, per_wave).all(1)
         assert np.all(sw_g[on, 0] >= sw_o[on].max(1) - 2) and np.all(sw_g[on, 0] <= sw_o[on].sum(1) + 2), (k, sw_g[:, 0], sw_o)
         assert np.all(sw_g >= 13) and np.all(sw_g <= 13 * 50)
     assert on.any()
     _say("residual rule %s lanes %d: executed sweeps/tick %.2f vs oracle per robot %.2f" % (terrain, lanes, sw_g.mean() / 13, sw_o.mean() / 13))
-    _lt_robots(worst_q, 1e-3 if hf else 1e-4, "residual rule %s lanes %d joint angles, 20 steps" % (terrain, lanes))   # measured (toe spheres only): 8e-6 / 5e-7 on flat ground
-    _lt_robots(worst_p, 2e-4 if hf else 2e-5, "residual rule %s lanes %d base position" % (terrain, lanes))
+    sens_robots(worst_q, sq, 1e-3 if hf else 1e-4, "residual rule %s lanes %d joint angles, 20 steps" % (terrain, lanes))   # measured (toe spheres only): 8e-6 / 5e-7 on flat ground
+    sens_robots(worst_p, sp, 2e-4 if hf else 2e-5, "residual rule %s lanes %d base position" % (terrain, lanes))
     env.close()
 
 
@@ -266,18 +267,19 @@ def test_four_lane_mapping_at_16384_robots():
         small.step(torch.as_tensor(act[k]), want_info=False)
     assert np.array_equal(small.get_state().cpu().numpy(), st[:m])              # batch invariance: 256 alone == 256 of 16384
     small.close()
-    orc = _oracle(m)
-    orc.threads = NCPU
+    orc = _ensemble(m)
     orc.set_params(etg_w=W, etg_b=B)
     orc.reset()
+    sq, sp = np.zeros(m), np.zeros(m)
     for k in range(12):
         orc.step(act[k].astype(np.float64), want_info=False)
+        sq = np.maximum(sq, orc.spread(slice(13, 25))); sp = np.maximum(sp, orc.spread(slice(0, 3)))
     so = orc.get_state()
     eq, ep = np.abs(st[:m] - so)[:, 13:25].max(1), np.abs(st[:m] - so)[:, :3].max(1)
     _say("4 lanes, 16384 robots: q err median %.2e max %.2e | pos err max %.2e (256-robot oracle sample, 12 steps)" %
          (np.median(eq), eq.max(), ep.max()))
-    _lt_robots(eq, 2e-4, "4 lanes, 16384 robots: joint angles, 12 steps", frac=0.95)
-    _lt_robots(ep, 5e-5, "4 lanes, 16384 robots: base position", frac=0.95)
+    sens_robots(eq, sq, 2e-4, "4 lanes, 16384 robots: joint angles, 12 steps (end state; spread = largest along the way)")
+    sens_robots(ep, sp, 5e-5, "4 lanes, 16384 robots: base position")
     # heightfield at the same size
     hf = _heightfield()
     envh = _make(n, task="heightfield", heightfield=hf)
@@ -333,18 +335,20 @@ def test_pyramid_friction_option_matches_oracle(lanes):
     n = 32
     W, B = _etg_params(n, seed=31)
     env = _make(n, lanes_per_robot=lanes, friction_model=1)
-    orc = _oracle(n, friction_model=1)
+    orc = _ensemble(n, friction_model=1)
     env.reset(ETG_w=W, ETG_b=B)
     orc.set_params(etg_w=W, etg_b=B)
     orc.reset()
     rng = np.random.default_rng(8)
     dyn = np.tile(A.default_dynamic_row(), (n, 1))
+    sq = np.zeros(n)
     for k in range(15):
         act = rng.uniform(-0.2, 0.2, size=(n, 12))                              # large residuals: feet slide
         env.step(torch.as_tensor(act, dtype=torch.float32), want_info=False)
         orc.step(act, want_info=False)
+        sq = np.maximum(sq, orc.spread(slice(13, 25)))
     sg, so = env.get_state().cpu().numpy(), orc.get_state()
-    _lt_robots(np.abs(sg - so)[:, 13:25].max(1), 2e-4, "pyramid friction lanes %d: joint angles after 15 steps" % lanes)
+    sens_robots(np.abs(sg - so)[:, 13:25].max(1), sq, 2e-4, "pyramid friction lanes %d: joint angles after 15 steps" % lanes)
     # and it is a different model: the disc result differs from it
     disc = _make(n, lanes_per_robot=lanes)
     disc.reset(ETG_w=W, ETG_b=B)
@@ -522,7 +526,7 @@ def test_pd_latency_matches_oracle(lanes):
     n = 32
     W, B = _etg_params(n, seed=43)
     env = _make(n, lanes_per_robot=lanes, pd_latency=0.0013)
-    orc = _oracle(n, pd_latency=0.0013)
+    orc = _ensemble(n, pd_latency=0.0013)
     env.reset(ETG_w=W, ETG_b=B)
     orc.set_params(etg_w=W, etg_b=B)
     orc.reset()
@@ -530,11 +534,13 @@ def test_pd_latency_matches_oracle(lanes):
     assert np.abs(s0 - orc.get_state())[:, 13:25].max() < 1e-5
     rng = np.random.default_rng(9)
     acts = rng.uniform(-0.1, 0.1, size=(12, n, 12))
+    sq = np.zeros(n)
     for k in range(12):
         env.step(torch.as_tensor(acts[k], dtype=torch.float32), want_info=False)
         orc.step(acts[k], want_info=False)
+        sq = np.maximum(sq, orc.spread(slice(13, 25)))
     sg, so = env.get_state().cpu().numpy(), orc.get_state()
-    _lt_robots(np.abs(sg - so)[:, 13:25].max(1), 1e-4, "pd_latency 1.3 ms lanes %d: joint angles after 12 steps" % lanes)
+    sens_robots(np.abs(sg - so)[:, 13:25].max(1), sq, 1e-4, "pd_latency 1.3 ms lanes %d: joint angles after 12 steps" % lanes)
     env.reset()                                             # from the settle cache
     assert np.array_equal(env.get_state().cpu().numpy(), s0)
     for k in range(12):
@@ -573,24 +579,32 @@ def test_four_lane_closed_loop_kernel(variant):
         step4.step(pol.predict(view.contiguous(), 0.3, prec), want_info=False)
     rets, lns = step4.episode_stats()
     s4, ss, s16 = (e.get_state().cpu().numpy() for e in (fused4, step4, fused16))
-    tol = 2e-2 if variant == "bf16" else 1e-4                   # bf16 operands: the two kernels round activations alike, the split of K differs
-    _lt_robots(np.abs(s4 - ss)[:, 13:25].max(1), tol, "4-lane closed loop %s: joint gap to predict+step, 12 steps" % variant)
-    _lt_robots(np.abs(s4 - s16)[:, 13:25].max(1), tol, "4-lane closed loop %s: joint gap to the 16-lane fused kernel" % variant)
-    assert (ln4.cpu().numpy() == lns.cpu().numpy()).mean() > 0.97
-    assert np.quantile(np.abs(ret4.cpu().numpy() - rets.cpu().numpy()), 0.9) < (0.5 if variant == "bf16" else 5e-3) * (1 + np.abs(rets.cpu().numpy()).max()) * 1e-1 + 5e-3
+    # the oracle ensemble's closed loop (every member on its own observations).  bf16 operands: the members' actions carry a
+    # relative noise of 2^-8, the input uncertainty of that arithmetic; otherwise +-1 fp32 ulp
+    orc = _ensemble(m, terrain=1 if hf else 0, heightfield=hf, rel_noise=2.0 ** -8 if variant == "bf16" else 0.0)
+    if hf:
+        orc.set_heightfield(hf["heights"])
+    orc.set_params(etg_w=W, etg_b=B)
+    orc.reset()
+    sq = np.zeros(m)
+    for _ in range(steps):
+        orc.closed_loop_step(ws, 0.3, col0=3 if variant == "student" else 0)
+        sq = np.maximum(sq, orc.spread(slice(13, 25)))
+    sqn = np.tile(sq, n // m)
+    tol = 2e-3 if variant == "bf16" else 1e-4
+    # two fp32 evaluations of one trajectory are as far apart as the trajectory is sensitive: the kernel-to-kernel gaps are held
+    # to the same per-robot criterion as the gap to the oracle
+    sens_robots(np.abs(s4 - ss)[:, 13:25].max(1), sqn, tol, "4-lane closed loop %s: joint gap to predict+step, 12 steps" % variant)
+    sens_robots(np.abs(s4 - s16)[:, 13:25].max(1), sqn, tol, "4-lane closed loop %s: joint gap to the 16-lane fused kernel" % variant)
+    one = sqn < 1e-5
+    assert np.array_equal(ln4.cpu().numpy()[one], lns.cpu().numpy()[one])
+    dr = np.abs(ret4.cpu().numpy() - rets.cpu().numpy())[one]
+    assert np.all(dr < (0.5 if variant == "bf16" else 5e-3) * (1 + np.abs(rets.cpu().numpy()).max()) * 1e-1 + 5e-3)
     assert np.array_equal(s4[:m], s4[m:])                       # copies of the sample: batch invariance across workgroups
-    if variant in ("flat", "heightfield"):
-        orc = _oracle(m, terrain=1 if hf else 0, heightfield=hf)
-        orc.threads = NCPU
-        if hf:
-            orc.set_heightfield(hf["heights"])
-        orc.set_params(etg_w=W, etg_b=B)
-        obs = orc.reset()
-        for _ in range(steps):
-            obs, _, _, _ = orc.step(O.mlp_forward(obs, *ws, scale=0.3), want_info=False)
-        eq = np.abs(s4[:m] - orc.get_state())[:, 13:25].max(1)
-        _say("4-lane closed loop %s vs oracle: q err median %.2e max %.2e" % (variant, np.median(eq), eq.max()))
-        _lt_robots(eq, 2e-4, "4-lane closed loop %s vs oracle: joint angles" % variant)
+    eq = np.abs(s4[:m] - orc.get_state())[:, 13:25].max(1)
+    _say("4-lane closed loop %s vs oracle: q err median %.2e max %.2e" % (variant, np.median(eq), eq.max()))
+    sens_robots(eq, sq, 5e-2 if variant == "bf16" else 2e-4, "4-lane closed loop %s vs oracle: joint angles" % variant)
+    if variant != "bf16":
         assert np.median(eq) < 1e-5
     with pytest.raises(Exception):
         odd = _make(96, lanes_per_robot=4)                      # not a multiple of 64: the C-ABI refuses, env falls back to stepping

@@ -3,9 +3,9 @@
   * ONE-STEP CONSISTENCY along the GPU's own trajectory (default contact set: toe spheres + body contacts with friction, the
     Bullet-default stopping rule).  Trajectory comparisons let a robot drift off the oracle after its first grip bifurcation, and
     from then on say nothing about it.  Here every control step is checked on its own: the GPU's state before the step (fp32,
-    read through the C-ABI) is installed in a second GPU env AND in the oracles (etg_set_state semantics on both sides: impulses
-    zeroed, latency ring re-seeded), both take the step with the same action, and the results are compared -- for every robot
-    and every step.  The criterion is the sharp one (tests/parity_util.nearest_member): the GPU's result must lie within the
+    read through the C-ABI: etg_get_state + etg_get_contact_impulses, the solver's warm start) is installed in a second GPU env
+    AND in the oracles (etg_set_state semantics on both sides: latency ring re-seeded), both take the step with the same
+    action, and the results are compared -- for every robot and every step.  The criterion is the sharp one (tests/parity_util.nearest_member): the GPU's result must lie within the
     floor of the result of the fp64 oracle, of the fp32 oracle or of one of E fp64 oracles whose action is nudged by +-1 fp32
     ulp.  A step map with a discontinuity has several branches; the GPU has to be ON one of them.  The [parity] line lists how
     many (robot, step) pairs were on the nominal branch, how many on another member's, and none may be on no branch.
@@ -53,9 +53,11 @@ def one_step_consistency(env_kw, orc_kw, n, steps, seed, amp, floor_q, floor_p, 
     offenders = []
     for k in range(steps):
         act = rng.uniform(-amp, amp, size=(n, 12)).astype(np.float32)
-        st = run.get_state()                                      # fp32 [N,37]: what both sides start the step from
+        st, lam = run.get_state(), run.get_contact_impulses()     # fp32 [N,37] + [N,12]: what both sides start the step from
         probe.set_state(st)
+        probe.set_contact_impulses(lam)
         ens.set_state(st.cpu().numpy().astype(np.float64))
+        ens.set_lambda(lam.cpu().numpy().astype(np.float64))
         a = torch.as_tensor(act)
         probe.step(a, want_info=False)
         ens.step(act)

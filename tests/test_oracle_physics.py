@@ -421,6 +421,7 @@ def _bullet_order_solve(sim, s0, lam_prev, tau, cfg, mu, sweeps, trace=None):
     # body contacts (EtgConfig.body_contacts 1 / 2), stated independently of the oracle's row construction: the sphere centres from
     # plain rotation matrices, the deepest-of-three pick, and the joint columns of a row by CENTRAL DIFFERENCES of the contact
     # point's base-frame position (the point rides on its link); rows ("bn" | "bt", leg), not warm-started
+    _bullet_order_solve.body_weights = {}
     if cfg.body_contacts in (1, 2):
         Rx = lambda a: np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
         Ry = lambda a: np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
@@ -438,28 +439,37 @@ def _bullet_order_solve(sim, s0, lam_prev, tau, cfg, mu, sweeps, trace=None):
             if cfg.body_contacts == 2:
                 cands.append(("calf", knee + Rc @ np.array([0.0, 0.0, -0.5 * m.lower_len])))
                 cands.append(("trunk", np.array([np.sign(hip[0]) * cfg.trunk_half[0], np.sign(hip[1]) * cfg.trunk_half[1], -cfg.trunk_half[2]])))
-            depth = [s0[2] + (R @ c)[2] - cfg.knee_radius for _, c in cands]
-            pick = int(np.argmin(depth))                           # (np.argmin returns the FIRST minimum: ties to the earlier candidate)
-            phi = depth[pick]
+            depth = np.array([s0[2] + (R @ c)[2] - cfg.knee_radius for _, c in cands])
+            # the contact's impulse is carried by the deepest sphere (np.argmin returns the FIRST minimum: ties to the earlier
+            # candidate) or, with EtgConfig.body_blend > 0, shared by the spheres with weights exp(-(d_i - d_min) / body_blend):
+            # the contact sphere sits at the weighted mean of the centres, its point moves with the joints as the weighted sum of
+            # the spheres' own points does (weights frozen over the tick)
+            wts = np.zeros(len(cands))
+            wts[int(np.argmin(depth))] = 1.0
+            if cfg.body_blend > 0 and len(cands) > 1:
+                wts = np.exp(-(depth - depth.min()) / cfg.body_blend)
+                wts /= wts.sum()
+            _bullet_order_solve.body_weights[l] = wts.copy()
+            centre = sum(w * c for w, (_, c) in zip(wts, cands))
+            phi = s0[2] + (R @ centre)[2] - cfg.knee_radius         # flat ground: = sum_i w_i depth_i
             if not phi < cfg.contact_margin:
                 continue
-            link, centre = cands[pick]
             cp = centre - cfg.knee_radius * nb                     # contact point, base frame
-            if link == "trunk":
-                point = lambda q: cp
-            else:
+            Jc = np.zeros((3, 3))
+            h = 1e-6
+            for w_i, (link, c_i) in zip(wts, cands):
+                if w_i == 0.0 or link == "trunk":                  # (no joint moves the trunk corner)
+                    continue
+                cp_i = c_i - cfg.knee_radius * nb                  # sphere i's own point, riding on its link
                 R0 = Rt if link == "thigh" else Rc
-                c0 = knee
-                local = R0.T @ (cp - c0)                           # the point in its link's frame (origin: the knee)
+                local = R0.T @ (cp_i - knee)                       # ... in its link's frame (origin: the knee)
 
                 def point(q, local=local, link=link):
                     Rt_, knee_, Rc_ = frames(q)
                     return knee_ + (Rt_ if link == "thigh" else Rc_) @ local
-            Jc = np.zeros((3, 3))
-            h = 1e-6
-            for j in range(3):
-                dq = np.zeros(3); dq[j] = h
-                Jc[:, j] = (point(ql + dq) - point(ql - dq)) / (2 * h)
+                for j in range(3):
+                    dq = np.zeros(3); dq[j] = h
+                    Jc[:, j] += w_i * (point(ql + dq) - point(ql - dq)) / (2 * h)
             pen = phi + cfg.contact_slop
             for k, dw in enumerate(dirs_w):
                 db = R.T @ dw
@@ -509,7 +519,7 @@ def _bullet_order_solve(sim, s0, lam_prev, tau, cfg, mu, sweeps, trace=None):
     return out, jl, vstar + Mi @ J.T @ lam
 
 
-@pytest.mark.parametrize("case", ["kick", "sliding", "calf_at_its_stop", "kneeling", "belly"])
+@pytest.mark.parametrize("case", ["kick", "sliding", "calf_at_its_stop", "kneeling", "belly", "shins_flat"])
 def test_sweeps_follow_bullets_row_order_in_an_independent_numpy_statement(case):
     """The oracle's contact solve after exactly K = 1, 2, 3, 6 sweeps against the compact numpy statement above: row order,
     warm-start factors (normal 0.1, friction 0), slop / erp targets, the friction skip while lambda_n = 0 and the disc projection
@@ -543,6 +553,19 @@ def test_sweeps_follow_bullets_row_order_in_an_independent_numpy_statement(case)
             st[0, 2] = A.TRUNK_HALF[2] + 0.02 + 0.001
             st[0, 3:7] = np.array([0.0, 0.0, 0.0, 1.0])
             st[0, 7:10] = np.array([0.3, -0.2, -0.5]); st[0, 10:13] = np.array([0.0, 0.0, 0.6])
+        if case == "shins_flat":
+            # the four shins lying along the ground, tilted by 3 mrad: knee and shin-midpoint spheres 0.3 mm apart in depth -- the
+            # contact's impulse is SHARED by the two (EtgConfig.body_blend = 1 mm: weights ~0.57 / 0.43)
+            st[0, 13:25] = np.tile([0.0, 2.65 - np.pi / 2 - 0.003, -2.65], 4)   # (all four; knee end lower: the foot at the far end stays 0.6 mm higher)
+            st[0, 3:7] = np.array([0.0, 0.0, 0.0, 1.0])
+            st[0, 7:10] = np.array([0.2, 0.05, -0.2]); st[0, 10:13] = np.array([0.0, 0.3, 0.2])
+            probe = O.OracleSim(cfg)
+            probe.set_params(dyn=row[None]); probe.reset()
+            for _ in range(3):                              # base height: the hind body contacts 0.5 mm inside the ground
+                probe.set_state(st)
+                probe.trace(0, 2)
+                probe.tick(np.zeros((1, 12)), 1)
+                st[0, 2] -= probe.trace_rows()[0, 10] + 0.0005
         sim.set_state(st)
         s0, lam_prev = sim.get_state()[0].copy(), sim.get_lambda()[0].copy()
         tau = -row[21:33] * (s0[13:25] - A.INIT_MOTOR_ANGLES) - row[33:45] * s0[25:37]
@@ -560,5 +583,10 @@ def test_sweeps_follow_bullets_row_order_in_an_independent_numpy_statement(case)
             bi = _bullet_order_solve.body_impulses       # the scenario does load body rows, normal and friction
             assert sum(1 for k, v in bi.items() if k[0] == "bn" and v > 1e-3) >= 2, bi
             assert any(k[0] == "bt" and abs(v) > 1e-4 for k, v in bi.items()), bi
+        if case == "shins_flat":
+            wt = _bullet_order_solve.body_weights
+            assert cfg.body_blend > 0 and any(0.2 < w.max() < 0.8 for w in wt.values()), wt          # the load IS shared
+            if K >= 2:
+                assert sum(1 for k, v in _bullet_order_solve.body_impulses.items() if k[0] == "bn" and v > 1e-5) >= 1   # (the hind feet share the load)
         if case == "sliding" and K == 6:
             assert any(abs(np.hypot(lam[3 * l + 1], lam[3 * l + 2]) - mu * lam[3 * l]) < 1e-9 for l in range(4) if lam[3 * l] > 0)
