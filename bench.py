@@ -389,6 +389,22 @@ def main():
     elapsed = float(np.median(wall))
     kern_ms = float(np.median(kern))
     live_value = (world * float(np.median(live_steps)) / elapsed) if live_steps else None
+    # how unevenly the sweeps load the wavefronts: per-wave shader-clock cycles of the LAST timed repeat's launches (every launch
+    # ends with a chip-wide barrier: it lasts as long as its slowest wave)
+    imbalance = None
+    if fused and policy is None:
+        try:
+            cyc = env.rollout_wave_cycles().double()
+            if cyc.numel() and cyc.shape[0] > 0:
+                per_launch_max = cyc.max(dim=1).values
+                tot = cyc.sum(dim=0)
+                imbalance = {"value": float(per_launch_max.sum().item() / tot.mean().item()), "launches": int(cyc.shape[0]), "waves": int(cyc.shape[1]),
+                             "kernel_cycles_per_step": float(per_launch_max.sum().item()) / K, "mean_wave_cycles_per_step": float(tot.mean().item()) / K,
+                             "slowest_wave_total_over_mean": float(tot.max().item() / tot.mean().item()),
+                             "is": "sum over the launches of the slowest wave's cycles / mean over the waves of their total cycles, last timed "
+                                   "repeat (etg_rollout_wave_cycles: clock64 at kernel entry and exit of every wavefront)"}
+        except Exception as e:                                       # noqa: BLE001 - diagnostics must not lose the line
+            imbalance = {"error": repr(e)[:200]}
     # N > 1: every rank's own median step time, and the one exchange of the path (the all_gather of the returns) on its own
     multi = None
     if dist is not None:
@@ -506,7 +522,7 @@ def main():
         out = {
             "metric": "env-steps/sec, 4096 A1 quadrupeds; 1/2/4/8-GPU scaling",
             "value": value, "unit": "env-steps/s", "n_gpus": world, "steps": K, "warmup": args.warmup,
-            "ms_per_step": elapsed / K * 1e3, "live_env_steps_per_s": live_value, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": elapsed / K * 1e3, "live_env_steps_per_s": live_value, "imbalance": imbalance, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": ("configs[1]: %d parallel A1 per GPU, flat terrain, ETG open-loop, per-env ETG "
                                     "params = prior + N(0,0.02^2)" % N) if args.config == 2 else

@@ -332,6 +332,12 @@ int etg_episode_stats(EtgHandle* h, float* ret, int32_t* len, void* stream);
  * etg_set_rollout_mode(h, 1) brings back the behaviour of ABI version 1 -- finished robots are simulated on, only their
  * accumulators are masked -- for callers that measure it or look at a robot after its fall; 0 = the default.          */
 int etg_set_rollout_mode(EtgHandle* h, int simulate_finished);
+/* Measurement: the shader-clock cycles every wavefront spent in each launch of the LAST etg_rollout_openloop call, cycles
+ * [launches][waves] int64 (device pointer; NULL = only report the two sizes).  A launch lasts as long as its slowest wave: the
+ * sum over the launches of the largest entry against the mean of the waves' totals says how unevenly the contact solver's
+ * sweeps load the wavefronts (bench.py: "imbalance").  A rollout is cut into launches of 50 control steps; the environment
+ * variable ETG_ROLLOUT_CHUNK changes that for a process (a measurement aid: profiles/r06_chunk_sweep.txt).            */
+int etg_rollout_wave_cycles(EtgHandle* h, int64_t* cycles, int capacity, int* launches, int* waves, void* stream);
 /* open-loop rollout: n_steps x etg_step(action = 0) enqueued back-to-back
  * (pretrain.py:129-154), then etg_episode_stats. obs [N,49] (or NULL)
  * receives the final observation of every robot (see above: of a finished

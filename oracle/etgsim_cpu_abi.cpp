@@ -194,6 +194,12 @@ int etg_episode_stats(EtgHandle* h, float* ret, int32_t* len, void*) {
   return ETG_OK;
 }
 
+int etg_rollout_wave_cycles(EtgHandle* h, int64_t*, int, int* launches, int* waves, void*) {
+  if (!h || !launches || !waves) return cfail(ETG_ERR_BAD_ARG, "etg_rollout_wave_cycles: null");
+  *launches = 0; *waves = 0;        // no wavefronts on the host
+  return ETG_OK;
+}
+
 int etg_set_rollout_mode(EtgHandle* h, int simulate_finished) {
   if (!h) return cfail(ETG_ERR_BAD_ARG, "null handle");
   H(h)->simulate_finished = simulate_finished != 0;

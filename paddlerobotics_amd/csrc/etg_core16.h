@@ -1400,11 +1400,13 @@ ETG_HD void rollout_store16(const Ctx& c, const KCfg& K, const State16<F>& L, F 
 // state, control variables and tick constants stay in registers between the steps, and the per-launch cost
 // (parameter staging, state load/store, launch ramp) is paid once
 template <class F, class Ctx>
-ETG_HD void rollout_steps16(const Ctx& c, const KCfg& K, State16<F>& L, float* base, float* leg, float* ring, float* ctl, int* ictl,
+ETG_HD void rollout_steps16(Ctx& c, const KCfg& K, State16<F>& L, float* base, float* leg, float* ring, float* ctl, int* ictl,
                             float* legctl, const float* etgp, int n_steps, float* obs) {
   StepCtl16<F> S = load_ctl16<F>(c, K, ctl, ictl, legctl);
   TickPar<F> tp = load_tick_par<F>(c);
-  if (!Ctx::kPlain && K.ext_force) tp.fext = load_fext16<F>(c, ctl);
+  V3<F> fext = {F(0.0f), F(0.0f), F(0.0f)};
+  if (!Ctx::kPlain && K.ext_force) fext = load_fext16<F>(c, ctl);
+  tp.fext = fext;
   F reward, done;
   const bool skip = K.stop_at_done != 0;
   // only the LAST observation of an open-loop rollout is ever read (etg_rollout_openloop hands it to the caller): the inner
@@ -1412,6 +1414,15 @@ ETG_HD void rollout_steps16(const Ctx& c, const KCfg& K, State16<F>& L, float* b
   // (stop_at_done: a robot's last row is the one of the step that ended its episode)
   for (int s = 0; s < n_steps; s++) {
     if (skip && !c.any(S.alive > F(0.5f))) break;     // every robot of the wave has finished
+    if (Ctx::kStepLocal) {
+      // Contexts whose tick constants sit in LDS (GpuCtx16W) form everything that is constant over the rollout anew at the top
+      // of every control step -- the lane's coordinates go through an empty asm, the tick constants are read back from LDS --
+      // instead of keeping ~60 hoisted registers alive from the kernel's head through every tick: the tick's register peak
+      // falls, and with it the accumulator-register moves the allocator puts around it.
+      c.launder_lane();
+      tp = load_tick_par<F>(c);
+      tp.fext = fext;
+    }
     const F was_alive = S.alive;
     control_step16_core(c, K, tp, L, S, ring, etgp, F(0.0f), F(0.0f), obs, reward, done, (float*)nullptr, (const F*)nullptr,
                         s == n_steps - 1, (float*)nullptr, (float*)nullptr, skip);

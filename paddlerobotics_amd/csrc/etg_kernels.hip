@@ -475,16 +475,20 @@ __global__ void __launch_bounds__(BLOCK) k_step_ar(KCfg K, DevState D, const flo
   step4_body<FLAT, PLAIN, true, BODY>(K, D, action, donef, obs, reward, done, info, lds_par, NX);
 }
 
-struct StatOut { float* ret; int* len; };   // episode returns / lengths [N] for the caller, or nulls
+// episode returns / lengths [N] for the caller, or nulls; cyc: one slot per wavefront of the launch receiving the shader-clock
+// cycles the wave spent in the kernel (etg_rollout_wave_cycles: how unevenly the sweeps load the wavefronts), or null
+struct StatOut { float* ret; int* len; long long* cyc; };
 // n_steps open-loop control steps per launch (rollout_steps), the 4-lanes-per-robot counterpart of k_rollout16
 template <bool FLAT, bool PLAIN, int BODY = 0>
 __global__ void __launch_bounds__(BLOCK) k_rollout(KCfg K, DevState D, int n_steps, float* obs, StatOut so) {
   GpuCtxT<FLAT, PLAIN, BODY> c;
   if (!make_ctx(K, c)) return;
+  const long long t0 = so.cyc ? clock64() : 0;
   __shared__ float lds_par[PR_N * BLOCK];
   stage_params(c, D, lds_par);
   LaneState<float> L = load_state<float>(c, D.base, D.leg);
   rollout_steps(c, K, L, D.base, D.leg, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, n_steps, obs);   // (stores the state itself: stop_at_done)
+  if (so.cyc && threadIdx.x == 0) so.cyc[blockIdx.x] = clock64() - t0;
   if (so.ret && c.lane == 0) {   // the last launch of a rollout hands the episode statistics to the caller itself (no extra launch)
     so.ret[c.env] = D.ctl[(size_t)CT_RET * K.n_env + c.env];
     so.len[c.env] = (int)D.ctl[(size_t)CT_LEN * K.n_env + c.env];
@@ -560,6 +564,17 @@ struct GpuCtx16 {
   __device__ __forceinline__ void set_gate(bool on) const { gate = on; }
   __device__ __forceinline__ void open_gate() const { gate = true; }
   __device__ __forceinline__ int sel_i(bool m, int a, int b) const { return m ? a : b; }
+  // The lane's coordinates through an empty asm: everything derived from them after this point (the tick's lane masks, per-lane
+  // constants selected from the config block: ~60 registers) is computed HERE again instead of being hoisted out of the caller's
+  // loop -- the per-wave closed-loop kernel calls it at the top of every control step, so that none of it lives across the
+  // policy tile (where the allocator would spill it to scratch).
+  __device__ __forceinline__ void launder_lane() {
+    asm volatile("" : "+v"(r), "+v"(leg), "+v"(sub), "+v"(sc));
+    int lo = (int)col, e = env;             // (the array columns too: addresses are formed where they are used, not kept from the kernel's head)
+    asm volatile("" : "+v"(lo), "+v"(e));
+    col = (size_t)(unsigned)lo;
+    env = e;
+  }
   __device__ __forceinline__ float jointf() const { return sub < 3 ? 1.0f : 0.0f; }
   __device__ __forceinline__ bool sub_is(int j) const { return sub == j; }
   __device__ __forceinline__ bool leg_is(int j) const { return leg == j; }
@@ -943,12 +958,42 @@ template <bool FLAT, bool KNEE = false, bool PLAIN = false, bool SLOTB_LDS = fal
   static constexpr bool kKnee = KNEE;
   static constexpr bool kPlain = PLAIN;
   static constexpr bool kSlotBLds = SLOTB_LDS;   // the body friction rows' Delassus columns live in LDS (etg_core16.h: finish_tick)
+  static constexpr bool kStepLocal = false;      // (GpuCtx16W: rollout constants are formed anew every control step)
 #ifdef ETG_NO_ASM_SWEEP
   static constexpr bool kAsmSweep = false;
 #else
   static constexpr bool kAsmSweep = true;     // pgs_normals / pgs_tangents_disc: the hand-scheduled sweep
 #endif
 };
+
+// The context of the per-wave closed-loop kernels: the tick constants come from the lane's LDS column (staged in full at kernel
+// start) instead of HBM, so that control_step can re-read them at the top of every control step -- they need not stay in
+// registers across the policy tile (45 registers per lane that the allocator otherwise spills to scratch around the tile).
+template <bool FLAT, bool KNEE, bool PLAIN> struct GpuCtx16W : GpuCtx16T<FLAT, KNEE, PLAIN> {
+  static constexpr bool kStepLocal = true;
+  __device__ __forceinline__ float tpar(int k) const { return this->lds[k * 64]; }
+  __device__ __forceinline__ float tpar_joint(int base) const { return this->lds[(base + this->sc) * 64]; }
+  __device__ __forceinline__ float tpar_link(int k) const { return this->sub < 3 ? this->lds[(PR_LINK + 10 * this->sub + k) * 64] : 0.0f; }
+};
+// register parking around the policy tile: the robot state and the control variables of the lane, in LDS (one column per lane)
+constexpr int PARK16 = 36;
+__device__ __forceinline__ void park16(float* p, const State16<float>& L, const StepCtl16<float>& S) {
+  const float v[PARK16] = {L.p.x, L.p.y, L.p.z, L.qx, L.qy, L.qz, L.qw, L.wb.x, L.wb.y, L.wb.z, L.vb.x, L.vb.y, L.vb.z, L.q, L.qd, L.lam, L.contact,
+                           __int_as_float(S.step_count), __int_as_float(S.tick), __int_as_float(S.has_last), S.last, S.lbx, S.lby, S.lbz, S.last_fwx,
+                           S.ret, S.len, S.r0, S.r1, S.r2, S.fx0, S.fx1, S.fy0, S.fy1, 0.0f, 0.0f};
+#pragma unroll
+  for (int k = 0; k < PARK16; k++) p[k * 64] = v[k];
+}
+__device__ __forceinline__ void unpark16(const float* p, State16<float>& L, StepCtl16<float>& S) {
+  float v[PARK16];
+#pragma unroll
+  for (int k = 0; k < PARK16; k++) v[k] = p[k * 64];
+  L.p = {v[0], v[1], v[2]}; L.qx = v[3]; L.qy = v[4]; L.qz = v[5]; L.qw = v[6];
+  L.wb = {v[7], v[8], v[9]}; L.vb = {v[10], v[11], v[12]}; L.q = v[13]; L.qd = v[14]; L.lam = v[15]; L.contact = v[16];
+  S.step_count = __float_as_int(v[17]); S.tick = __float_as_int(v[18]); S.has_last = __float_as_int(v[19]);
+  S.last = v[20]; S.lbx = v[21]; S.lby = v[22]; S.lbz = v[23]; S.last_fwx = v[24]; S.ret = v[25]; S.len = v[26];
+  S.r0 = v[27]; S.r1 = v[28]; S.r2 = v[29]; S.fx0 = v[30]; S.fx1 = v[31]; S.fy0 = v[32]; S.fy1 = v[33];
+}
 
 // robot_block = index of the group of 4 robots this wave carries, lane = lane in the wave, lds_wave = the wave's
 // own [LDS16_FIELDS][64] parameter staging area.  Three steps so that a caller can put its own loads between the staging
@@ -1126,10 +1171,20 @@ __global__ void __launch_bounds__(BLOCK) k_step16_ar(KCfg K, DevState D, const f
 template <bool FLAT, bool KNEE, bool PLAIN>
 __global__ void __launch_bounds__(BLOCK) k_rollout16(KCfg K, DevState D, int n_steps, float* obs, StatOut so) {
   __shared__ float lds_par[LDS16_FIELDS * BLOCK];
+#ifndef ETG_ROLLOUT16_STEP_LOCAL   // the default: rollout constants hoisted to the kernel's head, tick constants from HBM.  (A/B build
+  // variant -DETG_ROLLOUT16_STEP_LOCAL: formed anew every control step like the tape and closed-loop kernels -- 343 registers
+  // instead of 448 and 60 % fewer accumulator-register moves, and 0.4 % SLOWER on the same box: profiles/r06_ab_experiments.txt)
   GpuCtx16T<FLAT, KNEE, PLAIN> c;
   if (!make_ctx16(K, D, c, lds_par)) return;
+#else
+  GpuCtx16W<FLAT, KNEE, PLAIN> c;
+  if (!make_ctx16_fields(K, D, c, lds_par, xcd_contiguous_block(), threadIdx.x)) return;
+  for (int k = 0; k < PR_N; k++) lds_par[k * 64 + threadIdx.x] = D.par[(size_t)k * c.NL + c.col];   // the lane's whole parameter column
+#endif
+  const long long t0 = so.cyc ? clock64() : 0;
   State16<float> L = load_state16<float>(c, D.base, D.leg);
   rollout_steps16(c, K, L, D.base, D.leg, D.ring, D.ctl, D.ictl, D.legctl, D.etgp, n_steps, obs);   // (stores the state itself: stop_at_done)
+  if (so.cyc && threadIdx.x == 0) so.cyc[blockIdx.x] = clock64() - t0;
   if (so.ret && c.r == 0) {   // the last launch of a rollout hands the episode statistics to the caller itself (no extra launch):
     so.ret[c.env] = D.ctl[(size_t)CT_RET * K.n_env + c.env];        // lane 0 of the robot's row re-reads what it has just stored
     so.len[c.env] = (int)D.ctl[(size_t)CT_LEN * K.n_env + c.env];
@@ -1140,16 +1195,20 @@ __global__ void __launch_bounds__(BLOCK) k_rollout16(KCfg K, DevState D, int n_s
 template <bool FLAT, bool KNEE, bool PLAIN>
 __global__ void __launch_bounds__(BLOCK) k_rollout_actions16(KCfg K, DevState D, int n_steps, const float* actions, float* obs, TapeOut T) {
   __shared__ float lds_par[LDS16_FIELDS * BLOCK];
-  GpuCtx16T<FLAT, KNEE, PLAIN> c;
-  if (!make_ctx16(K, D, c, lds_par)) return;
+  GpuCtx16W<FLAT, KNEE, PLAIN> c;             // (rollout constants formed anew every control step: see rollout_steps16)
+  if (!make_ctx16_fields(K, D, c, lds_par, xcd_contiguous_block(), threadIdx.x)) return;
+  for (int k = 0; k < PR_N; k++) lds_par[k * 64 + threadIdx.x] = D.par[(size_t)k * c.NL + c.col];
   State16<float> L = load_state16<float>(c, D.base, D.leg);
   StepCtl16<float> S = load_ctl16<float>(c, K, D.ctl, D.ictl, D.legctl);
-  TickPar<float> tp = load_tick_par<float>(c);
-  if (!PLAIN && K.ext_force) tp.fext = load_fext16<float>(c, D.ctl);
+  V3<float> fext = {0.0f, 0.0f, 0.0f};
+  if (!PLAIN && K.ext_force) fext = load_fext16<float>(c, D.ctl);
   const size_t N = K.n_env;
   float reward, done;
   const bool skip = K.stop_at_done != 0;
   for (int s = 0; s < n_steps; s++) {
+    c.launder_lane();
+    TickPar<float> tp = load_tick_par<float>(c);
+    tp.fext = fext;
     const float act = c.ld_row_joint(actions + (size_t)s * N * ETG_ACT_DIM, ETG_ACT_DIM, 0);
     const bool last = s == n_steps - 1;
     const float was_alive = S.alive;
@@ -1176,6 +1235,7 @@ __global__ void __launch_bounds__(BLOCK) k_rollout_actions16(KCfg K, DevState D,
 // the next observation back to LDS.  Nothing but the final observation, the ring and the episode accumulators
 // touches HBM between steps.  (run_EStrain_episode / run_evaluate_episodes, train.py:182-249, with a fixed actor.)
 struct PolicyW { const float4 *w1, *w2, *w3; const float *b1, *b2, *b3; int in_dim, out_dim, col0; };   // col0: first observation column the actor sees
+// (the per-wave kernels: w1 = the k_pack_wave12 stream of both hidden layers, w2 unused, w3 / RecOut::w3s = the k_pack_head copies)
 // per-step outputs of the recording variant ([n_steps][N][...]); noise != NULL: the STOCHASTIC actor of SAC.sample
 // (alg/sac.py:65-76) on the caller's N(0,1) draws [n_steps][N][12]: x = mean + exp(clamp(log_std, -20, 2)) * noise,
 // action = tanh(x); w3s / b3s = the packed log-std head (etg_policy_load_std)
@@ -1324,6 +1384,150 @@ __global__ void __launch_bounds__(256) k_rollout_policy16(KCfg K, DevState D, Po
   __shared__ float live_lds[TM];
   rollout_policy16_body<FLAT, BF16, KNEE, PLAIN, false>(K, D, P, n_steps, act_scale, obs, RecOut{}, bufA, bufB, part, nullptr, act_lds, obs_lds, lds_par, live_lds);
 }
+
+// ---- closed loop, precision 0, the 16-lane mapping: ONE WAVE per workgroup, the policy tile per wave (policy_core.h: wave_layer).
+// A wave runs the actor for its own 4 robots on v_mfma_f32_4x4x1_16B_f32 and then their control step; nothing is shared with
+// another wave, so there is no workgroup barrier anywhere in the loop (the __syncthreads() below are the LDS hand-overs between
+// the lanes of this one wave: a wait, not a rendezvous).  REC: the recording variant (RecOut; see rollout_policy16_body).
+template <bool FLAT, bool KNEE, bool PLAIN, bool REC>
+__device__ __forceinline__ void rollout_policy16w_body(const KCfg& K, const DevState& D, const PolicyW& P, int n_steps, float act_scale,
+                                                       float* obs, const RecOut& R, float* lds_par, float* obs4, float* abuf, float* hA,
+                                                       float* hB, float* part, float (*act4)[16], float* live4, float* park) {
+  using namespace pol;
+  const int lane0 = threadIdx.x;
+  int lane = lane0;
+  const int blk = xcd_contiguous_block();             // 4 robots; the host guarantees N % 4 == 0
+  GpuCtx16W<FLAT, KNEE, PLAIN> c;
+  make_ctx16_fields(K, D, c, lds_par, blk, lane);
+  for (int k = 0; k < PR_N; k++) lds_par[k * 64 + lane] = D.par[(size_t)k * c.NL + c.col];   // the lane's whole parameter column
+  State16<float> L = load_state16<float>(c, D.base, D.leg);
+  StepCtl16<float> S = load_ctl16<float>(c, K, D.ctl, D.ictl, D.legctl);
+  V3<float> fext = {0.0f, 0.0f, 0.0f};
+  if (!PLAIN && K.ext_force) fext = load_fext16<float>(c, D.ctl);
+  park16(park + lane0, L, S);
+  float alive = S.alive;                              // (the one control variable the loop itself looks at)
+  const size_t row0 = (size_t)blk * 4;
+  for (int idx = lane; idx < 4 * ETG_OBS_DIM; idx += 64) obs4[idx] = obs[row0 * ETG_OBS_DIM + idx];
+  if (lane < 4) live4[lane] = 1.0f;
+  c.row_base = (int)row0;                             // the step code addresses observation rows by robot index
+  const bool skip = K.stop_at_done != 0;
+  float reward, done;
+  int s_at = 0;
+#ifdef ETG_PROFILE_TILE   // debugging build: cycles in the policy tile / in the control step / sweeps, per wave (written over the wave's first obs row)
+  long long pt_tile = 0, pt_step = 0, pt_t = clock64();
+#endif
+  for (int s = 0; s < n_steps; s++, s_at = s) {
+    if (skip && !c.any(alive > 0.5f)) break;          // every robot of the wave has finished: the wave is done (nobody waits for it)
+    // (the lane index through an empty asm: what the tile derives from it -- LDS offsets, row addresses -- is formed here, per
+    // step, instead of being kept in registers from the kernel's head through the ticks)
+    lane = lane0;
+    asm volatile("" : "+v"(lane));
+    const int rob = lane >> 4;                        // this lane's robot in the physics mapping
+    float* pk = park + lane;
+    __syncthreads();
+    if (K.noise_on && s > 0) {   // sensor noise on the rows the previous step wrote (the last step's: the launch's epilogue)
+      if (live4[rob] > 0.5f) add_sensor_noise(K, (unsigned)(row0 + rob), K.noise_call + s - 1, lane & 15, &obs4[rob * ETG_OBS_DIM]);
+      __syncthreads();
+    }
+    WaveRing ring;
+    wave_ring_start(ring, P.w1, lane);                // the first k-groups of layer 1 arrive while the rows are staged
+    // the actor's rows, zero padded to WS columns; REC: the rows it acts on
+    for (int idx = lane; idx < 4 * WS; idx += 64) {
+      const int r = idx / WS, col = idx - r * WS;
+      abuf[idx] = col < P.in_dim ? obs4[r * ETG_OBS_DIM + P.col0 + col] : 0.0f;
+    }
+    if (REC)
+      for (int idx = lane; idx < 4 * ETG_OBS_DIM; idx += 64) R.obs[((size_t)s * K.n_env + row0) * ETG_OBS_DIM + idx] = obs4[idx];
+    __syncthreads();
+    HeadW hw;
+    wave_hidden12(abuf, hA, hB, ring, P.w1, P.b1, P.b2, hw, P.w3, lane);
+    f32x4 mean = wave_head(hB, hw, part, lane);
+    f32x4 lstd = {0.f, 0.f, 0.f, 0.f};
+    if (REC && R.noise) {
+      head_fetch(hw, R.w3s, lane);
+      lstd = wave_head(hB, hw, part, lane);
+    }
+    if (lane < 12) {                                  // lane = output neuron (the actor has 12: ETG_ACT_DIM)
+      const float b3 = lane < P.out_dim ? P.b3[lane] : 0.0f;
+      const float b3s = (REC && R.noise && lane < ETG_ACT_DIM) ? R.b3s[lane] : 0.0f;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        float v = mean[i] + b3;
+        if (REC && R.noise && lane < ETG_ACT_DIM) {
+          const float ls = fminf(fmaxf(lstd[i] + b3s, -20.0f), 2.0f);
+          v = v + expf(ls) * R.noise[((size_t)s * K.n_env + row0 + i) * ETG_ACT_DIM + lane];
+        }
+        const float t = tanhf(v);
+        act4[i][lane] = t * act_scale;
+        if (REC && lane < ETG_ACT_DIM) R.act[((size_t)s * K.n_env + row0 + i) * ETG_ACT_DIM + lane] = t;   // the UNSCALED action (train.py:159)
+      }
+    }
+    __syncthreads();
+    const float action = c.sub < 3 ? act4[rob][3 * c.leg + c.sub] : 0.0f;
+#ifdef ETG_PROFILE_TILE
+    { const long long t = clock64(); pt_tile += t - pt_t; pt_t = t; }
+#endif
+    // the robot state, the control variables and the tick constants come back from LDS for the step and go back after it: none
+    // of them occupies a register during the tile
+    c.launder_lane();
+    unpark16(pk, L, S);
+    S.alive = alive;
+    TickPar<float> tp = load_tick_par<float>(c);
+    tp.fext = fext;
+    const float was_alive = alive;
+    control_step16_core(c, K, tp, L, S, D.ring, D.etgp, action, 0.0f, obs4, reward, done, (float*)nullptr, (const float*)nullptr, true,
+                        (float*)nullptr, (float*)nullptr, skip);
+    if (skip) rollout_dead_store16(c, K, L, was_alive, done, s == n_steps - 1, false, (int)K.noise_call + s, D.base, D.leg, D.ictl);
+    alive = S.alive;
+    park16(pk, L, S);
+#ifdef ETG_PROFILE_TILE
+    { const long long t = clock64(); pt_step += t - pt_t; pt_t = t; }
+#endif
+    if (c.r == 0) live4[rob] = skip ? was_alive : 1.0f;   // did this step write the robot's row?
+    if (REC && c.r == 0) {
+      R.rew[(size_t)s * K.n_env + c.env] = reward;
+      R.done[(size_t)s * K.n_env + c.env] = done > 0.5f ? 1 : 0;
+    }
+  }
+  if (REC && c.r == 0)   // the wave left the loop early: the remaining steps read reward 0 / done 1 (their obs / action rows stay unwritten)
+    for (int s2 = s_at; s2 < n_steps; s2++) {
+      R.rew[(size_t)s2 * K.n_env + c.env] = 0.0f;
+      R.done[(size_t)s2 * K.n_env + c.env] = 1;
+    }
+  c.launder_lane();
+  unpark16(park + lane0, L, S);
+  S.alive = alive;
+  store_ctl16(c, K, S, D.ctl, D.ictl, D.legctl);
+  rollout_store16(c, K, L, S.alive, D.base, D.leg);
+  __syncthreads();
+  for (int idx = lane0; idx < 4 * ETG_OBS_DIM; idx += 64) obs[row0 * ETG_OBS_DIM + idx] = obs4[idx];
+#ifdef ETG_PROFILE_TILE
+  __syncthreads();
+  if (lane0 == 0) { obs[row0 * ETG_OBS_DIM + 0] = (float)pt_tile; obs[row0 * ETG_OBS_DIM + 1] = (float)pt_step; obs[row0 * ETG_OBS_DIM + 2] = (float)s_at; }
+#endif
+}
+
+#define ETG_POLICY16W_LDS                                                                    \
+  __shared__ float lds_par[LDS16_FIELDS * BLOCK];                                            \
+  __shared__ __attribute__((aligned(16))) float obs4[4 * ETG_OBS_DIM];                       \
+  __shared__ __attribute__((aligned(16))) float abuf[4 * pol::WS];                           \
+  __shared__ __attribute__((aligned(16))) float hA[4 * pol::HS];                             \
+  __shared__ __attribute__((aligned(16))) float hB[4 * pol::HS];                             \
+  __shared__ __attribute__((aligned(16))) float part[64 * 4];                                \
+  __shared__ float park[PARK16 * BLOCK];                                                     \
+  __shared__ float act4[4][16];                                                              \
+  __shared__ float live4[4];
+template <bool FLAT, bool KNEE, bool PLAIN>
+__global__ void __launch_bounds__(BLOCK) k_rollout_policy16w(KCfg K, DevState D, PolicyW P, int n_steps, float act_scale, float* obs) {
+  ETG_POLICY16W_LDS
+  rollout_policy16w_body<FLAT, KNEE, PLAIN, false>(K, D, P, n_steps, act_scale, obs, RecOut{}, lds_par, obs4, abuf, hA, hB, part, act4, live4, park);
+}
+template <bool FLAT, bool KNEE, bool PLAIN>
+__global__ void __launch_bounds__(BLOCK) k_rollout_policy16w_rec(KCfg K, DevState D, PolicyW P, int n_steps, float act_scale, float* obs, RecOut R) {
+  ETG_POLICY16W_LDS
+  rollout_policy16w_body<FLAT, KNEE, PLAIN, true>(K, D, P, n_steps, act_scale, obs, R, lds_par, obs4, abuf, hA, hB, part, act4, live4, park);
+}
+#undef ETG_POLICY16W_LDS
 
 // Closed loop on the 4-lanes-per-robot mapping (the mapping of every batch above 4096 robots): a workgroup of 4 waves owns
 // 64 robots (16 per wave, one leg per lane).  The policy runs over TWO stacked 16-row tiles at a time (hidden_layer_rt): every
@@ -1673,6 +1877,8 @@ ETG_INST16(k_step16, 6, 7, 1, 2, 3, 4, ETG_ARGS_STEP)
 ETG_INST16(k_step16_ar, 5, 6, 7, 1, 2, 3, ETG_ARGS_STEP_AR)
 ETG_INST16(k_rollout16, 4, 5, 6, 7, 1, 2, ETG_ARGS_ROLLOUT)
 ETG_INST16(k_rollout_actions16, 3, 4, 5, 6, 7, 1, ETG_ARGS_TAPE)
+ETG_INST16(k_rollout_policy16w, 2, 4, 6, 1, 3, 5, ETG_ARGS_POLICY)
+ETG_INST16(k_rollout_policy16w_rec, 7, 2, 4, 6, 1, 3, ETG_ARGS_POLICY_REC)
 ETG_INSTP16(k_rollout_policy16, false, 2, 3, 4, 5, 6, 7, ETG_ARGS_POLICY)
 ETG_INSTP16(k_rollout_policy16, true, 1, 2, 3, 4, 5, 6, ETG_ARGS_POLICY)
 ETG_INSTP16(k_rollout_policy16_rec, false, 7, 1, 2, 3, 4, 5, ETG_ARGS_POLICY_REC)
@@ -1707,6 +1913,10 @@ struct EtgHandle {
   bool fext_set, push_on;         // a set force / random pushes are installed: K.ext_force = fext_set || push_on
   bool all_cached;                // every robot has a valid cached settle (true after a full etg_reset until parameters,
                                   // terrain or -- on a heightfield -- start offsets change): etg_step_autoreset's fast path
+  // etg_rollout_wave_cycles: [launches of the last open-loop rollout][wavefronts] shader-clock cycles, written by the launches
+  long long* wave_cycles;
+  int wc_cap, wc_launches, wc_waves;
+  int rollout_chunk;            // control steps per fused launch (50; ETG_ROLLOUT_CHUNK overrides it: a measurement aid)
   float *tmp_obs, *tmp_reward;  // sinks for etg_rollout_openloop
   uint8_t* tmp_done;
   // etg_prepare_next_dynamics: rows waiting for the robots' next episodes + the scratch state / ring / flags its settle runs on
@@ -1797,6 +2007,13 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   h->nx_base = h->nx_leg = h->nx_ring = nullptr;
   h->nx_cache_ok = nullptr;
   h->nx_mask = nullptr;
+  h->wave_cycles = nullptr;
+  h->wc_cap = h->wc_launches = h->wc_waves = 0;
+  h->rollout_chunk = 50;
+  if (const char* e = getenv("ETG_ROLLOUT_CHUNK")) {
+    const int v = atoi(e);
+    if (v >= 1 && v <= 100000) h->rollout_chunk = v;
+  }
   // 0 = auto.  Both kernels hold one wave per SIMD (register footprint), so the chip runs 1024 waves
   // at a time: 16 lanes/robot fills it with 4096 robots and is faster per robot up to there; beyond
   // that the 4-lanes/robot kernel packs 4x the robots per wave (measured crossover).
@@ -1843,7 +2060,7 @@ extern "C" void etg_destroy(EtgHandle* h) {
   (void)hipSetDevice(h->device);
   void* ptrs[] = {h->D.base, h->D.leg, h->D.ctl, h->D.ictl, h->D.legctl, h->D.etgp, h->D.par, h->D.ring, h->hf, h->D.dyn,
                   h->D.cache_base, h->D.cache_leg, h->D.cache_ring, h->D.cache_ok, h->D.reset_off, h->D.cache_off,
-                  h->tmp_obs, h->tmp_reward, h->tmp_done, h->NX.par, h->NX.dyn, h->NX.ok, h->nx_base, h->nx_leg, h->nx_ring, h->nx_cache_ok, h->nx_mask};
+                  h->tmp_obs, h->tmp_reward, h->tmp_done, h->wave_cycles, h->NX.par, h->NX.dyn, h->NX.ok, h->nx_base, h->nx_leg, h->nx_ring, h->nx_cache_ok, h->nx_mask};
   for (void* p : ptrs)
     if (p) (void)hipFree(p);
   if (h->cached_report) (void)hipHostFree((void*)h->cached_report);
@@ -2199,6 +2416,18 @@ extern "C" int etg_step_autoreset(EtgHandle* h, const float* action, const uint8
 #ifdef ETG_TRACE_TICKS
 extern "C" int etg_debug_set_trace(EtgHandle* h, float* buf) { if (!h) return ETG_ERR_BAD_ARG; h->K.trace = buf; return ETG_OK; }
 #endif
+extern "C" int etg_rollout_wave_cycles(EtgHandle* h, int64_t* cycles, int capacity, int* launches, int* waves, void* stream) {
+  CHECK_HANDLE(h);
+  if (!launches || !waves) return fail(ETG_ERR_BAD_ARG, "etg_rollout_wave_cycles: launches / waves are null");
+  *launches = h->wc_launches;
+  *waves = h->wc_waves;
+  if (!cycles) return ETG_OK;      // the size query
+  if (capacity < h->wc_launches * h->wc_waves) return fail(ETG_ERR_BAD_ARG, "etg_rollout_wave_cycles: the buffer is too small");
+  if (h->wc_launches > 0)
+    HIP_TRY(hipMemcpyAsync(cycles, h->wave_cycles, (size_t)h->wc_launches * h->wc_waves * sizeof(long long), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return ETG_OK;
+}
+
 extern "C" int etg_set_rollout_mode(EtgHandle* h, int simulate_finished) {
   CHECK_HANDLE(h);
   h->K.stop_at_done = simulate_finished ? 0 : 1;
@@ -2221,16 +2450,28 @@ extern "C" int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float
   if (n_steps <= 0 || !ret || !len) return fail(ETG_ERR_BAD_ARG, "etg_rollout_openloop: bad arguments");
   if (!h->was_reset) return fail(ETG_ERR_STATE, "etg_rollout_openloop: call etg_reset first");
   if (h->K.motor_mode != 2) {
-    // fused: up to ROLLOUT_CHUNK control steps per launch, everything in registers in between
-    constexpr int ROLLOUT_CHUNK = 50;
+    // fused: up to rollout_chunk control steps per launch, everything in registers in between
+    const int ROLLOUT_CHUNK = h->rollout_chunk;
     const dim3 g16((h->N + 3) / 4), g4(grid_for(h));
     hipStream_t s = (hipStream_t)stream;
-    for (int done_steps = 0; done_steps < n_steps; done_steps += ROLLOUT_CHUNK) {
+    // per-wave cycle counters of this call's launches (etg_rollout_wave_cycles): one 8-byte store per wave and launch
+    const int n_launch = (n_steps + ROLLOUT_CHUNK - 1) / ROLLOUT_CHUNK, n_waves = (int)(h->lanes == 16 ? g16.x : g4.x);
+    if (h->wc_cap < n_launch * n_waves) {
+      if (h->wave_cycles) (void)hipFree(h->wave_cycles);
+      h->wave_cycles = nullptr;
+      h->wc_cap = 0;
+      if (hipMalloc((void**)&h->wave_cycles, (size_t)n_launch * n_waves * sizeof(long long)) == hipSuccess) h->wc_cap = n_launch * n_waves;
+    }
+    h->wc_launches = h->wave_cycles ? n_launch : 0;
+    h->wc_waves = n_waves;
+    int launch = 0;
+    for (int done_steps = 0; done_steps < n_steps; done_steps += ROLLOUT_CHUNK, launch++) {
       const int m = n_steps - done_steps < ROLLOUT_CHUNK ? n_steps - done_steps : ROLLOUT_CHUNK;
       const bool last = done_steps + m == n_steps;
       // stop_at_done: a robot's last row is written by the launch its episode ends in -- every launch writes to the caller's rows
       float* o = (obs && (last || h->K.stop_at_done)) ? obs : h->tmp_obs;
-      const StatOut so = last ? StatOut{ret, (int*)len} : StatOut{nullptr, nullptr};
+      long long* cyc = h->wave_cycles ? h->wave_cycles + (size_t)launch * n_waves : nullptr;
+      const StatOut so = last ? StatOut{ret, (int*)len, cyc} : StatOut{nullptr, nullptr, cyc};
       advance_obs_stream(h, m);
       if (h->lanes == 16) {
         LAUNCH16(k_rollout16, g16, s, h->K, h->D, m, o, so);
@@ -2259,7 +2500,7 @@ extern "C" int etg_rollout_actions(EtgHandle* h, const float* actions, int n_ste
   if (!h->was_reset) return fail(ETG_ERR_STATE, "etg_rollout_actions: call etg_reset first");
   if (h->K.motor_mode == 2) return fail(ETG_ERR_STATE, "etg_rollout_actions: POSITION / TORQUE commands only ([n_steps,N,12] tapes)");
   if (h->K.noise_on && rec_obs) return fail(ETG_ERR_STATE, "etg_rollout_actions: per-step observations are recorded without sensor noise; switch it off");
-  constexpr int ROLLOUT_CHUNK = 50;
+  const int ROLLOUT_CHUNK = h->rollout_chunk;
   const dim3 g16((h->N + 3) / 4), g4(grid_for(h));
   hipStream_t s = (hipStream_t)stream;
   const size_t N = h->N;
@@ -2300,7 +2541,7 @@ extern "C" int etg_rollout_policy(EtgHandle* h, EtgPolicy* pol, int n_steps, flo
   const bool bf = precision != 0;   // the bf16 kernels read the bf16 fragments packed at load time
   PolicyW P = {(const float4*)(bf ? pol->w1h : pol->w1), (const float4*)(bf ? pol->w2h : pol->w2), (const float4*)(bf ? pol->w3h : pol->w3), pol->b1, pol->b2, pol->b3,
                pol->in_dim, pol->out_dim, obs_col0};
-  constexpr int ROLLOUT_CHUNK = 50;
+  const int ROLLOUT_CHUNK = h->rollout_chunk;
   const dim3 g(h->N / 16), b(256);
   hipStream_t s = (hipStream_t)stream;
   const bool flat = h->K.terrain == 0;
@@ -2330,12 +2571,17 @@ extern "C" int etg_rollout_policy(EtgHandle* h, EtgPolicy* pol, int n_steps, flo
     if (ret || len) return etg_episode_stats(h, ret, len, stream);
     return ETG_OK;
   }
+  // precision 0: one wave per workgroup, the policy tile per wave (k_rollout_policy16w: no workgroup barrier); precision 1 (bf16
+  // operands, an opt-in arithmetic): the 16-robot tile of 4 waves (k_rollout_policy16)
+  const bool per_wave = precision == 0 && pol->in_dim <= 4 * pol::KQ1 && pol->out_dim <= 12;
+  const PolicyW Pq = {(const float4*)pol->w12q, nullptr, (const float4*)pol->w3q, pol->b1, pol->b2, pol->b3, pol->in_dim, pol->out_dim, obs_col0};
   for (int done_steps = 0; done_steps < n_steps; done_steps += ROLLOUT_CHUNK) {
     const int m = n_steps - done_steps < ROLLOUT_CHUNK ? n_steps - done_steps : ROLLOUT_CHUNK;
     advance_obs_stream(h, m);
 #define LAUNCH_POLICY16(F_, K_, P_)                                                                                   \
   do {                                                                                                                \
-    if (precision == 0) hipLaunchKernelGGL((k_rollout_policy16<F_, false, K_, P_>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs); \
+    if (per_wave) hipLaunchKernelGGL((k_rollout_policy16w<F_, K_, P_>), dim3(h->N / 4), dim3(BLOCK), 0, s, h->K, h->D, Pq, m, act_scale, obs); \
+    else if (precision == 0) hipLaunchKernelGGL((k_rollout_policy16<F_, false, K_, P_>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs); \
     else hipLaunchKernelGGL((k_rollout_policy16<F_, true, K_, P_>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs);    \
   } while (0)
     DISPATCH16(LAUNCH_POLICY16);
@@ -2363,7 +2609,7 @@ extern "C" int etg_rollout_policy_record(EtgHandle* h, EtgPolicy* pol, int n_ste
   const bool bf = precision != 0;   // the bf16 kernels read the bf16 fragments packed at load time
   PolicyW P = {(const float4*)(bf ? pol->w1h : pol->w1), (const float4*)(bf ? pol->w2h : pol->w2), (const float4*)(bf ? pol->w3h : pol->w3), pol->b1, pol->b2, pol->b3,
                pol->in_dim, pol->out_dim, obs_col0};
-  constexpr int ROLLOUT_CHUNK = 50;
+  const int ROLLOUT_CHUNK = h->rollout_chunk;
   const dim3 g(h->N / 16), b(256);
   hipStream_t s = (hipStream_t)stream;
   const bool flat = h->K.terrain == 0;
@@ -2372,12 +2618,16 @@ extern "C" int etg_rollout_policy_record(EtgHandle* h, EtgPolicy* pol, int n_ste
     const int m = n_steps - done_steps < ROLLOUT_CHUNK ? n_steps - done_steps : ROLLOUT_CHUNK;
     advance_obs_stream(h, m);
     const bool kn = h->K.knee != 0, pl = plain_config(h->K);
+    const bool per_wave = precision == 0 && pol->in_dim <= 4 * pol::KQ1 && pol->out_dim <= 12;
     const RecOut R = {rec_obs + (size_t)done_steps * N * ETG_OBS_DIM, rec_act + (size_t)done_steps * N * ETG_ACT_DIM,
                       rec_reward + (size_t)done_steps * N, rec_done + (size_t)done_steps * N,
-                      noise ? noise + (size_t)done_steps * N * ETG_ACT_DIM : nullptr, (const float4*)(bf ? pol->w3sh : pol->w3s), pol->b3s};
+                      noise ? noise + (size_t)done_steps * N * ETG_ACT_DIM : nullptr,
+                      (const float4*)(per_wave ? pol->w3sq : (bf ? pol->w3sh : pol->w3s)), pol->b3s};
+    const PolicyW Pq = {(const float4*)pol->w12q, nullptr, (const float4*)pol->w3q, pol->b1, pol->b2, pol->b3, pol->in_dim, pol->out_dim, obs_col0};
 #define LAUNCH_POLICY16R(F_, K_, P_)                                                                                  \
   do {                                                                                                                \
-    if (precision == 0) hipLaunchKernelGGL((k_rollout_policy16_rec<F_, false, K_, P_>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs, R); \
+    if (per_wave) hipLaunchKernelGGL((k_rollout_policy16w_rec<F_, K_, P_>), dim3(h->N / 4), dim3(BLOCK), 0, s, h->K, h->D, Pq, m, act_scale, obs, R); \
+    else if (precision == 0) hipLaunchKernelGGL((k_rollout_policy16_rec<F_, false, K_, P_>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs, R); \
     else hipLaunchKernelGGL((k_rollout_policy16_rec<F_, true, K_, P_>), g, b, 0, s, h->K, h->D, P, m, act_scale, obs, R);    \
   } while (0)
     DISPATCH16(LAUNCH_POLICY16R);

@@ -323,6 +323,130 @@ __device__ __forceinline__ void output_partial(const float* bufA, const float4* 
   for (int r = 0; r < 4; r++) part[wave][4 * g + r][i] = acc[r];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The policy tile of ONE wave (closed-loop kernels of the 16-lane mapping, precision 0): the whole MLP for the wave's 4 robots
+// on v_mfma_f32_4x4x1_16B_f32.  That instruction computes 16 independent 4 x 4 outer products per wave64 -- block b = lanes
+// 4b .. 4b+3, D_b[i][j] += A[lane 4b+i] * B[lane 4b+j], D held at lane 4b+j / register i (layout verified on the hardware:
+// tools/ubench/mfma4x4.hip).  Mapping: i = ROBOT of the wave (A at lane l = activation of robot l & 3: the same in every block),
+// j = NEURON (B at lane l = weight of neuron 64 * chunk + l): one instruction = 4 robots x 64 neurons x one input, fp32 products
+// accumulated in fp32, the matrix rate of v_mfma_f32_16x16x4_f32 with all four "rows" used.  Nothing is shared with another
+// wave, so the closed loop has no workgroup barrier: a wave waits for its own 4 robots only (the 16-robot tile of rounds 1-5
+// made 16 robots wait for the slowest at 5 barriers per control step: +32 us at 4096 robots).
+// Price: every wave streams ALL the weights (325 KB fp32) from L2 per control step instead of a quarter of them; they are packed
+// so that a wave's fetch is one coalesced 1-KiB global_load_dwordx4 (k_pack_wave12) and kept WR - 1 k-groups ahead in a register
+// ring (wave_hidden12).
+constexpr int WS = 68;       // row stride (floats) of the wave's padded observation rows: in_dim <= 64 columns in 16 float4 groups
+                             // (68 = 4 mod 32: the four robots' rows start 4 banks apart, a 16-byte read of each is conflict-free)
+constexpr int KQ1 = 16;      // k-groups (float4) of layer 1
+constexpr int KQ2 = HID / 4; // k-groups of layer 2
+constexpr int KQH = HID / 16;// k-groups of the head PER SLICE: the head splits K over 4 slices (wave_head)
+constexpr int WR = 16; // ring slots of a hidden layer's weight stream: WR - 1 k-groups (x 4 chunks x 1 KiB) in flight
+
+constexpr int NCHW = HID / 64;          // chunks of 64 neurons in a hidden layer
+constexpr int KG = KQ1 + KQ2;           // k-groups of the two hidden layers, streamed as ONE sequence (k_pack_wave12)
+
+// The two hidden layers of the wave tile.  Their weights are ONE stream of KG groups of NCHW x 1 KiB -- the 16 groups of layer
+// 1, then the 64 of layer 2 (k_pack_wave12: wq[(g * NCHW + c) * 64 + lane] = W[64 c + lane][4 k .. 4 k + 3]) -- kept WR - 1 groups
+// ahead in a register ring that never drains between the layers: the L2 latency of a layer's first groups is hidden behind the
+// layer before it (and layer 1's behind the staging of the observation rows: wave_ring_start is called before it).  The k
+// loop is ROLLED in blocks of WR groups (static ring indices inside a block); KQ1 is a multiple of WR, so the hand-over between
+// the layers -- bias, relu, the activations through LDS into the other operand's layout -- falls between two blocks.
+struct WaveRing { float4 w[WR][NCHW]; };
+__device__ __forceinline__ void wave_ring_start(WaveRing& r, const float4* __restrict__ wq, int lane) {
+#pragma unroll
+  for (int p = 0; p < WR - 1; p++)
+#pragma unroll
+    for (int c = 0; c < NCHW; c++) r.w[p][c] = wq[(p * NCHW + c) * 64 + lane];
+}
+struct HeadW { float4 w[KQH]; };         // the output head's weights of this lane (wave_head below)
+__device__ __forceinline__ void head_fetch(HeadW& h, const float4* __restrict__ wq, int lane) {
+#pragma unroll
+  for (int kq = 0; kq < KQH; kq++) h.w[kq] = wq[kq * 64 + lane];
+}
+// abuf: the 4 observation rows (stride WS); hA / hB: the activations of layers 1 / 2 (rows of HS floats); hw / wh: the head's
+// weights, fetched while layer 2 runs
+__device__ __forceinline__ void wave_hidden12(const float* abuf, float* hA, float* hB, WaveRing& ring, const float4* __restrict__ wq,
+                                              const float* __restrict__ b1, const float* __restrict__ b2, HeadW& hw,
+                                              const float4* __restrict__ wh, int lane) {
+  static_assert(KQ1 % WR == 0 && KQ2 % WR == 0, "the layers' k-groups come in whole blocks of the ring");
+  f32x4 acc[NCHW];
+#pragma unroll
+  for (int c = 0; c < NCHW; c++) acc[c] = {0.f, 0.f, 0.f, 0.f};
+  const float* row = abuf + (lane & 3) * WS;
+  float4 a_next = *reinterpret_cast<const float4*>(row);
+  const float4* base = wq + lane;
+  auto epilogue = [&](const float* __restrict__ b, float* out) {
+#pragma unroll
+    for (int c = 0; c < NCHW; c++) {
+      const float bias = b[64 * c + lane];
+#pragma unroll
+      for (int i = 0; i < 4; i++) out[i * HS + 64 * c + lane] = fmaxf(acc[c][i] + bias, 0.0f);
+      acc[c] = {0.f, 0.f, 0.f, 0.f};
+    }
+    __syncthreads();                      // (one wave per workgroup: a wait for its own LDS writes)
+  };
+#pragma unroll 1
+  for (int kb = 0; kb < KG; kb += WR) {
+    if (kb == KQ1) {                      // layer 1 is complete: its activations become layer 2's input rows
+      epilogue(b1, hA);
+      row = hA + (lane & 3) * HS - 4 * KQ1;   // (so that row + 4 g addresses column 4 (g - KQ1))
+      a_next = *reinterpret_cast<const float4*>(row + 4 * kb);
+    }
+    if (kb == KQ1 + KQ2 / 2) head_fetch(hw, wh, lane);
+#pragma unroll
+    for (int j = 0; j < WR; j++) {
+      const int g = kb + j;
+      const float4 a = a_next;
+      a_next = *reinterpret_cast<const float4*>(row + 4 * (g + 1));       // (one group past a layer's end: inside the row's padding)
+      const int gl = g + (WR - 1) < KG ? g + (WR - 1) : KG - 1;           // (past the end: the last group again, unused)
+#pragma unroll
+      for (int c = 0; c < NCHW; c++) ring.w[(j + WR - 1) % WR][c] = base[(gl * NCHW + c) * 64];
+      __builtin_amdgcn_sched_barrier(0);   // keep the fetches WR - 1 groups ahead (the scheduler otherwise sinks them to their use)
+      const float4* w = ring.w[j];
+      // input outer, chunk inner: NCHW independent accumulators back to back
+#pragma unroll
+      for (int c = 0; c < NCHW; c++) acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, w[c].x, acc[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < NCHW; c++) acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, w[c].y, acc[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < NCHW; c++) acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, w[c].z, acc[c], 0, 0, 0);
+#pragma unroll
+      for (int c = 0; c < NCHW; c++) acc[c] = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, w[c].w, acc[c], 0, 0, 0);
+    }
+  }
+  epilogue(b2, hB);
+}
+
+// The output head (<= 12 neurons): 3 blocks of 4 neurons, K = 256 split over 4 SLICES of 64 -- block b = 3 * slice + nb of the
+// instruction works on neurons 4 nb .. 4 nb + 3 and inputs 64 slice .. 64 slice + 63 (blocks 12..15 idle): 64 instructions and
+// 16 KiB of weights instead of 256 and 64 KiB for a whole chunk of 64 lanes with 12 live ones.  k_pack_head lays the weights
+// out accordingly: wq[kq * 64 + lane] = W[4 nb + j][64 slice + 4 kq ..], lane = 4 (3 slice + nb) + j.  The fetch is started
+// by head_fetch (before the layer in front of it: nothing of it is exposed) and consumed by wave_head; the four slices'
+// partial sums meet in LDS (part: [64 lanes][4 robots]): lane n < 12 returns neuron n's pre-activations of the 4 robots.
+__device__ __forceinline__ f32x4 wave_head(const float* in, const HeadW& h, float* part, int lane) {
+  const int blk = lane >> 2, slice = blk / 3;           // (blocks 12..15: slice 4 -- their weights are zeros, their rows clamped)
+  const float* row = in + (lane & 3) * HS + 64 * (slice < 4 ? slice : 3);
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int kq = 0; kq < KQH; kq++) {
+    const float4 a = *reinterpret_cast<const float4*>(row + 4 * kq);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a.x, h.w[kq].x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a.y, h.w[kq].y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a.z, h.w[kq].z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_4x4x1f32(a.w, h.w[kq].w, acc, 0, 0, 0);
+  }
+  *reinterpret_cast<f32x4*>(part + 4 * lane) = acc;
+  __syncthreads();                                      // (one wave per workgroup: a wait for its own LDS writes)
+  f32x4 out = {0.f, 0.f, 0.f, 0.f};
+  if (lane < 12) {
+    const f32x4 p0 = *reinterpret_cast<const f32x4*>(part + 4 * lane), p1 = *reinterpret_cast<const f32x4*>(part + 4 * (lane + 12));
+    const f32x4 p2 = *reinterpret_cast<const f32x4*>(part + 4 * (lane + 24)), p3 = *reinterpret_cast<const f32x4*>(part + 4 * (lane + 36));
+    out = (p0 + p1) + (p2 + p3);
+  }
+  __syncthreads();
+  return out;
+}
+
 }  // namespace pol
 
 // the policy handle (C-ABI EtgPolicy of include/etgsim.h)
@@ -332,4 +456,5 @@ struct EtgPolicy {
   float *w3s, *b3s;                    // log-std head (etg_policy_load_std), packed like w3
   int has_std;
   float *w1h, *w2h, *w3h, *w3sh;       // the bf16 fragments (k_pack_bf16) behind precision = 1: half the size, no per-use conversion
+  float *w12q, *w3q, *w3sq;            // the per-wave tile's packing (k_pack_wave12 / k_pack_head; pol::wave_hidden12, wave_head), fp32
 };

@@ -44,6 +44,32 @@ __global__ void k_pack_weights(const float* __restrict__ w, int nout, int kdim, 
   out[idx] = (n < nout && k < kdim) ? w[(size_t)n * kdim + k] : 0.0f;
 }
 
+// the per-wave tile's packing of the two hidden layers as ONE stream of k-groups (policy_core.h: wave_hidden12):
+//   out[((g * NCHW + chunk) * 64 + lane) * 4 + c] = W[64 chunk + lane][4 k + c],  W = W1, k = g for g < KQ1;  W = W2, k = g - KQ1 after
+// (zero outside the matrices): a wave's fetch of one k-group is four coalesced 1-KiB loads at consecutive addresses
+__global__ void k_pack_wave12(const float* __restrict__ w1, int in_dim, const float* __restrict__ w2, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= pol::KG * pol::NCHW * 256) return;
+  const int c = idx & 3, lane = (idx >> 2) & 63, blk = idx >> 8;
+  const int chunk = blk % pol::NCHW, g = blk / pol::NCHW;
+  const int n = 64 * chunk + lane;
+  float v;
+  if (g < pol::KQ1) { const int k = 4 * g + c; v = k < in_dim ? w1[(size_t)n * in_dim + k] : 0.0f; }
+  else { const int k = 4 * (g - pol::KQ1) + c; v = w2[(size_t)n * pol::HID + k]; }
+  out[idx] = v;
+}
+
+// the per-wave head's packing (policy_core.h: wave_head): out[(kq * 64 + lane) * 4 + c] = W[4 nb + j][64 slice + 4 kq + c] with
+// lane = 4 (3 slice + nb) + j, nb < 3, slice < 4; zeros on lanes 48..63 and for neurons >= nout
+__global__ void k_pack_head(const float* __restrict__ w, int nout, int kdim, float* __restrict__ out) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= pol::KQH * 256) return;
+  const int c = idx & 3, lane = (idx >> 2) & 63, kq = idx >> 8;
+  const int blk = lane >> 2, j = lane & 3, slice = blk / 3, nb = blk % 3;
+  const int n = 4 * nb + j, k = 64 * slice + 4 * kq + c;
+  out[idx] = (slice < 4 && n < nout && k < kdim) ? w[(size_t)n * kdim + k] : 0.0f;
+}
+
 // bf16 fragments from the fp32 ones: out[(tile * nkb / 2 + kp) * 64 + lane] = pack_bf16(in[(tile * nkb + 2 kp) * 64 + lane],
 // in[(tile * nkb + 2 kp + 1) * 64 + lane]) -- the B operand of v_mfma_f32_16x16x32_bf16 as the kernels used to build it per use
 __global__ void k_pack_bf16(const float4* __restrict__ in, int ntiles, int nkb, float4* __restrict__ out) {
@@ -145,7 +171,8 @@ extern "C" int etg_policy_create(int in_dim, int hidden, int out_dim, int device
                                          {&p->w3, packed_floats(1, HID / 16)}, {&p->b3, (size_t)out_dim},
                                          {&p->w3s, packed_floats(1, HID / 16)}, {&p->b3s, (size_t)out_dim},
                                          {&p->w1h, packed_floats(HID / 16, 4) / 2}, {&p->w2h, packed_floats(HID / 16, HID / 16) / 2},
-                                         {&p->w3h, packed_floats(1, HID / 16) / 2}, {&p->w3sh, packed_floats(1, HID / 16) / 2}};
+                                         {&p->w3h, packed_floats(1, HID / 16) / 2}, {&p->w3sh, packed_floats(1, HID / 16) / 2},
+                                         {&p->w12q, (size_t)KG * NCHW * 256}, {&p->w3q, (size_t)KQH * 256}, {&p->w3sq, (size_t)KQH * 256}};
   p->has_std = 0;
   for (auto& x : a)
     if (hipMalloc((void**)x.q, x.n * 4) != hipSuccess) return pfail(ETG_ERR_ALLOC, "etg_policy_create: hipMalloc failed");
@@ -168,6 +195,10 @@ extern "C" int etg_policy_load(EtgPolicy* p, const float* w1, const float* b1, c
     const int th = x.ntiles * (x.nkb / 2) * 64;
     hipLaunchKernelGGL(k_pack_bf16, dim3((th + 255) / 256), dim3(256), 0, s, (const float4*)x.d, x.ntiles, x.nkb, (float4*)x.dh);
   }
+  // the per-wave tile's packing (closed-loop kernels, precision 0; observation rows of up to pol::WS columns)
+  if (p->in_dim <= 4 * KQ1)
+    hipLaunchKernelGGL(k_pack_wave12, dim3(KG * NCHW), dim3(256), 0, s, w1, p->in_dim, w2, p->w12q);
+  hipLaunchKernelGGL(k_pack_head, dim3(KQH), dim3(256), 0, s, w3, p->out_dim, p->hidden, p->w3q);
   struct { float* d; const float* src; size_t n; } c[] = {{p->b1, b1, (size_t)p->hidden}, {p->b2, b2, (size_t)p->hidden},
                                                          {p->b3, b3, (size_t)p->out_dim}};
   for (auto& x : c)
@@ -184,6 +215,7 @@ extern "C" int etg_policy_load_std(EtgPolicy* p, const float* w_std, const float
   const int total = (HID / 16) * 256;
   hipLaunchKernelGGL(k_pack_weights, dim3((total + 255) / 256), dim3(256), 0, s, w_std, p->out_dim, p->hidden, 1, HID / 16, p->w3s);
   hipLaunchKernelGGL(k_pack_bf16, dim3(((HID / 32) * 64 + 255) / 256), dim3(256), 0, s, (const float4*)p->w3s, 1, HID / 16, (float4*)p->w3sh);
+  hipLaunchKernelGGL(k_pack_head, dim3(KQH), dim3(256), 0, s, w_std, p->out_dim, p->hidden, p->w3sq);
   if (hipMemcpyAsync(p->b3s, b_std, (size_t)p->out_dim * 4, hipMemcpyDeviceToDevice, s) != hipSuccess)
     return pfail(ETG_ERR_HIP, "etg_policy_load_std: hipMemcpyAsync failed");
   if (hipGetLastError() != hipSuccess) return pfail(ETG_ERR_HIP, "etg_policy_load_std: pack launch failed");
@@ -231,7 +263,7 @@ extern "C" int etg_policy_sample(EtgPolicy* p, const float* obs, int n, const fl
 extern "C" void etg_policy_destroy(EtgPolicy* p) {
   if (!p) return;
   (void)hipSetDevice(p->device);
-  float* ptrs[] = {p->w1, p->b1, p->w2, p->b2, p->w3, p->b3, p->w3s, p->b3s, p->w1h, p->w2h, p->w3h, p->w3sh};
+  float* ptrs[] = {p->w1, p->b1, p->w2, p->b2, p->w3, p->b3, p->w3s, p->b3s, p->w1h, p->w2h, p->w3h, p->w3sh, p->w12q, p->w3q, p->w3sq};
   for (float* q : ptrs)
     if (q) (void)hipFree(q);
   delete p;

@@ -644,6 +644,15 @@ class BatchedQuadrupedEnv:
         _lib.check(self._lib.etg_set_rollout_mode(self._h, int(bool(simulate_finished))))
         self.simulate_finished = bool(simulate_finished)
 
+    def rollout_wave_cycles(self):
+        """shader-clock cycles of every wavefront in each launch of the last rollout_openloop: int64 [launches, waves]"""
+        nl, nw = C.c_int32(0), C.c_int32(0)
+        _lib.check(self._lib.etg_rollout_wave_cycles(self._h, None, 0, C.byref(nl), C.byref(nw), self._stream()))
+        out = torch.zeros(max(nl.value, 0), max(nw.value, 1), dtype=torch.int64, device=self.device)
+        if nl.value > 0:
+            _lib.check(self._lib.etg_rollout_wave_cycles(self._h, _ptr(out), out.numel(), C.byref(nl), C.byref(nw), self._stream()))
+        return out
+
     def rollout_openloop(self, n_steps, out=None):
         """n_steps control steps with zero residual action (pretrain.py:129-154) enqueued back to
         back; returns (episode_return[N], episode_len[N]) since the last reset, alive-masked.  out = (ret float32 [N],

@@ -131,11 +131,16 @@ def make_dynamics_id_evaluator(env, gait, mean_dict, e_steps=100, keys=("exp", "
             if fused:
                 # the commands are known in advance: one launch per 50 steps, the two info columns recorded in the kernel;
                 # configurations the fused kernel does not cover (HYBRID commands, auto_reset envs) take the stepping loop
+                # (the reference's replay runs all e_steps whatever `done` says -- Dynamic_parallel_model.py:58-64 has no break --
+                # so the tape is rolled with finished robots simulated on)
                 try:
+                    env.set_rollout_mode(simulate_finished=True)
                     _, _, rec = env.rollout_actions(acts[key], record=("joint_angle", "obs-IMU"))
                     motor, drpy = rec["joint_angle"].transpose(0, 1), rec["obs-IMU"][:, :, 3:].transpose(0, 1)
                 except FusedKernelUnavailable:
                     rec = None
+                finally:
+                    env.set_rollout_mode(simulate_finished=False)
             if rec is None:
                 if motor is None or motor.shape != (n, e_steps, 12) or not motor.is_contiguous():
                     motor = torch.empty(n, e_steps, 12, device=env.device)

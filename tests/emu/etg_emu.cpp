@@ -247,6 +247,8 @@ template <bool FLAT, bool KNEE = false, bool PLAIN = false> struct EmuCtx16T : E
   static constexpr bool kKnee = KNEE;
   static constexpr bool kPlain = PLAIN;
   static constexpr bool kAsmSweep = false;   // the C++ statement of the sweep (the device build hand-schedules it)
+  static constexpr bool kStepLocal = false;
+  void launder_lane() {}
 #ifdef ETG_EMU_SLOTB_LDS
   static constexpr bool kSlotBLds = true;    // (build variant: the parked form of the body friction rows' Delassus columns)
 #else

@@ -435,19 +435,21 @@ def test_joint_limits_match_oracle(lanes):
     act[2::4, 2::3] = 8.0
     act[3::4, 2::3] = -8.0; act[3::4, 1::3] = 3.0
     env = _make(n, motor_control_mode="torque", joint_limits=True, solver_iters=4, lanes_per_robot=lanes)
-    orc = _oracle(n, motor_mode=1, joint_limits=1, solver_iters=4)
+    orc = _ensemble(n, motor_mode=1, joint_limits=1, solver_iters=4)
     env.reset(); orc.reset()
     ta = torch.as_tensor(act, device="cuda:0")
-    worst = 0.0
+    worst, wp, sq, sp = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)
     for k in range(12):
         env.step(ta); orc.step(act)
         sg, so = env.get_state().cpu().numpy(), orc.get_state()
-        worst = max(worst, np.abs(sg - so)[:, 13:25].max())
-        assert np.abs(sg - so)[:, :3].max() < 2e-3, k
-        if k == 5:      # before the splayed robot sinks into the floor (no body contacts here) and its feet push a hip off its stop
+        worst = np.maximum(worst, np.abs(sg - so)[:, 13:25].max(1)); wp = np.maximum(wp, np.abs(sg - so)[:, :3].max(1))
+        sq = np.maximum(sq, orc.spread(slice(13, 25))); sp = np.maximum(sp, orc.spread(slice(0, 3)))
+        if k == 5:      # before the splayed robot lies on its body spheres and its feet push a hip off its stop
             q6 = sg[:, 13:25].reshape(n, 4, 3)
-    _say("joint limits lanes=%d: q err max %.2e" % (lanes, worst))
-    assert worst < 5e-3
+    # (a joint RESTING on its stop sits exactly at the bound: whether its row exists in a tick is decided by the last bit, and
+    # the driven joint jumps a few mrad when it drops out -- every evaluation does so on its own ticks: the ensemble's spread)
+    sens_robots(worst, sq, 5e-4, "joint limits lanes %d: joint angles, 12 steps of constant torques" % lanes)
+    sens_robots(wp, sp, 2e-4, "joint limits lanes %d: base position" % lanes)
     q = env.get_state()[:, 13:25].cpu().numpy().reshape(n, 4, 3)
     lo, hi = np.array(A.JOINT_LOWER), np.array(A.JOINT_UPPER)
     assert (q <= hi + 0.03).all() and (q >= lo - 0.03).all()
@@ -632,6 +634,7 @@ def test_simultaneous_body_rows_match_oracle():
         # the same 10 further steps through the fused rollout and through stepping
         twin = _make(n, motor_control_mode="torque", body_contacts=3, solver_iters=4, joint_limits=False, **kw)
         twin.reset(); twin.set_state(env.get_state())
+        env.set_rollout_mode(simulate_finished=True)      # (the landed robots' episodes have ended: the fused rollouts would leave them alone)
         env.rollout_openloop(10)
         for _ in range(10):
             twin.step(ta)

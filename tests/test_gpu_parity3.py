@@ -65,6 +65,7 @@ def test_residual_rule_matches_oracle(lanes, terrain):
     rng = np.random.default_rng(2)
     worst_q, worst_p, sq, sp = np.zeros(n), np.zeros(n), np.zeros(n), np.zeros(n)
     per_wave = 64 // lanes
+    waves_compared = 0
     for k in range(20):
         act = rng.uniform(-0.1, 0.1, size=(n, 12))
         _, rg, dg, info = env.step(torch.as_tensor(act, dtype=torch.float32))
@@ -80,9 +81,10 @@ def test_residual_rule_matches_oracle(lanes, terrain):
         # the wave runs, per tick, the count of its slowest robot: between the largest per-robot step total and the sum
         # (waves whose robots' ensembles are all still one trajectory: a robot past a grip bifurcation counts its own sweeps)
         on = (sq < 1e-5).reshape(-1, per_wave).all(1)
+        waves_compared += int(on.sum())
         assert np.all(sw_g[on, 0] >= sw_o[on].max(1) - 2) and np.all(sw_g[on, 0] <= sw_o[on].sum(1) + 2), (k, sw_g[:, 0], sw_o)
         assert np.all(sw_g >= 13) and np.all(sw_g <= 13 * 50)
-    assert on.any()
+    assert waves_compared >= 10
     _say("residual rule %s lanes %d: executed sweeps/tick %.2f vs oracle per robot %.2f" % (terrain, lanes, sw_g.mean() / 13, sw_o.mean() / 13))
     sens_robots(worst_q, sq, 1e-3 if hf else 1e-4, "residual rule %s lanes %d joint angles, 20 steps" % (terrain, lanes))   # measured (toe spheres only): 8e-6 / 5e-7 on flat ground
     sens_robots(worst_p, sp, 2e-4 if hf else 2e-5, "residual rule %s lanes %d base position" % (terrain, lanes))
@@ -591,7 +593,7 @@ def test_four_lane_closed_loop_kernel(variant):
         orc.closed_loop_step(ws, 0.3, col0=3 if variant == "student" else 0)
         sq = np.maximum(sq, orc.spread(slice(13, 25)))
     sqn = np.tile(sq, n // m)
-    tol = 2e-3 if variant == "bf16" else 1e-4
+    tol = 5e-3 if variant == "bf16" else 1e-4     # (bf16 operands: an opt-in arithmetic with its own tolerances; SURVEY 8d: 2e-2 on the actor's output)
     # two fp32 evaluations of one trajectory are as far apart as the trajectory is sensitive: the kernel-to-kernel gaps are held
     # to the same per-robot criterion as the gap to the oracle
     sens_robots(np.abs(s4 - ss)[:, 13:25].max(1), sqn, tol, "4-lane closed loop %s: joint gap to predict+step, 12 steps" % variant)
