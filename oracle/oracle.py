@@ -175,6 +175,19 @@ class OracleSim:
         self._trace_env = env
         self._f("set_trace")(self._h, int(env), _p(self._trace_buf), int(cap_ticks))
 
+    def trace_all(self, cap_ticks=16):
+        """record EVERY robot's physics ticks from now on into one buffer [N, cap_ticks, 64] (each call rewinds every robot's
+        tick count to 0: call it before the control step of interest); the rows are read from the returned array, the number
+        of ticks a robot recorded from trace_counts()"""
+        if getattr(self, "_trace_all", None) is None or self._trace_all.shape[1] != cap_ticks:
+            self._trace_all = np.zeros((self.N, cap_ticks, self.TRACE_W), dtype=np.float64)
+        for i in range(self.N):
+            self._f("set_trace")(self._h, i, _p(self._trace_all[i]), int(cap_ticks))
+        return self._trace_all
+
+    def trace_counts(self):
+        return np.array([self._f("set_trace")(self._h, i, None, -1) for i in range(self.N)])
+
     def trace_rows(self, stop=True):
         """-> the ticks recorded since trace() as float64 [n, 64] (and stop recording)"""
         n = self._f("set_trace")(self._h, int(self._trace_env), None, 0 if stop else -1)

@@ -64,55 +64,129 @@ def compare_traces(ta, tb, margin):
     return None
 
 
-def one_step_report(make_env_fn, make_ens_fn, install, state_before, action, robot, steps_taken, floor_q=2e-5, say=print):
-    """The one-step analysis of `robot` from `state_before` [N,37] (fp32) with `action` [N,adim].  make_env_fn() -> a fresh env
-    (same configuration as the trajectory's), make_ens_fn() -> OracleEnsemble, install(env, ens): parameters + reset on both.
-    steps_taken: control steps the trajectory had taken before this one (the ETG phase): probe and members take that many steps
-    from their own reset first, then get the state.  -> dict(nearest, dist, gaps, divergence)"""
-    import torch
-    probe = make_env_fn()
-    ens = make_ens_fn()
-    install(probe, ens)
-    n = probe.num_envs
-    adim = action.shape[1]
-    zero = np.zeros((n, adim), dtype=np.float32)
-    for _ in range(steps_taken):      # advance the step counters (ETG phase) to the trajectory's
-        probe.step(torch.as_tensor(zero), want_info=False)
-        ens.step(zero, want_info=False)
-    st = torch.as_tensor(state_before, dtype=torch.float32)
-    probe.set_state(st)
-    ens.set_state(np.asarray(state_before, dtype=np.float64))
-    members = [ens.nominal] + ens.members
-    names = ["fp64 oracle", "fp32 oracle"] + ["fp64 oracle, action +-1 ulp (%d)" % i for i in range(len(ens.nudged))]
-    for o in members:
-        o.trace(robot, 64)
-    _, _, _, info = probe.step(torch.as_tensor(action, dtype=torch.float32))
-    ens.step(action)
-    traces = [o.trace_rows() for o in members]
-    sg = probe.get_state().cpu().numpy().astype(np.float64)[robot]
-    states = [np.asarray(o.get_state(), dtype=np.float64)[robot] for o in members]
-    dq = [float(np.abs(sg[13:25] - s[13:25]).max()) for s in states]
-    gaps = [float(np.abs(s[13:25] - states[0][13:25]).max()) for s in states]
-    near = int(np.argmin(dq))
-    sweeps_gpu = int(info["solver_sweeps"].cpu().numpy().reshape(-1)[robot]) if "solver_sweeps" in info else -1
-    say("    one control step from the GPU's own state, robot %d: GPU joints vs each member (member's own gap to the fp64 oracle):" % robot)
-    for nm, d, g, tr in zip(names, dq, gaps, traces):
-        say("      %-38s %.2e (%.2e)  sweeps in the step %d" % (nm, d, g, int(tr[:, 3].sum())))
-    say("      GPU: sweeps its wave executed in the step %d" % sweeps_gpu)
-    out = dict(nearest=names[near], dist=dq[near], dist_nominal=dq[0], gaps=gaps, divergence=None, on_branch=dq[near] <= floor_q)
-    margin = float(ens.cfg.contact_margin)
-    if near != 0 and dq[0] > floor_q:
-        div = compare_traces(traces[0], traces[near], margin)
-        out["divergence"] = div
-        if div:
-            say("      the nearest member (%s) parts from the fp64 oracle at tick %d of 13: %s -- %s; sweeps of that tick %d / %d"
-                % (names[near], div["tick"], div["kind"], "; ".join(div["detail"]), div["sweeps"][0], div["sweeps"][1]))
-        else:
-            say("      the nearest member (%s) has the same active and loaded row sets as the fp64 oracle in every tick: a smooth gap" % names[near])
-    elif dq[0] <= floor_q:
-        say("      the GPU is on the fp64 oracle's own branch (%.2e <= %.1e)" % (dq[0], floor_q))
-    probe.close()
+def emu_tick_rows(tr, i, t):
+    """the emulation's / GPU debugging build's tick trace ([N,16,16,10]: physics_tick16's rowf, phi, lam, lam2, jactf, lamq, sphere
+    code, sweeps so far, q, qd per lane) of robot i, tick t -> dict(act, loaded, pick, sweeps_cum, lam[36], phi_f, phi_b)"""
+    x = tr[i, t]
+    act, ld = 0, 0
+    for leg in range(4):
+        for sub in range(3):
+            if x[4 * leg + sub, 0] > 0.5: act |= 1 << (3 * leg + sub)
+        if x[4 * leg, 0] > 0.5 and x[4 * leg, 2] > 0: ld |= 1 << (3 * leg)
+        if x[4 * leg + 3, 0] > 0.5:
+            act |= 7 << (12 + 3 * leg)
+            if x[4 * leg + 3, 2] > 0: ld |= 1 << (12 + 3 * leg)
+        for sub in range(3):
+            if x[4 * leg + sub, 4] > 0.5: act |= 1 << (24 + 3 * leg + sub)
+    pick = 0
+    for leg in range(4):        # w_shin + 2 w_trunk of the leg's body contact: 0 knee, 1 shin midpoint, 2 trunk corner (soft weights: rounded)
+        pick |= min(max(int(round(float(x[4 * leg, 6]))), 0), 2) << (2 * leg)
+    lam = np.zeros(36)
+    for leg in range(4):
+        for sub in range(3):
+            lam[3 * leg + sub] = x[4 * leg + sub, 2]
+            lam[24 + 3 * leg + sub] = x[4 * leg + sub, 5]
+        lam[12 + 3 * leg] = x[4 * leg + 3, 2]
+        lam[12 + 3 * leg + 1] = x[4 * leg + 1, 3]; lam[12 + 3 * leg + 2] = x[4 * leg + 2, 3]
+    return dict(act=act, loaded=ld, pick=pick, sweeps_cum=int(x[0, 7]), lam=lam,
+                phi_f=[float(x[4 * leg, 1]) for leg in range(4)], phi_b=[float(x[4 * leg + 3, 1]) for leg in range(4)])
+
+
+def first_decision_gap(emu_tr, i, orc_tr, margin=0.02):
+    """the first physics tick of a control step at which the kernel source (emulation trace of robot i) and an oracle (trace_rows of
+    the robot) DECIDE differently -> (tick, kind, text) or None.  kinds: "sphere" (another sphere of a leg's body contact is the
+    deepest), "active" (a row inside the margin / a joint at its stop in one only), "loaded" (a normal row carries load in one
+    only), "sweeps" (the residual test stopped one evaluation earlier: the emulated wave holds one robot, so the counts compare)"""
+    prev = 0
+    for t in range(min(13, len(orc_tr))):
+        g = emu_tick_rows(emu_tr, i, t)
+        o_act, o_ld, o_pick, o_sw = int(orc_tr[t, 0]), int(orc_tr[t, 1]) & 0b001001001001001001001001, int(orc_tr[t, 2]), int(orc_tr[t, 3])
+        sw = g["sweeps_cum"] - prev
+        prev = g["sweeps_cum"]
+        for leg in range(4):
+            if (o_act >> (12 + 3 * leg)) & 1 and (g["act"] >> (12 + 3 * leg)) & 1 and ((g["pick"] >> (2 * leg)) & 3) != ((o_pick >> (2 * leg)) & 3):
+                names = ("knee", "shin midpoint", "trunk corner")
+                return t, "sphere", "tick %d: the body contact of leg %s sits on the %s in the kernel source and on the %s in the oracle (contact distance %.3e / %.3e)" % (
+                    t, ("FR", "FL", "RR", "RL")[leg], names[(g["pick"] >> (2 * leg)) & 3], names[(o_pick >> (2 * leg)) & 3], g["phi_b"][leg], orc_tr[t, 8 + leg])
+        if g["act"] != o_act:
+            rows = _bits(g["act"] ^ o_act)
+            return t, "active", "tick %d: rows active in one evaluation only: %s (distances %s / %s, margin %.3g)" % (
+                t, [ROW_NAMES[r] for r in rows], ["%.6e" % x for x in g["phi_f"] + g["phi_b"]], ["%.6e" % x for x in orc_tr[t, 4:12]], margin)
+        if g["loaded"] != o_ld:
+            rows = _bits(g["loaded"] ^ o_ld)
+            return t, "loaded", "tick %d: normal rows loaded in one evaluation only: %s" % (t, [ROW_NAMES[r] for r in rows])
+        if sw != o_sw:
+            return t, "sweeps", "tick %d: %d sweeps in the kernel source, %d in the oracle" % (t, sw, o_sw)
+    return None
+
+
+def oracle_pick_changes(orc_tr):
+    """an oracle's tick trace of one control step -> [(tick, leg)] at which the sphere an ACTIVE body contact sits on changes
+    from the tick before (hard deepest-of-three choice: the robot crosses a tie of two spheres within this step)"""
+    out = []
+    for t in range(1, len(orc_tr)):
+        for leg in range(4):
+            both = (int(orc_tr[t, 0]) >> (12 + 3 * leg)) & (int(orc_tr[t - 1, 0]) >> (12 + 3 * leg)) & 1
+            if both and ((int(orc_tr[t, 2]) ^ int(orc_tr[t - 1, 2])) >> (2 * leg)) & 3:
+                out.append((t, leg))
     return out
+
+
+def lockstep_offenders(run, probe, ens, emu, steps, action_fn, floor_q=2e-5, floor_p=1e-5, say=print, what=""):
+    """The one-step consistency run of tests/test_gpu_parity5.py with the classification of every (robot, step) pair that is off
+    every branch of the oracle ensemble.  run / probe: two GPU envs in the same state (probe repeats every step of run from run's
+    own state + contact impulses); ens: OracleEnsemble, emu: EmuSim of the same configuration with set_trace() on (16-lane
+    mapping), all reset and ready.  For an offending pair the emulation -- the kernel SOURCE on the host: plain C++, fp32, libm, no
+    FMA contraction -- is asked: if it is within the floor of the GPU, the GPU computes what its source says, and the tick at which
+    that source first decides differently from the fp64 oracle names the cause.
+    -> (tally dict, [dict(step, robot, gap, emu_gap, kind, text)])"""
+    import torch
+    n = run.num_envs
+    etr = emu.set_trace(True)
+    tally = dict(pairs=0, nominal=0, other=0, none=0)
+    out = []
+    for k in range(steps):
+        act = np.asarray(action_fn(k), dtype=np.float32)
+        st, lam = run.get_state(), run.get_contact_impulses()
+        stn, lamn = st.cpu().numpy(), lam.cpu().numpy()
+        probe.set_state(st); probe.set_contact_impulses(lam)
+        ens.set_state(stn.astype(np.float64)); ens.set_lambda(lamn.astype(np.float64))
+        emu.set_state(stn); emu.set_contact_impulses(lamn)
+        a = torch.as_tensor(act)
+        probe.step(a, want_info=False)
+        otr = ens.nominal.trace_all(16)                  # the fp64 oracle's tick trace of this step, every robot
+        ens.step(act, want_info=False)
+        ocnt = ens.nominal.trace_counts()
+        emu.step(act)
+        run.step(a, want_info=False)
+        sg = probe.get_state().cpu().numpy().astype(np.float64)
+        so, mem = ens.get_state(), ens.member_states()
+        se = emu.get_state().astype(np.float64)
+        dq = np.stack([np.abs(sg - m)[:, 13:25].max(1) for m in [so] + mem])
+        dp = np.stack([np.abs(sg - m)[:, :7].max(1) for m in [so] + mem])
+        on = (dq <= floor_q) & (dp <= floor_p)
+        tally["pairs"] += n
+        tally["nominal"] += int(on[0].sum())
+        tally["other"] += int((on.any(0) & ~on[0]).sum())
+        bad = np.nonzero(~on.any(0))[0]
+        tally["none"] += len(bad)
+        for i in bad:
+            emu_gap = float(np.abs(se[i] - sg[i])[13:25].max())
+            kind, text = "?", "the emulation does not reproduce the GPU's result (%.2e): not classified" % emu_gap
+            if emu_gap <= 10 * floor_q:
+                d = first_decision_gap(etr, int(i), otr[i, :ocnt[i]], float(ens.cfg.contact_margin))
+                kind, text = (d[1], d[2]) if d else ("smooth", "no tick with a differing decision: a smooth gap")
+            ties = oracle_pick_changes(otr[i, :ocnt[i]])
+            if ties:
+                text += "; in the fp64 oracle's own step the sphere under the body contact changes at (tick, leg) %s" % ties[:4]
+            out.append(dict(step=k, robot=int(i), gap=float(dq[0, i]), nearest=float(dq[:, i].min()), emu_gap=emu_gap, kind=kind, text=text,
+                            tie_in_step=bool(ties)))
+            say("[parity]    %s step %d robot %d: GPU %.2e off the fp64 oracle (nearest member %.2e); the kernel source on the host is %.2e from the GPU; %s"
+                % (what, k, i, dq[0, i], dq[:, i].min(), emu_gap, text))
+    say("[parity] %-50s (robot, step) pairs %d: on the fp64 oracle's branch %d, on another member's %d, on none %d %s"
+        % (what, tally["pairs"], tally["nominal"], tally["other"], tally["none"],
+           ("(first differing decision: %s)" % dict((k_, sum(1 for o_ in out if o_["kind"] == k_)) for k_ in sorted(set(o_["kind"] for o_ in out)))) if out else ""))
+    return tally, out
 
 
 def first_jump(gaps, floor):

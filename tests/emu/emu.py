@@ -15,8 +15,10 @@ def lib():
     global _LIB
     if _LIB is None:
         # ETG_EMU_FLAGS: extra compiler flags (e.g. -DETG_TRUNK_ON_AUX) to emulate a build variant of the kernel source
-        flags = os.environ.get("ETG_EMU_FLAGS", "").split()
+        # (the per-tick trace of physics_tick16 -- set_trace(), tests/divergence.py -- is always compiled into the emulation)
+        flags = [f for f in os.environ.get("ETG_EMU_FLAGS", "").split() if f != "-DETG_TRACE_TICKS"]
         so = os.path.join(_HERE, "libetg_emu%s.so" % ("_" + "".join(ch for ch in "".join(flags) if ch.isalnum()) if flags else ""))
+        flags = flags + ["-DETG_TRACE_TICKS"]
         srcs = [os.path.join(_HERE, "etg_emu.cpp"), os.path.join(_HERE, "emu_lanes.h")] + [
             os.path.join(_HERE, "..", "..", "paddlerobotics_amd", "csrc", f)
             for f in ("etg_core.h", "etg_core16.h", "etg_layout.h") if os.path.exists(
@@ -121,6 +123,11 @@ class EmuSim:
     def set_contact_impulses(self, lam):
         lam = np.ascontiguousarray(lam, dtype=np.float32)
         self._l.emu_set_contact_impulses(self._h, _p(lam))
+
+    def get_contact_impulses(self):
+        lam = np.zeros((self.N, 12), dtype=np.float32)
+        self._l.emu_get_contact_impulses(self._h, _p(lam))
+        return lam
 
     def set_trace(self, on=True):
         """tick trace of an ETG_EMU_FLAGS=-DETG_TRACE_TICKS build: [N,16,16,10] float32 (tools/first_divergence.py)"""

@@ -502,6 +502,13 @@ extern "C" void emu_set_contact_impulses(void* h, const float* lam) {   // [N,12
     for (int l = 0; l < 4; l++)
       for (int k = 0; k < 3; k++) e->leg[(size_t)(LG_LAM + k) * NL + 4 * i + l] = lam[i * 12 + 3 * l + k];
 }
+extern "C" void emu_get_contact_impulses(void* h, float* lam) {
+  Emu* e = (Emu*)h;
+  const size_t N = e->N, NL = 4 * N;
+  for (size_t i = 0; i < N; i++)
+    for (int l = 0; l < 4; l++)
+      for (int k = 0; k < 3; k++) lam[i * 12 + 3 * l + k] = e->leg[(size_t)(LG_LAM + k) * NL + 4 * i + l];
+}
 extern "C" void emu_get_state(void* h, float* st) {
   Emu* e = (Emu*)h;
   for (int i = 0; i < e->N; i++) {

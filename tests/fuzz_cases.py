@@ -72,12 +72,13 @@ def trial_rng(seed, trial):
     return np.random.default_rng(1000 * seed + trial)
 
 
-def setup_trial(seed, trial, N, make_oracles):
+def setup_trial(seed, trial, N, make_oracles, kw_extra=None):
     """-> dict(rng, lanes, kw, ex, env, orcs, W, B, rows, sr, f, offs, mode, loose).  make_oracles(cfg) -> list of oracle-like objects
     (OracleSim / tests.parity_util.OracleEnsemble) built from a copy of the env's EtgConfig; every installer is called on each."""
     from paddlerobotics_amd.env import make_env
     rng = trial_rng(seed, trial)
     lanes, kw, ex = draw(rng)
+    kw.update(kw_extra or {})      # (a regression case pins an option of the trial, e.g. body_blend = 0)
     if ex["noise"]:
         kw["observation_noise_stdev"] = NOISE      # (counter-based draws: the oracle's stream is seeded like the env's)
     offs = rng.uniform(-0.3, 0.3, size=(64, 2)) if ex["offsets"] else None

@@ -1,6 +1,6 @@
 """CPU suite: the code generation of the hot kernels is pinned ("nothing pins the hot loops ... a toolchain bump
 can silently move the headline").  The step time of these kernels is (instructions per wave) x ~4.4 cycles with one wave per
-SIMD, and their register allocation sits close to where hipcc starts spilling; profiles/r05_isa_baseline.json records, for the
+SIMD, and their register allocation sits close to where hipcc starts spilling; profiles/r06_isa_baseline.json records, for the
 headline kernels, registers, scratch and the static instruction mix of the build the round's numbers were measured with.
 This test disassembles the library that was just built (llvm-objdump on its gfx950 code object) and compares:
   * no scratch (spills) in the headline 16-lane kernels, registers within +8 of the recorded allocation;
@@ -13,7 +13,7 @@ import sys
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-BASE = os.path.join(ROOT, "profiles", "r05_isa_baseline.json")
+BASE = os.path.join(ROOT, "profiles", "r06_isa_baseline.json")
 
 
 def test_hot_kernel_code_generation_matches_the_recorded_baseline():
@@ -37,7 +37,7 @@ def test_hot_kernel_code_generation_matches_the_recorded_baseline():
         for key, tol in (("valu", 0.03), ("dpp", 0.03), ("trans", 0.03), ("s_nop", 0.10), ("all", 0.03)):
             if abs(g.get(key, 0) - want[key]) > tol * want[key] + 2:
                 report.append("%s: %s %d, recorded %d" % (sym, key, g.get(key, 0), want[key]))
-    assert not report, "code generation moved (regenerate profiles/r05_isa_baseline.json if intended):\n" + "\n".join(report)
+    assert not report, "code generation moved (regenerate profiles/r06_isa_baseline.json if intended):\n" + "\n".join(report)
 
 
 def test_no_accumulator_is_its_own_broadcast_source():

@@ -172,7 +172,8 @@ BASELINE_KERNELS = (
     "_ZN3etg8k_step16ILb1ELb1ELb1EEEvNS_4KCfgENS_8DevStateEPKfPKhPfS7_PhS7_",      # k_step16<flat, body rows, plain>: env.step()
     "_ZN3etg8k_step16ILb1ELb0ELb1EEEvNS_4KCfgENS_8DevStateEPKfPKhPfS7_PhS7_",      # k_step16<flat, toe spheres only, plain>
     "_ZN3etg9k_rolloutILb1ELb0ELi1EEEvNS_4KCfgENS_8DevStateEiPfNS_7StatOutE",      # k_rollout<flat, all options, body rows>: the 4-lane mapping (> 4096 robots)
-    "_ZN3etg18k_rollout_policy16ILb1ELb0ELb1ELb1EEEvNS_4KCfgENS_8DevStateENS_7PolicyWEifPf",   # closed loop (configs[2]), fp32 MFMA, body rows
+    "_ZN3etg19k_rollout_policy16wILb1ELb1ELb1EEEvNS_4KCfgENS_8DevStateENS_7PolicyWEifPf",   # closed loop (configs[2]) since round 6: one wave = 4 robots + their policy tile, fp32, body rows; no scratch
+    "_ZN3etg18k_rollout_policy16ILb1ELb0ELb1ELb1EEEvNS_4KCfgENS_8DevStateENS_7PolicyWEifPf",   # the workgroup-tile closed loop of rounds 3-5 (kept for bf16 operands), body rows
 )
 
 
@@ -183,7 +184,7 @@ def write_baseline(so, path):
     if missing:
         raise SystemExit("kernels not found in %s: %s" % (so, sorted(missing)))
     hipcc = subprocess.run(["/opt/rocm/bin/hipcc", "--version"], capture_output=True, text=True).stdout.strip().split("\n")
-    json.dump({"what": "static ISA statistics of the hot kernels in the library build the round-5 numbers were measured with "
+    json.dump({"what": "static ISA statistics of the hot kernels in the library build the round-6 numbers were measured with "
                        "(tools/kernel_isa_stats.py; compared by tests/test_kernel_isa.py)",
                "toolchain": hipcc[:2], "kernels": st}, open(path, "w"), indent=1, sort_keys=True)
     print("wrote", path)
@@ -192,7 +193,7 @@ def write_baseline(so, path):
 if __name__ == "__main__":
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     if "--write-baseline" in sys.argv:
-        write_baseline(os.path.join(root, "paddlerobotics_amd", "csrc", "libetgsim.so"), os.path.join(root, "profiles", "r05_isa_baseline.json"))
+        write_baseline(os.path.join(root, "paddlerobotics_amd", "csrc", "libetgsim.so"), os.path.join(root, "profiles", "r06_isa_baseline.json"))
         sys.exit(0)
     so = sys.argv[1] if len(sys.argv) > 1 and sys.argv[1].endswith(".so") else os.path.join(root, "paddlerobotics_amd", "csrc", "libetgsim.so")
     want = [a for a in sys.argv[1:] if not a.endswith(".so")]
