@@ -24,7 +24,10 @@ class SimpleGA:
         self.best_param = torch.zeros(self.num_params, dtype=dtype, device=self.device) if param is None else \
             torch.as_tensor(param, dtype=dtype, device=self.device).clone()
         self.curr_best_param = self.best_param
-        self.best_reward = 0
+        # the best rewards stay 0-d tensors on the solver's device (tell() does not synchronise: the generation loop of
+        # rollout.es_generation queues ask -> fit -> rollout -> tell without a host read); result() turns them into floats
+        self._best_reward = torch.zeros((), dtype=dtype, device=self.device)
+        self._curr_best_reward = torch.zeros((), dtype=dtype, device=self.device)
         self.first_iteration = True
         self.forget_best = forget_best
         self.weight_decay = weight_decay
@@ -76,14 +79,26 @@ class SimpleGA:
         idx = torch.argsort(reward, stable=True).flip(0)[: self.elite_popsize]
         self.elite_rewards = reward[idx]
         self.elite_params = solution[idx]
-        self.curr_best_reward = float(self.elite_rewards[0])
+        self._curr_best_reward = self.elite_rewards[0].clone()
         self.curr_best_param = self.elite_params[0].clone()
-        if self.first_iteration or (self.curr_best_reward > self.best_reward):
+        if self.first_iteration:
             self.first_iteration = False
-            self.best_reward = float(self.elite_rewards[0])
-            self.best_param = self.elite_params[0].clone()
+            self._best_reward = self._curr_best_reward
+            self.best_param = self.curr_best_param
+        else:                                               # alg/es.py:308-311 `if curr_best_reward > best_reward`, as a select on the device
+            better = self._curr_best_reward > self._best_reward
+            self._best_reward = torch.where(better, self._curr_best_reward, self._best_reward)
+            self.best_param = torch.where(better, self.curr_best_param, self.best_param)
         if self.sigma > self.sigma_limit:
             self.sigma *= self.sigma_decay
+
+    @property
+    def best_reward(self):
+        return float(self._best_reward)
+
+    @property
+    def curr_best_reward(self):
+        return float(self._curr_best_reward)
 
     def current_param(self):
         return self.elite_params[0]
