@@ -294,6 +294,15 @@ int etg_reset(EtgHandle* h, const uint8_t* mask, float* obs, void* stream);
  * done [N] uint8, info [N,64] or NULL.                                       */
 int etg_step(EtgHandle* h, const float* action, const uint8_t* donef, float* obs,
              float* reward, uint8_t* done, float* info, void* stream);
+/* etg_step for the sub-batch [env0, env0 + count) only (ABI version 2).  Every pointer is the WHOLE batch's array, indexed by
+ * the robot's number exactly as in etg_step; rows and states of the other robots are not touched.  env0 and count are
+ * multiples of 16 robots (the last range may end at N).  Robots are independent, so G ranges enqueued on G streams are the
+ * same computation as one etg_step, robot by robot and bit for bit -- but each sub-batch's next step can start when ITS slowest
+ * wavefront has finished (the Gym loop of train.py:129-178 with one barrier per group instead of one per batch).  The
+ * sensor-noise stream position moves on with the range that starts at robot 0: call the ranges of one control step in
+ * ascending order.                                                                                                      */
+int etg_step_range(EtgHandle* h, int env0, int count, const float* action, const uint8_t* donef, float* obs,
+                   float* reward, uint8_t* done, float* info, void* stream);
 /* etg_step followed by the reset of every robot whose `done` byte the step set (Gym-style auto-reset, on the device,
  * no host synchronisation): obs rows of those robots hold their reset observation, reward / done / info rows the
  * finished step.  While every robot has a cached settle (after a full etg_reset, until dynamic parameters, terrain or

@@ -179,6 +179,33 @@ int etg_step(EtgHandle* h, const float* action, const uint8_t* donef, float* obs
   return ETG_OK;
 }
 
+int etg_step_range(EtgHandle* h, int env0, int count, const float* action, const uint8_t* donef, float* obs, float* reward,
+                   uint8_t* done, float* info, void*) {
+  if (!h) return cfail(ETG_ERR_BAD_ARG, "null handle");
+  if (!obs || !reward || !done) return cfail(ETG_ERR_BAD_ARG, "etg_step: obs/reward/done must be non-null");
+  CpuHandle* c = H(h);
+  if (!c->was_reset) return cfail(ETG_ERR_STATE, "etg_step: call etg_reset first");
+  const int adim = c->sim->cfg.motor_mode == 2 ? ETG_HYBRID_DIM : ETG_ACT_DIM;
+  if (c->sim->cfg.motor_mode == 2 && !action) return cfail(ETG_ERR_BAD_ARG, "etg_step: the HYBRID motor mode needs a [N,60] command");
+  const size_t N = c->N;
+  if (env0 < 0 || count <= 0 || (size_t)(env0 + count) > N || env0 % 16 != 0 || (count % 16 != 0 && (size_t)(env0 + count) != N))
+    return cfail(ETG_ERR_BAD_ARG, "etg_step_range: env0 and count must be multiples of 16 robots (the last range may end at N)");
+  const size_t a0 = env0, a1 = env0 + count;
+  std::vector<double> a(N * adim, 0.0), o(N * ETG_OBS_DIM), r(N), inf(info ? N * ETG_INFO_DIM : 0);
+  if (action) for (size_t k = a0 * adim; k < a1 * adim; k++) a[k] = action[k];
+  etgo_step_range64(c->sim, env0, count, a.data(), donef, o.data(), r.data(), done, info ? inf.data() : nullptr, 1);
+  for (size_t k = a0 * ETG_OBS_DIM; k < a1 * ETG_OBS_DIM; k++) obs[k] = (float)o[k];
+  for (size_t i = a0; i < a1; i++) {
+    reward[i] = (float)r[i];
+    c->ret[i] += c->alive[i] * r[i];
+    c->len[i] += (int32_t)c->alive[i];
+    if (done[i]) c->alive[i] = 0.0;
+    c->age_ticks[i] += c->sim->cfg.action_repeat;
+  }
+  if (info) for (size_t k = a0 * ETG_INFO_DIM; k < a1 * ETG_INFO_DIM; k++) info[k] = (float)inf[k];
+  return ETG_OK;
+}
+
 int etg_step_autoreset(EtgHandle* h, const float* action, const uint8_t* donef, float* obs, float* reward, uint8_t* done, float* info, void* s) {
   int rc = etg_step(h, action, donef, obs, reward, done, info, s);
   if (rc != ETG_OK) return rc;

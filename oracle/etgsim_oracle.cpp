@@ -1418,6 +1418,19 @@ template <class F> void par_for(int n, int threads, F f) {
                info ? info + (size_t)i * ETG_INFO_DIM : (T*)nullptr);                               \
     });                                                                                             \
   }                                                                                                 \
+  /* the control step of robots [env0, env0 + count) only (arrays are the whole batch's): include/etgsim.h etg_step_range; \
+   * the sensor-noise stream moves on with the range that starts at robot 0                                             */ \
+  extern "C" void etgo_step_range##SFX(void* h, int env0, int count, const T* action, const uint8_t* donef, T* obs,   \
+                                        T* reward, uint8_t* done, T* info, int threads) {           \
+    auto* s = (Sim<T>*)h;                                                                           \
+    if (env0 == 0) s->noise_call = s->obs_calls++;                                                  \
+    par_for(count, threads, [=](int k) {                                                            \
+      const int i = env0 + k;                                                                       \
+      step_env(*s, s->env[i], action + (size_t)i * (s->cfg.motor_mode == 2 ? ETG_HYBRID_DIM : 12), donef ? donef[i] : 0, \
+               obs + (size_t)i * ETG_OBS_DIM, reward + i, done + i,                                 \
+               info ? info + (size_t)i * ETG_INFO_DIM : (T*)nullptr);                               \
+    });                                                                                             \
+  }                                                                                                 \
   /* nsteps control steps with a constant action row set (action [N,12] or NULL = zeros), every thread running ITS   \
    * slice of the robots through all the steps (no per-step thread spawn / join): the all-core CPU baseline of       \
    * bench.py.  ret / len [N]: episode return and length with alive masking (frozen after the first done).          \

@@ -18,7 +18,7 @@ SYMBOLS = [
     "etg_policy_destroy", "etg_rollout_policy", "etg_fit_etg", "etg_leg_kinematics", "etg_extra_sensors", "etg_step_autoreset",
     "etg_replay_begin", "etg_replay_end", "etg_rollout_policy_record", "etg_rollout_actions",
     "etg_prepare_next_dynamics", "etg_next_dynamics_pending",
-    "etg_config_size", "etg_model_size", "etg_get_contact_impulses", "etg_set_contact_impulses", "etg_set_rollout_mode", "etg_rollout_wave_cycles",
+    "etg_config_size", "etg_model_size", "etg_get_contact_impulses", "etg_set_contact_impulses", "etg_set_rollout_mode", "etg_rollout_wave_cycles", "etg_step_range",
 ]
 ABI_VERSION = 2      # include/etgsim.h: etg_version()
 
@@ -59,6 +59,7 @@ def load():
     lib.etg_reset.argtypes = [vp, vp, vp, vp]
     lib.etg_step.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
     lib.etg_step_autoreset.argtypes = [vp, vp, vp, vp, vp, vp, vp, vp]
+    lib.etg_step_range.argtypes = [vp, i32, i32, vp, vp, vp, vp, vp, vp, vp]
     lib.etg_episode_stats.argtypes = [vp, vp, vp, vp]
     lib.etg_rollout_openloop.argtypes = [vp, i32, vp, vp, vp, vp]
     lib.etg_get_state.argtypes = [vp, vp, vp]

@@ -147,7 +147,7 @@ __device__ __forceinline__ int xcd_contiguous_block() {
 }
 
 __device__ __forceinline__ bool make_ctx(const KCfg& K, GpuCtx& c) {
-  c.gid = xcd_contiguous_block() * blockDim.x + threadIdx.x;
+  c.gid = (K.block0 + xcd_contiguous_block()) * blockDim.x + threadIdx.x;   // (block0: etg_step_range; 0 in every other launch)
   c.N = K.n_env;
   c.NL = 4 * K.n_env;
   c.env = c.gid >> 2;
@@ -1093,7 +1093,7 @@ template <bool FLAT, bool KNEE, bool PLAIN, bool AUTO>
 __device__ __forceinline__ void step16_body(const KCfg& K, const DevState& D, const float* action, const uint8_t* donef, float* obs,
                                             float* reward, uint8_t* done, float* info, float* lds_par, const NextDyn NX = NextDyn{nullptr, nullptr, nullptr}) {
   GpuCtx16T<FLAT, KNEE, PLAIN> c;
-  if (!make_ctx16_fields(K, D, c, lds_par, xcd_contiguous_block(), threadIdx.x)) return;
+  if (!make_ctx16_fields(K, D, c, lds_par, K.block0 + xcd_contiguous_block(), threadIdx.x)) return;   // (block0: etg_step_range)
   // the head of a launch is a chain of cold loads (the L2s are invalidated at kernel boundaries): ALL of them -- staged
   // parameters, state, control state, tick constants, action, done flag -- are requested before the first use, so the launch
   // pays one HBM round trip here instead of one per group (the LDS writes of the staging used to wait in front of the rest)
@@ -1635,6 +1635,13 @@ __global__ void k_add_noise(KCfg K, unsigned call, const uint8_t* mask, int inve
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int env = i >> 4;
   if (env >= K.n_env || (mask && (mask[env] != 0) == (invert != 0))) return;   // mask: rows to touch (or, inverted, to leave)
+  add_sensor_noise(K, env, call, i & 15, obs + (size_t)env * ETG_OBS_DIM);
+}
+
+__global__ void k_add_noise_range(KCfg K, unsigned call, int env0, int count, float* obs) {   // etg_step_range's rows
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if ((i >> 4) >= count) return;
+  const int env = env0 + (i >> 4);
   add_sensor_noise(K, env, call, i & 15, obs + (size_t)env * ETG_OBS_DIM);
 }
 
@@ -2384,6 +2391,35 @@ extern "C" int etg_step(EtgHandle* h, const float* action, const uint8_t* donef,
     LAUNCH4(k_step, dim3(grid_for(h)), (hipStream_t)stream, h->K, h->D, action, donef, obs, reward, done, info);
   }
   launch_obs_noise(h, 1, nullptr, obs, (hipStream_t)stream);
+  HIP_TRY(hipGetLastError());
+  return ETG_OK;
+}
+
+// One control step of the sub-batch [env0, env0 + count) only -- every array is the WHOLE batch's ([N, ...], indexed by the
+// robot's number as in etg_step), the other robots' rows and states are not touched.  Sub-batches are independent (a robot's
+// step depends on its own state, parameters and action: tests/test_gpu_parity3.py::test_wave_neighbours_...), so G ranges
+// enqueued on G streams let each sub-batch start its next step when ITS slowest wavefront has finished instead of the batch's
+// (env.step(groups=G), rollout_policy(fused=False, groups=G): train.py:129-178's loop with one barrier per group).
+extern "C" int etg_step_range(EtgHandle* h, int env0, int count, const float* action, const uint8_t* donef, float* obs,
+                              float* reward, uint8_t* done, float* info, void* stream) {
+  CHECK_HANDLE(h);
+  if (int rc = step_checks(h, action, obs, reward, done)) return rc;
+  const int per_block = h->lanes == 16 ? BLOCK / 16 : BLOCK / 4;
+  if (env0 < 0 || count <= 0 || env0 + count > h->N || env0 % 16 != 0 || (count % 16 != 0 && env0 + count != h->N))
+    return fail(ETG_ERR_BAD_ARG, "etg_step_range: env0 and count must be multiples of 16 robots (the last range may end at N)");
+  // the sensor-noise stream moves on with the range that starts at robot 0: the ranges of one control step are called in
+  // ascending order and share the position, so that every robot draws what it draws in etg_step
+  if (env0 == 0) advance_obs_stream(h, 1);
+  KCfg K = h->K;
+  K.block0 = env0 / per_block;
+  const dim3 grid((count + per_block - 1) / per_block);
+  if (h->lanes == 16) {
+    LAUNCH16(k_step16, grid, (hipStream_t)stream, K, h->D, action, donef, obs, reward, done, info);
+  } else {
+    LAUNCH4(k_step, grid, (hipStream_t)stream, K, h->D, action, donef, obs, reward, done, info);
+  }
+  if (h->K.noise_on)
+    hipLaunchKernelGGL(k_add_noise_range, dim3((16 * count + 255) / 256), dim3(256), 0, (hipStream_t)stream, h->K, h->K.noise_call, env0, count, obs);
   HIP_TRY(hipGetLastError());
   return ETG_OK;
 }

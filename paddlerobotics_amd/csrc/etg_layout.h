@@ -89,6 +89,7 @@ struct KCfg {
   float slop;            // EtgConfig.contact_slop: added to a contact's distance before the velocity target is formed
   float restitution;     // EtgConfig.foot_restitution (combined coefficient; 0 = off)
   int strength_on;       // motor strength ratios other than 1 are installed (etg_set_motor_strength)
+  int block0;            // first workgroup of a sub-batch launch (etg_step_range): the launch's own block index is added to it; 0 otherwise
   int stop_at_done;      // fused rollouts: a robot whose episode has ended is not simulated any more (etg_set_rollout_mode; default 1)
 #ifdef ETG_TRACE_TICKS   // debugging build only: [N][16 ticks][16 lanes][10] floats written by physics_tick16 (etg_debug_set_trace)
   float* trace;
@@ -372,6 +373,7 @@ inline KCfg make_kcfg(const EtgConfig& c, const EtgRobotModel& m) {
   K.warmstart_t = (float)c.warmstart_friction; K.slop = (float)c.contact_slop; K.restitution = (float)c.foot_restitution;
   K.strength_on = 0;
   K.stop_at_done = 1;
+  K.block0 = 0;
 #ifdef ETG_TRACE_TICKS
   K.trace = nullptr;
 #endif

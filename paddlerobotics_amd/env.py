@@ -592,7 +592,54 @@ class BatchedQuadrupedEnv:
         _lib.check(self._lib.etg_leg_kinematics(self._h, _ptr(t), n, _ptr(foot), _ptr(jac), self._stream()))
         return (foot, jac) if want_jacobian else foot
 
-    def step(self, action, donef=None, want_info=True):
+    # ---- sub-batches (etg_step_range): the Gym loop with one barrier per group instead of one per batch
+    def group_ranges(self, groups):
+        """[(first robot, one past the last)] of `groups` sub-batches: equal sizes rounded up to whole wavefronts of the 4-lane
+        mapping (16 robots), the last one takes what is left"""
+        G = int(groups)
+        if G < 1:
+            raise ValueError("groups must be >= 1")
+        per = -(-self.num_envs // G)
+        per = -(-per // 16) * 16
+        return [(a, min(a + per, self.num_envs)) for a in range(0, self.num_envs, per)]
+
+    def _groups_ok(self, what):
+        if self.auto_reset or self._rand_force or self._hist_T > 0 or len(self._xcols) > 0:
+            raise ValueError("%s: sub-batches are for envs without auto_reset, random pushes, observation history and extra sensors" % what)
+
+    def _group_streams(self, n):
+        if len(getattr(self, "_gstreams", ())) < n:
+            self._gstreams = [torch.cuda.Stream(device=self.device) for _ in range(n)]
+        return self._gstreams[:n]
+
+    def step_range(self, first, last, action, donef=None, want_info=False):
+        """One control step of robots [first, last) only, enqueued on the CURRENT stream (etg_step_range).  `action` / `donef`
+        are the whole batch's [N, ...] arrays (rows outside the range are not read); returns views of the range's rows of
+        (obs, reward, done).  Ranges come from group_ranges(); those of one control step are called in ascending order."""
+        self._groups_ok("step_range")
+        a = None if action is None else self._f32(action, (self.num_envs, self.action_space.shape[0]), "action")
+        df = None if donef is None else torch.as_tensor(donef, device=self.device).to(torch.uint8).contiguous()
+        _lib.check(self._lib.etg_step_range(self._h, int(first), int(last - first), _ptr(a), _ptr(df), _ptr(self.obs), _ptr(self.reward),
+                                            _ptr(self.done), _ptr(self.info_buf) if want_info else None, self._stream()))
+        self._keep_step = (a, df)
+        return self.obs[first:last], self.reward[first:last], self.done[first:last]
+
+    def _step_grouped(self, a, df, want_info, groups):
+        """step() as `groups` launches on as many side streams, joined on the current stream: the same result, robot by robot"""
+        self._groups_ok("step(groups=G)")
+        cur = torch.cuda.current_stream(self.device)
+        streams = self._group_streams(len(self.group_ranges(groups)))
+        for (lo, hi), st in zip(self.group_ranges(groups), streams):
+            st.wait_stream(cur)
+            with torch.cuda.stream(st):
+                _lib.check(self._lib.etg_step_range(self._h, lo, hi - lo, _ptr(a), _ptr(df), _ptr(self.obs), _ptr(self.reward), _ptr(self.done),
+                                                    _ptr(self.info_buf) if want_info else None, self._stream()))
+        for st in streams:
+            cur.wait_stream(st)
+
+    def step(self, action, donef=None, want_info=True, groups=1):
+        """One control step of every robot (env.step of the reference, batched).  groups=G > 1: the batch is stepped as G
+        sub-batches on G streams (identical results); see rollout_policy(fused=False, groups=G) for the loop that gains from it."""
         a = None if action is None else self._f32(action, (self.num_envs, self.action_space.shape[0]), "action")   # NULL = zero residual
         df = None
         if donef is not None:
@@ -613,8 +660,11 @@ class BatchedQuadrupedEnv:
         # With random_dynamics the reset robots first draw new parameters, which needs the masked calls of reset().
         fused_reset = self.auto_reset and (not self._rand_dyn or self._nx_on)   # (_nx_on: the next episodes' dynamics are prepared)
         step_fn = self._lib.etg_step_autoreset if fused_reset else self._lib.etg_step
-        _lib.check(step_fn(self._h, _ptr(a), _ptr(df), _ptr(self.obs), _ptr(self.reward), _ptr(self.done),
-                           _ptr(self.info_buf) if want_info else None, self._stream()))
+        if int(groups) > 1:
+            self._step_grouped(a, df, want_info, groups)
+        else:
+            _lib.check(step_fn(self._h, _ptr(a), _ptr(df), _ptr(self.obs), _ptr(self.reward), _ptr(self.done),
+                               _ptr(self.info_buf) if want_info else None, self._stream()))
         self._keep_step = (a, df)
         info = self._info() if want_info else {}
         if self.auto_reset:
@@ -672,7 +722,7 @@ class BatchedQuadrupedEnv:
                                                   self._stream()))
         return ret, ln
 
-    def rollout_policy(self, policy, n_steps, act_scale=0.3, precision=0, fused=None):
+    def rollout_policy(self, policy, n_steps, act_scale=0.3, precision=0, fused=None, groups=1):
         """n_steps closed-loop control steps with a fixed actor (policy.predict semantics); returns (episode_return[N],
         episode_len[N]).  The batched run_EStrain_episode / run_evaluate_episodes (train.py:182-249).  fused: True = the
         fused kernel (actor MLP + control step, 50 steps per launch; FusedKernelUnavailable when the configuration is outside
@@ -689,6 +739,8 @@ class BatchedQuadrupedEnv:
             raise FusedKernelUnavailable("rollout_policy(fused=True): this configuration is outside the fused closed-loop kernel")
         if fused is None:
             fused = ok and (self.lanes_per_robot == 16 or self.cfg.body_contacts == 0)
+        if not fused and int(groups) > 1:
+            return self._rollout_policy_grouped(policy, n_steps, act_scale, precision, groups)
         if not fused:
             act = None
             for _ in range(int(n_steps)):
@@ -701,6 +753,33 @@ class BatchedQuadrupedEnv:
                                                 int(self._cols[0]), _ptr(self.obs), _ptr(ret), _ptr(ln), self._stream()))
         self._last_view = self._obs_view()
         return ret, ln
+
+    def _rollout_policy_grouped(self, policy, n_steps, act_scale, precision, groups):
+        """predict() + step() per control step as in rollout_policy(fused=False), the batch split into `groups` sub-batches that
+        run their loops on their own streams: sub-batch g's step k + 1 is queued behind ITS step k only, so it starts when its
+        own slowest wavefront has finished (train.py:129-178's loop; per-robot results identical to groups = 1)."""
+        self._groups_ok("rollout_policy(groups=G)")
+        if policy.obs_dim != len(self._cols):
+            raise ValueError("the policy reads %d observation columns, the env shows %d" % (policy.obs_dim, len(self._cols)))
+        ranges = self.group_ranges(groups)
+        cur = torch.cuda.current_stream(self.device)
+        streams = self._group_streams(len(ranges))
+        full = len(self._cols) == A.OBS_DIM
+        act = torch.empty(self.num_envs, self.action_space.shape[0], device=self.device)
+        for st in streams:
+            st.wait_stream(cur)
+        for _ in range(int(n_steps)):
+            for (lo, hi), st in zip(ranges, streams):
+                with torch.cuda.stream(st):
+                    rows = self.obs[lo:hi] if full else self.obs[lo:hi].index_select(1, self._col_idx)
+                    policy.predict(rows, act_scale, precision, out=act[lo:hi])
+                    _lib.check(self._lib.etg_step_range(self._h, lo, hi - lo, _ptr(act), None, _ptr(self.obs), _ptr(self.reward),
+                                                        _ptr(self.done), None, self._stream()))
+        for st in streams:
+            cur.wait_stream(st)
+        self._keep_step = (act, None)
+        self._last_view = self._obs_view()
+        return self.episode_stats()
 
     def rollout_policy_record(self, policy, n_steps, act_scale=0.3, precision=0, noise=None):
         """rollout_policy that also records the episode (etg_rollout_policy_record): returns (ret [N], len [N], rec) with
