@@ -313,6 +313,8 @@ def main():
     wall_local = []      # this rank's own wall seconds of the last timed_repeats() call (before the max over ranks)
     live_steps = []      # this rank's env-steps of still-running episodes inside the timed region, per repeat of the last call
 
+    step_groups = [1]     # sub-batches of the stepping legs (env.run_groups): 1 = one launch per control step
+
     def run_steps(e, pol, n, fused):
         """n control steps of the hot path: the fused rollouts (etg_rollout_openloop / etg_rollout_policy, <= 50 control steps
         per launch) or env.step() per control step (policy.predict() before each in closed loop)"""
@@ -320,6 +322,8 @@ def main():
             return e.episode_stats()
         if fused:   # the fused entry points return the episode statistics themselves (etg_episode_stats inside the C call)
             return e.rollout_openloop(n, out=stat_buf) if pol is None else e.rollout_policy(pol, n, 0.3, args.precision)
+        if step_groups[0] > 1:   # the Gym loop per sub-batch on its own stream: one barrier per group instead of one per batch
+            return e.run_groups(n, step_groups[0]) if pol is None else e.rollout_policy(pol, n, 0.3, args.precision, fused=False, groups=step_groups[0])
         for _ in range(n):
             if pol is not None:
                 pol.predict(e.obs, 0.3, args.precision, out=act)
@@ -422,6 +426,21 @@ def main():
             return out_
         extra["stepwise"] = leg(env, policy, False, "env.step() per control step (%s)%s" % (
             "k_step16" if lanes == 16 else "k_step", ", policy.predict() before each" if policy is not None else ""))
+        # the same loop with the batch as G sub-batches on G streams (etg_step_range): per-robot results identical
+        # (tests/test_gpu_groups.py), group g's step k + 1 starts when ITS slowest wavefront has finished
+        # (their streams have to sit on different hardware queues of the 4 the runtime uses, or the groups serialise at ~2x:
+        # env.tune_groups measures the candidates, retrying a colliding one on fresh streams)
+        g_best, g_table = env.tune_groups((2, 4))
+        by_g = {}
+        for G in sorted(g for g in g_table if g > 1):
+            step_groups[0] = G
+            try:
+                by_g[G] = leg(env, policy, False, "env.run_groups(K, %d): %d sub-batches of %d robots, each stepping on its own stream" % (G, G, -(-N // G)))
+            finally:
+                step_groups[0] = 1
+        best = min(by_g, key=lambda g: by_g[g]["ms_per_step"])
+        extra["stepwise_groups"] = {"best_groups": best, "ms_per_step_by_groups": {"1": extra["stepwise"]["ms_per_step"], **{str(g): by_g[g]["ms_per_step"] for g in by_g}},
+                                    "tune_groups_us_per_step": {str(g): round(t, 1) for g, t in g_table.items()}, **by_g[best]}
         # rounds 1-5 for continuity: finished robots simulated on inside the fused rollout (accumulators masked)
         env.set_rollout_mode(simulate_finished=True)
         try:

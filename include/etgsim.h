@@ -162,7 +162,10 @@ typedef struct EtgConfig {
                             * carried by the thigh); 2 one contact per leg on the DEEPEST of three spheres: knee, shin midpoint
                             * (carried by the calf), trunk corner next to the leg's hip (trunk_half below).  A contact of modes
                             * 1 / 2 has a normal row and two friction rows (body_friction) like a foot's, solved after the feet's
-                            * rows of the same kind; not warm-started.  3 all three spheres of every leg at once, a FRICTIONLESS
+                            * rows of the same kind.  Its normal row is warm-started like a foot's (`warmstart` x its impulse
+                            * of the tick before; friction rows from 0) when the contact is one persistent point -- mode 1,
+                            * mode 2 with body_blend > 0 -- as Bullet's persistent manifold does (ABI version 2); under the
+                            * hard deepest-of-three choice (body_blend = 0) it starts cold.  3 all three spheres of every leg at once, a FRICTIONLESS
                             * normal row each (24 contact rows per robot; served by the 4-lanes-per-robot mapping, which the
                             * setting selects; the fused closed-loop call is not available with it)                      */
   double knee_radius;
@@ -379,9 +382,10 @@ int etg_extra_sensors(EtgHandle* h, const float* obs, float* out, void* stream);
 /* ---- state access for parity tests (device pointers, [N,37] f32) --------- */
 int etg_get_state(EtgHandle* h, float* state, void* stream);
 int etg_set_state(EtgHandle* h, const float* state, void* stream);
-/* the feet's contact impulses of the last tick, [N,12] = per leg (n, t1, t2): the solver's warm start (EtgConfig.warmstart).
- * etg_set_state zeroes them; a parity test that re-creates a robot's step from its state installs them afterwards, so that the
- * re-created step is the robot's own (tests/test_gpu_parity5.py).  Body contacts and joint stops are not warm-started. */
+/* the contact impulses of the last tick that the solver warm-starts from (EtgConfig.warmstart), [N,16] = per leg (foot n, t1, t2,
+ * body contact's normal impulse).  etg_set_state zeroes them; a parity test that re-creates a robot's step from its state
+ * installs them afterwards, so that the re-created step is the robot's own (tests/test_gpu_parity5.py).  The body contact's
+ * friction rows, the legacy body_contacts = 3 rows and the joint stops are not warm-started (their entries stay 0). */
 int etg_get_contact_impulses(EtgHandle* h, float* lam, void* stream);
 int etg_set_contact_impulses(EtgHandle* h, const float* lam, void* stream);
 

@@ -276,7 +276,7 @@ int etg_set_state(EtgHandle* h, const float* state, void*) {
 
 int etg_get_contact_impulses(EtgHandle* h, float* lam, void*) {
   if (!h || !lam) return cfail(ETG_ERR_BAD_ARG, "etg_get_contact_impulses: null");
-  std::vector<double> l((size_t)H(h)->N * 12);
+  std::vector<double> l((size_t)H(h)->N * 16);
   etgo_get_lambda64(H(h)->sim, l.data());
   for (size_t k = 0; k < l.size(); k++) lam[k] = (float)l[k];
   return ETG_OK;
@@ -284,7 +284,7 @@ int etg_get_contact_impulses(EtgHandle* h, float* lam, void*) {
 
 int etg_set_contact_impulses(EtgHandle* h, const float* lam, void*) {
   if (!h || !lam) return cfail(ETG_ERR_BAD_ARG, "etg_set_contact_impulses: null");
-  std::vector<double> l = to_d(lam, (size_t)H(h)->N * 12);
+  std::vector<double> l = to_d(lam, (size_t)H(h)->N * 16);
   etgo_set_lambda64(H(h)->sim, l.data());
   return ETG_OK;
 }

@@ -275,6 +275,7 @@ template <class T> struct Env {
   T pos[3], quat[4], wb[3], vb[3];  // base twist in base coordinates
   T q[12], qd[12];
   T lam[12];  // warm-start impulses, per foot (n, t1, t2)
+  T lamb[4];  // the normal impulse of each leg's body contact in the last tick (0: the row was outside the margin): its warm start
   // latency ring
   T hist[RING][HIST];
   int64_t tick;  // ticks since reset (hist[(tick) % RING] is the newest)
@@ -574,6 +575,7 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
   const int NRC = 24;                                      // contact rows
   const int NR = NRC + 12;
   const int NBR = all_bodies ? 3 : 1;                      // body contact points per leg
+  const bool body_warm = s.cfg.body_contacts == 1 || (s.cfg.body_contacts == 2 && s.cfg.body_blend > 0);   // (see "Warm start" below)
   auto body_row = [&](int l, int b) { return 12 + 3 * l + b; };
   T J[NRMAX][NV];
   T target[NRMAX];
@@ -652,8 +654,14 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
   // moves it).  A contact of modes 1 / 2 has a normal row and two friction rows like a foot's (Bullet gives every contact point
   // friction), with the coefficient cfg.body_friction (the product of the link's and the ground's lateralFriction: only the
   // FEET's is ever changed by the reference, minitaur.py:1100-1110).  3: all three spheres of every leg collide at once, a
-  // frictionless normal row each (solved in that order).  Body rows are not warm-started: the deepest-of-three point changes
-  // identity from tick to tick, so no contact point persists the way a Bullet manifold point does.
+  // frictionless normal row each (solved in that order).
+  // Warm start (Bullet's persistent manifold keeps a contact point's applied impulse from step to step and
+  // setupMultiBodyContactConstraint restarts the NORMAL row from it x warmstartingFactor, friction rows from zero): a leg's
+  // body contact is one persistent point when the single knee sphere carries it (mode 1) or when it is the blended contact
+  // (mode 2 with body_blend > 0: its position is continuous in the state) -- its normal row then starts from cfg.warmstart x
+  // the impulse of the tick before (0 if the row was outside the margin then), like a foot's.  Under the hard deepest-of-three
+  // choice (mode 2, body_blend = 0) the point changes identity from tick to tick, and in mode 3 the rows are the legacy
+  // frictionless set: no warm start there.
   bool any_margin = false;
   for (int l = 0; l < 4; l++) {
     if (!s.cfg.body_contacts) continue;
@@ -752,6 +760,7 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
       }
       const T pen = phi + T(s.cfg.contact_slop);
       target[rk] = (pen > 0) ? -pen / dt : -T(s.cfg.erp) * pen / dt;
+      if (body_warm) klam[rk] = T(s.cfg.warmstart) * e.lamb[l];
     }
   }
   // joint-limit rows (cfg.joint_limits; bounds of a1.py:186-195 = the URDF limits Bullet turns into btMultiBodyJointLimitConstraint
@@ -891,6 +900,7 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
     for (int k = 0; k < NV; k++) vel[k] += MiJt[r][k] * lam_of(r);
   }
   for (int l = 0; l < 4; l++) e.contact[l] = active[l] && e.lam[3 * l] > 0;
+  for (int l = 0; l < 4; l++) e.lamb[l] = (body_warm && kactive[body_row(l, 0)]) ? klam[body_row(l, 0)] : T(0);
   double* tr = (e.trace && e.trace_n < e.trace_cap) ? e.trace + (size_t)TRACE_W * e.trace_n++ : nullptr;
   if (tr) {
     unsigned long long am = 0, lm = 0;
@@ -1140,7 +1150,7 @@ template <class T> void reset_env(Sim<T>& s, Env<T>& e, T* obs) {
   e.pos[0] += e.reset_off[0]; e.pos[1] += e.reset_off[1];
   e.quat[0] = e.quat[1] = e.quat[2] = 0; e.quat[3] = 1;
   for (int j = 0; j < 12; j++) { e.q[j] = T(m.pose_ori[j]); e.qd[j] = 0; e.lam[j] = 0; e.tau[j] = 0; }
-  for (int l = 0; l < 4; l++) e.contact[l] = 0;
+  for (int l = 0; l < 4; l++) { e.contact[l] = 0; e.lamb[l] = 0; }
   e.tick = 0; e.energy = 0;
   std::memset(e.hist, 0, sizeof(e.hist));
   // ReceiveObservation before settling (a1.py:290): fill the whole ring with the
@@ -1309,6 +1319,7 @@ template <class T> void set_state(Env<T>& e, const T* st) {
   mat3T_mul_vec(R, st + 7, e.vb);
   mat3T_mul_vec(R, st + 10, e.wb);
   for (int j = 0; j < 12; j++) { e.q[j] = st[13 + j]; e.qd[j] = st[25 + j]; e.lam[j] = 0; }
+  for (int l = 0; l < 4; l++) e.lamb[l] = 0;
   // re-seed the latency ring with the new reading
   e.tick = -1;
   push_history(e);
@@ -1507,13 +1518,22 @@ template <class F> void par_for(int n, int threads, F f) {
     if (cap_ticks >= 0) { s->env[env].trace = buf; s->env[env].trace_cap = buf ? cap_ticks : 0; s->env[env].trace_n = 0; } \
     return n;                                                                                       \
   }                                                                                                 \
+  /* the solver's warm start [N,4,4]: per leg the foot's (n, t1, t2) and the body contact's normal impulse of the last tick */ \
   extern "C" void etgo_get_lambda##SFX(void* h, T* lam) {                                           \
     auto* s = (Sim<T>*)h;                                                                           \
-    for (int i = 0; i < s->N; i++) std::memcpy(lam + (size_t)i * 12, s->env[i].lam, sizeof(T) * 12); \
+    for (int i = 0; i < s->N; i++)                                                                  \
+      for (int l = 0; l < 4; l++) {                                                                 \
+        for (int k = 0; k < 3; k++) lam[(size_t)i * 16 + 4 * l + k] = s->env[i].lam[3 * l + k];     \
+        lam[(size_t)i * 16 + 4 * l + 3] = s->env[i].lamb[l];                                        \
+      }                                                                                             \
   }                                                                                                 \
   extern "C" void etgo_set_lambda##SFX(void* h, const T* lam) {                                     \
     auto* s = (Sim<T>*)h;                                                                           \
-    for (int i = 0; i < s->N; i++) std::memcpy(s->env[i].lam, lam + (size_t)i * 12, sizeof(T) * 12); \
+    for (int i = 0; i < s->N; i++)                                                                  \
+      for (int l = 0; l < 4; l++) {                                                                 \
+        for (int k = 0; k < 3; k++) s->env[i].lam[3 * l + k] = lam[(size_t)i * 16 + 4 * l + k];     \
+        s->env[i].lamb[l] = lam[(size_t)i * 16 + 4 * l + 3];                                        \
+      }                                                                                             \
   }                                                                                                 \
   extern "C" void etgo_etg_rbf##SFX(void* h, T t, T* r) { ((Sim<T>*)h)->basis.rbf(t, r); }         \
   extern "C" void etgo_etg_action##SFX(void* h, int env, T t, T* act) {                             \

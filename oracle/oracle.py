@@ -206,14 +206,20 @@ class OracleSim:
         tau = self._arr(tau, (self.N, 12))
         self._f("tick")(self._h, _p(tau), int(nticks))
 
-    def get_lambda(self):
-        lam = np.zeros((self.N, 12), dtype=self.dtype)
+    def get_lambda(self, full=False):
+        """the contact impulses of the last tick: [N,12] the feet's, per leg (n, t1, t2); full=True: [N,16] = per leg (foot n, t1,
+        t2, body contact's normal) -- everything the solver warm-starts from (etg_get_contact_impulses' layout)"""
+        lam = np.zeros((self.N, 16), dtype=self.dtype)
         self._f("get_lambda")(self._h, _p(lam))
-        return lam
+        return lam if full else np.ascontiguousarray(lam.reshape(self.N, 4, 4)[:, :, :3]).reshape(self.N, 12)
 
     def set_lambda(self, lam):
-        """install the feet's contact impulses [N,12] (the warm start of the next tick; set_state zeroes them)"""
-        lam = self._arr(lam, (self.N, 12))
+        """install the solver's warm start: [N,16] = per leg (foot n, t1, t2, body contact's normal impulse) of the last tick
+        (etg_set_contact_impulses), or [N,12] = the feet's only (body contacts start cold); set_state zeroes them"""
+        lam = np.asarray(lam, dtype=self.dtype)
+        if lam.shape == (self.N, 12):
+            lam = np.concatenate([lam.reshape(self.N, 4, 3), np.zeros((self.N, 4, 1), dtype=self.dtype)], axis=2).reshape(self.N, 16)
+        lam = self._arr(lam, (self.N, 16))
         self._f("set_lambda")(self._h, _p(lam))
 
     def dynamics_terms(self, env=0):

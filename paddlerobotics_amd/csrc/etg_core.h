@@ -195,6 +195,7 @@ template <class F> struct LaneState {
   F qx, qy, qz, qw;   // base orientation (xyzw, body -> world)
   V3<F> wb, vb;       // base twist in base coordinates
   F q[3], qd[3], lam[3];
+  F lamb;             // the normal impulse of this leg's body contact in the last tick (its warm start: K.warmstart_b)
   F contact;          // 1 if this lane's foot carried load in the last tick
   F energy;           // sum |tau qd| dt of this lane's joints since the step began
   int sweeps;         // PGS sweeps this wave executed since the step began (wave-uniform; not stored)
@@ -209,6 +210,7 @@ template <class F, class Ctx> ETG_HD LaneState<F> load_state(const Ctx& c, const
   for (int j = 0; j < 3; j++) {
     L.q[j] = c.ld_lane(leg, LG_Q + j); L.qd[j] = c.ld_lane(leg, LG_QD + j); L.lam[j] = c.ld_lane(leg, LG_LAM + j);
   }
+  L.lamb = c.ld_lane(leg, LG_LAMB);
   L.contact = c.ld_lane(leg, LG_CONTACT);
   L.energy = F(0.0f);
   L.sweeps = 0;
@@ -222,6 +224,7 @@ template <class F, class Ctx> ETG_HD void store_state(const Ctx& c, float* base,
   for (int j = 0; j < 3; j++) {
     c.st_lane(leg, LG_Q + j, L.q[j]); c.st_lane(leg, LG_QD + j, L.qd[j]); c.st_lane(leg, LG_LAM + j, L.lam[j]);
   }
+  c.st_lane(leg, LG_LAMB, L.lamb);
   c.st_lane(leg, LG_CONTACT, L.contact);
 }
 
@@ -646,7 +649,8 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
   // warm start: the normal impulse x K.warmstart, the friction impulses x K.warmstart_t (Bullet's multibody solver restarts
   // them from zero); inactive feet forget their impulse
   F l0 = actf * F(K.warmstart) * L.lam[0], l1 = actf * F(K.warmstart_t) * L.lam[1], l2 = actf * F(K.warmstart_t) * L.lam[2];
-  // the body rows: their own points' velocities, Baumgarte / speculative target like the foot's normal row, no warm start;
+  // the body rows: their own points' velocities, Baumgarte / speculative target like the foot's normal row; the normal row of
+  // the leg's ONE body contact (kBody = 1) starts from K.warmstart_b x its impulse of the tick before (physics_tick16), the rest at 0;
   // kbf[b][x]: A[3+b][3+x] / A[3+b][3+b] for the body rows x < b solved earlier in the leg's turn
   F ub[NBA], lb[NBA], cb[NBA], kbf[NBA][NBA];
 #pragma unroll
@@ -669,6 +673,16 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
     u2 = u2 + A[j][2][0] * b0 + A[j][2][1] * b1 + A[j][2][2] * b2;
 #pragma unroll
     for (int b = 0; b < NBR; b++) ub[b] = ub[b] + A[j][3 + b][0] * b0 + A[j][3 + b][1] * b1 + A[j][3 + b][2] * b2;
+  }
+  if constexpr (bfric) {   // the body normal's warm start enters every row's velocity like the feet's
+    lb[0] = actbf[0] * F(K.warmstart_b) * L.lamb;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const F bb0 = c.qbcast(lb[0], j);
+      u0 = u0 + A[j][0][3] * bb0; u1 = u1 + A[j][1][3] * bb0; u2 = u2 + A[j][2][3] * bb0;
+#pragma unroll
+      for (int b = 0; b < NBR; b++) ub[b] = ub[b] + A[j][3 + b][3] * bb0;
+    }
   }
   c.phase(7);
   // ---- projected Gauss-Seidel in the order of Bullet's btMultiBodyConstraintSolver::solveSingleIteration (the oracle's
@@ -971,6 +985,7 @@ ETG_HD void physics_tick(const Ctx& c, const KCfg& K, const TickPar4<F>& tp, Lan
     for (int i = 0; i < 3; i++) L.qd[i] = L.qd[i] + (Hinv[i][0] * sl0 + Hinv[i][1] * sl1 + Hinv[i][2] * sl2);
   }
   L.lam[0] = l0; L.lam[1] = l1; L.lam[2] = l2;
+  L.lamb = bfric ? lb[0] : zero;
   L.contact = sel_(act && (l0 > zero), one, zero);
   };   // finish_tick
   if (anyj) finish_tick(std::true_type{});
@@ -1486,6 +1501,7 @@ ETG_HD void reset_settle(const Ctx& c, const KCfg& K, LaneState<F>& L, float* ri
   L.vb = {F(0.0f), F(0.0f), F(0.0f)};
   F pose[3] = {c.par(PR_POSE), c.par(PR_POSE + 1), c.par(PR_POSE + 2)};
   for (int j = 0; j < 3; j++) { L.q[j] = pose[j]; L.qd[j] = F(0.0f); L.lam[j] = F(0.0f); }
+  L.lamb = F(0.0f);
   L.contact = F(0.0f);
   L.energy = F(0.0f);
   L.sweeps = 0;
@@ -1575,6 +1591,7 @@ ETG_HD void set_state_quad(const Ctx& c, const float* st, LaneState<F>& L, float
     L.qd[j] = c.ld_row_lane(st, ETG_STATE_DIM, 25 + j, 3);
     L.lam[j] = F(0.0f);
   }
+  L.lamb = F(0.0f);
   L.contact = F(0.0f);
   for (int sl = 0; sl < RING; sl++) ring_push(c, ring, sl, L);  // re-seed the latency ring
   // tick0: the HIP library passes settle_ticks + RING, so that every later reading is newer than the reset tick and comes

@@ -43,7 +43,7 @@ template <class F, class Ctx> ETG_HD State16<F> load_state16(const Ctx& c, const
   const F mj = c.jointf();
   L.q = mj * c.ld_joint(leg, LG_Q);
   L.qd = mj * c.ld_joint(leg, LG_QD);
-  L.lam = mj * c.ld_joint(leg, LG_LAM);
+  L.lam = c.ld_quad(leg, LG_LAM);            // joint lanes: the foot's (n, t1, t2); aux lane: the body contact's normal (LG_LAMB)
   L.contact = c.ld_legf(leg, LG_CONTACT);
   L.energy = F(0.0f);
   L.sweeps = 0;
@@ -54,7 +54,7 @@ template <class F, class Ctx> ETG_HD void store_state16(const Ctx& c, float* bas
   c.st_env(base, BS_QX, L.qx); c.st_env(base, BS_QY, L.qy); c.st_env(base, BS_QZ, L.qz); c.st_env(base, BS_QW, L.qw);
   c.st_env(base, BS_WX, L.wb.x); c.st_env(base, BS_WY, L.wb.y); c.st_env(base, BS_WZ, L.wb.z);
   c.st_env(base, BS_VX, L.vb.x); c.st_env(base, BS_VY, L.vb.y); c.st_env(base, BS_VZ, L.vb.z);
-  c.st_joint(leg, LG_Q, L.q); c.st_joint(leg, LG_QD, L.qd); c.st_joint(leg, LG_LAM, L.lam);
+  c.st_joint(leg, LG_Q, L.q); c.st_joint(leg, LG_QD, L.qd); c.st_quad(leg, LG_LAM, L.lam);
   c.st_legf(leg, LG_CONTACT, L.contact);
 }
 
@@ -391,8 +391,9 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
   // J_l H^-1 J_l^T.  (The 4-lane kernel contracts the same products on the matrix pipe; with one row per
   // lane the DPP form needs no accumulator shuffles and no MFMA latency padding.)
   // warm start (defined here: DPP source below): the normal row x K.warmstart, the friction rows x K.warmstart_t (Bullet's
-  // multibody solver restarts friction rows from zero); body rows start at 0
-  F lam = mj * rowf * sel_(s0, F(K.warmstart), F(K.warmstart_t)) * L.lam;
+  // multibody solver restarts friction rows from zero); the aux lane's body normal x K.warmstart_b (= warmstart when the body
+  // contact is one persistent point, 0 otherwise: etg_layout.h), the body contact's friction rows start at 0
+  F lam = rowf * sel_(s0, F(K.warmstart), sel_(c.sub_is(3), F(K.warmstart_b), F(K.warmstart_t))) * L.lam;
   F hj[3] = {HJ0, HJ1, HJ2};
   c.dpp_ready10(Z, hj, &lam);                                   // one fence for all broadcast sources of this phase
   F A[4][3];
@@ -494,6 +495,9 @@ ETG_HD void physics_tick16(const Ctx& c, const KCfg& K, const TickPar<F>& tp, St
     c.fmac_qb(ownk, hj[2], Jl2, 3);
 #pragma unroll
     for (int lp = 0; lp < 4; lp++) Ak[lp] = Ak[lp] + ownl[lp] * ownk;
+    // the body normals' warm start (K.warmstart_b; `lam` of the aux lanes) enters every first row's velocity, as the feet's did above
+#pragma unroll
+    for (int lp = 0; lp < 4; lp++) c.fmac_rbcast(u, lam, Ak[lp], 4 * lp + 3);
     c.phase_p(10);
   }
   // ---- the SECOND row set (body == true only): the two friction rows of the leg's body contact, t1 on sub-lane 1, t2 on

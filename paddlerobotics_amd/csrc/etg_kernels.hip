@@ -900,6 +900,9 @@ struct GpuCtx16 {
   // ---- memory (same SoA arrays as the 4-lane kernels)
   __device__ __forceinline__ float ld_joint(const float* p, int f0) const { return p[(size_t)(f0 + sc) * NL + col]; }
   __device__ __forceinline__ void st_joint(float* p, int f0, float v) const { if (gate && sub < 3) p[(size_t)(f0 + sub) * NL + col] = v; }
+  // four fields f0 .. f0 + 3, one per lane of the leg (LG_LAM .. LG_LAMB: the foot's three impulses and the body contact's normal)
+  __device__ __forceinline__ float ld_quad(const float* p, int f0) const { return p[(size_t)(f0 + sub) * NL + col]; }
+  __device__ __forceinline__ void st_quad(float* p, int f0, float v) const { if (gate) p[(size_t)(f0 + sub) * NL + col] = v; }
   __device__ __forceinline__ float ld_legf(const float* p, int f) const { return p[(size_t)f * NL + col]; }
   __device__ __forceinline__ void st_legf(float* p, int f, float v) const { if (gate && sub == 0) p[(size_t)f * NL + col] = v; }
   __device__ __forceinline__ float ld_env(const float* p, int f) const { return p[(size_t)f * N + env]; }
@@ -2706,10 +2709,10 @@ __global__ void __launch_bounds__(256) k_lam_io(KCfg K, DevState D, float* lam, 
   const int NL = 4 * K.n_env;
   if (col >= NL) return;
   const int env = col >> 2, leg = col & 3;
-  for (int k = 0; k < 3; k++) {
+  for (int k = 0; k < 4; k++) {   // LG_LAM .. LG_LAMB: the foot's (n, t1, t2) and the body contact's normal
     float* cell = D.leg + (size_t)(LG_LAM + k) * NL + col;
-    if (write) *cell = lam[(size_t)env * 12 + 3 * leg + k];
-    else lam[(size_t)env * 12 + 3 * leg + k] = *cell;
+    if (write) *cell = lam[(size_t)env * 16 + 4 * leg + k];
+    else lam[(size_t)env * 16 + 4 * leg + k] = *cell;
   }
 }
 extern "C" int etg_get_contact_impulses(EtgHandle* h, float* lam, void* stream) {

@@ -28,7 +28,7 @@ namespace etg {
 constexpr int RING = 64;  // ticks of history; latency <= 80 ms at dt = 2 ms needs 42
 
 enum { BS_PX, BS_PY, BS_PZ, BS_QX, BS_QY, BS_QZ, BS_QW, BS_WX, BS_WY, BS_WZ, BS_VX, BS_VY, BS_VZ, BS_N };
-enum { LG_Q = 0, LG_QD = 3, LG_LAM = 6, LG_CONTACT = 9, LG_N = 10 };
+enum { LG_Q = 0, LG_QD = 3, LG_LAM = 6, LG_LAMB = 9, LG_CONTACT = 10, LG_N = 11 };   // LG_LAMB = LG_LAM + 3: the body contact's normal impulse (the aux lane's fourth "joint" slot)
 // CT_RET/LEN/ALIVE: per-robot episode accumulators (return, length, alive mask) updated by every step
 // CT_FEXT: external force on the trunk COM (world frame, N), etg_set_external_force(); CT_PUSH: the random push of
 // etg_random_pushes() -- separate columns, the kernels apply their sum (a set force survives pushes and their clearing)
@@ -85,6 +85,8 @@ struct KCfg {
   int fric_pyramid;      // EtgConfig.friction_model == 1: per-direction clamp instead of the disc projection
   int pd_n;              // EtgConfig.pd_latency: n_steps_ago of the PD law's reading (minitaur.py:1185), -1 = off (true state)
   float pd_a;            // its blend_alpha (minitaur.py:1188)
+  float warmstart_b;     // warm-start factor of a leg's body contact's normal row: warmstart when the contact is one persistent point
+                         // (body_contacts 1, or 2 with body_blend > 0), else 0 (oracle: "Warm start" in tick())
   float warmstart_t;     // EtgConfig.warmstart_friction: warm-start factor of the friction rows (warmstart: the normal rows)
   float slop;            // EtgConfig.contact_slop: added to a contact's distance before the velocity target is formed
   float restitution;     // EtgConfig.foot_restitution (combined coefficient; 0 = off)
@@ -370,6 +372,7 @@ inline KCfg make_kcfg(const EtgConfig& c, const EtgRobotModel& m) {
     K.pd_n = n;
     K.pd_a = (float)((c.pd_latency - n * c.sim_dt) / c.sim_dt);
   }
+  K.warmstart_b = (c.body_contacts == 1 || (c.body_contacts == 2 && c.body_blend > 0)) ? (float)c.warmstart : 0.0f;
   K.warmstart_t = (float)c.warmstart_friction; K.slop = (float)c.contact_slop; K.restitution = (float)c.foot_restitution;
   K.strength_on = 0;
   K.stop_at_done = 1;

@@ -14,6 +14,7 @@ tensor; the work is done by hand-written gfx950 kernels behind the C-ABI of
 include/etgsim.h.  There is no CPU path.
 """
 import ctypes as C
+import time
 
 import numpy as np
 import torch
@@ -607,10 +608,50 @@ class BatchedQuadrupedEnv:
         if self.auto_reset or self._rand_force or self._hist_T > 0 or len(self._xcols) > 0:
             raise ValueError("%s: sub-batches are for envs without auto_reset, random pushes, observation history and extra sensors" % what)
 
-    def _group_streams(self, n):
-        if len(getattr(self, "_gstreams", ())) < n:
-            self._gstreams = [torch.cuda.Stream(device=self.device) for _ in range(n)]
-        return self._gstreams[:n]
+    def _group_streams(self, n, fresh=False):
+        """the n side streams of a split into n sub-batches (kept per n: tune_groups() may have picked them)"""
+        sets = self.__dict__.setdefault("_gstreams", {})
+        if fresh or n not in sets:
+            sets[n] = [torch.cuda.Stream(device=self.device) for _ in range(n)]
+        return sets[n]
+
+    def tune_groups(self, candidates=(2, 4), steps=15, tries=3):
+        """Pick the number of sub-batches for run_groups() / rollout_policy(fused=False, groups=G) by measurement; returns
+        (best G, {G: microseconds per control step}) with G = 1 always among the candidates.  Steps the robots (zero residual
+        action, restarts from the settle cache in between): call it before the reset that starts the real work.
+
+        Why measure: the gain comes from the sub-batches' kernels running CONCURRENTLY, which needs their streams on different
+        hardware queues.  The HIP runtime multiplexes streams onto 4 hardware queues (GPU_MAX_HW_QUEUES); two sub-batches that
+        land on one queue run one after the other, and a step kernel's duration is its slowest wavefront's whatever its size
+        -- so a collision costs ~2x instead of gaining ~10 % (profiles/r06_groups.txt).  A candidate that measures slower than
+        1.15 x the one-batch loop is retried on fresh streams (`tries` times) before it is given up."""
+        self._groups_ok("tune_groups")
+
+        def measure(G):
+            self.reset()
+            self.run_groups(steps, G)
+            torch.cuda.synchronize(self.device)
+            t0 = time.perf_counter()
+            self.run_groups(steps, G)
+            torch.cuda.synchronize(self.device)
+            return (time.perf_counter() - t0) / steps * 1e6
+        table = {1: min(measure(1) for _ in range(2))}
+        for G in candidates:
+            G = len(self.group_ranges(G))
+            if G <= 1 or G in table:
+                continue
+            best_t, best_streams = None, None
+            for k in range(max(1, int(tries))):
+                streams = self._group_streams(G, fresh=k > 0)
+                t = min(measure(G) for _ in range(2))
+                if best_t is None or t < best_t:
+                    best_t, best_streams = t, streams
+                if t <= 1.15 * table[1]:
+                    break
+            self._gstreams[G] = best_streams
+            table[G] = best_t
+        best = min(table, key=table.get)
+        return best, table
 
     def step_range(self, first, last, action, donef=None, want_info=False):
         """One control step of robots [first, last) only, enqueued on the CURRENT stream (etg_step_range).  `action` / `donef`
@@ -754,25 +795,25 @@ class BatchedQuadrupedEnv:
         self._last_view = self._obs_view()
         return ret, ln
 
-    def _rollout_policy_grouped(self, policy, n_steps, act_scale, precision, groups):
-        """predict() + step() per control step as in rollout_policy(fused=False), the batch split into `groups` sub-batches that
-        run their loops on their own streams: sub-batch g's step k + 1 is queued behind ITS step k only, so it starts when its
-        own slowest wavefront has finished (train.py:129-178's loop; per-robot results identical to groups = 1)."""
-        self._groups_ok("rollout_policy(groups=G)")
-        if policy.obs_dim != len(self._cols):
-            raise ValueError("the policy reads %d observation columns, the env shows %d" % (policy.obs_dim, len(self._cols)))
+    def run_groups(self, n_steps, groups, action_fn=None):
+        """The Gym loop (train.py:129-178) per sub-batch: n_steps control steps of every robot, the batch split into `groups`
+        sub-batches (group_ranges) whose loops run on their own streams -- sub-batch g's step k + 1 is queued behind ITS step k
+        only, so it starts when its own slowest wavefront has finished, not the batch's.  action_fn(g, first, last, act_rows)
+        is called on group g's stream before each of its steps and fills act_rows (the view [first:last] of the batch's action
+        array) from self.obs[first:last]; None = zero residual action (the open loop of pretrain.py:129-154).  Per-robot results
+        are those of groups = 1, bit for bit.  Returns (episode_return[N], episode_len[N])."""
+        self._groups_ok("run_groups")
         ranges = self.group_ranges(groups)
         cur = torch.cuda.current_stream(self.device)
         streams = self._group_streams(len(ranges))
-        full = len(self._cols) == A.OBS_DIM
-        act = torch.empty(self.num_envs, self.action_space.shape[0], device=self.device)
+        act = None if action_fn is None else torch.empty(self.num_envs, self.action_space.shape[0], device=self.device)
         for st in streams:
             st.wait_stream(cur)
         for _ in range(int(n_steps)):
-            for (lo, hi), st in zip(ranges, streams):
+            for g, ((lo, hi), st) in enumerate(zip(ranges, streams)):
                 with torch.cuda.stream(st):
-                    rows = self.obs[lo:hi] if full else self.obs[lo:hi].index_select(1, self._col_idx)
-                    policy.predict(rows, act_scale, precision, out=act[lo:hi])
+                    if action_fn is not None:
+                        action_fn(g, lo, hi, act[lo:hi])
                     _lib.check(self._lib.etg_step_range(self._h, lo, hi - lo, _ptr(act), None, _ptr(self.obs), _ptr(self.reward),
                                                         _ptr(self.done), None, self._stream()))
         for st in streams:
@@ -780,6 +821,17 @@ class BatchedQuadrupedEnv:
         self._keep_step = (act, None)
         self._last_view = self._obs_view()
         return self.episode_stats()
+
+    def _rollout_policy_grouped(self, policy, n_steps, act_scale, precision, groups):
+        """predict() + step() per control step as in rollout_policy(fused=False), per sub-batch on its own stream (run_groups)"""
+        if policy.obs_dim != len(self._cols):
+            raise ValueError("the policy reads %d observation columns, the env shows %d" % (policy.obs_dim, len(self._cols)))
+        full = len(self._cols) == A.OBS_DIM
+
+        def act_rows(g, lo, hi, out):
+            rows = self.obs[lo:hi] if full else self.obs[lo:hi].index_select(1, self._col_idx)
+            policy.predict(rows, act_scale, precision, out=out)
+        return self.run_groups(n_steps, groups, act_rows)
 
     def rollout_policy_record(self, policy, n_steps, act_scale=0.3, precision=0, noise=None):
         """rollout_policy that also records the episode (etg_rollout_policy_record): returns (ret [N], len [N], rec) with
@@ -880,14 +932,14 @@ class BatchedQuadrupedEnv:
         self._keep_state = st
 
     def get_contact_impulses(self):
-        """[N,12] the feet's contact impulses of the last tick, per leg (n, t1, t2): the contact solver's warm start"""
-        lam = torch.zeros(self.num_envs, A.NUM_MOTORS, device=self.device)
+        """[N,16] the contact impulses of the last tick the solver warm-starts from: per leg (foot n, t1, t2, body contact's normal)"""
+        lam = torch.zeros(self.num_envs, 16, device=self.device)
         _lib.check(self._lib.etg_get_contact_impulses(self._h, _ptr(lam), self._stream()))
         return lam
 
     def set_contact_impulses(self, lam):
         """install them (after set_state, which zeroes them): a re-created step then starts from the robot's own warm start"""
-        lam = self._f32(lam, (self.num_envs, A.NUM_MOTORS), "contact impulses")
+        lam = self._f32(lam, (self.num_envs, 16), "contact impulses")
         _lib.check(self._lib.etg_set_contact_impulses(self._h, _ptr(lam), self._stream()))
         self._keep_lam = lam
 

@@ -125,7 +125,7 @@ class EmuSim:
         self._l.emu_set_contact_impulses(self._h, _p(lam))
 
     def get_contact_impulses(self):
-        lam = np.zeros((self.N, 12), dtype=np.float32)
+        lam = np.zeros((self.N, 16), dtype=np.float32)
         self._l.emu_get_contact_impulses(self._h, _p(lam))
         return lam
 

@@ -201,6 +201,8 @@ struct EmuCtx16Base {
   // memory
   F16 ld_joint(const float* p, int f0) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = p[(size_t)(f0 + sc(r)) * NL() + col(r)]; return o; }
   void st_joint(float* p, int f0, F16 v) const { if (!gate) return; for (int r = 0; r < 16; r++) if (sub(r) < 3) p[(size_t)(f0 + sub(r)) * NL() + col(r)] = v.v[r]; }
+  F16 ld_quad(const float* p, int f0) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = p[(size_t)(f0 + sub(r)) * NL() + col(r)]; return o; }
+  void st_quad(float* p, int f0, F16 v) const { if (!gate) return; for (int r = 0; r < 16; r++) p[(size_t)(f0 + sub(r)) * NL() + col(r)] = v.v[r]; }
   F16 ld_legf(const float* p, int f) const { F16 o; for (int r = 0; r < 16; r++) o.v[r] = p[(size_t)f * NL() + col(r)]; return o; }
   void st_legf(float* p, int f, F16 v) const { if (!gate) return; for (int r = 0; r < 16; r += 4) p[(size_t)f * NL() + col(r)] = v.v[r]; }
   F16 ld_env(const float* p, int f) const { return F16(p[(size_t)f * N + env]); }
@@ -495,19 +497,19 @@ extern "C" void emu_rollout_openloop(void* h, int n_steps, int stop_at_done, flo
 #ifdef ETG_TRACE_TICKS
 extern "C" void emu_debug_set_trace(void* h, float* buf) { ((Emu*)h)->K.trace = buf; }
 #endif
-extern "C" void emu_set_contact_impulses(void* h, const float* lam) {   // [N,12] per leg (n, t1, t2): the warm start (after emu_set_state)
+extern "C" void emu_set_contact_impulses(void* h, const float* lam) {   // [N,16] per leg (n, t1, t2, body normal): the warm start (after emu_set_state)
   Emu* e = (Emu*)h;
   const size_t N = e->N, NL = 4 * N;
   for (size_t i = 0; i < N; i++)
     for (int l = 0; l < 4; l++)
-      for (int k = 0; k < 3; k++) e->leg[(size_t)(LG_LAM + k) * NL + 4 * i + l] = lam[i * 12 + 3 * l + k];
+      for (int k = 0; k < 4; k++) e->leg[(size_t)(LG_LAM + k) * NL + 4 * i + l] = lam[i * 16 + 4 * l + k];
 }
 extern "C" void emu_get_contact_impulses(void* h, float* lam) {
   Emu* e = (Emu*)h;
   const size_t N = e->N, NL = 4 * N;
   for (size_t i = 0; i < N; i++)
     for (int l = 0; l < 4; l++)
-      for (int k = 0; k < 3; k++) lam[i * 12 + 3 * l + k] = e->leg[(size_t)(LG_LAM + k) * NL + 4 * i + l];
+      for (int k = 0; k < 4; k++) lam[i * 16 + 4 * l + k] = e->leg[(size_t)(LG_LAM + k) * NL + 4 * i + l];
 }
 extern "C" void emu_get_state(void* h, float* st) {
   Emu* e = (Emu*)h;

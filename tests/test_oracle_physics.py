@@ -382,6 +382,11 @@ def _bullet_order_solve(sim, s0, lam_prev, tau, cfg, mu, sweeps, trace=None):
     reference's analytic leg Jacobian (a1.py:143-173).  Returns (lambda[12], joint-limit impulses[12], new generalized velocity)."""
     m = A.default_model()
     dt = cfg.sim_dt
+    lam_prev = np.asarray(lam_prev, dtype=np.float64)
+    body_prev = np.zeros(4)                 # the body contacts' normal impulses of the tick before ([16]: per leg n, t1, t2, body n)
+    if lam_prev.size == 16:
+        body_prev = lam_prev.reshape(4, 4)[:, 3].copy()
+        lam_prev = lam_prev.reshape(4, 4)[:, :3].reshape(12)
     M, C = sim.dynamics_terms()
     R = quat2mat(s0[3:7])
     v = np.concatenate([R.T @ s0[10:13], R.T @ s0[7:10], s0[25:37]])
@@ -420,7 +425,9 @@ def _bullet_order_solve(sim, s0, lam_prev, tau, cfg, mu, sweeps, trace=None):
             lam0.append(lam_prev[3 * l + k] * (cfg.warmstart if k == 0 else cfg.warmstart_friction))
     # body contacts (EtgConfig.body_contacts 1 / 2), stated independently of the oracle's row construction: the sphere centres from
     # plain rotation matrices, the deepest-of-three pick, and the joint columns of a row by CENTRAL DIFFERENCES of the contact
-    # point's base-frame position (the point rides on its link); rows ("bn" | "bt", leg), not warm-started
+    # point's base-frame position (the point rides on its link); rows ("bn" | "bt", leg).  The normal row starts from warmstart x its
+    # impulse of the tick before when the leg's contact is one persistent point (mode 1; mode 2 with the blended contact), like a
+    # foot's -- Bullet's persistent manifold point; the friction rows start at 0
     _bullet_order_solve.body_weights = {}
     if cfg.body_contacts in (1, 2):
         Rx = lambda a: np.array([[1, 0, 0], [0, np.cos(a), -np.sin(a)], [0, np.sin(a), np.cos(a)]])
@@ -478,7 +485,8 @@ def _bullet_order_solve(sim, s0, lam_prev, tau, cfg, mu, sweeps, trace=None):
                 rows.append(r)
                 tgt.append((-pen / dt if pen > 0 else -cfg.erp * pen / dt) if k == 0 else 0.0)
                 kind.append(("bn" if k == 0 else "bt", l))
-                lam0.append(0.0)
+                persistent = cfg.body_contacts == 1 or cfg.body_blend > 0
+                lam0.append(cfg.warmstart * body_prev[l] if (k == 0 and persistent) else 0.0)
     J = np.array(rows).reshape(-1, 18)
     lam = np.array(lam0)
     A_ = J @ Mi @ J.T
@@ -570,6 +578,7 @@ def test_sweeps_follow_bullets_row_order_in_an_independent_numpy_statement(case)
         s0, lam_prev = sim.get_state()[0].copy(), sim.get_lambda()[0].copy()
         tau = -row[21:33] * (s0[13:25] - A.INIT_MOTOR_ANGLES) - row[33:45] * s0[25:37]
         lam_ref, jl_ref, v_ref = _bullet_order_solve(sim, s0, lam_prev, tau, cfg, mu, K)
+        bi_first, wt_first = dict(_bullet_order_solve.body_impulses), dict(_bullet_order_solve.body_weights)
         sim.tick(tau[None], 1)
         s1, lam = sim.get_state()[0], sim.get_lambda()[0]
         scale = max(1e-3, np.abs(lam_ref).max())
@@ -577,16 +586,29 @@ def test_sweeps_follow_bullets_row_order_in_an_independent_numpy_statement(case)
         R1 = quat2mat(s1[3:7])                             # (the state holds world-frame velocities: through the NEW orientation)
         assert np.abs(s1[25:37] - v_ref[6:]).max() < 1e-8 * max(1.0, np.abs(v_ref).max())          # joint rates after the tick
         assert np.abs(R1.T @ s1[7:10] - v_ref[3:6]).max() < 1e-8 and np.abs(R1.T @ s1[10:13] - v_ref[0:3]).max() < 1e-8
+        # the NEXT tick starts warm: the feet's normals and the body contacts' normals from 0.1 x this tick's impulses
+        s0, warm = sim.get_state()[0].copy(), sim.get_lambda(full=True)[0].copy()
+        tau2 = -row[21:33] * (s0[13:25] - A.INIT_MOTOR_ANGLES) - row[33:45] * s0[25:37]
+        lam_ref2, _, v_ref2 = _bullet_order_solve(sim, s0, warm, tau2, cfg, mu, K)
+        body_ref2 = dict(_bullet_order_solve.body_impulses)
+        sim.tick(tau2[None], 1)
+        lam2, full2 = sim.get_lambda()[0], sim.get_lambda(full=True)[0].reshape(4, 4)
+        assert np.abs(lam2 - lam_ref2).max() < 1e-8 * max(1e-3, np.abs(lam_ref2).max()), (case, K, "second tick")
+        assert np.abs(sim.get_state()[0][25:37] - v_ref2[6:]).max() < 1e-8 * max(1.0, np.abs(v_ref2).max())
+        for l in range(4):
+            assert abs(full2[l, 3] - body_ref2.get(("bn", l), 0.0)) < 1e-8 * max(1e-3, np.abs(lam_ref2).max()), (case, K, l)
+        if case in ("kneeling", "belly", "shins_flat") and K >= 2:
+            assert warm.reshape(4, 4)[:, 3].max() > 1e-5              # (the second tick did start from loaded body normals)
         if case == "calf_at_its_stop":
             assert (jl_ref[2::3] > 0).sum() >= 3          # the stops pushed back
         if case in ("kneeling", "belly") and K >= 2:
-            bi = _bullet_order_solve.body_impulses       # the scenario does load body rows, normal and friction
+            bi = bi_first                                # the scenario does load body rows, normal and friction
             assert sum(1 for k, v in bi.items() if k[0] == "bn" and v > 1e-3) >= 2, bi
             assert any(k[0] == "bt" and abs(v) > 1e-4 for k, v in bi.items()), bi
         if case == "shins_flat":
-            wt = _bullet_order_solve.body_weights
+            wt = wt_first
             assert cfg.body_blend > 0 and any(0.2 < w.max() < 0.8 for w in wt.values()), wt          # the load IS shared
             if K >= 2:
-                assert sum(1 for k, v in _bullet_order_solve.body_impulses.items() if k[0] == "bn" and v > 1e-5) >= 1   # (the hind feet share the load)
+                assert sum(1 for k, v in bi_first.items() if k[0] == "bn" and v > 1e-5) >= 1   # (the hind feet share the load)
         if case == "sliding" and K == 6:
             assert any(abs(np.hypot(lam[3 * l + 1], lam[3 * l + 2]) - mu * lam[3 * l]) < 1e-9 for l in range(4) if lam[3 * l] > 0)
