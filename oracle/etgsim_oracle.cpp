@@ -327,6 +327,12 @@ template <class T> struct Sim {
   float noise_std[5] = {0, 0, 0, 0, 0};
   uint64_t noise_seed = 0;
   unsigned obs_calls = 0, noise_call = 0;
+  // TEST KNOB (etgo_set_solve_noise; tests/parity_util.OracleEnsemble): every impulse the contact solve returns is multiplied by
+  // 1 + solve_noise * U(-1, 1) (counter-based: robot, tick, row, seed) before it is applied -- a model of the rounding noise of an
+  // fp32 solve (incremental row velocities over tens of sweeps: ~5e-6 relative on the impulses of a hard landing, measured on the
+  // kernel source), so that an ensemble of oracles shows how far that noise moves a robot's trajectory.  0 (always, outside tests).
+  double solve_noise = 0;
+  uint64_t solve_noise_seed = 0;
   mutable T* dbgM = nullptr;  // optional taps (tests): 18x18 mass matrix, 18 bias
   mutable T* dbgC = nullptr;
   // tree description
@@ -889,6 +895,16 @@ template <class T> void physics_tick(const Sim<T>& s, Env<T>& e, const T* tau) {
   }
   e.sweep_hist[sweeps < 63 ? sweeps : 63]++;
   e.sweeps_total += sweeps;
+  if (s.solve_noise > 0) {   // test knob: see Sim::solve_noise
+    const uint64_t envi = (uint64_t)(&e - &s.env[0]);
+    for (int r = 0; r < NR; r++) {
+      if (!row_active(r)) continue;
+      uint64_t z = s.solve_noise_seed * 0x9E3779B97F4A7C15ull + (envi << 40) + ((uint64_t)e.tick << 8) + (uint64_t)r;
+      z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; z ^= z >> 31;
+      const double u01 = (double)(z >> 11) * (1.0 / 9007199254740992.0);
+      lam_of(r) = lam_of(r) * T(1.0 + s.solve_noise * (2.0 * u01 - 1.0));
+    }
+  }
   {
     bool loaded = false;
     for (int l = 0; l < 4; l++)
@@ -1517,6 +1533,10 @@ template <class F> void par_for(int n, int threads, F f) {
     const int n = s->env[env].trace_n;                                                              \
     if (cap_ticks >= 0) { s->env[env].trace = buf; s->env[env].trace_cap = buf ? cap_ticks : 0; s->env[env].trace_n = 0; } \
     return n;                                                                                       \
+  }                                                                                                 \
+  extern "C" void etgo_set_solve_noise##SFX(void* h, double rel, uint64_t seed) {                    \
+    auto* s = (Sim<T>*)h;                                                                           \
+    s->solve_noise = rel; s->solve_noise_seed = seed;                                               \
   }                                                                                                 \
   /* the solver's warm start [N,4,4]: per leg the foot's (n, t1, t2) and the body contact's normal impulse of the last tick */ \
   extern "C" void etgo_get_lambda##SFX(void* h, T* lam) {                                           \

@@ -206,6 +206,13 @@ class OracleSim:
         tau = self._arr(tau, (self.N, 12))
         self._f("tick")(self._h, _p(tau), int(nticks))
 
+    def set_solve_noise(self, rel, seed=0):
+        """TEST KNOB: every impulse a tick's contact solve returns is multiplied by 1 + rel * U(-1, 1) before it is applied -- the
+        rounding noise of an fp32 solve, for the members of tests/parity_util.OracleEnsemble (Sim::solve_noise in the C++)"""
+        f = self._f("set_solve_noise")
+        f.argtypes = [C.c_void_p, C.c_double, C.c_uint64]
+        f(self._h, float(rel), int(seed))
+
     def get_lambda(self, full=False):
         """the contact impulses of the last tick: [N,12] the feet's, per leg (n, t1, t2); full=True: [N,16] = per leg (foot n, t1,
         t2, body contact's normal) -- everything the solver warm-starts from (etg_get_contact_impulses' layout)"""

@@ -92,7 +92,7 @@ def emu_tick_rows(tr, i, t):
                 phi_f=[float(x[4 * leg, 1]) for leg in range(4)], phi_b=[float(x[4 * leg + 3, 1]) for leg in range(4)])
 
 
-def first_decision_gap(emu_tr, i, orc_tr, margin=0.02):
+def first_decision_gap(emu_tr, i, orc_tr, margin=0.02, sweeps=True):
     """the first physics tick of a control step at which the kernel source (emulation trace of robot i) and an oracle (trace_rows of
     the robot) DECIDE differently -> (tick, kind, text) or None.  kinds: "sphere" (another sphere of a leg's body contact is the
     deepest), "active" (a row inside the margin / a joint at its stop in one only), "loaded" (a normal row carries load in one
@@ -115,7 +115,7 @@ def first_decision_gap(emu_tr, i, orc_tr, margin=0.02):
         if g["loaded"] != o_ld:
             rows = _bits(g["loaded"] ^ o_ld)
             return t, "loaded", "tick %d: normal rows loaded in one evaluation only: %s" % (t, [ROW_NAMES[r] for r in rows])
-        if sw != o_sw:
+        if sweeps and sw != o_sw:
             return t, "sweeps", "tick %d: %d sweeps in the kernel source, %d in the oracle" % (t, sw, o_sw)
     return None
 
@@ -143,6 +143,16 @@ def lockstep_offenders(run, probe, ens, emu, steps, action_fn, floor_q=2e-5, flo
     import torch
     n = run.num_envs
     etr = emu.set_trace(True)
+    # on a tracing build of the library (tools/build_variant.sh trace -DETG_TRACE_TICKS; ETG_LIB=...) the GPU's own tick trace of
+    # the probe's step is read as well: the first differing decision is then the GPU's, not inferred through the emulation
+    gtr = None
+    lib = getattr(probe, "_lib", None)
+    if lib is not None and hasattr(lib, "etg_debug_set_trace") and getattr(probe, "lanes_per_robot", 0) == 16:
+        import ctypes as C
+        gtr_t = torch.zeros(n, 16, 16, 10, device=probe.device)
+        lib.etg_debug_set_trace.argtypes = [C.c_void_p, C.c_void_p]
+        assert lib.etg_debug_set_trace(probe._h, C.c_void_p(gtr_t.data_ptr())) == 0
+        gtr = gtr_t
     tally = dict(pairs=0, nominal=0, other=0, none=0)
     out = []
     for k in range(steps):
@@ -176,6 +186,11 @@ def lockstep_offenders(run, probe, ens, emu, steps, action_fn, floor_q=2e-5, flo
             if emu_gap <= 10 * floor_q:
                 d = first_decision_gap(etr, int(i), otr[i, :ocnt[i]], float(ens.cfg.contact_margin))
                 kind, text = (d[1], d[2]) if d else ("smooth", "no tick with a differing decision: a smooth gap")
+            if gtr is not None:                          # the GPU's own trace (its sweep counts are the WAVE's: not compared)
+                d = first_decision_gap(gtr.cpu().numpy(), int(i), otr[i, :ocnt[i]], float(ens.cfg.contact_margin), sweeps=False)
+                kind, text = (d[1], "GPU trace: " + d[2]) if d else (kind, text + "; GPU trace: no tick with a differing row set")
+                per = [emu_tick_rows(gtr.cpu().numpy(), int(i), t)["sweeps_cum"] for t in range(13)]
+                text += "; wave sweeps per tick on the GPU %s, oracle (this robot) %s" % (list(np.diff([0] + per)), [int(x) for x in otr[i, :ocnt[i], 3]])
             ties = oracle_pick_changes(otr[i, :ocnt[i]])
             if ties:
                 text += "; in the fp64 oracle's own step the sphere under the body contact changes at (tick, leg) %s" % ties[:4]
