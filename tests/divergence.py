@@ -172,13 +172,15 @@ def lockstep_offenders(run, probe, ens, emu, steps, action_fn, floor_q=2e-5, flo
         sg = probe.get_state().cpu().numpy().astype(np.float64)
         so, mem = ens.get_state(), ens.member_states()
         se = emu.get_state().astype(np.float64)
+        from tests.parity_util import one_step_verdict
         dq = np.stack([np.abs(sg - m)[:, 13:25].max(1) for m in [so] + mem])
-        dp = np.stack([np.abs(sg - m)[:, :7].max(1) for m in [so] + mem])
-        on = (dq <= floor_q) & (dp <= floor_p)
+        nq, aq, _, _ = one_step_verdict(sg[:, 13:25], so[:, 13:25], [m[:, 13:25] for m in mem], floor_q)
+        npz, ap, _, _ = one_step_verdict(sg[:, :7], so[:, :7], [m[:, :7] for m in mem], floor_p)
+        on_nom, on_any = nq & npz, aq & ap
         tally["pairs"] += n
-        tally["nominal"] += int(on[0].sum())
-        tally["other"] += int((on.any(0) & ~on[0]).sum())
-        bad = np.nonzero(~on.any(0))[0]
+        tally["nominal"] += int(on_nom.sum())
+        tally["other"] += int((on_any & ~on_nom).sum())
+        bad = np.nonzero(~on_any)[0]
         tally["none"] += len(bad)
         for i in bad:
             emu_gap = float(np.abs(se[i] - sg[i])[13:25].max())

@@ -70,7 +70,7 @@ def test_round4_options_match_oracle(lanes, option):
         mk.update(warmstart=0.85, warmstart_friction=0.85); ok.update(warmstart=0.85, warmstart_friction=0.85)
     else:
         mk.update(friction_model=1, contact_slop=0.0); ok.update(friction_model=1, contact_slop=0.0)
-    env, ens = _make(n, **mk), OracleEnsemble(n, E=3, seed=31, **ok)
+    env, ens = _make(n, **mk), OracleEnsemble(n, E=5, E64=3, seed=31, **ok)
     orc = ens.nominal
     acts = [rng.uniform(-scale, scale, size=(n, 12)) for _ in range(4 if option == "strength_torque_mode" else 12)]
     eg, sp, wp = _run_pair(env, ens, acts, strength, W, B)

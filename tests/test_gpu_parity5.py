@@ -5,9 +5,9 @@
     from then on say nothing about it.  Here every control step is checked on its own: the GPU's state before the step (fp32,
     read through the C-ABI: etg_get_state + etg_get_contact_impulses, the solver's warm start) is installed in a second GPU env
     AND in the oracles (etg_set_state semantics on both sides: latency ring re-seeded), both take the step with the same
-    action, and the results are compared -- for every robot and every step.  The criterion is the sharp one (tests/parity_util.nearest_member): the GPU's result must lie within the
-    floor of the result of the fp64 oracle, of the fp32 oracle or of one of E fp64 oracles whose action is nudged by +-1 fp32
-    ulp.  A step map with a discontinuity has several branches; the GPU has to be ON one of them.  The [parity] line lists how
+    action, and the results are compared -- for every robot and every step.  The criterion (tests/parity_util.one_step_verdict): the GPU's result must lie within the floor (+ 4 x the
+    spread of the members on that branch) of the result of the fp64 oracle or of a member of the ensemble -- the fp32 oracle,
+    oracles with actions nudged by +-1 fp32 ulp and the solve's own rounding noise, oracles with a nudged stopping threshold.  A step map with a discontinuity has several branches; the GPU has to be ON one of them.  The [parity] line lists how
     many (robot, step) pairs were on the nominal branch, how many on another member's, and none may be on no branch.
   * the named regression cases the round-5 review asked for (the 8.5e-3 rad robot of test_residual_rule_matches_oracle[flat-16]
     and the two failed fuzz trials) with a first-divergent-step report: tests/test_gpu_regressions.py.
@@ -23,7 +23,7 @@ pytestmark = pytest.mark.gpu
 torch = pytest.importorskip("torch")
 
 from tests.test_gpu_parity import _need_gpu, _etg_params, _make   # noqa: E402
-from tests.parity_util import OracleEnsemble, nearest_member, ulp_nudge, NCPU   # noqa: E402
+from tests.parity_util import OracleEnsemble, nearest_member, one_step_verdict, ulp_nudge, NCPU   # noqa: E402
 
 
 def _rolling_hills():
@@ -66,12 +66,11 @@ def one_step_consistency(env_kw, orc_kw, n, steps, seed, amp, floor_q, floor_p, 
         sg = probe.get_state().cpu().numpy().astype(np.float64)
         so = ens.get_state()
         mem = ens.member_states()
-        dq, iq = nearest_member(sg[:, 13:25], so[:, 13:25], [m[:, 13:25] for m in mem], floor_q)
-        dp, _ = nearest_member(sg[:, :7], so[:, :7], [m[:, :7] for m in mem], floor_p)
-        d_nom = np.abs(sg - so)[:, 13:25].max(1)
+        nq, aq, d_nom, dq = one_step_verdict(sg[:, 13:25], so[:, 13:25], [m[:, 13:25] for m in mem], floor_q)
+        npz, ap, _, dp = one_step_verdict(sg[:, :7], so[:, :7], [m[:, :7] for m in mem], floor_p)
         fin = np.isfinite(sg).all(1)
-        on_nom = d_nom <= floor_q
-        on_any = (dq <= floor_q) & (dp <= floor_p)
+        on_nom = nq & npz
+        on_any = aq & ap
         tally["pairs"] += n
         tally["nominal"] += int(on_nom.sum())
         tally["other"] += int((on_any & ~on_nom).sum())
