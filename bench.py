@@ -46,7 +46,7 @@ CLOCK_WARM_STEPS = 600     # untimed scratch-env steps (~22 ms) right before eve
 # `rocprofv3 --pmc` passes of this same command (tools/pmc_gpu.sh), summarised per kernel and control step in this file.
 # The file is stamped with the hash of the kernel sources it was collected on (tools/make_pmc_json.py); when the sources have
 # changed since, the figures are reported as STALE (roofline.traffic = null) instead of being passed off as this build's.
-PMC_FILE = os.path.join(ROOT, "profiles", "r05_pmc.json")
+PMC_FILE = os.path.join(ROOT, "profiles", "r06_pmc.json")
 VALU_PEAK_GUIDE = 0.5              # MI355X_MICROARCH.md: a SIMD issues one wave64 VALU instruction every 2 cycles
 VALU_PEAK_MEASURED = 0.384         # tools/ubench/occupancy_rate.hip: 8 resident waves of v_fma_f32 per SIMD
 NOMINAL_HZ = 2.4e9
@@ -522,8 +522,8 @@ def main():
         value = world * N * K / elapsed
         bytes_per = BYTES_PER_STEP_CFG3 if args.config == 3 else BYTES_PER_STEP_CFG2
         kname = ("k_rollout16" if fused else "k_step16") if lanes == 16 else ("k_rollout" if fused else "k_step")
-        if fused and policy is not None:
-            kname = "k_rollout_policy16"
+        if fused and policy is not None:   # fp32 operands: one wave = 4 robots + their policy tile (round 6); bf16: the workgroup tile
+            kname = ("k_rollout_policy16w" if args.precision == 0 else "k_rollout_policy16") if lanes == 16 else "k_rollout_policy"
         achieved = bytes_per * N / (kern_ms * 1e-3)
         pmc, pmc_state = {}, "absent"
         try:

@@ -2119,7 +2119,11 @@ static inline void launch_rollout_noise(EtgHandle* h, int n, float* obs, hipStre
   } while (0)
 #define LAUNCH16_X_(F_, K_, P_) launch_(std::integral_constant<bool, F_>{}, std::integral_constant<bool, K_>{}, std::integral_constant<bool, P_>{})
 
-// 4-lane kernels: {flat ground, heightfield} x {plain robot layer, all options, all options + 1 body row per leg, + 3 body rows}
+// 4-lane kernels: {flat ground, heightfield} x {plain robot layer, all options, all options + 1 body row per leg, + 3 body rows}.
+// A plain robot layer WITH body rows (the default configuration beyond 8192 robots) runs the all-options instantiation: the
+// PLAIN specialisation is worth ~3 % where the tick fits the register file, but the 4-lane tick with body rows is at the
+// 512-register budget with 528-544 B of scratch either way (profiles/r06_isa_baseline.json: k_rollout<flat, all options, 1>), its
+// time is the spills' and the sweeps', and every further instantiation of it costs ~70 s of build for the six 4-lane kernels.
 #define LAUNCH4(KERN, grid, stream, ...)                                                                              \
   do {                                                                                                                \
     const bool pl_ = plain_config(h->K);                                                                              \
@@ -2656,7 +2660,6 @@ extern "C" int etg_rollout_policy_record(EtgHandle* h, EtgPolicy* pol, int n_ste
   for (int done_steps = 0; done_steps < n_steps; done_steps += ROLLOUT_CHUNK) {
     const int m = n_steps - done_steps < ROLLOUT_CHUNK ? n_steps - done_steps : ROLLOUT_CHUNK;
     advance_obs_stream(h, m);
-    const bool kn = h->K.knee != 0, pl = plain_config(h->K);
     const bool per_wave = precision == 0 && pol->in_dim <= 4 * pol::KQ1 && pol->out_dim <= 12;
     const RecOut R = {rec_obs + (size_t)done_steps * N * ETG_OBS_DIM, rec_act + (size_t)done_steps * N * ETG_ACT_DIM,
                       rec_reward + (size_t)done_steps * N, rec_done + (size_t)done_steps * N,

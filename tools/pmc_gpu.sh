@@ -33,7 +33,7 @@ for name in ("fetch", "write", "valu", "lds", "mfma"):
     if not fs: print(name, "no output"); continue
     acc = collections.defaultdict(list)
     for r in csv.DictReader(open(fs[0])):
-        m = re.search(r"::(k_step16|k_rollout16|k_rollout_policy16|k_step|k_rollout|k_policy)<", r["Kernel_Name"])   # etg:: or (anonymous namespace)::
+        m = re.search(r"::(k_step16|k_rollout16|k_rollout_policy16w|k_rollout_policy16|k_step|k_rollout|k_policy)<", r["Kernel_Name"])   # etg:: or (anonymous namespace)::
         if m:
             acc[(m.group(1), r["Counter_Name"])].append(float(r["Counter_Value"]))
     for (kern, k), v in sorted(acc.items()):
