@@ -316,7 +316,7 @@ def main():
     step_groups = [1]     # sub-batches of the stepping legs (env.run_groups): 1 = one launch per control step
 
     def run_steps(e, pol, n, fused):
-        """n control steps of the hot path: the fused rollouts (etg_rollout_openloop / etg_rollout_policy, <= 50 control steps
+        """n control steps of the hot path: the fused rollouts (etg_rollout_openloop / etg_rollout_policy, <= 400 control steps
         per launch) or env.step() per control step (policy.predict() before each in closed loop)"""
         if n <= 0:
             return e.episode_stats()
@@ -484,7 +484,7 @@ def main():
             m = float(np.median(wl))
             extra["config3"] = {"value": world * N * K / m, "ms_per_step": m / K * 1e3, "kernel_ms_per_step": float(np.median(kn)),
                                 "survivors": sv, "note": "configs[2]: ETG + residual MLP policy (random init, fp32 MFMA), "
-                                "etg_rollout_policy: policy tile + control step fused, <= 50 control steps per launch"}
+                                "etg_rollout_policy: policy tile + control step fused, <= 400 control steps per launch"}
             if args.precision == 0:     # the opt-in bf16 tile next to it (reduced precision: a side note, never the config-3 number)
                 args.precision = 1
                 try:
@@ -569,8 +569,8 @@ def main():
                        "scratch env to keep the clocks up, barrier + synchronize, %d timed steps + return gather, barrier + synchronize, "
                        "max over ranks" % (args.warmup, CLOCK_WARM_STEPS, K)},
             "path": ("env.step per control step" if not fused else
-                     "etg_rollout_openloop: fused kernel, up to 50 control steps per launch" if policy is None else
-                     "etg_rollout_policy: policy MFMA tile + control step fused, up to 50 control steps per launch"),
+                     "etg_rollout_openloop: fused kernel, up to 400 control steps per launch" if policy is None else
+                     "etg_rollout_policy: policy MFMA tile + control step fused, up to 400 control steps per launch"),
             "roofline": {"bound": "hbm", "kernel": "etg::" + kname, "achieved": achieved / 1e9, "peak": HBM_PEAK / 1e9,
                          "unit": "GB/s", "frac": achieved / HBM_PEAK,
                          "traffic": (traffic * N / 4096.0) if traffic else None,

@@ -347,7 +347,7 @@ int etg_set_rollout_mode(EtgHandle* h, int simulate_finished);
 /* Measurement: the shader-clock cycles every wavefront spent in each launch of the LAST etg_rollout_openloop call, cycles
  * [launches][waves] int64 (device pointer; NULL = only report the two sizes).  A launch lasts as long as its slowest wave: the
  * sum over the launches of the largest entry against the mean of the waves' totals says how unevenly the contact solver's
- * sweeps load the wavefronts (bench.py: "imbalance").  A rollout is cut into launches of 50 control steps; the environment
+ * sweeps load the wavefronts (bench.py: "imbalance").  A rollout is cut into launches of 400 control steps; the environment
  * variable ETG_ROLLOUT_CHUNK changes that for a process (a measurement aid: profiles/r06_chunk_sweep.txt).            */
 int etg_rollout_wave_cycles(EtgHandle* h, int64_t* cycles, int capacity, int* launches, int* waves, void* stream);
 /* open-loop rollout: n_steps x etg_step(action = 0) enqueued back-to-back
@@ -357,7 +357,7 @@ int etg_rollout_wave_cycles(EtgHandle* h, int64_t* cycles, int capacity, int* la
 int etg_rollout_openloop(EtgHandle* h, int n_steps, float* obs, float* ret, int32_t* len,
                          void* stream);
 
-/* n_steps control steps over a caller-supplied action tape, fused (<= 50 control steps per launch, robot state and control
+/* n_steps control steps over a caller-supplied action tape, fused (<= 400 control steps per launch, robot state and control
  * variables in registers in between): actions [n_steps,N,12] (device, already scaled: what etg_step takes), step s applies
  * row block s.  The loops it serves know their commands in advance: the dynamics-identification evaluator replays 2 x 100
  * recorded joint targets and reads info["joint_angle"] and info["obs-IMU"] after every step
@@ -408,7 +408,7 @@ int etg_policy_sample(EtgPolicy* p, const float* obs, int n, const float* noise,
                       int precision, float* act, float* logp, void* stream);
 void etg_policy_destroy(EtgPolicy* p);
 
-/* closed-loop rollout with a fixed actor in ONE kernel per 50 control steps (run_EStrain_episode / run_evaluate_episodes,
+/* closed-loop rollout with a fixed actor in ONE kernel per 400 control steps (run_EStrain_episode / run_evaluate_episodes,
  * train.py:182-249): per step action = tanh(mean(obs)) * act_scale as etg_policy_forward computes it, then one
  * control step; a workgroup keeps its 16 robots' observations, actions and states on chip between the steps.
  * obs [N,49]: in = the current observation (as left by etg_reset / etg_step), out = the final one.  The actor sees the

@@ -1926,7 +1926,7 @@ struct EtgHandle {
   // etg_rollout_wave_cycles: [launches of the last open-loop rollout][wavefronts] shader-clock cycles, written by the launches
   long long* wave_cycles;
   int wc_cap, wc_launches, wc_waves;
-  int rollout_chunk;            // control steps per fused launch (50; ETG_ROLLOUT_CHUNK overrides it: a measurement aid)
+  int rollout_chunk;            // control steps per fused launch (400: one launch for BASELINE's episode; 25 .. 400 measured, profiles/r06_chunk_sweep.txt; ETG_ROLLOUT_CHUNK overrides it: a measurement aid)
   float *tmp_obs, *tmp_reward;  // sinks for etg_rollout_openloop
   uint8_t* tmp_done;
   // etg_prepare_next_dynamics: rows waiting for the robots' next episodes + the scratch state / ring / flags its settle runs on
@@ -2019,7 +2019,7 @@ extern "C" int etg_create(const EtgConfig* cfg, const EtgRobotModel* model, int 
   h->nx_mask = nullptr;
   h->wave_cycles = nullptr;
   h->wc_cap = h->wc_launches = h->wc_waves = 0;
-  h->rollout_chunk = 50;
+  h->rollout_chunk = 400;   // (a 400-step launch lasts ~37 ms; fewer launches = fewer chip-wide barriers: 93.3 us per step against 94.0 at 50)
   if (const char* e = getenv("ETG_ROLLOUT_CHUNK")) {
     const int v = atoi(e);
     if (v >= 1 && v <= 100000) h->rollout_chunk = v;

@@ -766,7 +766,7 @@ class BatchedQuadrupedEnv:
     def rollout_policy(self, policy, n_steps, act_scale=0.3, precision=0, fused=None, groups=1):
         """n_steps closed-loop control steps with a fixed actor (policy.predict semantics); returns (episode_return[N],
         episode_len[N]).  The batched run_EStrain_episode / run_evaluate_episodes (train.py:182-249).  fused: True = the
-        fused kernel (actor MLP + control step, 50 steps per launch; FusedKernelUnavailable when the configuration is outside
+        fused kernel (actor MLP + control step, up to 400 steps per launch; FusedKernelUnavailable when the configuration is outside
         it), False = policy.predict() + step() per control step, None = whichever is faster for this env: the fused kernel
         on the 16-lane mapping (7-13 % ahead), and on the 4-lane mapping only without body rows (there it is level with
         stepping; with body rows its 512-register budget spills and it is 25 % behind -- tools/closed_loop_probe.py)."""

@@ -21,7 +21,7 @@ def run_episodes(env, max_step, ETG_w=None, ETG_b=None, policy=None, action_boun
     donef=(steps > max_step)); returns per-robot (episode_return, episode_length) with alive masking."""
     env.reset(ETG_w=ETG_w, ETG_b=ETG_b, dynamic_param=dynamic_param)
     if policy is None and not getattr(env, "_rand_force", False):
-        # open loop: the fused rollout (etg_rollout_openloop, up to 50 control steps per launch).  The forced `done`
+        # open loop: the fused rollout (etg_rollout_openloop, up to 400 control steps per launch).  The forced `done`
         # of the last step only ends the episode; return and length are the same as with the stepping loop.
         return env.rollout_openloop(max_step + 1)
     if policy is not None and hasattr(env, "rollout_policy") and not getattr(env, "_rand_force", False):

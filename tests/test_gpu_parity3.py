@@ -363,11 +363,13 @@ def test_pyramid_friction_option_matches_oracle(lanes):
 
 @pytest.mark.parametrize("lanes", [4, 16])
 @pytest.mark.parametrize("variant", ["default", "etg0_filter", "heightfield"])
-def test_action_tape_rollout_equals_stepping(lanes, variant):
-    """etg_rollout_actions (one launch per 50 control steps, commands known in advance) against env.step() with the same
+def test_action_tape_rollout_equals_stepping(lanes, variant, monkeypatch):
+    """etg_rollout_actions (one launch per ROLLOUT_CHUNK control steps -- 400 by default, 50 here so that the continuation from
+    one launch to the next is part of the test --, commands known in advance) against env.step() with the same
     actions: bookkeeping exact (lengths, done bytes), trajectories to the rounding noise two kernels of the same source
     differ by (FMA contraction; cf. test_fused_rollout_equals_stepping), every recorded column against the stepped info."""
     _need_gpu()
+    monkeypatch.setenv("ETG_ROLLOUT_CHUNK", "50")      # (read by etg_create)
     n, T = 64, 60                          # 60 > 50: two launches
     # (toe spheres only: two kernels of one source agree to rounding, and a gripping knee sphere amplifies rounding past any
     # fixed bound within tens of steps -- the default contact set is compared through distributions and against the oracle)
@@ -422,12 +424,13 @@ def test_action_tape_rollout_equals_stepping(lanes, variant):
     a.close(); b.close()
 
 
-def test_dynamics_identification_evaluator_fused_equals_stepping(golden):
-    """make_dynamics_id_evaluator through the action-tape rollout (2 launches per 100-step replay) gives the fitness of the
+def test_dynamics_identification_evaluator_fused_equals_stepping(golden, monkeypatch):
+    """make_dynamics_id_evaluator through the action-tape rollout (2 launches per 100-step replay: ROLLOUT_CHUNK 50) gives the fitness of the
     env.step() loop (Dynamic_parallel_model.py:53-77) -- and how long a generation takes either way."""
     _need_gpu()
     import time
     from paddlerobotics_amd import rollout as R
+    monkeypatch.setenv("ETG_ROLLOUT_CHUNK", "50")
     n, T = 256, 100
     g = golden("dynid")
     POSE = A.INIT_MOTOR_ANGLES

@@ -120,44 +120,32 @@ def test_one_step_consistency_under_the_reference_randomisation():
 
 
 def test_closed_loop_kernels_on_a_forced_body_scene_robot_by_robot():
-    """The default contact set where it matters: 64 robots dropped from a crouch onto folded legs (knee / shin spheres loaded from
-    the first steps on, joints at their stops) run the closed loop -- actor + control step -- three ways on the GPU: the fused
-    kernel (k_rollout_policy16w), the RECORDING kernel (k_rollout_policy16w_rec: every step's row on the tape) and predict() +
-    step() (k_step16), all with finished robots simulated on so that every robot is compared at every step.  Each against the
-    oracle ensemble's closed loop from the same state, robot by robot (sens_robots); and the tape's rows against the stepping
-    loop's rows step by step."""
+    """The default contact set where it matters: 64 walking robots pushed over sideways (30 .. 90 N on the trunk: knee, shin and
+    trunk-corner spheres load from the sixth step on, every robot's by the end) run the closed loop -- actor + control step --
+    three ways on the GPU: the fused kernel (k_rollout_policy16w), the RECORDING kernel (k_rollout_policy16w_rec: every step's
+    row on the tape) and predict() + step() (k_step16), all with finished robots simulated on so that every robot is compared at
+    every step.  Each against the oracle ensemble's closed loop, robot by robot (sens_robots); and the tape's rows against the
+    stepping loop's rows step by step."""
     _need_gpu()
     from tests.test_gpu_parity2 import _policy
-    n, T = 64, 10
+    n, T = 64, 16
     pol, ws = _policy()
+    W, B = _etg_params(n, seed=43)
+    f = np.zeros((n, 3)); f[:, 1] = np.linspace(30.0, 90.0, n)
     envs = [_make(n) for _ in range(3)]
     ens = OracleEnsemble(n, E=4, seed=41)
-    rng = np.random.default_rng(41)
+    ens.set_params(etg_w=W, etg_b=B)
     for e in envs:
-        e.reset()
+        e.reset(ETG_w=W, ETG_b=B)
+        e.set_external_force(torch.as_tensor(f, dtype=torch.float32))
         e.set_rollout_mode(simulate_finished=True)
     ens.reset()
-    st = ens.get_state().copy()
-    st[:, 2] = 0.16 + 0.01 * rng.uniform(size=n)
-    st[:, 7:13] = 0.0
-    st[:, 13:25] = np.tile([0.0, 1.2, -2.55], 4)[None, :] + 0.03 * rng.normal(size=(n, 12))
-    st[:, 25:37] = 0.0
-    st = st.astype(np.float32).astype(np.float64)
-    for e in envs:
-        e.set_state(torch.as_tensor(st, dtype=torch.float32))
-    ens.set_state(st)
-    # (set_state leaves the observation row to the next step: one zero-action step on every side makes the first policy input)
-    z = np.zeros((n, 12), np.float32)
-    for e in envs:
-        e.step(torch.as_tensor(z), want_info=False)
-    ens.step(z, want_info=False)
+    ens.set_external_force(f)
     ens.nominal.body_stats()
     fused, recd, stepped = envs
     sq = np.zeros(n)
-    rows_o = []
     for _ in range(T):
-        obs_o, _, _, _ = ens.closed_loop_step(ws, 0.3)
-        rows_o.append(np.asarray(obs_o))
+        ens.closed_loop_step(ws, 0.3)
         sq = np.maximum(sq, ens.spread(slice(13, 25)))
     loaded = int((ens.nominal.body_stats()[:, 1] > 0).sum())
     assert loaded >= n // 2, loaded                                    # the scene does load the body rows
@@ -165,17 +153,17 @@ def test_closed_loop_kernels_on_a_forced_body_scene_robot_by_robot():
     _, _, rec = recd.rollout_policy_record(pol, T, 0.3)
     rows_s = []
     for _ in range(T):
+        rows_s.append(stepped.obs.clone())                               # the row the actor acts on: what the tape holds for this step
         stepped.step(pol.predict(stepped.obs, 0.3), want_info=False)
-        rows_s.append(stepped.obs.clone())
     so = ens.get_state()
     for name, e in (("fused kernel", fused), ("recording kernel", recd), ("predict + step", stepped)):
         eq = np.abs(e.get_state().cpu().numpy() - so)[:, 13:25].max(1)
         sens_robots(eq, sq, 1e-4, "forced-body closed loop, %s vs the oracle: joint angles after %d steps" % (name, T))
     # the tape against the stepping loop, step by step (joint-angle columns of the observation rows, normalised units)
     gap = torch.stack([(rec["obs"][k] - rows_s[k])[:, 13:25].abs().max(1).values for k in range(T)]).max(0).values.cpu().numpy()
-    gap_o = np.max([np.abs(rec["obs"][k].cpu().numpy() - rows_o[k])[:, 13:25].max(1) for k in range(T)], axis=0)
-    print("[parity] forced-body closed loop: tape rows vs stepping rows, worst over %d steps: median %.2e max %.2e | vs the oracle's rows: median %.2e"
-          % (T, np.median(gap), gap.max(), np.median(gap_o)), flush=True)
+    assert torch.equal(rec["obs"][0], rows_s[0])                         # both start from the reset row
+    print("[parity] forced-body closed loop: tape rows vs stepping rows (the rows the actor acted on), worst over %d steps: median %.2e max %.2e"
+          % (T, np.median(gap), gap.max()), flush=True)
     sens_robots(gap / 10.0, sq, 1e-4, "forced-body closed loop, tape rows vs stepping rows (joint angle columns / their scale 10)")
     for e in envs:
         e.close()

@@ -68,6 +68,13 @@ def _compare_with_stepping(tag, fused_state, fused_obs, ln_f, ret_f, st_end, obs
     assert np.median(gr[same]) < 5e-3, tag
 
 
+@pytest.fixture(autouse=True)
+def _launches_of_50_steps(monkeypatch):
+    """every env of this file cuts its fused rollouts into launches of 50 control steps (ETG_ROLLOUT_CHUNK, read by etg_create;
+    the default is 400): what a later LAUNCH does to a finished robot is part of what is tested here"""
+    monkeypatch.setenv("ETG_ROLLOUT_CHUNK", "50")
+
+
 @pytest.mark.parametrize("lanes", [16, 4])
 def test_open_loop_rollout_stops_at_done(lanes):
     _need_gpu()
