@@ -168,10 +168,8 @@ class OracleEnsemble:
         return np.abs(np.asarray(self.o32.get_state(), dtype=np.float64)[:, cols] - self.nominal.get_state()[:, cols]).max(1)
 
 
-def sens_robots(err_gpu, spread, floor, what, factor=4.0):
-    """A robot is inside when err_gpu <= floor + factor * spread; the GPU may be outside on as many robots as the ensemble's
-    worst member is when judged the same way against the other members, plus one per 64 robots (module docstring).  Prints the
-    tally of the robots that needed the allowance and of those outside."""
+def sens_tally(err_gpu, spread, floor, factor=4.0):
+    """the counts behind sens_robots, without asserting -> dict(n, need, bad (indices), allowed, loo, text)"""
     err_gpu, spread = np.asarray(err_gpu, dtype=np.float64), np.asarray(spread, dtype=np.float64)
     n = len(err_gpu)
     need = err_gpu > floor
@@ -181,7 +179,7 @@ def sens_robots(err_gpu, spread, floor, what, factor=4.0):
         txt += " (their gaps %.1e .. %.1e, their ensemble spread %.1e .. %.1e)" % (err_gpu[need].min(), err_gpu[need].max(),
                                                                                    spread[need].min(), spread[need].max())
     per = _member_record(spread)
-    allowed, loo_txt = 0, ""
+    allowed, loo, loo_txt = 0, None, ""
     if per is not None and per.shape[0] >= 3:
         loo = []
         for m in range(per.shape[0]):
@@ -191,11 +189,21 @@ def sens_robots(err_gpu, spread, floor, what, factor=4.0):
         loo_txt = " | the members judged alike against the rest of the ensemble: %s outside -> allowed %d" % (loo, allowed)
     if bad.any():
         loo_txt += " | the GPU's outside robots: " + ", ".join("#%d gap %.1e spread %.1e" % (i, err_gpu[i], spread[i]) for i in np.nonzero(bad)[0][:6])
+    return dict(n=n, need=int(need.sum()), bad=np.nonzero(bad)[0], allowed=allowed, loo=loo, text=txt, loo_text=loo_txt)
+
+
+def sens_robots(err_gpu, spread, floor, what, factor=4.0):
+    """A robot is inside when err_gpu <= floor + factor * spread; the GPU may be outside on as many robots as the ensemble's
+    worst member is when judged the same way against the other members, plus one per 64 robots (module docstring).  Prints the
+    tally of the robots that needed the allowance and of those outside."""
+    err_gpu, spread = np.asarray(err_gpu, dtype=np.float64), np.asarray(spread, dtype=np.float64)
+    t = sens_tally(err_gpu, spread, floor, factor)
+    n = t["n"]
     print("[parity] %-70s median %.3e max %.3e (floor %.1e) | %s | outside floor + %g x spread: %d%s"
-          % (what, float(np.median(err_gpu)), float(err_gpu.max()), floor, txt, factor, int(bad.sum()), loo_txt), flush=True)
-    REPORT.append((what, n, int(need.sum()), txt))
+          % (what, float(np.median(err_gpu)), float(err_gpu.max()), floor, t["text"], factor, len(t["bad"]), t["loo_text"]), flush=True)
+    REPORT.append((what, n, t["need"], t["text"]))
     assert np.isfinite(err_gpu).all(), what
-    assert int(bad.sum()) <= allowed, (what, np.nonzero(bad)[0].tolist(), err_gpu[bad].tolist(), spread[bad].tolist())
+    assert len(t["bad"]) <= t["allowed"], (what, t["bad"].tolist(), err_gpu[t["bad"]].tolist(), spread[t["bad"]].tolist())
     # a wrong kernel moves EVERY robot: the quarter of the robots whose ensemble stayed closest together is held to half the floor
     # (or, where even those part -- torque commands, joints riding their stops --, to 4 x their own median spread)
     calm = np.argsort(spread)[:max(4, n // 4)]

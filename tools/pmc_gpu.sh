@@ -4,6 +4,9 @@
 # Writes gpurun_out/pmc_<tag>.txt (raw means per launch) and gpurun_out/pmc_<tag>.json (per kernel and control step,
 # the format bench.py reads from profiles/r04_pmc.json).
 cd /tmp && export TMPDIR=/tmp
+# every fused launch of this run covers <= STEPS control steps (the library's default is 400 per launch: the clock-warming rollouts
+# of bench.py would otherwise be longer launches than the timed ones, and the per-launch counters below are divided by STEPS)
+export ETG_ROLLOUT_CHUNK=50
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=/tmp/pmc_$1
 STEPS=50

@@ -2,6 +2,9 @@
 # rocprofv3 kernel-trace summary of the bench command (run on the GPU box via gpurun)
 set -e
 cd /tmp && export TMPDIR=/tmp
+# launches of 50 control steps (the library's default is 400): every k_rollout* launch of the run then has the same length and the
+# summary's AverageNs / 50 is the per-control-step kernel time that bench.py's own HIP events report (roofline.kernel_ms)
+export ETG_ROLLOUT_CHUNK=50
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/prof_$1
 mkdir -p $OUT
