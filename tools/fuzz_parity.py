@@ -31,7 +31,7 @@ N = args.n
 fails = []
 t_start = time.time()
 for trial in range(args.trials):
-    T_ = setup_trial(args.seed, trial, N, lambda cfg: [OracleEnsemble(N, E=2, E64=1, seed=args.seed + trial, cfg=type(cfg).from_buffer_copy(cfg))])
+    T_ = setup_trial(args.seed, trial, N, lambda cfg: [OracleEnsemble(N, E=4, E64=2, seed=args.seed + trial, cfg=type(cfg).from_buffer_copy(cfg))])
     rng, lanes, kw, ex, env, ens = T_["rng"], T_["lanes"], T_["kw"], T_["ex"], T_["env"], T_["orcs"][0]
     orcs = [ens.nominal, ens.o32]
     W, B, rows, sr, f, offs, loose = T_["W"], T_["B"], T_["rows"], T_["sr"], T_["f"], T_["offs"], T_["loose"]
@@ -66,7 +66,11 @@ for trial in range(args.trials):
     # torque commands and limp limbs are chaotic within a handful of steps: the ensemble's own spread is the yardstick there; the
     # quarter of the robots whose ensemble stayed closest together must be tight (a wrong kernel moves every robot)
     calm = np.argsort(spread)[:max(4, N // 4)]
-    checks = dict(finite=finite, robots=len(tl["bad"]) <= tl["allowed"], median=np.median(eg[calm]) < max(5e-5 * loose, 4.0 * np.median(spread[calm])), reset=bool(reset_ok),
+    # (a random heightfield is C0 with ~1 rad normal jumps at every cell edge: any two fp32 evaluations keep ~45 % of the robots on one
+    # trajectory, profiles/r04_hf_tracking.txt, and which robot parts is decided by which side of an edge a foot lands on to 1e-7 m --
+    # there the trial is held to the share of robots inside, as in rounds 4-5)
+    robots_ok = (frac >= need) if kw.get("task") == "heightfield" else (len(tl["bad"]) <= tl["allowed"])
+    checks = dict(finite=finite, robots=robots_ok, median=np.median(eg[calm]) < max(5e-5 * loose, 4.0 * np.median(spread[calm])), reset=bool(reset_ok),
                   obs=eobs < max(5e-3, 300 * np.median(eg)))   # (velocity columns: ~100 x the angle gap)
     ok = all(checks.values())
     print("%s trial %3d lanes %2d reset gap %.1e | joints vs fp64 oracle: median %.1e max %.1e (fp32 oracle %.1e / %.1e) inside floor + 4 x spread %.2f (outside %d, allowed %d) | obs %.1e reward %.1e done-mismatch %d | %s %s"
@@ -86,6 +90,7 @@ for trial in range(args.trials):
         T = 5
         tape = torch.as_tensor(rng.uniform(-0.2, 0.2, size=(T, N, 12)) * (20.0 if mode == "torque" else 1.0), dtype=torch.float32, device="cuda:0")
         # (the tape records observations without sensor noise and says so: with noise on, rewards and done flags only)
+        env.set_rollout_mode(simulate_finished=True)   # (the stepping loop it is compared with steps finished robots on)
         _, _, rec = env.rollout_actions(tape, record=("reward", "done") if ex["noise"] else ("obs", "reward", "done"))
         # (same source, two kernels: the compiler contracts multiply-adds differently in the two contexts, so the comparison is
         # to rounding noise amplified by the contacts -- tests/test_gpu_parity.py::test_fused_rollout_equals_stepping -- plus
@@ -153,6 +158,7 @@ for trial in range(args.trials):
             e.reset(ETG_w=rep(W), ETG_b=rep(B)) if W is not None else e.reset()
             if ex["push"]: e.set_external_force(torch.as_tensor(rep(f), dtype=torch.float32))
         scale = 6.0 if mode == "torque" else 0.3
+        ec.set_rollout_mode(simulate_finished=True)
         ret_c, len_c = ec.rollout_policy(pol, 6, scale, fused=True)   # (the kernel itself: env's own choice may be the stepping loop)
         for k in range(6):
             ed.step(pol.predict(ed.obs, scale), want_info=False)
