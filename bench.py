@@ -407,6 +407,11 @@ def main():
                              "slowest_wave_total_over_mean": float(tot.max().item() / tot.mean().item()),
                              "is": "sum over the launches of the slowest wave's cycles / mean over the waves of their total cycles, last timed "
                                    "repeat (etg_rollout_wave_cycles: clock64 at kernel entry and exit of every wavefront)"}
+                # the shader clock the timed launches effectively ran at: boxes of this pool differ by ~5 % in it, and a 20-step
+                # launch runs ~5 % below a 400-step one on the same box (profiles/r06_ab_experiments.txt sections 0 and 11) -- the
+                # cycle count is the kernel's, the clock is the box's
+                if kern_ms > 0:
+                    imbalance["effective_clock_ghz"] = imbalance["kernel_cycles_per_step"] / (kern_ms * 1e-3) * 1e-9
         except Exception as e:                                       # noqa: BLE001 - diagnostics must not lose the line
             imbalance = {"error": repr(e)[:200]}
     # N > 1: every rank's own median step time, and the one exchange of the path (the all_gather of the returns) on its own
