@@ -41,7 +41,7 @@ BYTES_PER_STEP_CFG2 = 816  # 564 B + 252 B per-env ETG w,b
 BYTES_PER_STEP_CFG3 = 808 + 252
 REPEATS = 5
 CLOCK_WARM_SECONDS = 0.25
-CLOCK_WARM_STEPS = 600     # untimed scratch-env steps (~22 ms) right before every timed repeat's barrier
+CLOCK_WARM_STEPS = 600     # untimed scratch-env steps (~57 ms) right before every timed repeat's barrier, in launches of K steps
 # PMC figures (HBM traffic, VALU instructions per wave) are NOT measured by this process: they come from separate
 # `rocprofv3 --pmc` passes of this same command (tools/pmc_gpu.sh), summarised per kernel and control step in this file.
 # The file is stamped with the hash of the kernel sources it was collected on (tools/make_pmc_json.py); when the sources have
@@ -346,7 +346,12 @@ def main():
             # the reset and a short warm-up leave the GPU mostly idle for a millisecond or more and its clocks drop: a timed
             # region of K = 20 steps (0.8 ms) then runs 14 % slower than the same steps inside a long run.  Keep the chip
             # loaded right up to the barrier with untimed stepping of a scratch env (warm clocks).
-            run_steps(warm_env, None, CLOCK_WARM_STEPS, True)
+            # ... in launches of the timed region's own length: what precedes the region sets the clock it runs at (all 1024 waves
+            # busy without a break -> ~2.25 GHz; launches of <= 50 steps, whose tails leave SIMDs idle -> ~2.34 GHz: 4 % on a
+            # 20-step region, profiles/r06_ab_experiments.txt section 14), so the chip enters the region in the state a steady run
+            # of such launches leaves it in
+            for _ in range((CLOCK_WARM_STEPS + K - 1) // K):
+                run_steps(warm_env, None, K, True)
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             barrier()
             if events:
@@ -570,9 +575,10 @@ def main():
                        "world_size_reported_by": ("torch.distributed/" + dist.get_backend()) if dist is not None else "single process"},
             "timing": {"repeats": repeats, "value_is": "median repeat", "ms_per_step_min": min(wall) / K * 1e3,
                        "ms_per_step_max": max(wall) / K * 1e3, "value_min": world * N * K / max(wall), "value_max": world * N * K / min(wall),
-                       "clock_warm_s": CLOCK_WARM_SECONDS, "each_repeat": "reset (untimed), %d warm-up steps (untimed), %d untimed steps of a "
-                       "scratch env to keep the clocks up, barrier + synchronize, %d timed steps + return gather, barrier + synchronize, "
-                       "max over ranks" % (args.warmup, CLOCK_WARM_STEPS, K)},
+                       "clock_warm_s": CLOCK_WARM_SECONDS, "each_repeat": "reset (untimed), %d warm-up steps (untimed), >= %d untimed steps of a "
+                       "scratch env in launches of %d steps (the timed region's own length) to keep the clocks where a steady run of "
+                       "such launches has them, barrier + synchronize, %d timed steps + return gather, barrier + synchronize, "
+                       "max over ranks" % (args.warmup, CLOCK_WARM_STEPS, K, K)},
             "path": ("env.step per control step" if not fused else
                      "etg_rollout_openloop: fused kernel, up to 400 control steps per launch" if policy is None else
                      "etg_rollout_policy: policy MFMA tile + control step fused, up to 400 control steps per launch"),
